@@ -1,0 +1,83 @@
+// Shared device/host helpers for libneuroir_hip (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/neuroir_hip.h"
+
+namespace nir {
+
+void set_error(const char* fmt, ...);
+
+#define NIR_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            nir::set_error(__VA_ARGS__);       \
+            return NIR_ERR_BAD_ARG;            \
+        }                                      \
+    } while (0)
+
+// Check the launch just enqueued; returns the hipError_t (>0) on failure.
+#define NIR_CHECK_LAUNCH(name)                                                      \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            nir::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                        \
+        }                                                                           \
+    } while (0)
+
+#define NIR_PROPAGATE(expr)        \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// sigma / tanh built on the hardware exp2 (v_exp_f32, ~1 ulp) -- absolute error ~1e-7, far inside the
+// 1e-4 score tolerance while ~4x cheaper than the ocml tanhf in the 64..290-step recurrences.
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    float ax = fabsf(x);
+    float e = __expf(-2.0f * ax);           // in (0,1]
+    float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == NIR_ACT_TANH) return fast_tanh(v);
+    if (act == NIR_ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over the caller-provided workspace.
+struct Workspace {
+    char* base;
+    size_t cap, off;
+    Workspace(void* p, size_t bytes) : base((char*)p), cap(bytes), off(0) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* r = (T*)(base ? base + off : nullptr);
+        off += n * sizeof(T);
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+}  // namespace nir

@@ -1,0 +1,226 @@
+// ESM (neuroir/rankers/esm.py:19-45) and DRMM (neuroir/rankers/drmm.py:29-84) -- the two HBM-bound rankers.
+//
+// Both are pure embedding-gather reductions: every doc token fetches its 4*E-byte table row exactly once,
+// nothing of size [B*N, DL, E] (let alone the reference's [B*N, QL, DL, E] broadcasts) is ever materialised.
+// Row access: a wave reads one row as 16-byte lanes (E=300 -> 75 x float4: lanes 0..63 + lanes 0..10), several
+// rows in flight per wave; reductions are wave shuffles.  Algorithmic HBM bytes per pair =
+// DL*(4E+8) + QL*(4E+8)/N + 4  (SURVEY.md section 8d).
+#include "common.hpp"
+
+namespace nir {
+
+constexpr int MAXCH = 2;  // float4 chunks per lane: supports E <= 512
+
+// sum of `L` gathered rows (ids wave-uniform via shuffle); chunk c of the row lives in lane (c & 63), slot c>>6
+__device__ __forceinline__ void gather_sum(const int64_t* ids, int L, const float* table, int E, int lane,
+                                           float4 (&acc)[MAXCH]) {
+    const int nch = E >> 2;
+#pragma unroll
+    for (int s = 0; s < MAXCH; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < L; base += 64) {
+        int64_t myid = (base + lane < L) ? ids[base + lane] : 0;
+        int cnt = min(64, L - base);
+        int r = 0;
+        for (; r + 4 <= cnt; r += 4) {
+            const float* rp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rp[u] = table + __shfl(myid, r + u, 64) * (int64_t)E;
+            float4 v[4][MAXCH];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int s = 0; s < MAXCH; ++s) {
+                    int c = lane + 64 * s;
+                    v[u][s] = (c < nch) ? *reinterpret_cast<const float4*>(rp[u] + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int s = 0; s < MAXCH; ++s) {
+                    acc[s].x += v[u][s].x; acc[s].y += v[u][s].y; acc[s].z += v[u][s].z; acc[s].w += v[u][s].w;
+                }
+        }
+        for (; r < cnt; ++r) {
+            const float* rp = table + __shfl(myid, r, 64) * (int64_t)E;
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                int c = lane + 64 * s;
+                if (c < nch) {
+                    float4 v = *reinterpret_cast<const float4*>(rp + 4 * c);
+                    acc[s].x += v.x; acc[s].y += v.y; acc[s].z += v.z; acc[s].w += v.w;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 scale4(const float4& a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 div4(const float4& a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+
+// grid (ceil(N/4), B); one wave per (query, candidate)
+__global__ __launch_bounds__(256) void esm_kernel(const int64_t* q_ids, const int64_t* d_ids, int N, int QL, int DL,
+                                                  const float* table, int E, float* scores) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float4 qs[MAXCH], ds[MAXCH];
+    gather_sum(q_ids + (int64_t)b * QL, QL, table, E, lane, qs);
+    gather_sum(d_ids + ((int64_t)b * N + n) * DL, DL, table, E, lane, ds);
+    const float iq = 1.0f / (float)QL, id = 1.0f / (float)DL;  // mean over the PADDED length (esm.py:35,40)
+    float nq = 0.f, nd = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXCH; ++s) {
+        qs[s] = scale4(qs[s], iq);
+        ds[s] = scale4(ds[s], id);
+        nq += dot4(qs[s], qs[s]);
+        nd += dot4(ds[s], ds[s]);
+    }
+    nq = fmaxf(sqrtf(wave_sum(nq)), 1e-8f);  // ATen cosine_similarity: x/max(|x|,eps) . y/max(|y|,eps)
+    nd = fmaxf(sqrtf(wave_sum(nd)), 1e-8f);
+    float dot = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXCH; ++s) dot += dot4(div4(qs[s], nq), div4(ds[s], nd));
+    dot = wave_sum(dot);
+    if (lane == 0) scores[(int64_t)b * N + n] = dot;
+}
+
+struct DrmmW {
+    const float *gate_w, *gate_b, *f0w, *f0b, *f1w, *f1b, *ow, *ob;
+};
+
+// one workgroup (4 waves) per (query, candidate) pair; dynamic LDS: qn[QL][E] + glog[QL] + hist[QL*5]
+__global__ __launch_bounds__(256) void drmm_kernel(const int64_t* q_ids, const int64_t* d_ids, int N, int QL, int DL,
+                                                   const float* table, int E, DrmmW w, float* scores, float* hist_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* qn = smem;                 // [QL][E] rows normalised by max(|q_i|, eps)
+    float* glog = qn + QL * E;        // [QL]   gate logits
+    int* hist = (int*)(glog + QL);    // [QL*5]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t pair = blockIdx.x;
+    const int b = (int)(pair / N);
+    const int nch = E >> 2;
+    for (int i = tid; i < QL * 5; i += 256) hist[i] = 0;
+    // phase 1: query rows
+    for (int i = wave; i < QL; i += 4) {
+        const float* rp = table + q_ids[(int64_t)b * QL + i] * (int64_t)E;
+        float4 v[MAXCH];
+        float nn = 0.f, gl = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXCH; ++s) {
+            int c = lane + 64 * s;
+            v[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nch) {
+                v[s] = *reinterpret_cast<const float4*>(rp + 4 * c);
+                gl += dot4(v[s], *reinterpret_cast<const float4*>(w.gate_w + 4 * c));
+            }
+            nn += dot4(v[s], v[s]);
+        }
+        nn = fmaxf(sqrtf(wave_sum(nn)), 1e-8f);
+        gl = wave_sum(gl);
+#pragma unroll
+        for (int s = 0; s < MAXCH; ++s) {
+            int c = lane + 64 * s;
+            if (c < nch) *reinterpret_cast<float4*>(qn + i * E + 4 * c) = div4(v[s], nn);
+        }
+        if (lane == 0) glog[i] = gl + w.gate_b[0];
+    }
+    __syncthreads();
+    // phase 2: stream the document rows once; lane (i*5+bin) of each wave keeps that counter
+    int cnt0 = 0, cnt1 = 0;
+    const int64_t* dids = d_ids + pair * DL;
+    for (int j0 = wave * 2; j0 < DL; j0 += 8) {     // 2 rows in flight per wave
+        float4 v[2][MAXCH];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ok[u] = j0 + u < DL;
+            const float* rp = table + (ok[u] ? dids[j0 + u] : 0) * (int64_t)E;
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                int c = lane + 64 * s;
+                v[u][s] = (c < nch) ? *reinterpret_cast<const float4*>(rp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            float nn = 0.f;
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) nn += dot4(v[u][s], v[u][s]);
+            nn = fmaxf(sqrtf(wave_sum(nn)), 1e-8f);
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) v[u][s] = div4(v[u][s], nn);
+            for (int i = 0; i < QL; ++i) {
+                float d = 0.f;
+#pragma unroll
+                for (int s = 0; s < MAXCH; ++s) {
+                    int c = lane + 64 * s;
+                    if (c < nch) d += dot4(v[u][s], *reinterpret_cast<const float4*>(qn + i * E + 4 * c));
+                }
+                d = wave_sum(d);
+                // numpy.histogram(bins=[-1,-.5,0,.5,1,1]): [-1,-.5) [-.5,0) [0,.5) [.5,1) {1}; outside -> dropped
+                int bin = -1;
+                if (d >= -1.0f && d <= 1.0f) bin = d < -0.5f ? 0 : d < 0.0f ? 1 : d < 0.5f ? 2 : d < 1.0f ? 3 : 4;
+                int slot = i * 5 + bin;
+                if (bin >= 0) {
+                    if (slot == lane) ++cnt0;
+                    if (slot == lane + 64) ++cnt1;
+                }
+            }
+        }
+    }
+    if (lane < QL * 5 && cnt0) atomicAdd(&hist[lane], cnt0);
+    if (lane + 64 < QL * 5 && cnt1) atomicAdd(&hist[lane + 64], cnt1);
+    __syncthreads();
+    if (hist_out)
+        for (int i = tid; i < QL * 5; i += 256) hist_out[pair * QL * 5 + i] = (float)hist[i];
+    if (tid == 0) {
+        float mx = -INFINITY;
+        for (int i = 0; i < QL; ++i) mx = fmaxf(mx, glog[i]);
+        float den = 0.f, num = 0.f;
+        for (int i = 0; i < QL; ++i) {
+            float e = expf(glog[i] - mx);
+            float z = w.f0b[0];
+            for (int k = 0; k < 5; ++k) z += w.f0w[k] * (float)hist[i * 5 + k];
+            z = w.f1w[0] * z + w.f1b[0];
+            den += e;
+            num += e * z;
+        }
+        scores[pair] = w.ow[0] * (num / den) + w.ob[0];
+    }
+}
+
+}  // namespace nir
+
+extern "C" int nir_esm_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
+                             const float* table, int64_t V, int E, float* scores, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(q_ids && d_ids && table && scores, "esm: null pointer");
+    NIR_REQUIRE(B >= 0 && N > 0 && QL > 0 && DL > 0 && V > 0, "esm: bad dims B=%d N=%d QL=%d DL=%d", B, N, QL, DL);
+    NIR_REQUIRE(E % 4 == 0 && E > 0 && E <= 256 * MAXCH, "esm: emsize %d unsupported (multiple of 4, <= %d)", E, 256 * MAXCH);
+    NIR_REQUIRE(((uintptr_t)table & 15) == 0, "esm: table must be 16-byte aligned");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(esm_kernel, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q_ids, d_ids, N, QL, DL,
+                       table, E, scores);
+    NIR_CHECK_LAUNCH("nir_esm_score");
+    return 0;
+}
+
+extern "C" int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
+                              const float* table, int64_t V, int E, const nir_drmm_weights* w, float* scores,
+                              float* hist_out, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(q_ids && d_ids && table && scores && w, "drmm: null pointer");
+    NIR_REQUIRE(B >= 0 && N > 0 && QL > 0 && DL > 0 && V > 0, "drmm: bad dims B=%d N=%d QL=%d DL=%d", B, N, QL, DL);
+    NIR_REQUIRE(QL <= 25, "drmm: query length %d > 25 unsupported", QL);
+    NIR_REQUIRE(E % 4 == 0 && E > 0 && E <= 256 * MAXCH, "drmm: emsize %d unsupported", E);
+    NIR_REQUIRE(((uintptr_t)table & 15) == 0 && ((uintptr_t)w->gate_w & 15) == 0, "drmm: table/gate weight must be 16-byte aligned");
+    if (B == 0) return 0;
+    DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b};
+    size_t lds = (size_t)QL * E * 4 + QL * 4 + QL * 5 * 4;
+    hipLaunchKernelGGL(drmm_kernel, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, q_ids, d_ids, N,
+                       QL, DL, table, E, dw, scores, hist_out);
+    NIR_CHECK_LAUNCH("nir_drmm_score");
+    return 0;
+}

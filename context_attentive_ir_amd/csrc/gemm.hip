@@ -1,0 +1,209 @@
+// nir_linear_f32 / nir_rowdot_f32: nn.Linear and Conv1d-as-GEMM with the embedding gather fused into the
+// A-operand load.  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products/accumulation at the fp32 vector
+// rate, one VGPR per operand per lane (cdna guide section 3).
+//
+// Tiling: 256 threads = 4 waves, block tile 64(M) x 64(N) x 32(K); each wave owns a 32x32 accumulator
+// (16 VGPRs).  Operand tiles are staged in LDS k-contiguous with a +4-float row pad (row stride 36 floats):
+// a lane's ds_read_b128 then covers 4 consecutive k of its row and the 16-lane read groups hit 16 distinct
+// 16-byte slots (conflict-free).  The 4 floats feed 4 successive MFMAs; the k-order inside an 8-wide group
+// is permuted identically for A and W (lane>>5 selects which half), which leaves the sum unchanged.
+#include "common.hpp"
+
+namespace nir {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* a;
+    int64_t lda;
+    const int64_t* ids;
+    const float* table;
+    int E;
+    int64_t rows_per_seq, seq_stride;
+    const float* w;
+    int64_t ldw;
+    const float* bias;
+    const float* bias2;
+    float* c;
+    int64_t ldc;
+    int64_t M;
+    int N, K, act;
+};
+
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = 36;
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int lr = tid >> 3, lk = (tid & 7) * 4;
+
+    // per-thread source rows (2 A rows, 2 W rows)
+    const float* arow[2];
+    int64_t aidx[2];
+    bool aval[2];
+    const float* wrow[2];
+    bool wval[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t m = m0 + lr + 32 * i;
+        aval[i] = m < p.M;
+        arow[i] = nullptr;
+        aidx[i] = 0;
+        if (aval[i]) {
+            if (p.ids) aidx[i] = (m / p.rows_per_seq) * p.seq_stride + (m % p.rows_per_seq);
+            else arow[i] = p.a + m * p.lda;
+        }
+        int n = n0 + lr + 32 * i;
+        wval[i] = n < p.N;
+        wrow[i] = p.w + (int64_t)(wval[i] ? n : 0) * p.ldw;
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        const int k = k0 + lk;
+        float4 ra[2], rw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (VEC) {
+                if (k < p.K) {
+                    if (aval[i]) {
+                        const float* src;
+                        if (p.ids) {
+                            int seg = k / p.E;
+                            src = p.table + p.ids[aidx[i] + seg] * (int64_t)p.E + (k - seg * p.E);
+                        } else {
+                            src = arow[i] + k;
+                        }
+                        ra[i] = *reinterpret_cast<const float4*>(src);
+                    }
+                    if (wval[i]) rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k);
+                }
+            } else {
+                float ta[4] = {0.f, 0.f, 0.f, 0.f}, tw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int kk = k + e;
+                    if (kk < p.K) {
+                        if (aval[i]) {
+                            if (p.ids) {
+                                int seg = kk / p.E;
+                                ta[e] = p.table[p.ids[aidx[i] + seg] * (int64_t)p.E + (kk - seg * p.E)];
+                            } else {
+                                ta[e] = arow[i][kk];
+                            }
+                        }
+                        if (wval[i]) tw[e] = wrow[i][kk];
+                    }
+                }
+                ra[i] = make_float4(ta[0], ta[1], ta[2], ta[3]);
+                rw[i] = make_float4(tw[0], tw[1], tw[2], tw[3]);
+            }
+        }
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4*>(&As[(lr + 32 * i) * LDS_LD + lk]) = ra[i];
+            *reinterpret_cast<float4*>(&Ws[(lr + 32 * i) * LDS_LD + lk]) = rw[i];
+        }
+        __syncthreads();
+        const float* ap = &As[(wm * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4];
+        const float* bp = &Ws[(wn * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a4 = *reinterpret_cast<const float4*>(ap + q * 8);
+            float4 b4 = *reinterpret_cast<const float4*>(bp + q * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n < p.N) {
+        float bsum = 0.f;
+        if (p.bias) bsum += p.bias[n];
+        if (p.bias2) bsum += p.bias2[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < p.M) {
+                float v = acc[r] + bsum;
+                if (p.act == NIR_ACT_TANH) v = fast_tanh(v);
+                else if (p.act == NIR_ACT_RELU) v = fmaxf(v, 0.f);
+                p.c[m * p.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// One wave per output row.
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* x, int64_t ldx, const float* w, const float* b,
+                                                     float* out, int64_t M, int K, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* xr = x + m * ldx;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += xr[k] * w[k];
+    s = wave_sum(s);
+    if (lane == 0) {
+        float v = s + (b ? b[0] : 0.f);
+        if (act == NIR_ACT_TANH) v = fast_tanh(v);
+        else if (act == NIR_ACT_RELU) v = fmaxf(v, 0.f);
+        out[m] = v;
+    }
+}
+
+int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                  int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                  int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st) {
+    NIR_REQUIRE(M >= 0 && N > 0 && K > 0, "linear: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
+    NIR_REQUIRE(w && c, "linear: null weight/output");
+    NIR_REQUIRE(ids ? (table != nullptr && E > 0 && rows_per_seq > 0) : (a != nullptr), "linear: null A operand");
+    if (M == 0) return 0;
+    GemmArgs p{a, lda, ids, table, E, rows_per_seq, seq_stride, w, ldw, bias, bias2, c, ldc, M, N, K, act};
+    bool vec = (K % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    if (ids) vec = vec && (E % 4 == 0) && (((uintptr_t)table & 15) == 0);
+    else vec = vec && (lda % 4 == 0) && (((uintptr_t)a & 15) == 0);
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+    if (vec) hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, st, p);
+    NIR_CHECK_LAUNCH("nir_linear_f32");
+    return 0;
+}
+
+int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
+                  hipStream_t st) {
+    NIR_REQUIRE(x && w && out && K > 0, "rowdot: bad args");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, ldx, w, b, out, M, K, act);
+    NIR_CHECK_LAUNCH("nir_rowdot_f32");
+    return 0;
+}
+
+}  // namespace nir
+
+extern "C" int nir_linear_f32(const float* a, int64_t lda, const int64_t* ids, const float* table, int E,
+                              int64_t rows_per_seq, int64_t seq_stride, const float* w, int64_t ldw,
+                              const float* bias, const float* bias2, float* c, int64_t ldc, int64_t M, int N, int K,
+                              int act, nir_stream_t stream) {
+    return nir::launch_linear(a, lda, ids, table, E, rows_per_seq, seq_stride, w, ldw, bias, bias2, c, ldc, M, N, K,
+                              act, (hipStream_t)stream);
+}
+
+extern "C" int nir_rowdot_f32(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M,
+                              int K, int act, nir_stream_t stream) {
+    return nir::launch_rowdot(x, ldx, w, b, out, M, K, act, (hipStream_t)stream);
+}

@@ -1,0 +1,165 @@
+"""ctypes binding of libneuroir_hip.so (the C-ABI declared in include/neuroir_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a tensor is not on a ROCm device the
+call raises RuntimeError (mirrors how the reference surfaces torch errors).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libneuroir_hip.so")
+
+c_fp = C.c_void_p      # const float*   (device)
+c_ip = C.c_void_p      # const int64_t* (device)
+c_st = C.c_void_p      # hipStream_t
+
+
+def _struct(name, float_fields, int_fields=()):
+    fields = [(f, c_fp) for f in float_fields] + [(f, C.c_int) for f in int_fields]
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+DrmmWeights = _struct("nir_drmm_weights",
+                      ["gate_w", "gate_b", "ffnn0_w", "ffnn0_b", "ffnn1_w", "ffnn1_b", "out_w", "out_b"])
+MatchTensorWeights = _struct(
+    "nir_matchtensor_weights",
+    ["proj_w", "proj_b", "q_wih", "q_whh", "q_bih", "q_bhh", "d_wih", "d_whh", "d_bih", "d_bhh",
+     "qproj_w", "qproj_b", "dproj_w", "dproj_b", "alpha", "conv1_w", "conv1_b", "conv2_w", "conv2_b",
+     "conv3_w", "conv3_b", "conv_w", "conv_b", "out_w", "out_b"],
+    ["F", "Hq", "Hd", "C", "NF", "MF"])
+DuetWeights = _struct(
+    "nir_duet_weights",
+    ["l_conv_w", "l_conv_b", "l_fc1_w", "l_fc1_b", "l_fc2_w", "l_fc2_b", "l_fc3_w", "l_fc3_b",
+     "convq_w", "convq_b", "convd1_w", "convd1_b", "convd2_w", "convd2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+     "fc3_w", "fc3_b", "fc4_w", "fc4_b"],
+    ["NF", "pool"])
+CarsEncoderWeights = _struct(
+    "nir_cars_encoder_weights",
+    ["wih", "whh", "bih", "bhh", "attn0_w", "attn0_b", "attn3_w", "attn3_b"], ["H"])
+CarsSessionWeights = _struct(
+    "nir_cars_session_weights",
+    ["click0_w", "click0_b", "click3_w", "click3_b", "sq_attn_w", "sq_attn_b", "sd_attn_w", "sd_attn_b",
+     "sq_wih", "sq_whh", "sq_bih", "sq_bhh", "sd_wih", "sd_whh", "sd_bih", "sd_bhh", "qproj_w", "qproj_b",
+     "shared_w", "priv1_w", "mo0_w", "mo0_b", "mo1_w", "mo1_b", "mo2_w", "mo2_b"],
+    ["D", "HS"])
+
+_i, _l, _z = C.c_int, C.c_int64, C.c_size_t
+# name -> (restype, argtypes); must list EVERY symbol include/neuroir_hip.h declares (tests check this)
+SIGNATURES = {
+    "nir_version": (_i, []),
+    "nir_last_error_string": (C.c_char_p, []),
+    "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
+    "nir_rowdot_f32": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, _i, _i, c_st]),
+    "nir_bilstm_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
+    "nir_bilstm_supported": (_i, [_i]),
+    "nir_softmax_rows": (_i, [c_fp, c_fp, _l, _i, c_st]),
+    "nir_rank_loss_bce": (_i, [c_fp, c_fp, _l, _i, c_fp, c_st]),
+    "nir_rank_loss_softmax_nll": (_i, [c_fp, c_fp, _l, _i, c_fp, c_st]),
+    "nir_esm_score": (_i, [c_ip, c_ip, _i, _i, _i, _i, c_fp, _l, _i, c_fp, c_st]),
+    "nir_drmm_score": (_i, [c_ip, c_ip, _i, _i, _i, _i, c_fp, _l, _i, C.POINTER(DrmmWeights), c_fp, c_fp, c_st]),
+    "nir_matchtensor_workspace_bytes": (_z, [_i, _i, _i, _i, C.POINTER(MatchTensorWeights)]),
+    "nir_matchtensor_score": (_i, [c_ip, c_ip, c_ip, c_ip, _i, _i, _i, _i, c_fp, _l, _i,
+                                   C.POINTER(MatchTensorWeights), C.c_void_p, _z, c_fp, c_fp, c_fp, c_fp, c_fp, c_st]),
+    "nir_duet_workspace_bytes": (_z, [_i, _i, _i, _i, _i, C.POINTER(DuetWeights)]),
+    "nir_duet_score": (_i, [c_ip, c_ip, _i, _i, _i, _i, c_fp, _l, _i, C.POINTER(DuetWeights), C.c_void_p, _z,
+                            c_fp, c_fp, c_fp, c_st]),
+    "nir_cars_encode_workspace_bytes": (_z, [_l, _i, _i, C.POINTER(CarsEncoderWeights)]),
+    "nir_cars_encode": (_i, [c_ip, c_ip, _l, _i, c_fp, _l, _i, C.POINTER(CarsEncoderWeights), C.c_void_p, _z,
+                             c_fp, c_fp, c_st]),
+    "nir_cars_session_workspace_bytes": (_z, [_i, _i, _i, C.POINTER(CarsSessionWeights)]),
+    "nir_cars_rank_session": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
+                                   c_fp, c_fp, c_st]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library (never builds implicitly; run `python -m context_attentive_ir_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libneuroir_hip.so not found at %s -- build it with `python -m context_attentive_ir_amd.build` "
+                "(hipcc, gfx950). The HIP path has no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().nir_last_error_string().decode("utf-8", "replace")
+        kind = "argument error" if rc < 0 else "hipError_t"
+        raise RuntimeError("%s failed (%s %d): %s" % (what, kind, rc, msg))
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("context_attentive_ir_amd runs on a ROCm device only (got a %s tensor); "
+                               "there is no CPU fallback -- move the model and inputs to cuda" % t.device)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ids64(t):
+    """int64 contiguous view of an id / length tensor (the reference feeds torch.LongTensor)."""
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t.contiguous()
+
+
+class Packed(object):
+    """A ctypes weight struct + the tensors that back its pointers (kept alive together)."""
+
+    def __init__(self, struct_cls, tensors, ints=None):
+        self.keep = {k: v.detach().to(torch.float32).contiguous() for k, v in tensors.items()}
+        for k, v in self.keep.items():
+            if v.data_ptr() % 16:
+                self.keep[k] = v.clone()
+        self.struct = struct_cls()
+        for k, v in self.keep.items():
+            setattr(self.struct, k, v.data_ptr())
+        for k, v in (ints or {}).items():
+            setattr(self.struct, k, int(v))
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+class PackCache(object):
+    """Re-pack weights only when a parameter was modified (tensor._version) or moved."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, params, builder):
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        if key != self.key:
+            self.val, self.key = builder(), key
+        return self.val
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream); the C library never allocates device memory."""
+    k = (str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(k)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[k] = buf
+    return buf

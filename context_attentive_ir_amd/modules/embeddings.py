@@ -1,0 +1,53 @@
+"""Word-embedding table with the reference's state-dict layout.
+
+Mirror of neuroir.modules.embeddings.Embeddings (/root/reference/neuroir/modules/embeddings.py:88-252) for the
+word-only case the hot path uses: one nn.Embedding(padding_idx=PAD) stored under
+`make_embedding.emb_luts.0.weight` so reference checkpoints load unchanged.
+On the HIP path the table is never "looked up" into a [.., L, E] tensor: kernels take `table` and gather
+rows inside their operand loads.  `forward` exists for callers outside the hot path (e.g. CARS.decode on
+stock PyTorch) and is plain torch.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Embeddings(nn.Module):
+    def __init__(self, word_vec_size, word_vocab_size, word_padding_idx):
+        super().__init__()
+        self.word_vec_size = word_vec_size
+        self.word_padding_idx = word_padding_idx
+        self.embedding_size = word_vec_size
+        self.make_embedding = nn.Sequential()
+        self.make_embedding.add_module(
+            "emb_luts", nn.ModuleList([nn.Embedding(word_vocab_size, word_vec_size, padding_idx=word_padding_idx)]))
+
+    @property
+    def word_lut(self):
+        return self.make_embedding[0][0]
+
+    @property
+    def table(self):
+        """[V, E] fp32 table handed to the kernels."""
+        return self.word_lut.weight
+
+    def init_word_vectors(self, vocabulary, embeddings_index, fixed):
+        """Same contract as embeddings.py:213-226: rows for known tokens, zeros elsewhere."""
+        pretrained = torch.zeros(len(vocabulary), self.word_vec_size)
+        for i in range(len(vocabulary)):
+            tok = vocabulary.ind2tok[i]
+            if tok in embeddings_index:
+                pretrained[i] = embeddings_index[tok]
+        self.word_lut.weight.data.copy_(pretrained)
+        if fixed:
+            self.word_lut.weight.requires_grad = False
+
+    def load_pretrained_vectors(self, emb_file, fixed):
+        if emb_file:
+            self.word_lut.weight.data.copy_(torch.load(emb_file))
+            if fixed:
+                self.word_lut.weight.requires_grad = False
+
+    def forward(self, source):
+        """source [B, L, 1] -> [B, L, E] (stock torch; not used by the HIP hot path)."""
+        return F.embedding(source.squeeze(2), self.word_lut.weight, self.word_padding_idx)

@@ -1,0 +1,65 @@
+"""DRMM -- deep relevance matching model (drop-in for neuroir.rankers.drmm.DRMM,
+/root/reference/neuroir/rankers/drmm.py:10-98).
+
+The reference materialises two [B*N,QL,DL,E] tensors, takes their cosine, copies it to the HOST for a
+per-row numpy.histogram and copies the counts back.  nir_drmm_score streams each document row once,
+keeps the QL normalised query rows in LDS, bins cosines in registers and finishes gate softmax / FFN /
+output in the same kernel -- no host round trip.  Bin edges follow numpy.histogram(bins=[-1,-.5,0,.5,1,1]).
+Parity note: cosines within fp32 rounding of a bin edge (incl. exact token matches,
+cos ~ 1) may land in a neighbouring bin relative to ATen's CPU reduction order.
+"""
+import torch
+import torch.nn as nn
+
+from .. import lib
+from ..constants import PAD
+from ..modules import Embeddings
+
+
+class GatingNetwork(nn.Module):
+    """Term gating network parameters (drmm.py:87-98): Linear(emsize -> 1), softmax over query slots."""
+
+    def __init__(self, emsize):
+        super().__init__()
+        self.weight = nn.Linear(emsize, 1)
+
+
+class DRMM(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.word_embeddings = Embeddings(args.emsize, args.src_vocab_size, PAD)
+        self.emb_drop = nn.Dropout(p=args.dropout_emb)
+        self.nbins = args.nbins
+        if self.nbins != 5:
+            raise NotImplementedError("DRMM bins are fixed to [-1,-.5,0,.5,1,1] in the reference (drmm.py:22-23)")
+        self.bins = [-1.0, -0.5, 0, 0.5, 1.0, 1.0]
+        self.gating_network = GatingNetwork(args.emsize)
+        self.ffnn = nn.Sequential(nn.Linear(self.nbins, 1), nn.Linear(1, 1))
+        self.output = nn.Linear(1, 1)
+        self._pack = lib.PackCache()
+
+    def _weights(self):
+        def build():
+            return lib.Packed(lib.DrmmWeights, dict(
+                gate_w=self.gating_network.weight.weight, gate_b=self.gating_network.weight.bias,
+                ffnn0_w=self.ffnn[0].weight, ffnn0_b=self.ffnn[0].bias, ffnn1_w=self.ffnn[1].weight,
+                ffnn1_b=self.ffnn[1].bias, out_w=self.output.weight, out_b=self.output.bias))
+        params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
+        return self._pack.get(params, build)
+
+    def forward(self, batch_queries, query_len, batch_docs, doc_len, return_hist=False):
+        assert batch_queries.shape[0] == batch_docs.shape[0]
+        if self.training and self.emb_drop.p > 0:
+            raise NotImplementedError("HIP DRMM implements the eval-mode forward (SURVEY.md Appendix E7)")
+        table = self.word_embeddings.table
+        lib.require_device(batch_queries, batch_docs, table)
+        q, d = lib.ids64(batch_queries), lib.ids64(batch_docs)
+        B, QL = q.shape
+        N, DL = d.shape[1], d.shape[2]
+        w = self._weights()
+        scores = torch.empty(B, N, device=q.device, dtype=torch.float32)
+        hist = torch.empty(B * N, QL, 5, device=q.device, dtype=torch.float32) if return_hist else None
+        lib.check(lib.load().nir_drmm_score(lib.ptr(q), lib.ptr(d), B, N, QL, DL, lib.ptr(table), table.shape[0],
+                                            table.shape[1], w.ref(), lib.ptr(scores), lib.ptr(hist), lib.stream()),
+                  "nir_drmm_score")
+        return (scores, hist) if return_hist else scores

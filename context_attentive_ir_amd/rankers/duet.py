@@ -1,0 +1,100 @@
+"""DUET (drop-in for neuroir.rankers.duet.DUET, /root/reference/neuroir/rankers/duet.py:9-208).
+
+local model       : exact-match matrix x Conv1d(k=1, channels = doc positions) -> tanh -> fc1..fc3
+distributed model : Conv1d(E->300,k=3)+tanh on q and d, pools, 1x1 conv, Hadamard with the query vector,
+                    Linear over positions, two more Linear+tanh.
+One C-ABI call (nir_duet_score).  Both convolutions run as fp32-MFMA GEMMs with the embedding gather fused
+into the A operand (K = 3*E, conv weights re-laid-out [NF][3][E] once at pack time); the exact-match
+"convolution" is evaluated sparsely (only matching (doc,query) positions add a weight row).
+Like the reference (hyparam.py:34-46 `force_pad`), inputs must be padded to max_query_len / max_doc_len.
+"""
+import torch
+import torch.nn as nn
+
+from .. import lib
+from ..constants import PAD
+from ..modules import Embeddings
+
+
+class LocalModel(nn.Module):
+    """Parameters of duet.py:62-121."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.conv1d = nn.Conv1d(args.max_doc_len, args.nfilters, args.local_filter_size)
+        self.drop = nn.Dropout(args.dropout)
+        self.fc1 = nn.Linear(args.max_query_len, 1)
+        self.fc2 = nn.Linear(args.nfilters, args.nfilters)
+        self.fc3 = nn.Linear(args.nfilters, 1)
+
+
+class DistributedModel(nn.Module):
+    """Parameters of duet.py:124-208."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.conv_q = nn.Conv1d(args.emsize, args.nfilters, args.dist_filter_size)
+        self.conv_d1 = nn.Conv1d(args.emsize, args.nfilters, args.dist_filter_size)
+        self.conv_d2 = nn.Conv1d(args.nfilters, args.nfilters, 1)
+        self.pool_size = args.pool_size
+        self.dropout = nn.Dropout(args.dropout)
+        self.fc1 = nn.Linear(args.nfilters, args.nfilters)
+        self.fc2 = nn.Linear(args.max_doc_len - args.pool_size - 1, 1)
+        self.fc3 = nn.Linear(args.nfilters, args.nfilters)
+        self.fc4 = nn.Linear(args.nfilters, 1)
+
+
+class DUET(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.use_word = args.use_word
+        if not self.use_word:
+            raise TypeError("Non-word inputs are not supported!")
+        if args.local_filter_size != 1 or args.dist_filter_size != 3:
+            raise NotImplementedError("HIP DUET supports local_filter_size=1, dist_filter_size=3 (hyparam.py:34-39)")
+        self.word_embeddings = Embeddings(args.emsize, args.src_vocab_size, PAD)
+        self.emb_drop = nn.Dropout(p=args.dropout_emb)
+        self.local_model = LocalModel(args)
+        self.distributed_model = DistributedModel(args)
+        self.max_doc_len, self.max_query_len = args.max_doc_len, args.max_query_len
+        self._dims = dict(NF=args.nfilters, pool=args.pool_size)
+        self._pack = lib.PackCache()
+
+    def _weights(self):
+        def build():
+            lm, dm = self.local_model, self.distributed_model
+            t = dict(l_conv_w=lm.conv1d.weight.squeeze(2).t(),  # [DL][NF]: a matching position adds one contiguous row
+                     l_conv_b=lm.conv1d.bias, l_fc1_w=lm.fc1.weight, l_fc1_b=lm.fc1.bias, l_fc2_w=lm.fc2.weight,
+                     l_fc2_b=lm.fc2.bias, l_fc3_w=lm.fc3.weight, l_fc3_b=lm.fc3.bias,
+                     convq_w=dm.conv_q.weight.permute(0, 2, 1), convq_b=dm.conv_q.bias,      # [NF][3][E]
+                     convd1_w=dm.conv_d1.weight.permute(0, 2, 1), convd1_b=dm.conv_d1.bias,  # [NF][3][E]
+                     convd2_w=dm.conv_d2.weight.squeeze(2), convd2_b=dm.conv_d2.bias,
+                     fc1_w=dm.fc1.weight, fc1_b=dm.fc1.bias, fc2_w=dm.fc2.weight, fc2_b=dm.fc2.bias,
+                     fc3_w=dm.fc3.weight, fc3_b=dm.fc3.bias, fc4_w=dm.fc4.weight, fc4_b=dm.fc4.bias)
+            return lib.Packed(lib.DuetWeights, t, self._dims)
+        params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
+        return self._pack.get(params, build)
+
+    def forward(self, batch_queries, query_len, batch_docs, doc_len, return_parts=False):
+        assert batch_queries.shape[0] == batch_docs.shape[0]
+        if self.training and (self.emb_drop.p > 0 or self.local_model.drop.p > 0):
+            raise NotImplementedError("HIP DUET implements the eval-mode forward (SURVEY.md Appendix E7)")
+        table = self.word_embeddings.table
+        lib.require_device(batch_queries, batch_docs, table)
+        q, d = lib.ids64(batch_queries), lib.ids64(batch_docs)
+        B, QL = q.shape
+        N, DL = d.shape[1], d.shape[2]
+        if QL != self.max_query_len or DL != self.max_doc_len:
+            raise RuntimeError("DUET needs inputs padded to max_query_len=%d / max_doc_len=%d (force_pad), got %d / %d"
+                               % (self.max_query_len, self.max_doc_len, QL, DL))
+        L = lib.load()
+        w = self._weights()
+        dev = q.device
+        ws = lib.workspace(L.nir_duet_workspace_bytes(B, N, QL, DL, table.shape[1], w.ref()), dev)
+        scores = torch.empty(B, N, device=dev, dtype=torch.float32)
+        loc = torch.empty_like(scores) if return_parts else None
+        dist = torch.empty_like(scores) if return_parts else None
+        lib.check(L.nir_duet_score(lib.ptr(q), lib.ptr(d), B, N, QL, DL, lib.ptr(table), table.shape[0], table.shape[1],
+                                   w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(scores), lib.ptr(loc), lib.ptr(dist),
+                                   lib.stream()), "nir_duet_score")
+        return (scores, loc, dist) if return_parts else scores

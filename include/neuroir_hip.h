@@ -1,0 +1,193 @@
+/*
+ * neuroir_hip.h -- C-ABI of libneuroir_hip.so: the MI355X (gfx950) encode-and-rank hot path of neuroir.
+ *
+ * The reference (/root/reference) is pure Python on PyTorch and has NO FFI of its own; the "interface each
+ * entry point replaces" is therefore the torch-op composition inside the reference nn.Module named beside
+ * each function (file:line relative to /root/reference).  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions:
+ *   - plain C types only; every pointer is a DEVICE pointer unless marked "host";
+ *   - ids / lengths are int64 (torch.LongTensor, neuroir/inputters/ranker/vector.py:53-69), floats are fp32;
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates or frees
+ *     device memory and keeps no pointer after return;
+ *   - kernels are enqueued on `stream` (a hipStream_t) and the call never synchronises;
+ *   - return 0 on success, >0 = hipError_t of the failed launch, <0 = argument error
+ *     (nir_last_error_string() gives the text; thread-local);
+ *   - weight tensors use the PyTorch state-dict layouts, row-major.
+ */
+#ifndef NEUROIR_HIP_H
+#define NEUROIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nir_stream_t; /* hipStream_t */
+
+#define NIR_ERR_BAD_ARG (-1)
+#define NIR_ERR_UNSUPPORTED (-2)
+#define NIR_ERR_WORKSPACE (-3)
+
+int nir_version(void);
+const char* nir_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Building blocks
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Activation codes for nir_linear_f32. */
+#define NIR_ACT_NONE 0
+#define NIR_ACT_TANH 1
+#define NIR_ACT_RELU 2
+
+/* C[m,n] = act( sum_k A(m,k) W[n,k] + bias[n] + bias2[n] ),  m<M, n<N   (nn.Linear / nn.Conv1d as GEMM).
+ *   dense  (ids == NULL): A(m,k) = a[m*lda + k]
+ *   gather (ids != NULL): A(m,k) = table[ ids[(m / rows_per_seq)*seq_stride + (m % rows_per_seq) + k / E ] * E + k % E ]
+ *       i.e. the embedding gather (neuroir/modules/embeddings.py:243-252) fused into the A-operand load; with
+ *       K = ksize*E and rows_per_seq = L-ksize+1, seq_stride = L it is Conv1d(E -> N, ksize) over a padded
+ *       id sequence (neuroir/rankers/duet.py:172-174).  W for the conv case must be laid out [N][ksize][E].
+ * bias / bias2 may be NULL.  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 products. */
+int nir_linear_f32(const float* a, int64_t lda, const int64_t* ids, const float* table, int E,
+                   int64_t rows_per_seq, int64_t seq_stride, const float* w, int64_t ldw, const float* bias,
+                   const float* bias2, float* c, int64_t ldc, int64_t M, int N, int K, int act,
+                   nir_stream_t stream);
+
+/* out[m] = act( sum_k x[m*ldx+k] * w[k] + b[0] )  -- Linear(K -> 1). */
+int nir_rowdot_f32(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K,
+                   int act, nir_stream_t stream);
+
+/* Recurrent half of RNNEncoder (neuroir/encoders/rnn_encoder.py:62-141; nn.LSTM, 1 layer, batch_first):
+ *   gates_in [M,T,ndir*4H]  = x W_ih^T + b_ih + b_hh, PyTorch gate order (i,f,g,o), forward direction first;
+ *   lengths  [M] (>=1, or NULL = all T); w_hh [ndir,4H,H];
+ *   h0/c0 [ndir,M,H] or NULL (zeros);  out [M,T,ndir*H], zero at t >= length (pack/unpack semantics);
+ *   hn/cn [ndir,M,H] or NULL.  Variable length is handled by masking -- no sort, no host sync.
+ * Supported H: 1..128 for ndir*... see nir_bilstm_supported(). */
+int nir_bilstm_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0,
+                   const float* c0, float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir,
+                   nir_stream_t stream);
+int nir_bilstm_supported(int H);
+
+/* softmax over the last dim of [rows, n] (models/ranker.py:258, models/multitask.py:279); in/out may alias. */
+int nir_softmax_rows(const float* in, float* out, int64_t rows, int n, nir_stream_t stream);
+/* mean BCE-with-logits over rows*n entries (models/ranker.py:55-69, multitask/cars.py:603) -> loss[0]. */
+int nir_rank_loss_bce(const float* scores, const float* labels, int64_t rows, int n, float* loss,
+                      nir_stream_t stream);
+/* -(log_softmax(s) * y).sum(1).mean()  (models/ranker.py:79-89) -> loss[0]. */
+int nir_rank_loss_softmax_nll(const float* scores, const float* labels, int64_t rows, int n, float* loss,
+                              nir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * ESM  (neuroir/rankers/esm.py:19-45):  scores[b,n] = cos(mean_L emb(q_b), mean_L emb(d_bn))
+ * ------------------------------------------------------------------------------------------------ */
+int nir_esm_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
+                  const float* table, int64_t V, int E, float* scores, nir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * DRMM  (neuroir/rankers/drmm.py:29-84, 95-98)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* gate_w;  /* gating_network.weight.weight [1,E] */
+    const float* gate_b;  /* gating_network.weight.bias   [1]   */
+    const float* ffnn0_w; /* ffnn.0.weight [1,5] */
+    const float* ffnn0_b; /* ffnn.0.bias   [1]   */
+    const float* ffnn1_w; /* ffnn.1.weight [1,1] */
+    const float* ffnn1_b; /* ffnn.1.bias   [1]   */
+    const float* out_w;   /* output.weight [1,1] */
+    const float* out_b;   /* output.bias   [1]   */
+} nir_drmm_weights;
+/* hist_out (optional, may be NULL): [B*N, QL, 5] matching-histogram counts as float. */
+int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
+                   const float* table, int64_t V, int E, const nir_drmm_weights* w /*host*/, float* scores,
+                   float* hist_out, nir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * MatchTensor  (neuroir/rankers/mtensor.py:62-131, 144-158)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float *proj_w, *proj_b;                    /* linear_projection [F,E],[F] */
+    const float *q_wih, *q_whh, *q_bih, *q_bhh;      /* query_encoder.rnns.0 fwd+rev concatenated: [2*4Hq,F],[2,4Hq,Hq],[2*4Hq],[2*4Hq] */
+    const float *d_wih, *d_whh, *d_bih, *d_bhh;      /* document_encoder.rnns.0, same layout with Hd */
+    const float *qproj_w, *qproj_b;                  /* query_projection [C,2Hq],[C] */
+    const float *dproj_w, *dproj_b;                  /* document_projection [C,2Hd],[C] */
+    const float* alpha;                              /* exact_match_channel.alpha [1] */
+    const float *conv1_w, *conv1_b;                  /* [NF,C+1,3,3],[NF] */
+    const float *conv2_w, *conv2_b;                  /* [NF,C+1,3,5] */
+    const float *conv3_w, *conv3_b;                  /* [NF,C+1,3,7] */
+    const float *conv_w, *conv_b;                    /* [MF,3NF,1,1],[MF] */
+    const float *out_w, *out_b;                      /* output [1,MF],[1] */
+    int F, Hq, Hd, C, NF, MF;                        /* 40, 15, 70, 50, 6, 20 */
+} nir_matchtensor_weights;
+size_t nir_matchtensor_workspace_bytes(int B, int N, int QL, int DL, const nir_matchtensor_weights* w /*host*/);
+/* Optional debug outputs (NULL to skip): enc_q [B,QL,2Hq], enc_d [B*N,DL,2Hd], proj_q [B,QL,C], proj_d [B*N,DL,C]. */
+int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len, const int64_t* d_ids, const int64_t* d_len,
+                          int B, int N, int QL, int DL, const float* table, int64_t V, int E,
+                          const nir_matchtensor_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                          float* scores, float* enc_q, float* enc_d, float* proj_q, float* proj_d,
+                          nir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * DUET  (neuroir/rankers/duet.py:28-59 forward, 77-121 local, 148-208 distributed)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float *l_conv_w, *l_conv_b;  /* local_model.conv1d [NF,DL,1],[NF] */
+    const float *l_fc1_w, *l_fc1_b;    /* [1,QL],[1] */
+    const float *l_fc2_w, *l_fc2_b;    /* [NF,NF],[NF] */
+    const float *l_fc3_w, *l_fc3_b;    /* [1,NF],[1] */
+    const float *convq_w, *convq_b;    /* distributed_model.conv_q, RE-LAID-OUT by the host as [NF][3][E] */
+    const float *convd1_w, *convd1_b;  /* conv_d1, re-laid-out [NF][3][E] */
+    const float *convd2_w, *convd2_b;  /* conv_d2 [NF,NF,1] == [NF][NF] */
+    const float *fc1_w, *fc1_b;        /* [NF,NF] */
+    const float *fc2_w, *fc2_b;        /* [1,DL-6],[1] */
+    const float *fc3_w, *fc3_b;        /* [NF,NF] */
+    const float *fc4_w, *fc4_b;        /* [1,NF],[1] */
+    int NF, pool;                      /* 300, 5 */
+} nir_duet_weights;
+size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w /*host*/);
+/* local_out / dist_out: optional [B,N] debug outputs (NULL to skip). Requires QL >= 3 and DL >= 7. */
+int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
+                   const float* table, int64_t V, int E, const nir_duet_weights* w /*host*/, void* workspace,
+                   size_t workspace_bytes, float* scores, float* local_out, float* dist_out, nir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CARS ranking path  (neuroir/multitask/cars.py:193-540, 671-691; neuroir/modules/maxout.py:70-84)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float *wih, *whh, *bih, *bhh;  /* <enc>.encoder.rnns.0 fwd+rev concatenated [2*4H,E],[2,4H,H],[2*4H],[2*4H] */
+    const float *attn0_w, *attn0_b;      /* {q,d}_attn.0 [2H,2H],[2H] */
+    const float *attn3_w, *attn3_b;      /* {q,d}_attn.3 [1,2H],[1] */
+    int H;                               /* 128 per direction */
+} nir_cars_encoder_weights;
+size_t nir_cars_encode_workspace_bytes(int64_t M, int T, int E, const nir_cars_encoder_weights* w /*host*/);
+/* CARS.encode / CARS.encode_document (cars.py:193-260): ids [M,T], lens [M] -> pooled [M,2H];
+ * encoded (optional) [M,T,2H] memory bank. */
+int nir_cars_encode(const int64_t* ids, const int64_t* lens, int64_t M, int T, const float* table, int64_t V, int E,
+                    const nir_cars_encoder_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                    float* pooled, float* encoded, nir_stream_t stream);
+
+typedef struct {
+    const float *click0_w, *click0_b, *click3_w, *click3_b; /* click_attn.{0,3} [D,D],[D],[1,D],[1] */
+    const float *sq_attn_w, *sq_attn_b;                     /* session_query_attn [D,HS],[D] */
+    const float *sd_attn_w, *sd_attn_b;                     /* session_doc_attn   [D,HS],[D] */
+    const float *sq_wih, *sq_whh, *sq_bih, *sq_bhh;         /* session_query_encoder.encoder.rnns.0 [4HS,D],[4HS,HS],.. */
+    const float *sd_wih, *sd_whh, *sd_bih, *sd_bhh;         /* session_doc_encoder.encoder.rnns.0 */
+    const float *qproj_w, *qproj_b;                         /* q_projection.linear [D,D],[D] */
+    const float *shared_w, *priv1_w;                        /* shared_session_projector / private_session_projector1 [D,2HS] */
+    const float *mo0_w, *mo0_b, *mo1_w, *mo1_b, *mo2_w, *mo2_b; /* ranknet._linear_layers.{0,1,2} [512,4D],[256,256],[2,128] */
+    int D, HS;                                              /* 256, 512 */
+} nir_cars_session_weights;
+size_t nir_cars_session_workspace_bytes(int B, int S, int N, const nir_cars_session_weights* w /*host*/);
+/* encode_clicks + encode_session ranking outputs (cars.py:262-520):
+ * pooled_q [B,S,D], pooled_docs [B,S,N,D], labels [B,S,N] -> click_scores [B,S,N];
+ * clicks_out (optional) [B,S,D] = encode_clicks result. */
+int nir_cars_rank_session(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
+                          const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                          float* click_scores, float* clicks_out, nir_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUROIR_HIP_H */

@@ -1,0 +1,350 @@
+"""CPU oracle for the neuroir encode-and-rank hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain PyTorch-CPU (fp32) restatement of the reference algorithms on the hot path
+(SURVEY.md section 8a), written as pure functions over a state dict `sd` whose keys are the
+reference's own state-dict keys.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this module; the product package
+(context_attentive_ir_amd) never does, and it has no CPU fallback.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against
+tests/golden/*.npz, which tests/golden/generate.py produced by running the real reference
+(/root/reference, torch 2.10 CPU) on the same inputs and the same deterministic weights.
+
+The dataflow deliberately keeps the reference's tensor materialisations (broadcast copies,
+the host-side numpy histogram) so that timing this module is a fair "port" CPU baseline.
+Each function cites the reference lines it restates.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+EMB = "make_embedding.emb_luts.0.weight"
+
+
+def _lin(sd, p, x):
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def embed(sd, prefix, ids):
+    """neuroir/modules/embeddings.py:243-252 -- row gather; PAD row is zero in the table itself."""
+    return F.embedding(ids, sd[prefix + "." + EMB])
+
+
+_LSTM_CACHE = {}
+
+
+def rnn_encode(sd, prefix, x, lengths, bidirectional=True, init=None):
+    """neuroir/encoders/rnn_encoder.py:62-141 with nlayers=1, rnn_type='LSTM', use_last=True.
+
+    sort by length (desc) -> pack -> nn.LSTM -> unpack -> unsort -> zero-pad back to x.size(1).
+    Returns (final_state, memory_bank).  final_state stays in sorted order like the reference.
+    """
+    w_ih = sd[prefix + ".rnns.0.weight_ih_l0"]
+    hid, inp = w_ih.shape[0] // 4, w_ih.shape[1]
+    key = (prefix, id(w_ih))
+    lstm = _LSTM_CACHE.get(key)
+    if lstm is None:
+        lstm = torch.nn.LSTM(inp, hid, 1, batch_first=True, bidirectional=bidirectional)
+        names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+        if bidirectional:
+            names += [n + "_reverse" for n in names]
+        lstm.load_state_dict({n: sd[prefix + ".rnns.0." + n] for n in names})
+        lstm.eval()
+        _LSTM_CACHE[key] = lstm
+    if lengths is None:
+        out, fin = lstm(x, init) if init is not None else lstm(x)
+        return fin, out
+    slen, order = torch.sort(lengths, 0, True)
+    packed = pack_padded_sequence(x[order], slen.tolist(), batch_first=True)
+    out, fin = lstm(packed)
+    out = pad_packed_sequence(out, batch_first=True)[0]
+    out = out[torch.sort(order, 0)[1]]
+    if out.size(1) < x.size(1):
+        out = torch.cat([out, out.new_zeros(out.size(0), x.size(1) - out.size(1), out.size(2))], 1)
+    return fin, out
+
+
+# ------------------------------------------------------------------------------------------
+# ESM  (neuroir/rankers/esm.py:19-45)
+# ------------------------------------------------------------------------------------------
+@torch.no_grad()
+def esm_scores(sd, q, q_len, d, d_len):
+    B, N, DL = d.shape
+    qm = embed(sd, "word_embeddings", q).mean(1)                       # divides by padded QL
+    dm = embed(sd, "word_embeddings", d.view(B * N, DL)).mean(1).view(B, N, -1)
+    return F.cosine_similarity(qm.unsqueeze(1).expand_as(dm), dm, dim=2)
+
+
+# ------------------------------------------------------------------------------------------
+# MatchTensor  (neuroir/rankers/mtensor.py:62-131, 144-158)
+# ------------------------------------------------------------------------------------------
+@torch.no_grad()
+def match_tensor_parts(sd, q, q_len, d, d_len):
+    B, QL = q.shape
+    N, DL = d.shape[1], d.shape[2]
+    xq = _lin(sd, "linear_projection", embed(sd, "word_embeddings", q))
+    xd = _lin(sd, "linear_projection", embed(sd, "word_embeddings", d.view(B * N, DL)))
+    _, hq = rnn_encode(sd, "query_encoder", xq, q_len)
+    _, hd = rnn_encode(sd, "document_encoder", xd, d_len.reshape(-1))
+    pq = _lin(sd, "query_projection", hq)                              # [B,QL,C]
+    pd = _lin(sd, "document_projection", hd)                           # [B*N,DL,C]; == bias at padded t
+    return hq, hd, pq, pd
+
+
+@torch.no_grad()
+def match_tensor_scores(sd, q, q_len, d, d_len):
+    B, QL = q.shape
+    N, DL = d.shape[1], d.shape[2]
+    hq, hd, pq, pd = match_tensor_parts(sd, q, q_len, d, d_len)
+    C = pq.shape[-1]
+    # the reference materialises both broadcast operands (torch.stack) before multiplying
+    pq_x = pq.unsqueeze(1).expand(B, N, QL, C).reshape(B * N, QL, 1, C).expand(-1, -1, DL, -1).contiguous()
+    pd_x = pd.unsqueeze(1).expand(-1, QL, -1, -1).contiguous()
+    prod = pq_x * pd_x
+    qi = q.unsqueeze(1).expand(B, N, QL).reshape(B * N, QL, 1)
+    exact = (qi == d.view(B * N, 1, DL)).float() * sd["exact_match_channel.alpha"]  # PAD==PAD counts
+    t = torch.cat((prod, exact.unsqueeze(3)), 3).permute(0, 3, 1, 2)   # [B*N, C+1, QL, DL]
+    feats = [F.conv2d(t, sd["conv%d.weight" % k], sd["conv%d.bias" % k], padding=(1, k))
+             for k in (1, 2, 3)]
+    g = F.conv2d(F.relu(torch.cat(feats, 1)), sd["conv.weight"], sd["conv.bias"])   # [B*N,20,QL,DL]
+    pooled = g.flatten(2).max(2)[0]                                    # max over all (padded) positions
+    return _lin(sd, "output", pooled).view(B, N)
+
+
+# ------------------------------------------------------------------------------------------
+# DRMM  (neuroir/rankers/drmm.py:29-84, 95-98)
+# ------------------------------------------------------------------------------------------
+DRMM_BINS = [-1.0, -0.5, 0, 0.5, 1.0, 1.0]
+
+
+@torch.no_grad()
+def drmm_parts(sd, q, d):
+    B, QL = q.shape
+    N, DL = d.shape[1], d.shape[2]
+    eq = embed(sd, "word_embeddings", q)
+    gate = F.softmax(_lin(sd, "gating_network.weight", eq).squeeze(2), 1)           # over all QL slots
+    ed = embed(sd, "word_embeddings", d.view(B * N, DL))
+    eq_x = eq.unsqueeze(1).expand(B, N, QL, -1).reshape(B * N, QL, 1, -1).expand(-1, -1, DL, -1).contiguous()
+    ed_x = ed.unsqueeze(1).expand(-1, QL, -1, -1).contiguous()
+    cos = F.cosine_similarity(eq_x, ed_x, 3)                                        # [B*N,QL,DL]
+    c = cos.numpy()
+    hist = np.empty(c.shape[:2] + (5,), np.float32)
+    for a in range(c.shape[0]):                                                     # host histogram, drmm.py:71-75
+        for b in range(c.shape[1]):
+            hist[a, b] = np.histogram(c[a, b], bins=DRMM_BINS)[0]
+    return gate, cos, torch.from_numpy(hist)
+
+
+@torch.no_grad()
+def drmm_scores_from_hist(sd, gate, hist, B, N):
+    z = _lin(sd, "ffnn.1", _lin(sd, "ffnn.0", hist)).squeeze(2).view(B, N, -1)
+    s = (z * gate.unsqueeze(1)).sum(2, keepdim=True)
+    return _lin(sd, "output", s).view(B, N)
+
+
+@torch.no_grad()
+def drmm_scores(sd, q, q_len, d, d_len):
+    gate, _, hist = drmm_parts(sd, q, d)
+    return drmm_scores_from_hist(sd, gate, hist, d.shape[0], d.shape[1])
+
+
+# ------------------------------------------------------------------------------------------
+# DUET  (neuroir/rankers/duet.py:28-59, 77-121, 148-208)
+# ------------------------------------------------------------------------------------------
+@torch.no_grad()
+def duet_local(sd, q, d):
+    B, QL = q.shape
+    N, DL = d.shape[1], d.shape[2]
+    m = (d.view(B, N, DL, 1) == q.view(B, 1, 1, QL)).float().view(B * N, DL, QL)    # PAD==PAD -> 1
+    u = torch.tanh(F.conv1d(m, sd["local_model.conv1d.weight"], sd["local_model.conv1d.bias"]))
+    u = torch.tanh(_lin(sd, "local_model.fc1", u)).squeeze(2)
+    v = torch.tanh(_lin(sd, "local_model.fc2", u))
+    return torch.tanh(_lin(sd, "local_model.fc3", v)).view(B, N)
+
+
+@torch.no_grad()
+def duet_distributed(sd, q, d, pool_size=5):
+    B, QL = q.shape
+    N, DL = d.shape[1], d.shape[2]
+    p = "distributed_model."
+    eq = embed(sd, "word_embeddings", q)
+    ed = embed(sd, "word_embeddings", d.view(B * N, DL))
+    cq = torch.tanh(F.conv1d(eq.transpose(1, 2), sd[p + "conv_q.weight"], sd[p + "conv_q.bias"]))
+    cd = torch.tanh(F.conv1d(ed.transpose(1, 2), sd[p + "conv_d1.weight"], sd[p + "conv_d1.bias"]))
+    qv = torch.tanh(_lin(sd, p + "fc1", cq.max(2)[0]))                              # [B,F]
+    dd = torch.tanh(F.conv1d(F.max_pool1d(cd, pool_size, 1), sd[p + "conv_d2.weight"], sd[p + "conv_d2.bias"]))
+    had = (qv.view(B, 1, -1, 1).expand(B, N, -1, dd.size(2)).reshape(B * N, -1, dd.size(2)).contiguous() * dd)
+    m1 = torch.tanh(_lin(sd, p + "fc2", had)).squeeze(2)                            # Linear(DL-6 -> 1) over t
+    m2 = torch.tanh(_lin(sd, p + "fc3", m1))
+    return torch.tanh(_lin(sd, p + "fc4", m2)).view(B, N)
+
+
+@torch.no_grad()
+def duet_scores(sd, q, q_len, d, d_len):
+    return duet_local(sd, q, d) + duet_distributed(sd, q, d)
+
+
+# ------------------------------------------------------------------------------------------
+# CARS ranking path  (neuroir/multitask/cars.py:193-540, 671-691; modules/maxout.py:70-84)
+# ------------------------------------------------------------------------------------------
+def _seq_mask(lengths, max_len):
+    return torch.arange(max_len).unsqueeze(0) < lengths.unsqueeze(1)               # utils/misc.py:65-74
+
+
+def _attn_pool(sd, p, h, mask):
+    """cars.py:671-691 -- softmax(mask(w2.tanh(W1 h + b1) + b2)) weighted sum over time."""
+    a = _lin(sd, p + ".3", torch.tanh(_lin(sd, p + ".0", h))).squeeze(2)
+    a = a.masked_fill(~mask, float("-inf"))
+    return torch.bmm(h.transpose(1, 2), F.softmax(a, 1).unsqueeze(2)).squeeze(2)
+
+
+@torch.no_grad()
+def cars_encode(sd, q, q_len):
+    """cars.py:193-225 -> (pooled [B,S,256], encoded [B*S,QL,256])."""
+    B, S, QL = q.shape
+    lens = q_len.reshape(-1)
+    _, h = rnn_encode(sd, "query_encoder.encoder", embed(sd, "embedder.word_embeddings", q.view(B * S, QL)), lens)
+    return _attn_pool(sd, "q_attn", h, _seq_mask(lens, QL)).view(B, S, -1), h
+
+
+@torch.no_grad()
+def cars_encode_document(sd, d, d_len):
+    """cars.py:227-260 -> pooled docs [B,S,N,256]."""
+    B, S, N, DL = d.shape
+    lens = d_len.reshape(-1)
+    _, h = rnn_encode(sd, "document_encoder.encoder",
+                      embed(sd, "embedder.word_embeddings", d.view(B * S * N, DL)), lens)
+    return _attn_pool(sd, "d_attn", h, _seq_mask(lens, DL)).view(B, S, N, -1)
+
+
+@torch.no_grad()
+def cars_encode_clicks(sd, docs, labels):
+    """cars.py:262-304 incl. the batch-dependent mask quirk."""
+    B, S, N, H = docs.shape
+    order = labels.sort(dim=2, descending=True, stable=True)[1]
+    sdocs = torch.gather(docs, 2, order.unsqueeze(3).expand(-1, -1, -1, H)).view(B * S, N, H)
+    count = (labels.view(B * S, N) != 0).sum(1)
+    m = int(count.max())
+    keep = torch.ones(B * S, N, dtype=torch.bool)
+    keep[:, :m] = torch.arange(m).unsqueeze(0) < count.unsqueeze(1)
+    a = _lin(sd, "click_attn.3", torch.tanh(_lin(sd, "click_attn.0", sdocs))).squeeze(2)
+    a = F.softmax(a.masked_fill(~keep, float("-inf")), 1)
+    return torch.bmm(sdocs.transpose(1, 2), a.unsqueeze(2)).squeeze(2).view(B, S, H)
+
+
+def _maxout(sd, p, x, dims=(256, 128, 1), pool=2):
+    for i, o in enumerate(dims):                                                    # maxout.py:70-84
+        x = _lin(sd, "%s._linear_layers.%d" % (p, i), x).view(*x.shape[:-1], o, pool).max(-1)[0]
+    return x
+
+
+def _cars_rank(sd, qv, sq, sdv, docs):
+    """cars.py:460-520."""
+    B, N, H = docs.shape
+    sess = torch.cat((sq, sdv), 1)
+    qp = _lin(sd, "q_projection.linear", qv) + _lin(sd, "shared_session_projector.linear", sess) \
+        + _lin(sd, "private_session_projector1.linear", sess)
+    qx = qp.unsqueeze(1).expand(B, N, H).reshape(B * N, H)
+    dx = docs.reshape(B * N, H)
+    feats = torch.cat((qx, dx, (qx - dx).abs(), qx * dx), 1)
+    return _maxout(sd, "ranknet", feats).view(B, N)
+
+
+def _lstm_step(sd, p, x, state):
+    """single-step unidirectional LSTM (cars.py:378-380, 400-402), PyTorch gate order i,f,g,o."""
+    h, c = state
+    g = F.linear(x, sd[p + ".weight_ih_l0"], sd[p + ".bias_ih_l0"]) + F.linear(h, sd[p + ".weight_hh_l0"], sd[p + ".bias_hh_l0"])
+    i, f, gg, o = g.chunk(4, 1)
+    c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+    return torch.sigmoid(o) * torch.tanh(c), c
+
+
+@torch.no_grad()
+def cars_encode_session(sd, pooled_q, pooled_docs, clicks):
+    """cars.py:306-458, ranking outputs only -> click scores [B,S,N]."""
+    B, S, _ = pooled_q.shape
+    HS = sd["session_query_attn.weight"].shape[1]
+    qs, ds = [pooled_q.new_zeros(B, HS)], [pooled_q.new_zeros(B, HS)]
+    qstate = (pooled_q.new_zeros(B, HS), pooled_q.new_zeros(B, HS))
+    dstate = (pooled_q.new_zeros(B, HS), pooled_q.new_zeros(B, HS))
+    scores = []
+    for t in range(S):
+        qv = pooled_q[:, t]
+
+        def attend(states, p):
+            st = torch.stack(states, 1)                                             # incl. the initial zero state
+            w = F.softmax(torch.bmm(_lin(sd, p, st), qv.unsqueeze(2)).squeeze(2), 1)
+            return torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2)
+
+        sq = attend(qs, "session_query_attn")
+        sdv = attend(ds, "session_doc_attn")                                        # keyed by the QUERY vector (:361)
+        scores.append(_cars_rank(sd, qv, sq, sdv, pooled_docs[:, t]))
+        qstate = _lstm_step(sd, "session_query_encoder.encoder.rnns.0", qv, qstate)
+        dstate = _lstm_step(sd, "session_doc_encoder.encoder.rnns.0", clicks[:, t], dstate)
+        qs.append(qstate[0]); ds.append(dstate[0])
+    return torch.stack(scores, 1)
+
+
+@torch.no_grad()
+def cars_rank_document(sd, pooled_q, d, d_len, labels):
+    """cars.py:522-540 -> click_scores [B,S,N]."""
+    docs = cars_encode_document(sd, d, d_len)
+    return cars_encode_session(sd, pooled_q, docs, cars_encode_clicks(sd, docs, labels))
+
+
+@torch.no_grad()
+def cars_scores(sd, q, q_len, d, d_len, labels):
+    pooled, _ = cars_encode(sd, q, q_len)
+    return cars_rank_document(sd, pooled, d, d_len, labels)
+
+
+# ------------------------------------------------------------------------------------------
+# losses / predict softmax / metrics
+# ------------------------------------------------------------------------------------------
+def bce_with_logits(scores, labels):
+    """models/ranker.py:55-69, cars.py:603 -- mean over all B*N (B*S*N) entries."""
+    return F.binary_cross_entropy_with_logits(scores, labels.float())
+
+
+def softmax_nll(scores, labels):
+    """models/ranker.py:79-89."""
+    return -(F.log_softmax(scores, -1) * labels.float()).sum(1).mean()
+
+
+def predict_softmax(scores):
+    """models/ranker.py:258, models/multitask.py:279."""
+    return F.softmax(scores, -1)
+
+
+def mean_average_precision(pred, target):
+    """eval/ltorank.py:4-26 (AP over all ranked candidates; needs >=1 relevant per row)."""
+    tot = 0.0
+    for row_p, row_t in zip(np.asarray(pred), np.asarray(target)):
+        hits, ap = 0, 0.0
+        for rank, idx in enumerate(row_p):
+            if row_t[idx] == 1:
+                hits += 1
+                ap += hits / (rank + 1)
+        tot += ap / hits
+    return tot / len(pred)
+
+
+def mean_reciprocal_rank(pred, target):
+    """eval/ltorank.py:104-123."""
+    tot = 0.0
+    for row_p, row_t in zip(np.asarray(pred), np.asarray(target)):
+        for rank, idx in enumerate(row_p):
+            if row_t[idx] == 1:
+                tot += 1.0 / (rank + 1)
+                break
+    return tot / len(pred)
+
+
+def precision_at_k(pred, target, k):
+    """eval/ltorank.py:29-47."""
+    pred, target = np.asarray(pred), np.asarray(target)
+    return float(np.mean([np.count_nonzero(t[p[:k]]) / k for p, t in zip(pred, target)]))
+
+
+MODEL_FNS = {"ESM": esm_scores, "MATCH_TENSOR": match_tensor_scores, "DRMM": drmm_scores, "DUET": duet_scores}

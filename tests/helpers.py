@@ -1,0 +1,27 @@
+"""Shared test plumbing: build a product model with the deterministic fixture weights and expose its
+state dict to the oracle (tests are the only place where product and oracle meet)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from context_attentive_ir_amd.config import default_args  # noqa: E402
+from context_attentive_ir_amd.detinit import fill_module_  # noqa: E402
+
+SEED = 1013
+
+
+def build_model(model_type, vocab=200, seed=SEED, device="cpu", **overrides):
+    from context_attentive_ir_amd import rankers
+    from context_attentive_ir_amd.multitask import CARS
+    cls = {"ESM": rankers.ESM, "MATCH_TENSOR": rankers.MatchTensor, "DRMM": rankers.DRMM, "DUET": rankers.DUET,
+           "CARS": CARS}[model_type]
+    args = default_args(model_type, src_vocab_size=vocab, **overrides)
+    model = fill_module_(cls(args), seed).eval()
+    return model.to(device)
+
+
+def cpu_state_dict(model):
+    return {k: v.detach().cpu().float() for k, v in model.state_dict().items()}

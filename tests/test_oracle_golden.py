@@ -1,0 +1,84 @@
+"""CPU: the oracle (oracle/neuroir_cpu.py) against the golden vectors produced by the REAL reference
+(tests/golden/generate.py).  This is what pins the oracle; tolerance 1e-6 (same ATen ops, same machine class)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden
+from helpers import build_model, cpu_state_dict
+from oracle import neuroir_cpu as O
+
+TOL = 1e-6
+
+
+def _close(a, b, tol=TOL):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=0, atol=tol)
+
+
+def test_esm():
+    g = load_golden("esm")
+    sd = cpu_state_dict(build_model("ESM"))
+    s = O.esm_scores(sd, T(g["que_rep"]), T(g["que_len"]), T(g["doc_rep"]), T(g["doc_len"]))
+    _close(s, g["scores"])
+    _close(O.predict_softmax(s), g["softmax"])
+    assert s[1, 2].item() == 0.0  # all-PAD document -> zero vector -> cosine 0
+
+
+def test_match_tensor():
+    g = load_golden("match_tensor")
+    sd = cpu_state_dict(build_model("MATCH_TENSOR"))
+    args = [T(g[k]) for k in ("que_rep", "que_len", "doc_rep", "doc_len")]
+    hq, hd, pq, pd = O.match_tensor_parts(sd, *args)
+    _close(hq, g["enc_q"]); _close(hd, g["enc_d"]); _close(pq, g["proj_q"]); _close(pd, g["proj_d"])
+    _close(O.match_tensor_scores(sd, *args), g["scores"], 2e-6)
+
+
+@pytest.mark.parametrize("tag", ["safe", "overlap"])
+def test_drmm(tag):
+    g = load_golden("drmm_" + tag)
+    sd = cpu_state_dict(build_model("DRMM"))
+    q, d = T(g["que_rep"]), T(g["doc_rep"])
+    gate, cos, hist = O.drmm_parts(sd, q, d)
+    _close(gate, g["gate"]); _close(cos, g["cos"])
+    np.testing.assert_array_equal(hist.numpy(), g["hist"])       # integer counts: bit-exact
+    _close(O.drmm_scores(sd, q, T(g["que_len"]), d, T(g["doc_len"])), g["scores"], 1e-5)
+
+
+def test_duet():
+    g = load_golden("duet")
+    QL, DL = g["que_rep"].shape[1], g["doc_rep"].shape[2]
+    sd = cpu_state_dict(build_model("DUET", max_query_len=QL, max_doc_len=DL))
+    q, d = T(g["que_rep"]), T(g["doc_rep"])
+    _close(O.duet_local(sd, q, d), g["local"])
+    _close(O.duet_distributed(sd, q, d), g["dist"])
+    _close(O.duet_scores(sd, q, None, d, None), g["scores"])
+
+
+@pytest.mark.parametrize("tag", ["oneclick", "multiclick"])
+def test_cars(tag):
+    g = load_golden("cars_" + tag)
+    sd = cpu_state_dict(build_model("CARS"))
+    q, ql, d, dl, lab = (T(g[k]) for k in ("source_words", "source_lens", "document_words", "document_lens", "document_labels"))
+    pooled, enc = O.cars_encode(sd, q, ql)
+    _close(pooled, g["pooled_q"]); _close(enc, g["enc_q"])
+    docs = O.cars_encode_document(sd, d, dl)
+    _close(docs, g["pooled_docs"])
+    _close(O.cars_encode_clicks(sd, docs, lab), g["encoded_clicks"])
+    s = O.cars_rank_document(sd, pooled, d, dl, lab)
+    _close(s, g["click_scores"], 2e-6)
+    _close(O.bce_with_logits(s, lab), g["ranking_loss"])
+    _close(O.predict_softmax(s), g["softmax"])
+
+
+def test_losses_and_metrics():
+    g = load_golden("losses_metrics")
+    s, y = T(g["scores"]), T(g["labels"])
+    _close(O.bce_with_logits(s, y), g["bce"]); _close(O.softmax_nll(s, y), g["softmax_nll"])
+    _close(O.predict_softmax(s), g["softmax"])
+    pred = np.argsort(-g["softmax"], kind="stable")
+    np.testing.assert_array_equal(pred, g["predictions"])
+    assert O.mean_average_precision(pred, g["labels"]) == pytest.approx(float(g["MAP"]), abs=1e-12)
+    assert O.mean_reciprocal_rank(pred, g["labels"]) == pytest.approx(float(g["MRR"]), abs=1e-12)
+    assert O.precision_at_k(pred, g["labels"], 1) == pytest.approx(float(g["P1"]), abs=1e-12)
+    assert O.precision_at_k(pred, g["labels"], 3) == pytest.approx(float(g["P3"]), abs=1e-12)
