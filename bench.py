@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""bench.py -- ranked (query,doc) pairs/sec of the encode-and-rank hot path on N MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on that fits one GPU):
+    match_tensor ranker, batch = 32 queries x 10 candidates, q_len 4, doc_len 64, emb_dim 300, fp32,
+    synthetic MSMARCO-shaped ids (Zipf over a 100 000 x 300 table, seed 1013), full-length sequences.
+A "step" = Ranker.predict on one batch already resident in HBM: network forward + softmax over candidates.
+N > 1 (weak scaling): the CANDIDATE axis is sharded -- every rank scores its own 10 candidates of each of the
+32 queries (global candidate set = 10*N per query) and one RCCL all-gather assembles the [32, 10*N] score
+matrix on every rank before the softmax.  value = pairs all ranks ranked / max-rank time.
+
+Besides the driver's contract keys the JSON line carries
+    roofline     -- the dominant kernel (by summed duration), timed with HIP events on its launch stream in a
+                    profiled pass over the same workload right after the timed region (events inside the timed
+                    region would distort it); its algorithmic flops/bytes per launch are stated in DESIGN.md;
+    cpu_baseline -- the CPU oracle (oracle/neuroir_cpu.py, pinned to the reference) timed on the host cores
+                    on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from context_attentive_ir_amd import lib, sharding, synth  # noqa: E402
+from context_attentive_ir_amd.config import default_args  # noqa: E402
+from context_attentive_ir_amd.detinit import fill_module_  # noqa: E402
+from context_attentive_ir_amd.wrappers import Multitask, Ranker  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_FP32_TFLOPS = 157.3     # fp32 vector == fp32 MFMA peak
+
+
+def algorithmic_bytes_per_pair(N, QL, DL, E=300):
+    """every token occurrence gathers its fp32 row once + int64 id, + 4 B score."""
+    return DL * (4 * E + 8) + QL * (4 * E + 8) / N + 4
+
+
+# per-kernel algorithmic work for one launch of the MatchTensor pipeline (derivations in DESIGN.md section 5)
+def kernel_work(name, B, N, QL, DL, E=300, F=40, Hq=15, Hd=70, C=50):
+    M = B * N
+    w = {
+        "lstm_rec_kernel<80>": dict(flops=M * 2 * DL * 2 * Hd * 4 * Hd, bytes=M * DL * (8 * Hd + 2 * Hd) * 4),
+        "lstm_rec_kernel<16>": dict(flops=B * 2 * QL * 2 * Hq * 4 * Hq, bytes=B * QL * (8 * Hq + 2 * Hq) * 4),
+        "mt_head_kernel": dict(flops=M * QL * DL * 2 * (15 * C * 6 + 45 * 6 + 18 * 20), bytes=M * DL * (C * 4 + 8) + M * 4),
+        "gemm_kernel[gather]": dict(flops=(M * DL + B * QL) * 2 * E * F, bytes=(M * DL + B * QL) * (4 * E + 8 + 4 * F)),
+        "gemm_kernel": dict(flops=M * DL * 2 * (F * 8 * Hd + 2 * Hd * C) + B * QL * 2 * (F * 8 * Hq + 2 * Hq * C),
+                            bytes=M * DL * 4 * (F + 8 * Hd + 2 * Hd + C)),
+        "mt_fold_kernel": dict(flops=B * QL * 15 * C * 3 * 6 * 2, bytes=B * QL * 15 * C * 8 * 4),
+    }
+    return w.get(name)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="match_tensor", choices=["match_tensor", "esm", "drmm", "duet", "cars"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--cands", type=int, default=10)
+    ap.add_argument("--qlen", type=int, default=4)
+    ap.add_argument("--dlen", type=int, default=64)
+    ap.add_argument("--session", type=int, default=7)
+    ap.add_argument("--vocab", type=int, default=100000)
+    ap.add_argument("--nbatches", type=int, default=8, help="distinct resident batches cycled through")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build(args, dev):
+    kind = args.model.upper()
+    extra = dict(max_query_len=args.qlen, max_doc_len=args.dlen) if kind == "DUET" else {}
+    margs = default_args(kind, src_vocab_size=args.vocab, **extra)
+    wrapper = Multitask(margs) if kind == "CARS" else Ranker(margs)
+    fill_module_(wrapper.network, 1013)
+    wrapper.cuda()
+    wrapper.network.eval()
+    return wrapper
+
+
+def make_batches(args, rank, dev):
+    out = []
+    for i in range(args.nbatches):
+        seed = 1013 + 7919 * i + 104729 * rank
+        if args.model == "cars":
+            b = synth.session_batch(args.batch, args.session, args.cands, args.qlen, args.dlen, args.vocab, seed)
+        else:
+            b = synth.ranker_batch(args.batch, args.cands, args.qlen, args.dlen, args.vocab, seed)
+        out.append({k: v.to(dev) for k, v in b.items()})
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    L = lib.load()
+    model = build(args, dev)
+    batches = make_batches(args, rank, dev)
+    is_cars = args.model == "cars"
+    pairs_per_step_rank = args.batch * args.cands * (args.session if is_cars else 1)
+
+    def step(i):
+        ex = batches[i % len(batches)]
+        if is_cars:
+            return model.predict(ex)["click_scores"]
+        s = model.scores(ex)
+        if world > 1:
+            s = sharding.gather_scores(s, args.cands * world)
+        out = torch.empty_like(s)
+        lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
+        return out
+
+    # ---- optional hipGraph replay of the step (single GPU; removes host launch overhead) -------------
+    graphs = None
+    use_graph = (not args.no_graph) and world == 1
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    for i in range(max(3, min(args.warmup, 5))):
+        step(i)
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            graphs = []
+            for i in range(len(batches)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    out = step(i)
+                graphs.append((g, out))
+        except Exception as e:  # pragma: no cover - graph capture is an optimisation only
+            print("[bench] graph capture unavailable (%s); timing eager launches" % e, file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
+
+    def run(i):
+        if graphs is not None:
+            graphs[i % len(graphs)][0].replay()
+        else:
+            step(i)
+
+    for i in range(args.warmup):
+        run(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_pairs = pairs_per_step_rank * world * args.steps
+    value = total_pairs / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- profiled pass: HIP events around every kernel of the library, same workload -------------------
+    roofline = None
+    if rank == 0:
+        import ctypes
+        nprof = max(10, min(args.steps, 50))
+        L.nir_profile_enable(1)
+        for i in range(nprof):
+            step(i)
+        torch.cuda.synchronize()
+        L.nir_profile_enable(0)
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.nir_profile_report(buf, len(buf))
+        kern = {}
+        for line in buf.value.decode().strip().splitlines():
+            name, cnt, ms = line.rsplit(",", 2)
+            kern[name] = (int(cnt), float(ms))
+        if kern:
+            dom = max(kern, key=lambda k: kern[k][1])
+            cnt, ms = kern[dom]
+            launches_per_step = cnt / nprof
+            avg_us = ms / cnt * 1e3
+            roofline = {"kernel": dom, "avg_us": round(avg_us, 3), "launches_per_step": launches_per_step,
+                        "kernels_us_per_step": {k: round(v[1] / nprof * 1e3, 2) for k, v in sorted(kern.items())}}
+            work = kernel_work(dom, args.batch, args.cands, args.qlen, args.dlen) if args.model == "match_tensor" else None
+            if work:
+                fl = work["flops"] / launches_per_step
+                by = work["bytes"] / launches_per_step
+                tf = fl / (avg_us * 1e-6) / 1e12
+                gbs = by / (avg_us * 1e-6) / 1e9
+                if fl / by > PEAK_FP32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+                    roofline.update(bound="mfma", achieved=round(tf, 4), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
+                                    frac=round(tf / PEAK_FP32_TFLOPS, 5))
+                else:
+                    roofline.update(bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                    frac=round(gbs / PEAK_HBM_GBS, 5))
+                roofline["alg_flops_per_launch"] = fl
+                roofline["alg_bytes_per_launch"] = by
+            elif args.model in ("esm", "drmm"):
+                by = algorithmic_bytes_per_pair(args.cands, args.qlen, args.dlen) * args.batch * args.cands
+                gbs = by / (avg_us * 1e-6) / 1e9
+                roofline.update(bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                frac=round(gbs / PEAK_HBM_GBS, 5), alg_bytes_per_launch=by)
+            roofline["traffic"] = None  # PMC FETCH_SIZE pass: see profiles/ (collected separately, per the guide)
+            # whole-step HBM fraction BASELINE.json asks for (algorithmic bytes of SURVEY.md 8d x pairs/s)
+            bpp = algorithmic_bytes_per_pair(args.cands, args.qlen, args.dlen)
+            roofline["step_hbm_GBps"] = round(value / world * bpp / 1e9, 2)
+            roofline["step_hbm_frac"] = round(value / world * bpp / 1e9 / PEAK_HBM_GBS, 5)
+
+    # ---- CPU baseline: the oracle (pinned port of the reference) on the host cores ---------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import neuroir_cpu as O
+        sd = {k: v.detach().cpu().float() for k, v in model.network.state_dict().items()}
+        ex = {k: v.cpu() for k, v in batches[0].items()}
+        ncores = torch.get_num_threads()
+        if is_cars:
+            fn = lambda: O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])  # noqa: E731
+        else:
+            f = O.MODEL_FNS[args.model.upper()]
+            fn = lambda: O.predict_softmax(f(sd, ex["que_rep"], ex["que_len"], ex["doc_rep"], ex["doc_len"]))  # noqa: E731
+        ref = fn()
+        gpu = step(0).cpu()
+        maxdiff = float((gpu - ref.view_as(gpu)).abs().max())
+        n, t1 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            dt = time.perf_counter() - t1
+            if dt > args.cpu_seconds or n >= 2000:
+                break
+        cpu = {"value": round(n * pairs_per_step_rank / dt, 1), "unit": "pairs/s", "cores": ncores, "kind": "port",
+               "sample": "%d batches of the same %s workload in %.1f s (oracle/neuroir_cpu.py, torch %s CPU, %d threads)"
+                         % (n, args.model, dt, torch.__version__, ncores),
+               "max_abs_diff_vs_gpu_softmax": maxdiff}
+
+    if rank == 0:
+        cfg = {"workload": "%s ranker, batch=%d queries x %d candidates%s, q_len=%d, doc_len=%d, emb_dim=300, vocab=%d, fp32, full-length Zipf ids"
+                           % (args.model, args.batch, args.cands * world, (" x session %d" % args.session) if is_cars else "",
+                              args.qlen, args.dlen, args.vocab),
+               "global_batch_pairs": pairs_per_step_rank * world,
+               "parallelism": "candidate-sharded x%d + RCCL all-gather of scores" % world if world > 1 else "single GPU",
+               "hipgraph": graphs is not None}
+        line = {"metric": "ranked (query,doc) pairs/sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,380 @@
+// CARS ranking path (neuroir/multitask/cars.py).
+//
+// nir_cars_encode       : CARS.encode / encode_document (:193-260) = embedding gather fused into the LSTM gate
+//                         GEMM (K=E, N=8H, fp32 MFMA) -> BiLSTM recurrence -> attention MLP GEMM + tanh -> logit row
+//                         dot -> masked softmax + weighted sum (apply_pooling, :671-691), one wave per sequence.
+// nir_cars_rank_session : encode_clicks (:262-304, incl. the batch-dependent mask quirk) + the sequential session
+//                         loop of encode_session (:306-458) restricted to what ranking needs: cross attention over
+//                         the previous session states (incl. the initial zero state), rank() with the maxout
+//                         ranknet (:460-520), and the two single-step session LSTMs.  Every step is enqueued from
+//                         here -- no host sync anywhere (the reference syncs at .cpu().numpy() and lengths.tolist()).
+#include "common.hpp"
+
+namespace nir {
+
+int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                  int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                  int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
+int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
+                  hipStream_t st);
+int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
+                  float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------------
+// attention pooling: one wave per sequence; logits [M,T], h [M,T,D] (D % 4 == 0, D <= 1024)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict__ h, const float* __restrict__ logits,
+                                                        const int64_t* __restrict__ lens, int64_t M, int T, int D,
+                                                        float* __restrict__ pooled) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    int len = lens ? (int)lens[m] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const float* lg = logits + m * T;
+    float mx = -INFINITY;
+    for (int t = lane; t < len; t += 64) mx = fmaxf(mx, lg[t]);
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int t = lane; t < len; t += 64) den += expf(lg[t] - mx);
+    den = wave_sum(den);
+    const int nch = D >> 2;
+    for (int c = lane; c < nch; c += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < len; ++t) {
+            float p = expf(lg[t] - mx) / den;
+            float4 v = *reinterpret_cast<const float4*>(h + (m * T + t) * D + 4 * c);
+            acc.x = fmaf(p, v.x, acc.x); acc.y = fmaf(p, v.y, acc.y); acc.z = fmaf(p, v.z, acc.z); acc.w = fmaf(p, v.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(pooled + m * D + 4 * c) = acc;
+    }
+}
+
+struct EncPlan {
+    float *gates, *enc, *a1, *logit;
+    size_t bytes;
+};
+static EncPlan enc_plan(void* ws, size_t cap, int64_t M, int T, int H) {
+    Workspace a(ws, cap);
+    EncPlan p;
+    p.gates = a.take<float>((size_t)M * T * 8 * H);
+    p.enc = a.take<float>((size_t)M * T * 2 * H);
+    p.a1 = a.take<float>((size_t)M * T * 2 * H);
+    p.logit = a.take<float>((size_t)M * T);
+    p.bytes = align_up(a.off, 256);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// session kernels
+// ------------------------------------------------------------------------------------------------------
+// m = max over rows of count_nonzero(labels[row, :])   (cars.py:285-289, batch-wide)
+__global__ __launch_bounds__(256) void click_maxcount_kernel(const float* labels, int rows, int N, int* mout) {
+    __shared__ int part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int best = 0;
+    for (int r = wave; r < rows; r += 4) {
+        int c = 0;
+        for (int k = lane; k < N; k += 64) c += labels[(int64_t)r * N + k] != 0.f;
+        c = (int)wave_sum((float)c);
+        best = max(best, c);
+    }
+    if (lane == 0) part[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) mout[0] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
+// one wave per (b,s) row, N <= 64: stable descending rank by label, attend over {rank < count} U {rank >= m}
+__global__ __launch_bounds__(256) void click_pool_kernel(const float* __restrict__ docs, const float* __restrict__ e,
+                                                         const float* __restrict__ labels, const int* __restrict__ mptr,
+                                                         int rows, int N, int D, float* __restrict__ clicks) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int m = mptr[0];
+    const float lab = lane < N ? labels[(int64_t)r * N + lane] : -INFINITY;
+    int rank = 0;
+    for (int k = 0; k < N; ++k) {
+        float lk = __shfl(lab, k, 64);
+        rank += (lk > lab) || (lk == lab && k < lane);
+    }
+    const int count = (int)wave_sum((lane < N && lab != 0.f) ? 1.f : 0.f);
+    const bool keep = lane < N && (rank < count || rank >= m);
+    const float lg = keep ? e[(int64_t)r * N + lane] : -INFINITY;
+    const float mx = wave_max(lg);
+    const float ex = keep ? expf(lg - mx) : 0.f;
+    const float p = ex / wave_sum(ex);   // all masked -> NaN, exactly like softmax of all -inf in the reference
+    const int nch = D >> 2;
+    for (int c = lane; c < nch; c += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < N; ++k) {
+            float pk = __shfl(p, k, 64);
+            float4 v = *reinterpret_cast<const float4*>(docs + ((int64_t)r * N + k) * D + 4 * c);
+            acc.x = fmaf(pk, v.x, acc.x); acc.y = fmaf(pk, v.y, acc.y); acc.z = fmaf(pk, v.z, acc.z); acc.w = fmaf(pk, v.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(clicks + (int64_t)r * D + 4 * c) = acc;
+    }
+}
+
+// cross attention over the session states 0..t (cars.py:348-366): one workgroup per session b.
+//   logit_k = inter[k][b] . q[b]   (inter_k = W states_k + bias, cached per state)
+//   out[b]  = sum_k softmax(logit)_k * states[k][b]          -> written into xcat[b, off : off+HS]
+__global__ __launch_bounds__(256) void session_attend_kernel(const float* __restrict__ inter, const float* __restrict__ states,
+                                                             const float* __restrict__ q, int64_t qstride, int B, int nstates,
+                                                             int D, int HS, float* __restrict__ out, int64_t ostride) {
+    __shared__ float lg[64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < nstates; k += 4) {
+        float s = 0.f;
+        for (int f = lane; f < D; f += 64) s += inter[((int64_t)k * B + b) * D + f] * q[(int64_t)b * qstride + f];
+        s = wave_sum(s);
+        if (lane == 0) lg[k] = s;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int k = 0; k < nstates; ++k) mx = fmaxf(mx, lg[k]);
+    float den = 0.f;
+    for (int k = 0; k < nstates; ++k) den += expf(lg[k] - mx);
+    for (int f = threadIdx.x; f < HS; f += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < nstates; ++k) acc = fmaf(expf(lg[k] - mx) / den, states[((int64_t)k * B + b) * HS + f], acc);
+        out[(int64_t)b * ostride + f] = acc;
+    }
+}
+
+// dst[r, doff : doff+n] = src[r*sstride : +n]
+__global__ void copy_cols_kernel(const float* src, int64_t sstride, float* dst, int64_t dstride, int64_t doff, int rows, int n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)rows * n) {
+        int r = (int)(i / n), c = (int)(i % n);
+        dst[r * dstride + doff + c] = src[r * sstride + c];
+    }
+}
+
+// wcat[o, 0:K1] = w1[o,:], wcat[o, K1:K1+K2] = w2[o,:] (+ w3[o,:] if given)
+__global__ void concat_weights_kernel(const float* w1, int K1, const float* w2, const float* w3, int K2, int O, float* wcat) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = K1 + K2;
+    if (i < (int64_t)O * K) {
+        int o = (int)(i / K), k = (int)(i % K);
+        float v;
+        if (k < K1) v = w1[(int64_t)o * K1 + k];
+        else {
+            v = w2[(int64_t)o * K2 + (k - K1)];
+            if (w3) v += w3[(int64_t)o * K2 + (k - K1)];
+        }
+        wcat[i] = v;
+    }
+}
+
+// feats[b*N+n] = [q', d, |q'-d|, q'*d]   (cars.py:514-518)
+__global__ void rank_feats_kernel(const float* qp, const float* docs, int64_t dstride_b, int N, int D, int rows, float* feats) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)rows * D) {
+        int r = (int)(i / D), f = (int)(i % D);
+        int b = r / N, n = r % N;
+        float q = qp[(int64_t)b * D + f], d = docs[(int64_t)b * dstride_b + (int64_t)n * D + f];
+        float* o = feats + (int64_t)r * 4 * D;
+        o[f] = q; o[D + f] = d; o[2 * D + f] = fabsf(q - d); o[3 * D + f] = q * d;
+    }
+}
+
+// y[r, o] = max_p z[r, o*pool + p]   (maxout.py:77-81)
+__global__ void maxout_kernel(const float* z, int rows, int O, int pool, float* y, int64_t ystride) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)rows * O) {
+        int r = (int)(i / O), o = (int)(i % O);
+        float m = -INFINITY;
+        for (int p = 0; p < pool; ++p) m = fmaxf(m, z[((int64_t)r * O + o) * pool + p]);
+        y[r * ystride + o] = m;
+    }
+}
+
+// LSTM cell on pre-computed gates [B,4HS] (i,f,g,o): updates c in place, writes h to hout (states list) and
+// into the [x ; h] concat buffer used by the next step's gate GEMM.
+__global__ void lstm_cell_kernel(const float* gates, float* c, float* hout, float* xh, int64_t xhstride, int64_t xhoff, int B, int HS) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)B * HS) {
+        int b = (int)(i / HS), j = (int)(i % HS);
+        const float* g = gates + (int64_t)b * 4 * HS;
+        float cc = fast_sigmoid(g[HS + j]) * c[i] + fast_sigmoid(g[j]) * fast_tanh(g[2 * HS + j]);
+        float h = fast_sigmoid(g[3 * HS + j]) * fast_tanh(cc);
+        c[i] = cc;
+        hout[i] = h;
+        xh[b * xhstride + xhoff + j] = h;
+    }
+}
+
+// click_scores[b][t][n] = max(z2[b*N+n][0], z2[b*N+n][1])   (last maxout layer: 2 -> 1)
+__global__ void final_score_kernel(const float* z2, int B, int N, int S, int t, float* click_scores) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * N) {
+        int b = i / N, n = i % N;
+        click_scores[((int64_t)b * S + t) * N + n] = fmaxf(z2[2 * i], z2[2 * i + 1]);
+    }
+}
+
+__global__ void fill_kernel(float* p, float v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// dst[r, :] = bias   (inter of the zero state = bias of the attention Linear)
+__global__ void bias_rows_kernel(const float* bias, float* dst, int rows, int D) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)rows * D) dst[i] = bias[i % D];
+}
+
+struct SessPlan {
+    float *a1, *e, *clicks, *Qs, *Ds, *interQ, *interD, *xcat, *wrank, *wq_lstm, *wd_lstm, *xhq, *xhd, *cq, *cd, *gates;
+    float *qp, *feats, *z0, *y0, *z1, *y1, *z2;
+    int* m;
+    size_t bytes;
+};
+static SessPlan sess_plan(void* ws, size_t cap, int B, int S, int N, int D, int HS) {
+    Workspace a(ws, cap);
+    SessPlan p;
+    const size_t R = (size_t)B * S * N;
+    p.a1 = a.take<float>(R * D);
+    p.e = a.take<float>(R);
+    p.clicks = a.take<float>((size_t)B * S * D);
+    p.Qs = a.take<float>((size_t)(S + 1) * B * HS);
+    p.Ds = a.take<float>((size_t)(S + 1) * B * HS);
+    p.interQ = a.take<float>((size_t)(S + 1) * B * D);
+    p.interD = a.take<float>((size_t)(S + 1) * B * D);
+    p.xcat = a.take<float>((size_t)B * (D + 2 * HS));
+    p.wrank = a.take<float>((size_t)D * (D + 2 * HS));
+    p.wq_lstm = a.take<float>((size_t)4 * HS * (D + HS));
+    p.wd_lstm = a.take<float>((size_t)4 * HS * (D + HS));
+    p.xhq = a.take<float>((size_t)B * (D + HS));
+    p.xhd = a.take<float>((size_t)B * (D + HS));
+    p.cq = a.take<float>((size_t)B * HS);
+    p.cd = a.take<float>((size_t)B * HS);
+    p.gates = a.take<float>((size_t)B * 4 * HS);
+    p.qp = a.take<float>((size_t)B * D);
+    p.feats = a.take<float>((size_t)B * N * 4 * D);
+    p.z0 = a.take<float>((size_t)B * N * 512);
+    p.y0 = a.take<float>((size_t)B * N * 256);
+    p.z1 = a.take<float>((size_t)B * N * 256);
+    p.y1 = a.take<float>((size_t)B * N * 128);
+    p.z2 = a.take<float>((size_t)B * N * 2);
+    p.m = a.take<int>(4);
+    p.bytes = align_up(a.off, 256);
+    return p;
+}
+
+static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace nir
+
+extern "C" size_t nir_cars_encode_workspace_bytes(int64_t M, int T, int E, const nir_cars_encoder_weights* w) {
+    if (!w || M < 0 || T <= 0) return 0;
+    return nir::enc_plan(nullptr, 0, M, T, w->H).bytes;
+}
+
+extern "C" int nir_cars_encode(const int64_t* ids, const int64_t* lens, int64_t M, int T, const float* table, int64_t V,
+                               int E, const nir_cars_encoder_weights* w, void* workspace, size_t workspace_bytes,
+                               float* pooled, float* encoded, nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(ids && lens && table && w && pooled, "cars_encode: null pointer");
+    NIR_REQUIRE(M >= 0 && T > 0 && V > 0 && E > 0, "cars_encode: bad dims");
+    NIR_REQUIRE(nir_bilstm_supported(w->H) && (2 * w->H) % 4 == 0, "cars_encode: hidden size %d unsupported", w->H);
+    if (M == 0) return 0;
+    const int H = w->H, D = 2 * H;
+    EncPlan p = enc_plan(workspace, workspace_bytes, M, T, H);
+    if (!workspace || p.bytes > workspace_bytes) {
+        set_error("cars_encode: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+        return NIR_ERR_WORKSPACE;
+    }
+    float* enc = encoded ? encoded : p.enc;
+    NIR_PROPAGATE(launch_linear(nullptr, 0, ids, table, E, 1, 1, w->wih, E, w->bih, w->bhh, p.gates, 8 * H, M * T, 8 * H, E, NIR_ACT_NONE, st));
+    NIR_PROPAGATE(launch_bilstm(p.gates, lens, w->whh, nullptr, nullptr, enc, nullptr, nullptr, M, T, H, 2, st));
+    NIR_PROPAGATE(launch_linear(enc, D, nullptr, nullptr, 0, 0, 0, w->attn0_w, D, w->attn0_b, nullptr, p.a1, D, M * T, D, D, NIR_ACT_TANH, st));
+    NIR_PROPAGATE(launch_rowdot(p.a1, D, w->attn3_w, w->attn3_b, p.logit, M * T, D, NIR_ACT_NONE, st));
+    {
+        ProfScope ps("attn_pool_kernel", st);
+        hipLaunchKernelGGL(attn_pool_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, enc, p.logit, lens, M, T, D, pooled);
+    }
+    NIR_CHECK_LAUNCH("attn_pool_kernel");
+    return 0;
+}
+
+extern "C" size_t nir_cars_session_workspace_bytes(int B, int S, int N, const nir_cars_session_weights* w) {
+    if (!w || B < 0 || S <= 0 || N <= 0) return 0;
+    return nir::sess_plan(nullptr, 0, B, S, N, w->D, w->HS).bytes;
+}
+
+extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S,
+                                     int N, const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
+                                     float* click_scores, float* clicks_out, nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(pooled_q && pooled_docs && labels && w && click_scores, "cars_rank_session: null pointer");
+    NIR_REQUIRE(B >= 0 && S > 0 && N > 0, "cars_rank_session: bad dims");
+    NIR_REQUIRE(N <= 64, "cars_rank_session: %d candidates > 64 unsupported", N);
+    NIR_REQUIRE(S + 1 <= 64, "cars_rank_session: session length %d > 63 unsupported", S);
+    NIR_REQUIRE(w->D % 4 == 0 && w->HS % 4 == 0, "cars_rank_session: D/HS must be multiples of 4");
+    if (B == 0) return 0;
+    const int D = w->D, HS = w->HS;
+    SessPlan p = sess_plan(workspace, workspace_bytes, B, S, N, D, HS);
+    if (!workspace || p.bytes > workspace_bytes) {
+        set_error("cars_rank_session: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+        return NIR_ERR_WORKSPACE;
+    }
+    const int rows = B * S;
+    const int64_t R = (int64_t)rows * N;
+    float* clicks = clicks_out ? clicks_out : p.clicks;
+    ProfScope ps_all("cars_rank_session[all kernels]", st);
+    // ---- encode_clicks (cars.py:262-304)
+    NIR_PROPAGATE(launch_linear(pooled_docs, D, nullptr, nullptr, 0, 0, 0, w->click0_w, D, w->click0_b, nullptr, p.a1, D, R, D, D, NIR_ACT_TANH, st));
+    NIR_PROPAGATE(launch_rowdot(p.a1, D, w->click3_w, w->click3_b, p.e, R, D, NIR_ACT_NONE, st));
+    hipLaunchKernelGGL(click_maxcount_kernel, dim3(1), dim3(256), 0, st, labels, rows, N, p.m);
+    hipLaunchKernelGGL(click_pool_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, pooled_docs, p.e, labels, p.m, rows, N, D, clicks);
+    NIR_CHECK_LAUNCH("click_pool_kernel");
+    // ---- one-time setup of the session loop
+    const int KR = D + 2 * HS, KL = D + HS;
+    hipLaunchKernelGGL(concat_weights_kernel, g1((int64_t)D * KR), dim3(256), 0, st, w->qproj_w, D, w->shared_w, w->priv1_w, 2 * HS, D, p.wrank);
+    hipLaunchKernelGGL(concat_weights_kernel, g1((int64_t)4 * HS * KL), dim3(256), 0, st, w->sq_wih, D, w->sq_whh, (const float*)nullptr, HS, 4 * HS, p.wq_lstm);
+    hipLaunchKernelGGL(concat_weights_kernel, g1((int64_t)4 * HS * KL), dim3(256), 0, st, w->sd_wih, D, w->sd_whh, (const float*)nullptr, HS, 4 * HS, p.wd_lstm);
+    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.Qs, 0.f, (int64_t)B * HS);   // state 0 = zeros
+    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.Ds, 0.f, (int64_t)B * HS);
+    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.cq, 0.f, (int64_t)B * HS);
+    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.cd, 0.f, (int64_t)B * HS);
+    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * KL), dim3(256), 0, st, p.xhq, 0.f, (int64_t)B * KL);  // h_0 = 0
+    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * KL), dim3(256), 0, st, p.xhd, 0.f, (int64_t)B * KL);
+    hipLaunchKernelGGL(bias_rows_kernel, g1((int64_t)B * D), dim3(256), 0, st, w->sq_attn_b, p.interQ, B, D);  // W*0 + b
+    hipLaunchKernelGGL(bias_rows_kernel, g1((int64_t)B * D), dim3(256), 0, st, w->sd_attn_b, p.interD, B, D);
+    NIR_CHECK_LAUNCH("cars session setup");
+    const int64_t qstride = (int64_t)S * D;            // pooled_q[b, t, :]
+    const int64_t dstride_b = (int64_t)S * N * D;      // pooled_docs[b, t, :, :]
+    for (int t = 0; t < S; ++t) {
+        const float* qt = pooled_q + (int64_t)t * D;
+        // xcat = [q_t ; attend(Q) ; attend(D)]  (both attentions are keyed by the QUERY vector, cars.py:350,361)
+        hipLaunchKernelGGL(copy_cols_kernel, g1((int64_t)B * D), dim3(256), 0, st, qt, qstride, p.xcat, (int64_t)KR, (int64_t)0, B, D);
+        hipLaunchKernelGGL(session_attend_kernel, dim3(B), dim3(256), 0, st, p.interQ, p.Qs, qt, qstride, B, t + 1, D, HS, p.xcat + D, (int64_t)KR);
+        hipLaunchKernelGGL(session_attend_kernel, dim3(B), dim3(256), 0, st, p.interD, p.Ds, qt, qstride, B, t + 1, D, HS, p.xcat + D + HS, (int64_t)KR);
+        NIR_CHECK_LAUNCH("session_attend_kernel");
+        // rank (cars.py:460-520): q' = W_q q + b + (W_shared + W_priv1)[sq;sd]; feats; maxout 1024->256->128->1
+        NIR_PROPAGATE(launch_linear(p.xcat, KR, nullptr, nullptr, 0, 0, 0, p.wrank, KR, w->qproj_b, nullptr, p.qp, D, B, D, KR, NIR_ACT_NONE, st));
+        hipLaunchKernelGGL(rank_feats_kernel, g1((int64_t)B * N * D), dim3(256), 0, st, p.qp, pooled_docs + (int64_t)t * N * D, dstride_b, N, D, B * N, p.feats);
+        NIR_PROPAGATE(launch_linear(p.feats, 4 * D, nullptr, nullptr, 0, 0, 0, w->mo0_w, 4 * D, w->mo0_b, nullptr, p.z0, 512, (int64_t)B * N, 512, 4 * D, NIR_ACT_NONE, st));
+        hipLaunchKernelGGL(maxout_kernel, g1((int64_t)B * N * 256), dim3(256), 0, st, p.z0, B * N, 256, 2, p.y0, (int64_t)256);
+        NIR_PROPAGATE(launch_linear(p.y0, 256, nullptr, nullptr, 0, 0, 0, w->mo1_w, 256, w->mo1_b, nullptr, p.z1, 256, (int64_t)B * N, 256, 256, NIR_ACT_NONE, st));
+        hipLaunchKernelGGL(maxout_kernel, g1((int64_t)B * N * 128), dim3(256), 0, st, p.z1, B * N, 128, 2, p.y1, (int64_t)128);
+        NIR_PROPAGATE(launch_linear(p.y1, 128, nullptr, nullptr, 0, 0, 0, w->mo2_w, 128, w->mo2_b, nullptr, p.z2, 2, (int64_t)B * N, 2, 128, NIR_ACT_NONE, st));
+        hipLaunchKernelGGL(final_score_kernel, g1((int64_t)B * N), dim3(256), 0, st, p.z2, B, N, S, t, click_scores);
+        NIR_CHECK_LAUNCH("ranknet");
+        if (t + 1 == S) break;  // the states after the last query are only used by the suggestion decoder
+        // session LSTM steps (cars.py:378-380, 400-402): x = q_t / clicks_t, carried (h,c)
+        hipLaunchKernelGGL(copy_cols_kernel, g1((int64_t)B * D), dim3(256), 0, st, qt, qstride, p.xhq, (int64_t)KL, (int64_t)0, B, D);
+        NIR_PROPAGATE(launch_linear(p.xhq, KL, nullptr, nullptr, 0, 0, 0, p.wq_lstm, KL, w->sq_bih, w->sq_bhh, p.gates, 4 * HS, B, 4 * HS, KL, NIR_ACT_NONE, st));
+        hipLaunchKernelGGL(lstm_cell_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.gates, p.cq, p.Qs + (int64_t)(t + 1) * B * HS, p.xhq, (int64_t)KL, (int64_t)D, B, HS);
+        NIR_PROPAGATE(launch_linear(p.Qs + (int64_t)(t + 1) * B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sq_attn_w, HS, w->sq_attn_b, nullptr, p.interQ + (int64_t)(t + 1) * B * D, D, B, D, HS, NIR_ACT_NONE, st));
+        hipLaunchKernelGGL(copy_cols_kernel, g1((int64_t)B * D), dim3(256), 0, st, clicks + (int64_t)t * D, qstride, p.xhd, (int64_t)KL, (int64_t)0, B, D);
+        NIR_PROPAGATE(launch_linear(p.xhd, KL, nullptr, nullptr, 0, 0, 0, p.wd_lstm, KL, w->sd_bih, w->sd_bhh, p.gates, 4 * HS, B, 4 * HS, KL, NIR_ACT_NONE, st));
+        hipLaunchKernelGGL(lstm_cell_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.gates, p.cd, p.Ds + (int64_t)(t + 1) * B * HS, p.xhd, (int64_t)KL, (int64_t)D, B, HS);
+        NIR_PROPAGATE(launch_linear(p.Ds + (int64_t)(t + 1) * B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sd_attn_w, HS, w->sd_attn_b, nullptr, p.interD + (int64_t)(t + 1) * B * D, D, B, D, HS, NIR_ACT_NONE, st));
+        NIR_CHECK_LAUNCH("session lstm step");
+    }
+    return 0;
+}

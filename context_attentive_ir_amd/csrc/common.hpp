@@ -34,6 +34,15 @@ void set_error(const char* fmt, ...);
         if (rc__ != 0) return rc__; \
     } while (0)
 
+// Optional per-kernel timing (nir_profile_enable / nir_profile_report): HIP events recorded on the launch stream
+// around every kernel launch while enabled.  Never enabled during graph capture or timed regions.
+struct ProfScope {
+    void* rec;
+    hipStream_t st;
+    ProfScope(const char* name, hipStream_t stream);
+    ~ProfScope();
+};
+
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -49,12 +58,19 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // sigma / tanh built on the hardware exp2 (v_exp_f32, ~1 ulp) -- absolute error ~1e-7, far inside the
 // 1e-4 score tolerance while ~4x cheaper than the ocml tanhf in the 64..290-step recurrences.
-__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) {
     float ax = fabsf(x);
     float e = __expf(-2.0f * ax);           // in (0,1]
-    float t = (1.0f - e) / (1.0f + e);
+    float t = (1.0f - e) * fast_rcp(1.0f + e);
     return copysignf(t, x);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (global loads AND stores
+// share that counter on gfx950), which would expose a full HBM round trip per recurrence step.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

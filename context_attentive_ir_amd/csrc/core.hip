@@ -1,6 +1,11 @@
 // Library-level entry points: version, thread-local error text.
 #include "common.hpp"
 #include <string.h>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 namespace nir {
 static thread_local char g_err[512] = "";
@@ -11,6 +16,65 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 }  // namespace nir
+
+namespace nir {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
+static std::vector<ProfRec*> g_prof;
+static std::atomic<int> g_prof_on{0};
+
+ProfScope::ProfScope(const char* name, hipStream_t stream) : rec(nullptr), st(stream) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    ProfRec* r = new ProfRec{name, nullptr, nullptr};
+    hipEventCreate(&r->a);
+    hipEventCreate(&r->b);
+    hipEventRecord(r->a, st);
+    rec = r;
+}
+ProfScope::~ProfScope() {
+    if (!rec) return;
+    ProfRec* r = (ProfRec*)rec;
+    hipEventRecord(r->b, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+}
+}  // namespace nir
+
+extern "C" int nir_profile_enable(int on) {
+    nir::g_prof_on.store(on ? 1 : 0);
+    return 0;
+}
+
+// Writes "kernel_name,launches,total_ms\n" lines (aggregated by name) into buf; drains the recorded events.
+extern "C" int nir_profile_report(char* buf, size_t cap) {
+    using namespace nir;
+    std::vector<ProfRec*> recs;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        recs.swap(g_prof);
+    }
+    std::map<std::string, std::pair<long, double>> agg;
+    for (ProfRec* r : recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r->b) == hipSuccess && hipEventElapsedTime(&ms, r->a, r->b) == hipSuccess) {
+            auto& e = agg[r->name];
+            e.first += 1;
+            e.second += ms;
+        }
+        hipEventDestroy(r->a);
+        hipEventDestroy(r->b);
+        delete r;
+    }
+    size_t off = 0;
+    if (buf && cap) buf[0] = 0;
+    for (auto& kv : agg) {
+        int n = snprintf(buf ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "%s,%ld,%.6f\n", kv.first.c_str(),
+                         kv.second.first, kv.second.second);
+        if (n < 0 || off + (size_t)n >= cap) break;
+        off += (size_t)n;
+    }
+    return (int)agg.size();
+}
 
 extern "C" int nir_version(void) { return 100; }
 extern "C" const char* nir_last_error_string(void) { return nir::g_err; }

@@ -1,0 +1,184 @@
+// DUET (neuroir/rankers/duet.py): local model (:77-121) + distributed model (:148-208).
+//
+// local : M[j,i] = [d_j == q_i]  (PAD==PAD counts);  U[f,i] = tanh(b_f + sum_j W[f,j] M[j,i]) -- evaluated
+//         SPARSELY: only matching (j,i) add the contiguous weight row Wt[j][:] (the reference runs a dense
+//         Conv1d over a [B*N, DL, QL] 0/1 tensor);  then fc1 over i, fc2 (GEMM), fc3 (row dot), tanh each.
+// dist  : conv_q / conv_d1 = Conv1d(E->NF, k=3) as fp32-MFMA GEMMs with K = 3E whose A rows are gathered from
+//         the embedding table on the fly (no [B*N, DL, E] block is materialised); max-pool(5, stride 1) over t;
+//         conv_d2 (1x1) as GEMM; Hadamard with the query vector, Linear over positions, fc3, fc4.
+// Round-1 structure: GEMM launches + small element kernels (conv_d1 output is written once and re-read by the
+// pool); the fully fused per-document tile pipeline is the next optimisation.
+#include "common.hpp"
+
+namespace nir {
+
+int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                  int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                  int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
+int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
+                  hipStream_t st);
+
+// one workgroup per pair: u[pair][f] = tanh(fc1_b + sum_i fc1_w[i] * tanh(conv_b[f] + sum_{j: d_j==q_i} Wt[j][f]))
+__global__ __launch_bounds__(256) void duet_local_kernel(const int64_t* __restrict__ q_ids, const int64_t* __restrict__ d_ids,
+                                                         const float* __restrict__ wt /*[DL][NF]*/, const float* __restrict__ cb,
+                                                         const float* __restrict__ fc1w, const float* __restrict__ fc1b, int N,
+                                                         int QL, int DL, int NF, float* __restrict__ u) {
+    extern __shared__ int64_t dsh[];  // [DL] doc ids, then [QL] query ids
+    int64_t* qsh = dsh + DL;
+    const int64_t pair = blockIdx.x;
+    const int b = (int)(pair / N);
+    for (int j = threadIdx.x; j < DL; j += 256) dsh[j] = d_ids[pair * DL + j];
+    for (int i = threadIdx.x; i < QL; i += 256) qsh[i] = q_ids[(int64_t)b * QL + i];
+    __syncthreads();
+    for (int f = threadIdx.x; f < NF; f += 256) {
+        float acc = fc1b[0];
+        for (int i = 0; i < QL; ++i) {
+            const int64_t qid = qsh[i];
+            float s = cb[f];
+            for (int j = 0; j < DL; ++j)
+                if (dsh[j] == qid) s += wt[(int64_t)j * NF + f];  // wave-uniform branch, coalesced row read
+            acc = fmaf(fc1w[i], fast_tanh(s), acc);
+        }
+        u[pair * NF + f] = fast_tanh(acc);
+    }
+}
+
+// out[r][f] = max_{t < T} x[r][t][f]      (global max-pool of the query conv, duet.py:178)
+__global__ __launch_bounds__(256) void colmax_kernel(const float* x, float* out, int T, int NF) {
+    const int64_t r = blockIdx.x;
+    for (int f = threadIdx.x; f < NF; f += 256) {
+        float m = -INFINITY;
+        for (int t = 0; t < T; ++t) m = fmaxf(m, x[(r * T + t) * NF + f]);
+        out[r * NF + f] = m;
+    }
+}
+
+// pooled[m][t][f] = max_{dt < P} x[m][t+dt][f], t < Tin-P+1   (max_pool1d(P, stride 1), duet.py:180); float4 over f
+__global__ __launch_bounds__(256) void maxpool_t_kernel(const float* x, float* out, int Tin, int P, int NF4, int64_t total) {
+    const int Tout = Tin - P + 1;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int f4 = (int)(e % NF4);
+        int64_t r = e / NF4;
+        int t = (int)(r % Tout);
+        int64_t m = r / Tout;
+        const float4* src = reinterpret_cast<const float4*>(x) + (m * Tin + t) * NF4 + f4;
+        float4 v = src[0];
+        for (int dt = 1; dt < P; ++dt) {
+            float4 o = src[(int64_t)dt * NF4];
+            v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
+        }
+        reinterpret_cast<float4*>(out)[e] = v;
+    }
+}
+
+// m1[pair][f] = tanh(fc2_b + sum_t fc2_w[t] * qv[b][f] * dd[pair][t][f])     (Hadamard + Linear over positions)
+__global__ __launch_bounds__(256) void duet_hadamard_kernel(const float* dd, const float* qv, const float* fc2w,
+                                                            const float* fc2b, int N, int T, int NF, float* m1) {
+    const int64_t pair = blockIdx.x;
+    const int b = (int)(pair / N);
+    for (int f = threadIdx.x; f < NF; f += 256) {
+        const float q = qv[(int64_t)b * NF + f];
+        float acc = fc2b[0];
+        for (int t = 0; t < T; ++t) acc = fmaf(fc2w[t], q * dd[(pair * T + t) * NF + f], acc);
+        m1[pair * NF + f] = fast_tanh(acc);
+    }
+}
+
+__global__ void add2_kernel(const float* a, const float* b, float* out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+struct DuetPlan {
+    float *u, *v, *sloc, *cq, *qmax, *qv, *cd, *pooled, *dd, *m1, *m2, *sdist;
+    size_t bytes;
+};
+
+static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, int NF, int P) {
+    Workspace a(ws, cap);
+    const size_t M = (size_t)B * N;
+    const int Tc = DL - 2, Tp = Tc - P + 1;
+    DuetPlan p;
+    p.u = a.take<float>(M * NF);
+    p.v = a.take<float>(M * NF);
+    p.sloc = a.take<float>(M);
+    p.cq = a.take<float>((size_t)B * (QL - 2) * NF);
+    p.qmax = a.take<float>((size_t)B * NF);
+    p.qv = a.take<float>((size_t)B * NF);
+    p.cd = a.take<float>(M * Tc * NF);
+    p.pooled = a.take<float>(M * Tp * NF);
+    p.dd = a.take<float>(M * Tp * NF);
+    p.m1 = a.take<float>(M * NF);
+    p.m2 = a.take<float>(M * NF);
+    p.sdist = a.take<float>(M);
+    p.bytes = align_up(a.off, 256);
+    return p;
+}
+
+}  // namespace nir
+
+extern "C" size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w) {
+    if (!w || B < 0 || N <= 0 || QL < 3 || DL < w->pool + 2) return 0;
+    return nir::duet_plan(nullptr, 0, B, N, QL, DL, w->NF, w->pool).bytes;
+}
+
+extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
+                              const float* table, int64_t V, int E, const nir_duet_weights* w, void* workspace,
+                              size_t workspace_bytes, float* scores, float* local_out, float* dist_out,
+                              nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(q_ids && d_ids && table && w && scores, "duet: null pointer");
+    NIR_REQUIRE(B >= 0 && N > 0 && V > 0 && E > 0, "duet: bad dims");
+    NIR_REQUIRE(QL >= 3, "duet: query length %d < dist_filter_size 3 (Conv1d would be empty)", QL);
+    NIR_REQUIRE(DL >= w->pool + 2, "duet: doc length %d too short for conv(3) + max_pool(%d)", DL, w->pool);
+    NIR_REQUIRE(w->NF % 4 == 0, "duet: nfilters %d must be a multiple of 4", w->NF);
+    if (B == 0) return 0;
+    const int NF = w->NF, P = w->pool, Tc = DL - 2, Tp = Tc - P + 1;
+    DuetPlan p = duet_plan(workspace, workspace_bytes, B, N, QL, DL, NF, P);
+    if (!workspace || p.bytes > workspace_bytes) {
+        set_error("duet: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+        return NIR_ERR_WORKSPACE;
+    }
+    const int64_t M = (int64_t)B * N;
+    float* sloc = local_out ? local_out : p.sloc;
+    float* sdist = dist_out ? dist_out : p.sdist;
+    // ---- local model (duet.py:77-121)
+    {
+        ProfScope ps("duet_local_kernel", st);
+        hipLaunchKernelGGL(duet_local_kernel, dim3((unsigned)M), dim3(256), (size_t)(DL + QL) * 8, st, q_ids, d_ids,
+                           w->l_conv_w, w->l_conv_b, w->l_fc1_w, w->l_fc1_b, N, QL, DL, NF, p.u);
+    }
+    NIR_CHECK_LAUNCH("duet_local_kernel");
+    NIR_PROPAGATE(launch_linear(p.u, NF, nullptr, nullptr, 0, 0, 0, w->l_fc2_w, NF, w->l_fc2_b, nullptr, p.v, NF, M, NF, NF, NIR_ACT_TANH, st));
+    NIR_PROPAGATE(launch_rowdot(p.v, NF, w->l_fc3_w, w->l_fc3_b, sloc, M, NF, NIR_ACT_TANH, st));
+    // ---- distributed model, query side (duet.py:172,178,183)
+    NIR_PROPAGATE(launch_linear(nullptr, 0, q_ids, table, E, QL - 2, QL, w->convq_w, 3 * E, w->convq_b, nullptr, p.cq, NF, (int64_t)B * (QL - 2), NF, 3 * E, NIR_ACT_TANH, st));
+    {
+        ProfScope ps("colmax_kernel", st);
+        hipLaunchKernelGGL(colmax_kernel, dim3(B), dim3(256), 0, st, p.cq, p.qmax, QL - 2, NF);
+    }
+    NIR_CHECK_LAUNCH("colmax_kernel");
+    NIR_PROPAGATE(launch_linear(p.qmax, NF, nullptr, nullptr, 0, 0, 0, w->fc1_w, NF, w->fc1_b, nullptr, p.qv, NF, B, NF, NF, NIR_ACT_TANH, st));
+    // ---- distributed model, document side (duet.py:174,180,185)
+    NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, Tc, DL, w->convd1_w, 3 * E, w->convd1_b, nullptr, p.cd, NF, M * Tc, NF, 3 * E, NIR_ACT_TANH, st));
+    {
+        const int64_t total = M * Tp * (NF / 4);
+        ProfScope ps("maxpool_t_kernel", st);
+        hipLaunchKernelGGL(maxpool_t_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, st, p.cd,
+                           p.pooled, Tc, P, NF / 4, total);
+    }
+    NIR_CHECK_LAUNCH("maxpool_t_kernel");
+    NIR_PROPAGATE(launch_linear(p.pooled, NF, nullptr, nullptr, 0, 0, 0, w->convd2_w, NF, w->convd2_b, nullptr, p.dd, NF, M * Tp, NF, NF, NIR_ACT_TANH, st));
+    // ---- Hadamard + fc2 over positions, fc3, fc4 (duet.py:187-207)
+    {
+        ProfScope ps("duet_hadamard_kernel", st);
+        hipLaunchKernelGGL(duet_hadamard_kernel, dim3((unsigned)M), dim3(256), 0, st, p.dd, p.qv, w->fc2_w, w->fc2_b, N, Tp, NF, p.m1);
+    }
+    NIR_CHECK_LAUNCH("duet_hadamard_kernel");
+    NIR_PROPAGATE(launch_linear(p.m1, NF, nullptr, nullptr, 0, 0, 0, w->fc3_w, NF, w->fc3_b, nullptr, p.m2, NF, M, NF, NF, NIR_ACT_TANH, st));
+    NIR_PROPAGATE(launch_rowdot(p.m2, NF, w->fc4_w, w->fc4_b, sdist, M, NF, NIR_ACT_TANH, st));
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, sloc, sdist, scores, M);
+    NIR_CHECK_LAUNCH("add2_kernel");
+    return 0;
+}

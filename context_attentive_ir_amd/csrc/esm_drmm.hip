@@ -201,6 +201,7 @@ extern "C" int nir_esm_score(const int64_t* q_ids, const int64_t* d_ids, int B, 
     NIR_REQUIRE(E % 4 == 0 && E > 0 && E <= 256 * MAXCH, "esm: emsize %d unsupported (multiple of 4, <= %d)", E, 256 * MAXCH);
     NIR_REQUIRE(((uintptr_t)table & 15) == 0, "esm: table must be 16-byte aligned");
     if (B == 0) return 0;
+    ProfScope ps("esm_kernel", (hipStream_t)stream);
     hipLaunchKernelGGL(esm_kernel, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q_ids, d_ids, N, QL, DL,
                        table, E, scores);
     NIR_CHECK_LAUNCH("nir_esm_score");
@@ -219,6 +220,7 @@ extern "C" int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     if (B == 0) return 0;
     DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b};
     size_t lds = (size_t)QL * E * 4 + QL * 4 + QL * 5 * 4;
+    ProfScope ps("drmm_kernel", (hipStream_t)stream);
     hipLaunchKernelGGL(drmm_kernel, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, q_ids, d_ids, N,
                        QL, DL, table, E, dw, scores, hist_out);
     NIR_CHECK_LAUNCH("nir_drmm_score");

@@ -178,8 +178,11 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
     if (ids) vec = vec && (E % 4 == 0) && (((uintptr_t)table & 15) == 0);
     else vec = vec && (lda % 4 == 0) && (((uintptr_t)a & 15) == 0);
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-    if (vec) hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, st, p);
+    {
+        ProfScope ps(ids ? "gemm_kernel[gather]" : "gemm_kernel", st);
+        if (vec) hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, st, p);
+    }
     NIR_CHECK_LAUNCH("nir_linear_f32");
     return 0;
 }
@@ -188,7 +191,10 @@ int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, f
                   hipStream_t st) {
     NIR_REQUIRE(x && w && out && K > 0, "rowdot: bad args");
     if (M == 0) return 0;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, ldx, w, b, out, M, K, act);
+    {
+        ProfScope ps("rowdot_kernel", st);
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, ldx, w, b, out, M, K, act);
+    }
     NIR_CHECK_LAUNCH("nir_rowdot_f32");
     return 0;
 }

@@ -13,6 +13,7 @@
 // at step >= len; the reverse direction walks t = len-1-step, exactly the packed-sequence semantics, with no
 // sort, no pack and no host sync (the reference does lengths.tolist(), rnn_encoder.py:73).
 #include "common.hpp"
+#include <string>
 
 namespace nir {
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) gbuf[(s * 4 + g) * KP + j] = acc[s];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int pidx = tid + r * NT;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     // zero the padded tail (pad_packed_sequence) and emit final states
 #pragma unroll
@@ -156,6 +157,8 @@ __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
 
 template <int KP>
 static int launch_kp(const LstmArgs& p, int S, hipStream_t st) {
+    static const std::string pname = "lstm_rec_kernel<" + std::to_string(KP) + ">";
+    ProfScope ps(pname.c_str(), st);
     dim3 block(4 * KP);
     auto grid = [&](int s) { return dim3((unsigned)((p.M + s - 1) / s), (unsigned)p.ND); };
     switch (S) {

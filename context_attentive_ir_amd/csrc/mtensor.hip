@@ -229,12 +229,18 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     hw.conv_b[0] = w->conv1_b; hw.conv_b[1] = w->conv2_b; hw.conv_b[2] = w->conv3_b;
     hw.alpha = w->alpha; hw.cw = w->conv_w; hw.cb = w->conv_b; hw.ow = w->out_w; hw.ob = w->out_b;
     hw.C = w->C; hw.NF = w->NF; hw.MF = w->MF;
-    hipLaunchKernelGGL(mt_fold_kernel, dim3(B), dim3(256), 0, st, pq, hw, QL, p.U);
+    {
+        ProfScope ps("mt_fold_kernel", st);
+        hipLaunchKernelGGL(mt_fold_kernel, dim3(B), dim3(256), 0, st, pq, hw, QL, p.U);
+    }
     NIR_CHECK_LAUNCH("mt_fold_kernel");
     size_t lds = (size_t)((w->C * (DL + 6) + 1) & ~1) * 4 + (size_t)DL * 8;
     NIR_REQUIRE(lds <= 150 * 1024, "match_tensor: doc length %d too long for the LDS-resident head (lds=%zu)", DL, lds);
-    hipLaunchKernelGGL((mt_head_kernel<6, 20>), dim3((unsigned)((int64_t)B * N)), dim3(256), lds, st, pd, p.U, q_ids, d_ids,
-                       hw, N, QL, DL, scores);
+    {
+        ProfScope ps("mt_head_kernel", st);
+        hipLaunchKernelGGL((mt_head_kernel<6, 20>), dim3((unsigned)((int64_t)B * N)), dim3(256), lds, st, pd, p.U, q_ids,
+                           d_ids, hw, N, QL, DL, scores);
+    }
     NIR_CHECK_LAUNCH("mt_head_kernel");
     return 0;
 }

@@ -50,6 +50,8 @@ _i, _l, _z = C.c_int, C.c_int64, C.c_size_t
 SIGNATURES = {
     "nir_version": (_i, []),
     "nir_last_error_string": (C.c_char_p, []),
+    "nir_profile_enable": (_i, [_i]),
+    "nir_profile_report": (_i, [C.c_char_p, _z]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_rowdot_f32": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, _i, _i, c_st]),
     "nir_bilstm_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),

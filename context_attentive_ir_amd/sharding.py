@@ -1,0 +1,51 @@
+"""Candidate-axis sharding over the GPUs of one node.
+
+Every (query, candidate) pair of the rankers is independent given the query, so rank g scores the slice
+doc_rep[:, n_g:n_{g+1}] of the N candidates (queries, weights and the embedding table are replicated) and the
+only exchange is ONE all-gather of fp32 scores [B, ceil(N/G)] -> [B, N] -- KB-sized, latency-bound, so a single
+all_gather_into_tensor (RCCL over the xGMI mesh when the group's backend is 'nccl'; 'gloo' in the CPU tests).
+N not divisible by G: shards are padded to ceil(N/G) by repeating the last candidate, the padded scores are
+dropped after the gather.  Softmax over N, losses and MAP run after the gather, replicated.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(N, world, rank):
+    """Half-open candidate range [lo, hi) of `rank` and the padded per-rank width."""
+    per = (N + world - 1) // world
+    lo = min(rank * per, N)
+    return lo, min(lo + per, N), per
+
+
+def shard_candidates(doc_rep, doc_len, world, rank):
+    """Slice [B,N,DL]/[B,N] along candidates and pad to the common width (repeat last real candidate)."""
+    N = doc_rep.shape[1]
+    lo, hi, per = shard_bounds(N, world, rank)
+    if hi > lo:
+        d, l = doc_rep[:, lo:hi], doc_len[:, lo:hi]
+    else:  # rank beyond the candidates (N < world): score a dummy copy of candidate 0, dropped later
+        d, l = doc_rep[:, :1], doc_len[:, :1]
+    pad = per - d.shape[1]
+    if pad > 0:
+        d = torch.cat([d, d[:, -1:].expand(-1, pad, -1)], 1)
+        l = torch.cat([l, l[:, -1:].expand(-1, pad)], 1)
+    return d.contiguous(), l.contiguous()
+
+
+def gather_scores(local, N, group=None):
+    """all-gather [B,per] from every rank -> [B,N] on every rank (padding removed)."""
+    world = dist.get_world_size(group)
+    B, per = local.shape
+    out = torch.empty(world * B, per, device=local.device, dtype=local.dtype)   # rank-major concatenation
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out.view(world, B, per).permute(1, 0, 2).reshape(B, world * per)[:, :N].contiguous()
+
+
+def sharded_scores(score_fn, doc_rep, doc_len, group=None):
+    """score_fn(doc_shard [B,per,DL], len_shard [B,per]) -> [B,per]; returns the full [B,N] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return score_fn(doc_rep, doc_len)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    d, l = shard_candidates(doc_rep, doc_len, world, rank)
+    return gather_scores(score_fn(d, l), doc_rep.shape[1], group)

@@ -1,0 +1,100 @@
+"""Ranker -- high-level wrapper with the call shapes of neuroir.models.ranker.Ranker
+(/root/reference/neuroir/models/ranker.py:25-346) for the hot-path models: build the network from
+`args.model_type`, `.cuda()`, `predict(ex)` = softmax(network(...), -1), `loss(ex)` and save/load of
+`{state_dict, args}`.  Training (`update`) is outside this round's scope.
+
+Multi-GPU: instead of the reference's nn.DataParallel batch split (models/ranker.py:341-346) the wrapper can
+shard the CANDIDATE axis over the ranks of a torch.distributed group and all-gather the scores (sharding.py).
+"""
+import torch
+
+from .. import lib, sharding
+from ..rankers import DRMM, DUET, ESM, MatchTensor
+
+NETWORKS = {"ESM": ESM, "DUET": DUET, "DRMM": DRMM, "MATCH_TENSOR": MatchTensor}
+BCE_MODELS = {"DUET", "DRMM", "MATCH_TENSOR"}
+
+
+class Ranker(object):
+    def __init__(self, args, src_dict=None, state_dict=None):
+        self.args = args
+        self.src_dict = src_dict
+        if src_dict is not None:
+            self.args.src_vocab_size = len(src_dict)
+        self.updates, self.use_cuda, self.parallel = 0, False, False
+        kind = args.model_type.upper()
+        if kind not in NETWORKS:
+            raise RuntimeError("Unsupported model: %s (hot-path models: %s)" % (args.model_type, sorted(NETWORKS)))
+        self.kind = kind
+        self.network = NETWORKS[kind](args)
+        if state_dict:
+            self.network.load_state_dict(state_dict)
+        self.group = None
+
+    # -- device / parallel -----------------------------------------------------------------------
+    def cuda(self):
+        self.use_cuda = True
+        self.network = self.network.cuda()
+        return self
+
+    def cpu(self):
+        self.use_cuda = False
+        self.network = self.network.cpu()
+        return self
+
+    def parallelize(self, group=None):
+        """Candidate-axis sharding over `group` (default WORLD) -- replaces nn.DataParallel."""
+        self.parallel = True
+        self.group = group
+
+    # -- prediction --------------------------------------------------------------------------------
+    def _inputs(self, ex):
+        keys = ("que_rep", "que_len", "doc_rep", "doc_len")
+        return [ex[k].cuda(non_blocking=True) if self.use_cuda else ex[k] for k in keys]
+
+    @torch.no_grad()
+    def scores(self, ex):
+        """raw network scores [B,N] (models/ranker.py:257)."""
+        self.network.eval()
+        q, ql, d, dl = self._inputs(ex)
+        if self.parallel:
+            return sharding.sharded_scores(lambda dd, ll: self.network(q, ql, dd, ll), d, dl, group=self.group)
+        return self.network(q, ql, d, dl)
+
+    @torch.no_grad()
+    def predict(self, ex):
+        """softmax over the candidates (models/ranker.py:236-260)."""
+        s = self.scores(ex).contiguous()
+        out = torch.empty_like(s)
+        lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()),
+                  "nir_softmax_rows")
+        return out
+
+    @torch.no_grad()
+    def loss(self, ex):
+        """forward + criterion of the model (BCEWithLogits, models/ranker.py:55-69); ESM has none."""
+        if self.kind not in BCE_MODELS:
+            raise RuntimeError("%s has no training criterion (main/ranker.py:414)" % self.kind)
+        s = self.scores(ex).contiguous()
+        y = ex["label"].to(s.device).float().contiguous()
+        out = torch.empty(1, device=s.device)
+        lib.check(lib.load().nir_rank_loss_bce(lib.ptr(s), lib.ptr(y), s.shape[0], s.shape[1], lib.ptr(out),
+                                               lib.stream()), "nir_rank_loss_bce")
+        return out[0]
+
+    def update(self, ex):
+        raise NotImplementedError("training step (backward + Adam) is the next scope row, SURVEY.md section 8f rank 1")
+
+    # -- persistence ---------------------------------------------------------------------------------
+    def save(self, filename):
+        state = {k: v.cpu() for k, v in self.network.state_dict().items()}
+        torch.save({"state_dict": state, "src_dict": self.src_dict, "args": self.args}, filename)
+
+    @staticmethod
+    def load(filename, new_args=None):
+        saved = torch.load(filename, map_location="cpu", weights_only=False)
+        args = saved["args"]
+        if new_args is not None:
+            from ..config import override_model_args
+            args = override_model_args(args, new_args)
+        return Ranker(args, saved.get("src_dict"), saved["state_dict"])

@@ -35,6 +35,13 @@ typedef void* nir_stream_t; /* hipStream_t */
 int nir_version(void);
 const char* nir_last_error_string(void);
 
+/* Per-kernel timing for bench.py's roofline block: while enabled, every kernel launch of this library is
+ * bracketed by two hipEvents recorded on its own stream.  nir_profile_report synchronises those events and
+ * writes "kernel_name,launches,total_ms\n" lines (aggregated by kernel) into a HOST buffer; returns the number
+ * of distinct kernels.  Must be off during graph capture. */
+int nir_profile_enable(int on);
+int nir_profile_report(char* buf /*host*/, size_t cap);
+
 /* ---------------------------------------------------------------------------------------------------
  * Building blocks
  * ------------------------------------------------------------------------------------------------ */
@@ -133,7 +140,7 @@ int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len, const int6
  * DUET  (neuroir/rankers/duet.py:28-59 forward, 77-121 local, 148-208 distributed)
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
-    const float *l_conv_w, *l_conv_b;  /* local_model.conv1d [NF,DL,1],[NF] */
+    const float *l_conv_w, *l_conv_b;  /* local_model.conv1d weight TRANSPOSED by the host to [DL][NF]; bias [NF] */
     const float *l_fc1_w, *l_fc1_b;    /* [1,QL],[1] */
     const float *l_fc2_w, *l_fc2_b;    /* [NF,NF],[NF] */
     const float *l_fc3_w, *l_fc3_b;    /* [1,NF],[1] */

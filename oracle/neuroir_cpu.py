@@ -31,9 +31,6 @@ def embed(sd, prefix, ids):
     return F.embedding(ids, sd[prefix + "." + EMB])
 
 
-_LSTM_CACHE = {}
-
-
 def rnn_encode(sd, prefix, x, lengths, bidirectional=True, init=None):
     """neuroir/encoders/rnn_encoder.py:62-141 with nlayers=1, rnn_type='LSTM', use_last=True.
 
@@ -42,8 +39,9 @@ def rnn_encode(sd, prefix, x, lengths, bidirectional=True, init=None):
     """
     w_ih = sd[prefix + ".rnns.0.weight_ih_l0"]
     hid, inp = w_ih.shape[0] // 4, w_ih.shape[1]
-    key = (prefix, id(w_ih))
-    lstm = _LSTM_CACHE.get(key)
+    cache = sd.setdefault("__lstm_modules__", {})       # cache lives and dies with this state dict
+    key = (prefix, bidirectional)
+    lstm = cache.get(key)
     if lstm is None:
         lstm = torch.nn.LSTM(inp, hid, 1, batch_first=True, bidirectional=bidirectional)
         names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
@@ -51,7 +49,7 @@ def rnn_encode(sd, prefix, x, lengths, bidirectional=True, init=None):
             names += [n + "_reverse" for n in names]
         lstm.load_state_dict({n: sd[prefix + ".rnns.0." + n] for n in names})
         lstm.eval()
-        _LSTM_CACHE[key] = lstm
+        cache[key] = lstm
     if lengths is None:
         out, fin = lstm(x, init) if init is not None else lstm(x)
         return fin, out

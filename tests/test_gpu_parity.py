@@ -1,0 +1,281 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against (a) the committed golden vectors from the real
+reference and (b) the CPU oracle on seeded synthetic inputs.  Tolerance: 1e-4 absolute on fp32 scores
+(BASELINE.json north_star); integer histogram counts are compared exactly on edge-safe inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden
+from helpers import build_model, cpu_state_dict
+from oracle import neuroir_cpu as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda"
+
+
+def _close(a, b, tol=TOL):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=0, atol=tol)
+
+
+def _synth(rng, B, N, QL, DL, V, full=False):
+    qlen = rng.integers(1, QL + 1, size=B); dlen = rng.integers(1, DL + 1, size=(B, N))
+    if full:
+        qlen[:] = QL; dlen[:] = DL
+    qlen[0] = QL; dlen[0, 0] = DL
+    q = rng.integers(4, V, size=(B, QL)); d = rng.integers(4, V, size=(B, N, DL))
+    q[np.arange(QL)[None] >= qlen[:, None]] = 0
+    d[np.arange(DL)[None, None] >= dlen[..., None]] = 0
+    return [torch.from_numpy(x.astype(np.int64)) for x in (q, qlen, d, dlen)]
+
+
+# ------------------------------------------------------------------ building blocks
+@pytest.mark.parametrize("M,N,K,act", [(37, 40, 300, 0), (130, 50, 30, 0), (64, 64, 32, 1), (257, 301, 900, 2), (5, 1, 7, 0)])
+def test_linear_dense(M, N, K, act):
+    from context_attentive_ir_amd import lib
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    ref = torch.nn.functional.linear(a, w, b)
+    ref = torch.tanh(ref) if act == 1 else torch.relu(ref) if act == 2 else ref
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    c = torch.empty(M, N, device=DEV)
+    lib.check(lib.load().nir_linear_f32(lib.ptr(ad), K, None, None, 0, 0, 0, lib.ptr(wd), K, lib.ptr(bd), None,
+                                        lib.ptr(c), N, M, N, K, act, lib.stream()), "linear")
+    _close(c, ref, 2e-5)
+
+
+def test_linear_gather_conv():
+    """Conv1d(E->F, k=3) over gathered embeddings == the GEMM with K=3E and the [F][3][E] weight layout."""
+    from context_attentive_ir_amd import lib
+    g = torch.Generator().manual_seed(7)
+    V, E, F_, nseq, L = 50, 300, 70, 5, 11
+    table = torch.randn(V, E, generator=g); ids = torch.randint(0, V, (nseq, L), generator=g)
+    w = torch.randn(F_, E, 3, generator=g) / 30; b = torch.randn(F_, generator=g)
+    ref = torch.nn.functional.conv1d(table[ids].transpose(1, 2), w, b).transpose(1, 2)   # [nseq, L-2, F]
+    wd = w.permute(0, 2, 1).contiguous().to(DEV)
+    idd, td, bd = ids.to(DEV), table.to(DEV), b.to(DEV)       # keep device copies alive across the async launch
+    out = torch.empty(nseq * (L - 2), F_, device=DEV)
+    lib.check(lib.load().nir_linear_f32(None, 0, lib.ptr(idd), lib.ptr(td), E, L - 2, L, lib.ptr(wd), 3 * E,
+                                        lib.ptr(bd), None, lib.ptr(out), F_, nseq * (L - 2), F_, 3 * E, 0,
+                                        lib.stream()), "linear")
+    _close(out.view(nseq, L - 2, F_), ref, 2e-5)
+
+
+@pytest.mark.parametrize("H,I,M,T_", [(15, 40, 7, 6), (70, 40, 33, 20), (128, 300, 19, 12), (128, 300, 700, 9), (32, 16, 1200, 5)])
+def test_rnn_encoder(H, I, M, T_):
+    from context_attentive_ir_amd.encoders import RNNEncoder
+    from context_attentive_ir_amd.detinit import fill_module_
+    enc = fill_module_(RNNEncoder("LSTM", I, True, 1, 2 * H), seed=3).eval()
+    g = torch.Generator().manual_seed(H + M)
+    x = torch.randn(M, T_, I, generator=g); lens = torch.randint(1, T_ + 1, (M,), generator=g); lens[0] = T_
+    sd = {"e." + k: v for k, v in enc.state_dict().items()}
+    (hn_ref, cn_ref), ref = O.rnn_encode(sd, "e", x, lens)
+    enc = enc.to(DEV)
+    (hn, cn), out = enc(x.to(DEV), lens.to(DEV))
+    _close(out, ref, 2e-5)
+    order = torch.sort(lens, 0, True)[1]                   # reference leaves final states in sorted order
+    _close(hn[:, order], hn_ref, 2e-5); _close(cn[:, order], cn_ref, 2e-5)
+
+
+def test_losses_softmax_golden():
+    from context_attentive_ir_amd import lib
+    g = load_golden("losses_metrics")
+    s, y = T(g["scores"], DEV), T(g["labels"], DEV).float()
+    L = lib.load()
+    out = torch.empty_like(s); loss = torch.empty(2, device=DEV)
+    lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
+    lib.check(L.nir_rank_loss_bce(lib.ptr(s), lib.ptr(y), s.shape[0], s.shape[1], lib.ptr(loss), lib.stream()), "bce")
+    lib.check(L.nir_rank_loss_softmax_nll(lib.ptr(s), lib.ptr(y), s.shape[0], s.shape[1], C_off(loss, 1), lib.stream()), "nll")
+    _close(out, g["softmax"], 1e-6); _close(loss[0], g["bce"], 1e-6); _close(loss[1], g["softmax_nll"], 1e-6)
+
+
+def C_off(t, i):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + 4 * i)
+
+
+# ------------------------------------------------------------------ ESM
+def test_esm_golden():
+    g = load_golden("esm")
+    m = build_model("ESM", device=DEV)
+    s = m(T(g["que_rep"], DEV), T(g["que_len"], DEV), T(g["doc_rep"], DEV), T(g["doc_len"], DEV))
+    _close(s, g["scores"])
+    assert s[1, 2].item() == 0.0
+
+
+@pytest.mark.parametrize("B,N,QL,DL", [(8, 5, 4, 64), (3, 50, 6, 290), (1, 1, 1, 1), (2, 7, 20, 130)])
+def test_esm_oracle(B, N, QL, DL):
+    rng = np.random.default_rng(B * 100 + N)
+    m = build_model("ESM", vocab=5000, device=DEV)
+    q, ql, d, dl = _synth(rng, B, N, QL, DL, 5000)
+    ref = O.esm_scores(cpu_state_dict(m), q, ql, d, dl)
+    _close(m(q.to(DEV), ql.to(DEV), d.to(DEV), dl.to(DEV)), ref)
+
+
+# ------------------------------------------------------------------ MatchTensor
+def test_match_tensor_golden():
+    g = load_golden("match_tensor")
+    m = build_model("MATCH_TENSOR", device=DEV)
+    s, (hq, hd, pq, pd) = m(T(g["que_rep"], DEV), T(g["que_len"], DEV), T(g["doc_rep"], DEV), T(g["doc_len"], DEV),
+                            return_parts=True)
+    _close(hq, g["enc_q"], 2e-5); _close(hd, g["enc_d"], 2e-5)
+    _close(pq, g["proj_q"], 2e-5); _close(pd, g["proj_d"], 2e-5)
+    _close(s, g["scores"])
+
+
+@pytest.mark.parametrize("B,N,QL,DL,full", [(32, 10, 4, 64, True), (4, 3, 6, 64, False), (2, 5, 1, 7, False), (3, 2, 9, 130, False)])
+def test_match_tensor_oracle(B, N, QL, DL, full):
+    rng = np.random.default_rng(B * 100 + DL)
+    m = build_model("MATCH_TENSOR", vocab=300, device=DEV)     # small vocab -> exact-match channel is exercised
+    q, ql, d, dl = _synth(rng, B, N, QL, DL, 300, full)
+    ref = O.match_tensor_scores(cpu_state_dict(m), q, ql, d, dl)
+    _close(m(q.to(DEV), ql.to(DEV), d.to(DEV), dl.to(DEV)), ref)
+
+
+# ------------------------------------------------------------------ DRMM
+def test_drmm_golden_safe():
+    g = load_golden("drmm_safe")
+    m = build_model("DRMM", device=DEV)
+    s, hist = m(T(g["que_rep"], DEV), T(g["que_len"], DEV), T(g["doc_rep"], DEV), T(g["doc_len"], DEV), return_hist=True)
+    np.testing.assert_array_equal(hist.cpu().numpy(), g["hist"].astype(np.float32))
+    _close(s, g["scores"])
+
+
+def test_drmm_golden_overlap_policy():
+    """Appendix E1 policy: with exact token overlaps the count of histogram mismatches is reported; pairs whose
+    histograms agree must agree in score."""
+    g = load_golden("drmm_overlap")
+    m = build_model("DRMM", device=DEV)
+    s, hist = m(T(g["que_rep"], DEV), T(g["que_len"], DEV), T(g["doc_rep"], DEV), T(g["doc_len"], DEV), return_hist=True)
+    same = (hist.cpu().numpy() == g["hist"]).all(axis=(1, 2))
+    print("drmm overlap: %d/%d pairs with identical histograms" % (same.sum(), same.size))
+    assert same.mean() >= 0.5
+    _close(s.cpu().numpy().reshape(-1)[same], g["scores"].reshape(-1)[same])
+    # counts always sum to DL minus dropped (>1) values
+    assert (hist.sum(-1) <= g["doc_rep"].shape[2]).all()
+
+
+@pytest.mark.parametrize("B,N,QL,DL", [(4, 6, 4, 290), (2, 3, 12, 64)])
+def test_drmm_oracle(B, N, QL, DL):
+    rng = np.random.default_rng(QL)
+    V = 5000
+    m = build_model("DRMM", vocab=V, device=DEV)
+    q, ql, d, dl = _synth(rng, B, N, QL, DL, V)
+    q[q > 0] = q[q > 0] % 1000 + 4; d[d > 0] = d[d > 0] % 3000 + 1500      # disjoint vocab halves: edge-safe
+    sd = cpu_state_dict(m)
+    gate, cos, hist_ref = O.drmm_parts(sd, q, d)
+    s, hist = m(q.to(DEV), ql.to(DEV), d.to(DEV), dl.to(DEV), return_hist=True)
+    c = cos.numpy(); edge = np.abs(c[..., None] - np.array([-1, -.5, 0, .5, 1.0])).min(-1); edge[c == 0] = 1
+    safe = (edge > 2e-6).all(axis=(1, 2))
+    np.testing.assert_array_equal(hist.cpu().numpy()[safe], hist_ref.numpy()[safe])
+    ref = O.drmm_scores_from_hist(sd, gate, hist_ref, B, N).reshape(-1)
+    _close(s.reshape(-1)[torch.from_numpy(safe)], ref[torch.from_numpy(safe)], 2e-4)   # |scores| ~ 20 -> relative 1e-5
+
+
+# ------------------------------------------------------------------ DUET
+def test_duet_golden():
+    g = load_golden("duet")
+    QL, DL = g["que_rep"].shape[1], g["doc_rep"].shape[2]
+    m = build_model("DUET", device=DEV, max_query_len=QL, max_doc_len=DL)
+    s, loc, dist = m(T(g["que_rep"], DEV), T(g["que_len"], DEV), T(g["doc_rep"], DEV), T(g["doc_len"], DEV), return_parts=True)
+    _close(loc, g["local"]); _close(dist, g["dist"]); _close(s, g["scores"])
+
+
+@pytest.mark.parametrize("B,N,QL,DL", [(3, 4, 4, 64), (2, 3, 6, 290), (1, 2, 3, 7)])
+def test_duet_oracle(B, N, QL, DL):
+    rng = np.random.default_rng(DL)
+    m = build_model("DUET", vocab=400, device=DEV, max_query_len=QL, max_doc_len=DL)
+    q, ql, d, dl = _synth(rng, B, N, QL, DL, 400)
+    sd = cpu_state_dict(m)
+    s, loc, dist = m(q.to(DEV), ql.to(DEV), d.to(DEV), dl.to(DEV), return_parts=True)
+    _close(loc, O.duet_local(sd, q, d)); _close(dist, O.duet_distributed(sd, q, d))
+    _close(s, O.duet_scores(sd, q, ql, d, dl))
+
+
+def test_duet_rejects_unpadded_and_short_query():
+    m = build_model("DUET", device=DEV, max_query_len=5, max_doc_len=24)
+    q = torch.zeros(2, 4, dtype=torch.long, device=DEV); d = torch.zeros(2, 3, 24, dtype=torch.long, device=DEV)
+    with pytest.raises(RuntimeError):
+        m(q, None, d, None)
+    m2 = build_model("DUET", device=DEV, max_query_len=2, max_doc_len=24)
+    with pytest.raises(RuntimeError):   # QL < 3: the reference's Conv1d(k=3) is invalid too
+        m2(torch.zeros(2, 2, dtype=torch.long, device=DEV), None, d, None)
+
+
+# ------------------------------------------------------------------ CARS
+@pytest.mark.parametrize("tag", ["oneclick", "multiclick"])
+def test_cars_golden(tag):
+    g = load_golden("cars_" + tag)
+    m = build_model("CARS", device=DEV)
+    q, ql, d, dl, lab = (T(g[k], DEV) for k in ("source_words", "source_lens", "document_words", "document_lens", "document_labels"))
+    pooled, enc, _ = m.encode(q, ql)
+    _close(enc, g["enc_q"], 2e-5); _close(pooled, g["pooled_q"], 2e-5)
+    docs = m.encode_document(d, dl)
+    _close(docs, g["pooled_docs"], 2e-5)
+    _close(m.encode_clicks(docs, lab), g["encoded_clicks"], 2e-5)
+    scores, _, _ = m.rank_document(pooled, d, dl, lab)
+    _close(scores, g["click_scores"])
+    out = m(q, ql, None, None, None, d, dl, lab)
+    _close(out["ranking_loss"], g["ranking_loss"], 1e-5)
+
+
+@pytest.mark.parametrize("B,S,N,QL,DL,multi", [(16, 7, 10, 4, 64, False), (3, 2, 50, 6, 33, True), (2, 1, 1, 3, 5, False)])
+def test_cars_oracle(B, S, N, QL, DL, multi):
+    from context_attentive_ir_amd import synth
+    V = 3000
+    m = build_model("CARS", vocab=V, device=DEV)
+    ex = synth.session_batch(B, S, N, QL, DL, V, seed=B * 10 + S, full_length=False, multi_click=multi)
+    sd = cpu_state_dict(m)
+    ref = O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])
+    dex = {k: v.to(DEV) for k, v in ex.items()}
+    pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
+    s, _, _ = m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"])
+    _close(s, ref)
+
+
+# ------------------------------------------------------------------ wrappers / MAP parity
+def test_ranker_predict_and_map_parity():
+    """MAP@10 parity through the Ranker wrapper (predict = softmax(network(...))).  DRMM is checked on edge-safe
+    ids (query and document tokens from disjoint vocabulary halves): with exact token overlaps cos ~ 1 lands in
+    a rounding-dependent bin even inside the reference itself."""
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.eval import MAP, rank_candidates
+    from context_attentive_ir_amd.wrappers import Ranker
+    V = 3000
+    for kind in ("ESM", "MATCH_TENSOR", "DRMM", "DUET"):
+        ex = synth.ranker_batch(16, 10, 4, 64, V, seed=5, full_length=(kind == "DUET"))
+        if kind == "DRMM":
+            q, d = ex["que_rep"], ex["doc_rep"]
+            q[q > 0] = q[q > 0] % 1000 + 4
+            d[d > 0] = d[d > 0] % 1500 + 1200
+        extra = dict(max_query_len=4, max_doc_len=64) if kind == "DUET" else {}
+        r = Ranker(default_args(kind, src_vocab_size=V, **extra)); fill_module_(r.network, 1013); r.cuda()
+        got = r.predict(ex).cpu()
+        sd = {k: v.detach().cpu() for k, v in r.network.state_dict().items()}
+        ref = O.predict_softmax(O.MODEL_FNS[kind](sd, ex["que_rep"], ex["que_len"], ex["doc_rep"], ex["doc_len"]))
+        _close(got, ref)
+        assert MAP(rank_candidates(got.numpy()), ex["label"].numpy()) == pytest.approx(
+            O.mean_average_precision(rank_candidates(ref.numpy()), ex["label"].numpy()), abs=1e-12), kind
+
+
+def test_multitask_predict_map_parity():
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.eval import MAP, rank_candidates
+    from context_attentive_ir_amd.wrappers import Multitask
+    V = 3000
+    ex = synth.session_batch(4, 5, 10, 4, 48, V, seed=11, full_length=False)
+    mt = Multitask(default_args("CARS", src_vocab_size=V)); fill_module_(mt.network, 1013); mt.cuda()
+    got = mt.predict(ex)["click_scores"].cpu()
+    sd = {k: v.detach().cpu() for k, v in mt.network.state_dict().items()}
+    ref = O.predict_softmax(O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"],
+                                          ex["document_lens"], ex["document_labels"]))
+    _close(got, ref)
+    lab = ex["document_labels"].numpy().reshape(-1, 10).astype(np.int64)
+    assert MAP(rank_candidates(got.numpy().reshape(-1, 10)), lab) == pytest.approx(
+        O.mean_average_precision(rank_candidates(ref.numpy().reshape(-1, 10)), lab), abs=1e-12)
