@@ -76,5 +76,20 @@ extern "C" int nir_profile_report(char* buf, size_t cap) {
     return (int)agg.size();
 }
 
+// Debug: effective shader clock.  Each workgroup runs a dependent FMA chain and records s_memtime (shader clock)
+// and the constant 100 MHz wall clock at entry/exit: out[0..3] = {dclk, dwall, 0, 0} of block 0.
+__global__ void clock_probe_kernel(unsigned long long* out, int iters, float* sink) {
+    unsigned long long c0 = clock64(), w0 = wall_clock64();
+    float a = threadIdx.x * 1e-9f, b = 1.000001f;
+    for (int i = 0; i < iters; ++i) a = fmaf(a, b, 1e-7f);
+    unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (a == 123.456f) sink[0] = a;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+extern "C" int nir_debug_clock_probe(void* out, int iters, int blocks, void* sink, nir_stream_t stream) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)out, iters, (float*)sink);
+    return (int)hipGetLastError();
+}
+
 extern "C" int nir_version(void) { return 100; }
 extern "C" const char* nir_last_error_string(void) { return nir::g_err; }

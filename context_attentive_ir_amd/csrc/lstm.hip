@@ -1,24 +1,42 @@
-// nir_bilstm_fwd: the recurrent half of RNNEncoder (neuroir/encoders/rnn_encoder.py:62-141, nn.LSTM).
+// nir_bilstm_fwd / nir_bilstm_fused_fwd: the recurrence of RNNEncoder (neuroir/encoders/rnn_encoder.py:62-141).
 //
-// The input half (x W_ih^T + b_ih + b_hh for every token, both directions) is one big MFMA GEMM
-// (nir_linear_f32) whose result `gates_in` this kernel consumes step by step.
+// One workgroup owns S sequences of ONE direction for the whole recurrence (time loop = workgroup barriers only).
+// Mapping: a QUAD of 4 lanes owns hidden unit j; lane q of the quad holds the W_hh rows of all four gates (i,f,g,o)
+// of unit j restricted to its quarter of K (4 x KP/4 = KP floats in VGPRs for all T steps), reads only that quarter
+// of h_{t-1} from LDS (ds_read_b128, 4 distinct conflict-free addresses per wave), accumulates with packed FMAs and
+// the four partial gate sums are combined across the quad with two DPP quad_perm adds -- no gate exchange through
+// LDS.  Every lane then has i,f,g,o of its unit, applies the cell update with c_t in a register, lane q==0 writes
+// h_t to the ping-pong LDS buffer and to HBM.  One LDS-only barrier per step.
+// (First version: one gate column per thread + broadcast reads of all of h + gate exchange via LDS: 4x the LDS
+// reads, two barriers, 2.1-3.4 us/step at 2.4 GHz -- latency-bound with ~2 LDS round trips in flight; profiles/.)
 //
-// Design (CDNA4): one workgroup owns S sequences of ONE direction for the whole recurrence, so the time
-// loop needs only workgroup barriers.  Thread c of the 4*KP threads owns gate column c = gate*KP + unit and
-// keeps its W_hh row (<=128 floats) in VGPRs for all T steps; h_{t-1} of the S sequences lives in LDS and is
-// read as wave-uniform (broadcast) ds_read_b128.  Gate pre-activations are exchanged through LDS so that one
-// thread per (sequence, unit) applies the cell update with c_t kept in a register.  S is chosen by the host so
-// that small batches still spread over all 256 CUs (latency-bound regime) while large batches reuse each
-// register-resident W_hh row S times per step.  Variable length = masking: a sequence simply stops updating
-// at step >= len; the reverse direction walks t = len-1-step, exactly the packed-sequence semantics, with no
-// sort, no pack and no host sync (the reference does lengths.tolist(), rnn_encoder.py:73).
+// Two input modes:
+//   IP == 0 : `gates_in` = x W_ih^T + b (one big fp32-MFMA GEMM, nir_linear_f32) is streamed from HBM, prefetched
+//             two steps ahead into registers; lane q adds gate q's pre-activation (CARS: I = 300);
+//   IP  > 0 : "fused" -- the lane also keeps its quarter of the four W_ih rows (I <= 64) in VGPRs and the x tile of
+//             its S sequences is staged once in LDS: no global loads in the loop and the [tokens, 8H] gate tensor
+//             never exists (MatchTensor: I = 40; saves a GEMM launch and a 2 x 46 MB HBM round trip).
+//
+// Global accesses inside the loop are branch-free raw-buffer ops (out-of-range lanes are dropped / read 0 by the
+// hardware bounds check) so the compiler can count outstanding VMEM ops exactly instead of falling back to
+// `s_waitcnt vmcnt(0)` (a full store round trip) every step.
+//
+// Variable length = masking: a sequence stops updating at step >= len; the reverse direction walks t = len-1-step
+// (packed-sequence semantics) -- no sort, no pack, no host sync (the reference does lengths.tolist(), :73).
 #include "common.hpp"
+#include <stdlib.h>
 #include <string>
 
 namespace nir {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct LstmArgs {
-    const float* gin;       // [M,T,ND*4H]
+    const float* gin;       // [M,T,ND*4H]            (IP == 0)
+    const float* x;         // [M,T,I]                (IP  > 0)
+    const float* wih;       // [ND*4H, I]             (IP  > 0)
+    const float* bih;       // [ND*4H]                (IP  > 0)
+    const float* bhh;       // [ND*4H]                (IP  > 0)
     const int64_t* lens;    // [M] or null
     const float* whh;       // [ND,4H,H]
     const float* h0;        // [ND,M,H] or null
@@ -27,148 +45,272 @@ struct LstmArgs {
     float* hn;              // [ND,M,H] or null
     float* cn;
     int64_t M;
-    int T, H, ND;
+    int T, H, ND, I;
 };
 
-template <int KP, int S>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// sum over the 4 lanes of a quad; every lane gets the total (DPP quad_perm [1,0,3,2] then [2,3,0,1])
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+
+template <int KP, int S, int IP>
 __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
     constexpr int NT = 4 * KP;
-    constexpr int R = (S * KP + NT - 1) / NT;  // cell-update rounds per thread
-    __shared__ __attribute__((aligned(16))) float hbuf[S * KP];
-    __shared__ __attribute__((aligned(16))) float gbuf[S * 4 * KP];
-    __shared__ int slen[S];
+    constexpr int KQ = KP / 4;            // k's per lane (multiple of 4)
+    constexpr int QS = KQ + 4;            // padded quarter stride in LDS (keeps the 4 quad addresses on distinct banks)
+    constexpr int HB = 4 * QS;            // floats per sequence in one h buffer
+    constexpr int IQ = IP / 4;            // x elements per lane (fused mode)
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hbuf = smem;                   // [2][S][HB]  ping-pong
+    float* xbuf = smem + 2 * S * HB;      // [S][T][IP]  (fused mode only)
 
     const int tid = threadIdx.x;
-    const int g = tid / KP, j = tid % KP;
+    const int j = tid >> 2, q = tid & 3;
     const int dir = blockIdx.y;
     const int64_t m0 = (int64_t)blockIdx.x * S;
     const int H = p.H, T = p.T;
-    const int64_t G = (int64_t)p.ND * 4 * H;   // gates_in row width
-    const int64_t OW = (int64_t)p.ND * H;      // out row width
+    const int nvalid = (int)min((int64_t)S, p.M - m0);
+    const int G = p.ND * 4 * H;   // gates_in row width
+    const int OW = p.ND * H;      // out row width
+    const bool uvalid = j < H;
 
-    if (tid < S) {
-        int64_t m = m0 + tid;
+    int len[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
         int l = 0;
-        if (m < p.M) {
-            l = p.lens ? (int)p.lens[m] : T;
+        if (s < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + s] : T;
             l = l < 0 ? 0 : (l > T ? T : l);
         }
-        slen[tid] = l;
+        len[s] = l;
     }
-    // recurrent weights of my gate column -> registers
-    float w[KP];
-    {
-        const bool valid = j < H;
-        const float* wr = p.whh + ((int64_t)dir * 4 * H + (int64_t)g * H + (valid ? j : 0)) * H;
+    int tmax = 0;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) w[k] = (valid && k < H) ? wr[k] : 0.f;
-    }
-    // initial state
-    float creg[R];
+    for (int s = 0; s < S; ++s) tmax = max(tmax, len[s]);
+
+    // my quarter of the four gate rows of unit j -> registers (packed pairs for v_pk_fma_f32)
+    v2f w[4][KQ / 2];
+    v2f wi[4][IP > 0 ? IQ / 2 : 1];
+    float bias = 0.f;   // lane q carries the bias of gate q (added once per quad)
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int pidx = tid + r * NT;
-        creg[r] = 0.f;
-        if (pidx < S * KP) {
-            int s = pidx / KP, jj = pidx % KP;
-            int64_t m = m0 + s;
-            float hv = 0.f;
-            if (jj < H && m < p.M) {
-                if (p.h0) hv = p.h0[((int64_t)dir * p.M + m) * H + jj];
-                if (p.c0) creg[r] = p.c0[((int64_t)dir * p.M + m) * H + jj];
+    for (int g = 0; g < 4; ++g) {
+        const int64_t row = (int64_t)dir * 4 * H + (int64_t)g * H + (uvalid ? j : 0);
+        const float* wr = p.whh + row * H;
+#pragma unroll
+        for (int k = 0; k < KQ; k += 2) {
+            const int k0 = q * KQ + k;
+            w[g][k / 2].x = (uvalid && k0 < H) ? wr[k0] : 0.f;
+            w[g][k / 2].y = (uvalid && k0 + 1 < H) ? wr[k0 + 1] : 0.f;
+        }
+        if (IP > 0) {
+            const float* wir = p.wih + row * p.I;
+#pragma unroll
+            for (int k = 0; k < IQ; k += 2) {
+                const int k0 = q * IQ + k;
+                wi[g][k / 2].x = (uvalid && k0 < p.I) ? wir[k0] : 0.f;
+                wi[g][k / 2].y = (uvalid && k0 + 1 < p.I) ? wir[k0 + 1] : 0.f;
             }
-            hbuf[pidx] = hv;
+            if (uvalid && g == q) bias = p.bih[row] + p.bhh[row];
+        }
+    }
+    if (IP > 0) {  // stage the x tile of my sequences: xbuf[s][t][k], zero padded to IP
+        const int per = T * IP;
+        for (int e = tid; e < S * per; e += NT) {
+            int s = e / per, r = e - s * per, t = r / IP, k = r - t * IP;
+            float v = 0.f;
+            if (s < nvalid && k < p.I) v = p.x[((m0 + s) * T + t) * p.I + k];
+            xbuf[e] = v;
+        }
+    }
+    // initial state (h index k lives at hbuf[(k / KQ) * QS + k % KQ])
+    float creg[S];
+    for (int e = tid; e < 2 * S * HB; e += NT) hbuf[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        creg[s] = 0.f;
+        if (uvalid && s < nvalid) {
+            const int64_t si = ((int64_t)dir * p.M + m0 + s) * H + j;
+            if (p.c0) creg[s] = p.c0[si];
+            if (p.h0 && q == 0) hbuf[s * HB + (j / KQ) * QS + (j % KQ)] = p.h0[si];
         }
     }
     __syncthreads();
-    int tmax = 0;
-#pragma unroll
-    for (int s = 0; s < S; ++s) tmax = max(tmax, slen[s]);
 
-    const int64_t gcol = (int64_t)dir * 4 * H + (int64_t)g * H + j;
+    // per-workgroup buffer descriptors (wave-uniform: built from blockIdx only)
+    const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(p.out + m0 * T * OW, (uint32_t)nvalid * T * OW * 4u);
+    const __amdgpu_buffer_rsrc_t gin_rs =
+        make_rsrc(IP == 0 ? (const void*)(p.gin + m0 * T * G) : (const void*)p.out, IP == 0 ? (uint32_t)nvalid * T * G * 4u : 0u);
+    const uint32_t gcol = (uint32_t)(dir * 4 * H + q * H + j) * 4u;   // lane q fetches gate q of unit j
+
     auto load_gin = [&](int step, float (&dst)[S]) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            int l = slen[s];
-            dst[s] = 0.f;
-            if (j < H && step < l) {
-                int t = dir == 0 ? step : l - 1 - step;
-                dst[s] = p.gin[((m0 + s) * T + t) * G + gcol];
-            }
+            const int l = len[s];
+            const int t = dir == 0 ? step : l - 1 - step;
+            const uint32_t off = (uvalid && step < l) ? (uint32_t)((s * T + t) * G) * 4u + gcol : OOB;
+            dst[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gin_rs, off, 0, 0));  // OOB -> 0
         }
     };
-    float pre[S];
-    if (tmax > 0) load_gin(0, pre);
 
-    for (int step = 0; step < tmax; ++step) {
-        float acc[S];
+    auto do_step = [&](int step, float (&cur)[S]) {
+        const float* hrd = hbuf + (step & 1) * S * HB + q * QS;
+        float* hwr = hbuf + ((step + 1) & 1) * S * HB;
+        float gin_now[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] = pre[s];
-        if (step + 1 < tmax) load_gin(step + 1, pre);  // in flight during the mat-vec below
+        for (int s = 0; s < S; ++s) gin_now[s] = IP > 0 ? bias : cur[s];
+        if (IP == 0 && step + 2 < tmax) load_gin(step + 2, cur);   // two steps ahead
 #pragma unroll
-        for (int k = 0; k < KP; k += 4) {
+        for (int s = 0; s < S; ++s) {
+            const int l = len[s];
+            v2f acc[4];
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                float4 hv = *reinterpret_cast<const float4*>(&hbuf[s * KP + k]);  // wave-uniform broadcast
-                acc[s] = fmaf(w[k], hv.x, acc[s]);
-                acc[s] = fmaf(w[k + 1], hv.y, acc[s]);
-                acc[s] = fmaf(w[k + 2], hv.z, acc[s]);
-                acc[s] = fmaf(w[k + 3], hv.w, acc[s]);
+            for (int g = 0; g < 4; ++g) {
+                acc[g].x = (g == q) ? gin_now[s] : 0.f;
+                acc[g].y = 0.f;
             }
-        }
+            // this lane's quarter of h_{t-1}: issue all reads, then the FMAs
+            float4 hv[KQ / 4];
 #pragma unroll
-        for (int s = 0; s < S; ++s) gbuf[(s * 4 + g) * KP + j] = acc[s];
-        lds_barrier();
+            for (int k = 0; k < KQ / 4; ++k) hv[k] = *reinterpret_cast<const float4*>(hrd + s * HB + 4 * k);
+            if (IP > 0) {
+                int t = dir == 0 ? step : l - 1 - step;
+                t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+                const float* xr = xbuf + (s * T + t) * IP + q * IQ;
+                float4 xv[IQ / 4 > 0 ? IQ / 4 : 1];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int pidx = tid + r * NT;
-            if (pidx < S * KP) {
-                int s = pidx / KP, jj = pidx % KP;
-                int l = slen[s];
-                if (jj < H && step < l) {
-                    float gi = gbuf[(s * 4 + 0) * KP + jj], gf = gbuf[(s * 4 + 1) * KP + jj];
-                    float gg = gbuf[(s * 4 + 2) * KP + jj], go = gbuf[(s * 4 + 3) * KP + jj];
-                    float c = fast_sigmoid(gf) * creg[r] + fast_sigmoid(gi) * fast_tanh(gg);
-                    float h = fast_sigmoid(go) * fast_tanh(c);
-                    creg[r] = c;
-                    hbuf[pidx] = h;
-                    int t = dir == 0 ? step : l - 1 - step;
-                    p.out[((m0 + s) * T + t) * OW + (int64_t)dir * H + jj] = h;
+                for (int k = 0; k < IQ / 4; ++k) xv[k] = *reinterpret_cast<const float4*>(xr + 4 * k);
+#pragma unroll
+                for (int k = 0; k < IQ / 4; ++k) {
+                    const v2f lo = {xv[k].x, xv[k].y}, hi = {xv[k].z, xv[k].w};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[g] = __builtin_elementwise_fma(wi[g][2 * k], lo, acc[g]);
+                        acc[g] = __builtin_elementwise_fma(wi[g][2 * k + 1], hi, acc[g]);
+                    }
                 }
             }
+#pragma unroll
+            for (int k = 0; k < KQ / 4; ++k) {
+                const v2f lo = {hv[k].x, hv[k].y}, hi = {hv[k].z, hv[k].w};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[g] = __builtin_elementwise_fma(w[g][2 * k], lo, acc[g]);
+                    acc[g] = __builtin_elementwise_fma(w[g][2 * k + 1], hi, acc[g]);
+                }
+            }
+            const float gi = quad_sum(acc[0].x + acc[0].y), gf = quad_sum(acc[1].x + acc[1].y);
+            const float gg = quad_sum(acc[2].x + acc[2].y), go = quad_sum(acc[3].x + acc[3].y);
+            const float c = fast_sigmoid(gf) * creg[s] + fast_sigmoid(gi) * fast_tanh(gg);
+            const float h = fast_sigmoid(go) * fast_tanh(c);
+            const bool act = uvalid && step < l;
+            if (act) creg[s] = c;
+            // h_t -> the other LDS buffer (frozen state is carried over when the sequence has ended)
+            const int hidx = s * HB + (j / KQ) * QS + (j % KQ);
+            if (q == 0 && uvalid) hwr[hidx] = act ? h : hbuf[(step & 1) * S * HB + hidx];
+            const int t = dir == 0 ? step : l - 1 - step;
+            const uint32_t off = (act && q == 0) ? (uint32_t)((s * T + t) * OW + dir * H + j) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), out_rs, off, 0, 0);   // OOB lanes dropped
         }
         lds_barrier();
+    };
+
+    float preA[S], preB[S];
+    if (IP == 0) {
+        if (tmax > 0) load_gin(0, preA);
+        if (tmax > 1) load_gin(1, preB);
     }
+    int step = 0;
+    for (; step + 2 <= tmax; step += 2) {
+        do_step(step, preA);
+        do_step(step + 1, preB);
+    }
+    if (step < tmax) {
+        do_step(step, preA);
+        ++step;
+    }
+
     // zero the padded tail (pad_packed_sequence) and emit final states
+    if (q == 0 && uvalid) {
+        const float* hfin = hbuf + (step & 1) * S * HB;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int pidx = tid + r * NT;
-        if (pidx < S * KP) {
-            int s = pidx / KP, jj = pidx % KP;
-            int64_t m = m0 + s;
-            if (jj < H && m < p.M) {
-                for (int t = slen[s]; t < T; ++t) p.out[(m * T + t) * OW + (int64_t)dir * H + jj] = 0.f;
-                if (p.hn) p.hn[((int64_t)dir * p.M + m) * H + jj] = hbuf[pidx];
-                if (p.cn) p.cn[((int64_t)dir * p.M + m) * H + jj] = creg[r];
+        for (int s = 0; s < S; ++s) {
+            if (s < nvalid) {
+                const int64_t m = m0 + s;
+                for (int t = len[s]; t < T; ++t) p.out[(m * T + t) * OW + (int64_t)dir * H + j] = 0.f;
+                const int64_t si = ((int64_t)dir * p.M + m) * H + j;
+                if (p.hn) p.hn[si] = hfin[s * HB + (j / KQ) * QS + (j % KQ)];
+                if (p.cn) p.cn[si] = creg[s];
             }
         }
     }
 }
 
-template <int KP>
-static int launch_kp(const LstmArgs& p, int S, hipStream_t st) {
-    static const std::string pname = "lstm_rec_kernel<" + std::to_string(KP) + ">";
-    ProfScope ps(pname.c_str(), st);
-    dim3 block(4 * KP);
-    auto grid = [&](int s) { return dim3((unsigned)((p.M + s - 1) / s), (unsigned)p.ND); };
-    switch (S) {
-        case 1: hipLaunchKernelGGL((lstm_rec_kernel<KP, 1>), grid(1), block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((lstm_rec_kernel<KP, 2>), grid(2), block, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((lstm_rec_kernel<KP, 4>), grid(4), block, 0, st, p); break;
-        default: hipLaunchKernelGGL((lstm_rec_kernel<KP, 8>), grid(8), block, 0, st, p); break;
+template <int KP, int S, int IP>
+static int launch_one(const LstmArgs& p, hipStream_t st) {
+    static const std::string pname =
+        std::string(IP > 0 ? "lstm_rec_kernel[fused]<" : "lstm_rec_kernel<") + std::to_string(KP) + ">";
+    const size_t lds = (size_t)(2 * S * 4 * (KP / 4 + 4) + (IP > 0 ? S * p.T * IP : 0)) * 4;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_kernel<KP, S, IP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("bilstm: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
     }
+    ProfScope ps(pname.c_str(), st);
+    hipLaunchKernelGGL((lstm_rec_kernel<KP, S, IP>), dim3((unsigned)((p.M + S - 1) / S), (unsigned)p.ND), dim3(4 * KP), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fwd");
     return 0;
+}
+
+template <int KP, int IP>
+static int launch_s(const LstmArgs& p, int S, hipStream_t st) {
+    switch (S) {
+        case 1: return launch_one<KP, 1, IP>(p, st);
+        case 2: return launch_one<KP, 2, IP>(p, st);
+        case 4: return launch_one<KP, 4, IP>(p, st);
+        default:
+            if (IP > 0) return launch_one<KP, 4, IP>(p, st);   // fused variant is built for S <= 4
+            return launch_one<KP, 8, 0>(p, st);
+    }
+}
+
+template <int IP>
+static int launch_kp(const LstmArgs& p, int S, hipStream_t st) {
+    const int KP = (p.H + 15) / 16 * 16;
+    switch (KP) {
+        case 16: return launch_s<16, IP>(p, S, st);
+        case 32: return launch_s<32, IP>(p, S, st);
+        case 48: return launch_s<48, IP>(p, S, st);
+        case 64: return launch_s<64, IP>(p, S, st);
+        case 80: return launch_s<80, IP>(p, S, st);
+        case 96: return launch_s<96, IP>(p, S, st);
+        case 112: return launch_s<112, IP>(p, S, st);
+        default: return launch_s<128, IP>(p, S, st);
+    }
+}
+
+static int pick_s(int64_t seqdirs, bool fused) {
+    // sequences per workgroup: spread small batches over the 256 CUs, amortise the register-resident weights
+    // (and the per-step barrier) over more sequences for large ones
+    int S = 8;
+    if (seqdirs <= 1024) S = 1;
+    else if (seqdirs <= 2048) S = 2;
+    else if (seqdirs <= 8192) S = 4;
+    if (const char* ov = getenv("NIR_LSTM_S")) {  // tuning override
+        int v = atoi(ov);
+        if (v == 1 || v == 2 || v == 4 || v == 8) S = v;
+    }
+    if (fused && S > 4) S = 4;
+    return S;
 }
 
 int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
@@ -176,25 +318,25 @@ int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const
     NIR_REQUIRE(gin && whh && out, "bilstm: null pointer");
     NIR_REQUIRE(M >= 0 && T > 0 && (ND == 1 || ND == 2), "bilstm: bad dims M=%lld T=%d ndir=%d", (long long)M, T, ND);
     NIR_REQUIRE(H >= 1 && H <= 128, "bilstm: hidden size %d per direction unsupported (1..128)", H);
+    NIR_REQUIRE((int64_t)8 * T * ND * 4 * H * 4 < 0x7FFFFFF0LL, "bilstm: T*H too large for 32-bit tile offsets");
     if (M == 0) return 0;
-    LstmArgs p{gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND};
-    // sequences per workgroup: spread small batches over the 256 CUs, amortise W_hh for large ones
-    const int64_t seqdirs = M * ND;
-    int S = 8;
-    if (seqdirs <= 512) S = 1;
-    else if (seqdirs <= 1024) S = 2;
-    else if (seqdirs <= 4096) S = 4;
-    const int KP = (H + 15) / 16 * 16;
-    switch (KP) {
-        case 16: return launch_kp<16>(p, S, st);
-        case 32: return launch_kp<32>(p, S, st);
-        case 48: return launch_kp<48>(p, S, st);
-        case 64: return launch_kp<64>(p, S, st);
-        case 80: return launch_kp<80>(p, S, st);
-        case 96: return launch_kp<96>(p, S, st);
-        case 112: return launch_kp<112>(p, S, st);
-        default: return launch_kp<128>(p, S, st);
-    }
+    LstmArgs p{gin, nullptr, nullptr, nullptr, nullptr, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, 0};
+    return launch_kp<0>(p, pick_s(M * ND, false), st);
+}
+
+int launch_bilstm_fused(const float* x, int I, const float* wih, const float* bih, const float* bhh, const int64_t* lens,
+                        const float* whh, const float* h0, const float* c0, float* out, float* hn, float* cn, int64_t M,
+                        int T, int H, int ND, hipStream_t st) {
+    NIR_REQUIRE(x && wih && bih && bhh && whh && out, "bilstm_fused: null pointer");
+    NIR_REQUIRE(M >= 0 && T > 0 && (ND == 1 || ND == 2), "bilstm_fused: bad dims");
+    NIR_REQUIRE(H >= 1 && H <= 128 && I >= 1 && I <= 64, "bilstm_fused: H=%d (1..128) / I=%d (1..64) unsupported", H, I);
+    if (M == 0) return 0;
+    LstmArgs p{nullptr, x, wih, bih, bhh, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, I};
+    int S = pick_s(M * ND, true);
+    const int IP = I <= 48 ? 48 : 64;
+    while (S > 1 && (size_t)S * T * IP * 4 > 96 * 1024) S >>= 1;   // keep the x tile comfortably inside LDS
+    NIR_REQUIRE((size_t)S * T * IP * 4 <= 140 * 1024, "bilstm_fused: sequence length %d too long for the LDS x tile", T);
+    return IP == 48 ? launch_kp<48>(p, S, st) : launch_kp<64>(p, S, st);
 }
 
 }  // namespace nir
@@ -205,4 +347,12 @@ extern "C" int nir_bilstm_fwd(const float* gates_in, const int64_t* lengths, con
                               const float* c0, float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir,
                               nir_stream_t stream) {
     return nir::launch_bilstm(gates_in, lengths, w_hh, h0, c0, out, hn, cn, M, T, H, ndir, (hipStream_t)stream);
+}
+
+extern "C" int nir_bilstm_fused_fwd(const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
+                                    const int64_t* lengths, const float* w_hh, const float* h0, const float* c0,
+                                    float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir,
+                                    nir_stream_t stream) {
+    return nir::launch_bilstm_fused(x, I, w_ih, b_ih, b_hh, lengths, w_hh, h0, c0, out, hn, cn, M, T, H, ndir,
+                                    (hipStream_t)stream);
 }

@@ -16,144 +16,196 @@ namespace nir {
 int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
                   int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
                   int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
-int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
-                  float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st);
+int launch_bilstm_fused(const float* x, int I, const float* wih, const float* bih, const float* bhh, const int64_t* lens,
+                        const float* whh, const float* h0, const float* c0, float* out, float* hn, float* cn, int64_t M,
+                        int T, int H, int ND, hipStream_t st);
 
-constexpr int NKD = 15;  // (conv, dj) combos: 3 + 5 + 7
-constexpr int FP = 8;    // filters per conv padded 6 -> 8 (one s_load_dwordx8 per (kd,c))
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__host__ __device__ inline void kd_decode(int kd, int& k, int& dj, int& kw) {
-    if (kd < 3) { k = 0; dj = kd; kw = 3; }
-    else if (kd < 8) { k = 1; dj = kd - 3; kw = 5; }
-    else { k = 2; dj = kd - 8; kw = 7; }
-}
+constexpr int CP = 56;     // channels padded 50 -> 56 so an 8-wide K group never straddles a conv tap (dj)
+constexpr int NFC = 6;     // filters per conv (hyparam.py:101)
+constexpr int MFC = 20;    // match_filter_size
+constexpr int JT = 64;     // document positions per chunk (2 MFMA column tiles)
 
 struct MtHeadW {
     const float* conv_w[3];
     const float* conv_b[3];
     const float *alpha, *cw, *cb, *ow, *ob;
-    int C, NF, MF;
+    int C;
 };
 
-// U[b][i][kd][c][FP] = sum_di W_k[f][c][di][dj] * Pq[b][i+di-1][c]     grid B, block 256
-__global__ __launch_bounds__(256) void mt_fold_kernel(const float* pq, MtHeadW w, int QL, float* U) {
-    const int b = blockIdx.x, C = w.C, NF = w.NF;
+__host__ __device__ inline int mt_kp(int k) { return (3 + 2 * k) * CP; }          // padded K of conv k: 168, 280, 392
+__host__ __device__ inline int mt_koff(int k) { return k == 0 ? 0 : (k == 1 ? 3 * CP : 8 * CP); }
+constexpr int KTOT = 15 * CP;                                                    // 840
+
+// A operand of the interaction GEMM, folded once per query and shared by its N candidates:
+//   U[b][mt][k][r][kk],  r = i*6 + f (row inside the 32-row tile mt),  kk = dj*CP + c
+//   U = sum_di W_k[f][c][di][dj] * Pq[b][i+di-1][c]      (zero for c >= C, rows >= 6*QL)
+// grid (B, 3 convs), block 256
+__global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ pq, MtHeadW w, int QL, int MT, float* __restrict__ U) {
+    const int b = blockIdx.x, k = blockIdx.y, C = w.C;
+    const int kw = 3 + 2 * k, Kp = mt_kp(k);
     const float* pqb = pq + (int64_t)b * QL * C;
-    const int total = QL * NKD * C;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        int c = e % C, kd = (e / C) % NKD, i = e / (C * NKD);
-        int k, dj, kw;
-        kd_decode(kd, k, dj, kw);
-        float acc[FP];
+    const float* wk = w.conv_w[k];
+    const int rows = MT * 32;
+    float* ub = U + (int64_t)b * rows * KTOT;   // per query: [mt][k-slab][32][Kp] laid out as consecutive slabs
+    for (int e = threadIdx.x; e < rows * Kp; e += 256) {
+        const int r = e / Kp, kk = e - r * Kp;
+        const int dj = kk / CP, c = kk - dj * CP;
+        const int i = r / NFC, f = r - i * NFC;
+        float acc = 0.f;
+        if (c < C && i < QL) {
 #pragma unroll
-        for (int f = 0; f < FP; ++f) acc[f] = 0.f;
-        for (int di = 0; di < 3; ++di) {
-            int ii = i + di - 1;
-            if (ii < 0 || ii >= QL) continue;
-            float q = pqb[ii * C + c];
-            for (int f = 0; f < NF; ++f) acc[f] += w.conv_w[k][((f * (C + 1) + c) * 3 + di) * kw + dj] * q;
+            for (int di = 0; di < 3; ++di) {
+                const int ii = i + di - 1;
+                if (ii >= 0 && ii < QL) acc = fmaf(wk[((f * (C + 1) + c) * 3 + di) * kw + dj], pqb[ii * C + c], acc);
+            }
         }
-        float* dst = U + (((int64_t)b * QL + i) * NKD + kd) * C * FP + c * FP;
-#pragma unroll
-        for (int f = 0; f < FP; ++f) dst[f] = acc[f];
+        const int mt = r >> 5, rr = r & 31;
+        ub[(int64_t)mt * 32 * KTOT + (int64_t)mt_koff(k) * 32 + (int64_t)rr * Kp + kk] = acc;
     }
 }
 
-// one workgroup per (query, candidate) pair.  dynamic LDS: PdT[C][DLP] (zero halo of 3 each side) + dids[DL]
-template <int NF, int MF>
+// One workgroup (4 waves) per (query, candidate) pair.  Per 64-position chunk of the document:
+//   phase 1 (MFMA): for each conv k and 32-column tile, D[32 rows x 32 cols] += U[rows][kk] * Pd[j+dj-pw][c]
+//            with B read straight out of the transposed, zero-haloed LDS image PdT[c][j] (an im2col view: the K
+//            index kk = dj*CP + c only shifts the column), A streamed from L2 as one float4 per 4 MFMAs;
+//   phase 2 (VALU): one lane per (query position, doc position): + bias + exact-match taps, ReLU, 1x1 conv,
+//            running max-pool;  finally max over lanes/waves and the output Linear.
+// dynamic LDS: PdT[CP][DLP] | Y[3][MT*32][JT+1] | small weights | dids[DL]
 __global__ __launch_bounds__(256) void mt_head_kernel(const float* __restrict__ pd, const float* __restrict__ U,
                                                       const int64_t* __restrict__ q_ids, const int64_t* __restrict__ d_ids,
-                                                      MtHeadW w, int N, int QL, int DL, float* scores) {
+                                                      MtHeadW w, int N, int QL, int DL, int MT, float* __restrict__ scores) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = w.C;
-    const int DLP = DL + 6;
-    float* pdt = smem;                                    // [C][DLP]
-    int64_t* dids = (int64_t*)(smem + ((C * DLP + 1) & ~1));  // [DL] (8-byte aligned)
-    __shared__ float wmax[4][MF];
+    const int nchunk = (DL + JT - 1) / JT;
+    const int DLP = nchunk * JT + 8;               // halo: 3 left, >= 3 right (+ padding of the last chunk)
+    const int rows = MT * 32;
+    constexpr int YLD = JT + 1;
+    float* pdt = smem;                             // [CP][DLP]
+    float* Y = pdt + CP * DLP;                     // [3][rows][YLD]
+    float* wsm = Y + 3 * rows * YLD;               // cw[20*18] | cb[20] | bias[18] | wm[3 convs: 6*3*kw] (270)
+    float* cw_s = wsm;
+    float* cb_s = cw_s + MFC * 3 * NFC;
+    float* bias_s = cb_s + MFC;
+    float* wm_s = bias_s + 3 * NFC;
+    int64_t* dids = (int64_t*)(wsm + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + 1) & ~1));
+    __shared__ float wmax[4][MFC];
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t pair = blockIdx.x;
     const int b = (int)(pair / N);
 
-    for (int e = tid; e < C * DLP; e += 256) pdt[e] = 0.f;
+    for (int e = tid; e < CP * DLP; e += 256) pdt[e] = 0.f;
+    for (int e = tid; e < MFC * 3 * NFC; e += 256) cw_s[e] = w.cw[e];
+    if (tid < MFC) cb_s[tid] = w.cb[tid];
+    if (tid < 3 * NFC) bias_s[tid] = w.conv_b[tid / NFC][tid % NFC];
+    {   // exact-match channel weights alpha * W_k[f][C][di][dj] -> wm_s[k-slab][(di*kw + dj)*6 + f]
+        const float alpha = w.alpha[0];
+        for (int e = tid; e < 270; e += 256) {
+            const int k = e < 54 ? 0 : (e < 144 ? 1 : 2);
+            const int kw = 3 + 2 * k, r = e - (k == 0 ? 0 : (k == 1 ? 54 : 144));
+            const int f = r % NFC, t = r / NFC, dj = t % kw, di = t / kw;
+            wm_s[e] = alpha * w.conv_w[k][((f * (C + 1) + C) * 3 + di) * kw + dj];
+        }
+    }
     __syncthreads();
     const float* pdm = pd + pair * DL * C;
     for (int e = tid; e < DL * C; e += 256) {
-        int j = e / C, c = e - j * C;
+        const int j = e / C, c = e - j * C;
         pdt[c * DLP + j + 3] = pdm[e];
     }
     for (int j = tid; j < DL; j += 256) dids[j] = d_ids[pair * DL + j];
     __syncthreads();
 
-    float zmax[MF];
+    float zmax[MFC];
 #pragma unroll
-    for (int g = 0; g < MF; ++g) zmax[g] = -INFINITY;
-    const float alpha = w.alpha[0];
-    const int jchunks = (DL + 63) / 64;
-    const int ntask = QL * jchunks;
-    for (int task = wave; task < ntask; task += 4) {
-        const int i = __builtin_amdgcn_readfirstlane(task / jchunks);
-        const int j = (task % jchunks) * 64 + lane;
-        const bool jvalid = j < DL;
-        const int jc = jvalid ? j : 0;
-        float acc[3 * NF];
+    for (int g = 0; g < MFC; ++g) zmax[g] = -INFINITY;
+
+    const float* ub = U + (int64_t)b * rows * KTOT;
+    const int g2 = lane >> 5, col = lane & 31;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int j0 = ch * JT;
+        // ---- phase 1: tasks (conv k, row tile mt, column tile nt); heavy convs first for balance
+        const int ntask = 3 * MT * 2;
+        for (int task = wave; task < ntask; task += 4) {
+            const int k = 2 - task / (MT * 2);
+            const int rem = task % (MT * 2);
+            const int mt = rem >> 1, nt = rem & 1;
+            const int kw = 3 + 2 * k, pw = k + 1, Kp = kw * CP;
+            const float* arow = ub + (int64_t)mt * 32 * KTOT + (int64_t)mt_koff(k) * 32 + (int64_t)col * Kp + 4 * g2;
+            const float* bcol = pdt + (4 * g2) * DLP + (j0 + nt * 32 + col) - pw + 3;
+            f32x16 acc;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int dj = 0; dj < kw; ++dj) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) acc[k * NF + f] = w.conv_b[k][f];
-        // dense channels: sum over (kd, c) of U (wave-uniform) * Pd (per lane)
-        const float* ub = U + ((int64_t)b * QL + i) * NKD * C * FP;
-#pragma unroll
-        for (int kd = 0; kd < NKD; ++kd) {
-            const int k = kd < 3 ? 0 : kd < 8 ? 1 : 2;
-            const int dj = kd < 3 ? kd : kd < 8 ? kd - 3 : kd - 8;
-            const int pw = k + 1;
-            const float* pcol = pdt + (jc + dj - pw + 3);
-            const float* uk = ub + kd * C * FP;
-            for (int c = 0; c < C; ++c) {
-                float p = pcol[c * DLP];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) acc[k * NF + f] = fmaf(uk[c * FP + f], p, acc[k * NF + f]);
+                for (int c0 = 0; c0 < CP; c0 += 8) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(arow + dj * CP + c0);
+                    const float* bp = bcol + c0 * DLP + dj;
+                    const float b0 = bp[0], b1 = bp[DLP], b2 = bp[2 * DLP], b3 = bp[3 * DLP];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+                }
             }
+            float* yk = Y + ((int64_t)k * rows + mt * 32) * YLD + nt * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yk[((r & 3) + 8 * (r >> 2) + 4 * g2) * YLD] = acc[r];
         }
-        // exact-match channel (index C): alpha * [q_id == d_id], PAD==PAD counts (mtensor.py:144-158)
+        __syncthreads();
+        // ---- phase 2: positions (i, j) of this chunk
+        for (int pos = tid; pos < QL * JT; pos += 256) {
+            const int i = pos / JT, jl = pos - i * JT, j = j0 + jl;
+            float v[3 * NFC];
 #pragma unroll
-        for (int di = 0; di < 3; ++di) {
-            const int ii = i + di - 1;
-            if (ii < 0 || ii >= QL) continue;
-            const int64_t qid = q_ids[(int64_t)b * QL + ii];
+            for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int kw = 3 + 2 * k, pw = k + 1;
+                for (int f = 0; f < NFC; ++f) v[k * NFC + f] = Y[((int64_t)k * rows + i * NFC + f) * YLD + jl] + bias_s[k * NFC + f];
+            // exact-match channel: alpha * [q_id == d_id], PAD==PAD counts (mtensor.py:144-158)
 #pragma unroll
-                for (int dj = 0; dj < 7; ++dj) {
-                    if (dj >= kw) continue;
-                    const int jj = jc + dj - pw;
-                    const bool hit = jj >= 0 && jj < DL && dids[jj < 0 ? 0 : (jj >= DL ? DL - 1 : jj)] == qid;
-                    const float m = hit ? alpha : 0.f;
+            for (int di = 0; di < 3; ++di) {
+                const int ii = i + di - 1;
+                if (ii < 0 || ii >= QL) continue;
+                const int64_t qid = q_ids[(int64_t)b * QL + ii];
 #pragma unroll
-                    for (int f = 0; f < NF; ++f)
-                        acc[k * NF + f] = fmaf(w.conv_w[k][((f * (C + 1) + C) * 3 + di) * kw + dj], m, acc[k * NF + f]);
+                for (int dd = -3; dd <= 3; ++dd) {
+                    const int jj = j + dd;
+                    if (jj < 0 || jj >= DL || dids[jj] != qid) continue;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int kw = 3 + 2 * k, pw = k + 1, dj = dd + pw;
+                        if (dj < 0 || dj >= kw) continue;
+                        const float* wm = wm_s + (k == 0 ? 0 : (k == 1 ? 54 : 144)) + (di * kw + dj) * NFC;
+#pragma unroll
+                        for (int f = 0; f < NFC; ++f) v[k * NFC + f] += wm[f];
+                    }
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < 3 * NFC; ++f) v[f] = fmaxf(v[f], 0.f);
+            if (j < DL) {
+#pragma unroll
+                for (int g = 0; g < MFC; ++g) {
+                    float z = cb_s[g];
+#pragma unroll
+                    for (int f = 0; f < 3 * NFC; ++f) z = fmaf(cw_s[g * 3 * NFC + f], v[f], z);
+                    zmax[g] = fmaxf(zmax[g], z);
                 }
             }
         }
-        // ReLU -> 1x1 conv (3NF -> MF) -> running max over positions (padded positions included, E3)
-#pragma unroll
-        for (int g = 0; g < MF; ++g) {
-            float z = w.cb[g];
-#pragma unroll
-            for (int f = 0; f < 3 * NF; ++f) z = fmaf(w.cw[g * 3 * NF + f], fmaxf(acc[f], 0.f), z);
-            if (jvalid) zmax[g] = fmaxf(zmax[g], z);
-        }
+        __syncthreads();
     }
 #pragma unroll
-    for (int g = 0; g < MF; ++g) {
+    for (int g = 0; g < MFC; ++g) {
         float v = wave_max(zmax[g]);
         if (lane == 0) wmax[wave][g] = v;
     }
     __syncthreads();
     if (tid == 0) {
         float s = w.ob[0];
-        for (int g = 0; g < MF; ++g) {
+        for (int g = 0; g < MFC; ++g) {
             float v = fmaxf(fmaxf(wmax[0][g], wmax[1][g]), fmaxf(wmax[2][g], wmax[3][g]));
             s += w.ow[g] * v;
         }
@@ -161,8 +213,14 @@ __global__ __launch_bounds__(256) void mt_head_kernel(const float* __restrict__ 
     }
 }
 
+static size_t mt_head_lds(int QL, int DL, int MT) {
+    const int nchunk = (DL + JT - 1) / JT, DLP = nchunk * JT + 8;
+    size_t fl = (size_t)CP * DLP + (size_t)3 * MT * 32 * (JT + 1) + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + 1) & ~1);
+    return fl * 4 + (size_t)DL * 8;
+}
+
 struct MtPlan {
-    float *xq, *xd, *gq, *gd, *hq, *hd, *pq, *pd, *U;
+    float *xq, *xd, *hq, *hd, *pq, *pd, *U;
     size_t bytes;
 };
 
@@ -172,13 +230,11 @@ static MtPlan mt_plan(void* ws, size_t cap, int B, int N, int QL, int DL, const 
     MtPlan p;
     p.xq = a.take<float>(Mq * w->F);
     p.xd = a.take<float>(Md * w->F);
-    p.gq = a.take<float>(Mq * 8 * w->Hq);
-    p.gd = a.take<float>(Md * 8 * w->Hd);
     p.hq = a.take<float>(Mq * 2 * w->Hq);
     p.hd = a.take<float>(Md * 2 * w->Hd);
     p.pq = a.take<float>(Mq * w->C);
     p.pd = a.take<float>(Md * w->C);
-    p.U = a.take<float>(Mq * NKD * w->C * FP);
+    p.U = a.take<float>((size_t)B * ((6 * QL + 31) / 32) * 32 * KTOT);
     p.bytes = align_up(a.off, 256);
     return p;
 }
@@ -199,8 +255,10 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     hipStream_t st = (hipStream_t)stream;
     NIR_REQUIRE(q_ids && q_len && d_ids && d_len && table && w && scores, "match_tensor: null pointer");
     NIR_REQUIRE(B >= 0 && N > 0 && QL > 0 && DL > 0 && V > 0 && E > 0, "match_tensor: bad dims");
-    NIR_REQUIRE(w->NF == 6 && w->MF == 20, "match_tensor: nfilters=%d match_filter_size=%d unsupported (6, 20)", w->NF, w->MF);
+    NIR_REQUIRE(w->NF == NFC && w->MF == MFC, "match_tensor: nfilters=%d match_filter_size=%d unsupported (6, 20)", w->NF, w->MF);
+    NIR_REQUIRE(w->C >= 1 && w->C <= CP - 6, "match_tensor: nchannels=%d unsupported (<= 50)", w->C);
     NIR_REQUIRE(nir_bilstm_supported(w->Hq) && nir_bilstm_supported(w->Hd), "match_tensor: hidden size unsupported");
+    NIR_REQUIRE(w->F >= 1 && w->F <= 64, "match_tensor: featsize %d unsupported (1..64)", w->F);
     if (B == 0) return 0;
     MtPlan p = mt_plan(workspace, workspace_bytes, B, N, QL, DL, w);
     if (!workspace || p.bytes > workspace_bytes) {
@@ -215,11 +273,10 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     // step 1-2: gather + Linear(E->F) fused into the GEMM A-load (mtensor.py:76-90)
     NIR_PROPAGATE(launch_linear(nullptr, 0, q_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xq, w->F, Mq, w->F, E, NIR_ACT_NONE, st));
     NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xd, w->F, Md, w->F, E, NIR_ACT_NONE, st));
-    // step 3: BiLSTM = input GEMM (both directions at once) + recurrence (mtensor.py:92-94)
-    NIR_PROPAGATE(launch_linear(p.xq, w->F, nullptr, nullptr, 0, 0, 0, w->q_wih, w->F, w->q_bih, w->q_bhh, p.gq, 8 * w->Hq, Mq, 8 * w->Hq, w->F, NIR_ACT_NONE, st));
-    NIR_PROPAGATE(launch_linear(p.xd, w->F, nullptr, nullptr, 0, 0, 0, w->d_wih, w->F, w->d_bih, w->d_bhh, p.gd, 8 * w->Hd, Md, 8 * w->Hd, w->F, NIR_ACT_NONE, st));
-    NIR_PROPAGATE(launch_bilstm(p.gq, q_len, w->q_whh, nullptr, nullptr, hq, nullptr, nullptr, B, QL, w->Hq, 2, st));
-    NIR_PROPAGATE(launch_bilstm(p.gd, d_len, w->d_whh, nullptr, nullptr, hd, nullptr, nullptr, (int64_t)B * N, DL, w->Hd, 2, st));
+    // step 3: BiLSTM with the input projection fused into the recurrence (I = featsize = 40 <= 64): W_ih rows sit
+    // in registers next to W_hh, the x tile in LDS; the [tokens, 8H] gate tensor is never written (mtensor.py:92-94)
+    NIR_PROPAGATE(launch_bilstm_fused(p.xq, w->F, w->q_wih, w->q_bih, w->q_bhh, q_len, w->q_whh, nullptr, nullptr, hq, nullptr, nullptr, B, QL, w->Hq, 2, st));
+    NIR_PROPAGATE(launch_bilstm_fused(p.xd, w->F, w->d_wih, w->d_bih, w->d_bhh, d_len, w->d_whh, nullptr, nullptr, hd, nullptr, nullptr, (int64_t)B * N, DL, w->Hd, 2, st));
     // step 4: projections to nchannels (mtensor.py:98-110); padded positions give the bias (E3)
     NIR_PROPAGATE(launch_linear(hq, 2 * w->Hq, nullptr, nullptr, 0, 0, 0, w->qproj_w, 2 * w->Hq, w->qproj_b, nullptr, pq, w->C, Mq, w->C, 2 * w->Hq, NIR_ACT_NONE, st));
     NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
@@ -228,18 +285,26 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     hw.conv_w[0] = w->conv1_w; hw.conv_w[1] = w->conv2_w; hw.conv_w[2] = w->conv3_w;
     hw.conv_b[0] = w->conv1_b; hw.conv_b[1] = w->conv2_b; hw.conv_b[2] = w->conv3_b;
     hw.alpha = w->alpha; hw.cw = w->conv_w; hw.cb = w->conv_b; hw.ow = w->out_w; hw.ob = w->out_b;
-    hw.C = w->C; hw.NF = w->NF; hw.MF = w->MF;
+    hw.C = w->C;
+    const int MT = (NFC * QL + 31) / 32;
     {
         ProfScope ps("mt_fold_kernel", st);
-        hipLaunchKernelGGL(mt_fold_kernel, dim3(B), dim3(256), 0, st, pq, hw, QL, p.U);
+        hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3), dim3(256), 0, st, pq, hw, QL, MT, p.U);
     }
     NIR_CHECK_LAUNCH("mt_fold_kernel");
-    size_t lds = (size_t)((w->C * (DL + 6) + 1) & ~1) * 4 + (size_t)DL * 8;
-    NIR_REQUIRE(lds <= 150 * 1024, "match_tensor: doc length %d too long for the LDS-resident head (lds=%zu)", DL, lds);
+    const size_t lds = mt_head_lds(QL, DL, MT);
+    NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: QL=%d / DL=%d need %zu bytes of LDS (> 160 KiB)", QL, DL, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)mt_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("match_tensor: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
     {
         ProfScope ps("mt_head_kernel", st);
-        hipLaunchKernelGGL((mt_head_kernel<6, 20>), dim3((unsigned)((int64_t)B * N)), dim3(256), lds, st, pd, p.U, q_ids,
-                           d_ids, hw, N, QL, DL, scores);
+        hipLaunchKernelGGL(mt_head_kernel, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, st, pd, p.U, q_ids, d_ids, hw, N,
+                           QL, DL, MT, scores);
     }
     NIR_CHECK_LAUNCH("mt_head_kernel");
     return 0;

@@ -49,10 +49,7 @@ class RNNEncoder(nn.Module):
         H, ND = self.hidden, self.ndir
         wih, whh, bih, bhh = self.packed()
         x = emb.float().contiguous()
-        gates = torch.empty(M * T, ND * 4 * H, device=emb.device, dtype=torch.float32)
         st = lib.stream()
-        lib.check(L.nir_linear_f32(lib.ptr(x), I, None, None, 0, 0, 0, lib.ptr(wih), I, lib.ptr(bih), lib.ptr(bhh),
-                                   lib.ptr(gates), ND * 4 * H, M * T, ND * 4 * H, I, 0, st), "nir_linear_f32")
         out = torch.empty(M, T, ND * H, device=emb.device, dtype=torch.float32)
         hn = torch.empty(ND, M, H, device=emb.device, dtype=torch.float32)
         cn = torch.empty_like(hn)
@@ -60,6 +57,14 @@ class RNNEncoder(nn.Module):
         if init_states is not None:
             h0, c0 = (s.float().contiguous() for s in init_states)
         lens = lib.ids64(lengths) if lengths is not None else None
+        if I <= 64:   # narrow inputs: W_ih lives in registers inside the recurrence, no gate tensor
+            lib.check(L.nir_bilstm_fused_fwd(lib.ptr(x), I, lib.ptr(wih), lib.ptr(bih), lib.ptr(bhh), lib.ptr(lens),
+                                             lib.ptr(whh), lib.ptr(h0), lib.ptr(c0), lib.ptr(out), lib.ptr(hn),
+                                             lib.ptr(cn), M, T, H, ND, st), "nir_bilstm_fused_fwd")
+            return (hn, cn), out
+        gates = torch.empty(M * T, ND * 4 * H, device=emb.device, dtype=torch.float32)
+        lib.check(L.nir_linear_f32(lib.ptr(x), I, None, None, 0, 0, 0, lib.ptr(wih), I, lib.ptr(bih), lib.ptr(bhh),
+                                   lib.ptr(gates), ND * 4 * H, M * T, ND * 4 * H, I, 0, st), "nir_linear_f32")
         lib.check(L.nir_bilstm_fwd(lib.ptr(gates), lib.ptr(lens), lib.ptr(whh), lib.ptr(h0), lib.ptr(c0), lib.ptr(out),
                                    lib.ptr(hn), lib.ptr(cn), M, T, H, ND, st), "nir_bilstm_fwd")
         return (hn, cn), out

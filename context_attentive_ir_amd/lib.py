@@ -50,12 +50,14 @@ _i, _l, _z = C.c_int, C.c_int64, C.c_size_t
 SIGNATURES = {
     "nir_version": (_i, []),
     "nir_last_error_string": (C.c_char_p, []),
+    "nir_debug_clock_probe": (_i, [C.c_void_p, _i, _i, C.c_void_p, c_st]),
     "nir_profile_enable": (_i, [_i]),
     "nir_profile_report": (_i, [C.c_char_p, _z]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_rowdot_f32": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, _i, _i, c_st]),
     "nir_bilstm_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
     "nir_bilstm_supported": (_i, [_i]),
+    "nir_bilstm_fused_fwd": (_i, [c_fp, _i, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
     "nir_softmax_rows": (_i, [c_fp, c_fp, _l, _i, c_st]),
     "nir_rank_loss_bce": (_i, [c_fp, c_fp, _l, _i, c_fp, c_st]),
     "nir_rank_loss_softmax_nll": (_i, [c_fp, c_fp, _l, _i, c_fp, c_st]),

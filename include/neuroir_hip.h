@@ -39,6 +39,9 @@ const char* nir_last_error_string(void);
  * bracketed by two hipEvents recorded on its own stream.  nir_profile_report synchronises those events and
  * writes "kernel_name,launches,total_ms\n" lines (aggregated by kernel) into a HOST buffer; returns the number
  * of distinct kernels.  Must be off during graph capture. */
+/* Debug aid: out[0] = shader-clock ticks, out[1] = 100 MHz wall ticks spent by block 0 in a dependent FMA chain of
+ * `iters` steps while `blocks` workgroups run it -> effective sclk = out[0]/out[1] * 100 MHz. */
+int nir_debug_clock_probe(void* out /*device u64[2]*/, int iters, int blocks, void* sink /*device float[1]*/, nir_stream_t stream);
 int nir_profile_enable(int on);
 int nir_profile_report(char* buf /*host*/, size_t cap);
 
@@ -77,6 +80,11 @@ int nir_bilstm_fwd(const float* gates_in, const int64_t* lengths, const float* w
                    const float* c0, float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir,
                    nir_stream_t stream);
 int nir_bilstm_supported(int H);
+/* Same recurrence with the input projection fused in (input width I <= 64): x [M,T,I], w_ih [ndir*4H, I],
+ * b_ih / b_hh [ndir*4H]; the gate tensor is never materialised. */
+int nir_bilstm_fused_fwd(const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
+                         const int64_t* lengths, const float* w_hh, const float* h0, const float* c0, float* out,
+                         float* hn, float* cn, int64_t M, int T, int H, int ndir, nir_stream_t stream);
 
 /* softmax over the last dim of [rows, n] (models/ranker.py:258, models/multitask.py:279); in/out may alias. */
 int nir_softmax_rows(const float* in, float* out, int64_t rows, int n, nir_stream_t stream);
