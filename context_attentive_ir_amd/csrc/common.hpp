@@ -43,6 +43,18 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Fork/join helper: independent kernel chains of one C-ABI call (e.g. the query side and the document side of a
+// ranker) run concurrently on a lazily created per-device side stream.  Event record / wait are capturable, so the
+// whole call still records into a hipGraph.
+struct ForkJoin {
+    hipStream_t main, side;
+    hipEvent_t ev_fork, ev_join;
+    bool ok;
+    explicit ForkJoin(hipStream_t main_stream);
+    void fork();   // side waits for everything enqueued on main so far
+    void join();   // main waits for everything enqueued on side so far
+};
+
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1,6 +1,7 @@
 // Library-level entry points: version, thread-local error text.
 #include "common.hpp"
 #include <string.h>
+#include <stdlib.h>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -75,6 +76,35 @@ extern "C" int nir_profile_report(char* buf, size_t cap) {
     }
     return (int)agg.size();
 }
+
+namespace nir {
+struct SideRes { hipStream_t side = nullptr; hipEvent_t f = nullptr, j = nullptr; bool ok = false; };
+static std::mutex g_side_mu;
+static std::map<int, SideRes> g_side;
+
+ForkJoin::ForkJoin(hipStream_t main_stream) : main(main_stream), side(main_stream), ev_fork(nullptr), ev_join(nullptr), ok(false) {
+    if (getenv("NIR_NO_FORK")) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideRes& r = g_side[dev];
+    if (!r.side) {
+        r.ok = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&r.f, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&r.j, hipEventDisableTiming) == hipSuccess;
+    }
+    if (r.ok) { side = r.side; ev_fork = r.f; ev_join = r.j; ok = true; }
+}
+void ForkJoin::fork() {
+    if (!ok) return;
+    if (hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) { ok = false; side = main; }
+}
+void ForkJoin::join() {
+    if (!ok) return;
+    hipEventRecord(ev_join, side);
+    hipStreamWaitEvent(main, ev_join, 0);
+}
+}  // namespace nir
 
 // Debug: effective shader clock.  Each workgroup runs a dependent FMA chain and records s_memtime (shader clock)
 // and the constant 100 MHz wall clock at entry/exit: out[0..3] = {dclk, dwall, 0, 0} of block 0.

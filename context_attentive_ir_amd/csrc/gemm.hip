@@ -2,8 +2,8 @@
 // A-operand load.  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products/accumulation at the fp32 vector
 // rate, one VGPR per operand per lane (cdna guide section 3).
 //
-// Tiling: 256 threads = 4 waves, block tile 64(M) x 64(N) x 32(K); each wave owns a 32x32 accumulator
-// (16 VGPRs).  Operand tiles are staged in LDS k-contiguous with a +4-float row pad (row stride 36 floats):
+// Tiling: 256 threads = 4 waves, block tile 64(M) x 64(N) x 64(K); each wave owns a 32x32 accumulator
+// (16 VGPRs).  Operand tiles are staged in LDS k-contiguous with a +4-float row pad (row stride 68 floats):
 // a lane's ds_read_b128 then covers 4 consecutive k of its row and the 16-lane read groups hit 16 distinct
 // 16-byte slots (conflict-free).  The 4 floats feed 4 successive MFMAs; the k-order inside an 8-wide group
 // is permuted identically for A and W (lane>>5 selects which half), which leaves the sum unchanged.
@@ -30,55 +30,59 @@ struct GemmArgs {
     int N, K, act;
 };
 
-constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = 36;
+constexpr int BM = 64, BN = 64, BK = 64, LDS_LD = BK + 4;   // row stride 68 floats: 16-lane b128 groups hit 16 slots
+constexpr int LPT = BM * BK / 4 / 256;                        // float4 loads per thread per operand tile (4)
 
+// Software pipeline: the global loads of tile t+1 (gathered embedding rows for the A operand) are issued before the
+// MFMAs of tile t and land in the other LDS buffer afterwards -- one barrier per tile, 2 x 16 KB per block in flight.
 template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_LD];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][LDS_LD]
+    float* Ws = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int lr = tid >> 3, lk = (tid & 7) * 4;
+    const int lr = tid >> 4, lk = (tid & 15) * 4;     // 16 threads cover one 64-float row; rows lr + 16*i
 
-    // per-thread source rows (2 A rows, 2 W rows)
-    const float* arow[2];
-    int64_t aidx[2];
-    bool aval[2];
-    const float* wrow[2];
-    bool wval[2];
+    const float* arow[LPT];
+    int64_t aidx[LPT];
+    bool aval[LPT];
+    const float* wrow[LPT];
+    bool wval[LPT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int64_t m = m0 + lr + 32 * i;
+    for (int i = 0; i < LPT; ++i) {
+        int64_t m = m0 + lr + 16 * i;
         aval[i] = m < p.M;
         arow[i] = nullptr;
         aidx[i] = 0;
         if (aval[i]) {
-            if (p.ids) aidx[i] = (m / p.rows_per_seq) * p.seq_stride + (m % p.rows_per_seq);
-            else arow[i] = p.a + m * p.lda;
+            if (p.ids) {
+                aidx[i] = (m / p.rows_per_seq) * p.seq_stride + (m % p.rows_per_seq);
+                // single-segment gather (K <= E): resolve the row pointer once, not once per k-tile
+                if (p.K <= p.E) arow[i] = p.table + p.ids[aidx[i]] * (int64_t)p.E;
+            } else {
+                arow[i] = p.a + m * p.lda;
+            }
         }
-        int n = n0 + lr + 32 * i;
+        int n = n0 + lr + 16 * i;
         wval[i] = n < p.N;
         wrow[i] = p.w + (int64_t)(wval[i] ? n : 0) * p.ldw;
     }
 
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
+    float4 ra[LPT], rw[LPT];
+    auto load_tile = [&](int k0) {
         const int k = k0 + lk;
-        float4 ra[2], rw[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < LPT; ++i) {
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (VEC) {
                 if (k < p.K) {
                     if (aval[i]) {
                         const float* src;
-                        if (p.ids) {
+                        if (p.ids && p.K > p.E) {
                             int seg = k / p.E;
                             src = p.table + p.ids[aidx[i] + seg] * (int64_t)p.E + (k - seg * p.E);
                         } else {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                     int kk = k + e;
                     if (kk < p.K) {
                         if (aval[i]) {
-                            if (p.ids) {
+                            if (p.ids && p.K > p.E) {
                                 int seg = kk / p.E;
                                 ta[e] = p.table[p.ids[aidx[i] + seg] * (int64_t)p.E + (kk - seg * p.E)];
                             } else {
@@ -109,17 +113,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 rw[i] = make_float4(tw[0], tw[1], tw[2], tw[3]);
             }
         }
-        __syncthreads();  // previous tile fully consumed
+    };
+    auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<float4*>(&As[(lr + 32 * i) * LDS_LD + lk]) = ra[i];
-            *reinterpret_cast<float4*>(&Ws[(lr + 32 * i) * LDS_LD + lk]) = rw[i];
+        for (int i = 0; i < LPT; ++i) {
+            *reinterpret_cast<float4*>(&As[(buf * BM + lr + 16 * i) * LDS_LD + lk]) = ra[i];
+            *reinterpret_cast<float4*>(&Ws[(buf * BN + lr + 16 * i) * LDS_LD + lk]) = rw[i];
         }
-        __syncthreads();
-        const float* ap = &As[(wm * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4];
-        const float* bp = &Ws[(wn * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4];
+    };
+
+    f32x16 acc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);   // in flight during the MFMAs below
+        const float* ap = &As[(buf * BM + wm * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4];
+        const float* bp = &Ws[(buf * BN + wn * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4];
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
             float4 a4 = *reinterpret_cast<const float4*>(ap + q * 8);
             float4 b4 = *reinterpret_cast<const float4*>(bp + q * 8);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
@@ -127,6 +144,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
+        if (kt + 1 < nk) store_tile(buf ^ 1);        // the other buffer was last read in iteration kt-1
+        __syncthreads();
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -180,8 +199,15 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     {
         ProfScope ps(ids ? "gemm_kernel[gather]" : "gemm_kernel", st);
-        if (vec) hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, st, p);
+        constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * 4;   // 69632 B: needs the >64 KB opt-in
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        if (vec) hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), lds, st, p);
     }
     NIR_CHECK_LAUNCH("nir_linear_f32");
     return 0;

@@ -130,16 +130,17 @@ __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
         }
     }
     // initial state (h index k lives at hbuf[(k / KQ) * QS + k % KQ])
-    float creg[S];
+    float creg[(S + 3) / 4];              // c_t of the sequences this lane finalises (s = 4r + q)
     for (int e = tid; e < 2 * S * HB; e += NT) hbuf[e] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        creg[s] = 0.f;
+    for (int r = 0; r < (S + 3) / 4; ++r) {
+        creg[r] = 0.f;
+        const int s = 4 * r + q;
         if (uvalid && s < nvalid) {
             const int64_t si = ((int64_t)dir * p.M + m0 + s) * H + j;
-            if (p.c0) creg[s] = p.c0[si];
-            if (p.h0 && q == 0) hbuf[s * HB + (j / KQ) * QS + (j % KQ)] = p.h0[si];
+            if (p.c0) creg[r] = p.c0[si];
+            if (p.h0) hbuf[s * HB + (j / KQ) * QS + (j % KQ)] = p.h0[si];
         }
     }
     __syncthreads();
@@ -160,27 +161,31 @@ __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
         }
     };
 
+    // Sequences are distributed over the quad for the cell update: lane q finalises sequences s with (s & 3) == q
+    // (every lane has all gate totals after the quad reduction), so the transcendental work is not done 4x.
+    constexpr int R = (S + 3) / 4;
     auto do_step = [&](int step, float (&cur)[S]) {
-        const float* hrd = hbuf + (step & 1) * S * HB + q * QS;
+        const float* hrd = hbuf + (step & 1) * S * HB;
         float* hwr = hbuf + ((step + 1) & 1) * S * HB;
         float gin_now[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) gin_now[s] = IP > 0 ? bias : cur[s];
         if (IP == 0 && step + 2 < tmax) load_gin(step + 2, cur);   // two steps ahead
+        // ---- stage A: partial gate sums of every sequence (no LDS writes in between -> reads pipeline freely)
+        float tot[S][4];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int l = len[s];
             v2f acc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 acc[g].x = (g == q) ? gin_now[s] : 0.f;
                 acc[g].y = 0.f;
             }
-            // this lane's quarter of h_{t-1}: issue all reads, then the FMAs
             float4 hv[KQ / 4];
 #pragma unroll
-            for (int k = 0; k < KQ / 4; ++k) hv[k] = *reinterpret_cast<const float4*>(hrd + s * HB + 4 * k);
+            for (int k = 0; k < KQ / 4; ++k) hv[k] = *reinterpret_cast<const float4*>(hrd + s * HB + q * QS + 4 * k);
             if (IP > 0) {
+                const int l = len[s];
                 int t = dir == 0 ? step : l - 1 - step;
                 t = t < 0 ? 0 : (t >= T ? T - 1 : t);
                 const float* xr = xbuf + (s * T + t) * IP + q * IQ;
@@ -206,17 +211,36 @@ __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
                     acc[g] = __builtin_elementwise_fma(w[g][2 * k + 1], hi, acc[g]);
                 }
             }
-            const float gi = quad_sum(acc[0].x + acc[0].y), gf = quad_sum(acc[1].x + acc[1].y);
-            const float gg = quad_sum(acc[2].x + acc[2].y), go = quad_sum(acc[3].x + acc[3].y);
-            const float c = fast_sigmoid(gf) * creg[s] + fast_sigmoid(gi) * fast_tanh(gg);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) tot[s][g] = quad_sum(acc[g].x + acc[g].y);
+        }
+        // ---- stage B: cell update; lane q owns sequences 4r + q
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float gi = tot[4 * r][0], gf = tot[4 * r][1], gg = tot[4 * r][2], go = tot[4 * r][3];
+            int l = len[4 * r], sidx = 4 * r;
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                if (4 * r + u < S) {
+                    const bool mine = q == u;
+                    gi = mine ? tot[4 * r + u][0] : gi;
+                    gf = mine ? tot[4 * r + u][1] : gf;
+                    gg = mine ? tot[4 * r + u][2] : gg;
+                    go = mine ? tot[4 * r + u][3] : go;
+                    l = mine ? len[4 * r + u] : l;
+                    sidx = mine ? 4 * r + u : sidx;
+                }
+            }
+            const bool owner = (4 * r + q < S);            // lanes without a sequence of their own shadow seq 4r
+            const float c = fast_sigmoid(gf) * creg[r] + fast_sigmoid(gi) * fast_tanh(gg);
             const float h = fast_sigmoid(go) * fast_tanh(c);
-            const bool act = uvalid && step < l;
-            if (act) creg[s] = c;
-            // h_t -> the other LDS buffer (frozen state is carried over when the sequence has ended)
-            const int hidx = s * HB + (j / KQ) * QS + (j % KQ);
-            if (q == 0 && uvalid) hwr[hidx] = act ? h : hbuf[(step & 1) * S * HB + hidx];
+            const bool act = uvalid && owner && step < l;
+            if (act) creg[r] = c;
+            const int hidx = sidx * HB + (j / KQ) * QS + (j % KQ);
+            // h_t -> the other LDS buffer (a finished sequence carries its frozen state over)
+            if (uvalid && owner) hwr[hidx] = act ? h : hrd[hidx];
             const int t = dir == 0 ? step : l - 1 - step;
-            const uint32_t off = (act && q == 0) ? (uint32_t)((s * T + t) * OW + dir * H + j) * 4u : OOB;
+            const uint32_t off = act ? (uint32_t)((sidx * T + t) * OW + dir * H + j) * 4u : OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), out_rs, off, 0, 0);   // OOB lanes dropped
         }
         lds_barrier();
@@ -237,17 +261,21 @@ __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
         ++step;
     }
 
-    // zero the padded tail (pad_packed_sequence) and emit final states
-    if (q == 0 && uvalid) {
+    // zero the padded tail (pad_packed_sequence) and emit final states (lane q owns sequences 4r + q)
+    if (uvalid) {
         const float* hfin = hbuf + (step & 1) * S * HB;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
+        for (int r = 0; r < (S + 3) / 4; ++r) {
+            const int s = 4 * r + q;
             if (s < nvalid) {
+                int l = 0;
+#pragma unroll
+                for (int u = 0; u < S; ++u) l = (u == s) ? len[u] : l;
                 const int64_t m = m0 + s;
-                for (int t = len[s]; t < T; ++t) p.out[(m * T + t) * OW + (int64_t)dir * H + j] = 0.f;
+                for (int t = l; t < T; ++t) p.out[(m * T + t) * OW + (int64_t)dir * H + j] = 0.f;
                 const int64_t si = ((int64_t)dir * p.M + m) * H + j;
                 if (p.hn) p.hn[si] = hfin[s * HB + (j / KQ) * QS + (j % KQ)];
-                if (p.cn) p.cn[si] = creg[s];
+                if (p.cn) p.cn[si] = creg[r];
             }
         }
     }
@@ -265,6 +293,12 @@ static int launch_one(const LstmArgs& p, hipStream_t st) {
             return (int)e;
         }
     }
+    if (getenv("NIR_DEBUG")) {
+        int nb = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lstm_rec_kernel<KP, S, IP>, 4 * KP, lds);
+        fprintf(stderr, "[nir] %s S=%d: grid=%lld x %d, block=%d, lds=%zu B, max active blocks/CU=%d\n", pname.c_str(), S,
+                (long long)((p.M + S - 1) / S), p.ND, 4 * KP, lds, nb);
+    }
     ProfScope ps(pname.c_str(), st);
     hipLaunchKernelGGL((lstm_rec_kernel<KP, S, IP>), dim3((unsigned)((p.M + S - 1) / S), (unsigned)p.ND), dim3(4 * KP), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fwd");
@@ -276,6 +310,7 @@ static int launch_s(const LstmArgs& p, int S, hipStream_t st) {
     switch (S) {
         case 1: return launch_one<KP, 1, IP>(p, st);
         case 2: return launch_one<KP, 2, IP>(p, st);
+        case 3: return launch_one<KP, 3, IP>(p, st);
         case 4: return launch_one<KP, 4, IP>(p, st);
         default:
             if (IP > 0) return launch_one<KP, 4, IP>(p, st);   // fused variant is built for S <= 4
@@ -299,18 +334,27 @@ static int launch_kp(const LstmArgs& p, int S, hipStream_t st) {
 }
 
 static int pick_s(int64_t seqdirs, bool fused) {
-    // sequences per workgroup: spread small batches over the 256 CUs, amortise the register-resident weights
-    // (and the per-step barrier) over more sequences for large ones
-    int S = 8;
-    if (seqdirs <= 1024) S = 1;
-    else if (seqdirs <= 2048) S = 2;
-    else if (seqdirs <= 8192) S = 4;
+    // Sequences per workgroup.  Measured on MI355X (tools/bench_lstm.py, profiles/): one recurrence step of a
+    // workgroup costs ~(0.85 + 0.29*S) us, S == 1 fits two workgroups per CU (VGPR-limited), S > 1 one; a launch
+    // runs ceil(workgroups / resident slots) rounds.  Pick the S that minimises rounds x step cost.
+    const int cand[5] = {1, 2, 3, 4, 8};
+    int best = 1;
+    double best_cost = 1e30;
+    for (int i = 0; i < 5; ++i) {
+        const int S = cand[i];
+        if (fused && S > 4) continue;
+        const int64_t wgs = (seqdirs + S - 1) / S;
+        const int64_t slots = 256 * (S == 1 ? 2 : 1);
+        const double rounds = (double)((wgs + slots - 1) / slots);
+        const double cost = rounds * (0.85 + 0.29 * S);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+    }
     if (const char* ov = getenv("NIR_LSTM_S")) {  // tuning override
         int v = atoi(ov);
-        if (v == 1 || v == 2 || v == 4 || v == 8) S = v;
+        if (v == 1 || v == 2 || v == 3 || v == 4 || v == 8) best = v;
     }
-    if (fused && S > 4) S = 4;
-    return S;
+    if (fused && best > 4) best = 4;
+    return best;
 }
 
 int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,

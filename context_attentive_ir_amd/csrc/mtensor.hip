@@ -270,28 +270,33 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     float* hd = enc_d ? enc_d : p.hd;
     float* pq = proj_q ? proj_q : p.pq;
     float* pd = proj_d ? proj_d : p.pd;
-    // step 1-2: gather + Linear(E->F) fused into the GEMM A-load (mtensor.py:76-90)
-    NIR_PROPAGATE(launch_linear(nullptr, 0, q_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xq, w->F, Mq, w->F, E, NIR_ACT_NONE, st));
-    NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xd, w->F, Md, w->F, E, NIR_ACT_NONE, st));
-    // step 3: BiLSTM with the input projection fused into the recurrence (I = featsize = 40 <= 64): W_ih rows sit
-    // in registers next to W_hh, the x tile in LDS; the [tokens, 8H] gate tensor is never written (mtensor.py:92-94)
-    NIR_PROPAGATE(launch_bilstm_fused(p.xq, w->F, w->q_wih, w->q_bih, w->q_bhh, q_len, w->q_whh, nullptr, nullptr, hq, nullptr, nullptr, B, QL, w->Hq, 2, st));
-    NIR_PROPAGATE(launch_bilstm_fused(p.xd, w->F, w->d_wih, w->d_bih, w->d_bhh, d_len, w->d_whh, nullptr, nullptr, hd, nullptr, nullptr, (int64_t)B * N, DL, w->Hd, 2, st));
-    // step 4: projections to nchannels (mtensor.py:98-110); padded positions give the bias (E3)
-    NIR_PROPAGATE(launch_linear(hq, 2 * w->Hq, nullptr, nullptr, 0, 0, 0, w->qproj_w, 2 * w->Hq, w->qproj_b, nullptr, pq, w->C, Mq, w->C, 2 * w->Hq, NIR_ACT_NONE, st));
-    NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
-    // step 5-7: folded interaction + conv head
     MtHeadW hw;
     hw.conv_w[0] = w->conv1_w; hw.conv_w[1] = w->conv2_w; hw.conv_w[2] = w->conv3_w;
     hw.conv_b[0] = w->conv1_b; hw.conv_b[1] = w->conv2_b; hw.conv_b[2] = w->conv3_b;
     hw.alpha = w->alpha; hw.cw = w->conv_w; hw.cb = w->conv_b; hw.ow = w->out_w; hw.ob = w->out_b;
     hw.C = w->C;
     const int MT = (NFC * QL + 31) / 32;
-    {
-        ProfScope ps("mt_fold_kernel", st);
-        hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3), dim3(256), 0, st, pq, hw, QL, MT, p.U);
+    // The query chain (tiny, latency-bound) runs on a side stream concurrently with the document chain.
+    ForkJoin fj(st);
+    fj.fork();
+    {   // ---- query side: gather+projection GEMM -> BiLSTM -> channel projection -> per-query weight folding
+        hipStream_t qs = fj.side;
+        NIR_PROPAGATE(launch_linear(nullptr, 0, q_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xq, w->F, Mq, w->F, E, NIR_ACT_NONE, qs));
+        NIR_PROPAGATE(launch_bilstm_fused(p.xq, w->F, w->q_wih, w->q_bih, w->q_bhh, q_len, w->q_whh, nullptr, nullptr, hq, nullptr, nullptr, B, QL, w->Hq, 2, qs));
+        NIR_PROPAGATE(launch_linear(hq, 2 * w->Hq, nullptr, nullptr, 0, 0, 0, w->qproj_w, 2 * w->Hq, w->qproj_b, nullptr, pq, w->C, Mq, w->C, 2 * w->Hq, NIR_ACT_NONE, qs));
+        {
+            ProfScope ps("mt_fold_kernel", qs);
+            hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3), dim3(256), 0, qs, pq, hw, QL, MT, p.U);
+        }
+        NIR_CHECK_LAUNCH("mt_fold_kernel");
     }
-    NIR_CHECK_LAUNCH("mt_fold_kernel");
+    // ---- document side (mtensor.py:80-110): gather fused into the projection GEMM; the LSTM input projection
+    // (I = featsize = 40) is fused into the recurrence, so the [tokens, 8H] gate tensor is never written;
+    // padded positions of the channel projection give the bias (E3)
+    NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xd, w->F, Md, w->F, E, NIR_ACT_NONE, st));
+    NIR_PROPAGATE(launch_bilstm_fused(p.xd, w->F, w->d_wih, w->d_bih, w->d_bhh, d_len, w->d_whh, nullptr, nullptr, hd, nullptr, nullptr, (int64_t)B * N, DL, w->Hd, 2, st));
+    NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
+    fj.join();
     const size_t lds = mt_head_lds(QL, DL, MT);
     NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: QL=%d / DL=%d need %zu bytes of LDS (> 160 KiB)", QL, DL, lds);
     if (lds > 64 * 1024) {
