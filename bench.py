@@ -110,13 +110,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    local = local % torch.cuda.device_count()   # (smoke-testing N ranks on a 1-GPU box maps them all to device 0)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": flow test without RCCL (gathers through the host)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     L = lib.load()
@@ -131,7 +136,10 @@ def main():
             return model.predict(ex)["click_scores"]
         s = model.scores(ex)
         if world > 1:
-            s = sharding.gather_scores(s, args.cands * world)
+            if backend == "nccl":
+                s = sharding.gather_scores(s, args.cands * world)
+            else:
+                s = sharding.gather_scores(s.cpu(), args.cands * world).to(dev)
         out = torch.empty_like(s)
         lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
         return out
@@ -178,7 +186,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -230,7 +238,16 @@ def main():
                 gbs = by / (avg_us * 1e-6) / 1e9
                 roofline.update(bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s",
                                 frac=round(gbs / PEAK_HBM_GBS, 5), alg_bytes_per_launch=by)
-            roofline["traffic"] = None  # PMC FETCH_SIZE pass: see profiles/ (collected separately, per the guide)
+            # HBM bytes per launch from the committed PMC capture of this same workload (profiles/traffic.json:
+            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction); null when no capture matches
+            roofline["traffic"] = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                default_wl = (args.model, args.batch, args.cands, args.qlen, args.dlen) == ("match_tensor", 32, 10, 4, 64)
+                if default_wl and dom in tj["kernels"]:
+                    roofline["traffic"] = tj["kernels"][dom]["bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
             # whole-step HBM fraction BASELINE.json asks for (algorithmic bytes of SURVEY.md 8d x pairs/s)
             bpp = algorithmic_bytes_per_pair(args.cands, args.qlen, args.dlen)
             roofline["step_hbm_GBps"] = round(value / world * bpp / 1e9, 2)
