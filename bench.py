@@ -196,16 +196,17 @@ def main():
 
     # ---- profiled pass: HIP events around every kernel of the library, same workload -------------------
     roofline = None
+    import ctypes
+    nprof = max(10, min(args.steps, 50))
+    os.environ["NIR_NO_FORK"] = "1"   # time every kernel in isolation (no query/document stream overlap)
     if rank == 0:
-        import ctypes
-        nprof = max(10, min(args.steps, 50))
-        os.environ["NIR_NO_FORK"] = "1"   # time every kernel in isolation (no query/document stream overlap)
         L.nir_profile_enable(1)
-        for i in range(nprof):
-            step(i)
-        torch.cuda.synchronize()
-        L.nir_profile_enable(0)
-        os.environ.pop("NIR_NO_FORK", None)
+    for i in range(nprof):            # every rank runs the steps (the all-gather is collective); rank 0 records
+        step(i)
+    torch.cuda.synchronize()
+    L.nir_profile_enable(0)
+    os.environ.pop("NIR_NO_FORK", None)
+    if rank == 0:
         buf = ctypes.create_string_buffer(1 << 16)
         L.nir_profile_report(buf, len(buf))
         kern = {}

@@ -55,17 +55,34 @@ struct ForkJoin {
     void join();   // main waits for everything enqueued on side so far
 };
 
+// Optional device debug buffer (nir_debug_set_buffer): kernels that support it drop s_memtime stamps there.
+extern unsigned long long* g_debug_buf;
+
 constexpr int WAVE = 64;
 
+// Wave (64-lane) all-reduce without LDS traffic: two quad_perm butterflies, row_half_mirror, row_mirror (DPP, VALU
+// rate) leave every 16-lane row fully reduced; the four rows are combined through v_readlane (SGPRs).  The
+// __shfl_xor version lowers to 6 ds_bpermute round trips (~600+ cycles per value when latency-bound).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 // sigma / tanh built on the hardware exp2 (v_exp_f32, ~1 ulp) -- absolute error ~1e-7, far inside the

@@ -106,18 +106,31 @@ void ForkJoin::join() {
 }
 }  // namespace nir
 
+namespace nir { unsigned long long* g_debug_buf = nullptr; }
+extern "C" int nir_debug_set_buffer(void* dev_u64) { nir::g_debug_buf = (unsigned long long*)dev_u64; return 0; }
+
 // Debug: effective shader clock.  Each workgroup runs a dependent FMA chain and records s_memtime (shader clock)
 // and the constant 100 MHz wall clock at entry/exit: out[0..3] = {dclk, dwall, 0, 0} of block 0.
 __global__ void clock_probe_kernel(unsigned long long* out, int iters, float* sink) {
+    extern __shared__ float probe_lds[];
     unsigned long long c0 = clock64(), w0 = wall_clock64();
+    if (iters < 0) probe_lds[threadIdx.x] = 1.f;
     float a = threadIdx.x * 1e-9f, b = 1.000001f;
     for (int i = 0; i < iters; ++i) a = fmaf(a, b, 1e-7f);
     unsigned long long c1 = clock64(), w1 = wall_clock64();
     if (a == 123.456f) sink[0] = a;
     if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {   // per-block residency record: start, end (100 MHz), HW_ID
+        out[2 + 3 * blockIdx.x] = w0;
+        out[3 + 3 * blockIdx.x] = w1;
+        out[4 + 3 * blockIdx.x] = __builtin_amdgcn_s_getreg(63492);
+    }
 }
 extern "C" int nir_debug_clock_probe(void* out, int iters, int blocks, void* sink, nir_stream_t stream) {
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)out, iters, (float*)sink);
+    size_t lds = 0;
+    if (const char* e = getenv("NIR_PROBE_LDS")) lds = (size_t)atol(e);
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)clock_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (unsigned long long*)out, iters, (float*)sink);
     return (int)hipGetLastError();
 }
 

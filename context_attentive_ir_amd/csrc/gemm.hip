@@ -8,6 +8,7 @@
 // 16-byte slots (conflict-free).  The 4 floats feed 4 successive MFMAs; the k-order inside an 8-wide group
 // is permuted identically for A and W (lane>>5 selects which half), which leaves the sum unchanged.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace nir {
 
@@ -42,8 +43,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     float* Ws = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware block order (blocks are dealt round-robin to the 8 XCDs, each with its own L2): the N-blocks that
+    // share one A row-block get ids 8 apart, i.e. the same XCD back to back, so the (gathered) A rows are fetched
+    // from HBM once and re-read from that L2.
+    const int nb = (p.N + BN - 1) / BN;
+    const int64_t mb = (p.M + BM - 1) / BM;
+    const int64_t bid = blockIdx.x;
+    const int64_t tq = bid >> 3;
+    const int64_t mblk = (tq / nb) * 8 + (bid & 7);
+    if (mblk >= mb) return;
+    const int64_t m0 = mblk * BM;
+    const int n0 = (int)(tq % nb) * BN;
     const int lr = tid >> 4, lk = (tid & 15) * 4;     // 16 threads cover one 64-float row; rows lr + 16*i
 
     const float* arow[LPT];
@@ -167,6 +177,100 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Small-M path (session LSTM steps, ranknet, attention MLPs on a handful of rows): the 64x64 tiling would leave
+// most CUs idle and serialise K.  Here one workgroup owns ONE 16x16 output tile, its 4 waves split K, operands are
+// read straight from L2 as MFMA fragments (v_mfma_f32_16x16x4_f32; lane group g = lane>>4 takes k = 16q+4g..+3 for
+// both operands, one float4 per 4 MFMAs) and the 4 partial tiles are summed through LDS.
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p) {
+    __shared__ float red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t m = (int64_t)blockIdx.x * 16 + i;
+    const int n = blockIdx.y * 16 + i;
+    const bool mval = m < p.M, nval = n < p.N;
+    const float* arow = nullptr;
+    int64_t aidx = 0;
+    if (mval) {
+        if (p.ids) {
+            aidx = (m / p.rows_per_seq) * p.seq_stride + (m % p.rows_per_seq);
+            if (p.K <= p.E) arow = p.table + p.ids[aidx] * (int64_t)p.E;
+        } else {
+            arow = p.a + m * p.lda;
+        }
+    }
+    const float* wrow = p.w + (int64_t)(nval ? n : 0) * p.ldw;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nq = (p.K + 15) / 16;
+#pragma unroll 4
+    for (int q = wave; q < nq; q += 4) {
+        const int k = 16 * q + 4 * g;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (VEC) {
+            if (k < p.K) {
+                if (mval) {
+                    const float* src;
+                    if (p.ids && p.K > p.E) {
+                        int seg = k / p.E;
+                        src = p.table + p.ids[aidx + seg] * (int64_t)p.E + (k - seg * p.E);
+                    } else {
+                        src = arow + k;
+                    }
+                    a4 = *reinterpret_cast<const float4*>(src);
+                }
+                if (nval) b4 = *reinterpret_cast<const float4*>(wrow + k);
+            }
+        } else {
+            float ta[4] = {0.f, 0.f, 0.f, 0.f}, tw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int kk = k + e;
+                if (kk < p.K) {
+                    if (mval) {
+                        if (p.ids && p.K > p.E) {
+                            int seg = kk / p.E;
+                            ta[e] = p.table[p.ids[aidx + seg] * (int64_t)p.E + (kk - seg * p.E)];
+                        } else {
+                            ta[e] = arow[kk];
+                        }
+                    }
+                    if (nval) tw[e] = wrow[kk];
+                }
+            }
+            a4 = make_float4(ta[0], ta[1], ta[2], ta[3]);
+            b4 = make_float4(tw[0], tw[1], tw[2], tw[3]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+        // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
+        const int nn = blockIdx.y * 16 + (lane & 15);
+        if (nn < p.N) {
+            float bsum = 0.f;
+            if (p.bias) bsum += p.bias[nn];
+            if (p.bias2) bsum += p.bias2[nn];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t mm = (int64_t)blockIdx.x * 16 + (lane >> 4) * 4 + r;
+                if (mm < p.M) {
+                    float v = red[0][r * 64 + lane] + red[1][r * 64 + lane] + red[2][r * 64 + lane] + red[3][r * 64 + lane] + bsum;
+                    if (p.act == NIR_ACT_TANH) v = fast_tanh(v);
+                    else if (p.act == NIR_ACT_RELU) v = fmaxf(v, 0.f);
+                    p.c[mm * p.ldc + nn] = v;
+                }
+            }
+        }
+    }
+}
+
 // One wave per output row.
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* x, int64_t ldx, const float* w, const float* b,
                                                      float* out, int64_t M, int K, int act) {
@@ -196,8 +300,15 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
     bool vec = (K % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)w & 15) == 0);
     if (ids) vec = vec && (E % 4 == 0) && (((uintptr_t)table & 15) == 0);
     else vec = vec && (lda % 4 == 0) && (((uintptr_t)a & 15) == 0);
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-    {
+    const int64_t mb = (M + BM - 1) / BM;
+    const int nb = (N + BN - 1) / BN;
+    if (mb * nb < 160 && !getenv("NIR_NO_GEMM16")) {
+        // too few 64x64 tiles to fill 256 CUs: one 16x16 tile per workgroup, K split over the waves
+        ProfScope ps(ids ? "gemm16_kernel[gather]" : "gemm16_kernel", st);
+        dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
+        if (vec) hipLaunchKernelGGL(gemm16_kernel<true>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(gemm16_kernel<false>, grid, dim3(256), 0, st, p);
+    } else {
         ProfScope ps(ids ? "gemm_kernel[gather]" : "gemm_kernel", st);
         constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * 4;   // 69632 B: needs the >64 KB opt-in
         static bool attr_done = false;
@@ -206,6 +317,7 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
             hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
+        dim3 grid((unsigned)(8 * nb * ((mb + 7) / 8)));
         if (vec) hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), lds, st, p);
     }

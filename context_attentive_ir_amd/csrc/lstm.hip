@@ -59,6 +59,9 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
+// Occupancy note (measured, tools/bench_lstm.py): a second workgroup only becomes resident next to the first when the
+// kernel stays <= 168 VGPRs (3 waves/SIMD).  Forcing that budget here makes the compiler spill inside the time loop
+// (fused S=3: 109 -> 512 us), so the kernel keeps its natural ~200 VGPRs and one workgroup per CU.
 template <int KP, int S, int IP>
 __global__ __launch_bounds__(4 * KP) void lstm_rec_kernel(LstmArgs p) {
     constexpr int NT = 4 * KP;

@@ -10,6 +10,7 @@
 // wave-uniform SGPR operands, the document projections sit transposed in LDS (one lane per doc position), and
 // ReLU / 1x1 conv / global max-pool / output Linear are fused in registers + wave shuffles.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace nir {
 
@@ -32,6 +33,7 @@ struct MtHeadW {
     const float* conv_b[3];
     const float *alpha, *cw, *cb, *ow, *ob;
     int C;
+    unsigned long long* dbg;
 };
 
 __host__ __device__ inline int mt_kp(int k) { return (3 + 2 * k) * CP; }          // padded K of conv k: 168, 280, 392
@@ -43,10 +45,31 @@ constexpr int KTOT = 15 * CP;                                                   
 //   U = sum_di W_k[f][c][di][dj] * Pq[b][i+di-1][c]      (zero for c >= C, rows >= 6*QL)
 // grid (B, 3 convs), block 256
 __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ pq, MtHeadW w, int QL, int MT, float* __restrict__ U) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];   // Pq[QL][C] | W_k[NF][C+1][3][kw]
     const int b = blockIdx.x, k = blockIdx.y, C = w.C;
     const int kw = 3 + 2 * k, Kp = mt_kp(k);
-    const float* pqb = pq + (int64_t)b * QL * C;
-    const float* wk = w.conv_w[k];
+    const int nw = NFC * (C + 1) * 3 * kw;
+    float* pqs = fsm;
+    float* wks = fsm + ((QL * C + 3) & ~3);
+    {   // batched staging: all global loads of a batch are in flight before the first LDS write
+        const float* pqb = pq + (int64_t)b * QL * C;
+        const float* wk = w.conv_w[k];
+        for (int base = 0; base < nw; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * 256 + threadIdx.x;
+                v[u] = e < nw ? wk[e] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * 256 + threadIdx.x;
+                if (e < nw) wks[e] = v[u];
+            }
+        }
+        for (int e = threadIdx.x; e < QL * C; e += 256) pqs[e] = pqb[e];
+    }
+    __syncthreads();
     const int rows = MT * 32;
     float* ub = U + (int64_t)b * rows * KTOT;   // per query: [mt][k-slab][32][Kp] laid out as consecutive slabs
     for (int e = threadIdx.x; e < rows * Kp; e += 256) {
@@ -58,7 +81,7 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ 
 #pragma unroll
             for (int di = 0; di < 3; ++di) {
                 const int ii = i + di - 1;
-                if (ii >= 0 && ii < QL) acc = fmaf(wk[((f * (C + 1) + c) * 3 + di) * kw + dj], pqb[ii * C + c], acc);
+                if (ii >= 0 && ii < QL) acc = fmaf(wks[((f * (C + 1) + c) * 3 + di) * kw + dj], pqs[ii * C + c], acc);
             }
         }
         const int mt = r >> 5, rr = r & 31;
@@ -73,9 +96,9 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ 
 //   phase 2 (VALU): one lane per (query position, doc position): + bias + exact-match taps, ReLU, 1x1 conv,
 //            running max-pool;  finally max over lanes/waves and the output Linear.
 // dynamic LDS: PdT[CP][DLP] | Y[3][MT*32][JT+1] | small weights | dids[DL]
-__global__ __launch_bounds__(256) void mt_head_kernel(const float* __restrict__ pd, const float* __restrict__ U,
+__global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict__ pd, const float* __restrict__ U,
                                                       const int64_t* __restrict__ q_ids, const int64_t* __restrict__ d_ids,
-                                                      MtHeadW w, int N, int QL, int DL, int MT, float* __restrict__ scores) {
+                                                      MtHeadW w, int B, int N, int QL, int DL, int MT, float* __restrict__ scores) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = w.C;
     const int nchunk = (DL + JT - 1) / JT;
@@ -89,34 +112,87 @@ __global__ __launch_bounds__(256) void mt_head_kernel(const float* __restrict__ 
     float* cb_s = cw_s + MFC * 3 * NFC;
     float* bias_s = cb_s + MFC;
     float* wm_s = bias_s + 3 * NFC;
-    int64_t* dids = (int64_t*)(wsm + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + 1) & ~1));
+    float* ow_s = wm_s + 270;                      // output Linear weights [MFC] + bias
+    int64_t* dids = (int64_t*)(wsm + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + MFC + 2 + 1) & ~1));   // [DL]
+    int64_t* qsh = dids + DL;                                                             // [QL]
     __shared__ float wmax[4][MFC];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t pair = blockIdx.x;
-    const int b = (int)(pair / N);
+    // XCD-aware order: the N candidates of one query reuse the same folded operand U (107 KB); give them block ids
+    // 8 apart so they run on ONE XCD back to back and U is served by that L2 instead of the fabric
+    // (round-1 PMC: FETCH_SIZE 15.7 MB per launch = U re-fetched for every pair).
+    const int bid = blockIdx.x;
+    const int tq = bid >> 3;
+    const int b = (tq / N) * 8 + (bid & 7);
+    if (b >= B) return;
+    const int64_t pair = (int64_t)b * N + (tq % N);
 
-    for (int e = tid; e < CP * DLP; e += 256) pdt[e] = 0.f;
-    for (int e = tid; e < MFC * 3 * NFC; e += 256) cw_s[e] = w.cw[e];
-    if (tid < MFC) cb_s[tid] = w.cb[tid];
-    if (tid < 3 * NFC) bias_s[tid] = w.conv_b[tid / NFC][tid % NFC];
-    {   // exact-match channel weights alpha * W_k[f][C][di][dj] -> wm_s[k-slab][(di*kw + dj)*6 + f]
-        const float alpha = w.alpha[0];
-        for (int e = tid; e < 270; e += 256) {
+#define MT_STAMP(slot) do { if (w.dbg && blockIdx.x == 0 && lane == 0) w.dbg[wave * 8 + (slot)] = clock64(); } while (0)
+    MT_STAMP(0);
+    if (w.dbg && tid == 0) { w.dbg[64 + 4 * blockIdx.x] = wall_clock64(); w.dbg[64 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(63492 /*HW_REG_HW_ID, 32 bits*/); }
+    // ---- prologue: every global load is issued before anything waits on it (batched), then the LDS images are built
+    const float* pdm = pd + pair * DL * C;
+    const int npd = DL * C;
+    constexpr int PB = 8;                                  // Pd elements per thread per batch
+    float pv[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+        const int e = u * 256 + tid;
+        pv[u] = e < npd ? pdm[e] : 0.f;
+    }
+    float cwv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = u * 256 + tid;
+        cwv[u] = e < MFC * 3 * NFC ? w.cw[e] : 0.f;
+    }
+    const float cbv = tid < MFC ? w.cb[tid] : 0.f;
+    const float owv = tid < MFC ? w.ow[tid] : (tid == MFC ? w.ob[0] : 0.f);
+    const float biasv = tid < 3 * NFC ? w.conv_b[tid / NFC][tid % NFC] : 0.f;
+    float wmv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {   // exact-match channel weights W_k[f][C][di][dj] -> wm_s[k-slab][(di*kw + dj)*6 + f]
+        const int e = u * 256 + tid;
+        wmv[u] = 0.f;
+        if (e < 270) {
             const int k = e < 54 ? 0 : (e < 144 ? 1 : 2);
             const int kw = 3 + 2 * k, r = e - (k == 0 ? 0 : (k == 1 ? 54 : 144));
             const int f = r % NFC, t = r / NFC, dj = t % kw, di = t / kw;
-            wm_s[e] = alpha * w.conv_w[k][((f * (C + 1) + C) * 3 + di) * kw + dj];
+            wmv[u] = w.conv_w[k][((f * (C + 1) + C) * 3 + di) * kw + dj];
         }
     }
+    const float alpha = w.alpha[0];
+    const int64_t did0 = tid < DL ? d_ids[pair * DL + tid] : 0;
+    const int64_t qid0 = tid < QL ? q_ids[(int64_t)b * QL + tid] : 0;
+
+    for (int e = tid; e < CP * DLP; e += 256) pdt[e] = 0.f;
     __syncthreads();
-    const float* pdm = pd + pair * DL * C;
-    for (int e = tid; e < DL * C; e += 256) {
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+        const int e = u * 256 + tid;
+        if (e < npd) {
+            const int j = e / C, c = e - j * C;
+            pdt[c * DLP + j + 3] = pv[u];
+        }
+    }
+    for (int e = PB * 256 + tid; e < npd; e += 256) {      // long documents: remaining elements
         const int j = e / C, c = e - j * C;
         pdt[c * DLP + j + 3] = pdm[e];
     }
-    for (int j = tid; j < DL; j += 256) dids[j] = d_ids[pair * DL + j];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = u * 256 + tid;
+        if (e < MFC * 3 * NFC) cw_s[e] = cwv[u];
+        if (e < 270) wm_s[e] = alpha * wmv[u];
+    }
+    if (tid < MFC) cb_s[tid] = cbv;
+    if (tid <= MFC) ow_s[tid] = owv;
+    if (tid < 3 * NFC) bias_s[tid] = biasv;
+    if (tid < DL) dids[tid] = did0;
+    for (int j = 256 + tid; j < DL; j += 256) dids[j] = d_ids[pair * DL + j];
+    if (tid < QL) qsh[tid] = qid0;
     __syncthreads();
+    MT_STAMP(1);
 
     float zmax[MFC];
 #pragma unroll
@@ -138,23 +214,37 @@ __global__ __launch_bounds__(256) void mt_head_kernel(const float* __restrict__ 
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int dj = 0; dj < kw; ++dj) {
+            // A fragments (U, served by L2) are prefetched one tap ahead: 7 float4 in flight while the 28 MFMAs of
+            // the current tap run (round-1 PMC: 66 % of wave cycles were s_waitcnt on these loads).
+            constexpr int NG = CP / 8;
+            float4 an[NG];
 #pragma unroll
-                for (int c0 = 0; c0 < CP; c0 += 8) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(arow + dj * CP + c0);
-                    const float* bp = bcol + c0 * DLP + dj;
+            for (int u = 0; u < NG; ++u) an[u] = *reinterpret_cast<const float4*>(arow + u * 8);
+            for (int dj = 0; dj < kw; ++dj) {
+                float4 ac[NG];
+#pragma unroll
+                for (int u = 0; u < NG; ++u) ac[u] = an[u];
+                if (dj + 1 < kw) {
+#pragma unroll
+                    for (int u = 0; u < NG; ++u) an[u] = *reinterpret_cast<const float4*>(arow + (dj + 1) * CP + u * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < NG; ++u) {
+                    const float* bp = bcol + (u * 8) * DLP + dj;
                     const float b0 = bp[0], b1 = bp[DLP], b2 = bp[2 * DLP], b3 = bp[3 * DLP];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].x, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].y, b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].z, b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].w, b3, acc, 0, 0, 0);
                 }
             }
             float* yk = Y + ((int64_t)k * rows + mt * 32) * YLD + nt * 32 + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) yk[((r & 3) + 8 * (r >> 2) + 4 * g2) * YLD] = acc[r];
         }
+        MT_STAMP(2);
         __syncthreads();
+        MT_STAMP(3);
         // ---- phase 2: positions (i, j) of this chunk
         for (int pos = tid; pos < QL * JT; pos += 256) {
             const int i = pos / JT, jl = pos - i * JT, j = j0 + jl;
@@ -163,17 +253,18 @@ __global__ __launch_bounds__(256) void mt_head_kernel(const float* __restrict__ 
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int f = 0; f < NFC; ++f) v[k * NFC + f] = Y[((int64_t)k * rows + i * NFC + f) * YLD + jl] + bias_s[k * NFC + f];
-            // exact-match channel: alpha * [q_id == d_id], PAD==PAD counts (mtensor.py:144-158)
-#pragma unroll
+            // exact-match channel: alpha * [q_id == d_id], PAD==PAD counts (mtensor.py:144-158); hits are rare,
+            // so these loops stay rolled (keeps the kernel under 168 VGPRs -> 3 workgroups per CU)
+#pragma unroll 1
             for (int di = 0; di < 3; ++di) {
                 const int ii = i + di - 1;
                 if (ii < 0 || ii >= QL) continue;
-                const int64_t qid = q_ids[(int64_t)b * QL + ii];
-#pragma unroll
+                const int64_t qid = qsh[ii];
+#pragma unroll 1
                 for (int dd = -3; dd <= 3; ++dd) {
                     const int jj = j + dd;
                     if (jj < 0 || jj >= DL || dids[jj] != qid) continue;
-#pragma unroll
+#pragma unroll 1
                     for (int k = 0; k < 3; ++k) {
                         const int kw = 3 + 2 * k, pw = k + 1, dj = dd + pw;
                         if (dj < 0 || dj >= kw) continue;
@@ -195,6 +286,7 @@ __global__ __launch_bounds__(256) void mt_head_kernel(const float* __restrict__ 
                 }
             }
         }
+        MT_STAMP(4);
         __syncthreads();
     }
 #pragma unroll
@@ -203,20 +295,20 @@ __global__ __launch_bounds__(256) void mt_head_kernel(const float* __restrict__ 
         if (lane == 0) wmax[wave][g] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-        float s = w.ob[0];
-        for (int g = 0; g < MFC; ++g) {
-            float v = fmaxf(fmaxf(wmax[0][g], wmax[1][g]), fmaxf(wmax[2][g], wmax[3][g]));
-            s += w.ow[g] * v;
-        }
-        scores[pair] = s;
+    if (wave == 0) {   // global max over the 4 waves, then the output Linear as one wave reduction
+        float t = 0.f;
+        if (lane < MFC) t = ow_s[lane] * fmaxf(fmaxf(wmax[0][lane], wmax[1][lane]), fmaxf(wmax[2][lane], wmax[3][lane]));
+        t = wave_sum(t);
+        if (lane == 0) scores[pair] = t + ow_s[MFC];
     }
+    MT_STAMP(5);
+    if (w.dbg && tid == 0) w.dbg[64 + 4 * blockIdx.x + 1] = wall_clock64();
 }
 
 static size_t mt_head_lds(int QL, int DL, int MT) {
     const int nchunk = (DL + JT - 1) / JT, DLP = nchunk * JT + 8;
-    size_t fl = (size_t)CP * DLP + (size_t)3 * MT * 32 * (JT + 1) + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + 1) & ~1);
-    return fl * 4 + (size_t)DL * 8;
+    size_t fl = (size_t)CP * DLP + (size_t)3 * MT * 32 * (JT + 1) + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + MFC + 2 + 1) & ~1);
+    return fl * 4 + (size_t)(DL + QL) * 8;
 }
 
 struct MtPlan {
@@ -259,6 +351,7 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     NIR_REQUIRE(w->C >= 1 && w->C <= CP - 6, "match_tensor: nchannels=%d unsupported (<= 50)", w->C);
     NIR_REQUIRE(nir_bilstm_supported(w->Hq) && nir_bilstm_supported(w->Hd), "match_tensor: hidden size unsupported");
     NIR_REQUIRE(w->F >= 1 && w->F <= 64, "match_tensor: featsize %d unsupported (1..64)", w->F);
+    NIR_REQUIRE(QL <= 256, "match_tensor: query length %d > 256 unsupported", QL);
     if (B == 0) return 0;
     MtPlan p = mt_plan(workspace, workspace_bytes, B, N, QL, DL, w);
     if (!workspace || p.bytes > workspace_bytes) {
@@ -275,6 +368,7 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     hw.conv_b[0] = w->conv1_b; hw.conv_b[1] = w->conv2_b; hw.conv_b[2] = w->conv3_b;
     hw.alpha = w->alpha; hw.cw = w->conv_w; hw.cb = w->conv_b; hw.ow = w->out_w; hw.ob = w->out_b;
     hw.C = w->C;
+    hw.dbg = g_debug_buf;
     const int MT = (NFC * QL + 31) / 32;
     // The query chain (tiny, latency-bound) runs on a side stream concurrently with the document chain.
     ForkJoin fj(st);
@@ -286,7 +380,8 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
         NIR_PROPAGATE(launch_linear(hq, 2 * w->Hq, nullptr, nullptr, 0, 0, 0, w->qproj_w, 2 * w->Hq, w->qproj_b, nullptr, pq, w->C, Mq, w->C, 2 * w->Hq, NIR_ACT_NONE, qs));
         {
             ProfScope ps("mt_fold_kernel", qs);
-            hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3), dim3(256), 0, qs, pq, hw, QL, MT, p.U);
+            const size_t flds = (size_t)(((QL * w->C + 3) & ~3) + NFC * (w->C + 1) * 3 * 7) * 4;
+        hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3), dim3(256), flds, qs, pq, hw, QL, MT, p.U);
         }
         NIR_CHECK_LAUNCH("mt_fold_kernel");
     }
@@ -297,7 +392,8 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     NIR_PROPAGATE(launch_bilstm_fused(p.xd, w->F, w->d_wih, w->d_bih, w->d_bhh, d_len, w->d_whh, nullptr, nullptr, hd, nullptr, nullptr, (int64_t)B * N, DL, w->Hd, 2, st));
     NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
     fj.join();
-    const size_t lds = mt_head_lds(QL, DL, MT);
+    size_t lds = mt_head_lds(QL, DL, MT);
+    if (const char* padv = getenv("NIR_MT_LDS_PAD")) lds += (size_t)atoi(padv);   // occupancy experiment
     NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: QL=%d / DL=%d need %zu bytes of LDS (> 160 KiB)", QL, DL, lds);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)mt_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -306,10 +402,18 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
             return (int)e;
         }
     }
+    if (getenv("NIR_DEBUG")) {
+        int nb = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)mt_head_kernel, 256, lds);
+        hipFuncAttributes fa;
+        hipFuncGetAttributes(&fa, (const void*)mt_head_kernel);
+        fprintf(stderr, "[nir] mt_head_kernel: lds dyn=%zu static=%zu regs=%d maxThreads=%d -> max active blocks/CU=%d\n", lds,
+                (size_t)fa.sharedSizeBytes, fa.numRegs, fa.maxThreadsPerBlock, nb);
+    }
     {
         ProfScope ps("mt_head_kernel", st);
-        hipLaunchKernelGGL(mt_head_kernel, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, st, pd, p.U, q_ids, d_ids, hw, N,
-                           QL, DL, MT, scores);
+        hipLaunchKernelGGL(mt_head_kernel, dim3((unsigned)(8 * N * ((B + 7) / 8))), dim3(256), lds, st, pd, p.U, q_ids, d_ids, hw,
+                           B, N, QL, DL, MT, scores);
     }
     NIR_CHECK_LAUNCH("mt_head_kernel");
     return 0;

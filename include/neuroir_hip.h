@@ -42,6 +42,8 @@ const char* nir_last_error_string(void);
 /* Debug aid: out[0] = shader-clock ticks, out[1] = 100 MHz wall ticks spent by block 0 in a dependent FMA chain of
  * `iters` steps while `blocks` workgroups run it -> effective sclk = out[0]/out[1] * 100 MHz. */
 int nir_debug_clock_probe(void* out /*device u64[2]*/, int iters, int blocks, void* sink /*device float[1]*/, nir_stream_t stream);
+/* Debug aid: device buffer (>= 64 u64) that instrumented kernels fill with s_memtime stamps; NULL disables. */
+int nir_debug_set_buffer(void* dev_u64);
 int nir_profile_enable(int on);
 int nir_profile_report(char* buf /*host*/, size_t cap);
 

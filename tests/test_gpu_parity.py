@@ -32,7 +32,8 @@ def _synth(rng, B, N, QL, DL, V, full=False):
 
 
 # ------------------------------------------------------------------ building blocks
-@pytest.mark.parametrize("M,N,K,act", [(37, 40, 300, 0), (130, 50, 30, 0), (64, 64, 32, 1), (257, 301, 900, 2), (5, 1, 7, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(37, 40, 300, 0), (130, 50, 30, 0), (64, 64, 32, 1), (257, 301, 900, 2), (5, 1, 7, 0),
+                                       (16, 2048, 768, 0), (1100, 800, 260, 1), (20480, 40, 300, 0), (3000, 70, 35, 2)])
 def test_linear_dense(M, N, K, act):
     from context_attentive_ir_amd import lib
     g = torch.Generator().manual_seed(M * 1000 + N)
@@ -51,6 +52,11 @@ def test_linear_gather_conv():
     from context_attentive_ir_amd import lib
     g = torch.Generator().manual_seed(7)
     V, E, F_, nseq, L = 50, 300, 70, 5, 11
+    _gather_conv_case(lib, g, V, E, F_, nseq, L)
+    _gather_conv_case(lib, g, 500, 300, 300, 400, 40)       # large enough for the 64x64-tile kernel
+
+
+def _gather_conv_case(lib, g, V, E, F_, nseq, L):
     table = torch.randn(V, E, generator=g); ids = torch.randint(0, V, (nseq, L), generator=g)
     w = torch.randn(F_, E, 3, generator=g) / 30; b = torch.randn(F_, generator=g)
     ref = torch.nn.functional.conv1d(table[ids].transpose(1, 2), w, b).transpose(1, 2)   # [nseq, L-2, F]
