@@ -15,6 +15,10 @@ namespace nir {
 int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
                   int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
                   int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
+int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                     int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                     int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st);
+constexpr int ACT_MAXOUT2 = 16;
 int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
                   hipStream_t st);
 int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
@@ -116,42 +120,47 @@ __global__ __launch_bounds__(256) void click_pool_kernel(const float* __restrict
     }
 }
 
-// cross attention over the session states 0..t (cars.py:348-366): one workgroup per session b.
-//   logit_k = inter[k][b] . q[b]   (inter_k = W states_k + bias, cached per state)
-//   out[b]  = sum_k softmax(logit)_k * states[k][b]          -> written into xcat[b, off : off+HS]
-__global__ __launch_bounds__(256) void session_attend_kernel(const float* __restrict__ inter, const float* __restrict__ states,
-                                                             const float* __restrict__ q, int64_t qstride, int B, int nstates,
-                                                             int D, int HS, float* __restrict__ out, int64_t ostride) {
-    __shared__ float lg[64];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave; k < nstates; k += 4) {
-        float s = 0.f;
-        for (int f = lane; f < D; f += 64) s += inter[((int64_t)k * B + b) * D + f] * q[(int64_t)b * qstride + f];
-        s = wave_sum(s);
-        if (lane == 0) lg[k] = s;
+// Batched cross attention over the session states (cars.py:348-366), one workgroup per (session b, step t):
+//   logit_k = inter[k][b] . q[b,t]  for k = 0..t   (inter_k = W states_k + bias; state 0 is the zero vector)
+//   out     = sum_k softmax(logit)_k * states[k][b]
+// for both the query-session and the document-session states (both keyed by the QUERY vector, :350,361), written
+// next to q[b,t] into xcat[(b,t)] = [q ; sq ; sd], the input row of the rank() projection.
+__global__ __launch_bounds__(256) void session_attend_kernel(const float* __restrict__ interQ, const float* __restrict__ Qs,
+                                                             const float* __restrict__ interD, const float* __restrict__ Ds,
+                                                             const float* __restrict__ q, int B, int S, int D, int HS,
+                                                             float* __restrict__ xcat) {
+    __shared__ float lg[2][64];
+    const int bt = blockIdx.x, b = bt / S, t = bt % S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nstates = t + 1;
+    const float* qv = q + (int64_t)bt * D;
+    float* orow = xcat + (int64_t)bt * (D + 2 * HS);
+    for (int e = wave; e < 2 * nstates; e += 4) {
+        const int which = e / nstates, k = e % nstates;
+        const float* in = (which ? interD : interQ) + ((int64_t)k * B + b) * D;
+        float sacc = 0.f;
+        for (int f = lane; f < D; f += 64) sacc += in[f] * qv[f];
+        sacc = wave_sum(sacc);
+        if (lane == 0) lg[which][k] = sacc;
     }
+    for (int f = threadIdx.x; f < D; f += 256) orow[f] = qv[f];
     __syncthreads();
-    float mx = -INFINITY;
-    for (int k = 0; k < nstates; ++k) mx = fmaxf(mx, lg[k]);
-    float den = 0.f;
-    for (int k = 0; k < nstates; ++k) den += expf(lg[k] - mx);
-    for (int f = threadIdx.x; f < HS; f += 256) {
-        float acc = 0.f;
-        for (int k = 0; k < nstates; ++k) acc = fmaf(expf(lg[k] - mx) / den, states[((int64_t)k * B + b) * HS + f], acc);
-        out[(int64_t)b * ostride + f] = acc;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float* st = which ? Ds : Qs;
+        float mx = -INFINITY;
+        for (int k = 0; k < nstates; ++k) mx = fmaxf(mx, lg[which][k]);
+        float den = 0.f;
+        for (int k = 0; k < nstates; ++k) den += expf(lg[which][k] - mx);
+        for (int f = threadIdx.x; f < HS; f += 256) {
+            float acc = 0.f;
+            for (int k = 0; k < nstates; ++k) acc = fmaf(expf(lg[which][k] - mx) / den, st[((int64_t)k * B + b) * HS + f], acc);
+            orow[D + which * HS + f] = acc;
+        }
     }
 }
 
-// dst[r, doff : doff+n] = src[r*sstride : +n]
-__global__ void copy_cols_kernel(const float* src, int64_t sstride, float* dst, int64_t dstride, int64_t doff, int rows, int n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (int64_t)rows * n) {
-        int r = (int)(i / n), c = (int)(i % n);
-        dst[r * dstride + doff + c] = src[r * sstride + c];
-    }
-}
-
-// wcat[o, 0:K1] = w1[o,:], wcat[o, K1:K1+K2] = w2[o,:] (+ w3[o,:] if given)
+// wsum[o,k] = w1[o,k] + w2[o,k]   (W_shared + W_priv1)  and  wcat[o,:] = [wq[o,:] | wsum[o,:]]
 __global__ void concat_weights_kernel(const float* w1, int K1, const float* w2, const float* w3, int K2, int O, float* wcat) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int K = K1 + K2;
@@ -167,50 +176,27 @@ __global__ void concat_weights_kernel(const float* w1, int K1, const float* w2, 
     }
 }
 
-// feats[b*N+n] = [q', d, |q'-d|, q'*d]   (cars.py:514-518)
-__global__ void rank_feats_kernel(const float* qp, const float* docs, int64_t dstride_b, int N, int D, int rows, float* feats) {
+// feats[(b,t,n)] = [q', d, |q'-d|, q'*d]   (cars.py:514-518); q' row = (b,t), d row = (b,t,n)
+__global__ void rank_feats_kernel(const float* qp, const float* docs, int N, int D, int64_t rows, float* feats) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (int64_t)rows * D) {
-        int r = (int)(i / D), f = (int)(i % D);
-        int b = r / N, n = r % N;
-        float q = qp[(int64_t)b * D + f], d = docs[(int64_t)b * dstride_b + (int64_t)n * D + f];
-        float* o = feats + (int64_t)r * 4 * D;
+    if (i < rows * D) {
+        int64_t r = i / D;
+        int f = (int)(i % D);
+        float q = qp[(r / N) * D + f], d = docs[r * D + f];
+        float* o = feats + r * 4 * D;
         o[f] = q; o[D + f] = d; o[2 * D + f] = fabsf(q - d); o[3 * D + f] = q * d;
     }
 }
 
-// y[r, o] = max_p z[r, o*pool + p]   (maxout.py:77-81)
-__global__ void maxout_kernel(const float* z, int rows, int O, int pool, float* y, int64_t ystride) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (int64_t)rows * O) {
-        int r = (int)(i / O), o = (int)(i % O);
-        float m = -INFINITY;
-        for (int p = 0; p < pool; ++p) m = fmaxf(m, z[((int64_t)r * O + o) * pool + p]);
-        y[r * ystride + o] = m;
-    }
-}
-
-// LSTM cell on pre-computed gates [B,4HS] (i,f,g,o): updates c in place, writes h to hout (states list) and
-// into the [x ; h] concat buffer used by the next step's gate GEMM.
-__global__ void lstm_cell_kernel(const float* gates, float* c, float* hout, float* xh, int64_t xhstride, int64_t xhoff, int B, int HS) {
+// LSTM cell on gate pre-activations [B,4HS] (i,f,g,o) laid out with row stride gstride: updates c in place, writes h.
+__global__ void lstm_cell_kernel(const float* gates, int64_t gstride, float* c, float* hout, int B, int HS) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (int64_t)B * HS) {
         int b = (int)(i / HS), j = (int)(i % HS);
-        const float* g = gates + (int64_t)b * 4 * HS;
+        const float* g = gates + (int64_t)b * gstride;
         float cc = fast_sigmoid(g[HS + j]) * c[i] + fast_sigmoid(g[j]) * fast_tanh(g[2 * HS + j]);
-        float h = fast_sigmoid(g[3 * HS + j]) * fast_tanh(cc);
         c[i] = cc;
-        hout[i] = h;
-        xh[b * xhstride + xhoff + j] = h;
-    }
-}
-
-// click_scores[b][t][n] = max(z2[b*N+n][0], z2[b*N+n][1])   (last maxout layer: 2 -> 1)
-__global__ void final_score_kernel(const float* z2, int B, int N, int S, int t, float* click_scores) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B * N) {
-        int b = i / N, n = i % N;
-        click_scores[((int64_t)b * S + t) * N + n] = fmaxf(z2[2 * i], z2[2 * i + 1]);
+        hout[i] = fast_sigmoid(g[3 * HS + j]) * fast_tanh(cc);
     }
 }
 
@@ -218,45 +204,35 @@ __global__ void fill_kernel(float* p, float v, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-// dst[r, :] = bias   (inter of the zero state = bias of the attention Linear)
-__global__ void bias_rows_kernel(const float* bias, float* dst, int rows, int D) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (int64_t)rows * D) dst[i] = bias[i % D];
-}
 
 struct SessPlan {
-    float *a1, *e, *clicks, *Qs, *Ds, *interQ, *interD, *xcat, *wrank, *wq_lstm, *wd_lstm, *xhq, *xhd, *cq, *cd, *gates;
-    float *qp, *feats, *z0, *y0, *z1, *y1, *z2;
+    float *a1, *e, *clicks, *Qs, *Ds, *interQ, *interD, *gxq, *gxd, *gates_q, *gates_d, *cq, *cd, *xcat, *wrank, *qp, *feats, *y0, *y1;
     int* m;
     size_t bytes;
 };
 static SessPlan sess_plan(void* ws, size_t cap, int B, int S, int N, int D, int HS) {
     Workspace a(ws, cap);
     SessPlan p;
-    const size_t R = (size_t)B * S * N;
+    const size_t R = (size_t)B * S * N, BS = (size_t)B * S;
     p.a1 = a.take<float>(R * D);
     p.e = a.take<float>(R);
-    p.clicks = a.take<float>((size_t)B * S * D);
-    p.Qs = a.take<float>((size_t)(S + 1) * B * HS);
-    p.Ds = a.take<float>((size_t)(S + 1) * B * HS);
-    p.interQ = a.take<float>((size_t)(S + 1) * B * D);
-    p.interD = a.take<float>((size_t)(S + 1) * B * D);
-    p.xcat = a.take<float>((size_t)B * (D + 2 * HS));
-    p.wrank = a.take<float>((size_t)D * (D + 2 * HS));
-    p.wq_lstm = a.take<float>((size_t)4 * HS * (D + HS));
-    p.wd_lstm = a.take<float>((size_t)4 * HS * (D + HS));
-    p.xhq = a.take<float>((size_t)B * (D + HS));
-    p.xhd = a.take<float>((size_t)B * (D + HS));
+    p.clicks = a.take<float>(BS * D);
+    p.Qs = a.take<float>((size_t)S * B * HS);            // states 0..S-1 (state 0 = zeros)
+    p.Ds = a.take<float>((size_t)S * B * HS);
+    p.interQ = a.take<float>((size_t)S * B * D);
+    p.interD = a.take<float>((size_t)S * B * D);
+    p.gxq = a.take<float>(BS * 4 * HS);                  // x W_ih^T + b_ih + b_hh for every (b,t)
+    p.gxd = a.take<float>(BS * 4 * HS);
+    p.gates_q = a.take<float>((size_t)B * 4 * HS);
+    p.gates_d = a.take<float>((size_t)B * 4 * HS);
     p.cq = a.take<float>((size_t)B * HS);
     p.cd = a.take<float>((size_t)B * HS);
-    p.gates = a.take<float>((size_t)B * 4 * HS);
-    p.qp = a.take<float>((size_t)B * D);
-    p.feats = a.take<float>((size_t)B * N * 4 * D);
-    p.z0 = a.take<float>((size_t)B * N * 512);
-    p.y0 = a.take<float>((size_t)B * N * 256);
-    p.z1 = a.take<float>((size_t)B * N * 256);
-    p.y1 = a.take<float>((size_t)B * N * 128);
-    p.z2 = a.take<float>((size_t)B * N * 2);
+    p.xcat = a.take<float>(BS * (D + 2 * HS));
+    p.wrank = a.take<float>((size_t)D * (D + 2 * HS));
+    p.qp = a.take<float>(BS * D);
+    p.feats = a.take<float>(R * 4 * D);
+    p.y0 = a.take<float>(R * 256);
+    p.y1 = a.take<float>(R * 128);
     p.m = a.take<int>(4);
     p.bytes = align_up(a.off, 256);
     return p;
@@ -312,7 +288,7 @@ extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_
     NIR_REQUIRE(pooled_q && pooled_docs && labels && w && click_scores, "cars_rank_session: null pointer");
     NIR_REQUIRE(B >= 0 && S > 0 && N > 0, "cars_rank_session: bad dims");
     NIR_REQUIRE(N <= 64, "cars_rank_session: %d candidates > 64 unsupported", N);
-    NIR_REQUIRE(S + 1 <= 64, "cars_rank_session: session length %d > 63 unsupported", S);
+    NIR_REQUIRE(S <= 64, "cars_rank_session: session length %d > 64 unsupported", S);
     NIR_REQUIRE(w->D % 4 == 0 && w->HS % 4 == 0, "cars_rank_session: D/HS must be multiples of 4");
     if (B == 0) return 0;
     const int D = w->D, HS = w->HS;
@@ -321,60 +297,65 @@ extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_
         set_error("cars_rank_session: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
         return NIR_ERR_WORKSPACE;
     }
-    const int rows = B * S;
-    const int64_t R = (int64_t)rows * N;
+    const int64_t BS = (int64_t)B * S, R = BS * N;
     float* clicks = clicks_out ? clicks_out : p.clicks;
     ProfScope ps_all("cars_rank_session[all kernels]", st);
-    // ---- encode_clicks (cars.py:262-304)
+    // The session states depend only on the queries and the clicks, never on the rank outputs, so the two session
+    // LSTM chains run first (x projections batched over all steps; the chains run concurrently on two streams) and
+    // attention + ranknet are then evaluated ONCE for all (session, step) pairs instead of once per step.
+    ForkJoin fj(st);
+    fj.fork();
+    {   // ---- query-session chain (side stream): Qs[t+1] = LSTM(q_t), t = 0..S-2   (cars.py:378-380)
+        hipStream_t qs = fj.side;
+        NIR_PROPAGATE(launch_linear(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->sq_wih, D, w->sq_bih, w->sq_bhh, p.gxq, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE, qs));
+        hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, qs, p.Qs, 0.f, (int64_t)B * HS);   // state 0 = zeros
+        hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, qs, p.cq, 0.f, (int64_t)B * HS);
+        for (int t = 0; t + 1 < S; ++t) {
+            const float* gates = p.gxq + (int64_t)t * 4 * HS;      // row b at stride S*4HS
+            int64_t gstride = (int64_t)S * 4 * HS;
+            if (t > 0) {   // h_0 = 0: the first step needs no recurrent GEMM
+                NIR_PROPAGATE(launch_linear_ex(p.Qs + (int64_t)t * B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sq_whh, HS, nullptr, nullptr, p.gates_q, 4 * HS, B, 4 * HS, HS, NIR_ACT_NONE, gates, gstride, qs));
+                gates = p.gates_q;
+                gstride = 4 * HS;
+            }
+            hipLaunchKernelGGL(lstm_cell_kernel, g1((int64_t)B * HS), dim3(256), 0, qs, gates, gstride, p.cq, p.Qs + (int64_t)(t + 1) * B * HS, B, HS);
+        }
+        NIR_CHECK_LAUNCH("session query LSTM");
+        NIR_PROPAGATE(launch_linear(p.Qs, HS, nullptr, nullptr, 0, 0, 0, w->sq_attn_w, HS, w->sq_attn_b, nullptr, p.interQ, D, (int64_t)S * B, D, HS, NIR_ACT_NONE, qs));
+    }
+    // ---- document-session chain (main stream): encode_clicks (cars.py:262-304), then Ds[t+1] = LSTM(clicks_t)
     NIR_PROPAGATE(launch_linear(pooled_docs, D, nullptr, nullptr, 0, 0, 0, w->click0_w, D, w->click0_b, nullptr, p.a1, D, R, D, D, NIR_ACT_TANH, st));
     NIR_PROPAGATE(launch_rowdot(p.a1, D, w->click3_w, w->click3_b, p.e, R, D, NIR_ACT_NONE, st));
-    hipLaunchKernelGGL(click_maxcount_kernel, dim3(1), dim3(256), 0, st, labels, rows, N, p.m);
-    hipLaunchKernelGGL(click_pool_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, pooled_docs, p.e, labels, p.m, rows, N, D, clicks);
+    hipLaunchKernelGGL(click_maxcount_kernel, dim3(1), dim3(256), 0, st, labels, (int)BS, N, p.m);
+    hipLaunchKernelGGL(click_pool_kernel, dim3((unsigned)((BS + 3) / 4)), dim3(256), 0, st, pooled_docs, p.e, labels, p.m, (int)BS, N, D, clicks);
     NIR_CHECK_LAUNCH("click_pool_kernel");
-    // ---- one-time setup of the session loop
-    const int KR = D + 2 * HS, KL = D + HS;
-    hipLaunchKernelGGL(concat_weights_kernel, g1((int64_t)D * KR), dim3(256), 0, st, w->qproj_w, D, w->shared_w, w->priv1_w, 2 * HS, D, p.wrank);
-    hipLaunchKernelGGL(concat_weights_kernel, g1((int64_t)4 * HS * KL), dim3(256), 0, st, w->sq_wih, D, w->sq_whh, (const float*)nullptr, HS, 4 * HS, p.wq_lstm);
-    hipLaunchKernelGGL(concat_weights_kernel, g1((int64_t)4 * HS * KL), dim3(256), 0, st, w->sd_wih, D, w->sd_whh, (const float*)nullptr, HS, 4 * HS, p.wd_lstm);
-    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.Qs, 0.f, (int64_t)B * HS);   // state 0 = zeros
+    NIR_PROPAGATE(launch_linear(clicks, D, nullptr, nullptr, 0, 0, 0, w->sd_wih, D, w->sd_bih, w->sd_bhh, p.gxd, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE, st));
     hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.Ds, 0.f, (int64_t)B * HS);
-    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.cq, 0.f, (int64_t)B * HS);
     hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.cd, 0.f, (int64_t)B * HS);
-    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * KL), dim3(256), 0, st, p.xhq, 0.f, (int64_t)B * KL);  // h_0 = 0
-    hipLaunchKernelGGL(fill_kernel, g1((int64_t)B * KL), dim3(256), 0, st, p.xhd, 0.f, (int64_t)B * KL);
-    hipLaunchKernelGGL(bias_rows_kernel, g1((int64_t)B * D), dim3(256), 0, st, w->sq_attn_b, p.interQ, B, D);  // W*0 + b
-    hipLaunchKernelGGL(bias_rows_kernel, g1((int64_t)B * D), dim3(256), 0, st, w->sd_attn_b, p.interD, B, D);
-    NIR_CHECK_LAUNCH("cars session setup");
-    const int64_t qstride = (int64_t)S * D;            // pooled_q[b, t, :]
-    const int64_t dstride_b = (int64_t)S * N * D;      // pooled_docs[b, t, :, :]
-    for (int t = 0; t < S; ++t) {
-        const float* qt = pooled_q + (int64_t)t * D;
-        // xcat = [q_t ; attend(Q) ; attend(D)]  (both attentions are keyed by the QUERY vector, cars.py:350,361)
-        hipLaunchKernelGGL(copy_cols_kernel, g1((int64_t)B * D), dim3(256), 0, st, qt, qstride, p.xcat, (int64_t)KR, (int64_t)0, B, D);
-        hipLaunchKernelGGL(session_attend_kernel, dim3(B), dim3(256), 0, st, p.interQ, p.Qs, qt, qstride, B, t + 1, D, HS, p.xcat + D, (int64_t)KR);
-        hipLaunchKernelGGL(session_attend_kernel, dim3(B), dim3(256), 0, st, p.interD, p.Ds, qt, qstride, B, t + 1, D, HS, p.xcat + D + HS, (int64_t)KR);
-        NIR_CHECK_LAUNCH("session_attend_kernel");
-        // rank (cars.py:460-520): q' = W_q q + b + (W_shared + W_priv1)[sq;sd]; feats; maxout 1024->256->128->1
-        NIR_PROPAGATE(launch_linear(p.xcat, KR, nullptr, nullptr, 0, 0, 0, p.wrank, KR, w->qproj_b, nullptr, p.qp, D, B, D, KR, NIR_ACT_NONE, st));
-        hipLaunchKernelGGL(rank_feats_kernel, g1((int64_t)B * N * D), dim3(256), 0, st, p.qp, pooled_docs + (int64_t)t * N * D, dstride_b, N, D, B * N, p.feats);
-        NIR_PROPAGATE(launch_linear(p.feats, 4 * D, nullptr, nullptr, 0, 0, 0, w->mo0_w, 4 * D, w->mo0_b, nullptr, p.z0, 512, (int64_t)B * N, 512, 4 * D, NIR_ACT_NONE, st));
-        hipLaunchKernelGGL(maxout_kernel, g1((int64_t)B * N * 256), dim3(256), 0, st, p.z0, B * N, 256, 2, p.y0, (int64_t)256);
-        NIR_PROPAGATE(launch_linear(p.y0, 256, nullptr, nullptr, 0, 0, 0, w->mo1_w, 256, w->mo1_b, nullptr, p.z1, 256, (int64_t)B * N, 256, 256, NIR_ACT_NONE, st));
-        hipLaunchKernelGGL(maxout_kernel, g1((int64_t)B * N * 128), dim3(256), 0, st, p.z1, B * N, 128, 2, p.y1, (int64_t)128);
-        NIR_PROPAGATE(launch_linear(p.y1, 128, nullptr, nullptr, 0, 0, 0, w->mo2_w, 128, w->mo2_b, nullptr, p.z2, 2, (int64_t)B * N, 2, 128, NIR_ACT_NONE, st));
-        hipLaunchKernelGGL(final_score_kernel, g1((int64_t)B * N), dim3(256), 0, st, p.z2, B, N, S, t, click_scores);
-        NIR_CHECK_LAUNCH("ranknet");
-        if (t + 1 == S) break;  // the states after the last query are only used by the suggestion decoder
-        // session LSTM steps (cars.py:378-380, 400-402): x = q_t / clicks_t, carried (h,c)
-        hipLaunchKernelGGL(copy_cols_kernel, g1((int64_t)B * D), dim3(256), 0, st, qt, qstride, p.xhq, (int64_t)KL, (int64_t)0, B, D);
-        NIR_PROPAGATE(launch_linear(p.xhq, KL, nullptr, nullptr, 0, 0, 0, p.wq_lstm, KL, w->sq_bih, w->sq_bhh, p.gates, 4 * HS, B, 4 * HS, KL, NIR_ACT_NONE, st));
-        hipLaunchKernelGGL(lstm_cell_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.gates, p.cq, p.Qs + (int64_t)(t + 1) * B * HS, p.xhq, (int64_t)KL, (int64_t)D, B, HS);
-        NIR_PROPAGATE(launch_linear(p.Qs + (int64_t)(t + 1) * B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sq_attn_w, HS, w->sq_attn_b, nullptr, p.interQ + (int64_t)(t + 1) * B * D, D, B, D, HS, NIR_ACT_NONE, st));
-        hipLaunchKernelGGL(copy_cols_kernel, g1((int64_t)B * D), dim3(256), 0, st, clicks + (int64_t)t * D, qstride, p.xhd, (int64_t)KL, (int64_t)0, B, D);
-        NIR_PROPAGATE(launch_linear(p.xhd, KL, nullptr, nullptr, 0, 0, 0, p.wd_lstm, KL, w->sd_bih, w->sd_bhh, p.gates, 4 * HS, B, 4 * HS, KL, NIR_ACT_NONE, st));
-        hipLaunchKernelGGL(lstm_cell_kernel, g1((int64_t)B * HS), dim3(256), 0, st, p.gates, p.cd, p.Ds + (int64_t)(t + 1) * B * HS, p.xhd, (int64_t)KL, (int64_t)D, B, HS);
-        NIR_PROPAGATE(launch_linear(p.Ds + (int64_t)(t + 1) * B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sd_attn_w, HS, w->sd_attn_b, nullptr, p.interD + (int64_t)(t + 1) * B * D, D, B, D, HS, NIR_ACT_NONE, st));
-        NIR_CHECK_LAUNCH("session lstm step");
+    for (int t = 0; t + 1 < S; ++t) {
+        const float* gates = p.gxd + (int64_t)t * 4 * HS;
+        int64_t gstride = (int64_t)S * 4 * HS;
+        if (t > 0) {
+            NIR_PROPAGATE(launch_linear_ex(p.Ds + (int64_t)t * B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sd_whh, HS, nullptr, nullptr, p.gates_d, 4 * HS, B, 4 * HS, HS, NIR_ACT_NONE, gates, gstride, st));
+            gates = p.gates_d;
+            gstride = 4 * HS;
+        }
+        hipLaunchKernelGGL(lstm_cell_kernel, g1((int64_t)B * HS), dim3(256), 0, st, gates, gstride, p.cd, p.Ds + (int64_t)(t + 1) * B * HS, B, HS);
     }
+    NIR_CHECK_LAUNCH("session doc LSTM");
+    NIR_PROPAGATE(launch_linear(p.Ds, HS, nullptr, nullptr, 0, 0, 0, w->sd_attn_w, HS, w->sd_attn_b, nullptr, p.interD, D, (int64_t)S * B, D, HS, NIR_ACT_NONE, st));
+    const int KR = D + 2 * HS;
+    hipLaunchKernelGGL(concat_weights_kernel, g1((int64_t)D * KR), dim3(256), 0, st, w->qproj_w, D, w->shared_w, w->priv1_w, 2 * HS, D, p.wrank);
+    fj.join();
+    // ---- batched over all (b,t): cross attention (incl. the zero state), rank projection, ranknet (cars.py:348-366,460-520)
+    hipLaunchKernelGGL(session_attend_kernel, dim3((unsigned)BS), dim3(256), 0, st, p.interQ, p.Qs, p.interD, p.Ds, pooled_q, B, S, D, HS, p.xcat);
+    NIR_CHECK_LAUNCH("session_attend_kernel");
+    NIR_PROPAGATE(launch_linear(p.xcat, KR, nullptr, nullptr, 0, 0, 0, p.wrank, KR, w->qproj_b, nullptr, p.qp, D, BS, D, KR, NIR_ACT_NONE, st));
+    hipLaunchKernelGGL(rank_feats_kernel, g1(R * D), dim3(256), 0, st, p.qp, pooled_docs, N, D, R, p.feats);
+    NIR_CHECK_LAUNCH("rank_feats_kernel");
+    // maxout 1024 -> 256 -> 128 -> 1 (pool 2): the pairwise max is fused into the GEMM epilogues
+    NIR_PROPAGATE(launch_linear_ex(p.feats, 4 * D, nullptr, nullptr, 0, 0, 0, w->mo0_w, 4 * D, w->mo0_b, nullptr, p.y0, 256, R, 512, 4 * D, ACT_MAXOUT2, nullptr, 0, st));
+    NIR_PROPAGATE(launch_linear_ex(p.y0, 256, nullptr, nullptr, 0, 0, 0, w->mo1_w, 256, w->mo1_b, nullptr, p.y1, 128, R, 256, 256, ACT_MAXOUT2, nullptr, 0, st));
+    NIR_PROPAGATE(launch_linear_ex(p.y1, 128, nullptr, nullptr, 0, 0, 0, w->mo2_w, 128, w->mo2_b, nullptr, click_scores, 1, R, 2, 128, ACT_MAXOUT2, nullptr, 0, st));
     return 0;
 }

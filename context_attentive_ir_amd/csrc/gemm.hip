@@ -29,7 +29,26 @@ struct GemmArgs {
     int64_t ldc;
     int64_t M;
     int N, K, act;
+    const float* add;    // optional addend [M, ldadd] added before the activation (e.g. precomputed x W_ih^T)
+    int64_t ldadd;
 };
+
+constexpr int ACT_MAXOUT2 = 16;   // internal: out[m, n/2] = max(v[m,n], v[m,n+1])  (maxout pool 2, maxout.py:77-81)
+
+// epilogue shared by both kernels: bias / addend / activation / optional pairwise maxout over adjacent columns
+__device__ __forceinline__ void gemm_store(const GemmArgs& p, int64_t m, int n, float v, float bsum) {
+    v += bsum;
+    if (p.add && m < p.M && n < p.N) v += p.add[m * p.ldadd + n];
+    if (p.act == NIR_ACT_TANH) v = fast_tanh(v);
+    else if (p.act == NIR_ACT_RELU) v = fmaxf(v, 0.f);
+    if (p.act == ACT_MAXOUT2) {
+        const float other = dpp_mov<0xB1>(v);          // partner column = adjacent lane (quad_perm [1,0,3,2])
+        v = fmaxf(v, other);
+        if (m < p.M && n < p.N && !(n & 1)) p.c[m * p.ldc + (n >> 1)] = v;
+    } else if (m < p.M && n < p.N) {
+        p.c[m * p.ldc + n] = v;
+    }
+}
 
 constexpr int BM = 64, BN = 64, BK = 64, LDS_LD = BK + 4;   // row stride 68 floats: 16-lane b128 groups hit 16 slots
 constexpr int LPT = BM * BK / 4 / 256;                        // float4 loads per thread per operand tile (4)
@@ -160,20 +179,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int n = n0 + wn * 32 + (lane & 31);
+    float bsum = 0.f;
     if (n < p.N) {
-        float bsum = 0.f;
         if (p.bias) bsum += p.bias[n];
         if (p.bias2) bsum += p.bias2[n];
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < p.M) {
-                float v = acc[r] + bsum;
-                if (p.act == NIR_ACT_TANH) v = fast_tanh(v);
-                else if (p.act == NIR_ACT_RELU) v = fmaxf(v, 0.f);
-                p.c[m * p.ldc + n] = v;
-            }
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        gemm_store(p, m, n, acc[r], bsum);
     }
 }
 
@@ -253,20 +267,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p) {
     if (wave == 0) {
         // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
         const int nn = blockIdx.y * 16 + (lane & 15);
+        float bsum = 0.f;
         if (nn < p.N) {
-            float bsum = 0.f;
             if (p.bias) bsum += p.bias[nn];
             if (p.bias2) bsum += p.bias2[nn];
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t mm = (int64_t)blockIdx.x * 16 + (lane >> 4) * 4 + r;
-                if (mm < p.M) {
-                    float v = red[0][r * 64 + lane] + red[1][r * 64 + lane] + red[2][r * 64 + lane] + red[3][r * 64 + lane] + bsum;
-                    if (p.act == NIR_ACT_TANH) v = fast_tanh(v);
-                    else if (p.act == NIR_ACT_RELU) v = fmaxf(v, 0.f);
-                    p.c[mm * p.ldc + nn] = v;
-                }
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int64_t mm = (int64_t)blockIdx.x * 16 + (lane >> 4) * 4 + r;
+            const float v = red[0][r * 64 + lane] + red[1][r * 64 + lane] + red[2][r * 64 + lane] + red[3][r * 64 + lane];
+            gemm_store(p, mm, nn, v, bsum);
         }
     }
 }
@@ -289,14 +299,15 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* x, int64_t ldx
     }
 }
 
-int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
-                  int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
-                  int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st) {
+int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                     int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                     int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st) {
     NIR_REQUIRE(M >= 0 && N > 0 && K > 0, "linear: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
     NIR_REQUIRE(w && c, "linear: null weight/output");
     NIR_REQUIRE(ids ? (table != nullptr && E > 0 && rows_per_seq > 0) : (a != nullptr), "linear: null A operand");
     if (M == 0) return 0;
-    GemmArgs p{a, lda, ids, table, E, rows_per_seq, seq_stride, w, ldw, bias, bias2, c, ldc, M, N, K, act};
+    NIR_REQUIRE(act != ACT_MAXOUT2 || (N % 2 == 0), "linear: maxout epilogue needs an even N");
+    GemmArgs p{a, lda, ids, table, E, rows_per_seq, seq_stride, w, ldw, bias, bias2, c, ldc, M, N, K, act, add, ldadd};
     bool vec = (K % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)w & 15) == 0);
     if (ids) vec = vec && (E % 4 == 0) && (((uintptr_t)table & 15) == 0);
     else vec = vec && (lda % 4 == 0) && (((uintptr_t)a & 15) == 0);
@@ -323,6 +334,13 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
     }
     NIR_CHECK_LAUNCH("nir_linear_f32");
     return 0;
+}
+
+int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                  int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                  int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st) {
+    return launch_linear_ex(a, lda, ids, table, E, rows_per_seq, seq_stride, w, ldw, bias, bias2, c, ldc, M, N, K, act,
+                            nullptr, 0, st);
 }
 
 int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
