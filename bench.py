@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--dlen", type=int, default=64)
     ap.add_argument("--session", type=int, default=7)
     ap.add_argument("--vocab", type=int, default=100000)
+    ap.add_argument("--uniform", action="store_true", help="uniform token ids (worst case for the gather) instead of Zipf")
     ap.add_argument("--nbatches", type=int, default=8, help="distinct resident batches cycled through")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,7 +99,7 @@ def make_batches(args, rank, dev):
         if args.model == "cars":
             b = synth.session_batch(args.batch, args.session, args.cands, args.qlen, args.dlen, args.vocab, seed)
         else:
-            b = synth.ranker_batch(args.batch, args.cands, args.qlen, args.dlen, args.vocab, seed)
+            b = synth.ranker_batch(args.batch, args.cands, args.qlen, args.dlen, args.vocab, seed, uniform=args.uniform)
         out.append({k: v.to(dev) for k, v in b.items()})
     return out
 
@@ -130,23 +131,36 @@ def main():
     is_cars = args.model == "cars"
     pairs_per_step_rank = args.batch * args.cands * (args.session if is_cars else 1)
 
-    def step(i):
+    def forward(i):
+        """rank-local part of a step: network forward on this rank's candidate shard (captured into a hipGraph)."""
         ex = batches[i % len(batches)]
         if is_cars:
             return model.predict(ex)["click_scores"]
         s = model.scores(ex)
         if world > 1:
-            if backend == "nccl":
-                s = sharding.gather_scores(s, args.cands * world)
-            else:
-                s = sharding.gather_scores(s.cpu(), args.cands * world).to(dev)
+            return s
         out = torch.empty_like(s)
         lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
         return out
 
-    # ---- optional hipGraph replay of the step (single GPU; removes host launch overhead) -------------
+    def finish(s):
+        """cross-rank part (eager): one all-gather of the score shards, then the softmax over all candidates."""
+        if world == 1 or is_cars:
+            return s
+        if backend == "nccl":
+            s = sharding.gather_scores(s, args.cands * world)
+        else:
+            s = sharding.gather_scores(s.cpu(), args.cands * world).to(dev)
+        out = torch.empty_like(s)
+        lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
+        return out
+
+    def step(i):
+        return finish(forward(i))
+
+    # ---- hipGraph replay of the rank-local forward (removes host launch overhead; the collective stays eager) ----
     graphs = None
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = not args.no_graph
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     for i in range(max(3, min(args.warmup, 5))):
@@ -158,7 +172,7 @@ def main():
             for i in range(len(batches)):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=stream):
-                    out = step(i)
+                    out = forward(i)
                 graphs.append((g, out))
         except Exception as e:  # pragma: no cover - graph capture is an optimisation only
             print("[bench] graph capture unavailable (%s); timing eager launches" % e, file=sys.stderr)
@@ -167,7 +181,9 @@ def main():
 
     def run(i):
         if graphs is not None:
-            graphs[i % len(graphs)][0].replay()
+            g, out = graphs[i % len(graphs)]
+            g.replay()
+            finish(out)
         else:
             step(i)
 
@@ -296,9 +312,9 @@ def main():
                "max_abs_diff_vs_gpu_softmax": maxdiff}
 
     if rank == 0:
-        cfg = {"workload": "%s ranker, batch=%d queries x %d candidates%s, q_len=%d, doc_len=%d, emb_dim=300, vocab=%d, fp32, full-length Zipf ids"
+        cfg = {"workload": "%s ranker, batch=%d queries x %d candidates%s, q_len=%d, doc_len=%d, emb_dim=300, vocab=%d, fp32, full-length %s ids"
                            % (args.model, args.batch, args.cands * world, (" x session %d" % args.session) if is_cars else "",
-                              args.qlen, args.dlen, args.vocab),
+                              args.qlen, args.dlen, args.vocab, "uniform" if args.uniform else "Zipf"),
                "global_batch_pairs": pairs_per_step_rank * world,
                "parallelism": "candidate-sharded x%d + RCCL all-gather of scores" % world if world > 1 else "single GPU",
                "hipgraph": graphs is not None}

@@ -89,19 +89,39 @@ struct DrmmW {
     const float *gate_w, *gate_b, *f0w, *f0b, *f1w, *f1b, *ow, *ob;
 };
 
-// one workgroup (4 waves) per (query, candidate) pair; dynamic LDS: qn[QL][E] + glog[QL] + hist[QL*5]
-__global__ __launch_bounds__(256) void drmm_kernel(const int64_t* q_ids, const int64_t* d_ids, int N, int QL, int DL,
-                                                   const float* table, int E, DrmmW w, float* scores, float* hist_out) {
+// sum over the 16 lanes of a DPP row; every lane of the row gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+
+// One workgroup (4 waves = 16 row groups of 16 lanes) per (query, candidate) pair.
+// A row group owns one document row at a time: its 16 lanes read the 4E-byte table row as 16-byte pieces
+// (contiguous 256-B segments), accumulate |d|^2 and the QL dot products against the normalised query rows held
+// in LDS, and reduce inside their own DPP row (4 DPP adds, no cross-row traffic) -- so a wave retires 4 document
+// rows per pass.  cos = (d . q_i/|q_i|) / max(|d|, eps); each lane of the group owns histogram slots
+// (i*5 + bin) == lane16 (mod 16) in registers.  First version (one row per wave, element-wise IEEE division, 5
+// full-wave reductions per row) was VALU-issue-bound at 2.45 TB/s algorithmic.
+// dynamic LDS: qn[QL][E] + glog[QL] + hist[QL*5]
+constexpr int DR_MAXC = 8;   // float4 pieces per lane: supports E <= 512
+template <int NU>            // histogram slots per lane: NU*16 >= QL*5
+__global__ __launch_bounds__(256) void drmm_kernel(const int64_t* __restrict__ q_ids, const int64_t* __restrict__ d_ids, int N,
+                                                   int QL, int DL, const float* __restrict__ table, int E, DrmmW w,
+                                                   float* __restrict__ scores, float* __restrict__ hist_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qn = smem;                 // [QL][E] rows normalised by max(|q_i|, eps)
     float* glog = qn + QL * E;        // [QL]   gate logits
     int* hist = (int*)(glog + QL);    // [QL*5]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = tid & 15, rg = tid >> 4;
     const int64_t pair = blockIdx.x;
     const int b = (int)(pair / N);
     const int nch = E >> 2;
     for (int i = tid; i < QL * 5; i += 256) hist[i] = 0;
-    // phase 1: query rows
+    // phase 1: query rows (one wave per row): normalise into LDS, gate logit
     for (int i = wave; i < QL; i += 4) {
         const float* rp = table + q_ids[(int64_t)b * QL + i] * (int64_t)E;
         float4 v[MAXCH];
@@ -126,52 +146,51 @@ __global__ __launch_bounds__(256) void drmm_kernel(const int64_t* q_ids, const i
         if (lane == 0) glog[i] = gl + w.gate_b[0];
     }
     __syncthreads();
-    // phase 2: stream the document rows once; lane (i*5+bin) of each wave keeps that counter
-    int cnt0 = 0, cnt1 = 0;
+    // phase 2: stream the document rows once
+    int cnt[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) cnt[u] = 0;
     const int64_t* dids = d_ids + pair * DL;
-    for (int j0 = wave * 2; j0 < DL; j0 += 8) {     // 2 rows in flight per wave
-        float4 v[2][MAXCH];
+    for (int j0 = rg; j0 < DL; j0 += 32) {          // 2 rows in flight per row group
+        float4 v[2][DR_MAXC];
         bool ok[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            ok[u] = j0 + u < DL;
-            const float* rp = table + (ok[u] ? dids[j0 + u] : 0) * (int64_t)E;
+        for (int r = 0; r < 2; ++r) {
+            const int j = j0 + 16 * r;
+            ok[r] = j < DL;
+            const float* rp = table + (ok[r] ? dids[j] : 0) * (int64_t)E;
 #pragma unroll
-            for (int s = 0; s < MAXCH; ++s) {
-                int c = lane + 64 * s;
-                v[u][s] = (c < nch) ? *reinterpret_cast<const float4*>(rp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < DR_MAXC; ++u) {
+                const int c = l16 + 16 * u;
+                v[r][u] = (c < nch) ? *reinterpret_cast<const float4*>(rp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!ok[u]) continue;
+        for (int r = 0; r < 2; ++r) {
             float nn = 0.f;
 #pragma unroll
-            for (int s = 0; s < MAXCH; ++s) nn += dot4(v[u][s], v[u][s]);
-            nn = fmaxf(sqrtf(wave_sum(nn)), 1e-8f);
-#pragma unroll
-            for (int s = 0; s < MAXCH; ++s) v[u][s] = div4(v[u][s], nn);
+            for (int u = 0; u < DR_MAXC; ++u) nn += dot4(v[r][u], v[r][u]);
+            const float inv = 1.0f / fmaxf(sqrtf(row16_sum(nn)), 1e-8f);
             for (int i = 0; i < QL; ++i) {
                 float d = 0.f;
 #pragma unroll
-                for (int s = 0; s < MAXCH; ++s) {
-                    int c = lane + 64 * s;
-                    if (c < nch) d += dot4(v[u][s], *reinterpret_cast<const float4*>(qn + i * E + 4 * c));
+                for (int u = 0; u < DR_MAXC; ++u) {
+                    const int c = l16 + 16 * u;
+                    if (c < nch) d += dot4(v[r][u], *reinterpret_cast<const float4*>(qn + i * E + 4 * c));
                 }
-                d = wave_sum(d);
+                d = row16_sum(d) * inv;
                 // numpy.histogram(bins=[-1,-.5,0,.5,1,1]): [-1,-.5) [-.5,0) [0,.5) [.5,1) {1}; outside -> dropped
                 int bin = -1;
                 if (d >= -1.0f && d <= 1.0f) bin = d < -0.5f ? 0 : d < 0.0f ? 1 : d < 0.5f ? 2 : d < 1.0f ? 3 : 4;
-                int slot = i * 5 + bin;
-                if (bin >= 0) {
-                    if (slot == lane) ++cnt0;
-                    if (slot == lane + 64) ++cnt1;
-                }
+                const int slot = (ok[r] && bin >= 0) ? i * 5 + bin : -1;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) cnt[u] += (slot == l16 + 16 * u);
             }
         }
     }
-    if (lane < QL * 5 && cnt0) atomicAdd(&hist[lane], cnt0);
-    if (lane + 64 < QL * 5 && cnt1) atomicAdd(&hist[lane + 64], cnt1);
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+        if (cnt[u] && l16 + 16 * u < QL * 5) atomicAdd(&hist[l16 + 16 * u], cnt[u]);
     __syncthreads();
     if (hist_out)
         for (int i = tid; i < QL * 5; i += 256) hist_out[pair * QL * 5 + i] = (float)hist[i];
@@ -221,8 +240,12 @@ extern "C" int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b};
     size_t lds = (size_t)QL * E * 4 + QL * 4 + QL * 5 * 4;
     ProfScope ps("drmm_kernel", (hipStream_t)stream);
-    hipLaunchKernelGGL(drmm_kernel, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, q_ids, d_ids, N,
-                       QL, DL, table, E, dw, scores, hist_out);
+    if (QL * 5 <= 32)
+        hipLaunchKernelGGL(drmm_kernel<2>, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, q_ids, d_ids, N,
+                           QL, DL, table, E, dw, scores, hist_out);
+    else
+        hipLaunchKernelGGL(drmm_kernel<8>, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, q_ids, d_ids, N,
+                           QL, DL, table, E, dw, scores, hist_out);
     NIR_CHECK_LAUNCH("nir_drmm_score");
     return 0;
 }
