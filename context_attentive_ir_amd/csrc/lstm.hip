@@ -371,6 +371,10 @@ int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const
     return launch_kp<0>(p, pick_s(M * ND, false), st);
 }
 
+int launch_bilstm_fused_mfma(const float* x, int I, const float* wih, const float* bih, const float* bhh, const int64_t* lens,
+                             const float* whh, const float* h0, const float* c0, float* out, float* hn, float* cn, int64_t M,
+                             int T, int H, int ND, hipStream_t st);
+
 int launch_bilstm_fused(const float* x, int I, const float* wih, const float* bih, const float* bhh, const int64_t* lens,
                         const float* whh, const float* h0, const float* c0, float* out, float* hn, float* cn, int64_t M,
                         int T, int H, int ND, hipStream_t st) {
@@ -378,6 +382,10 @@ int launch_bilstm_fused(const float* x, int I, const float* wih, const float* bi
     NIR_REQUIRE(M >= 0 && T > 0 && (ND == 1 || ND == 2), "bilstm_fused: bad dims");
     NIR_REQUIRE(H >= 1 && H <= 128 && I >= 1 && I <= 64, "bilstm_fused: H=%d (1..128) / I=%d (1..64) unsupported", H, I);
     if (M == 0) return 0;
+    if (!getenv("NIR_LSTM_VALU")) {   // matrix-core recurrence (lstm_mfma.hip) when the shape has an instantiation
+        int rc = launch_bilstm_fused_mfma(x, I, wih, bih, bhh, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, st);
+        if (rc != NIR_ERR_UNSUPPORTED) return rc;
+    }
     LstmArgs p{nullptr, x, wih, bih, bhh, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, I};
     int S = pick_s(M * ND, true);
     const int IP = I <= 48 ? 48 : 64;

@@ -1,0 +1,239 @@
+// BiLSTM recurrence on the matrix cores for narrow inputs (fused input projection): MatchTensor's encoders.
+//
+// v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 outer products per instruction (probed layout,
+// tools/mfma4_layout.hip: block b = lane/4, A[i] from lane 4b+i, B[j] from lane 4b+j, D[i][j] in lane 4b+j reg i).
+// With A = z[seq = lane&3][k] (the same 4 values replicated over the 16 blocks) and B = W[col = lane][k] one
+// instruction advances 64 gate columns x 4 sequences by one k:  M = 4, so a workgroup needs only FOUR sequences to
+// use the matrix pipe (the 16x16 / 32x32 shapes would need 16/32 and starve a small batch of workgroups).
+//
+// One workgroup = 4 sequences x 1 direction, 4 waves.  z = [h_{t-1} ; x_t] (K = H + I, zero padded) lives in a
+// ping-pong LDS buffer; the 4 waves split K evenly (perfect SIMD balance for any H -- the VALU kernel's H = 70 gave a
+// 5-wave workgroup with 2 waves on one SIMD) and every wave covers all gate columns with its W slice in VGPRs
+// (NG*KQ floats).  Per step: 7 ds_read_b128 + NG*KQ MFMAs per wave, partial sums -> LDS (one b128 per column group),
+// barrier, (unit, seq) threads add the 4 partials + bias, apply the cell update (c_t in a register), write h_t and
+// x_{t+1} (prefetched from HBM one step ahead) into the other z buffer and h_t to HBM through a branch-free
+// raw-buffer store, barrier.  Masking / reverse-direction semantics as in lstm.hip.
+#include "common.hpp"
+#include <string>
+
+namespace nir {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct LstmMfmaArgs {
+    const float* x;         // [M,T,I]
+    const float* wih;       // [ND*4H, I]
+    const float* bih;       // [ND*4H]
+    const float* bhh;       // [ND*4H]
+    const int64_t* lens;    // [M] or null
+    const float* whh;       // [ND,4H,H]
+    const float* h0;        // [ND,M,H] or null
+    const float* c0;
+    float* out;             // [M,T,ND*H]
+    float* hn;              // [ND,M,H] or null
+    float* cn;
+    int64_t M;
+    int T, H, ND, I;
+    unsigned long long* dbg;
+};
+
+template <int NG, int KQ>
+__global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
+    constexpr int NW = 4, KZ = NW * KQ, NC = 64 * NG, SEQ = 4;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* z = smem;                               // [2][SEQ][KZ]
+    float* part = z + 2 * SEQ * KZ;                // [NW][NC][SEQ]
+    float* bias_s = part + NW * NC * SEQ;          // [NC]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int H = p.H, I = p.I, T = p.T, H4 = 4 * H;
+    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int OW = p.ND * H;
+    const int myseq = tid & 3;                     // the sequence this thread serves in every role
+
+    int len4[SEQ];
+#pragma unroll
+    for (int s = 0; s < SEQ; ++s) {
+        int l = 0;
+        if (s < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + s] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        len4[s] = l;
+    }
+    const int tmax = max(max(len4[0], len4[1]), max(len4[2], len4[3]));
+    const int mylen = myseq == 0 ? len4[0] : myseq == 1 ? len4[1] : myseq == 2 ? len4[2] : len4[3];
+
+    // my K slice of every gate column I cover -> registers
+    float wreg[NG][KQ];
+#pragma unroll
+    for (int cg = 0; cg < NG; ++cg) {
+        const int col = 64 * cg + lane;
+        const bool cv = col < H4;
+        const int64_t row = (int64_t)dir * H4 + (cv ? col : 0);
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int k = wave * KQ + kk;
+            float v = 0.f;
+            if (cv) {
+                if (k < H) v = p.whh[row * H + k];
+                else if (k < H + I) v = p.wih[row * I + (k - H)];
+            }
+            wreg[cg][kk] = v;
+        }
+    }
+    for (int c = tid; c < NC; c += 256) bias_s[c] = c < H4 ? p.bih[(int64_t)dir * H4 + c] + p.bhh[(int64_t)dir * H4 + c] : 0.f;
+    for (int e = tid; e < 2 * SEQ * KZ; e += 256) z[e] = 0.f;
+    __syncthreads();
+
+    // x role: thread (i = tid >> 2, seq = tid & 3) moves x[seq][t][i] into z[.][seq][H + i]
+    const bool xrole = (tid >> 2) < I;
+    const int xi = tid >> 2;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + m0 * T * I), 0,
+                                                                           (int)((uint32_t)nvalid * T * I * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
+                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    auto load_x = [&](int step) -> float {
+        const int t = dir == 0 ? step : mylen - 1 - step;
+        const uint32_t off = (xrole && step < mylen) ? (uint32_t)((myseq * T + t) * I + xi) * 4u : OOB;
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rs, off, 0, 0));   // OOB -> 0
+    };
+    // cell role: thread (unit cj = tid >> 1, sequence pair cs = 2*(tid & 1)) finalises sequences cs and cs+1
+    const int cj = tid >> 1, cs = 2 * (tid & 1);
+    const bool cuv = cj < H;
+    const int clen0 = cs == 0 ? len4[0] : len4[2], clen1 = cs == 0 ? len4[1] : len4[3];
+    float creg0 = 0.f, creg1 = 0.f;
+    if (cuv) {   // initial state: h0 / c0
+        if (cs < nvalid) {
+            const int64_t si = ((int64_t)dir * p.M + m0 + cs) * H + cj;
+            if (p.c0) creg0 = p.c0[si];
+            if (p.h0) z[cs * KZ + cj] = p.h0[si];
+        }
+        if (cs + 1 < nvalid) {
+            const int64_t si = ((int64_t)dir * p.M + m0 + cs + 1) * H + cj;
+            if (p.c0) creg1 = p.c0[si];
+            if (p.h0) z[(cs + 1) * KZ + cj] = p.h0[si];
+        }
+    }
+    if (xrole) z[myseq * KZ + H + xi] = load_x(0);
+    float xnext = load_x(1);
+    __syncthreads();
+
+    for (int step = 0; step < tmax; ++step) {
+        const float* zc = z + (step & 1) * SEQ * KZ;
+        float* zn = z + ((step + 1) & 1) * SEQ * KZ;
+#define LM_STAMP(slot) do { if (p.dbg && step == 10 && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) p.dbg[wave * 8 + (slot)] = clock64(); } while (0)
+        LM_STAMP(0);
+        const float xcur = xnext;                 // x_{step+1}, loaded one step ago
+        xnext = load_x(step + 2);                 // in flight during this step
+        // ---- gate pre-activations: 4 sequences x all columns x my K slice on the matrix pipe
+        f32x4 acc[NG];
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg) acc[cg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* zr = zc + myseq * KZ + wave * KQ;
+#pragma unroll
+        for (int q4 = 0; q4 < KQ / 4; ++q4) {
+            const float4 zv = *reinterpret_cast<const float4*>(zr + 4 * q4);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv.x, wreg[cg][4 * q4 + 0], acc[cg], 0, 0, 0);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv.y, wreg[cg][4 * q4 + 1], acc[cg], 0, 0, 0);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv.z, wreg[cg][4 * q4 + 2], acc[cg], 0, 0, 0);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv.w, wreg[cg][4 * q4 + 3], acc[cg], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg)
+            *reinterpret_cast<f32x4*>(part + ((wave * NC) + 64 * cg + lane) * SEQ) = acc[cg];   // [seq0..3] of my column
+        LM_STAMP(1);
+        lds_barrier();
+        LM_STAMP(2);
+        // ---- cell update: thread = (unit cj, sequences cs, cs+1): 16 ds_read_b64 of the wave partials, one round
+        {
+            const int jj = cuv ? cj : 0;
+            float ga[4], gb[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * H + jj;
+                const float bsv = bias_s[col];
+                float2 t0 = *reinterpret_cast<const float2*>(part + (0 * NC + col) * SEQ + cs);
+                float2 t1 = *reinterpret_cast<const float2*>(part + (1 * NC + col) * SEQ + cs);
+                float2 t2 = *reinterpret_cast<const float2*>(part + (2 * NC + col) * SEQ + cs);
+                float2 t3 = *reinterpret_cast<const float2*>(part + (3 * NC + col) * SEQ + cs);
+                ga[g] = bsv + t0.x + t1.x + t2.x + t3.x;
+                gb[g] = bsv + t0.y + t1.y + t2.y + t3.y;
+            }
+            const float c0 = fast_sigmoid(ga[1]) * creg0 + fast_sigmoid(ga[0]) * fast_tanh(ga[2]);
+            const float c1 = fast_sigmoid(gb[1]) * creg1 + fast_sigmoid(gb[0]) * fast_tanh(gb[2]);
+            const float h0v = fast_sigmoid(ga[3]) * fast_tanh(c0);
+            const float h1v = fast_sigmoid(gb[3]) * fast_tanh(c1);
+            const bool act0 = cuv && step < clen0, act1 = cuv && step < clen1;
+            if (act0) creg0 = c0;
+            if (act1) creg1 = c1;
+            if (cuv) {   // a finished sequence carries its state over
+                zn[cs * KZ + cj] = act0 ? h0v : zc[cs * KZ + cj];
+                zn[(cs + 1) * KZ + cj] = act1 ? h1v : zc[(cs + 1) * KZ + cj];
+            }
+            const int t0i = dir == 0 ? step : clen0 - 1 - step, t1i = dir == 0 ? step : clen1 - 1 - step;
+            const uint32_t off0 = act0 ? (uint32_t)((cs * T + t0i) * OW + dir * H + cj) * 4u : OOB;
+            const uint32_t off1 = act1 ? (uint32_t)(((cs + 1) * T + t1i) * OW + dir * H + cj) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h0v), out_rs, off0, 0, 0);   // OOB lanes dropped
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h1v), out_rs, off1, 0, 0);
+        }
+        if (xrole) zn[myseq * KZ + H + xi] = xcur;
+        LM_STAMP(3);
+        lds_barrier();
+        LM_STAMP(4);
+    }
+
+    // zero the padded tail (pad_packed_sequence) and emit final states
+    const float* zf = z + (tmax & 1) * SEQ * KZ;
+    if (cuv) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int sq = cs + u;
+            if (sq < nvalid) {
+                const int l = u == 0 ? clen0 : clen1;
+                const int64_t m = m0 + sq;
+                for (int t = l; t < T; ++t) p.out[(m * T + t) * OW + (int64_t)dir * H + cj] = 0.f;
+                const int64_t si = ((int64_t)dir * p.M + m) * H + cj;
+                if (p.hn) p.hn[si] = zf[sq * KZ + cj];
+                if (p.cn) p.cn[si] = u == 0 ? creg0 : creg1;
+            }
+        }
+    }
+}
+
+template <int NG, int KQ>
+static int launch_mfma(const LstmMfmaArgs& p, hipStream_t st) {
+    static const std::string pname = "lstm_mfma_kernel<" + std::to_string(NG) + "," + std::to_string(KQ) + ">";
+    constexpr size_t lds = (size_t)(2 * 4 * 4 * KQ + 4 * 64 * NG * 4 + 64 * NG) * 4;
+    ProfScope ps(pname.c_str(), st);
+    hipLaunchKernelGGL((lstm_mfma_kernel<NG, KQ>), dim3((unsigned)((p.M + 3) / 4), (unsigned)p.ND), dim3(256), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_fused_fwd[mfma]");
+    return 0;
+}
+
+// returns NIR_ERR_UNSUPPORTED when the shape has no instantiation (caller falls back to the VALU kernel)
+int launch_bilstm_fused_mfma(const float* x, int I, const float* wih, const float* bih, const float* bhh, const int64_t* lens,
+                             const float* whh, const float* h0, const float* c0, float* out, float* hn, float* cn, int64_t M,
+                             int T, int H, int ND, hipStream_t st) {
+    if (I > 64 || (int64_t)4 * T * max(I, ND * H) * 4 >= 0x7FFFFFF0LL) return NIR_ERR_UNSUPPORTED;
+    LstmMfmaArgs p{x, wih, bih, bhh, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, I, g_debug_buf};
+    const int NG = (4 * H + 63) / 64;
+    const int KQ = ((H + I + 15) / 16) * 4;
+#define NIR_MFMA_CASE(ng, kq) if (NG == ng && KQ == kq) return launch_mfma<ng, kq>(p, st);
+    NIR_MFMA_CASE(1, 8) NIR_MFMA_CASE(1, 12) NIR_MFMA_CASE(1, 16) NIR_MFMA_CASE(1, 20)
+    NIR_MFMA_CASE(2, 12) NIR_MFMA_CASE(2, 16) NIR_MFMA_CASE(2, 20) NIR_MFMA_CASE(2, 24)
+    NIR_MFMA_CASE(3, 16) NIR_MFMA_CASE(3, 20) NIR_MFMA_CASE(3, 24) NIR_MFMA_CASE(3, 28)
+    NIR_MFMA_CASE(4, 20) NIR_MFMA_CASE(4, 24) NIR_MFMA_CASE(4, 28) NIR_MFMA_CASE(4, 32)
+    NIR_MFMA_CASE(5, 24) NIR_MFMA_CASE(5, 28) NIR_MFMA_CASE(5, 32) NIR_MFMA_CASE(5, 36)
+#undef NIR_MFMA_CASE
+    return NIR_ERR_UNSUPPORTED;
+}
+
+}  // namespace nir
