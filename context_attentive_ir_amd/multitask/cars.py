@@ -187,11 +187,17 @@ class CARS(nn.Module):
         dummy_q = torch.zeros(B, S, D, device=docs.device)
         return self._rank_session(dummy_q, docs, doc_labels, want_clicks=True)[1]
 
-    def rank_document(self, pooled_rep, document_rep, document_len, document_label):
+    def rank_document(self, pooled_rep, document_rep, document_len, document_label, group=None, shard=False):
         """cars.py:522-540 -> (click_scores [B,S,N], hidden_states=None, session_attns=(None, None)).
-        The decoder-initialisation states are suggestion-only and not produced."""
+        The decoder-initialisation states are suggestion-only and not produced.
+        shard=True: candidate-sharded document encoding over the torch.distributed `group` + one all-gather of the
+        pooled document vectors (sharding.sharded_pooled_docs); the session part runs replicated."""
         self._check_eval()
-        encoded_docs = self.encode_document(document_rep, document_len)
+        if shard:
+            from .. import sharding
+            encoded_docs = sharding.sharded_pooled_docs(self.encode_document, document_rep, document_len, group)
+        else:
+            encoded_docs = self.encode_document(document_rep, document_len)
         scores, _ = self._rank_session(pooled_rep, encoded_docs, document_label)
         return scores, None, (None, None)
 

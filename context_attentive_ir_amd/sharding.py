@@ -49,3 +49,35 @@ def sharded_scores(score_fn, doc_rep, doc_len, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     d, l = shard_candidates(doc_rep, doc_len, world, rank)
     return gather_scores(score_fn(d, l), doc_rep.shape[1], group)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# CARS (SURVEY.md section 8e): document encoding (~96 % of the FLOPs) shards by candidate exactly like the rankers,
+# but encode_clicks needs ALL N pooled document vectors of a query, so the exchange is one all-gather of the pooled
+# vectors [B,S,ceil(N/G),D] (C3: 229 KB per rank); click attention, session LSTMs and the ranknet then run
+# replicated on every rank (cheap) and produce the full [B,S,N] scores with no second collective.
+# ----------------------------------------------------------------------------------------------------------
+def shard_session_candidates(document_words, document_lens, world, rank):
+    """[B,S,N,DL] / [B,S,N] -> this rank's candidate slice, padded to the common width."""
+    B, S, N, DL = document_words.shape
+    d, l = shard_candidates(document_words.reshape(B * S, N, DL), document_lens.reshape(B * S, N), world, rank)
+    per = d.shape[1]
+    return d.view(B, S, per, DL), l.view(B, S, per)
+
+
+def gather_pooled_docs(local, N, group=None):
+    """all-gather pooled document vectors [B,S,per,D] from every rank -> [B,S,N,D] (padding removed)."""
+    world = dist.get_world_size(group)
+    B, S, per, D = local.shape
+    out = torch.empty(world * B * S, per * D, device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(out, local.reshape(B * S, per * D).contiguous(), group=group)
+    return out.view(world, B, S, per, D).permute(1, 2, 0, 3, 4).reshape(B, S, world * per, D)[:, :, :N].contiguous()
+
+
+def sharded_pooled_docs(encode_fn, document_words, document_lens, group=None):
+    """encode_fn(doc_shard [B,S,per,DL], len_shard [B,S,per]) -> pooled [B,S,per,D]; returns [B,S,N,D] everywhere."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return encode_fn(document_words, document_lens)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    d, l = shard_session_candidates(document_words, document_lens, world, rank)
+    return gather_pooled_docs(encode_fn(d, l), document_words.shape[2], group)

@@ -21,6 +21,13 @@ class Multitask(object):
         if state_dict:
             self.network.load_state_dict(state_dict)
         self.updates, self.use_cuda, self.parallel = 0, False, False
+        self.group = None
+
+    def parallelize(self, group=None):
+        """Candidate-axis sharding of the document encoder over `group` (replaces nn.DataParallel,
+        models/multitask.py:402-407)."""
+        self.parallel = True
+        self.group = group
 
     def cuda(self):
         self.use_cuda = True
@@ -35,7 +42,7 @@ class Multitask(object):
         self.network.eval()
         pooled, _, _ = self.network.encode(self._dev(ex["source_words"]), self._dev(ex["source_lens"]))
         s, _, _ = self.network.rank_document(pooled, self._dev(ex["document_words"]), self._dev(ex["document_lens"]),
-                                             self._dev(ex["document_labels"]))
+                                             self._dev(ex["document_labels"]), group=self.group, shard=self.parallel)
         return s
 
     @torch.no_grad()

@@ -136,6 +136,19 @@ for N in (5, 10, 1):
     full = fn(ex["doc_rep"], ex["doc_len"])
     got = sharding.sharded_scores(fn, ex["doc_rep"], ex["doc_len"])
     assert got.shape == full.shape and torch.equal(got, full), (rank, N, (got - full).abs().max())
+# CARS: shard the document encoder, all-gather pooled vectors, replicated session part (oracle stands in for HIP)
+from context_attentive_ir_amd.multitask import CARS
+sdc = {k: v for k, v in fill_module_(CARS(default_args("CARS", src_vocab_size=300))).state_dict().items()}
+for N in (5, 3):
+    ex = synth.session_batch(2, 3, N, 4, 10, 300, seed=N, full_length=False, multi_click=True)
+    enc = lambda d, l: O.cars_encode_document(sdc, d, l)
+    full = enc(ex["document_words"], ex["document_lens"])
+    got = sharding.sharded_pooled_docs(enc, ex["document_words"], ex["document_lens"])
+    assert got.shape == full.shape and torch.allclose(got, full, atol=1e-6), (rank, N)
+    pooled, _ = O.cars_encode(sdc, ex["source_words"], ex["source_lens"])
+    s_full = O.cars_encode_session(sdc, pooled, full, O.cars_encode_clicks(sdc, full, ex["document_labels"]))
+    s_got = O.cars_encode_session(sdc, pooled, got, O.cars_encode_clicks(sdc, got, ex["document_labels"]))
+    assert torch.allclose(s_got, s_full, atol=1e-6)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
