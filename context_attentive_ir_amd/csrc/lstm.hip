@@ -31,6 +31,10 @@ namespace nir {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// matrix-core variants (lstm_mfma.hip); return NIR_ERR_UNSUPPORTED when the shape has no instantiation
+int launch_bilstm_mfma(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
+                       float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st);
+
 struct LstmArgs {
     const float* gin;       // [M,T,ND*4H]            (IP == 0)
     const float* x;         // [M,T,I]                (IP  > 0)
@@ -367,6 +371,14 @@ int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const
     NIR_REQUIRE(H >= 1 && H <= 128, "bilstm: hidden size %d per direction unsupported (1..128)", H);
     NIR_REQUIRE((int64_t)8 * T * ND * 4 * H * 4 < 0x7FFFFFF0LL, "bilstm: T*H too large for 32-bit tile offsets");
     if (M == 0) return 0;
+    // Measured (tools/bench_lstm.py): the quad/VALU kernel wins when its workgroup fills the 4 SIMDs evenly
+    // (KP/16 waves a multiple of 4: H = 128 -> 439 us vs 520 us on the matrix pipe at M = 1120); the 4x4x1-MFMA
+    // recurrence wins for the unbalanced sizes (H = 70: 5 waves).
+    const bool valu_balanced = (((H + 15) / 16) % 4) == 0;
+    if (!valu_balanced && !getenv("NIR_LSTM_VALU")) {
+        int rc = launch_bilstm_mfma(gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, st);
+        if (rc != NIR_ERR_UNSUPPORTED) return rc;
+    }
     LstmArgs p{gin, nullptr, nullptr, nullptr, nullptr, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, 0};
     return launch_kp<0>(p, pick_s(M * ND, false), st);
 }

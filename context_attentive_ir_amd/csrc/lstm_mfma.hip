@@ -208,6 +208,168 @@ __global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Unfused variant (wide inputs, e.g. CARS: H = 128, I = 300): z = h_{t-1} only; the gate pre-activations
+// x W_ih^T + b come from the big gather-GEMM (`gates_in`) and are added in the cell update, prefetched one step ahead.
+// Waves = NWC column slices x 4 K-quarters; thread (unit = tid >> 2, seq = tid & 3) owns one cell.
+// ------------------------------------------------------------------------------------------------------------------
+struct LstmMfmaGinArgs {
+    const float* gin;       // [M,T,ND*4H]
+    const int64_t* lens;
+    const float* whh;       // [ND,4H,H]
+    const float* h0;
+    const float* c0;
+    float* out;             // [M,T,ND*H]
+    float* hn;
+    float* cn;
+    int64_t M;
+    int T, H, ND;
+};
+
+template <int NG, int KQ, int NWC>
+__global__ __launch_bounds__(256 * NWC) void lstm_mfma_gin_kernel(LstmMfmaGinArgs p) {
+    constexpr int NWK = 4, KZ = NWK * KQ, NC = 64 * NG * NWC, SEQ = 4, NT = 256 * NWC;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* z = smem;                               // [2][SEQ][KZ]
+    float* part = z + 2 * SEQ * KZ;                // [NWK][NC][SEQ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = wave & 3, ch = wave >> 2;       // my K quarter / column slice
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int H = p.H, T = p.T, H4 = 4 * H;
+    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int OW = p.ND * H, G = p.ND * H4;
+    const int myseq = tid & 3, cj = tid >> 2;      // cell role: (unit cj, sequence myseq); needs 4H <= NT
+    const bool cuv = cj < H;
+
+    int len4[SEQ];
+#pragma unroll
+    for (int s = 0; s < SEQ; ++s) {
+        int l = 0;
+        if (s < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + s] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        len4[s] = l;
+    }
+    const int tmax = max(max(len4[0], len4[1]), max(len4[2], len4[3]));
+    const int mylen = myseq == 0 ? len4[0] : myseq == 1 ? len4[1] : myseq == 2 ? len4[2] : len4[3];
+
+    float wreg[NG][KQ];
+#pragma unroll
+    for (int cg = 0; cg < NG; ++cg) {
+        const int col = 64 * (ch * NG + cg) + lane;
+        const bool cv = col < H4;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (cv ? col : 0)) * H;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int k = kq * KQ + kk;
+            wreg[cg][kk] = (cv && k < H) ? wr[k] : 0.f;
+        }
+    }
+    for (int e = tid; e < 2 * SEQ * KZ; e += NT) z[e] = 0.f;
+    __syncthreads();
+    float creg = 0.f;
+    if (cuv && myseq < nvalid) {
+        const int64_t si = ((int64_t)dir * p.M + m0 + myseq) * H + cj;
+        if (p.c0) creg = p.c0[si];
+        if (p.h0) z[myseq * KZ + cj] = p.h0[si];
+    }
+    const __amdgpu_buffer_rsrc_t gin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gin + m0 * T * G), 0,
+                                                                             (int)((uint32_t)nvalid * T * G * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
+                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    auto load_gin = [&](int step, float (&dst)[4]) {
+        const int t = dir == 0 ? step : mylen - 1 - step;
+        const bool ok = cuv && step < mylen;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t off = ok ? (uint32_t)((myseq * T + t) * G + dir * H4 + g * H + cj) * 4u : OOB;
+            dst[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gin_rs, off, 0, 0));   // OOB -> 0
+        }
+    };
+    float gcur[4], gnext[4];
+    load_gin(0, gcur);
+    __syncthreads();
+
+    for (int step = 0; step < tmax; ++step) {
+        const float* zc = z + (step & 1) * SEQ * KZ;
+        float* zn = z + ((step + 1) & 1) * SEQ * KZ;
+        load_gin(step + 1, gnext);                 // lands during this step's MFMA phase
+        f32x4 acc[NG];
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg) acc[cg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* zr = zc + myseq * KZ + kq * KQ;
+#pragma unroll
+        for (int q4 = 0; q4 < KQ / 4; ++q4) {
+            const float4 zv = *reinterpret_cast<const float4*>(zr + 4 * q4);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv.x, wreg[cg][4 * q4 + 0], acc[cg], 0, 0, 0);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv.y, wreg[cg][4 * q4 + 1], acc[cg], 0, 0, 0);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv.z, wreg[cg][4 * q4 + 2], acc[cg], 0, 0, 0);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(zv.w, wreg[cg][4 * q4 + 3], acc[cg], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg)
+            *reinterpret_cast<f32x4*>(part + ((kq * NC) + 64 * (ch * NG + cg) + lane) * SEQ) = acc[cg];
+        lds_barrier();
+        {   // ---- cell update: one (unit, sequence) per thread
+            const int jj = cuv ? cj : 0;
+            float g4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * H + jj;
+                g4[g] = gcur[g] + part[(0 * NC + col) * SEQ + myseq] + part[(1 * NC + col) * SEQ + myseq] +
+                        part[(2 * NC + col) * SEQ + myseq] + part[(3 * NC + col) * SEQ + myseq];
+            }
+            const float c = fast_sigmoid(g4[1]) * creg + fast_sigmoid(g4[0]) * fast_tanh(g4[2]);
+            const float h = fast_sigmoid(g4[3]) * fast_tanh(c);
+            const bool act = cuv && step < mylen;
+            if (act) creg = c;
+            if (cuv) zn[myseq * KZ + cj] = act ? h : zc[myseq * KZ + cj];
+            const int t = dir == 0 ? step : mylen - 1 - step;
+            const uint32_t off = act ? (uint32_t)((myseq * T + t) * OW + dir * H + cj) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), out_rs, off, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gcur[g] = gnext[g];
+        }
+        lds_barrier();
+    }
+    if (cuv && myseq < nvalid) {
+        const float* zf = z + (tmax & 1) * SEQ * KZ;
+        const int64_t m = m0 + myseq;
+        for (int t = mylen; t < T; ++t) p.out[(m * T + t) * OW + (int64_t)dir * H + cj] = 0.f;
+        const int64_t si = ((int64_t)dir * p.M + m) * H + cj;
+        if (p.hn) p.hn[si] = zf[myseq * KZ + cj];
+        if (p.cn) p.cn[si] = creg;
+    }
+}
+
+template <int NG, int KQ, int NWC>
+static int launch_mfma_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
+    static const std::string pname = "lstm_mfma_gin_kernel<" + std::to_string(NG) + "," + std::to_string(KQ) + "," + std::to_string(NWC) + ">";
+    constexpr size_t lds = (size_t)(2 * 4 * 4 * KQ + 4 * 64 * NG * NWC * 4) * 4;
+    ProfScope ps(pname.c_str(), st);
+    hipLaunchKernelGGL((lstm_mfma_gin_kernel<NG, KQ, NWC>), dim3((unsigned)((p.M + 3) / 4), (unsigned)p.ND), dim3(256 * NWC), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_fwd[mfma]");
+    return 0;
+}
+
+int launch_bilstm_mfma(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
+                       float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st) {
+    if ((int64_t)4 * T * ND * 4 * H * 4 >= 0x7FFFFFF0LL || H < 17) return NIR_ERR_UNSUPPORTED;
+    LstmMfmaGinArgs p{gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND};
+    if (H <= 64) return launch_mfma_gin<4, 16, 1>(p, st);
+    if (H <= 96) return launch_mfma_gin<3, 24, 2>(p, st);
+    if (H <= 128) return launch_mfma_gin<4, 32, 2>(p, st);
+    return NIR_ERR_UNSUPPORTED;
+}
+
 template <int NG, int KQ>
 static int launch_mfma(const LstmMfmaArgs& p, hipStream_t st) {
     static const std::string pname = "lstm_mfma_kernel<" + std::to_string(NG) + "," + std::to_string(KQ) + ">";
