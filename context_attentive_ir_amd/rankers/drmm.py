@@ -58,6 +58,8 @@ class DRMM(nn.Module):
         N, DL = d.shape[1], d.shape[2]
         w = self._weights()
         scores = torch.empty(B, N, device=q.device, dtype=torch.float32)
+        if B == 0 and not return_hist:
+            return scores
         hist = torch.empty(B * N, QL, 5, device=q.device, dtype=torch.float32) if return_hist else None
         lib.check(lib.load().nir_drmm_score(lib.ptr(q), lib.ptr(d), B, N, QL, DL, lib.ptr(table), table.shape[0],
                                             table.shape[1], w.ref(), lib.ptr(scores), lib.ptr(hist), lib.stream()),

@@ -92,6 +92,8 @@ class DUET(nn.Module):
         dev = q.device
         ws = lib.workspace(L.nir_duet_workspace_bytes(B, N, QL, DL, table.shape[1], w.ref()), dev)
         scores = torch.empty(B, N, device=dev, dtype=torch.float32)
+        if B == 0 and not return_parts:
+            return scores
         loc = torch.empty_like(scores) if return_parts else None
         dist = torch.empty_like(scores) if return_parts else None
         lib.check(L.nir_duet_score(lib.ptr(q), lib.ptr(d), B, N, QL, DL, lib.ptr(table), table.shape[0], table.shape[1],

@@ -24,6 +24,8 @@ class ESM(nn.Module):
         N, DL = d.shape[1], d.shape[2]
         table = self.word_embeddings.table
         scores = torch.empty(B, N, device=q.device, dtype=torch.float32)
+        if B == 0:   # empty batch: nothing to enqueue (zero-size tensors have no device pointer)
+            return scores
         lib.check(lib.load().nir_esm_score(lib.ptr(q), lib.ptr(d), B, N, QL, DL, lib.ptr(table), table.shape[0],
                                            table.shape[1], lib.ptr(scores), lib.stream()), "nir_esm_score")
         return scores

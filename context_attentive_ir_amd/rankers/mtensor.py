@@ -80,6 +80,8 @@ class MatchTensor(nn.Module):
         nbytes = L.nir_matchtensor_workspace_bytes(B, N, QL, DL, w.ref())
         ws = lib.workspace(nbytes, dev)
         scores = torch.empty(B, N, device=dev, dtype=torch.float32)
+        if B == 0 and not return_parts:
+            return scores
         parts = [None] * 4
         if return_parts:
             dm = self._dims

@@ -69,7 +69,8 @@ def _gather_conv_case(lib, g, V, E, F_, nseq, L):
     _close(out.view(nseq, L - 2, F_), ref, 2e-5)
 
 
-@pytest.mark.parametrize("H,I,M,T_", [(15, 40, 7, 6), (70, 40, 33, 20), (128, 300, 19, 12), (128, 300, 700, 9), (32, 16, 1200, 5)])
+@pytest.mark.parametrize("H,I,M,T_", [(15, 40, 7, 6), (70, 40, 33, 20), (128, 300, 19, 12), (128, 300, 700, 9), (32, 16, 1200, 5),
+                                      (70, 100, 21, 17), (40, 100, 9, 30), (96, 64, 5, 8), (1, 1, 3, 4)])
 def test_rnn_encoder(H, I, M, T_):
     from context_attentive_ir_amd.encoders import RNNEncoder
     from context_attentive_ir_amd.detinit import fill_module_
@@ -285,3 +286,29 @@ def test_multitask_predict_map_parity():
     lab = ex["document_labels"].numpy().reshape(-1, 10).astype(np.int64)
     assert MAP(rank_candidates(got.numpy().reshape(-1, 10)), lab) == pytest.approx(
         O.mean_average_precision(rank_candidates(ref.numpy().reshape(-1, 10)), lab), abs=1e-12)
+
+
+# ------------------------------------------------------------------ properties
+@pytest.mark.parametrize("kind", ["ESM", "MATCH_TENSOR", "DRMM", "DUET"])
+def test_candidate_permutation_permutes_scores(kind):
+    """Every (query, candidate) pair is independent given the query: permuting candidates permutes scores."""
+    rng = np.random.default_rng(17)
+    B, N, QL, DL, V = 3, 7, 4, 24, 500
+    extra = dict(max_query_len=QL, max_doc_len=DL) if kind == "DUET" else {}
+    m = build_model(kind, vocab=V, device=DEV, **extra)
+    q, ql, d, dl = (t.to(DEV) for t in _synth(rng, B, N, QL, DL, V, full=(kind == "DUET")))
+    perm = torch.from_numpy(rng.permutation(N)).to(DEV)
+    s0 = m(q, ql, d, dl)
+    s1 = m(q, ql, d[:, perm].contiguous(), dl[:, perm].contiguous())
+    _close(s1, s0[:, perm], 1e-6)
+
+
+def test_empty_batch_and_single_token():
+    m = build_model("ESM", device=DEV)
+    q = torch.zeros(0, 4, dtype=torch.long, device=DEV); d = torch.zeros(0, 3, 8, dtype=torch.long, device=DEV)
+    assert m(q, q[:, 0], d, d[:, :, 0]).shape == (0, 3)
+    mt = build_model("MATCH_TENSOR", device=DEV)
+    q1 = torch.full((1, 1), 5, dtype=torch.long, device=DEV); d1 = torch.full((1, 1, 1), 5, dtype=torch.long, device=DEV)
+    one = torch.ones(1, dtype=torch.long, device=DEV)
+    ref = O.match_tensor_scores(cpu_state_dict(mt), q1.cpu(), one.cpu(), d1.cpu(), one.cpu().view(1, 1))
+    _close(mt(q1, one, d1, one.view(1, 1)), ref)
