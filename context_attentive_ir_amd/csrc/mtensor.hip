@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = w.C;
     const int nchunk = (DL + JT - 1) / JT;
-    const int DLP = nchunk * JT + 8;               // halo: 3 left, >= 3 right (+ padding of the last chunk)
+    const int DLP = nchunk * JT + 9;               // halo: 3 left, >= 3 right; odd pitch -> the transposed prologue
+                                                   // writes pdt[c*DLP + j] (consecutive c per lane) are conflict-free
     const int rows = MT * 32;
     constexpr int YLD = JT + 1;
     float* pdt = smem;                             // [CP][DLP]
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
 }
 
 static size_t mt_head_lds(int QL, int DL, int MT) {
-    const int nchunk = (DL + JT - 1) / JT, DLP = nchunk * JT + 8;
+    const int nchunk = (DL + JT - 1) / JT, DLP = nchunk * JT + 9;
     size_t fl = (size_t)CP * DLP + (size_t)3 * MT * 32 * (JT + 1) + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + MFC + 2 + 1) & ~1);
     return fl * 4 + (size_t)(DL + QL) * 8;
 }
