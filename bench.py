@@ -212,20 +212,25 @@ def main():
     value = total_pairs / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- second number (never `value`): ids start in pinned HOST memory, H2D copy of the id tensors inside the loop
+    # ---- second number (never `value`): ids start in pinned HOST memory; every step copies them H2D into the static
+    # buffers of a captured hipGraph (context_attentive_ir_amd/graph_runner.py) and replays it
     h2d_value = None
-    if world == 1 and not is_cars:
-        host = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in batches]
-        nh = max(10, min(args.steps, 100))
-        torch.cuda.synchronize()
-        th = time.perf_counter()
-        for i in range(nh):
-            ex = {k: v.to(dev, non_blocking=True) for k, v in host[i % len(host)].items()}
-            s = model.scores(ex)
-            out = torch.empty_like(s)
-            lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
-        torch.cuda.synchronize()
-        h2d_value = pairs_per_step_rank * nh / (time.perf_counter() - th)
+    if world == 1:
+        try:
+            from context_attentive_ir_amd.graph_runner import GraphedPredictor
+            host = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in batches]
+            gp = GraphedPredictor(model, batches[0])
+            nh = max(10, min(args.steps, 100))
+            for i in range(3):
+                gp.predict(host[i % len(host)], clone=False)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for i in range(nh):
+                gp.predict(host[i % len(host)], clone=False)
+            torch.cuda.synchronize()
+            h2d_value = pairs_per_step_rank * nh / (time.perf_counter() - th)
+        except Exception as e:  # pragma: no cover - secondary figure only
+            print("[bench] H2D-inclusive figure unavailable: %s" % e, file=sys.stderr)
 
     # ---- profiled pass: HIP events around every kernel of the library, same workload -------------------
     roofline = None
@@ -335,7 +340,7 @@ def main():
                "global_batch_pairs": pairs_per_step_rank * world,
                "parallelism": "candidate-sharded x%d + RCCL all-gather of scores" % world if world > 1 else "single GPU",
                "hipgraph": graphs is not None,
-               "pairs_per_s_with_host_ids_h2d_eager": None if h2d_value is None else round(h2d_value, 1)}
+               "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1)}
         line = {"metric": "ranked (query,doc) pairs/sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,

@@ -1,0 +1,68 @@
+"""hipGraph replay of Ranker.predict / Multitask.predict for fixed batch shapes.
+
+At MSMARCO-shaped batch sizes a forward is a dozen short kernels (~200 us), so host launch overhead dominates an
+eager call.  GraphedPredictor captures one predict() into a hipGraph over STATIC input buffers; each call copies the
+ids (pinned host or device tensors) into those buffers on the capture stream and replays the graph.  Shapes are
+fixed at capture time (one predictor per (B, N, QL, DL) bucket -- the reference's length-bucketing samplers,
+neuroir/inputters/ranker/data.py:37-56, already group batches by shape).
+"""
+import torch
+
+
+class GraphedPredictor(object):
+    def __init__(self, wrapper, example, warmup=3):
+        """wrapper: wrappers.Ranker or wrappers.Multitask (already .cuda()); example: a batch dict of that shape."""
+        if not wrapper.use_cuda:
+            raise RuntimeError("GraphedPredictor needs a wrapper on a ROCm device (call .cuda() first)")
+        self.wrapper = wrapper
+        dev = next(wrapper.network.parameters()).device
+        self.stream = torch.cuda.Stream(device=dev)
+        # one device byte buffer + one pinned staging buffer hold every input tensor (16-byte aligned slots):
+        # a step costs ONE H2D copy; the captured graph reads typed views of the device buffer
+        self.slots, off = {}, 0
+        for k, v in example.items():
+            if torch.is_tensor(v):
+                nbytes = v.numel() * v.element_size()
+                self.slots[k] = (off, nbytes, v.dtype, tuple(v.shape))
+                off = (off + nbytes + 15) // 16 * 16
+        self.dev_buf = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
+        self.host_buf = torch.empty(max(off, 16), dtype=torch.uint8).pin_memory()
+        self.static = {k: self.dev_buf[o:o + n].view(dt).view(shape) for k, (o, n, dt, shape) in self.slots.items()}
+        self._host_views = {k: self.host_buf[o:o + n].view(dt).view(shape) for k, (o, n, dt, shape) in self.slots.items()}
+        for k, v in example.items():
+            if k in self.static:
+                self.static[k].copy_(v)
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                self._call()
+            self.stream.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.out = self._call()
+
+    def _call(self):
+        out = self.wrapper.predict(self.static)
+        return out["click_scores"] if isinstance(out, dict) else out
+
+    def predict(self, ex, clone=True):
+        """ex must have the captured shapes; returns the softmax scores (a fresh tensor unless clone=False)."""
+        on_host = all(not ex[k].is_cuda for k in self.slots)
+        with torch.cuda.stream(self.stream):
+            if on_host:
+                self.stream.synchronize()            # the previous H2D out of the staging buffer has completed
+                for k, hv in self._host_views.items():
+                    src = ex[k]
+                    if src.shape != hv.shape:
+                        raise RuntimeError("GraphedPredictor captured %s with shape %s, got %s" % (k, tuple(hv.shape), tuple(src.shape)))
+                    hv.copy_(src)
+                self.dev_buf.copy_(self.host_buf, non_blocking=True)
+            else:
+                for k, buf in self.static.items():
+                    src = ex[k]
+                    if src.shape != buf.shape:
+                        raise RuntimeError("GraphedPredictor captured %s with shape %s, got %s" % (k, tuple(buf.shape), tuple(src.shape)))
+                    buf.copy_(src, non_blocking=True)
+            self.graph.replay()
+            out = self.out.clone() if clone else self.out
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return out

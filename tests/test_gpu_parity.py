@@ -312,3 +312,20 @@ def test_empty_batch_and_single_token():
     one = torch.ones(1, dtype=torch.long, device=DEV)
     ref = O.match_tensor_scores(cpu_state_dict(mt), q1.cpu(), one.cpu(), d1.cpu(), one.cpu().view(1, 1))
     _close(mt(q1, one, d1, one.view(1, 1)), ref)
+
+
+def test_graphed_predictor_matches_eager():
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.graph_runner import GraphedPredictor
+    from context_attentive_ir_amd.wrappers import Ranker
+    V = 2000
+    r = Ranker(default_args("MATCH_TENSOR", src_vocab_size=V)); fill_module_(r.network, 1013); r.cuda()
+    exs = [synth.ranker_batch(8, 6, 4, 32, V, seed=s, full_length=False) for s in (1, 2, 3)]
+    gp = GraphedPredictor(r, {k: v.cuda() for k, v in exs[0].items()})
+    for ex in exs:                                    # host (unpinned or pinned) ids -> static buffers -> replay
+        eager = r.predict(ex)
+        _close(gp.predict({k: v.pin_memory() for k, v in ex.items()}), eager, 1e-7)
+    with pytest.raises(RuntimeError):
+        gp.predict(synth.ranker_batch(4, 6, 4, 32, V))
