@@ -33,7 +33,8 @@ def _synth(rng, B, N, QL, DL, V, full=False):
 
 # ------------------------------------------------------------------ building blocks
 @pytest.mark.parametrize("M,N,K,act", [(37, 40, 300, 0), (130, 50, 30, 0), (64, 64, 32, 1), (257, 301, 900, 2), (5, 1, 7, 0),
-                                       (16, 2048, 768, 0), (1100, 800, 260, 1), (20480, 40, 300, 0), (3000, 70, 35, 2)])
+                                       (16, 2048, 768, 0), (1100, 800, 260, 1), (20480, 40, 300, 0), (3000, 70, 35, 2),
+                                       (8200, 512, 301, 1), (4100, 1024, 70, 2), (33000, 128, 64, 0)])
 def test_linear_dense(M, N, K, act):
     from context_attentive_ir_amd import lib
     g = torch.Generator().manual_seed(M * 1000 + N)
@@ -54,6 +55,7 @@ def test_linear_gather_conv():
     V, E, F_, nseq, L = 50, 300, 70, 5, 11
     _gather_conv_case(lib, g, V, E, F_, nseq, L)
     _gather_conv_case(lib, g, 500, 300, 300, 400, 40)       # large enough for the 64x64-tile kernel
+    _gather_conv_case(lib, g, 500, 300, 256, 900, 40)       # N % 128 == 0 and >= 256 tiles: the 128x128-tile kernel
 
 
 def _gather_conv_case(lib, g, V, E, F_, nseq, L):
