@@ -6,6 +6,8 @@ ids (pinned host or device tensors) into those buffers on the capture stream and
 fixed at capture time (one predictor per (B, N, QL, DL) bucket -- the reference's length-bucketing samplers,
 neuroir/inputters/ranker/data.py:37-56, already group batches by shape).
 """
+import ctypes
+
 import torch
 
 
@@ -54,7 +56,12 @@ class GraphedPredictor(object):
                     src = ex[k]
                     if src.shape != hv.shape:
                         raise RuntimeError("GraphedPredictor captured %s with shape %s, got %s" % (k, tuple(hv.shape), tuple(src.shape)))
-                    hv.copy_(src)
+                    if src.dtype != hv.dtype:
+                        raise RuntimeError("GraphedPredictor captured %s as %s, got %s" % (k, hv.dtype, src.dtype))
+                    # plain memmove: torch's copy_ goes parallel above 32K elements, and waking the OpenMP team
+                    # costs 10-20 ms per call on a many-core host (measured, tools/graph_probe.py)
+                    src = src.contiguous()
+                    ctypes.memmove(hv.data_ptr(), src.data_ptr(), hv.numel() * hv.element_size())
                 self.dev_buf.copy_(self.host_buf, non_blocking=True)
             else:
                 for k, buf in self.static.items():
