@@ -118,9 +118,11 @@ def main():
     dev = torch.device("cuda", local)
     backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": flow test without RCCL (gathers through the host)
     dist = None
-    if world > 1:
+    multi = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))   # BENCH_FORCE_DIST: 1-rank group, exercises the RCCL path
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -139,7 +141,7 @@ def main():
         if is_cars:
             return model.predict(ex)["click_scores"]
         s = model.scores(ex)
-        if world > 1:
+        if multi:
             return s
         out = torch.empty_like(s)
         lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
@@ -147,7 +149,7 @@ def main():
 
     def finish(s):
         """cross-rank part (eager): one all-gather of the score shards, then the softmax over all candidates."""
-        if world == 1 or is_cars:
+        if not multi or is_cars:
             return s
         if backend == "nccl":
             s = sharding.gather_scores(s, args.cands * world)
@@ -181,16 +183,42 @@ def main():
             graphs = None
             torch.cuda.synchronize()
 
+    # N > 1: the score all-gather of step k is issued asynchronously (RCCL's own stream) and consumed one step later,
+    # so it overlaps step k+1's scoring kernels; `drain()` completes the last step inside the timed region.
+    pipelined = [multi and not is_cars and backend == "nccl" and not os.environ.get("BENCH_SYNC_GATHER")]
+    pending = []
+
+    def softmax_rows(s):
+        out = torch.empty_like(s)
+        lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
+        return out
+
+    def drain():
+        while pending:
+            softmax_rows(pending.pop(0).wait())
+
     def run(i):
         if graphs is not None:
             g, out = graphs[i % len(graphs)]
             g.replay()
-            finish(out)
         else:
-            step(i)
+            out = forward(i)
+        if pipelined[0]:
+            try:
+                h = sharding.ScoreGather(out, args.cands * world)
+            except Exception as e:  # pragma: no cover - fall back to the blocking gather
+                print("[bench] async all-gather unavailable (%s); using the blocking gather" % e, file=sys.stderr)
+                pipelined[0] = False
+                finish(out)
+                return
+            drain()
+            pending.append(h)
+        else:
+            finish(out)
 
     for i in range(args.warmup):
         run(i)
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -198,6 +226,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         run(i)
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -338,16 +367,25 @@ def main():
                            % (args.model, args.batch, args.cands * world, (" x session %d" % args.session) if is_cars else "",
                               args.qlen, args.dlen, args.vocab, "uniform" if args.uniform else "Zipf"),
                "global_batch_pairs": pairs_per_step_rank * world,
-               "parallelism": "candidate-sharded x%d + RCCL all-gather of scores" % world if world > 1 else "single GPU",
+               "parallelism": ("candidate-sharded x%d + RCCL all-gather of scores%s"
+                               % (world, " (async, consumed one step later)" if pipelined[0] else "")) if world > 1 else "single GPU",
                "hipgraph": graphs is not None,
                "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1)}
         line = {"metric": "ranked (query,doc) pairs/sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
                 "roofline": roofline, "cpu_baseline": cpu}
-        print(json.dumps(line))
+        result_line = json.dumps(line)
+    else:
+        result_line = None
     if dist:
         dist.destroy_process_group()
+    # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it out first so that the
+    # JSON line is the LAST line of rank 0's stdout
+    import ctypes as _ct
+    _ct.CDLL(None).fflush(None)
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -42,6 +42,26 @@ def gather_scores(local, N, group=None):
     return out.view(world, B, per).permute(1, 0, 2).reshape(B, world * per)[:, :N].contiguous()
 
 
+class ScoreGather(object):
+    """Asynchronous form of gather_scores: the all-gather is issued on the backend's communication stream when
+    the object is built and `wait()` (typically called one batch later) returns the [B,N] scores.  Between the two,
+    the caller's stream is free, so batch k's gather overlaps batch k+1's scoring (SURVEY.md section 8e:
+    "overlap batch k's gather with batch k+1's document encoding")."""
+
+    def __init__(self, local, N, group=None):
+        world = dist.get_world_size(group)
+        self.B, self.per = local.shape
+        self.N, self.world = N, world
+        self.local = local.contiguous()                  # kept alive until wait()
+        self.out = torch.empty(world * self.B, self.per, device=local.device, dtype=local.dtype)
+        self.work = dist.all_gather_into_tensor(self.out, self.local, group=group, async_op=True)
+
+    def wait(self):
+        self.work.wait()                                 # device backends: the current stream waits, the host does not
+        s = self.out.view(self.world, self.B, self.per).permute(1, 0, 2).reshape(self.B, self.world * self.per)
+        return s[:, :self.N].contiguous()
+
+
 def sharded_scores(score_fn, doc_rep, doc_len, group=None):
     """score_fn(doc_shard [B,per,DL], len_shard [B,per]) -> [B,per]; returns the full [B,N] on every rank."""
     if not (dist.is_available() and dist.is_initialized()):

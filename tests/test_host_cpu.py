@@ -163,3 +163,39 @@ def test_candidate_sharding_two_rank_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in o, o
+
+
+def _async_gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from context_attentive_ir_amd import sharding
+    try:
+        B, N = 3, 7
+        full = [torch.arange(B * N, dtype=torch.float32).view(B, N) + 100 * k for k in range(3)]
+        per = (N + world - 1) // world
+        handles = []
+        for k in range(3):                       # three batches in flight before the first wait
+            lo, hi, _ = sharding.shard_bounds(N, world, rank)
+            loc = torch.zeros(B, per)
+            loc[:, :hi - lo] = full[k][:, lo:hi]
+            handles.append(sharding.ScoreGather(loc, N))
+        ok = all(torch.equal(h.wait(), full[k]) for k, h in enumerate(handles))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_async_score_gather_two_ranks():
+    """ScoreGather (async all-gather consumed a batch later) returns the same [B,N] as the blocking gather."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    procs = [ctx.Process(target=_async_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
