@@ -49,8 +49,9 @@ def kernel_work(name, B, N, QL, DL, E=300, F=40, Hq=15, Hd=70, C=50):
     w = {
         # BiLSTM recurrence with the input projection fused in: 2 dirs x DL steps x 4H x (H + F) MACs per sequence;
         # HBM: x [DL,F] read once per direction, h [DL,2H] written once
-        "lstm_mfma_kernel<5,28>": dict(flops=M * 2 * DL * 2 * 4 * Hd * (Hd + F), bytes=M * DL * (2 * F + 2 * Hd) * 4),
-        "lstm_mfma_kernel<1,16>": dict(flops=B * 2 * QL * 2 * 4 * Hq * (Hq + F), bytes=B * QL * (2 * F + 2 * Hq) * 4),
+        "lstm_mfma_kernel<5,28,3,1>": dict(flops=M * 2 * DL * 2 * 4 * Hd * (Hd + F), bytes=M * DL * (2 * F + 2 * Hd) * 4),
+        "lstm_mfma_kernel<5,28,4,2>": dict(flops=M * 2 * DL * 2 * 4 * Hd * (Hd + F), bytes=M * DL * (2 * F + 2 * Hd) * 4),
+        "lstm_mfma_kernel<1,16,4,1>": dict(flops=B * 2 * QL * 2 * 4 * Hq * (Hq + F), bytes=B * QL * (2 * F + 2 * Hq) * 4),
         "lstm_rec_kernel[fused]<80>": dict(flops=M * 2 * DL * 2 * 4 * Hd * (Hd + F), bytes=M * DL * (2 * F + 2 * Hd) * 4),
         "lstm_rec_kernel[fused]<16>": dict(flops=B * 2 * QL * 2 * 4 * Hq * (Hq + F), bytes=B * QL * (2 * F + 2 * Hq) * 4),
         # interaction GEMM after folding the query taps: per (i,j) position 15 taps x C channels x 6 filters MACs,

@@ -37,7 +37,12 @@ struct LstmMfmaArgs {
     unsigned long long* dbg;
 };
 
-template <int NG, int KQ>
+// S = sequences a workgroup owns (3 or 4; the MFMA always carries 4 rows, row 3 stays zero for S = 3).  Cell tasks per
+// workgroup = S*H: with S = 4 and H = 70 that is 280 > 256 threads, i.e. two tasks on the critical path of every thread
+// that has any; S = 3 gives 210 tasks = one per thread (cell phase ~halved) and 214 instead of 160 workgroups at
+// M = 320 -- still one round on 256 CUs.  TPT = cell tasks per thread: 1 whenever S*H <= 256 (thread = (unit tid / S,
+// sequence tid % S)), 2 only for S = 4 with 4H > 256.  The launcher picks S from a rounds x step-cost model.
+template <int NG, int KQ, int S, int TPT>
 __global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
     constexpr int NW = 4, KZ = NW * KQ, NC = 64 * NG, SEQ = 4;
     constexpr uint32_t OOB = 0x7FFFFFF0u;
@@ -48,9 +53,9 @@ __global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dir = blockIdx.y;
-    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int64_t m0 = (int64_t)blockIdx.x * S;
     const int H = p.H, I = p.I, T = p.T, H4 = 4 * H;
-    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int nvalid = (int)min((int64_t)S, p.M - m0);
     const int OW = p.ND * H;
     const int myseq = tid & 3;                     // the sequence this thread serves in every role
 
@@ -101,10 +106,14 @@ __global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
         const uint32_t off = (xrole && step < mylen) ? (uint32_t)((myseq * T + t) * I + xi) * 4u : OOB;
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rs, off, 0, 0));   // OOB -> 0
     };
-    // cell role: thread (unit cj = tid >> 1, sequence pair cs = 2*(tid & 1)) finalises sequences cs and cs+1
-    const int cj = tid >> 1, cs = 2 * (tid & 1);
+    // cell role.  TPT == 2: thread (unit cj = tid >> 1, sequence pair cs = 2*(tid & 1)) finalises sequences cs and cs+1;
+    //             TPT == 1: thread (unit cj = tid / S, sequence cs = tid % S) finalises one sequence.
+    static_assert(TPT == 1 || S == 4, "two tasks per thread only in the 4-sequence layout");
+    const int cj = TPT == 2 ? tid >> 1 : tid / S;
+    const int cs = TPT == 2 ? 2 * (tid & 1) : tid - S * cj;
     const bool cuv = cj < H;
-    const int clen0 = cs == 0 ? len4[0] : len4[2], clen1 = cs == 0 ? len4[1] : len4[3];
+    const int clen0 = cs == 0 ? len4[0] : cs == 1 ? len4[1] : cs == 2 ? len4[2] : len4[3];
+    const int clen1 = TPT == 2 ? (cs == 0 ? len4[1] : len4[3]) : 0;
     float creg0 = 0.f, creg1 = 0.f;
     if (cuv) {   // initial state: h0 / c0
         if (cs < nvalid) {
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
             if (p.c0) creg0 = p.c0[si];
             if (p.h0) z[cs * KZ + cj] = p.h0[si];
         }
-        if (cs + 1 < nvalid) {
+        if (TPT == 2 && cs + 1 < nvalid) {
             const int64_t si = ((int64_t)dir * p.M + m0 + cs + 1) * H + cj;
             if (p.c0) creg1 = p.c0[si];
             if (p.h0) z[(cs + 1) * KZ + cj] = p.h0[si];
@@ -152,8 +161,8 @@ __global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
         LM_STAMP(1);
         lds_barrier();
         LM_STAMP(2);
-        // ---- cell update: thread = (unit cj, sequences cs, cs+1): 16 ds_read_b64 of the wave partials, one round
-        {
+        // ---- cell update: 4 wave partials + bias per gate, c_t stays in a register
+        if constexpr (TPT == 2) {
             const int jj = cuv ? cj : 0;
             float ga[4], gb[4];
 #pragma unroll
@@ -183,6 +192,23 @@ __global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
             const uint32_t off1 = act1 ? (uint32_t)(((cs + 1) * T + t1i) * OW + dir * H + cj) * 4u : OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h0v), out_rs, off0, 0, 0);   // OOB lanes dropped
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h1v), out_rs, off1, 0, 0);
+        } else {
+            const int jj = cuv ? cj : 0;
+            float ga[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * H + jj;
+                ga[g] = bias_s[col] + part[(0 * NC + col) * SEQ + cs] + part[(1 * NC + col) * SEQ + cs] +
+                        part[(2 * NC + col) * SEQ + cs] + part[(3 * NC + col) * SEQ + cs];
+            }
+            const float c0 = fast_sigmoid(ga[1]) * creg0 + fast_sigmoid(ga[0]) * fast_tanh(ga[2]);
+            const float h0v = fast_sigmoid(ga[3]) * fast_tanh(c0);
+            const bool act0 = cuv && step < clen0;
+            if (act0) creg0 = c0;
+            if (cuv) zn[cs * KZ + cj] = act0 ? h0v : zc[cs * KZ + cj];
+            const int t0i = dir == 0 ? step : clen0 - 1 - step;
+            const uint32_t off0 = act0 ? (uint32_t)((cs * T + t0i) * OW + dir * H + cj) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h0v), out_rs, off0, 0, 0);   // OOB lanes dropped
         }
         if (xrole) zn[myseq * KZ + H + xi] = xcur;
         LM_STAMP(3);
@@ -194,7 +220,7 @@ __global__ __launch_bounds__(256) void lstm_mfma_kernel(LstmMfmaArgs p) {
     const float* zf = z + (tmax & 1) * SEQ * KZ;
     if (cuv) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < TPT; ++u) {
             const int sq = cs + u;
             if (sq < nvalid) {
                 const int l = u == 0 ? clen0 : clen1;
@@ -370,14 +396,33 @@ int launch_bilstm_mfma(const float* gin, const int64_t* lens, const float* whh, 
     return NIR_ERR_UNSUPPORTED;
 }
 
-template <int NG, int KQ>
-static int launch_mfma(const LstmMfmaArgs& p, hipStream_t st) {
-    static const std::string pname = "lstm_mfma_kernel<" + std::to_string(NG) + "," + std::to_string(KQ) + ">";
+template <int NG, int KQ, int S, int TPT>
+static int launch_mfma_s(const LstmMfmaArgs& p, hipStream_t st) {
+    static const std::string pname = "lstm_mfma_kernel<" + std::to_string(NG) + "," + std::to_string(KQ) + "," + std::to_string(S) + "," + std::to_string(TPT) + ">";
     constexpr size_t lds = (size_t)(2 * 4 * 4 * KQ + 4 * 64 * NG * 4 + 64 * NG) * 4;
     ProfScope ps(pname.c_str(), st);
-    hipLaunchKernelGGL((lstm_mfma_kernel<NG, KQ>), dim3((unsigned)((p.M + 3) / 4), (unsigned)p.ND), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((lstm_mfma_kernel<NG, KQ, S, TPT>), dim3((unsigned)((p.M + S - 1) / S), (unsigned)p.ND), dim3(256), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fused_fwd[mfma]");
     return 0;
+}
+
+// Layout choice.  4H <= 256: four sequences, one cell task per thread.  Otherwise (3H <= 256 holds for every
+// instantiated NG <= 5) three sequences with one task per thread against four with two: rounds over the 256 CUs x
+// per-step cost (measured at H = 70: the S = 3 step costs ~0.85 of the S = 4 / two-task step).
+template <int NG, int KQ>
+static int launch_mfma(const LstmMfmaArgs& p, hipStream_t st) {
+    if constexpr (NG <= 4) {
+        if (4 * p.H <= 256) return launch_mfma_s<NG, KQ, 4, 1>(p, st);
+    }
+    bool three = false;
+    const char* force = getenv("NIR_LSTM_MFMA_S");
+    if (force) {
+        three = atoi(force) == 3;
+    } else {
+        const int64_t wg4 = ((p.M + 3) / 4) * p.ND, wg3 = ((p.M + 2) / 3) * p.ND;
+        three = (double)((wg3 + 255) / 256) * 0.85 < (double)((wg4 + 255) / 256);
+    }
+    return three ? launch_mfma_s<NG, KQ, 3, 1>(p, st) : launch_mfma_s<NG, KQ, 4, 2>(p, st);
 }
 
 // returns NIR_ERR_UNSUPPORTED when the shape has no instantiation (caller falls back to the VALU kernel)
