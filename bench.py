@@ -77,7 +77,8 @@ def parse():
     ap.add_argument("--session", type=int, default=7)
     ap.add_argument("--vocab", type=int, default=100000)
     ap.add_argument("--uniform", action="store_true", help="uniform token ids (worst case for the gather) instead of Zipf")
-    ap.add_argument("--nbatches", type=int, default=8, help="distinct resident batches cycled through")
+    ap.add_argument("--nbatches", type=int, default=12, help="distinct resident batches cycled through")
+    ap.add_argument("--streams", type=int, default=3, help="batches in flight: step i runs on HIP stream i %% streams")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -164,19 +165,29 @@ def main():
         return finish(forward(i))
 
     # ---- hipGraph replay of the rank-local forward (removes host launch overhead; the collective stays eager) ----
+    # Steps are independent batches, so `--streams` of them are kept in flight: step i runs on HIP stream (lane)
+    # i % streams.  One batch of 320 pairs cannot fill 256 CUs (the recurrence occupies 214 CUs with 4 waves each), a
+    # second batch's kernels co-run in the idle slots.  Every lane has its own workspace (lib.workspace keys on the
+    # stream) and its own captured graphs, so lanes share only read-only weights.
     graphs = None
     use_graph = not args.no_graph
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    for i in range(max(3, min(args.warmup, 5))):
-        step(i)
+    lanes = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+    if len(lanes) > 1:
+        # with several batches in flight the library's own query/document fork inside one batch buys nothing and its
+        # side-branch makes the graphs compete for hardware queues (measured: 2 lanes 1.66 M pairs/s with, 2.11 M without)
+        os.environ["NIR_NO_FORK"] = "1"
+    lane_of = lambda i: (i % len(batches)) % len(lanes)   # noqa: E731  (a batch/graph always runs on the same lane)
+    torch.cuda.set_stream(lanes[0])
+    for i in range(max(3, min(args.warmup, 5)) * len(lanes)):
+        with torch.cuda.stream(lanes[lane_of(i)]):
+            step(i)
     torch.cuda.synchronize()
     if use_graph:
         try:
             graphs = []
             for i in range(len(batches)):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
+                with torch.cuda.graph(g, stream=lanes[lane_of(i)]):
                     out = forward(i)
                 graphs.append((g, out))
         except Exception as e:  # pragma: no cover - graph capture is an optimisation only
@@ -187,35 +198,39 @@ def main():
     # N > 1: the score all-gather of step k is issued asynchronously (RCCL's own stream) and consumed one step later,
     # so it overlaps step k+1's scoring kernels; `drain()` completes the last step inside the timed region.
     pipelined = [multi and not is_cars and backend == "nccl" and not os.environ.get("BENCH_SYNC_GATHER")]
-    pending = []
+    pending = [[] for _ in lanes]
 
     def softmax_rows(s):
         out = torch.empty_like(s)
         lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
         return out
 
-    def drain():
-        while pending:
-            softmax_rows(pending.pop(0).wait())
+    def drain(lane=None):
+        for ln in range(len(lanes)) if lane is None else [lane]:
+            with torch.cuda.stream(lanes[ln]):
+                while pending[ln]:
+                    softmax_rows(pending[ln].pop(0).wait())
 
-    def run(i):
-        if graphs is not None:
-            g, out = graphs[i % len(graphs)]
-            g.replay()
-        else:
-            out = forward(i)
-        if pipelined[0]:
-            try:
-                h = sharding.ScoreGather(out, args.cands * world)
-            except Exception as e:  # pragma: no cover - fall back to the blocking gather
-                print("[bench] async all-gather unavailable (%s); using the blocking gather" % e, file=sys.stderr)
-                pipelined[0] = False
+    def run(i, only_lane=None):
+        ln = lane_of(i) if only_lane is None else only_lane
+        with torch.cuda.stream(lanes[ln]):
+            if graphs is not None:
+                g, out = graphs[i % len(graphs)]
+                g.replay()
+            else:
+                out = forward(i)
+            if pipelined[0]:
+                try:
+                    h = sharding.ScoreGather(out, args.cands * world)
+                except Exception as e:  # pragma: no cover - fall back to the blocking gather
+                    print("[bench] async all-gather unavailable (%s); using the blocking gather" % e, file=sys.stderr)
+                    pipelined[0] = False
+                    finish(out)
+                    return
+                drain(ln)
+                pending[ln].append(h)
+            else:
                 finish(out)
-                return
-            drain()
-            pending.append(h)
-        else:
-            finish(out)
 
     for i in range(args.warmup):
         run(i)
@@ -242,6 +257,30 @@ def main():
     value = total_pairs / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
+    # for reference: the same steps strictly one after another on a single stream (per-batch latency), and a race check:
+    # the scores the concurrent replays left in the graphs' output buffers must equal a serial replay's bit for bit
+    single_ms = ms_per_step
+    overlap_diff = None
+    if len(lanes) > 1:
+        if graphs is not None and not pipelined[0]:
+            conc = [out.clone() for _, out in graphs]
+            torch.cuda.synchronize()
+            overlap_diff = 0.0
+            for j, (g, out) in enumerate(graphs):
+                g.replay()
+                torch.cuda.synchronize()
+                overlap_diff = max(overlap_diff, float((out - conc[j]).abs().max()))
+        ns = max(10, min(args.steps, 100))
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(ns):
+            run(i, only_lane=0)
+        drain()
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - ts) / ns * 1e3
+        if dist:
+            dist.barrier()
+
     # ---- second number (never `value`): ids start in pinned HOST memory; every step copies them H2D into the static
     # buffers of a captured hipGraph (context_attentive_ir_amd/graph_runner.py) and replays it
     h2d_value = None
@@ -249,14 +288,14 @@ def main():
         try:
             from context_attentive_ir_amd.graph_runner import GraphedPredictor
             host = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in batches]
-            gp = GraphedPredictor(model, batches[0])
+            gps = [GraphedPredictor(model, batches[0]) for _ in lanes]   # one predictor (stream + staging) per lane
             nh = max(10, min(args.steps, 100))
-            for i in range(3):
-                gp.predict(host[i % len(host)], clone=False)
+            for i in range(3 * len(gps)):
+                gps[i % len(gps)].predict(host[i % len(host)], clone=False)
             torch.cuda.synchronize()
             th = time.perf_counter()
             for i in range(nh):
-                gp.predict(host[i % len(host)], clone=False)
+                gps[i % len(gps)].predict(host[i % len(host)], clone=False)
             torch.cuda.synchronize()
             h2d_value = pairs_per_step_rank * nh / (time.perf_counter() - th)
         except Exception as e:  # pragma: no cover - secondary figure only
@@ -273,7 +312,8 @@ def main():
         step(i)
     torch.cuda.synchronize()
     L.nir_profile_enable(0)
-    os.environ.pop("NIR_NO_FORK", None)
+    if len(lanes) == 1:
+        os.environ.pop("NIR_NO_FORK", None)
     if rank == 0:
         buf = ctypes.create_string_buffer(1 << 16)
         L.nir_profile_report(buf, len(buf))
@@ -371,6 +411,9 @@ def main():
                "parallelism": ("candidate-sharded x%d + RCCL all-gather of scores%s"
                                % (world, " (async, consumed one step later)" if pipelined[0] else "")) if world > 1 else "single GPU",
                "hipgraph": graphs is not None,
+               "batches_in_flight": len(lanes),
+               "ms_per_step_one_batch_in_flight": round(single_ms, 5),
+               "overlapped_vs_serial_max_abs_diff": overlap_diff,
                "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1)}
         line = {"metric": "ranked (query,doc) pairs/sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,

@@ -80,14 +80,14 @@ extern "C" int nir_profile_report(char* buf, size_t cap) {
 namespace nir {
 struct SideRes { hipStream_t side = nullptr; hipEvent_t f = nullptr, j = nullptr; bool ok = false; };
 static std::mutex g_side_mu;
-static std::map<int, SideRes> g_side;
+static std::map<std::pair<int, hipStream_t>, SideRes> g_side;   // one side stream + event pair per (device, caller stream)
 
 ForkJoin::ForkJoin(hipStream_t main_stream) : main(main_stream), side(main_stream), ev_fork(nullptr), ev_join(nullptr), ok(false) {
     if (getenv("NIR_NO_FORK")) return;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lk(g_side_mu);
-    SideRes& r = g_side[dev];
+    SideRes& r = g_side[std::make_pair(dev, main_stream)];   // callers on different streams never share events
     if (!r.side) {
         r.ok = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&r.f, hipEventDisableTiming) == hipSuccess &&
