@@ -8,6 +8,7 @@
 // 16-byte slots (conflict-free).  The 4 floats feed 4 successive MFMAs; the k-order inside an 8-wide group
 // is permuted identically for A and W (lane>>5 selects which half), which leaves the sum unchanged.
 #include "common.hpp"
+#include <algorithm>
 #include <stdlib.h>
 
 namespace nir {
@@ -281,6 +282,125 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p) {
     }
 }
 
+// Skinny-N path (N <= 64 over many rows: MatchTensor's 300 -> 40 embedding projection and 140 -> 50 channel projection on
+// M = B*N*DL token rows).  The 64x64 tiling wastes 37 % of its N tile there and, with K = 140..300, spends most of a
+// block's life in prologue/epilogue.  Here W (zero padded to 16*NT x Kp) is resident in LDS for the whole workgroup, a wave
+// owns a 16-row tile, reads its A rows straight from global/L2 as MFMA fragments (lane (i = lane & 15, g = lane >> 4)
+// takes k = 16q + 4g .. +3 of row i: one float4 feeds 4 v_mfma_f32_16x16x4_f32 per 16-column tile) with the loads of the
+// next 4 k-groups in flight behind the MFMAs of the current 4, and loops over tiles persistently.
+constexpr int SK_WAVES = 8, SK_CH = 4;
+
+template <int NT>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, int G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Kp = G * 16, LD = Kp + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int nch = (G + SK_CH - 1) / SK_CH;
+    const int64_t ntiles = (p.M + 15) / 16;
+    const int64_t tstep = (int64_t)gridDim.x * SK_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * SK_WAVES + wave;
+
+    auto row_ptr = [&](int64_t t) -> const float* {
+        const int64_t m = t * 16 + i;
+        if (t >= ntiles || m >= p.M) return nullptr;
+        if (p.ids) return p.table + p.ids[(m / p.rows_per_seq) * p.seq_stride + (m % p.rows_per_seq)] * (int64_t)p.E;
+        return p.a + m * p.lda;
+    };
+    auto load_chunk = [&](const float* arow, int c, float4 (&dst)[SK_CH]) {
+#pragma unroll
+        for (int j = 0; j < SK_CH; ++j) {
+            const int k = (c * SK_CH + j) * 16 + 4 * g;
+            dst[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (arow && k < p.K) dst[j] = *reinterpret_cast<const float4*>(arow + k);
+        }
+    };
+    // the first tile's id -> row -> data chain starts before W is staged, so the two latencies overlap
+    const float* arow = row_ptr(tile);
+    float4 a0[SK_CH], a1[SK_CH];
+    load_chunk(arow, 0, a0);
+    float bsum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = 16 * t + i;
+        bsum[t] = 0.f;
+        if (n < p.N) {
+            if (p.bias) bsum[t] += p.bias[n];
+            if (p.bias2) bsum[t] += p.bias2[n];
+        }
+    }
+    {   // W -> LDS, 8 loads in flight per thread (a load->store loop would expose one memory round trip per iteration)
+        const int kq = Kp / 4, total = 16 * NT * kq;
+        for (int e0 = tid; e0 < total; e0 += 8 * 64 * SK_WAVES) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 64 * SK_WAVES;
+                const int n = e / kq, k = (e - n * kq) * 4;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < total && n < p.N && k < p.K) v[u] = *reinterpret_cast<const float4*>(p.w + (int64_t)n * p.ldw + k);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 64 * SK_WAVES;
+                const int n = e / kq, k = (e - n * kq) * 4;
+                if (e < total) *reinterpret_cast<float4*>(&smem[n * LD + k]) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    const float* wl = smem + i * LD + 4 * g;
+    for (; tile < ntiles; tile += tstep) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto mma_chunk = [&](int c, const float4 (&a)[SK_CH]) {
+#pragma unroll
+            for (int j = 0; j < SK_CH; ++j) {
+                const int q = c * SK_CH + j;
+                if (q < G) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(wl + 16 * t * LD + q * 16);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b4.x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b4.y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b4.z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b4.w, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        const float* next_row = nullptr;
+        for (int c = 0; c < nch; c += 2) {
+            if (c + 1 < nch) load_chunk(arow, c + 1, a1);
+            else next_row = row_ptr(tile + tstep);           // last chunk pair: start the next tile's id -> row chain
+            mma_chunk(c, a0);
+            if (c + 2 < nch) load_chunk(arow, c + 2, a0);
+            else if (c + 1 < nch) next_row = row_ptr(tile + tstep);
+            if (c + 1 < nch) mma_chunk(c + 1, a1);
+        }
+        load_chunk(next_row, 0, a0);                          // in flight behind this tile's epilogue
+        arow = next_row;
+        // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gemm_store(p, tile * 16 + g * 4 + r, 16 * t + i, acc[t][r], bsum[t]);
+    }
+}
+
+template <int NT>
+static void launch_skinny(const GemmArgs& p, int G, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)gemm_skinny_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_done = true;
+    }
+    const int64_t ntiles = (p.M + 15) / 16;
+    const unsigned grid = (unsigned)std::min<int64_t>((ntiles + SK_WAVES - 1) / SK_WAVES, 512);
+    hipLaunchKernelGGL(gemm_skinny_kernel<NT>, dim3(grid), dim3(64 * SK_WAVES), lds, st, p, G);
+}
+
 // One wave per output row.
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* x, int64_t ldx, const float* w, const float* b,
                                                      float* out, int64_t M, int K, int act) {
@@ -313,7 +433,15 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     else vec = vec && (lda % 4 == 0) && (((uintptr_t)a & 15) == 0);
     const int64_t mb = (M + BM - 1) / BM;
     const int nb = (N + BN - 1) / BN;
-    if (mb * nb < 160 && !getenv("NIR_NO_GEMM16")) {
+    const int skG = (K + 15) / 16, skNT = (N + 15) / 16;
+    const size_t sk_lds = (size_t)16 * skNT * (skG * 16 + 4) * 4;
+    if (N <= 64 && vec && M >= 4096 && (!ids || K <= E) && sk_lds <= 128 * 1024 && act != ACT_MAXOUT2 && !getenv("NIR_NO_SKINNY")) {
+        ProfScope ps(ids ? "gemm_skinny_kernel[gather]" : "gemm_skinny_kernel", st);
+        if (skNT == 1) launch_skinny<1>(p, skG, sk_lds, st);
+        else if (skNT == 2) launch_skinny<2>(p, skG, sk_lds, st);
+        else if (skNT == 3) launch_skinny<3>(p, skG, sk_lds, st);
+        else launch_skinny<4>(p, skG, sk_lds, st);
+    } else if (mb * nb < 160 && !getenv("NIR_NO_GEMM16")) {
         // too few 64x64 tiles to fill 256 CUs: one 16x16 tile per workgroup, K split over the waves
         ProfScope ps(ids ? "gemm16_kernel[gather]" : "gemm16_kernel", st);
         dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));

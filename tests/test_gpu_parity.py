@@ -34,7 +34,8 @@ def _synth(rng, B, N, QL, DL, V, full=False):
 # ------------------------------------------------------------------ building blocks
 @pytest.mark.parametrize("M,N,K,act", [(37, 40, 300, 0), (130, 50, 30, 0), (64, 64, 32, 1), (257, 301, 900, 2), (5, 1, 7, 0),
                                        (16, 2048, 768, 0), (1100, 800, 260, 1), (20480, 40, 300, 0), (3000, 70, 35, 2),
-                                       (8200, 512, 301, 1), (4100, 1024, 70, 2), (33000, 128, 64, 0)])
+                                       (8200, 512, 301, 1), (4100, 1024, 70, 2), (33000, 128, 64, 0),
+                                       (5000, 50, 140, 0), (4100, 64, 300, 1), (4097, 17, 20, 2), (20481, 33, 8, 0)])
 def test_linear_dense(M, N, K, act):
     from context_attentive_ir_amd import lib
     g = torch.Generator().manual_seed(M * 1000 + N)
@@ -56,6 +57,22 @@ def test_linear_gather_conv():
     _gather_conv_case(lib, g, V, E, F_, nseq, L)
     _gather_conv_case(lib, g, 500, 300, 300, 400, 40)       # large enough for the 64x64-tile kernel
     _gather_conv_case(lib, g, 500, 300, 256, 900, 40)       # N % 128 == 0 and >= 256 tiles: the 128x128-tile kernel
+
+
+def test_linear_gather_skinny():
+    """Embedding gather + Linear(E -> N <= 64) over many token rows: the LDS-resident-W skinny kernel (PAD row stays zero)."""
+    from context_attentive_ir_amd import lib
+    g = torch.Generator().manual_seed(11)
+    for V, E, N, M in ((300, 300, 40, 20608), (50, 64, 64, 4099), (1000, 300, 7, 9000)):
+        table = torch.randn(V, E, generator=g); table[0] = 0
+        ids = torch.randint(0, V, (M,), generator=g)
+        w = torch.randn(N, E, generator=g) / E ** 0.5; b = torch.randn(N, generator=g)
+        ref = torch.tanh(table[ids] @ w.t() + b)
+        idd, td, wd, bd = ids.to(DEV), table.to(DEV), w.to(DEV), b.to(DEV)
+        out = torch.empty(M, N, device=DEV)
+        lib.check(lib.load().nir_linear_f32(None, 0, lib.ptr(idd), lib.ptr(td), E, 1, 1, lib.ptr(wd), E, lib.ptr(bd), None,
+                                            lib.ptr(out), N, M, N, E, 1, lib.stream()), "linear")
+        _close(out, ref, 2e-5)
 
 
 def _gather_conv_case(lib, g, V, E, F_, nseq, L):
