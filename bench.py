@@ -27,7 +27,9 @@ import time
 # The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With 4 batches in
 # flight plus torch's own streams that leaves no spare queue and lanes serialise behind each other (measured: 2.35 M
 # pairs/s at 4 queues, 3.13 M at 8).  Must be set before the HIP runtime initialises, i.e. before `import torch`.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (With a single lane the default of 4 is kept: 8 queues measured slower there.)
+if not ("--streams" in sys.argv and sys.argv[sys.argv.index("--streams") + 1:][:1] == ["1"]):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -159,12 +161,24 @@ def main():
         if not multi or is_cars:
             return s
         if backend == "nccl":
-            s = sharding.gather_scores(s, args.cands * world)
-        else:
-            s = sharding.gather_scores(s.cpu(), args.cands * world).to(dev)
+            # blocking gather into this lane's persistent buffer (the lane waits, the other lanes keep the GPU busy; a
+            # blocking collective also keeps torch's allocator free of cross-stream bookkeeping), then ONE kernel that
+            # does the softmax straight off the rank-major gather buffer
+            ln = lanes.index(torch.cuda.current_stream()) if torch.cuda.current_stream() in lanes else 0
+            if fbufs[ln] is None:
+                fbufs[ln] = (torch.empty(world * s.shape[0], s.shape[1], device=dev),
+                             torch.empty(s.shape[0], args.cands * world, device=dev))
+            gbuf, probs = fbufs[ln]
+            dist.all_gather_into_tensor(gbuf, s.contiguous())
+            lib.check(L.nir_softmax_gathered(lib.ptr(gbuf), lib.ptr(probs), None, world, s.shape[0], s.shape[1],
+                                             args.cands * world, lib.stream()), "nir_softmax_gathered")
+            return probs
+        s = sharding.gather_scores(s.cpu(), args.cands * world).to(dev)
         out = torch.empty_like(s)
         lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
         return out
+
+    fbufs = []          # per-lane (gather buffer, probabilities), filled once the lanes exist
 
     def step(i):
         return finish(forward(i))
@@ -177,6 +191,7 @@ def main():
     graphs = None
     use_graph = not args.no_graph
     lanes = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+    fbufs.extend([None] * len(lanes))
     if len(lanes) > 1:
         # with several batches in flight the library's own query/document fork inside one batch buys nothing and its
         # side-branch makes the graphs compete for hardware queues (measured: 2 lanes 1.66 M pairs/s with, 2.11 M without)
@@ -200,21 +215,28 @@ def main():
             graphs = None
             torch.cuda.synchronize()
 
-    # N > 1: the score all-gather of step k is issued asynchronously (RCCL's own stream) and consumed one step later,
-    # so it overlaps step k+1's scoring kernels; `drain()` completes the last step inside the timed region.
-    pipelined = [multi and not is_cars and backend == "nccl" and not os.environ.get("BENCH_SYNC_GATHER")]
+    # N > 1 with ONE batch in flight: the score all-gather of step k is issued asynchronously (RCCL's own stream) and
+    # consumed one step later, so it overlaps step k+1's scoring kernels; `drain()` completes the last step inside the
+    # timed region.  With several lanes the other lanes already cover a lane's gather latency, and chaining every lane's
+    # deferred wait through the single RCCL stream measured slower (1-rank RCCL group: 0.122 vs 0.100 ms/step), so the
+    # lane simply waits for its own gather.  BENCH_ASYNC_GATHER=1 / BENCH_SYNC_GATHER=1 force either behaviour.
+    want_async = len(lanes) == 1 or bool(os.environ.get("BENCH_ASYNC_GATHER"))
+    pipelined = [multi and not is_cars and backend == "nccl" and want_async and not os.environ.get("BENCH_SYNC_GATHER")]
     pending = [[] for _ in lanes]
 
-    def softmax_rows(s):
-        out = torch.empty_like(s)
-        lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
-        return out
+    # caller-owned gather / probability buffers, two per lane (a lane has at most one gather outstanding)
+    gbufs = [[None, None] for _ in lanes]
+    pbufs = [[None, None] for _ in lanes]
+    gparity = [0 for _ in lanes]
 
     def drain(lane=None):
         for ln in range(len(lanes)) if lane is None else [lane]:
             with torch.cuda.stream(lanes[ln]):
                 while pending[ln]:
-                    softmax_rows(pending[ln].pop(0).wait())
+                    h, par = pending[ln].pop(0)
+                    if pbufs[ln][par] is None:
+                        pbufs[ln][par] = torch.empty(h.B, h.N, device=dev)
+                    h.softmax(pbufs[ln][par])
 
     def run(i, only_lane=None):
         ln = lane_of(i) if only_lane is None else only_lane
@@ -226,14 +248,18 @@ def main():
                 out = forward(i)
             if pipelined[0]:
                 try:
-                    h = sharding.ScoreGather(out, args.cands * world)
+                    par = gparity[ln]
+                    gparity[ln] ^= 1
+                    if gbufs[ln][par] is None:
+                        gbufs[ln][par] = torch.empty(world * out.shape[0], out.shape[1], device=dev)
+                    h = sharding.ScoreGather(out, args.cands * world, out=gbufs[ln][par])
                 except Exception as e:  # pragma: no cover - fall back to the blocking gather
                     print("[bench] async all-gather unavailable (%s); using the blocking gather" % e, file=sys.stderr)
                     pipelined[0] = False
                     finish(out)
                     return
                 drain(ln)
-                pending[ln].append(h)
+                pending[ln].append((h, par))
             else:
                 finish(out)
 
@@ -248,6 +274,7 @@ def main():
     for i in range(args.steps):
         run(i)
     drain()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3     # host enqueue time per step (diagnostic)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -420,6 +447,7 @@ def main():
                                % (world, " (async, consumed one step later)" if pipelined[0] else "")) if world > 1 else "single GPU",
                "hipgraph": graphs is not None,
                "batches_in_flight": len(lanes),
+               "host_enqueue_ms_per_step": round(host_ms, 5),
                "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                "ms_per_step_one_batch_in_flight": round(single_ms, 5),
                "overlapped_vs_serial_max_abs_diff": overlap_diff,

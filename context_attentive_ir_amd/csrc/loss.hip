@@ -21,6 +21,28 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, floa
     for (int i = lane; i < n; i += 64) out[r * n + i] = expf(x[i] - mx) / s;
 }
 
+// Softmax over the candidates of a query straight from the rank-major all-gather buffer [world][B][per] (what
+// all_gather_into_tensor leaves on every rank): candidate n of query b lives at ((n / per) * B + b) * per + n % per.
+// Writes the query-major [B][N] probabilities (N <= world*per drops the padded tail); optionally also the raw scores.
+__global__ __launch_bounds__(256) void softmax_gathered_kernel(const float* in, float* probs, float* scores, int world,
+                                                               int64_t B, int per, int N) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    auto at = [&](int n) { return in[((int64_t)(n / per) * B + b) * per + (n % per)]; };
+    float mx = -INFINITY;
+    for (int i = lane; i < N; i += 64) mx = fmaxf(mx, at(i));
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < N; i += 64) s += expf(at(i) - mx);
+    s = wave_sum(s);
+    for (int i = lane; i < N; i += 64) {
+        const float v = at(i);
+        probs[b * N + i] = expf(v - mx) / s;
+        if (scores) scores[b * N + i] = v;
+    }
+}
+
 // mode 0: BCE with logits, per-element  max(x,0) - x*y + log1p(exp(-|x|));  mode 1: -(log_softmax(x)*y).sum()
 template <int MODE>
 __global__ __launch_bounds__(1024) void rank_loss_kernel(const float* sc, const float* lab, int64_t rows, int n, float* loss) {
@@ -67,6 +89,17 @@ extern "C" int nir_softmax_rows(const float* in, float* out, int64_t rows, int n
     if (rows == 0) return 0;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, rows, n);
     NIR_CHECK_LAUNCH("nir_softmax_rows");
+    return 0;
+}
+
+extern "C" int nir_softmax_gathered(const float* gathered, float* probs, float* scores, int world, int64_t B, int per, int N,
+                                    nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(gathered && probs && world > 0 && B >= 0 && per > 0 && N > 0 && N <= world * per, "softmax_gathered: bad args");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(softmax_gathered_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, gathered, probs,
+                       scores, world, B, per, N);
+    NIR_CHECK_LAUNCH("nir_softmax_gathered");
     return 0;
 }
 

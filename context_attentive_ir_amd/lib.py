@@ -60,6 +60,7 @@ SIGNATURES = {
     "nir_bilstm_supported": (_i, [_i]),
     "nir_bilstm_fused_fwd": (_i, [c_fp, _i, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
     "nir_softmax_rows": (_i, [c_fp, c_fp, _l, _i, c_st]),
+    "nir_softmax_gathered": (_i, [c_fp, c_fp, c_fp, _i, _l, _i, _i, c_st]),
     "nir_rank_loss_bce": (_i, [c_fp, c_fp, _l, _i, c_fp, c_st]),
     "nir_rank_loss_softmax_nll": (_i, [c_fp, c_fp, _l, _i, c_fp, c_st]),
     "nir_esm_score": (_i, [c_ip, c_ip, _i, _i, _i, _i, c_fp, _l, _i, c_fp, c_st]),

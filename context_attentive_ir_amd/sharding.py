@@ -44,22 +44,37 @@ def gather_scores(local, N, group=None):
 
 class ScoreGather(object):
     """Asynchronous form of gather_scores: the all-gather is issued on the backend's communication stream when
-    the object is built and `wait()` (typically called one batch later) returns the [B,N] scores.  Between the two,
+    the object is built and `wait()` / `softmax()` (typically called one batch later) consume it.  Between the two
     the caller's stream is free, so batch k's gather overlaps batch k+1's scoring (SURVEY.md section 8e:
-    "overlap batch k's gather with batch k+1's document encoding")."""
+    "overlap batch k's gather with batch k+1's document encoding").  `out` may be a caller-owned, reused
+    [world*B, per] buffer (no allocation per batch)."""
 
-    def __init__(self, local, N, group=None):
+    def __init__(self, local, N, group=None, out=None):
         world = dist.get_world_size(group)
         self.B, self.per = local.shape
         self.N, self.world = N, world
         self.local = local.contiguous()                  # kept alive until wait()
-        self.out = torch.empty(world * self.B, self.per, device=local.device, dtype=local.dtype)
+        self.out = out if out is not None else torch.empty(world * self.B, self.per, device=local.device, dtype=local.dtype)
         self.work = dist.all_gather_into_tensor(self.out, self.local, group=group, async_op=True)
 
     def wait(self):
+        """-> raw scores [B,N] (query-major, padding removed)."""
         self.work.wait()                                 # device backends: the current stream waits, the host does not
         s = self.out.view(self.world, self.B, self.per).permute(1, 0, 2).reshape(self.B, self.world * self.per)
         return s[:, :self.N].contiguous()
+
+    def softmax(self, probs=None):
+        """-> softmax over the N gathered candidates, [B,N]: one kernel straight off the rank-major gather buffer
+        (device tensors; the CPU/gloo path goes through wait())."""
+        if not self.out.is_cuda:
+            return torch.softmax(self.wait(), -1)
+        from . import lib
+        self.work.wait()
+        if probs is None:
+            probs = torch.empty(self.B, self.N, device=self.out.device, dtype=self.out.dtype)
+        lib.check(lib.load().nir_softmax_gathered(lib.ptr(self.out), lib.ptr(probs), None, self.world, self.B, self.per, self.N,
+                                                  lib.stream()), "nir_softmax_gathered")
+        return probs
 
 
 def sharded_scores(score_fn, doc_rep, doc_len, group=None):

@@ -90,6 +90,11 @@ int nir_bilstm_fused_fwd(const float* x, int I, const float* w_ih, const float* 
 
 /* softmax over the last dim of [rows, n] (models/ranker.py:258, models/multitask.py:279); in/out may alias. */
 int nir_softmax_rows(const float* in, float* out, int64_t rows, int n, nir_stream_t stream);
+/* Multi-GPU tail of Ranker.predict: `gathered` is the rank-major [world][B][per] buffer an all-gather of the
+ * per-rank score shards [B,per] leaves on every rank; writes softmax over the first N <= world*per candidates of each
+ * query as probs [B,N] (models/ranker.py:258 applied to the re-assembled row) and, if scores != NULL, the raw [B,N]. */
+int nir_softmax_gathered(const float* gathered, float* probs, float* scores, int world, int64_t B, int per, int N,
+                         nir_stream_t stream);
 /* mean BCE-with-logits over rows*n entries (models/ranker.py:55-69, multitask/cars.py:603) -> loss[0]. */
 int nir_rank_loss_bce(const float* scores, const float* labels, int64_t rows, int n, float* loss,
                       nir_stream_t stream);

@@ -59,6 +59,20 @@ def test_linear_gather_conv():
     _gather_conv_case(lib, g, 500, 300, 256, 900, 40)       # N % 128 == 0 and >= 256 tiles: the 128x128-tile kernel
 
 
+@pytest.mark.parametrize("world,B,per,N", [(8, 32, 10, 80), (8, 64, 7, 50), (2, 3, 1, 2), (1, 5, 130, 130), (4, 1, 40, 157)])
+def test_softmax_gathered(world, B, per, N):
+    """softmax straight off the rank-major all-gather buffer == softmax of the re-assembled [B,N] score rows."""
+    from context_attentive_ir_amd import lib
+    g = torch.Generator().manual_seed(world * 100 + N)
+    gathered = torch.randn(world, B, per, generator=g) * 3
+    full = gathered.permute(1, 0, 2).reshape(B, world * per)[:, :N]
+    gd = gathered.to(DEV)
+    probs = torch.empty(B, N, device=DEV); raw = torch.empty(B, N, device=DEV)
+    lib.check(lib.load().nir_softmax_gathered(lib.ptr(gd), lib.ptr(probs), lib.ptr(raw), world, B, per, N, lib.stream()), "sg")
+    assert torch.equal(raw.cpu(), full)
+    _close(probs, torch.softmax(full, -1), 1e-6)
+
+
 def test_linear_gather_skinny():
     """Embedding gather + Linear(E -> N <= 64) over many token rows: the LDS-resident-W skinny kernel (PAD row stays zero)."""
     from context_attentive_ir_amd import lib

@@ -181,6 +181,7 @@ def _async_gather_worker(rank, world, port, q):
             loc[:, :hi - lo] = full[k][:, lo:hi]
             handles.append(sharding.ScoreGather(loc, N))
         ok = all(torch.equal(h.wait(), full[k]) for k, h in enumerate(handles))
+        ok = ok and all(torch.allclose(h.softmax(), torch.softmax(full[k], -1)) for k, h in enumerate(handles))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
