@@ -42,6 +42,23 @@ def gather_scores(local, N, group=None):
     return out.view(world, B, per).permute(1, 0, 2).reshape(B, world * per)[:, :N].contiguous()
 
 
+def gathered_softmax(local, N, group=None):
+    """Blocking all-gather of the score shards [B,per] + softmax over the N candidates -> [B,N] on every rank.
+    On a ROCm device the softmax reads the rank-major gather buffer directly (nir_softmax_gathered: no permute/slice
+    copies); on CPU tensors (gloo tests) it is gather_scores + torch.softmax."""
+    if not local.is_cuda:
+        return torch.softmax(gather_scores(local, N, group), -1)
+    from . import lib
+    world = dist.get_world_size(group)
+    B, per = local.shape
+    buf = torch.empty(world * B, per, device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(buf, local.contiguous(), group=group)
+    probs = torch.empty(B, N, device=local.device, dtype=local.dtype)
+    lib.check(lib.load().nir_softmax_gathered(lib.ptr(buf), lib.ptr(probs), None, world, B, per, N, lib.stream()),
+              "nir_softmax_gathered")
+    return probs
+
+
 class ScoreGather(object):
     """Asynchronous form of gather_scores: the all-gather is issued on the backend's communication stream when
     the object is built and `wait()` / `softmax()` (typically called one batch later) consume it.  Between the two

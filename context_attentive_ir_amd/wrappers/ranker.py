@@ -64,6 +64,12 @@ class Ranker(object):
     @torch.no_grad()
     def predict(self, ex):
         """softmax over the candidates (models/ranker.py:236-260)."""
+        if self.parallel and sharding.dist.is_available() and sharding.dist.is_initialized():
+            self.network.eval()
+            q, ql, d, dl = self._inputs(ex)
+            world, rank = sharding.dist.get_world_size(self.group), sharding.dist.get_rank(self.group)
+            dd, ll = sharding.shard_candidates(d, dl, world, rank)
+            return sharding.gathered_softmax(self.network(q, ql, dd, ll), d.shape[1], self.group)
         s = self.scores(ex).contiguous()
         out = torch.empty_like(s)
         lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()),

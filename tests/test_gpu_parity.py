@@ -1,6 +1,8 @@
 """GPU (-m gpu): the HIP path, called through the C-ABI, against (a) the committed golden vectors from the real
 reference and (b) the CPU oracle on seeded synthetic inputs.  Tolerance: 1e-4 absolute on fp32 scores
 (BASELINE.json north_star); integer histogram counts are compared exactly on edge-safe inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -419,3 +421,31 @@ def test_fuzz_cars(B, S, N, QL, DL):
     pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
     s, _, _ = m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"])
     _close(s, ref)
+
+
+def test_parallel_predict_one_rank_rccl():
+    """Ranker.parallelize(): candidate sharding + RCCL all-gather + nir_softmax_gathered, on a 1-rank 'nccl' group, must
+    reproduce the unsharded predict exactly (the N>1 arithmetic is covered by the 2-rank gloo tests on CPU)."""
+    import torch.distributed as dist
+    from context_attentive_ir_amd.wrappers import Ranker
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    started = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+        started = True
+    try:
+        w = Ranker(default_args("MATCH_TENSOR", src_vocab_size=300))
+        fill_module_(w.network, 5)
+        w.cuda()
+        q, ql, d, dl = _synth(np.random.default_rng(3), 4, 7, 5, 33, 300)
+        ex = {"que_rep": q, "que_len": ql, "doc_rep": d, "doc_len": dl}
+        ref, ref_scores = w.predict(ex), w.scores(ex)
+        w.parallelize()
+        assert torch.equal(w.predict(ex).cpu(), ref.cpu())
+        assert torch.equal(w.scores(ex).cpu(), ref_scores.cpu())
+    finally:
+        if started:
+            dist.destroy_process_group()
