@@ -43,7 +43,8 @@ constexpr int KTOT = 15 * CP;                                                   
 // A operand of the interaction GEMM, folded once per query and shared by its N candidates:
 //   U[b][mt][k][r][kk],  r = i*6 + f (row inside the 32-row tile mt),  kk = dj*CP + c
 //   U = sum_di W_k[f][c][di][dj] * Pq[b][i+di-1][c]      (zero for c >= C, rows >= 6*QL)
-// grid (B, 3 convs), block 256
+// grid (B, 3 convs, FOLD_Z element slices), block 256
+constexpr int FOLD_Z = 4;
 __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ pq, MtHeadW w, int QL, int MT, float* __restrict__ U) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];   // Pq[QL][C] | W_k[NF][C+1][3][kw]
     const int b = blockIdx.x, k = blockIdx.y, C = w.C;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ 
     __syncthreads();
     const int rows = MT * 32;
     float* ub = U + (int64_t)b * rows * KTOT;   // per query: [mt][k-slab][32][Kp] laid out as consecutive slabs
-    for (int e = threadIdx.x; e < rows * Kp; e += 256) {
+    for (int e = threadIdx.x + 256 * blockIdx.z; e < rows * Kp; e += 256 * FOLD_Z) {
         const int r = e / Kp, kk = e - r * Kp;
         const int dj = kk / CP, c = kk - dj * CP;
         const int i = r / NFC, f = r - i * NFC;
@@ -382,7 +383,7 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
         {
             ProfScope ps("mt_fold_kernel", qs);
             const size_t flds = (size_t)(((QL * w->C + 3) & ~3) + NFC * (w->C + 1) * 3 * 7) * 4;
-        hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3), dim3(256), flds, qs, pq, hw, QL, MT, p.U);
+        hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3, FOLD_Z), dim3(256), flds, qs, pq, hw, QL, MT, p.U);
         }
         NIR_CHECK_LAUNCH("mt_fold_kernel");
     }
