@@ -57,6 +57,7 @@ struct ForkJoin {
 
 // Optional device debug buffer (nir_debug_set_buffer): kernels that support it drop s_memtime stamps there.
 extern unsigned long long* g_debug_buf;
+extern int g_batches_in_flight;   // nir_set_batches_in_flight(): > 1 -> favour chip throughput over single-call latency
 
 constexpr int WAVE = 64;
 

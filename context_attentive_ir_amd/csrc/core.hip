@@ -83,7 +83,7 @@ static std::mutex g_side_mu;
 static std::map<std::pair<int, hipStream_t>, SideRes> g_side;   // one side stream + event pair per (device, caller stream)
 
 ForkJoin::ForkJoin(hipStream_t main_stream) : main(main_stream), side(main_stream), ev_fork(nullptr), ev_join(nullptr), ok(false) {
-    if (getenv("NIR_NO_FORK")) return;
+    if (getenv("NIR_NO_FORK") || g_batches_in_flight > 1) return;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lk(g_side_mu);
@@ -106,7 +106,12 @@ void ForkJoin::join() {
 }
 }  // namespace nir
 
-namespace nir { unsigned long long* g_debug_buf = nullptr; }
+namespace nir { unsigned long long* g_debug_buf = nullptr; int g_batches_in_flight = 1; }
+extern "C" int nir_set_batches_in_flight(int n) {
+    const int old = nir::g_batches_in_flight;
+    nir::g_batches_in_flight = n < 1 ? 1 : n;
+    return old;
+}
 extern "C" int nir_debug_set_buffer(void* dev_u64) { nir::g_debug_buf = (unsigned long long*)dev_u64; return 0; }
 
 // Debug: effective shader clock.  Each workgroup runs a dependent FMA chain and records s_memtime (shader clock)

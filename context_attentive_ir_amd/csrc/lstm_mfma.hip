@@ -418,7 +418,9 @@ static int launch_mfma(const LstmMfmaArgs& p, hipStream_t st) {
     const char* force = getenv("NIR_LSTM_MFMA_S");
     if (force) {
         three = atoi(force) == 3;
-    } else {
+    } else if (g_batches_in_flight <= 1) {
+        // (with several batches in flight the 4-sequence layout wins: all 4 MFMA rows carry work and 160 workgroups of
+        //  one batch leave CUs for the next -- measured 3.69 M vs 3.36 M pairs/s at 4 batches in flight)
         const int64_t wg4 = ((p.M + 3) / 4) * p.ND, wg3 = ((p.M + 2) / 3) * p.ND;
         three = (double)((wg3 + 255) / 256) * 0.85 < (double)((wg4 + 255) / 256);
     }

@@ -52,6 +52,7 @@ SIGNATURES = {
     "nir_last_error_string": (C.c_char_p, []),
     "nir_debug_clock_probe": (_i, [C.c_void_p, _i, _i, C.c_void_p, c_st]),
     "nir_debug_set_buffer": (_i, [C.c_void_p]),
+    "nir_set_batches_in_flight": (_i, [_i]),
     "nir_profile_enable": (_i, [_i]),
     "nir_profile_report": (_i, [C.c_char_p, _z]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),

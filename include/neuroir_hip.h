@@ -35,6 +35,13 @@ typedef void* nir_stream_t; /* hipStream_t */
 int nir_version(void);
 const char* nir_last_error_string(void);
 
+/* Scheduling hint (process-wide, default 1): how many independent batches the caller keeps in flight on separate
+ * streams.  One MSMARCO-sized batch cannot fill 256 CUs, so with n == 1 the library optimises the latency of a single
+ * call (query chain forked onto a side stream, recurrence spread over more, smaller workgroups); with n > 1 other
+ * batches fill the idle slots and it optimises chip throughput instead (no internal fork -- every extra stream
+ * competes for a hardware queue -- and fuller workgroups).  Results are identical either way.  Returns the old value. */
+int nir_set_batches_in_flight(int n);
+
 /* Per-kernel timing for bench.py's roofline block: while enabled, every kernel launch of this library is
  * bracketed by two hipEvents recorded on its own stream.  nir_profile_report synchronises those events and
  * writes "kernel_name,launches,total_ms\n" lines (aggregated by kernel) into a HOST buffer; returns the number

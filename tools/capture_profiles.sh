@@ -8,7 +8,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-SERIAL="python $REPO/bench.py --streams 1 --no-graph --steps 50 --warmup 5 --no-cpu-baseline"
+# NIR_LSTM_MFMA_S=4: the recurrence layout the default (4 batches in flight) run uses, so the kernels are the same ones
+SERIAL="env NIR_LSTM_MFMA_S=4 python $REPO/bench.py --streams 1 --no-graph --steps 50 --warmup 5 --no-cpu-baseline"
 # 1. per-kernel durations, one batch in flight, eager launches (every launch attributed, kernels not stretched by overlap)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o s -- $SERIAL > $OUT/stats_serial.log 2>&1
 # 2. the default command (4 batches in flight, hipGraph replay): durations include co-running kernels of other batches
