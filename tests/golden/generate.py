@@ -232,7 +232,57 @@ def gen_losses_metrics():
          R3=np.asarray(ltorank.recall_at_k(pred, lab, 3)), NDCG3=np.asarray(ltorank.NDCG_at_k(pred, lab, 3)))
 
 
+def gen_batchify():
+    """Input contract: the reference's own collate functions on ragged synthetic examples."""
+    from neuroir.inputters.ranker.vector import batchify as ranker_batchify
+    from neuroir.inputters.multitask.vector import batchify as session_batchify
+    rng = np.random.default_rng(SEED + 77)
+    B, N = 5, 4
+    qlens = rng.integers(1, 7, size=B); dlens = rng.integers(1, 23, size=(B, N))
+    qflat = rng.integers(4, V, size=int(qlens.sum())); dflat = rng.integers(4, V, size=int(dlens.sum()))
+    labels = rng.integers(0, 2, size=(B, N))
+    batch, qo, do = [], 0, 0
+    for b in range(B):
+        q = qflat[qo:qo + qlens[b]]; qo += qlens[b]
+        docs = []
+        for n in range(N):
+            docs.append(torch.LongTensor(dflat[do:do + dlens[b, n]])); do += dlens[b, n]
+        batch.append({"id": b, "query_words": torch.LongTensor(q), "doc_words": docs, "label": torch.LongTensor(labels[b]),
+                      "num_candidates": N, "max_doc_len": int(dlens[b].max()), "max_query_len": int(qlens[b])})
+    out = ranker_batchify(batch)
+    arrs = dict(r_qlens=qlens, r_dlens=dlens, r_qflat=qflat, r_dflat=dflat, r_labels=labels,
+                **{"r_out_" + k: out[k] for k in ("doc_rep", "doc_len", "que_rep", "que_len", "label")})
+    # sessions: S fixed per batch, per-session maxima differ
+    Bs, S, Ns = 3, 4, 3
+    sess = []
+    for b in range(Bs):
+        ql, dl, tl = int(rng.integers(2, 6)), int(rng.integers(3, 12)), int(rng.integers(2, 6))
+        sl = rng.integers(1, ql + 1, size=S); sl[rng.integers(0, S)] = ql
+        dls = rng.integers(1, dl + 1, size=(S, Ns)); dls[0, 0] = dl
+        tls = rng.integers(1, tl + 1, size=S - 1); tls[0] = tl
+        sw = rng.integers(4, V, size=(S, ql)); sw[np.arange(ql)[None] >= sl[:, None]] = 0
+        dw = rng.integers(4, V, size=(S, Ns, dl)); dw[np.arange(dl)[None, None] >= dls[..., None]] = 0
+        tw = rng.integers(4, V, size=(S - 1, tl)); tw[np.arange(tl)[None] >= tls[:, None]] = 0
+        ts = rng.integers(4, V, size=(S - 1, tl)); ts[np.arange(tl)[None] >= tls[:, None]] = 0
+        lab = rng.integers(0, 2, size=(S, Ns))
+        sess.append({"id": b, "source_tokens": None, "target_tokens": None, "session_len": S, "num_candidates": Ns,
+                     "source_words": torch.LongTensor(sw), "source_lens": torch.LongTensor(sl),
+                     "target_words": torch.LongTensor(tw), "target_lens": torch.LongTensor(tls), "target_seq": torch.LongTensor(ts),
+                     "document_words": torch.LongTensor(dw), "document_lens": torch.LongTensor(dls),
+                     "document_labels": torch.LongTensor(lab), "max_source_len": ql, "max_target_len": tl,
+                     "max_document_len": dl})
+    sout = session_batchify(sess)
+    keys = ("source_words", "source_lens", "target_words", "target_lens", "target_seq", "document_words", "document_lens",
+            "document_labels")
+    for b, ex in enumerate(sess):
+        for k in keys:
+            arrs["s_in%d_%s" % (b, k)] = ex[k]
+    arrs.update({"s_out_" + k: sout[k] for k in keys})
+    arrs["s_out_document_labels_is_float"] = np.asarray(sout["document_labels"].dtype == torch.float32)
+    save("batchify", **arrs)
+
+
 if __name__ == "__main__":
     torch.manual_seed(SEED)
     torch.set_num_threads(4)
-    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics()
+    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics(); gen_batchify()

@@ -449,3 +449,31 @@ def test_parallel_predict_one_rank_rccl():
     finally:
         if started:
             dist.destroy_process_group()
+
+
+def test_batchify_to_graphed_predictor():
+    """inputters.ranker_batchify -> one packed (pinned) buffer -> GraphedPredictor's single-copy fast path == eager predict."""
+    from context_attentive_ir_amd.inputters import ranker_batchify, flat_examples
+    from context_attentive_ir_amd.graph_runner import GraphedPredictor
+    from context_attentive_ir_amd.wrappers import Ranker
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    w = Ranker(default_args("MATCH_TENSOR", src_vocab_size=300))
+    fill_module_(w.network, 9)
+    w.cuda()
+    rng = np.random.default_rng(21)
+
+    def make(seed):
+        r = np.random.default_rng(seed)
+        B, N = 6, 5
+        q = [r.integers(4, 300, size=r.integers(1, 6)) for _ in range(B)]
+        d = [[r.integers(4, 300, size=r.integers(1, 30)) for _ in range(N)] for _ in range(B)]
+        lab = r.integers(0, 2, size=(B, N))
+        return ranker_batchify(flat_examples(q, d, lab, force_pad=(5, 29)), pin=True)
+    b0, b1 = make(1), make(2)
+    gp = GraphedPredictor(w, {k: v.cuda() for k, v in b0.items() if torch.is_tensor(v) and not k.startswith("_")})
+    for b in (b1, b0, b1):
+        got = gp.predict(b)
+        assert gp._keep is b["_buffer"]          # the single-copy path was taken
+        ref = w.predict({k: v for k, v in b.items() if torch.is_tensor(v) and not k.startswith("_")})
+        assert torch.equal(got.cpu(), ref.cpu())

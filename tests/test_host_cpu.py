@@ -204,3 +204,46 @@ def test_async_score_gather_two_ranks():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_batchify_matches_reference_collate():
+    """Row a0: ranker_batchify / session_batchify reproduce the reference's collate outputs (fixture generated by
+    tests/golden/generate.py from neuroir.inputters.*.vector.batchify) bit for bit, dtypes included."""
+    from context_attentive_ir_amd.inputters import ranker_batchify, session_batchify
+    g = load_golden("batchify")
+    qlens, dlens = g["r_qlens"], g["r_dlens"]
+    B, N = dlens.shape
+    batch, qo, do = [], 0, 0
+    for b in range(B):
+        q = g["r_qflat"][qo:qo + qlens[b]]; qo += qlens[b]
+        docs = []
+        for n in range(N):
+            docs.append(torch.from_numpy(g["r_dflat"][do:do + dlens[b, n]].astype(np.int64))); do += dlens[b, n]
+        batch.append({"id": b, "query_words": torch.from_numpy(q.astype(np.int64)), "doc_words": docs,
+                      "label": torch.from_numpy(g["r_labels"][b].astype(np.int64)), "num_candidates": N,
+                      "max_doc_len": int(dlens[b].max()), "max_query_len": int(qlens[b])})
+    out = ranker_batchify(batch)
+    for k in ("doc_rep", "doc_len", "que_rep", "que_len", "label"):
+        assert out[k].dtype == torch.int64 and np.array_equal(out[k].numpy(), g["r_out_" + k]), k
+    assert out["batch_size"] == B and out["ids"] == list(range(B))
+    # all fields are views of one contiguous buffer (single H2D copy)
+    base = out["_buffer"].data_ptr()
+    assert all(base <= out[k].data_ptr() < base + out["_buffer"].numel() for k in ("doc_rep", "doc_len", "que_rep", "que_len", "label"))
+
+    keys = ("source_words", "source_lens", "target_words", "target_lens", "target_seq", "document_words", "document_lens",
+            "document_labels")
+    sess, b = [], 0
+    while "s_in%d_source_words" % b in g:
+        ex = {k: torch.from_numpy(g["s_in%d_%s" % (b, k)]) for k in keys}
+        ex.update(id=b, session_len=ex["source_words"].shape[0], num_candidates=ex["document_lens"].shape[1],
+                  max_source_len=ex["source_words"].shape[1], max_target_len=ex["target_words"].shape[1],
+                  max_document_len=ex["document_words"].shape[2])
+        sess.append(ex); b += 1
+    sout = session_batchify(sess)
+    for k in keys:
+        assert np.array_equal(sout[k].numpy(), g["s_out_" + k]), k
+        assert sout[k].dtype == (torch.float32 if k == "document_labels" else torch.int64), k
+    assert bool(g["s_out_document_labels_is_float"])
+    sess[1]["session_len"] = 99
+    with pytest.raises(AssertionError):
+        session_batchify(sess)
