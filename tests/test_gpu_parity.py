@@ -477,3 +477,31 @@ def test_batchify_to_graphed_predictor():
         assert gp._keep is b["_buffer"]          # the single-copy path was taken
         ref = w.predict({k: v for k, v in b.items() if torch.is_tensor(v) and not k.startswith("_")})
         assert torch.equal(got.cpu(), ref.cpu())
+
+
+def test_validate_official_gpu_vs_oracle():
+    """The evaluation driver on the HIP path gives the same MAP/MRR/P@k as the same loop over the CPU oracle."""
+    from context_attentive_ir_amd.eval import validate_official
+    from context_attentive_ir_amd.wrappers import Ranker
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    w = Ranker(default_args("MATCH_TENSOR", src_vocab_size=300))
+    fill_module_(w.network, 13)
+    sd = cpu_state_dict(w.network)
+    w.cuda()
+    rng = np.random.default_rng(8)
+    batches = []
+    for _ in range(5):
+        q, ql, d, dl = _synth(rng, 6, 10, 4, 24, 300)
+        lab = torch.zeros(6, 10, dtype=torch.int64)
+        lab[torch.arange(6), torch.from_numpy(rng.integers(0, 10, size=6))] = 1
+        batches.append({"que_rep": q, "que_len": ql, "doc_rep": d, "doc_len": dl, "label": lab})
+
+    class OraclePredictor(object):
+        def predict(self, ex):
+            return torch.softmax(O.match_tensor_scores(sd, ex["que_rep"], ex["que_len"], ex["doc_rep"], ex["doc_len"]), -1)
+    got = validate_official(batches, w)
+    ref = validate_official(batches, OraclePredictor())
+    assert got["examples"] == ref["examples"] == 30
+    for k in ("map", "mrr", "prec@1", "prec@3", "prec@5"):
+        assert abs(got[k] - ref[k]) < 1e-12, (k, got[k], ref[k])

@@ -247,3 +247,39 @@ def test_batchify_matches_reference_collate():
     sess[1]["session_len"] = 99
     with pytest.raises(AssertionError):
         session_batchify(sess)
+
+
+def test_validate_official_matches_reference_loop():
+    """eval.validate_official == the reference's per-batch loop (main/ranker.py:236-297): mean over batches of the
+    batch metrics, driven here by a stand-in predictor (CPU tensors) so the host logic is covered without a GPU."""
+    from context_attentive_ir_amd.eval import validate_official, MAP, MRR, precision_at_k
+
+    class Stub(object):
+        def predict(self, ex):
+            return ex["_scores"]
+
+    rng = np.random.default_rng(5)
+    batches = []
+    for _ in range(7):
+        B, N = int(rng.integers(1, 6)), 6
+        lab = np.zeros((B, N), dtype=np.int64)
+        lab[np.arange(B), rng.integers(0, N, size=B)] = 1
+        batches.append({"_scores": torch.from_numpy(rng.standard_normal((B, N)).astype(np.float32)), "label": torch.from_numpy(lab)})
+    got = validate_official(batches, Stub(), depth=2)
+    ref = {"map": [], "mrr": [], "prec@1": [], "prec@3": [], "prec@5": []}
+    for ex in batches:
+        pred = np.argsort(-ex["_scores"].numpy(), kind="stable")
+        lab = ex["label"].numpy()
+        ref["map"].append(MAP(pred, lab)); ref["mrr"].append(MRR(pred, lab))
+        for k in (1, 3, 5):
+            ref["prec@%d" % k].append(precision_at_k(pred, lab, k))
+    for k, v in ref.items():
+        assert abs(got[k] - float(np.mean(v))) < 1e-12, k
+    assert got["examples"] == sum(b["label"].shape[0] for b in batches)
+    # CARS layout: dict output, [B,S,N] rows flattened to B*S
+    class Stub2(object):
+        def predict(self, ex):
+            return {"click_scores": ex["_scores"], "predictions": None}
+    ex = {"_scores": torch.randn(2, 3, 5), "document_labels": torch.eye(5)[torch.randint(0, 5, (2, 3))]}
+    r = validate_official([ex], Stub2())
+    assert r["examples"] == 6 and 0 < r["map"] <= 1
