@@ -319,9 +319,10 @@ def main():
     if world == 1:
         try:
             from context_attentive_ir_amd.graph_runner import GraphedPredictor
-            host = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in batches]
-            gps = [GraphedPredictor(model, batches[0]) for _ in lanes]   # one predictor (stream + staging) per lane
-            nh = max(10, min(args.steps, 100))
+            gps = [GraphedPredictor(model, batches[0], queue_ahead=len(lanes) == 1) for _ in lanes]   # one predictor (stream + static inputs) per lane
+            # every batch packed into one pinned host buffer (what inputters.*_batchify produces): ONE H2D copy per step
+            host = [gps[0].pack({k: v.cpu() for k, v in b.items()}) for b in batches]
+            nh = max(10, min(args.steps, 400))
             for i in range(3 * len(gps)):
                 gps[i % len(gps)].predict(host[i % len(host)], clone=False)
             torch.cuda.synchronize()

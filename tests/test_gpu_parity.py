@@ -473,8 +473,9 @@ def test_batchify_to_graphed_predictor():
     b0, b1 = make(1), make(2)
     gp = GraphedPredictor(w, {k: v.cuda() for k, v in b0.items() if torch.is_tensor(v) and not k.startswith("_")})
     for b in (b1, b0, b1):
+        before = gp.fast_path_calls
         got = gp.predict(b)
-        assert gp._keep is b["_buffer"]          # the single-copy path was taken
+        assert gp.fast_path_calls == before + 1  # the packed single-memmove path was taken
         ref = w.predict({k: v for k, v in b.items() if torch.is_tensor(v) and not k.startswith("_")})
         assert torch.equal(got.cpu(), ref.cpu())
 
