@@ -81,17 +81,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     bool aval[LPT];
     const float* wrow[LPT];
     bool wval[LPT];
+    // conv-style gather with 2..3 taps (K = taps*E): the tap rows are resolved once per block as well, so a k-tile load
+    // is ONE dependent access (table row) instead of two (id, then row) plus an integer division
+    const bool taps3 = p.ids && p.K > p.E && p.K <= 3 * p.E;
+    const float* arow1[LPT];
+    const float* arow2[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         int64_t m = m0 + lr + 16 * i;
         aval[i] = m < p.M;
-        arow[i] = nullptr;
+        arow[i] = arow1[i] = arow2[i] = nullptr;
         aidx[i] = 0;
         if (aval[i]) {
             if (p.ids) {
                 aidx[i] = (m / p.rows_per_seq) * p.seq_stride + (m % p.rows_per_seq);
                 // single-segment gather (K <= E): resolve the row pointer once, not once per k-tile
                 if (p.K <= p.E) arow[i] = p.table + p.ids[aidx[i]] * (int64_t)p.E;
+                if (taps3) {   // pointers pre-biased by the tap's k offset: element k of tap s is arow_s[k]
+                    arow[i] = p.table + p.ids[aidx[i]] * (int64_t)p.E;
+                    arow1[i] = p.table + p.ids[aidx[i] + 1] * (int64_t)p.E - p.E;
+                    arow2[i] = p.K > 2 * p.E ? p.table + p.ids[aidx[i] + 2] * (int64_t)p.E - 2 * p.E : arow1[i];
+                }
             } else {
                 arow[i] = p.a + m * p.lda;
             }
@@ -112,7 +122,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 if (k < p.K) {
                     if (aval[i]) {
                         const float* src;
-                        if (p.ids && p.K > p.E) {
+                        if (taps3) {
+                            src = (k < p.E ? arow[i] : (k < 2 * p.E ? arow1[i] : arow2[i])) + k;
+                        } else if (p.ids && p.K > p.E) {
                             int seg = k / p.E;
                             src = p.table + p.ids[aidx[i] + seg] * (int64_t)p.E + (k - seg * p.E);
                         } else {
