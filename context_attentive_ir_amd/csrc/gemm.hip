@@ -51,11 +51,18 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& p, int64_t m, int n, 
     }
 }
 
-constexpr int BM = 64, BN = 64, BK = 64, LDS_LD = BK + 4;   // row stride 68 floats: 16-lane b128 groups hit 16 slots
+// BK = 32 (36 KB of LDS, 4 blocks = 16 waves per CU) beats BK = 64 (68 KB, 2 blocks per CU) on this path's shapes, whose K
+// is short (300..900) so a block lives only 5-30 k-tiles and prologue/epilogue must hide behind other blocks: measured
+// 71680x1024x300 gather 68 -> 86 TFLOP/s, 921600x300x900 86 -> 96, 4096^3 107 -> 104.
+#ifndef NIR_GEMM_BK
+#define NIR_GEMM_BK 32
+#endif
+constexpr int BM = 64, BN = 64, BK = NIR_GEMM_BK, LDS_LD = BK + 4;   // odd multiple of 4 floats: conflict-free ds_read_b128
+constexpr int TPR = BK / 4, RPP = 256 / TPR;                // threads per tile row, rows per pass
 constexpr int LPT = BM * BK / 4 / 256;                        // float4 loads per thread per operand tile (4)
 
 // Software pipeline: the global loads of tile t+1 (gathered embedding rows for the A operand) are issued before the
-// MFMAs of tile t and land in the other LDS buffer afterwards -- one barrier per tile, 2 x 16 KB per block in flight.
+// MFMAs of tile t and land in the other LDS buffer afterwards -- one barrier per tile.
 template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     if (mblk >= mb) return;
     const int64_t m0 = mblk * BM;
     const int n0 = (int)(tq % nb) * BN;
-    const int lr = tid >> 4, lk = (tid & 15) * 4;     // 16 threads cover one 64-float row; rows lr + 16*i
+    const int lr = tid / TPR, lk = (tid % TPR) * 4;   // TPR threads cover one BK-float row; rows lr + RPP*i
 
     const float* arow[LPT];
     int64_t aidx[LPT];
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const float* arow2[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-        int64_t m = m0 + lr + 16 * i;
+        int64_t m = m0 + lr + RPP * i;
         aval[i] = m < p.M;
         arow[i] = arow1[i] = arow2[i] = nullptr;
         aidx[i] = 0;
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 arow[i] = p.a + m * p.lda;
             }
         }
-        int n = n0 + lr + 16 * i;
+        int n = n0 + lr + RPP * i;
         wval[i] = n < p.N;
         wrow[i] = p.w + (int64_t)(wval[i] ? n : 0) * p.ldw;
     }
@@ -159,8 +166,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            *reinterpret_cast<float4*>(&As[(buf * BM + lr + 16 * i) * LDS_LD + lk]) = ra[i];
-            *reinterpret_cast<float4*>(&Ws[(buf * BN + lr + 16 * i) * LDS_LD + lk]) = rw[i];
+            *reinterpret_cast<float4*>(&As[(buf * BM + lr + RPP * i) * LDS_LD + lk]) = ra[i];
+            *reinterpret_cast<float4*>(&Ws[(buf * BN + lr + RPP * i) * LDS_LD + lk]) = rw[i];
         }
     };
 
@@ -461,7 +468,7 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
         else hipLaunchKernelGGL(gemm16_kernel<false>, grid, dim3(256), 0, st, p);
     } else {
         ProfScope ps(ids ? "gemm_kernel[gather]" : "gemm_kernel", st);
-        constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * 4;   // 69632 B: needs the >64 KB opt-in
+        constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * 4;   // 36864 B at BK = 32 (the opt-in only matters for BK = 64)
         static bool attr_done = false;
         if (!attr_done) {
             hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
