@@ -204,10 +204,19 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
     const int g2 = lane >> 5, col = lane & 31;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int j0 = ch * JT;
-        // ---- phase 1: tasks (conv k, row tile mt, column tile nt); heavy convs first for balance
+        // ---- phase 1: tasks (conv k, row tile mt, column tile nt), heaviest first, each handed to the least-loaded wave
+        // (weights 7:5:3 taps).  Round-robin gave waves 0/1 a 7+3 pair and waves 2/3 a single 5 at MT = 1 (measured
+        // 56 K vs 30 K cycles before the barrier); this gives 7, 7, 5+3, 5+3.
         const int ntask = 3 * MT * 2;
-        for (int task = wave; task < ntask; task += 4) {
+        int wload[4] = {0, 0, 0, 0};
+        for (int task = 0; task < ntask; ++task) {
             const int k = 2 - task / (MT * 2);
+            int wsel = 0;
+#pragma unroll
+            for (int x = 1; x < 4; ++x) wsel = wload[x] < wload[wsel] ? x : wsel;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) wload[x] += x == wsel ? 3 + 2 * k : 0;
+            if (wsel != wave) continue;
             const int rem = task % (MT * 2);
             const int mt = rem >> 1, nt = rem & 1;
             const int kw = 3 + 2 * k, pw = k + 1, Kp = kw * CP;
@@ -230,10 +239,18 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
 #pragma unroll
                     for (int u = 0; u < NG; ++u) an[u] = *reinterpret_cast<const float4*>(arow + (dj + 1) * CP + u * 8);
                 }
+                // B operands (LDS) one channel group ahead of their MFMAs: left to itself the compiler issued each
+                // ds_read right before its MFMA behind an lgkmcnt(0), i.e. one exposed LDS round trip per 64-cycle MFMA
+                const float* bp0 = bcol + dj;
+                float bn0 = bp0[0], bn1 = bp0[DLP], bn2 = bp0[2 * DLP], bn3 = bp0[3 * DLP];
 #pragma unroll
                 for (int u = 0; u < NG; ++u) {
-                    const float* bp = bcol + (u * 8) * DLP + dj;
-                    const float b0 = bp[0], b1 = bp[DLP], b2 = bp[2 * DLP], b3 = bp[3 * DLP];
+                    const float b0 = bn0, b1 = bn1, b2 = bn2, b3 = bn3;
+                    if (u + 1 < NG) {
+                        const float* bp = bcol + ((u + 1) * 8) * DLP + dj;
+                        bn0 = bp[0]; bn1 = bp[DLP]; bn2 = bp[2 * DLP]; bn3 = bp[3 * DLP];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].x, b0, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].y, b1, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].z, b2, acc, 0, 0, 0);
