@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
         __syncthreads();
         MT_STAMP(3);
         // ---- phase 2: positions (i, j) of this chunk
+        typedef const float __attribute__((address_space(4))) * const_fp;      // constant address space: uniform -> s_load
+        const const_fp cw_c = (const_fp)(uintptr_t)w.cw, cb_c = (const_fp)(uintptr_t)w.cb;
         for (int pos = tid; pos < QL * JT; pos += 256) {
             const int i = pos / JT, jl = pos - i * JT, j = j0 + jl;
             float v[3 * NFC];
@@ -272,24 +274,34 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int f = 0; f < NFC; ++f) v[k * NFC + f] = Y[((int64_t)k * rows + i * NFC + f) * YLD + jl] + bias_s[k * NFC + f];
-            // exact-match channel: alpha * [q_id == d_id], PAD==PAD counts (mtensor.py:144-158); hits are rare,
-            // so these loops stay rolled (keeps the kernel under 168 VGPRs -> 3 workgroups per CU)
-#pragma unroll 1
+            // exact-match channel: alpha * [q_id == d_id], PAD==PAD counts (mtensor.py:144-158).  The 7 document ids
+            // around j are read once into registers (a rolled loop of 21 dependent LDS reads cost ~2 K cycles per
+            // position); hits are rare, so the weight adds stay in a rolled, rarely taken branch
+            int64_t dwin[7];
+#pragma unroll
+            for (int dd = 0; dd < 7; ++dd) {
+                const int jj = j + dd - 3;
+                dwin[dd] = (jj >= 0 && jj < DL) ? dids[jj] : (int64_t)-1 - (int64_t)dd;   // sentinel < 0: never equals an id
+            }
+#pragma unroll
             for (int di = 0; di < 3; ++di) {
                 const int ii = i + di - 1;
-                if (ii < 0 || ii >= QL) continue;
-                const int64_t qid = qsh[ii];
-#pragma unroll 1
-                for (int dd = -3; dd <= 3; ++dd) {
-                    const int jj = j + dd;
-                    if (jj < 0 || jj >= DL || dids[jj] != qid) continue;
-#pragma unroll 1
-                    for (int k = 0; k < 3; ++k) {
-                        const int kw = 3 + 2 * k, pw = k + 1, dj = dd + pw;
-                        if (dj < 0 || dj >= kw) continue;
-                        const float* wm = wm_s + (k == 0 ? 0 : (k == 1 ? 54 : 144)) + (di * kw + dj) * NFC;
+                const int64_t qid = (ii >= 0 && ii < QL) ? qsh[ii] : (int64_t)-100;
+                unsigned hit = 0;
 #pragma unroll
-                        for (int f = 0; f < NFC; ++f) v[k * NFC + f] += wm[f];
+                for (int dd = 0; dd < 7; ++dd) hit |= (dwin[dd] == qid ? 1u : 0u) << dd;
+                if (hit) {
+#pragma unroll 1
+                    for (int dd = 0; dd < 7; ++dd) {
+                        if (!((hit >> dd) & 1u)) continue;
+#pragma unroll 1
+                        for (int k = 0; k < 3; ++k) {
+                            const int kw = 3 + 2 * k, pw = k + 1, dj = dd - 3 + pw;
+                            if (dj < 0 || dj >= kw) continue;
+                            const float* wm = wm_s + (k == 0 ? 0 : (k == 1 ? 54 : 144)) + (di * kw + dj) * NFC;
+#pragma unroll
+                            for (int f = 0; f < NFC; ++f) v[k * NFC + f] += wm[f];
+                        }
                     }
                 }
             }
@@ -298,9 +310,12 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
             if (j < DL) {
 #pragma unroll
                 for (int g = 0; g < MFC; ++g) {
-                    float z = cb_s[g];
+                    // 1x1 conv weights straight from global memory: the index is wave-uniform, so they arrive through
+                    // the scalar cache as SGPR operands of the FMAs (as LDS reads every one of the 380 values cost an
+                    // exposed ds_read round trip per position)
+                    float z = cb_c[g];
 #pragma unroll
-                    for (int f = 0; f < 3 * NFC; ++f) z = fmaf(cw_s[g * 3 * NFC + f], v[f], z);
+                    for (int f = 0; f < 3 * NFC; ++f) z = fmaf(cw_c[g * 3 * NFC + f], v[f], z);
                     zmax[g] = fmaxf(zmax[g], z);
                 }
             }
