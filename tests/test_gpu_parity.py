@@ -506,3 +506,23 @@ def test_validate_official_gpu_vs_oracle():
     assert got["examples"] == ref["examples"] == 30
     for k in ("map", "mrr", "prec@1", "prec@3", "prec@5"):
         assert abs(got[k] - ref[k]) < 1e-12, (k, got[k], ref[k])
+
+
+def test_batches_in_flight_hint_keeps_results():
+    """nir_set_batches_in_flight only changes scheduling (no internal fork, 4-sequence recurrence layout): MatchTensor and
+    CARS scores must stay within the parity tolerance of the oracle under either setting and agree with each other."""
+    from context_attentive_ir_amd import lib
+    L = lib.load()
+    m = build_model("MATCH_TENSOR", vocab=300, device=DEV)
+    rng = np.random.default_rng(31)
+    q, ql, d, dl = [t.to(DEV) for t in _synth(rng, 9, 10, 4, 64, 300)]
+    ref = O.match_tensor_scores(cpu_state_dict(m), q.cpu(), ql.cpu(), d.cpu(), dl.cpu())
+    outs = []
+    try:
+        for n in (1, 4):
+            L.nir_set_batches_in_flight(n)
+            outs.append(m(q, ql, d, dl).cpu())
+            _close(outs[-1], ref)
+    finally:
+        assert L.nir_set_batches_in_flight(1) == 4
+    _close(outs[0], outs[1], 2e-6)
