@@ -22,6 +22,7 @@ class GraphedPredictor(object):
         if not wrapper.use_cuda:
             raise RuntimeError("GraphedPredictor needs a wrapper on a ROCm device (call .cuda() first)")
         self.wrapper = wrapper
+        self.replay_done = None           # event: the previous replay has finished
         self.copy_done = None             # event: the H2D copy out of the staging buffer has been executed
         self.fast_path_calls = 0          # batches that arrived packed (inputters.*_batchify / pack()) and took one memmove
         dev = next(wrapper.network.parameters()).device
@@ -64,10 +65,10 @@ class GraphedPredictor(object):
     def _staging_free(self):
         """Host-side wait until the previous H2D out of the staging buffer has run.  Waiting for that copy -- not for the
         whole previous replay -- lets the host queue the next batch behind the one executing (bounded: one ahead)."""
-        if not self.queue_ahead:
-            self.stream.synchronize()
-        elif self.copy_done is not None:
-            self.copy_done.synchronize()
+        ev = self.copy_done if self.queue_ahead else self.replay_done
+        if ev is not None:
+            while not ev.query():        # spin: a blocking synchronize can put the host thread to sleep, and the wake-up
+                pass                     # (tens of us) is of the order of a whole C2 batch
 
     def _h2d(self):
         self.dev_buf.copy_(self.host_buf, non_blocking=True)     # stream order keeps it behind the previous replay
@@ -81,14 +82,17 @@ class GraphedPredictor(object):
 
     def predict(self, ex, clone=True):
         """ex must have the captured shapes; returns the softmax scores (a fresh tensor unless clone=False)."""
-        on_host = all(not ex[k].is_cuda for k in self.slots)
-        packed = ex.get("_buffer") if on_host else None
-        if packed is not None:   # a batch from inputters.*_batchify built with this predictor's field order: already one buffer
+        packed = ex.get("_buffer")
+        if packed is not None:   # a batch from inputters.*_batchify / pack() in this predictor's field order: already one buffer
             base = packed.data_ptr()
-            if packed.numel() != self.host_buf.numel() or any(
-                    ex[k].data_ptr() - base != o or tuple(ex[k].shape) != shape or ex[k].dtype != dt
-                    for k, (o, n, dt, shape) in self.slots.items()):
-                packed = None
+            if ex.get("_layout_ok") is not self:       # validated once per batch object, not once per call
+                if packed.is_cuda or packed.numel() != self.host_buf.numel() or any(
+                        ex[k].data_ptr() - base != o or tuple(ex[k].shape) != shape or ex[k].dtype != dt
+                        for k, (o, n, dt, shape) in self.slots.items()):
+                    packed = None
+                else:
+                    ex["_layout_ok"] = self
+        on_host = packed is not None or all(not ex[k].is_cuda for k in self.slots)
         with torch.cuda.stream(self.stream):
             if packed is not None:
                 # one memmove into this predictor's own pinned staging buffer, one H2D.  (Copying straight out of the
@@ -118,6 +122,10 @@ class GraphedPredictor(object):
                         raise RuntimeError("GraphedPredictor captured %s with shape %s, got %s" % (k, tuple(buf.shape), tuple(src.shape)))
                     buf.copy_(src, non_blocking=True)
             self.graph.replay()
+            if not self.queue_ahead:
+                if self.replay_done is None:
+                    self.replay_done = torch.cuda.Event()
+                self.replay_done.record(self.stream)
             out = self.out.clone() if clone else self.out
         torch.cuda.current_stream().wait_stream(self.stream)
         return out
