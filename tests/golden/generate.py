@@ -282,7 +282,25 @@ def gen_batchify():
     save("batchify", **arrs)
 
 
+def gen_samplers():
+    """Batch composition of the reference's length-bucketing samplers under a fixed numpy seed."""
+    from neuroir.inputters.ranker.data import SortedBatchSampler as RankerSampler
+    from neuroir.inputters.multitask.data import SortedBatchSampler as SessionSampler
+    rng = np.random.default_rng(SEED + 5)
+    lengths = np.stack([rng.integers(5, 40, size=57), rng.integers(1, 8, size=57)], 1)
+    out = {"r_lengths": lengths}
+    for shuffle in (False, True):
+        np.random.seed(SEED)
+        out["r_flat_shuffle%d" % shuffle] = np.asarray(list(RankerSampler([tuple(l) for l in lengths], 8, shuffle=shuffle)))
+    slens = rng.integers(2, 6, size=61)
+    out["s_lengths"] = slens
+    for shuffle in (False, True):
+        np.random.seed(SEED)
+        out["s_flat_shuffle%d" % shuffle] = np.asarray(list(SessionSampler(list(slens), 4, shuffle=shuffle)))
+    save("samplers", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(SEED)
     torch.set_num_threads(4)
-    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics(); gen_batchify()
+    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics(); gen_batchify(); gen_samplers()

@@ -283,3 +283,41 @@ def test_validate_official_matches_reference_loop():
     ex = {"_scores": torch.randn(2, 3, 5), "document_labels": torch.eye(5)[torch.randint(0, 5, (2, 3))]}
     r = validate_official([ex], Stub2())
     assert r["examples"] == 6 and 0 < r["map"] <= 1
+
+
+def test_samplers_match_reference_batches():
+    """inputters.samplers reproduce the reference samplers' index sequence under the same numpy seed (fixture from
+    neuroir.inputters.{ranker,multitask}.data.SortedBatchSampler)."""
+    from context_attentive_ir_amd.inputters import length_sorted_batches, session_length_batches, flat_indices
+    g = load_golden("samplers")
+    seed = int(str(g["meta_seed"]))
+    for shuffle in (False, True):
+        np.random.seed(seed)
+        got = flat_indices(length_sorted_batches(g["r_lengths"], 8, shuffle=shuffle))
+        assert got == g["r_flat_shuffle%d" % shuffle].tolist()
+        np.random.seed(seed)
+        batches = session_length_batches(g["s_lengths"], 4, shuffle=shuffle)
+        assert flat_indices(batches) == g["s_flat_shuffle%d" % shuffle].tolist()
+        assert all(len(set(g["s_lengths"][b].tolist())) == 1 and len(b) == 4 for b in batches)
+
+
+def test_prefetching_stream_order_and_shutdown():
+    from context_attentive_ir_amd.inputters import PrefetchingBatchStream, ranker_batchify, flat_examples, length_sorted_batches
+    rng = np.random.default_rng(3)
+    n, N = 23, 3
+    q = [rng.integers(4, 99, size=rng.integers(1, 6)) for _ in range(n)]
+    d = [[rng.integers(4, 99, size=rng.integers(1, 12)) for _ in range(N)] for _ in range(n)]
+    ex = flat_examples(q, d, rng.integers(0, 2, size=(n, N)))
+    batches = length_sorted_batches([(max(len(x) for x in dd), len(qq)) for qq, dd in zip(q, d)], 4, shuffle=True,
+                                    rng=np.random.RandomState(0))
+    stream = PrefetchingBatchStream(ex, batches, ranker_batchify, depth=2, pin=False)
+    got = list(stream)
+    assert len(got) == len(batches) == 6
+    for b, idx in zip(got, batches):
+        ref = ranker_batchify([ex[int(i)] for i in idx])
+        assert b["ids"] == [int(i) for i in idx] and torch.equal(b["doc_rep"], ref["doc_rep"]) and torch.equal(b["que_rep"], ref["que_rep"])
+    it = iter(stream)            # abandoning the iterator early must not leave the producer blocked
+    next(it)
+    it.close()
+    import threading
+    assert not any(t.name == "nir-batch-prefetch" and t.is_alive() for t in threading.enumerate())
