@@ -32,6 +32,8 @@ namespace nir {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // matrix-core variants (lstm_mfma.hip); return NIR_ERR_UNSUPPORTED when the shape has no instantiation
+int launch_bilstm_mfma16(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
+                         float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st);
 int launch_bilstm_mfma(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
                        float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st);
 
@@ -371,9 +373,14 @@ int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const
     NIR_REQUIRE(H >= 1 && H <= 128, "bilstm: hidden size %d per direction unsupported (1..128)", H);
     NIR_REQUIRE((int64_t)8 * T * ND * 4 * H * 4 < 0x7FFFFFF0LL, "bilstm: T*H too large for 32-bit tile offsets");
     if (M == 0) return 0;
-    // Measured (tools/bench_lstm.py): the quad/VALU kernel wins when its workgroup fills the 4 SIMDs evenly
-    // (KP/16 waves a multiple of 4: H = 128 -> 439 us vs 520 us on the matrix pipe at M = 1120); the 4x4x1-MFMA
-    // recurrence wins for the unbalanced sizes (H = 70: 5 waves).
+    // Measured (tools/bench_lstm.py).  From ~1000 sequences up the 16-sequence 16x16x4-MFMA layout wins (H = 128:
+    // M = 1120 353 vs 439 us, M = 22400 3.86 vs 7.06 ms).  Below that: the quad/VALU kernel when its workgroup fills the
+    // 4 SIMDs evenly (KP/16 waves a multiple of 4: H = 128 439 us vs 520 us for the 4x4x1 layout at M = 1120), the
+    // 4x4x1-MFMA recurrence for the unbalanced sizes (H = 70: 5 waves).
+    if (!getenv("NIR_LSTM_VALU")) {   // many sequences, wide H: 16 sequences per workgroup on 16x16x4 MFMAs
+        int rc = launch_bilstm_mfma16(gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, st);
+        if (rc != NIR_ERR_UNSUPPORTED) return rc;
+    }
     const bool valu_balanced = (((H + 15) / 16) % 4) == 0;
     if (!valu_balanced && !getenv("NIR_LSTM_VALU")) {
         int rc = launch_bilstm_mfma(gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, st);

@@ -386,6 +386,200 @@ static int launch_mfma_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Wide hidden sizes with many sequences (CARS: H = 128, thousands of documents): 16 sequences per workgroup on
+// v_mfma_f32_16x16x4_f32, 16 waves.
+//   * D = W_tile (16 gate rows x K = H) * h^T (K x 16 sequences).  All 16 MFMA columns carry a sequence (the 4x4x1
+//     layout above fills 4), the 8-pass MFMA holds the matrix pipe for 32 cycles but the issue port for 4, and with 4
+//     waves per SIMD one wave's cell update runs in the shadow of the others' MFMAs.
+//   * gate rows are interleaved as row = 4*unit + gate, so the C/D layout (lane (col = lane & 15, rows 4*(lane >> 4)
+//     + r)) hands ONE lane the four gates i,f,g,o of (unit = 4*tile + (lane >> 4), sequence = lane & 15) in its four
+//     accumulator registers: no partial sums, no exchange, c_t / h_t stay in registers.
+//   * wave w owns tiles w and w + 16 (4 hidden units each, two interleaved accumulate chains), K is not split, so a
+//     step needs ONE barrier (h ping-pong in LDS); its slice of W_hh (2 x 4*ceil(H/16) floats per lane) stays in VGPRs
+//     for all T steps.  The input part of the gates (gates_in, biases included) is prefetched one step ahead.
+// ------------------------------------------------------------------------------------------------------------------
+template <int G, int NT>
+__global__ __launch_bounds__(1024) void lstm_mfma16_gin_kernel(LstmMfmaGinArgs p) {
+    constexpr int SEQ = 16, KP = 16 * G, ZLD = KP + 4, NW = 16;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    __shared__ __attribute__((aligned(16))) float z[2][SEQ][ZLD];
+    __shared__ int lens_s[SEQ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;       // operand view: (row/col sq, k quarter kq); result view: (sequence sq, local unit kq)
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int H = p.H, T = p.T, H4 = 4 * H;
+    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int OW = p.ND * H, GW = p.ND * H4;
+    const int ntiles = (H + 3) / 4;
+
+    if (tid < SEQ) {
+        int l = 0;
+        if (tid < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    for (int e = tid; e < 2 * SEQ * ZLD; e += 1024) (&z[0][0][0])[e] = 0.f;
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    const int mylen = lens_s[sq];
+
+    float wreg[NT][4 * G];
+    float creg[NT], hreg[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tile = wave + NW * t;
+        const int unit_a = 4 * tile + (sq >> 2), gate_a = sq & 3;
+        const bool av = unit_a < H;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0)) * H;
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * q + 4 * kq + j;
+                wreg[t][4 * q + j] = (av && k < H) ? wr[k] : 0.f;
+            }
+        const int unit_d = 4 * tile + kq;
+        creg[t] = 0.f;
+        hreg[t] = 0.f;
+        if (unit_d < H && sq < nvalid) {
+            const int64_t si = ((int64_t)dir * p.M + m0 + sq) * H + unit_d;
+            if (p.c0) creg[t] = p.c0[si];
+            if (p.h0) { hreg[t] = p.h0[si]; z[0][sq][unit_d] = hreg[t]; }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t gin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gin + m0 * T * GW), 0,
+                                                                             (int)((uint32_t)nvalid * T * GW * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
+                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    auto load_gin = [&](int step, float (&dst)[NT][4]) {
+        const int t_ = dir == 0 ? step : mylen - 1 - step;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int unit_d = 4 * (wave + NW * t) + kq;
+            const bool ok = unit_d < H && step < mylen;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t off = ok ? (uint32_t)((sq * T + t_) * GW + dir * H4 + r * H + unit_d) * 4u : OOB;
+                dst[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gin_rs, off, 0, 0));   // OOB -> 0
+            }
+        }
+    };
+    float gcur[NT][4], gnext[NT][4];
+    load_gin(0, gcur);
+    __syncthreads();
+
+    const bool has1 = wave < ntiles;
+    const bool has2 = NT > 1 && wave + NW < ntiles;    // wave-uniform
+    for (int step = 0; step < tmax; ++step) {
+        const float* zc = &z[step & 1][0][0];
+        float* zn = &z[(step + 1) & 1][0][0];
+        load_gin(step + 1, gnext);                   // lands during this step's MFMAs
+        const bool live = step < mylen;
+        const int tt = dir == 0 ? step : mylen - 1 - step;
+        auto cell_tile = [&](int t, const f32x4& acc) {
+            const int unit_d = 4 * (wave + NW * t) + kq;
+            const bool dv = unit_d < H;
+            const float gi = fast_sigmoid(acc[0] + gcur[t][0]);
+            const float gf = fast_sigmoid(acc[1] + gcur[t][1]);
+            const float gg = fast_tanh(acc[2] + gcur[t][2]);
+            const float go = fast_sigmoid(acc[3] + gcur[t][3]);
+            const float cn = gf * creg[t] + gi * gg;
+            const float hn = go * fast_tanh(cn);
+            const bool act = dv && live;
+            creg[t] = act ? cn : creg[t];            // a finished sequence carries its state over
+            hreg[t] = act ? hn : hreg[t];
+            if (dv) zn[sq * ZLD + unit_d] = hreg[t];
+            const uint32_t off = act ? (uint32_t)((sq * T + tt) * OW + dir * H + unit_d) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn), out_rs, off, 0, 0);   // OOB lanes dropped
+        };
+        if (has1) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* zr = zc + sq * ZLD + 4 * kq;
+            if (has2) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 0], zf.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 0], zf.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 1], zf.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 1], zf.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 2], zf.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 2], zf.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 3], zf.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 3], zf.w, acc1, 0, 0, 0);
+                }
+                cell_tile(0, acc0);
+                cell_tile(NT - 1, acc1);
+            } else {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 0], zf.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 1], zf.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 2], zf.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 3], zf.w, acc0, 0, 0, 0);
+                }
+                cell_tile(0, acc0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gcur[t][r] = gnext[t][r];
+        lds_barrier();
+    }
+
+    // zero the padded tail (pad_packed_sequence) and emit final states
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int unit_d = 4 * (wave + NW * t) + kq;
+        if (unit_d < H && sq < nvalid) {
+            const int64_t m = m0 + sq;
+            for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d] = 0.f;
+            const int64_t si = ((int64_t)dir * p.M + m) * H + unit_d;
+            if (p.hn) p.hn[si] = hreg[t];
+            if (p.cn) p.cn[si] = creg[t];
+        }
+    }
+}
+
+template <int G, int NT>
+static int launch_mfma16_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
+    static const std::string pname = "lstm_mfma16_gin_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
+    ProfScope ps(pname.c_str(), st);
+    hipLaunchKernelGGL((lstm_mfma16_gin_kernel<G, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), 0, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_fwd[mfma16]");
+    return 0;
+}
+
+// 16-sequence layout: pays once there are enough sequences to give most CUs a workgroup (otherwise the quad/VALU
+// kernel spreads a small batch over more CUs).  NIR_LSTM_MFMA16=0/1 forces it off/on.
+int launch_bilstm_mfma16(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
+                         float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st) {
+    const char* f = getenv("NIR_LSTM_MFMA16");
+    if (f ? atoi(f) == 0 : ((M + 15) / 16) * ND < 128) return NIR_ERR_UNSUPPORTED;
+    if (H < 33 || H > 128 || (int64_t)16 * T * ND * 4 * H * 4 >= 0x7FFFFFF0LL) return NIR_ERR_UNSUPPORTED;
+    LstmMfmaGinArgs p{gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND};
+    const int G = (H + 15) / 16;
+    if (H <= 64) {
+        if (G == 3) return launch_mfma16_gin<3, 1>(p, st);
+        return launch_mfma16_gin<4, 1>(p, st);
+    }
+    switch (G) {
+        case 5: return launch_mfma16_gin<5, 2>(p, st);
+        case 6: return launch_mfma16_gin<6, 2>(p, st);
+        case 7: return launch_mfma16_gin<7, 2>(p, st);
+        default: return launch_mfma16_gin<8, 2>(p, st);
+    }
+}
+
 int launch_bilstm_mfma(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
                        float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st) {
     if ((int64_t)4 * T * ND * 4 * H * 4 >= 0x7FFFFFF0LL || H < 17) return NIR_ERR_UNSUPPORTED;
