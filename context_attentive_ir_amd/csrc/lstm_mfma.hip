@@ -621,12 +621,202 @@ static int launch_mfma(const LstmMfmaArgs& p, hipStream_t st) {
     return three ? launch_mfma_s<NG, KQ, 3, 1>(p, st) : launch_mfma_s<NG, KQ, 4, 2>(p, st);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same 16-sequence / 16-wave layout with the input projection fused (z = [h ; x], K = H + I): for narrow inputs
+// (MatchTensor) once there are enough sequences to give most CUs a 16-sequence workgroup.  At the C2 batch (640
+// sequences = 40 workgroups) the 4x4x1 layout above is faster (102 vs 176 us); at 6400 sequences this one needs one
+// round of ~180 us where the 4x4x1 layout needs 6.
+// ------------------------------------------------------------------------------------------------------------------
+template <int G, int NT>
+__global__ __launch_bounds__(1024) void lstm_mfma16_kernel(LstmMfmaArgs p) {
+    constexpr int SEQ = 16, KP = 16 * G, ZLD = KP + 4, NW = 16;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    __shared__ __attribute__((aligned(16))) float z[2][SEQ][ZLD];
+    __shared__ int lens_s[SEQ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int H = p.H, I = p.I, T = p.T, H4 = 4 * H;
+    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int OW = p.ND * H;
+    const int ntiles = (H + 3) / 4;
+
+    if (tid < SEQ) {
+        int l = 0;
+        if (tid < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    for (int e = tid; e < 2 * SEQ * ZLD; e += 1024) (&z[0][0][0])[e] = 0.f;
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    const int mylen = lens_s[sq];
+
+    float wreg[NT][4 * G];
+    float bias[NT][4];
+    float creg[NT], hreg[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tile = wave + NW * t;
+        const int unit_a = 4 * tile + (sq >> 2), gate_a = sq & 3;
+        const bool av = unit_a < H;
+        const int64_t wrow = (int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0);
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * q + 4 * kq + j;
+                float v = 0.f;
+                if (av) {
+                    if (k < H) v = p.whh[wrow * H + k];
+                    else if (k < H + I) v = p.wih[wrow * I + (k - H)];
+                }
+                wreg[t][4 * q + j] = v;
+            }
+        const int unit_d = 4 * tile + kq;
+        const bool dv = unit_d < H;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t bi = (int64_t)dir * H4 + (int64_t)r * H + (dv ? unit_d : 0);
+            bias[t][r] = dv ? p.bih[bi] + p.bhh[bi] : 0.f;
+        }
+        creg[t] = 0.f;
+        hreg[t] = 0.f;
+        if (dv && sq < nvalid) {
+            const int64_t si = ((int64_t)dir * p.M + m0 + sq) * H + unit_d;
+            if (p.c0) creg[t] = p.c0[si];
+            if (p.h0) { hreg[t] = p.h0[si]; z[0][sq][unit_d] = hreg[t]; }
+        }
+    }
+
+    // x role: thread e = tid -> (sequence xs = e / I, input xi = e % I) moves x[xs][t][xi] into z[.][xs][H + xi]  (16*I <= 1024)
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + m0 * T * I), 0,
+                                                                           (int)((uint32_t)nvalid * T * I * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
+                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    const int xs = tid / I, xi = tid - xs * I;
+    const bool xrole = xs < SEQ;
+    const int xl = xrole ? lens_s[xs] : 0;
+    auto load_x = [&](int step) -> float {
+        const int t = dir == 0 ? step : xl - 1 - step;
+        const uint32_t off = step < xl ? (uint32_t)((xs * T + t) * I + xi) * 4u : OOB;
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_rs, off, 0, 0));   // OOB -> 0
+    };
+    if (xrole) z[0][xs][H + xi] = load_x(0);
+    float xnext = load_x(1);
+    __syncthreads();
+
+    const bool has1 = wave < ntiles;
+    const bool has2 = NT > 1 && wave + NW < ntiles;    // wave-uniform
+    for (int step = 0; step < tmax; ++step) {
+        const float* zc = &z[step & 1][0][0];
+        float* zn = &z[(step + 1) & 1][0][0];
+        const float xcur = xnext;
+        xnext = load_x(step + 2);                    // in flight during this step
+        const bool live = step < mylen;
+        const int tt = dir == 0 ? step : mylen - 1 - step;
+        auto cell_tile = [&](int t, const f32x4& acc) {
+            const int unit_d = 4 * (wave + NW * t) + kq;
+            const bool dv = unit_d < H;
+            const float gi = fast_sigmoid(acc[0] + bias[t][0]);
+            const float gf = fast_sigmoid(acc[1] + bias[t][1]);
+            const float gg = fast_tanh(acc[2] + bias[t][2]);
+            const float go = fast_sigmoid(acc[3] + bias[t][3]);
+            const float cn = gf * creg[t] + gi * gg;
+            const float hn = go * fast_tanh(cn);
+            const bool act = dv && live;
+            creg[t] = act ? cn : creg[t];            // a finished sequence carries its state over
+            hreg[t] = act ? hn : hreg[t];
+            if (dv) zn[sq * ZLD + unit_d] = hreg[t];
+            const uint32_t off = act ? (uint32_t)((sq * T + tt) * OW + dir * H + unit_d) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn), out_rs, off, 0, 0);   // OOB lanes dropped
+        };
+        if (has1) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* zr = zc + sq * ZLD + 4 * kq;
+            if (has2) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 0], zf.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 0], zf.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 1], zf.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 1], zf.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 2], zf.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 2], zf.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 3], zf.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 3], zf.w, acc1, 0, 0, 0);
+                }
+                cell_tile(0, acc0);
+                cell_tile(NT - 1, acc1);
+            } else {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 0], zf.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 1], zf.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 2], zf.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 3], zf.w, acc0, 0, 0, 0);
+                }
+                cell_tile(0, acc0);
+            }
+        }
+        if (xrole) zn[xs * ZLD + H + xi] = xcur;
+        lds_barrier();
+    }
+
+    // zero the padded tail (pad_packed_sequence) and emit final states
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int unit_d = 4 * (wave + NW * t) + kq;
+        if (unit_d < H && sq < nvalid) {
+            const int64_t m = m0 + sq;
+            for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d] = 0.f;
+            const int64_t si = ((int64_t)dir * p.M + m) * H + unit_d;
+            if (p.hn) p.hn[si] = hreg[t];
+            if (p.cn) p.cn[si] = creg[t];
+        }
+    }
+}
+
+template <int G, int NT>
+static int launch_mfma16(const LstmMfmaArgs& p, hipStream_t st) {
+    static const std::string pname = "lstm_mfma16_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
+    ProfScope ps(pname.c_str(), st);
+    hipLaunchKernelGGL((lstm_mfma16_kernel<G, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), 0, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_fused_fwd[mfma16]");
+    return 0;
+}
+
+// NIR_ERR_UNSUPPORTED when the shape has no instantiation (H <= 128, I <= 64, H + I <= 160) or there are too few sequences
+static int launch_bilstm_fused_mfma16(const LstmMfmaArgs& p, hipStream_t st) {
+    const char* f = getenv("NIR_LSTM_MFMA16");
+    if (f ? atoi(f) == 0 : ((p.M + 15) / 16) * p.ND < 160) return NIR_ERR_UNSUPPORTED;   // H = 70: 1024 seqs 178 vs 169 us, 3200 358 vs 509
+    if ((int64_t)16 * p.T * max(p.I, p.ND * p.H) * 4 >= 0x7FFFFFF0LL || 16 * p.I > 1024) return NIR_ERR_UNSUPPORTED;
+    const int G = (p.H + p.I + 15) / 16, NT = (p.H + 3) / 4 > 16 ? 2 : 1;
+#define NIR_M16_CASE(g) if (G == g) return NT == 2 ? launch_mfma16<g, 2>(p, st) : launch_mfma16<g, 1>(p, st);
+    NIR_M16_CASE(1) NIR_M16_CASE(2) NIR_M16_CASE(3) NIR_M16_CASE(4) NIR_M16_CASE(5)
+    NIR_M16_CASE(6) NIR_M16_CASE(7) NIR_M16_CASE(8) NIR_M16_CASE(9) NIR_M16_CASE(10)
+#undef NIR_M16_CASE
+    return NIR_ERR_UNSUPPORTED;
+}
+
 // returns NIR_ERR_UNSUPPORTED when the shape has no instantiation (caller falls back to the VALU kernel)
 int launch_bilstm_fused_mfma(const float* x, int I, const float* wih, const float* bih, const float* bhh, const int64_t* lens,
                              const float* whh, const float* h0, const float* c0, float* out, float* hn, float* cn, int64_t M,
                              int T, int H, int ND, hipStream_t st) {
     if (I > 64 || (int64_t)4 * T * max(I, ND * H) * 4 >= 0x7FFFFFF0LL) return NIR_ERR_UNSUPPORTED;
     LstmMfmaArgs p{x, wih, bih, bhh, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, I, g_debug_buf};
+    {   // enough sequences for 16-sequence workgroups on most CUs: the 16x16x4 layout
+        const int rc = launch_bilstm_fused_mfma16(p, st);
+        if (rc != NIR_ERR_UNSUPPORTED) return rc;
+    }
     const int NG = (4 * H + 63) / 64;
     const int KQ = ((H + I + 15) / 16) * 4;
 #define NIR_MFMA_CASE(ng, kq) if (NG == ng && KQ == kq) return launch_mfma<ng, kq>(p, st);

@@ -121,6 +121,21 @@ def test_rnn_encoder(H, I, M, T_):
     _close(hn[:, order], hn_ref, 2e-5); _close(cn[:, order], cn_ref, 2e-5)
 
 
+@pytest.mark.parametrize("H,I,M,T_", [(70, 40, 37, 20), (15, 40, 50, 6), (128, 300, 40, 12), (96, 64, 21, 8), (96, 100, 33, 9),
+                                      (40, 16, 17, 11), (128, 24, 19, 7)])
+def test_rnn_encoder_16_sequence_layout(H, I, M, T_, monkeypatch):
+    """The 16-sequence 16x16x4-MFMA recurrences (chosen by the library only from ~1000 sequences up) forced on small,
+    ragged batches: partial workgroups, one- and two-tile waves, fused and unfused input projection."""
+    monkeypatch.setenv("NIR_LSTM_MFMA16", "1")
+    test_rnn_encoder(H, I, M, T_)
+
+
+def test_rnn_encoder_many_sequences():
+    """Enough sequences for the library to pick the 16-sequence layouts on its own (fused H=70/I=40, unfused H=128/I=300)."""
+    test_rnn_encoder(70, 40, 1300, 5)
+    test_rnn_encoder(128, 300, 1100, 4)
+
+
 def test_losses_softmax_golden():
     from context_attentive_ir_amd import lib
     g = load_golden("losses_metrics")
