@@ -1,0 +1,130 @@
+"""M_MATCH_TENSOR -- ranking side of the session-aware MatchTensor (drop-in for
+neuroir.multitask.mmtensor.M_MATCH_TENSOR, /root/reference/neuroir/multitask/mmtensor.py:10-189).
+
+Its document ranking is MatchTensor applied to the B*S (session, query) rows of a batch: `encode` gives the projected
+queries (mmtensor.py:70-88) and `rank_document` the scores [B,S,N] (mmtensor.py:127-189), both through the same HIP
+pipeline as rankers.MatchTensor (one nir_matchtensor_score call; the [B*S*N,51,QL,DL] match tensor is never built).
+The session-level encoder, the suggestion decoder and the generator only feed query suggestion (`decode`), which is
+outside the hot path: their parameters are kept under the reference's state-dict keys so checkpoints load with
+strict=True, `decode` raises, and `encode` returns None for session_bank / states.
+"""
+import torch
+import torch.nn as nn
+
+from .. import lib
+from ..encoders.rnn_encoder import lstm_cat_weights
+from ..rankers.mtensor import ExactMatchChannel
+from .layers import Embedder, Encoder
+
+
+class _PlainDecoderParams(nn.Module):
+    """`decoder.decoder.rnn.*` (RNNDecoder without attention); parameters only."""
+
+    def __init__(self, emsize, nhid):
+        super().__init__()
+        self.rnn = nn.LSTM(emsize, nhid, 1, batch_first=True)
+
+
+class M_MATCH_TENSOR(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1:
+            raise NotImplementedError("HIP M_MATCH_TENSOR expects the reference configuration: 1-layer bidirectional LSTM")
+        self.embedder = Embedder(args.emsize, args.src_vocab_size, args.dropout_emb)
+        self.linear_projection = nn.Linear(args.emsize, args.featsize)
+        self.query_encoder = Encoder(args.rnn_type, args.featsize, args.bidirection, args.nlayers, args.nhid_query,
+                                     args.dropout_rnn)
+        self.document_encoder = Encoder(args.rnn_type, args.featsize, args.bidirection, args.nlayers,
+                                        args.nhid_document, args.dropout_rnn)
+        self.query_projection = nn.Linear(args.nhid_query, args.nchannels)
+        self.document_projection = nn.Linear(args.nhid_document, args.nchannels)
+        self.exact_match_channel = ExactMatchChannel()
+        self.conv1 = nn.Conv2d(args.nchannels + 1, args.nfilters, (3, 3), padding=1)
+        self.conv2 = nn.Conv2d(args.nchannels + 1, args.nfilters, (3, 5), padding=(1, 2))
+        self.conv3 = nn.Conv2d(args.nchannels + 1, args.nfilters, (3, 7), padding=(1, 3))
+        self.relu = nn.ReLU()
+        self.conv = nn.Conv2d(args.nfilters * 3, args.match_filter_size, (1, 1))
+        self.output = nn.Linear(args.match_filter_size, 1)
+        # suggestion side: parameters only (state-dict compatibility)
+        self.nhid_session = args.nhid_session
+        self.session_query_encoder = Encoder(args.rnn_type, args.nchannels, False, args.nlayers, args.nhid_session,
+                                             args.dropout_rnn)
+        self.decoder = nn.Module()
+        self.decoder.decoder = _PlainDecoderParams(args.emsize, args.nhid_session)
+        self.dropout = nn.Dropout(args.dropout)
+        self.generator = nn.Linear(args.nhid_session, args.tgt_vocab_size)
+        self.regularize_coeff = args.regularize_coeff
+        self._dims = dict(F=args.featsize, Hq=args.nhid_query // 2, Hd=args.nhid_document // 2, C=args.nchannels,
+                          NF=args.nfilters, MF=args.match_filter_size)
+        self._pack = lib.PackCache()
+
+    def _weights(self):
+        def build():
+            q = lstm_cat_weights(self.query_encoder.encoder.rnns[0])
+            d = lstm_cat_weights(self.document_encoder.encoder.rnns[0])
+            t = dict(proj_w=self.linear_projection.weight, proj_b=self.linear_projection.bias,
+                     q_wih=q[0], q_whh=q[1], q_bih=q[2], q_bhh=q[3], d_wih=d[0], d_whh=d[1], d_bih=d[2], d_bhh=d[3],
+                     qproj_w=self.query_projection.weight, qproj_b=self.query_projection.bias,
+                     dproj_w=self.document_projection.weight, dproj_b=self.document_projection.bias,
+                     alpha=self.exact_match_channel.alpha,
+                     conv1_w=self.conv1.weight, conv1_b=self.conv1.bias, conv2_w=self.conv2.weight,
+                     conv2_b=self.conv2.bias, conv3_w=self.conv3.weight, conv3_b=self.conv3.bias,
+                     conv_w=self.conv.weight, conv_b=self.conv.bias, out_w=self.output.weight, out_b=self.output.bias)
+            return lib.Packed(lib.MatchTensorWeights, t, self._dims)
+        skip = ("embedder.", "session_query_encoder.", "decoder.", "generator.")
+        params = [p for n, p in self.named_parameters() if not n.startswith(skip)]
+        return self._pack.get(params, build)
+
+    def _check_eval(self):
+        if self.training and (self.dropout.p > 0 or self.embedder.dropout.p > 0):
+            raise NotImplementedError("HIP M_MATCH_TENSOR implements the eval-mode forward (SURVEY.md Appendix E7)")
+
+    def encode(self, source_rep, source_len):
+        """source_rep [B,S,QL] ids, source_len [B,S] -> (projected_queries [B*S,QL,C], None, None)  (mmtensor.py:70-88;
+        session_bank / states belong to the suggestion side)."""
+        self._check_eval()
+        table = self.embedder.word_embeddings.table
+        lib.require_device(source_rep, source_len, table)
+        L, st = lib.load(), lib.stream()
+        B, S, QL = source_rep.shape
+        ids = lib.ids64(source_rep.reshape(B * S, QL))
+        M, E, F_, C = B * S * QL, table.shape[1], self._dims["F"], self._dims["C"]
+        x = torch.empty(B * S, QL, F_, device=ids.device, dtype=torch.float32)
+        lib.check(L.nir_linear_f32(None, 0, lib.ptr(ids), lib.ptr(table), E, 1, 1, lib.ptr(self.linear_projection.weight), E,
+                                   lib.ptr(self.linear_projection.bias), None, lib.ptr(x), F_, M, F_, E, 0, st), "nir_linear_f32")
+        _, enc = self.query_encoder(x, source_len.reshape(-1))
+        pq = torch.empty(B * S, QL, C, device=ids.device, dtype=torch.float32)
+        Hq2 = enc.shape[2]
+        lib.check(L.nir_linear_f32(lib.ptr(enc), Hq2, None, None, 0, 0, 0, lib.ptr(self.query_projection.weight), Hq2,
+                                   lib.ptr(self.query_projection.bias), None, lib.ptr(pq), C, M, C, Hq2, 0, st), "nir_linear_f32")
+        self._src_len = source_len                     # rank_document's signature carries no query lengths
+        return pq, None, None
+
+    def rank_document(self, source_rep, projected_queries, session_bank, document_rep, document_len, source_len=None):
+        """-> scores [B,S,N]  (mmtensor.py:127-189).  The query side is re-derived from the ids inside the fused call
+        (bitwise the same values as `projected_queries`); `source_len` defaults to the lengths given to encode()."""
+        self._check_eval()
+        table = self.embedder.word_embeddings.table
+        src_len = source_len if source_len is not None else getattr(self, "_src_len", None)
+        if src_len is None:
+            raise RuntimeError("rank_document needs the query lengths: call encode() first or pass source_len")
+        lib.require_device(source_rep, document_rep, document_len, src_len, table)
+        L = lib.load()
+        B, S, N, DL = document_rep.shape
+        QL = source_rep.shape[2]
+        q, d = lib.ids64(source_rep.reshape(B * S, QL)), lib.ids64(document_rep.reshape(B * S, N, DL))
+        ql, dl = lib.ids64(src_len.reshape(-1)), lib.ids64(document_len.reshape(-1))
+        w = self._weights()
+        ws = lib.workspace(L.nir_matchtensor_workspace_bytes(B * S, N, QL, DL, w.ref()), q.device)
+        scores = torch.empty(B * S, N, device=q.device, dtype=torch.float32)
+        if B * S > 0:
+            lib.check(L.nir_matchtensor_score(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B * S, N, QL, DL,
+                                              lib.ptr(table), table.shape[0], table.shape[1], w.ref(), lib.ptr(ws), ws.numel(),
+                                              lib.ptr(scores), None, None, None, None, lib.stream()), "nir_matchtensor_score")
+        return scores.view(B, S, N)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward (ranking + suggestion losses) is outside the hot path (SURVEY.md 8f)")
+
+    def decode(self, **kwargs):
+        raise NotImplementedError("query suggestion decoding is outside the hot path (SURVEY.md section 8f rank 4)")

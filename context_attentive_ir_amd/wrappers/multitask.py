@@ -1,10 +1,12 @@
 """Multitask -- wrapper with the call shapes of neuroir.models.multitask.Multitask
-(/root/reference/neuroir/models/multitask.py:24-407) for CARS, ranking side only:
+(/root/reference/neuroir/models/multitask.py:24-407) for CARS and M_MATCH_TENSOR, ranking side only:
 predict(ex) -> {'click_scores': softmax over candidates [B,S,N]} (multitask.py:262-279)."""
 import torch
 
 from .. import lib
-from ..multitask import CARS
+from ..multitask import CARS, M_MATCH_TENSOR
+
+NETWORKS = {"CARS": CARS, "M_MATCH_TENSOR": M_MATCH_TENSOR}
 
 
 class Multitask(object):
@@ -15,9 +17,10 @@ class Multitask(object):
             self.args.src_vocab_size = len(src_dict)
         if tgt_dict is not None:
             self.args.tgt_vocab_size = len(tgt_dict)
-        if args.model_type.upper() != "CARS":
-            raise RuntimeError("Unsupported model: %s (hot-path multitask model: CARS)" % args.model_type)
-        self.network = CARS(args)
+        self.type = args.model_type.upper()
+        if self.type not in NETWORKS:
+            raise RuntimeError("Unsupported model: %s (hot-path multitask models: %s)" % (args.model_type, sorted(NETWORKS)))
+        self.network = NETWORKS[self.type](args)
         if state_dict:
             self.network.load_state_dict(state_dict)
         self.updates, self.use_cuda, self.parallel = 0, False, False
@@ -40,6 +43,11 @@ class Multitask(object):
     @torch.no_grad()
     def scores(self, ex):
         self.network.eval()
+        if self.type != "CARS":     # models/multitask.py:271-278: encode -> rank_document(source, memory, session, docs, lens)
+            src = self._dev(ex["source_words"])
+            memory_bank, session_bank, _ = self.network.encode(src, self._dev(ex["source_lens"]))
+            return self.network.rank_document(src, memory_bank, session_bank, self._dev(ex["document_words"]),
+                                              self._dev(ex["document_lens"]))
         pooled, _, _ = self.network.encode(self._dev(ex["source_words"]), self._dev(ex["source_lens"]))
         s, _, _ = self.network.rank_document(pooled, self._dev(ex["document_words"]), self._dev(ex["document_lens"]),
                                              self._dev(ex["document_labels"]), group=self.group, shard=self.parallel)

@@ -111,6 +111,41 @@ def match_tensor_scores(sd, q, q_len, d, d_len):
 
 
 # ------------------------------------------------------------------------------------------
+# M_MATCH_TENSOR, ranking side  (neuroir/multitask/mmtensor.py:70-88 encode, :127-189 rank_document):
+# MatchTensor over the B*S (session, query) rows; only the module nesting of the state dict differs.
+# ------------------------------------------------------------------------------------------
+def _mmt_as_match_tensor(sd):
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("embedder."):
+            out[k[len("embedder."):]] = v
+        elif k.startswith(("query_encoder.encoder.", "document_encoder.encoder.")):
+            out[k.replace(".encoder.", ".", 1)] = v
+        elif not k.startswith(("session_query_encoder.", "decoder.", "generator.")):
+            out[k] = v
+    return out
+
+
+@torch.no_grad()
+def m_match_tensor_encode(sd, source_rep, source_len):
+    """-> projected_queries [B*S, QL, C]"""
+    m = _mmt_as_match_tensor(sd)
+    B, S, QL = source_rep.shape
+    xq = _lin(m, "linear_projection", embed(m, "word_embeddings", source_rep.reshape(B * S, QL)))
+    _, hq = rnn_encode(m, "query_encoder", xq, source_len.reshape(-1))
+    return _lin(m, "query_projection", hq)
+
+
+@torch.no_grad()
+def m_match_tensor_scores(sd, source_rep, source_len, document_rep, document_len):
+    """-> scores [B, S, N]"""
+    B, S, N, DL = document_rep.shape
+    s = match_tensor_scores(_mmt_as_match_tensor(sd), source_rep.reshape(B * S, -1), source_len.reshape(-1),
+                            document_rep.reshape(B * S, N, DL), document_len.reshape(B * S, N))
+    return s.view(B, S, N)
+
+
+# ------------------------------------------------------------------------------------------
 # DRMM  (neuroir/rankers/drmm.py:29-84, 95-98)
 # ------------------------------------------------------------------------------------------
 DRMM_BINS = [-1.0, -0.5, 0, 0.5, 1.0, 1.0]

@@ -232,6 +232,26 @@ def gen_losses_metrics():
          R3=np.asarray(ltorank.recall_at_k(pred, lab, 3)), NDCG3=np.asarray(ltorank.NDCG_at_k(pred, lab, 3)))
 
 
+@torch.no_grad()
+def gen_m_match_tensor():
+    """Session-aware MatchTensor (multitask/mmtensor.py): encode -> rank_document, eval mode."""
+    from neuroir.multitask.mmtensor import M_MATCH_TENSOR
+    args = base_args("M_MATCH_TENSOR", tgt_vocab_size=50)
+    net = M_MATCH_TENSOR(args).eval()
+    from context_attentive_ir_amd.detinit import fill_module_
+    fill_module_(net, SEED)
+    rng = np.random.default_rng(SEED + 21)
+    B, S, N, QL, DL = 2, 3, 4, 5, 17
+    slen = rng.integers(1, QL + 1, size=(B, S)); slen[0, 0] = QL
+    dlen = rng.integers(1, DL + 1, size=(B, S, N)); dlen[0, 0, 0] = DL
+    src = rand_ids(rng, (B, S, QL), slen); docs = rand_ids(rng, (B, S, N, DL), dlen)
+    docs[0, 0, 1, :3] = src[0, 0, :3]                              # some exact matches
+    pq, session_bank, _ = net.encode(T(src), T(slen))
+    scores = net.rank_document(T(src), pq, session_bank, T(docs), T(dlen))
+    save("m_match_tensor", source_words=src, source_lens=slen, document_words=docs, document_lens=dlen,
+         projected_queries=pq, scores=scores, softmax=torch.softmax(scores, -1), tgt_vocab_size=50)
+
+
 def gen_batchify():
     """Input contract: the reference's own collate functions on ragged synthetic examples."""
     from neuroir.inputters.ranker.vector import batchify as ranker_batchify
@@ -303,4 +323,4 @@ def gen_samplers():
 if __name__ == "__main__":
     torch.manual_seed(SEED)
     torch.set_num_threads(4)
-    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics(); gen_batchify(); gen_samplers()
+    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics(); gen_batchify(); gen_samplers(); gen_m_match_tensor()

@@ -572,3 +572,48 @@ def test_input_pipeline_end_to_end():
     assert got["examples"] == ref["examples"] == n
     for k in ("map", "mrr", "prec@1", "prec@3", "prec@5"):
         assert abs(got[k] - ref[k]) < 1e-12, (k, got[k], ref[k])
+
+
+# ------------------------------------------------------------------ M_MATCH_TENSOR
+def test_m_match_tensor_golden_and_oracle():
+    """Session-aware MatchTensor ranking side: encode + rank_document vs the reference fixture, and vs the oracle on a
+    ragged random batch through the Multitask wrapper (softmax over candidates)."""
+    from context_attentive_ir_amd.wrappers import Multitask
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    g = load_golden("m_match_tensor")
+    m = build_model("M_MATCH_TENSOR", tgt_vocab_size=int(g["tgt_vocab_size"]), device=DEV)
+    src, sl, d, dl = (T(g[k], DEV) for k in ("source_words", "source_lens", "document_words", "document_lens"))
+    pq, bank, states = m.encode(src, sl)
+    assert bank is None and states is None
+    _close(pq, g["projected_queries"])
+    _close(m.rank_document(src, pq, bank, d, dl), g["scores"])
+
+    w = Multitask(default_args("M_MATCH_TENSOR", src_vocab_size=300, tgt_vocab_size=40))
+    fill_module_(w.network, 77)
+    sd = cpu_state_dict(w.network)
+    w.cuda()
+    rng = np.random.default_rng(41)
+    B, S, N, QL, DL = 3, 4, 6, 5, 40
+    slen = rng.integers(1, QL + 1, size=(B, S)); dlen = rng.integers(1, DL + 1, size=(B, S, N))
+    srcw = rng.integers(4, 300, size=(B, S, QL)); srcw[np.arange(QL)[None, None] >= slen[..., None]] = 0
+    docw = rng.integers(4, 300, size=(B, S, N, DL)); docw[np.arange(DL)[None, None, None] >= dlen[..., None]] = 0
+    ex = {"source_words": torch.from_numpy(srcw), "source_lens": torch.from_numpy(slen),
+          "document_words": torch.from_numpy(docw), "document_lens": torch.from_numpy(dlen),
+          "document_labels": torch.zeros(B, S, N)}
+    out = w.predict(ex)["click_scores"]
+    ref = torch.softmax(O.m_match_tensor_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)
+    _close(out, ref)
+    with pytest.raises(NotImplementedError):
+        w.network.decode()
+
+
+def test_m_match_tensor_state_dict_keys():
+    """Reference checkpoints load with strict=True: the key set is the reference's (probed from neuroir M_MATCH_TENSOR)."""
+    m = build_model("M_MATCH_TENSOR", tgt_vocab_size=50)
+    keys = set(m.state_dict().keys())
+    for k in ("embedder.word_embeddings.make_embedding.emb_luts.0.weight", "query_encoder.encoder.rnns.0.weight_hh_l0_reverse",
+              "document_encoder.encoder.rnns.0.bias_ih_l0", "session_query_encoder.encoder.rnns.0.weight_ih_l0",
+              "decoder.decoder.rnn.weight_hh_l0", "generator.weight", "exact_match_channel.alpha", "conv3.weight", "output.bias"):
+        assert k in keys, k
+    assert len(keys) == 44

@@ -71,6 +71,16 @@ def test_cars(tag):
     _close(O.predict_softmax(s), g["softmax"])
 
 
+def test_m_match_tensor():
+    g = load_golden("m_match_tensor")
+    sd = cpu_state_dict(build_model("M_MATCH_TENSOR", tgt_vocab_size=int(g["tgt_vocab_size"])))
+    src, sl, d, dl = (T(g[k]) for k in ("source_words", "source_lens", "document_words", "document_lens"))
+    _close(O.m_match_tensor_encode(sd, src, sl), g["projected_queries"])
+    s = O.m_match_tensor_scores(sd, src, sl, d, dl)
+    _close(s, g["scores"], 2e-6)
+    _close(O.predict_softmax(s), g["softmax"])
+
+
 def test_losses_and_metrics():
     g = load_golden("losses_metrics")
     s, y = T(g["scores"]), T(g["labels"])
