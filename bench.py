@@ -404,7 +404,9 @@ def main():
         sd = {k: v.detach().cpu().float() for k, v in model.network.state_dict().items()}
         ex = {k: v.cpu() for k, v in batches[0].items()}
         ncores = torch.get_num_threads()
-        if is_cars:
+        if args.model == "m_match_tensor":
+            fn = lambda: torch.softmax(O.m_match_tensor_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)  # noqa: E731
+        elif is_cars:
             fn = lambda: O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])  # noqa: E731
         else:
             f = O.MODEL_FNS[args.model.upper()]
