@@ -396,6 +396,14 @@ def main():
             bpp = algorithmic_bytes_per_pair(args.cands, args.qlen, args.dlen)
             roofline["step_hbm_GBps"] = round(value / world * bpp / 1e9, 2)
             roofline["step_hbm_frac"] = round(value / world * bpp / 1e9 / PEAK_HBM_GBS, 5)
+            # ... and "FLOP/s / peak next to it" (SURVEY.md 8d): algorithmic flops per pair of the reference's op
+            # sequence at the named config shapes (MatchTensor C2 1.76e7, CARS C3 6.72e7, DUET C4 2.08e8, DRMM C4 8.7e5)
+            named = {("match_tensor", 4, 64): 1.76e7, ("m_match_tensor", 4, 64): 1.76e7, ("cars", 4, 64): 6.72e7,
+                     ("duet", 4, 290): 2.08e8, ("drmm", 4, 290): 8.7e5}
+            fpp = named.get((args.model, args.qlen, args.dlen))
+            if fpp:
+                roofline["step_alg_TFLOPs"] = round(value / world * fpp / 1e12, 2)
+                roofline["step_flop_frac"] = round(value / world * fpp / 1e12 / PEAK_FP32_TFLOPS, 5)
 
     # ---- CPU baseline: the oracle (pinned port of the reference) on the host cores ---------------------
     cpu = None
