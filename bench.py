@@ -415,7 +415,7 @@ def main():
         if args.model == "m_match_tensor":
             fn = lambda: torch.softmax(O.m_match_tensor_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)  # noqa: E731
         elif is_cars:
-            fn = lambda: O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])  # noqa: E731
+            fn = lambda: O.predict_softmax(O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"]))  # noqa: E731
         else:
             f = O.MODEL_FNS[args.model.upper()]
             fn = lambda: O.predict_softmax(f(sd, ex["que_rep"], ex["que_len"], ex["doc_rep"], ex["doc_len"]))  # noqa: E731
