@@ -450,11 +450,13 @@ def main():
 
     if rank == 0:
         cfg = {"workload": "%s ranker, batch=%d queries x %d candidates%s, q_len=%d, doc_len=%d, emb_dim=300, vocab=%d, fp32, full-length %s ids"
-                           % (args.model, args.batch, args.cands * world, (" x session %d" % args.session) if is_cars else "",
+                           % (args.model, args.batch * (world if is_cars else 1), args.cands * (1 if is_cars else world), (" x session %d" % args.session) if is_cars else "",
                               args.qlen, args.dlen, args.vocab, "uniform" if args.uniform else "Zipf"),
                "global_batch_pairs": pairs_per_step_rank * world,
-               "parallelism": ("candidate-sharded x%d + RCCL all-gather of scores%s"
-                               % (world, " (async, consumed one step later)" if pipelined[0] else "")) if world > 1 else "single GPU",
+               "parallelism": "single GPU" if world == 1 else
+                              ("x%d independent per-rank session batches, no collective (sharded CARS = Multitask.parallelize)" % world)
+                              if is_cars else ("candidate-sharded x%d + RCCL all-gather of scores%s"
+                                               % (world, " (async, consumed one step later)" if pipelined[0] else "")),
                "hipgraph": graphs is not None,
                "batches_in_flight": len(lanes),
                "host_enqueue_ms_per_step": round(host_ms, 5),
