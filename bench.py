@@ -74,8 +74,8 @@ def kernel_work(name, B, N, QL, DL, E=300, F=40, Hq=15, Hd=70, C=50):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--model", default="match_tensor", choices=["match_tensor", "esm", "drmm", "duet", "cars", "m_match_tensor"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--cands", type=int, default=10)
