@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--model", default="match_tensor", choices=["match_tensor", "esm", "drmm", "duet", "cars", "m_match_tensor"])
+    ap.add_argument("--model", default="match_tensor", choices=["match_tensor", "esm", "drmm", "duet", "cars", "m_match_tensor", "mnsrf"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--cands", type=int, default=10)
     ap.add_argument("--qlen", type=int, default=4)
@@ -96,7 +96,7 @@ def build(args, dev):
     kind = args.model.upper()
     extra = dict(max_query_len=args.qlen, max_doc_len=args.dlen) if kind == "DUET" else {}
     margs = default_args(kind, src_vocab_size=args.vocab, **extra)
-    wrapper = Multitask(margs) if kind in ("CARS", "M_MATCH_TENSOR") else Ranker(margs)
+    wrapper = Multitask(margs) if kind in ("CARS", "M_MATCH_TENSOR", "MNSRF") else Ranker(margs)
     fill_module_(wrapper.network, 1013)
     wrapper.cuda()
     wrapper.network.eval()
@@ -107,7 +107,7 @@ def make_batches(args, rank, dev):
     out = []
     for i in range(args.nbatches):
         seed = 1013 + 7919 * i + 104729 * rank
-        if args.model in ("cars", "m_match_tensor"):
+        if args.model in ("cars", "m_match_tensor", "mnsrf"):
             b = synth.session_batch(args.batch, args.session, args.cands, args.qlen, args.dlen, args.vocab, seed)
         else:
             b = synth.ranker_batch(args.batch, args.cands, args.qlen, args.dlen, args.vocab, seed, uniform=args.uniform)
@@ -141,7 +141,7 @@ def main():
     L = lib.load()
     model = build(args, dev)
     batches = make_batches(args, rank, dev)
-    is_cars = args.model in ("cars", "m_match_tensor")      # session-structured batch [B,S,N,DL]
+    is_cars = args.model in ("cars", "m_match_tensor", "mnsrf")      # session-structured batch [B,S,N,DL]
     pairs_per_step_rank = args.batch * args.cands * (args.session if is_cars else 1)
 
     def forward(i):
@@ -412,7 +412,9 @@ def main():
         sd = {k: v.detach().cpu().float() for k, v in model.network.state_dict().items()}
         ex = {k: v.cpu() for k, v in batches[0].items()}
         ncores = torch.get_num_threads()
-        if args.model == "m_match_tensor":
+        if args.model == "mnsrf":
+            fn = lambda: torch.softmax(O.mnsrf_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)  # noqa: E731
+        elif args.model == "m_match_tensor":
             fn = lambda: torch.softmax(O.m_match_tensor_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)  # noqa: E731
         elif is_cars:
             fn = lambda: O.predict_softmax(O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"]))  # noqa: E731

@@ -23,6 +23,8 @@ MODEL_ARCHITECTURE = {
     "MATCH_TENSOR": dict(arch=dict(_LSTM, featsize=40, nhid_query=30, nhid_doc=140, nchannels=50,
                                    nfilters=6, match_filter_size=20),
                          data=dict(src_vocab_size=None, fix_embeddings=True)),
+    "MNSRF": dict(arch=dict(_LSTM, nhid_query=512, nhid_document=512, nhid_session=1024, regularize_coeff=0.1, alpha=0.5),
+                  data=dict(tgt_vocab_size=30000, fix_embeddings=True)),
     "M_MATCH_TENSOR": dict(arch=dict(_LSTM, featsize=40, nhid_query=30, nhid_document=140, nhid_session=300, nchannels=50,
                                      nfilters=6, match_filter_size=20, regularize_coeff=0.1, alpha=0.5),
                            data=dict(max_doc_len=100, max_query_len=10, tgt_vocab_size=30000, fix_embeddings=True)),

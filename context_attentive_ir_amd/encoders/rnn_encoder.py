@@ -57,7 +57,7 @@ class RNNEncoder(nn.Module):
         if init_states is not None:
             h0, c0 = (s.float().contiguous() for s in init_states)
         lens = lib.ids64(lengths) if lengths is not None else None
-        if I <= 64:   # narrow inputs: W_ih lives in registers inside the recurrence, no gate tensor
+        if I <= 64 and H <= 128:   # narrow inputs: W_ih lives in registers inside the recurrence, no gate tensor
             lib.check(L.nir_bilstm_fused_fwd(lib.ptr(x), I, lib.ptr(wih), lib.ptr(bih), lib.ptr(bhh), lib.ptr(lens),
                                              lib.ptr(whh), lib.ptr(h0), lib.ptr(c0), lib.ptr(out), lib.ptr(hn),
                                              lib.ptr(cn), M, T, H, ND, st), "nir_bilstm_fused_fwd")
@@ -65,6 +65,12 @@ class RNNEncoder(nn.Module):
         gates = torch.empty(M * T, ND * 4 * H, device=emb.device, dtype=torch.float32)
         lib.check(L.nir_linear_f32(lib.ptr(x), I, None, None, 0, 0, 0, lib.ptr(wih), I, lib.ptr(bih), lib.ptr(bhh),
                                    lib.ptr(gates), ND * 4 * H, M * T, ND * 4 * H, I, 0, st), "nir_linear_f32")
+        if H > 128:   # beyond the register-resident recurrences: streaming form, one GEMM + one cell kernel per step
+            ws = lib.workspace(L.nir_bilstm_steps_workspace_bytes(M, H), emb.device)
+            lib.check(L.nir_bilstm_steps_fwd(lib.ptr(gates), lib.ptr(lens), lib.ptr(whh), lib.ptr(h0), lib.ptr(c0), lib.ptr(out),
+                                             lib.ptr(hn), lib.ptr(cn), M, T, H, ND, lib.ptr(ws), ws.numel(), st),
+                      "nir_bilstm_steps_fwd")
+            return (hn, cn), out
         lib.check(L.nir_bilstm_fwd(lib.ptr(gates), lib.ptr(lens), lib.ptr(whh), lib.ptr(h0), lib.ptr(c0), lib.ptr(out),
                                    lib.ptr(hn), lib.ptr(cn), M, T, H, ND, st), "nir_bilstm_fwd")
         return (hn, cn), out

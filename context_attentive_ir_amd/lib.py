@@ -45,6 +45,11 @@ CarsSessionWeights = _struct(
      "shared_w", "priv1_w", "mo0_w", "mo0_b", "mo1_w", "mo1_b", "mo2_w", "mo2_b"],
     ["D", "HS"])
 
+MnsrfWeights = _struct(
+    "nir_mnsrf_weights",
+    ["q_wih", "q_whh", "q_bih", "q_bhh", "d_wih", "d_whh", "d_bih", "d_bhh", "s_wih", "s_whh", "s_bih", "s_bhh",
+     "proj_w", "proj_b"], ["Hq", "Hd", "HS"])
+
 _i, _l, _z = C.c_int, C.c_int64, C.c_size_t
 # name -> (restype, argtypes); must list EVERY symbol include/neuroir_hip.h declares (tests check this)
 SIGNATURES = {
@@ -60,6 +65,12 @@ SIGNATURES = {
     "nir_bilstm_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
     "nir_bilstm_supported": (_i, [_i]),
     "nir_bilstm_fused_fwd": (_i, [c_fp, _i, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
+    "nir_bilstm_steps_workspace_bytes": (_z, [_l, _i]),
+    "nir_bilstm_steps_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, C.c_void_p, _z, c_st]),
+    "nir_mnsrf_workspace_bytes": (_z, [_l, _i, _i, _i, _i, C.POINTER(MnsrfWeights)]),
+    "nir_mnsrf_encode": (_i, [c_ip, c_ip, _l, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z, c_fp, c_fp, c_st]),
+    "nir_mnsrf_score": (_i, [c_ip, c_ip, c_ip, c_ip, _l, _i, _i, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z,
+                            c_fp, c_st]),
     "nir_softmax_rows": (_i, [c_fp, c_fp, _l, _i, c_st]),
     "nir_softmax_gathered": (_i, [c_fp, c_fp, c_fp, _i, _l, _i, _i, c_st]),
     "nir_rank_loss_bce": (_i, [c_fp, c_fp, _l, _i, c_fp, c_st]),

@@ -1,0 +1,106 @@
+"""MNSRF -- ranking side of the multi-task neural session relevance framework (drop-in for
+neuroir.multitask.mnsrf.MNSRF, /root/reference/neuroir/multitask/mnsrf.py:10-162).
+
+encode():        BiLSTM over every query of a session + max pooling over time -> memory_bank [B,S,nhid_query];
+                 a unidirectional session LSTM over the S pooled queries   -> session_bank [B,S,nhid_session]
+rank_document(): BiLSTM + max pooling over every candidate document; score = tanh(W [q_t ; t > 0 ? s_t : 0] + b) . d
+One C-ABI call each (nir_mnsrf_encode / nir_mnsrf_score, csrc/mnsrf.hip).  The hidden sizes (256 per direction, 1024
+session units) are beyond the register-resident recurrences, so the LSTMs run in the streaming form (one MFMA GEMM +
+one cell kernel per time step).  The suggestion decoder / generator are parameter containers only (`decode` raises).
+"""
+import torch
+import torch.nn as nn
+from collections import OrderedDict
+
+from .. import lib
+from ..encoders.rnn_encoder import lstm_cat_weights
+from .layers import Embedder, Encoder
+from .mmtensor import _PlainDecoderParams
+
+
+class MNSRF(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1:
+            raise NotImplementedError("HIP MNSRF expects the reference configuration: 1-layer bidirectional LSTM encoders")
+        self.embedder = Embedder(args.emsize, args.src_vocab_size, args.dropout_emb)
+        self.query_encoder = Encoder(args.rnn_type, args.emsize, args.bidirection, args.nlayers, args.nhid_query, args.dropout_rnn)
+        self.document_encoder = Encoder(args.rnn_type, args.emsize, args.bidirection, args.nlayers, args.nhid_document,
+                                        args.dropout_rnn)
+        self.nhid_session = args.nhid_session
+        self.session_query_encoder = Encoder(args.rnn_type, args.nhid_query, False, args.nlayers, args.nhid_session,
+                                             args.dropout_rnn)
+        self.decoder = nn.Module()
+        self.decoder.decoder = _PlainDecoderParams(args.emsize, args.nhid_session)
+        self.projection = nn.Sequential(OrderedDict([("linear", nn.Linear(args.nhid_query + args.nhid_session, args.nhid_document)),
+                                                     ("tanh", nn.Tanh())]))
+        self.dropout = nn.Dropout(args.dropout)
+        self.generator = nn.Linear(args.nhid_session, args.tgt_vocab_size)
+        self.regularize_coeff = args.regularize_coeff
+        self._dims = dict(Hq=args.nhid_query // 2, Hd=args.nhid_document // 2, HS=args.nhid_session)
+        self._pack = lib.PackCache()
+
+    def _weights(self):
+        def build():
+            q = lstm_cat_weights(self.query_encoder.encoder.rnns[0])
+            d = lstm_cat_weights(self.document_encoder.encoder.rnns[0])
+            s = lstm_cat_weights(self.session_query_encoder.encoder.rnns[0])
+            t = dict(q_wih=q[0], q_whh=q[1], q_bih=q[2], q_bhh=q[3], d_wih=d[0], d_whh=d[1], d_bih=d[2], d_bhh=d[3],
+                     s_wih=s[0], s_whh=s[1], s_bih=s[2], s_bhh=s[3],
+                     proj_w=self.projection.linear.weight, proj_b=self.projection.linear.bias)
+            return lib.Packed(lib.MnsrfWeights, t, self._dims)
+        skip = ("embedder.", "decoder.", "generator.")
+        return self._pack.get([p for n, p in self.named_parameters() if not n.startswith(skip)], build)
+
+    def _check_eval(self):
+        if self.training and (self.dropout.p > 0 or self.embedder.dropout.p > 0):
+            raise NotImplementedError("HIP MNSRF implements the eval-mode forward (SURVEY.md Appendix E7)")
+
+    def encode(self, source_rep, source_len):
+        """source_rep [B,S,QL], source_len [B,S] -> (memory_bank [B,S,nhid_query], session_bank [B,S,nhid_session], None)
+        (mnsrf.py:62-114; the per-step decoder states are suggestion-side and not produced)."""
+        self._check_eval()
+        table = self.embedder.word_embeddings.table
+        lib.require_device(source_rep, source_len, table)
+        L = lib.load()
+        B, S, QL = source_rep.shape
+        src, sl = lib.ids64(source_rep.reshape(B * S, QL)), lib.ids64(source_len.reshape(-1))
+        w = self._weights()
+        ws = lib.workspace(L.nir_mnsrf_workspace_bytes(B, S, 0, QL, 1, w.ref()), src.device)
+        mem = torch.empty(B, S, 2 * self._dims["Hq"], device=src.device, dtype=torch.float32)
+        sess = torch.empty(B, S, self._dims["HS"], device=src.device, dtype=torch.float32)
+        if B > 0:
+            lib.check(L.nir_mnsrf_encode(lib.ptr(src), lib.ptr(sl), B, S, QL, lib.ptr(table), table.shape[0], table.shape[1],
+                                         w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(mem), lib.ptr(sess), lib.stream()),
+                      "nir_mnsrf_encode")
+        self._src_len = source_len
+        return mem, sess, None
+
+    def rank_document(self, source_rep, memory_bank, session_bank, document_rep, document_len, source_len=None):
+        """-> scores [B,S,N]  (mnsrf.py:116-162).  The query side is re-derived from the ids inside the fused call (the
+        same values as memory_bank / session_bank); `source_len` defaults to the lengths given to encode()."""
+        self._check_eval()
+        table = self.embedder.word_embeddings.table
+        src_len = source_len if source_len is not None else getattr(self, "_src_len", None)
+        if src_len is None:
+            raise RuntimeError("rank_document needs the query lengths: call encode() first or pass source_len")
+        lib.require_device(source_rep, document_rep, document_len, src_len, table)
+        L = lib.load()
+        B, S, N, DL = document_rep.shape
+        QL = source_rep.shape[2]
+        src, sl = lib.ids64(source_rep.reshape(B * S, QL)), lib.ids64(src_len.reshape(-1))
+        d, dl = lib.ids64(document_rep.reshape(B * S * N, DL)), lib.ids64(document_len.reshape(-1))
+        w = self._weights()
+        ws = lib.workspace(L.nir_mnsrf_workspace_bytes(B, S, N, QL, DL, w.ref()), src.device)
+        scores = torch.empty(B, S, N, device=src.device, dtype=torch.float32)
+        if B > 0:
+            lib.check(L.nir_mnsrf_score(lib.ptr(src), lib.ptr(sl), lib.ptr(d), lib.ptr(dl), B, S, N, QL, DL, lib.ptr(table),
+                                        table.shape[0], table.shape[1], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(scores),
+                                        lib.stream()), "nir_mnsrf_score")
+        return scores
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward (ranking + suggestion losses) is outside the hot path (SURVEY.md 8f)")
+
+    def decode(self, **kwargs):
+        raise NotImplementedError("query suggestion decoding is outside the hot path (SURVEY.md section 8f rank 4)")

@@ -1,12 +1,12 @@
 """Multitask -- wrapper with the call shapes of neuroir.models.multitask.Multitask
-(/root/reference/neuroir/models/multitask.py:24-407) for CARS and M_MATCH_TENSOR, ranking side only:
+(/root/reference/neuroir/models/multitask.py:24-407) for CARS, M_MATCH_TENSOR and MNSRF, ranking side only:
 predict(ex) -> {'click_scores': softmax over candidates [B,S,N]} (multitask.py:262-279)."""
 import torch
 
 from .. import lib
-from ..multitask import CARS, M_MATCH_TENSOR
+from ..multitask import CARS, M_MATCH_TENSOR, MNSRF
 
-NETWORKS = {"CARS": CARS, "M_MATCH_TENSOR": M_MATCH_TENSOR}
+NETWORKS = {"CARS": CARS, "M_MATCH_TENSOR": M_MATCH_TENSOR, "MNSRF": MNSRF}
 
 
 class Multitask(object):

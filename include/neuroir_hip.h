@@ -216,6 +216,38 @@ int nir_cars_rank_session(const float* pooled_q, const float* pooled_docs, const
                           const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
                           float* click_scores, float* clicks_out, nir_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Streaming recurrence for any hidden size (one GEMM h W_hh^T + one cell kernel per time step and direction; W_hh is
+ * re-read every step).  Same contract as nir_bilstm_fwd; needs nir_bilstm_steps_workspace_bytes(M, H) of scratch.
+ * Used for H > 128 (MNSRF: 256 per direction, 1024 session units).
+ * ------------------------------------------------------------------------------------------------ */
+size_t nir_bilstm_steps_workspace_bytes(int64_t M, int H);
+int nir_bilstm_steps_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0,
+                         float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir, void* workspace,
+                         size_t workspace_bytes, nir_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * MNSRF, ranking side (neuroir/multitask/mnsrf.py:62-162)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float *q_wih, *q_whh, *q_bih, *q_bhh;   /* query_encoder.encoder.rnns.0, both directions concatenated: [8Hq,E],[2,4Hq,Hq],[8Hq],[8Hq] */
+    const float *d_wih, *d_whh, *d_bih, *d_bhh;   /* document_encoder.encoder.rnns.0 */
+    const float *s_wih, *s_whh, *s_bih, *s_bhh;   /* session_query_encoder.encoder.rnns.0 (unidirectional) [4HS,2Hq],[4HS,HS],[4HS],[4HS] */
+    const float *proj_w, *proj_b;                 /* projection.linear [2Hd, 2Hq+HS], [2Hd] */
+    int Hq, Hd, HS;                               /* per-direction hidden sizes 256, 256; session 1024 */
+} nir_mnsrf_weights;
+size_t nir_mnsrf_workspace_bytes(int64_t B, int S, int N, int QL, int DL, const nir_mnsrf_weights* w /*host*/);
+/* MNSRF.encode (mnsrf.py:62-114): source ids [B,S,QL], lens [B,S] -> memory_bank [B,S,2Hq] (BiLSTM, max over time),
+ * session_bank [B,S,HS] (session LSTM over the S queries). */
+int nir_mnsrf_encode(const int64_t* source_ids, const int64_t* source_lens, int64_t B, int S, int QL, const float* table,
+                     int64_t V, int E, const nir_mnsrf_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                     float* memory_bank, float* session_bank, nir_stream_t stream);
+/* MNSRF.encode + rank_document (mnsrf.py:116-162): scores [B,S,N] = tanh(W [q_t ; t>0 ? s_t : 0] + b) . maxpool(BiLSTM(doc)). */
+int nir_mnsrf_score(const int64_t* source_ids, const int64_t* source_lens, const int64_t* doc_ids, const int64_t* doc_lens,
+                    int64_t B, int S, int N, int QL, int DL, const float* table, int64_t V, int E,
+                    const nir_mnsrf_weights* w /*host*/, void* workspace, size_t workspace_bytes, float* scores,
+                    nir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,46 @@ def match_tensor_scores(sd, q, q_len, d, d_len):
 
 
 # ------------------------------------------------------------------------------------------
+# MNSRF, ranking side  (neuroir/multitask/mnsrf.py:62-114 encode, :116-162 rank_document)
+# ------------------------------------------------------------------------------------------
+def _strip_encoder_nesting(sd):
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("embedder."):
+            out[k[len("embedder."):]] = v
+        elif ".encoder.rnns." in k:
+            out[k.replace(".encoder.", ".", 1)] = v
+        else:
+            out[k] = v
+    return out
+
+
+@torch.no_grad()
+def mnsrf_encode(sd, source_rep, source_len):
+    """-> (memory_bank [B,S,nhid_query], session_bank [B,S,nhid_session])"""
+    m = _strip_encoder_nesting(sd)
+    B, S, QL = source_rep.shape
+    _, enc = rnn_encode(m, "query_encoder", embed(m, "word_embeddings", source_rep.reshape(B * S, QL)), source_len.reshape(-1))
+    memory_bank = enc.max(1)[0].view(B, S, -1)                    # max over all (padded) positions, mnsrf.py:235-237
+    # the reference steps the session LSTM one query at a time carrying (h, c): the same as one pass over the S queries
+    _, session_bank = rnn_encode(m, "session_query_encoder", memory_bank, None, bidirectional=False)
+    return memory_bank, session_bank
+
+
+@torch.no_grad()
+def mnsrf_scores(sd, source_rep, source_len, document_rep, document_len):
+    """-> scores [B,S,N]"""
+    m = _strip_encoder_nesting(sd)
+    memory_bank, session_bank = mnsrf_encode(sd, source_rep, source_len)
+    B, S, N, DL = document_rep.shape
+    _, enc = rnn_encode(m, "document_encoder", embed(m, "word_embeddings", document_rep.reshape(B * S * N, DL)), document_len.reshape(-1))
+    docs = enc.max(1)[0].view(B, S, N, -1)
+    sess_in = torch.cat([torch.zeros_like(session_bank[:, :1]), session_bank[:, 1:]], 1)   # zeros at t = 0, s_t afterwards
+    comb = torch.tanh(_lin(m, "projection.linear", torch.cat([memory_bank, sess_in], 2)))   # [B,S,nhid_document]
+    return (comb.unsqueeze(2) * docs).sum(3)
+
+
+# ------------------------------------------------------------------------------------------
 # M_MATCH_TENSOR, ranking side  (neuroir/multitask/mmtensor.py:70-88 encode, :127-189 rank_document):
 # MatchTensor over the B*S (session, query) rows; only the module nesting of the state dict differs.
 # ------------------------------------------------------------------------------------------

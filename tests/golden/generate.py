@@ -252,6 +252,24 @@ def gen_m_match_tensor():
          projected_queries=pq, scores=scores, softmax=torch.softmax(scores, -1), tgt_vocab_size=50)
 
 
+@torch.no_grad()
+def gen_mnsrf():
+    """MNSRF (multitask/mnsrf.py): encode -> rank_document, eval mode."""
+    from neuroir.multitask.mnsrf import MNSRF
+    from context_attentive_ir_amd.detinit import fill_module_
+    args = base_args("MNSRF", tgt_vocab_size=50)
+    net = fill_module_(MNSRF(args).eval(), SEED)
+    rng = np.random.default_rng(SEED + 33)
+    B, S, N, QL, DL = 2, 3, 3, 4, 9
+    slen = rng.integers(1, QL + 1, size=(B, S)); slen[0, 0] = QL
+    dlen = rng.integers(1, DL + 1, size=(B, S, N)); dlen[0, 0, 0] = DL
+    src = rand_ids(rng, (B, S, QL), slen); docs = rand_ids(rng, (B, S, N, DL), dlen)
+    mem, sess, _ = net.encode(T(src), T(slen))
+    scores = net.rank_document(T(src), mem, sess, T(docs), T(dlen))
+    save("mnsrf", source_words=src, source_lens=slen, document_words=docs, document_lens=dlen, memory_bank=mem,
+         session_bank=sess, scores=scores, softmax=torch.softmax(scores, -1), tgt_vocab_size=50)
+
+
 def gen_batchify():
     """Input contract: the reference's own collate functions on ragged synthetic examples."""
     from neuroir.inputters.ranker.vector import batchify as ranker_batchify
@@ -323,4 +341,4 @@ def gen_samplers():
 if __name__ == "__main__":
     torch.manual_seed(SEED)
     torch.set_num_threads(4)
-    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics(); gen_batchify(); gen_samplers(); gen_m_match_tensor()
+    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics(); gen_batchify(); gen_samplers(); gen_m_match_tensor(); gen_mnsrf()

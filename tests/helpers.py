@@ -15,9 +15,9 @@ SEED = 1013
 
 def build_model(model_type, vocab=200, seed=SEED, device="cpu", **overrides):
     from context_attentive_ir_amd import rankers
-    from context_attentive_ir_amd.multitask import CARS, M_MATCH_TENSOR
+    from context_attentive_ir_amd.multitask import CARS, M_MATCH_TENSOR, MNSRF
     cls = {"ESM": rankers.ESM, "MATCH_TENSOR": rankers.MatchTensor, "DRMM": rankers.DRMM, "DUET": rankers.DUET,
-           "CARS": CARS, "M_MATCH_TENSOR": M_MATCH_TENSOR}[model_type]
+           "CARS": CARS, "M_MATCH_TENSOR": M_MATCH_TENSOR, "MNSRF": MNSRF}[model_type]
     args = default_args(model_type, src_vocab_size=vocab, **overrides)
     model = fill_module_(cls(args), seed).eval()
     return model.to(device)

@@ -617,3 +617,55 @@ def test_m_match_tensor_state_dict_keys():
               "decoder.decoder.rnn.weight_hh_l0", "generator.weight", "exact_match_channel.alpha", "conv3.weight", "output.bias"):
         assert k in keys, k
     assert len(keys) == 44
+
+
+# ------------------------------------------------------------------ MNSRF and the streaming recurrence
+def test_mnsrf_golden_and_oracle():
+    """MNSRF ranking side vs the reference fixture, then vs the oracle on a ragged random batch through the wrapper."""
+    from context_attentive_ir_amd.wrappers import Multitask
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    g = load_golden("mnsrf")
+    m = build_model("MNSRF", tgt_vocab_size=int(g["tgt_vocab_size"]), device=DEV)
+    src, sl, d, dl = (T(g[k], DEV) for k in ("source_words", "source_lens", "document_words", "document_lens"))
+    mem, sess, states = m.encode(src, sl)
+    assert states is None
+    _close(mem, g["memory_bank"]); _close(sess, g["session_bank"])
+    _close(m.rank_document(src, mem, sess, d, dl), g["scores"])
+
+    w = Multitask(default_args("MNSRF", src_vocab_size=300, tgt_vocab_size=40))
+    fill_module_(w.network, 23)
+    sd = cpu_state_dict(w.network)
+    w.cuda()
+    rng = np.random.default_rng(43)
+    B, S, N, QL, DL = 3, 4, 5, 5, 21
+    slen = rng.integers(1, QL + 1, size=(B, S)); dlen = rng.integers(1, DL + 1, size=(B, S, N))
+    srcw = rng.integers(4, 300, size=(B, S, QL)); srcw[np.arange(QL)[None, None] >= slen[..., None]] = 0
+    docw = rng.integers(4, 300, size=(B, S, N, DL)); docw[np.arange(DL)[None, None, None] >= dlen[..., None]] = 0
+    ex = {"source_words": torch.from_numpy(srcw), "source_lens": torch.from_numpy(slen),
+          "document_words": torch.from_numpy(docw), "document_lens": torch.from_numpy(dlen),
+          "document_labels": torch.zeros(B, S, N)}
+    out = w.predict(ex)["click_scores"]
+    ref = torch.softmax(O.mnsrf_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)
+    _close(out, ref)
+    assert len(w.network.state_dict()) == 29                  # the reference's key set (probed)
+    with pytest.raises(NotImplementedError):
+        w.network.decode()
+
+
+@pytest.mark.parametrize("H,I,M,T_,bi", [(256, 300, 9, 7, True), (200, 40, 5, 6, True), (1024, 64, 4, 5, False), (130, 300, 33, 4, True)])
+def test_rnn_encoder_streaming_recurrence(H, I, M, T_, bi):
+    """Hidden sizes beyond the register-resident kernels (H > 128): one GEMM + one cell kernel per step."""
+    from context_attentive_ir_amd.encoders import RNNEncoder
+    from context_attentive_ir_amd.detinit import fill_module_
+    nd = 2 if bi else 1
+    enc = fill_module_(RNNEncoder("LSTM", I, bi, 1, nd * H), seed=5).eval()
+    g = torch.Generator().manual_seed(H + M)
+    x = torch.randn(M, T_, I, generator=g); lens = torch.randint(1, T_ + 1, (M,), generator=g); lens[0] = T_
+    sd = {"e." + k: v for k, v in enc.state_dict().items()}
+    (hn_ref, cn_ref), ref = O.rnn_encode(sd, "e", x, lens, bidirectional=bi)
+    enc = enc.to(DEV)
+    (hn, cn), out = enc(x.to(DEV), lens.to(DEV))
+    _close(out, ref, 3e-5)
+    order = torch.sort(lens, 0, True)[1]
+    _close(hn[:, order], hn_ref, 3e-5); _close(cn[:, order], cn_ref, 3e-5)

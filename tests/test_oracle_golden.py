@@ -81,6 +81,17 @@ def test_m_match_tensor():
     _close(O.predict_softmax(s), g["softmax"])
 
 
+def test_mnsrf():
+    g = load_golden("mnsrf")
+    sd = cpu_state_dict(build_model("MNSRF", tgt_vocab_size=int(g["tgt_vocab_size"])))
+    src, sl, d, dl = (T(g[k]) for k in ("source_words", "source_lens", "document_words", "document_lens"))
+    mem, sess = O.mnsrf_encode(sd, src, sl)
+    _close(mem, g["memory_bank"]); _close(sess, g["session_bank"])
+    s = O.mnsrf_scores(sd, src, sl, d, dl)
+    _close(s, g["scores"], 5e-6)
+    _close(O.predict_softmax(s), g["softmax"], 2e-6)
+
+
 def test_losses_and_metrics():
     g = load_golden("losses_metrics")
     s, y = T(g["scores"]), T(g["labels"])
