@@ -53,31 +53,37 @@ __global__ void copy_f32_kernel(const float* s, float* d, int64_t n) {
 }
 static dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
-size_t lstm_steps_ws_floats(int64_t M, int H) { return (size_t)M * H * 2 + (size_t)M * 4 * H; }
+size_t lstm_steps_ws_floats(int64_t M, int H) { return 2 * ((size_t)M * H * 2 + (size_t)M * 4 * H); }   // one set per direction
 
-// gates_in [M,T,ND*4H] (both biases included), w_hh [ND,4H,H]; out [M,T,ND*H] zero beyond each length; hn/cn [ND,M,H] or null
+// gates_in [M,T,ND*4H] (both biases included), w_hh [ND,4H,H]; out [M,T,ND*H] zero beyond each length; hn/cn [ND,M,H] or null.
+// The two directions are independent chains of T x (GEMM, cell): with one batch in flight the reverse direction runs on
+// the side stream (own state / scratch set), with several batches in flight ForkJoin is a no-op and they run back to back.
 int launch_bilstm_steps(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0, float* out,
                         float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st) {
-    float* hs = ws;
-    float* cs = hs + M * H;
-    float* hw = cs + M * H;
     hipLaunchKernelGGL(fill_f32_kernel, g1(M * T * ND * H), dim3(256), 0, st, out, 0.f, M * T * ND * (int64_t)H);
+    ForkJoin fj(st);
+    if (ND == 2) fj.fork();
     for (int dir = 0; dir < ND; ++dir) {
+        hipStream_t ds = dir == 1 ? fj.side : st;
+        float* hs = ws + (size_t)dir * ((size_t)M * H * 2 + (size_t)M * 4 * H);
+        float* cs = hs + M * H;
+        float* hw = cs + M * H;
         const float* w = whh + (int64_t)dir * 4 * H * H;
-        if (h0) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, st, h0 + (int64_t)dir * M * H, hs, M * (int64_t)H);
-        else hipLaunchKernelGGL(fill_f32_kernel, g1(M * H), dim3(256), 0, st, hs, 0.f, M * (int64_t)H);
-        if (c0) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, st, c0 + (int64_t)dir * M * H, cs, M * (int64_t)H);
-        else hipLaunchKernelGGL(fill_f32_kernel, g1(M * H), dim3(256), 0, st, cs, 0.f, M * (int64_t)H);
+        if (h0) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, h0 + (int64_t)dir * M * H, hs, M * (int64_t)H);
+        else hipLaunchKernelGGL(fill_f32_kernel, g1(M * H), dim3(256), 0, ds, hs, 0.f, M * (int64_t)H);
+        if (c0) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, c0 + (int64_t)dir * M * H, cs, M * (int64_t)H);
+        else hipLaunchKernelGGL(fill_f32_kernel, g1(M * H), dim3(256), 0, ds, cs, 0.f, M * (int64_t)H);
         for (int step = 0; step < T; ++step) {
             const bool skip_gemm = step == 0 && !h0;          // h_{-1} = 0
-            if (!skip_gemm) NIR_PROPAGATE(launch_linear(hs, H, nullptr, nullptr, 0, 0, 0, w, H, nullptr, nullptr, hw, 4 * H, M, 4 * H, H, NIR_ACT_NONE, st));
-            ProfScope ps("lstm_step_cell_kernel", st);
-            hipLaunchKernelGGL(lstm_step_cell_kernel, g1(M * H), dim3(256), 0, st, skip_gemm ? nullptr : hw, gin, lens, hs, cs, out, M, T, H,
+            if (!skip_gemm) NIR_PROPAGATE(launch_linear(hs, H, nullptr, nullptr, 0, 0, 0, w, H, nullptr, nullptr, hw, 4 * H, M, 4 * H, H, NIR_ACT_NONE, ds));
+            ProfScope ps("lstm_step_cell_kernel", ds);
+            hipLaunchKernelGGL(lstm_step_cell_kernel, g1(M * H), dim3(256), 0, ds, skip_gemm ? nullptr : hw, gin, lens, hs, cs, out, M, T, H,
                                ND, dir, step);
         }
-        if (hn) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, st, hs, hn + (int64_t)dir * M * H, M * (int64_t)H);
-        if (cn) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, st, cs, cn + (int64_t)dir * M * H, M * (int64_t)H);
+        if (hn) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, hs, hn + (int64_t)dir * M * H, M * (int64_t)H);
+        if (cn) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, cs, cn + (int64_t)dir * M * H, M * (int64_t)H);
     }
+    if (ND == 2) fj.join();
     NIR_CHECK_LAUNCH("nir_bilstm_steps_fwd");
     return 0;
 }
