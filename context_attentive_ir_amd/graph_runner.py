@@ -7,6 +7,7 @@ fixed at capture time (one predictor per (B, N, QL, DL) bucket -- the reference'
 neuroir/inputters/ranker/data.py:37-56, already group batches by shape).
 """
 import ctypes
+import time
 
 import torch
 
@@ -68,7 +69,8 @@ class GraphedPredictor(object):
         ev = self.copy_done if self.queue_ahead else self.replay_done
         if ev is not None:
             while not ev.query():        # spin: a blocking synchronize can put the host thread to sleep, and the wake-up
-                pass                     # (tens of us) is of the order of a whole C2 batch
+                time.sleep(0)            # (tens of us) is of the order of a whole C2 batch; sleep(0) only yields the GIL
+                                         # (e.g. to inputters.PrefetchingBatchStream's collating thread)
 
     def _h2d(self):
         self.dev_buf.copy_(self.host_buf, non_blocking=True)     # stream order keeps it behind the previous replay
