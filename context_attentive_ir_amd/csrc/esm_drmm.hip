@@ -106,8 +106,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // (i*5 + bin) == lane16 (mod 16) in registers.  First version (one row per wave, element-wise IEEE division, 5
 // full-wave reductions per row) was VALU-issue-bound at 2.45 TB/s algorithmic.
 // dynamic LDS: qn[QL][E] + glog[QL] + hist[QL*5]
-constexpr int DR_MAXC = 8;   // float4 pieces per lane: supports E <= 512
-template <int NU>            // histogram slots per lane: NU*16 >= QL*5
+// NU: histogram slots per lane (NU*16 >= QL*5); DR_MAXC: float4 pieces per lane of a 16-lane row group (16*4*DR_MAXC >= E):
+// 5 for the 300-d tables of the reference (a fixed 8 spent 3 of every 8 load/dot slots on always-false guards), 8 up to E = 512
+template <int NU, int DR_MAXC>
 __global__ __launch_bounds__(256) void drmm_kernel(const int64_t* __restrict__ q_ids, const int64_t* __restrict__ d_ids, int N,
                                                    int QL, int DL, const float* __restrict__ table, int E, DrmmW w,
                                                    float* __restrict__ scores, float* __restrict__ hist_out) {
@@ -240,12 +241,14 @@ extern "C" int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b};
     size_t lds = (size_t)QL * E * 4 + QL * 4 + QL * 5 * 4;
     ProfScope ps("drmm_kernel", (hipStream_t)stream);
-    if (QL * 5 <= 32)
-        hipLaunchKernelGGL(drmm_kernel<2>, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, q_ids, d_ids, N,
-                           QL, DL, table, E, dw, scores, hist_out);
-    else
-        hipLaunchKernelGGL(drmm_kernel<8>, dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, q_ids, d_ids, N,
-                           QL, DL, table, E, dw, scores, hist_out);
+    const bool small = QL * 5 <= 32, narrow = E <= 320;
+#define NIR_DRMM_LAUNCH(nu, pc) hipLaunchKernelGGL((drmm_kernel<nu, pc>), dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, \
+                                                   q_ids, d_ids, N, QL, DL, table, E, dw, scores, hist_out)
+    if (small && narrow) NIR_DRMM_LAUNCH(2, 5);
+    else if (small) NIR_DRMM_LAUNCH(2, 8);
+    else if (narrow) NIR_DRMM_LAUNCH(8, 5);
+    else NIR_DRMM_LAUNCH(8, 8);
+#undef NIR_DRMM_LAUNCH
     NIR_CHECK_LAUNCH("nir_drmm_score");
     return 0;
 }
