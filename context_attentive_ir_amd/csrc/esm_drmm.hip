@@ -85,10 +85,6 @@ __global__ __launch_bounds__(256) void esm_kernel(const int64_t* q_ids, const in
     if (lane == 0) scores[(int64_t)b * N + n] = dot;
 }
 
-struct DrmmW {
-    const float *gate_w, *gate_b, *f0w, *f0b, *f1w, *f1b, *ow, *ob;
-};
-
 // sum over the 16 lanes of a DPP row; every lane of the row gets the total
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -97,6 +93,82 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0x140>(v);   // row_mirror
     return v;
 }
+
+// 16-lane row groups (as in drmm_kernel below): a wave reads FOUR rows per load instruction, group g = lane >> 4 takes
+// rows g, g+4, ..., lane l16 owns the 16-byte pieces l16 + 16u of its row (E = 300: 5 pieces, 75 of 80 lane slots used;
+// the full-wave form above spends a second load instruction per row on 11 active lanes).  PCS = pieces per lane.
+template <int PCS>
+__device__ __forceinline__ void gather_sum16(const int64_t* ids, int L, const float* table, int E, int lane, float4 (&acc)[PCS]) {
+    const int nch = E >> 2, l16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < PCS; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < L; base += 64) {
+        const int64_t myid = (base + lane < L) ? ids[base + lane] : 0;
+        const int cnt = min(64, L - base);
+        for (int r = 0; r < cnt; r += 8) {                  // 2 rows in flight per group = 8 per wave
+            float4 v[2][PCS];
+            bool ok[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int row = r + g + 4 * k;
+                ok[k] = row < cnt;
+                const float* rp = table + __shfl(myid, ok[k] ? row : 0, 64) * (int64_t)E;
+#pragma unroll
+                for (int u = 0; u < PCS; ++u) {
+                    const int c = l16 + 16 * u;
+                    v[k][u] = (ok[k] && c < nch) ? *reinterpret_cast<const float4*>(rp + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int u = 0; u < PCS; ++u) {
+                    acc[u].x += v[k][u].x; acc[u].y += v[k][u].y; acc[u].z += v[k][u].z; acc[u].w += v[k][u].w;
+                }
+        }
+    }
+    // fold the 4 row groups: afterwards every lane holds the full sum of its pieces
+#pragma unroll
+    for (int u = 0; u < PCS; ++u) {
+        acc[u].x += __shfl_xor(acc[u].x, 16, 64); acc[u].y += __shfl_xor(acc[u].y, 16, 64);
+        acc[u].z += __shfl_xor(acc[u].z, 16, 64); acc[u].w += __shfl_xor(acc[u].w, 16, 64);
+        acc[u].x += __shfl_xor(acc[u].x, 32, 64); acc[u].y += __shfl_xor(acc[u].y, 32, 64);
+        acc[u].z += __shfl_xor(acc[u].z, 32, 64); acc[u].w += __shfl_xor(acc[u].w, 32, 64);
+    }
+}
+
+// grid (ceil(N/4), B); one wave per (query, candidate); 16-lane row groups
+template <int PCS>
+__global__ __launch_bounds__(256) void esm16_kernel(const int64_t* q_ids, const int64_t* d_ids, int N, int QL, int DL,
+                                                    const float* table, int E, float* scores) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float4 qs[PCS], ds[PCS];
+    gather_sum16<PCS>(q_ids + (int64_t)b * QL, QL, table, E, lane, qs);
+    gather_sum16<PCS>(d_ids + ((int64_t)b * N + n) * DL, DL, table, E, lane, ds);
+    const float iq = 1.0f / (float)QL, id = 1.0f / (float)DL;  // mean over the PADDED length (esm.py:35,40)
+    float nq = 0.f, nd = 0.f;
+#pragma unroll
+    for (int u = 0; u < PCS; ++u) {
+        qs[u] = scale4(qs[u], iq);
+        ds[u] = scale4(ds[u], id);
+        nq += dot4(qs[u], qs[u]);
+        nd += dot4(ds[u], ds[u]);
+    }
+    // every piece is replicated in the 4 row groups: reduce inside one 16-lane row
+    nq = fmaxf(sqrtf(row16_sum(nq)), 1e-8f);  // ATen cosine_similarity: x/max(|x|,eps) . y/max(|y|,eps)
+    nd = fmaxf(sqrtf(row16_sum(nd)), 1e-8f);
+    float dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < PCS; ++u) dot += dot4(div4(qs[u], nq), div4(ds[u], nd));
+    dot = row16_sum(dot);
+    if (lane == 0) scores[(int64_t)b * N + n] = dot;
+}
+
+struct DrmmW {
+    const float *gate_w, *gate_b, *f0w, *f0b, *f1w, *f1b, *ow, *ob;
+};
 
 // One workgroup (4 waves = 16 row groups of 16 lanes) per (query, candidate) pair.
 // A row group owns one document row at a time: its 16 lanes read the 4E-byte table row as 16-byte pieces
@@ -221,9 +293,15 @@ extern "C" int nir_esm_score(const int64_t* q_ids, const int64_t* d_ids, int B, 
     NIR_REQUIRE(E % 4 == 0 && E > 0 && E <= 256 * MAXCH, "esm: emsize %d unsupported (multiple of 4, <= %d)", E, 256 * MAXCH);
     NIR_REQUIRE(((uintptr_t)table & 15) == 0, "esm: table must be 16-byte aligned");
     if (B == 0) return 0;
-    ProfScope ps("esm_kernel", (hipStream_t)stream);
-    hipLaunchKernelGGL(esm_kernel, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q_ids, d_ids, N, QL, DL,
-                       table, E, scores);
+    if (E <= 320 && !getenv("NIR_ESM_WAVE_ROWS")) {
+        ProfScope ps("esm16_kernel", (hipStream_t)stream);
+        hipLaunchKernelGGL(esm16_kernel<5>, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q_ids, d_ids, N, QL, DL,
+                           table, E, scores);
+    } else {
+        ProfScope ps("esm_kernel", (hipStream_t)stream);
+        hipLaunchKernelGGL(esm_kernel, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q_ids, d_ids, N, QL, DL,
+                           table, E, scores);
+    }
     NIR_CHECK_LAUNCH("nir_esm_score");
     return 0;
 }
