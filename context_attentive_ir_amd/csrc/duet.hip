@@ -19,24 +19,43 @@ int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, f
                   hipStream_t st);
 
 // one workgroup per pair: u[pair][f] = tanh(fc1_b + sum_i fc1_w[i] * tanh(conv_b[f] + sum_{j: d_j==q_i} Wt[j][f]))
+// The QL x DL id comparisons do not depend on f: they are done ONCE per pair (a wave per query position, ballot +
+// mbcnt compaction keeps the matching j in ascending order, so the sums below are taken in the reference's order)
+// and every filter thread then walks only the (few) matches.  The first version repeated all QL*DL comparisons in
+// every one of the NF filter threads (C4: 480 us per launch).
 __global__ __launch_bounds__(256) void duet_local_kernel(const int64_t* __restrict__ q_ids, const int64_t* __restrict__ d_ids,
                                                          const float* __restrict__ wt /*[DL][NF]*/, const float* __restrict__ cb,
                                                          const float* __restrict__ fc1w, const float* __restrict__ fc1b, int N,
                                                          int QL, int DL, int NF, float* __restrict__ u) {
-    extern __shared__ int64_t dsh[];  // [DL] doc ids, then [QL] query ids
+    extern __shared__ int64_t dsh[];              // [DL] doc ids | [QL] query ids | int cnt[QL] | int list[QL][DL]
     int64_t* qsh = dsh + DL;
+    int* cnt = (int*)(qsh + QL);
+    int* list = cnt + QL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pair = blockIdx.x;
     const int b = (int)(pair / N);
     for (int j = threadIdx.x; j < DL; j += 256) dsh[j] = d_ids[pair * DL + j];
     for (int i = threadIdx.x; i < QL; i += 256) qsh[i] = q_ids[(int64_t)b * QL + i];
     __syncthreads();
+    for (int i = wave; i < QL; i += 4) {          // ordered compaction of {j : d_j == q_i}
+        const int64_t qid = qsh[i];
+        int n = 0;
+        for (int j0 = 0; j0 < DL; j0 += 64) {
+            const int j = j0 + lane;
+            const bool hit = j < DL && dsh[j] == qid;
+            const unsigned long long m = __ballot(hit);
+            if (hit) list[i * DL + n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = j;
+            n += __popcll(m);
+        }
+        if (lane == 0) cnt[i] = n;
+    }
+    __syncthreads();
     for (int f = threadIdx.x; f < NF; f += 256) {
         float acc = fc1b[0];
         for (int i = 0; i < QL; ++i) {
-            const int64_t qid = qsh[i];
             float s = cb[f];
-            for (int j = 0; j < DL; ++j)
-                if (dsh[j] == qid) s += wt[(int64_t)j * NF + f];  // wave-uniform branch, coalesced row read
+            const int n = cnt[i];
+            for (int m = 0; m < n; ++m) s += wt[(int64_t)list[i * DL + m] * NF + f];   // coalesced row read
             acc = fmaf(fc1w[i], fast_tanh(s), acc);
         }
         u[pair * NF + f] = fast_tanh(acc);
@@ -53,34 +72,89 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float* x, float* out,
     }
 }
 
-// pooled[m][t][f] = max_{dt < P} x[m][t+dt][f], t < Tin-P+1   (max_pool1d(P, stride 1), duet.py:180); float4 over f
-__global__ __launch_bounds__(256) void maxpool_t_kernel(const float* x, float* out, int Tin, int P, int NF4, int64_t total) {
+// pooled[m][t][f] = max_{dt < P} x[m][t+dt][f], t < Tin-P+1   (max_pool1d(P, stride 1), duet.py:180); float4 over f.
+// A thread produces a run of TR consecutive positions of one 16-byte column: TR + P - 1 loads for TR outputs (the
+// one-output-per-thread form issued P loads per output and ran at 4.1 TB/s of HBM traffic).
+constexpr int MP_TR = 8, MP_PMAX = 8;
+__global__ __launch_bounds__(256) void maxpool_t_kernel(const float* __restrict__ x, float* __restrict__ out, int Tin, int P, int NF4,
+                                                        int64_t M) {
     const int Tout = Tin - P + 1;
+    const int nrun = (Tout + MP_TR - 1) / MP_TR;
+    const int64_t total = M * nrun * NF4;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        int f4 = (int)(e % NF4);
-        int64_t r = e / NF4;
-        int t = (int)(r % Tout);
-        int64_t m = r / Tout;
-        const float4* src = reinterpret_cast<const float4*>(x) + (m * Tin + t) * NF4 + f4;
-        float4 v = src[0];
-        for (int dt = 1; dt < P; ++dt) {
-            float4 o = src[(int64_t)dt * NF4];
-            v.x = fmaxf(v.x, o.x); v.y = fmaxf(v.y, o.y); v.z = fmaxf(v.z, o.z); v.w = fmaxf(v.w, o.w);
+        const int f4 = (int)(e % NF4);
+        const int64_t r = e / NF4;
+        const int run = (int)(r % nrun);
+        const int64_t m = r / nrun;
+        const int t0 = run * MP_TR;
+        const float4* src = reinterpret_cast<const float4*>(x) + (m * Tin + t0) * NF4 + f4;
+        float4 v[MP_TR + MP_PMAX - 1];
+#pragma unroll
+        for (int k = 0; k < MP_TR + MP_PMAX - 1; ++k)
+            v[k] = (k < MP_TR + P - 1 && t0 + k < Tin) ? src[(int64_t)k * NF4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        float4* dst = reinterpret_cast<float4*>(out) + (m * Tout + t0) * NF4 + f4;
+#pragma unroll
+        for (int k = 0; k < MP_TR; ++k) {
+            if (t0 + k < Tout) {
+                float4 a = v[k];
+#pragma unroll
+                for (int dt = 1; dt < MP_PMAX; ++dt)
+                    if (dt < P) {
+                        a.x = fmaxf(a.x, v[k + dt].x); a.y = fmaxf(a.y, v[k + dt].y);
+                        a.z = fmaxf(a.z, v[k + dt].z); a.w = fmaxf(a.w, v[k + dt].w);
+                    }
+                dst[(int64_t)k * NF4] = a;
+            }
         }
-        reinterpret_cast<float4*>(out)[e] = v;
     }
 }
 
 // m1[pair][f] = tanh(fc2_b + sum_t fc2_w[t] * qv[b][f] * dd[pair][t][f])     (Hadamard + Linear over positions)
-__global__ __launch_bounds__(256) void duet_hadamard_kernel(const float* dd, const float* qv, const float* fc2w,
-                                                            const float* fc2b, int N, int T, int NF, float* m1) {
+// One workgroup per pair streams its [T, NF] block once: 16-byte lanes over f, the positions split over
+// 256 / (NF/4) thread groups with 4 loads in flight each, partial sums folded through LDS.  (The first version gave a
+// thread one f and walked all T positions with a single dependent 4-byte load in flight: 2.4 TB/s.)
+__global__ __launch_bounds__(256) void duet_hadamard_kernel(const float* __restrict__ dd, const float* __restrict__ qv,
+                                                            const float* __restrict__ fc2w, const float* __restrict__ fc2b, int N,
+                                                            int T, int NF, float* __restrict__ m1) {
+    extern __shared__ __attribute__((aligned(16))) float4 hsm[];       // [groups][NF/4]
     const int64_t pair = blockIdx.x;
     const int b = (int)(pair / N);
-    for (int f = threadIdx.x; f < NF; f += 256) {
-        const float q = qv[(int64_t)b * NF + f];
-        float acc = fc2b[0];
-        for (int t = 0; t < T; ++t) acc = fmaf(fc2w[t], q * dd[(pair * T + t) * NF + f], acc);
-        m1[pair * NF + f] = fast_tanh(acc);
+    const int NF4 = NF >> 2, groups = 256 / NF4;
+    const int f4 = threadIdx.x % NF4, tg = threadIdx.x / NF4;
+    if (tg < groups) {
+        const float4 q = reinterpret_cast<const float4*>(qv + (int64_t)b * NF)[f4];
+        const float4* src = reinterpret_cast<const float4*>(dd + pair * T * (int64_t)NF) + f4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = tg;
+        for (; t + 3 * groups < T; t += 4 * groups) {
+            float4 v[4];
+            float wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = src[(int64_t)(t + k * groups) * NF4]; wv[k] = fc2w[t + k * groups]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc.x = fmaf(wv[k], q.x * v[k].x, acc.x); acc.y = fmaf(wv[k], q.y * v[k].y, acc.y);
+                acc.z = fmaf(wv[k], q.z * v[k].z, acc.z); acc.w = fmaf(wv[k], q.w * v[k].w, acc.w);
+            }
+        }
+        for (; t < T; t += groups) {
+            const float4 v = src[(int64_t)t * NF4];
+            const float wv = fc2w[t];
+            acc.x = fmaf(wv, q.x * v.x, acc.x); acc.y = fmaf(wv, q.y * v.y, acc.y);
+            acc.z = fmaf(wv, q.z * v.z, acc.z); acc.w = fmaf(wv, q.w * v.w, acc.w);
+        }
+        hsm[tg * NF4 + f4] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < NF4) {
+        float4 a = hsm[threadIdx.x];
+        for (int g2 = 1; g2 < groups; ++g2) {
+            const float4 o = hsm[g2 * NF4 + threadIdx.x];
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        const float bias = fc2b[0];
+        reinterpret_cast<float4*>(m1 + pair * NF)[threadIdx.x] =
+            make_float4(fast_tanh(a.x + bias), fast_tanh(a.y + bias), fast_tanh(a.z + bias), fast_tanh(a.w + bias));
     }
 }
 
@@ -132,7 +206,10 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     NIR_REQUIRE(B >= 0 && N > 0 && V > 0 && E > 0, "duet: bad dims");
     NIR_REQUIRE(QL >= 3, "duet: query length %d < dist_filter_size 3 (Conv1d would be empty)", QL);
     NIR_REQUIRE(DL >= w->pool + 2, "duet: doc length %d too short for conv(3) + max_pool(%d)", DL, w->pool);
-    NIR_REQUIRE(w->NF % 4 == 0, "duet: nfilters %d must be a multiple of 4", w->NF);
+    NIR_REQUIRE(w->pool >= 1 && w->pool <= 8, "duet: pool_size %d unsupported (1..8)", w->pool);
+    NIR_REQUIRE(w->NF % 4 == 0 && w->NF <= 1024, "duet: nfilters %d must be a multiple of 4 and <= 1024", w->NF);
+    NIR_REQUIRE((size_t)(DL + QL) * 8 + (size_t)(QL + (size_t)QL * DL) * 4 <= 64 * 1024,
+                "duet: QL=%d x DL=%d exact-match lists exceed 64 KB of LDS", QL, DL);
     if (B == 0) return 0;
     const int NF = w->NF, P = w->pool, Tc = DL - 2, Tp = Tc - P + 1;
     DuetPlan p = duet_plan(workspace, workspace_bytes, B, N, QL, DL, NF, P);
@@ -146,7 +223,7 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     // ---- local model (duet.py:77-121)
     {
         ProfScope ps("duet_local_kernel", st);
-        hipLaunchKernelGGL(duet_local_kernel, dim3((unsigned)M), dim3(256), (size_t)(DL + QL) * 8, st, q_ids, d_ids,
+        hipLaunchKernelGGL(duet_local_kernel, dim3((unsigned)M), dim3(256), (size_t)(DL + QL) * 8 + (size_t)(QL + QL * DL) * 4, st, q_ids, d_ids,
                            w->l_conv_w, w->l_conv_b, w->l_fc1_w, w->l_fc1_b, N, QL, DL, NF, p.u);
     }
     NIR_CHECK_LAUNCH("duet_local_kernel");
@@ -163,17 +240,18 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     // ---- distributed model, document side (duet.py:174,180,185)
     NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, Tc, DL, w->convd1_w, 3 * E, w->convd1_b, nullptr, p.cd, NF, M * Tc, NF, 3 * E, NIR_ACT_TANH, st));
     {
-        const int64_t total = M * Tp * (NF / 4);
+        const int64_t total = (int64_t)M * ((Tp + MP_TR - 1) / MP_TR) * (NF / 4);
         ProfScope ps("maxpool_t_kernel", st);
-        hipLaunchKernelGGL(maxpool_t_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, st, p.cd,
-                           p.pooled, Tc, P, NF / 4, total);
+        hipLaunchKernelGGL(maxpool_t_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, p.cd,
+                           p.pooled, Tc, P, NF / 4, (int64_t)M);
     }
     NIR_CHECK_LAUNCH("maxpool_t_kernel");
     NIR_PROPAGATE(launch_linear(p.pooled, NF, nullptr, nullptr, 0, 0, 0, w->convd2_w, NF, w->convd2_b, nullptr, p.dd, NF, M * Tp, NF, NF, NIR_ACT_TANH, st));
     // ---- Hadamard + fc2 over positions, fc3, fc4 (duet.py:187-207)
     {
         ProfScope ps("duet_hadamard_kernel", st);
-        hipLaunchKernelGGL(duet_hadamard_kernel, dim3((unsigned)M), dim3(256), 0, st, p.dd, p.qv, w->fc2_w, w->fc2_b, N, Tp, NF, p.m1);
+        hipLaunchKernelGGL(duet_hadamard_kernel, dim3((unsigned)M), dim3(256), (size_t)(256 / (NF / 4)) * (NF / 4) * 16, st, p.dd, p.qv, w->fc2_w,
+                           w->fc2_b, N, Tp, NF, p.m1);
     }
     NIR_CHECK_LAUNCH("duet_hadamard_kernel");
     NIR_PROPAGATE(launch_linear(p.m1, NF, nullptr, nullptr, 0, 0, 0, w->fc3_w, NF, w->fc3_b, nullptr, p.m2, NF, M, NF, NF, NIR_ACT_TANH, st));
