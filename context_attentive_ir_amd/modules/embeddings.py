@@ -9,7 +9,6 @@ stock PyTorch) and is plain torch.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 class Embeddings(nn.Module):
@@ -49,5 +48,7 @@ class Embeddings(nn.Module):
                 self.word_lut.weight.requires_grad = False
 
     def forward(self, source):
-        """source [B, L, 1] -> [B, L, E] (stock torch; not used by the HIP hot path)."""
-        return F.embedding(source.squeeze(2), self.word_lut.weight, self.word_padding_idx)
+        """The reference materialises [B, L, E] here (embeddings.py:243-252).  On the HIP path nothing of that shape
+        exists: every consumer gathers the rows inside its own operand loads (nir_linear_f32 with ids, nir_esm_score,
+        ...), reading `self.table`.  There is deliberately no stock-torch lookup to fall back on."""
+        raise NotImplementedError("Embeddings.forward is fused into the consuming HIP kernels (pass ids + .table to the C-ABI)")

@@ -16,8 +16,8 @@ class Embedder(nn.Module):
         self.dropout = nn.Dropout(dropout_emb)
 
     def forward(self, sequence):
-        """stock-torch lookup for callers outside the HIP hot path (e.g. a suggestion decoder)."""
-        return self.dropout(self.word_embeddings(sequence.unsqueeze(2)))
+        """Fused into the consuming kernels like Embeddings.forward (layers.py:23-27 of the reference)."""
+        raise NotImplementedError("Embedder.forward is fused into the consuming HIP kernels (pass ids + word_embeddings.table)")
 
 
 class Encoder(nn.Module):

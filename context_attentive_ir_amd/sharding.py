@@ -44,10 +44,11 @@ def gather_scores(local, N, group=None):
 
 def gathered_softmax(local, N, group=None):
     """Blocking all-gather of the score shards [B,per] + softmax over the N candidates -> [B,N] on every rank.
-    On a ROCm device the softmax reads the rank-major gather buffer directly (nir_softmax_gathered: no permute/slice
-    copies); on CPU tensors (gloo tests) it is gather_scores + torch.softmax."""
+    The softmax reads the rank-major gather buffer directly (nir_softmax_gathered: no permute/slice copies).  Device
+    tensors only -- there is no CPU arithmetic in this package (the gloo tests exercise gather_scores / ScoreGather.wait,
+    which only move data)."""
     if not local.is_cuda:
-        return torch.softmax(gather_scores(local, N, group), -1)
+        raise RuntimeError("gathered_softmax needs score shards on a ROCm device (no CPU fallback)")
     from . import lib
     world = dist.get_world_size(group)
     B, per = local.shape
@@ -82,9 +83,9 @@ class ScoreGather(object):
 
     def softmax(self, probs=None):
         """-> softmax over the N gathered candidates, [B,N]: one kernel straight off the rank-major gather buffer
-        (device tensors; the CPU/gloo path goes through wait())."""
+        (device tensors only; no CPU fallback)."""
         if not self.out.is_cuda:
-            return torch.softmax(self.wait(), -1)
+            raise RuntimeError("ScoreGather.softmax needs device tensors (no CPU fallback); use wait() to get the raw scores")
         from . import lib
         self.work.wait()
         if probs is None:

@@ -181,11 +181,11 @@ def _async_gather_worker(rank, world, port, q):
             loc[:, :hi - lo] = full[k][:, lo:hi]
             handles.append(sharding.ScoreGather(loc, N))
         ok = all(torch.equal(h.wait(), full[k]) for k, h in enumerate(handles))
-        ok = ok and all(torch.allclose(h.softmax(), torch.softmax(full[k], -1)) for k, h in enumerate(handles))
-        lo, hi, _ = sharding.shard_bounds(N, world, rank)
-        loc = torch.zeros(B, per)
-        loc[:, :hi - lo] = full[0][:, lo:hi]
-        ok = ok and torch.allclose(sharding.gathered_softmax(loc, N), torch.softmax(full[0], -1))
+        try:                                     # the softmax forms are device-only: no CPU arithmetic in the product
+            handles[0].softmax()
+            ok = False
+        except RuntimeError:
+            pass
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
