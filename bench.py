@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--nbatches", type=int, default=12, help="distinct resident batches cycled through")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight: step i runs on HIP stream i %% streams")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="CARS: bf16 = bf16 folded tables + bf16 MFMA recurrence (BASELINE config 5)")
+    ap.add_argument("--no-fold", action="store_true", help="CARS: per-batch gather-GEMM instead of the folded embedding table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -98,6 +100,9 @@ def build(args, dev):
     margs = default_args(kind, src_vocab_size=args.vocab, **extra)
     wrapper = Multitask(margs) if kind in ("CARS", "M_MATCH_TENSOR", "MNSRF") else Ranker(margs)
     fill_module_(wrapper.network, 1013)
+    if kind == "CARS":
+        wrapper.network.compute_dtype = args.dtype
+        wrapper.network.fold_embeddings = not args.no_fold
     wrapper.cuda()
     wrapper.network.eval()
     return wrapper

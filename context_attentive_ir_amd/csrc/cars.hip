@@ -19,6 +19,9 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
                      int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
                      int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st);
 constexpr int ACT_MAXOUT2 = 16;
+constexpr int ACT_TANH_ROWDOT16 = 17;
+int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
+                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st);
 int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
                   hipStream_t st);
 int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
@@ -50,6 +53,55 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(const float* __restrict_
             float4 v = *reinterpret_cast<const float4*>(h + (m * T + t) * D + 4 * c);
             acc.x = fmaf(p, v.x, acc.x); acc.y = fmaf(p, v.y, acc.y); acc.z = fmaf(p, v.z, acc.z); acc.w = fmaf(p, v.w, acc.w);
         }
+        *reinterpret_cast<float4*>(pooled + m * D + 4 * c) = acc;
+    }
+}
+
+// attention pooling over logit partials (the fused GEMM epilogue ACT_TANH_ROWDOT16 leaves NP = D/16 partial sums per row):
+// logit[t] = sum_j lpart[t][j] + b3;  p = softmax over t < len;  pooled = sum_t p_t h_t.  One wave per sequence; the
+// probabilities are computed once (lane = time step) and broadcast through LDS, every lane then owns 4 channels per pass.
+__global__ __launch_bounds__(256) void attn_pool2_kernel(const float* __restrict__ h, const float* __restrict__ lpart, int NP,
+                                                         const float* __restrict__ b3, const int64_t* __restrict__ lens,
+                                                         int64_t M, int T, int D, float* __restrict__ pooled) {
+    extern __shared__ float pr[];                    // [4][T]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    float* pw = pr + wave * T;
+    int len = lens ? (int)lens[m] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const float bias = b3 ? b3[0] : 0.f;
+    float mx = -INFINITY;
+    for (int t = lane; t < len; t += 64) {
+        const float* lp = lpart + (m * T + t) * NP;
+        float s = bias;
+        for (int j = 0; j < NP; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(lp + j);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        pw[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int t = lane; t < len; t += 64) {
+        const float e = expf(pw[t] - mx);
+        pw[t] = e;
+        den += e;
+    }
+    den = wave_sum(den);
+    const float inv = 1.0f / den;                    // len == 0 -> 0/0 = NaN rows, like softmax over an all -inf row
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes are visible to its own lanes
+    const int nch = D >> 2;
+    for (int c = lane; c < nch; c += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* hp = h + m * T * D + 4 * c;
+        for (int t = 0; t < len; ++t) {
+            const float p = pw[t] * inv;
+            const float4 v = *reinterpret_cast<const float4*>(hp + (int64_t)t * D);
+            acc.x = fmaf(p, v.x, acc.x); acc.y = fmaf(p, v.y, acc.y); acc.z = fmaf(p, v.z, acc.z); acc.w = fmaf(p, v.w, acc.w);
+        }
+        if (len == 0) acc = make_float4(NAN, NAN, NAN, NAN);
         *reinterpret_cast<float4*>(pooled + m * D + 4 * c) = acc;
     }
 }
@@ -272,6 +324,53 @@ extern "C" int nir_cars_encode(const int64_t* ids, const int64_t* lens, int64_t 
         hipLaunchKernelGGL(attn_pool_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, enc, p.logit, lens, M, T, D, pooled);
     }
     NIR_CHECK_LAUNCH("attn_pool_kernel");
+    return 0;
+}
+
+namespace nir {
+struct EncFoldPlan { float *enc, *lpart; size_t bytes; };
+static EncFoldPlan enc_fold_plan(void* ws, size_t cap, int64_t M, int T, int H) {
+    Workspace a(ws, cap);
+    EncFoldPlan p;
+    p.enc = a.take<float>((size_t)M * T * 2 * H);
+    p.lpart = a.take<float>((size_t)M * T * (2 * H / 16));
+    p.bytes = align_up(a.off, 256);
+    return p;
+}
+}  // namespace nir
+
+extern "C" size_t nir_cars_encode_folded_workspace_bytes(int64_t M, int T, const nir_cars_encoder_weights* w) {
+    if (!w || M < 0 || T <= 0) return 0;
+    return nir::enc_fold_plan(nullptr, 0, M, T, w->H).bytes;
+}
+
+// CARS.encode / encode_document over a folded table (nir_lstm_fold_table): 3 launches -- recurrence gathering its gate
+// pre-activations by token id, attention MLP GEMM with the tanh + Linear(D,1) epilogue, masked softmax + weighted sum.
+extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, int64_t M, int T, const void* folded, int dtype,
+                                      int64_t V, const nir_cars_encoder_weights* w, void* workspace, size_t workspace_bytes,
+                                      float* pooled, float* encoded, int* err_flag, nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(ids && lens && folded && w && pooled, "cars_encode_folded: null pointer");
+    NIR_REQUIRE(M >= 0 && T > 0 && V > 0, "cars_encode_folded: bad dims");
+    NIR_REQUIRE(w->H >= 8 && w->H <= 128 && (2 * w->H) % 64 == 0, "cars_encode_folded: hidden size %d unsupported", w->H);
+    if (M == 0) return 0;
+    const int H = w->H, D = 2 * H, NP = D / 16;
+    EncFoldPlan p = enc_fold_plan(workspace, workspace_bytes, M, T, H);
+    if (!workspace || p.bytes > workspace_bytes) {
+        set_error("cars_encode_folded: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+        return NIR_ERR_WORKSPACE;
+    }
+    float* enc = encoded ? encoded : p.enc;
+    NIR_PROPAGATE(launch_bilstm_folded(folded, dtype, ids, lens, w->whh, enc, err_flag, M, V, T, H, 2, st));
+    NIR_PROPAGATE(launch_linear_ex(enc, D, nullptr, nullptr, 0, 0, 0, w->attn0_w, D, w->attn0_b, nullptr, p.lpart, NP, M * T, D, D,
+                                   ACT_TANH_ROWDOT16, w->attn3_w, 0, st));
+    {
+        ProfScope ps("attn_pool2_kernel", st);
+        hipLaunchKernelGGL(attn_pool2_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), (size_t)4 * T * 4, st, enc, p.lpart, NP,
+                           w->attn3_b, lens, M, T, D, pooled);
+    }
+    NIR_CHECK_LAUNCH("attn_pool2_kernel");
     return 0;
 }
 

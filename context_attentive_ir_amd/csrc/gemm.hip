@@ -35,10 +35,23 @@ struct GemmArgs {
 };
 
 constexpr int ACT_MAXOUT2 = 16;   // internal: out[m, n/2] = max(v[m,n], v[m,n+1])  (maxout pool 2, maxout.py:77-81)
+// internal: the attention MLP's second layer fused into the first one's epilogue (cars.py:671-691, Linear -> Tanh -> Linear(D,1)):
+// out[m, n/16] = sum over the 16 columns n..n+15 of tanh(v[m,n]) * add[n]   (add = the [N] weight row of the second layer;
+// ldadd unused); the consumer sums the N/16 partials of a row, so the [M,N] hidden activation never reaches HBM.
+constexpr int ACT_TANH_ROWDOT16 = 17;
 
 // epilogue shared by both kernels: bias / addend / activation / optional pairwise maxout over adjacent columns
 __device__ __forceinline__ void gemm_store(const GemmArgs& p, int64_t m, int n, float v, float bsum) {
     v += bsum;
+    if (p.act == ACT_TANH_ROWDOT16) {
+        v = n < p.N ? fast_tanh(v) * p.add[n] : 0.f;
+        v += dpp_mov<0xB1>(v);     // 16-lane row reduction (the 16 lanes of a DPP row hold 16 consecutive columns)
+        v += dpp_mov<0x4E>(v);
+        v += dpp_mov<0x141>(v);
+        v += dpp_mov<0x140>(v);
+        if (m < p.M && n < p.N && !(n & 15)) p.c[m * p.ldc + (n >> 4)] = v;
+        return;
+    }
     if (p.add && m < p.M && n < p.N) v += p.add[m * p.ldadd + n];
     if (p.act == NIR_ACT_TANH) v = fast_tanh(v);
     else if (p.act == NIR_ACT_RELU) v = fmaxf(v, 0.f);
@@ -446,6 +459,7 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     NIR_REQUIRE(ids ? (table != nullptr && E > 0 && rows_per_seq > 0) : (a != nullptr), "linear: null A operand");
     if (M == 0) return 0;
     NIR_REQUIRE(act != ACT_MAXOUT2 || (N % 2 == 0), "linear: maxout epilogue needs an even N");
+    NIR_REQUIRE(act != ACT_TANH_ROWDOT16 || (N % 16 == 0 && add != nullptr), "linear: tanh-rowdot epilogue needs N %% 16 == 0 and the weight row");
     GemmArgs p{a, lda, ids, table, E, rows_per_seq, seq_stride, w, ldw, bias, bias2, c, ldc, M, N, K, act, add, ldadd};
     bool vec = (K % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)w & 15) == 0);
     if (ids) vec = vec && (E % 4 == 0) && (((uintptr_t)table & 15) == 0);
@@ -454,7 +468,7 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     const int nb = (N + BN - 1) / BN;
     const int skG = (K + 15) / 16, skNT = (N + 15) / 16;
     const size_t sk_lds = (size_t)16 * skNT * (skG * 16 + 4) * 4;
-    if (N <= 64 && vec && M >= 4096 && (!ids || K <= E) && sk_lds <= 128 * 1024 && act != ACT_MAXOUT2 && !getenv("NIR_NO_SKINNY")) {
+    if (N <= 64 && vec && M >= 4096 && (!ids || K <= E) && sk_lds <= 128 * 1024 && act != ACT_MAXOUT2 && act != ACT_TANH_ROWDOT16 && !getenv("NIR_NO_SKINNY")) {
         ProfScope ps(ids ? "gemm_skinny_kernel[gather]" : "gemm_skinny_kernel", st);
         if (skNT == 1) launch_skinny<1>(p, skG, sk_lds, st);
         else if (skNT == 2) launch_skinny<2>(p, skG, sk_lds, st);

@@ -1,0 +1,473 @@
+// Folded-embedding BiLSTM (inference): RNNEncoder over an embedding lookup (neuroir/encoders/rnn_encoder.py:62-141 fed by
+// neuroir/modules/embeddings.py:243-252; CARS: multitask/cars.py:193-260) with the input projection folded into the table.
+//
+//   gates_x[m,t,:] = emb(ids[m,t]) W_ih^T + b_ih + b_hh  ==  (table W_ih^T + b)[ids[m,t], :]
+//
+// In eval mode (dropout = identity) the left side only depends on the token id, so the product is computed ONCE per
+// vocabulary row when the weights are packed (nir_lstm_fold_table: V x 8H x E MACs, the cost of about one C3 batch) and
+// the per-batch gate GEMM (59 % of the CARS FLOPs) disappears: the recurrence gathers its gate pre-activations straight
+// from the folded table by token id.  288 GB of HBM make the V x 8H table (410 MB at V = 100 000, H = 128) a non-issue.
+// The [M*T, 8H] gate tensor (293 MB written + re-read per C3 batch) is never materialised.
+//
+// Folded-table layout: pt[v][dir][unit][gate]  (gate order i,f,g,o interleaved innermost), fp32 or bf16: the recurrence
+// lane that owns (unit, sequence) reads its four gate pre-activations with ONE 16-byte (fp32) / 8-byte (bf16) load, and a
+// wave covers 4*NT consecutive units = 64*NT contiguous bytes of each of its 16 rows.
+//
+// Recurrence kernels (16 sequences per workgroup, one direction, 16 waves; same MFMA mapping as lstm_mfma16_gin_kernel):
+//   lstm16_pt_kernel<G,NT>       fp32: v_mfma_f32_16x16x4_f32, W_hh slice in VGPRs, exact-fp32 (the parity path)
+//   lstm16_pt_bf16_kernel<KB,NT> bf16: v_mfma_f32_16x16x32_bf16, bf16 W_hh / h_t operands, fp32 accumulate, fp32 cell
+//                                state, bf16 folded table (BASELINE config 5)
+#include "common.hpp"
+#include <hip/hip_bf16.h>
+#include <string>
+#include <algorithm>
+
+namespace nir {
+
+int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                  int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                  int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even, NaN preserved
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// wperm[(dir*H + unit)*4 + gate][:] = wih[dir*4H + gate*H + unit][:],  bperm likewise = bih + bhh
+__global__ void fold_permute_kernel(const float* __restrict__ wih, const float* __restrict__ bih, const float* __restrict__ bhh,
+                                    int H, int ND, int E, float* __restrict__ wperm, float* __restrict__ bperm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = (int64_t)ND * 4 * H;
+    if (i >= rows * E) return;
+    const int64_t ro = i / E;
+    const int k = (int)(i % E);
+    const int gate = (int)(ro & 3), unit = (int)((ro >> 2) % H), dir = (int)((ro >> 2) / H);
+    const int64_t ri = (int64_t)dir * 4 * H + (int64_t)gate * H + unit;
+    wperm[i] = wih[ri * E + k];
+    if (k == 0) bperm[ro] = bih[ri] + bhh[ri];
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        ushort4 o;
+        o.x = f2bf(v.x); o.y = f2bf(v.y); o.z = f2bf(v.z); o.w = f2bf(v.w);
+        *reinterpret_cast<ushort4*>(dst + i) = o;
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+    }
+}
+
+struct LstmPtArgs {
+    const void* pt;         // folded table [V][ND][H][4]  (fp32 or bf16)
+    const int64_t* ids;     // [M,T]
+    const int64_t* lens;    // [M] or NULL
+    const float* whh;       // [ND,4H,H]  (state-dict layout, fp32)
+    float* out;             // [M,T,ND*H] fp32
+    int* err;               // device flag (may be NULL): set to 1 when an id falls outside [0,V)
+    int64_t M, V;
+    int T, H, ND;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 recurrence over the folded table
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G, int NT>
+__global__ __launch_bounds__(1024) void lstm16_pt_kernel(LstmPtArgs p) {
+    constexpr int SEQ = 16, KP = 16 * G, ZLD = KP + 4;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* z = smem;                                   // [2][SEQ][ZLD]
+    int* lens_s = reinterpret_cast<int*>(z + 2 * SEQ * ZLD);
+    int* ids_s = lens_s + SEQ;                         // [SEQ][T]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;          // operand view: (row/col sq, k quarter kq); result view: (sequence sq, local unit kq)
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int H = p.H, T = p.T, H4 = 4 * H;
+    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int OW = p.ND * H;
+    const int64_t GW = (int64_t)p.ND * H4;
+    const int ntiles = (H + 3) / 4;
+
+    if (tid < SEQ) {
+        int l = 0;
+        if (tid < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    {   // token ids of the 16 sequences -> LDS (int32), validated against V (nn.Embedding raises IndexError there)
+        bool bad = false;
+        for (int e = tid; e < SEQ * T; e += 1024) {
+            const int s = e / T;
+            int64_t id = 0;
+            if (s < nvalid) id = p.ids[m0 * T + e];
+            if (id < 0 || id >= p.V) { bad = true; id = 0; }
+            ids_s[e] = (int)id;
+        }
+        if (bad && p.err) atomicOr(p.err, 1);
+    }
+    for (int e = tid; e < 2 * SEQ * ZLD; e += 1024) z[e] = 0.f;
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    const int mylen = lens_s[sq];
+
+    float wreg[NT][4 * G];
+    float creg[NT], hreg[NT];
+    int unit_d[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tile = NT * wave + t;
+        const int unit_a = 4 * tile + (sq >> 2), gate_a = sq & 3;
+        const bool av = unit_a < H;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0)) * H;
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * q + 4 * kq + j;
+                wreg[t][4 * q + j] = (av && k < H) ? wr[k] : 0.f;
+            }
+        unit_d[t] = 4 * tile + kq;
+        creg[t] = 0.f;
+        hreg[t] = 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
+                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;
+    auto load_g = [&](int step, f32x4 (&dst)[NT]) {
+        int s_ = min(step, mylen - 1);
+        s_ = s_ < 0 ? 0 : s_;
+        const int t_ = dir == 0 ? s_ : mylen - 1 - s_;
+        const int id = ids_s[sq * T + (t_ < 0 ? 0 : t_)];
+        const float* row = ptf + (int64_t)id * GW;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int u = unit_d[t] < H ? unit_d[t] : H - 1;      // branch-free: out-of-range units re-read a valid lane's data
+            dst[t] = *reinterpret_cast<const f32x4*>(row + 4 * u);
+        }
+    };
+    f32x4 gcur[NT], gnext[NT];
+    load_g(0, gcur);
+
+    const bool has1 = NT * wave < ntiles;
+    const bool has2 = NT > 1 && NT * wave + 1 < ntiles;   // wave-uniform
+    for (int step = 0; step < tmax; ++step) {
+        const float* zc = z + (step & 1) * SEQ * ZLD;
+        float* zn = z + ((step + 1) & 1) * SEQ * ZLD;
+        load_g(step + 1, gnext);                     // lands during this step's MFMAs
+        const bool live = step < mylen;
+        const int tt = dir == 0 ? step : mylen - 1 - step;
+        auto cell_tile = [&](int t, const f32x4& acc) {
+            const bool dv = unit_d[t] < H;
+            const float gi = fast_sigmoid(acc[0] + gcur[t][0]);
+            const float gf = fast_sigmoid(acc[1] + gcur[t][1]);
+            const float gg = fast_tanh(acc[2] + gcur[t][2]);
+            const float go = fast_sigmoid(acc[3] + gcur[t][3]);
+            const float cn = gf * creg[t] + gi * gg;
+            const float hn = go * fast_tanh(cn);
+            const bool act = dv && live;
+            creg[t] = act ? cn : creg[t];            // a finished sequence carries its state over
+            hreg[t] = act ? hn : hreg[t];
+            if (dv) zn[sq * ZLD + unit_d[t]] = hreg[t];
+            const uint32_t off = act ? (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn), out_rs, off, 0, 0);   // OOB lanes dropped
+        };
+        if (has1) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* zr = zc + sq * ZLD + 4 * kq;
+            if (has2) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 0], zf.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 0], zf.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 1], zf.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 1], zf.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 2], zf.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 2], zf.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 3], zf.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[NT - 1][4 * q + 3], zf.w, acc1, 0, 0, 0);
+                }
+                cell_tile(0, acc0);
+                cell_tile(NT - 1, acc1);
+            } else {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 0], zf.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 1], zf.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 2], zf.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][4 * q + 3], zf.w, acc0, 0, 0, 0);
+                }
+                cell_tile(0, acc0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gcur[t] = gnext[t];
+        lds_barrier();
+    }
+
+    // zero the padded tail (pad_packed_sequence)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (unit_d[t] < H && sq < nvalid) {
+            const int64_t m = m0 + sq;
+            for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 recurrence over the bf16 folded table: W_hh and h_t as bf16 MFMA operands (v_mfma_f32_16x16x32_bf16), fp32
+// accumulators, fp32 gate math and cell state.  KB = ceil(H / 32) K-blocks; wave w owns tiles NT*w .. NT*w+NT-1.
+// A operand (16 gate rows x 32 k): lane (row = lane & 15, k = 8*(lane >> 4) + j), B operand (32 k x 16 sequences): lane
+// (col = lane & 15, k = 8*(lane >> 4) + j); C/D: col = lane & 15 (sequence), row = 4*(lane >> 4) + r (unit kq, gate r).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KB, int NT>
+__global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
+    constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // bf16 elements per h row (+8: 16-byte aligned, bank-staggered)
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* z = reinterpret_cast<unsigned short*>(smem);   // [2][SEQ][ZLD] bf16
+    int* lens_s = reinterpret_cast<int*>(z + 2 * SEQ * ZLD);
+    int* ids_s = lens_s + SEQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int H = p.H, T = p.T, H4 = 4 * H;
+    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int OW = p.ND * H;
+    const int64_t GW = (int64_t)p.ND * H4;
+    const int ntiles = (H + 3) / 4;
+
+    if (tid < SEQ) {
+        int l = 0;
+        if (tid < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    {
+        bool bad = false;
+        for (int e = tid; e < SEQ * T; e += 1024) {
+            const int s = e / T;
+            int64_t id = 0;
+            if (s < nvalid) id = p.ids[m0 * T + e];
+            if (id < 0 || id >= p.V) { bad = true; id = 0; }
+            ids_s[e] = (int)id;
+        }
+        if (bad && p.err) atomicOr(p.err, 1);
+    }
+    for (int e = tid; e < SEQ * ZLD; e += 1024) reinterpret_cast<unsigned*>(z)[e] = 0u;   // both buffers (2*SEQ*ZLD bf16)
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    const int mylen = lens_s[sq];
+
+    bf16x8 wreg[NT][KB];
+    float creg[NT], hreg[NT];
+    int unit_d[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tile = NT * wave + t;
+        const int unit_a = 4 * tile + (sq >> 2), gate_a = sq & 3;
+        const bool av = unit_a < H;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0)) * H;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * kb + 8 * kq + j;
+                wreg[t][kb][j] = (short)f2bf((av && k < H) ? wr[k] : 0.f);
+            }
+        unit_d[t] = 4 * tile + kq;
+        creg[t] = 0.f;
+        hreg[t] = 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
+                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    const unsigned short* pth = reinterpret_cast<const unsigned short*>(p.pt) + (int64_t)dir * H4;
+    auto load_g = [&](int step, uint2 (&dst)[NT]) {
+        int s_ = min(step, mylen - 1);
+        s_ = s_ < 0 ? 0 : s_;
+        const int t_ = dir == 0 ? s_ : mylen - 1 - s_;
+        const int id = ids_s[sq * T + (t_ < 0 ? 0 : t_)];
+        const unsigned short* row = pth + (int64_t)id * GW;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int u = unit_d[t] < H ? unit_d[t] : H - 1;
+            dst[t] = *reinterpret_cast<const uint2*>(row + 4 * u);
+        }
+    };
+    uint2 gcur[NT], gnext[NT], gnext2[NT];
+    load_g(0, gcur);
+    load_g(1, gnext);
+
+    for (int step = 0; step < tmax; ++step) {
+        const unsigned short* zc = z + (step & 1) * SEQ * ZLD;
+        unsigned short* zn = z + ((step + 1) & 1) * SEQ * ZLD;
+        load_g(step + 2, gnext2);                    // two steps ahead: a bf16 step is shorter than an HBM round trip
+        const bool live = step < mylen;
+        const int tt = dir == 0 ? step : mylen - 1 - step;
+        bf16x8 hb[KB];
+        const unsigned short* zr = zc + sq * ZLD + 8 * kq;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) hb[kb] = *reinterpret_cast<const bf16x8*>(zr + 32 * kb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (NT * wave + t < ntiles) {            // wave-uniform
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][kb], hb[kb], acc, 0, 0, 0);
+                const bool dv = unit_d[t] < H;
+                const float xi = bf2f((unsigned short)(gcur[t].x & 0xFFFFu)), xf = bf2f((unsigned short)(gcur[t].x >> 16));
+                const float xg = bf2f((unsigned short)(gcur[t].y & 0xFFFFu)), xo = bf2f((unsigned short)(gcur[t].y >> 16));
+                const float gi = fast_sigmoid(acc[0] + xi);
+                const float gf = fast_sigmoid(acc[1] + xf);
+                const float gg = fast_tanh(acc[2] + xg);
+                const float go = fast_sigmoid(acc[3] + xo);
+                const float cn = gf * creg[t] + gi * gg;
+                const float hn = go * fast_tanh(cn);
+                const bool act = dv && live;
+                creg[t] = act ? cn : creg[t];
+                hreg[t] = act ? hn : hreg[t];
+                if (dv) zn[sq * ZLD + unit_d[t]] = f2bf(hreg[t]);
+                const uint32_t off = act ? (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn), out_rs, off, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { gcur[t] = gnext[t]; gnext[t] = gnext2[t]; }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (unit_d[t] < H && sq < nvalid) {
+            const int64_t m = m0 + sq;
+            for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
+        }
+    }
+}
+
+template <int G, int NT>
+static int launch_pt(const LstmPtArgs& p, hipStream_t st) {
+    static const std::string pname = "lstm16_pt_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
+    const size_t lds = (size_t)(2 * 16 * (16 * G + 4)) * 4 + 16 * 4 + (size_t)16 * p.T * 4;
+    ProfScope ps(pname.c_str(), st);
+    hipLaunchKernelGGL((lstm16_pt_kernel<G, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f32]");
+    return 0;
+}
+template <int KB, int NT>
+static int launch_pt_bf16(const LstmPtArgs& p, hipStream_t st) {
+    static const std::string pname = "lstm16_pt_bf16_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + ">";
+    const size_t lds = (size_t)(2 * 16 * (32 * KB + 8)) * 2 + 16 * 4 + (size_t)16 * p.T * 4;
+    ProfScope ps(pname.c_str(), st);
+    hipLaunchKernelGGL((lstm16_pt_bf16_kernel<KB, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[bf16]");
+    return 0;
+}
+
+int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
+                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st) {
+    NIR_REQUIRE(pt && ids && whh && out, "bilstm_folded: null pointer");
+    NIR_REQUIRE(M >= 0 && V > 0 && T > 0 && (ND == 1 || ND == 2), "bilstm_folded: bad dims");
+    NIR_REQUIRE(H >= 4 && H <= 128, "bilstm_folded: hidden size %d per direction unsupported (4..128)", H);
+    NIR_REQUIRE(T <= 512, "bilstm_folded: sequence length %d > 512 unsupported", T);
+    NIR_REQUIRE((int64_t)16 * T * ND * H * 4 < 0x7FFFFFF0LL, "bilstm_folded: T*H too large for 32-bit tile offsets");
+    NIR_REQUIRE(pt_dtype == NIR_DTYPE_F32 || pt_dtype == NIR_DTYPE_BF16, "bilstm_folded: unknown table dtype %d", pt_dtype);
+    if (M == 0) return 0;
+    LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND};
+    if (pt_dtype == NIR_DTYPE_BF16) {
+        const int KB = (H + 31) / 32;
+        if (H <= 64) return KB == 1 ? launch_pt_bf16<1, 1>(p, st) : launch_pt_bf16<2, 1>(p, st);
+        return KB == 3 ? launch_pt_bf16<3, 2>(p, st) : launch_pt_bf16<4, 2>(p, st);
+    }
+    const int G = (H + 15) / 16;
+    if (H <= 64) {
+        switch (G) {
+            case 1: return launch_pt<1, 1>(p, st);
+            case 2: return launch_pt<2, 1>(p, st);
+            case 3: return launch_pt<3, 1>(p, st);
+            default: return launch_pt<4, 1>(p, st);
+        }
+    }
+    switch (G) {
+        case 5: return launch_pt<5, 2>(p, st);
+        case 6: return launch_pt<6, 2>(p, st);
+        case 7: return launch_pt<7, 2>(p, st);
+        default: return launch_pt<8, 2>(p, st);
+    }
+}
+
+}  // namespace nir
+
+extern "C" size_t nir_lstm_fold_table_bytes(int64_t V, int H, int ndir, int dtype) {
+    if (V <= 0 || H <= 0 || ndir <= 0) return 0;
+    return (size_t)V * ndir * 4 * H * (dtype == NIR_DTYPE_BF16 ? 2 : 4);
+}
+
+extern "C" size_t nir_lstm_fold_table_workspace_bytes(int64_t V, int E, int H, int ndir, int dtype) {
+    if (V <= 0 || H <= 0 || ndir <= 0 || E <= 0) return 0;
+    size_t b = nir::align_up((size_t)ndir * 4 * H * E * 4, 256) + nir::align_up((size_t)ndir * 4 * H * 4, 256);
+    if (dtype == NIR_DTYPE_BF16) b += nir::align_up((size_t)std::min<int64_t>(V, 65536) * ndir * 4 * H * 4, 256);
+    return b;
+}
+
+extern "C" int nir_lstm_fold_table(const float* table, int64_t V, int E, const float* w_ih, const float* b_ih, const float* b_hh,
+                                   int H, int ndir, void* folded, int dtype, void* workspace, size_t workspace_bytes,
+                                   nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(table && w_ih && b_ih && b_hh && folded, "lstm_fold_table: null pointer");
+    NIR_REQUIRE(V > 0 && E > 0 && H > 0 && (ndir == 1 || ndir == 2), "lstm_fold_table: bad dims");
+    NIR_REQUIRE(dtype == NIR_DTYPE_F32 || dtype == NIR_DTYPE_BF16, "lstm_fold_table: unknown dtype %d", dtype);
+    const size_t need = nir_lstm_fold_table_workspace_bytes(V, E, H, ndir, dtype);
+    if (!workspace || workspace_bytes < need) {
+        set_error("lstm_fold_table: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return NIR_ERR_WORKSPACE;
+    }
+    const int GW = ndir * 4 * H;
+    Workspace a(workspace, workspace_bytes);
+    float* wperm = a.take<float>((size_t)GW * E);
+    float* bperm = a.take<float>((size_t)GW);
+    {
+        const int64_t n = (int64_t)GW * E;
+        hipLaunchKernelGGL(fold_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_ih, b_ih, b_hh, H, ndir, E, wperm, bperm);
+        NIR_CHECK_LAUNCH("fold_permute_kernel");
+    }
+    if (dtype == NIR_DTYPE_F32)
+        return launch_linear(table, E, nullptr, nullptr, 0, 0, 0, wperm, E, bperm, nullptr, (float*)folded, GW, V, GW, E, NIR_ACT_NONE, st);
+    float* tmp = a.take<float>((size_t)std::min<int64_t>(V, 65536) * GW);
+    for (int64_t v0 = 0; v0 < V; v0 += 65536) {     // fp32 product, rounded once to bf16
+        const int64_t nv = std::min<int64_t>(65536, V - v0);
+        NIR_PROPAGATE(launch_linear(table + v0 * E, E, nullptr, nullptr, 0, 0, 0, wperm, E, bperm, nullptr, tmp, GW, nv, GW, E, NIR_ACT_NONE, st));
+        const int64_t n = nv * GW;
+        hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, st, tmp,
+                           (unsigned short*)folded + v0 * GW, n);
+        NIR_CHECK_LAUNCH("f32_to_bf16_kernel");
+    }
+    return 0;
+}
+
+extern "C" int nir_bilstm_folded_fwd(const void* folded, int dtype, const int64_t* ids, const int64_t* lengths, const float* w_hh,
+                                     float* out, int* err_flag, int64_t M, int64_t V, int T, int H, int ndir, nir_stream_t stream) {
+    return nir::launch_bilstm_folded(folded, dtype, ids, lengths, w_hh, out, err_flag, M, V, T, H, ndir, (hipStream_t)stream);
+}

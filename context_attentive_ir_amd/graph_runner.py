@@ -11,6 +11,8 @@ import time
 
 import torch
 
+from . import lib
+
 
 class GraphedPredictor(object):
     def __init__(self, wrapper, example, warmup=3, queue_ahead=True):
@@ -25,6 +27,7 @@ class GraphedPredictor(object):
         self.wrapper = wrapper
         self.replay_done = None           # event: the previous replay has finished
         self.copy_done = None             # event: the H2D copy out of the staging buffer has been executed
+        self.clone_done = None            # event on the caller's stream: its copy of the previous output has been made
         self.fast_path_calls = 0          # batches that arrived packed (inputters.*_batchify / pack()) and took one memmove
         dev = next(wrapper.network.parameters()).device
         self.stream = torch.cuda.Stream(device=dev)
@@ -43,7 +46,10 @@ class GraphedPredictor(object):
         for k, v in example.items():
             if k in self.static:
                 self.static[k].copy_(v)
-        with torch.cuda.stream(self.stream):
+        self.stream.wait_stream(torch.cuda.current_stream(dev))    # the initial copies above ran on the caller's stream
+        # scratch requested during warm-up / capture belongs to this predictor (lib.workspace_owner): the addresses baked
+        # into the graph cannot be superseded by another predictor or an eager caller that shares the stream handle
+        with torch.cuda.stream(self.stream), lib.workspace_owner(self):
             for _ in range(warmup):
                 self._call()
             self.stream.synchronize()
@@ -95,6 +101,15 @@ class GraphedPredictor(object):
                 else:
                     ex["_layout_ok"] = self
         on_host = packed is not None or all(not ex[k].is_cuda for k in self.slots)
+        caller = torch.cuda.current_stream()
+        # cross-stream ordering (only where there is a hazard, so that several predictors fed from one host thread still
+        # overlap): device inputs were produced on the caller's stream; and the clone of the PREVIOUS call's output, made on
+        # the caller's stream below, must have read self.out before this replay overwrites it
+        if not on_host:
+            self.stream.wait_stream(caller)
+        if self.clone_done is not None:
+            self.stream.wait_event(self.clone_done)
+            self.clone_done = None
         with torch.cuda.stream(self.stream):
             if packed is not None:
                 # one memmove into this predictor's own pinned staging buffer, one H2D.  (Copying straight out of the
@@ -128,6 +143,12 @@ class GraphedPredictor(object):
                 if self.replay_done is None:
                     self.replay_done = torch.cuda.Event()
                 self.replay_done.record(self.stream)
-            out = self.out.clone() if clone else self.out
-        torch.cuda.current_stream().wait_stream(self.stream)
+        caller.wait_stream(self.stream)
+        # the copy is allocated AND written on the caller's stream (after the wait): the caching allocator then tracks it
+        # on the stream that uses it, and no block is handed back while another stream still reads it
+        if not clone:
+            return self.out
+        out = self.out.clone()
+        self.clone_done = torch.cuda.Event()
+        self.clone_done.record(caller)
         return out

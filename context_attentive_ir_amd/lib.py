@@ -86,10 +86,20 @@ SIGNATURES = {
     "nir_cars_encode_workspace_bytes": (_z, [_l, _i, _i, C.POINTER(CarsEncoderWeights)]),
     "nir_cars_encode": (_i, [c_ip, c_ip, _l, _i, c_fp, _l, _i, C.POINTER(CarsEncoderWeights), C.c_void_p, _z,
                              c_fp, c_fp, c_st]),
+    "nir_lstm_fold_table_bytes": (_z, [_l, _i, _i, _i]),
+    "nir_lstm_fold_table_workspace_bytes": (_z, [_l, _i, _i, _i, _i]),
+    "nir_lstm_fold_table": (_i, [c_fp, _l, _i, c_fp, c_fp, c_fp, _i, _i, C.c_void_p, _i, C.c_void_p, _z, c_st]),
+    "nir_bilstm_folded_fwd": (_i, [C.c_void_p, _i, c_ip, c_ip, c_fp, c_fp, C.c_void_p, _l, _l, _i, _i, _i, c_st]),
+    "nir_cars_encode_folded_workspace_bytes": (_z, [_l, _i, C.POINTER(CarsEncoderWeights)]),
+    "nir_cars_encode_folded": (_i, [c_ip, c_ip, _l, _i, C.c_void_p, _i, _l, C.POINTER(CarsEncoderWeights), C.c_void_p, _z,
+                                    c_fp, c_fp, C.c_void_p, c_st]),
     "nir_cars_session_workspace_bytes": (_z, [_i, _i, _i, C.POINTER(CarsSessionWeights)]),
     "nir_cars_rank_session": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
                                    c_fp, c_fp, c_st]),
 }
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "bf16": DTYPE_BF16}
 
 _lib = None
 
@@ -158,26 +168,81 @@ class Packed(object):
 
 
 class PackCache(object):
-    """Re-pack weights only when a parameter was modified (tensor._version) or moved."""
+    """Re-pack weights only when a parameter was modified (tensor._version) or moved.
+
+    Keys may mix tensors and plain hashables (e.g. a dtype name).  `tensor._version` is bumped by every in-place op
+    (optimizer steps, load_state_dict, `with torch.no_grad(): p.copy_()`), but NOT by writes through `p.data`; code that
+    writes that way must call invalidate().  Superseded packs are kept alive (the last RETAIN of them): a hipGraph
+    captured earlier still holds their device pointers, so freeing them on a repack would let the graph read freed memory.
+    """
+    RETAIN = 8
 
     def __init__(self):
-        self.key, self.val = None, None
+        self.key, self.val, self.retired = None, None, []
+
+    def invalidate(self):
+        self.key = None
 
     def get(self, params, builder):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) if torch.is_tensor(p) else p for p in params)
         if key != self.key:
+            if self.val is not None:
+                self.retired = (self.retired + [self.val])[-self.RETAIN:]
             self.val, self.key = builder(), key
         return self.val
 
 
 _WS = {}
+_WS_RETIRED = []
+_WS_OWNER = [None]
+
+
+class workspace_owner(object):
+    """Context manager: scratch requested inside the block belongs to `owner` (any object; buffers are stored on it as
+    `_nir_ws`) instead of the shared per-(device, stream) pool.  graph_runner.GraphedPredictor captures under it, so the
+    pointers baked into its hipGraph stay valid for the predictor's whole life no matter what other callers do."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __enter__(self):
+        self.prev = _WS_OWNER[0]
+        _WS_OWNER[0] = self.owner
+        if not hasattr(self.owner, "_nir_ws"):
+            self.owner._nir_ws = {}
+        return self
+
+    def __exit__(self, *exc):
+        _WS_OWNER[0] = self.prev
+        return False
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per (device, stream); the C library never allocates device memory."""
+    """Scratch buffer per (device, stream) -- or per workspace_owner; the C library never allocates device memory.
+    Buffers only grow (geometrically); a superseded buffer is retired, never freed, because a captured hipGraph may still
+    hold its address."""
+    owner = _WS_OWNER[0]
+    pool = _WS if owner is None else owner._nir_ws
     k = (str(device), torch.cuda.current_stream().cuda_stream)
-    buf = _WS.get(k)
+    buf = pool.get(k)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _WS[k] = buf
+        if buf is not None:
+            _WS_RETIRED.append(buf)
+        grow = 0 if buf is None else 2 * buf.numel()
+        buf = torch.empty(max(int(nbytes), grow, 1 << 20), dtype=torch.uint8, device=device)
+        pool[k] = buf
     return buf
+
+
+def fold_lstm_table(table, wih, bih, bhh, H, ndir, dtype):
+    """nir_lstm_fold_table: [V, ndir*4H] folded gate table (fp32, or bf16 stored as int16) -- weight packing, run once
+    per parameter version (PackCache)."""
+    L = load()
+    V, E = table.shape
+    dt = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    out = torch.empty(V, ndir * 4 * H, device=table.device, dtype=torch.float32 if dt == DTYPE_F32 else torch.int16)
+    ws = torch.empty(max(1, L.nir_lstm_fold_table_workspace_bytes(V, E, H, ndir, dt)), dtype=torch.uint8, device=table.device)
+    t = table.detach().float().contiguous()
+    check(L.nir_lstm_fold_table(ptr(t), V, E, ptr(wih), ptr(bih), ptr(bhh), H, ndir, ptr(out), dt, ptr(ws), ws.numel(), stream()),
+          "nir_lstm_fold_table")
+    return out

@@ -37,13 +37,15 @@ class Embeddings(nn.Module):
             tok = vocabulary.ind2tok[i]
             if tok in embeddings_index:
                 pretrained[i] = embeddings_index[tok]
-        self.word_lut.weight.data.copy_(pretrained)
+        with torch.no_grad():
+            self.word_lut.weight.copy_(pretrained)      # in-place on the parameter itself: bumps _version (lib.PackCache)
         if fixed:
             self.word_lut.weight.requires_grad = False
 
     def load_pretrained_vectors(self, emb_file, fixed):
         if emb_file:
-            self.word_lut.weight.data.copy_(torch.load(emb_file))
+            with torch.no_grad():
+                self.word_lut.weight.copy_(torch.load(emb_file))
             if fixed:
                 self.word_lut.weight.requires_grad = False
 

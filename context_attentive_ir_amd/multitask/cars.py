@@ -93,6 +93,14 @@ class CARS(nn.Module):
             raise NotImplementedError("HIP CARS expects nhid_query == nhid_document and equal session sizes")
         self._dims = dict(D=args.nhid_document, HS=args.nhid_session_query)
         self._pq, self._pd, self._ps = lib.PackCache(), lib.PackCache(), lib.PackCache()
+        # Inference-time folding of the embedding table into the LSTM input projection (csrc/lstm_fold.hip): on in eval
+        # mode while the two folded tables (V x 8H each) stay under `fold_budget_bytes`; `compute_dtype` "bf16" selects the
+        # bf16 folded table + bf16 MFMA recurrence (BASELINE config 5), "f32" is the parity path.
+        self.fold_embeddings = getattr(args, "fold_embeddings", True)
+        self.fold_budget_bytes = 64 << 30
+        self.compute_dtype = getattr(args, "compute_dtype", "f32")
+        self._fq, self._fd = lib.PackCache(), lib.PackCache()
+        self._err_flag = None
 
     # ---- weight packing -------------------------------------------------------------------------
     def _enc_weights(self, which):
@@ -133,6 +141,29 @@ class CARS(nn.Module):
             raise NotImplementedError("HIP CARS implements the eval-mode forward (dropout is RNG-dependent, "
                                       "SURVEY.md Appendix E7)")
 
+    def _folded_table(self, which, w):
+        """[V, 8H] folded gate table of one encoder (fp32 or bf16), rebuilt when the table or the LSTM weights change."""
+        table = self.embedder.word_embeddings.table
+        enc = (self.query_encoder if which == "q" else self.document_encoder).encoder
+        cache = self._fq if which == "q" else self._fd
+        dt = self.compute_dtype
+        return cache.get([table] + list(enc.parameters()) + [dt],
+                         lambda: lib.fold_lstm_table(table, w.keep["wih"], w.keep["bih"], w.keep["bhh"], w.struct.H, 2, dt))
+
+    def _use_fold(self, table, H):
+        if not self.fold_embeddings or self.training:
+            return False
+        per = table.shape[0] * 8 * H * (2 if self.compute_dtype == "bf16" else 4)
+        return 2 * per <= self.fold_budget_bytes and H >= 8 and (2 * H) % 64 == 0
+
+    def check_ids(self):
+        """Raise IndexError if any folded-path call since the last check saw a token id outside the vocabulary (the
+        reference's nn.Embedding raises at the lookup; the kernels clamp to row 0 and set a device flag instead of faulting).
+        Reads one int from the device, i.e. synchronises -- call it outside latency-critical loops."""
+        if self._err_flag is not None and int(self._err_flag.item()) != 0:
+            self._err_flag.zero_()
+            raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
+
     def _encode_seqs(self, which, ids, lens, want_encoded):
         table = self.embedder.word_embeddings.table
         lib.require_device(ids, lens, table)
@@ -142,6 +173,17 @@ class CARS(nn.Module):
         w = self._enc_weights(which)
         H2 = 2 * w.struct.H
         dev = ids.device
+        if self._use_fold(table, w.struct.H):
+            folded = self._folded_table(which, w)
+            if self._err_flag is None or self._err_flag.device != dev:
+                self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            ws = lib.workspace(L.nir_cars_encode_folded_workspace_bytes(M, T, w.ref()), dev)
+            pooled = torch.empty(M, H2, device=dev, dtype=torch.float32)
+            encoded = torch.empty(M, T, H2, device=dev, dtype=torch.float32) if want_encoded else None
+            lib.check(L.nir_cars_encode_folded(lib.ptr(ids), lib.ptr(lens), M, T, lib.ptr(folded), lib.DTYPES[self.compute_dtype],
+                                               table.shape[0], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(pooled),
+                                               lib.ptr(encoded), lib.ptr(self._err_flag), lib.stream()), "nir_cars_encode_folded")
+            return pooled, encoded
         ws = lib.workspace(L.nir_cars_encode_workspace_bytes(M, T, table.shape[1], w.ref()), dev)
         pooled = torch.empty(M, H2, device=dev, dtype=torch.float32)
         encoded = torch.empty(M, T, H2, device=dev, dtype=torch.float32) if want_encoded else None

@@ -32,6 +32,10 @@ typedef void* nir_stream_t; /* hipStream_t */
 #define NIR_ERR_UNSUPPORTED (-2)
 #define NIR_ERR_WORKSPACE (-3)
 
+/* element types of buffers whose precision is a caller choice (folded tables) */
+#define NIR_DTYPE_F32 0
+#define NIR_DTYPE_BF16 1
+
 int nir_version(void);
 const char* nir_last_error_string(void);
 
@@ -196,6 +200,29 @@ size_t nir_cars_encode_workspace_bytes(int64_t M, int T, int E, const nir_cars_e
 int nir_cars_encode(const int64_t* ids, const int64_t* lens, int64_t M, int T, const float* table, int64_t V, int E,
                     const nir_cars_encoder_weights* w /*host*/, void* workspace, size_t workspace_bytes,
                     float* pooled, float* encoded, nir_stream_t stream);
+
+/* --- inference-time folding of the embedding table into the LSTM input projection ------------------------------------
+ * In eval mode `emb(ids) W_ih^T + b_ih + b_hh` (rnn_encoder.py:76-102 fed by embeddings.py:243-252) depends only on the
+ * token id, so it is computed once per vocabulary row when weights are packed:
+ *     folded[v][dir][unit][gate] = table[v] . w_ih[dir*4H + gate*H + unit] + b_ih[..] + b_hh[..]     (gate order i,f,g,o)
+ * as fp32 (NIR_DTYPE_F32: bit-identical products to the per-batch gate GEMM) or rounded once to bf16 (NIR_DTYPE_BF16).
+ * The per-batch [M*T, 8H] gate GEMM and gate tensor disappear; the recurrence gathers folded rows by id.
+ * w_ih [ndir*4H, E], b_ih / b_hh [ndir*4H] in the concatenated fwd+rev layout of nir_cars_encoder_weights. */
+size_t nir_lstm_fold_table_bytes(int64_t V, int H, int ndir, int dtype);
+size_t nir_lstm_fold_table_workspace_bytes(int64_t V, int E, int H, int ndir, int dtype);
+int nir_lstm_fold_table(const float* table, int64_t V, int E, const float* w_ih, const float* b_ih, const float* b_hh, int H,
+                        int ndir, void* folded, int dtype, void* workspace, size_t workspace_bytes, nir_stream_t stream);
+/* BiLSTM over a folded table: ids [M,T] int64, lengths [M] (or NULL), w_hh [ndir,4H,H] fp32 -> out [M,T,ndir*H] fp32, zero at
+ * t >= length.  dtype F32: v_mfma_f32_16x16x4_f32 recurrence (parity path).  dtype BF16: bf16 folded table, bf16 W_hh / h_t
+ * MFMA operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation, gate math and cell state.  An id outside [0,V) is read as id 0
+ * and sets *err_flag (device int, may be NULL) to 1 -- the reference's nn.Embedding raises IndexError. */
+int nir_bilstm_folded_fwd(const void* folded, int dtype, const int64_t* ids, const int64_t* lengths, const float* w_hh,
+                          float* out, int* err_flag, int64_t M, int64_t V, int T, int H, int ndir, nir_stream_t stream);
+/* CARS.encode / encode_document (cars.py:193-260) over a folded table: same outputs as nir_cars_encode. */
+size_t nir_cars_encode_folded_workspace_bytes(int64_t M, int T, const nir_cars_encoder_weights* w /*host*/);
+int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, int64_t M, int T, const void* folded, int dtype, int64_t V,
+                           const nir_cars_encoder_weights* w /*host*/, void* workspace, size_t workspace_bytes, float* pooled,
+                           float* encoded, int* err_flag, nir_stream_t stream);
 
 typedef struct {
     const float *click0_w, *click0_b, *click3_w, *click3_b; /* click_attn.{0,3} [D,D],[D],[1,D],[1] */

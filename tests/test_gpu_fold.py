@@ -1,0 +1,157 @@
+"""GPU (-m gpu): folded-embedding BiLSTM (csrc/lstm_fold.hip) and the CARS encoders built on it.
+
+fp32 folded path = the parity path: same 1e-4 bar on scores as everything else (observed ~1e-6).
+bf16 path (BASELINE config 5): bf16 cannot meet 1e-4; the stated bound is |score - oracle| <= BF16_SCORE_TOL on raw
+click scores of O(1) magnitude, |softmax prob diff| <= BF16_PROB_TOL, and identical MAP on candidate sets whose oracle
+scores are separated by more than the bound."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, cpu_state_dict
+from oracle import neuroir_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF16_SCORE_TOL = 6e-2
+BF16_PROB_TOL = 2e-2
+
+
+def _close(a, b, tol):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("H,M,T_,V", [(128, 40, 12, 500), (128, 1, 1, 50), (70, 33, 20, 300), (15, 50, 6, 100), (96, 21, 290, 800),
+                                      (40, 17, 11, 64), (8, 5, 3, 20), (100, 35, 64, 1000)])
+def test_bilstm_folded_f32_vs_oracle(H, M, T_, V):
+    """nir_lstm_fold_table + nir_bilstm_folded_fwd against the oracle's embedding lookup + RNNEncoder, ragged lengths,
+    partial workgroups (M % 16 != 0), hidden sizes that do not fill the last MFMA tile."""
+    from context_attentive_ir_amd import lib
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.encoders import RNNEncoder
+    from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
+    E = 300
+    enc = fill_module_(RNNEncoder("LSTM", E, True, 1, 2 * H), seed=5).eval()
+    g = torch.Generator().manual_seed(H * 7 + M)
+    table = (torch.rand(V, E, generator=g) - 0.5)
+    table[0].zero_()
+    lens = torch.randint(1, T_ + 1, (M,), generator=g); lens[0] = T_
+    ids = torch.randint(1, V, (M, T_), generator=g)
+    ids[torch.arange(T_)[None] >= lens[:, None]] = 0
+    sd = {"e." + k: v for k, v in enc.state_dict().items()}
+    _, ref = O.rnn_encode(sd, "e", table[ids], lens)
+    wih, whh, bih, bhh = (t.detach().float().contiguous().to(DEV) for t in lstm_cat_weights(enc.rnns[0]))
+    folded = lib.fold_lstm_table(table.to(DEV), wih, bih, bhh, H, 2, "f32")
+    out = torch.empty(M, T_, 2 * H, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    idd, ld = ids.to(DEV), lens.to(DEV)
+    lib.check(lib.load().nir_bilstm_folded_fwd(lib.ptr(folded), lib.DTYPE_F32, lib.ptr(idd), lib.ptr(ld), lib.ptr(whh), lib.ptr(out),
+                                               lib.ptr(err), M, V, T_, H, 2, lib.stream()), "folded")
+    _close(out, ref, 2e-5)
+    assert int(err.item()) == 0
+
+
+@pytest.mark.parametrize("H,M,T_,V", [(128, 40, 12, 500), (128, 19, 64, 900), (64, 33, 20, 300), (96, 21, 30, 200), (32, 5, 9, 50)])
+def test_bilstm_folded_bf16_vs_oracle(H, M, T_, V):
+    """bf16 folded table + bf16 MFMA recurrence: hidden states within 3e-2 of the fp32 oracle (|h| < 1)."""
+    from context_attentive_ir_amd import lib
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.encoders import RNNEncoder
+    from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
+    E = 300
+    enc = fill_module_(RNNEncoder("LSTM", E, True, 1, 2 * H), seed=5).eval()
+    g = torch.Generator().manual_seed(H * 7 + M)
+    table = (torch.rand(V, E, generator=g) - 0.5)
+    table[0].zero_()
+    lens = torch.randint(1, T_ + 1, (M,), generator=g); lens[0] = T_
+    ids = torch.randint(1, V, (M, T_), generator=g)
+    ids[torch.arange(T_)[None] >= lens[:, None]] = 0
+    sd = {"e." + k: v for k, v in enc.state_dict().items()}
+    _, ref = O.rnn_encode(sd, "e", table[ids], lens)
+    wih, whh, bih, bhh = (t.detach().float().contiguous().to(DEV) for t in lstm_cat_weights(enc.rnns[0]))
+    folded = lib.fold_lstm_table(table.to(DEV), wih, bih, bhh, H, 2, "bf16")
+    out = torch.empty(M, T_, 2 * H, device=DEV)
+    idd, ld = ids.to(DEV), lens.to(DEV)
+    lib.check(lib.load().nir_bilstm_folded_fwd(lib.ptr(folded), lib.DTYPE_BF16, lib.ptr(idd), lib.ptr(ld), lib.ptr(whh), lib.ptr(out),
+                                               None, M, V, T_, H, 2, lib.stream()), "folded bf16")
+    _close(out, ref, 3e-2)
+    assert float((out.cpu() - ref).abs().mean()) < 4e-3
+
+
+def test_folded_matches_unfolded_cars_encoders():
+    """CARS.encode / encode_document: folded path (default in eval) vs the per-batch gather-GEMM path, fp32."""
+    from context_attentive_ir_amd import synth
+    V = 3000
+    m = build_model("CARS", vocab=V, device=DEV)
+    ex = {k: v.to(DEV) for k, v in synth.session_batch(3, 4, 9, 6, 41, V, seed=11, full_length=False).items()}
+    assert m.fold_embeddings
+    p1, e1, _ = m.encode(ex["source_words"], ex["source_lens"])
+    d1 = m.encode_document(ex["document_words"], ex["document_lens"])
+    m.fold_embeddings = False
+    p0, e0, _ = m.encode(ex["source_words"], ex["source_lens"])
+    d0 = m.encode_document(ex["document_words"], ex["document_lens"])
+    _close(e1, e0, 5e-6); _close(p1, p0, 5e-6); _close(d1, d0, 5e-6)
+
+
+def test_folded_table_follows_weight_updates():
+    """The folded tables are re-derived when the embedding table or the LSTM weights change (lib.PackCache keys)."""
+    from context_attentive_ir_amd import synth
+    V = 500
+    m = build_model("CARS", vocab=V, device=DEV)
+    ex = {k: v.to(DEV) for k, v in synth.session_batch(2, 2, 3, 4, 9, V, seed=3).items()}
+    a = m.encode_document(ex["document_words"], ex["document_lens"]).clone()
+    with torch.no_grad():
+        m.embedder.word_embeddings.table.mul_(0.5)
+    b = m.encode_document(ex["document_words"], ex["document_lens"]).clone()
+    m.fold_embeddings = False
+    c = m.encode_document(ex["document_words"], ex["document_lens"])
+    assert float((a - b).abs().max()) > 1e-3
+    _close(b, c, 5e-6)
+
+
+def test_out_of_vocabulary_id_raises_index_error():
+    """nn.Embedding raises IndexError for id >= V (reference); the folded kernels clamp + flag, check_ids() raises."""
+    from context_attentive_ir_amd import synth
+    V = 200
+    m = build_model("CARS", vocab=V, device=DEV)
+    ex = {k: v.to(DEV) for k, v in synth.session_batch(2, 2, 3, 4, 9, V, seed=3).items()}
+    m.encode_document(ex["document_words"], ex["document_lens"])
+    m.check_ids()
+    bad = ex["document_words"].clone()
+    bad[0, 0, 0, 0] = V + 5
+    m.encode_document(bad, ex["document_lens"])
+    with pytest.raises(IndexError):
+        m.check_ids()
+    m.encode_document(ex["document_words"], ex["document_lens"])
+    m.check_ids()      # flag was cleared
+
+
+@pytest.mark.parametrize("B,S,N,QL,DL", [(4, 7, 10, 6, 64), (2, 3, 50, 6, 64)])
+def test_cars_bf16_scores_and_map(B, S, N, QL, DL):
+    """BASELINE config 5 precision: bf16 folded tables + bf16 recurrence against the fp32 oracle."""
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.eval import ltorank
+    V = 3000
+    m = build_model("CARS", vocab=V, device=DEV)
+    m.compute_dtype = "bf16"
+    ex = synth.session_batch(B, S, N, QL, DL, V, seed=B + S, full_length=False)
+    sd = cpu_state_dict(m)
+    ref = O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])
+    dex = {k: v.to(DEV) for k, v in ex.items()}
+    pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
+    s, _, _ = m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"])
+    s = s.cpu()
+    assert float((s - ref).abs().max()) <= BF16_SCORE_TOL, float((s - ref).abs().max())
+    _close(torch.softmax(s, -1), torch.softmax(ref, -1), BF16_PROB_TOL)
+    # rank agreement wherever the oracle separates neighbours by more than twice the bound
+    lab = ex["document_labels"].reshape(-1, N).numpy()
+    r_ref, r_got = ref.reshape(-1, N).numpy(), s.reshape(-1, N).numpy()
+    srt = np.sort(r_ref, 1)
+    safe = (np.diff(srt, axis=1).min(1) > 2 * BF16_SCORE_TOL)
+    if safe.any():
+        assert (np.argsort(-r_ref[safe], 1) == np.argsort(-r_got[safe], 1)).all()
+    map_ref = ltorank.MAP(np.argsort(-r_ref, 1), lab)
+    map_got = ltorank.MAP(np.argsort(-r_got, 1), lab)
+    assert abs(map_ref - map_got) <= 0.02, (map_ref, map_got)
