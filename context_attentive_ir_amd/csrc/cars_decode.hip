@@ -1,0 +1,227 @@
+// CARS.decode -- greedy query suggestion (neuroir/multitask/cars.py:706-791; RNNDecoder: decoders/decoder.py:94-168,
+// decoders/rnn_decoder.py:19-88; Luong "general" attention: modules/global_attention.py:98-196).
+//
+// Per decoding step, for all Bd = B*(S-1) rows at once (the reference runs the same ops, one torch call each, plus a host
+// round trip per step to map target-vocabulary ids back to source-vocabulary ids through two Python dicts):
+//   x = emb(tgt)                      gathered inside the LSTM step kernel (no [Bd,1,E] tensor)
+//   (h,c) = LSTM(x, (h,c))            lstm_step_kernel (16x16x4 MFMA, cell fused)
+//   q = W_in h                        GEMM
+//   a = softmax_j(mask(q . m_j)); ctx = sum_j a_j m_j; cat = [ctx ; h]      dec_attend_kernel (m = dec_attn(encoded queries))
+//   o = tanh(W_out cat)               GEMM + tanh epilogue
+//   p = W_p1 o + session_rep          GEMM + addend epilogue (session_rep = (W_shared + W_priv2) [inner_q ; inner_d], once)
+//   logits = W_p2 p                   GEMM  [Bd, V_tgt]
+//   pred = argmax logits; tgt = lut[pred]                                    argmax_map_kernel (softmax is monotone; first
+//                                                                           index wins ties like torch.max)
+// Everything is enqueued on the caller's stream; no host synchronisation.
+#include "common.hpp"
+
+namespace nir {
+
+int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                  int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                  int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
+int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                     int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                     int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st);
+
+struct LstmStepArgs {
+    const float* x[2];
+    const int64_t* xid[2];
+    int64_t xstride[2];
+    const float* wih[2];
+    const float* whh[2];
+    const float* bih[2];
+    const float* bhh[2];
+    const float* hprev[2];
+    const float* cprev[2];
+    float* hnext[2];
+    float* cnext[2];
+    int chain0;
+    int B, I, H;
+};
+int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st);
+
+// one wave per decode row i: memory block = mem[rowmap[i]] ([QL, HD]), valid length = lens[rowmap[i]]
+__global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict__ qv, const float* __restrict__ h,
+                                                         const float* __restrict__ mem, const int64_t* __restrict__ rowmap,
+                                                         const int64_t* __restrict__ lens, int Bd, int QL, int HD,
+                                                         float* __restrict__ cat) {
+    extern __shared__ float pr[];                 // [4][QL]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= Bd) return;
+    float* pw = pr + wave * QL;
+    const int64_t r = rowmap[i];
+    int len = (int)lens[r];
+    len = len < 0 ? 0 : (len > QL ? QL : len);
+    const float* mb = mem + r * QL * HD;
+    const float* q = qv + (int64_t)i * HD;
+    float mx = -INFINITY;
+    for (int j = 0; j < len; ++j) {
+        float s = 0.f;
+        for (int f = 4 * lane; f < HD; f += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(mb + (int64_t)j * HD + f), b = *reinterpret_cast<const float4*>(q + f);
+            s += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+        }
+        s = wave_sum(s);
+        if (lane == 0) pw[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float den = 0.f;
+    for (int j = 0; j < len; ++j) den += expf(pw[j] - mx);
+    float* o = cat + (int64_t)i * 2 * HD;
+    for (int f = 4 * lane; f < HD; f += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < len; ++j) {
+            const float p = expf(pw[j] - mx) / den;
+            const float4 v = *reinterpret_cast<const float4*>(mb + (int64_t)j * HD + f);
+            acc.x = fmaf(p, v.x, acc.x); acc.y = fmaf(p, v.y, acc.y); acc.z = fmaf(p, v.z, acc.z); acc.w = fmaf(p, v.w, acc.w);
+        }
+        if (len == 0) acc = make_float4(NAN, NAN, NAN, NAN);      // softmax over an all -inf row
+        *reinterpret_cast<float4*>(o + f) = acc;
+        *reinterpret_cast<float4*>(o + HD + f) = *reinterpret_cast<const float4*>(h + (int64_t)i * HD + f);
+    }
+}
+
+// pred[i*pstride] = argmax_v logits[i,v] (first index on ties); tgt[i] = lut ? lut[pred] : pred
+__global__ __launch_bounds__(256) void argmax_map_kernel(const float* __restrict__ logits, int64_t V, const int64_t* __restrict__ lut,
+                                                         int64_t* __restrict__ pred, int64_t pstride, int64_t* __restrict__ tgt) {
+    __shared__ float bv[256];
+    __shared__ int64_t bi[256];
+    const int i = blockIdx.x;
+    const float* row = logits + (int64_t)i * V;
+    float best = -INFINITY;
+    int64_t idx = V;                                 // V = "none yet"
+    for (int64_t v = threadIdx.x; v < V; v += 256) {
+        const float x = row[v];
+        if (x > best || (x == best && v < idx)) { best = x; idx = v; }
+    }
+    bv[threadIdx.x] = best;
+    bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float ob = bv[threadIdx.x + s];
+            const int64_t oi = bi[threadIdx.x + s];
+            if (ob > bv[threadIdx.x] || (ob == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ob; bi[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int64_t w = bi[0] < V ? bi[0] : 0;
+        pred[(int64_t)i * pstride] = w;
+        tgt[i] = lut ? lut[w] : w;
+    }
+}
+
+__global__ void fill_i64_kernel(int64_t* p, int64_t v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// wsum = w1 + w2  (shared_session_projector + private_session_projector2, packed once)
+__global__ void add_weights_kernel(const float* a, const float* b, float* o, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+
+struct DecPlan {
+    float *mem, *sess, *h[2], *c[2], *qv, *cat, *ah, *p1, *logits;
+    int64_t* tgt;
+    size_t bytes;
+};
+static DecPlan dec_plan(void* ws, size_t cap, int64_t rows_src, int64_t Bd, int QL, int HD, int P, int64_t VT) {
+    Workspace a(ws, cap);
+    DecPlan p;
+    p.mem = a.take<float>((size_t)rows_src * QL * HD);
+    p.sess = a.take<float>((size_t)Bd * P);
+    for (int k = 0; k < 2; ++k) { p.h[k] = a.take<float>((size_t)Bd * HD); p.c[k] = a.take<float>((size_t)Bd * HD); }
+    p.qv = a.take<float>((size_t)Bd * HD);
+    p.cat = a.take<float>((size_t)Bd * 2 * HD);
+    p.ah = a.take<float>((size_t)Bd * HD);
+    p.p1 = a.take<float>((size_t)Bd * P);
+    p.logits = a.take<float>((size_t)Bd * VT);
+    p.tgt = a.take<int64_t>((size_t)Bd);
+    p.bytes = align_up(a.off, 256);
+    return p;
+}
+
+}  // namespace nir
+
+extern "C" int nir_add_f32(const float* a, const float* b, float* out, int64_t n, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(a && b && out && n >= 0, "add_f32: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(add_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    NIR_CHECK_LAUNCH("add_weights_kernel");
+    return 0;
+}
+
+extern "C" size_t nir_cars_decode_workspace_bytes(int64_t rows_src, int64_t Bd, int QL, const nir_cars_decoder_weights* w) {
+    if (!w || rows_src < 0 || Bd < 0 || QL <= 0) return 0;
+    return nir::dec_plan(nullptr, 0, rows_src, Bd, QL, w->HD, w->P, w->VT).bytes;
+}
+
+extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, const float* encoded_source, const int64_t* source_len,
+                                      int64_t rows_src, int QL, const int64_t* rowmap, int64_t Bd, const float* session_cat,
+                                      const float* table, int64_t V, int E, const int64_t* tgt2src, int64_t bos, int max_len,
+                                      const nir_cars_decoder_weights* w, void* workspace, size_t workspace_bytes,
+                                      int64_t* predictions, nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(dec_h && dec_c && encoded_source && source_len && rowmap && table && w && predictions, "cars_decode: null pointer");
+    NIR_REQUIRE(rows_src > 0 && Bd >= 0 && QL > 0 && max_len > 0 && V > 0 && E > 0, "cars_decode: bad dims");
+    NIR_REQUIRE(w->HD % 4 == 0 && E % 4 == 0 && w->DQ % 4 == 0 && w->P % 4 == 0, "cars_decode: dims must be multiples of 4");
+    NIR_REQUIRE(w->KS == 0 || (session_cat && w->sess_w), "cars_decode: session representation / packed projector missing");
+    NIR_REQUIRE(bos >= 0 && bos < V, "cars_decode: BOS id outside the vocabulary");
+    if (Bd == 0) return 0;
+    const int HD = w->HD, P = w->P;
+    DecPlan p = dec_plan(workspace, workspace_bytes, rows_src, Bd, QL, HD, P, w->VT);
+    if (!workspace || p.bytes > workspace_bytes) {
+        set_error("cars_decode: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+        return NIR_ERR_WORKSPACE;
+    }
+    // memory bank = dec_attn(encoded queries)  (cars.py:757-767), all (session, query) rows; rowmap picks [:, :-1]
+    NIR_PROPAGATE(launch_linear(encoded_source, w->DQ, nullptr, nullptr, 0, 0, 0, w->dec_attn_w, w->DQ, nullptr, nullptr, p.mem, HD,
+                                rows_src * QL, HD, w->DQ, NIR_ACT_NONE, st));
+    // session_rep = (shared + private2)(cat_session_rep[:, :-1])  (cars.py:775-778): rows gathered through rowmap
+    if (w->KS > 0)
+        NIR_PROPAGATE(launch_linear(nullptr, 0, rowmap, session_cat, w->KS, 1, 1, w->sess_w, w->KS, nullptr, nullptr, p.sess, P, Bd, P, w->KS,
+                                    NIR_ACT_NONE, st));
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((Bd + 255) / 256)), dim3(256), 0, st, p.tgt, bos, Bd);
+    NIR_CHECK_LAUNCH("fill_i64_kernel");
+    LstmStepArgs a;
+    a.x[0] = table; a.xid[0] = p.tgt; a.xstride[0] = E;
+    a.wih[0] = w->rnn_wih; a.whh[0] = w->rnn_whh; a.bih[0] = w->rnn_bih; a.bhh[0] = w->rnn_bhh;
+    a.x[1] = nullptr; a.xid[1] = nullptr; a.xstride[1] = 0; a.wih[1] = a.whh[1] = a.bih[1] = a.bhh[1] = nullptr;
+    a.hprev[1] = a.cprev[1] = nullptr; a.hnext[1] = a.cnext[1] = nullptr;
+    a.chain0 = 0; a.B = (int)Bd; a.I = E; a.H = HD;
+    const float* hp = dec_h;
+    const float* cp = dec_c;
+    for (int step = 0; step < max_len; ++step) {
+        float* hn = p.h[step & 1];
+        float* cn = p.c[step & 1];
+        a.hprev[0] = hp; a.cprev[0] = cp; a.hnext[0] = hn; a.cnext[0] = cn;
+        NIR_PROPAGATE(launch_lstm_step(a, 1, st));
+        NIR_PROPAGATE(launch_linear(hn, HD, nullptr, nullptr, 0, 0, 0, w->attn_in_w, HD, nullptr, nullptr, p.qv, HD, Bd, HD, HD, NIR_ACT_NONE, st));
+        {
+            ProfScope ps("dec_attend_kernel", st);
+            hipLaunchKernelGGL(dec_attend_kernel, dim3((unsigned)((Bd + 3) / 4)), dim3(256), (size_t)4 * QL * 4, st, p.qv, hn, p.mem, rowmap,
+                               source_len, (int)Bd, QL, HD, p.cat);
+        }
+        NIR_CHECK_LAUNCH("dec_attend_kernel");
+        NIR_PROPAGATE(launch_linear(p.cat, 2 * HD, nullptr, nullptr, 0, 0, 0, w->attn_out_w, 2 * HD, nullptr, nullptr, p.ah, HD, Bd, HD, 2 * HD, NIR_ACT_TANH, st));
+        NIR_PROPAGATE(launch_linear_ex(p.ah, HD, nullptr, nullptr, 0, 0, 0, w->pred1_w, HD, nullptr, nullptr, p.p1, P, Bd, P, HD, NIR_ACT_NONE,
+                                       w->KS > 0 ? p.sess : nullptr, P, st));
+        NIR_PROPAGATE(launch_linear(p.p1, P, nullptr, nullptr, 0, 0, 0, w->pred2_w, P, nullptr, nullptr, p.logits, w->VT, Bd, (int)w->VT, P, NIR_ACT_NONE, st));
+        {
+            ProfScope ps("argmax_map_kernel", st);
+            hipLaunchKernelGGL(argmax_map_kernel, dim3((unsigned)Bd), dim3(256), 0, st, p.logits, w->VT, tgt2src, predictions + step, (int64_t)max_len, p.tgt);
+        }
+        NIR_CHECK_LAUNCH("argmax_map_kernel");
+        hp = hn;
+        cp = cn;
+    }
+    return 0;
+}

@@ -1,0 +1,492 @@
+// CARS session part (neuroir/multitask/cars.py:262-520): encode_clicks, encode_session, rank -- and, on request, the
+// session outputs the suggestion decoder consumes (decoder-initialisation states and inner-attention pools, :382-456).
+//
+// The session states depend only on the queries and the clicks, never on the rank outputs, so the two session LSTM chains
+// run first and cross attention + ranknet are evaluated ONCE for all (session, step) pairs.  Launch plan (C3: 15 launches,
+// the reference issues ~25 torch ops x S steps and two host syncs):
+//   1 click-attention MLP (GEMM, tanh + Linear(D,1) fused into the epilogue)          [doc chain on]
+//   1 click_pool2 (batch-wide max click count, stable label sort, quirk mask, softmax, weighted sum)
+//   1 U = pooled_q [W_sq^T | W_sd^T | b_sq | b_sd]: the cross-attention projection moved to the query side,
+//       logit_k = (W s_k + b) . q  ==  s_k . (W^T q) + b . q   -- independent of the LSTM chains
+//   S-1 session_lstm_step: BOTH chains in one launch; a workgroup owns 4 hidden units (16 gate rows, gate-interleaved so
+//       one lane ends up with i,f,g,o of its (unit, session)), x W_ih^T + h W_hh^T on v_mfma_f32_16x16x4_f32 with K split
+//       over the 4 waves, cell update in the same kernel -- no gate tensor, no separate cell kernel, no fill kernels
+//   1 session_attend2 (softmax over the t+1 previous states incl. the zero state, weighted sums, [q; sq; sd] rows)
+//   1 rank projection GEMM (W_q | W_shared + W_priv1 packed once per weight version), 1 feature kernel, 3 maxout GEMMs
+#include "common.hpp"
+#include <algorithm>
+
+namespace nir {
+
+int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                  int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                  int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
+int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
+                     int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
+                     int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st);
+constexpr int ACT_MAXOUT2 = 16;
+constexpr int ACT_TANH_ROWDOT16 = 17;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one wave per (b,s) row, N <= 64: batch-wide m = max_rows count_nonzero(labels) (cars.py:285-289), stable descending
+// rank by label, attend over {rank < count} U {rank >= m} (Appendix E2), logits e_k = sum of the NP epilogue partials + b3
+__global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restrict__ docs, const float* __restrict__ epart, int NP,
+                                                          const float* __restrict__ b3, const float* __restrict__ labels,
+                                                          int rows, int N, int D, float* __restrict__ clicks) {
+    __shared__ int part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {   // every workgroup recomputes m from the (tiny) label matrix: no extra launch, no cross-workgroup dependency
+        int best = 0;
+        for (int r = wave; r < rows; r += 4) {
+            float c = 0.f;
+            for (int k = lane; k < N; k += 64) c += labels[(int64_t)r * N + k] != 0.f ? 1.f : 0.f;
+            best = max(best, (int)wave_sum(c));
+        }
+        if (lane == 0) part[wave] = best;
+    }
+    __syncthreads();
+    const int m = max(max(part[0], part[1]), max(part[2], part[3]));
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float lab = lane < N ? labels[(int64_t)r * N + lane] : -INFINITY;
+    int rank = 0;
+    for (int k = 0; k < N; ++k) {
+        const float lk = __shfl(lab, k, 64);
+        rank += (lk > lab) || (lk == lab && k < lane);
+    }
+    const int count = (int)wave_sum((lane < N && lab != 0.f) ? 1.f : 0.f);
+    const bool keep = lane < N && (rank < count || rank >= m);
+    float lg = -INFINITY;
+    if (keep) {
+        const float* lp = epart + ((int64_t)r * N + lane) * NP;
+        float s = b3[0];
+        for (int j = 0; j < NP; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(lp + j);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        lg = s;
+    }
+    const float mx = wave_max(lg);
+    const float ex = keep ? expf(lg - mx) : 0.f;
+    const float p = ex / wave_sum(ex);   // all masked -> NaN, exactly like softmax of all -inf in the reference
+    const int nch = D >> 2;
+    for (int c = lane; c < nch; c += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < N; ++k) {
+            const float pk = __shfl(p, k, 64);
+            const float4 v = *reinterpret_cast<const float4*>(docs + ((int64_t)r * N + k) * D + 4 * c);
+            acc.x = fmaf(pk, v.x, acc.x); acc.y = fmaf(pk, v.y, acc.y); acc.z = fmaf(pk, v.z, acc.z); acc.w = fmaf(pk, v.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(clicks + (int64_t)r * D + 4 * c) = acc;
+    }
+}
+
+// One LSTM cell step for up to two independent chains in one launch (session LSTMs: cars.py:378-380, 400-402 via
+// rnn_encoder.py:76-102; decoder LSTM: decoders/decoder.py:94-95).  A workgroup owns 4 hidden units = 16 gate rows,
+// interleaved as row = 4*unit + gate so the 16x16 MFMA's C/D layout hands ONE lane the four gates i,f,g,o of its
+// (unit, batch row): gates = x W_ih^T + h W_hh^T on v_mfma_f32_16x16x4_f32 with K split over the 4 waves, operands read
+// straight from L2 as MFMA fragments, partial tiles summed through LDS, cell update in the same kernel.
+struct LstmStepArgs {
+    const float* x[2];        // input rows: row b at x + (xid ? xid[b] : b) * xstride   (xid: embedding gather by token id)
+    const int64_t* xid[2];
+    int64_t xstride[2];
+    const float* wih[2];      // [4H, I]
+    const float* whh[2];      // [4H, H]
+    const float* bih[2];
+    const float* bhh[2];
+    const float* hprev[2];    // [B,H] or NULL (zero state: the recurrent product is skipped)
+    const float* cprev[2];    // [B,H] or NULL
+    float* hnext[2];          // [B,H]
+    float* cnext[2];
+    int chain0;               // blockIdx.y + chain0 = chain id
+    int B, I, H;
+};
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
+    __shared__ float red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ch = blockIdx.y + p.chain0;
+    const int u0 = blockIdx.x * 4;
+    const int I = p.I, H = p.H;
+    // A operand rows: row i = 4*unit_local + gate  ->  weight row gate*H + u0 + unit_local
+    const int ua = u0 + (i >> 2);
+    const int arow = (i & 3) * H + (ua < H ? ua : H - 1);
+    const float* wi = p.wih[ch] + (int64_t)arow * I;
+    const float* wh = p.whh[ch] + (int64_t)arow * H;
+    const float* hprev = p.hprev[ch];
+    const float* cprev = p.cprev[ch];
+    const int nq1 = (I + 15) >> 4, nq2 = hprev ? ((H + 15) >> 4) : 0;
+    // result view: lane = (batch column i, unit_local g), registers r = gates i,f,g,o
+    const int ud = u0 + g;
+    const bool uv = ud < H;
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = uv ? p.bih[ch][r * H + ud] + p.bhh[ch][r * H + ud] : 0.f;
+    for (int b0 = 0; b0 < p.B; b0 += 16) {
+        const int b = b0 + i;
+        const bool bv = b < p.B;
+        const int64_t xr_i = bv ? (p.xid[ch] ? p.xid[ch][b] : (int64_t)b) : 0;
+        const float* xr = p.x[ch] + xr_i * p.xstride[ch];
+        const float* hr = hprev ? hprev + (int64_t)(bv ? b : 0) * H : nullptr;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int q = wave; q < nq1; q += 4) {
+            const int k = 16 * q + 4 * g;
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < I) {
+                a4 = *reinterpret_cast<const float4*>(wi + k);
+                if (bv) b4 = *reinterpret_cast<const float4*>(xr + k);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+#pragma unroll 4
+        for (int q = wave; q < nq2; q += 4) {
+            const int k = 16 * q + 4 * g;
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < H) {
+                a4 = *reinterpret_cast<const float4*>(wh + k);
+                if (bv) b4 = *reinterpret_cast<const float4*>(hr + k);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][r * 64 + lane] = acc[r];
+        __syncthreads();
+        if (wave == 0) {
+            float g4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                g4[r] = bias[r] + ((red[0][r * 64 + lane] + red[1][r * 64 + lane]) + (red[2][r * 64 + lane] + red[3][r * 64 + lane]));
+            if (bv && uv) {
+                const int64_t si = (int64_t)b * H + ud;
+                const float c0 = cprev ? cprev[si] : 0.f;
+                const float cn = fast_sigmoid(g4[1]) * c0 + fast_sigmoid(g4[0]) * fast_tanh(g4[2]);
+                p.cnext[ch][si] = cn;
+                p.hnext[ch][si] = fast_sigmoid(g4[3]) * fast_tanh(cn);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st) {
+    NIR_REQUIRE(a.I % 4 == 0 && a.H % 4 == 0 && a.B >= 0, "lstm_step: I and H must be multiples of 4");
+    if (a.B == 0) return 0;
+    ProfScope ps("lstm_step_kernel", st);
+    hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)((a.H + 3) / 4), (unsigned)nchains), dim3(256), 0, st, a);
+    NIR_CHECK_LAUNCH("lstm_step_kernel");
+    return 0;
+}
+
+// Cross attention over the session states (cars.py:348-366) for one (session b, step t) per workgroup, projection folded
+// onto the query side: U[bt] = [W_sq^T q | W_sd^T q | b_sq.q | b_sd.q]; logit_k = s_k . U_chain + bias term, k = 0..t with
+// s_0 = 0; out = sum_k softmax(logit)_k s_k.  Writes xcat[bt] = [q ; sq ; sd] (only the chains that are on).
+__global__ __launch_bounds__(256) void session_attend2_kernel(const float* __restrict__ U, int NU, const float* __restrict__ Qs,
+                                                              const float* __restrict__ Ds, const float* __restrict__ q,
+                                                              int B, int S, int D, int HS, int q_on, int d_on,
+                                                              float* __restrict__ xcat) {
+    __shared__ float lg[2][64];
+    const int bt = blockIdx.x, b = bt / S, t = bt % S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = q_on + d_on;
+    const int HSQ = q_on ? HS : 0;
+    const float* ur = U + (int64_t)bt * NU;
+    const float* qv = q + (int64_t)bt * D;
+    float* orow = xcat + (int64_t)bt * (D + nch * HS);
+    // chain slot c (0..nch-1): states pointer, U column offset, bias column
+    for (int e = wave; e < nch * t; e += 4) {
+        const int c = e / t, k = e % t + 1;
+        const float* st = (c == 0 && q_on) ? Qs : Ds;
+        const float* sv = st + ((int64_t)k * B + b) * HS;
+        const float* uv = ur + c * HS;
+        float sacc = 0.f;
+        for (int f = 4 * lane; f < HS; f += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(sv + f), w = *reinterpret_cast<const float4*>(uv + f);
+            sacc += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+        }
+        sacc = wave_sum(sacc);
+        if (lane == 0) lg[c][k] = sacc + ur[nch * HS + c];
+    }
+    if (threadIdx.x < nch) lg[threadIdx.x][0] = ur[nch * HS + threadIdx.x];
+    for (int f = threadIdx.x; f < D; f += 256) orow[f] = qv[f];
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const float* st = (c == 0 && q_on) ? Qs : Ds;
+        float mx = -INFINITY;
+        for (int k = 0; k <= t; ++k) mx = fmaxf(mx, lg[c][k]);
+        float den = 0.f;
+        for (int k = 0; k <= t; ++k) den += expf(lg[c][k] - mx);
+        for (int f = threadIdx.x; f < HS; f += 256) {
+            float acc = 0.f;
+            for (int k = 1; k <= t; ++k) acc = fmaf(expf(lg[c][k] - mx) / den, st[((int64_t)k * B + b) * HS + f], acc);
+            orow[D + c * HS + f] = acc;
+        }
+    }
+    (void)HSQ;
+}
+
+// Pack-time weights: wrank[o,:] = [W_q[o,:] | W_shared[o,:] + W_priv1[o,:]]  ([D, D + KS]);
+//                    ut = [W_sq^T ; W_sd^T ; b_sq ; b_sd]                      ([KS + nch, D]) for the U GEMM.
+__global__ void session_pack_kernel(const float* wq, const float* wshared, const float* wpriv, const float* sqw, const float* sqb,
+                                    const float* sdw, const float* sdb, int D, int HS, int q_on, int d_on, float* wrank, float* ut) {
+    const int nch = q_on + d_on, KS = nch * HS, KR = D + KS;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)D * KR) {
+        const int o = (int)(i / KR), k = (int)(i % KR);
+        float v;
+        if (k < D) v = wq[(int64_t)o * D + k];
+        else v = wshared[(int64_t)o * KS + (k - D)] + wpriv[(int64_t)o * KS + (k - D)];
+        wrank[i] = v;
+    }
+    if (i < (int64_t)(KS + nch) * D) {
+        const int j = (int)(i / D), f = (int)(i % D);
+        float v;
+        if (j < KS) {
+            const int c = j / HS, jj = j % HS;
+            const float* w = (c == 0 && q_on) ? sqw : sdw;        // [D, HS]
+            v = w[(int64_t)f * HS + jj];
+        } else {
+            const int c = j - KS;
+            v = ((c == 0 && q_on) ? sqb : sdb)[f];
+        }
+        ut[i] = v;
+    }
+}
+
+// feats[(b,t,n)] = [q', d, |q'-d|, q'*d]   (cars.py:514-518); q' row = (b,t), d row = (b,t,n)
+__global__ void rank_feats_kernel(const float* qp, const float* docs, int N, int D, int64_t rows, float* feats) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < rows * D) {
+        const int64_t r = i / D;
+        const int f = (int)(i % D);
+        const float4 q = *reinterpret_cast<const float4*>(qp + (r / N) * D + f), d = *reinterpret_cast<const float4*>(docs + r * D + f);
+        float* o = feats + r * 4 * D + f;
+        *reinterpret_cast<float4*>(o) = q;
+        *reinterpret_cast<float4*>(o + D) = d;
+        *reinterpret_cast<float4*>(o + 2 * D) = make_float4(fabsf(q.x - d.x), fabsf(q.y - d.y), fabsf(q.z - d.z), fabsf(q.w - d.w));
+        *reinterpret_cast<float4*>(o + 3 * D) = make_float4(q.x * d.x, q.y * d.y, q.z * d.z, q.w * d.w);
+    }
+}
+
+// inner self-attention pools over the states produced so far (cars.py:385-388, 407-410), suggestion side only:
+// inner[b,t] = sum_{k=1..t+1} softmax_k(l_k) s_k,  l_k = sum of the NP epilogue partials of state row (k,b) + b3;
+// `states` and `lpart` both start at state 1
+__global__ __launch_bounds__(256) void session_inner_pool_kernel(const float* __restrict__ states, const float* __restrict__ lpart,
+                                                                 int NP, const float* __restrict__ b3, int B, int S, int HS,
+                                                                 float* __restrict__ out /*[B,S,HS]*/) {
+    __shared__ float lg[64];
+    const int bt = blockIdx.x, b = bt / S, t = bt % S;
+    const int n = t + 1;                                  // states 1..t+1
+    if (threadIdx.x < n) {
+        const float* lp = lpart + ((int64_t)threadIdx.x * B + b) * NP;     // lpart row 0 = state 1
+        float s = b3[0];
+        for (int j = 0; j < NP; ++j) s += lp[j];
+        lg[threadIdx.x] = s;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int k = 0; k < n; ++k) mx = fmaxf(mx, lg[k]);
+    float den = 0.f;
+    for (int k = 0; k < n; ++k) den += expf(lg[k] - mx);
+    for (int f = threadIdx.x; f < HS; f += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc = fmaf(expf(lg[k] - mx) / den, states[((int64_t)k * B + b) * HS + f], acc);
+        out[(int64_t)bt * HS + f] = acc;
+    }
+}
+
+// cat[(t,b)] = [hq_{t+1}[b] ; hd_{t+1}[b]]  for t = 0..S-2  (the reference concatenates the per-step states along the batch
+// axis in step-major order, cars.py:431-436 -- kept as is, including the resulting (step, session) row order)
+__global__ void session_cat_states_kernel(const float* a, const float* b2, int rows, int HSa, int HSb, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = HSa + HSb;
+    if (i < (int64_t)rows * W) {
+        const int r = (int)(i / W), f = (int)(i % W);
+        out[i] = f < HSa ? a[(int64_t)r * HSa + f] : b2[(int64_t)r * HSb + (f - HSa)];
+    }
+}
+
+struct SessPlan {
+    float *epart, *clicks, *Qs, *Ds, *Cq, *Cd, *U, *xcat, *qp, *feats, *y0, *y1, *lin, *cat;
+    size_t bytes;
+};
+static SessPlan sess_plan(void* ws, size_t cap, int B, int S, int N, int D, int HS, int nch, bool rank_on, bool want_states) {
+    Workspace a(ws, cap);
+    SessPlan p;
+    const size_t R = (size_t)B * S * N, BS = (size_t)B * S;
+    p.epart = a.take<float>(R * (D / 16));
+    p.clicks = a.take<float>(BS * D);
+    p.Qs = a.take<float>((size_t)(S + 1) * B * HS);
+    p.Ds = a.take<float>((size_t)(S + 1) * B * HS);
+    p.Cq = a.take<float>((size_t)(S + 1) * B * HS);
+    p.Cd = a.take<float>((size_t)(S + 1) * B * HS);
+    p.U = a.take<float>(BS * (size_t)(nch * HS + nch + 4));
+    p.xcat = a.take<float>(BS * (size_t)(D + nch * HS));
+    p.qp = a.take<float>(BS * D);
+    p.feats = a.take<float>(rank_on ? R * 4 * D : 0);
+    p.y0 = a.take<float>(rank_on ? R * 256 : 0);
+    p.y1 = a.take<float>(rank_on ? R * 128 : 0);
+    p.lin = a.take<float>(want_states ? (size_t)(S + 1) * B * (HS / 16) : 0);
+    p.cat = a.take<float>(want_states ? (size_t)S * B * nch * HS : 0);
+    p.bytes = align_up(a.off, 256);
+    return p;
+}
+
+static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace nir
+
+extern "C" size_t nir_cars_session_pack_floats(const nir_cars_session_weights* w, size_t* wrank_floats, size_t* ut_floats) {
+    if (!w) return 0;
+    const int nch = (w->q_on ? 1 : 0) + (w->d_on ? 1 : 0);
+    const size_t a = (size_t)w->D * (w->D + nch * w->HS), b = (size_t)(nch * w->HS + nch) * w->D;
+    if (wrank_floats) *wrank_floats = a;
+    if (ut_floats) *ut_floats = b;
+    return a + b;
+}
+
+extern "C" int nir_cars_session_pack(const nir_cars_session_weights* w, float* wrank, float* ut, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(w && wrank && ut, "cars_session_pack: null pointer");
+    const int q_on = w->q_on ? 1 : 0, d_on = w->d_on ? 1 : 0, nch = q_on + d_on;
+    NIR_REQUIRE(w->qproj_w, "cars_session_pack: q_projection missing (ranker off?)");
+    NIR_REQUIRE(nch == 0 || (w->shared_w && w->priv1_w), "cars_session_pack: session projectors missing");
+    const int64_t n = std::max((int64_t)w->D * (w->D + nch * w->HS), (int64_t)(nch * w->HS + nch) * w->D);
+    hipLaunchKernelGGL(session_pack_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, w->qproj_w, w->shared_w, w->priv1_w, w->sq_attn_w,
+                       w->sq_attn_b, w->sd_attn_w, w->sd_attn_b, w->D, w->HS, q_on, d_on, wrank, ut);
+    NIR_CHECK_LAUNCH("session_pack_kernel");
+    return 0;
+}
+
+extern "C" size_t nir_cars_session_workspace_bytes(int B, int S, int N, const nir_cars_session_weights* w) {
+    if (!w || B < 0 || S <= 0 || N <= 0) return 0;
+    const int nch = (w->q_on ? 1 : 0) + (w->d_on ? 1 : 0);
+    return nir::sess_plan(nullptr, 0, B, S, N, w->D, w->HS, nch, true, true).bytes;
+}
+
+extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
+                                     const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
+                                     float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
+                                     nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(pooled_q && w, "cars_rank_session: null pointer");
+    const bool q_on = w->q_on != 0, d_on = w->d_on != 0, rank_on = w->rank_on != 0;
+    const int nch = (q_on ? 1 : 0) + (d_on ? 1 : 0);
+    NIR_REQUIRE(!rank_on || (pooled_docs && click_scores && w->wrank), "cars_rank_session: ranker on needs documents, scores and packed weights");
+    NIR_REQUIRE(!d_on || (pooled_docs && labels), "cars_rank_session: the document session needs documents and labels");
+    NIR_REQUIRE(nch == 0 || !rank_on || w->attn_ut, "cars_rank_session: packed attention weights missing (nir_cars_session_pack)");
+    NIR_REQUIRE(B >= 0 && S > 0 && N > 0, "cars_rank_session: bad dims");
+    NIR_REQUIRE(N <= 64, "cars_rank_session: %d candidates > 64 unsupported", N);
+    NIR_REQUIRE(S <= 63, "cars_rank_session: session length %d > 63 unsupported", S);
+    NIR_REQUIRE(w->D % 64 == 0 && w->HS % 16 == 0 && w->D % 16 == 0, "cars_rank_session: D %% 64 / HS %% 16 required");
+    if (B == 0) return 0;
+    const int D = w->D, HS = w->HS, NP = D / 16;
+    const bool want_states = extra != nullptr;
+    SessPlan p = sess_plan(workspace, workspace_bytes, B, S, N, D, HS, nch, rank_on, want_states);
+    if (!workspace || p.bytes > workspace_bytes) {
+        set_error("cars_rank_session: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+        return NIR_ERR_WORKSPACE;
+    }
+    const int64_t BS = (int64_t)B * S, R = BS * N;
+    float* clicks = clicks_out ? clicks_out : p.clicks;
+    // ---- encode_clicks (cars.py:262-304)
+    if (d_on) {
+        NIR_PROPAGATE(launch_linear_ex(pooled_docs, D, nullptr, nullptr, 0, 0, 0, w->click0_w, D, w->click0_b, nullptr, p.epart, NP, R, D, D,
+                                       ACT_TANH_ROWDOT16, w->click3_w, 0, st));
+        {
+            ProfScope ps("click_pool2_kernel", st);
+            hipLaunchKernelGGL(click_pool2_kernel, dim3((unsigned)((BS + 3) / 4)), dim3(256), 0, st, pooled_docs, p.epart, NP, w->click3_b, labels,
+                               (int)BS, N, D, clicks);
+        }
+        NIR_CHECK_LAUNCH("click_pool2_kernel");
+    }
+    // ---- U = pooled_q [W_sq^T | W_sd^T | b_sq | b_sd]  (independent of the chains)
+    const int NU = nch * HS + nch;
+    if (nch && rank_on)
+        NIR_PROPAGATE(launch_linear(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->attn_ut, D, nullptr, nullptr, p.U, NU, BS, NU, D, NIR_ACT_NONE, st));
+    // ---- session LSTM chains: state t+1 = LSTM(x_t, state t); the ranking path needs states 1..S-1, the decoder S as well
+    const int nsteps = want_states ? S : S - 1;
+    if (nch) {
+        LstmStepArgs a;
+        a.wih[0] = w->sq_wih; a.whh[0] = w->sq_whh; a.bih[0] = w->sq_bih; a.bhh[0] = w->sq_bhh;
+        a.wih[1] = w->sd_wih; a.whh[1] = w->sd_whh; a.bih[1] = w->sd_bih; a.bhh[1] = w->sd_bhh;
+        a.xid[0] = a.xid[1] = nullptr;
+        a.xstride[0] = a.xstride[1] = (int64_t)S * D;
+        a.chain0 = q_on ? 0 : 1;
+        a.B = B; a.I = D; a.H = HS;
+        const int64_t slot = (int64_t)B * HS;
+        for (int t = 0; t < nsteps; ++t) {      // slot 0 = the initial zero state: never read (NULL previous state), never written
+            a.x[0] = pooled_q + (int64_t)t * D; a.x[1] = clicks + (int64_t)t * D;
+            a.hprev[0] = t ? p.Qs + t * slot : nullptr; a.cprev[0] = t ? p.Cq + t * slot : nullptr;
+            a.hprev[1] = t ? p.Ds + t * slot : nullptr; a.cprev[1] = t ? p.Cd + t * slot : nullptr;
+            a.hnext[0] = p.Qs + (t + 1) * slot; a.cnext[0] = p.Cq + (t + 1) * slot;
+            a.hnext[1] = p.Ds + (t + 1) * slot; a.cnext[1] = p.Cd + (t + 1) * slot;
+            NIR_PROPAGATE(launch_lstm_step(a, nch, st));
+        }
+    }
+    if (rank_on) {
+        const int KR = D + nch * HS;
+        const float* xrows = pooled_q;
+        if (nch) {
+            {
+                ProfScope ps("session_attend2_kernel", st);
+                hipLaunchKernelGGL(session_attend2_kernel, dim3((unsigned)BS), dim3(256), 0, st, p.U, NU, p.Qs, p.Ds, pooled_q, B, S, D, HS,
+                                   (int)q_on, (int)d_on, p.xcat);
+            }
+            NIR_CHECK_LAUNCH("session_attend2_kernel");
+            xrows = p.xcat;
+        }
+        NIR_PROPAGATE(launch_linear(xrows, KR, nullptr, nullptr, 0, 0, 0, w->wrank, KR, w->qproj_b, nullptr, p.qp, D, BS, D, KR, NIR_ACT_NONE, st));
+        {
+            ProfScope ps("rank_feats_kernel", st);
+            hipLaunchKernelGGL(rank_feats_kernel, g1(R * D / 4), dim3(256), 0, st, p.qp, pooled_docs, N, D, R, p.feats);
+        }
+        NIR_CHECK_LAUNCH("rank_feats_kernel");
+        // maxout 1024 -> 256 -> 128 -> 1 (pool 2): the pairwise max is fused into the GEMM epilogues
+        NIR_PROPAGATE(launch_linear_ex(p.feats, 4 * D, nullptr, nullptr, 0, 0, 0, w->mo0_w, 4 * D, w->mo0_b, nullptr, p.y0, 256, R, 512, 4 * D, ACT_MAXOUT2, nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear_ex(p.y0, 256, nullptr, nullptr, 0, 0, 0, w->mo1_w, 256, w->mo1_b, nullptr, p.y1, 128, R, 256, 256, ACT_MAXOUT2, nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear_ex(p.y1, 128, nullptr, nullptr, 0, 0, 0, w->mo2_w, 128, w->mo2_b, nullptr, click_scores, 1, R, 2, 128, ACT_MAXOUT2, nullptr, 0, st));
+    }
+    if (want_states) {
+        // ---- suggestion-side outputs (cars.py:382-456): inner attention pools and the decoder initial states
+        NIR_REQUIRE(nch > 0, "cars_rank_session: decoder states need at least one session encoder");
+        const float* st_a = q_on ? p.Qs : p.Ds;
+        const float* st_b = (q_on && d_on) ? p.Ds : nullptr;
+        const float* c_a = q_on ? p.Cq : p.Cd;
+        const float* c_b = (q_on && d_on) ? p.Cd : nullptr;
+        const int HSb = st_b ? HS : 0, W = HS + HSb;
+        const int rows = (S - 1) * B;                                // hidden_states[:-1]: steps 0..S-2 -> states 1..S-1
+        if (extra->inner_q && q_on) {
+            NIR_PROPAGATE(launch_linear_ex(p.Qs + (int64_t)B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sq_inner0_w, HS, w->sq_inner0_b, nullptr, p.lin, HS / 16,
+                                           (int64_t)S * B, HS, HS, ACT_TANH_ROWDOT16, w->sq_inner3_w, 0, st));
+            hipLaunchKernelGGL(session_inner_pool_kernel, dim3((unsigned)BS), dim3(256), 0, st, p.Qs + (int64_t)B * HS, p.lin, HS / 16, w->sq_inner3_b, B, S, HS, extra->inner_q);
+        }
+        if (extra->inner_d && d_on) {
+            NIR_PROPAGATE(launch_linear_ex(p.Ds + (int64_t)B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sd_inner0_w, HS, w->sd_inner0_b, nullptr, p.lin, HS / 16,
+                                           (int64_t)S * B, HS, HS, ACT_TANH_ROWDOT16, w->sd_inner3_w, 0, st));
+            hipLaunchKernelGGL(session_inner_pool_kernel, dim3((unsigned)BS), dim3(256), 0, st, p.Ds + (int64_t)B * HS, p.lin, HS / 16, w->sd_inner3_b, B, S, HS, extra->inner_d);
+        }
+        NIR_CHECK_LAUNCH("session_inner_pool_kernel");
+        if (rows > 0 && extra->dec_h && w->th_w) {
+            hipLaunchKernelGGL(session_cat_states_kernel, g1((int64_t)rows * W), dim3(256), 0, st, st_a + (int64_t)B * HS,
+                               st_b ? st_b + (int64_t)B * HS : nullptr, rows, HS, HSb, p.cat);
+            NIR_PROPAGATE(launch_linear(p.cat, W, nullptr, nullptr, 0, 0, 0, w->th_w, W, w->th_b, nullptr, extra->dec_h, w->HDEC, rows, w->HDEC, W, NIR_ACT_NONE, st));
+        }
+        if (rows > 0 && extra->dec_c && w->tc_w) {
+            hipLaunchKernelGGL(session_cat_states_kernel, g1((int64_t)rows * W), dim3(256), 0, st, c_a + (int64_t)B * HS,
+                               c_b ? c_b + (int64_t)B * HS : nullptr, rows, HS, HSb, p.cat);
+            NIR_PROPAGATE(launch_linear(p.cat, W, nullptr, nullptr, 0, 0, 0, w->tc_w, W, w->tc_b, nullptr, extra->dec_c, w->HDEC, rows, w->HDEC, W, NIR_ACT_NONE, st));
+        }
+        NIR_CHECK_LAUNCH("session_cat_states_kernel");
+    }
+    return 0;
+}

@@ -42,8 +42,16 @@ CarsSessionWeights = _struct(
     "nir_cars_session_weights",
     ["click0_w", "click0_b", "click3_w", "click3_b", "sq_attn_w", "sq_attn_b", "sd_attn_w", "sd_attn_b",
      "sq_wih", "sq_whh", "sq_bih", "sq_bhh", "sd_wih", "sd_whh", "sd_bih", "sd_bhh", "qproj_w", "qproj_b",
-     "shared_w", "priv1_w", "mo0_w", "mo0_b", "mo1_w", "mo1_b", "mo2_w", "mo2_b"],
-    ["D", "HS"])
+     "shared_w", "priv1_w", "mo0_w", "mo0_b", "mo1_w", "mo1_b", "mo2_w", "mo2_b", "wrank", "attn_ut",
+     "sq_inner0_w", "sq_inner0_b", "sq_inner3_w", "sq_inner3_b", "sd_inner0_w", "sd_inner0_b", "sd_inner3_w", "sd_inner3_b",
+     "th_w", "th_b", "tc_w", "tc_b"],
+    ["D", "HS", "HDEC", "q_on", "d_on", "rank_on"])
+class CarsDecoderWeights(C.Structure):
+    _fields_ = [(f, c_fp) for f in ("rnn_wih", "rnn_whh", "rnn_bih", "rnn_bhh", "attn_in_w", "attn_out_w", "dec_attn_w", "pred1_w",
+                                    "pred2_w", "sess_w")] + [(f, C.c_int) for f in ("HD", "DQ", "P", "KS")] + [("VT", C.c_int64)]
+
+
+CarsSessionOutputs = _struct("nir_cars_session_outputs", ["inner_q", "inner_d", "dec_h", "dec_c"])
 
 MnsrfWeights = _struct(
     "nir_mnsrf_weights",
@@ -94,8 +102,14 @@ SIGNATURES = {
     "nir_cars_encode_folded": (_i, [c_ip, c_ip, _l, _i, C.c_void_p, _i, _l, C.POINTER(CarsEncoderWeights), C.c_void_p, _z,
                                     c_fp, c_fp, C.c_void_p, c_st]),
     "nir_cars_session_workspace_bytes": (_z, [_i, _i, _i, C.POINTER(CarsSessionWeights)]),
+    "nir_add_f32": (_i, [c_fp, c_fp, c_fp, _l, c_st]),
+    "nir_cars_decode_workspace_bytes": (_z, [_l, _l, _i, C.POINTER(CarsDecoderWeights)]),
+    "nir_cars_decode_greedy": (_i, [c_fp, c_fp, c_fp, c_ip, _l, _i, c_ip, _l, c_fp, c_fp, _l, _i, c_ip, _l, _i,
+                                    C.POINTER(CarsDecoderWeights), C.c_void_p, _z, c_ip, c_st]),
+    "nir_cars_session_pack_floats": (_z, [C.POINTER(CarsSessionWeights), C.POINTER(_z), C.POINTER(_z)]),
+    "nir_cars_session_pack": (_i, [C.POINTER(CarsSessionWeights), c_fp, c_fp, c_st]),
     "nir_cars_rank_session": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
-                                   c_fp, c_fp, c_st]),
+                                   c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_st]),
 }
 
 DTYPE_F32, DTYPE_BF16 = 0, 1

@@ -1,25 +1,29 @@
-"""CARS -- context attentive ranking and suggestion, RANKING path (drop-in for neuroir.multitask.cars.CARS,
-/root/reference/neuroir/multitask/cars.py:13-540,671-691).
+"""CARS -- context attentive ranking and suggestion (drop-in for neuroir.multitask.cars.CARS,
+/root/reference/neuroir/multitask/cars.py:13-791).
 
-Scope: encode, encode_document, encode_clicks, encode_session/rank, rank_document and the
-ranking loss run on hand-written HIP kernels.  The query-suggestion decoder (cars.py:605-657,706-791) is out
-of scope: its parameters are kept (same state-dict keys, so reference checkpoints load strictly) but
-`decode`/the suggestion loss raise NotImplementedError.
+Everything CARS computes at inference time runs on hand-written HIP kernels through the C-ABI:
 
-HIP mapping
-  encode / encode_document : nir_cars_encode  = gather fused into the gate GEMM (fp32 MFMA) -> BiLSTM recurrence
-                             -> attention MLP GEMM+tanh -> masked softmax + weighted sum (one wave per sequence)
-  encode_clicks + session  : nir_cars_rank_session = click attention with the reference's batch-dependent mask
-                             quirk (Appendix E2), then the sequential session loop (cross attention over previous
-                             states incl. the zero state, ranknet maxout, two LSTM steps) with no host sync.
+  encode / encode_document : eval mode: nir_cars_encode_folded -- embedding table folded into the LSTM input projection
+                             once per weight version (csrc/lstm_fold.hip), recurrence gathers gate rows by token id, attention
+                             MLP with tanh + Linear(D,1) in the GEMM epilogue, masked softmax + weighted sum.
+                             (fold_embeddings=False: nir_cars_encode, gather fused into the per-batch gate GEMM.)
+  encode_clicks + session  : nir_cars_rank_session (csrc/cars_session.hip) -- click attention with the reference's
+                             batch-dependent mask quirk (Appendix E2), both session LSTM chains, cross attention over the
+                             previous states incl. the zero state, maxout ranknet; honours query_session_off /
+                             doc_session_off / turn_ranker_off (cars.py:185-188, 329-410, 485-533); on request also the
+                             decoder-initialisation states and inner-attention pools (cars.py:382-456).
+  decode                   : nir_cars_decode_greedy (csrc/cars_decode.hip) -- greedy suggestion, LSTM step + Luong general
+                             attention + the 256 -> V_tgt projection, no host round trip per step.
+  forward                  : the ranking loss (BCE-with-logits, cars.py:603); the suggestion loss / training mode is the
+                             training-step row.
 """
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import lib
+from ..constants import BOS
 from ..encoders.rnn_encoder import lstm_cat_weights
 from ..modules import Maxout
 from .layers import Embedder, Encoder
@@ -33,9 +37,9 @@ def _projector(i, o, p, bias):
     return nn.Sequential(OrderedDict([("dropout", nn.Dropout(p=p)), ("linear", nn.Linear(i, o, bias=bias))]))
 
 
-class _SuggestionDecoderParams(nn.Module):
-    """Parameter container for `decoder.decoder.*` (RNNDecoder: LSTM + general attention), kept only so that
-    reference checkpoints load; evaluated by nobody on the ranking path."""
+class _RNNDecoderParams(nn.Module):
+    """Parameters of `decoder.decoder.*` (RNNDecoder: nn.LSTM + GlobalAttention('general'), decoders/decoder.py:69-117) under
+    the reference's state-dict keys; evaluated by nir_cars_decode_greedy, never by torch."""
 
     def __init__(self, emsize, nhid):
         super().__init__()
@@ -51,48 +55,65 @@ class CARS(nn.Module):
         if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1 or args.pool_type != "attn":
             raise NotImplementedError("HIP CARS supports the reference configuration (hyparam.py:197-225): "
                                       "LSTM, bidirectional, 1 layer, pool_type='attn'")
-        if args.query_session_off or args.doc_session_off or args.turn_ranker_off:
-            raise NotImplementedError("HIP CARS needs both session encoders and the ranker on")
+        if getattr(args, "attn_type", "general") != "general":
+            raise NotImplementedError("HIP CARS decoder supports attn_type='general' (hyparam.py:206)")
         p = args.dropout
+        self.no_ranker = bool(args.turn_ranker_off)
+        self.no_recommender = bool(args.turn_recommender_off)
+        self.no_query_session_encoding = bool(args.query_session_off)
+        self.no_document_session_encoding = bool(args.doc_session_off)
+        q_on, d_on = not self.no_query_session_encoding, not self.no_document_session_encoding
+        need_docs = not (self.no_ranker and self.no_document_session_encoding)
+        if (q_on and d_on and args.nhid_session_query != args.nhid_session_document) or args.nhid_query != args.nhid_document:
+            raise NotImplementedError("HIP CARS expects nhid_query == nhid_document and equal session sizes")
         self.embedder = Embedder(args.emsize, args.src_vocab_size, args.dropout_emb)
         self.query_encoder = Encoder(args.rnn_type, args.emsize, True, 1, args.nhid_query, args.dropout_rnn)
-        self.document_encoder = Encoder(args.rnn_type, args.emsize, True, 1, args.nhid_document, args.dropout_rnn)
         self.q_attn = _attn_mlp(args.nhid_query, p)
-        self.d_attn = _attn_mlp(args.nhid_document, p)
-        self.nhid_session_query = args.nhid_session_query
-        self.session_query_encoder = Encoder(args.rnn_type, args.nhid_query, False, 1, args.nhid_session_query, args.dropout_rnn)
-        self.session_query_attn = nn.Linear(args.nhid_session_query, args.nhid_query)
-        self.session_query_inner_attn = _attn_mlp(args.nhid_session_query, p)
-        self.click_attn = _attn_mlp(args.nhid_document, p)
-        self.nhid_session_document = args.nhid_session_document
-        self.session_doc_encoder = Encoder(args.rnn_type, args.nhid_document, False, 1, args.nhid_session_document, args.dropout_rnn)
-        self.session_doc_attn = nn.Linear(args.nhid_session_document, args.nhid_document)
-        self.session_doc_inner_attn = _attn_mlp(args.nhid_session_document, p)
-        sess = args.nhid_session_query + args.nhid_session_document
-        self.shared_session_projector = _projector(sess, args.nhid_document, p, False)
-        self.q_projection = _projector(args.nhid_query, args.nhid_document, p, True)
-        self.private_session_projector1 = _projector(sess, args.nhid_document, p, False)
-        self.ranknet = Maxout(args.nhid_document * 4, 3, [256, 128, 1], [2, 2, 2])
-        self.no_recommender = args.turn_recommender_off
-        if not self.no_recommender:  # suggestion-only parameters: containers for checkpoint compatibility
+        if need_docs:                                       # cars.py:29-58
+            self.document_encoder = Encoder(args.rnn_type, args.emsize, True, 1, args.nhid_document, args.dropout_rnn)
+            self.d_attn = _attn_mlp(args.nhid_document, p)
+        sess = 0
+        if q_on:                                            # cars.py:60-79
+            self.nhid_session_query = args.nhid_session_query
+            self.session_query_encoder = Encoder(args.rnn_type, args.nhid_query, False, 1, args.nhid_session_query, args.dropout_rnn)
+            self.session_query_attn = nn.Linear(args.nhid_session_query, args.nhid_query)
+            self.session_query_inner_attn = _attn_mlp(args.nhid_session_query, p)
+            sess += args.nhid_session_query
+        if d_on:                                            # cars.py:82-107
+            self.click_attn = _attn_mlp(args.nhid_document, p)
+            self.nhid_session_document = args.nhid_session_document
+            self.session_doc_encoder = Encoder(args.rnn_type, args.nhid_document, False, 1, args.nhid_session_document, args.dropout_rnn)
+            self.session_doc_attn = nn.Linear(args.nhid_session_document, args.nhid_document)
+            self.session_doc_inner_attn = _attn_mlp(args.nhid_session_document, p)
+            sess += args.nhid_session_document
+        self.session_rep_size = sess
+        if sess > 0:
+            self.shared_session_projector = _projector(sess, args.nhid_document, p, False)
+        if not self.no_ranker:                              # cars.py:116-132
+            self.q_projection = _projector(args.nhid_query, args.nhid_document, p, True)
+            if sess > 0:
+                self.private_session_projector1 = _projector(sess, args.nhid_document, p, False)
+            self.ranknet = Maxout(args.nhid_document * 4, 3, [256, 128, 1], [2, 2, 2])
+        if not self.no_recommender:                         # cars.py:134-178
+            if sess == 0:
+                raise ValueError("Both session-level RNNs cannot be off!")
             self.private_session_projector2 = _projector(sess, args.nhid_document, p, False)
             self.transform_hid = _projector(sess, args.nhid_decoder, p, True)
             self.transform_cell = _projector(sess, args.nhid_decoder, p, True)
             self.decoder = nn.Module()
-            self.decoder.decoder = _SuggestionDecoderParams(args.emsize, args.nhid_decoder)
+            self.decoder.decoder = _RNNDecoderParams(args.emsize, args.nhid_decoder)
             self.dec_attn = nn.Linear(args.nhid_query, args.nhid_decoder, bias=False)
-            self.token_prob_predictor1 = nn.Linear(args.nhid_decoder, args.nhid_document, bias=False)
-            self.token_prob_predictor2 = nn.Linear(args.nhid_document, args.tgt_vocab_size, bias=False)
+            pred_in = args.nhid_document if need_docs else args.emsize
+            self.token_prob_predictor1 = nn.Linear(args.nhid_decoder, pred_in, bias=False)
+            self.token_prob_predictor2 = nn.Linear(pred_in, args.tgt_vocab_size, bias=False)
         self.dropout = nn.Dropout(args.dropout)
         self.regularize_coeff = args.regularize_coeff
-        self.no_ranker = False
-        self.no_query_session_encoding = self.no_document_session_encoding = False
         self.pool_type = args.pool_type
         self.lambda1, self.lambda2 = args.lambda1, args.lambda2
-        if args.nhid_query != args.nhid_document or args.nhid_session_query != args.nhid_session_document:
-            raise NotImplementedError("HIP CARS expects nhid_query == nhid_document and equal session sizes")
-        self._dims = dict(D=args.nhid_document, HS=args.nhid_session_query)
-        self._pq, self._pd, self._ps = lib.PackCache(), lib.PackCache(), lib.PackCache()
+        hs = args.nhid_session_query if q_on else args.nhid_session_document
+        self._dims = dict(D=args.nhid_document, HS=hs, HDEC=args.nhid_decoder, q_on=int(q_on), d_on=int(d_on),
+                          rank_on=int(not self.no_ranker))
+        self._pq, self._pd, self._ps, self._pdec = lib.PackCache(), lib.PackCache(), lib.PackCache(), lib.PackCache()
         # Inference-time folding of the embedding table into the LSTM input projection (csrc/lstm_fold.hip): on in eval
         # mode while the two folded tables (V x 8H each) stay under `fold_budget_bytes`; `compute_dtype` "bf16" selects the
         # bf16 folded table + bf16 MFMA recurrence (BASELINE config 5), "f32" is the parity path.
@@ -115,26 +136,73 @@ class CARS(nn.Module):
                                    attn3_w=attn[3].weight, attn3_b=attn[3].bias), dict(H=enc.hidden))
         return cache.get(list(enc.parameters()) + list(attn.parameters()), build)
 
+    def _session_modules(self):
+        names = ["click_attn", "session_query_attn", "session_doc_attn", "session_query_encoder", "session_doc_encoder",
+                 "q_projection", "shared_session_projector", "private_session_projector1", "ranknet",
+                 "session_query_inner_attn", "session_doc_inner_attn", "transform_hid", "transform_cell"]
+        return [getattr(self, n) for n in names if hasattr(self, n)]
+
     def _session_weights(self):
         def build():
-            sq, sd = self.session_query_encoder.encoder.rnns[0], self.session_doc_encoder.encoder.rnns[0]
-            mo = self.ranknet._linear_layers
-            t = dict(click0_w=self.click_attn[0].weight, click0_b=self.click_attn[0].bias,
-                     click3_w=self.click_attn[3].weight, click3_b=self.click_attn[3].bias,
-                     sq_attn_w=self.session_query_attn.weight, sq_attn_b=self.session_query_attn.bias,
-                     sd_attn_w=self.session_doc_attn.weight, sd_attn_b=self.session_doc_attn.bias,
-                     sq_wih=sq.weight_ih_l0, sq_whh=sq.weight_hh_l0, sq_bih=sq.bias_ih_l0, sq_bhh=sq.bias_hh_l0,
-                     sd_wih=sd.weight_ih_l0, sd_whh=sd.weight_hh_l0, sd_bih=sd.bias_ih_l0, sd_bhh=sd.bias_hh_l0,
-                     qproj_w=self.q_projection.linear.weight, qproj_b=self.q_projection.linear.bias,
-                     shared_w=self.shared_session_projector.linear.weight,
-                     priv1_w=self.private_session_projector1.linear.weight,
-                     mo0_w=mo[0].weight, mo0_b=mo[0].bias, mo1_w=mo[1].weight, mo1_b=mo[1].bias,
-                     mo2_w=mo[2].weight, mo2_b=mo[2].bias)
-            return lib.Packed(lib.CarsSessionWeights, t, self._dims)
-        mods = [self.click_attn, self.session_query_attn, self.session_doc_attn, self.session_query_encoder,
-                self.session_doc_encoder, self.q_projection, self.shared_session_projector,
-                self.private_session_projector1, self.ranknet]
-        return self._ps.get([p for m in mods for p in m.parameters()], build)
+            t = {}
+            if hasattr(self, "click_attn"):
+                sd = self.session_doc_encoder.encoder.rnns[0]
+                t.update(click0_w=self.click_attn[0].weight, click0_b=self.click_attn[0].bias,
+                         click3_w=self.click_attn[3].weight, click3_b=self.click_attn[3].bias,
+                         sd_attn_w=self.session_doc_attn.weight, sd_attn_b=self.session_doc_attn.bias,
+                         sd_wih=sd.weight_ih_l0, sd_whh=sd.weight_hh_l0, sd_bih=sd.bias_ih_l0, sd_bhh=sd.bias_hh_l0,
+                         sd_inner0_w=self.session_doc_inner_attn[0].weight, sd_inner0_b=self.session_doc_inner_attn[0].bias,
+                         sd_inner3_w=self.session_doc_inner_attn[3].weight, sd_inner3_b=self.session_doc_inner_attn[3].bias)
+            if hasattr(self, "session_query_encoder"):
+                sq = self.session_query_encoder.encoder.rnns[0]
+                t.update(sq_attn_w=self.session_query_attn.weight, sq_attn_b=self.session_query_attn.bias,
+                         sq_wih=sq.weight_ih_l0, sq_whh=sq.weight_hh_l0, sq_bih=sq.bias_ih_l0, sq_bhh=sq.bias_hh_l0,
+                         sq_inner0_w=self.session_query_inner_attn[0].weight, sq_inner0_b=self.session_query_inner_attn[0].bias,
+                         sq_inner3_w=self.session_query_inner_attn[3].weight, sq_inner3_b=self.session_query_inner_attn[3].bias)
+            if not self.no_ranker:
+                mo = self.ranknet._linear_layers
+                t.update(qproj_w=self.q_projection.linear.weight, qproj_b=self.q_projection.linear.bias,
+                         mo0_w=mo[0].weight, mo0_b=mo[0].bias, mo1_w=mo[1].weight, mo1_b=mo[1].bias,
+                         mo2_w=mo[2].weight, mo2_b=mo[2].bias)
+                if self.session_rep_size:
+                    t.update(shared_w=self.shared_session_projector.linear.weight,
+                             priv1_w=self.private_session_projector1.linear.weight)
+            if not self.no_recommender:
+                t.update(th_w=self.transform_hid.linear.weight, th_b=self.transform_hid.linear.bias,
+                         tc_w=self.transform_cell.linear.weight, tc_b=self.transform_cell.linear.bias)
+            pk = lib.Packed(lib.CarsSessionWeights, t, self._dims)
+            if not self.no_ranker:      # [W_q | W_shared + W_priv1] and the query-side attention projection, once per version
+                L = lib.load()
+                na, nb = lib.C.c_size_t(0), lib.C.c_size_t(0)
+                L.nir_cars_session_pack_floats(pk.ref(), lib.C.byref(na), lib.C.byref(nb))
+                dev = self.q_projection.linear.weight.device
+                pk.keep["wrank"] = torch.empty(max(na.value, 1), device=dev)
+                pk.keep["attn_ut"] = torch.empty(max(nb.value, 1), device=dev)
+                lib.check(L.nir_cars_session_pack(pk.ref(), lib.ptr(pk.keep["wrank"]), lib.ptr(pk.keep["attn_ut"]), lib.stream()),
+                          "nir_cars_session_pack")
+                pk.struct.wrank = pk.keep["wrank"].data_ptr()
+                pk.struct.attn_ut = pk.keep["attn_ut"].data_ptr()
+            return pk
+        return self._ps.get([p for m in self._session_modules() for p in m.parameters()], build)
+
+    def _decoder_weights(self):
+        def build():
+            rnn, att = self.decoder.decoder.rnn, self.decoder.decoder.attn
+            t = dict(rnn_wih=rnn.weight_ih_l0, rnn_whh=rnn.weight_hh_l0, rnn_bih=rnn.bias_ih_l0, rnn_bhh=rnn.bias_hh_l0,
+                     attn_in_w=att.linear_in.weight, attn_out_w=att.linear_out.weight, dec_attn_w=self.dec_attn.weight,
+                     pred1_w=self.token_prob_predictor1.weight, pred2_w=self.token_prob_predictor2.weight)
+            ints = dict(HD=rnn.hidden_size, DQ=self.dec_attn.weight.shape[1], P=self.token_prob_predictor1.weight.shape[0],
+                        KS=self.session_rep_size, VT=self.token_prob_predictor2.weight.shape[0])
+            pk = lib.Packed(lib.CarsDecoderWeights, t, ints)
+            a = self.shared_session_projector.linear.weight.detach().float().contiguous()
+            b = self.private_session_projector2.linear.weight.detach().float().contiguous()
+            pk.keep["sess_w"] = torch.empty_like(a)
+            lib.check(lib.load().nir_add_f32(lib.ptr(a), lib.ptr(b), lib.ptr(pk.keep["sess_w"]), a.numel(), lib.stream()), "nir_add_f32")
+            pk.struct.sess_w = pk.keep["sess_w"].data_ptr()
+            return pk
+        mods = [self.decoder, self.dec_attn, self.token_prob_predictor1, self.token_prob_predictor2,
+                self.shared_session_projector, self.private_session_projector2]
+        return self._pdec.get([p for m in mods for p in m.parameters()], build)
 
     def _check_eval(self):
         if self.training:
@@ -173,20 +241,18 @@ class CARS(nn.Module):
         w = self._enc_weights(which)
         H2 = 2 * w.struct.H
         dev = ids.device
+        pooled = torch.empty(M, H2, device=dev, dtype=torch.float32)
+        encoded = torch.empty(M, T, H2, device=dev, dtype=torch.float32) if want_encoded else None
         if self._use_fold(table, w.struct.H):
             folded = self._folded_table(which, w)
             if self._err_flag is None or self._err_flag.device != dev:
                 self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
             ws = lib.workspace(L.nir_cars_encode_folded_workspace_bytes(M, T, w.ref()), dev)
-            pooled = torch.empty(M, H2, device=dev, dtype=torch.float32)
-            encoded = torch.empty(M, T, H2, device=dev, dtype=torch.float32) if want_encoded else None
             lib.check(L.nir_cars_encode_folded(lib.ptr(ids), lib.ptr(lens), M, T, lib.ptr(folded), lib.DTYPES[self.compute_dtype],
                                                table.shape[0], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(pooled),
                                                lib.ptr(encoded), lib.ptr(self._err_flag), lib.stream()), "nir_cars_encode_folded")
             return pooled, encoded
         ws = lib.workspace(L.nir_cars_encode_workspace_bytes(M, T, table.shape[1], w.ref()), dev)
-        pooled = torch.empty(M, H2, device=dev, dtype=torch.float32)
-        encoded = torch.empty(M, T, H2, device=dev, dtype=torch.float32) if want_encoded else None
         lib.check(L.nir_cars_encode(lib.ptr(ids), lib.ptr(lens), M, T, lib.ptr(table), table.shape[0], table.shape[1],
                                     w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(pooled), lib.ptr(encoded), lib.stream()),
                   "nir_cars_encode")
@@ -194,7 +260,8 @@ class CARS(nn.Module):
 
     # ---- reference API ----------------------------------------------------------------------------
     def encode(self, queries, query_length):
-        """cars.py:193-225 -> (pooled [B,S,2H], encoded [B*S,QL,2H], hidden=None)."""
+        """cars.py:193-225 -> (pooled [B,S,2H], encoded [B*S,QL,2H], hidden=None).
+        (`hidden`, the final BiLSTM state in length-sorted order, has no consumer in the reference.)"""
         self._check_eval()
         B, S, QL = queries.shape
         pooled, enc = self._encode_seqs("q", queries.reshape(B * S, QL), query_length.reshape(-1), True)
@@ -207,54 +274,127 @@ class CARS(nn.Module):
         pooled, _ = self._encode_seqs("d", docs.reshape(B * S * N, DL), docs_length.reshape(-1), False)
         return pooled.view(B, S, N, -1)
 
-    def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False):
+    def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False):
         lib.require_device(pooled_q, pooled_docs, labels)
         L = lib.load()
-        B, S, N, D = pooled_docs.shape
+        B, S, D = pooled_q.shape
+        N = pooled_docs.shape[2] if pooled_docs is not None else 1
         w = self._session_weights()
-        dev = pooled_docs.device
+        dev = pooled_q.device
         ws = lib.workspace(L.nir_cars_session_workspace_bytes(B, S, N, w.ref()), dev)
-        pq, pdv, lab = pooled_q.float().contiguous(), pooled_docs.float().contiguous(), labels.float().contiguous()
-        scores = torch.empty(B, S, N, device=dev, dtype=torch.float32)
+        pq = pooled_q.float().contiguous()
+        pdv = pooled_docs.float().contiguous() if pooled_docs is not None else None
+        lab = labels.float().contiguous() if labels is not None else None
+        HS, HDEC = self._dims["HS"], self._dims["HDEC"]
+        scores = torch.empty(B, S, N, device=dev, dtype=torch.float32) if not self.no_ranker else None
         clicks = torch.empty(B, S, D, device=dev, dtype=torch.float32) if want_clicks else None
-        lib.check(L.nir_cars_rank_session(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws),
-                                          ws.numel(), lib.ptr(scores), lib.ptr(clicks), lib.stream()),
-                  "nir_cars_rank_session")
-        return scores, clicks
+        extra, outs = None, {}
+        if want_states:
+            extra = lib.CarsSessionOutputs()
+            if not self.no_query_session_encoding:
+                outs["inner_q"] = torch.empty(B, S, HS, device=dev)
+            if not self.no_document_session_encoding:
+                outs["inner_d"] = torch.empty(B, S, HS, device=dev)
+            outs["dec_h"] = torch.empty(1, (S - 1) * B, HDEC, device=dev)
+            outs["dec_c"] = torch.empty(1, (S - 1) * B, HDEC, device=dev)
+            for k, v in outs.items():
+                setattr(extra, k, v.data_ptr())
+        lib.check(L.nir_cars_rank_session(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
+                                          lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
+                                          lib.stream()), "nir_cars_rank_session")
+        return scores, clicks, outs
 
     def encode_clicks(self, docs, doc_labels):
         """cars.py:262-304 -> [B,S,2H] (computed by the same kernel family as rank_document)."""
         self._check_eval()
+        if self.no_document_session_encoding:
+            raise RuntimeError("encode_clicks needs the document session encoder (doc_session_off=False)")
         B, S, N, D = docs.shape
         dummy_q = torch.zeros(B, S, D, device=docs.device)
         return self._rank_session(dummy_q, docs, doc_labels, want_clicks=True)[1]
 
-    def rank_document(self, pooled_rep, document_rep, document_len, document_label, group=None, shard=False):
-        """cars.py:522-540 -> (click_scores [B,S,N], hidden_states=None, session_attns=(None, None)).
-        The decoder-initialisation states are suggestion-only and not produced.
+    def rank_document(self, pooled_rep, document_rep, document_len, document_label, group=None, shard=False, want_states=None):
+        """cars.py:522-540 -> (click_scores [B,S,N] (or [] when the ranker is off), hidden_states, session_attns).
+        hidden_states = (transform_hid(h), transform_cell(c)) [1,(S-1)*B,nhid_decoder] and session_attns = (inner_q, inner_d)
+        [B,S,HS] are the decoder inputs (cars.py:382-456); they are produced when `want_states` (default: whenever the
+        recommender is on, like the reference), otherwise returned as None / (None, None).
         shard=True: candidate-sharded document encoding over the torch.distributed `group` + one all-gather of the
         pooled document vectors (sharding.sharded_pooled_docs); the session part runs replicated."""
         self._check_eval()
-        if shard:
-            from .. import sharding
-            encoded_docs = sharding.sharded_pooled_docs(self.encode_document, document_rep, document_len, group)
-        else:
-            encoded_docs = self.encode_document(document_rep, document_len)
-        scores, _ = self._rank_session(pooled_rep, encoded_docs, document_label)
-        return scores, None, (None, None)
+        if want_states is None:
+            want_states = not self.no_recommender
+        encoded_docs = None
+        if not (self.no_ranker and self.no_document_session_encoding):
+            if shard:
+                from .. import sharding
+                encoded_docs = sharding.sharded_pooled_docs(self.encode_document, document_rep, document_len, group)
+            else:
+                encoded_docs = self.encode_document(document_rep, document_len)
+        scores, _, outs = self._rank_session(pooled_rep, encoded_docs, document_label, want_states=want_states)
+        states = (outs["dec_h"], outs["dec_c"]) if want_states else None
+        attns = (outs.get("inner_q"), outs.get("inner_d")) if want_states else (None, None)
+        return (scores if scores is not None else []), states, attns
 
     def forward(self, source_rep, source_len, target_rep, target_len, target_seq, document_rep, document_len,
                 document_label):
         """cars.py:542-669, ranking branch: {'ranking_loss': BCE-with-logits over [B,S,N], 'suggestion_loss': None}."""
         pooled, _, _ = self.encode(source_rep, source_len)
-        scores, _, _ = self.rank_document(pooled, document_rep, document_len, document_label)
-        lab = document_label.float().contiguous()
-        loss = torch.empty(1, device=scores.device, dtype=torch.float32)
-        rows = scores.shape[0] * scores.shape[1]
-        lib.check(lib.load().nir_rank_loss_bce(lib.ptr(scores), lib.ptr(lab), rows, scores.shape[2], lib.ptr(loss),
-                                               lib.stream()), "nir_rank_loss_bce")
-        return {"ranking_loss": loss[0], "suggestion_loss": None, "click_scores": scores}
+        scores, _, _ = self.rank_document(pooled, document_rep, document_len, document_label, want_states=False)
+        out = {"ranking_loss": None, "suggestion_loss": None, "click_scores": scores if not self.no_ranker else None}
+        if not self.no_ranker:
+            lab = document_label.float().contiguous()
+            loss = torch.empty(1, device=scores.device, dtype=torch.float32)
+            rows = scores.shape[0] * scores.shape[1]
+            lib.check(lib.load().nir_rank_loss_bce(lib.ptr(scores), lib.ptr(lab), rows, scores.shape[2], lib.ptr(loss),
+                                                   lib.stream()), "nir_rank_loss_bce")
+            out["ranking_loss"] = loss[0]
+        return out
 
-    def decode(self, **kwargs):
-        raise NotImplementedError("CARS.decode (query suggestion, cars.py:706-791) is outside the accelerated "
-                                  "ranking hot path (SURVEY.md section 8f, rank 4)")
+    def decode(self, states, max_len, src_dict, tgt_dict, batch_size, session_len, use_cuda, encoded_source, source_len,
+               session_attns, tgt2src=None):
+        """cars.py:706-791 (greedy): -> {'predictions': LongTensor [batch_size, session_len, max_len]} in target-vocabulary ids.
+        `session_len` is the number of decoded queries per session (the caller passes S-1, models/multitask.py:286).
+        The reference maps each predicted token back to a source-vocabulary id on the host (tgt_dict[idx] -> word ->
+        src_dict[word]); here that mapping is ONE device lookup table `tgt2src` [V_tgt] (built from the two dictionaries on
+        first use and cached; identity when no dictionaries are given)."""
+        self._check_eval()
+        if self.no_recommender:
+            raise RuntimeError("decode needs the recommender (turn_recommender_off=False)")
+        assert all(s is not None for s in states)
+        L = lib.load()
+        dec_h, dec_c = (s.reshape(-1, s.shape[-1]).float().contiguous() for s in states)
+        B, SD = int(batch_size), int(session_len)
+        Bd = B * SD
+        if dec_h.shape[0] != Bd:
+            raise RuntimeError("decode: %d initial states for %d x %d decode rows" % (dec_h.shape[0], B, SD))
+        dev = dec_h.device
+        enc = encoded_source.float().contiguous()
+        rows_src, QL = enc.shape[0], enc.shape[1]
+        lens = lib.ids64(source_len.reshape(-1))
+        if rows_src != B * (SD + 1) or lens.numel() != rows_src:
+            raise RuntimeError("decode: encoded_source must hold batch_size*(session_len+1) query rows")
+        i = torch.arange(Bd, device=dev)
+        rowmap = ((i // SD) * (SD + 1) + i % SD).contiguous()                       # the reference's [:, :-1] selection
+        cat = [a for a in session_attns if a is not None]
+        session_cat = torch.cat(cat, 2).reshape(rows_src, -1).float().contiguous() if cat else None
+        if tgt2src is None:
+            tgt2src = self._tgt2src(src_dict, tgt_dict, dev)
+        w = self._decoder_weights()
+        table = self.embedder.word_embeddings.table
+        ws = lib.workspace(L.nir_cars_decode_workspace_bytes(rows_src, Bd, QL, w.ref()), dev)
+        preds = torch.empty(Bd, int(max_len), dtype=torch.int64, device=dev)
+        lib.check(L.nir_cars_decode_greedy(lib.ptr(dec_h), lib.ptr(dec_c), lib.ptr(enc), lib.ptr(lens), rows_src, QL, lib.ptr(rowmap), Bd,
+                                           lib.ptr(session_cat), lib.ptr(table), table.shape[0], table.shape[1], lib.ptr(tgt2src), BOS,
+                                           int(max_len), w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(preds), lib.stream()),
+                  "nir_cars_decode_greedy")
+        return {"predictions": preds.view(B, SD, int(max_len))}
+
+    def _tgt2src(self, src_dict, tgt_dict, dev):
+        if src_dict is None or tgt_dict is None:
+            return None
+        key = (id(src_dict), id(tgt_dict), len(src_dict), len(tgt_dict), str(dev))
+        if getattr(self, "_lut_key", None) != key:
+            n = self.token_prob_predictor2.weight.shape[0]
+            lut = [int(src_dict[tgt_dict[i]]) if i < len(tgt_dict) else 0 for i in range(n)]
+            self._lut, self._lut_key = torch.tensor(lut, dtype=torch.int64, device=dev), key
+        return self._lut

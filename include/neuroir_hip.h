@@ -231,17 +231,65 @@ typedef struct {
     const float *sq_wih, *sq_whh, *sq_bih, *sq_bhh;         /* session_query_encoder.encoder.rnns.0 [4HS,D],[4HS,HS],.. */
     const float *sd_wih, *sd_whh, *sd_bih, *sd_bhh;         /* session_doc_encoder.encoder.rnns.0 */
     const float *qproj_w, *qproj_b;                         /* q_projection.linear [D,D],[D] */
-    const float *shared_w, *priv1_w;                        /* shared_session_projector / private_session_projector1 [D,2HS] */
+    const float *shared_w, *priv1_w;                        /* shared_session_projector / private_session_projector1 [D, nch*HS] */
     const float *mo0_w, *mo0_b, *mo1_w, *mo1_b, *mo2_w, *mo2_b; /* ranknet._linear_layers.{0,1,2} [512,4D],[256,256],[2,128] */
-    int D, HS;                                              /* 256, 512 */
+    /* packed once per weight version by nir_cars_session_pack (sizes: nir_cars_session_pack_floats): */
+    const float *wrank;                                     /* [D, D + nch*HS] = [W_q | W_shared + W_priv1] */
+    const float *attn_ut;                                   /* [nch*HS + nch, D] = [W_sq^T ; W_sd^T ; b_sq ; b_sd] */
+    /* suggestion side (only read when `extra` outputs are requested; may be NULL otherwise): */
+    const float *sq_inner0_w, *sq_inner0_b, *sq_inner3_w, *sq_inner3_b; /* session_query_inner_attn.{0,3} [HS,HS],[HS],[1,HS],[1] */
+    const float *sd_inner0_w, *sd_inner0_b, *sd_inner3_w, *sd_inner3_b; /* session_doc_inner_attn.{0,3} */
+    const float *th_w, *th_b, *tc_w, *tc_b;                 /* transform_hid / transform_cell .linear [HDEC, nch*HS],[HDEC] */
+    int D, HS, HDEC;                                        /* 256, 512, 512 */
+    int q_on, d_on, rank_on;                                /* !query_session_off, !doc_session_off, !turn_ranker_off (cars.py:185-188) */
 } nir_cars_session_weights;
+/* Optional suggestion-side outputs of the session loop (cars.py:382-456); any pointer may be NULL. */
+typedef struct {
+    float* inner_q;   /* [B,S,HS] inner self-attention pool over the query-session states 1..t+1 (session_attns[0]) */
+    float* inner_d;   /* [B,S,HS] the same for the document session (session_attns[1]) */
+    float* dec_h;     /* [(S-1)*B, HDEC] transform_hid(cat(h_q, h_d)) of steps 0..S-2, rows in (step, session) order -- the
+                         order torch.cat(hidden_states[:-1], dim=1) produces in the reference */
+    float* dec_c;     /* [(S-1)*B, HDEC] transform_cell(...) */
+} nir_cars_session_outputs;
+size_t nir_cars_session_pack_floats(const nir_cars_session_weights* w /*host*/, size_t* wrank_floats /*host*/, size_t* ut_floats /*host*/);
+int nir_cars_session_pack(const nir_cars_session_weights* w /*host*/, float* wrank, float* attn_ut, nir_stream_t stream);
 size_t nir_cars_session_workspace_bytes(int B, int S, int N, const nir_cars_session_weights* w /*host*/);
-/* encode_clicks + encode_session ranking outputs (cars.py:262-520):
- * pooled_q [B,S,D], pooled_docs [B,S,N,D], labels [B,S,N] -> click_scores [B,S,N];
- * clicks_out (optional) [B,S,D] = encode_clicks result. */
+/* encode_clicks + encode_session + rank (cars.py:262-520):
+ * pooled_q [B,S,D], pooled_docs [B,S,N,D], labels [B,S,N] -> click_scores [B,S,N] (when rank_on);
+ * clicks_out (optional) [B,S,D] = encode_clicks result; extra (optional, host struct) = suggestion-side outputs.
+ * Honours query_session_off / doc_session_off / turn_ranker_off through q_on / d_on / rank_on. */
 int nir_cars_rank_session(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
                           const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
-                          float* click_scores, float* clicks_out, nir_stream_t stream);
+                          float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra /*host*/,
+                          nir_stream_t stream);
+
+/* --- CARS.decode: greedy query suggestion (cars.py:706-791; decoders/rnn_decoder.py:19-88; global_attention.py:98-196) ---- */
+typedef struct {
+    const float *rnn_wih, *rnn_whh, *rnn_bih, *rnn_bhh; /* decoder.decoder.rnn.{weight_ih,weight_hh,bias_ih,bias_hh}_l0 [4HD,E],[4HD,HD],[4HD] */
+    const float *attn_in_w;                             /* decoder.decoder.attn.linear_in.weight  [HD,HD]  (attn_type 'general') */
+    const float *attn_out_w;                            /* decoder.decoder.attn.linear_out.weight [HD,2HD] */
+    const float *dec_attn_w;                            /* dec_attn.weight [HD,DQ] */
+    const float *pred1_w;                               /* token_prob_predictor1.weight [P,HD] */
+    const float *pred2_w;                               /* token_prob_predictor2.weight [VT,P] */
+    const float *sess_w;                                /* shared_session_projector + private_session_projector2, summed once
+                                                           (nir_add_f32) [P,KS]; NULL when KS == 0 */
+    int HD, DQ, P, KS;                                  /* 512, 256, 256, nch*HS */
+    int64_t VT;                                         /* tgt_vocab_size */
+} nir_cars_decoder_weights;
+/* out = a + b (weight packing helper). */
+int nir_add_f32(const float* a, const float* b, float* out, int64_t n, nir_stream_t stream);
+size_t nir_cars_decode_workspace_bytes(int64_t rows_src, int64_t Bd, int QL, const nir_cars_decoder_weights* w /*host*/);
+/* dec_h / dec_c [Bd,HD]: decoder initial states (nir_cars_session_outputs); encoded_source [rows_src,QL,DQ] and source_len
+ * [rows_src]: every (session, query) row of CARS.encode; rowmap [Bd]: source row of each decode row (the reference's
+ * [:, :-1] selection, b*(S)+idx for decode row b*(S-1)+idx); session_cat [rows_src,KS] = [inner_q ; inner_d] (NULL if KS == 0);
+ * table [V,E]: source embedding table; tgt2src [VT] (or NULL = identity): source-vocabulary id of every target-vocabulary
+ * token (the reference maps through two Python dicts on the host each step, cars.py:783-787); bos: first input token.
+ * predictions [Bd,max_len] int64 = argmax token (target vocabulary) per step. */
+int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, const float* encoded_source, const int64_t* source_len,
+                           int64_t rows_src, int QL, const int64_t* rowmap, int64_t Bd, const float* session_cat,
+                           const float* table, int64_t V, int E, const int64_t* tgt2src, int64_t bos, int max_len,
+                           const nir_cars_decoder_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                           int64_t* predictions, nir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Streaming recurrence for any hidden size (one GEMM h W_hh^T + one cell kernel per time step and direction; W_hh is

@@ -333,15 +333,44 @@ def _lstm_step(sd, p, x, state):
     return torch.sigmoid(o) * torch.tanh(c), c
 
 
+def _cars_rank_sw(sd, qv, sess_parts, docs):
+    """cars.py:460-520 with the session switches: session_rep = cat of the encoders that are on (:485-500)."""
+    B, N, H = docs.shape
+    qp = _lin(sd, "q_projection.linear", qv)
+    if sess_parts:
+        sess = torch.cat(sess_parts, 1)
+        qp = qp + _lin(sd, "shared_session_projector.linear", sess) + _lin(sd, "private_session_projector1.linear", sess)
+    qx = qp.unsqueeze(1).expand(B, N, H).reshape(B * N, H)
+    dx = docs.reshape(B * N, H)
+    feats = torch.cat((qx, dx, (qx - dx).abs(), qx * dx), 1)
+    return _maxout(sd, "ranknet", feats).view(B, N)
+
+
+def _inner_pool(sd, p, states):
+    """cars.py:385-388 / 407-410: self-attention pool over the states produced so far (without the zero state)."""
+    st = torch.stack(states, 1)
+    w = F.softmax(_lin(sd, p + ".3", torch.tanh(_lin(sd, p + ".0", st))).squeeze(2), 1)
+    return torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2)
+
+
 @torch.no_grad()
-def cars_encode_session(sd, pooled_q, pooled_docs, clicks):
-    """cars.py:306-458, ranking outputs only -> click scores [B,S,N]."""
+def cars_session_full(sd, pooled_q, pooled_docs, clicks, q_on=True, d_on=True, rank_on=True, recommender=True):
+    """cars.py:306-458 -> (click scores [B,S,N] or None, (dec_h, dec_c) or None, (inner_q, inner_d)).
+
+    dec_h / dec_c = transform_hid / transform_cell of cat(h_q, h_d) for steps 0..S-2, concatenated along the BATCH axis in
+    step-major order ([1,(S-1)*B,nhid_decoder], cars.py:431-445); inner_* [B,S,HS]."""
     B, S, _ = pooled_q.shape
-    HS = sd["session_query_attn.weight"].shape[1]
-    qs, ds = [pooled_q.new_zeros(B, HS)], [pooled_q.new_zeros(B, HS)]
-    qstate = (pooled_q.new_zeros(B, HS), pooled_q.new_zeros(B, HS))
-    dstate = (pooled_q.new_zeros(B, HS), pooled_q.new_zeros(B, HS))
-    scores = []
+    qs, ds = [], []
+    qstate = dstate = None
+    if q_on:
+        HS = sd["session_query_attn.weight"].shape[1]
+        qs.append(pooled_q.new_zeros(B, HS))
+        qstate = (pooled_q.new_zeros(B, HS), pooled_q.new_zeros(B, HS))
+    if d_on:
+        HSd = sd["session_doc_attn.weight"].shape[1]
+        ds.append(pooled_q.new_zeros(B, HSd))
+        dstate = (pooled_q.new_zeros(B, HSd), pooled_q.new_zeros(B, HSd))
+    scores, hid, cell, inner_q, inner_d = [], [], [], [], []
     for t in range(S):
         qv = pooled_q[:, t]
 
@@ -350,13 +379,36 @@ def cars_encode_session(sd, pooled_q, pooled_docs, clicks):
             w = F.softmax(torch.bmm(_lin(sd, p, st), qv.unsqueeze(2)).squeeze(2), 1)
             return torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2)
 
-        sq = attend(qs, "session_query_attn")
-        sdv = attend(ds, "session_doc_attn")                                        # keyed by the QUERY vector (:361)
-        scores.append(_cars_rank(sd, qv, sq, sdv, pooled_docs[:, t]))
-        qstate = _lstm_step(sd, "session_query_encoder.encoder.rnns.0", qv, qstate)
-        dstate = _lstm_step(sd, "session_doc_encoder.encoder.rnns.0", clicks[:, t], dstate)
-        qs.append(qstate[0]); ds.append(dstate[0])
-    return torch.stack(scores, 1)
+        if rank_on:
+            parts = []
+            if q_on:
+                parts.append(attend(qs, "session_query_attn"))
+            if d_on:
+                parts.append(attend(ds, "session_doc_attn"))                        # keyed by the QUERY vector (:361)
+            scores.append(_cars_rank_sw(sd, qv, parts, pooled_docs[:, t]))
+        h_parts, c_parts = [], []
+        if q_on:
+            qstate = _lstm_step(sd, "session_query_encoder.encoder.rnns.0", qv, qstate)
+            qs.append(qstate[0]); h_parts.append(qstate[0]); c_parts.append(qstate[1])
+            inner_q.append(_inner_pool(sd, "session_query_inner_attn", qs[1:]))
+        if d_on:
+            dstate = _lstm_step(sd, "session_doc_encoder.encoder.rnns.0", clicks[:, t], dstate)
+            ds.append(dstate[0]); h_parts.append(dstate[0]); c_parts.append(dstate[1])
+            inner_d.append(_inner_pool(sd, "session_doc_inner_attn", ds[1:]))
+        if h_parts:
+            hid.append(torch.cat(h_parts, 1)); cell.append(torch.cat(c_parts, 1))
+    states = None
+    if recommender and hid and S > 1:
+        states = (_lin(sd, "transform_hid.linear", torch.cat(hid[:-1], 0)).unsqueeze(0),
+                  _lin(sd, "transform_cell.linear", torch.cat(cell[:-1], 0)).unsqueeze(0))
+    attns = (torch.stack(inner_q, 1) if inner_q else None, torch.stack(inner_d, 1) if inner_d else None)
+    return (torch.stack(scores, 1) if scores else None), states, attns
+
+
+@torch.no_grad()
+def cars_encode_session(sd, pooled_q, pooled_docs, clicks):
+    """cars.py:306-458, ranking outputs only -> click scores [B,S,N]."""
+    return cars_session_full(sd, pooled_q, pooled_docs, clicks, recommender=False)[0]
 
 
 @torch.no_grad()
@@ -367,9 +419,55 @@ def cars_rank_document(sd, pooled_q, d, d_len, labels):
 
 
 @torch.no_grad()
+def cars_rank_document_full(sd, pooled_q, d, d_len, labels, q_on=True, d_on=True, rank_on=True, recommender=True):
+    """cars.py:522-540 with the switches -> (click_scores, states, session_attns)."""
+    docs = clicks = None
+    if rank_on or d_on:
+        docs = cars_encode_document(sd, d, d_len)
+        if d_on:
+            clicks = cars_encode_clicks(sd, docs, labels)
+    return cars_session_full(sd, pooled_q, docs, clicks, q_on, d_on, rank_on, recommender)
+
+
+@torch.no_grad()
 def cars_scores(sd, q, q_len, d, d_len, labels):
     pooled, _ = cars_encode(sd, q, q_len)
     return cars_rank_document(sd, pooled, d, d_len, labels)
+
+
+@torch.no_grad()
+def cars_decode(sd, states, max_len, B, SD, encoded_source, source_len, session_attns, tgt2src=None, bos=2):
+    """cars.py:706-791 (greedy) with RNNDecoder (decoders/decoder.py:94-168, rnn_decoder.py:19-88) and Luong 'general'
+    attention (modules/global_attention.py:98-196) -> predictions [B, SD, max_len] (target-vocabulary ids).
+    tgt2src: LongTensor [V_tgt] = src_dict[tgt_dict[i]] (the reference maps through the two dicts on the host, :783-787)."""
+    h, c = states[0][0], states[1][0]
+    QL, DQ = encoded_source.shape[1], encoded_source.shape[2]
+    mem = encoded_source.view(B, SD + 1, QL, DQ)[:, :-1].reshape(B * SD, QL, DQ)
+    mem = F.linear(mem, sd["dec_attn.weight"])
+    mlen = source_len.view(B, SD + 1)[:, :-1].reshape(-1)
+    mask = _seq_mask(mlen, QL)
+    cat = [a for a in session_attns if a is not None]
+    sess = None
+    if cat:
+        cs = torch.cat(cat, 2)[:, :-1].reshape(B * SD, -1)
+        sess = _lin(sd, "shared_session_projector.linear", cs) + _lin(sd, "private_session_projector2.linear", cs)
+    tgt = torch.full((B * SD,), bos, dtype=torch.long)
+    table = sd["embedder.word_embeddings.make_embedding.emb_luts.0.weight"]
+    preds = []
+    for _ in range(max_len):
+        h, c = _lstm_step(sd, "decoder.decoder.rnn", table[tgt], (h, c))
+        qv = F.linear(h, sd["decoder.decoder.attn.linear_in.weight"])
+        align = torch.bmm(mem, qv.unsqueeze(2)).squeeze(2).masked_fill(~mask, float("-inf"))
+        ctx = torch.bmm(F.softmax(align, 1).unsqueeze(1), mem).squeeze(1)
+        out = torch.tanh(F.linear(torch.cat((ctx, h), 1), sd["decoder.decoder.attn.linear_out.weight"]))
+        out = F.linear(out, sd["token_prob_predictor1.weight"])
+        if sess is not None:
+            out = out + sess
+        prob = F.softmax(F.linear(out, sd["token_prob_predictor2.weight"]), 1)
+        w = prob.max(1)[1]
+        preds.append(w)
+        tgt = tgt2src[w] if tgt2src is not None else w
+    return torch.stack(preds, 1).view(B, SD, max_len)
 
 
 # ------------------------------------------------------------------------------------------

@@ -214,6 +214,44 @@ def gen_cars():
 
 
 @torch.no_grad()
+def gen_cars_decode():
+    """CARS suggestion side + session switches from the real reference: decoder-initialisation states, inner-attention
+    pools, greedy decode predictions (cars.py:382-456, 706-791); click scores with query_session_off / doc_session_off /
+    both off (cars.py:185-188, 329-410, 485-533)."""
+    rng = np.random.default_rng(17)
+    B, S, N, QL, DL, MAXLEN = 3, 4, 5, 6, 9, 5
+    qlen = rng.integers(1, QL + 1, size=(B, S)); qlen[0, 0] = QL
+    dlen = rng.integers(1, DL + 1, size=(B, S, N)); dlen[0, 0, 0] = DL
+    q = rand_ids(rng, (B, S, QL), qlen); d = rand_ids(rng, (B, S, N, DL), dlen)
+    lab = np.zeros((B, S, N), np.float32)
+    for b in range(B):
+        for s_ in range(S):
+            lab[b, s_, rng.choice(N, int(rng.integers(1, 3)), replace=False)] = 1.0
+    tq, tql, td, tdl, tl = T(q), T(qlen), T(d), T(dlen), T(lab)
+    tgt2src = rng.permutation(V).astype(np.int64)           # src_dict[tgt_dict[i]]: tgt_dict = identity, src_dict = a permutation
+    tgt_dict, src_dict = list(range(V)), [int(x) for x in tgt2src]
+    out = dict(source_words=q, source_lens=qlen, document_words=d, document_lens=dlen, document_labels=lab, tgt2src=tgt2src,
+               max_len=MAXLEN)
+    for tag, kw in (("full", {}), ("qoff", dict(query_session_off=True)), ("doff", dict(doc_session_off=True))):
+        m = load_det(CARS(base_args("CARS", tgt_vocab_size=V, **kw)))
+        pooled, enc_q, _ = m.encode(tq, tql)
+        scores, states, attns = m.rank_document(pooled, td, tdl, tl)
+        dec = m.decode(states=states, max_len=MAXLEN, src_dict=src_dict, tgt_dict=tgt_dict, batch_size=B, session_len=S - 1,
+                       use_cuda=False, encoded_source=enc_q, source_len=tql, session_attns=attns)
+        out[tag + "_click_scores"] = scores
+        out[tag + "_dec_h"], out[tag + "_dec_c"] = states
+        if attns[0] is not None:
+            out[tag + "_inner_q"] = attns[0]
+        if attns[1] is not None:
+            out[tag + "_inner_d"] = attns[1]
+        out[tag + "_predictions"] = dec["predictions"]
+    m = load_det(CARS(base_args("CARS", tgt_vocab_size=V, query_session_off=True, doc_session_off=True, turn_recommender_off=True)))
+    pooled, _, _ = m.encode(tq, tql)
+    out["bothoff_click_scores"] = m.rank_document(pooled, td, tdl, tl)[0]
+    save("cars_decode", **out)
+
+
+@torch.no_grad()
 def gen_losses_metrics():
     rng = np.random.default_rng(6)
     B, N = 6, 10
@@ -341,4 +379,10 @@ def gen_samplers():
 if __name__ == "__main__":
     torch.manual_seed(SEED)
     torch.set_num_threads(4)
-    gen_esm(); gen_match_tensor(); gen_drmm(); gen_duet(); gen_cars(); gen_losses_metrics(); gen_batchify(); gen_samplers(); gen_m_match_tensor(); gen_mnsrf()
+    only = set(sys.argv[1:])          # e.g. `generate.py cars_decode` regenerates one fixture family
+    gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode,
+                losses_metrics=gen_losses_metrics, batchify=gen_batchify, samplers=gen_samplers, m_match_tensor=gen_m_match_tensor,
+                mnsrf=gen_mnsrf)
+    for name, fn in gens.items():
+        if not only or name in only:
+            fn()

@@ -103,3 +103,40 @@ def test_losses_and_metrics():
     assert O.mean_reciprocal_rank(pred, g["labels"]) == pytest.approx(float(g["MRR"]), abs=1e-12)
     assert O.precision_at_k(pred, g["labels"], 1) == pytest.approx(float(g["P1"]), abs=1e-12)
     assert O.precision_at_k(pred, g["labels"], 3) == pytest.approx(float(g["P3"]), abs=1e-12)
+
+
+CARS_CFG = {"full": {}, "qoff": dict(query_session_off=True), "doff": dict(doc_session_off=True)}
+
+
+@pytest.mark.parametrize("tag", ["full", "qoff", "doff"])
+def test_cars_decode_and_switches(tag):
+    """Oracle restatement of the session switches, the decoder-initialisation states, the inner-attention pools and the
+    greedy decoder against the real reference (tests/golden/generate.py:gen_cars_decode)."""
+    g = load_golden("cars_decode")
+    V = int(g["meta_vocab"])
+    kw = CARS_CFG[tag]
+    sd = cpu_state_dict(build_model("CARS", tgt_vocab_size=V, **kw))
+    q, ql, d, dl, lab = (T(g[k]) for k in ("source_words", "source_lens", "document_words", "document_lens", "document_labels"))
+    B, S, _ = q.shape
+    pooled, enc = O.cars_encode(sd, q, ql)
+    q_on, d_on = not kw.get("query_session_off", False), not kw.get("doc_session_off", False)
+    scores, states, attns = O.cars_rank_document_full(sd, pooled, d, dl, lab, q_on=q_on, d_on=d_on)
+    _close(scores, g[tag + "_click_scores"], 2e-6)
+    _close(states[0], g[tag + "_dec_h"], 2e-6); _close(states[1], g[tag + "_dec_c"], 2e-6)
+    if q_on:
+        _close(attns[0], g[tag + "_inner_q"], 2e-6)
+    if d_on:
+        _close(attns[1], g[tag + "_inner_d"], 2e-6)
+    pred = O.cars_decode(sd, states, int(g["max_len"]), B, S - 1, enc, ql, attns, tgt2src=T(g["tgt2src"]))
+    assert (pred.numpy() == g[tag + "_predictions"]).all()
+
+
+def test_cars_both_sessions_off():
+    g = load_golden("cars_decode")
+    sd = cpu_state_dict(build_model("CARS", tgt_vocab_size=int(g["meta_vocab"]), query_session_off=True, doc_session_off=True,
+                                    turn_recommender_off=True))
+    q, ql, d, dl, lab = (T(g[k]) for k in ("source_words", "source_lens", "document_words", "document_lens", "document_labels"))
+    pooled, _ = O.cars_encode(sd, q, ql)
+    scores, states, _ = O.cars_rank_document_full(sd, pooled, d, dl, lab, q_on=False, d_on=False, recommender=False)
+    _close(scores, g["bothoff_click_scores"], 2e-6)
+    assert states is None
