@@ -43,6 +43,10 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Interned "name[M=..,N=..,K=..]" label for shape-resolved profiles (NIR_PROFILE_SHAPES=1 at load time); returns `base`
+// unchanged otherwise.  The returned pointer stays valid for the life of the process.
+const char* prof_shape_name(const char* base, long long M, long long N, long long K);
+
 // Fork/join helper: independent kernel chains of one C-ABI call (e.g. the query side and the document side of a
 // ranker) run concurrently on a lazily created per-device side stream.  Event record / wait are capturable, so the
 // whole call still records into a hipGraph.
@@ -95,6 +99,26 @@ __device__ __forceinline__ float fast_tanh(float x) {
     float e = __expf(-2.0f * ax);           // in (0,1]
     float t = (1.0f - e) * fast_rcp(1.0f + e);
     return copysignf(t, x);
+}
+
+// bf16 helpers (round-to-nearest-even on the raw bits; NaN stays NaN)
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+// 3 x bf16 split of an fp32 value: x = b0 + b1 + b2 up to 2^-27 |x| (each term takes the next 8 mantissa bits; the
+// residuals x - b0, x - b0 - b1 are exact in fp32).  Products of two such triples keep the six leading cross terms
+// (b0b0, b0b1, b1b0, b0b2, b1b1, b2b0): every bf16 x bf16 product is exact in fp32, so six bf16 MFMAs with fp32 accumulation
+// reproduce an fp32 dot product to fp32 accuracy at 6/16 of the fp32-MFMA cost.
+__device__ __forceinline__ void split3(float x, unsigned short& b0, unsigned short& b1, unsigned short& b2) {
+    b0 = f2bf(x);
+    const float r1 = x - bf2f(b0);
+    b1 = f2bf(r1);
+    const float r2 = r1 - bf2f(b1);
+    b2 = f2bf(r2);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (global loads AND stores

@@ -24,6 +24,19 @@ static std::mutex g_prof_mu;
 static std::vector<ProfRec*> g_prof;
 static std::atomic<int> g_prof_on{0};
 
+static const bool g_prof_shapes = getenv("NIR_PROFILE_SHAPES") != nullptr;   // read once, at library load
+const char* prof_shape_name(const char* base, long long M, long long N, long long K) {
+    if (!g_prof_shapes || !g_prof_on.load(std::memory_order_relaxed)) return base;
+    static std::mutex mu;
+    static std::map<std::string, std::string*> names;
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s[M=%lld,N=%lld,K=%lld]", base, M, N, K);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = names.find(buf);
+    if (it == names.end()) it = names.emplace(buf, new std::string(buf)).first;
+    return it->second->c_str();
+}
+
 ProfScope::ProfScope(const char* name, hipStream_t stream) : rec(nullptr), st(stream) {
     if (!g_prof_on.load(std::memory_order_relaxed)) return;
     ProfRec* r = new ProfRec{name, nullptr, nullptr};

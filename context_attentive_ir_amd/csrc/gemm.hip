@@ -421,6 +421,189 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-precision GEMM: fp32 operands, fp32 result, products on the bf16 matrix cores.
+//   Every fp32 operand element is split into three bf16 terms (common.hpp: split3) while its tile is staged into LDS; the
+//   six leading cross terms go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation (smallest terms first).  bf16 x bf16
+//   products are exact in fp32, so the result carries fp32-class error (measured: max |err| 6e-7 vs 1.2e-6 for the plain
+//   fp32 chain at K = 900) while the matrix pipe does 6 bf16 instructions where the f32 MFMA path needs 16 instruction
+//   slots: peak = 2.5 PFLOP/s / 6 = 417 TFLOP/s fp32-equivalent, 2.65 x the 157 TFLOP/s fp32 MFMA roof.
+// Tiling: 128(M) x 128(N) per workgroup, 2 x 2 waves of 64 x 64 (4 accumulator tiles = 64 VGPRs), BK = 16 fp32 = one bf16
+// MFMA k-block.  LDS per operand, stage and term: [k-half][128 rows][8 bf16] (a 32-lane half-wave reads 512 contiguous bytes:
+// conflict-free ds_read_b128) -> 2 operands x 2 stages x 3 terms x 4 KB = 48 KB, 3 workgroups per CU.  Global loads of tile
+// t+1 are in flight during the 24 MFMAs of tile t; the split (VALU) runs in the shadow of the other waves' MFMAs.
+// Operand addressing (dense / embedding gather / conv taps), epilogues and the XCD-aware block order are gemm_kernel's.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int G3_BM = 128, G3_BN = 128, G3_BK = 16;
+constexpr int G3_HALF = 128 * 8 + 32;                 // one k-half: 128 rows x 8 bf16, + 64 B so the two halves sit 16 banks apart
+constexpr int G3_PLANE = 2 * G3_HALF;                 // bf16 elements per (operand, stage, term): [k-half][row][8]
+
+// Split four k-consecutive fp32 values into the three bf16 term planes and store them (8 bytes per plane).  The split
+// TRUNCATES (term = top 16 bits of the running residual; the residual stays exact and keeps its sign): three terms still cover
+// 24 mantissa bits, and v_perm_b32 packs two terms per instruction -- 5.5 VALU ops per element instead of ~25 for
+// round-to-nearest splits, which would make this kernel VALU-bound (measured: 97 TFLOP/s, no better than the f32 MFMA path).
+__device__ __forceinline__ void g3_split_store(unsigned short* base, int row, int kq, const float4& v) {
+    const unsigned x0 = __float_as_uint(v.x), x1 = __float_as_uint(v.y), x2 = __float_as_uint(v.z), x3 = __float_as_uint(v.w);
+    const unsigned a01 = __builtin_amdgcn_perm(x1, x0, 0x07060302u), a23 = __builtin_amdgcn_perm(x3, x2, 0x07060302u);
+    const float r0 = v.x - __uint_as_float(x0 & 0xFFFF0000u), r1 = v.y - __uint_as_float(x1 & 0xFFFF0000u);
+    const float r2 = v.z - __uint_as_float(x2 & 0xFFFF0000u), r3 = v.w - __uint_as_float(x3 & 0xFFFF0000u);
+    const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1), y2 = __float_as_uint(r2), y3 = __float_as_uint(r3);
+    const unsigned b01 = __builtin_amdgcn_perm(y1, y0, 0x07060302u), b23 = __builtin_amdgcn_perm(y3, y2, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(y0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(y2 & 0xFFFF0000u), s3 = r3 - __uint_as_float(y3 & 0xFFFF0000u);
+    const unsigned c01 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    const unsigned c23 = __builtin_amdgcn_perm(__float_as_uint(s3), __float_as_uint(s2), 0x07060302u);
+    unsigned short* d = base + (kq >> 1) * G3_HALF + row * 8 + (kq & 1) * 4;
+    *reinterpret_cast<uint2*>(d) = make_uint2(a01, a23);
+    *reinterpret_cast<uint2*>(d + G3_PLANE) = make_uint2(b01, b23);
+    *reinterpret_cast<uint2*>(d + 2 * G3_PLANE) = make_uint2(c01, c23);
+}
+
+// MODE 0: dense A; 1: embedding gather, one row per A row (K <= E); 2: conv taps (E < K <= 3E, one table row per tap).
+// The mode is a template parameter and every load is unconditional (row pointers of out-of-range rows are clamped to a valid
+// row -- their products land in accumulator rows / columns the epilogue never stores), so the k-loop has no branches: a
+// predicated load would become its own basic block with a vmcnt(0) in front of it.  Only the K tail tile masks its operands.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem3[];
+    unsigned short* As = smem3;                        // [2 stages][3 terms][G3_PLANE]
+    unsigned short* Ws = smem3 + 2 * 3 * G3_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nb = (p.N + G3_BN - 1) / G3_BN;
+    const int64_t mb = (p.M + G3_BM - 1) / G3_BM;
+    const int64_t bid = blockIdx.x;
+    const int64_t tq = bid >> 3;
+    const int64_t mblk = (tq / nb) * 8 + (bid & 7);
+    if (mblk >= mb) return;
+    const int64_t m0 = mblk * G3_BM;
+    const int n0 = (int)(tq % nb) * G3_BN;
+    const int lr = tid >> 2, kq = tid & 3;             // thread loads rows lr and lr + 64, k = 4*kq .. +3 of the k-tile
+
+    const float* arow[2];
+    const float* arow1[2];
+    const float* arow2[2];
+    const float* wrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t m = m0 + lr + 64 * i;
+        m = m < p.M ? m : p.M - 1;
+        arow1[i] = arow2[i] = nullptr;
+        if (MODE == 0) {
+            arow[i] = p.a + m * p.lda;
+        } else {
+            const int64_t ai = (m / p.rows_per_seq) * p.seq_stride + (m % p.rows_per_seq);
+            arow[i] = p.table + p.ids[ai] * (int64_t)p.E;
+            if (MODE == 2) {   // pointers pre-biased by the tap's k offset: element k of tap s is arow_s[k]
+                arow1[i] = p.table + p.ids[ai + 1] * (int64_t)p.E - p.E;
+                arow2[i] = p.K > 2 * p.E ? p.table + p.ids[ai + 2] * (int64_t)p.E - 2 * p.E : arow1[i];
+            }
+        }
+        int n = n0 + lr + 64 * i;
+        n = n < p.N ? n : p.N - 1;
+        wrow[i] = p.w + (int64_t)n * p.ldw;
+    }
+    float4 ra[2], rw[2];
+    auto load_tile = [&](int k0, bool tail) {
+        int k = k0 + 4 * kq;
+        const bool kv = k < p.K;
+        k = kv ? k : p.K - 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* src = arow[i];
+            if (MODE == 2) src = k < p.E ? arow[i] : (k < 2 * p.E ? arow1[i] : arow2[i]);
+            ra[i] = *reinterpret_cast<const float4*>(src + k);
+            rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k);
+            if (tail && !kv) {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            g3_split_store(As + buf * 3 * G3_PLANE, lr + 64 * i, kq, ra[i]);
+            g3_split_store(Ws + buf * 3 * G3_PLANE, lr + 64 * i, kq, rw[i]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nk = (p.K + G3_BK - 1) / G3_BK;
+    const bool ktail = (p.K % G3_BK) != 0;
+    load_tile(0, nk == 1 && ktail);
+    store_tile(0);
+    __syncthreads();
+    // fragment address inside a plane: [k-half = lane >> 5][row][8]
+    const int foff_a = (lane >> 5) * G3_HALF + (wm * 64 + (lane & 31)) * 8;
+    const int foff_w = (lane >> 5) * G3_HALF + (wn * 64 + (lane & 31)) * 8;
+    auto mma_tile = [&](int buf) {
+        const unsigned short* ab = As + buf * 3 * G3_PLANE + foff_a;
+        const unsigned short* wb = Ws + buf * 3 * G3_PLANE + foff_w;
+        bf16x8 af[2][3], wf[2][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i][t] = *reinterpret_cast<const bf16x8*>(ab + t * G3_PLANE + i * 32 * 8);
+                wf[i][t] = *reinterpret_cast<const bf16x8*>(wb + t * G3_PLANE + i * 32 * 8);
+            }
+        }
+        // six cross terms, smallest first; the four accumulator tiles are interleaved inside each term so that consecutive
+        // MFMAs never depend on each other
+#define G3_TERM(TA, TW)                                                                                          \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][TA], wf[0][TW], acc[0][0], 0, 0, 0);           \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][TA], wf[1][TW], acc[0][1], 0, 0, 0);           \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][TA], wf[0][TW], acc[1][0], 0, 0, 0);           \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][TA], wf[1][TW], acc[1][1], 0, 0, 0);
+        G3_TERM(2, 0) G3_TERM(1, 1) G3_TERM(0, 2) G3_TERM(1, 0) G3_TERM(0, 1) G3_TERM(0, 0)
+#undef G3_TERM
+    };
+    for (int kt = 0; kt + 2 < nk; ++kt) {              // steady state: the next tile is a full one
+        load_tile((kt + 1) * G3_BK, false);
+        __builtin_amdgcn_sched_barrier(0);             // keep the loads ABOVE the MFMAs (the scheduler sinks them to their first use)
+        mma_tile(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile((kt & 1) ^ 1);
+        __syncthreads();
+    }
+    if (nk >= 2) {                                     // second-to-last tile: prefetches the (possibly partial) last tile
+        const int kt = nk - 2;
+        load_tile((kt + 1) * G3_BK, ktail);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile((kt & 1) ^ 1);
+        __syncthreads();
+    }
+    mma_tile((nk - 1) & 1);
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wn * 64 + b * 32 + (lane & 31);
+        float bsum = 0.f;
+        if (n < p.N) {
+            if (p.bias) bsum += p.bias[n];
+            if (p.bias2) bsum += p.bias2[n];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                gemm_store(p, m, n, acc[a][b][r], bsum);
+            }
+    }
+}
+
 template <int NT>
 static void launch_skinny(const GemmArgs& p, int G, size_t lds, hipStream_t st) {
     static bool attr_done = false;
@@ -468,20 +651,35 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     const int nb = (N + BN - 1) / BN;
     const int skG = (K + 15) / 16, skNT = (N + 15) / 16;
     const size_t sk_lds = (size_t)16 * skNT * (skG * 16 + 4) * 4;
+    static const bool exact_f32 = getenv("NIR_EXACT_F32") != nullptr;    // read once: force the f32-MFMA kernels everywhere
+    const int64_t mb3 = (M + G3_BM - 1) / G3_BM;
+    const int nb3 = (N + G3_BN - 1) / G3_BN;
+    const int mode3 = !ids ? 0 : (K <= E ? 1 : (K <= 3 * E ? 2 : -1));
+    if (vec && !exact_f32 && mode3 >= 0 && N >= 96 && K >= 32 && mb3 * nb3 >= 96) {
+        // large GEMMs: fp32 accuracy from three-term bf16 splits on the bf16 matrix cores (2.65 x the f32 MFMA roof)
+        ProfScope ps(prof_shape_name(ids ? "gemm3_kernel[gather]" : "gemm3_kernel", M, N, K), st);
+        constexpr size_t lds3 = (size_t)2 * 2 * 3 * G3_PLANE * 2;
+        dim3 grid((unsigned)(8 * nb3 * ((mb3 + 7) / 8)));
+        if (mode3 == 0) hipLaunchKernelGGL(gemm3_kernel<0>, grid, dim3(256), lds3, st, p);
+        else if (mode3 == 1) hipLaunchKernelGGL(gemm3_kernel<1>, grid, dim3(256), lds3, st, p);
+        else hipLaunchKernelGGL(gemm3_kernel<2>, grid, dim3(256), lds3, st, p);
+        NIR_CHECK_LAUNCH("nir_linear_f32[bf16x3]");
+        return 0;
+    }
     if (N <= 64 && vec && M >= 4096 && (!ids || K <= E) && sk_lds <= 128 * 1024 && act != ACT_MAXOUT2 && act != ACT_TANH_ROWDOT16 && !getenv("NIR_NO_SKINNY")) {
-        ProfScope ps(ids ? "gemm_skinny_kernel[gather]" : "gemm_skinny_kernel", st);
+        ProfScope ps(prof_shape_name(ids ? "gemm_skinny_kernel[gather]" : "gemm_skinny_kernel", M, N, K), st);
         if (skNT == 1) launch_skinny<1>(p, skG, sk_lds, st);
         else if (skNT == 2) launch_skinny<2>(p, skG, sk_lds, st);
         else if (skNT == 3) launch_skinny<3>(p, skG, sk_lds, st);
         else launch_skinny<4>(p, skG, sk_lds, st);
     } else if (mb * nb < 160 && !getenv("NIR_NO_GEMM16")) {
         // too few 64x64 tiles to fill 256 CUs: one 16x16 tile per workgroup, K split over the waves
-        ProfScope ps(ids ? "gemm16_kernel[gather]" : "gemm16_kernel", st);
+        ProfScope ps(prof_shape_name(ids ? "gemm16_kernel[gather]" : "gemm16_kernel", M, N, K), st);
         dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
         if (vec) hipLaunchKernelGGL(gemm16_kernel<true>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm16_kernel<false>, grid, dim3(256), 0, st, p);
     } else {
-        ProfScope ps(ids ? "gemm_kernel[gather]" : "gemm_kernel", st);
+        ProfScope ps(prof_shape_name(ids ? "gemm_kernel[gather]" : "gemm_kernel", M, N, K), st);
         constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * 4;   // 36864 B at BK = 32 (the opt-in only matters for BK = 64)
         static bool attr_done = false;
         if (!attr_done) {

@@ -31,14 +31,6 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even, NaN preserved
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-
 // wperm[(dir*H + unit)*4 + gate][:] = wih[dir*4H + gate*H + unit][:],  bperm likewise = bih + bhh
 __global__ void fold_permute_kernel(const float* __restrict__ wih, const float* __restrict__ bih, const float* __restrict__ bhh,
                                     int H, int ND, int E, float* __restrict__ wperm, float* __restrict__ bperm) {

@@ -37,7 +37,9 @@ def _synth(rng, B, N, QL, DL, V, full=False):
 @pytest.mark.parametrize("M,N,K,act", [(37, 40, 300, 0), (130, 50, 30, 0), (64, 64, 32, 1), (257, 301, 900, 2), (5, 1, 7, 0),
                                        (16, 2048, 768, 0), (1100, 800, 260, 1), (20480, 40, 300, 0), (3000, 70, 35, 2),
                                        (8200, 512, 301, 1), (4100, 1024, 70, 2), (33000, 128, 64, 0),
-                                       (5000, 50, 140, 0), (4100, 64, 300, 1), (4097, 17, 20, 2), (20481, 33, 8, 0)])
+                                       (5000, 50, 140, 0), (4100, 64, 300, 1), (4097, 17, 20, 2), (20481, 33, 8, 0),
+                                       # large enough for the split-precision (3 x bf16) kernel: ragged M/N/K tails included
+                                       (13000, 300, 900, 1), (71680, 256, 256, 0), (12289, 129, 36, 2), (40000, 1024, 300, 0)])
 def test_linear_dense(M, N, K, act):
     from context_attentive_ir_amd import lib
     g = torch.Generator().manual_seed(M * 1000 + N)
@@ -59,6 +61,7 @@ def test_linear_gather_conv():
     _gather_conv_case(lib, g, V, E, F_, nseq, L)
     _gather_conv_case(lib, g, 500, 300, 300, 400, 40)       # large enough for the 64x64-tile kernel
     _gather_conv_case(lib, g, 500, 300, 256, 900, 40)       # N % 128 == 0 and >= 256 tiles: the 128x128-tile kernel
+    _gather_conv_case(lib, g, 3000, 300, 300, 450, 64)      # DUET conv shape: split-precision kernel, 3 taps, N tail
 
 
 @pytest.mark.parametrize("world,B,per,N", [(8, 32, 10, 80), (8, 64, 7, 50), (2, 3, 1, 2), (1, 5, 130, 130), (4, 1, 40, 157)])
