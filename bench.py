@@ -3,31 +3,40 @@
 
     python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
 
-Workload (BASELINE.json configs[1], the config the metric is quoted on that fits one GPU):
-    match_tensor ranker, batch = 32 queries x 10 candidates, q_len 4, doc_len 64, emb_dim 300, fp32,
-    synthetic MSMARCO-shaped ids (Zipf over a 100 000 x 300 table, seed 1013), full-length sequences.
-A "step" = Ranker.predict on one batch already resident in HBM: network forward + softmax over candidates.
-N > 1 (weak scaling): the CANDIDATE axis is sharded -- every rank scores its own 10 candidates of each of the
-32 queries (global candidate set = 10*N per query) and one RCCL all-gather assembles the [32, 10*N] score
-matrix on every rank before the softmax.  value = pairs all ranks ranked / max-rank time.
+HEADLINE (the JSON line's metric/value/roofline/cpu_baseline): BASELINE.json configs[2], the largest configuration
+BASELINE marks 1 x MI355X -- CARS multitask, 16 sessions x session_len 7 x 10 candidates, q_len 4, doc_len 64,
+emb_dim 300, fp32, synthetic MSMARCO-shaped ids (Zipf over a 100 000 x 300 table, seed 1013), full-length sequences.
+A "step" = Multitask.predict's ranking path on one batch already resident in HBM: encode + rank_document + softmax
+over the candidates (the suggestion decoder is not a ranking step; `config.sub.C3_cars_with_decode` times the full predict).
 
-Besides the driver's contract keys the JSON line carries
-    roofline     -- the dominant kernel (by summed duration), timed with HIP events on its launch stream in a
-                    profiled pass over the same workload right after the timed region (events inside the timed
-                    region would distort it); its algorithmic flops/bytes per launch are stated in DESIGN.md;
-    cpu_baseline -- the CPU oracle (oracle/neuroir_cpu.py, pinned to the reference) timed on the host cores
-                    on a bounded sample of the same workload (rank 0, N=1 only).
+The same default run also measures every other single-GPU BASELINE configuration as a SUB-RECORD under `config.sub`,
+each with its own throughput, dominant kernel and roofline (kernel, avg_us, bound, achieved, peak, frac, traffic):
+C1 ESM 8x5, C2 MatchTensor 32x10, the north-star 32x50 MatchTensor shape, C4 DUET and DRMM 64x50xdoc_len 290 (DRMM / ESM
+with uniform ids over a 1M-row table so the gather really comes from HBM) and the C5 shape (CARS 64x7x50) in bf16.
+
+N > 1 (strong scaling): every rank holds the SAME global batch and scores its own slice of the
+candidate axis (ceil(N_cand / N) per rank, padded); rankers all-gather the score shards over RCCL, CARS goes through
+Multitask.parallelize() = candidate-sharded document encoding + one all-gather of the pooled document vectors.  value =
+global pairs / max-rank time.  `config.weak_scaling_pairs_per_s` (labelled, secondary) = every rank scoring its own
+full batch with no collective.
+
+roofline: the dominant kernel (largest summed duration), timed with HIP events on its launch stream in a profiled pass
+over the same workload right after the timed region; algorithmic flops / bytes per launch are priced from the launch's
+own shape.  Peaks: HBM 8 TB/s; fp32 MFMA 157.3 TFLOP/s; split-precision GEMM (3 x bf16 terms, 6 bf16
+MFMAs per fp32-accurate product block) 2500 / 6 = 416.7 TFLOP/s; bf16 MFMA 2500 TFLOP/s.
+cpu_baseline: the pinned CPU oracle (oracle/neuroir_cpu.py) on the host cores, bounded sample, rank 0 at N = 1 only.
 """
 import argparse
+import ctypes
 import json
 import os
+import re
 import sys
 import time
 
 # The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With 4 batches in
 # flight plus torch's own streams that leaves no spare queue and lanes serialise behind each other (measured: 2.35 M
-# pairs/s at 4 queues, 3.13 M at 8).  Must be set before the HIP runtime initialises, i.e. before `import torch`.
-# (With a single lane the default of 4 is kept: 8 queues measured slower there.)
+# pairs/s at 4 queues, 3.13 M at 8 on C2).  Must be set before the HIP runtime initialises, i.e. before `import torch`.
 if not ("--streams" in sys.argv and sys.argv[sys.argv.index("--streams") + 1:][:1] == ["1"]):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -43,170 +52,241 @@ from context_attentive_ir_amd.wrappers import Multitask, Ranker  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_FP32_TFLOPS = 157.3     # fp32 vector == fp32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA
+PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 6.0
+
+SESSION_MODELS = ("cars", "m_match_tensor", "mnsrf")
+
+# name -> workload (BASELINE.json configs; SURVEY.md section 8d shapes)
+CONFIGS = {
+    "C3_cars": dict(model="cars", batch=16, session=7, cands=10, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32",
+                    baseline="configs[2]: CARS multitask, session_len=7, batch=16 sessions x 10 candidates, 1xMI355X"),
+    "C1_esm": dict(model="esm", batch=8, cands=5, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32",
+                   baseline="configs[0]: ESM ranker, batch=8 queries x 5 candidates, q_len=4/doc_len=64"),
+    "C2_match_tensor": dict(model="match_tensor", batch=32, cands=10, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32",
+                            baseline="configs[1]: match_tensor ranker, batch=32 x 10 candidates, emb_dim=300, fp32"),
+    "NS_match_tensor_50": dict(model="match_tensor", batch=32, cands=50, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32",
+                               baseline="north_star shape: q_len 4, doc_len 64, 50 candidates"),
+    "C4_duet": dict(model="duet", batch=64, cands=50, qlen=4, dlen=290, vocab=100000, uniform=False, dtype="f32",
+                    baseline="configs[3]: DUET, batch=64 x 50 candidates, doc_len=290"),
+    "C4_drmm": dict(model="drmm", batch=64, cands=50, qlen=4, dlen=290, vocab=1000000, uniform=True, dtype="f32",
+                    baseline="configs[3]: DRMM, batch=64 x 50 candidates, doc_len=290 (uniform ids, 1M-row table: HBM-resident gather)"),
+    "C4_esm_hbm": dict(model="esm", batch=64, cands=50, qlen=4, dlen=290, vocab=1000000, uniform=True, dtype="f32",
+                       baseline="ESM at the C4 shape (uniform ids, 1M-row table): the pure gather-reduce HBM roofline"),
+    "C5_cars_bf16": dict(model="cars", batch=64, session=7, cands=50, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="bf16",
+                         baseline="configs[4] shape on one GPU: CARS, 50 candidates/query, bf16 folded tables + bf16 MFMA recurrence"),
+}
+HEADLINE = "C3_cars"
+SUB_STEPS = {"C1_esm": 400, "C2_match_tensor": 400, "NS_match_tensor_50": 200, "C4_duet": 12, "C4_drmm": 60, "C4_esm_hbm": 60,
+             "C5_cars_bf16": 24}
 
 
-def algorithmic_bytes_per_pair(N, QL, DL, E=300):
-    """every token occurrence gathers its fp32 row once + int64 id, + 4 B score."""
-    return DL * (4 * E + 8) + QL * (4 * E + 8) / N + 4
+def algorithmic_bytes_per_pair(N, QL, DL, E=300, table_bytes=4):
+    """every token occurrence gathers its row once + int64 id, + 4 B score."""
+    return DL * (table_bytes * E + 8) + QL * (table_bytes * E + 8) / N + 4
 
 
-# per-kernel algorithmic work for one launch of the MatchTensor pipeline (derivations in DESIGN.md section 5)
-def kernel_work(name, B, N, QL, DL, E=300, F=40, Hq=15, Hd=70, C=50):
-    M = B * N
-    w = {
-        # BiLSTM recurrence with the input projection fused in: 2 dirs x DL steps x 4H x (H + F) MACs per sequence;
-        # HBM: x [DL,F] read once per direction, h [DL,2H] written once
-        "lstm_mfma_kernel<5,28,3,1>": dict(flops=M * 2 * DL * 2 * 4 * Hd * (Hd + F), bytes=M * DL * (2 * F + 2 * Hd) * 4),
-        "lstm_mfma_kernel<5,28,4,2>": dict(flops=M * 2 * DL * 2 * 4 * Hd * (Hd + F), bytes=M * DL * (2 * F + 2 * Hd) * 4),
-        "lstm_mfma_kernel<1,16,4,1>": dict(flops=B * 2 * QL * 2 * 4 * Hq * (Hq + F), bytes=B * QL * (2 * F + 2 * Hq) * 4),
-        "lstm_rec_kernel[fused]<80>": dict(flops=M * 2 * DL * 2 * 4 * Hd * (Hd + F), bytes=M * DL * (2 * F + 2 * Hd) * 4),
-        "lstm_rec_kernel[fused]<16>": dict(flops=B * 2 * QL * 2 * 4 * Hq * (Hq + F), bytes=B * QL * (2 * F + 2 * Hq) * 4),
-        # interaction GEMM after folding the query taps: per (i,j) position 15 taps x C channels x 6 filters MACs,
-        # + 18->20 1x1 conv; HBM: Pd [DL,C] + ids read once per pair (U is per query, L2-resident)
-        "mt_head_kernel": dict(flops=M * QL * DL * 2 * (15 * C * 6 + 45 * 6 + 18 * 20), bytes=M * DL * (C * 4 + 8) + M * 4),
-        "gemm_kernel[gather]": dict(flops=(M * DL + B * QL) * 2 * E * F, bytes=(M * DL + B * QL) * (4 * E + 8 + 4 * F)),
-        "gemm_kernel": dict(flops=M * DL * 2 * (2 * Hd * C) + B * QL * 2 * (2 * Hq * C), bytes=M * DL * 4 * (2 * Hd + C)),
-        "mt_fold_kernel": dict(flops=B * QL * 15 * C * 3 * 6 * 2, bytes=B * QL * 15 * C * 8 * 4),
-    }
-    return w.get(name)
+def flops_per_pair(model, qlen, dlen):
+    named = {("match_tensor", 4, 64): 1.76e7, ("cars", 4, 64): 6.72e7, ("duet", 4, 290): 2.08e8, ("drmm", 4, 290): 8.7e5,
+             ("esm", 4, 64): 2.1e4}
+    return named.get((model, qlen, dlen))
+
+
+_SHAPE = re.compile(r"^(.*)\[M=(\d+),N=(\d+),K=(\d+)\]$")
+
+
+def kernel_work(name, c):
+    """Algorithmic flops / HBM bytes of ONE launch, priced from the launch's own shape label.
+    Returns dict(flops, bytes, peak_tflops) or None."""
+    m = _SHAPE.match(name)
+    base, M, N, K = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))) if m else (name, 0, 0, 0)
+    B, NC, QL, DL, E = c["batch"], c["cands"], c["qlen"], c["dlen"], 300
+    pairs = B * NC * (c.get("session", 1) if c["model"] in SESSION_MODELS else 1)
+    if base.startswith("gemm3_kernel"):
+        gathered = "[gather]" in base
+        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),
+                    peak=PEAK_BF16X3_TFLOPS)
+    if base.startswith("gemm_kernel") or base.startswith("gemm16_kernel") or base.startswith("gemm_skinny_kernel"):
+        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N), peak=PEAK_FP32_TFLOPS)
+    if base.startswith("lstm16_pt_bf16_kernel"):      # M sequences, N = T steps, K = H; both directions in one launch
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * 4), peak=PEAK_BF16_TFLOPS)
+    if base.startswith("lstm16_pt_kernel"):
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), peak=PEAK_FP32_TFLOPS)
+    if base.startswith("lstm_mfma16_gin_kernel") or base.startswith("lstm_mfma_gin_kernel") or base.startswith("lstm_rec_kernel<"):
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (2 * 4 * K * 4 + 2 * K * 4.0), peak=PEAK_FP32_TFLOPS)
+    if base.startswith("lstm_mfma_kernel") or base.startswith("lstm_mfma16_kernel") or base.startswith("lstm_rec_kernel[fused]"):
+        F = 40                                         # MatchTensor: input projection fused (I = featsize 40)
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * (K + F), bytes=M * N * (2 * F + 2 * K) * 4.0, peak=PEAK_FP32_TFLOPS)
+    if base == "mt_head_kernel":
+        C = 50
+        return dict(flops=pairs * QL * DL * 2.0 * (15 * C * 6 + 45 * 6 + 18 * 20), bytes=pairs * DL * (C * 4 + 8.0) + pairs * 4,
+                    peak=PEAK_FP32_TFLOPS)
+    if base in ("esm16_kernel", "esm_kernel", "drmm_kernel"):
+        fl = flops_per_pair(c["model"], QL, DL) or (2.0 * DL * E if base != "drmm_kernel" else 2.0 * QL * DL * E)
+        return dict(flops=fl * pairs, bytes=algorithmic_bytes_per_pair(NC, QL, DL) * pairs, peak=PEAK_FP32_TFLOPS)
+    return None
+
+
+def traffic_entry(kernels, prof_name):
+    """profiles/traffic.json is keyed by rocprofv3's kernel names (template arguments, no shape label); match the library's
+    profile label: exact template name first, then the family (a "[gather]" label = the gathering instantiation <1>/<2>)."""
+    m = _SHAPE.match(prof_name)
+    base = m.group(1) if m else prof_name
+    gather = "[gather]" in base
+    fam = base.replace("[gather]", "").replace("[fused]", "")
+    if fam in kernels:
+        return kernels[fam]
+    cands = [k for k in kernels if k.split("<")[0] == fam.split("<")[0]]
+    if fam.split("<")[0] == "gemm3_kernel":
+        cands = [k for k in cands if (k != "gemm3_kernel<0>") == gather]
+    return kernels[max(cands, key=lambda k: kernels[k]["bytes_per_launch"])] if cands else None
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--model", default="match_tensor", choices=["match_tensor", "esm", "drmm", "duet", "cars", "m_match_tensor", "mnsrf"])
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--cands", type=int, default=10)
-    ap.add_argument("--qlen", type=int, default=4)
-    ap.add_argument("--dlen", type=int, default=64)
-    ap.add_argument("--session", type=int, default=7)
-    ap.add_argument("--vocab", type=int, default=100000)
-    ap.add_argument("--uniform", action="store_true", help="uniform token ids (worst case for the gather) instead of Zipf")
+    ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS), help="headline workload (default: C3 CARS)")
+    ap.add_argument("--sub", default=None, help="comma-separated sub-records to measure (default: all; 'none' to skip)")
+    # ad-hoc shapes (tools/, profiling): override fields of --config
+    ap.add_argument("--model", default=None, choices=["match_tensor", "esm", "drmm", "duet", "cars", "m_match_tensor", "mnsrf"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--cands", type=int, default=None)
+    ap.add_argument("--qlen", type=int, default=None)
+    ap.add_argument("--dlen", type=int, default=None)
+    ap.add_argument("--session", type=int, default=None)
+    ap.add_argument("--vocab", type=int, default=None)
+    ap.add_argument("--uniform", action="store_true", default=None, help="uniform token ids (worst case for the gather) instead of Zipf")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="CARS: bf16 = bf16 folded tables + bf16 MFMA recurrence")
+    ap.add_argument("--no-fold", action="store_true", help="CARS: per-batch gather-GEMM instead of the folded embedding table")
     ap.add_argument("--nbatches", type=int, default=12, help="distinct resident batches cycled through")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight: step i runs on HIP stream i %% streams")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="CARS: bf16 = bf16 folded tables + bf16 MFMA recurrence (BASELINE config 5)")
-    ap.add_argument("--no-fold", action="store_true", help="CARS: per-batch gather-GEMM instead of the folded embedding table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
 
-def build(args, dev):
-    kind = args.model.upper()
-    extra = dict(max_query_len=args.qlen, max_doc_len=args.dlen) if kind == "DUET" else {}
-    margs = default_args(kind, src_vocab_size=args.vocab, **extra)
-    wrapper = Multitask(margs) if kind in ("CARS", "M_MATCH_TENSOR", "MNSRF") else Ranker(margs)
+def build_model(c, args):
+    kind = c["model"].upper()
+    extra = dict(max_query_len=c["qlen"], max_doc_len=c["dlen"]) if kind == "DUET" else {}
+    margs = default_args(kind, src_vocab_size=c["vocab"], **extra)
+    wrapper = Multitask(margs) if c["model"] in SESSION_MODELS else Ranker(margs)
     fill_module_(wrapper.network, 1013)
     if kind == "CARS":
-        wrapper.network.compute_dtype = args.dtype
+        wrapper.network.compute_dtype = c.get("dtype", "f32")
         wrapper.network.fold_embeddings = not args.no_fold
     wrapper.cuda()
     wrapper.network.eval()
     return wrapper
 
 
-def make_batches(args, rank, dev):
+def make_batches(c, nbatches, rank_seed, dev):
     out = []
-    for i in range(args.nbatches):
-        seed = 1013 + 7919 * i + 104729 * rank
-        if args.model in ("cars", "m_match_tensor", "mnsrf"):
-            b = synth.session_batch(args.batch, args.session, args.cands, args.qlen, args.dlen, args.vocab, seed)
+    for i in range(nbatches):
+        seed = 1013 + 7919 * i + 104729 * rank_seed
+        if c["model"] in SESSION_MODELS:
+            b = synth.session_batch(c["batch"], c["session"], c["cands"], c["qlen"], c["dlen"], c["vocab"], seed)
         else:
-            b = synth.ranker_batch(args.batch, args.cands, args.qlen, args.dlen, args.vocab, seed, uniform=args.uniform)
+            b = synth.ranker_batch(c["batch"], c["cands"], c["qlen"], c["dlen"], c["vocab"], seed, uniform=c["uniform"])
         out.append({k: v.to(dev) for k, v in b.items()})
     return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    local = local % torch.cuda.device_count()   # (smoke-testing N ranks on a 1-GPU box maps them all to device 0)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": flow test without RCCL (gathers through the host)
-    dist = None
-    multi = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))   # BENCH_FORCE_DIST: 1-rank group, exercises the RCCL path
-    if multi:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+class Env(object):
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # (N ranks on a 1-GPU box share device 0)
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        self.backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": flow test without RCCL (gathers through the host)
+        self.dist = None
+        self.multi = self.world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+        if self.multi:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
 
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if not self.dist:
+            return x
+        t = torch.tensor([x], device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2d=False):
+    """Time one workload; returns the record dict (rank 0) or None."""
     L = lib.load()
-    model = build(args, dev)
-    batches = make_batches(args, rank, dev)
-    is_cars = args.model in ("cars", "m_match_tensor", "mnsrf")      # session-structured batch [B,S,N,DL]
-    pairs_per_step_rank = args.batch * args.cands * (args.session if is_cars else 1)
+    dev, world, rank = env.dev, env.world, env.rank
+    is_sess = c["model"] in SESSION_MODELS
+    sharded = shard and env.multi
+    model = build_model(c, args)
+    # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
+    batches = make_batches(c, args.nbatches, 0 if sharded or not env.multi else rank, dev)
+    pairs_global = c["batch"] * c["cands"] * (c["session"] if is_sess else 1)
+    ncand = c["cands"]
+    if sharded and is_sess:
+        model.parallelize()
+    if sharded and not is_sess:       # pre-slice this rank's candidate shard (resident in HBM like the full batch would be)
+        for b in batches:
+            b["doc_rep"], b["doc_len"] = sharding.shard_candidates(b["doc_rep"], b["doc_len"], world, rank)
 
     def forward(i):
-        """rank-local part of a step: network forward on this rank's candidate shard (captured into a hipGraph)."""
         ex = batches[i % len(batches)]
-        if is_cars:
-            return model.predict(ex)["click_scores"]
-        s = model.scores(ex)
-        if multi:
+        if is_sess:
+            return model.predict(ex, suggest=False)["click_scores"]
+        s = model.network(ex["que_rep"], ex["que_len"], ex["doc_rep"], ex["doc_len"])
+        if sharded:
             return s
         out = torch.empty_like(s)
         lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
         return out
+
+    lanes = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+    fbufs = [None] * len(lanes)
 
     def finish(s):
-        """cross-rank part (eager): one all-gather of the score shards, then the softmax over all candidates."""
-        if not multi or is_cars:
+        """cross-rank part of a ranker step (eager): one all-gather of the score shards, softmax over all candidates."""
+        if not sharded or is_sess:
             return s
-        if backend == "nccl":
-            # blocking gather into this lane's persistent buffer (the lane waits, the other lanes keep the GPU busy; a
-            # blocking collective also keeps torch's allocator free of cross-stream bookkeeping), then ONE kernel that
-            # does the softmax straight off the rank-major gather buffer
-            ln = lanes.index(torch.cuda.current_stream()) if torch.cuda.current_stream() in lanes else 0
+        if env.backend == "nccl":
+            cur = torch.cuda.current_stream()
+            ln = lanes.index(cur) if cur in lanes else 0
             if fbufs[ln] is None:
-                fbufs[ln] = (torch.empty(world * s.shape[0], s.shape[1], device=dev),
-                             torch.empty(s.shape[0], args.cands * world, device=dev))
+                fbufs[ln] = (torch.empty(world * s.shape[0], s.shape[1], device=dev), torch.empty(s.shape[0], ncand, device=dev))
             gbuf, probs = fbufs[ln]
-            dist.all_gather_into_tensor(gbuf, s.contiguous())
-            lib.check(L.nir_softmax_gathered(lib.ptr(gbuf), lib.ptr(probs), None, world, s.shape[0], s.shape[1],
-                                             args.cands * world, lib.stream()), "nir_softmax_gathered")
+            env.dist.all_gather_into_tensor(gbuf, s.contiguous())
+            lib.check(L.nir_softmax_gathered(lib.ptr(gbuf), lib.ptr(probs), None, world, s.shape[0], s.shape[1], ncand, lib.stream()),
+                      "nir_softmax_gathered")
             return probs
-        s = sharding.gather_scores(s.cpu(), args.cands * world).to(dev)
-        out = torch.empty_like(s)
-        lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
+        full = sharding.gather_scores(s.cpu(), ncand).to(dev)
+        out = torch.empty_like(full)
+        lib.check(L.nir_softmax_rows(lib.ptr(full), lib.ptr(out), full.shape[0], full.shape[1], lib.stream()), "softmax")
         return out
 
-    fbufs = []          # per-lane (gather buffer, probabilities), filled once the lanes exist
-
-    def step(i):
-        return finish(forward(i))
-
-    # ---- hipGraph replay of the rank-local forward (removes host launch overhead; the collective stays eager) ----
-    # Steps are independent batches, so `--streams` of them are kept in flight: step i runs on HIP stream (lane)
-    # i % streams.  One batch of 320 pairs cannot fill 256 CUs (the recurrence occupies 214 CUs with 4 waves each), a
-    # second batch's kernels co-run in the idle slots.  Every lane has its own workspace (lib.workspace keys on the
-    # stream) and its own captured graphs, so lanes share only read-only weights.
-    graphs = None
-    use_graph = not args.no_graph
-    lanes = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
-    fbufs.extend([None] * len(lanes))
-    # tell the library: with several batches in flight it drops its own query/document fork inside a batch (the side
-    # branch made the lanes' graphs compete for hardware queues: 2 lanes 1.66 M pairs/s with, 2.11 M without) and packs
-    # the recurrence into fuller workgroups (3.69 M vs 3.36 M at 4 lanes)
+    # several batches in flight: the library drops its own query/document fork and packs fuller workgroups
     L.nir_set_batches_in_flight(len(lanes))
-    lane_of = lambda i: (i % len(batches)) % len(lanes)   # noqa: E731  (a batch/graph always runs on the same lane)
+    lane_of = lambda i: (i % len(batches)) % len(lanes)   # noqa: E731
     torch.cuda.set_stream(lanes[0])
-    for i in range(max(3, min(args.warmup, 5)) * len(lanes)):
+    for i in range(max(2, min(warmup, 3)) * len(lanes)):
         with torch.cuda.stream(lanes[lane_of(i)]):
-            step(i)
+            finish(forward(i))
     torch.cuda.synchronize()
+    graphs = None
+    # the sharded CARS step contains a collective (all-gather of the pooled documents) between its kernels: replayed eagerly
+    use_graph = not args.no_graph and not (sharded and is_sess) and not (env.backend != "nccl" and env.multi)
     if use_graph:
         try:
             graphs = []
@@ -216,32 +296,9 @@ def main():
                     out = forward(i)
                 graphs.append((g, out))
         except Exception as e:  # pragma: no cover - graph capture is an optimisation only
-            print("[bench] graph capture unavailable (%s); timing eager launches" % e, file=sys.stderr)
+            print("[bench] graph capture unavailable for %s (%s); timing eager launches" % (name, e), file=sys.stderr)
             graphs = None
             torch.cuda.synchronize()
-
-    # N > 1 with ONE batch in flight: the score all-gather of step k is issued asynchronously (RCCL's own stream) and
-    # consumed one step later, so it overlaps step k+1's scoring kernels; `drain()` completes the last step inside the
-    # timed region.  With several lanes the other lanes already cover a lane's gather latency, and chaining every lane's
-    # deferred wait through the single RCCL stream measured slower (1-rank RCCL group: 0.122 vs 0.100 ms/step), so the
-    # lane simply waits for its own gather.  BENCH_ASYNC_GATHER=1 / BENCH_SYNC_GATHER=1 force either behaviour.
-    want_async = len(lanes) == 1 or bool(os.environ.get("BENCH_ASYNC_GATHER"))
-    pipelined = [multi and not is_cars and backend == "nccl" and want_async and not os.environ.get("BENCH_SYNC_GATHER")]
-    pending = [[] for _ in lanes]
-
-    # caller-owned gather / probability buffers, two per lane (a lane has at most one gather outstanding)
-    gbufs = [[None, None] for _ in lanes]
-    pbufs = [[None, None] for _ in lanes]
-    gparity = [0 for _ in lanes]
-
-    def drain(lane=None):
-        for ln in range(len(lanes)) if lane is None else [lane]:
-            with torch.cuda.stream(lanes[ln]):
-                while pending[ln]:
-                    h, par = pending[ln].pop(0)
-                    if pbufs[ln][par] is None:
-                        pbufs[ln][par] = torch.empty(h.B, h.N, device=dev)
-                    h.softmax(pbufs[ln][par])
 
     def run(i, only_lane=None):
         ln = lane_of(i) if only_lane is None else only_lane
@@ -251,55 +308,28 @@ def main():
                 g.replay()
             else:
                 out = forward(i)
-            if pipelined[0]:
-                try:
-                    par = gparity[ln]
-                    gparity[ln] ^= 1
-                    if gbufs[ln][par] is None:
-                        gbufs[ln][par] = torch.empty(world * out.shape[0], out.shape[1], device=dev)
-                    h = sharding.ScoreGather(out, args.cands * world, out=gbufs[ln][par])
-                except Exception as e:  # pragma: no cover - fall back to the blocking gather
-                    print("[bench] async all-gather unavailable (%s); using the blocking gather" % e, file=sys.stderr)
-                    pipelined[0] = False
-                    finish(out)
-                    return
-                drain(ln)
-                pending[ln].append((h, par))
-            else:
-                finish(out)
+            return finish(out)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         run(i)
-    drain()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         run(i)
-    drain()
-    host_ms = (time.perf_counter() - t0) / args.steps * 1e3     # host enqueue time per step (diagnostic)
+    host_ms = (time.perf_counter() - t0) / steps * 1e3
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    env.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    per_step_pairs = pairs_global if (sharded or not env.multi) else pairs_global * world
+    value = per_step_pairs * steps / elapsed
+    ms_per_step = elapsed / steps * 1e3
 
-    total_pairs = pairs_per_step_rank * world * args.steps
-    value = total_pairs / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
-
-    # for reference: the same steps strictly one after another on a single stream (per-batch latency), and a race check:
-    # the scores the concurrent replays left in the graphs' output buffers must equal a serial replay's bit for bit
-    single_ms = ms_per_step
-    overlap_diff = None
+    single_ms, overlap_diff = ms_per_step, None
     if len(lanes) > 1:
-        if graphs is not None and not pipelined[0]:
+        if graphs is not None and not sharded:
             conc = [out.clone() for _, out in graphs]
             torch.cuda.synchronize()
             overlap_diff = 0.0
@@ -307,27 +337,23 @@ def main():
                 g.replay()
                 torch.cuda.synchronize()
                 overlap_diff = max(overlap_diff, float((out - conc[j]).abs().max()))
-        ns = max(10, min(args.steps, 100))
+        ns = max(6, min(steps, 60))
         torch.cuda.synchronize()
+        env.barrier()
         ts = time.perf_counter()
         for i in range(ns):
             run(i, only_lane=0)
-        drain()
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - ts) / ns * 1e3
-        if dist:
-            dist.barrier()
+        env.barrier()
 
-    # ---- second number (never `value`): ids start in pinned HOST memory; every step copies them H2D into the static
-    # buffers of a captured hipGraph (context_attentive_ir_amd/graph_runner.py) and replays it
     h2d_value = None
-    if world == 1:
+    if with_h2d and world == 1 and not env.multi:
         try:
             from context_attentive_ir_amd.graph_runner import GraphedPredictor
-            gps = [GraphedPredictor(model, batches[0], queue_ahead=len(lanes) == 1) for _ in lanes]   # one predictor (stream + static inputs) per lane
-            # every batch packed into one pinned host buffer (what inputters.*_batchify produces): ONE H2D copy per step
+            gps = [GraphedPredictor(model, batches[0], queue_ahead=len(lanes) == 1) for _ in lanes]
             host = [gps[0].pack({k: v.cpu() for k, v in b.items()}) for b in batches]
-            nh = max(10, min(args.steps, 400))
+            nh = max(10, min(steps, 200))
             for i in range(3 * len(gps)):
                 gps[i % len(gps)].predict(host[i % len(host)], clone=False)
             torch.cuda.synchronize()
@@ -335,157 +361,214 @@ def main():
             for i in range(nh):
                 gps[i % len(gps)].predict(host[i % len(host)], clone=False)
             torch.cuda.synchronize()
-            h2d_value = pairs_per_step_rank * nh / (time.perf_counter() - th)
+            h2d_value = pairs_global * nh / (time.perf_counter() - th)
         except Exception as e:  # pragma: no cover - secondary figure only
             print("[bench] H2D-inclusive figure unavailable: %s" % e, file=sys.stderr)
 
-    # ---- profiled pass: HIP events around every kernel of the library, same workload -------------------
-    roofline = None
-    import ctypes
-    nprof = max(10, min(args.steps, 50))
-    os.environ["NIR_NO_FORK"] = "1"   # time every kernel in isolation (no query/document stream overlap)
+    # ---- profiled pass: HIP events around every kernel of the library, same workload, serial -------------------
+    torch.cuda.set_stream(lanes[0])
+    L.nir_set_batches_in_flight(1 if len(lanes) == 1 else len(lanes))
+    nprof = max(4, min(steps, 30))
+    L.nir_debug_set_tunable(b"no_fork", 1)          # time every kernel in isolation (no query/document stream overlap)
     if rank == 0:
         L.nir_profile_enable(1)
-    for i in range(nprof):            # every rank runs the steps (the all-gather is collective); rank 0 records
-        step(i)
+    for i in range(nprof):
+        finish(forward(i))
     torch.cuda.synchronize()
     L.nir_profile_enable(0)
-    os.environ.pop("NIR_NO_FORK", None)
+    L.nir_debug_set_tunable(b"no_fork", 0)
+    roofline = None
     if rank == 0:
-        buf = ctypes.create_string_buffer(1 << 16)
+        buf = ctypes.create_string_buffer(1 << 17)
         L.nir_profile_report(buf, len(buf))
         kern = {}
         for line in buf.value.decode().strip().splitlines():
-            name, cnt, ms = line.rsplit(",", 2)
-            kern[name] = (int(cnt), float(ms))
+            kname, cnt, ms = line.rsplit(",", 2)
+            kern[kname] = (int(cnt), float(ms))
         if kern:
             dom = max(kern, key=lambda k: kern[k][1])
             cnt, ms = kern[dom]
-            launches_per_step = cnt / nprof
             avg_us = ms / cnt * 1e3
-            roofline = {"kernel": dom, "avg_us": round(avg_us, 3), "launches_per_step": launches_per_step,
-                        "kernels_us_per_step": {k: round(v[1] / nprof * 1e3, 2) for k, v in sorted(kern.items())}}
-            work = kernel_work(dom, args.batch, args.cands, args.qlen, args.dlen) if args.model == "match_tensor" else None
+            roofline = {"kernel": dom, "avg_us": round(avg_us, 3), "launches_per_step": cnt / nprof,
+                        "kernels_us_per_step": {k: round(v[1] / nprof * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
+            cc = dict(c)
+            if sharded and not is_sess:
+                cc["cands"] = batches[0]["doc_rep"].shape[1]
+            work = kernel_work(dom, cc)
             if work:
-                fl = work["flops"] / launches_per_step
-                by = work["bytes"] / launches_per_step
-                tf = fl / (avg_us * 1e-6) / 1e12
-                gbs = by / (avg_us * 1e-6) / 1e9
-                if fl / by > PEAK_FP32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
-                    roofline.update(bound="mfma", achieved=round(tf, 4), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s",
-                                    frac=round(tf / PEAK_FP32_TFLOPS, 5))
+                tf = work["flops"] / (avg_us * 1e-6) / 1e12
+                gbs = work["bytes"] / (avg_us * 1e-6) / 1e9
+                if work["flops"] / work["bytes"] > work["peak"] * 1e12 / (PEAK_HBM_GBS * 1e9):
+                    roofline.update(bound="mfma", achieved=round(tf, 4), peak=round(work["peak"], 1), unit="TFLOP/s", frac=round(tf / work["peak"], 5))
                 else:
-                    roofline.update(bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                                    frac=round(gbs / PEAK_HBM_GBS, 5))
-                roofline["alg_flops_per_launch"] = fl
-                roofline["alg_bytes_per_launch"] = by
-            elif args.model in ("esm", "drmm"):
-                by = algorithmic_bytes_per_pair(args.cands, args.qlen, args.dlen) * args.batch * args.cands
-                gbs = by / (avg_us * 1e-6) / 1e9
-                roofline.update(bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                                frac=round(gbs / PEAK_HBM_GBS, 5), alg_bytes_per_launch=by)
-                if gbs > PEAK_HBM_GBS:
-                    roofline["note"] = ("algorithmic bytes/s above the HBM peak: repeated (Zipf) ids are served from L2/MALL, "
-                                        "not HBM; run with --uniform --vocab 2000000 for the HBM-resident figure")
-            # HBM bytes per launch from the committed PMC capture of this same workload (profiles/traffic.json:
-            # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction); null when no capture matches
+                    roofline.update(bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5))
+                roofline["alg_flops_per_launch"] = work["flops"]
+                roofline["alg_bytes_per_launch"] = work["bytes"]
+                if roofline["bound"] == "hbm" and gbs > PEAK_HBM_GBS:
+                    roofline["note"] = "algorithmic bytes/s above the HBM peak: repeated (Zipf) ids are served from L2/MALL, not HBM"
+            # HBM bytes per launch from the committed PMC capture of this same workload (profiles/traffic.json: separate
+            # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction); null when no capture matches
             roofline["traffic"] = None
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                default_wl = (args.model, args.batch, args.cands, args.qlen, args.dlen) == ("match_tensor", 32, 10, 4, 64)
-                if default_wl and dom in tj["kernels"]:
-                    roofline["traffic"] = tj["kernels"][dom]["bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
+                ent = traffic_entry(tj.get("configs", {}).get(name, {}), dom)
+                if ent and not sharded:
+                    roofline["traffic"] = ent["bytes_per_launch"]
+            except (OSError, ValueError, KeyError, AttributeError):
                 pass
-            # whole-step HBM fraction BASELINE.json asks for (algorithmic bytes of SURVEY.md 8d x pairs/s)
-            bpp = algorithmic_bytes_per_pair(args.cands, args.qlen, args.dlen)
-            roofline["step_hbm_GBps"] = round(value / world * bpp / 1e9, 2)
-            roofline["step_hbm_frac"] = round(value / world * bpp / 1e9 / PEAK_HBM_GBS, 5)
-            # ... and "FLOP/s / peak next to it" (SURVEY.md 8d): algorithmic flops per pair of the reference's op
-            # sequence at the named config shapes (MatchTensor C2 1.76e7, CARS C3 6.72e7, DUET C4 2.08e8, DRMM C4 8.7e5)
-            named = {("match_tensor", 4, 64): 1.76e7, ("m_match_tensor", 4, 64): 1.76e7, ("cars", 4, 64): 6.72e7,
-                     ("duet", 4, 290): 2.08e8, ("drmm", 4, 290): 8.7e5}
-            fpp = named.get((args.model, args.qlen, args.dlen))
+            bpp = algorithmic_bytes_per_pair(c["cands"], c["qlen"], c["dlen"])
+            roofline["step_hbm_GBps"] = round(value * bpp / 1e9 / (1 if sharded or not env.multi else world), 2)
+            roofline["step_hbm_frac"] = round(roofline["step_hbm_GBps"] / PEAK_HBM_GBS, 5)
+            fpp = flops_per_pair(c["model"], c["qlen"], c["dlen"])
             if fpp:
-                roofline["step_alg_TFLOPs"] = round(value / world * fpp / 1e12, 2)
-                roofline["step_flop_frac"] = round(value / world * fpp / 1e12 / PEAK_FP32_TFLOPS, 5)
+                roofline["step_alg_TFLOPs"] = round(value * fpp / 1e12, 2)
+                roofline["step_flop_frac_of_fp32_peak"] = round(value * fpp / 1e12 / PEAK_FP32_TFLOPS / (world if env.multi else 1), 5)
 
-    # ---- CPU baseline: the oracle (pinned port of the reference) on the host cores ---------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import neuroir_cpu as O
-        sd = {k: v.detach().cpu().float() for k, v in model.network.state_dict().items()}
-        ex = {k: v.cpu() for k, v in batches[0].items()}
-        ncores = torch.get_num_threads()
-        if args.model == "mnsrf":
-            fn = lambda: torch.softmax(O.mnsrf_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)  # noqa: E731
-        elif args.model == "m_match_tensor":
-            fn = lambda: torch.softmax(O.m_match_tensor_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)  # noqa: E731
-        elif is_cars:
-            fn = lambda: O.predict_softmax(O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"]))  # noqa: E731
+    if want_cpu and rank == 0 and not env.multi and not args.no_cpu_baseline:
+        cpu = cpu_baseline(c, model, batches, lambda: finish(forward(0)), pairs_global, args)
+    L.nir_set_batches_in_flight(1)
+    if rank != 0:
+        return None
+    tag = "%s, batch=%d%s x %d candidates, q_len=%d, doc_len=%d, emb_dim=300, vocab=%d, %s, full-length %s ids" % (
+        c["model"], c["batch"], (" sessions x session_len %d" % c["session"]) if is_sess else " queries", c["cands"], c["qlen"], c["dlen"],
+        c["vocab"], c.get("dtype", "f32"), "uniform" if c["uniform"] else "Zipf")
+    par = "single GPU"
+    if env.multi:
+        if not sharded:
+            par = "x%d independent per-rank batches, no collective (weak scaling)" % world
+        elif is_sess:
+            par = "strong: candidate-sharded document encoding x%d (Multitask.parallelize) + RCCL all-gather of pooled documents, session part replicated" % world
         else:
-            f = O.MODEL_FNS[args.model.upper()]
-            fn = lambda: O.predict_softmax(f(sd, ex["que_rep"], ex["que_len"], ex["doc_rep"], ex["doc_len"]))  # noqa: E731
-        ref = fn()
-        gpu = step(0).cpu()
-        maxdiff = float((gpu - ref.view_as(gpu)).abs().max())
-        # be fair to the CPU: tiny per-op tensors oversubscribe a big host, so probe a few thread counts first
-        avail = os.cpu_count() or ncores
-        best_t, best_rate = ncores, 0.0
-        for t in sorted({min(avail, c) for c in (8, 16, 32, 64)}):
-            torch.set_num_threads(t)
-            fn()
-            n0, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < 0.75:
-                fn(); n0 += 1
-            rate = n0 / (time.perf_counter() - t0)
-            if rate > best_rate:
-                best_t, best_rate = t, rate
-        torch.set_num_threads(best_t)
-        n, t1 = 0, time.perf_counter()
-        while True:
-            fn()
-            n += 1
-            dt = time.perf_counter() - t1
-            if dt > args.cpu_seconds or n >= 5000:
-                break
-        cpu = {"value": round(n * pairs_per_step_rank / dt, 1), "unit": "pairs/s", "cores": best_t, "kind": "port",
-               "sample": "%d batches of the same %s workload in %.1f s (oracle/neuroir_cpu.py = pinned port of the reference, "
-                         "torch %s CPU, best of {8,16,32,64} threads = %d; host has %d logical cores)"
-                         % (n, args.model, dt, torch.__version__, best_t, avail),
-               "max_abs_diff_vs_gpu_softmax": maxdiff}
+            par = "strong: candidate-sharded x%d (%d per rank) + RCCL all-gather of scores" % (world, batches[0]["doc_rep"].shape[1])
+    return {"name": name, "baseline_config": c.get("baseline"), "workload": tag, "pairs_per_s": round(value, 1), "ms_per_step": round(ms_per_step, 5),
+            "ms_per_step_one_batch_in_flight": round(single_ms, 5), "global_batch_pairs": per_step_pairs, "parallelism": par, "world_size": world,
+            "steps": steps, "hipgraph": graphs is not None, "batches_in_flight": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
+            "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
+            "dtype": c.get("dtype", "f32"), "roofline": roofline, "cpu_baseline": cpu}
 
-    if rank == 0:
-        cfg = {"workload": "%s ranker, batch=%d queries x %d candidates%s, q_len=%d, doc_len=%d, emb_dim=300, vocab=%d, fp32, full-length %s ids"
-                           % (args.model, args.batch * (world if is_cars else 1), args.cands * (1 if is_cars else world), (" x session %d" % args.session) if is_cars else "",
-                              args.qlen, args.dlen, args.vocab, "uniform" if args.uniform else "Zipf"),
-               "global_batch_pairs": pairs_per_step_rank * world,
-               "parallelism": "single GPU" if world == 1 else
-                              ("x%d independent per-rank session batches, no collective (sharded CARS = Multitask.parallelize)" % world)
-                              if is_cars else ("candidate-sharded x%d + RCCL all-gather of scores%s"
-                                               % (world, " (async, consumed one step later)" if pipelined[0] else "")),
-               "hipgraph": graphs is not None,
-               "batches_in_flight": len(lanes),
-               "host_enqueue_ms_per_step": round(host_ms, 5),
-               "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-               "ms_per_step_one_batch_in_flight": round(single_ms, 5),
-               "overlapped_vs_serial_max_abs_diff": overlap_diff,
-               "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1)}
-        line = {"metric": "ranked (query,doc) pairs/sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
-                "roofline": roofline, "cpu_baseline": cpu}
-        result_line = json.dumps(line)
+
+def cpu_baseline(c, model, batches, gpu_step, pairs, args):
+    from oracle import neuroir_cpu as O
+    sd = {k: v.detach().cpu().float() for k, v in model.network.state_dict().items()}
+    ex = {k: v.cpu() for k, v in batches[0].items()}
+    ncores = torch.get_num_threads()
+    m = c["model"]
+    if m == "mnsrf":
+        fn = lambda: torch.softmax(O.mnsrf_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)  # noqa: E731
+    elif m == "m_match_tensor":
+        fn = lambda: torch.softmax(O.m_match_tensor_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)  # noqa: E731
+    elif m == "cars":
+        fn = lambda: O.predict_softmax(O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"]))  # noqa: E731
     else:
-        result_line = None
-    if dist:
-        dist.destroy_process_group()
+        f = O.MODEL_FNS[m.upper()]
+        fn = lambda: O.predict_softmax(f(sd, ex["que_rep"], ex["que_len"], ex["doc_rep"], ex["doc_len"]))  # noqa: E731
+    ref = fn()
+    gpu = gpu_step().cpu()
+    maxdiff = float((gpu - ref.view_as(gpu)).abs().max())
+    avail = os.cpu_count() or ncores
+    best_t, best_rate = ncores, 0.0
+    for t in sorted({min(avail, k) for k in (8, 16, 32, 64)}):    # tiny per-op tensors oversubscribe a big host: probe thread counts
+        torch.set_num_threads(t)
+        fn()
+        n0, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 0.75:
+            fn(); n0 += 1
+        rate = n0 / (time.perf_counter() - t0)
+        if rate > best_rate:
+            best_t, best_rate = t, rate
+    torch.set_num_threads(best_t)
+    n, t1 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t1
+        if dt > args.cpu_seconds or n >= 5000:
+            break
+    return {"value": round(n * pairs / dt, 1), "unit": "pairs/s", "cores": best_t, "kind": "port",
+            "sample": "%d batches of the same %s workload in %.1f s (oracle/neuroir_cpu.py = pinned port of the reference, torch %s CPU, "
+                      "best of {8,16,32,64} threads = %d; host has %d logical cores)" % (n, m, dt, torch.__version__, best_t, avail),
+            "max_abs_diff_vs_gpu_softmax": maxdiff}
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    env = Env()
+    assert env.world == args.gpus or env.world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    head = dict(CONFIGS[args.config])
+    adhoc = False
+    for k in ("model", "batch", "cands", "qlen", "dlen", "session", "vocab", "uniform", "dtype"):
+        v = getattr(args, k)
+        if v is not None:
+            head[k] = v
+            adhoc = True
+    if head["model"] in SESSION_MODELS:
+        head.setdefault("session", 7)
+    hname = args.config if not adhoc else "adhoc_" + head["model"]
+    rec = run_config(hname, head, args, env, args.steps, args.warmup, shard=True, want_cpu=True, with_h2d=True)
+
+    sub = {}
+    names = [] if adhoc else [n for n in CONFIGS if n != args.config]
+    if args.sub is not None:
+        names = [] if args.sub == "none" else [n for n in args.sub.split(",") if n in CONFIGS]
+    for n in names:
+        try:
+            r = run_config(n, dict(CONFIGS[n]), args, env, SUB_STEPS.get(n, 100), min(args.warmup, 8), shard=True)
+        except Exception as e:  # a sub-record must never take the headline down
+            r = {"name": n, "error": "%s: %s" % (type(e).__name__, e)} if env.rank == 0 else None
+            torch.cuda.synchronize()
+        if r is not None:
+            sub[n] = r
+        torch.cuda.empty_cache()
+    if head["model"] == "cars" and not adhoc and args.sub != "none" and not env.multi:
+        sub["C3_cars_with_decode"] = decode_record(head, args, env)
+    weak = None
+    if env.multi:           # labelled secondary number: every rank scores its own full batch, no collective
+        r = run_config(hname + "_weak", head, args, env, max(20, args.steps // 4), min(args.warmup, 8), shard=False)
+        weak = r["pairs_per_s"] if r else None
+
+    result_line = None
+    if env.rank == 0:
+        roof = rec.pop("roofline")
+        cpu = rec.pop("cpu_baseline")
+        cfg = dict(rec)
+        cfg["hw_queues"] = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        cfg["weak_scaling_pairs_per_s"] = weak
+        cfg["sub"] = sub
+        line = {"metric": "ranked (query,doc) pairs/sec", "value": rec["pairs_per_s"], "unit": "pairs/s", "n_gpus": env.world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+                "scaling": "strong" if env.multi else "weak", "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
+                "config": cfg, "roofline": roof, "cpu_baseline": cpu}
+        result_line = json.dumps(line)
+    if env.dist:
+        env.dist.destroy_process_group()
     # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it out first so that the
     # JSON line is the LAST line of rank 0's stdout
-    import ctypes as _ct
-    _ct.CDLL(None).fflush(None)
+    ctypes.CDLL(None).fflush(None)
     if result_line is not None:
         print(result_line, flush=True)
+
+
+def decode_record(c, args, env):
+    """Full Multitask.predict (ranking + greedy suggestion decode, models/multitask.py:229-317) on the headline workload."""
+    try:
+        model = build_model(c, args)
+        batches = make_batches(c, 4, 0, env.dev)
+        for i in range(3):
+            model.predict(batches[i % 4])
+        torch.cuda.synchronize()
+        n, t0 = 20, time.perf_counter()
+        for i in range(n):
+            model.predict(batches[i % 4])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        pairs = c["batch"] * c["session"] * c["cands"]
+        return {"workload": "headline batch through the full predict: ranking + greedy decode of max_query_len tokens", "ms_per_step": round(dt * 1e3, 4),
+                "pairs_per_s": round(pairs / dt, 1), "suggested_queries_per_s": round(c["batch"] * (c["session"] - 1) / dt, 1), "eager": True}
+    except Exception as e:  # pragma: no cover
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 if __name__ == "__main__":

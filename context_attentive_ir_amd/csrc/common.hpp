@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/neuroir_hip.h"
 
 namespace nir {
@@ -43,8 +44,8 @@ struct ProfScope {
     ~ProfScope();
 };
 
-// Interned "name[M=..,N=..,K=..]" label for shape-resolved profiles (NIR_PROFILE_SHAPES=1 at load time); returns `base`
-// unchanged otherwise.  The returned pointer stays valid for the life of the process.
+// Interned "name[M=..,N=..,K=..]" label (recurrences: M sequences, N = T steps, K = H units) while profiling is enabled --
+// bench.py prices every launch by its own shape; returns `base` unchanged otherwise.  The returned pointer stays valid for the life of the process.
 const char* prof_shape_name(const char* base, long long M, long long N, long long K);
 
 // Fork/join helper: independent kernel chains of one C-ABI call (e.g. the query side and the document side of a
@@ -61,7 +62,20 @@ struct ForkJoin {
 
 // Optional device debug buffer (nir_debug_set_buffer): kernels that support it drop s_memtime stamps there.
 extern unsigned long long* g_debug_buf;
-extern int g_batches_in_flight;   // nir_set_batches_in_flight(): > 1 -> favour chip throughput over single-call latency
+// Scheduling hint of the caller: how many independent batches it keeps in flight (nir_set_batches_in_flight: process default;
+// nir_set_stream_batches_in_flight: per stream, overrides the default for calls enqueued on that stream).  > 1 -> favour chip
+// throughput over single-call latency.  Reads are lock-free for the default, one mutex-protected map lookup per C-ABI call
+// when per-stream hints exist.
+int batches_in_flight(hipStream_t st);
+
+// Tuning / debug switches.  Initialised ONCE from the environment when the library is loaded (NIR_NO_FORK, NIR_LSTM_VALU,
+// NIR_LSTM_MFMA16, NIR_LSTM_MFMA_S, NIR_LSTM_S, NIR_NO_SKINNY, NIR_NO_GEMM16, NIR_ESM_WAVE_ROWS, NIR_DEBUG, NIR_EXACT_F32);
+// nir_debug_set_tunable changes one at run time (tests, profilers).  Hot entry points only do relaxed atomic loads.
+struct Tunables {
+    std::atomic<int> no_fork, lstm_valu, lstm_mfma16, lstm_mfma_s, lstm_s, no_skinny, no_gemm16, esm_wave_rows, debug, exact_f32;
+};
+extern Tunables g_tun;
+inline int tun(const std::atomic<int>& a) { return a.load(std::memory_order_relaxed); }
 
 constexpr int WAVE = 64;
 

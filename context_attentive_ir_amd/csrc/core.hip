@@ -24,9 +24,8 @@ static std::mutex g_prof_mu;
 static std::vector<ProfRec*> g_prof;
 static std::atomic<int> g_prof_on{0};
 
-static const bool g_prof_shapes = getenv("NIR_PROFILE_SHAPES") != nullptr;   // read once, at library load
 const char* prof_shape_name(const char* base, long long M, long long N, long long K) {
-    if (!g_prof_shapes || !g_prof_on.load(std::memory_order_relaxed)) return base;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return base;
     static std::mutex mu;
     static std::map<std::string, std::string*> names;
     char buf[160];
@@ -96,7 +95,7 @@ static std::mutex g_side_mu;
 static std::map<std::pair<int, hipStream_t>, SideRes> g_side;   // one side stream + event pair per (device, caller stream)
 
 ForkJoin::ForkJoin(hipStream_t main_stream) : main(main_stream), side(main_stream), ev_fork(nullptr), ev_join(nullptr), ok(false) {
-    if (getenv("NIR_NO_FORK") || g_batches_in_flight > 1) return;
+    if (tun(g_tun.no_fork) || batches_in_flight(main_stream) > 1) return;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lk(g_side_mu);
@@ -119,11 +118,50 @@ void ForkJoin::join() {
 }
 }  // namespace nir
 
-namespace nir { unsigned long long* g_debug_buf = nullptr; int g_batches_in_flight = 1; }
+namespace nir {
+unsigned long long* g_debug_buf = nullptr;
+static std::atomic<int> g_bif_default{1};
+static std::atomic<int> g_bif_streams{0};                 // number of per-stream entries (0 -> skip the map lookup)
+static std::mutex g_bif_mu;
+static std::map<hipStream_t, int> g_bif_map;
+int batches_in_flight(hipStream_t st) {
+    if (g_bif_streams.load(std::memory_order_relaxed)) {
+        std::lock_guard<std::mutex> lk(g_bif_mu);
+        auto it = g_bif_map.find(st);
+        if (it != g_bif_map.end()) return it->second;
+    }
+    return g_bif_default.load(std::memory_order_relaxed);
+}
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? (e[0] ? atoi(e) : 1) : dflt;
+}
+static int env_flag(const char* name) { return getenv(name) ? 1 : 0; }
+Tunables g_tun{{env_flag("NIR_NO_FORK")}, {env_flag("NIR_LSTM_VALU")}, {env_int("NIR_LSTM_MFMA16", -1)}, {env_int("NIR_LSTM_MFMA_S", 0)},
+               {env_int("NIR_LSTM_S", 0)}, {env_flag("NIR_NO_SKINNY")}, {env_flag("NIR_NO_GEMM16")}, {env_flag("NIR_ESM_WAVE_ROWS")},
+               {env_flag("NIR_DEBUG")}, {env_flag("NIR_EXACT_F32")}};
+}  // namespace nir
 extern "C" int nir_set_batches_in_flight(int n) {
-    const int old = nir::g_batches_in_flight;
-    nir::g_batches_in_flight = n < 1 ? 1 : n;
-    return old;
+    return nir::g_bif_default.exchange(n < 1 ? 1 : n);
+}
+extern "C" int nir_set_stream_batches_in_flight(nir_stream_t stream, int n) {
+    std::lock_guard<std::mutex> lk(nir::g_bif_mu);
+    if (n < 1) nir::g_bif_map.erase((hipStream_t)stream);
+    else nir::g_bif_map[(hipStream_t)stream] = n;
+    nir::g_bif_streams.store((int)nir::g_bif_map.size());
+    return 0;
+}
+extern "C" int nir_debug_set_tunable(const char* name, int value) {
+    using namespace nir;
+    if (!name) return NIR_ERR_BAD_ARG;
+    struct { const char* n; std::atomic<int>* a; } tab[] = {
+        {"no_fork", &g_tun.no_fork}, {"lstm_valu", &g_tun.lstm_valu}, {"lstm_mfma16", &g_tun.lstm_mfma16}, {"lstm_mfma_s", &g_tun.lstm_mfma_s},
+        {"lstm_s", &g_tun.lstm_s}, {"no_skinny", &g_tun.no_skinny}, {"no_gemm16", &g_tun.no_gemm16}, {"esm_wave_rows", &g_tun.esm_wave_rows},
+        {"debug", &g_tun.debug}, {"exact_f32", &g_tun.exact_f32}};
+    for (auto& t : tab)
+        if (!strcmp(t.n, name)) { t.a->store(value); return 0; }
+    set_error("nir_debug_set_tunable: unknown tunable '%s'", name);
+    return NIR_ERR_BAD_ARG;
 }
 extern "C" int nir_debug_set_buffer(void* dev_u64) { nir::g_debug_buf = (unsigned long long*)dev_u64; return 0; }
 

@@ -293,7 +293,7 @@ extern "C" int nir_esm_score(const int64_t* q_ids, const int64_t* d_ids, int B, 
     NIR_REQUIRE(E % 4 == 0 && E > 0 && E <= 256 * MAXCH, "esm: emsize %d unsupported (multiple of 4, <= %d)", E, 256 * MAXCH);
     NIR_REQUIRE(((uintptr_t)table & 15) == 0, "esm: table must be 16-byte aligned");
     if (B == 0) return 0;
-    if (E <= 320 && !getenv("NIR_ESM_WAVE_ROWS")) {
+    if (E <= 320 && !tun(g_tun.esm_wave_rows)) {
         ProfScope ps("esm16_kernel", (hipStream_t)stream);
         hipLaunchKernelGGL(esm16_kernel<5>, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q_ids, d_ids, N, QL, DL,
                            table, E, scores);

@@ -9,6 +9,7 @@
 // is permuted identically for A and W (lane>>5 selects which half), which leaves the sum unchanged.
 #include "common.hpp"
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
 
 namespace nir {
@@ -606,11 +607,8 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
 
 template <int NT>
 static void launch_skinny(const GemmArgs& p, int G, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm_skinny_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_done = true;
-    }
+    static std::once_flag once;       // one-time opt-in to > 64 KB of dynamic LDS, race-free
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); });
     const int64_t ntiles = (p.M + 15) / 16;
     const unsigned grid = (unsigned)std::min<int64_t>((ntiles + SK_WAVES - 1) / SK_WAVES, 512);
     hipLaunchKernelGGL(gemm_skinny_kernel<NT>, dim3(grid), dim3(64 * SK_WAVES), lds, st, p, G);
@@ -651,7 +649,7 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     const int nb = (N + BN - 1) / BN;
     const int skG = (K + 15) / 16, skNT = (N + 15) / 16;
     const size_t sk_lds = (size_t)16 * skNT * (skG * 16 + 4) * 4;
-    static const bool exact_f32 = getenv("NIR_EXACT_F32") != nullptr;    // read once: force the f32-MFMA kernels everywhere
+    const bool exact_f32 = tun(g_tun.exact_f32) != 0;                    // force the f32-MFMA kernels everywhere
     const int64_t mb3 = (M + G3_BM - 1) / G3_BM;
     const int nb3 = (N + G3_BN - 1) / G3_BN;
     const int mode3 = !ids ? 0 : (K <= E ? 1 : (K <= 3 * E ? 2 : -1));
@@ -666,13 +664,13 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
         NIR_CHECK_LAUNCH("nir_linear_f32[bf16x3]");
         return 0;
     }
-    if (N <= 64 && vec && M >= 4096 && (!ids || K <= E) && sk_lds <= 128 * 1024 && act != ACT_MAXOUT2 && act != ACT_TANH_ROWDOT16 && !getenv("NIR_NO_SKINNY")) {
+    if (N <= 64 && vec && M >= 4096 && (!ids || K <= E) && sk_lds <= 128 * 1024 && act != ACT_MAXOUT2 && act != ACT_TANH_ROWDOT16 && !tun(g_tun.no_skinny)) {
         ProfScope ps(prof_shape_name(ids ? "gemm_skinny_kernel[gather]" : "gemm_skinny_kernel", M, N, K), st);
         if (skNT == 1) launch_skinny<1>(p, skG, sk_lds, st);
         else if (skNT == 2) launch_skinny<2>(p, skG, sk_lds, st);
         else if (skNT == 3) launch_skinny<3>(p, skG, sk_lds, st);
         else launch_skinny<4>(p, skG, sk_lds, st);
-    } else if (mb * nb < 160 && !getenv("NIR_NO_GEMM16")) {
+    } else if (mb * nb < 160 && !tun(g_tun.no_gemm16)) {
         // too few 64x64 tiles to fill 256 CUs: one 16x16 tile per workgroup, K split over the waves
         ProfScope ps(prof_shape_name(ids ? "gemm16_kernel[gather]" : "gemm16_kernel", M, N, K), st);
         dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16));
@@ -681,12 +679,11 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     } else {
         ProfScope ps(prof_shape_name(ids ? "gemm_kernel[gather]" : "gemm_kernel", M, N, K), st);
         constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * 4;   // 36864 B at BK = 32 (the opt-in only matters for BK = 64)
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
         dim3 grid((unsigned)(8 * nb * ((mb + 7) / 8)));
         if (vec) hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), lds, st, p);

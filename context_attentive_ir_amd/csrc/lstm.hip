@@ -302,13 +302,13 @@ static int launch_one(const LstmArgs& p, hipStream_t st) {
             return (int)e;
         }
     }
-    if (getenv("NIR_DEBUG")) {
+    if (tun(g_tun.debug)) {
         int nb = -1;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lstm_rec_kernel<KP, S, IP>, 4 * KP, lds);
         fprintf(stderr, "[nir] %s S=%d: grid=%lld x %d, block=%d, lds=%zu B, max active blocks/CU=%d\n", pname.c_str(), S,
                 (long long)((p.M + S - 1) / S), p.ND, 4 * KP, lds, nb);
     }
-    ProfScope ps(pname.c_str(), st);
+    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
     hipLaunchKernelGGL((lstm_rec_kernel<KP, S, IP>), dim3((unsigned)((p.M + S - 1) / S), (unsigned)p.ND), dim3(4 * KP), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fwd");
     return 0;
@@ -358,8 +358,8 @@ static int pick_s(int64_t seqdirs, bool fused) {
         const double cost = rounds * (0.85 + 0.29 * S);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
     }
-    if (const char* ov = getenv("NIR_LSTM_S")) {  // tuning override
-        int v = atoi(ov);
+    {   // tuning override
+        const int v = tun(g_tun.lstm_s);
         if (v == 1 || v == 2 || v == 3 || v == 4 || v == 8) best = v;
     }
     if (fused && best > 4) best = 4;
@@ -377,12 +377,12 @@ int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const
     // M = 1120 353 vs 439 us, M = 22400 3.86 vs 7.06 ms).  Below that: the quad/VALU kernel when its workgroup fills the
     // 4 SIMDs evenly (KP/16 waves a multiple of 4: H = 128 439 us vs 520 us for the 4x4x1 layout at M = 1120), the
     // 4x4x1-MFMA recurrence for the unbalanced sizes (H = 70: 5 waves).
-    if (!getenv("NIR_LSTM_VALU")) {   // many sequences, wide H: 16 sequences per workgroup on 16x16x4 MFMAs
+    if (!tun(g_tun.lstm_valu)) {   // many sequences, wide H: 16 sequences per workgroup on 16x16x4 MFMAs
         int rc = launch_bilstm_mfma16(gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, st);
         if (rc != NIR_ERR_UNSUPPORTED) return rc;
     }
     const bool valu_balanced = (((H + 15) / 16) % 4) == 0;
-    if (!valu_balanced && !getenv("NIR_LSTM_VALU")) {
+    if (!valu_balanced && !tun(g_tun.lstm_valu)) {
         int rc = launch_bilstm_mfma(gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, st);
         if (rc != NIR_ERR_UNSUPPORTED) return rc;
     }
@@ -401,7 +401,7 @@ int launch_bilstm_fused(const float* x, int I, const float* wih, const float* bi
     NIR_REQUIRE(M >= 0 && T > 0 && (ND == 1 || ND == 2), "bilstm_fused: bad dims");
     NIR_REQUIRE(H >= 1 && H <= 128 && I >= 1 && I <= 64, "bilstm_fused: H=%d (1..128) / I=%d (1..64) unsupported", H, I);
     if (M == 0) return 0;
-    if (!getenv("NIR_LSTM_VALU")) {   // matrix-core recurrence (lstm_mfma.hip) when the shape has an instantiation
+    if (!tun(g_tun.lstm_valu)) {   // matrix-core recurrence (lstm_mfma.hip) when the shape has an instantiation
         int rc = launch_bilstm_fused_mfma(x, I, wih, bih, bhh, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, st);
         if (rc != NIR_ERR_UNSUPPORTED) return rc;
     }

@@ -362,7 +362,7 @@ template <int G, int NT>
 static int launch_pt(const LstmPtArgs& p, hipStream_t st) {
     static const std::string pname = "lstm16_pt_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
     const size_t lds = (size_t)(2 * 16 * (16 * G + 4)) * 4 + 16 * 4 + (size_t)16 * p.T * 4;
-    ProfScope ps(pname.c_str(), st);
+    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
     hipLaunchKernelGGL((lstm16_pt_kernel<G, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f32]");
     return 0;
@@ -371,7 +371,7 @@ template <int KB, int NT>
 static int launch_pt_bf16(const LstmPtArgs& p, hipStream_t st) {
     static const std::string pname = "lstm16_pt_bf16_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + ">";
     const size_t lds = (size_t)(2 * 16 * (32 * KB + 8)) * 2 + 16 * 4 + (size_t)16 * p.T * 4;
-    ProfScope ps(pname.c_str(), st);
+    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
     hipLaunchKernelGGL((lstm16_pt_bf16_kernel<KB, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[bf16]");
     return 0;

@@ -380,7 +380,7 @@ template <int NG, int KQ, int NWC>
 static int launch_mfma_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
     static const std::string pname = "lstm_mfma_gin_kernel<" + std::to_string(NG) + "," + std::to_string(KQ) + "," + std::to_string(NWC) + ">";
     constexpr size_t lds = (size_t)(2 * 4 * 4 * KQ + 4 * 64 * NG * NWC * 4) * 4;
-    ProfScope ps(pname.c_str(), st);
+    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
     hipLaunchKernelGGL((lstm_mfma_gin_kernel<NG, KQ, NWC>), dim3((unsigned)((p.M + 3) / 4), (unsigned)p.ND), dim3(256 * NWC), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fwd[mfma]");
     return 0;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(1024) void lstm_mfma16_gin_kernel(LstmMfmaGinArgs p
 template <int G, int NT>
 static int launch_mfma16_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
     static const std::string pname = "lstm_mfma16_gin_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
-    ProfScope ps(pname.c_str(), st);
+    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
     hipLaunchKernelGGL((lstm_mfma16_gin_kernel<G, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), 0, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fwd[mfma16]");
     return 0;
@@ -563,8 +563,8 @@ static int launch_mfma16_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
 // kernel spreads a small batch over more CUs).  NIR_LSTM_MFMA16=0/1 forces it off/on.
 int launch_bilstm_mfma16(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
                          float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st) {
-    const char* f = getenv("NIR_LSTM_MFMA16");
-    if (f ? atoi(f) == 0 : ((M + 15) / 16) * ND < 128) return NIR_ERR_UNSUPPORTED;
+    const int f = tun(g_tun.lstm_mfma16);       // -1 auto, 0 off, 1 forced
+    if (f >= 0 ? f == 0 : ((M + 15) / 16) * ND < 128) return NIR_ERR_UNSUPPORTED;
     if (H < 33 || H > 128 || (int64_t)16 * T * ND * 4 * H * 4 >= 0x7FFFFFF0LL) return NIR_ERR_UNSUPPORTED;
     LstmMfmaGinArgs p{gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND};
     const int G = (H + 15) / 16;
@@ -594,7 +594,7 @@ template <int NG, int KQ, int S, int TPT>
 static int launch_mfma_s(const LstmMfmaArgs& p, hipStream_t st) {
     static const std::string pname = "lstm_mfma_kernel<" + std::to_string(NG) + "," + std::to_string(KQ) + "," + std::to_string(S) + "," + std::to_string(TPT) + ">";
     constexpr size_t lds = (size_t)(2 * 4 * 4 * KQ + 4 * 64 * NG * 4 + 64 * NG) * 4;
-    ProfScope ps(pname.c_str(), st);
+    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
     hipLaunchKernelGGL((lstm_mfma_kernel<NG, KQ, S, TPT>), dim3((unsigned)((p.M + S - 1) / S), (unsigned)p.ND), dim3(256), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fused_fwd[mfma]");
     return 0;
@@ -609,10 +609,10 @@ static int launch_mfma(const LstmMfmaArgs& p, hipStream_t st) {
         if (4 * p.H <= 256) return launch_mfma_s<NG, KQ, 4, 1>(p, st);
     }
     bool three = false;
-    const char* force = getenv("NIR_LSTM_MFMA_S");
+    const int force = tun(g_tun.lstm_mfma_s);
     if (force) {
-        three = atoi(force) == 3;
-    } else if (g_batches_in_flight <= 1) {
+        three = force == 3;
+    } else if (batches_in_flight(st) <= 1) {
         // (with several batches in flight the 4-sequence layout wins: all 4 MFMA rows carry work and 160 workgroups of
         //  one batch leave CUs for the next -- measured 3.69 M vs 3.36 M pairs/s at 4 batches in flight)
         const int64_t wg4 = ((p.M + 3) / 4) * p.ND, wg3 = ((p.M + 2) / 3) * p.ND;
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(1024) void lstm_mfma16_kernel(LstmMfmaArgs p) {
 template <int G, int NT>
 static int launch_mfma16(const LstmMfmaArgs& p, hipStream_t st) {
     static const std::string pname = "lstm_mfma16_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
-    ProfScope ps(pname.c_str(), st);
+    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
     hipLaunchKernelGGL((lstm_mfma16_kernel<G, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), 0, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fused_fwd[mfma16]");
     return 0;
@@ -796,8 +796,8 @@ static int launch_mfma16(const LstmMfmaArgs& p, hipStream_t st) {
 
 // NIR_ERR_UNSUPPORTED when the shape has no instantiation (H <= 128, I <= 64, H + I <= 160) or there are too few sequences
 static int launch_bilstm_fused_mfma16(const LstmMfmaArgs& p, hipStream_t st) {
-    const char* f = getenv("NIR_LSTM_MFMA16");
-    if (f ? atoi(f) == 0 : ((p.M + 15) / 16) * p.ND < 160) return NIR_ERR_UNSUPPORTED;   // H = 70: 1024 seqs 178 vs 169 us, 3200 358 vs 509
+    const int f = tun(g_tun.lstm_mfma16);
+    if (f >= 0 ? f == 0 : ((p.M + 15) / 16) * p.ND < 160) return NIR_ERR_UNSUPPORTED;   // H = 70: 1024 seqs 178 vs 169 us, 3200 358 vs 509
     if ((int64_t)16 * p.T * max(p.I, p.ND * p.H) * 4 >= 0x7FFFFFF0LL || 16 * p.I > 1024) return NIR_ERR_UNSUPPORTED;
     const int G = (p.H + p.I + 15) / 16, NT = (p.H + 3) / 4 > 16 ? 2 : 1;
 #define NIR_M16_CASE(g) if (G == g) return NT == 2 ? launch_mfma16<g, 2>(p, st) : launch_mfma16<g, 1>(p, st);

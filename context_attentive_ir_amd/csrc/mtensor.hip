@@ -427,7 +427,6 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
     fj.join();
     size_t lds = mt_head_lds(QL, DL, MT);
-    if (const char* padv = getenv("NIR_MT_LDS_PAD")) lds += (size_t)atoi(padv);   // occupancy experiment
     NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: QL=%d / DL=%d need %zu bytes of LDS (> 160 KiB)", QL, DL, lds);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)mt_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -436,7 +435,7 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
             return (int)e;
         }
     }
-    if (getenv("NIR_DEBUG")) {
+    if (tun(g_tun.debug)) {
         int nb = -1;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)mt_head_kernel, 256, lds);
         hipFuncAttributes fa;

@@ -85,8 +85,9 @@ class GraphedPredictor(object):
         self.copy_done.record(self.stream)
 
     def _call(self):
-        out = self.wrapper.predict(self.static)
-        return out["click_scores"] if isinstance(out, dict) else out
+        if hasattr(self.wrapper, "tgt_dict"):      # Multitask: the ranking path (the greedy decoder is not part of the captured step)
+            return self.wrapper.predict(self.static, suggest=False)["click_scores"]
+        return self.wrapper.predict(self.static)
 
     def predict(self, ex, clone=True):
         """ex must have the captured shapes; returns the softmax scores (a fresh tensor unless clone=False)."""

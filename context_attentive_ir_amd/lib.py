@@ -66,6 +66,8 @@ SIGNATURES = {
     "nir_debug_clock_probe": (_i, [C.c_void_p, _i, _i, C.c_void_p, c_st]),
     "nir_debug_set_buffer": (_i, [C.c_void_p]),
     "nir_set_batches_in_flight": (_i, [_i]),
+    "nir_set_stream_batches_in_flight": (_i, [c_st, _i]),
+    "nir_debug_set_tunable": (_i, [C.c_char_p, _i]),
     "nir_profile_enable": (_i, [_i]),
     "nir_profile_report": (_i, [C.c_char_p, _z]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
@@ -260,3 +262,18 @@ def fold_lstm_table(table, wih, bih, bhh, H, ndir, dtype):
     check(L.nir_lstm_fold_table(ptr(t), V, E, ptr(wih), ptr(bih), ptr(bhh), H, ndir, ptr(out), dt, ptr(ws), ws.numel(), stream()),
           "nir_lstm_fold_table")
     return out
+
+
+class tunable(object):
+    """Context manager: `with lib.tunable("lstm_mfma16", 1): ...` (nir_debug_set_tunable; restores `restore` on exit)."""
+
+    def __init__(self, name, value, restore):
+        self.name, self.value, self.restore = name.encode(), int(value), int(restore)
+
+    def __enter__(self):
+        check(load().nir_debug_set_tunable(self.name, self.value), "nir_debug_set_tunable")
+        return self
+
+    def __exit__(self, *exc):
+        load().nir_debug_set_tunable(self.name, self.restore)
+        return False

@@ -1,0 +1,113 @@
+"""Host-side surface shared by the Ranker / Multitask wrappers: everything main/ranker.py and main/multitask.py call on the
+model object besides predict/update (/root/reference/neuroir/models/ranker.py:95-190, 262-346; models/multitask.py:62-160,
+319-407).  Pure bookkeeping -- no arithmetic on activations happens here."""
+import copy
+import logging
+
+import torch
+import torch.optim as optim
+
+logger = logging.getLogger(__name__)
+
+
+class WrapperBase(object):
+    optimizer = None
+
+    # the module whose `.word_vec_size / .init_word_vectors / .parameters()` the drivers use
+    def _word_embeddings(self):
+        net = self.network
+        return net.word_embeddings if hasattr(net, "word_embeddings") else net.embedder.word_embeddings
+
+    def count_parameters(self):
+        return sum(p.numel() for p in self.network.parameters() if p.requires_grad)
+
+    def layer_wise_parameters(self):
+        rows = [(n, list(p.shape), p.numel()) for n, p in self.network.named_parameters() if p.requires_grad]
+        w = max([len(r[0]) for r in rows] + [10])
+        return "\n".join("%-*s %20s %12d" % (w, n, s, c) for n, s, c in rows)
+
+    def load_embeddings(self, words, embedding_file):
+        """models/ranker.py:105-150: text embeddings (one token + emsize floats per line, optional count/dim header) for
+        the tokens of `words` present in the source dictionary; duplicates after normalisation are averaged."""
+        emb_layer = self._word_embeddings()
+        words = {w for w in words if w in self.src_dict}
+        logger.info("Loading pre-trained embeddings for %d words from %s" % (len(words), embedding_file))
+        vec_counts, embedding = {}, {}
+        with open(embedding_file) as f:
+            line = f.readline().rstrip().split(" ")
+            if len(line) != 2:
+                f.seek(0)
+            for line in f:
+                parsed = line.rstrip().split(" ")
+                assert len(parsed) == emb_layer.word_vec_size + 1
+                w = self.src_dict.normalize(parsed[0]) if hasattr(self.src_dict, "normalize") else parsed[0]
+                if w in words:
+                    vec = torch.tensor([float(i) for i in parsed[1:]])
+                    if w not in vec_counts:
+                        vec_counts[w], embedding[w] = 1, vec
+                    else:
+                        vec_counts[w] += 1
+                        embedding[w].add_(vec)
+        for w, c in vec_counts.items():
+            embedding[w].div_(c)
+        emb_layer.init_word_vectors(self.src_dict, embedding, self.args.fix_embeddings)
+        logger.info("Loaded %d embeddings (%.2f%%)" % (len(vec_counts), 100.0 * len(vec_counts) / max(len(words), 1)))
+
+    def init_optimizer(self, state_dict=None, use_gpu=True):
+        """models/ranker.py:152-190: freeze the embedding table when fix_embeddings, build sgd/adam/adamax/adadelta over the
+        free parameters, optionally restore its state."""
+        if self.args.fix_embeddings:
+            for p in self._word_embeddings().parameters():
+                p.requires_grad = False
+        parameters = [p for p in self.network.parameters() if p.requires_grad]
+        a = self.args
+        if a.optimizer == "sgd":
+            self.optimizer = optim.SGD(parameters, a.learning_rate, momentum=a.momentum, weight_decay=a.weight_decay)
+        elif a.optimizer == "adam":
+            self.optimizer = optim.Adam(parameters, a.learning_rate, weight_decay=a.weight_decay)
+        elif a.optimizer == "adamax":
+            self.optimizer = optim.Adamax(parameters, a.learning_rate, weight_decay=a.weight_decay)
+        elif a.optimizer == "adadelta":
+            self.optimizer = optim.Adadelta(parameters, a.learning_rate, weight_decay=a.weight_decay)
+        else:
+            raise RuntimeError("Unsupported optimizer: %s" % a.optimizer)
+        if state_dict is not None:
+            self.optimizer.load_state_dict(state_dict)
+            if use_gpu:
+                for state in self.optimizer.state.values():
+                    for k, v in state.items():
+                        if isinstance(v, torch.Tensor):
+                            state[k] = v.cuda()
+
+    def _params(self, extra=None):
+        state = copy.copy(self.network.state_dict())
+        state.pop("fixed_embedding", None)
+        p = {"state_dict": {k: v.cpu() for k, v in state.items()}, "src_dict": self.src_dict, "args": self.args}
+        if hasattr(self, "tgt_dict"):
+            p["tgt_dict"] = self.tgt_dict
+        p.update(extra or {})
+        return p
+
+    def save(self, filename):
+        try:
+            torch.save(self._params(), filename)
+        except BaseException:
+            logger.warning("WARN: Saving failed... continuing anyway.")
+
+    def checkpoint(self, filename, epoch):
+        if self.optimizer is None:
+            raise RuntimeError("No optimizer set.")
+        try:
+            torch.save(self._params({"epoch": epoch, "optimizer": self.optimizer.state_dict()}), filename)
+        except BaseException:
+            logger.warning("WARN: Saving failed... continuing anyway.")
+
+    def cuda(self):
+        self.use_cuda = True
+        self.network = self.network.cuda()
+        return self
+
+    def cpu(self):
+        self.use_cuda = False
+        self.network = self.network.cpu()
+        return self

@@ -5,11 +5,12 @@ import torch
 
 from .. import lib
 from ..multitask import CARS, M_MATCH_TENSOR, MNSRF
+from .common import WrapperBase
 
 NETWORKS = {"CARS": CARS, "M_MATCH_TENSOR": M_MATCH_TENSOR, "MNSRF": MNSRF}
 
 
-class Multitask(object):
+class Multitask(WrapperBase):
     def __init__(self, args, src_dict=None, tgt_dict=None, state_dict=None):
         self.args = args
         self.src_dict, self.tgt_dict = src_dict, tgt_dict
@@ -32,43 +33,68 @@ class Multitask(object):
         self.parallel = True
         self.group = group
 
-    def cuda(self):
-        self.use_cuda = True
-        self.network = self.network.cuda()
-        return self
-
     def _dev(self, t):
         return t.cuda(non_blocking=True) if self.use_cuda else t
 
     @torch.no_grad()
-    def scores(self, ex):
+    def _rank(self, ex, want_states):
         self.network.eval()
         if self.type != "CARS":     # models/multitask.py:271-278: encode -> rank_document(source, memory, session, docs, lens)
             src = self._dev(ex["source_words"])
             memory_bank, session_bank, _ = self.network.encode(src, self._dev(ex["source_lens"]))
-            return self.network.rank_document(src, memory_bank, session_bank, self._dev(ex["document_words"]),
-                                              self._dev(ex["document_lens"]))
-        pooled, _, _ = self.network.encode(self._dev(ex["source_words"]), self._dev(ex["source_lens"]))
-        s, _, _ = self.network.rank_document(pooled, self._dev(ex["document_words"]), self._dev(ex["document_lens"]),
-                                             self._dev(ex["document_labels"]), group=self.group, shard=self.parallel)
-        return s
+            s = self.network.rank_document(src, memory_bank, session_bank, self._dev(ex["document_words"]), self._dev(ex["document_lens"]))
+            return s, None, None, None
+        src_lens = self._dev(ex["source_lens"])
+        pooled, encoded, _ = self.network.encode(self._dev(ex["source_words"]), src_lens)
+        s, states, attns = self.network.rank_document(pooled, self._dev(ex["document_words"]), self._dev(ex["document_lens"]),
+                                                      self._dev(ex["document_labels"]), group=self.group, shard=self.parallel,
+                                                      want_states=want_states)
+        return s, states, attns, (encoded, src_lens)
 
     @torch.no_grad()
-    def predict(self, ex):
-        s = self.scores(ex).contiguous()
-        out = torch.empty_like(s)
-        lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0] * s.shape[1], s.shape[2],
-                                              lib.stream()), "nir_softmax_rows")
-        return {"click_scores": out, "predictions": None}
+    def scores(self, ex):
+        """raw click scores [B,S,N] (ranking path only)."""
+        return self._rank(ex, False)[0]
+
+    @torch.no_grad()
+    def predict(self, ex, suggest=True):
+        """models/multitask.py:229-317: {'click_scores': softmax over candidates [B,S,N], 'predictions': LongTensor
+        [B,S-1,max_query_len] (CARS with the recommender on, suggest=True; else None)}.
+        suggest=False = the ranking path only (what bench.py times as a step and GraphedPredictor captures)."""
+        do_decode = bool(suggest) and self.type == "CARS" and not self.network.no_recommender
+        s, states, attns, enc = self._rank(ex, do_decode)
+        out = {"click_scores": None, "predictions": None}
+        if torch.is_tensor(s):
+            s = s.contiguous()
+            probs = torch.empty_like(s)
+            lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()),
+                      "nir_softmax_rows")
+            out["click_scores"] = probs
+        if do_decode:
+            B, S = ex["source_words"].shape[0], ex["source_words"].shape[1]
+            dec = self.network.decode(states=states, max_len=self.args.max_query_len, src_dict=self.src_dict, tgt_dict=self.tgt_dict,
+                                      batch_size=B, session_len=S - 1, use_cuda=self.use_cuda, encoded_source=enc[0], source_len=enc[1],
+                                      session_attns=attns)
+            out["predictions"] = dec["predictions"]
+        return out
 
     def update(self, ex):
         raise NotImplementedError("training step is the next scope row, SURVEY.md section 8f rank 1")
 
-    def save(self, filename):
-        state = {k: v.cpu() for k, v in self.network.state_dict().items()}
-        torch.save({"state_dict": state, "src_dict": self.src_dict, "tgt_dict": self.tgt_dict, "args": self.args}, filename)
+    @staticmethod
+    def load(filename, new_args=None):
+        saved = torch.load(filename, map_location="cpu", weights_only=False)
+        args = saved["args"]
+        if new_args is not None:
+            from ..config import override_model_args
+            args = override_model_args(args, new_args)
+        return Multitask(args, saved.get("src_dict"), saved.get("tgt_dict"), saved["state_dict"])
 
     @staticmethod
-    def load(filename):
+    def load_checkpoint(filename, use_gpu=True):
         saved = torch.load(filename, map_location="cpu", weights_only=False)
-        return Multitask(saved["args"], saved.get("src_dict"), saved.get("tgt_dict"), saved["state_dict"])
+        model = Multitask(saved["args"], saved.get("src_dict"), saved.get("tgt_dict"), saved["state_dict"])
+        if use_gpu:
+            model.cuda()
+        model.init_optimizer(saved["optimizer"], use_gpu)
+        return model, saved["epoch"]

@@ -10,12 +10,13 @@ import torch
 
 from .. import lib, sharding
 from ..rankers import DRMM, DUET, ESM, MatchTensor
+from .common import WrapperBase
 
 NETWORKS = {"ESM": ESM, "DUET": DUET, "DRMM": DRMM, "MATCH_TENSOR": MatchTensor}
 BCE_MODELS = {"DUET", "DRMM", "MATCH_TENSOR"}
 
 
-class Ranker(object):
+class Ranker(WrapperBase):
     def __init__(self, args, src_dict=None, state_dict=None):
         self.args = args
         self.src_dict = src_dict
@@ -31,17 +32,7 @@ class Ranker(object):
             self.network.load_state_dict(state_dict)
         self.group = None
 
-    # -- device / parallel -----------------------------------------------------------------------
-    def cuda(self):
-        self.use_cuda = True
-        self.network = self.network.cuda()
-        return self
-
-    def cpu(self):
-        self.use_cuda = False
-        self.network = self.network.cpu()
-        return self
-
+    # -- device / parallel (cuda()/cpu() in WrapperBase) ------------------------------------------
     def parallelize(self, group=None):
         """Candidate-axis sharding over `group` (default WORLD) -- replaces nn.DataParallel."""
         self.parallel = True
@@ -91,11 +82,7 @@ class Ranker(object):
     def update(self, ex):
         raise NotImplementedError("training step (backward + Adam) is the next scope row, SURVEY.md section 8f rank 1")
 
-    # -- persistence ---------------------------------------------------------------------------------
-    def save(self, filename):
-        state = {k: v.cpu() for k, v in self.network.state_dict().items()}
-        torch.save({"state_dict": state, "src_dict": self.src_dict, "args": self.args}, filename)
-
+    # -- persistence (save / checkpoint in WrapperBase) ---------------------------------------------
     @staticmethod
     def load(filename, new_args=None):
         saved = torch.load(filename, map_location="cpu", weights_only=False)
@@ -104,3 +91,13 @@ class Ranker(object):
             from ..config import override_model_args
             args = override_model_args(args, new_args)
         return Ranker(args, saved.get("src_dict"), saved["state_dict"])
+
+    @staticmethod
+    def load_checkpoint(filename, use_gpu=True):
+        """models/ranker.py:315-327 -> (model with its optimizer restored, epoch)."""
+        saved = torch.load(filename, map_location="cpu", weights_only=False)
+        model = Ranker(saved["args"], saved.get("src_dict"), saved["state_dict"])
+        if use_gpu:
+            model.cuda()
+        model.init_optimizer(saved["optimizer"], use_gpu)
+        return model, saved["epoch"]

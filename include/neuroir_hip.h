@@ -45,6 +45,14 @@ const char* nir_last_error_string(void);
  * batches fill the idle slots and it optimises chip throughput instead (no internal fork -- every extra stream
  * competes for a hardware queue -- and fuller workgroups).  Results are identical either way.  Returns the old value. */
 int nir_set_batches_in_flight(int n);
+/* The same hint for calls enqueued on ONE stream (overrides the process default for that stream; n < 1 removes the entry), so
+ * that independent callers sharing the library do not steer each other. */
+int nir_set_stream_batches_in_flight(nir_stream_t stream, int n);
+/* Tuning / debug switches (kernel-family selection, fork on/off, exact f32 MFMA instead of the split-precision GEMM ...).  They
+ * are read from the environment ONCE when the library is loaded (NIR_NO_FORK, NIR_LSTM_VALU, NIR_LSTM_MFMA16, NIR_LSTM_MFMA_S,
+ * NIR_LSTM_S, NIR_NO_SKINNY, NIR_NO_GEMM16, NIR_ESM_WAVE_ROWS, NIR_DEBUG, NIR_EXACT_F32); this call changes one at run time by
+ * its lower-case name without the prefix ("lstm_mfma16", ...).  Never changes results beyond fp32 rounding. */
+int nir_debug_set_tunable(const char* name /*host*/, int value);
 
 /* Per-kernel timing for bench.py's roofline block: while enabled, every kernel launch of this library is
  * bracketed by two hipEvents recorded on its own stream.  nir_profile_report synchronises those events and

@@ -129,8 +129,9 @@ def test_rnn_encoder(H, I, M, T_):
 def test_rnn_encoder_16_sequence_layout(H, I, M, T_, monkeypatch):
     """The 16-sequence 16x16x4-MFMA recurrences (chosen by the library only from ~1000 sequences up) forced on small,
     ragged batches: partial workgroups, one- and two-tile waves, fused and unfused input projection."""
-    monkeypatch.setenv("NIR_LSTM_MFMA16", "1")
-    test_rnn_encoder(H, I, M, T_)
+    from context_attentive_ir_amd import lib
+    with lib.tunable("lstm_mfma16", 1, restore=-1):
+        test_rnn_encoder(H, I, M, T_)
 
 
 def test_rnn_encoder_many_sequences():

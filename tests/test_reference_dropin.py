@@ -1,0 +1,127 @@
+"""Drop-in check against the REAL reference wrappers (authoring container only: /root/reference is not on the GPU box).
+
+The reference's own `neuroir.models.ranker.Ranker` / `neuroir.models.multitask.Multitask` are constructed with this package's
+network classes monkey-patched in (the two import lines a maintainer changes) and everything the
+drivers main/ranker.py / main/multitask.py do with a model object is exercised up to the kernel launch: construction from
+`config.get_model_args`, state-dict key identity with the reference's own networks, load_embeddings, init_optimizer
+(fix_embeddings freezes `network.word_embeddings` / `network.embedder.word_embeddings`), save -> load, checkpoint ->
+load_checkpoint.  predict/update on CPU tensors must fail loudly (no CPU fallback)."""
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference is only present in the authoring container")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.path.insert(0, REF)
+    pt = types.ModuleType("prettytable")
+
+    class _PT(object):
+        def __init__(self, *a, **k):
+            self.field_names, self.align = [], {}
+
+        def add_row(self, *a, **k):
+            pass
+
+    pt.PrettyTable = _PT
+    sys.modules.setdefault("prettytable", pt)
+    if not hasattr(np, "float_"):
+        np.float_ = np.float64
+    orig_load = torch.load                        # SURVEY Appendix D shim 5: the reference pickles Namespace / Vocabulary objects
+
+    def _load(*a, **k):
+        k.setdefault("weights_only", False)
+        return orig_load(*a, **k)
+
+    torch.load = _load
+    import neuroir.models.multitask as rm
+    import neuroir.models.ranker as rr
+    from neuroir import hyparam
+    from neuroir.inputters.vocabulary import Vocabulary
+    yield types.SimpleNamespace(rr=rr, rm=rm, hyparam=hyparam, Vocabulary=Vocabulary)
+    torch.load = orig_load
+    sys.path.remove(REF)
+
+
+def _vocab(ref, n):
+    v = ref.Vocabulary()
+    for i in range(n):
+        v.add("tok%d" % i)
+    return v
+
+
+def _args(ref, model, **kw):
+    a = dict(emsize=300, dropout_emb=0.2, dropout=0.2, dropout_rnn=0.2, max_doc_len=20, max_query_len=6, num_candidates=4,
+             use_word=True, fix_embeddings=True, model_type=model, optimizer="adam", learning_rate=0.001, weight_decay=0,
+             momentum=0, grad_clipping=10)
+    a.update(ref.hyparam.get_model_specific_params(model, "arch"))
+    a.update(kw)
+    return Namespace(**a)
+
+
+@pytest.mark.parametrize("model,attr", [("ESM", "ESM"), ("MATCH_TENSOR", "MatchTensor"), ("DRMM", "DRMM"), ("DUET", "DUET")])
+def test_reference_ranker_with_swapped_network(ref, model, attr, monkeypatch, tmp_path):
+    from context_attentive_ir_amd import rankers
+    vocab = _vocab(ref, 40)
+    own = ref.rr.Ranker(_args(ref, model), vocab)                       # the reference's own network: the key set to match
+    ref_keys = {k: tuple(v.shape) for k, v in own.network.state_dict().items()}
+    monkeypatch.setattr(ref.rr, attr, getattr(rankers, attr))
+    m = ref.rr.Ranker(_args(ref, model), vocab)
+    assert type(m.network).__module__.startswith("context_attentive_ir_amd")
+    assert {k: tuple(v.shape) for k, v in m.network.state_dict().items()} == ref_keys
+    assert m.count_parameters() == own.count_parameters()
+    # load_embeddings -> init_word_vectors on the swapped network's word_embeddings
+    emb = tmp_path / "emb.txt"
+    emb.write_text("\n".join("tok%d %s" % (i, " ".join(["%.3f" % (0.01 * i)] * 300)) for i in range(5)))
+    m.load_embeddings(["tok%d" % i for i in range(5)], str(emb))
+    row = m.network.word_embeddings.table[vocab["tok3"]]
+    assert torch.allclose(row, torch.full((300,), 0.03), atol=1e-6)
+    if model != "ESM":
+        m.init_optimizer()
+        assert all(not p.requires_grad for p in m.network.word_embeddings.parameters())
+        m.checkpoint(str(tmp_path / "c.mdl"), 3)
+        m2, epoch = ref.rr.Ranker.load_checkpoint(str(tmp_path / "c.mdl"), use_gpu=False)
+        assert epoch == 3 and type(m2.network) is type(m.network)
+    m.save(str(tmp_path / "m.mdl"))
+    m3 = ref.rr.Ranker.load(str(tmp_path / "m.mdl"))
+    for k, v in m.network.state_dict().items():
+        assert torch.equal(v, m3.network.state_dict()[k])
+    own.network.load_state_dict(m.network.state_dict())                 # and the reference's own class loads our weights strictly
+    ex = dict(que_rep=torch.zeros(2, 6, dtype=torch.long), que_len=torch.full((2,), 6), doc_rep=torch.zeros(2, 4, 20, dtype=torch.long),
+              doc_len=torch.full((2, 4), 20), label=torch.zeros(2, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.predict(ex)
+
+
+@pytest.mark.parametrize("kw", [{}, dict(query_session_off=True), dict(doc_session_off=True)])
+def test_reference_multitask_with_swapped_cars(ref, kw, monkeypatch, tmp_path):
+    from context_attentive_ir_amd.multitask import CARS
+    src, tgt = _vocab(ref, 40), _vocab(ref, 30)
+    own = ref.rm.Multitask(_args(ref, "CARS", **kw), src, tgt)
+    ref_keys = {k: tuple(v.shape) for k, v in own.network.state_dict().items()}
+    monkeypatch.setattr(ref.rm, "CARS", CARS)
+    m = ref.rm.Multitask(_args(ref, "CARS", **kw), src, tgt)
+    assert type(m.network) is CARS
+    assert {k: tuple(v.shape) for k, v in m.network.state_dict().items()} == ref_keys
+    m.init_optimizer()
+    assert all(not p.requires_grad for p in m.network.embedder.word_embeddings.parameters())
+    m.save(str(tmp_path / "m.mdl"))
+    m2 = ref.rm.Multitask.load(str(tmp_path / "m.mdl"))
+    assert type(m2.network) is CARS
+    own.network.load_state_dict(m.network.state_dict())
+    # every attribute / method Multitask.predict touches on the network exists with the reference's signature
+    for name in ("encode", "rank_document", "decode", "forward", "embedder"):
+        assert hasattr(m.network, name)
+    ex = dict(source_words=torch.zeros(2, 3, 6, dtype=torch.long), source_lens=torch.full((2, 3), 6),
+              document_words=torch.zeros(2, 3, 4, 20, dtype=torch.long), document_lens=torch.full((2, 3, 4), 20),
+              document_labels=torch.zeros(2, 3, 4), session_len=3, ids=["a", "b"], batch_size=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.predict(ex)

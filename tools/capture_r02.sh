@@ -1,0 +1,24 @@
+#!/bin/bash
+# rocprofv3 evidence for every bench.py configuration (run on the GPU box through gpurun from the repo root):
+#   gpurun --timeout 2400 -- 'bash tools/capture_r02.sh [config ...]'
+# per config: (1) --kernel-trace --stats of the serial eager run (one batch in flight: every launch attributed, not stretched by
+# co-running batches -- the condition bench.py's own HIP-event pass measures under); (2) FETCH_SIZE pass; (3) WRITE_SIZE pass;
+# (4) SQ/MFMA pass.  Counter passes use --kernel-trace only (never combined with sys/hip/hsa trace domains).
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/r02prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CFGS=${@:-C3_cars C1_esm C2_match_tensor NS_match_tensor_50 C4_duet C4_drmm C4_esm_hbm C5_cars_bf16}
+for c in $CFGS; do
+  steps=20; case $c in C4_duet|C5_cars_bf16) steps=6;; esac
+  RUN="python $REPO/bench.py --config $c --sub none --streams 1 --no-graph --steps $steps --warmup 3 --no-cpu-baseline"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$c/stats -o s -- $RUN > $OUT/$c.stats.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/$c/fetch -o p -- $RUN > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/$c/write -o p -- $RUN > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/$c/sq -o p -- $RUN > /dev/null 2>&1
+  echo "captured $c"
+done
+# keep the merged-back payload small: the per-dispatch traces are condensed on the box
+python $REPO/tools/derive_r02.py $OUT
+find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
