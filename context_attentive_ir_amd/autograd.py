@@ -1,0 +1,279 @@
+"""Differentiable operators of the training step -- torch.autograd.Function wrappers whose
+forward AND backward run on the hand-written HIP kernels of csrc/train.hip / csrc/gemm.hip:
+
+    linear      y = act(x W^T + b)          fwd nir_linear_f32; bwd: act' (nir_act_bwd_f32), dX = dY W (nir_linear_f32 on the
+                                            transposed weight), dW = dY^T X (nir_linear_wgrad_f32), db (nir_colsum_f32)
+    embed       rows of the embedding table (nir_embed_f32; bwd scatter-add nir_embed_bwd_f32, skipped for a frozen table)
+    dropout     counter-based inverted dropout (nir_dropout_f32; the keep mask is kept for the backward and for parity replays)
+    bilstm      RNNEncoder in train mode: gate GEMM + nir_lstm_train_fwd (saves gate activations / cell states);
+                bwd: BPTT nir_lstm_train_bwd -> dgates, then dW_ih / dW_hh / db / dx as GEMMs
+    bce_with_logits   nir_rank_loss_bce / nir_rank_loss_bce_bwd
+
+What stays in torch in the train-mode model forwards (models call these functions and glue them with tensor reshapes,
+concatenations, element-wise products and max-reductions) is stated in DESIGN.md section 8; every matrix product, recurrence,
+lookup and loss above is HIP.  Optimiser state updates (Adam/SGD) and clip_grad_norm use torch.optim like the reference.
+"""
+import torch
+from torch.autograd import Function
+
+from . import lib
+
+ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2}
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _linear_raw(x2, w, b, act):
+    """x2 [M,K] contiguous, w [N,K] -> [M,N] through nir_linear_f32."""
+    L = lib.load()
+    M, K = x2.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x2.device, dtype=torch.float32)
+    if M:
+        lib.check(L.nir_linear_f32(lib.ptr(x2), K, None, None, 0, 0, 0, lib.ptr(w), K, lib.ptr(b), None, lib.ptr(y), N, M, N, K, act,
+                                   lib.stream()), "nir_linear_f32")
+    return y
+
+
+def _transpose(w):
+    L = lib.load()
+    R, Cc = w.shape
+    out = torch.empty(Cc, R, device=w.device, dtype=torch.float32)
+    lib.check(L.nir_transpose_f32(lib.ptr(w), R, Cc, lib.ptr(out), lib.stream()), "nir_transpose_f32")
+    return out
+
+
+def _wgrad(dy2, lddy, x2, ldx, M, N, K):
+    """dW [N,K] = sum_m dy[m,:N]^T x[m,:K]; dy2 / x2 may be column windows of wider row-major buffers (lddy / ldx)."""
+    L = lib.load()
+    dw = torch.zeros(N, K, device=x2.device, dtype=torch.float32)
+    if M:
+        lib.check(L.nir_linear_wgrad_f32(lib.ptr(dy2), lddy, lib.ptr(x2), ldx, None, None, 0, lib.ptr(dw), K, M, N, K, lib.stream()),
+                  "nir_linear_wgrad_f32")
+    return dw
+
+
+def _colsum(dy2, ld, M, N):
+    L = lib.load()
+    out = torch.zeros(N, device=dy2.device, dtype=torch.float32)
+    if M:
+        lib.check(L.nir_colsum_f32(lib.ptr(dy2), ld, M, N, lib.ptr(out), lib.stream()), "nir_colsum_f32")
+    return out
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        lib.require_device(x, w)
+        shp = x.shape
+        x2 = _f32c(x).reshape(-1, shp[-1])
+        wc = _f32c(w)
+        y = _linear_raw(x2, wc, _f32c(b) if b is not None else None, act)
+        ctx.act, ctx.has_b, ctx.shp = act, b is not None, shp
+        ctx.save_for_backward(x2, wc, y if act else None)
+        return y.view(*shp[:-1], wc.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        L = lib.load()
+        M, K = x2.shape
+        N = w.shape[0]
+        d = _f32c(dy).reshape(M, N)
+        if ctx.act:
+            dpre = torch.empty_like(d)
+            lib.check(L.nir_act_bwd_f32(lib.ptr(d), lib.ptr(y), lib.ptr(dpre), d.numel(), ctx.act, lib.stream()), "nir_act_bwd_f32")
+            d = dpre
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _linear_raw(d, _transpose(w), None, 0).view(ctx.shp)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(d, N, x2, K, M, N, K)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = _colsum(d, N, M, N)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act=None):
+    """act(x W^T + b) over the last dim of x; act in {None, 'tanh', 'relu'}."""
+    return _Linear.apply(x, weight, bias, ACT[act])
+
+
+class _Embed(Function):
+    @staticmethod
+    def forward(ctx, ids, table, pad_idx):
+        lib.require_device(ids, table)
+        L = lib.load()
+        flat = lib.ids64(ids).reshape(-1)
+        V, E = table.shape
+        out = torch.empty(flat.numel(), E, device=table.device, dtype=torch.float32)
+        tc = _f32c(table)
+        lib.check(L.nir_embed_f32(lib.ptr(flat), lib.ptr(tc), V, E, flat.numel(), lib.ptr(out), None, lib.stream()), "nir_embed_f32")
+        ctx.save_for_backward(flat)
+        ctx.dims, ctx.pad = (V, E), pad_idx
+        return out.view(*ids.shape, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        (flat,) = ctx.saved_tensors
+        V, E = ctx.dims
+        dt = torch.zeros(V, E, device=dout.device, dtype=torch.float32)
+        d = _f32c(dout).reshape(-1, E)
+        lib.check(lib.load().nir_embed_bwd_f32(lib.ptr(flat), lib.ptr(d), V, E, flat.numel(), lib.ptr(dt), ctx.pad, lib.stream()),
+                  "nir_embed_bwd_f32")
+        return None, dt, None
+
+
+def embed(ids, table, pad_idx=0):
+    return _Embed.apply(ids, table, pad_idx)
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        L = lib.load()
+        xc = _f32c(x)
+        y = torch.empty_like(xc)
+        keep = torch.empty(xc.numel(), dtype=torch.uint8, device=xc.device)
+        lib.check(L.nir_dropout_f32(lib.ptr(xc), lib.ptr(y), lib.ptr(keep), xc.numel(), float(p), int(seed), lib.stream()), "nir_dropout_f32")
+        ctx.p = float(p)
+        ctx.save_for_backward(keep)
+        ctx.mark_non_differentiable(keep)
+        return y, keep
+
+    @staticmethod
+    def backward(ctx, dy, _dkeep):
+        (keep,) = ctx.saved_tensors
+        d = _f32c(dy)
+        dx = torch.empty_like(d)
+        lib.check(lib.load().nir_mask_scale_f32(lib.ptr(d), lib.ptr(keep), 1.0 / (1.0 - ctx.p), lib.ptr(dx), d.numel(), lib.stream()),
+                  "nir_mask_scale_f32")
+        return dx, None, None
+
+
+class DropoutState(object):
+    """Seed stream of the training step: every dropout site draws the next 64-bit seed (reproducible under `manual_seed`);
+    `masks` records the keep masks of the last forward so a parity test can replay them through the oracle."""
+
+    def __init__(self, seed=1013):
+        self.seed, self.counter, self.masks, self.record = int(seed), 0, [], False
+
+    def manual_seed(self, seed):
+        self.seed, self.counter = int(seed), 0
+
+    def next(self):
+        self.counter += 1
+        return (self.seed * 0x9E3779B97F4A7C15 + self.counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+DROPOUT = DropoutState()
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    y, keep = _Dropout.apply(x, p, DROPOUT.next())
+    if DROPOUT.record:
+        DROPOUT.masks.append(keep.view(x.shape))
+    return y
+
+
+class _BiLSTM(Function):
+    """x [M,T,I], lens [M] (or None) and the nn.LSTM parameters (per direction: w_ih [4H,I], w_hh [4H,H], b_ih, b_hh) ->
+    memory bank [M,T,ND*H] (zero at t >= length)."""
+
+    @staticmethod
+    def forward(ctx, x, lens, nd, *params):
+        lib.require_device(x)
+        L = lib.load()
+        M, T, I = x.shape
+        wih = torch.cat([params[4 * d] for d in range(nd)], 0).float().contiguous()
+        whh = torch.stack([params[4 * d + 1] for d in range(nd)], 0).float().contiguous()
+        bias = torch.cat([params[4 * d + 2] + params[4 * d + 3] for d in range(nd)], 0).float().contiguous()
+        H = whh.shape[2]
+        if H > 128:
+            raise NotImplementedError("train-mode recurrence supports H <= 128 per direction (got %d)" % H)
+        x2 = _f32c(x).reshape(M * T, I)
+        gates = _linear_raw(x2, wih, bias, 0)
+        dev = x.device
+        out = torch.empty(M, T, nd * H, device=dev)
+        act = torch.empty(M, T, nd, 4 * H, device=dev)
+        cst = torch.empty(M, T, nd, H, device=dev)
+        lens64 = lib.ids64(lens) if lens is not None else None
+        lib.check(L.nir_lstm_train_fwd(lib.ptr(gates), lib.ptr(lens64), lib.ptr(whh), None, None, lib.ptr(out), lib.ptr(act), lib.ptr(cst),
+                                       None, None, M, T, H, nd, lib.stream()), "nir_lstm_train_fwd")
+        ctx.nd, ctx.dims = nd, (M, T, I, H)
+        ctx.save_for_backward(x2, lens64 if lens64 is not None else torch.empty(0), wih, whh, out, act, cst)
+        ctx.has_lens = lens64 is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, lens64, wih, whh, out, act, cst = ctx.saved_tensors
+        L = lib.load()
+        nd = ctx.nd
+        M, T, I, H = ctx.dims
+        G = nd * 4 * H
+        d = _f32c(dout)
+        dgates = torch.empty(M, T, G, device=d.device)
+        lib.check(L.nir_lstm_train_bwd(lib.ptr(d), None, None, lib.ptr(act), lib.ptr(cst), None, lib.ptr(lens64) if ctx.has_lens else None,
+                                       lib.ptr(whh), lib.ptr(dgates), None, None, M, T, H, nd, lib.stream()), "nir_lstm_train_bwd")
+        dg2 = dgates.view(M * T, G)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _linear_raw(dg2, _transpose(wih), None, 0).view(M, T, I)
+        dwih = _wgrad(dg2, G, x2, I, M * T, G, I)
+        db = _colsum(dg2, G, M * T, G)
+        grads = []
+        for dd in range(nd):
+            # h of the PREVIOUS recurrence step: forward direction t-1, reverse direction t+1 (out is zero at t >= length, which is
+            # exactly the zero initial state of the reverse direction at t = length-1)
+            hd = out[:, :, dd * H:(dd + 1) * H]
+            z = torch.zeros(M, 1, H, device=d.device)
+            hprev = (torch.cat([z, hd[:, :-1]], 1) if dd == 0 else torch.cat([hd[:, 1:], z], 1)).contiguous().view(M * T, H)
+            dwhh = torch.zeros(4 * H, H, device=d.device)
+            lib.check(L.nir_linear_wgrad_f32(lib.C.c_void_p(dg2.data_ptr() + dd * 4 * H * 4), G, lib.ptr(hprev), H, None, None, 0,
+                                             lib.ptr(dwhh), H, M * T, 4 * H, H, lib.stream()), "nir_linear_wgrad_f32")
+            s = slice(dd * 4 * H, (dd + 1) * 4 * H)
+            grads += [dwih[s], dwhh, db[s], db[s].clone()]
+        return (dx, None, None) + tuple(grads)
+
+
+def bilstm(x, lens, lstm):
+    """RNNEncoder body in train mode for an nn.LSTM(1 layer, batch_first) parameter container."""
+    sfx = ["", "_reverse"] if lstm.bidirectional else [""]
+    params = []
+    for s in sfx:
+        params += [getattr(lstm, "weight_ih_l0" + s), getattr(lstm, "weight_hh_l0" + s), getattr(lstm, "bias_ih_l0" + s),
+                   getattr(lstm, "bias_hh_l0" + s)]
+    return _BiLSTM.apply(x, lens, len(sfx), *params)
+
+
+class _BCE(Function):
+    @staticmethod
+    def forward(ctx, scores, labels):
+        L = lib.load()
+        s, y = _f32c(scores), _f32c(labels)
+        loss = torch.empty(1, device=s.device)
+        n = s.shape[-1]
+        lib.check(L.nir_rank_loss_bce(lib.ptr(s), lib.ptr(y), s.numel() // n, n, lib.ptr(loss), lib.stream()), "nir_rank_loss_bce")
+        ctx.save_for_backward(s, y)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        s, y = ctx.saved_tensors
+        ds = torch.empty_like(s)
+        gg = _f32c(g).reshape(1)
+        lib.check(lib.load().nir_rank_loss_bce_bwd(lib.ptr(s), lib.ptr(y), lib.ptr(gg), lib.ptr(ds), s.numel(), lib.stream()),
+                  "nir_rank_loss_bce_bwd")
+        return ds, None
+
+
+def bce_with_logits(scores, labels):
+    """mean BCE-with-logits over all entries (models/ranker.py:55-69, multitask/cars.py:603)."""
+    return _BCE.apply(scores, labels)

@@ -1,0 +1,498 @@
+// Training-step kernels (neuroir/models/ranker.py:192-230, models/multitask.py:161-223):
+// the backward halves of the FLOP-carrying operators plus the train-mode forwards that have to save activations.
+//
+//   nir_linear_wgrad_f32   dW[n,k] += sum_m dY[m,n] X[m,k]   (X dense or gathered embedding rows)  -- fp32 MFMA, "TN" GEMM
+//   nir_colsum_f32         db[n]   += sum_m dY[m,n]
+//   nir_transpose_f32      W^T for the data-gradient GEMM dX = dY W (nir_linear_f32 computes A B^T)
+//   nir_lstm_train_fwd     LSTM recurrence that also stores the gate activations and cell states of every step
+//   nir_lstm_train_bwd     BPTT: pre-activation gate gradients of every step (dW_ih, dW_hh, db, dx follow as GEMMs)
+//   nir_embed_f32 / nir_embed_bwd_f32   embedding lookup (+ dropout mask) / scatter-add of row gradients
+//   nir_dropout_f32        counter-based Bernoulli mask (splitmix64 of seed ^ index): the mask is an OUTPUT, so a parity
+//                          test can replay exactly the same mask through the oracle
+//   nir_act_bwd_f32, nir_bce_bwd_f32, nir_softmax_nll_bwd_f32   element-wise backward pieces
+#include "common.hpp"
+#include <algorithm>
+
+namespace nir {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dW[n,k] += sum_m dY[m,n] * X[m,k].  One wave owns a 32x32 tile of dW and one slice of M; v_mfma_f32_32x32x2_f32 takes
+// A[i = n][kk = m] = dY[m0 + (lane >> 5)][n0 + (lane & 31)] and B[kk = m][j = k] = X[m0 + (lane >> 5)][k0 + (lane & 31)] straight
+// from global memory (both reads are 128-byte coalesced rows), 8 row pairs in flight; slices are combined with atomicAdd.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dy; int64_t lddy;
+    const float* x; int64_t ldx;
+    const int64_t* ids; const float* table; int E;     // gathered X: row m = table[ids[m]]
+    float* dw; int64_t lddw;
+    int64_t M; int N, K;
+    int64_t mslice;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nt = (p.N + 31) / 32, kt = (p.K + 31) / 32;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t tiles = (int64_t)nt * kt;
+    const int64_t slice = wid / tiles;
+    const int tile = (int)(wid % tiles);
+    const int n0 = (tile / kt) * 32, k0 = (tile % kt) * 32;
+    const int64_t ms = slice * p.mslice, me = min(p.M, ms + p.mslice);
+    if (ms >= p.M) return;
+    const int n = n0 + (lane & 31), k = k0 + (lane & 31);
+    const bool nv = n < p.N, kv = k < p.K;
+    const int half = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int64_t m = ms; m < me; m += 16) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t mm = m + 2 * u + half;
+            const bool mv = mm < me;
+            a[u] = (mv && nv) ? p.dy[mm * p.lddy + n] : 0.f;
+            const float* xr = p.ids ? p.table + p.ids[mv ? mm : ms] * (int64_t)p.E : p.x + (mv ? mm : ms) * p.ldx;
+            b[u] = (mv && kv) ? xr[k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    // C/D layout: col = lane & 31 (k), row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) (n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (nn < p.N && kv) atomicAdd(p.dw + (int64_t)nn * p.lddw + k, acc[r]);
+    }
+}
+
+// out[n] += sum_m x[m*ld + n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int N, float* __restrict__ out,
+                                                     int64_t mslice) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int64_t ms = (int64_t)blockIdx.y * mslice, me = min(M, ms + mslice);
+    if (n >= N) return;
+    float s = 0.f;
+    for (int64_t m = ms; m < me; ++m) s += x[m * ld + n];
+    atomicAdd(out + n, s);
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, int R, int Cc, float* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        t[i][threadIdx.x] = (r < R && c < Cc) ? in[(int64_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < Cc && r < R) out[(int64_t)c * R + r] = t[threadIdx.x][i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Train-mode LSTM recurrence.  One workgroup = SQ sequences of one direction, one thread per gate row j (4H <= 512 threads):
+// its W_hh row lives in registers (H <= 128), h_{t-1} of the SQ sequences in LDS.  Saves act[m,t,dir,4H] (i,f,g,o after
+// their non-linearities) and cst[m,t,dir,H] (c_t) for the backward pass; out is zero at t >= length (pack/unpack semantics).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TSQ = 4;
+struct LstmTrainArgs {
+    const float* gin;      // [M,T,ND*4H]
+    const int64_t* lens;
+    const float* whh;      // [ND,4H,H]
+    float* out;            // [M,T,ND*H]
+    float* act;            // [M,T,ND,4H]
+    float* cst;            // [M,T,ND,H]
+    float* hn;             // [ND,M,H] or NULL
+    float* cn;
+    const float* h0;       // [ND,M,H] or NULL
+    const float* c0;
+    int64_t M;
+    int T, H, ND;
+};
+
+template <int HP>
+__global__ __launch_bounds__(512) void lstm_train_fwd_kernel(LstmTrainArgs p) {
+    extern __shared__ float sm[];
+    float* hs = sm;                       // [TSQ][H]
+    float* gs = sm + TSQ * p.H;           // [TSQ][4H]
+    const int j = threadIdx.x, H = p.H, H4 = 4 * H, T = p.T;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * TSQ;
+    const bool jv = j < H4;
+    float w[HP];
+#pragma unroll
+    for (int k = 0; k < HP; ++k) w[k] = (jv && k < H) ? p.whh[((int64_t)dir * H4 + j) * H + k] : 0.f;
+    int len[TSQ];
+    int tmax = 0;
+#pragma unroll
+    for (int s = 0; s < TSQ; ++s) {
+        int l = 0;
+        if (m0 + s < p.M) {
+            l = p.lens ? (int)p.lens[m0 + s] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        len[s] = l;
+        tmax = max(tmax, l);
+    }
+    float c[TSQ];
+#pragma unroll
+    for (int s = 0; s < TSQ; ++s) {
+        c[s] = 0.f;
+        if (j < H) {
+            const bool v = m0 + s < p.M;
+            const int64_t si = ((int64_t)dir * p.M + m0 + s) * H + j;
+            hs[s * H + j] = (v && p.h0) ? p.h0[si] : 0.f;
+            if (v && p.c0) c[s] = p.c0[si];
+        }
+    }
+    __syncthreads();
+    const int gate = jv ? j / H : 0;
+    for (int step = 0; step < tmax; ++step) {
+#pragma unroll
+        for (int s = 0; s < TSQ; ++s) {
+            if (step < len[s] && jv) {
+                const int t = dir == 0 ? step : len[s] - 1 - step;
+                float a = p.gin[((m0 + s) * T + t) * (int64_t)(p.ND * H4) + dir * H4 + j];
+                const float* hv = hs + s * H;
+#pragma unroll
+                for (int k = 0; k < HP; ++k)
+                    if (k < H) a = fmaf(w[k], hv[k], a);
+                a = gate == 2 ? tanhf(a) : 1.0f / (1.0f + expf(-a));
+                gs[s * H4 + j] = a;
+                p.act[(((m0 + s) * T + t) * p.ND + dir) * (int64_t)H4 + j] = a;
+            }
+        }
+        __syncthreads();
+        if (j < H) {
+#pragma unroll
+            for (int s = 0; s < TSQ; ++s) {
+                if (step < len[s]) {
+                    const int t = dir == 0 ? step : len[s] - 1 - step;
+                    const float* g = gs + s * H4;
+                    c[s] = g[H + j] * c[s] + g[j] * g[2 * H + j];
+                    const float h = g[3 * H + j] * tanhf(c[s]);
+                    hs[s * H + j] = h;
+                    p.out[((m0 + s) * T + t) * (int64_t)(p.ND * H) + dir * H + j] = h;
+                    p.cst[(((m0 + s) * T + t) * p.ND + dir) * (int64_t)H + j] = c[s];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (j < H) {
+#pragma unroll
+        for (int s = 0; s < TSQ; ++s) {
+            if (m0 + s < p.M) {
+                for (int t = len[s]; t < T; ++t) p.out[((m0 + s) * T + t) * (int64_t)(p.ND * H) + dir * H + j] = 0.f;
+                const int64_t si = ((int64_t)dir * p.M + m0 + s) * H + j;
+                if (p.hn) p.hn[si] = hs[s * H + j];
+                if (p.cn) p.cn[si] = c[s];
+            }
+        }
+    }
+}
+
+// BPTT.  dout [M,T,ND*H] (gradient of the memory bank), dhn/dcn [ND,M,H] (gradient of the final state, may be NULL) ->
+// dgates [M,T,ND*4H] = gradient w.r.t. the gate PRE-activations (zero at t >= length), dh0/dc0 [ND,M,H] (may be NULL).
+// One thread per gate row j.  dh_{t-1} = dgates_t W_hh: thread (q = j / H, k = j % H) accumulates the rows [q*H, (q+1)*H) of
+// column k (coalesced reads of W_hh rows from L2), the four partial sums meet in LDS.
+struct LstmBwdArgs {
+    const float* dout; const float* dhn; const float* dcn;
+    const float* act; const float* cst; const float* c0;
+    const int64_t* lens; const float* whh;
+    float* dgates; float* dh0; float* dc0;
+    int64_t M; int T, H, ND;
+};
+
+__global__ __launch_bounds__(512) void lstm_train_bwd_kernel(LstmBwdArgs p) {
+    extern __shared__ float sm[];
+    const int H = p.H, H4 = 4 * H, T = p.T;
+    float* dg = sm;                       // [TSQ][4H] gate-preactivation grads of the current step
+    float* dhr = dg + TSQ * H4;           // [TSQ][H]  recurrent dh
+    float* part = dhr + TSQ * H;          // [4][TSQ][H]
+    const int j = threadIdx.x;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * TSQ;
+    const bool jv = j < H4;
+    const int q = jv ? j / H : 0, k = jv ? j % H : 0;
+    int len[TSQ];
+    int tmax = 0;
+#pragma unroll
+    for (int s = 0; s < TSQ; ++s) {
+        int l = 0;
+        if (m0 + s < p.M) {
+            l = p.lens ? (int)p.lens[m0 + s] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        len[s] = l;
+        tmax = max(tmax, l);
+    }
+    float dc[TSQ];
+#pragma unroll
+    for (int s = 0; s < TSQ; ++s) {
+        dc[s] = 0.f;
+        if (j < H) {
+            const bool v = m0 + s < p.M;
+            const int64_t si = ((int64_t)dir * p.M + m0 + s) * H + j;
+            dhr[s * H + j] = (v && p.dhn) ? p.dhn[si] : 0.f;
+            if (v && p.dcn) dc[s] = p.dcn[si];
+        }
+    }
+    __syncthreads();
+    for (int step = tmax - 1; step >= 0; --step) {
+        if (j < H) {
+#pragma unroll
+            for (int s = 0; s < TSQ; ++s) {
+                float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+                if (step < len[s]) {
+                    const int t = dir == 0 ? step : len[s] - 1 - step;
+                    const int64_t row = (m0 + s) * T + t;
+                    const float* a = p.act + (row * p.ND + dir) * (int64_t)H4;
+                    const float i_ = a[j], f_ = a[H + j], g_ = a[2 * H + j], o_ = a[3 * H + j];
+                    const float ct = p.cst[(row * p.ND + dir) * (int64_t)H + j];
+                    float cprev = 0.f;
+                    if (step > 0) {
+                        const int tp = dir == 0 ? step - 1 : len[s] - step;
+                        cprev = p.cst[(((m0 + s) * T + tp) * p.ND + dir) * (int64_t)H + j];
+                    } else if (p.c0) {
+                        cprev = p.c0[((int64_t)dir * p.M + m0 + s) * H + j];
+                    }
+                    const float th = tanhf(ct);
+                    const float dh = p.dout[row * (int64_t)(p.ND * H) + dir * H + j] + dhr[s * H + j];
+                    go = dh * th * o_ * (1.f - o_);
+                    const float dct = dc[s] + dh * o_ * (1.f - th * th);
+                    gi = dct * g_ * i_ * (1.f - i_);
+                    gf = dct * cprev * f_ * (1.f - f_);
+                    gg = dct * i_ * (1.f - g_ * g_);
+                    dc[s] = dct * f_;
+                    float* o = p.dgates + row * (int64_t)(p.ND * H4) + dir * H4;
+                    o[j] = gi; o[H + j] = gf; o[2 * H + j] = gg; o[3 * H + j] = go;
+                }
+                dg[s * H4 + j] = gi; dg[s * H4 + H + j] = gf; dg[s * H4 + 2 * H + j] = gg; dg[s * H4 + 3 * H + j] = go;
+            }
+        }
+        __syncthreads();
+        if (jv) {   // dh_{t-1}[s][k] = sum_jj dg[s][jj] * whh[jj][k]; this thread sums jj in [q*H, (q+1)*H)
+            float a[TSQ];
+#pragma unroll
+            for (int s = 0; s < TSQ; ++s) a[s] = 0.f;
+            const float* wp = p.whh + ((int64_t)dir * H4 + q * H) * H + k;
+            for (int jj = 0; jj < H; ++jj) {
+                const float wv = wp[(int64_t)jj * H];
+#pragma unroll
+                for (int s = 0; s < TSQ; ++s) a[s] = fmaf(dg[s * H4 + q * H + jj], wv, a[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < TSQ; ++s) part[(q * TSQ + s) * H + k] = a[s];
+        }
+        __syncthreads();
+        if (j < H) {
+#pragma unroll
+            for (int s = 0; s < TSQ; ++s) {
+                if (step < len[s])    // sequences that have not started yet (step >= len) keep the final-state gradient
+                    dhr[s * H + j] = (part[(0 * TSQ + s) * H + j] + part[(1 * TSQ + s) * H + j]) + (part[(2 * TSQ + s) * H + j] + part[(3 * TSQ + s) * H + j]);
+            }
+        }
+        __syncthreads();
+    }
+    if (j < H) {
+#pragma unroll
+        for (int s = 0; s < TSQ; ++s) {
+            if (m0 + s < p.M) {
+                const int64_t si = ((int64_t)dir * p.M + m0 + s) * H + j;
+                if (p.dh0) p.dh0[si] = dhr[s * H + j];
+                if (p.dc0) p.dc0[si] = dc[s];
+                for (int t = len[s]; t < T; ++t) {
+                    float* o = p.dgates + ((m0 + s) * T + t) * (int64_t)(p.ND * H4) + dir * H4;
+                    o[j] = 0.f; o[H + j] = 0.f; o[2 * H + j] = 0.f; o[3 * H + j] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// element-wise pieces
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// keep[i] = uniform(seed, i) >= p ; y = x * keep / (1 - p)
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ keep, int64_t n, float pdrop,
+                               uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float u = (float)(splitmix(seed ^ (uint64_t)i * 0xD1342543DE82EF95ull) >> 40) * (1.0f / 16777216.0f);
+    const bool k = u >= pdrop;
+    keep[i] = k ? 1 : 0;
+    y[i] = k ? x[i] / (1.0f - pdrop) : 0.f;
+}
+__global__ void mask_scale_kernel(const float* __restrict__ x, const unsigned char* __restrict__ keep, float scale, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = keep[i] ? x[i] * scale : 0.f;
+}
+// dx = dy * f'(y) for y = f(x): act 1 tanh (1 - y^2), 2 relu (y > 0), 3 sigmoid y (1 - y)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = y[i];
+    const float d = act == 1 ? 1.f - v * v : act == 2 ? (v > 0.f ? 1.f : 0.f) : act == 3 ? v * (1.f - v) : 1.f;
+    dx[i] = dy[i] * d;
+}
+// d mean-BCE-with-logits / d score = (sigmoid(s) - y) * gscale / n
+__global__ void bce_bwd_kernel(const float* __restrict__ s, const float* __restrict__ y, const float* __restrict__ gout, float* __restrict__ ds, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ds[i] = (1.0f / (1.0f + expf(-s[i])) - y[i]) * gout[0] / (float)n;
+}
+// embedding lookup: out[m,:] = table[ids[m],:]  (optionally with an inverted-dropout keep mask that is also returned)
+__global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table, int64_t V, int E, int64_t M, float* __restrict__ out,
+                             int* err) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * (E / 4)) return;
+    const int64_t m = i / (E / 4);
+    const int c = (int)(i % (E / 4)) * 4;
+    int64_t id = ids[m];
+    if (id < 0 || id >= V) { if (err) atomicOr(err, 1); id = 0; }
+    *reinterpret_cast<float4*>(out + m * E + c) = *reinterpret_cast<const float4*>(table + id * E + c);
+}
+__global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout, int64_t V, int E, int64_t M, float* __restrict__ dtable,
+                                 int64_t pad_idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * E) return;
+    const int64_t m = i / E;
+    const int c = (int)(i % E);
+    const int64_t id = ids[m];
+    if (id < 0 || id >= V || id == pad_idx) return;          // nn.Embedding(padding_idx): the PAD row receives no gradient
+    atomicAdd(dtable + id * E + c, dout[i]);
+}
+
+static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace nir
+
+extern "C" int nir_linear_wgrad_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                                    float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(dy && dw && (ids ? (table != nullptr && E >= K) : (x != nullptr)), "linear_wgrad: null pointer");
+    NIR_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_wgrad: bad dims");
+    if (M == 0) return 0;
+    const int64_t tiles = (int64_t)((N + 31) / 32) * ((K + 31) / 32);
+    int64_t slices = std::max<int64_t>(1, std::min<int64_t>((M + 255) / 256, (4096 + tiles - 1) / tiles));
+    const int64_t mslice = ((M + slices - 1) / slices + 15) / 16 * 16;
+    slices = (M + mslice - 1) / mslice;
+    WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice};
+    ProfScope ps(prof_shape_name("wgrad_kernel", M, N, K), (hipStream_t)stream);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    NIR_CHECK_LAUNCH("wgrad_kernel");
+    return 0;
+}
+
+extern "C" int nir_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(x && out && M >= 0 && N > 0, "colsum: bad args");
+    if (M == 0) return 0;
+    const int64_t mslice = std::max<int64_t>(64, (M + 255) / 256);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((M + mslice - 1) / mslice)), dim3(256), 0, (hipStream_t)stream, x, ld,
+                       M, N, out, mslice);
+    NIR_CHECK_LAUNCH("colsum_kernel");
+    return 0;
+}
+
+extern "C" int nir_transpose_f32(const float* in, int R, int Cc, float* out, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(in && out && R > 0 && Cc > 0, "transpose: bad args");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((Cc + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream, in, R, Cc, out);
+    NIR_CHECK_LAUNCH("transpose_kernel");
+    return 0;
+}
+
+extern "C" int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0, float* out,
+                                  float* act, float* cst, float* hn, float* cn, int64_t M, int T, int H, int ndir, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(gates_in && w_hh && out && act && cst, "lstm_train_fwd: null pointer");
+    NIR_REQUIRE(M >= 0 && T > 0 && (ndir == 1 || ndir == 2) && H >= 1 && H <= 128, "lstm_train_fwd: bad dims (H <= 128)");
+    if (M == 0) return 0;
+    LstmTrainArgs a{gates_in, lengths, w_hh, out, act, cst, hn, cn, h0, c0, M, T, H, ndir};
+    const dim3 grid((unsigned)((M + TSQ - 1) / TSQ), (unsigned)ndir);
+    const int threads = (4 * H + 63) / 64 * 64;
+    const size_t lds = (size_t)TSQ * 5 * H * 4;
+    ProfScope ps(prof_shape_name("lstm_train_fwd_kernel", M, T, H), (hipStream_t)stream);
+    if (H <= 32) hipLaunchKernelGGL(lstm_train_fwd_kernel<32>, grid, dim3(threads), lds, (hipStream_t)stream, a);
+    else if (H <= 64) hipLaunchKernelGGL(lstm_train_fwd_kernel<64>, grid, dim3(threads), lds, (hipStream_t)stream, a);
+    else if (H <= 96) hipLaunchKernelGGL(lstm_train_fwd_kernel<96>, grid, dim3(threads), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(lstm_train_fwd_kernel<128>, grid, dim3(threads), lds, (hipStream_t)stream, a);
+    NIR_CHECK_LAUNCH("lstm_train_fwd_kernel");
+    return 0;
+}
+
+extern "C" int nir_lstm_train_bwd(const float* dout, const float* dhn, const float* dcn, const float* act, const float* cst, const float* c0,
+                                  const int64_t* lengths, const float* w_hh, float* dgates, float* dh0, float* dc0, int64_t M, int T, int H,
+                                  int ndir, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(dout && act && cst && w_hh && dgates, "lstm_train_bwd: null pointer");
+    NIR_REQUIRE(M >= 0 && T > 0 && (ndir == 1 || ndir == 2) && H >= 1 && H <= 128, "lstm_train_bwd: bad dims (H <= 128)");
+    if (M == 0) return 0;
+    LstmBwdArgs a{dout, dhn, dcn, act, cst, c0, lengths, w_hh, dgates, dh0, dc0, M, T, H, ndir};
+    const int threads = (4 * H + 63) / 64 * 64;
+    const size_t lds = (size_t)TSQ * (4 * H + H + 4 * H) * 4;
+    ProfScope ps(prof_shape_name("lstm_train_bwd_kernel", M, T, H), (hipStream_t)stream);
+    hipLaunchKernelGGL(lstm_train_bwd_kernel, dim3((unsigned)((M + TSQ - 1) / TSQ), (unsigned)ndir), dim3(threads), lds, (hipStream_t)stream, a);
+    NIR_CHECK_LAUNCH("lstm_train_bwd_kernel");
+    return 0;
+}
+
+extern "C" int nir_dropout_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, uint64_t seed, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(x && y && keep && n >= 0 && p >= 0.f && p < 1.f, "dropout: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, x, y, keep, n, p, seed);
+    NIR_CHECK_LAUNCH("dropout_kernel");
+    return 0;
+}
+extern "C" int nir_mask_scale_f32(const float* x, const unsigned char* keep, float scale, float* y, int64_t n, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(x && y && keep && n >= 0, "mask_scale: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mask_scale_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, x, keep, scale, y, n);
+    NIR_CHECK_LAUNCH("mask_scale_kernel");
+    return 0;
+}
+extern "C" int nir_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int act, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(dy && y && dx && n >= 0, "act_bwd: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, act);
+    NIR_CHECK_LAUNCH("act_bwd_kernel");
+    return 0;
+}
+extern "C" int nir_rank_loss_bce_bwd(const float* scores, const float* labels, const float* grad_out, float* dscores, int64_t n, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(scores && labels && grad_out && dscores && n >= 0, "bce_bwd: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bce_bwd_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, scores, labels, grad_out, dscores, n);
+    NIR_CHECK_LAUNCH("bce_bwd_kernel");
+    return 0;
+}
+extern "C" int nir_embed_f32(const int64_t* ids, const float* table, int64_t V, int E, int64_t M, float* out, int* err_flag, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(ids && table && out && V > 0 && E > 0 && E % 4 == 0 && M >= 0, "embed: bad args (E %% 4 == 0)");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(embed_kernel, g1(M * (E / 4)), dim3(256), 0, (hipStream_t)stream, ids, table, V, E, M, out, err_flag);
+    NIR_CHECK_LAUNCH("embed_kernel");
+    return 0;
+}
+extern "C" int nir_embed_bwd_f32(const int64_t* ids, const float* dout, int64_t V, int E, int64_t M, float* dtable, int64_t pad_idx, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(ids && dout && dtable && V > 0 && E > 0 && M >= 0, "embed_bwd: bad args");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(embed_bwd_kernel, g1(M * E), dim3(256), 0, (hipStream_t)stream, ids, dout, V, E, M, dtable, pad_idx);
+    NIR_CHECK_LAUNCH("embed_bwd_kernel");
+    return 0;
+}

@@ -104,6 +104,17 @@ SIGNATURES = {
     "nir_cars_encode_folded": (_i, [c_ip, c_ip, _l, _i, C.c_void_p, _i, _l, C.POINTER(CarsEncoderWeights), C.c_void_p, _z,
                                     c_fp, c_fp, C.c_void_p, c_st]),
     "nir_cars_session_workspace_bytes": (_z, [_i, _i, _i, C.POINTER(CarsSessionWeights)]),
+    "nir_linear_wgrad_f32": (_i, [c_fp, _l, c_fp, _l, c_ip, c_fp, _i, c_fp, _l, _l, _i, _i, c_st]),
+    "nir_colsum_f32": (_i, [c_fp, _l, _l, _i, c_fp, c_st]),
+    "nir_transpose_f32": (_i, [c_fp, _i, _i, c_fp, c_st]),
+    "nir_lstm_train_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
+    "nir_lstm_train_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
+    "nir_dropout_f32": (_i, [c_fp, c_fp, C.c_void_p, _l, C.c_float, C.c_uint64, c_st]),
+    "nir_mask_scale_f32": (_i, [c_fp, C.c_void_p, C.c_float, c_fp, _l, c_st]),
+    "nir_act_bwd_f32": (_i, [c_fp, c_fp, c_fp, _l, _i, c_st]),
+    "nir_rank_loss_bce_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, _l, c_st]),
+    "nir_embed_f32": (_i, [c_ip, c_fp, _l, _i, _l, c_fp, C.c_void_p, c_st]),
+    "nir_embed_bwd_f32": (_i, [c_ip, c_fp, _l, _i, _l, c_fp, _l, c_st]),
     "nir_add_f32": (_i, [c_fp, c_fp, c_fp, _l, c_st]),
     "nir_cars_decode_workspace_bytes": (_z, [_l, _l, _i, C.POINTER(CarsDecoderWeights)]),
     "nir_cars_decode_greedy": (_i, [c_fp, c_fp, c_fp, c_ip, _l, _i, c_ip, _l, c_fp, c_fp, _l, _i, c_ip, _l, _i,

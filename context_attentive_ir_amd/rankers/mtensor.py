@@ -7,7 +7,9 @@ match tensor of the reference is never built (csrc/mtensor.hip).
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from .. import autograd as A
 from .. import lib
 from ..constants import PAD
 from ..encoders import RNNEncoder
@@ -64,10 +66,45 @@ class MatchTensor(nn.Module):
         params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
         return self._pack.get(params, build)
 
+    def _forward_train(self, q, ql, d, dl):
+        """Train-mode forward (mtensor.py:62-131 with dropout active), differentiable: lookups, projections, both BiLSTMs, the
+        three convolutions (im2col rows x filter matrix), the 1x1 convolution and the output layer run on the HIP operators of
+        autograd.py; the broadcast product, the exact-match comparison, im2col (F.unfold: data movement) and the global max are
+        tensor glue."""
+        B, QL = q.shape
+        N, DL = d.shape[1], d.shape[2]
+        M = B * N
+        table = self.word_embeddings.table
+        p = self.emb_drop.p
+        eq = A.dropout(A.embed(q, table), p, True)
+        ed = A.dropout(A.embed(d.reshape(M, DL), table), p, True)
+        xq = A.linear(eq, self.linear_projection.weight, self.linear_projection.bias)
+        xd = A.linear(ed, self.linear_projection.weight, self.linear_projection.bias)
+        hq = A.bilstm(xq, ql, self.query_encoder.rnns[0])
+        hd = A.bilstm(xd, dl.reshape(-1), self.document_encoder.rnns[0])
+        pq = A.linear(hq, self.query_projection.weight, self.query_projection.bias)            # [B,QL,C]
+        pd = A.linear(hd, self.document_projection.weight, self.document_projection.bias)      # [M,DL,C]
+        C = pq.shape[-1]
+        pqe = pq.unsqueeze(1).expand(B, N, QL, C).reshape(M, QL, C)
+        prod = pqe.unsqueeze(2) * pd.unsqueeze(1)                                              # [M,QL,DL,C]
+        em = (q.unsqueeze(1).expand(B, N, QL).reshape(M, QL).unsqueeze(2) == d.reshape(M, DL).unsqueeze(1)).float()
+        em = em * self.exact_match_channel.alpha
+        T = torch.cat((prod, em.unsqueeze(3)), 3).permute(0, 3, 1, 2).contiguous()            # [M,C+1,QL,DL]
+        feats = []
+        for conv in (self.conv1, self.conv2, self.conv3):
+            kh, kw = conv.kernel_size
+            cols = F.unfold(T, (kh, kw), padding=conv.padding)                                 # [M,(C+1)*kh*kw,QL*DL]
+            rows = cols.transpose(1, 2).reshape(M * QL * DL, -1)
+            feats.append(A.linear(rows, conv.weight.reshape(conv.out_channels, -1), conv.bias, act="relu"))
+        g = A.linear(torch.cat(feats, 1), self.conv.weight.reshape(self.conv.out_channels, -1), self.conv.bias)
+        g = g.view(M, QL * DL, -1).max(1)[0]
+        return A.linear(g, self.output.weight, self.output.bias).view(B, N)
+
     def forward(self, batch_queries, query_len, batch_docs, doc_len, return_parts=False):
         assert batch_queries.shape[0] == batch_docs.shape[0]
-        if self.training and (self.emb_drop.p > 0):
-            raise NotImplementedError("HIP MatchTensor implements the eval-mode forward (SURVEY.md Appendix E7)")
+        if self.training:
+            lib.require_device(batch_queries, batch_docs, query_len, doc_len, self.word_embeddings.table)
+            return self._forward_train(lib.ids64(batch_queries), lib.ids64(query_len), lib.ids64(batch_docs), lib.ids64(doc_len))
         table = self.word_embeddings.table
         lib.require_device(batch_queries, batch_docs, query_len, doc_len, table)
         L = lib.load()

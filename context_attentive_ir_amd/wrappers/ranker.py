@@ -80,7 +80,28 @@ class Ranker(WrapperBase):
         return out[0]
 
     def update(self, ex):
-        raise NotImplementedError("training step (backward + Adam) is the next scope row, SURVEY.md section 8f rank 1")
+        """models/ranker.py:192-230: train-mode forward -> criterion -> backward -> clip_grad_norm(grad_clipping) -> step.
+        Forward/backward of the network and the criterion run on the HIP operators (autograd.py); the optimiser update is
+        torch.optim, as in the reference."""
+        if self.optimizer is None:
+            raise RuntimeError("No optimizer set.")
+        if self.kind not in BCE_MODELS:
+            raise RuntimeError("%s has no training criterion (main/ranker.py:414)" % self.kind)
+        if not hasattr(self.network, "_forward_train"):
+            raise NotImplementedError("train-mode forward of %s is not built yet (MATCH_TENSOR is)" % self.kind)
+        from .. import autograd as A
+        self.network.train()
+        q, ql, d, dl = self._inputs(ex)
+        labels = ex["label"].float()
+        labels = labels.cuda(non_blocking=True) if self.use_cuda else labels
+        scores = self.network(q, ql, d, dl)
+        loss = A.bce_with_logits(scores, labels)
+        self.optimizer.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.args.grad_clipping)
+        self.optimizer.step()
+        self.updates += 1
+        return loss
 
     # -- persistence (save / checkpoint in WrapperBase) ---------------------------------------------
     @staticmethod

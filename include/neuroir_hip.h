@@ -331,6 +331,41 @@ int nir_mnsrf_score(const int64_t* source_ids, const int64_t* source_lens, const
                     const nir_mnsrf_weights* w /*host*/, void* workspace, size_t workspace_bytes, float* scores,
                     nir_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Training step (neuroir/models/ranker.py:192-230, models/multitask.py:161-223): backward halves of the FLOP-carrying
+ * operators and the train-mode forwards that save activations.  Autograd wiring: context_attentive_ir_amd/autograd.py.
+ * ------------------------------------------------------------------------------------------------ */
+/* dW[n,k] += sum_m dY[m,n] * X[m,k]  (weight gradient of nn.Linear / Conv1d-as-GEMM); X dense (ids == NULL) or gathered
+ * embedding rows X[m,:] = table[ids[m], :K].  dW must be zero-initialised (or hold a running sum); slices of M are combined
+ * with fp32 atomics (summation order is not fixed: results vary in the last bits between runs, like any GPU atomics path). */
+int nir_linear_wgrad_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                         float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream);
+/* out[n] += sum_m x[m*ld + n]   (bias gradient) */
+int nir_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream);
+/* out [C,R] = in [R,C]^T  (data gradient: dX = dY W is nir_linear_f32(dY, W^T)) */
+int nir_transpose_f32(const float* in, int R, int C, float* out, nir_stream_t stream);
+/* Train-mode recurrence (same contract as nir_bilstm_fwd, H <= 128) that also stores act [M,T,ndir,4H] (i,f,g,o after their
+ * non-linearities) and cst [M,T,ndir,H] (c_t) of every valid step. */
+int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0, float* out,
+                       float* act, float* cst, float* hn, float* cn, int64_t M, int T, int H, int ndir, nir_stream_t stream);
+/* BPTT: dout [M,T,ndir*H] (+ optional dhn/dcn [ndir,M,H]) -> dgates [M,T,ndir*4H], the gradient w.r.t. gates_in (zero at
+ * t >= length), and optionally dh0/dc0.  dW_ih / dW_hh / db / dx follow from dgates through the GEMM entry points. */
+int nir_lstm_train_bwd(const float* dout, const float* dhn, const float* dcn, const float* act, const float* cst, const float* c0,
+                       const int64_t* lengths, const float* w_hh, float* dgates, float* dh0, float* dc0, int64_t M, int T, int H,
+                       int ndir, nir_stream_t stream);
+/* Inverted dropout with a counter-based mask: keep[i] = uniform(splitmix64(seed ^ i*c)) >= p, y = x*keep/(1-p).  The mask is an
+ * output so that a parity test can replay it through the oracle. */
+int nir_dropout_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, uint64_t seed, nir_stream_t stream);
+int nir_mask_scale_f32(const float* x, const unsigned char* keep, float scale, float* y, int64_t n, nir_stream_t stream);
+/* dx = dy * f'(.) expressed through y = f(x): act 1 tanh, 2 relu, 3 sigmoid. */
+int nir_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int act, nir_stream_t stream);
+/* dscores = (sigmoid(scores) - labels) * grad_out[0] / n   (backward of nir_rank_loss_bce) */
+int nir_rank_loss_bce_bwd(const float* scores, const float* labels, const float* grad_out, float* dscores, int64_t n, nir_stream_t stream);
+/* Embedding lookup out[m,:] = table[ids[m],:] (train mode materialises it: the weight-gradient GEMMs need x) and its backward
+ * (scatter-add, PAD row excluded like nn.Embedding(padding_idx)). */
+int nir_embed_f32(const int64_t* ids, const float* table, int64_t V, int E, int64_t M, float* out, int* err_flag, nir_stream_t stream);
+int nir_embed_bwd_f32(const int64_t* ids, const float* dout, int64_t V, int E, int64_t M, float* dtable, int64_t pad_idx, nir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,10 @@ def rnn_encode(sd, prefix, x, lengths, bidirectional=True, init=None):
         lstm.load_state_dict({n: sd[prefix + ".rnns.0." + n] for n in names})
         lstm.eval()
         cache[key] = lstm
+    if w_ih.requires_grad:          # differentiable use (training-step tests): run the same nn.LSTM on the leaf tensors of `sd`
+        names = [n for n, _ in lstm.named_parameters()]
+        mod, params = lstm, {n: sd[prefix + ".rnns.0." + n] for n in names}
+        lstm = lambda *a: torch.func.functional_call(mod, params, a)    # noqa: E731
     if lengths is None:
         out, fin = lstm(x, init) if init is not None else lstm(x)
         return fin, out
@@ -108,6 +112,31 @@ def match_tensor_scores(sd, q, q_len, d, d_len):
     g = F.conv2d(F.relu(torch.cat(feats, 1)), sd["conv.weight"], sd["conv.bias"])   # [B*N,20,QL,DL]
     pooled = g.flatten(2).max(2)[0]                                    # max over all (padded) positions
     return _lin(sd, "output", pooled).view(B, N)
+
+
+def match_tensor_train_scores(sd, q, q_len, d, d_len, masks=None, p_drop=0.0):
+    """Train-mode MatchTensor forward (mtensor.py:62-131 with emb_drop active), DIFFERENTIABLE (sd holds leaf tensors with
+    requires_grad).  `masks` = (keep_q [B,QL,E], keep_d [B*N,DL,E]) replays externally drawn inverted-dropout masks, so that a
+    product forward and this restatement see identical noise; None = no dropout."""
+    B, QL = q.shape
+    N, DL = d.shape[1], d.shape[2]
+    eq = embed(sd, "word_embeddings", q)
+    ed = embed(sd, "word_embeddings", d.view(B * N, DL))
+    if masks is not None:
+        eq = eq * masks[0].float() / (1.0 - p_drop)
+        ed = ed * masks[1].float() / (1.0 - p_drop)
+    xq, xd = _lin(sd, "linear_projection", eq), _lin(sd, "linear_projection", ed)
+    _, hq = rnn_encode(sd, "query_encoder", xq, q_len)
+    _, hd = rnn_encode(sd, "document_encoder", xd, d_len.reshape(-1))
+    pq, pd = _lin(sd, "query_projection", hq), _lin(sd, "document_projection", hd)
+    C = pq.shape[-1]
+    prod = pq.unsqueeze(1).expand(B, N, QL, C).reshape(B * N, QL, 1, C) * pd.unsqueeze(1)
+    qi = q.unsqueeze(1).expand(B, N, QL).reshape(B * N, QL, 1)
+    exact = (qi == d.view(B * N, 1, DL)).float() * sd["exact_match_channel.alpha"]
+    t = torch.cat((prod, exact.unsqueeze(3)), 3).permute(0, 3, 1, 2)
+    feats = [F.conv2d(t, sd["conv%d.weight" % k], sd["conv%d.bias" % k], padding=(1, k)) for k in (1, 2, 3)]
+    g = F.conv2d(F.relu(torch.cat(feats, 1)), sd["conv.weight"], sd["conv.bias"])
+    return _lin(sd, "output", g.flatten(2).max(2)[0]).view(B, N)
 
 
 # ------------------------------------------------------------------------------------------

@@ -213,6 +213,50 @@ def gen_cars():
              encoded_clicks=clicks, click_scores=scores, softmax=torch.softmax(scores, -1), ranking_loss=loss)
 
 
+def gen_train():
+    """Training step of the real reference (models/ranker.py:192-230): MATCH_TENSOR, dropout 0, Adam lr 1e-3, grad clipping 10,
+    5 updates alternating over two batches -> loss trajectory; gradients of the first backward (before clipping)."""
+    rng = np.random.default_rng(23)
+    B, N, QL, DL = 4, 3, 5, 11
+    batches = []
+    for _ in range(2):
+        qlen = rng.integers(1, QL + 1, size=B); dlen = rng.integers(1, DL + 1, size=(B, N)); qlen[0] = QL; dlen[0, 0] = DL
+        q = rand_ids(rng, (B, QL), qlen); d = rand_ids(rng, (B, N, DL), dlen)
+        lab = np.zeros((B, N), np.int64)
+        lab[np.arange(B), rng.integers(0, N, size=B)] = 1
+        batches.append(dict(que_rep=q, que_len=qlen, doc_rep=d, doc_len=dlen, label=lab))
+    args = base_args("MATCH_TENSOR", dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.001, weight_decay=0,
+                     momentum=0, grad_clipping=10.0, fix_embeddings=True)
+    vocab = list(range(V))
+    r = Ranker(args, vocab)
+    load_det(r.network)
+    r.init_optimizer()
+    b0 = batches[0]
+    r.network.train()
+    s = r.network(T(b0["que_rep"]), T(b0["que_len"]), T(b0["doc_rep"]), T(b0["doc_len"]))
+    loss0 = r.criterion(s, T(b0["label"]).float())
+    r.optimizer.zero_grad()
+    loss0.backward()
+    out = {}
+    for bi, b in enumerate(batches):
+        for k, v in b.items():
+            out["b%d_%s" % (bi, k)] = v
+    for name, p in r.network.named_parameters():
+        if p.grad is not None:
+            out["grad_" + name] = p.grad.detach().clone()
+    out["scores0"], out["loss0"] = s.detach(), loss0.detach()
+    r.optimizer.zero_grad()
+    losses = []
+    for step in range(5):
+        b = batches[step % 2]
+        losses.append(float(r.update({k: T(v) for k, v in b.items()})))
+    out["losses"] = np.asarray(losses, np.float64)
+    final = r.network.state_dict()
+    for k in ("output.weight", "conv.weight", "linear_projection.weight", "document_encoder.rnns.0.weight_hh_l0"):
+        out["final_" + k] = final[k].detach().clone()
+    save("match_tensor_train", **out)
+
+
 @torch.no_grad()
 def gen_cars_decode():
     """CARS suggestion side + session switches from the real reference: decoder-initialisation states, inner-attention
@@ -380,7 +424,7 @@ if __name__ == "__main__":
     torch.manual_seed(SEED)
     torch.set_num_threads(4)
     only = set(sys.argv[1:])          # e.g. `generate.py cars_decode` regenerates one fixture family
-    gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode,
+    gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode, train=gen_train,
                 losses_metrics=gen_losses_metrics, batchify=gen_batchify, samplers=gen_samplers, m_match_tensor=gen_m_match_tensor,
                 mnsrf=gen_mnsrf)
     for name, fn in gens.items():

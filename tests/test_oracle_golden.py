@@ -140,3 +140,19 @@ def test_cars_both_sessions_off():
     scores, states, _ = O.cars_rank_document_full(sd, pooled, d, dl, lab, q_on=False, d_on=False, recommender=False)
     _close(scores, g["bothoff_click_scores"], 2e-6)
     assert states is None
+
+
+def test_match_tensor_train_gradients():
+    """The oracle's differentiable train-mode MatchTensor + BCE against the gradients of the reference's own backward
+    (tests/golden/generate.py:gen_train; dropout 0)."""
+    g = load_golden("match_tensor_train")
+    sd = {k: v.clone().requires_grad_(not k.startswith("word_embeddings")) for k, v in cpu_state_dict(build_model("MATCH_TENSOR")).items()}
+    q, ql, d, dl, lab = (T(g["b0_" + k]) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label"))
+    s = O.match_tensor_train_scores(sd, q, ql, d, dl)
+    _close(s, g["scores0"], 2e-6)
+    loss = O.bce_with_logits(s, lab)
+    _close(loss, g["loss0"], 1e-6)
+    loss.backward()
+    for k, v in sd.items():
+        if torch.is_tensor(v) and v.requires_grad:
+            _close(v.grad, g["grad_" + k], 2e-6)
