@@ -110,6 +110,8 @@ def kernel_work(name, c):
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N), peak=PEAK_FP32_TFLOPS)
     if base.startswith("lstm16_pt_bf16_kernel"):      # M sequences, N = T steps, K = H; both directions in one launch
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * 4), peak=PEAK_BF16_TFLOPS)
+    if base.startswith("lstm16_pt_h2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block -> peak 2500 / 3
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), peak=PEAK_BF16_TFLOPS / 3.0)
     if base.startswith("lstm16_pt_kernel"):
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), peak=PEAK_FP32_TFLOPS)
     if base.startswith("lstm_mfma16_gin_kernel") or base.startswith("lstm_mfma_gin_kernel") or base.startswith("lstm_rec_kernel<"):

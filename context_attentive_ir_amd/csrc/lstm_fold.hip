@@ -358,6 +358,187 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32-accurate recurrence on the fp16 matrix cores (the default parity path for H % 32 == 0):
+//   w = w1 + 2^-11 w2',  h = h1 + 2^-11 h2'   with  w1 = fp16(w), w2' = fp16(2^11 (w - w1))  (both terms carry 11 mantissa bits;
+//   the 2^11 scaling keeps the residual in fp16's normal range), so   w.h = w1.h1 + 2^-11 (w1.h2' + w2'.h1) + O(2^-22 |w.h|)
+// Three v_mfma_f32_16x16x32_f16 per 32-wide k-block (two accumulators: leading term, scaled cross terms) replace the 32
+// v_mfma_f32_16x16x4_f32 of the fp32 kernel: 12 x 16 cycles instead of 32 x 32 cycles of matrix pipe per tile and step, with
+// the same fp32-class error (measured against fp64: 2.9e-6 vs 3.4e-6 for the fp32 chain at K = 128).  Gate math, cell state,
+// the folded table and the output stay fp32.  W_hh terms live in VGPRs (2 x 16 per tile), the two h terms in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int KB, int NT>
+__global__ __launch_bounds__(1024) void lstm16_pt_h2_kernel(LstmPtArgs p) {
+    constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // fp16 elements per h row
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* z = reinterpret_cast<_Float16*>(smem);        // [2 buffers][2 terms][SEQ][ZLD]
+    int* lens_s = reinterpret_cast<int*>(z + 4 * SEQ * ZLD);
+    int* ids_s = lens_s + SEQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int H = p.H, T = p.T, H4 = 4 * H;
+    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int OW = p.ND * H;
+    const int64_t GW = (int64_t)p.ND * H4;
+    const int ntiles = (H + 3) / 4;
+
+    if (tid < SEQ) {
+        int l = 0;
+        if (tid < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    {
+        bool bad = false;
+        for (int e = tid; e < SEQ * T; e += 1024) {
+            const int s = e / T;
+            int64_t id = 0;
+            if (s < nvalid) id = p.ids[m0 * T + e];
+            if (id < 0 || id >= p.V) { bad = true; id = 0; }
+            ids_s[e] = (int)id;
+        }
+        if (bad && p.err) atomicOr(p.err, 1);
+    }
+    for (int e = tid; e < 2 * SEQ * ZLD; e += 1024) reinterpret_cast<unsigned*>(z)[e] = 0u;   // 4*SEQ*ZLD halves
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    const int mylen = lens_s[sq];
+
+    f16x8 w1[NT][KB], w2[NT][KB];
+    float creg[NT], hreg[NT];
+    int unit_d[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tile = NT * wave + t;
+        const int unit_a = 4 * tile + (sq >> 2), gate_a = sq & 3;
+        const bool av = unit_a < H;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0)) * H;
+        // the lane's 8*KB weights of this tile: issued as 2*KB independent 16-byte loads up front (a scalar load -> convert loop
+        // serialises 64 memory round trips and made the prologue cost ~35 us per launch)
+        float wv[KB][8];
+        const bool vec_ok = (H % 8) == 0 && ((reinterpret_cast<uintptr_t>(wr) & 15) == 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int k0 = 32 * kb + 8 * kq;
+            if (vec_ok) {
+                const int kc = k0 + 8 <= H ? k0 : 0;           // branch-free: out-of-range chunks re-read chunk 0 and are zeroed below
+                const float4 a = *reinterpret_cast<const float4*>(wr + kc), b = *reinterpret_cast<const float4*>(wr + kc + 4);
+                const float m = (av && k0 + 8 <= H) ? 1.f : 0.f;
+                wv[kb][0] = a.x * m; wv[kb][1] = a.y * m; wv[kb][2] = a.z * m; wv[kb][3] = a.w * m;
+                wv[kb][4] = b.x * m; wv[kb][5] = b.y * m; wv[kb][6] = b.z * m; wv[kb][7] = b.w * m;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[kb][j] = (av && k0 + j < H) ? wr[k0 + j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = wv[kb][j];
+                const _Float16 a = (_Float16)w;
+                w1[t][kb][j] = a;
+                w2[t][kb][j] = (_Float16)((w - (float)a) * SC);
+            }
+        unit_d[t] = 4 * tile + kq;
+        creg[t] = 0.f;
+        hreg[t] = 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
+                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;
+    auto load_g = [&](int step, f32x4 (&dst)[NT]) {
+        int s_ = min(step, mylen - 1);
+        s_ = s_ < 0 ? 0 : s_;
+        const int t_ = dir == 0 ? s_ : mylen - 1 - s_;
+        const int id = ids_s[sq * T + (t_ < 0 ? 0 : t_)];
+        const float* row = ptf + (int64_t)id * GW;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int u = unit_d[t] < H ? unit_d[t] : H - 1;
+            dst[t] = *reinterpret_cast<const f32x4*>(row + 4 * u);
+        }
+    };
+    f32x4 gcur[NT], gnext[NT];
+    load_g(0, gcur);
+
+    for (int step = 0; step < tmax; ++step) {
+        const _Float16* zc = z + (step & 1) * 2 * SEQ * ZLD;
+        _Float16* zn = z + ((step + 1) & 1) * 2 * SEQ * ZLD;
+        load_g(step + 1, gnext);                     // lands during this step (4 waves per SIMD cover an occasional late row)
+        const bool live = step < mylen;
+        const int tt = dir == 0 ? step : mylen - 1 - step;
+        const _Float16* zr = zc + sq * ZLD + 8 * kq;
+        f32x4 acc[NT], acx[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {            // h terms are read per k-block (8 live VGPRs instead of 8*KB)
+            const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+            const f16x8 h2 = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {           // independent accumulators back to back: no dependent-MFMA stalls
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h1, acc[t], 0, 0, 0);
+                acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h2, acx[t], 0, 0, 0);
+                acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], h1, acx[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (NT * wave + t < ntiles) {            // wave-uniform
+                const bool dv = unit_d[t] < H;
+                const float gi = fast_sigmoid(fmaf(acx[t][0], ISC, acc[t][0]) + gcur[t][0]);
+                const float gf = fast_sigmoid(fmaf(acx[t][1], ISC, acc[t][1]) + gcur[t][1]);
+                const float gg = fast_tanh(fmaf(acx[t][2], ISC, acc[t][2]) + gcur[t][2]);
+                const float go = fast_sigmoid(fmaf(acx[t][3], ISC, acc[t][3]) + gcur[t][3]);
+                const float cn = gf * creg[t] + gi * gg;
+                const float hn = go * fast_tanh(cn);
+                const bool act = dv && live;
+                creg[t] = act ? cn : creg[t];
+                hreg[t] = act ? hn : hreg[t];
+                if (dv) {
+                    const _Float16 a = (_Float16)hreg[t];
+                    zn[sq * ZLD + unit_d[t]] = a;
+                    zn[SEQ * ZLD + sq * ZLD + unit_d[t]] = (_Float16)((hreg[t] - (float)a) * SC);
+                }
+                const uint32_t off = act ? (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn), out_rs, off, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gcur[t] = gnext[t];
+        lds_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (unit_d[t] < H && sq < nvalid) {
+            const int64_t m = m0 + sq;
+            for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
+        }
+    }
+}
+
+template <int KB, int NT>
+static int launch_pt_h2(const LstmPtArgs& p, hipStream_t st) {
+    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + ">";
+    const size_t lds = (size_t)(4 * 16 * (32 * KB + 8)) * 2 + 16 * 4 + (size_t)16 * p.T * 4;
+    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
+    hipLaunchKernelGGL((lstm16_pt_h2_kernel<KB, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2]");
+    return 0;
+}
+
 template <int G, int NT>
 static int launch_pt(const LstmPtArgs& p, hipStream_t st) {
     static const std::string pname = "lstm16_pt_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
@@ -391,6 +572,11 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
         const int KB = (H + 31) / 32;
         if (H <= 64) return KB == 1 ? launch_pt_bf16<1, 1>(p, st) : launch_pt_bf16<2, 1>(p, st);
         return KB == 3 ? launch_pt_bf16<3, 2>(p, st) : launch_pt_bf16<4, 2>(p, st);
+    }
+    if (!tun(g_tun.exact_f32) && H >= 32) {      // fp32-accurate two-term fp16 split on the fp16 matrix cores
+        const int KB = (H + 31) / 32;
+        if (H <= 64) return KB == 1 ? launch_pt_h2<1, 1>(p, st) : launch_pt_h2<2, 1>(p, st);
+        return KB == 3 ? launch_pt_h2<3, 2>(p, st) : launch_pt_h2<4, 2>(p, st);
     }
     const int G = (H + 15) / 16;
     if (H <= 64) {
