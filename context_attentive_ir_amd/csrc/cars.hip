@@ -20,6 +20,7 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
                      int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st);
 constexpr int ACT_MAXOUT2 = 16;
 constexpr int ACT_TANH_ROWDOT16 = 17;
+constexpr int ACT_BOUNDED = 0x100;      // operands bounded by 2^15: the split-precision GEMM may use its fp16 two-term form
 int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
                          int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st);
 int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
@@ -192,8 +193,9 @@ extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, i
     }
     float* enc = encoded ? encoded : p.enc;
     NIR_PROPAGATE(launch_bilstm_folded(folded, dtype, ids, lens, w->whh, enc, err_flag, M, V, T, H, 2, st));
+    // enc = o * tanh(c) lies in (-1,1); the attention weights are bounded (checked by the host when it packs them)
     NIR_PROPAGATE(launch_linear_ex(enc, D, nullptr, nullptr, 0, 0, 0, w->attn0_w, D, w->attn0_b, nullptr, p.lpart, NP, M * T, D, D,
-                                   ACT_TANH_ROWDOT16, w->attn3_w, 0, st));
+                                   ACT_TANH_ROWDOT16 | (w->bounded ? ACT_BOUNDED : 0), w->attn3_w, 0, st));
     {
         ProfScope ps("attn_pool2_kernel", st);
         hipLaunchKernelGGL(attn_pool2_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), (size_t)4 * T * 4, st, enc, p.lpart, NP,

@@ -218,6 +218,7 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
         return NIR_ERR_WORKSPACE;
     }
     const int64_t M = (int64_t)B * N;
+    const int bnd = w->bounded ? 0x100 : 0;          // ACT_BOUNDED (gemm.hip): operands < 2^15 -> fp16 two-term split allowed
     float* sloc = local_out ? local_out : p.sloc;
     float* sdist = dist_out ? dist_out : p.sdist;
     // ---- local model (duet.py:77-121)
@@ -238,7 +239,7 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     NIR_CHECK_LAUNCH("colmax_kernel");
     NIR_PROPAGATE(launch_linear(p.qmax, NF, nullptr, nullptr, 0, 0, 0, w->fc1_w, NF, w->fc1_b, nullptr, p.qv, NF, B, NF, NF, NIR_ACT_TANH, st));
     // ---- distributed model, document side (duet.py:174,180,185)
-    NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, Tc, DL, w->convd1_w, 3 * E, w->convd1_b, nullptr, p.cd, NF, M * Tc, NF, 3 * E, NIR_ACT_TANH, st));
+    NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, Tc, DL, w->convd1_w, 3 * E, w->convd1_b, nullptr, p.cd, NF, M * Tc, NF, 3 * E, NIR_ACT_TANH | bnd, st));
     {
         const int64_t total = (int64_t)M * ((Tp + MP_TR - 1) / MP_TR) * (NF / 4);
         ProfScope ps("maxpool_t_kernel", st);
@@ -246,7 +247,7 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
                            p.pooled, Tc, P, NF / 4, (int64_t)M);
     }
     NIR_CHECK_LAUNCH("maxpool_t_kernel");
-    NIR_PROPAGATE(launch_linear(p.pooled, NF, nullptr, nullptr, 0, 0, 0, w->convd2_w, NF, w->convd2_b, nullptr, p.dd, NF, M * Tp, NF, NF, NIR_ACT_TANH, st));
+    NIR_PROPAGATE(launch_linear(p.pooled, NF, nullptr, nullptr, 0, 0, 0, w->convd2_w, NF, w->convd2_b, nullptr, p.dd, NF, M * Tp, NF, NF, NIR_ACT_TANH | bnd, st));
     // ---- Hadamard + fc2 over positions, fc3, fc4 (duet.py:187-207)
     {
         ProfScope ps("duet_hadamard_kernel", st);

@@ -40,6 +40,9 @@ constexpr int ACT_MAXOUT2 = 16;   // internal: out[m, n/2] = max(v[m,n], v[m,n+1
 // out[m, n/16] = sum over the 16 columns n..n+15 of tanh(v[m,n]) * add[n]   (add = the [N] weight row of the second layer;
 // ldadd unused); the consumer sums the N/16 partials of a row, so the [M,N] hidden activation never reaches HBM.
 constexpr int ACT_TANH_ROWDOT16 = 17;
+// flag OR-ed into `act` by internal callers: every element of both operands is bounded by 2^15 in magnitude (tanh / sigmoid
+// outputs, embedding tables and weights checked when they are packed) -> the large-GEMM path may use the two-term fp16 split
+constexpr int ACT_BOUNDED = 0x100;
 
 // epilogue shared by both kernels: bias / addend / activation / optional pairwise maxout over adjacent columns
 __device__ __forceinline__ void gemm_store(const GemmArgs& p, int64_t m, int n, float v, float bsum) {
@@ -461,15 +464,32 @@ __device__ __forceinline__ void g3_split_store(unsigned short* base, int row, in
     *reinterpret_cast<uint2*>(d + 2 * G3_PLANE) = make_uint2(c01, c23);
 }
 
+// Two-term fp16 split (operands bounded by 2^15, e.g. tanh/sigmoid outputs, embeddings, weights): x = h1 + 2^-11 h2' with
+// h1 = fp16_rtz(x) (v_cvt_pkrtz_f16_f32 converts and packs two values per instruction; the residual is exact) and
+// h2' = fp16(2^11 (x - h1)).  Leading products go to one accumulator set, the two cross terms (scaled by 2^11) to a second one:
+// 3 fp16 MFMAs per k-block instead of 6 bf16 ones, ~4 VALU ops per element instead of 5.5, 2 LDS planes instead of 3.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void g3_split_store_h2(unsigned short* base, int row, int kq, const float4& v) {
+    const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    const float r0 = (v.x - (float)a01[0]) * 2048.0f, r1 = (v.y - (float)a01[1]) * 2048.0f;
+    const float r2 = (v.z - (float)a23[0]) * 2048.0f, r3 = (v.w - (float)a23[1]) * 2048.0f;
+    const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz(r0, r1), b23 = __builtin_amdgcn_cvt_pkrtz(r2, r3);
+    unsigned short* d = base + (kq >> 1) * G3_HALF + row * 8 + (kq & 1) * 4;
+    *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
+    *reinterpret_cast<uint2*>(d + G3_PLANE) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+}
+
 // MODE 0: dense A; 1: embedding gather, one row per A row (K <= E); 2: conv taps (E < K <= 3E, one table row per tap).
 // The mode is a template parameter and every load is unconditional (row pointers of out-of-range rows are clamped to a valid
 // row -- their products land in accumulator rows / columns the epilogue never stores), so the k-loop has no branches: a
 // predicated load would become its own basic block with a vmcnt(0) in front of it.  Only the K tail tile masks its operands.
-template <int MODE>
+template <int MODE, bool H2>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
+    constexpr int NTERM = H2 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem3[];
-    unsigned short* As = smem3;                        // [2 stages][3 terms][G3_PLANE]
-    unsigned short* Ws = smem3 + 2 * 3 * G3_PLANE;
+    unsigned short* As = smem3;                        // [2 stages][NTERM terms][G3_PLANE]
+    unsigned short* Ws = smem3 + 2 * NTERM * G3_PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nb = (p.N + G3_BN - 1) / G3_BN;
@@ -525,18 +545,26 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            g3_split_store(As + buf * 3 * G3_PLANE, lr + 64 * i, kq, ra[i]);
-            g3_split_store(Ws + buf * 3 * G3_PLANE, lr + 64 * i, kq, rw[i]);
+            if (H2) {
+                g3_split_store_h2(As + buf * NTERM * G3_PLANE, lr + 64 * i, kq, ra[i]);
+                g3_split_store_h2(Ws + buf * NTERM * G3_PLANE, lr + 64 * i, kq, rw[i]);
+            } else {
+                g3_split_store(As + buf * NTERM * G3_PLANE, lr + 64 * i, kq, ra[i]);
+                g3_split_store(Ws + buf * NTERM * G3_PLANE, lr + 64 * i, kq, rw[i]);
+            }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], acx[H2 ? 2 : 1][H2 ? 2 : 1];     // acx: the 2^11-scaled cross terms of the fp16 split
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                acc[a][b][r] = 0.0f;
+                if (H2) acx[a][b][r] = 0.0f;
+            }
 
     const int nk = (p.K + G3_BK - 1) / G3_BK;
     const bool ktail = (p.K % G3_BK) != 0;
@@ -547,26 +575,44 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
     const int foff_a = (lane >> 5) * G3_HALF + (wm * 64 + (lane & 31)) * 8;
     const int foff_w = (lane >> 5) * G3_HALF + (wn * 64 + (lane & 31)) * 8;
     auto mma_tile = [&](int buf) {
-        const unsigned short* ab = As + buf * 3 * G3_PLANE + foff_a;
-        const unsigned short* wb = Ws + buf * 3 * G3_PLANE + foff_w;
-        bf16x8 af[2][3], wf[2][3];
+        const unsigned short* ab = As + buf * NTERM * G3_PLANE + foff_a;
+        const unsigned short* wb = Ws + buf * NTERM * G3_PLANE + foff_w;
+        if constexpr (H2) {
+            f16x8 af[2][2], wf[2][2];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i][t] = *reinterpret_cast<const bf16x8*>(ab + t * G3_PLANE + i * 32 * 8);
-                wf[i][t] = *reinterpret_cast<const bf16x8*>(wb + t * G3_PLANE + i * 32 * 8);
+                for (int i = 0; i < 2; ++i) {
+                    af[i][t] = *reinterpret_cast<const f16x8*>(ab + t * G3_PLANE + i * 32 * 8);
+                    wf[i][t] = *reinterpret_cast<const f16x8*>(wb + t * G3_PLANE + i * 32 * 8);
+                }
+#define G3_H2(ACC, TA, TW)                                                                                       \
+            ACC[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][TA], wf[0][TW], ACC[0][0], 0, 0, 0);        \
+            ACC[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][TA], wf[1][TW], ACC[0][1], 0, 0, 0);        \
+            ACC[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][TA], wf[0][TW], ACC[1][0], 0, 0, 0);        \
+            ACC[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][TA], wf[1][TW], ACC[1][1], 0, 0, 0);
+            G3_H2(acx, 1, 0) G3_H2(acx, 0, 1) G3_H2(acc, 0, 0)
+#undef G3_H2
+        } else {
+            bf16x8 af[2][3], wf[2][3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i][t] = *reinterpret_cast<const bf16x8*>(ab + t * G3_PLANE + i * 32 * 8);
+                    wf[i][t] = *reinterpret_cast<const bf16x8*>(wb + t * G3_PLANE + i * 32 * 8);
+                }
             }
-        }
-        // six cross terms, smallest first; the four accumulator tiles are interleaved inside each term so that consecutive
-        // MFMAs never depend on each other
+            // six cross terms, smallest first; the four accumulator tiles are interleaved inside each term so that consecutive
+            // MFMAs never depend on each other
 #define G3_TERM(TA, TW)                                                                                          \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][TA], wf[0][TW], acc[0][0], 0, 0, 0);           \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][TA], wf[1][TW], acc[0][1], 0, 0, 0);           \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][TA], wf[0][TW], acc[1][0], 0, 0, 0);           \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][TA], wf[1][TW], acc[1][1], 0, 0, 0);
-        G3_TERM(2, 0) G3_TERM(1, 1) G3_TERM(0, 2) G3_TERM(1, 0) G3_TERM(0, 1) G3_TERM(0, 0)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][TA], wf[0][TW], acc[0][0], 0, 0, 0);       \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][TA], wf[1][TW], acc[0][1], 0, 0, 0);       \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][TA], wf[0][TW], acc[1][0], 0, 0, 0);       \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][TA], wf[1][TW], acc[1][1], 0, 0, 0);
+            G3_TERM(2, 0) G3_TERM(1, 1) G3_TERM(0, 2) G3_TERM(1, 0) G3_TERM(0, 1) G3_TERM(0, 0)
 #undef G3_TERM
+        }
     };
     for (int kt = 0; kt + 2 < nk; ++kt) {              // steady state: the next tile is a full one
         load_tile((kt + 1) * G3_BK, false);
@@ -600,7 +646,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                gemm_store(p, m, n, acc[a][b][r], bsum);
+                float v = acc[a][b][r];
+                if (H2) v = fmaf(acx[a][b][r], 1.0f / 2048.0f, v);
+                gemm_store(p, m, n, v, bsum);
             }
     }
 }
@@ -635,6 +683,8 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* x, int64_t ldx
 int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
                      int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
                      int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st) {
+    const bool bounded = (act & ACT_BOUNDED) != 0;
+    act &= ~ACT_BOUNDED;
     NIR_REQUIRE(M >= 0 && N > 0 && K > 0, "linear: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
     NIR_REQUIRE(w && c, "linear: null weight/output");
     NIR_REQUIRE(ids ? (table != nullptr && E > 0 && rows_per_seq > 0) : (a != nullptr), "linear: null A operand");
@@ -655,12 +705,19 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     const int mode3 = !ids ? 0 : (K <= E ? 1 : (K <= 3 * E ? 2 : -1));
     if (vec && !exact_f32 && mode3 >= 0 && N >= 96 && K >= 32 && mb3 * nb3 >= 96) {
         // large GEMMs: fp32 accuracy from three-term bf16 splits on the bf16 matrix cores (2.65 x the f32 MFMA roof)
-        ProfScope ps(prof_shape_name(ids ? "gemm3_kernel[gather]" : "gemm3_kernel", M, N, K), st);
-        constexpr size_t lds3 = (size_t)2 * 2 * 3 * G3_PLANE * 2;
+        ProfScope ps(prof_shape_name(bounded ? (ids ? "gemm3h_kernel[gather]" : "gemm3h_kernel") : (ids ? "gemm3_kernel[gather]" : "gemm3_kernel"), M, N, K), st);
         dim3 grid((unsigned)(8 * nb3 * ((mb3 + 7) / 8)));
-        if (mode3 == 0) hipLaunchKernelGGL(gemm3_kernel<0>, grid, dim3(256), lds3, st, p);
-        else if (mode3 == 1) hipLaunchKernelGGL(gemm3_kernel<1>, grid, dim3(256), lds3, st, p);
-        else hipLaunchKernelGGL(gemm3_kernel<2>, grid, dim3(256), lds3, st, p);
+        if (bounded) {
+            constexpr size_t lds = (size_t)2 * 2 * 2 * G3_PLANE * 2;
+            if (mode3 == 0) hipLaunchKernelGGL((gemm3_kernel<0, true>), grid, dim3(256), lds, st, p);
+            else if (mode3 == 1) hipLaunchKernelGGL((gemm3_kernel<1, true>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((gemm3_kernel<2, true>), grid, dim3(256), lds, st, p);
+        } else {
+            constexpr size_t lds = (size_t)2 * 2 * 3 * G3_PLANE * 2;
+            if (mode3 == 0) hipLaunchKernelGGL((gemm3_kernel<0, false>), grid, dim3(256), lds, st, p);
+            else if (mode3 == 1) hipLaunchKernelGGL((gemm3_kernel<1, false>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((gemm3_kernel<2, false>), grid, dim3(256), lds, st, p);
+        }
         NIR_CHECK_LAUNCH("nir_linear_f32[bf16x3]");
         return 0;
     }

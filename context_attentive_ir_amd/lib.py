@@ -34,10 +34,10 @@ DuetWeights = _struct(
     ["l_conv_w", "l_conv_b", "l_fc1_w", "l_fc1_b", "l_fc2_w", "l_fc2_b", "l_fc3_w", "l_fc3_b",
      "convq_w", "convq_b", "convd1_w", "convd1_b", "convd2_w", "convd2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
      "fc3_w", "fc3_b", "fc4_w", "fc4_b"],
-    ["NF", "pool"])
+    ["NF", "pool", "bounded"])
 CarsEncoderWeights = _struct(
     "nir_cars_encoder_weights",
-    ["wih", "whh", "bih", "bhh", "attn0_w", "attn0_b", "attn3_w", "attn3_b"], ["H"])
+    ["wih", "whh", "bih", "bhh", "attn0_w", "attn0_b", "attn3_w", "attn3_b"], ["H", "bounded"])
 CarsSessionWeights = _struct(
     "nir_cars_session_weights",
     ["click0_w", "click0_b", "click3_w", "click3_b", "sq_attn_w", "sq_attn_b", "sd_attn_w", "sd_attn_b",

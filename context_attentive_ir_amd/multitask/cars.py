@@ -133,7 +133,8 @@ class CARS(nn.Module):
             wih, whh, bih, bhh = lstm_cat_weights(enc.rnns[0])
             return lib.Packed(lib.CarsEncoderWeights,
                               dict(wih=wih, whh=whh, bih=bih, bhh=bhh, attn0_w=attn[0].weight, attn0_b=attn[0].bias,
-                                   attn3_w=attn[3].weight, attn3_b=attn[3].bias), dict(H=enc.hidden))
+                                   attn3_w=attn[3].weight, attn3_b=attn[3].bias),
+                              dict(H=enc.hidden, bounded=int(float(attn[0].weight.detach().abs().max()) < 32768.0)))
         return cache.get(list(enc.parameters()) + list(attn.parameters()), build)
 
     def _session_modules(self):

@@ -71,8 +71,12 @@ class DUET(nn.Module):
                      convd2_w=dm.conv_d2.weight.squeeze(2), convd2_b=dm.conv_d2.bias,
                      fc1_w=dm.fc1.weight, fc1_b=dm.fc1.bias, fc2_w=dm.fc2.weight, fc2_b=dm.fc2.bias,
                      fc3_w=dm.fc3.weight, fc3_b=dm.fc3.bias, fc4_w=dm.fc4.weight, fc4_b=dm.fc4.bias)
-            return lib.Packed(lib.DuetWeights, t, self._dims)
-        params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
+            # host-side bound check, once per weight version: table and conv weights below 2^15 in magnitude -> the two big
+            # convolution GEMMs may use the fp16 two-term split (their other operand is a tanh output)
+            mx = max(float(self.word_embeddings.table.detach().abs().max()), float(dm.conv_d1.weight.detach().abs().max()),
+                     float(dm.conv_d2.weight.detach().abs().max()), float(dm.conv_q.weight.detach().abs().max()))
+            return lib.Packed(lib.DuetWeights, t, dict(self._dims, bounded=int(mx < 32768.0)))
+        params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")] + [self.word_embeddings.table]
         return self._pack.get(params, build)
 
     def forward(self, batch_queries, query_len, batch_docs, doc_len, return_parts=False):

@@ -186,6 +186,8 @@ typedef struct {
     const float *fc3_w, *fc3_b;        /* [NF,NF] */
     const float *fc4_w, *fc4_b;        /* [1,NF],[1] */
     int NF, pool;                      /* 300, 5 */
+    int bounded;                       /* host-checked: embedding table and conv weights < 2^15 in magnitude -> the convolution
+                                          GEMMs may use the fp16 two-term split */
 } nir_duet_weights;
 size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w /*host*/);
 /* local_out / dist_out: optional [B,N] debug outputs (NULL to skip). Requires QL >= 3 and DL >= 7. */
@@ -201,6 +203,8 @@ typedef struct {
     const float *attn0_w, *attn0_b;      /* {q,d}_attn.0 [2H,2H],[2H] */
     const float *attn3_w, *attn3_b;      /* {q,d}_attn.3 [1,2H],[1] */
     int H;                               /* 128 per direction */
+    int bounded;                         /* host-checked: every attention weight is < 2^15 in magnitude (the encoder outputs are in
+                                            (-1,1) by construction) -> the attention GEMM may use the fp16 two-term split */
 } nir_cars_encoder_weights;
 size_t nir_cars_encode_workspace_bytes(int64_t M, int T, int E, const nir_cars_encoder_weights* w /*host*/);
 /* CARS.encode / CARS.encode_document (cars.py:193-260): ids [M,T], lens [M] -> pooled [M,2H];
