@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
 
 // pred[i*pstride] = argmax_v logits[i,v] (first index on ties); tgt[i] = lut ? lut[pred] : pred
 __global__ __launch_bounds__(256) void argmax_map_kernel(const float* __restrict__ logits, int64_t V, const int64_t* __restrict__ lut,
-                                                         int64_t* __restrict__ pred, int64_t pstride, int64_t* __restrict__ tgt) {
+                                                         int64_t* __restrict__ pred, int64_t pstride, int64_t* __restrict__ tgt,
+                                                         int64_t Vsrc) {
     __shared__ float bv[256];
     __shared__ int64_t bi[256];
     const int i = blockIdx.x;
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(256) void argmax_map_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         int64_t w = bi[0] < V ? bi[0] : 0;
         pred[(int64_t)i * pstride] = w;
-        tgt[i] = lut ? lut[w] : w;
+        const int64_t nxt = lut ? lut[w] : w;
+        tgt[i] = (nxt >= 0 && nxt < Vsrc) ? nxt : 1;     // a token without a source-vocabulary row is fed back as <unk> (id 1), like src_dict[word]
     }
 }
 
@@ -217,7 +219,7 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
         NIR_PROPAGATE(launch_linear(p.p1, P, nullptr, nullptr, 0, 0, 0, w->pred2_w, P, nullptr, nullptr, p.logits, w->VT, Bd, (int)w->VT, P, NIR_ACT_NONE, st));
         {
             ProfScope ps("argmax_map_kernel", st);
-            hipLaunchKernelGGL(argmax_map_kernel, dim3((unsigned)Bd), dim3(256), 0, st, p.logits, w->VT, tgt2src, predictions + step, (int64_t)max_len, p.tgt);
+            hipLaunchKernelGGL(argmax_map_kernel, dim3((unsigned)Bd), dim3(256), 0, st, p.logits, w->VT, tgt2src, predictions + step, (int64_t)max_len, p.tgt, V);
         }
         NIR_CHECK_LAUNCH("argmax_map_kernel");
         hp = hn;

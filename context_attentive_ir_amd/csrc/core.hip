@@ -192,3 +192,31 @@ extern "C" int nir_debug_clock_probe(void* out, int iters, int blocks, void* sin
 
 extern "C" int nir_version(void) { return 100; }
 extern "C" const char* nir_last_error_string(void) { return nir::g_err; }
+
+
+// Token-id validation shared by every model front end (the reference's nn.Embedding raises IndexError for an id outside
+// [0, V); an unchecked gather would read out of bounds): copies up to two id tensors, replacing invalid ids by 0 (PAD) and raising
+// a device flag the host can poll (never synchronises here).
+__global__ void sanitize_ids_kernel(const int64_t* a, int64_t na, const int64_t* b, int64_t nb, int64_t V, int64_t* oa, int64_t* ob, int* err) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na + nb) return;
+    const bool first = i < na;
+    int64_t id = first ? a[i] : b[i - na];
+    if (id < 0 || id >= V) {
+        if (err) atomicOr(err, 1);
+        id = 0;
+    }
+    if (first) oa[i] = id;
+    else ob[i - na] = id;
+}
+extern "C" int nir_sanitize_ids(const int64_t* a, int64_t na, const int64_t* b, int64_t nb, int64_t V, int64_t* out_a, int64_t* out_b,
+                                int* err_flag, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(na >= 0 && nb >= 0 && V > 0, "sanitize_ids: bad dims");
+    NIR_REQUIRE((na == 0 || (a && out_a)) && (nb == 0 || (b && out_b)), "sanitize_ids: null pointer");
+    const int64_t n = na + nb;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sanitize_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, V, out_a, out_b, err_flag);
+    NIR_CHECK_LAUNCH("sanitize_ids_kernel");
+    return 0;
+}

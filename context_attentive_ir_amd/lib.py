@@ -70,6 +70,7 @@ SIGNATURES = {
     "nir_debug_set_tunable": (_i, [C.c_char_p, _i]),
     "nir_profile_enable": (_i, [_i]),
     "nir_profile_report": (_i, [C.c_char_p, _z]),
+    "nir_sanitize_ids": (_i, [c_ip, _l, c_ip, _l, _l, c_ip, c_ip, C.c_void_p, c_st]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_rowdot_f32": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, _i, _i, c_st]),
     "nir_bilstm_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
@@ -288,3 +289,32 @@ class tunable(object):
     def __exit__(self, *exc):
         load().nir_debug_set_tunable(self.name, self.restore)
         return False
+
+
+class IdCheck(object):
+    """Mixin of the network mirrors: `q, d = self._clean_ids(q, d, V)` validates token ids on the device (nir_sanitize_ids, one
+    launch, no sync) and `check_ids()` raises the IndexError the reference's nn.Embedding would have raised at the lookup.
+    `validate_ids = False` skips the launch for callers that guarantee 0 <= id < V themselves."""
+    validate_ids = True
+
+    def _clean_ids(self, a, b, V):
+        a = ids64(a)
+        b = ids64(b) if b is not None else None
+        if not self.validate_ids:
+            return a, b
+        flag = getattr(self, "_id_flag", None)
+        if flag is None or flag.device != a.device:
+            flag = self._id_flag = torch.zeros(1, dtype=torch.int32, device=a.device)
+        oa = torch.empty_like(a)
+        ob = torch.empty_like(b) if b is not None else None
+        check(load().nir_sanitize_ids(ptr(a), a.numel(), ptr(b), b.numel() if b is not None else 0, int(V), ptr(oa), ptr(ob), ptr(flag),
+                                      stream()), "nir_sanitize_ids")
+        return oa, ob
+
+    def check_ids(self):
+        """Synchronising: raise IndexError if any forward since the last check saw an id outside the vocabulary."""
+        for name in ("_id_flag", "_err_flag"):
+            flag = getattr(self, name, None)
+            if flag is not None and int(flag.item()) != 0:
+                flag.zero_()
+                raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")

@@ -49,7 +49,7 @@ class _RNNDecoderParams(nn.Module):
         self.attn.linear_out = nn.Linear(2 * nhid, nhid, bias=False)
 
 
-class CARS(nn.Module):
+class CARS(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1 or args.pool_type != "attn":
@@ -225,14 +225,6 @@ class CARS(nn.Module):
         per = table.shape[0] * 8 * H * (2 if self.compute_dtype == "bf16" else 4)
         return 2 * per <= self.fold_budget_bytes and H >= 8 and (2 * H) % 64 == 0
 
-    def check_ids(self):
-        """Raise IndexError if any folded-path call since the last check saw a token id outside the vocabulary (the
-        reference's nn.Embedding raises at the lookup; the kernels clamp to row 0 and set a device flag instead of faulting).
-        Reads one int from the device, i.e. synchronises -- call it outside latency-critical loops."""
-        if self._err_flag is not None and int(self._err_flag.item()) != 0:
-            self._err_flag.zero_()
-            raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
-
     def _encode_seqs(self, which, ids, lens, want_encoded):
         table = self.embedder.word_embeddings.table
         lib.require_device(ids, lens, table)
@@ -253,6 +245,7 @@ class CARS(nn.Module):
                                                table.shape[0], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(pooled),
                                                lib.ptr(encoded), lib.ptr(self._err_flag), lib.stream()), "nir_cars_encode_folded")
             return pooled, encoded
+        ids, _ = self._clean_ids(ids, None, table.shape[0])       # the per-batch gather-GEMM path has no in-kernel id check
         ws = lib.workspace(L.nir_cars_encode_workspace_bytes(M, T, table.shape[1], w.ref()), dev)
         lib.check(L.nir_cars_encode(lib.ptr(ids), lib.ptr(lens), M, T, lib.ptr(table), table.shape[0], table.shape[1],
                                     w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(pooled), lib.ptr(encoded), lib.stream()),

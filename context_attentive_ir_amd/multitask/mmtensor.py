@@ -25,7 +25,7 @@ class _PlainDecoderParams(nn.Module):
         self.rnn = nn.LSTM(emsize, nhid, 1, batch_first=True)
 
 
-class M_MATCH_TENSOR(nn.Module):
+class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1:
@@ -112,7 +112,7 @@ class M_MATCH_TENSOR(nn.Module):
         L = lib.load()
         B, S, N, DL = document_rep.shape
         QL = source_rep.shape[2]
-        q, d = lib.ids64(source_rep.reshape(B * S, QL)), lib.ids64(document_rep.reshape(B * S, N, DL))
+        q, d = self._clean_ids(source_rep.reshape(B * S, QL), document_rep.reshape(B * S, N, DL), table.shape[0])
         ql, dl = lib.ids64(src_len.reshape(-1)), lib.ids64(document_len.reshape(-1))
         w = self._weights()
         ws = lib.workspace(L.nir_matchtensor_workspace_bytes(B * S, N, QL, DL, w.ref()), q.device)

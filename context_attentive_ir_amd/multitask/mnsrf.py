@@ -18,7 +18,7 @@ from .layers import Embedder, Encoder
 from .mmtensor import _PlainDecoderParams
 
 
-class MNSRF(nn.Module):
+class MNSRF(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1:
@@ -88,8 +88,8 @@ class MNSRF(nn.Module):
         L = lib.load()
         B, S, N, DL = document_rep.shape
         QL = source_rep.shape[2]
-        src, sl = lib.ids64(source_rep.reshape(B * S, QL)), lib.ids64(src_len.reshape(-1))
-        d, dl = lib.ids64(document_rep.reshape(B * S * N, DL)), lib.ids64(document_len.reshape(-1))
+        src, d = self._clean_ids(source_rep.reshape(B * S, QL), document_rep.reshape(B * S * N, DL), table.shape[0])
+        sl, dl = lib.ids64(src_len.reshape(-1)), lib.ids64(document_len.reshape(-1))
         w = self._weights()
         ws = lib.workspace(L.nir_mnsrf_workspace_bytes(B, S, N, QL, DL, w.ref()), src.device)
         scores = torch.empty(B, S, N, device=src.device, dtype=torch.float32)

@@ -24,7 +24,7 @@ class GatingNetwork(nn.Module):
         self.weight = nn.Linear(emsize, 1)
 
 
-class DRMM(nn.Module):
+class DRMM(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         self.word_embeddings = Embeddings(args.emsize, args.src_vocab_size, PAD)
@@ -53,7 +53,7 @@ class DRMM(nn.Module):
             raise NotImplementedError("HIP DRMM implements the eval-mode forward (SURVEY.md Appendix E7)")
         table = self.word_embeddings.table
         lib.require_device(batch_queries, batch_docs, table)
-        q, d = lib.ids64(batch_queries), lib.ids64(batch_docs)
+        q, d = self._clean_ids(batch_queries, batch_docs, self.word_embeddings.table.shape[0])
         B, QL = q.shape
         N, DL = d.shape[1], d.shape[2]
         w = self._weights()

@@ -44,7 +44,7 @@ class DistributedModel(nn.Module):
         self.fc4 = nn.Linear(args.nfilters, 1)
 
 
-class DUET(nn.Module):
+class DUET(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         self.use_word = args.use_word
@@ -85,7 +85,7 @@ class DUET(nn.Module):
             raise NotImplementedError("HIP DUET implements the eval-mode forward (SURVEY.md Appendix E7)")
         table = self.word_embeddings.table
         lib.require_device(batch_queries, batch_docs, table)
-        q, d = lib.ids64(batch_queries), lib.ids64(batch_docs)
+        q, d = self._clean_ids(batch_queries, batch_docs, table.shape[0])
         B, QL = q.shape
         N, DL = d.shape[1], d.shape[2]
         if QL != self.max_query_len or DL != self.max_doc_len:

@@ -11,7 +11,7 @@ from ..constants import PAD
 from ..modules import Embeddings
 
 
-class ESM(nn.Module):
+class ESM(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         self.word_embeddings = Embeddings(args.emsize, args.src_vocab_size, PAD)
@@ -19,7 +19,7 @@ class ESM(nn.Module):
     def forward(self, batch_queries, query_len, batch_docs, doc_len):
         assert batch_queries.shape[0] == batch_docs.shape[0]
         lib.require_device(batch_queries, batch_docs, self.word_embeddings.table)
-        q, d = lib.ids64(batch_queries), lib.ids64(batch_docs)
+        q, d = self._clean_ids(batch_queries, batch_docs, self.word_embeddings.table.shape[0])
         B, QL = q.shape
         N, DL = d.shape[1], d.shape[2]
         table = self.word_embeddings.table

@@ -25,7 +25,7 @@ class ExactMatchChannel(nn.Module):
         self.alpha = nn.Parameter(torch.rand(1))
 
 
-class MatchTensor(nn.Module):
+class MatchTensor(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         self.word_embeddings = Embeddings(args.emsize, args.src_vocab_size, PAD)
@@ -104,11 +104,12 @@ class MatchTensor(nn.Module):
         assert batch_queries.shape[0] == batch_docs.shape[0]
         if self.training:
             lib.require_device(batch_queries, batch_docs, query_len, doc_len, self.word_embeddings.table)
-            return self._forward_train(lib.ids64(batch_queries), lib.ids64(query_len), lib.ids64(batch_docs), lib.ids64(doc_len))
+            q, d = self._clean_ids(batch_queries, batch_docs, self.word_embeddings.table.shape[0])
+            return self._forward_train(q, lib.ids64(query_len), d, lib.ids64(doc_len))
         table = self.word_embeddings.table
         lib.require_device(batch_queries, batch_docs, query_len, doc_len, table)
         L = lib.load()
-        q, d = lib.ids64(batch_queries), lib.ids64(batch_docs)
+        q, d = self._clean_ids(batch_queries, batch_docs, table.shape[0])
         ql, dl = lib.ids64(query_len), lib.ids64(doc_len.reshape(-1))
         B, QL = q.shape
         N, DL = d.shape[1], d.shape[2]

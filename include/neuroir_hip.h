@@ -66,6 +66,13 @@ int nir_debug_set_buffer(void* dev_u64);
 int nir_profile_enable(int on);
 int nir_profile_report(char* buf /*host*/, size_t cap);
 
+/* Token-id contract of every entry point that takes ids: 0 <= id < V.  The kernels gather table rows without a bounds check, so
+ * the host mirrors validate first with this call (one launch for up to two id tensors): invalid ids are replaced by 0 (PAD) in
+ * the copies out_a / out_b and *err_flag (device int, may be NULL) is set -- the reference's nn.Embedding raises IndexError; the
+ * mirrors raise it from `check_ids()`.  (nir_bilstm_folded_fwd / nir_cars_encode_folded validate in-kernel.) */
+int nir_sanitize_ids(const int64_t* a, int64_t na, const int64_t* b, int64_t nb, int64_t V, int64_t* out_a, int64_t* out_b,
+                     int* err_flag, nir_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Building blocks
  * ------------------------------------------------------------------------------------------------ */

@@ -673,3 +673,26 @@ def test_rnn_encoder_streaming_recurrence(H, I, M, T_, bi):
     _close(out, ref, 3e-5)
     order = torch.sort(lens, 0, True)[1]
     _close(hn[:, order], hn_ref, 3e-5); _close(cn[:, order], cn_ref, 3e-5)
+
+
+@pytest.mark.parametrize("kind", ["ESM", "MATCH_TENSOR", "DRMM", "DUET"])
+def test_out_of_vocabulary_ids_raise_index_error(kind):
+    """nn.Embedding raises IndexError for id >= V or < 0 (reference); the mirrors validate on the device (nir_sanitize_ids),
+    keep running on PAD instead of reading out of bounds, and raise from check_ids()."""
+    V = 300
+    kw = dict(max_query_len=5, max_doc_len=20) if kind == "DUET" else {}
+    m = build_model(kind, vocab=V, device=DEV, **kw)
+    rng = np.random.default_rng(5)
+    q, ql, d, dl = (t.to(DEV) for t in _synth(rng, 3, 4, 5, 20, V, full=True))
+    good = m(q, ql, d, dl).clone()
+    m.check_ids()
+    for bad_id in (V, V + 12345, -1):
+        bad = d.clone()
+        bad[1, 2, 3] = bad_id
+        out = m(q, ql, bad, dl)
+        with pytest.raises(IndexError):
+            m.check_ids()
+        ref = d.clone(); ref[1, 2, 3] = 0
+        _close(out, m(q, ql, ref, dl), 1e-6)            # the invalid id was scored as PAD, nothing was read out of bounds
+    m.check_ids()                                           # flag cleared
+    _close(m(q, ql, d, dl), good, 0)
