@@ -186,7 +186,8 @@ def test_match_tensor_golden():
     _close(s, g["scores"])
 
 
-@pytest.mark.parametrize("B,N,QL,DL,full", [(32, 10, 4, 64, True), (4, 3, 6, 64, False), (2, 5, 1, 7, False), (3, 2, 9, 130, False)])
+@pytest.mark.parametrize("B,N,QL,DL,full", [(32, 10, 4, 64, True), (4, 3, 6, 64, False), (2, 5, 1, 7, False), (3, 2, 9, 130, False),
+                                            (2, 3, 6, 290, True), (3, 50, 4, 290, False)])      # max_doc_len recurrences (T = 290)
 def test_match_tensor_oracle(B, N, QL, DL, full):
     rng = np.random.default_rng(B * 100 + DL)
     m = build_model("MATCH_TENSOR", vocab=300, device=DEV)     # small vocab -> exact-match channel is exercised
@@ -205,17 +206,25 @@ def test_drmm_golden_safe():
 
 
 def test_drmm_golden_overlap_policy():
-    """Appendix E1 policy: with exact token overlaps the count of histogram mismatches is reported; pairs whose
-    histograms agree must agree in score."""
+    """Appendix E1: at an exact token overlap the cosine is 1 +- 1 ulp depending on the reduction order, so numpy.histogram puts it
+    into [.5,1), {1} or drops it -- the reference itself is not reproducible there.  What IS pinned: (a) the three lower bins
+    never differ from the reference, (b) a (pair, query term) row can only differ in the two top bins, by at most 2 per exact
+    overlap of that query term (one count leaving a bin, one entering another), (c) pairs whose histograms agree agree in score,
+    (d) the number of affected pairs on the fixture is the measured 6 of 12 (+-1: one overlap sits exactly on the rounding edge)."""
     g = load_golden("drmm_overlap")
     m = build_model("DRMM", device=DEV)
     s, hist = m(T(g["que_rep"], DEV), T(g["que_len"], DEV), T(g["doc_rep"], DEV), T(g["doc_len"], DEV), return_hist=True)
-    same = (hist.cpu().numpy() == g["hist"]).all(axis=(1, 2))
-    print("drmm overlap: %d/%d pairs with identical histograms" % (same.sum(), same.size))
-    assert same.mean() >= 0.5
-    _close(s.cpu().numpy().reshape(-1)[same], g["scores"].reshape(-1)[same])
-    # counts always sum to DL minus dropped (>1) values
-    assert (hist.sum(-1) <= g["doc_rep"].shape[2]).all()
+    h, r = hist.cpu().numpy(), g["hist"]
+    q, d = g["que_rep"], g["doc_rep"]
+    B, N, DL = d.shape
+    np.testing.assert_array_equal(h[..., :3], r[..., :3])                                                   # (a)
+    overlaps = ((q[:, None, :, None] == d[:, :, None, :]) & (q[:, None, :, None] != 0)).sum(-1)              # [B,N,QL]
+    top_diff = np.abs(h[..., 3:] - r[..., 3:]).sum(-1).reshape(B, N, -1)
+    assert (top_diff <= 2 * overlaps).all()                                                                  # (b)
+    same = (h == r).all(axis=(1, 2))
+    _close(s.cpu().numpy().reshape(-1)[same], g["scores"].reshape(-1)[same])                                 # (c)
+    assert abs(int((~same).sum()) - 6) <= 1, int((~same).sum())                                              # (d)
+    assert (h.sum(-1) <= DL).all()
 
 
 @pytest.mark.parametrize("B,N,QL,DL", [(4, 6, 4, 290), (2, 3, 12, 64)])
@@ -282,7 +291,8 @@ def test_cars_golden(tag):
     _close(out["ranking_loss"], g["ranking_loss"], 1e-5)
 
 
-@pytest.mark.parametrize("B,S,N,QL,DL,multi", [(16, 7, 10, 4, 64, False), (3, 2, 50, 6, 33, True), (2, 1, 1, 3, 5, False)])
+@pytest.mark.parametrize("B,S,N,QL,DL,multi", [(16, 7, 10, 4, 64, False), (3, 2, 50, 6, 33, True), (2, 1, 1, 3, 5, False),
+                                               (2, 2, 5, 40, 290, True)])                       # max_doc_len / max query length recurrences
 def test_cars_oracle(B, S, N, QL, DL, multi):
     from context_attentive_ir_amd import synth
     V = 3000
@@ -696,3 +706,46 @@ def test_out_of_vocabulary_ids_raise_index_error(kind):
         _close(out, m(q, ql, ref, dl), 1e-6)            # the invalid id was scored as PAD, nothing was read out of bounds
     m.check_ids()                                           # flag cleared
     _close(m(q, ql, d, dl), good, 0)
+
+
+# ------------------------------------------------------------------ full C4 batch (BASELINE configs[3]: 64 x 50 x doc_len 290)
+def _c4_batch(V, QL=4, seed=1013):
+    from context_attentive_ir_amd import synth
+    return synth.ranker_batch(64, 50, QL, 290, V, seed, full_length=False)
+
+
+def test_c4_full_batch_drmm_duet_esm():
+    """The full C4 shape on one GPU: oracle parity on a slice of queries (the oracle materialises 4.45 GB tensors at the full
+    batch), and size-independent properties on all 3200 pairs: scores of a query do not depend on the rest of the batch (batch
+    slice == full batch), candidate permutation permutes scores, DUET stays inside (-2, 2), ESM inside [-1, 1]."""
+    V = 20000
+    ex = _c4_batch(V)
+    dev = {k: v.to(DEV) for k, v in ex.items()}
+    perm = torch.randperm(50, generator=torch.Generator().manual_seed(1))
+    for kind, tol in (("ESM", 1e-4), ("DRMM", 5e-4), ("DUET", 1e-4)):
+        kw = dict(max_query_len=4, max_doc_len=290) if kind == "DUET" else {}
+        m = build_model(kind, vocab=V, device=DEV, **kw)
+        full = m(dev["que_rep"], dev["que_len"], dev["doc_rep"], dev["doc_len"])
+        assert full.shape == (64, 50) and torch.isfinite(full).all()
+        sl = slice(5, 8)
+        part = m(dev["que_rep"][sl], dev["que_len"][sl], dev["doc_rep"][sl], dev["doc_len"][sl])
+        _close(part, full[sl], 1e-5 if kind != "DRMM" else 2e-4)
+        permuted = m(dev["que_rep"], dev["que_len"], dev["doc_rep"][:, perm], dev["doc_len"][:, perm])
+        _close(permuted, full[:, perm], 1e-5 if kind != "DRMM" else 2e-4)
+        sd = cpu_state_dict(m)
+        if kind == "DRMM":      # edge-safe comparison (Appendix E1): pairs whose histograms agree with the oracle's
+            gate, cos, hist_ref = O.drmm_parts(sd, ex["que_rep"][sl], ex["doc_rep"][sl])
+            _, hist = m(dev["que_rep"][sl], dev["que_len"][sl], dev["doc_rep"][sl], dev["doc_len"][sl], return_hist=True)
+            hc = hist.cpu()
+            assert (hc[..., :3] == hist_ref[..., :3]).all()        # only the two top bins are ambiguous (exact token overlaps, E1)
+            same = (hc == hist_ref).all(-1).all(-1)
+            ref = O.drmm_scores_from_hist(sd, gate, hist_ref, 3, 50).reshape(-1)
+            assert same.any()                                      # Zipf ids at doc_len 290: most pairs share a token with the query
+            _close(part.reshape(-1)[same], ref[same], tol)         # |scores| ~ 20..100: 5e-4 absolute = relative 1e-5
+        else:
+            ref = O.MODEL_FNS[kind](sd, ex["que_rep"][sl], ex["que_len"][sl], ex["doc_rep"][sl], ex["doc_len"][sl])
+            _close(part, ref, tol)
+        if kind == "DUET":
+            assert float(full.abs().max()) < 2.0
+        if kind == "ESM":
+            assert float(full.abs().max()) <= 1.0 + 1e-6
