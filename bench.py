@@ -440,9 +440,11 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         if not sharded:
             par = "x%d independent per-rank batches, no collective (weak scaling)" % world
         elif is_sess:
-            par = "strong: candidate-sharded document encoding x%d (Multitask.parallelize) + RCCL all-gather of pooled documents, session part replicated" % world
+            par = "strong: candidate-sharded document encoding x%d (Multitask.parallelize) + %s all-gather of pooled documents, session part replicated" % (
+                world, "RCCL" if env.backend == "nccl" else env.backend)
         else:
-            par = "strong: candidate-sharded x%d (%d per rank) + RCCL all-gather of scores" % (world, batches[0]["doc_rep"].shape[1])
+            par = "strong: candidate-sharded x%d (%d per rank) + %s all-gather of scores" % (
+                world, batches[0]["doc_rep"].shape[1], "RCCL" if env.backend == "nccl" else env.backend)
     return {"name": name, "baseline_config": c.get("baseline"), "workload": tag, "pairs_per_s": round(value, 1), "ms_per_step": round(ms_per_step, 5),
             "ms_per_step_one_batch_in_flight": round(single_ms, 5), "global_batch_pairs": per_step_pairs, "parallelism": par, "world_size": world,
             "steps": steps, "hipgraph": graphs is not None, "batches_in_flight": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),

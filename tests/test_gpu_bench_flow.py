@@ -1,0 +1,46 @@
+"""GPU (-m gpu): bench.py end to end -- the single-GPU contract line, and the N = 2 strong-scaling flow (two ranks on the one
+visible GPU, BENCH_BACKEND=gloo: the collectives go through the host, the sharding / gather / softmax code path is the one the
+driver's 8-GPU RCCL run takes)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline", "cpu_baseline"}
+
+
+def _last_json(out):
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def test_bench_single_gpu_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--sub", "C1_esm", "--cpu-seconds", "2"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["value"] > 0 and d["config"]["workload"].startswith("cars")
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1.5 and r["kernel"] and r["avg_us"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["max_abs_diff_vs_gpu_softmax"] < 1e-4
+    assert d["config"]["sub"]["C1_esm"]["pairs_per_s"] > 0
+
+
+def test_bench_two_ranks_strong_scaling_flow():
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--sub", "C2_match_tensor"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["world_size"] == 2 and "Multitask.parallelize" in d["config"]["parallelism"]
+    assert d["config"]["weak_scaling_pairs_per_s"] > 0
+    sub = d["config"]["sub"]["C2_match_tensor"]
+    assert sub["world_size"] == 2 and "5 per rank" in sub["parallelism"] and sub["pairs_per_s"] > 0
