@@ -183,11 +183,11 @@ def dropout(x, p, training):
 
 
 class _BiLSTM(Function):
-    """x [M,T,I], lens [M] (or None) and the nn.LSTM parameters (per direction: w_ih [4H,I], w_hh [4H,H], b_ih, b_hh) ->
-    memory bank [M,T,ND*H] (zero at t >= length)."""
+    """x [M,T,I], lens [M] (or None), optional initial state h0/c0 [ND,M,H] and the nn.LSTM parameters (per direction: w_ih
+    [4H,I], w_hh [4H,H], b_ih, b_hh) -> (memory bank [M,T,ND*H], zero at t >= length; cell states [M,T,ND,H])."""
 
     @staticmethod
-    def forward(ctx, x, lens, nd, *params):
+    def forward(ctx, x, lens, nd, h0, c0, *params):
         lib.require_device(x)
         L = lib.load()
         M, T, I = x.shape
@@ -195,33 +195,43 @@ class _BiLSTM(Function):
         whh = torch.stack([params[4 * d + 1] for d in range(nd)], 0).float().contiguous()
         bias = torch.cat([params[4 * d + 2] + params[4 * d + 3] for d in range(nd)], 0).float().contiguous()
         H = whh.shape[2]
-        if H > 128:
-            raise NotImplementedError("train-mode recurrence supports H <= 128 per direction (got %d)" % H)
+        if H > 128 * 4:
+            raise NotImplementedError("train-mode recurrence supports H <= 512 per direction (got %d)" % H)
         x2 = _f32c(x).reshape(M * T, I)
         gates = _linear_raw(x2, wih, bias, 0)
         dev = x.device
         out = torch.empty(M, T, nd * H, device=dev)
         act = torch.empty(M, T, nd, 4 * H, device=dev)
         cst = torch.empty(M, T, nd, H, device=dev)
+        if lens is not None:
+            cst.zero_()          # positions past a sequence's length are never written by the kernel
         lens64 = lib.ids64(lens) if lens is not None else None
-        lib.check(L.nir_lstm_train_fwd(lib.ptr(gates), lib.ptr(lens64), lib.ptr(whh), None, None, lib.ptr(out), lib.ptr(act), lib.ptr(cst),
-                                       None, None, M, T, H, nd, lib.stream()), "nir_lstm_train_fwd")
+        h0c = _f32c(h0) if h0 is not None else None
+        c0c = _f32c(c0) if c0 is not None else None
+        lib.check(L.nir_lstm_train_fwd(lib.ptr(gates), lib.ptr(lens64), lib.ptr(whh), lib.ptr(h0c), lib.ptr(c0c), lib.ptr(out), lib.ptr(act),
+                                       lib.ptr(cst), None, None, M, T, H, nd, lib.stream()), "nir_lstm_train_fwd")
         ctx.nd, ctx.dims = nd, (M, T, I, H)
-        ctx.save_for_backward(x2, lens64 if lens64 is not None else torch.empty(0), wih, whh, out, act, cst)
-        ctx.has_lens = lens64 is not None
-        return out
+        e = torch.empty(0)
+        ctx.save_for_backward(x2, lens64 if lens64 is not None else e, wih, whh, out, act, cst, h0c if h0c is not None else e,
+                              c0c if c0c is not None else e)
+        ctx.has_lens, ctx.has_init = lens64 is not None, h0c is not None
+        return out, cst
 
     @staticmethod
-    def backward(ctx, dout):
-        x2, lens64, wih, whh, out, act, cst = ctx.saved_tensors
+    def backward(ctx, dout, dcst):
+        x2, lens64, wih, whh, out, act, cst, h0, c0 = ctx.saved_tensors
         L = lib.load()
         nd = ctx.nd
         M, T, I, H = ctx.dims
         G = nd * 4 * H
-        d = _f32c(dout)
+        d = _f32c(dout) if dout is not None else torch.zeros(M, T, nd * H, device=x2.device)
+        dc = _f32c(dcst) if dcst is not None else None
         dgates = torch.empty(M, T, G, device=d.device)
-        lib.check(L.nir_lstm_train_bwd(lib.ptr(d), None, None, lib.ptr(act), lib.ptr(cst), None, lib.ptr(lens64) if ctx.has_lens else None,
-                                       lib.ptr(whh), lib.ptr(dgates), None, None, M, T, H, nd, lib.stream()), "nir_lstm_train_bwd")
+        dh0 = torch.empty(nd, M, H, device=d.device) if ctx.has_init else None
+        dc0 = torch.empty(nd, M, H, device=d.device) if ctx.has_init else None
+        lib.check(L.nir_lstm_train_bwd(lib.ptr(d), None, None, lib.ptr(dc), lib.ptr(act), lib.ptr(cst), lib.ptr(c0) if ctx.has_init else None,
+                                       lib.ptr(lens64) if ctx.has_lens else None, lib.ptr(whh), lib.ptr(dgates), lib.ptr(dh0), lib.ptr(dc0),
+                                       M, T, H, nd, lib.stream()), "nir_lstm_train_bwd")
         dg2 = dgates.view(M * T, G)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -230,27 +240,80 @@ class _BiLSTM(Function):
         db = _colsum(dg2, G, M * T, G)
         grads = []
         for dd in range(nd):
-            # h of the PREVIOUS recurrence step: forward direction t-1, reverse direction t+1 (out is zero at t >= length, which is
-            # exactly the zero initial state of the reverse direction at t = length-1)
+            # h of the PREVIOUS recurrence step: forward direction t-1 (h0 at t = 0), reverse direction t+1 (out is zero at
+            # t >= length, which is exactly the zero initial state of the reverse direction at t = length-1)
             hd = out[:, :, dd * H:(dd + 1) * H]
-            z = torch.zeros(M, 1, H, device=d.device)
-            hprev = (torch.cat([z, hd[:, :-1]], 1) if dd == 0 else torch.cat([hd[:, 1:], z], 1)).contiguous().view(M * T, H)
+            z = h0[dd].unsqueeze(1) if (ctx.has_init and dd == 0) else torch.zeros(M, 1, H, device=d.device)
+            hprev = (torch.cat([z, hd[:, :-1]], 1) if dd == 0 else torch.cat([hd[:, 1:], torch.zeros(M, 1, H, device=d.device)], 1))
+            hprev = hprev.contiguous().view(M * T, H)
             dwhh = torch.zeros(4 * H, H, device=d.device)
             lib.check(L.nir_linear_wgrad_f32(lib.C.c_void_p(dg2.data_ptr() + dd * 4 * H * 4), G, lib.ptr(hprev), H, None, None, 0,
                                              lib.ptr(dwhh), H, M * T, 4 * H, H, lib.stream()), "nir_linear_wgrad_f32")
             s = slice(dd * 4 * H, (dd + 1) * 4 * H)
             grads += [dwih[s], dwhh, db[s], db[s].clone()]
-        return (dx, None, None) + tuple(grads)
+        return (dx, None, None, dh0, dc0) + tuple(grads)
 
 
-def bilstm(x, lens, lstm):
-    """RNNEncoder body in train mode for an nn.LSTM(1 layer, batch_first) parameter container."""
+def _lstm_params(lstm):
     sfx = ["", "_reverse"] if lstm.bidirectional else [""]
     params = []
     for s in sfx:
         params += [getattr(lstm, "weight_ih_l0" + s), getattr(lstm, "weight_hh_l0" + s), getattr(lstm, "bias_ih_l0" + s),
                    getattr(lstm, "bias_hh_l0" + s)]
-    return _BiLSTM.apply(x, lens, len(sfx), *params)
+    return len(sfx), params
+
+
+def bilstm(x, lens, lstm):
+    """RNNEncoder body in train mode for an nn.LSTM(1 layer, batch_first) parameter container -> memory bank."""
+    nd, params = _lstm_params(lstm)
+    return _BiLSTM.apply(x, lens, nd, None, None, *params)[0]
+
+
+class _LSTMCell(Function):
+    @staticmethod
+    def forward(ctx, gates, c_prev):
+        L = lib.load()
+        g = _f32c(gates)
+        B, H4 = g.shape
+        H = H4 // 4
+        cp = _f32c(c_prev) if c_prev is not None else None
+        act = torch.empty_like(g)
+        c = torch.empty(B, H, device=g.device)
+        h = torch.empty(B, H, device=g.device)
+        lib.check(L.nir_lstm_cell_fwd(lib.ptr(g), lib.ptr(cp), lib.ptr(act), lib.ptr(c), lib.ptr(h), B, H, lib.stream()), "nir_lstm_cell_fwd")
+        ctx.save_for_backward(act, c, cp if cp is not None else torch.empty(0))
+        ctx.has_cp = cp is not None
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        act, c, cp = ctx.saved_tensors
+        B, H = c.shape
+        dg = torch.empty_like(act)
+        dcp = torch.empty_like(c)
+        lib.check(lib.load().nir_lstm_cell_bwd(lib.ptr(_f32c(dh)) if dh is not None else None, lib.ptr(_f32c(dc)) if dc is not None else None,
+                                               lib.ptr(act), lib.ptr(c), lib.ptr(cp) if ctx.has_cp else None, lib.ptr(dg), lib.ptr(dcp), B, H,
+                                               lib.stream()), "nir_lstm_cell_bwd")
+        return dg, (dcp if ctx.has_cp else None)
+
+
+def lstm_seq(x, lstm, h0=None, c0=None):
+    """Unidirectional LSTM over full-length sequences x [M,T,I] with an optional initial state ([M,H] each) -> (h of every step
+    [M,T,H], c of every step [M,T,H]), any hidden size: the input projection of all steps is one GEMM, each step adds the
+    recurrent GEMM and the fused cell kernel; BPTT is autograd over these HIP operators (T is a session or a query: <= ~20)."""
+    M, T, _ = x.shape
+    gx = linear(x, lstm.weight_ih_l0, lstm.bias_ih_l0)                       # [M,T,4H]
+    h, c = h0, c0
+    hs, cs = [], []
+    for t in range(T):
+        g = gx[:, t]
+        if h is not None:
+            g = g + linear(h, lstm.weight_hh_l0, lstm.bias_hh_l0)
+        else:
+            g = g + lstm.bias_hh_l0
+        h, c = _LSTMCell.apply(g, c)
+        hs.append(h); cs.append(c)
+    return torch.stack(hs, 1), torch.stack(cs, 1)
 
 
 class _BCE(Function):

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(512) void lstm_train_fwd_kernel(LstmTrainArgs p) {
 // column k (coalesced reads of W_hh rows from L2), the four partial sums meet in LDS.
 struct LstmBwdArgs {
     const float* dout; const float* dhn; const float* dcn;
+    const float* dcst;     // [M,T,ND,H] gradient flowing into the stored cell states (decoder-initialisation path), or NULL
     const float* act; const float* cst; const float* c0;
     const int64_t* lens; const float* whh;
     float* dgates; float* dh0; float* dc0;
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(512) void lstm_train_bwd_kernel(LstmBwdArgs p) {
                     const float th = tanhf(ct);
                     const float dh = p.dout[row * (int64_t)(p.ND * H) + dir * H + j] + dhr[s * H + j];
                     go = dh * th * o_ * (1.f - o_);
-                    const float dct = dc[s] + dh * o_ * (1.f - th * th);
+                    float dct = dc[s] + dh * o_ * (1.f - th * th);
+                    if (p.dcst) dct += p.dcst[(row * p.ND + dir) * (int64_t)H + j];
                     gi = dct * g_ * i_ * (1.f - i_);
                     gf = dct * cprev * f_ * (1.f - f_);
                     gg = dct * i_ * (1.f - g_ * g_);
@@ -373,9 +375,65 @@ __global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* _
     atomicAdd(dtable + id * E + c, dout[i]);
 }
 
+// Single LSTM cell step on summed gate pre-activations g [B,4H] (i,f,g,o): any hidden size (session LSTMs H = 512, decoder).
+// act [B,4H] keeps the gate activations for the backward.
+__global__ void lstm_cell_fwd_kernel(const float* __restrict__ g, const float* __restrict__ cprev, float* __restrict__ act, float* __restrict__ c,
+                                     float* __restrict__ h, int64_t B, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int64_t b = i / H;
+    const int j = (int)(i % H);
+    const float* gr = g + b * 4 * H;
+    const float gi = 1.0f / (1.0f + expf(-gr[j])), gf = 1.0f / (1.0f + expf(-gr[H + j]));
+    const float gg = tanhf(gr[2 * H + j]), go = 1.0f / (1.0f + expf(-gr[3 * H + j]));
+    float* ar = act + b * 4 * H;
+    ar[j] = gi; ar[H + j] = gf; ar[2 * H + j] = gg; ar[3 * H + j] = go;
+    const float cn = gf * (cprev ? cprev[i] : 0.f) + gi * gg;
+    c[i] = cn;
+    h[i] = go * tanhf(cn);
+}
+// dh, dc (either may be NULL) -> dg [B,4H] (pre-activation), dcprev [B,H]
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc, const float* __restrict__ act,
+                                     const float* __restrict__ c, const float* __restrict__ cprev, float* __restrict__ dg,
+                                     float* __restrict__ dcprev, int64_t B, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int64_t b = i / H;
+    const int j = (int)(i % H);
+    const float* ar = act + b * 4 * H;
+    const float gi = ar[j], gf = ar[H + j], gg = ar[2 * H + j], go = ar[3 * H + j];
+    const float th = tanhf(c[i]);
+    const float dhh = dh ? dh[i] : 0.f;
+    const float dct = (dc ? dc[i] : 0.f) + dhh * go * (1.f - th * th);
+    float* dr = dg + b * 4 * H;
+    dr[j] = dct * gg * gi * (1.f - gi);
+    dr[H + j] = dct * (cprev ? cprev[i] : 0.f) * gf * (1.f - gf);
+    dr[2 * H + j] = dct * gi * (1.f - gg * gg);
+    dr[3 * H + j] = dhh * th * go * (1.f - go);
+    dcprev[i] = dct * gf;
+}
+
 static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace nir
+
+extern "C" int nir_lstm_cell_fwd(const float* gates, const float* c_prev, float* act, float* c, float* h, int64_t B, int H, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(gates && act && c && h && B >= 0 && H > 0, "lstm_cell_fwd: bad args");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, g1(B * H), dim3(256), 0, (hipStream_t)stream, gates, c_prev, act, c, h, B, H);
+    NIR_CHECK_LAUNCH("lstm_cell_fwd_kernel");
+    return 0;
+}
+extern "C" int nir_lstm_cell_bwd(const float* dh, const float* dc, const float* act, const float* c, const float* c_prev, float* dgates,
+                                 float* dc_prev, int64_t B, int H, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(act && c && dgates && dc_prev && B >= 0 && H > 0, "lstm_cell_bwd: bad args");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, g1(B * H), dim3(256), 0, (hipStream_t)stream, dh, dc, act, c, c_prev, dgates, dc_prev, B, H);
+    NIR_CHECK_LAUNCH("lstm_cell_bwd_kernel");
+    return 0;
+}
 
 extern "C" int nir_linear_wgrad_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
                                     float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream) {
@@ -432,14 +490,14 @@ extern "C" int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths,
     return 0;
 }
 
-extern "C" int nir_lstm_train_bwd(const float* dout, const float* dhn, const float* dcn, const float* act, const float* cst, const float* c0,
+extern "C" int nir_lstm_train_bwd(const float* dout, const float* dhn, const float* dcn, const float* dcst, const float* act, const float* cst, const float* c0,
                                   const int64_t* lengths, const float* w_hh, float* dgates, float* dh0, float* dc0, int64_t M, int T, int H,
                                   int ndir, nir_stream_t stream) {
     using namespace nir;
     NIR_REQUIRE(dout && act && cst && w_hh && dgates, "lstm_train_bwd: null pointer");
     NIR_REQUIRE(M >= 0 && T > 0 && (ndir == 1 || ndir == 2) && H >= 1 && H <= 128, "lstm_train_bwd: bad dims (H <= 128)");
     if (M == 0) return 0;
-    LstmBwdArgs a{dout, dhn, dcn, act, cst, c0, lengths, w_hh, dgates, dh0, dc0, M, T, H, ndir};
+    LstmBwdArgs a{dout, dhn, dcn, dcst, act, cst, c0, lengths, w_hh, dgates, dh0, dc0, M, T, H, ndir};
     const int threads = (4 * H + 63) / 64 * 64;
     const size_t lds = (size_t)TSQ * (4 * H + H + 4 * H) * 4;
     ProfScope ps(prof_shape_name("lstm_train_bwd_kernel", M, T, H), (hipStream_t)stream);

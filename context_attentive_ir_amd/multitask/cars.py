@@ -22,8 +22,9 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from .. import autograd as A
 from .. import lib
-from ..constants import BOS
+from ..constants import BOS, PAD
 from ..encoders.rnn_encoder import lstm_cat_weights
 from ..modules import Maxout
 from .layers import Embedder, Encoder
@@ -107,6 +108,7 @@ class CARS(nn.Module, lib.IdCheck):
             self.token_prob_predictor1 = nn.Linear(args.nhid_decoder, pred_in, bias=False)
             self.token_prob_predictor2 = nn.Linear(pred_in, args.tgt_vocab_size, bias=False)
         self.dropout = nn.Dropout(args.dropout)
+        self.dec_dropout_p = float(args.dropout_rnn)        # RNNDecoder.dropout (decoders/decoder.py:87), train mode only
         self.regularize_coeff = args.regularize_coeff
         self.pool_type = args.pool_type
         self.lambda1, self.lambda2 = args.lambda1, args.lambda2
@@ -329,9 +331,152 @@ class CARS(nn.Module, lib.IdCheck):
         attns = (outs.get("inner_q"), outs.get("inner_d")) if want_states else (None, None)
         return (scores if scores is not None else []), states, attns
 
+    # ---- train-mode forward (cars.py:542-669 with dropout active) ----------------------------------------------------------
+    # Differentiable: every lookup, Linear, BiLSTM, LSTM cell and the ranking loss run on the HIP operators of autograd.py; softmax /
+    # masking / batched weighted sums (bmm) / concatenations / the label sort / max-pooling of the maxout / log-softmax of the
+    # suggestion loss are tensor glue.
+    @staticmethod
+    def _mlp_logits(mlp, x, p):
+        a = A.dropout(A.linear(x, mlp[0].weight, mlp[0].bias, act="tanh"), p, True)
+        return A.linear(a, mlp[3].weight, mlp[3].bias).squeeze(-1)
+
+    def _pool_train(self, mlp, enc, lens, p):
+        T = enc.shape[1]
+        mask = torch.arange(T, device=enc.device).unsqueeze(0) < lens.unsqueeze(1)
+        w = torch.softmax(self._mlp_logits(mlp, enc, p).masked_fill(~mask, float("-inf")), 1)
+        return torch.bmm(enc.transpose(1, 2), w.unsqueeze(2)).squeeze(2)
+
+    def _encode_train(self, which, ids, lens):
+        table = self.embedder.word_embeddings.table
+        enc_mod = (self.query_encoder if which == "q" else self.document_encoder).encoder
+        x = A.dropout(A.embed(ids, table), self.embedder.dropout.p, True)
+        enc = A.dropout(A.bilstm(x, lens, enc_mod.rnns[0]), self.dropout.p, True)
+        return self._pool_train(self.q_attn if which == "q" else self.d_attn, enc, lens, self.dropout.p), enc
+
+    def _proj(self, seq, x):
+        return A.linear(A.dropout(x, seq.dropout.p, True), seq.linear.weight, seq.linear.bias)
+
+    def _cell(self, lstm, x, state):
+        g = A.linear(x, lstm.weight_ih_l0, lstm.bias_ih_l0)
+        g = g + (A.linear(state[0], lstm.weight_hh_l0, lstm.bias_hh_l0) if state is not None else lstm.bias_hh_l0)
+        return A._LSTMCell.apply(g, state[1] if state is not None else None)
+
+    def _forward_train(self, source_rep, source_len, target_rep, target_len, target_seq, document_rep, document_len, document_label):
+        B, S, QL = source_rep.shape
+        N, DL = document_rep.shape[2], document_rep.shape[3]
+        p = self.dropout.p
+        q_on, d_on = not self.no_query_session_encoding, not self.no_document_session_encoding
+        src_lens = lib.ids64(source_len).reshape(-1)
+        pooled_q, enc_q = self._encode_train("q", lib.ids64(source_rep).reshape(B * S, QL), src_lens)
+        pooled_q = pooled_q.view(B, S, -1)
+        docs = clicks = None
+        if not (self.no_ranker and self.no_document_session_encoding):
+            docs, _ = self._encode_train("d", lib.ids64(document_rep).reshape(B * S * N, DL), lib.ids64(document_len).reshape(-1))
+            docs = docs.view(B, S, N, -1)
+            if d_on:                                                   # encode_clicks (cars.py:262-304)
+                lab = document_label.reshape(B * S, N)
+                order = torch.sort(lab, dim=1, descending=True, stable=True)[1]
+                sd = torch.gather(docs.reshape(B * S, N, -1), 1, order.unsqueeze(2).expand(-1, -1, docs.shape[-1]))
+                count = (lab != 0).sum(1)
+                pos = torch.arange(N, device=lab.device).unsqueeze(0)
+                keep = (pos < count.unsqueeze(1)) | (pos >= count.max())          # the batch-dependent mask quirk (Appendix E2)
+                w = torch.softmax(self._mlp_logits(self.click_attn, sd, p).masked_fill(~keep, float("-inf")), 1)
+                clicks = torch.bmm(sd.transpose(1, 2), w.unsqueeze(2)).squeeze(2).view(B, S, -1)
+        # ---- encode_session (cars.py:306-458)
+        dev = pooled_q.device
+        qs = [torch.zeros(B, self.nhid_session_query, device=dev)] if q_on else []
+        ds = [torch.zeros(B, self.nhid_session_document, device=dev)] if d_on else []
+        qstate = dstate = None
+        scores, hid, cell, inner_q, inner_d = [], [], [], [], []
+        for t in range(S):
+            qv = pooled_q[:, t]
+
+            def attend(states, lin):
+                st = torch.stack(states, 1)
+                w = torch.softmax(torch.bmm(A.linear(st, lin.weight, lin.bias), qv.unsqueeze(2)).squeeze(2), 1)
+                return torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2)
+
+            if not self.no_ranker:
+                parts = ([attend(qs, self.session_query_attn)] if q_on else []) + ([attend(ds, self.session_doc_attn)] if d_on else [])
+                qp = self._proj(self.q_projection, qv)
+                if parts:
+                    sess = torch.cat(parts, 1)
+                    qp = qp + self._proj(self.shared_session_projector, sess) + self._proj(self.private_session_projector1, sess)
+                D = docs.shape[-1]
+                qx = qp.unsqueeze(1).expand(B, N, D).reshape(B * N, D)
+                dx = docs[:, t].reshape(B * N, D)
+                x = torch.cat((qx, dx, (qx - dx).abs(), qx * dx), 1)
+                for layer, o, pool in zip(self.ranknet._linear_layers, self.ranknet._output_dims, self.ranknet._pool_sizes):
+                    x = A.linear(x, layer.weight, layer.bias).view(B * N, o, pool).max(-1)[0]
+                scores.append(x.view(B, N))
+            hparts, cparts = [], []
+            if q_on:
+                qstate = self._cell(self.session_query_encoder.encoder.rnns[0], qv, qstate)
+                qs.append(A.dropout(qstate[0], p, True))
+                hparts.append(qstate[0]); cparts.append(qstate[1])
+                st = torch.stack(qs[1:], 1)
+                w = torch.softmax(self._mlp_logits(self.session_query_inner_attn, st, p), 1)
+                inner_q.append(torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2))
+            if d_on:
+                dstate = self._cell(self.session_doc_encoder.encoder.rnns[0], clicks[:, t], dstate)
+                ds.append(A.dropout(dstate[0], p, True))
+                hparts.append(dstate[0]); cparts.append(dstate[1])
+                st = torch.stack(ds[1:], 1)
+                w = torch.softmax(self._mlp_logits(self.session_doc_inner_attn, st, p), 1)
+                inner_d.append(torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2))
+            hid.append(torch.cat(hparts, 1)); cell.append(torch.cat(cparts, 1))
+        out = {"ranking_loss": None, "suggestion_loss": None}
+        if not self.no_ranker:
+            click_scores = torch.stack(scores, 1)
+            out["ranking_loss"] = A.bce_with_logits(click_scores, document_label.float())
+            out["click_scores"] = click_scores
+        if not self.no_recommender:                                    # teacher-forced decoder (cars.py:605-657)
+            Bd = B * (S - 1)
+            dec_h = self._proj(self.transform_hid, torch.cat(hid[:-1], 0))        # (step, session) row order, like the reference
+            dec_c = self._proj(self.transform_cell, torch.cat(cell[:-1], 0))
+            cat = [torch.stack(a, 1) for a in (inner_q, inner_d) if a]
+            cs = torch.cat(cat, 2)[:, :-1].reshape(Bd, -1)
+            tgt = lib.ids64(target_rep).reshape(Bd, -1)
+            tseq = lib.ids64(target_seq).reshape(Bd, -1)
+            TL = tgt.shape[1]
+            temb = A.dropout(A.embed(tgt, self.embedder.word_embeddings.table), self.embedder.dropout.p, True)
+            mem = enc_q.view(B, S, QL, -1)[:, :-1].reshape(Bd, QL, -1)
+            mem = A.linear(mem, self.dec_attn.weight)
+            mlen = lib.ids64(source_len)[:, :-1].reshape(-1)
+            rnn, att = self.decoder.decoder.rnn, self.decoder.decoder.attn
+            h_all, _ = A.lstm_seq(temb, rnn, dec_h, dec_c)                            # [Bd,TL,HD]
+            align = torch.bmm(A.linear(h_all, att.linear_in.weight), mem.transpose(1, 2))      # [Bd,TL,QL]
+            mask = (torch.arange(QL, device=dev).unsqueeze(0) < mlen.unsqueeze(1)).unsqueeze(1)
+            ctx = torch.bmm(torch.softmax(align.masked_fill(~mask, float("-inf")), -1), mem)
+            dec_out = A.linear(torch.cat((ctx, h_all), 2), att.linear_out.weight, act="tanh")
+            dec_out = A.dropout(dec_out, self.dec_dropout_p, True)[:, :-1]
+            po = A.linear(dec_out, self.token_prob_predictor1.weight)
+            sess = self._proj(self.shared_session_projector, cs) + self._proj(self.private_session_projector2, cs)
+            po = A.dropout(po + sess.unsqueeze(1), p, True)
+            logll = torch.log_softmax(A.linear(po, self.token_prob_predictor2.weight), -1)
+            target = tseq[:, 1:]
+            ml = -logll.gather(2, target.unsqueeze(2)).squeeze(2) * (target != PAD).float()
+            loss = ml.sum(1).mean()
+            if self.regularize_coeff > 0:
+                loss = loss + ((logll.exp() * logll).sum(2) * self.regularize_coeff).sum(1).mean()
+            out["suggestion_loss"] = loss
+            _ = TL
+        if not self.no_ranker and not self.no_recommender:
+            if q_on and d_on:
+                w1 = self.shared_session_projector.linear.weight.norm(2)
+                w2 = self.private_session_projector1.linear.weight.norm(2) + self.private_session_projector2.linear.weight.norm(2)
+                out["regularization"] = self.lambda1 * w1 + self.lambda2 * w2
+            else:
+                out["regularization"] = None
+        return out
+
     def forward(self, source_rep, source_len, target_rep, target_len, target_seq, document_rep, document_len,
                 document_label):
-        """cars.py:542-669, ranking branch: {'ranking_loss': BCE-with-logits over [B,S,N], 'suggestion_loss': None}."""
+        """cars.py:542-669.  Eval mode: the ranking loss on the inference kernels.  Train mode: differentiable ranking +
+        suggestion (+ regularisation) losses (_forward_train)."""
+        if self.training:
+            lib.require_device(source_rep, document_rep, self.embedder.word_embeddings.table)
+            return self._forward_train(source_rep, source_len, target_rep, target_len, target_seq, document_rep, document_len, document_label)
         pooled, _, _ = self.encode(source_rep, source_len)
         scores, _, _ = self.rank_document(pooled, document_rep, document_len, document_label, want_states=False)
         out = {"ranking_loss": None, "suggestion_loss": None, "click_scores": scores if not self.no_ranker else None}

@@ -79,7 +79,27 @@ class Multitask(WrapperBase):
         return out
 
     def update(self, ex):
-        raise NotImplementedError("training step is the next scope row, SURVEY.md section 8f rank 1")
+        """models/multitask.py:161-223: train-mode forward -> (1 - alpha) ranking + alpha suggestion (+ regularisation) -> backward
+        -> clip_grad_norm(grad_clipping) -> optimizer step.  CARS only (the other multitask networks keep their eval mirrors)."""
+        if self.optimizer is None:
+            raise RuntimeError("No optimizer set.")
+        if self.type != "CARS":
+            raise NotImplementedError("train-mode forward of %s is not built (CARS and MATCH_TENSOR are)" % self.type)
+        self.network.train()
+        g = lambda k: self._dev(ex[k])        # noqa: E731
+        loss = self.network(source_rep=g("source_words"), source_len=g("source_lens"), target_rep=g("target_words"),
+                            target_len=g("target_lens"), target_seq=g("target_seq"), document_rep=g("document_words"),
+                            document_len=g("document_lens"), document_label=g("document_labels"))
+        total = (1 - self.args.alpha) * loss["ranking_loss"] + self.args.alpha * loss["suggestion_loss"]
+        if loss.get("regularization") is not None:
+            total = total + loss["regularization"]
+        loss["total_loss"] = total
+        self.optimizer.zero_grad()
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.args.grad_clipping)
+        self.optimizer.step()
+        self.updates += 1
+        return loss
 
     @staticmethod
     def load(filename, new_args=None):

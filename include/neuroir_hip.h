@@ -359,11 +359,17 @@ int nir_transpose_f32(const float* in, int R, int C, float* out, nir_stream_t st
  * non-linearities) and cst [M,T,ndir,H] (c_t) of every valid step. */
 int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0, float* out,
                        float* act, float* cst, float* hn, float* cn, int64_t M, int T, int H, int ndir, nir_stream_t stream);
-/* BPTT: dout [M,T,ndir*H] (+ optional dhn/dcn [ndir,M,H]) -> dgates [M,T,ndir*4H], the gradient w.r.t. gates_in (zero at
- * t >= length), and optionally dh0/dc0.  dW_ih / dW_hh / db / dx follow from dgates through the GEMM entry points. */
-int nir_lstm_train_bwd(const float* dout, const float* dhn, const float* dcn, const float* act, const float* cst, const float* c0,
+/* BPTT: dout [M,T,ndir*H] (+ optional dhn/dcn [ndir,M,H] and dcst [M,T,ndir,H], gradients w.r.t. the final state and the stored
+ * cell states) -> dgates [M,T,ndir*4H], the gradient w.r.t. gates_in (zero at t >= length), and optionally dh0/dc0.
+ * dW_ih / dW_hh / db / dx follow from dgates through the GEMM entry points. */
+int nir_lstm_train_bwd(const float* dout, const float* dhn, const float* dcn, const float* dcst, const float* act, const float* cst, const float* c0,
                        const int64_t* lengths, const float* w_hh, float* dgates, float* dh0, float* dc0, int64_t M, int T, int H,
                        int ndir, nir_stream_t stream);
+/* One LSTM cell step on summed gate pre-activations gates [B,4H] (i,f,g,o), any H (session LSTMs, teacher-forced decoder): saves
+ * the gate activations act [B,4H]; backward maps (dh, dc) (either may be NULL) to dgates [B,4H] and dc_prev [B,H]. */
+int nir_lstm_cell_fwd(const float* gates, const float* c_prev, float* act, float* c, float* h, int64_t B, int H, nir_stream_t stream);
+int nir_lstm_cell_bwd(const float* dh, const float* dc, const float* act, const float* c, const float* c_prev, float* dgates,
+                      float* dc_prev, int64_t B, int H, nir_stream_t stream);
 /* Inverted dropout with a counter-based mask: keep[i] = uniform(splitmix64(seed ^ i*c)) >= p, y = x*keep/(1-p).  The mask is an
  * output so that a parity test can replay it through the oracle. */
 int nir_dropout_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, uint64_t seed, nir_stream_t stream);
