@@ -21,6 +21,9 @@ int launch_bilstm_fused(const float* x, int I, const float* wih, const float* bi
                         const float* whh, const float* h0, const float* c0, float* out, float* hn, float* cn, int64_t M,
                         int T, int H, int ND, hipStream_t st);
 
+int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
+                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CP = 56;     // channels padded 50 -> 56 so an 8-wide K group never straddles a conv tap (dj)
@@ -372,14 +375,13 @@ extern "C" size_t nir_matchtensor_workspace_bytes(int B, int N, int QL, int DL, 
     return nir::mt_plan(nullptr, 0, B, N, QL, DL, w).bytes;
 }
 
-extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len, const int64_t* d_ids,
-                                     const int64_t* d_len, int B, int N, int QL, int DL, const float* table, int64_t V,
-                                     int E, const nir_matchtensor_weights* w, void* workspace, size_t workspace_bytes,
-                                     float* scores, float* enc_q, float* enc_d, float* proj_q, float* proj_d,
-                                     nir_stream_t stream) {
-    using namespace nir;
-    hipStream_t st = (hipStream_t)stream;
-    NIR_REQUIRE(q_ids && q_len && d_ids && d_len && table && w && scores, "match_tensor: null pointer");
+namespace nir {
+static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const int64_t* d_ids, const int64_t* d_len, int B, int N, int QL,
+                            int DL, const float* table, int64_t V, int E, const void* fold_q, const void* fold_d, int fold_dtype,
+                            const nir_matchtensor_weights* w, void* workspace, size_t workspace_bytes, float* scores, float* enc_q,
+                            float* enc_d, float* proj_q, float* proj_d, int* err_flag, hipStream_t st) {
+    const bool folded = fold_q != nullptr && fold_d != nullptr;
+    NIR_REQUIRE(q_ids && q_len && d_ids && d_len && (table || folded) && w && scores, "match_tensor: null pointer");
     NIR_REQUIRE(B >= 0 && N > 0 && QL > 0 && DL > 0 && V > 0 && E > 0, "match_tensor: bad dims");
     NIR_REQUIRE(w->NF == NFC && w->MF == MFC, "match_tensor: nfilters=%d match_filter_size=%d unsupported (6, 20)", w->NF, w->MF);
     NIR_REQUIRE(w->C >= 1 && w->C <= CP - 6, "match_tensor: nchannels=%d unsupported (<= 50)", w->C);
@@ -409,8 +411,12 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     fj.fork();
     {   // ---- query side: gather+projection GEMM -> BiLSTM -> channel projection -> per-query weight folding
         hipStream_t qs = fj.side;
-        NIR_PROPAGATE(launch_linear(nullptr, 0, q_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xq, w->F, Mq, w->F, E, NIR_ACT_NONE, qs));
-        NIR_PROPAGATE(launch_bilstm_fused(p.xq, w->F, w->q_wih, w->q_bih, w->q_bhh, q_len, w->q_whh, nullptr, nullptr, hq, nullptr, nullptr, B, QL, w->Hq, 2, qs));
+        if (folded) {   // embedding, Linear(E->F) and the LSTM input projection folded into one table lookup (nir_lstm_fold_table)
+            NIR_PROPAGATE(launch_bilstm_folded(fold_q, fold_dtype, q_ids, q_len, w->q_whh, hq, err_flag, B, V, QL, w->Hq, 2, qs));
+        } else {
+            NIR_PROPAGATE(launch_linear(nullptr, 0, q_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xq, w->F, Mq, w->F, E, NIR_ACT_NONE, qs));
+            NIR_PROPAGATE(launch_bilstm_fused(p.xq, w->F, w->q_wih, w->q_bih, w->q_bhh, q_len, w->q_whh, nullptr, nullptr, hq, nullptr, nullptr, B, QL, w->Hq, 2, qs));
+        }
         NIR_PROPAGATE(launch_linear(hq, 2 * w->Hq, nullptr, nullptr, 0, 0, 0, w->qproj_w, 2 * w->Hq, w->qproj_b, nullptr, pq, w->C, Mq, w->C, 2 * w->Hq, NIR_ACT_NONE, qs));
         {
             ProfScope ps("mt_fold_kernel", qs);
@@ -422,8 +428,12 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     // ---- document side (mtensor.py:80-110): gather fused into the projection GEMM; the LSTM input projection
     // (I = featsize = 40) is fused into the recurrence, so the [tokens, 8H] gate tensor is never written;
     // padded positions of the channel projection give the bias (E3)
-    NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xd, w->F, Md, w->F, E, NIR_ACT_NONE, st));
-    NIR_PROPAGATE(launch_bilstm_fused(p.xd, w->F, w->d_wih, w->d_bih, w->d_bhh, d_len, w->d_whh, nullptr, nullptr, hd, nullptr, nullptr, (int64_t)B * N, DL, w->Hd, 2, st));
+    if (folded) {
+        NIR_PROPAGATE(launch_bilstm_folded(fold_d, fold_dtype, d_ids, d_len, w->d_whh, hd, err_flag, (int64_t)B * N, V, DL, w->Hd, 2, st));
+    } else {
+        NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xd, w->F, Md, w->F, E, NIR_ACT_NONE, st));
+        NIR_PROPAGATE(launch_bilstm_fused(p.xd, w->F, w->d_wih, w->d_bih, w->d_bhh, d_len, w->d_whh, nullptr, nullptr, hd, nullptr, nullptr, (int64_t)B * N, DL, w->Hd, 2, st));
+    }
     NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
     fj.join();
     size_t lds = mt_head_lds(QL, DL, MT);
@@ -451,3 +461,24 @@ extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len,
     NIR_CHECK_LAUNCH("mt_head_kernel");
     return 0;
 }
+}  // namespace nir
+
+extern "C" int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len, const int64_t* d_ids,
+                                     const int64_t* d_len, int B, int N, int QL, int DL, const float* table, int64_t V,
+                                     int E, const nir_matchtensor_weights* w, void* workspace, size_t workspace_bytes,
+                                     float* scores, float* enc_q, float* enc_d, float* proj_q, float* proj_d,
+                                     nir_stream_t stream) {
+    return nir::matchtensor_impl(q_ids, q_len, d_ids, d_len, B, N, QL, DL, table, V, E, nullptr, nullptr, 0, w, workspace, workspace_bytes, scores,
+                                 enc_q, enc_d, proj_q, proj_d, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nir_matchtensor_score_folded(const int64_t* q_ids, const int64_t* q_len, const int64_t* d_ids, const int64_t* d_len, int B,
+                                            int N, int QL, int DL, const void* folded_q, const void* folded_d, int dtype, int64_t V,
+                                            const nir_matchtensor_weights* w, void* workspace, size_t workspace_bytes, float* scores,
+                                            float* enc_q, float* enc_d, float* proj_q, float* proj_d, int* err_flag, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(folded_q && folded_d, "match_tensor_folded: null folded table");
+    return matchtensor_impl(q_ids, q_len, d_ids, d_len, B, N, QL, DL, nullptr, V, 1, folded_q, folded_d, dtype, w, workspace, workspace_bytes,
+                            scores, enc_q, enc_d, proj_q, proj_d, err_flag, (hipStream_t)stream);
+}
+

@@ -91,6 +91,8 @@ SIGNATURES = {
     "nir_matchtensor_workspace_bytes": (_z, [_i, _i, _i, _i, C.POINTER(MatchTensorWeights)]),
     "nir_matchtensor_score": (_i, [c_ip, c_ip, c_ip, c_ip, _i, _i, _i, _i, c_fp, _l, _i,
                                    C.POINTER(MatchTensorWeights), C.c_void_p, _z, c_fp, c_fp, c_fp, c_fp, c_fp, c_st]),
+    "nir_matchtensor_score_folded": (_i, [c_ip, c_ip, c_ip, c_ip, _i, _i, _i, _i, C.c_void_p, C.c_void_p, _i, _l,
+                                          C.POINTER(MatchTensorWeights), C.c_void_p, _z, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_void_p, c_st]),
     "nir_duet_workspace_bytes": (_z, [_i, _i, _i, _i, _i, C.POINTER(DuetWeights)]),
     "nir_duet_score": (_i, [c_ip, c_ip, _i, _i, _i, _i, c_fp, _l, _i, C.POINTER(DuetWeights), C.c_void_p, _z,
                             c_fp, c_fp, c_fp, c_st]),

@@ -49,6 +49,28 @@ class MatchTensor(nn.Module, lib.IdCheck):
         self._dims = dict(F=args.featsize, Hq=args.nhid_query // 2, Hd=args.nhid_doc // 2, C=args.nchannels,
                           NF=args.nfilters, MF=args.match_filter_size)
         self._pack = lib.PackCache()
+        # eval mode: fold embedding -> Linear(E->F) -> LSTM input projection into one table per encoder (csrc/lstm_fold.hip)
+        self.fold_embeddings = getattr(args, "fold_embeddings", True)
+        self._fold = lib.PackCache()
+        self._err_flag = None
+
+    def _folded_tables(self, w):
+        table = self.word_embeddings.table
+
+        def build():
+            L = lib.load()
+            V, E = table.shape
+            F_ = self._dims["F"]
+            x = torch.empty(V, F_, device=table.device, dtype=torch.float32)           # projected table x[v] = W_p table[v] + b_p
+            t = table.detach().float().contiguous()
+            lib.check(L.nir_linear_f32(lib.ptr(t), E, None, None, 0, 0, 0, lib.ptr(w.keep["proj_w"]), E, lib.ptr(w.keep["proj_b"]), None,
+                                       lib.ptr(x), F_, V, F_, E, 0, lib.stream()), "nir_linear_f32")
+            fq = lib.fold_lstm_table(x, w.keep["q_wih"], w.keep["q_bih"], w.keep["q_bhh"], self._dims["Hq"], 2, "f32")
+            fd = lib.fold_lstm_table(x, w.keep["d_wih"], w.keep["d_bih"], w.keep["d_bhh"], self._dims["Hd"], 2, "f32")
+            return fq, fd
+        params = [table, self.linear_projection.weight, self.linear_projection.bias] + list(self.query_encoder.rnns[0].parameters()) \
+            + list(self.document_encoder.rnns[0].parameters())
+        return self._fold.get(params, build)
 
     def _weights(self):
         def build():
@@ -109,7 +131,11 @@ class MatchTensor(nn.Module, lib.IdCheck):
         table = self.word_embeddings.table
         lib.require_device(batch_queries, batch_docs, query_len, doc_len, table)
         L = lib.load()
-        q, d = self._clean_ids(batch_queries, batch_docs, table.shape[0])
+        fold = self.fold_embeddings and self._dims["Hq"] >= 4 and self._dims["Hd"] >= 4
+        if fold:      # the folded recurrences validate ids in-kernel
+            q, d = lib.ids64(batch_queries), lib.ids64(batch_docs)
+        else:
+            q, d = self._clean_ids(batch_queries, batch_docs, table.shape[0])
         ql, dl = lib.ids64(query_len), lib.ids64(doc_len.reshape(-1))
         B, QL = q.shape
         N, DL = d.shape[1], d.shape[2]
@@ -125,8 +151,17 @@ class MatchTensor(nn.Module, lib.IdCheck):
             dm = self._dims
             parts = [torch.empty(B, QL, 2 * dm["Hq"], device=dev), torch.empty(B * N, DL, 2 * dm["Hd"], device=dev),
                      torch.empty(B, QL, dm["C"], device=dev), torch.empty(B * N, DL, dm["C"], device=dev)]
-        lib.check(L.nir_matchtensor_score(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B, N, QL, DL,
-                                          lib.ptr(table), table.shape[0], table.shape[1], w.ref(),
-                                          lib.ptr(ws), ws.numel(), lib.ptr(scores), *[lib.ptr(p) for p in parts],
-                                          lib.stream()), "nir_matchtensor_score")
+        if fold:
+            fq, fd = self._folded_tables(w)
+            if self._err_flag is None or self._err_flag.device != dev:
+                self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            lib.check(L.nir_matchtensor_score_folded(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B, N, QL, DL, lib.ptr(fq), lib.ptr(fd),
+                                                     lib.DTYPE_F32, table.shape[0], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(scores),
+                                                     *[lib.ptr(p) for p in parts], lib.ptr(self._err_flag), lib.stream()),
+                      "nir_matchtensor_score_folded")
+        else:
+            lib.check(L.nir_matchtensor_score(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B, N, QL, DL,
+                                              lib.ptr(table), table.shape[0], table.shape[1], w.ref(),
+                                              lib.ptr(ws), ws.numel(), lib.ptr(scores), *[lib.ptr(p) for p in parts],
+                                              lib.stream()), "nir_matchtensor_score")
         return (scores, parts) if return_parts else scores

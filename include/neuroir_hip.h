@@ -177,6 +177,15 @@ int nir_matchtensor_score(const int64_t* q_ids, const int64_t* q_len, const int6
                           float* scores, float* enc_q, float* enc_d, float* proj_q, float* proj_d,
                           nir_stream_t stream);
 
+/* Inference form over folded tables: embedding -> Linear(E->F) -> LSTM input projection collapsed into one lookup per token.
+ * folded_q / folded_d = nir_lstm_fold_table applied to the projected table x[v] = proj_w table[v] + proj_b ([V,F], one
+ * nir_linear_f32) with the query / document encoder's w_ih, b_ih, b_hh; the recurrences gather their gate rows by token id
+ * (nir_bilstm_folded_fwd).  Same outputs as nir_matchtensor_score; ids are validated in-kernel (err_flag as there). */
+int nir_matchtensor_score_folded(const int64_t* q_ids, const int64_t* q_len, const int64_t* d_ids, const int64_t* d_len, int B, int N,
+                                 int QL, int DL, const void* folded_q, const void* folded_d, int dtype, int64_t V,
+                                 const nir_matchtensor_weights* w /*host*/, void* workspace, size_t workspace_bytes, float* scores,
+                                 float* enc_q, float* enc_d, float* proj_q, float* proj_d, int* err_flag, nir_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * DUET  (neuroir/rankers/duet.py:28-59 forward, 77-121 local, 148-208 distributed)
  * ------------------------------------------------------------------------------------------------ */
