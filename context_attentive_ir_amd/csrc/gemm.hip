@@ -653,6 +653,208 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same two-term fp16 GEMM with PRE-SPLIT operands: both operands arrive as fp16 term planes (x1 = fp16_rtz(x),
+// x2 = fp16(2^11 (x - x1)), nir_split_f16x2 or written directly by the producing kernel), so staging a tile is four 16-byte
+// copies per thread and the k-loop holds no VALU work besides addressing -- the in-kernel split made gemm3 VALU-bound.
+//   A planes: dense [M, lda] (MODE 0) or rows of plane TABLES [V, EP] gathered by token id, one row per conv tap (MODE 2, K =
+//   taps*EP; EP is the row length padded to a multiple of 8 so that no 16-byte chunk straddles a tap).  W planes: [N, K].
+// Tile 128 x 128, BK = 32 (two fp16 k-blocks: 24 MFMAs per wave between barriers), LDS 64 KB -> 2 workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmPlaneArgs {
+    const _Float16 *a1, *a2;      // dense A planes (MODE 0) or plane tables (MODE 2)
+    int64_t lda;                  // row stride of the A planes / tables, in elements (multiple of 8)
+    const int64_t* ids;
+    int64_t rows_per_seq, seq_stride;
+    int EP, taps;
+    const _Float16 *w1, *w2;      // [N, K] planes, row stride ldw
+    int64_t ldw;
+    GemmArgs ep;                  // epilogue description (bias, act, add, c, ldc, M, N) -- operand fields unused
+    int K;                        // padded K (multiple of 8)
+};
+constexpr int GP_BK = 32;
+constexpr int GP_CHUNK = 128 * 8 + 32;            // one (k-block, k-half) chunk: 128 rows x 8 halves (+64 B bank offset)
+constexpr int GP_PLANE = 4 * GP_CHUNK;            // per (operand, stage, term): [k-block 2][k-half 2][row][8]
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_h2p_kernel(GemmPlaneArgs q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smemp[];
+    unsigned short* As = smemp;                        // [2 stages][2 terms][GP_PLANE]
+    unsigned short* Ws = smemp + 2 * 2 * GP_PLANE;
+    const GemmArgs& p = q.ep;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nb = (p.N + G3_BN - 1) / G3_BN;
+    const int64_t mb = (p.M + G3_BM - 1) / G3_BM;
+    const int64_t bid = blockIdx.x;
+    const int64_t tq = bid >> 3;
+    const int64_t mblk = (tq / nb) * 8 + (bid & 7);
+    if (mblk >= mb) return;
+    const int64_t m0 = mblk * G3_BM;
+    const int n0 = (int)(tq % nb) * G3_BN;
+    const int lr = tid >> 1, hs = tid & 1;             // thread stages row lr, k-block hs (16 k = two 16-byte chunks) of every plane
+
+    int64_t m = m0 + lr;
+    m = m < p.M ? m : p.M - 1;
+    int64_t arow[3] = {0, 0, 0};                       // element offsets of the row (per tap) inside the A planes
+    if (MODE == 0) {
+        arow[0] = m * q.lda;
+    } else {
+        const int64_t ai = (m / q.rows_per_seq) * q.seq_stride + (m % q.rows_per_seq);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) arow[t] = (t < q.taps ? q.ids[ai + t] : q.ids[ai]) * q.lda - (int64_t)t * q.EP;   // pre-biased by the tap's k offset
+    }
+    int n = n0 + lr;
+    n = n < p.N ? n : p.N - 1;
+    const int64_t wrow = (int64_t)n * q.ldw;
+
+    uint4 ra[2][2], rw[2][2];                          // [term][k-half chunk]
+    auto load_tile = [&](int k0) {
+        int k = k0 + 16 * hs;
+        const bool kv = k < q.K;
+        k = kv ? k : 0;                                // K is a multiple of 8 but maybe not of 32: tail chunks are zeroed
+        const bool kv2 = k + 8 < q.K;
+        int64_t ao = arow[0];
+        if (MODE == 2) ao = k < q.EP ? arow[0] : (k < 2 * q.EP ? arow[1] : arow[2]);
+        int64_t ao2 = ao;
+        if (MODE == 2) { const int k2 = k + 8; ao2 = k2 < q.EP ? arow[0] : (k2 < 2 * q.EP ? arow[1] : arow[2]); }
+        const int k2 = kv2 ? k + 8 : k;
+        ra[0][0] = *reinterpret_cast<const uint4*>(q.a1 + ao + k);
+        ra[1][0] = *reinterpret_cast<const uint4*>(q.a2 + ao + k);
+        ra[0][1] = *reinterpret_cast<const uint4*>(q.a1 + ao2 + k2);
+        ra[1][1] = *reinterpret_cast<const uint4*>(q.a2 + ao2 + k2);
+        rw[0][0] = *reinterpret_cast<const uint4*>(q.w1 + wrow + k);
+        rw[1][0] = *reinterpret_cast<const uint4*>(q.w2 + wrow + k);
+        rw[0][1] = *reinterpret_cast<const uint4*>(q.w1 + wrow + k2);
+        rw[1][1] = *reinterpret_cast<const uint4*>(q.w2 + wrow + k2);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        if (!kv) { ra[0][0] = z; ra[1][0] = z; rw[0][0] = z; rw[1][0] = z; }
+        if (!kv2) { ra[0][1] = z; ra[1][1] = z; rw[0][1] = z; rw[1][1] = z; }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int off = (buf * 2 + t) * GP_PLANE + (hs * 2 + c) * GP_CHUNK + lr * 8;
+                *reinterpret_cast<uint4*>(As + off) = ra[t][c];
+                *reinterpret_cast<uint4*>(Ws + off) = rw[t][c];
+            }
+    };
+    f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.0f; acx[a][b][r] = 0.0f; }
+
+    const int nk = (q.K + GP_BK - 1) / GP_BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int foff_a = (lane >> 5) * GP_CHUNK + (wm * 64 + (lane & 31)) * 8;
+    const int foff_w = (lane >> 5) * GP_CHUNK + (wn * 64 + (lane & 31)) * 8;
+    auto mma_tile = [&](int buf) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const unsigned short* ab = As + buf * 2 * GP_PLANE + kb * 2 * GP_CHUNK + foff_a;
+            const unsigned short* wb = Ws + buf * 2 * GP_PLANE + kb * 2 * GP_CHUNK + foff_w;
+            f16x8 af[2][2], wf[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i][t] = *reinterpret_cast<const f16x8*>(ab + t * GP_PLANE + i * 32 * 8);
+                    wf[i][t] = *reinterpret_cast<const f16x8*>(wb + t * GP_PLANE + i * 32 * 8);
+                }
+#define GP_T(ACC, TA, TW)                                                                                        \
+            ACC[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][TA], wf[0][TW], ACC[0][0], 0, 0, 0);        \
+            ACC[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][TA], wf[1][TW], ACC[0][1], 0, 0, 0);        \
+            ACC[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][TA], wf[0][TW], ACC[1][0], 0, 0, 0);        \
+            ACC[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][TA], wf[1][TW], ACC[1][1], 0, 0, 0);
+            GP_T(acx, 1, 0) GP_T(acx, 0, 1) GP_T(acc, 0, 0)
+#undef GP_T
+        }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        load_tile((kt + 1) * GP_BK);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile((kt & 1) ^ 1);
+        __syncthreads();
+    }
+    mma_tile((nk - 1) & 1);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int nn = n0 + wn * 64 + b * 32 + (lane & 31);
+        float bsum = 0.f;
+        if (nn < p.N) {
+            if (p.bias) bsum += p.bias[nn];
+            if (p.bias2) bsum += p.bias2[nn];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t mm = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                gemm_store(p, mm, nn, fmaf(acx[a][b][r], 1.0f / 2048.0f, acc[a][b][r]), bsum);
+            }
+    }
+}
+
+// x [rows, cols] fp32 (row stride ld) -> two fp16 term planes [rows, cols_pad] (zero padded): p1 = fp16_rtz(x), p2 = fp16(2^11 (x - p1))
+__global__ void split_f16x2_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld, int cols_pad, _Float16* __restrict__ p1,
+                                   _Float16* __restrict__ p2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols_pad) return;
+    const int64_t r = i / cols_pad;
+    const int c = (int)(i % cols_pad);
+    const float v = c < cols ? x[r * ld + c] : 0.f;
+    const fp16x2_t a = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+    p1[i] = (_Float16)a[0];
+    p2[i] = (_Float16)((v - (float)a[0]) * 2048.0f);
+}
+
+int launch_split_f16x2(const float* x, int64_t rows, int cols, int64_t ld, int cols_pad, void* p1, void* p2, hipStream_t st) {
+    NIR_REQUIRE(x && p1 && p2 && rows >= 0 && cols > 0 && cols_pad >= cols && cols_pad % 8 == 0, "split_f16x2: bad args (cols_pad %% 8 == 0)");
+    if (rows == 0) return 0;
+    const int64_t n = rows * cols_pad;
+    hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, cols, ld, cols_pad, (_Float16*)p1, (_Float16*)p2);
+    NIR_CHECK_LAUNCH("split_f16x2_kernel");
+    return 0;
+}
+
+// C = act(A W^T + bias) from pre-split planes.  Dense: a1/a2 [M, lda]; gathered (ids != NULL): a1/a2 are plane tables [V, lda] and row m
+// is the concatenation of `taps` table rows (EP elements each).  K = padded reduction length (taps * EP or the padded dense K).
+int launch_linear_planes(const void* a1, const void* a2, int64_t lda, const int64_t* ids, int64_t rows_per_seq, int64_t seq_stride, int EP,
+                         int taps, const void* w1, const void* w2, int64_t ldw, const float* bias, float* c, int64_t ldc, int64_t M, int N, int K,
+                         int act, const float* add, int64_t ldadd, hipStream_t st) {
+    NIR_REQUIRE(a1 && a2 && w1 && w2 && c && M >= 0 && N > 0 && K > 0, "linear_planes: bad args");
+    NIR_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "linear_planes: K and the row strides must be multiples of 8");
+    NIR_REQUIRE(!ids || (taps >= 1 && taps <= 3 && EP % 8 == 0 && K == taps * EP), "linear_planes: gathered A needs K == taps*EP, EP %% 8 == 0");
+    if (M == 0) return 0;
+    GemmPlaneArgs q;
+    q.a1 = (const _Float16*)a1; q.a2 = (const _Float16*)a2; q.lda = lda; q.ids = ids; q.rows_per_seq = rows_per_seq; q.seq_stride = seq_stride;
+    q.EP = EP; q.taps = taps; q.w1 = (const _Float16*)w1; q.w2 = (const _Float16*)w2; q.ldw = ldw; q.K = K;
+    q.ep = GemmArgs{nullptr, 0, nullptr, nullptr, 0, 0, 0, nullptr, 0, bias, nullptr, c, ldc, M, N, K, act, add, ldadd};
+    const int64_t mb3 = (M + G3_BM - 1) / G3_BM;
+    const int nb3 = (N + G3_BN - 1) / G3_BN;
+    constexpr size_t lds = (size_t)2 * 2 * 2 * GP_PLANE * 2;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)gemm_h2p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_h2p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    ProfScope ps(prof_shape_name(ids ? "gemm_h2p_kernel[gather]" : "gemm_h2p_kernel", M, N, K), st);
+    dim3 grid((unsigned)(8 * nb3 * ((mb3 + 7) / 8)));
+    if (ids) hipLaunchKernelGGL(gemm_h2p_kernel<2>, grid, dim3(256), lds, st, q);
+    else hipLaunchKernelGGL(gemm_h2p_kernel<0>, grid, dim3(256), lds, st, q);
+    NIR_CHECK_LAUNCH("gemm_h2p_kernel");
+    return 0;
+}
+
 template <int NT>
 static void launch_skinny(const GemmArgs& p, int G, size_t lds, hipStream_t st) {
     static std::once_flag once;       // one-time opt-in to > 64 KB of dynamic LDS, race-free

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_kernel(LstmPtArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * q + 4 * kq + j;
-                wreg[t][4 * q + j] = (av && k < H) ? wr[k] : 0.f;
+                wreg[t][4 * q + j] = wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f);   // unconditional load, 0/1 mask (see the h2 kernel)
             }
         unit_d[t] = 4 * tile + kq;
         creg[t] = 0.f;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = 32 * kb + 8 * kq + j;
-                wreg[t][kb][j] = (short)f2bf((av && k < H) ? wr[k] : 0.f);
+                wreg[t][kb][j] = (short)f2bf(wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f));
             }
         unit_d[t] = 4 * tile + kq;
         creg[t] = 0.f;
@@ -428,19 +428,26 @@ __global__ __launch_bounds__(1024) void lstm16_pt_h2_kernel(LstmPtArgs p) {
         // serialises 64 memory round trips and made the prologue cost ~35 us per launch)
         float wv[KB][8];
         const bool vec_ok = (H % 8) == 0 && ((reinterpret_cast<uintptr_t>(wr) & 15) == 0);
+        if (vec_ok) {                                         // wave-uniform
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int k0 = 32 * kb + 8 * kq;
-            if (vec_ok) {
+            for (int kb = 0; kb < KB; ++kb) {
+                const int k0 = 32 * kb + 8 * kq;
                 const int kc = k0 + 8 <= H ? k0 : 0;           // branch-free: out-of-range chunks re-read chunk 0 and are zeroed below
                 const float4 a = *reinterpret_cast<const float4*>(wr + kc), b = *reinterpret_cast<const float4*>(wr + kc + 4);
                 const float m = (av && k0 + 8 <= H) ? 1.f : 0.f;
                 wv[kb][0] = a.x * m; wv[kb][1] = a.y * m; wv[kb][2] = a.z * m; wv[kb][3] = a.w * m;
                 wv[kb][4] = b.x * m; wv[kb][5] = b.y * m; wv[kb][6] = b.z * m; wv[kb][7] = b.w * m;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) wv[kb][j] = (av && k0 + j < H) ? wr[k0 + j] : 0.f;
             }
+        } else {                                              // any H: unconditional loads from a clamped index, masked afterwards
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * kb + 8 * kq + j;
+                    // multiply by a 0/1 mask instead of selecting: a select lets the compiler predicate the load, and each
+                    // predicated load became its own exec-masked block with an s_waitcnt vmcnt(0) behind it (64 serialised round trips)
+                    wv[kb][j] = wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f);
+                }
         }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
