@@ -102,6 +102,10 @@ def kernel_work(name, c):
     base, M, N, K = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))) if m else (name, 0, 0, 0)
     B, NC, QL, DL, E = c["batch"], c["cands"], c["qlen"], c["dlen"], 300
     pairs = B * NC * (c.get("session", 1) if c["model"] in SESSION_MODELS else 1)
+    if base.startswith("gemm3h_kernel") or base.startswith("gemm_h2p_kernel"):     # fp16 two-term split: 3 MFMAs per product block
+        gathered = "[gather]" in base
+        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),
+                    peak=PEAK_BF16_TFLOPS / 3.0)
     if base.startswith("gemm3_kernel"):
         gathered = "[gather]" in base
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),

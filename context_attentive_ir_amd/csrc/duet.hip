@@ -15,6 +15,9 @@ namespace nir {
 int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
                   int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
                   int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
+int launch_linear_planes(const void* a1, const void* a2, int64_t lda, const int64_t* ids, int64_t rows_per_seq, int64_t seq_stride, int EP,
+                         int taps, const void* w1, const void* w2, int64_t ldw, const float* bias, float* c, int64_t ldc, int64_t M, int N, int K,
+                         int act, const float* add, int64_t ldadd, hipStream_t st);
 int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
                   hipStream_t st);
 
@@ -109,6 +112,48 @@ __global__ __launch_bounds__(256) void maxpool_t_kernel(const float* __restrict_
     }
 }
 
+// The same pooling writing its output as the two fp16 term planes the pre-split GEMM consumes (rows padded to EP = 4*NF4P
+// columns, padding zeroed): conv_d2's A operand needs no split pass and no fp32 round trip.
+__global__ __launch_bounds__(256) void maxpool_t_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ o1, _Float16* __restrict__ o2,
+                                                               int Tin, int P, int NF4, int NF4P, int64_t M) {
+    const int Tout = Tin - P + 1;
+    const int nrun = (Tout + MP_TR - 1) / MP_TR;
+    const int64_t total = M * nrun * NF4P;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int f4 = (int)(e % NF4P);
+        const int64_t r = e / NF4P;
+        const int run = (int)(r % nrun);
+        const int64_t m = r / nrun;
+        const int t0 = run * MP_TR;
+        const bool real = f4 < NF4;
+        const float4* src = reinterpret_cast<const float4*>(x) + (m * Tin + t0) * NF4 + (real ? f4 : 0);
+        float4 v[MP_TR + MP_PMAX - 1];
+#pragma unroll
+        for (int k = 0; k < MP_TR + MP_PMAX - 1; ++k)
+            v[k] = (k < MP_TR + P - 1 && t0 + k < Tin) ? src[(int64_t)k * NF4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int k = 0; k < MP_TR; ++k) {
+            if (t0 + k < Tout) {
+                float4 a = v[k];
+#pragma unroll
+                for (int dt = 1; dt < MP_PMAX; ++dt)
+                    if (dt < P) {
+                        a.x = fmaxf(a.x, v[k + dt].x); a.y = fmaxf(a.y, v[k + dt].y);
+                        a.z = fmaxf(a.z, v[k + dt].z); a.w = fmaxf(a.w, v[k + dt].w);
+                    }
+                if (!real) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+                const h2_t p01 = __builtin_amdgcn_cvt_pkrtz(a.x, a.y), p23 = __builtin_amdgcn_cvt_pkrtz(a.z, a.w);
+                const h2_t q01 = __builtin_amdgcn_cvt_pkrtz((a.x - (float)p01[0]) * 2048.f, (a.y - (float)p01[1]) * 2048.f);
+                const h2_t q23 = __builtin_amdgcn_cvt_pkrtz((a.z - (float)p23[0]) * 2048.f, (a.w - (float)p23[1]) * 2048.f);
+                const int64_t off = ((m * Tout + t0 + k) * NF4P + f4) * 4;
+                *reinterpret_cast<uint2*>(o1 + off) = make_uint2(__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23));
+                *reinterpret_cast<uint2*>(o2 + off) = make_uint2(__builtin_bit_cast(unsigned, q01), __builtin_bit_cast(unsigned, q23));
+            }
+        }
+    }
+}
+
 // m1[pair][f] = tanh(fc2_b + sum_t fc2_w[t] * qv[b][f] * dd[pair][t][f])     (Hadamard + Linear over positions)
 // One workgroup per pair streams its [T, NF] block once: 16-byte lanes over f, the positions split over
 // 256 / (NF/4) thread groups with 4 loads in flight each, partial sums folded through LDS.  (The first version gave a
@@ -180,7 +225,7 @@ static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, in
     p.qmax = a.take<float>((size_t)B * NF);
     p.qv = a.take<float>((size_t)B * NF);
     p.cd = a.take<float>(M * Tc * NF);
-    p.pooled = a.take<float>(M * Tp * NF);
+    p.pooled = a.take<float>(M * Tp * (NF + 8));      // fp32 [M*Tp, NF] or two fp16 planes [M*Tp, EP <= NF + 8]
     p.dd = a.take<float>(M * Tp * NF);
     p.m1 = a.take<float>(M * NF);
     p.m2 = a.take<float>(M * NF);
@@ -239,15 +284,36 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     NIR_CHECK_LAUNCH("colmax_kernel");
     NIR_PROPAGATE(launch_linear(p.qmax, NF, nullptr, nullptr, 0, 0, 0, w->fc1_w, NF, w->fc1_b, nullptr, p.qv, NF, B, NF, NF, NIR_ACT_TANH, st));
     // ---- distributed model, document side (duet.py:174,180,185)
-    NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, Tc, DL, w->convd1_w, 3 * E, w->convd1_b, nullptr, p.cd, NF, M * Tc, NF, 3 * E, NIR_ACT_TANH | bnd, st));
-    {
-        const int64_t total = (int64_t)M * ((Tp + MP_TR - 1) / MP_TR) * (NF / 4);
-        ProfScope ps("maxpool_t_kernel", st);
-        hipLaunchKernelGGL(maxpool_t_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, p.cd,
-                           p.pooled, Tc, P, NF / 4, (int64_t)M);
+    const bool planes = w->bounded && w->EP > 0 && w->table_h1 && w->table_h2 && w->convd1_h1 && w->convd1_h2 && w->convd2_h1 && w->convd2_h2 &&
+                        w->EP % 8 == 0 && w->EP >= NF && w->EP <= NF + 8 && w->EP >= E;
+    if (planes) {
+        // pre-split fp16 term planes end to end: table planes gathered by id (3 taps) -> conv_d1 + tanh (fp32) -> pooling writes
+        // planes -> conv_d2 + tanh; no operand is split inside a GEMM
+        const int EP = w->EP;
+        NIR_PROPAGATE(launch_linear_planes(w->table_h1, w->table_h2, EP, d_ids, Tc, DL, EP, 3, w->convd1_h1, w->convd1_h2, 3 * EP, w->convd1_b, p.cd, NF,
+                                           M * Tc, NF, 3 * EP, NIR_ACT_TANH, nullptr, 0, st));
+        _Float16* pp1 = reinterpret_cast<_Float16*>(p.pooled);
+        _Float16* pp2 = pp1 + (size_t)M * Tp * EP;
+        {
+            const int64_t total = (int64_t)M * ((Tp + MP_TR - 1) / MP_TR) * (EP / 4);
+            ProfScope ps("maxpool_t_planes_kernel", st);
+            hipLaunchKernelGGL(maxpool_t_planes_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, p.cd, pp1,
+                               pp2, Tc, P, NF / 4, EP / 4, (int64_t)M);
+        }
+        NIR_CHECK_LAUNCH("maxpool_t_planes_kernel");
+        NIR_PROPAGATE(launch_linear_planes(pp1, pp2, EP, nullptr, 0, 0, 0, 0, w->convd2_h1, w->convd2_h2, EP, w->convd2_b, p.dd, NF, M * Tp, NF, EP,
+                                           NIR_ACT_TANH, nullptr, 0, st));
+    } else {
+        NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, Tc, DL, w->convd1_w, 3 * E, w->convd1_b, nullptr, p.cd, NF, M * Tc, NF, 3 * E, NIR_ACT_TANH | bnd, st));
+        {
+            const int64_t total = (int64_t)M * ((Tp + MP_TR - 1) / MP_TR) * (NF / 4);
+            ProfScope ps("maxpool_t_kernel", st);
+            hipLaunchKernelGGL(maxpool_t_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, p.cd,
+                               p.pooled, Tc, P, NF / 4, (int64_t)M);
+        }
+        NIR_CHECK_LAUNCH("maxpool_t_kernel");
+        NIR_PROPAGATE(launch_linear(p.pooled, NF, nullptr, nullptr, 0, 0, 0, w->convd2_w, NF, w->convd2_b, nullptr, p.dd, NF, M * Tp, NF, NF, NIR_ACT_TANH | bnd, st));
     }
-    NIR_CHECK_LAUNCH("maxpool_t_kernel");
-    NIR_PROPAGATE(launch_linear(p.pooled, NF, nullptr, nullptr, 0, 0, 0, w->convd2_w, NF, w->convd2_b, nullptr, p.dd, NF, M * Tp, NF, NF, NIR_ACT_TANH | bnd, st));
     // ---- Hadamard + fc2 over positions, fc3, fc4 (duet.py:187-207)
     {
         ProfScope ps("duet_hadamard_kernel", st);

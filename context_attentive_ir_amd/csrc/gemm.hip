@@ -709,16 +709,21 @@ __global__ __launch_bounds__(256, 2) void gemm_h2p_kernel(GemmPlaneArgs q) {
     const int64_t wrow = (int64_t)n * q.ldw;
 
     uint4 ra[2][2], rw[2][2];                          // [term][k-half chunk]
-    auto load_tile = [&](int k0) {
+    // `tail` is a literal at every call site: the steady-state loop carries no masking code (a masked overwrite of a register
+    // that a load is still filling forces an s_waitcnt vmcnt in front of the MFMA block, exposing the whole load latency)
+    auto load_tile = [&](int k0, bool tail) {
         int k = k0 + 16 * hs;
-        const bool kv = k < q.K;
-        k = kv ? k : 0;                                // K is a multiple of 8 but maybe not of 32: tail chunks are zeroed
-        const bool kv2 = k + 8 < q.K;
+        bool kv = true, kv2 = true;
+        if (tail) {
+            kv = k < q.K;
+            k = kv ? k : 0;                            // K is a multiple of 8 but maybe not of 32: tail chunks are zeroed
+            kv2 = kv && k + 8 < q.K;
+        }
         int64_t ao = arow[0];
         if (MODE == 2) ao = k < q.EP ? arow[0] : (k < 2 * q.EP ? arow[1] : arow[2]);
-        int64_t ao2 = ao;
-        if (MODE == 2) { const int k2 = k + 8; ao2 = k2 < q.EP ? arow[0] : (k2 < 2 * q.EP ? arow[1] : arow[2]); }
         const int k2 = kv2 ? k + 8 : k;
+        int64_t ao2 = ao;
+        if (MODE == 2) ao2 = k2 < q.EP ? arow[0] : (k2 < 2 * q.EP ? arow[1] : arow[2]);
         ra[0][0] = *reinterpret_cast<const uint4*>(q.a1 + ao + k);
         ra[1][0] = *reinterpret_cast<const uint4*>(q.a2 + ao + k);
         ra[0][1] = *reinterpret_cast<const uint4*>(q.a1 + ao2 + k2);
@@ -727,9 +732,11 @@ __global__ __launch_bounds__(256, 2) void gemm_h2p_kernel(GemmPlaneArgs q) {
         rw[1][0] = *reinterpret_cast<const uint4*>(q.w2 + wrow + k);
         rw[0][1] = *reinterpret_cast<const uint4*>(q.w1 + wrow + k2);
         rw[1][1] = *reinterpret_cast<const uint4*>(q.w2 + wrow + k2);
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        if (!kv) { ra[0][0] = z; ra[1][0] = z; rw[0][0] = z; rw[1][0] = z; }
-        if (!kv2) { ra[0][1] = z; ra[1][1] = z; rw[0][1] = z; rw[1][1] = z; }
+        if (tail) {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            if (!kv) { ra[0][0] = z; ra[1][0] = z; rw[0][0] = z; rw[1][0] = z; }
+            if (!kv2) { ra[0][1] = z; ra[1][1] = z; rw[0][1] = z; rw[1][1] = z; }
+        }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -750,7 +757,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h2p_kernel(GemmPlaneArgs q) {
             for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.0f; acx[a][b][r] = 0.0f; }
 
     const int nk = (q.K + GP_BK - 1) / GP_BK;
-    load_tile(0);
+    const bool ktail = (q.K % GP_BK) != 0;
+    if (nk == 1 && ktail) load_tile(0, true);
+    else load_tile(0, false);
     store_tile(0);
     __syncthreads();
     const int foff_a = (lane >> 5) * GP_CHUNK + (wm * 64 + (lane & 31)) * 8;
@@ -777,8 +786,18 @@ __global__ __launch_bounds__(256, 2) void gemm_h2p_kernel(GemmPlaneArgs q) {
 #undef GP_T
         }
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        load_tile((kt + 1) * GP_BK);
+    for (int kt = 0; kt + 2 < nk; ++kt) {              // steady state: the next tile is a full one
+        load_tile((kt + 1) * GP_BK, false);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile((kt & 1) ^ 1);
+        __syncthreads();
+    }
+    if (nk >= 2) {                                     // second-to-last tile prefetches the (possibly partial) last one
+        const int kt = nk - 2;
+        if (ktail) load_tile((kt + 1) * GP_BK, true);
+        else load_tile((kt + 1) * GP_BK, false);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile(kt & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -983,4 +1002,16 @@ extern "C" int nir_linear_f32(const float* a, int64_t lda, const int64_t* ids, c
 extern "C" int nir_rowdot_f32(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M,
                               int K, int act, nir_stream_t stream) {
     return nir::launch_rowdot(x, ldx, w, b, out, M, K, act, (hipStream_t)stream);
+}
+
+namespace nir { int launch_split_f16x2(const float* x, int64_t rows, int cols, int64_t ld, int cols_pad, void* p1, void* p2, hipStream_t st); }
+extern "C" int nir_split_f16x2(const float* x, int64_t rows, int cols, int64_t ld, int cols_pad, void* p1, void* p2, nir_stream_t stream) {
+    return nir::launch_split_f16x2(x, rows, cols, ld, cols_pad, p1, p2, (hipStream_t)stream);
+}
+
+extern "C" int nir_linear_planes_f32(const void* a1, const void* a2, int64_t lda, const int64_t* ids, int64_t rows_per_seq, int64_t seq_stride,
+                                     int EP, int taps, const void* w1, const void* w2, int64_t ldw, const float* bias, float* c, int64_t ldc,
+                                     int64_t M, int N, int K, int act, nir_stream_t stream) {
+    return nir::launch_linear_planes(a1, a2, lda, ids, rows_per_seq, seq_stride, EP, taps, w1, w2, ldw, bias, c, ldc, M, N, K, act, nullptr, 0,
+                                     (hipStream_t)stream);
 }

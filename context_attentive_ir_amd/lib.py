@@ -35,6 +35,8 @@ DuetWeights = _struct(
      "convq_w", "convq_b", "convd1_w", "convd1_b", "convd2_w", "convd2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
      "fc3_w", "fc3_b", "fc4_w", "fc4_b"],
     ["NF", "pool", "bounded"])
+DuetWeights = type("nir_duet_weights", (C.Structure,), {"_fields_": list(DuetWeights._fields_) + [
+    (f, C.c_void_p) for f in ("table_h1", "table_h2", "convd1_h1", "convd1_h2", "convd2_h1", "convd2_h2")] + [("EP", C.c_int)]})
 CarsEncoderWeights = _struct(
     "nir_cars_encoder_weights",
     ["wih", "whh", "bih", "bhh", "attn0_w", "attn0_b", "attn3_w", "attn3_b"], ["H", "bounded"])
@@ -70,6 +72,8 @@ SIGNATURES = {
     "nir_debug_set_tunable": (_i, [C.c_char_p, _i]),
     "nir_profile_enable": (_i, [_i]),
     "nir_profile_report": (_i, [C.c_char_p, _z]),
+    "nir_split_f16x2": (_i, [c_fp, _l, _i, _l, _i, C.c_void_p, C.c_void_p, c_st]),
+    "nir_linear_planes_f32": (_i, [C.c_void_p, C.c_void_p, _l, c_ip, _l, _l, _i, _i, C.c_void_p, C.c_void_p, _l, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_sanitize_ids": (_i, [c_ip, _l, c_ip, _l, _l, c_ip, c_ip, C.c_void_p, c_st]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_rowdot_f32": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, _i, _i, c_st]),
@@ -322,3 +326,14 @@ class IdCheck(object):
             if flag is not None and int(flag.item()) != 0:
                 flag.zero_()
                 raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
+
+
+def split_f16x2(x, cols_pad=None):
+    """nir_split_f16x2: fp32 [rows, cols] -> two fp16 term planes [rows, cols_pad] (stored as int16 tensors)."""
+    x = x.detach().float().contiguous()
+    rows, cols = x.shape
+    cp = (cols + 7) // 8 * 8 if cols_pad is None else int(cols_pad)
+    p1 = torch.empty(rows, cp, dtype=torch.int16, device=x.device)
+    p2 = torch.empty_like(p1)
+    check(load().nir_split_f16x2(ptr(x), rows, cols, cols, cp, ptr(p1), ptr(p2), stream()), "nir_split_f16x2")
+    return p1, p2

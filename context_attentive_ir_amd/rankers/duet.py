@@ -59,6 +59,10 @@ class DUET(nn.Module, lib.IdCheck):
         self.max_doc_len, self.max_query_len = args.max_doc_len, args.max_query_len
         self._dims = dict(NF=args.nfilters, pool=args.pool_size)
         self._pack = lib.PackCache()
+        # fp16 term planes of table / conv weights for the pre-split GEMM (csrc/gemm.hip: gemm_h2p_kernel).  Off by default: at the C4
+        # shape the pre-split kernel measured 2.9 ms for conv_d1 against 2.56 ms for the in-kernel split (its BK = 32 tile leaves
+        # 2 workgroups per CU and both kernels are bound by the load -> LDS -> barrier chain, not by the split VALU work)
+        self.presplit_operands = False
 
     def _weights(self):
         def build():
@@ -75,7 +79,19 @@ class DUET(nn.Module, lib.IdCheck):
             # convolution GEMMs may use the fp16 two-term split (their other operand is a tanh output)
             mx = max(float(self.word_embeddings.table.detach().abs().max()), float(dm.conv_d1.weight.detach().abs().max()),
                      float(dm.conv_d2.weight.detach().abs().max()), float(dm.conv_q.weight.detach().abs().max()))
-            return lib.Packed(lib.DuetWeights, t, dict(self._dims, bounded=int(mx < 32768.0)))
+            pk = lib.Packed(lib.DuetWeights, t, dict(self._dims, bounded=int(mx < 32768.0)))
+            E, NF = self.word_embeddings.table.shape[1], self._dims["NF"]
+            EP = (max(E, NF) + 7) // 8 * 8
+            if mx < 32768.0 and self.presplit_operands and EP <= NF + 8 and EP - E < 8:
+                # fp16 term planes of the table and of the two big conv weights, split once per weight version (122 MB at V = 100 000)
+                planes = dict(zip(("table_h1", "table_h2"), lib.split_f16x2(self.word_embeddings.table, EP)))
+                planes.update(zip(("convd1_h1", "convd1_h2"), lib.split_f16x2(pk.keep["convd1_w"].reshape(NF * 3, E), EP)))
+                planes.update(zip(("convd2_h1", "convd2_h2"), lib.split_f16x2(pk.keep["convd2_w"], EP)))
+                for k, v in planes.items():
+                    pk.keep[k] = v
+                    setattr(pk.struct, k, v.data_ptr())
+                pk.struct.EP = EP
+            return pk
         params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")] + [self.word_embeddings.table]
         return self._pack.get(params, build)
 

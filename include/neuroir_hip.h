@@ -66,6 +66,19 @@ int nir_debug_set_buffer(void* dev_u64);
 int nir_profile_enable(int on);
 int nir_profile_report(char* buf /*host*/, size_t cap);
 
+/* Two-term fp16 split of an fp32 matrix x [rows, cols] (row stride ld): p1 = fp16_rtz(x), p2 = fp16(2^11 (x - p1)), both written as
+ * [rows, cols_pad] with zero padding (cols_pad % 8 == 0).  x = p1 + 2^-11 p2 up to 2^-22 |x| for |x| < 2^15: the operand format of
+ * the pre-split GEMM (weights and embedding tables are split once when they are packed). */
+int nir_split_f16x2(const float* x, int64_t rows, int cols, int64_t ld, int cols_pad, void* p1, void* p2, nir_stream_t stream);
+
+/* C = act(A W^T + bias) from PRE-SPLIT fp16 term planes (nir_split_f16x2): the k-loop of the GEMM holds no conversion work.
+ * Dense A (ids == NULL): a1/a2 [M, lda]; gathered A: a1/a2 are plane TABLES [V, lda] and A row m is the concatenation of `taps`
+ * consecutive-token rows (EP elements each: Conv1d over token ids), K = taps*EP.  w1/w2 [N, K] with row stride ldw.  K, lda, ldw, EP
+ * multiples of 8.  Operands must be bounded by 2^15 in magnitude. */
+int nir_linear_planes_f32(const void* a1, const void* a2, int64_t lda, const int64_t* ids, int64_t rows_per_seq, int64_t seq_stride, int EP,
+                          int taps, const void* w1, const void* w2, int64_t ldw, const float* bias, float* c, int64_t ldc, int64_t M, int N,
+                          int K, int act, nir_stream_t stream);
+
 /* Token-id contract of every entry point that takes ids: 0 <= id < V.  The kernels gather table rows without a bounds check, so
  * the host mirrors validate first with this call (one launch for up to two id tensors): invalid ids are replaced by 0 (PAD) in
  * the copies out_a / out_b and *err_flag (device int, may be NULL) is set -- the reference's nn.Embedding raises IndexError; the
@@ -204,6 +217,11 @@ typedef struct {
     int NF, pool;                      /* 300, 5 */
     int bounded;                       /* host-checked: embedding table and conv weights < 2^15 in magnitude -> the convolution
                                           GEMMs may use the fp16 two-term split */
+    /* optional pre-split fp16 term planes (nir_split_f16x2; all NULL / EP = 0 to split inside the GEMM instead): the embedding table
+     * [V,EP] x 2, conv_d1 [NF][3][EP] x 2 and conv_d2 [NF][EP] x 2, EP = E and NF rounded up to a multiple of 8 (requires E == NF
+     * rounded alike, e.g. 300 -> 304).  Used only when `bounded`. */
+    const void *table_h1, *table_h2, *convd1_h1, *convd1_h2, *convd2_h1, *convd2_h2;
+    int EP;
 } nir_duet_weights;
 size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w /*host*/);
 /* local_out / dist_out: optional [B,N] debug outputs (NULL to skip). Requires QL >= 3 and DL >= 7. */

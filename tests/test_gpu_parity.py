@@ -749,3 +749,32 @@ def test_c4_full_batch_drmm_duet_esm():
             assert float(full.abs().max()) < 2.0
         if kind == "ESM":
             assert float(full.abs().max()) <= 1.0 + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 300, 304), (1000, 300, 300), (5000, 130, 64), (13000, 256, 256)])
+def test_linear_presplit_planes(M, N, K):
+    """nir_split_f16x2 + nir_linear_planes_f32 (two-term fp16 planes, 3 MFMAs per product block) against fp64."""
+    from context_attentive_ir_amd import lib
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.rand(M, K, generator=g) * 2 - 1).to(DEV); w = (torch.randn(N, K, generator=g) * 0.1).to(DEV); b = torch.randn(N, generator=g).to(DEV)
+    KP = (K + 7) // 8 * 8
+    a1, a2 = lib.split_f16x2(a, KP); w1, w2 = lib.split_f16x2(w, KP)
+    c = torch.empty(M, N, device=DEV)
+    lib.check(lib.load().nir_linear_planes_f32(lib.ptr(a1), lib.ptr(a2), KP, None, 0, 0, 0, 0, lib.ptr(w1), lib.ptr(w2), KP, lib.ptr(b), lib.ptr(c), N,
+                                               M, N, KP, 1, lib.stream()), "planes")
+    ref = torch.tanh(a.double() @ w.double().T + b.double()).float()
+    _close(c, ref, 5e-6)
+
+
+def test_duet_presplit_planes_path_matches_default():
+    """DUET with pre-split table / conv-weight planes (conv_d1 gathers plane-table rows by id over 3 taps, the pooling kernel
+    emits planes for conv_d2) against the default in-kernel split."""
+    V = 600
+    m = build_model("DUET", vocab=V, device=DEV, max_query_len=5, max_doc_len=40)
+    rng = np.random.default_rng(2)
+    q, ql, d, dl = (t.to(DEV) for t in _synth(rng, 3, 7, 5, 40, V, full=True))
+    ref = m(q, ql, d, dl).clone()
+    m.presplit_operands = True
+    m._pack.invalidate()
+    got = m(q, ql, d, dl)
+    _close(got, ref, 5e-6)
