@@ -44,3 +44,13 @@ def test_bench_two_ranks_strong_scaling_flow():
     assert d["config"]["weak_scaling_pairs_per_s"] > 0
     sub = d["config"]["sub"]["C2_match_tensor"]
     assert sub["world_size"] == 2 and "5 per rank" in sub["parallelism"] and sub["pairs_per_s"] > 0
+
+
+def test_two_rank_sharding_reproduces_single_rank_scores():
+    """Ranker.parallelize() / Multitask.parallelize() with 2 ranks (gloo, both on the one GPU): the candidate-sharded predict
+    equals the unsharded one on every rank."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "tests", "sharded_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "SHARDED_OK" in out.stdout
