@@ -11,6 +11,7 @@ cos ~ 1) may land in a neighbouring bin relative to ATen's CPU reduction order.
 import torch
 import torch.nn as nn
 
+from .. import autograd as A
 from .. import lib
 from ..constants import PAD
 from ..modules import Embeddings
@@ -47,13 +48,49 @@ class DRMM(nn.Module, lib.IdCheck):
         params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
         return self._pack.get(params, build)
 
+    def _hist(self, q, d, table):
+        """Matching histograms [B*N, QL, 5] from the scoring kernel (constants w.r.t. the parameters, as in the reference where
+        they pass through numpy, drmm.py:70-75)."""
+        B, QL = q.shape
+        N, DL = d.shape[1], d.shape[2]
+        hist = torch.empty(B * N, QL, 5, device=q.device, dtype=torch.float32)
+        scratch = torch.empty(B, N, device=q.device, dtype=torch.float32)
+        lib.check(lib.load().nir_drmm_score(lib.ptr(q), lib.ptr(d), B, N, QL, DL, lib.ptr(table), table.shape[0], table.shape[1],
+                                            self._weights().ref(), lib.ptr(scratch), lib.ptr(hist), lib.stream()), "nir_drmm_score")
+        return hist
+
+    def _forward_train(self, q, d):
+        """Train-mode forward (drmm.py:29-84) on the autograd operators of autograd.py: the trainable part is the gating network and the
+        three tiny Linear layers; the histograms come from the same HIP kernel as in eval.  With embedding dropout the kernel reads
+        the dropped rows: they are handed over as a [B*QL + M*DL, E] row table addressed by position."""
+        B, QL = q.shape
+        N, DL = d.shape[1], d.shape[2]
+        M = B * N
+        table = self.word_embeddings.table
+        p = self.emb_drop.p
+        eq = A.dropout(A.embed(q, table), p, True)                                              # [B,QL,E]
+        gate = torch.softmax(A.linear(eq, self.gating_network.weight.weight, self.gating_network.weight.bias).squeeze(2), 1)
+        if p > 0:
+            ed = A.dropout(A.embed(d.reshape(M, DL), table), p, True)
+            rows = torch.cat((eq.detach().reshape(B * QL, -1), ed.detach().reshape(M * DL, -1)), 0).contiguous()
+            pos = torch.arange(B * QL + M * DL, device=q.device, dtype=torch.int64)
+            hist = self._hist(pos[:B * QL].view(B, QL).contiguous(), pos[B * QL:].view(B, N, DL).contiguous(), rows)
+        else:
+            hist = self._hist(q, d, table.detach())
+        z = A.linear(A.linear(hist, self.ffnn[0].weight, self.ffnn[0].bias), self.ffnn[1].weight, self.ffnn[1].bias).squeeze(2)
+        pooled = (z.view(B, N, QL) * gate.unsqueeze(1)).sum(2, keepdim=True)                    # [B,N,1]
+        return A.linear(pooled, self.output.weight, self.output.bias).view(B, N)
+
     def forward(self, batch_queries, query_len, batch_docs, doc_len, return_hist=False):
         assert batch_queries.shape[0] == batch_docs.shape[0]
-        if self.training and self.emb_drop.p > 0:
-            raise NotImplementedError("HIP DRMM implements the eval-mode forward (SURVEY.md Appendix E7)")
         table = self.word_embeddings.table
         lib.require_device(batch_queries, batch_docs, table)
         q, d = self._clean_ids(batch_queries, batch_docs, self.word_embeddings.table.shape[0])
+        if self.training and not return_hist:
+            if table.requires_grad:
+                raise NotImplementedError("DRMM training needs fix_embeddings=True: the histogram features are not differentiable "
+                                          "(the reference detaches them through numpy, drmm.py:70)")
+            return self._forward_train(q, d)
         B, QL = q.shape
         N, DL = d.shape[1], d.shape[2]
         w = self._weights()

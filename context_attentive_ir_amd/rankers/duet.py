@@ -10,7 +10,9 @@ Like the reference (hyparam.py:34-46 `force_pad`), inputs must be padded to max_
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from .. import autograd as A
 from .. import lib
 from ..constants import PAD
 from ..modules import Embeddings
@@ -95,10 +97,47 @@ class DUET(nn.Module, lib.IdCheck):
         params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")] + [self.word_embeddings.table]
         return self._pack.get(params, build)
 
+    def _forward_train(self, q, d):
+        """Train-mode forward (duet.py:28-59, 73-121, 147-208) on the autograd operators of autograd.py: every Linear / Conv1d runs as
+        the HIP GEMM (the k=3 convolutions over three shifted row views, the k=1 ones directly), dropout and the embedding lookup on
+        their HIP kernels; compare / max / Hadamard / reshapes are tensor glue."""
+        B, QL = q.shape
+        N, DL = d.shape[1], d.shape[2]
+        M = B * N
+        lm, dm = self.local_model, self.distributed_model
+        NF = self._dims["NF"]
+        d2 = d.reshape(M, DL)
+        # local model: exact-match matrix (PAD == PAD counts, as in the reference), Conv1d over doc positions as channels
+        em = (d2.unsqueeze(1) == q.unsqueeze(1).expand(B, N, QL).reshape(M, QL).unsqueeze(2)).float()            # [M,QL,DL]
+        cu = A.linear(em.reshape(M * QL, DL), lm.conv1d.weight.squeeze(2), lm.conv1d.bias, act="tanh")         # [M*QL,NF]
+        cu = cu.view(M, QL, NF).transpose(1, 2).reshape(M * NF, QL)
+        f1 = A.linear(cu, lm.fc1.weight, lm.fc1.bias, act="tanh").view(M, NF)
+        f2 = A.dropout(A.linear(f1, lm.fc2.weight, lm.fc2.bias, act="tanh"), lm.drop.p, True)
+        local = A.linear(f2, lm.fc3.weight, lm.fc3.bias, act="tanh").view(B, N)
+        # distributed model
+        table = self.word_embeddings.table
+        eq = A.dropout(A.embed(q, table), self.emb_drop.p, True)
+        ed = A.dropout(A.embed(d2, table), self.emb_drop.p, True)
+
+        def conv3(x, conv):
+            L = x.shape[1] - 2
+            rows = torch.cat([x[:, k:k + L] for k in range(3)], 2).reshape(x.shape[0] * L, -1)                 # [rows, 3E] tap-major
+            w = conv.weight.permute(0, 2, 1).reshape(conv.out_channels, -1)
+            return A.linear(rows, w, conv.bias, act="tanh").view(x.shape[0], L, conv.out_channels)
+        cq, cp = conv3(eq, dm.conv_q), conv3(ed, dm.conv_d1)
+        mq = cq.max(1)[0]                                                                                       # [B,NF]
+        mp = F.max_pool1d(cp.transpose(1, 2), dm.pool_size, 1).transpose(1, 2)                                  # [M,P,NF]
+        P = mp.shape[1]
+        qr = A.linear(mq, dm.fc1.weight, dm.fc1.bias, act="tanh")
+        dr = A.linear(mp.reshape(M * P, NF), dm.conv_d2.weight.squeeze(2), dm.conv_d2.bias, act="tanh").view(M, P, NF)
+        had = qr.unsqueeze(1).expand(B, N, NF).reshape(M, 1, NF) * dr
+        m1 = A.linear(had.transpose(1, 2).reshape(M * NF, P), dm.fc2.weight, dm.fc2.bias, act="tanh").view(M, NF)
+        m2 = A.dropout(A.linear(m1, dm.fc3.weight, dm.fc3.bias, act="tanh"), dm.dropout.p, True)
+        dist = A.linear(m2, dm.fc4.weight, dm.fc4.bias, act="tanh").view(B, N)
+        return local + dist
+
     def forward(self, batch_queries, query_len, batch_docs, doc_len, return_parts=False):
         assert batch_queries.shape[0] == batch_docs.shape[0]
-        if self.training and (self.emb_drop.p > 0 or self.local_model.drop.p > 0):
-            raise NotImplementedError("HIP DUET implements the eval-mode forward (SURVEY.md Appendix E7)")
         table = self.word_embeddings.table
         lib.require_device(batch_queries, batch_docs, table)
         q, d = self._clean_ids(batch_queries, batch_docs, table.shape[0])
@@ -107,6 +146,8 @@ class DUET(nn.Module, lib.IdCheck):
         if QL != self.max_query_len or DL != self.max_doc_len:
             raise RuntimeError("DUET needs inputs padded to max_query_len=%d / max_doc_len=%d (force_pad), got %d / %d"
                                % (self.max_query_len, self.max_doc_len, QL, DL))
+        if self.training and not return_parts:
+            return self._forward_train(q, d)
         L = lib.load()
         w = self._weights()
         dev = q.device

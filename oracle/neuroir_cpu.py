@@ -238,7 +238,6 @@ def drmm_parts(sd, q, d):
     return gate, cos, torch.from_numpy(hist)
 
 
-@torch.no_grad()
 def drmm_scores_from_hist(sd, gate, hist, B, N):
     z = _lin(sd, "ffnn.1", _lin(sd, "ffnn.0", hist)).squeeze(2).view(B, N, -1)
     s = (z * gate.unsqueeze(1)).sum(2, keepdim=True)

@@ -213,20 +213,24 @@ def gen_cars():
              encoded_clicks=clicks, click_scores=scores, softmax=torch.softmax(scores, -1), ranking_loss=loss)
 
 
-def gen_train():
-    """Training step of the real reference (models/ranker.py:192-230): MATCH_TENSOR, dropout 0, Adam lr 1e-3, grad clipping 10,
+def gen_train(model="MATCH_TENSOR", fixture="match_tensor_train", seed=23, final_keys=("output.weight", "conv.weight", "linear_projection.weight",
+                                                                                      "document_encoder.rnns.0.weight_hh_l0"), disjoint=False):
+    """Training step of the real reference (models/ranker.py:192-230): dropout 0, Adam lr 1e-3, grad clipping 10,
     5 updates alternating over two batches -> loss trajectory; gradients of the first backward (before clipping)."""
-    rng = np.random.default_rng(23)
+    rng = np.random.default_rng(seed)
     B, N, QL, DL = 4, 3, 5, 11
     batches = []
     for _ in range(2):
         qlen = rng.integers(1, QL + 1, size=B); dlen = rng.integers(1, DL + 1, size=(B, N)); qlen[0] = QL; dlen[0, 0] = DL
-        q = rand_ids(rng, (B, QL), qlen); d = rand_ids(rng, (B, N, DL), dlen)
+        if disjoint:   # no shared tokens: no cosine lands on the cos == 1 histogram edge (SURVEY.md Appendix E1)
+            q = rand_ids(rng, (B, QL), qlen, 4, V // 2); d = rand_ids(rng, (B, N, DL), dlen, V // 2, V)
+        else:
+            q = rand_ids(rng, (B, QL), qlen); d = rand_ids(rng, (B, N, DL), dlen)
         lab = np.zeros((B, N), np.int64)
         lab[np.arange(B), rng.integers(0, N, size=B)] = 1
         batches.append(dict(que_rep=q, que_len=qlen, doc_rep=d, doc_len=dlen, label=lab))
-    args = base_args("MATCH_TENSOR", dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.001, weight_decay=0,
-                     momentum=0, grad_clipping=10.0, fix_embeddings=True)
+    args = base_args(model, dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.001, weight_decay=0,
+                     momentum=0, grad_clipping=10.0, fix_embeddings=True, max_query_len=QL, max_doc_len=DL)
     vocab = list(range(V))
     r = Ranker(args, vocab)
     load_det(r.network)
@@ -242,8 +246,11 @@ def gen_train():
         for k, v in b.items():
             out["b%d_%s" % (bi, k)] = v
     for name, p in r.network.named_parameters():
-        if p.grad is not None:
+        if p.grad is not None and p.numel() <= 20000:
             out["grad_" + name] = p.grad.detach().clone()
+        elif p.grad is not None:      # large tensors: every 37th element + the norm (keeps the fixture small)
+            out["gradsub37_" + name] = p.grad.detach().flatten()[::37].clone()
+            out["gradnorm_" + name] = p.grad.detach().norm()
     out["scores0"], out["loss0"] = s.detach(), loss0.detach()
     r.optimizer.zero_grad()
     losses = []
@@ -252,9 +259,18 @@ def gen_train():
         losses.append(float(r.update({k: T(v) for k, v in b.items()})))
     out["losses"] = np.asarray(losses, np.float64)
     final = r.network.state_dict()
-    for k in ("output.weight", "conv.weight", "linear_projection.weight", "document_encoder.rnns.0.weight_hh_l0"):
-        out["final_" + k] = final[k].detach().clone()
-    save("match_tensor_train", **out)
+    for k in final_keys:
+        out["final_" + k] = final[k].detach().clone() if final[k].numel() <= 20000 else final[k].detach().flatten()[::37].clone()
+    save(fixture, **out)
+
+
+def gen_duet_train():
+    gen_train("DUET", "duet_train", 31, ("local_model.conv1d.weight", "local_model.fc3.weight", "distributed_model.conv_d1.weight",
+                                         "distributed_model.fc2.weight", "distributed_model.fc4.bias"))
+
+
+def gen_drmm_train():
+    gen_train("DRMM", "drmm_train", 37, ("gating_network.weight.weight", "ffnn.0.weight", "ffnn.1.bias", "output.weight"), disjoint=True)
 
 
 def gen_cars_train():
@@ -485,7 +501,7 @@ if __name__ == "__main__":
     torch.manual_seed(SEED)
     torch.set_num_threads(4)
     only = set(sys.argv[1:])          # e.g. `generate.py cars_decode` regenerates one fixture family
-    gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode, train=gen_train, cars_train=gen_cars_train,
+    gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode, train=gen_train, duet_train=gen_duet_train, drmm_train=gen_drmm_train, cars_train=gen_cars_train,
                 losses_metrics=gen_losses_metrics, batchify=gen_batchify, samplers=gen_samplers, m_match_tensor=gen_m_match_tensor,
                 mnsrf=gen_mnsrf)
     for name, fn in gens.items():

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _rel(a, b, tol=1e-4):
+def _rel(a, b, tol=1e-4, floor=1e-5):
     a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
-    scale = max(float(np.abs(b).max()), 1e-5)     # (a mathematically-zero gradient is rounding noise ~1e-10 on both sides)
+    scale = max(float(np.abs(b).max()), floor)    # (a mathematically-zero gradient is rounding noise ~1e-10 on both sides)
     err = float(np.abs(a - b).max()) / scale
     assert err <= tol, "relative error %.3g > %.3g (scale %.3g)" % (err, tol, scale)
 
@@ -113,6 +113,140 @@ def test_ranker_update_matches_reference_loss_trajectory():
     for k in ("output.weight", "conv.weight", "linear_projection.weight", "document_encoder.rnns.0.weight_hh_l0"):
         _rel(sd[k], g["final_" + k], 2e-4)
     assert r.updates == 5
+
+
+def _check_grads(m, g, floor=1e-5):
+    for name, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        if "grad_" + name in g:
+            _rel(p.grad, g["grad_" + name], floor=floor)
+        else:                                      # large tensors are stored as every 37th element + the norm
+            _rel(p.grad.flatten()[::37], g["gradsub37_" + name])
+            _rel(p.grad.norm(), g["gradnorm_" + name])
+
+
+@pytest.mark.parametrize("model", ["DUET", "DRMM"])
+def test_duet_drmm_gradients_vs_reference(model):
+    """Train-mode forward + BCE backward of the real reference (tests/golden/{duet,drmm}_train.npz, dropout 0)."""
+    g = load_golden(model.lower() + "_train")
+    from context_attentive_ir_amd import autograd as A
+    q, ql, d, dl, lab = (T(g["b0_" + k], DEV) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label"))
+    m = build_model(model, device=DEV, dropout_emb=0.0, dropout=0.0, max_query_len=q.shape[1], max_doc_len=d.shape[2]).train()
+    m.word_embeddings.table.requires_grad_(False)
+    s = m(q, ql, d, dl)
+    assert s.requires_grad
+    _rel(s, g["scores0"], 2e-5)
+    loss = A.bce_with_logits(s, lab.float())
+    _rel(loss, g["loss0"], 1e-5)
+    loss.backward()
+    # DRMM: the gate-bias gradient is mathematically zero (softmax shift invariance); both sides hold ~1e-7 of rounding from O(0.1) terms
+    _check_grads(m, g, floor=1e-2 if model == "DRMM" else 1e-5)
+
+
+@pytest.mark.parametrize("model", ["DUET", "DRMM"])
+def test_duet_drmm_update_matches_reference_loss_trajectory(model):
+    g = load_golden(model.lower() + "_train")
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import Ranker
+    QL, DL = g["b0_que_rep"].shape[1], g["b0_doc_rep"].shape[2]
+    args = default_args(model, src_vocab_size=int(g["meta_vocab"]), dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam",
+                        learning_rate=0.001, weight_decay=0, momentum=0, grad_clipping=10.0, fix_embeddings=True, max_query_len=QL,
+                        max_doc_len=DL)
+    r = Ranker(args)
+    fill_module_(r.network, 1013)
+    r.cuda()
+    r.init_optimizer()
+    losses = []
+    for step in range(5):
+        b = {k: T(g["b%d_%s" % (step % 2, k)]) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label")}
+        losses.append(float(r.update(b)))
+    np.testing.assert_allclose(np.asarray(losses), g["losses"], rtol=1e-4, atol=0)
+    sd = r.network.state_dict()
+    for k in [f[6:] for f in g if f.startswith("final_")]:
+        have = sd[k] if sd[k].numel() <= 20000 else sd[k].flatten()[::37]
+        _rel(have, g["final_" + k], 2e-4)
+
+
+def test_duet_dropout_replayed_through_torch():
+    """DUET in train mode with dropout 0.2 at its three sites: the product's keep masks replayed through a torch-CPU restatement of
+    duet.py (F.conv1d / F.linear / autograd), scores and gradients compared."""
+    import torch.nn.functional as F
+    from context_attentive_ir_amd import autograd as A
+    from context_attentive_ir_amd import synth
+    V, B, N, QL, DL, pd = 300, 2, 3, 6, 14, 0.2
+    m = build_model("DUET", vocab=V, device=DEV, dropout_emb=pd, dropout=pd, max_query_len=QL, max_doc_len=DL).train()
+    m.word_embeddings.table.requires_grad_(False)
+    ex = synth.ranker_batch(B, N, QL, DL, V, seed=5, full_length=False)
+    A.DROPOUT.manual_seed(5)
+    A.DROPOUT.record, A.DROPOUT.masks = True, []
+    try:
+        s = m(ex["que_rep"].to(DEV), ex["que_len"].to(DEV), ex["doc_rep"].to(DEV), ex["doc_len"].to(DEV))
+    finally:
+        A.DROPOUT.record = False
+    k_loc, k_q, k_d, k_dist = [k.cpu().float() / (1 - pd) for k in A.DROPOUT.masks]      # order of the sites in _forward_train
+    lab = ex["label"].float()
+    A.bce_with_logits(s, lab.to(DEV)).backward()
+    sd = {k: v.clone().requires_grad_(not k.startswith("word_embeddings")) for k, v in cpu_state_dict(m).items()}
+    q, d = ex["que_rep"], ex["doc_rep"]
+    M = B * N
+    em = (d.view(B, N, DL, 1) == q.view(B, 1, 1, QL)).float().view(M, DL, QL)
+    lin = lambda n, x: F.linear(x, sd[n + ".weight"], sd[n + ".bias"])
+    u = torch.tanh(F.conv1d(em, sd["local_model.conv1d.weight"], sd["local_model.conv1d.bias"]))
+    u = torch.tanh(lin("local_model.fc1", u)).squeeze(2)
+    loc = torch.tanh(lin("local_model.fc3", torch.tanh(lin("local_model.fc2", u)) * k_loc.view(M, -1))).view(B, N)
+    tab = sd["word_embeddings.make_embedding.emb_luts.0.weight"] if "word_embeddings.make_embedding.emb_luts.0.weight" in sd else \
+        [v for k, v in sd.items() if k.startswith("word_embeddings")][0]
+    eq = tab[q] * k_q.view(B, QL, -1); ed = tab[d.view(M, DL)] * k_d.view(M, DL, -1)
+    pfx = "distributed_model."
+    cq = torch.tanh(F.conv1d(eq.transpose(1, 2), sd[pfx + "conv_q.weight"], sd[pfx + "conv_q.bias"]))
+    cd = torch.tanh(F.conv1d(ed.transpose(1, 2), sd[pfx + "conv_d1.weight"], sd[pfx + "conv_d1.bias"]))
+    qv = torch.tanh(lin(pfx + "fc1", cq.max(2)[0]))
+    dd = torch.tanh(F.conv1d(F.max_pool1d(cd, 5, 1), sd[pfx + "conv_d2.weight"], sd[pfx + "conv_d2.bias"]))
+    had = qv.view(B, 1, -1, 1).expand(B, N, -1, dd.size(2)).reshape(M, -1, dd.size(2)) * dd
+    m1 = torch.tanh(lin(pfx + "fc2", had)).squeeze(2)
+    m2 = torch.tanh(lin(pfx + "fc3", m1)) * k_dist.view(M, -1)
+    ref = loc + torch.tanh(lin(pfx + "fc4", m2)).view(B, N)
+    _rel(s, ref, 5e-5)
+    F.binary_cross_entropy_with_logits(ref, lab).backward()
+    for name, p in m.named_parameters():
+        if p.requires_grad:
+            _rel(p.grad, sd[name].grad)
+
+
+def test_drmm_dropout_histograms_use_the_dropped_rows():
+    """DRMM in train mode with embedding dropout: the kernel must bin cosines of the DROPPED embeddings (drmm.py:45-69)."""
+    from context_attentive_ir_amd import autograd as A
+    from context_attentive_ir_amd import synth
+    V, B, N, QL, DL, pd = 300, 2, 3, 5, 12, 0.3
+    m = build_model("DRMM", vocab=V, device=DEV, dropout_emb=pd).train()
+    m.word_embeddings.table.requires_grad_(False)
+    ex = synth.ranker_batch(B, N, QL, DL, V, seed=9, full_length=False)
+    A.DROPOUT.manual_seed(11)
+    A.DROPOUT.record, A.DROPOUT.masks = True, []
+    try:
+        s = m(ex["que_rep"].to(DEV), ex["que_len"].to(DEV), ex["doc_rep"].to(DEV), ex["doc_len"].to(DEV))
+    finally:
+        A.DROPOUT.record = False
+    k_q, k_d = [k.cpu().float() / (1 - pd) for k in A.DROPOUT.masks]
+    sd = {k: v.clone().requires_grad_(not k.startswith("word_embeddings")) for k, v in cpu_state_dict(m).items()}
+    tab = [v for k, v in sd.items() if k.startswith("word_embeddings")][0]
+    q, d = ex["que_rep"], ex["doc_rep"]
+    M = B * N
+    eq = tab[q] * k_q.view(B, QL, -1); ed = tab[d.view(M, DL)] * k_d.view(M, DL, -1)
+    gate = torch.softmax(torch.nn.functional.linear(eq, sd["gating_network.weight.weight"], sd["gating_network.weight.bias"]).squeeze(2), 1)
+    eqx = eq.unsqueeze(1).expand(B, N, QL, -1).reshape(M, QL, 1, -1)
+    cos = torch.nn.functional.cosine_similarity(eqx.expand(-1, -1, DL, -1), ed.unsqueeze(1).expand(-1, QL, -1, -1), 3).detach().numpy()
+    hist = np.stack([[np.histogram(cos[a, b], bins=[-1.0, -0.5, 0, 0.5, 1.0, 1.0])[0] for b in range(QL)] for a in range(M)]).astype(np.float32)
+    ref = O.drmm_scores_from_hist(sd, gate, torch.from_numpy(hist), B, N)
+    _rel(s, ref, 5e-5)
+    lab = ex["label"].float()
+    A.bce_with_logits(s, lab.to(DEV)).backward()
+    O.bce_with_logits(ref, lab).backward()
+    for name, p in m.named_parameters():
+        if p.requires_grad:
+            _rel(p.grad, sd[name].grad, floor=1e-2)
 
 
 def test_match_tensor_dropout_replayed_through_oracle():
