@@ -6,8 +6,8 @@
 // dist  : conv_q / conv_d1 = Conv1d(E->NF, k=3) as fp32-MFMA GEMMs with K = 3E whose A rows are gathered from
 //         the embedding table on the fly (no [B*N, DL, E] block is materialised); max-pool(5, stride 1) over t;
 //         conv_d2 (1x1) as GEMM; Hadamard with the query vector, Linear over positions, fc3, fc4.
-// Round-1 structure: GEMM launches + small element kernels (conv_d1 output is written once and re-read by the
-// pool); the fully fused per-document tile pipeline is the next optimisation.
+// The document branch (conv_d1 -> pool -> conv_d2 -> Hadamard . fc2) runs as ONE kernel per document tile when the pack carries
+// the fragment-ordered weight planes (duet_fused.hip); the GEMM-per-layer chain below it is the general fallback.
 #include "common.hpp"
 
 namespace nir {
@@ -20,6 +20,16 @@ int launch_linear_planes(const void* a1, const void* a2, int64_t lda, const int6
                          int act, const float* add, int64_t ldadd, hipStream_t st);
 int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
                   hipStream_t st);
+// duet_fused.hip
+bool duet_doc_usable(int NF, int P, int E, int DL, int K1P);
+size_t duet_doc_partial_floats(int64_t M, int DL, int P);
+int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int64_t M, int N, const void* wf1, int K1P, const void* wf2,
+                    const float* b1, const float* b2, const float* fc2w, const float* fc2b, const float* qv, int NF, int P, float* partial,
+                    float* m1, hipStream_t st);
+
+static bool duet_fused(const nir_duet_weights* w, int E, int DL) {
+    return w->bounded && w->fw1 && w->fw2 && !tun(g_tun.duet_unfused) && !tun(g_tun.exact_f32) && duet_doc_usable(w->NF, w->pool, E, DL, w->K1P);
+}
 
 // one workgroup per pair: u[pair][f] = tanh(fc1_b + sum_i fc1_w[i] * tanh(conv_b[f] + sum_{j: d_j==q_i} Wt[j][f]))
 // The QL x DL id comparisons do not depend on f: they are done ONCE per pair (a wave per query position, ballot +
@@ -213,7 +223,7 @@ struct DuetPlan {
     size_t bytes;
 };
 
-static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, int NF, int P) {
+static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, int NF, int P, bool fused) {
     Workspace a(ws, cap);
     const size_t M = (size_t)B * N;
     const int Tc = DL - 2, Tp = Tc - P + 1;
@@ -224,9 +234,14 @@ static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, in
     p.cq = a.take<float>((size_t)B * (QL - 2) * NF);
     p.qmax = a.take<float>((size_t)B * NF);
     p.qv = a.take<float>((size_t)B * NF);
-    p.cd = a.take<float>(M * Tc * NF);
-    p.pooled = a.take<float>(M * Tp * (NF + 8));      // fp32 [M*Tp, NF] or two fp16 planes [M*Tp, EP <= NF + 8]
-    p.dd = a.take<float>(M * Tp * NF);
+    if (fused) {                                      // the fused kernel keeps conv_d1 / pooled / conv_d2 on chip: only per-tile fc2 partials
+        p.cd = a.take<float>(duet_doc_partial_floats((int64_t)M, DL, P));
+        p.pooled = p.dd = nullptr;
+    } else {
+        p.cd = a.take<float>(M * Tc * NF);
+        p.pooled = a.take<float>(M * Tp * (NF + 8));  // fp32 [M*Tp, NF] or two fp16 planes [M*Tp, EP <= NF + 8]
+        p.dd = a.take<float>(M * Tp * NF);
+    }
     p.m1 = a.take<float>(M * NF);
     p.m2 = a.take<float>(M * NF);
     p.sdist = a.take<float>(M);
@@ -238,7 +253,7 @@ static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, in
 
 extern "C" size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w) {
     if (!w || B < 0 || N <= 0 || QL < 3 || DL < w->pool + 2) return 0;
-    return nir::duet_plan(nullptr, 0, B, N, QL, DL, w->NF, w->pool).bytes;
+    return nir::duet_plan(nullptr, 0, B, N, QL, DL, w->NF, w->pool, nir::duet_fused(w, E, DL)).bytes;
 }
 
 extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
@@ -257,7 +272,8 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
                 "duet: QL=%d x DL=%d exact-match lists exceed 64 KB of LDS", QL, DL);
     if (B == 0) return 0;
     const int NF = w->NF, P = w->pool, Tc = DL - 2, Tp = Tc - P + 1;
-    DuetPlan p = duet_plan(workspace, workspace_bytes, B, N, QL, DL, NF, P);
+    const bool fused = duet_fused(w, E, DL);
+    DuetPlan p = duet_plan(workspace, workspace_bytes, B, N, QL, DL, NF, P, fused);
     if (!workspace || p.bytes > workspace_bytes) {
         set_error("duet: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
         return NIR_ERR_WORKSPACE;
@@ -286,7 +302,10 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     // ---- distributed model, document side (duet.py:174,180,185)
     const bool planes = w->bounded && w->EP > 0 && w->table_h1 && w->table_h2 && w->convd1_h1 && w->convd1_h2 && w->convd2_h1 && w->convd2_h2 &&
                         w->EP % 8 == 0 && w->EP >= NF && w->EP <= NF + 8 && w->EP >= E;
-    if (planes) {
+    if (fused) {
+        NIR_PROPAGATE(launch_duet_doc(d_ids, table, E, DL, M, N, w->fw1, w->K1P, w->fw2, w->convd1_b, w->convd2_b, w->fc2_w, w->fc2_b, p.qv, NF, P,
+                                      p.cd, p.m1, st));
+    } else if (planes) {
         // pre-split fp16 term planes end to end: table planes gathered by id (3 taps) -> conv_d1 + tanh (fp32) -> pooling writes
         // planes -> conv_d2 + tanh; no operand is split inside a GEMM
         const int EP = w->EP;
@@ -315,12 +334,12 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
         NIR_PROPAGATE(launch_linear(p.pooled, NF, nullptr, nullptr, 0, 0, 0, w->convd2_w, NF, w->convd2_b, nullptr, p.dd, NF, M * Tp, NF, NF, NIR_ACT_TANH | bnd, st));
     }
     // ---- Hadamard + fc2 over positions, fc3, fc4 (duet.py:187-207)
-    {
+    if (!fused) {
         ProfScope ps("duet_hadamard_kernel", st);
         hipLaunchKernelGGL(duet_hadamard_kernel, dim3((unsigned)M), dim3(256), (size_t)(256 / (NF / 4)) * (NF / 4) * 16, st, p.dd, p.qv, w->fc2_w,
                            w->fc2_b, N, Tp, NF, p.m1);
+        NIR_CHECK_LAUNCH("duet_hadamard_kernel");
     }
-    NIR_CHECK_LAUNCH("duet_hadamard_kernel");
     NIR_PROPAGATE(launch_linear(p.m1, NF, nullptr, nullptr, 0, 0, 0, w->fc3_w, NF, w->fc3_b, nullptr, p.m2, NF, M, NF, NF, NIR_ACT_TANH, st));
     NIR_PROPAGATE(launch_rowdot(p.m2, NF, w->fc4_w, w->fc4_b, sdist, M, NF, NIR_ACT_TANH, st));
     hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, sloc, sdist, scores, M);

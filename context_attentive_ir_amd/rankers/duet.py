@@ -65,6 +65,8 @@ class DUET(nn.Module, lib.IdCheck):
         # shape the pre-split kernel measured 2.9 ms for conv_d1 against 2.56 ms for the in-kernel split (its BK = 32 tile leaves
         # 2 workgroups per CU and both kernels are bound by the load -> LDS -> barrier chain, not by the split VALU work)
         self.presplit_operands = False
+        # conv_d1 -> pool -> conv_d2 -> Hadamard . fc2 as one kernel per document tile (needs table / conv weights below 2^15)
+        self.fuse_document_branch = True
 
     def _weights(self):
         def build():
@@ -83,6 +85,19 @@ class DUET(nn.Module, lib.IdCheck):
                      float(dm.conv_d2.weight.detach().abs().max()), float(dm.conv_q.weight.detach().abs().max()))
             pk = lib.Packed(lib.DuetWeights, t, dict(self._dims, bounded=int(mx < 32768.0)))
             E, NF = self.word_embeddings.table.shape[1], self._dims["NF"]
+            if mx < 32768.0 and self.fuse_document_branch and NF <= 320 and NF % 4 == 0 and E % 4 == 0 and self._dims["pool"] <= 5:
+                # operands of the fused document-branch kernel (csrc/duet_fused.hip): conv_d1 / conv_d2 zero-padded to 320 filter rows and
+                # a multiple of 32 in k, split into two fp16 terms and re-ordered into MFMA fragments, once per weight version
+                def fragments(w2d):
+                    rows, k = w2d.shape
+                    kp = (k + 31) // 32 * 32
+                    pad = torch.zeros(320, kp, device=w2d.device, dtype=torch.float32)
+                    pad[:rows, :k] = w2d
+                    planes = torch.stack(lib.split_f16x2(pad, kp))                      # [2 terms, 320, kp] int16
+                    return planes.view(2, 20, 16, kp // 32, 4, 8).permute(3, 1, 0, 4, 2, 5).contiguous(), kp
+                pk.keep["fw1"], k1p = fragments(pk.keep["convd1_w"].reshape(NF, 3 * E))
+                pk.keep["fw2"], _ = fragments(pk.keep["convd2_w"].reshape(NF, NF))
+                pk.struct.fw1, pk.struct.fw2, pk.struct.K1P = pk.keep["fw1"].data_ptr(), pk.keep["fw2"].data_ptr(), k1p
             EP = (max(E, NF) + 7) // 8 * 8
             if mx < 32768.0 and self.presplit_operands and EP <= NF + 8 and EP - E < 8:
                 # fp16 term planes of the table and of the two big conv weights, split once per weight version (122 MB at V = 100 000)

@@ -222,6 +222,12 @@ typedef struct {
      * rounded alike, e.g. 300 -> 304).  Used only when `bounded`. */
     const void *table_h1, *table_h2, *convd1_h1, *convd1_h2, *convd2_h1, *convd2_h2;
     int EP;
+    /* optional operands of the fused document-branch kernel (csrc/duet_fused.hip; both NULL to run the unfused chain): conv_d1 as
+     * [320][K1P] (rows >= NF and k >= 3E zero, k = tap*E + e, K1P = 3E rounded up to a multiple of 32) and conv_d2 as [320][320],
+     * each split into two fp16 terms (nir_split_f16x2) and stored in MFMA-fragment order [K/32][20 column tiles][2 terms][64 lanes][8]
+     * with lane = 16*(k%32/8) + column%16.  Used only when `bounded`, NF <= 320, pool <= 5 and E % 4 == 0. */
+    const void *fw1, *fw2;
+    int K1P;
 } nir_duet_weights;
 size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w /*host*/);
 /* local_out / dist_out: optional [B,N] debug outputs (NULL to skip). Requires QL >= 3 and DL >= 7. */

@@ -778,3 +778,23 @@ def test_duet_presplit_planes_path_matches_default():
     m._pack.invalidate()
     got = m(q, ql, d, dl)
     _close(got, ref, 5e-6)
+
+
+@pytest.mark.parametrize("B,N,QL,DL,pool", [(2, 3, 4, 290, 5), (3, 5, 5, 64, 5), (1, 2, 3, 7, 5), (2, 2, 4, 131, 3), (1, 3, 4, 66, 1)])
+def test_duet_fused_document_branch_matches_layer_chain(B, N, QL, DL, pool):
+    """The fused per-document-tile kernel (csrc/duet_fused.hip: conv_d1 -> pool -> conv_d2 -> Hadamard . fc2 on chip) against the
+    GEMM-per-layer chain (tunable duet_unfused) and the oracle; tile counts 5 / 1 / 1 / 3 / 2 exercise the tile split and halos."""
+    from context_attentive_ir_amd import lib
+    V = 500
+    m = build_model("DUET", vocab=V, device=DEV, max_query_len=QL, max_doc_len=DL, pool_size=pool)
+    rng = np.random.default_rng(DL + pool)
+    q, ql, d, dl = _synth(rng, B, N, QL, DL, V)
+    qd, qld, dd, dld = (t.to(DEV) for t in (q, ql, d, dl))
+    assert m._weights().struct.fw1 and m._weights().struct.K1P == 928
+    s, loc, dist = m(qd, qld, dd, dld, return_parts=True)
+    with lib.tunable("duet_unfused", 1, 0):
+        s0, loc0, dist0 = m(qd, qld, dd, dld, return_parts=True)
+    _close(dist, dist0, 5e-6)
+    _close(s, s0, 5e-6)
+    if pool == 5:
+        _close(dist, O.duet_distributed(cpu_state_dict(m), q, d))
