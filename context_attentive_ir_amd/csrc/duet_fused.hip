@@ -1,20 +1,23 @@
-// DUET distributed model, document branch, fused per document tile (neuroir/rankers/duet.py:174-201):
+// DUET distributed model, document branch, fused per tile of conv positions (neuroir/rankers/duet.py:174-201):
 //     emb gather -> conv_d1 (k = 3) + tanh -> max_pool1d(P, stride 1) -> conv_d2 (1x1) + tanh -> Hadamard with the query vector
 //     -> Linear over positions (fc2)
-// The unfused chain writes conv_d1's [M, DL-2, NF] output, the pooled tensor and conv_d2's output to HBM and reads each back
-// (C4: 9.3 GB of counter traffic for 1.1 GB of embedding rows).  Here one workgroup owns 64 consecutive conv positions of one
-// document and keeps everything on chip:
-//   GEMM 1  D1[64, NFP] = A[64, 3E] W1^T      A = three shifted views of the gathered embedding rows (fp32 from HBM/L2, split into
+// The GEMM-per-layer chain writes conv_d1's [M, DL-2, NF] output, the pooled tensor and conv_d2's output to HBM and reads each back
+// (C4: 9.3 GB of counter traffic for 1.1 GB of embedding rows).  Here one workgroup owns 16*RT consecutive conv positions and keeps
+// everything on chip:
+//   GEMM 1  D1[rows, NFP] = A[rows, 3E] W1^T  A = three shifted views of the gathered embedding rows (fp32 from HBM/L2, split into
 //                                             two fp16 terms on the way into LDS); W1 = pre-split fp16 term planes stored by the
 //                                             host in MFMA-fragment order, streamed L2 -> VGPR (every wave owns 80 filter columns,
 //                                             so a W fragment has exactly one consumer and never needs LDS)
-//   pool    rows of an accumulator tile live in the wave that owns the column: the 5-row window is one ds_bpermute per value
-//   GEMM 2  D2[64, NFP] = P[64, NFP] W2^T     P = pooled tile as fp16 term planes in LDS (fragment order), W2 streamed like W1
-//   fc2     partial[doc][tile][f] = sum_rows fc2_w[t] * D2[row][f]   (rows outside the tile's share / the document get weight 0)
-// A second tiny kernel folds the tiles: m1[pair][f] = tanh(fc2_b + qv[b][f] * sum_tile partial).
+//   pool    rows of an accumulator tile live in the wave that owns the column: the P-row window is one ds_bpermute per value
+//   GEMM 2  D2[rows, NFP] = P[rows, NFP] W2^T P = pooled tile as fp16 term planes in LDS (fragment order), W2 streamed like W1
+//   fc2     partial[tile][slot][f] = sum_rows fc2_w[t] * D2[row][f]   (rows whose pooling window leaves the document get weight 0)
+// A second tiny kernel folds the tiles of a document: m1[pair][f] = tanh(fc2_b + qv[b][f] * sum partial).
 // Arithmetic: two-term fp16 split (x = h1 + 2^-11 h2', three v_mfma_f32_16x16x32_f16 per k-block, two accumulator sets) as in
 // gemm3_kernel<., true> -- needs |table|, |weights| < 2^15 (host-checked `bounded`); activations are tanh outputs.
-// One workgroup (4 waves, one per SIMD, 160 accumulator registers each) per CU; 104 KB of LDS.
+// The kernel is bound by the W stream out of L2 (measured with 64-row tiles: TCC busy 95 %, 13 TB/s of L2 reads, MFMA pipe 39 %),
+// so the tile is as tall as the register file and LDS allow: 96 rows = 240 accumulator AGPRs per lane and 150 KB of LDS, one
+// workgroup (4 waves, one per SIMD) per CU.  Tiles are cut from the FLATTENED (document, position) axis when documents are long
+// enough (a tile then touches at most two documents): 92 of 96 rows carry useful pooled rows.
 #include <mutex>
 #include "common.hpp"
 
@@ -24,15 +27,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DF_ROWS = 64;                 // conv positions per workgroup
 constexpr int DF_NFP = 320;                 // filter columns (4 waves x 5 tiles x 16)
 constexpr int DF_CT = 5;                    // column tiles per wave
-constexpr int DF_RT = DF_ROWS / 16;         // row tiles
-constexpr int DF_KG = DF_ROWS * 8 + 32;     // halves per k-group block [row][8] (+64 B so the 4 k-groups start in different banks)
 constexpr int DF_S2 = DF_NFP / 32;          // k-steps of GEMM 2
-constexpr int DF_A_HALVES = 2 * 2 * 4 * DF_KG;          // A stage: [2 buffers][2 terms][4 k-groups][DF_KG]
-constexpr int DF_P_HALVES = 2 * DF_S2 * 4 * DF_KG;      // P planes: [2 terms][DF_S2][4 k-groups][DF_KG]
-constexpr size_t DF_LDS = (size_t)(DF_A_HALVES + DF_P_HALVES) * 2;
+constexpr int DF_RT = 4;                    // row tiles of the launched instantiation
+constexpr int DF_ROWS = 16 * DF_RT;         // conv positions per workgroup
 
 struct DuetDocArgs {
     const int64_t* d_ids;       // [M, DL]
@@ -41,18 +40,21 @@ struct DuetDocArgs {
     const _Float16* wf2;        // [DF_S2][20][2][64][8]
     const float *b1, *b2;       // [NF]
     const float* fc2w;          // [PL]
-    float* partial;             // [M][ntile][DF_NFP]
-    int E, DL, S1, NF, PL, P, ntile, TPv;
+    float* partial;             // [tiles][2 slots][DF_NFP]
+    int64_t M;
+    int E, DL, S1, NF, Tc, PL, P;
+    int flat;                   // 1: tiles cut from the flattened (doc, position) axis with stride TS; 0: ntile tiles per document
+    int TS, ntile, TPv;
 };
 
-__device__ __forceinline__ void df_split_store(unsigned short* base, int row, int kg, int e0, const float4& v) {
+__device__ __forceinline__ void df_split_store(unsigned short* base, int kgs, int row, int kg, int e0, const float4& v) {
     const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
     const float r0 = (v.x - (float)a01[0]) * 2048.0f, r1 = (v.y - (float)a01[1]) * 2048.0f;
     const float r2 = (v.z - (float)a23[0]) * 2048.0f, r3 = (v.w - (float)a23[1]) * 2048.0f;
     const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz(r0, r1), b23 = __builtin_amdgcn_cvt_pkrtz(r2, r3);
-    unsigned short* d = base + kg * DF_KG + row * 8 + e0;
+    unsigned short* d = base + kg * kgs + row * 8 + e0;
     *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
-    *reinterpret_cast<uint2*>(d + 4 * DF_KG) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+    *reinterpret_cast<uint2*>(d + 4 * kgs) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
 }
 
 __device__ __forceinline__ float df_bperm(float v, int byte_idx) {
@@ -60,112 +62,200 @@ __device__ __forceinline__ float df_bperm(float v, int byte_idx) {
 }
 
 // In-place accumulate in AGPRs.  Written as inline assembly: with the builtin, hipcc assigns the result of each accumulator chain to a
-// different register tuple than its loop-carried input and rotates 28 of the 40 tuples through VGPRs on every k-step (112
-// v_accvgpr_* moves per 60 MFMAs).  The operands come straight from ds_read / global_load (s_waitcnt is still compiler-inserted);
-// the accumulators are first read by VALU code after DF_MMA_DRAIN.
+// different register tuple than its loop-carried input and rotates most tuples through VGPRs on every k-step (112 v_accvgpr_* moves per
+// 60 MFMAs).  The operands come straight from ds_read / global_load (s_waitcnt is still compiler-inserted); the accumulators are first
+// read by VALU code after DF_MMA_DRAIN.
 #define DF_MMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(W))
+#ifdef DF_TIMING
+__device__ long long df_dbg[16];
+#define DF_T(I) if (blockIdx.x == 3000 && threadIdx.x == 0) df_dbg[I] = __builtin_readcyclecounter();
+#else
+#define DF_T(I)
+#endif
 #define DF_MMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
-// 12 MFMAs of one column tile (4 row tiles x 3 term products): the cross terms go to acx, the leading term to acc
-__device__ __forceinline__ void df_mma_col(f32x4 (&acc)[DF_RT], f32x4 (&acx)[DF_RT], const f16x8 (&af)[DF_RT][2], const f16x8& w0,
-                                           const f16x8& w1) {
-#pragma unroll
-    for (int i = 0; i < DF_RT; ++i) DF_MMA(acx[i], af[i][1], w0);
-#pragma unroll
-    for (int i = 0; i < DF_RT; ++i) DF_MMA(acx[i], af[i][0], w1);
-#pragma unroll
-    for (int i = 0; i < DF_RT; ++i) DF_MMA(acc[i], af[i][0], w0);
+// MFMA number n of a k-step (n is a compile-time constant after unrolling): column tile n / (3 RT), term pair (n / RT) % 3, row tile n % RT
+template <int RT>
+__device__ __forceinline__ void df_mma_n(int n, f32x4 (&acc)[DF_CT][RT], f32x4 (&acx)[DF_CT][RT], const f16x8 (&af)[RT][2],
+                                         const f16x8 (&w)[DF_CT][2]) {
+    const int j = n / (3 * RT), ph = (n / RT) % 3, i = n % RT;
+    if (ph == 0) DF_MMA(acx[j][i], af[i][1], w[j][0]);
+    else if (ph == 1) DF_MMA(acx[j][i], af[i][0], w[j][1]);
+    else DF_MMA(acc[j][i], af[i][0], w[j][0]);
 }
 
+// one half (two elements) of a staged float4: split into the two fp16 terms and store 4 bytes into each term plane
+__device__ __forceinline__ void df_split_store_half(unsigned short* base, int kgs, int row, int kg, int e0, float x, float y) {
+    const fp16x2_t a = __builtin_amdgcn_cvt_pkrtz(x, y);
+    const fp16x2_t b = __builtin_amdgcn_cvt_pkrtz((x - (float)a[0]) * 2048.0f, (y - (float)a[1]) * 2048.0f);
+    unsigned short* d = base + kg * kgs + row * 8 + e0;
+    *reinterpret_cast<unsigned*>(d) = __builtin_bit_cast(unsigned, a);
+    *reinterpret_cast<unsigned*>(d + 4 * kgs) = __builtin_bit_cast(unsigned, b);
+}
+
+template <int RT>
+struct DfLayout {
+    static constexpr int ROWS = 16 * RT;
+    static constexpr int KG = ROWS * 8 + 32;            // halves per k-group block [row][8] (+64 B: the 4 k-groups start in different banks)
+    static constexpr int A_HALVES = 2 * 2 * 4 * KG;     // A stage: [2 buffers][2 terms][4 k-groups][KG]
+    static constexpr int P_HALVES = 2 * DF_S2 * 4 * KG; // P planes: [2 terms][DF_S2][4 k-groups][KG]
+    static constexpr size_t LDS = (size_t)(A_HALVES + P_HALVES) * 2;
+    static constexpr int LPT = ROWS * 8 / 256;          // A-stage float4 loads per thread and k-step
+};
+
+template <int RT>
 __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
+    using L = DfLayout<RT>;
+    constexpr int KG = L::KG, LPT = L::LPT;
     extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];
     unsigned short* As = dsm;
-    unsigned short* Pp = dsm + DF_A_HALVES;
+    unsigned short* Pp = dsm + L::A_HALVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int64_t doc = blockIdx.x / p.ntile;
-    const int tile = (int)(blockIdx.x % p.ntile);
-    const int t0 = tile * p.TPv;
-    const int E = p.E, S1 = p.S1, K1 = 3 * p.E;
+    const int E = p.E, S1 = p.S1, K1 = 3 * p.E, Tc = p.Tc;
+    // first conv row of the tile: document doc0, position t00 (one 64-bit division per workgroup; rows use 32-bit offsets from it)
+    int64_t doc0;
+    int t00;
+    if (p.flat) {
+        const int64_t R0 = (int64_t)blockIdx.x * p.TS;
+        doc0 = R0 / Tc;
+        t00 = (int)(R0 - doc0 * Tc);
+    } else {
+        doc0 = blockIdx.x / p.ntile;
+        t00 = (int)(blockIdx.x % p.ntile) * p.TPv;
+    }
+    // row pr of the tile -> (document offset d in 0..2, position t); flattened tiles run on into the following documents
+    auto row_pos = [&](int pr, int& d, int& t) {
+        t = t00 + pr;
+        d = 0;
+        if (p.flat) {
+            if (t >= Tc) { t -= Tc; d = 1; }
+            if (t >= Tc) { t -= Tc; d = 2; }
+            if (doc0 + d >= p.M) { d = (int)(p.M - 1 - doc0); t = Tc - 1; }     // past the last document: clamp (weight 0 later)
+        } else {
+            t = t < Tc - 1 ? t : Tc - 1;                                            // per-document tiles stay inside their document
+        }
+    };
 
-    // ---- A operand: row `arow` of the tile = conv position t0 + arow = tokens t, t+1, t+2 (positions past the document are clamped;
-    // their rows only feed pooled rows that get weight 0).  Tap s of the row starts at table + id_s * E; the offsets are pre-biased by
-    // the tap's k offset so that element k of the concatenated row is table[off_s + k].
-    const int arow = tid >> 2, aq = tid & 3;
-    int64_t off0, off1, off2;
-    {
-        int tok = t0 + arow;
-        tok = tok < p.DL - 3 ? tok : p.DL - 3;
-        const int64_t* idp = p.d_ids + doc * p.DL + tok;
-        off0 = idp[0] * (int64_t)E;
-        off1 = idp[1] * (int64_t)E - E;
-        off2 = idp[2] * (int64_t)E - 2 * E;
+    // ---- A operand: conv row (doc, t) reads tokens t, t+1, t+2 of its document (rows past the end are clamped; they only feed
+    // pooled rows that get weight 0).  Tap s of a row starts at table + id_s * E; the offsets are pre-biased by the tap's k offset so
+    // that element k of the concatenated row is table[off_s + k].
+    const int aq = tid & 7;
+    int64_t off[LPT][3];
+#pragma unroll
+    for (int h = 0; h < LPT; ++h) {
+        int d, t;
+        row_pos((tid >> 3) + 32 * h, d, t);
+        const int64_t* idp = p.d_ids + (doc0 + d) * p.DL + t;
+        off[h][0] = idp[0] * (int64_t)E;
+        off[h][1] = idp[1] * (int64_t)E - E;
+        off[h][2] = idp[2] * (int64_t)E - 2 * E;
     }
     const float* const table = p.table;
-    float4 ra0, ra1;
-#define DF_LOAD_A(S)                                                                                      \
+    float4 ra[LPT], rb[LPT];
+#define DF_LOAD_A(RA, S)                                                                                  \
     {                                                                                                     \
         int k_ = 32 * (S) + 4 * aq;                                                                       \
-        int ka_ = k_ < K1 ? k_ : K1 - 4, kb_ = k_ + 16 < K1 ? k_ + 16 : K1 - 4;                           \
-        const int64_t oa_ = ka_ < E ? off0 : (ka_ < 2 * E ? off1 : off2);                                 \
-        const int64_t ob_ = kb_ < E ? off0 : (kb_ < 2 * E ? off1 : off2);                                 \
-        ra0 = *reinterpret_cast<const float4*>(table + oa_ + ka_);                                        \
-        ra1 = *reinterpret_cast<const float4*>(table + ob_ + kb_);                                        \
+        k_ = k_ < K1 ? k_ : K1 - 4;                              /* k >= 3E: any finite value (W1 is zero there) */ \
+        _Pragma("unroll") for (int h_ = 0; h_ < LPT; ++h_) {                                              \
+            const int64_t o_ = k_ < E ? off[h_][0] : (k_ < 2 * E ? off[h_][1] : off[h_][2]);              \
+            RA[h_] = *reinterpret_cast<const float4*>(table + o_ + k_);                                   \
+        }                                                                                                 \
     }
-#define DF_STORE_A(BUF)                                                                                   \
+#define DF_STORE_A(RA, BUF)                                                                               \
     {                                                                                                     \
-        df_split_store(As + (BUF) * (2 * 4 * DF_KG), arow, (aq >> 1), 4 * (aq & 1), ra0);                 \
-        df_split_store(As + (BUF) * (2 * 4 * DF_KG), arow, (aq >> 1) + 2, 4 * (aq & 1), ra1);             \
+        _Pragma("unroll") for (int h_ = 0; h_ < LPT; ++h_)                                                \
+            df_split_store(As + (BUF) * (2 * 4 * KG), KG, (tid >> 3) + 32 * h_, aq >> 1, 4 * (aq & 1), RA[h_]); \
     }
     // ---- W operands: fragment-ordered planes, 1 KB contiguous per wave-level load; one register set, a column tile's pair is
-    // re-loaded for the next k-step as soon as its 12 MFMAs are issued (the other four tiles' MFMAs cover the L2 latency)
+    // re-loaded for the next k-step as soon as its MFMAs are issued (the other four tiles' MFMAs cover the L2 latency)
     const _Float16* wp1 = p.wf1 + ((int64_t)(DF_CT * wave) * 2 * 64 + lane) * 8;
     const _Float16* wp2 = p.wf2 + ((int64_t)(DF_CT * wave) * 2 * 64 + lane) * 8;
     constexpr int WSTEP = 20 * 2 * 64 * 8;
     f16x8 w[DF_CT][2];
-    f32x4 acc[DF_CT][DF_RT], acx[DF_CT][DF_RT];
+    f32x4 acc[DF_CT][RT], acx[DF_CT][RT];
 #pragma unroll
     for (int j = 0; j < DF_CT; ++j)
 #pragma unroll
-        for (int i = 0; i < DF_RT; ++i) {
+        for (int i = 0; i < RT; ++i) {
             acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    const int foff = g * DF_KG + c16 * 8;       // fragment address of the A-side operand: [term][k-group = lane >> 4][row][8]
+    const int foff = g * KG + c16 * 8;          // fragment address of the A-side operand: [term][k-group = lane >> 4][row][8]
 
     // ================= GEMM 1: conv_d1 =================
-    DF_LOAD_A(0)
-#pragma unroll
-    for (int j = 0; j < DF_CT; ++j) {
-        w[j][0] = *reinterpret_cast<const f16x8*>(wp1 + (j * 2) * 512);
-        w[j][1] = *reinterpret_cast<const f16x8*>(wp1 + (j * 2 + 1) * 512);
+    // One wave per SIMD: whatever is not an MFMA has to be issued in the 12 idle issue cycles behind each MFMA, so every k-step is
+    // written as its 15 RT MFMAs with the other work of the step pinned between them (sched_barrier after every MFMA):
+    //   W fragments of step s+1  -> the other register set, one load every 6 MFMAs (a full step of slack: with a single set re-loaded
+    //                               tile by tile, hipcc's loop-header s_waitcnt merge waited for loads issued ~200 cycles earlier)
+    //   A rows of step s+1       -> loaded during step s-1 (register set RAC), split + stored to LDS in the first third of step s
+    //   A rows of step s+2       -> global loads into the other set (RAN)
+    //   barrier                  -> after MFMA 8 LPT + 6; A fragments of step s+1 are read from LDS in the second half (set AFN)
+    // WAR hazard of the inline-assembly MFMAs: a VALU write to a VGPR that an MFMA issued fewer than ~8 slots earlier reads as A/B
+    // operand corrupts that operand (LLVM pads this for its own MFMAs -- SMFMA16x16ReadVgprVALUWarWaitStates -- but cannot see inside
+    // the asm, and happily re-uses a fragment register for split arithmetic right after its last MFMA: deterministic 1e-3 errors).
+    // DF_KEEP / DF_KEEP_HEAD are empty asm uses that keep the fragment registers of a step live until its end, and those read by the
+    // last MFMAs of a step until MFMA 8 of the next one, so nothing can be allocated on top of them in between.
+    DF_T(0)
+    f16x8 wb[DF_CT][2], afa[RT][2], afb[RT][2];
+#define DF_LOAD_W(W, PTR)                                                                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < DF_CT; ++j_) {                                \
+        W[j_][0] = *reinterpret_cast<const f16x8*>((PTR) + (j_ * 2) * 512);               \
+        W[j_][1] = *reinterpret_cast<const f16x8*>((PTR) + (j_ * 2 + 1) * 512);           \
     }
-    DF_STORE_A(0)
+#define DF_KEEP_HEAD(WN, AFN)                                                             \
+    _Pragma("unroll") for (int j_ = DF_CT - 2; j_ < DF_CT; ++j_) asm volatile("" ::"v"(WN[j_][0]), "v"(WN[j_][1])); \
+    _Pragma("unroll") for (int i_ = 0; i_ < RT; ++i_) asm volatile("" ::"v"(AFN[i_][0]), "v"(AFN[i_][1]));
+#define DF_KEEP(WC, AFC)                                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < DF_CT; ++j_) asm volatile("" ::"v"(WC[j_][0]), "v"(WC[j_][1]));   \
+    _Pragma("unroll") for (int i_ = 0; i_ < RT; ++i_) asm volatile("" ::"v"(AFC[i_][0]), "v"(AFC[i_][1]));
+#define DF_STEP1(S, AFC, AFN, WC, WN, RAC, RAN)                                           \
+    {                                                                                     \
+        const int s1_ = (S) + 1 < S1 ? (S) + 1 : S1 - 1;      /* past the end: re-load the last step's operands (branch-free) */ \
+        const int s2_ = (S) + 2 < S1 ? (S) + 2 : S1 - 1;                                  \
+        const _Float16* wn_ = wp1 + (int64_t)s1_ * WSTEP;                                 \
+        unsigned short* an_ = As + (((S) + 1) & 1) * (2 * 4 * KG);                        \
+        _Pragma("unroll") for (int n_ = 0; n_ < 15 * RT; ++n_) {                          \
+            df_mma_n<RT>(n_, acc, acx, AFC, WC);                                          \
+            if (n_ == 8) { DF_KEEP_HEAD(WN, AFN) }                                        \
+            if (n_ % 6 == 2 && n_ / 6 < 2 * DF_CT)                                        \
+                WN[(n_ / 6) >> 1][(n_ / 6) & 1] = *reinterpret_cast<const f16x8*>(wn_ + (n_ / 6) * 512); \
+            if (n_ % 4 == 1 && n_ / 4 < 2 * LPT) {                                        \
+                const int h_ = (n_ / 4) >> 1;                                             \
+                if ((n_ / 4) & 1) df_split_store_half(an_, KG, (tid >> 3) + 32 * h_, aq >> 1, 4 * (aq & 1) + 2, RAC[h_].z, RAC[h_].w); \
+                else df_split_store_half(an_, KG, (tid >> 3) + 32 * h_, aq >> 1, 4 * (aq & 1), RAC[h_].x, RAC[h_].y); \
+            }                                                                             \
+            if (n_ == 8 * LPT + 2) DF_LOAD_A(RAN, s2_)                                    \
+            if (n_ == 8 * LPT + 6) __syncthreads();                                       \
+            if (n_ >= 8 * LPT + 8 && (n_ - 8 * LPT - 8) % 3 == 0 && (n_ - 8 * LPT - 8) / 3 < 2 * RT) { \
+                const int q_ = (n_ - 8 * LPT - 8) / 3;                                    \
+                AFN[q_ % RT][q_ / RT] = *reinterpret_cast<const f16x8*>(an_ + (q_ / RT) * 4 * KG + foff + (q_ % RT) * 128); \
+            }                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+        DF_KEEP(WC, AFC)                                                                  \
+    }
+    DF_LOAD_A(ra, 0)
+    DF_LOAD_W(w, wp1)
+    DF_STORE_A(ra, 0)
+    DF_LOAD_A(ra, (1 < S1 ? 1 : 0))
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) afa[i][t] = *reinterpret_cast<const f16x8*>(As + t * 4 * KG + foff + i * 128);
+    DF_T(1)
+    {
+        int s = 0;
 #pragma unroll 1
-    for (int s = 0; s < S1; ++s) {
-        const int sn = s + 1 < S1 ? s + 1 : S1 - 1;           // the last step re-loads its own operands (branch-free)
-        DF_LOAD_A(sn)
-        const unsigned short* ab = As + (s & 1) * (2 * 4 * DF_KG) + foff;
-        f16x8 af[DF_RT][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < DF_RT; ++i) af[i][t] = *reinterpret_cast<const f16x8*>(ab + t * 4 * DF_KG + i * 128);
-        const _Float16* wn = wp1 + (int64_t)sn * WSTEP;
-#pragma unroll
-        for (int j = 0; j < DF_CT; ++j) {
-            __builtin_amdgcn_sched_barrier(0);
-            df_mma_col(acc[j], acx[j], af, w[j][0], w[j][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            w[j][0] = *reinterpret_cast<const f16x8*>(wn + (j * 2) * 512);
-            w[j][1] = *reinterpret_cast<const f16x8*>(wn + (j * 2 + 1) * 512);
+        for (; s + 1 < S1; s += 2) {
+            DF_STEP1(s, afa, afb, w, wb, ra, rb)
+            DF_STEP1(s + 1, afb, afa, wb, w, rb, ra)
         }
-        __builtin_amdgcn_sched_barrier(0);
-        DF_STORE_A((s + 1) & 1)
-        __syncthreads();
+        if (s < S1) DF_STEP1(s, afa, afb, w, wb, ra, rb)
     }
 
+    DF_T(2)
     DF_MMA_DRAIN();
     // ================= tanh, max-pool over rows, split into the P planes =================
     // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + r.  Pooled row pr needs rows pr .. pr+P-1: the rest of
@@ -177,20 +267,20 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         for (int j = 0; j < DF_CT; ++j) {
             const int col = 80 * wave + 16 * j + c16;
             const float bias = col < p.NF ? p.b1[col] : 0.f;
-            float v[DF_RT + 1][4], x[DF_RT + 1][4];
+            float v[RT][4], x[RT + 1][4];
 #pragma unroll
-            for (int i = 0; i < DF_RT; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[i][r] = fast_tanh(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]) + bias);
                     x[i][r] = df_bperm(v[i][r], nb_idx);
                 }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[DF_RT][r] = x[DF_RT - 1][r];     // rows past the tile: pooled rows >= 60 are never used
+            for (int r = 0; r < 4; ++r) x[RT][r] = x[RT - 1][r];           // rows past the tile: the last P-1 pooled rows are never used
             const int sk = col >> 5, kg = (col >> 3) & 3, e = col & 7;
-            unsigned short* dst = Pp + (sk * 4 + kg) * DF_KG + e;
+            unsigned short* dst = Pp + (sk * 4 + kg) * KG + e;
 #pragma unroll
-            for (int i = 0; i < DF_RT; ++i) {
+            for (int i = 0; i < RT; ++i) {
                 float cat[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -206,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
                     const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz((m - (float)h1[0]) * 2048.0f, 0.f);
                     const int row = 16 * i + 4 * g + r;
                     dst[row * 8] = __builtin_bit_cast(unsigned, h1) & 0xFFFFu;
-                    dst[DF_S2 * 4 * DF_KG + row * 8] = __builtin_bit_cast(unsigned, h2) & 0xFFFFu;
+                    dst[DF_S2 * 4 * KG + row * 8] = __builtin_bit_cast(unsigned, h2) & 0xFFFFu;
                 }
             }
         }
@@ -214,86 +304,119 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
 #pragma unroll
     for (int j = 0; j < DF_CT; ++j)
 #pragma unroll
-        for (int i = 0; i < DF_RT; ++i) {
+        for (int i = 0; i < RT; ++i) {
             acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-#pragma unroll
-    for (int j = 0; j < DF_CT; ++j) {
-        w[j][0] = *reinterpret_cast<const f16x8*>(wp2 + (j * 2) * 512);
-        w[j][1] = *reinterpret_cast<const f16x8*>(wp2 + (j * 2 + 1) * 512);
-    }
+    DF_LOAD_W(w, wp2)
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) afa[i][t] = *reinterpret_cast<const f16x8*>(Pp + t * DF_S2 * 4 * KG + foff + i * 128);
+    DF_T(3)
 
     // ================= GEMM 2: conv_d2 (A = P planes, static in LDS: no barriers) =================
+#define DF_STEP2(S, AFC, AFN, WC, WN)                                                     \
+    {                                                                                     \
+        const int sn_ = (S) + 1 < DF_S2 ? (S) + 1 : DF_S2 - 1;                            \
+        const _Float16* wn_ = wp2 + (int64_t)sn_ * WSTEP;                                 \
+        const unsigned short* pn_ = Pp + sn_ * 4 * KG + foff;                             \
+        _Pragma("unroll") for (int n_ = 0; n_ < 15 * RT; ++n_) {                          \
+            df_mma_n<RT>(n_, acc, acx, AFC, WC);                                          \
+            if (n_ == 8) { DF_KEEP_HEAD(WN, AFN) }                                        \
+            if (n_ % 6 == 2 && n_ / 6 < 2 * DF_CT)                                        \
+                WN[(n_ / 6) >> 1][(n_ / 6) & 1] = *reinterpret_cast<const f16x8*>(wn_ + (n_ / 6) * 512); \
+            if (n_ >= 11 && n_ % 6 == 5 && (n_ - 11) / 6 < 2 * RT)     /* after the head fence, which still names AFN */ \
+                AFN[((n_ - 11) / 6) % RT][((n_ - 11) / 6) / RT] =                         \
+                    *reinterpret_cast<const f16x8*>(pn_ + (((n_ - 11) / 6) / RT) * DF_S2 * 4 * KG + (((n_ - 11) / 6) % RT) * 128); \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+        DF_KEEP(WC, AFC)                                                                  \
+    }
 #pragma unroll 1
-    for (int s2 = 0; s2 < DF_S2; ++s2) {
-        const int sn = s2 + 1 < DF_S2 ? s2 + 1 : DF_S2 - 1;
-        f16x8 af[DF_RT][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < DF_RT; ++i)
-                af[i][t] = *reinterpret_cast<const f16x8*>(Pp + (t * DF_S2 + s2) * 4 * DF_KG + foff + i * 128);
-        const _Float16* wn = wp2 + (int64_t)sn * WSTEP;
-#pragma unroll
-        for (int j = 0; j < DF_CT; ++j) {
-            __builtin_amdgcn_sched_barrier(0);
-            df_mma_col(acc[j], acx[j], af, w[j][0], w[j][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            w[j][0] = *reinterpret_cast<const f16x8*>(wn + (j * 2) * 512);
-            w[j][1] = *reinterpret_cast<const f16x8*>(wn + (j * 2 + 1) * 512);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int s2 = 0; s2 < DF_S2; s2 += 2) {
+        DF_STEP2(s2, afa, afb, w, wb)
+        DF_STEP2(s2 + 1, afb, afa, wb, w)
     }
 
+    DF_T(4)
     DF_MMA_DRAIN();
     // ================= tanh, fc2 over the tile's rows =================
+    // Row weight = fc2_w[t] when the row is one of the tile's own pooled rows and its window stays inside the document, else 0.  A
+    // flattened tile touches at most two documents: slot 0 = the document of the tile's first row, slot 1 = the next one.
     {
-        float wrow[DF_RT][4];
+        const int own = p.flat ? p.TS : p.TPv;
+        float wrow[RT][4], w1row[RT][4];
 #pragma unroll
-        for (int i = 0; i < DF_RT; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pr = 16 * i + 4 * g + r;
-                const bool ok = pr < p.TPv && t0 + pr < p.PL;
-                wrow[i][r] = p.fc2w[ok ? t0 + pr : 0] * (ok ? 1.0f : 0.0f);
+                int t = t00 + pr;
+                const bool s1 = p.flat && t >= Tc;               // an owned row is in the tile's first document or the one after it
+                t = s1 ? t - Tc : t;
+                const bool ok = pr < own && t < p.PL && doc0 + (s1 ? 1 : 0) < p.M;
+                const float wv = p.fc2w[ok ? t : 0] * (ok ? 1.0f : 0.0f);
+                wrow[i][r] = s1 ? 0.f : wv;
+                w1row[i][r] = s1 ? wv : 0.f;
             }
-        float* out = p.partial + ((int64_t)blockIdx.x) * DF_NFP;
+        float* out = p.partial + (int64_t)blockIdx.x * 2 * DF_NFP;
 #pragma unroll
         for (int j = 0; j < DF_CT; ++j) {
             const int col = 80 * wave + 16 * j + c16;
             const float bias = col < p.NF ? p.b2[col] : 0.f;
-            float sum = 0.f;
+            float sum = 0.f, sum1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < DF_RT; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sum = fmaf(wrow[i][r], fast_tanh(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]) + bias), sum);
+                for (int r = 0; r < 4; ++r) {
+                    const float d2 = fast_tanh(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]) + bias);
+                    sum = fmaf(wrow[i][r], d2, sum);
+                    sum1 = fmaf(w1row[i][r], d2, sum1);
+                }
             sum += df_bperm(sum, ((lane + 16) & 63) * 4);
             sum += df_bperm(sum, ((lane + 32) & 63) * 4);
-            if (g == 0) out[col] = sum;
+            sum1 += df_bperm(sum1, ((lane + 16) & 63) * 4);
+            sum1 += df_bperm(sum1, ((lane + 32) & 63) * 4);
+            if (g == 0) {
+                out[col] = sum;
+                out[DF_NFP + col] = sum1;
+            }
         }
     }
+    DF_T(5)
 }
 
-// m1[pair][f] = tanh(fc2_b + qv[b][f] * sum_tile partial[pair][tile][f])
+// m1[pair][f] = tanh(fc2_b + qv[b][f] * sum over the tiles (and slots) that hold pooled rows of the pair's document)
 __global__ void duet_doc_finish_kernel(const float* __restrict__ partial, const float* __restrict__ qv, const float* __restrict__ fc2b, int N,
-                                       int NF, int ntile, int64_t total, float* __restrict__ m1) {
+                                       int NF, int flat, int TS, int Tc, int PL, int ntile, int64_t total, float* __restrict__ m1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int64_t pair = i / NF;
     const int f = (int)(i % NF);
     float s = 0.f;
-    for (int t = 0; t < ntile; ++t) s += partial[(pair * ntile + t) * DF_NFP + f];
+    if (flat) {
+        const int64_t ta = pair * Tc / TS, tb = (pair * Tc + PL - 1) / TS;
+        for (int64_t t = ta; t <= tb; ++t) {
+            const int slot = (int)(pair - t * TS / Tc);          // 0 or 1
+            s += partial[(t * 2 + slot) * DF_NFP + f];
+        }
+    } else {
+        for (int t = 0; t < ntile; ++t) s += partial[((pair * ntile + t) * 2) * DF_NFP + f];
+    }
     m1[i] = fast_tanh(fc2b[0] + qv[(pair / N) * NF + f] * s);
 }
 
-// Tiling of a document: 64 conv positions per workgroup give 64 - (P-1) pooled rows; the pooled rows are shared out evenly.
-void duet_doc_tiling(int DL, int P, int* ntile, int* tpv) {
-    const int PL = DL - 2 - P + 1, cap = DF_ROWS - (P - 1);
-    *ntile = (PL + cap - 1) / cap;
-    *tpv = (PL + *ntile - 1) / *ntile;
+// Tiling: a tile of DF_ROWS conv positions yields DF_ROWS - (P-1) pooled rows.  Long documents (>= that many positions): tiles are cut
+// from the flattened axis with that stride.  Short documents: ntile tiles per document, the pooled rows shared out evenly.
+static void duet_doc_tiling(int64_t M, int DL, int P, DuetDocArgs* a, int64_t* tiles) {
+    const int Tc = DL - 2, PL = Tc - P + 1, cap = DF_ROWS - (P - 1);
+    a->Tc = Tc; a->PL = PL; a->TS = cap;
+    a->flat = Tc >= cap ? 1 : 0;
+    a->ntile = (PL + cap - 1) / cap;
+    a->TPv = (PL + a->ntile - 1) / a->ntile;
+    *tiles = a->flat ? (M * Tc + cap - 1) / cap : M * a->ntile;
 }
 
 bool duet_doc_usable(int NF, int P, int E, int DL, int K1P) {
@@ -301,9 +424,10 @@ bool duet_doc_usable(int NF, int P, int E, int DL, int K1P) {
 }
 
 size_t duet_doc_partial_floats(int64_t M, int DL, int P) {
-    int nt, tpv;
-    duet_doc_tiling(DL, P, &nt, &tpv);
-    return (size_t)M * nt * DF_NFP;
+    DuetDocArgs a;
+    int64_t tiles;
+    duet_doc_tiling(M, DL, P, &a, &tiles);
+    return (size_t)tiles * 2 * DF_NFP;
 }
 
 int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int64_t M, int N, const void* wf1, int K1P, const void* wf2,
@@ -313,23 +437,31 @@ int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int
     if (M == 0) return 0;
     DuetDocArgs a;
     a.d_ids = d_ids; a.table = table; a.wf1 = (const _Float16*)wf1; a.wf2 = (const _Float16*)wf2; a.b1 = b1; a.b2 = b2; a.fc2w = fc2w;
-    a.partial = partial; a.E = E; a.DL = DL; a.S1 = K1P / 32; a.NF = NF; a.PL = DL - 2 - P + 1; a.P = P;
-    duet_doc_tiling(DL, P, &a.ntile, &a.TPv);
+    a.partial = partial; a.M = M; a.E = E; a.DL = DL; a.S1 = K1P / 32; a.NF = NF; a.P = P;
+    int64_t tiles;
+    duet_doc_tiling(M, DL, P, &a, &tiles);
+    constexpr size_t lds = DfLayout<DF_RT>::LDS;
     static std::once_flag once;
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)duet_doc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS); });
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)duet_doc_kernel<DF_RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     {
-        ProfScope ps(prof_shape_name("duet_doc_kernel", M * a.ntile * DF_ROWS, NF, 3 * E), st);
-        hipLaunchKernelGGL(duet_doc_kernel, dim3((unsigned)(M * a.ntile)), dim3(256), DF_LDS, st, a);
+        ProfScope ps(prof_shape_name("duet_doc_kernel", tiles * DF_ROWS, NF, 3 * E), st);
+        hipLaunchKernelGGL(duet_doc_kernel<DF_RT>, dim3((unsigned)tiles), dim3(256), lds, st, a);
     }
     NIR_CHECK_LAUNCH("duet_doc_kernel");
     {
         const int64_t total = M * NF;
         ProfScope ps("duet_doc_finish_kernel", st);
-        hipLaunchKernelGGL(duet_doc_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, qv, fc2b, N, NF, a.ntile, total,
-                           m1);
+        hipLaunchKernelGGL(duet_doc_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, qv, fc2b, N, NF, a.flat, a.TS,
+                           a.Tc, a.PL, a.ntile, total, m1);
     }
     NIR_CHECK_LAUNCH("duet_doc_finish_kernel");
     return 0;
 }
 
 }  // namespace nir
+
+#ifdef DF_TIMING
+extern "C" int nir_debug_duet_timing(long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(nir::df_dbg), sizeof(long long) * 16);
+}
+#endif
