@@ -57,6 +57,12 @@ __device__ __forceinline__ void df_split_store(unsigned short* base, int kgs, in
     *reinterpret_cast<uint2*>(d + 4 * kgs) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
 }
 
+// tanh(x) for z = 2 log2(e) x already formed:  1 - 2 / (1 + 2^z)   (v_exp_f32, v_rcp_f32; saturates correctly at +-inf)
+constexpr float DF_2LOG2E = 2.8853900817779268f;
+__device__ __forceinline__ float df_tanh_z(float z) {
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), 1.0f);
+}
+
 __device__ __forceinline__ float df_bperm(float v, int byte_idx) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_idx, __builtin_bit_cast(int, v)));
 }
@@ -103,7 +109,8 @@ struct DfLayout {
     static constexpr int LPT = ROWS * 8 / 256;          // A-stage float4 loads per thread and k-step
 };
 
-template <int RT>
+// POOL: pooling window known at compile time (5 = the reference's pool_size), or 0 = read it from the arguments (1..5)
+template <int RT, int POOL>
 __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
     using L = DfLayout<RT>;
     constexpr int KG = L::KG, LPT = L::LPT;
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         const int s2_ = (S) + 2 < S1 ? (S) + 2 : S1 - 1;                                  \
         const _Float16* wn_ = wp1 + (int64_t)s1_ * WSTEP;                                 \
         unsigned short* an_ = As + (((S) + 1) & 1) * (2 * 4 * KG);                        \
-        _Pragma("unroll") for (int n_ = 0; n_ < 15 * RT; ++n_) {                          \
+        _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 15 * RT; ++n_) {                          \
             df_mma_n<RT>(n_, acc, acx, AFC, WC);                                          \
             if (n_ == 8) { DF_KEEP_HEAD(WN, AFN) }                                        \
             if (n_ % 6 == 2 && n_ / 6 < 2 * DF_CT)                                        \
@@ -262,17 +269,17 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
     // this lane's quad and the quad of the next 16-lane group (the next row tile's group 0 for group 3), fetched by ds_bpermute.
     {
         const int nb_idx = ((lane + 16) & 63) * 4;
-        const int P = p.P;
+        const int P = POOL ? POOL : p.P;
 #pragma unroll
         for (int j = 0; j < DF_CT; ++j) {
             const int col = 80 * wave + 16 * j + c16;
-            const float bias = col < p.NF ? p.b1[col] : 0.f;
+            const float biasz = (col < p.NF ? p.b1[col] : 0.f) * DF_2LOG2E;
             float v[RT][4], x[RT + 1][4];
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[i][r] = fast_tanh(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]) + bias);
+                    v[i][r] = df_tanh_z(fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), DF_2LOG2E, biasz));
                     x[i][r] = df_bperm(v[i][r], nb_idx);
                 }
 #pragma unroll
@@ -281,19 +288,30 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             unsigned short* dst = Pp + (sk * 4 + kg) * KG + e;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                float cat[8];
+                float c[8], m[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    cat[r] = v[i][r];
-                    cat[4 + r] = g < 3 ? x[i][r] : x[i + 1][r];
+                    c[r] = v[i][r];
+                    c[4 + r] = g < 3 ? x[i][r] : x[i + 1][r];
+                }
+                if (POOL == 5) {                                           // shared partial maxima: 7 v_max / v_max3 for the four windows
+                    const float t = fmaxf(c[3], c[4]), u = fmaxf(c[1], c[2]), q = fmaxf(c[5], c[6]);
+                    m[0] = fmaxf(fmaxf(c[0], u), t);
+                    m[1] = fmaxf(fmaxf(u, t), c[5]);
+                    m[2] = fmaxf(fmaxf(c[2], t), q);
+                    m[3] = fmaxf(fmaxf(t, q), c[7]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        m[r] = c[r];
+#pragma unroll
+                        for (int q = 1; q < 5; ++q) m[r] = q < P ? fmaxf(m[r], c[r + q]) : m[r];
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float m = cat[r];
-#pragma unroll
-                    for (int q = 1; q < 5; ++q) m = q < P ? fmaxf(m, cat[r + q]) : m;
-                    const fp16x2_t h1 = __builtin_amdgcn_cvt_pkrtz(m, 0.f);
-                    const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz((m - (float)h1[0]) * 2048.0f, 0.f);
+                    const fp16x2_t h1 = __builtin_amdgcn_cvt_pkrtz(m[r], 0.f);
+                    const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz((m[r] - (float)h1[0]) * 2048.0f, 0.f);
                     const int row = 16 * i + 4 * g + r;
                     dst[row * 8] = __builtin_bit_cast(unsigned, h1) & 0xFFFFu;
                     dst[DF_S2 * 4 * KG + row * 8] = __builtin_bit_cast(unsigned, h2) & 0xFFFFu;
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         const int sn_ = (S) + 1 < DF_S2 ? (S) + 1 : DF_S2 - 1;                            \
         const _Float16* wn_ = wp2 + (int64_t)sn_ * WSTEP;                                 \
         const unsigned short* pn_ = Pp + sn_ * 4 * KG + foff;                             \
-        _Pragma("unroll") for (int n_ = 0; n_ < 15 * RT; ++n_) {                          \
+        _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 15 * RT; ++n_) {                          \
             df_mma_n<RT>(n_, acc, acx, AFC, WC);                                          \
             if (n_ == 8) { DF_KEEP_HEAD(WN, AFN) }                                        \
             if (n_ % 6 == 2 && n_ / 6 < 2 * DF_CT)                                        \
@@ -365,13 +383,13 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
 #pragma unroll
         for (int j = 0; j < DF_CT; ++j) {
             const int col = 80 * wave + 16 * j + c16;
-            const float bias = col < p.NF ? p.b2[col] : 0.f;
+            const float biasz = (col < p.NF ? p.b2[col] : 0.f) * DF_2LOG2E;
             float sum = 0.f, sum1 = 0.f;
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float d2 = fast_tanh(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]) + bias);
+                    const float d2 = df_tanh_z(fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), DF_2LOG2E, biasz));
                     sum = fmaf(wrow[i][r], d2, sum);
                     sum1 = fmaf(w1row[i][r], d2, sum1);
                 }
@@ -442,10 +460,14 @@ int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int
     duet_doc_tiling(M, DL, P, &a, &tiles);
     constexpr size_t lds = DfLayout<DF_RT>::LDS;
     static std::once_flag once;
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)duet_doc_kernel<DF_RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)duet_doc_kernel<DF_RT, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)duet_doc_kernel<DF_RT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
     {
         ProfScope ps(prof_shape_name("duet_doc_kernel", tiles * DF_ROWS, NF, 3 * E), st);
-        hipLaunchKernelGGL(duet_doc_kernel<DF_RT>, dim3((unsigned)tiles), dim3(256), lds, st, a);
+        if (P == 5) hipLaunchKernelGGL((duet_doc_kernel<DF_RT, 5>), dim3((unsigned)tiles), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((duet_doc_kernel<DF_RT, 0>), dim3((unsigned)tiles), dim3(256), lds, st, a);
     }
     NIR_CHECK_LAUNCH("duet_doc_kernel");
     {
