@@ -77,7 +77,7 @@ CONFIGS = {
                          baseline="configs[4] shape on one GPU: CARS, 50 candidates/query, bf16 folded tables + bf16 MFMA recurrence"),
 }
 HEADLINE = "C3_cars"
-SUB_STEPS = {"C1_esm": 400, "C2_match_tensor": 400, "NS_match_tensor_50": 200, "C4_duet": 12, "C4_drmm": 60, "C4_esm_hbm": 60,
+SUB_STEPS = {"C1_esm": 400, "C2_match_tensor": 400, "NS_match_tensor_50": 200, "C4_duet": 24, "C4_drmm": 60, "C4_esm_hbm": 60,
              "C5_cars_bf16": 24}
 
 
@@ -106,6 +106,12 @@ def kernel_work(name, c):
         gathered = "[gather]" in base
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),
                     peak=PEAK_BF16_TFLOPS / 3.0)
+    if base.startswith("duet_doc_kernel"):
+        # fused DUET document branch (csrc/duet_fused.hip): the algorithmic work of the pairs it covers -- conv_d1 (K = 3E) and conv_d2
+        # (K = NF) per pooled position -- not the padded tile work in the label (M = tiles x 64 rows, N = NF, K = 3E); bytes: the
+        # embedding rows once plus ids; arithmetic: fp16 two-term split, 3 MFMAs per product block
+        Tc, Tp = DL - 2, DL - 6
+        return dict(flops=pairs * 2.0 * N * (Tc * K + Tp * N), bytes=pairs * DL * (4.0 * E + 8), peak=PEAK_BF16_TFLOPS / 3.0)
     if base.startswith("gemm3_kernel"):
         gathered = "[gather]" in base
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[RT][r] = x[RT - 1][r];           // rows past the tile: the last P-1 pooled rows are never used
-            const int sk = col >> 5, kg = (col >> 3) & 3, e = col & 7;
+            const int sk = col >> 5, kg = (col >> 3) & 3, e = col & 6, odd = col & 1;
             unsigned short* dst = Pp + (sk * 4 + kg) * KG + e;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
@@ -308,13 +308,19 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
                         for (int q = 1; q < 5; ++q) m[r] = q < P ? fmaxf(m[r], c[r + q]) : m[r];
                     }
                 }
+                // Two neighbouring columns share a dword of a P plane: the even lane stores rows r = 0, 2 of the pair, the odd lane rows
+                // 1, 3 (values swapped through DPP quad_perm [1,0,3,2]) -- 4-byte stores instead of twice as many 2-byte ones, which
+                // collided on LDS banks (SQ_LDS_BANK_CONFLICT was 10 % of the kernel's cycles).
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const fp16x2_t h1 = __builtin_amdgcn_cvt_pkrtz(m[r], 0.f);
-                    const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz((m[r] - (float)h1[0]) * 2048.0f, 0.f);
-                    const int row = 16 * i + 4 * g + r;
-                    dst[row * 8] = __builtin_bit_cast(unsigned, h1) & 0xFFFFu;
-                    dst[DF_S2 * 4 * KG + row * 8] = __builtin_bit_cast(unsigned, h2) & 0xFFFFu;
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float mine = odd ? m[2 * hh + 1] : m[2 * hh], give = odd ? m[2 * hh] : m[2 * hh + 1];
+                    const float got = dpp_mov<0xB1>(give);
+                    const float lo = odd ? got : mine, hi = odd ? mine : got;
+                    const fp16x2_t h1 = __builtin_amdgcn_cvt_pkrtz(lo, hi);
+                    const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz((lo - (float)h1[0]) * 2048.0f, (hi - (float)h1[1]) * 2048.0f);
+                    const int row = 16 * i + 4 * g + 2 * hh + odd;
+                    *reinterpret_cast<unsigned*>(dst + row * 8) = __builtin_bit_cast(unsigned, h1);
+                    *reinterpret_cast<unsigned*>(dst + DF_S2 * 4 * KG + row * 8) = __builtin_bit_cast(unsigned, h2);
                 }
             }
         }
