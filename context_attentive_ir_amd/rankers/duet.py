@@ -3,9 +3,11 @@
 local model       : exact-match matrix x Conv1d(k=1, channels = doc positions) -> tanh -> fc1..fc3
 distributed model : Conv1d(E->300,k=3)+tanh on q and d, pools, 1x1 conv, Hadamard with the query vector,
                     Linear over positions, two more Linear+tanh.
-One C-ABI call (nir_duet_score).  Both convolutions run as fp32-MFMA GEMMs with the embedding gather fused
-into the A operand (K = 3*E, conv weights re-laid-out [NF][3][E] once at pack time); the exact-match
-"convolution" is evaluated sparsely (only matching (doc,query) positions add a weight row).
+One C-ABI call (nir_duet_score).  The document branch of the distributed model (conv_d1 -> tanh -> max-pool -> conv_d2 -> tanh
+-> Hadamard . fc2) is ONE fused kernel per tile of 64 conv positions (csrc/duet_fused.hip: embedding rows are the only HBM
+input, conv weights arrive as fp16 term planes in MFMA-fragment order built once per weight version below); the query side and
+the general fallback run as GEMMs with the embedding gather fused into the A operand; the exact-match "convolution" is
+evaluated sparsely (only matching (doc,query) positions add a weight row).
 Like the reference (hyparam.py:34-46 `force_pad`), inputs must be padded to max_query_len / max_doc_len.
 """
 import torch
