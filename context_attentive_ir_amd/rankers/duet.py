@@ -90,15 +90,15 @@ class DUET(nn.Module, lib.IdCheck):
             if mx < 32768.0 and self.fuse_document_branch and NF <= 320 and NF % 4 == 0 and E % 4 == 0 and self._dims["pool"] <= 5:
                 # operands of the fused document-branch kernel (csrc/duet_fused.hip): conv_d1 / conv_d2 zero-padded to 320 filter rows and
                 # a multiple of 32 in k, split into two fp16 terms and re-ordered into MFMA fragments, once per weight version
-                def fragments(w2d):
+                def fragments(w2d, kp=None):
                     rows, k = w2d.shape
-                    kp = (k + 31) // 32 * 32
+                    kp = (k + 31) // 32 * 32 if kp is None else kp
                     pad = torch.zeros(320, kp, device=w2d.device, dtype=torch.float32)
                     pad[:rows, :k] = w2d
                     planes = torch.stack(lib.split_f16x2(pad, kp))                      # [2 terms, 320, kp] int16
                     return planes.view(2, 20, 16, kp // 32, 4, 8).permute(3, 1, 0, 4, 2, 5).contiguous(), kp
                 pk.keep["fw1"], k1p = fragments(pk.keep["convd1_w"].reshape(NF, 3 * E))
-                pk.keep["fw2"], _ = fragments(pk.keep["convd2_w"].reshape(NF, NF))
+                pk.keep["fw2"], _ = fragments(pk.keep["convd2_w"].reshape(NF, NF), 320)   # GEMM 2 always runs its 10 k-steps
                 pk.struct.fw1, pk.struct.fw2, pk.struct.K1P = pk.keep["fw1"].data_ptr(), pk.keep["fw2"].data_ptr(), k1p
             EP = (max(E, NF) + 7) // 8 * 8
             if mx < 32768.0 and self.presplit_operands and EP <= NF + 8 and EP - E < 8:

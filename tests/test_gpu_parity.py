@@ -798,3 +798,19 @@ def test_duet_fused_document_branch_matches_layer_chain(B, N, QL, DL, pool):
     _close(s, s0, 5e-6)
     if pool == 5:
         _close(dist, O.duet_distributed(cpu_state_dict(m), q, d))
+
+
+@pytest.mark.parametrize("E,NF,DL,pool", [(52, 128, 150, 4), (100, 320, 97, 5), (300, 60, 200, 2), (64, 300, 290, 5)])
+def test_duet_fused_other_widths(E, NF, DL, pool):
+    """Fused document branch away from the reference's 300/300/5: embedding width (k tail of conv_d1: 3E not a multiple of 32),
+    filter count (masked columns, 320 = no padding), window, flattened and per-document tilings -- against the layer chain."""
+    from context_attentive_ir_amd import lib
+    V, B, N, QL = 400, 2, 3, 4
+    m = build_model("DUET", vocab=V, device=DEV, max_query_len=QL, max_doc_len=DL, pool_size=pool, emsize=E, nfilters=NF)
+    rng = np.random.default_rng(E + NF)
+    q, ql, d, dl = (t.to(DEV) for t in _synth(rng, B, N, QL, DL, V))
+    assert m._weights().struct.fw1 and m._weights().struct.K1P == (3 * E + 31) // 32 * 32
+    dist = m(q, ql, d, dl, return_parts=True)[2]
+    with lib.tunable("duet_unfused", 1, 0):
+        dist0 = m(q, ql, d, dl, return_parts=True)[2]
+    _close(dist, dist0, 5e-6)
