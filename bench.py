@@ -112,6 +112,10 @@ def kernel_work(name, c):
         # embedding rows once plus ids; arithmetic: fp16 two-term split, 3 MFMAs per product block
         Tc, Tp = DL - 2, DL - 6
         return dict(flops=pairs * 2.0 * N * (Tc * K + Tp * N), bytes=pairs * DL * (4.0 * E + 8), peak=PEAK_BF16_TFLOPS / 3.0)
+    if base.startswith("attn_pool_fused_kernel"):
+        # fused attention pooling (csrc/cars_attn.hip): M rows of D = N = K = 256: the attention MLP GEMM + row dot, softmax and the
+        # weighted sum; bytes: the encoder output read once (the second read for the weighted sum is served by L2) + pooled rows
+        return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=4.0 * M * K + 4.0 * N * K, peak=PEAK_BF16_TFLOPS / 3.0)
     if base.startswith("gemm3_kernel"):
         gathered = "[gather]" in base
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),

@@ -1,0 +1,249 @@
+// CARS.apply_pooling fused (neuroir/multitask/cars.py:671-691 with the {q,d}_attn MLP of :200-223 / :238-258):
+//     logits = Linear(D,1)(tanh(Linear(D,D)(h)))  ->  masked softmax over the sequence  ->  pooled = sum_t p_t h_t
+// for D = 2H = 256.  The layer chain ran this as a split-precision GEMM with a tanh + row-dot epilogue (gemm3h_kernel, 79 us at C3,
+// logit partials to HBM) plus a pooling kernel that read the encoder output a second time (23 us).  Here one workgroup owns 64
+// consecutive rows of the flattened (sequence, step) axis = 64 / T whole sequences and touches the encoder output once:
+//   rows -> split into two fp16 terms, LDS planes in MFMA-fragment order (read again from L2 as fp32 for the weighted sum)
+//   GEMM D1[64, 256] = h W0^T with W0 as pre-split fragment-ordered planes streamed L2 -> VGPR (every wave owns 64 columns); the
+//        k-loop is written MFMA by MFMA with the loads pinned between them, as in duet_fused.hip (same operand keep-alive fences
+//        against the VALU-after-MFMA WAR hazard of inline-assembly MFMAs)
+//   tanh, times w3, summed over the wave's columns (in-lane + DPP over the 16 lanes of a row group), the four waves' partials meet in
+//        LDS; softmax over each sequence's valid steps; the weighted sum of the fp32 rows is reduced over the waves through LDS.
+// Requires D == 256, T in {4, 8, 16, 32, 64}, |W0| < 2^15 (encoder outputs are o * tanh(c), inside (-1, 1)).
+#include <mutex>
+#include "common.hpp"
+
+namespace nir {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AP_D = 256;                   // 2H
+constexpr int AP_ROWS = 64, AP_RT = 4, AP_CT = 4, AP_S = AP_D / 32;
+constexpr int AP_KG = AP_ROWS * 8 + 32;     // halves per k-group block [row][8] (+64 B)
+constexpr int AP_PLANE_HALVES = 2 * AP_S * 4 * AP_KG;            // [2 terms][8 k-steps][4 k-groups][KG]
+constexpr int AP_RED_FLOATS = 4 * 16 * AP_D;                     // weighted-sum partials [4 waves][<= 16 sequences][256] (overlays the planes)
+constexpr size_t AP_LDS = (size_t)(AP_PLANE_HALVES * 2 > AP_RED_FLOATS * 4 ? AP_PLANE_HALVES * 2 : AP_RED_FLOATS * 4) + (4 * 64 + 64) * 4;
+
+#define AP_MMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(W))
+#define AP_MMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+
+__device__ __forceinline__ void ap_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32x4 (&acx)[AP_CT][AP_RT], const f16x8 (&af)[AP_RT][2],
+                                         const f16x8 (&w)[AP_CT][2]) {
+    const int j = n / (3 * AP_RT), ph = (n / AP_RT) % 3, i = n % AP_RT;
+    if (ph == 0) AP_MMA(acx[j][i], af[i][1], w[j][0]);
+    else if (ph == 1) AP_MMA(acx[j][i], af[i][0], w[j][1]);
+    else AP_MMA(acc[j][i], af[i][0], w[j][0]);
+}
+
+struct AttnPoolArgs {
+    const float* h;             // [M*T, 256] encoder output
+    const _Float16* wf;         // W0 fragments [8 k-steps][16 col tiles][2 terms][64 lanes][8]
+    const float *b0, *w3, *b3;  // [256], [256], [1]
+    const int64_t* lens;        // [M] or null
+    float* pooled;              // [M, 256]
+    int64_t M;
+    int T, logT;
+};
+
+__global__ __launch_bounds__(256, 1) void attn_pool_fused_kernel(AttnPoolArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short asm_[];
+    unsigned short* Pp = asm_;                                                   // term planes, later the weighted-sum partials
+    float* rowpart = reinterpret_cast<float*>(asm_ + (AP_LDS - (4 * 64 + 64) * 4) / 2);   // [4 waves][64 rows]
+    float* prob = rowpart + 4 * 64;                                              // [64 rows]
+    constexpr int KG = AP_KG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int T = p.T;
+    const int64_t row0 = (int64_t)blockIdx.x * AP_ROWS, nrows = p.M * T;
+
+    // ---- the tile's rows: thread (wave, lane) handles columns 4 lane .. 4 lane + 3 of rows wave + 4 j (coalesced 1 KB per wave and row):
+    // split into the two fp16 terms (x = h1 + 2^-11 h2') and stored in fragment order [term][k-step][k-group][row][8].  Rows past the
+    // end belong to sequences that are never written: clamped, not predicated (a predicated load is a branch per load).
+    const _Float16* wp = p.wf + ((int64_t)(AP_CT * wave) * 2 * 64 + lane) * 8;
+    constexpr int WSTEP = 16 * 2 * 64 * 8;
+    f16x8 w[AP_CT][2], wb[AP_CT][2], afa[AP_RT][2], afb[AP_RT][2];
+    {
+        float4 hv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int64_t r = row0 + wave + 4 * j;
+            r = r < nrows ? r : nrows - 1;
+            hv[j] = *reinterpret_cast<const float4*>(p.h + r * AP_D + 4 * lane);
+        }
+#pragma unroll
+        for (int j = 0; j < AP_CT; ++j) {
+            w[j][0] = *reinterpret_cast<const f16x8*>(wp + (j * 2) * 512);
+            w[j][1] = *reinterpret_cast<const f16x8*>(wp + (j * 2 + 1) * 512);
+        }
+        const int k = 4 * lane, sk = k >> 5, kg = (k >> 3) & 3, e0 = k & 7;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 v = hv[j];
+            const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+            const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz((v.x - (float)a01[0]) * 2048.0f, (v.y - (float)a01[1]) * 2048.0f);
+            const fp16x2_t b23 = __builtin_amdgcn_cvt_pkrtz((v.z - (float)a23[0]) * 2048.0f, (v.w - (float)a23[1]) * 2048.0f);
+            unsigned short* d = Pp + (sk * 4 + kg) * KG + (wave + 4 * j) * 8 + e0;
+            *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
+            *reinterpret_cast<uint2*>(d + AP_S * 4 * KG) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+        }
+    }
+    f32x4 acc[AP_CT][AP_RT], acx[AP_CT][AP_RT];
+#pragma unroll
+    for (int j = 0; j < AP_CT; ++j)
+#pragma unroll
+        for (int i = 0; i < AP_RT; ++i) {
+            acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    __syncthreads();
+    const int foff = g * KG + c16 * 8;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < AP_RT; ++i) afa[i][t] = *reinterpret_cast<const f16x8*>(Pp + t * AP_S * 4 * KG + foff + i * 128);
+
+    // ================= D1 = h W0^T (A planes static in LDS: no barriers) =================
+    // Two fragment register sets, every k-step written MFMA by MFMA with the next step's loads pinned between them, operand
+    // keep-alive fences against the VALU-after-MFMA WAR hazard of the inline-assembly MFMAs: see duet_fused.hip.  (A variant with one
+    // set and two workgroups per CU -- 128 + 128 registers -- was slower: 77 us against 62 us at C3.)
+#define AP_KEEP_HEAD(WN, AFN)                                                             \
+    _Pragma("unroll") for (int j_ = AP_CT - 2; j_ < AP_CT; ++j_) asm volatile("" ::"v"(WN[j_][0]), "v"(WN[j_][1])); \
+    _Pragma("unroll") for (int i_ = 0; i_ < AP_RT; ++i_) asm volatile("" ::"v"(AFN[i_][0]), "v"(AFN[i_][1]));
+#define AP_KEEP(WC, AFC)                                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < AP_CT; ++j_) asm volatile("" ::"v"(WC[j_][0]), "v"(WC[j_][1]));   \
+    _Pragma("unroll") for (int i_ = 0; i_ < AP_RT; ++i_) asm volatile("" ::"v"(AFC[i_][0]), "v"(AFC[i_][1]));
+#define AP_STEP(S, AFC, AFN, WC, WN)                                                      \
+    {                                                                                     \
+        const int sn_ = (S) + 1 < AP_S ? (S) + 1 : AP_S - 1;                              \
+        const _Float16* wn_ = wp + (int64_t)sn_ * WSTEP;                                  \
+        const unsigned short* pn_ = Pp + sn_ * 4 * KG + foff;                             \
+        _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 3 * AP_RT * AP_CT; ++n_) { \
+            ap_mma_n(n_, acc, acx, AFC, WC);                                              \
+            if (n_ == 8) { AP_KEEP_HEAD(WN, AFN) }                                        \
+            if (n_ % 6 == 2 && n_ / 6 < 2 * AP_CT)                                        \
+                WN[(n_ / 6) >> 1][(n_ / 6) & 1] = *reinterpret_cast<const f16x8*>(wn_ + (n_ / 6) * 512); \
+            if (n_ >= 9 && (n_ - 9) % 5 == 0 && (n_ - 9) / 5 < 2 * AP_RT)                 \
+                AFN[((n_ - 9) / 5) % AP_RT][((n_ - 9) / 5) / AP_RT] =                     \
+                    *reinterpret_cast<const f16x8*>(pn_ + (((n_ - 9) / 5) / AP_RT) * AP_S * 4 * KG + (((n_ - 9) / 5) % AP_RT) * 128); \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+        AP_KEEP(WC, AFC)                                                                  \
+    }
+#pragma unroll 1
+    for (int s = 0; s < AP_S; s += 2) {
+        AP_STEP(s, afa, afb, w, wb)
+        AP_STEP(s + 1, afb, afa, wb, w)
+    }
+    AP_MMA_DRAIN();
+    // the fp32 rows again for the weighted sum (L2 hits; holding them across the k-loop cost 64 VGPRs and pushed fragments into AGPR
+    // spills): issued here, consumed after the softmax
+    float4 hv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int64_t r = row0 + wave + 4 * j;
+        r = r < nrows ? r : nrows - 1;
+        hv[j] = *reinterpret_cast<const float4*>(p.h + r * AP_D + 4 * lane);
+    }
+
+    // ================= logits: tanh, times w3, summed over the columns =================
+    {
+        constexpr float C2 = 2.8853900817779268f;          // 2 log2(e): tanh(x) = 1 - 2 / (1 + 2^(C2 x))
+        float rs[AP_RT][4];
+#pragma unroll
+        for (int i = 0; i < AP_RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs[i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < AP_CT; ++j) {
+            const int col = 64 * wave + 16 * j + c16;
+            const float bz = p.b0[col] * C2, w3c = p.w3[col];
+#pragma unroll
+            for (int i = 0; i < AP_RT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), C2, bz);
+                    const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), 1.0f);
+                    rs[i][r] = fmaf(w3c, th, rs[i][r]);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < AP_RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                  // sum over the 16 lanes (columns) of the row group
+                float v = rs[i][r];
+                v += dpp_mov<0xB1>(v);
+                v += dpp_mov<0x4E>(v);
+                v += dpp_mov<0x141>(v);
+                v += dpp_mov<0x140>(v);
+                if (c16 == 0) rowpart[wave * 64 + 16 * i + 4 * g + r] = v;
+            }
+    }
+    __syncthreads();
+    // ================= masked softmax over each sequence (wave 0: lane = row of the tile) =================
+    if (wave == 0) {
+        const int64_t r = row0 + lane;
+        const int64_t seq = r / T;
+        const int t = (int)(r - seq * T);
+        int len = T;
+        if (p.lens && seq < p.M) len = (int)p.lens[seq];
+        len = len < 0 ? 0 : (len > T ? T : len);
+        const bool ok = seq < p.M && t < len;
+        const float lg = (rowpart[lane] + rowpart[64 + lane]) + (rowpart[128 + lane] + rowpart[192 + lane]) + p.b3[0];
+        float mx = ok ? lg : -INFINITY;
+        for (int o = 1; o < T; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));       // T is a power of two: groups of T lanes
+        const float e = ok ? __expf(lg - mx) : 0.f;
+        float den = e;
+        for (int o = 1; o < T; o <<= 1) den += __shfl_xor(den, o);
+        prob[lane] = e / den;                              // len == 0: 0/0 = NaN, like softmax over an all -inf row
+    }
+    __syncthreads();
+    // ================= pooled = sum_t p_t h_t =================
+    {
+        float4* red = reinterpret_cast<float4*>(Pp);       // [4 waves][RS sequences][64 float4]  (the planes are dead)
+        const int RS = AP_ROWS / T, per = T / 4;           // rows of one sequence held by this thread (rows wave + 4 j): T / 4
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {                     // row wave + 4 j belongs to sequence j / per of the tile
+            const float pr = prob[wave + 4 * j];
+            a.x = fmaf(pr, hv[j].x, a.x); a.y = fmaf(pr, hv[j].y, a.y); a.z = fmaf(pr, hv[j].z, a.z); a.w = fmaf(pr, hv[j].w, a.w);
+            if ((j + 1) % per == 0) {                      // last row of its sequence held by this thread
+                red[(wave * RS + j / per) * 64 + lane] = a;
+                a = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < RS * 64; idx += 256) {
+            const int q = idx >> 6, c = idx & 63;
+            const int64_t seq = row0 / T + q;
+            if (seq < p.M) {
+                const float4 a0 = red[(0 * RS + q) * 64 + c], a1 = red[(1 * RS + q) * 64 + c], a2 = red[(2 * RS + q) * 64 + c],
+                             a3 = red[(3 * RS + q) * 64 + c];
+                float4 o;
+                o.x = (a0.x + a1.x) + (a2.x + a3.x); o.y = (a0.y + a1.y) + (a2.y + a3.y);
+                o.z = (a0.z + a1.z) + (a2.z + a3.z); o.w = (a0.w + a1.w) + (a2.w + a3.w);
+                *reinterpret_cast<float4*>(p.pooled + seq * AP_D + 4 * c) = o;
+            }
+        }
+    }
+}
+
+bool attn_pool_fused_usable(int D, int T) { return D == AP_D && (T == 4 || T == 8 || T == 16 || T == 32 || T == 64); }
+
+int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, const float* w3, const float* b3, const int64_t* lens, int64_t M,
+                           int T, float* pooled, hipStream_t st) {
+    NIR_REQUIRE(h && wfrag && b0 && w3 && b3 && pooled && attn_pool_fused_usable(AP_D, T), "attn_pool_fused: bad args (T=%d)", T);
+    if (M == 0) return 0;
+    AttnPoolArgs a;
+    a.h = h; a.wf = (const _Float16*)wfrag; a.b0 = b0; a.w3 = w3; a.b3 = b3; a.lens = lens; a.pooled = pooled; a.M = M; a.T = T; a.logT = 0;
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)attn_pool_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS); });
+    const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
+    ProfScope ps(prof_shape_name("attn_pool_fused_kernel", M * T, AP_D, AP_D), st);
+    hipLaunchKernelGGL(attn_pool_fused_kernel, dim3((unsigned)tiles), dim3(256), AP_LDS, st, a);
+    NIR_CHECK_LAUNCH("attn_pool_fused_kernel");
+    return 0;
+}
+
+}  // namespace nir

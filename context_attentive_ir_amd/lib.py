@@ -41,6 +41,7 @@ DuetWeights = type("nir_duet_weights", (C.Structure,), {"_fields_": list(DuetWei
 CarsEncoderWeights = _struct(
     "nir_cars_encoder_weights",
     ["wih", "whh", "bih", "bhh", "attn0_w", "attn0_b", "attn3_w", "attn3_b"], ["H", "bounded"])
+CarsEncoderWeights = type("nir_cars_encoder_weights", (C.Structure,), {"_fields_": list(CarsEncoderWeights._fields_) + [("attn_frag", C.c_void_p)]})
 CarsSessionWeights = _struct(
     "nir_cars_session_weights",
     ["click0_w", "click0_b", "click3_w", "click3_b", "sq_attn_w", "sq_attn_b", "sd_attn_w", "sd_attn_b",

@@ -120,6 +120,7 @@ class CARS(nn.Module, lib.IdCheck):
         # mode while the two folded tables (V x 8H each) stay under `fold_budget_bytes`; `compute_dtype` "bf16" selects the
         # bf16 folded table + bf16 MFMA recurrence (BASELINE config 5), "f32" is the parity path.
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
+        self.fuse_attention_pooling = True   # attention MLP + masked softmax + weighted sum as one kernel (csrc/cars_attn.hip)
         self.fold_budget_bytes = 64 << 30
         self.compute_dtype = getattr(args, "compute_dtype", "f32")
         self._fq, self._fd = lib.PackCache(), lib.PackCache()
@@ -133,10 +134,18 @@ class CARS(nn.Module, lib.IdCheck):
 
         def build():
             wih, whh, bih, bhh = lstm_cat_weights(enc.rnns[0])
-            return lib.Packed(lib.CarsEncoderWeights,
-                              dict(wih=wih, whh=whh, bih=bih, bhh=bhh, attn0_w=attn[0].weight, attn0_b=attn[0].bias,
-                                   attn3_w=attn[3].weight, attn3_b=attn[3].bias),
-                              dict(H=enc.hidden, bounded=int(float(attn[0].weight.detach().abs().max()) < 32768.0)))
+            bounded = float(attn[0].weight.detach().abs().max()) < 32768.0
+            pk = lib.Packed(lib.CarsEncoderWeights,
+                            dict(wih=wih, whh=whh, bih=bih, bhh=bhh, attn0_w=attn[0].weight, attn0_b=attn[0].bias,
+                                 attn3_w=attn[3].weight, attn3_b=attn[3].bias),
+                            dict(H=enc.hidden, bounded=int(bounded)))
+            if bounded and 2 * enc.hidden == 256 and self.fuse_attention_pooling and attn[0].weight.is_cuda:
+                # operand of the fused attention-pooling kernel (csrc/cars_attn.hip): attn0_w as two fp16 term planes in MFMA-fragment
+                # order [K/32][16 column tiles][2 terms][64 lanes][8], built once per weight version
+                planes = torch.stack(lib.split_f16x2(pk.keep["attn0_w"], 256))                 # [2, 256, 256] int16
+                pk.keep["attn_frag"] = planes.view(2, 16, 16, 8, 4, 8).permute(3, 1, 0, 4, 2, 5).contiguous()
+                pk.struct.attn_frag = pk.keep["attn_frag"].data_ptr()
+            return pk
         return cache.get(list(enc.parameters()) + list(attn.parameters()), build)
 
     def _session_modules(self):

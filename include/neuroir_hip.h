@@ -245,6 +245,10 @@ typedef struct {
     int H;                               /* 128 per direction */
     int bounded;                         /* host-checked: every attention weight is < 2^15 in magnitude (the encoder outputs are in
                                             (-1,1) by construction) -> the attention GEMM may use the fp16 two-term split */
+    const void* attn_frag;               /* optional (NULL: GEMM + pooling kernels): attn0_w [2H,2H] with 2H = 256 split into two fp16 terms
+                                            (nir_split_f16x2) in MFMA-fragment order [K/32][16 column tiles][2 terms][64 lanes][8], lane =
+                                            16*(k%32/8) + column%16 -- operand of the fused attention-pooling kernel (csrc/cars_attn.hip),
+                                            used when `bounded` and T is 4, 8, 16, 32 or 64 */
 } nir_cars_encoder_weights;
 size_t nir_cars_encode_workspace_bytes(int64_t M, int T, int E, const nir_cars_encoder_weights* w /*host*/);
 /* CARS.encode / CARS.encode_document (cars.py:193-260): ids [M,T], lens [M] -> pooled [M,2H];

@@ -155,3 +155,25 @@ def test_cars_bf16_scores_and_map(B, S, N, QL, DL):
     map_ref = ltorank.MAP(np.argsort(-r_ref, 1), lab)
     map_got = ltorank.MAP(np.argsort(-r_got, 1), lab)
     assert abs(map_ref - map_got) <= 0.02, (map_ref, map_got)
+
+
+@pytest.mark.parametrize("S,N,QL,DL", [(3, 5, 4, 64), (2, 7, 8, 16), (4, 3, 16, 32), (1, 2, 4, 4)])
+def test_fused_attention_pooling_matches_layer_chain_and_oracle(S, N, QL, DL):
+    """The fused attention-pooling kernel (csrc/cars_attn.hip; sequence lengths 4 / 8 / 16 / 32 / 64 rows per tile, ragged lengths,
+    a partial last tile) against the GEMM + pooling chain (tunable attn_unfused) and the oracle's CARS.encode / encode_document."""
+    from context_attentive_ir_amd import lib, synth
+    V, B = 2000, 3
+    m = build_model("CARS", vocab=V, device=DEV)
+    ex = synth.session_batch(B, S, N, QL, DL, V, seed=QL + DL, full_length=False)
+    exd = {k: v.to(DEV) for k, v in ex.items()}
+    assert m._enc_weights("d").struct.attn_frag and m._enc_weights("q").struct.attn_frag
+    p1, e1, _ = m.encode(exd["source_words"], exd["source_lens"])
+    d1 = m.encode_document(exd["document_words"], exd["document_lens"])
+    with lib.tunable("attn_unfused", 1, 0):
+        p0, e0, _ = m.encode(exd["source_words"], exd["source_lens"])
+        d0 = m.encode_document(exd["document_words"], exd["document_lens"])
+    _close(p1, p0, 5e-6); _close(d1, d0, 5e-6); _close(e1, e0, 0)
+    sd = cpu_state_dict(m)
+    pq, _ = O.cars_encode(sd, ex["source_words"], ex["source_lens"])
+    _close(p1, pq, 1e-5)
+    _close(d1, O.cars_encode_document(sd, ex["document_words"], ex["document_lens"]), 1e-5)
