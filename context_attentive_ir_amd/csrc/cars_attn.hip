@@ -37,6 +37,26 @@ __device__ __forceinline__ void ap_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32x
     else AP_MMA(acc[j][i], af[i][0], w[j][0]);
 }
 
+// max / sum over aligned groups of T lanes (T a power of two, 4..64): DPP inside 16-lane rows, ds_bpermute only across rows
+__device__ __forceinline__ float ap_group_max(float v, int T) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    if (T >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+    if (T >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+    if (T >= 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if (T >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float ap_group_sum(float v, int T) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    if (T >= 8) v += dpp_mov<0x141>(v);
+    if (T >= 16) v += dpp_mov<0x140>(v);
+    if (T >= 32) v += __shfl_xor(v, 16);
+    if (T >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
 struct AttnPoolArgs {
     const float* h;             // [M*T, 256] encoder output
     const _Float16* wf;         // W0 fragments [8 k-steps][16 col tiles][2 terms][64 lanes][8]
@@ -191,11 +211,9 @@ __global__ __launch_bounds__(256, 1) void attn_pool_fused_kernel(AttnPoolArgs p)
         len = len < 0 ? 0 : (len > T ? T : len);
         const bool ok = seq < p.M && t < len;
         const float lg = (rowpart[lane] + rowpart[64 + lane]) + (rowpart[128 + lane] + rowpart[192 + lane]) + p.b3[0];
-        float mx = ok ? lg : -INFINITY;
-        for (int o = 1; o < T; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));       // T is a power of two: groups of T lanes
+        const float mx = ap_group_max(ok ? lg : -INFINITY, T);
         const float e = ok ? __expf(lg - mx) : 0.f;
-        float den = e;
-        for (int o = 1; o < T; o <<= 1) den += __shfl_xor(den, o);
+        const float den = ap_group_sum(e, T);
         prob[lane] = e / den;                              // len == 0: 0/0 = NaN, like softmax over an all -inf row
     }
     __syncthreads();
@@ -229,6 +247,245 @@ __global__ __launch_bounds__(256, 1) void attn_pool_fused_kernel(AttnPoolArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same computation as a persistent, role-specialised pipeline (many tiles per CU: document encoders).  The single-role kernel
+// above spends ~3 us of an 11 us tile in MFMAs; prologue (row loads, split) and epilogue (softmax, weighted sum) leave the matrix
+// pipe idle and one workgroup per CU cannot overlap them.  Here a workgroup has 8 waves: waves 0-3 (one per SIMD) only run the GEMM
+// and the tanh / row-dot epilogue of tile k, waves 4-7 (one per SIMD) meanwhile finish tile k-1 (softmax, weighted sum, store) and
+// stage tile k+1 (load, split, store planes) -- two plane buffers, one barrier per tile:
+//     iteration it:   MMA waves: G(it-1)  reads planes[(it-1)&1], writes rowpart[(it-1)&1]
+//                     IO waves : S(it-2)  reads rowpart[it&1];   L(it) writes planes[it&1]
+// Register budget 256 per lane (2 waves per SIMD): MMA waves 128 accumulator AGPRs + W fragments (two sets, the next k-step's loads
+// spread behind the MFMAs) + ONE A-fragment set whose row tile i is re-read for the next k-step 7+ MFMA slots after its last use;
+// MFMA order is row tile outermost.  IO waves work in halves of 8 rows (32 registers per half).  The IO waves never synchronise among
+// themselves: each computes the 64-row softmax redundantly (lane = row) and owns 64 of the 256 output columns.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef AP_TIMING
+__device__ long long ap_dbg[16];
+#define AP_T(I) if (blockIdx.x == 7 && lane == 0 && it == 5) ap_dbg[I] = __builtin_readcyclecounter();
+#else
+#define AP_T(I)
+#endif
+constexpr size_t AP2_LDS = (size_t)2 * AP_PLANE_HALVES * 2 + (2 * 4 * 64 + 4 * 64) * 4;
+
+__device__ __forceinline__ void ap2_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32x4 (&acx)[AP_CT][AP_RT], const f16x8 (&af)[AP_RT][2],
+                                          const f16x8 (&w)[AP_CT][2]) {
+    const int i = n / (3 * AP_CT), ph = (n / AP_CT) % 3, j = n % AP_CT;      // row tile outermost
+    if (ph == 0) AP_MMA(acx[j][i], af[i][1], w[j][0]);
+    else if (ph == 1) AP_MMA(acx[j][i], af[i][0], w[j][1]);
+    else AP_MMA(acc[j][i], af[i][0], w[j][0]);
+}
+
+__global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, int64_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short asm2_[];
+    constexpr int KG = AP_KG;
+    float* rowpart = reinterpret_cast<float*>(asm2_ + 2 * AP_PLANE_HALVES);      // [2 buffers][4 waves][64 rows]
+    float* probw = rowpart + 2 * 4 * 64;                                          // [4 IO waves][64 rows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w4 = wave & 3;
+    const bool mma_role = wave < 4;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int T = p.T;
+    const int64_t nrows = p.M * T;
+    const int64_t G = gridDim.x;
+    const int64_t nk = (ntiles - blockIdx.x + G - 1) / G;                         // tiles of this workgroup: blockIdx.x + k G
+
+    if (mma_role) {
+        // ================================================= MMA waves =================================================
+        const _Float16* wp = p.wf + ((int64_t)(AP_CT * w4) * 2 * 64 + lane) * 8;
+        constexpr int WSTEP = 16 * 2 * 64 * 8;
+        const int foff = g * KG + c16 * 8;
+        f16x8 wa[AP_CT][2], wb[AP_CT][2], af[AP_RT][2];
+        f32x4 acc[AP_CT][AP_RT], acx[AP_CT][AP_RT];
+#pragma unroll
+        for (int j = 0; j < AP_CT; ++j) {
+            wa[j][0] = *reinterpret_cast<const f16x8*>(wp + (j * 2) * 512);
+            wa[j][1] = *reinterpret_cast<const f16x8*>(wp + (j * 2 + 1) * 512);
+        }
+        for (int64_t it = 0; it < nk + 2; ++it) {
+            if (w4 == 0) { AP_T(0) }
+            if (it >= 1 && it <= nk) {
+                const unsigned short* Pp = asm2_ + ((it - 1) & 1) * AP_PLANE_HALVES;
+                float* rp = rowpart + ((it - 1) & 1) * 4 * 64;
+#pragma unroll
+                for (int j = 0; j < AP_CT; ++j)
+#pragma unroll
+                    for (int i = 0; i < AP_RT; ++i) {
+                        acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                for (int i = 0; i < AP_RT - 1; ++i) {      // row tile 3 of a k-step is read at MFMAs 7, 8 of that step
+                    af[i][0] = *reinterpret_cast<const f16x8*>(Pp + foff + i * 128);
+                    af[i][1] = *reinterpret_cast<const f16x8*>(Pp + AP_S * 4 * KG + foff + i * 128);
+                }
+                // k-step S with W set WC; WN receives the fragments of step S+1 (after step 7: step 0 again, for the next tile).  A
+                // fragments of row tile i for step S+1 are re-read into af[i] at MFMA 12 i + 19 / + 20 (>= 7 slots after their last use;
+                // row tile 3: MFMAs 7 / 8 of the step itself); the last step reads none -- the next tile's planes are not complete yet.
+#define AP2_STEP(S, WC, WN, LAST)                                                         \
+                {                                                                         \
+                    const int sn_ = ((S) + 1) & (AP_S - 1);                               \
+                    const _Float16* wn_ = wp + (int64_t)sn_ * WSTEP;                      \
+                    const unsigned short* pc_ = Pp + (S) * 4 * KG + foff;                 \
+                    const unsigned short* pn_ = Pp + sn_ * 4 * KG + foff;                 \
+                    _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 3 * AP_RT * AP_CT; ++n_) { \
+                        ap2_mma_n(n_, acc, acx, af, WC);                                  \
+                        if (n_ % 6 == 2 && n_ / 6 < 2 * AP_CT) {                          \
+                            asm volatile("" ::"v"(WN[(n_ / 6) >> 1][(n_ / 6) & 1]));      \
+                            WN[(n_ / 6) >> 1][(n_ / 6) & 1] = *reinterpret_cast<const f16x8*>(wn_ + (n_ / 6) * 512); \
+                        }                                                                 \
+                        if (n_ == 7 || n_ == 8) {                                         \
+                            asm volatile("" ::"v"(af[3][n_ - 7]));                        \
+                            af[3][n_ - 7] = *reinterpret_cast<const f16x8*>(pc_ + (n_ - 7) * AP_S * 4 * KG + 3 * 128); \
+                        }                                                                 \
+                        if (!(LAST) && n_ >= 19 && (n_ - 19) % 12 < 2 && (n_ - 19) / 12 < AP_RT - 1) { \
+                            asm volatile("" ::"v"(af[(n_ - 19) / 12][(n_ - 19) % 12]));   \
+                            af[(n_ - 19) / 12][(n_ - 19) % 12] =                          \
+                                *reinterpret_cast<const f16x8*>(pn_ + ((n_ - 19) % 12) * AP_S * 4 * KG + ((n_ - 19) / 12) * 128); \
+                        }                                                                 \
+                        __builtin_amdgcn_sched_barrier(0);                                \
+                    }                                                                     \
+                    _Pragma("unroll") for (int j_ = 0; j_ < AP_CT; ++j_) asm volatile("" ::"v"(WC[j_][0]), "v"(WC[j_][1])); \
+                    _Pragma("unroll") for (int i_ = 0; i_ < AP_RT; ++i_) asm volatile("" ::"v"(af[i_][0]), "v"(af[i_][1])); \
+                }
+#pragma unroll 1
+                for (int s = 0; s < AP_S - 2; s += 2) {
+                    AP2_STEP(s, wa, wb, 0)
+                    AP2_STEP(s + 1, wb, wa, 0)
+                }
+                AP2_STEP(AP_S - 2, wa, wb, 0)
+                AP2_STEP(AP_S - 1, wb, wa, 1)
+                if (w4 == 0) { AP_T(1) }
+                AP_MMA_DRAIN();
+                {   // logits: tanh, times w3, summed over this wave's 64 columns
+                    constexpr float C2 = 2.8853900817779268f;
+                    float rs[AP_RT][4];
+#pragma unroll
+                    for (int i = 0; i < AP_RT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rs[i][r] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < AP_CT; ++j) {
+                        const int col = 64 * w4 + 16 * j + c16;
+                        const float bz = p.b0[col] * C2, w3c = p.w3[col];
+#pragma unroll
+                        for (int i = 0; i < AP_RT; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float z = fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), C2, bz);
+                                const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), 1.0f);
+                                rs[i][r] = fmaf(w3c, th, rs[i][r]);
+                            }
+                    }
+#pragma unroll
+                    for (int i = 0; i < AP_RT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = rs[i][r];
+                            v += dpp_mov<0xB1>(v);
+                            v += dpp_mov<0x4E>(v);
+                            v += dpp_mov<0x141>(v);
+                            v += dpp_mov<0x140>(v);
+                            if (c16 == 0) rp[w4 * 64 + 16 * i + 4 * g + r] = v;
+                        }
+                }
+            }
+            if (w4 == 0) { AP_T(2) }
+            __syncthreads();
+            if (w4 == 0) { AP_T(3) }
+        }
+    } else {
+        // ================================================== IO waves ==================================================
+        // IO wave w4 owns the COLUMN block [64 w4, 64 w4 + 64) of every tile: lane = (row subgroup lane >> 4, 4 columns 4 (lane & 15) ..),
+        // rows 4 q + subgroup.  It stages that block of tile it into planes[it&1] and later reads only that block back for the weighted
+        // sum, so the IO waves never touch each other's data and need no barrier among themselves.  Iteration it:
+        //   (1) finish tile it-2: softmax from rowpart[it&1] (every IO wave computes all 64 rows, lane = row), weighted sum from that
+        //       tile's own term planes, still in planes[it&1] (h = h1 + 2^-11 h2' to 2^-22: no second read of the encoder output)
+        //   (2) split the rows of tile it -- loaded during the previous iteration -- into planes[it&1]
+        //   (3) issue the loads of tile it+1: in flight across the barrier (64 registers held): no memory latency exposed here
+        float* pw = probw + w4 * 64;
+        const int sub = lane >> 4, per = T / 4;
+        const int col = 64 * w4 + 4 * c16;
+        const int poff = ((col >> 5) * 4 + ((col >> 3) & 3)) * KG + (col & 7);
+        float4 ld[16];
+        auto load_rows = [&](int64_t k) {
+            const int64_t row0 = (blockIdx.x + k * G) * AP_ROWS;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int64_t r = row0 + 4 * q + sub;
+                r = r < nrows ? r : nrows - 1;             // rows past the end belong to sequences that are never written
+                ld[q] = *reinterpret_cast<const float4*>(p.h + r * AP_D + col);
+            }
+        };
+        if (nk > 0) load_rows(0);
+        for (int64_t it = 0; it < nk + 2; ++it) {
+            unsigned short* Pb = asm2_ + (it & 1) * AP_PLANE_HALVES + poff;
+            if (w4 == 0) { AP_T(4) }
+            if (it >= 2) {
+                const int64_t rowS = (blockIdx.x + (it - 2) * G) * AP_ROWS;
+                const float* rp = rowpart + (it & 1) * 4 * 64;
+                {
+                    const int64_t r = rowS + lane;
+                    const int64_t seq = r / T;
+                    const int t = (int)(r - seq * T);
+                    int len = T;
+                    if (p.lens && seq < p.M) len = (int)p.lens[seq];
+                    len = len < 0 ? 0 : (len > T ? T : len);
+                    const bool ok = seq < p.M && t < len;
+                    const float lg = (rp[lane] + rp[64 + lane]) + (rp[128 + lane] + rp[192 + lane]) + p.b3[0];
+                    const float mx = ap_group_max(ok ? lg : -INFINITY, T);
+                    const float e = ok ? __expf(lg - mx) : 0.f;
+                    const float den = ap_group_sum(e, T);
+                    pw[lane] = e / den;                    // len == 0: 0/0 = NaN, like softmax over an all -inf row
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = 4 * q + sub;
+                    const uint2 u1 = *reinterpret_cast<const uint2*>(Pb + row * 8);
+                    const uint2 u2 = *reinterpret_cast<const uint2*>(Pb + AP_S * 4 * KG + row * 8);
+                    const fp16x2_t a01 = __builtin_bit_cast(fp16x2_t, u1.x), a23 = __builtin_bit_cast(fp16x2_t, u1.y);
+                    const fp16x2_t b01 = __builtin_bit_cast(fp16x2_t, u2.x), b23 = __builtin_bit_cast(fp16x2_t, u2.y);
+                    const float pr = pw[row];
+                    a.x = fmaf(pr, fmaf((float)b01[0], 1.0f / 2048.0f, (float)a01[0]), a.x);
+                    a.y = fmaf(pr, fmaf((float)b01[1], 1.0f / 2048.0f, (float)a01[1]), a.y);
+                    a.z = fmaf(pr, fmaf((float)b23[0], 1.0f / 2048.0f, (float)a23[0]), a.z);
+                    a.w = fmaf(pr, fmaf((float)b23[1], 1.0f / 2048.0f, (float)a23[1]), a.w);
+                    if ((q + 1) % per == 0) {              // sequence complete: fold the four row subgroups, subgroup 0 stores
+                        a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
+                        a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+                        const int64_t seq = rowS / T + q / per;
+                        if (sub == 0 && seq < p.M) *reinterpret_cast<float4*>(p.pooled + seq * AP_D + col) = a;
+                        a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+            if (w4 == 0) { AP_T(5) }
+            if (it < nk) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float4 v = ld[q];
+                    const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+                    const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz((v.x - (float)a01[0]) * 2048.0f, (v.y - (float)a01[1]) * 2048.0f);
+                    const fp16x2_t b23 = __builtin_amdgcn_cvt_pkrtz((v.z - (float)a23[0]) * 2048.0f, (v.w - (float)a23[1]) * 2048.0f);
+                    unsigned short* d = Pb + (4 * q + sub) * 8;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
+                    *reinterpret_cast<uint2*>(d + AP_S * 4 * KG) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+                }
+                if (w4 == 0) { AP_T(6) }
+                if (it + 1 < nk) load_rows(it + 1);
+            }
+            if (w4 == 0) { AP_T(7) }
+            __syncthreads();
+        }
+    }
+}
+#ifdef AP_TIMING
+}  // namespace nir
+extern "C" int nir_debug_attn_timing(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(nir::ap_dbg), sizeof(long long) * 16); }
+namespace nir {
+#endif
+
 bool attn_pool_fused_usable(int D, int T) { return D == AP_D && (T == 4 || T == 8 || T == 16 || T == 32 || T == 64); }
 
 int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, const float* w3, const float* b3, const int64_t* lens, int64_t M,
@@ -241,7 +498,20 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)attn_pool_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS); });
     const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
     ProfScope ps(prof_shape_name("attn_pool_fused_kernel", M * T, AP_D, AP_D), st);
-    hipLaunchKernelGGL(attn_pool_fused_kernel, dim3((unsigned)tiles), dim3(256), AP_LDS, st, a);
+    static int ncu = 0;
+    static std::once_flag once2;
+    std::call_once(once2, [] {
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    });
+    if (tiles >= 2 * (int64_t)ncu && !tun(g_tun.attn_unfused_pipe)) {     // several tiles per CU: the role-specialised pipeline
+        hipLaunchKernelGGL(attn_pool_pipe_kernel, dim3((unsigned)ncu), dim3(512), AP2_LDS, st, a, tiles);
+    } else {
+        hipLaunchKernelGGL(attn_pool_fused_kernel, dim3((unsigned)tiles), dim3(256), AP_LDS, st, a);
+    }
     NIR_CHECK_LAUNCH("attn_pool_fused_kernel");
     return 0;
 }
