@@ -10,6 +10,7 @@
 //   tanh, times w3, summed over the wave's columns (in-lane + DPP over the 16 lanes of a row group), the four waves' partials meet in
 //        LDS; softmax over each sequence's valid steps; the weighted sum of the fp32 rows is reduced over the waves through LDS.
 // Requires D == 256, T in {4, 8, 16, 32, 64}, |W0| < 2^15 (encoder outputs are o * tanh(c), inside (-1, 1)).
+#include <algorithm>
 #include <mutex>
 #include "common.hpp"
 
@@ -507,8 +508,9 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
     });
-    if (tiles >= 2 * (int64_t)ncu && !tun(g_tun.attn_unfused_pipe)) {     // several tiles per CU: the role-specialised pipeline
-        hipLaunchKernelGGL(attn_pool_pipe_kernel, dim3((unsigned)ncu), dim3(512), AP2_LDS, st, a, tiles);
+    const int pipe = tun(g_tun.attn_unfused_pipe);     // 0: by size, 1: never, 2: always (tests)
+    if ((tiles >= 2 * (int64_t)ncu && pipe == 0) || pipe == 2) {          // several tiles per CU: the role-specialised pipeline
+        hipLaunchKernelGGL(attn_pool_pipe_kernel, dim3((unsigned)std::min<int64_t>(tiles, ncu)), dim3(512), AP2_LDS, st, a, tiles);
     } else {
         hipLaunchKernelGGL(attn_pool_fused_kernel, dim3((unsigned)tiles), dim3(256), AP_LDS, st, a);
     }

@@ -177,3 +177,20 @@ def test_fused_attention_pooling_matches_layer_chain_and_oracle(S, N, QL, DL):
     pq, _ = O.cars_encode(sd, ex["source_words"], ex["source_lens"])
     _close(p1, pq, 1e-5)
     _close(d1, O.cars_encode_document(sd, ex["document_words"], ex["document_lens"]), 1e-5)
+
+
+@pytest.mark.parametrize("S,N,QL,DL", [(3, 9, 4, 64), (2, 5, 8, 16), (5, 3, 16, 32), (1, 2, 4, 4)])
+def test_attention_pooling_pipeline_kernel(S, N, QL, DL):
+    """The persistent role-specialised attention-pooling kernel (bench-size document encoders select it by tile count; here it is forced,
+    tunable attn_unfused_pipe = 2): more tiles than / fewer tiles than workgroups, ragged lengths, a partial last tile."""
+    from context_attentive_ir_amd import lib, synth
+    V, B = 2000, 4
+    m = build_model("CARS", vocab=V, device=DEV)
+    ex = {k: v.to(DEV) for k, v in synth.session_batch(B, S, N, QL, DL, V, seed=QL * DL, full_length=False).items()}
+    with lib.tunable("attn_unfused", 1, 0):
+        p0, _, _ = m.encode(ex["source_words"], ex["source_lens"])
+        d0 = m.encode_document(ex["document_words"], ex["document_lens"])
+    with lib.tunable("attn_unfused_pipe", 2, 0):
+        p1, _, _ = m.encode(ex["source_words"], ex["source_lens"])
+        d1 = m.encode_document(ex["document_words"], ex["document_lens"])
+    _close(p1, p0, 5e-6); _close(d1, d0, 5e-6)
