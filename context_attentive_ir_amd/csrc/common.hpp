@@ -54,8 +54,10 @@ const char* prof_shape_name(const char* base, long long M, long long N, long lon
 struct ForkJoin {
     hipStream_t main, side;
     hipEvent_t ev_fork, ev_join;
-    bool ok;
+    bool ok, open;
     explicit ForkJoin(hipStream_t main_stream);
+    ~ForkJoin() { if (open) join(); }   // error returns between fork() and join() still re-join the side stream (an unjoined side
+                                        // stream would invalidate an in-progress hipGraph capture)
     void fork();   // side waits for everything enqueued on main so far
     void join();   // main waits for everything enqueued on side so far
 };

@@ -94,7 +94,7 @@ struct SideRes { hipStream_t side = nullptr; hipEvent_t f = nullptr, j = nullptr
 static std::mutex g_side_mu;
 static std::map<std::pair<int, hipStream_t>, SideRes> g_side;   // one side stream + event pair per (device, caller stream)
 
-ForkJoin::ForkJoin(hipStream_t main_stream) : main(main_stream), side(main_stream), ev_fork(nullptr), ev_join(nullptr), ok(false) {
+ForkJoin::ForkJoin(hipStream_t main_stream) : main(main_stream), side(main_stream), ev_fork(nullptr), ev_join(nullptr), ok(false), open(false) {
     if (tun(g_tun.no_fork) || batches_in_flight(main_stream) > 1) return;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
@@ -110,8 +110,10 @@ ForkJoin::ForkJoin(hipStream_t main_stream) : main(main_stream), side(main_strea
 void ForkJoin::fork() {
     if (!ok) return;
     if (hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) { ok = false; side = main; }
+    open = ok;
 }
 void ForkJoin::join() {
+    open = false;
     if (!ok) return;
     hipEventRecord(ev_join, side);
     hipStreamWaitEvent(main, ev_join, 0);

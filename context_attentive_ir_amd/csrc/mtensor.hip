@@ -406,6 +406,25 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     hw.C = w->C;
     hw.dbg = g_debug_buf;
     const int MT = (NFC * QL + 31) / 32;
+    // every shape / LDS feasibility check comes before the first launch (nothing is enqueued for a call that cannot finish)
+    const size_t lds = mt_head_lds(QL, DL, MT);
+    const size_t flds = (size_t)(((QL * w->C + 3) & ~3) + NFC * (w->C + 1) * 3 * 7) * 4;
+    NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: QL=%d / DL=%d need %zu bytes of LDS (> 160 KiB)", QL, DL, lds);
+    NIR_REQUIRE(flds <= 160 * 1024 - 512, "match_tensor: QL=%d needs %zu bytes of LDS for the query fold (> 160 KiB)", QL, flds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)mt_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("match_tensor: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    if (flds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)mt_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+        if (e != hipSuccess) {
+            set_error("match_tensor: cannot reserve %zu bytes of LDS for the query fold: %s", flds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
     // The query chain (tiny, latency-bound) runs on a side stream concurrently with the document chain.
     ForkJoin fj(st);
     fj.fork();
@@ -420,7 +439,6 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
         NIR_PROPAGATE(launch_linear(hq, 2 * w->Hq, nullptr, nullptr, 0, 0, 0, w->qproj_w, 2 * w->Hq, w->qproj_b, nullptr, pq, w->C, Mq, w->C, 2 * w->Hq, NIR_ACT_NONE, qs));
         {
             ProfScope ps("mt_fold_kernel", qs);
-            const size_t flds = (size_t)(((QL * w->C + 3) & ~3) + NFC * (w->C + 1) * 3 * 7) * 4;
         hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3, FOLD_Z), dim3(256), flds, qs, pq, hw, QL, MT, p.U);
         }
         NIR_CHECK_LAUNCH("mt_fold_kernel");
@@ -436,15 +454,6 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     }
     NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
     fj.join();
-    size_t lds = mt_head_lds(QL, DL, MT);
-    NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: QL=%d / DL=%d need %zu bytes of LDS (> 160 KiB)", QL, DL, lds);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mt_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("match_tensor: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return (int)e;
-        }
-    }
     if (tun(g_tun.debug)) {
         int nb = -1;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)mt_head_kernel, 256, lds);

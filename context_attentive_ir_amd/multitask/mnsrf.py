@@ -84,6 +84,9 @@ class MNSRF(nn.Module, lib.IdCheck):
         src_len = source_len if source_len is not None else getattr(self, "_src_len", None)
         if src_len is None:
             raise RuntimeError("rank_document needs the query lengths: call encode() first or pass source_len")
+        if src_len.numel() != source_rep.shape[0] * source_rep.shape[1]:
+            raise RuntimeError("rank_document: %d query lengths for %d x %d queries (lengths cached by encode() belong to another "
+                               "batch? pass source_len)" % (src_len.numel(), source_rep.shape[0], source_rep.shape[1]))
         lib.require_device(source_rep, document_rep, document_len, src_len, table)
         L = lib.load()
         B, S, N, DL = document_rep.shape
