@@ -11,6 +11,7 @@
 // ReLU / 1x1 conv / global max-pool / output Linear are fused in registers + wave shuffles.
 #include "common.hpp"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace nir {
 
@@ -48,6 +49,18 @@ constexpr int KTOT = 15 * CP;                                                   
 //   U = sum_di W_k[f][c][di][dj] * Pq[b][i+di-1][c]      (zero for c >= C, rows >= 6*QL)
 // grid (B, 3 convs, FOLD_Z element slices), block 256
 constexpr int FOLD_Z = 4;
+// fp16 two-term form (H2) of the same operand, for the v_mfma_f32_16x16x32_f16 interaction GEMM: every conv tap is padded to 64 channels
+// (two 32-wide k-steps) and stored as MFMA A-fragments,
+//   Uh[b][tap 0..14][half 0..1][row tile 0..2MT-1][term 0..1][lane 64][8],   lane = 16 * (c % 32 / 8) + row % 16,
+// x = h1 + 2^-11 h2' with h1 = fp16_rtz(x), h2' = fp16(2^11 (x - h1))  (requires |U| < 2^15: host-checked `bounded`).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int CH = 64;     // channels per tap in the H2 form
+__host__ __device__ inline int mt_tapoff(int k) { return k == 0 ? 0 : (k == 1 ? 3 : 8); }
+__host__ __device__ inline size_t mt_uh_halves(int MT) { return (size_t)15 * 2 * (2 * MT) * 2 * 64 * 8; }
+
+template <bool H2>
 __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ pq, MtHeadW w, int QL, int MT, float* __restrict__ U) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];   // Pq[QL][C] | W_k[NF][C+1][3][kw]
     const int b = blockIdx.x, k = blockIdx.y, C = w.C;
@@ -75,6 +88,32 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ 
     }
     __syncthreads();
     const int rows = MT * 32;
+    if (H2) {
+        _Float16* uh = reinterpret_cast<_Float16*>(U) + (int64_t)b * mt_uh_halves(MT);
+        for (int e = threadIdx.x + 256 * blockIdx.z; e < rows * kw * (CH / 2); e += 256 * FOLD_Z) {   // two channels per thread
+            const int r = e / (kw * (CH / 2)), rem = e - r * (kw * (CH / 2));
+            const int dj = rem / (CH / 2), c = 2 * (rem - dj * (CH / 2));
+            const int i = r / NFC, f = r - i * NFC;
+            float a0 = 0.f, a1 = 0.f;
+            if (i < QL) {
+#pragma unroll
+                for (int di = 0; di < 3; ++di) {
+                    const int ii = i + di - 1;
+                    if (ii >= 0 && ii < QL) {
+                        if (c < C) a0 = fmaf(wks[((f * (C + 1) + c) * 3 + di) * kw + dj], pqs[ii * C + c], a0);
+                        if (c + 1 < C) a1 = fmaf(wks[((f * (C + 1) + c + 1) * 3 + di) * kw + dj], pqs[ii * C + c + 1], a1);
+                    }
+                }
+            }
+            const fp16x2_t h1 = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+            const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz((a0 - (float)h1[0]) * 2048.0f, (a1 - (float)h1[1]) * 2048.0f);
+            const int tk = mt_tapoff(k) + dj, half = c >> 5, kg = (c >> 3) & 3, e8 = c & 7, rt = r >> 4, row16 = r & 15;
+            _Float16* d = uh + ((((int64_t)(tk * 2 + half) * (2 * MT) + rt) * 2) * 64 + kg * 16 + row16) * 8 + e8;
+            *reinterpret_cast<unsigned*>(d) = __builtin_bit_cast(unsigned, h1);
+            *reinterpret_cast<unsigned*>(d + 64 * 8) = __builtin_bit_cast(unsigned, h2);
+        }
+        return;
+    }
     float* ub = U + (int64_t)b * rows * KTOT;   // per query: [mt][k-slab][32][Kp] laid out as consecutive slabs
     for (int e = threadIdx.x + 256 * blockIdx.z; e < rows * Kp; e += 256 * FOLD_Z) {
         const int r = e / Kp, kk = e - r * Kp;
@@ -100,6 +139,11 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ 
 //   phase 2 (VALU): one lane per (query position, doc position): + bias + exact-match taps, ReLU, 1x1 conv,
 //            running max-pool;  finally max over lanes/waves and the output Linear.
 // dynamic LDS: PdT[CP][DLP] | Y[3][MT*32][JT+1] | small weights | dids[DL]
+// H2 = true: phase 1 on v_mfma_f32_16x16x32_f16 with both operands in the two-term fp16 form -- 720 MFMAs of 16 cycles per pair instead
+// of 840 of 64 (fp32 32x32x2): U arrives as A-fragments from mt_fold_kernel<true>, the document projections are split into two fp16
+// planes Pdh[term][position + 3][64 channels (+8 pad)] when they are staged (position-major: a B fragment = 16 bytes of one row).
+constexpr int CPH = CH + 8;     // halves per position row of a Pdh plane (144 B pitch: 16-byte reads of 16 consecutive rows hit 16 bank groups)
+template <bool H2>
 __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict__ pd, const float* __restrict__ U,
                                                       const int64_t* __restrict__ q_ids, const int64_t* __restrict__ d_ids,
                                                       MtHeadW w, int B, int N, int QL, int DL, int MT, float* __restrict__ scores) {
@@ -110,8 +154,11 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
                                                    // writes pdt[c*DLP + j] (consecutive c per lane) are conflict-free
     const int rows = MT * 32;
     constexpr int YLD = JT + 1;
-    float* pdt = smem;                             // [CP][DLP]
-    float* Y = pdt + CP * DLP;                     // [3][rows][YLD]
+    float* pdt = smem;                             // [CP][DLP]   (H2: Pdh[2 terms][DLH][CPH] halves in the same region)
+    const int DLH = nchunk * JT + 6;               // positions + 3 halo rows on each side
+    _Float16* pdh = reinterpret_cast<_Float16*>(smem);
+    const int pd_floats = H2 ? (2 * DLH * CPH + 1) / 2 : CP * DLP;
+    float* Y = pdt + ((pd_floats + 3) & ~3);       // [3][rows][YLD]
     float* wsm = Y + 3 * rows * YLD;               // cw[20*18] | cb[20] | bias[18] | wm[3 convs: 6*3*kw] (270)
     float* cw_s = wsm;
     float* cb_s = cw_s + MFC * 3 * NFC;
@@ -138,12 +185,18 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
     // ---- prologue: every global load is issued before anything waits on it (batched), then the LDS images are built
     const float* pdm = pd + pair * DL * C;
     const int npd = DL * C;
-    constexpr int PB = 8;                                  // Pd elements per thread per batch
-    float pv[PB];
+    constexpr int PB = 8;                                  // Pd elements (H2: pairs of elements) per thread per batch
+    float pv[PB], pv2[PB];
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
         const int e = u * 256 + tid;
-        pv[u] = e < npd ? pdm[e] : 0.f;
+        if (H2) {                                          // C even: a pair never straddles two positions; clamped, masked below
+            const int e2 = 2 * e < npd ? 2 * e : 0;
+            pv[u] = pdm[e2];
+            pv2[u] = pdm[e2 + 1];
+        } else {
+            pv[u] = e < npd ? pdm[e] : 0.f;
+        }
     }
     float cwv[2];
 #pragma unroll
@@ -170,6 +223,24 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
     const int64_t did0 = tid < DL ? d_ids[pair * DL + tid] : 0;
     const int64_t qid0 = tid < QL ? q_ids[(int64_t)b * QL + tid] : 0;
 
+    if (H2) {
+        for (int e = tid; e < (2 * DLH * CPH + 1) / 2; e += 256) pdt[e] = 0.f;       // zero halo rows and padded channels of both planes
+        __syncthreads();
+        auto put = [&](int e, float x0, float x1) {            // elements 2e, 2e+1 -> the two term planes
+            const int j = (2 * e) / C, c = 2 * e - j * C;
+            const fp16x2_t h1 = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+            const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz((x0 - (float)h1[0]) * 2048.0f, (x1 - (float)h1[1]) * 2048.0f);
+            _Float16* d = pdh + (j + 3) * CPH + c;
+            *reinterpret_cast<unsigned*>(d) = __builtin_bit_cast(unsigned, h1);
+            *reinterpret_cast<unsigned*>(d + DLH * CPH) = __builtin_bit_cast(unsigned, h2);
+        };
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int e = u * 256 + tid;
+            if (2 * e < npd) put(e, pv[u], pv2[u]);
+        }
+        for (int e = PB * 256 + tid; 2 * e < npd; e += 256) put(e, pdm[2 * e], pdm[2 * e + 1]);   // long documents
+    } else {
     for (int e = tid; e < CP * DLP; e += 256) pdt[e] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -183,6 +254,7 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
     for (int e = PB * 256 + tid; e < npd; e += 256) {      // long documents: remaining elements
         const int j = e / C, c = e - j * C;
         pdt[c * DLP + j + 3] = pdm[e];
+    }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -222,6 +294,65 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
             if (wsel != wave) continue;
             const int rem = task % (MT * 2);
             const int mt = rem >> 1, nt = rem & 1;
+            if (H2) {
+                // 32 rows x 32 positions of conv k: 2 x 2 tiles of 16 x 16, per tap two 32-channel k-steps, three MFMAs per product
+                // block (cross terms into acx, scaled by 2^-11 at the end); the A fragments of the next k-step are in flight (L2)
+                // while the 12 MFMAs of the current one run
+                const int kw2 = 3 + 2 * k, pw2 = k + 1, g4 = lane >> 4, c16 = lane & 15;
+                const _Float16* ua = reinterpret_cast<const _Float16*>(U) + (int64_t)b * mt_uh_halves(MT) +
+                                     ((((int64_t)mt_tapoff(k) * 2) * (2 * MT) + 2 * mt) * 2 * 64 + lane) * 8;
+                const int64_t astep = (int64_t)(2 * MT) * 2 * 64 * 8;                 // one (tap, half) k-step
+                const _Float16* bb = pdh + (j0 + nt * 32 + c16 - pw2 + 3) * CPH + 8 * g4;
+                f32x4 acc[2][2], acx[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                f16x8 an[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) an[i][t] = *reinterpret_cast<const f16x8*>(ua + (i * 2 + t) * 512);
+                const int nstep = 2 * kw2;
+                for (int st = 0; st < nstep; ++st) {
+                    f16x8 af[2][2], bf[2][2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) af[i][t] = an[i][t];
+                    const int sn = st + 1 < nstep ? st + 1 : st;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) an[i][t] = *reinterpret_cast<const f16x8*>(ua + sn * astep + (i * 2 + t) * 512);
+                    const _Float16* bp = bb + (st >> 1) * CPH + 32 * (st & 1);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) bf[j][t] = *reinterpret_cast<const f16x8*>(bp + t * DLH * CPH + j * 16 * CPH);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], acx[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], acx[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float* yk = Y + ((int64_t)k * rows + mt * 32 + 16 * i + 4 * g4) * YLD + nt * 32 + 16 * j + c16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) yk[r * YLD] = fmaf(acx[i][j][r], 1.0f / 2048.0f, acc[i][j][r]);
+                    }
+                continue;
+            }
             const int kw = 3 + 2 * k, pw = k + 1, Kp = kw * CP;
             const float* arow = ub + (int64_t)mt * 32 * KTOT + (int64_t)mt_koff(k) * 32 + (int64_t)col * Kp + 4 * g2;
             const float* bcol = pdt + (4 * g2) * DLP + (j0 + nt * 32 + col) - pw + 3;
@@ -342,9 +473,10 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
     if (w.dbg && tid == 0) w.dbg[64 + 4 * blockIdx.x + 1] = wall_clock64();
 }
 
-static size_t mt_head_lds(int QL, int DL, int MT) {
-    const int nchunk = (DL + JT - 1) / JT, DLP = nchunk * JT + 9;
-    size_t fl = (size_t)CP * DLP + (size_t)3 * MT * 32 * (JT + 1) + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + MFC + 2 + 1) & ~1);
+static size_t mt_head_lds(int QL, int DL, int MT, bool h2) {
+    const int nchunk = (DL + JT - 1) / JT, DLP = nchunk * JT + 9, DLH = nchunk * JT + 6;
+    const size_t pdf = ((h2 ? (size_t)(2 * DLH * CPH + 1) / 2 : (size_t)CP * DLP) + 3) & ~(size_t)3;
+    size_t fl = pdf + (size_t)3 * MT * 32 * (JT + 1) + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + MFC + 2 + 1) & ~1);
     return fl * 4 + (size_t)(DL + QL) * 8;
 }
 
@@ -363,7 +495,8 @@ static MtPlan mt_plan(void* ws, size_t cap, int B, int N, int QL, int DL, const 
     p.hd = a.take<float>(Md * 2 * w->Hd);
     p.pq = a.take<float>(Mq * w->C);
     p.pd = a.take<float>(Md * w->C);
-    p.U = a.take<float>((size_t)B * ((6 * QL + 31) / 32) * 32 * KTOT);
+    // fp32 form: [B][MT*32 rows][KTOT]; fp16 two-term fragment form: mt_uh_halves(MT) halves per query (larger: 64-channel taps)
+    p.U = a.take<float>((size_t)B * std::max((size_t)((6 * QL + 31) / 32) * 32 * KTOT, (mt_uh_halves((6 * QL + 31) / 32) + 1) / 2));
     p.bytes = align_up(a.off, 256);
     return p;
 }
@@ -407,19 +540,23 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     hw.dbg = g_debug_buf;
     const int MT = (NFC * QL + 31) / 32;
     // every shape / LDS feasibility check comes before the first launch (nothing is enqueued for a call that cannot finish)
-    const size_t lds = mt_head_lds(QL, DL, MT);
+    // two-term fp16 interaction GEMM when the host vouches for |U|, |Pd| < 2^15 (bounds derived from the projection / conv weights)
+    const bool h2 = w->bounded && w->C % 2 == 0 && w->C <= CH && !tun(g_tun.exact_f32);
+    const size_t lds = mt_head_lds(QL, DL, MT, h2);
     const size_t flds = (size_t)(((QL * w->C + 3) & ~3) + NFC * (w->C + 1) * 3 * 7) * 4;
     NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: QL=%d / DL=%d need %zu bytes of LDS (> 160 KiB)", QL, DL, lds);
     NIR_REQUIRE(flds <= 160 * 1024 - 512, "match_tensor: QL=%d needs %zu bytes of LDS for the query fold (> 160 KiB)", QL, flds);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mt_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(h2 ? (const void*)mt_head_kernel<true> : (const void*)mt_head_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("match_tensor: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
             return (int)e;
         }
     }
     if (flds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)mt_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+        hipError_t e = hipFuncSetAttribute(h2 ? (const void*)mt_fold_kernel<true> : (const void*)mt_fold_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
         if (e != hipSuccess) {
             set_error("match_tensor: cannot reserve %zu bytes of LDS for the query fold: %s", flds, hipGetErrorString(e));
             return (int)e;
@@ -439,7 +576,8 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
         NIR_PROPAGATE(launch_linear(hq, 2 * w->Hq, nullptr, nullptr, 0, 0, 0, w->qproj_w, 2 * w->Hq, w->qproj_b, nullptr, pq, w->C, Mq, w->C, 2 * w->Hq, NIR_ACT_NONE, qs));
         {
             ProfScope ps("mt_fold_kernel", qs);
-        hipLaunchKernelGGL(mt_fold_kernel, dim3(B, 3, FOLD_Z), dim3(256), flds, qs, pq, hw, QL, MT, p.U);
+            if (h2) hipLaunchKernelGGL(mt_fold_kernel<true>, dim3(B, 3, FOLD_Z), dim3(256), flds, qs, pq, hw, QL, MT, p.U);
+            else hipLaunchKernelGGL(mt_fold_kernel<false>, dim3(B, 3, FOLD_Z), dim3(256), flds, qs, pq, hw, QL, MT, p.U);
         }
         NIR_CHECK_LAUNCH("mt_fold_kernel");
     }
@@ -456,16 +594,18 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     fj.join();
     if (tun(g_tun.debug)) {
         int nb = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)mt_head_kernel, 256, lds);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h2 ? (const void*)mt_head_kernel<true> : (const void*)mt_head_kernel<false>, 256, lds);
         hipFuncAttributes fa;
-        hipFuncGetAttributes(&fa, (const void*)mt_head_kernel);
+        hipFuncGetAttributes(&fa, h2 ? (const void*)mt_head_kernel<true> : (const void*)mt_head_kernel<false>);
         fprintf(stderr, "[nir] mt_head_kernel: lds dyn=%zu static=%zu regs=%d maxThreads=%d -> max active blocks/CU=%d\n", lds,
                 (size_t)fa.sharedSizeBytes, fa.numRegs, fa.maxThreadsPerBlock, nb);
     }
     {
         ProfScope ps("mt_head_kernel", st);
-        hipLaunchKernelGGL(mt_head_kernel, dim3((unsigned)(8 * N * ((B + 7) / 8))), dim3(256), lds, st, pd, p.U, q_ids, d_ids, hw,
-                           B, N, QL, DL, MT, scores);
+        if (h2) hipLaunchKernelGGL(mt_head_kernel<true>, dim3((unsigned)(8 * N * ((B + 7) / 8))), dim3(256), lds, st, pd, p.U, q_ids, d_ids, hw,
+                                   B, N, QL, DL, MT, scores);
+        else hipLaunchKernelGGL(mt_head_kernel<false>, dim3((unsigned)(8 * N * ((B + 7) / 8))), dim3(256), lds, st, pd, p.U, q_ids, d_ids,
+                                hw, B, N, QL, DL, MT, scores);
     }
     NIR_CHECK_LAUNCH("mt_head_kernel");
     return 0;

@@ -25,6 +25,18 @@ class ExactMatchChannel(nn.Module):
         self.alpha = nn.Parameter(torch.rand(1))
 
 
+def interaction_bounded(m):
+    """Host-side bound check, once per weight version: the encoder outputs lie in (-1, 1), so |Pq| and |Pd| are at most the largest
+    L1 row norm of the projection plus |bias|, and the folded operand U is at most 3 max|conv_w| max|Pq|.  Below 2^15 the interaction
+    GEMM of the head may use the fp16 two-term split (csrc/mtensor.hip, mt_head_kernel<true>)."""
+    with torch.no_grad():
+        def reach(lin):
+            return float((lin.weight.detach().abs().sum(1) + lin.bias.detach().abs()).max())
+        pq, pd = reach(m.query_projection), reach(m.document_projection)
+        cw = max(float(c.weight.detach().abs().max()) for c in (m.conv1, m.conv2, m.conv3))
+        return max(pd, pq, 3.0 * cw * pq) < 32768.0
+
+
 class MatchTensor(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
@@ -84,7 +96,7 @@ class MatchTensor(nn.Module, lib.IdCheck):
                      conv1_w=self.conv1.weight, conv1_b=self.conv1.bias, conv2_w=self.conv2.weight,
                      conv2_b=self.conv2.bias, conv3_w=self.conv3.weight, conv3_b=self.conv3.bias,
                      conv_w=self.conv.weight, conv_b=self.conv.bias, out_w=self.output.weight, out_b=self.output.bias)
-            return lib.Packed(lib.MatchTensorWeights, t, self._dims)
+            return lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self))))
         params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
         return self._pack.get(params, build)
 

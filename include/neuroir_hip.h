@@ -181,6 +181,10 @@ typedef struct {
     const float *conv_w, *conv_b;                    /* [MF,3NF,1,1],[MF] */
     const float *out_w, *out_b;                      /* output [1,MF],[1] */
     int F, Hq, Hd, C, NF, MF;                        /* 40, 15, 70, 50, 6, 20 */
+    int bounded;                                     /* host-checked: the channel projections (|Pq|, |Pd| <= L1 norm of a projection row
+                                                        + |bias|, encoder outputs being inside (-1,1)) and 3 max|conv_w| |Pq| stay below
+                                                        2^15 -> the interaction GEMM may run on the fp16 two-term split (3 MFMAs of
+                                                        v_mfma_f32_16x16x32_f16 per product block instead of fp32 MFMAs) */
 } nir_matchtensor_weights;
 size_t nir_matchtensor_workspace_bytes(int B, int N, int QL, int DL, const nir_matchtensor_weights* w /*host*/);
 /* Optional debug outputs (NULL to skip): enc_q [B,QL,2Hq], enc_d [B*N,DL,2Hd], proj_q [B,QL,C], proj_d [B*N,DL,C]. */
