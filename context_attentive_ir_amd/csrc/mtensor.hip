@@ -38,6 +38,12 @@ struct MtHeadW {
     const float *alpha, *cw, *cb, *ow, *ob;
     int C;
     unsigned long long* dbg;
+    // fused channel projection of the documents (H2 head only; dpf == NULL: Pd is read from memory): encoder output hd [pairs*DL, HD2],
+    // document_projection as fp16 term planes in MFMA B-fragment order [ceil(HD2/32)][4 column tiles][2 terms][64 lanes][8], bias [C]
+    const float* hd;
+    const void* dpf;
+    const float* dpb;
+    int HD2;
 };
 
 __host__ __device__ inline int mt_kp(int k) { return (3 + 2 * k) * CP; }          // padded K of conv k: 168, 280, 392
@@ -187,10 +193,13 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
     const int npd = DL * C;
     constexpr int PB = 8;                                  // Pd elements (H2: pairs of elements) per thread per batch
     float pv[PB], pv2[PB];
+    const bool fuse_proj = H2 && w.dpf != nullptr;
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
         const int e = u * 256 + tid;
-        if (H2) {                                          // C even: a pair never straddles two positions; clamped, masked below
+        if (fuse_proj) {
+            pv[u] = pv2[u] = 0.f;
+        } else if (H2) {                                   // C even: a pair never straddles two positions; clamped, masked below
             const int e2 = 2 * e < npd ? 2 * e : 0;
             pv[u] = pdm[e2];
             pv2[u] = pdm[e2 + 1];
@@ -234,12 +243,78 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
             *reinterpret_cast<unsigned*>(d) = __builtin_bit_cast(unsigned, h1);
             *reinterpret_cast<unsigned*>(d + DLH * CPH) = __builtin_bit_cast(unsigned, h2);
         };
+        if (fuse_proj) {
+            // Pd = hd Wd^T + b computed here (replaces the [M*DL,140] x [140,50] projection launch and the Pd round trip): wave = 16
+            // channels, four 16-position row tiles per 64-position block; A fragments straight from the fp32 encoder output (split
+            // in registers), B fragments pre-split by the host.  Padded document positions give the bias, as in the reference.
+            const int g4 = lane >> 4, c16 = lane & 15, c = 16 * wave + c16, HD2 = w.HD2, SP = (HD2 + 31) / 32;
+            const _Float16* wfp = reinterpret_cast<const _Float16*>(w.dpf) + ((int64_t)wave * 2 * 64 + lane) * 8;
+            const float* hdm = w.hd + pair * DL * (int64_t)HD2;
+            const float bias = c < C ? w.dpb[c] : 0.f;
+            for (int jt = 0; jt < nchunk; ++jt) {
+                f32x4 pa[4], px[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pa[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; px[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                for (int sp = 0; sp < SP; ++sp) {
+                    const f16x8 wf0 = *reinterpret_cast<const f16x8*>(wfp + (int64_t)sp * (4 * 2 * 64 * 8));
+                    const f16x8 wf1 = *reinterpret_cast<const f16x8*>(wfp + (int64_t)sp * (4 * 2 * 64 * 8) + 512);
+                    // the lane's 8 k values start at k0; 2Hd is a multiple of 4, not of 8: each float4 is loaded from a clamped address and
+                    // multiplied by a 0/1 mask (no predicated loads)
+                    const int k0 = 32 * sp + 8 * g4;
+                    const int ka = k0 + 4 <= HD2 ? k0 : HD2 - 4, kb = k0 + 8 <= HD2 ? k0 + 4 : HD2 - 4;
+                    const float ma = k0 + 4 <= HD2 ? 1.f : 0.f, mb = k0 + 8 <= HD2 ? 1.f : 0.f;
+                    float4 x0[4], x1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int j = jt * JT + 16 * i + c16;
+                        j = j < DL ? j : DL - 1;
+                        const float* hp = hdm + (int64_t)j * HD2;
+                        x0[i] = *reinterpret_cast<const float4*>(hp + ka);
+                        x1[i] = *reinterpret_cast<const float4*>(hp + kb);
+                        x0[i].x *= ma; x0[i].y *= ma; x0[i].z *= ma; x0[i].w *= ma;
+                        x1[i].x *= mb; x1[i].y *= mb; x1[i].z *= mb; x1[i].w *= mb;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const fp16x2_t a0 = __builtin_amdgcn_cvt_pkrtz(x0[i].x, x0[i].y), a1 = __builtin_amdgcn_cvt_pkrtz(x0[i].z, x0[i].w);
+                        const fp16x2_t a2 = __builtin_amdgcn_cvt_pkrtz(x1[i].x, x1[i].y), a3 = __builtin_amdgcn_cvt_pkrtz(x1[i].z, x1[i].w);
+                        const fp16x2_t b0 = __builtin_amdgcn_cvt_pkrtz((x0[i].x - (float)a0[0]) * 2048.0f, (x0[i].y - (float)a0[1]) * 2048.0f);
+                        const fp16x2_t b1 = __builtin_amdgcn_cvt_pkrtz((x0[i].z - (float)a1[0]) * 2048.0f, (x0[i].w - (float)a1[1]) * 2048.0f);
+                        const fp16x2_t b2 = __builtin_amdgcn_cvt_pkrtz((x1[i].x - (float)a2[0]) * 2048.0f, (x1[i].y - (float)a2[1]) * 2048.0f);
+                        const fp16x2_t b3 = __builtin_amdgcn_cvt_pkrtz((x1[i].z - (float)a3[0]) * 2048.0f, (x1[i].w - (float)a3[1]) * 2048.0f);
+                        const f16x8 h1 = __builtin_bit_cast(f16x8, make_uint4(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
+                                                                                    __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)));
+                        const f16x8 h2 = __builtin_bit_cast(f16x8, make_uint4(__builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1),
+                                                                                    __builtin_bit_cast(unsigned, b2), __builtin_bit_cast(unsigned, b3)));
+                        px[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2, wf0, px[i], 0, 0, 0);
+                        px[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, wf1, px[i], 0, 0, 0);
+                        pa[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, wf0, pa[i], 0, 0, 0);
+                    }
+                }
+                if (c < C) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = jt * JT + 16 * i + 4 * g4 + r;
+                            if (j < DL) {
+                                const float v = fmaf(px[i][r], 1.0f / 2048.0f, pa[i][r]) + bias;
+                                const _Float16 a = (_Float16)__builtin_amdgcn_cvt_pkrtz(v, 0.f)[0];
+                                _Float16* d = pdh + (j + 3) * CPH + c;
+                                d[0] = a;
+                                d[DLH * CPH] = (_Float16)((v - (float)a) * 2048.0f);
+                            }
+                        }
+                }
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
             const int e = u * 256 + tid;
             if (2 * e < npd) put(e, pv[u], pv2[u]);
         }
         for (int e = PB * 256 + tid; 2 * e < npd; e += 256) put(e, pdm[2 * e], pdm[2 * e + 1]);   // long documents
+        }
     } else {
     for (int e = tid; e < CP * DLP; e += 256) pdt[e] = 0.f;
     __syncthreads();
@@ -538,6 +613,7 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     hw.alpha = w->alpha; hw.cw = w->conv_w; hw.cb = w->conv_b; hw.ow = w->out_w; hw.ob = w->out_b;
     hw.C = w->C;
     hw.dbg = g_debug_buf;
+    hw.hd = nullptr; hw.dpf = nullptr; hw.dpb = nullptr; hw.HD2 = 2 * w->Hd;
     const int MT = (NFC * QL + 31) / 32;
     // every shape / LDS feasibility check comes before the first launch (nothing is enqueued for a call that cannot finish)
     // two-term fp16 interaction GEMM when the host vouches for |U|, |Pd| < 2^15 (bounds derived from the projection / conv weights)
@@ -590,7 +666,12 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
         NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xd, w->F, Md, w->F, E, NIR_ACT_NONE, st));
         NIR_PROPAGATE(launch_bilstm_fused(p.xd, w->F, w->d_wih, w->d_bih, w->d_bhh, d_len, w->d_whh, nullptr, nullptr, hd, nullptr, nullptr, (int64_t)B * N, DL, w->Hd, 2, st));
     }
-    NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
+    // the channel projection of the documents runs inside the head kernel when the host supplied its fragment planes (fp16 two-term
+    // head only; 2Hd a multiple of 4 for the 16-byte row loads); a requested proj_d output keeps the separate GEMM
+    const bool fuse_proj = h2 && w->dproj_frag && (2 * w->Hd) % 4 == 0 && 2 * w->Hd >= 8 && w->C <= 64 && !tun(g_tun.no_skinny);
+    if (fuse_proj) { hw.hd = hd; hw.dpf = w->dproj_frag; hw.dpb = w->dproj_b; }
+    if (!fuse_proj || proj_d)
+        NIR_PROPAGATE(launch_linear(hd, 2 * w->Hd, nullptr, nullptr, 0, 0, 0, w->dproj_w, 2 * w->Hd, w->dproj_b, nullptr, pd, w->C, Md, w->C, 2 * w->Hd, NIR_ACT_NONE, st));
     fj.join();
     if (tun(g_tun.debug)) {
         int nb = -1;

@@ -29,6 +29,7 @@ MatchTensorWeights = _struct(
      "qproj_w", "qproj_b", "dproj_w", "dproj_b", "alpha", "conv1_w", "conv1_b", "conv2_w", "conv2_b",
      "conv3_w", "conv3_b", "conv_w", "conv_b", "out_w", "out_b"],
     ["F", "Hq", "Hd", "C", "NF", "MF", "bounded"])
+MatchTensorWeights = type("nir_matchtensor_weights", (C.Structure,), {"_fields_": list(MatchTensorWeights._fields_) + [("dproj_frag", C.c_void_p)]})
 DuetWeights = _struct(
     "nir_duet_weights",
     ["l_conv_w", "l_conv_b", "l_fc1_w", "l_fc1_b", "l_fc2_w", "l_fc2_b", "l_fc3_w", "l_fc3_b",

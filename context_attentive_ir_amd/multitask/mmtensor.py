@@ -70,8 +70,8 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
                      conv1_w=self.conv1.weight, conv1_b=self.conv1.bias, conv2_w=self.conv2.weight,
                      conv2_b=self.conv2.bias, conv3_w=self.conv3.weight, conv3_b=self.conv3.bias,
                      conv_w=self.conv.weight, conv_b=self.conv.bias, out_w=self.output.weight, out_b=self.output.bias)
-            from ..rankers.mtensor import interaction_bounded
-            return lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self))))
+            from ..rankers.mtensor import attach_projection_fragments, interaction_bounded
+            return attach_projection_fragments(lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self)))))
         skip = ("embedder.", "session_query_encoder.", "decoder.", "generator.")
         params = [p for n, p in self.named_parameters() if not n.startswith(skip)]
         return self._pack.get(params, build)

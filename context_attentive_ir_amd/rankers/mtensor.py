@@ -37,6 +37,22 @@ def interaction_bounded(m):
         return max(pd, pq, 3.0 * cw * pq) < 32768.0
 
 
+def attach_projection_fragments(pk):
+    """document_projection as the B operand of the head kernel's fused channel projection (csrc/mtensor.hip): [C, 2Hd] zero-padded to
+    [64][k rounded up to 32], split into two fp16 terms and re-ordered into MFMA fragments [k/32][4 column tiles][2 terms][64 lanes][8]."""
+    wd = pk.keep["dproj_w"]
+    C_, K = wd.shape
+    if not (pk.struct.bounded and wd.is_cuda and C_ <= 64 and K % 4 == 0 and K >= 8):
+        return pk
+    kp = (K + 31) // 32 * 32
+    pad = torch.zeros(64, kp, device=wd.device, dtype=torch.float32)
+    pad[:C_, :K] = wd
+    planes = torch.stack(lib.split_f16x2(pad, kp))                                   # [2 terms, 64, kp] int16
+    pk.keep["dproj_frag"] = planes.view(2, 4, 16, kp // 32, 4, 8).permute(3, 1, 0, 4, 2, 5).contiguous()
+    pk.struct.dproj_frag = pk.keep["dproj_frag"].data_ptr()
+    return pk
+
+
 class MatchTensor(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
@@ -96,7 +112,7 @@ class MatchTensor(nn.Module, lib.IdCheck):
                      conv1_w=self.conv1.weight, conv1_b=self.conv1.bias, conv2_w=self.conv2.weight,
                      conv2_b=self.conv2.bias, conv3_w=self.conv3.weight, conv3_b=self.conv3.bias,
                      conv_w=self.conv.weight, conv_b=self.conv.bias, out_w=self.output.weight, out_b=self.output.bias)
-            return lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self))))
+            return attach_projection_fragments(lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self)))))
         params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
         return self._pack.get(params, build)
 

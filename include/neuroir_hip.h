@@ -185,6 +185,10 @@ typedef struct {
                                                         + |bias|, encoder outputs being inside (-1,1)) and 3 max|conv_w| |Pq| stay below
                                                         2^15 -> the interaction GEMM may run on the fp16 two-term split (3 MFMAs of
                                                         v_mfma_f32_16x16x32_f16 per product block instead of fp32 MFMAs) */
+    const void* dproj_frag;                          /* optional (NULL: separate projection GEMM): document_projection [C <= 64, 2Hd] padded to
+                                                        [64][ceil(2Hd/32)*32], split into two fp16 terms (nir_split_f16x2) and stored in MFMA
+                                                        B-fragment order [K/32][4 column tiles][2 terms][64 lanes][8]; with `bounded` the head
+                                                        kernel then computes Pd = hd Wd^T + b itself */
 } nir_matchtensor_weights;
 size_t nir_matchtensor_workspace_bytes(int B, int N, int QL, int DL, const nir_matchtensor_weights* w /*host*/);
 /* Optional debug outputs (NULL to skip): enc_q [B,QL,2Hq], enc_d [B*N,DL,2Hd], proj_q [B,QL,C], proj_d [B*N,DL,C]. */
