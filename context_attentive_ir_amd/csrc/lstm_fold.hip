@@ -369,8 +369,12 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int KB, int NT>
-__global__ __launch_bounds__(1024) void lstm16_pt_h2_kernel(LstmPtArgs p) {
+// NW waves per workgroup, NT gate tiles per wave (NW * NT * 4 >= H units).  16 waves x 2 tiles is the latency form (H = 128); for
+// H <= 80 four waves x 5 tiles leave room for three workgroups per CU, which fill each other's per-step bubbles when several
+// batches are in flight.
+template <int KB, int NT, int NW>
+__global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(LstmPtArgs p) {
+    constexpr int NTH = 64 * NW;
     constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // fp16 elements per h row
     constexpr uint32_t OOB = 0x7FFFFFF0u;
     constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_h2_kernel(LstmPtArgs p) {
     }
     {
         bool bad = false;
-        for (int e = tid; e < SEQ * T; e += 1024) {
+        for (int e = tid; e < SEQ * T; e += NTH) {
             const int s = e / T;
             int64_t id = 0;
             if (s < nvalid) id = p.ids[m0 * T + e];
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_h2_kernel(LstmPtArgs p) {
         }
         if (bad && p.err) atomicOr(p.err, 1);
     }
-    for (int e = tid; e < 2 * SEQ * ZLD; e += 1024) reinterpret_cast<unsigned*>(z)[e] = 0u;   // 4*SEQ*ZLD halves
+    for (int e = tid; e < 2 * SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;   // 4*SEQ*ZLD halves
     __syncthreads();
     int tmax = 0;
 #pragma unroll
@@ -536,12 +540,12 @@ __global__ __launch_bounds__(1024) void lstm16_pt_h2_kernel(LstmPtArgs p) {
     }
 }
 
-template <int KB, int NT>
+template <int KB, int NT, int NW = 16>
 static int launch_pt_h2(const LstmPtArgs& p, hipStream_t st) {
-    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + ">";
+    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + ">";
     const size_t lds = (size_t)(4 * 16 * (32 * KB + 8)) * 2 + 16 * 4 + (size_t)16 * p.T * 4;
     ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
-    hipLaunchKernelGGL((lstm16_pt_h2_kernel<KB, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), lds, st, p);
+    hipLaunchKernelGGL((lstm16_pt_h2_kernel<KB, NT, NW>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(64 * NW), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2]");
     return 0;
 }
@@ -583,6 +587,20 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     if (!tun(g_tun.exact_f32) && H >= 32) {      // fp32-accurate two-term fp16 split on the fp16 matrix cores
         const int KB = (H + 31) / 32;
         if (H <= 64) return KB == 1 ? launch_pt_h2<1, 1>(p, st) : launch_pt_h2<2, 1>(p, st);
+        // 4 waves x 5 tiles, two workgroups per CU: pays when the workgroups in flight (this launch x the caller's batches in flight)
+        // outnumber the CUs twice over -- 32x50 MatchTensor with 4 batches in flight: 8.8 M -> 10.4 M pairs/s; at 32x10 the dispatcher
+        // pairs workgroups on a CU while other CUs idle and the same kernel LOSES 18 % (tunable lstm_s: 1 = never, 2 = always)
+        if (KB == 3 && H <= 80) {
+            static const int ncu = [] {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                           ? prop.multiProcessorCount : 256;
+            }();
+            const int64_t wgs = ((p.M + 15) / 16) * p.ND * (int64_t)std::max(1, batches_in_flight(st));
+            const int sel = tun(g_tun.lstm_s);
+            if (sel == 2 || (sel != 1 && wgs >= 2 * (int64_t)ncu)) return launch_pt_h2<3, 5, 4>(p, st);
+        }
         return KB == 3 ? launch_pt_h2<3, 2>(p, st) : launch_pt_h2<4, 2>(p, st);
     }
     const int G = (H + 15) / 16;

@@ -194,3 +194,26 @@ def test_attention_pooling_pipeline_kernel(S, N, QL, DL):
         p1, _, _ = m.encode(ex["source_words"], ex["source_lens"])
         d1 = m.encode_document(ex["document_words"], ex["document_lens"])
     _close(p1, p0, 5e-6); _close(d1, d0, 5e-6)
+
+
+def test_bilstm_folded_four_wave_variant_matches():
+    """H = 70: the 4-wave x 5-tile workgroup form (selected by workgroup count; forced here with tunable lstm_s = 2) against the
+    16-wave form (lstm_s = 1): the same arithmetic in another wave layout (agreement to rounding, 1e-6)."""
+    from context_attentive_ir_amd import lib
+    H, M, T_, V = 70, 37, 21, 300
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(V, 40, generator=g).to(DEV)
+    lstm = torch.nn.LSTM(40, H, bidirectional=True, batch_first=True).to(DEV)
+    from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
+    wih, whh, bih, bhh = [t.detach().contiguous() for t in lstm_cat_weights(lstm)]
+    folded = lib.fold_lstm_table(x, wih, bih, bhh, H, 2, "f32")
+    ids = torch.randint(0, V, (M, T_), generator=g).to(DEV)
+    lens = torch.randint(1, T_ + 1, (M,), generator=g).to(DEV)
+    outs = []
+    for sel in (1, 2):
+        out = torch.empty(M, T_, 2 * H, device=DEV)
+        with lib.tunable("lstm_s", sel, 0):
+            lib.check(lib.load().nir_bilstm_folded_fwd(lib.ptr(folded), lib.DTYPE_F32, lib.ptr(ids), lib.ptr(lens), lib.ptr(whh), lib.ptr(out),
+                                                        None, M, V, T_, H, 2, lib.stream()), "folded")
+        outs.append(out)
+    _close(outs[0], outs[1], 1e-6)
