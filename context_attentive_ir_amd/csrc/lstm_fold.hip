@@ -373,7 +373,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // H <= 80 four waves x 5 tiles leave room for three workgroups per CU, which fill each other's per-step bubbles when several
 // batches are in flight.
 template <int KB, int NT, int NW>
-__global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(LstmPtArgs p) {
+__global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(LstmPtArgs p) {   // (second argument: waves per SIMD)
     constexpr int NTH = 64 * NW;
     constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // fp16 elements per h row
     constexpr uint32_t OOB = 0x7FFFFFF0u;
