@@ -272,6 +272,14 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
 
     lanes = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
     fbufs = [None] * len(lanes)
+    # Candidate-sharded CARS over RCCL: the step is two hipGraphs (queries + this rank's document shard -> pooled vectors | session
+    # part + softmax) around ONE eager all-gather of the pooled shard; replaying the whole step eagerly is host-bound (measured
+    # 0.43 ms/step of enqueue against 0.22 ms of GPU time).  torch.distributed runs the collectives of all lanes on its own stream in
+    # issue order.
+    staged = sharded and is_sess and env.backend == "nccl" and c["model"] == "cars" and not args.no_graph
+    if staged:
+        for b in batches:
+            b["_doc_shard"], b["_len_shard"] = sharding.shard_session_candidates(b["document_words"], b["document_lens"], world, rank)
 
     def finish(s):
         """cross-rank part of a ranker step (eager): one all-gather of the score shards, softmax over all candidates."""
@@ -301,7 +309,32 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             finish(forward(i))
     torch.cuda.synchronize()
     graphs = None
-    # the sharded CARS step contains a collective (all-gather of the pooled documents) between its kernels: replayed eagerly
+    stages = None
+    if staged:
+        try:
+            stages = []
+            for i in range(len(batches)):
+                ex, ln = batches[i], lanes[lane_of(i)]
+                with torch.cuda.stream(ln):                     # warm (packs, workspaces), then capture both halves
+                    pq, pl = model.shard_stage_a(ex, ex["_doc_shard"], ex["_len_shard"])
+                    B_, S_, per_, D_ = pl.shape
+                    gbuf = torch.empty(world * B_ * S_, per_ * D_, device=dev, dtype=pl.dtype)
+                    env.dist.all_gather_into_tensor(gbuf, pl.reshape(B_ * S_, per_ * D_))
+                    model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand)
+                torch.cuda.synchronize()
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, stream=ln):
+                    pq, pl = model.shard_stage_a(ex, ex["_doc_shard"], ex["_len_shard"])
+                    flat = pl.reshape(B_ * S_, per_ * D_)
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, stream=ln):
+                    out = model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand)
+                stages.append((ga, flat, gbuf, gb, out))
+        except Exception as e:  # pragma: no cover - falls back to the eager sharded step
+            print("[bench] staged graph capture unavailable for %s (%s); eager sharded steps" % (name, e), file=sys.stderr)
+            stages = None
+            torch.cuda.synchronize()
+    # the sharded CARS step contains a collective (all-gather of the pooled documents) between its kernels: staged graphs above, else eager
     use_graph = not args.no_graph and not (sharded and is_sess) and not (env.backend != "nccl" and env.multi)
     if use_graph:
         try:
@@ -318,6 +351,13 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
 
     def run(i, only_lane=None):
         ln = lane_of(i) if only_lane is None else only_lane
+        if stages is not None:
+            ga, flat, gbuf, gb, out = stages[i % len(stages)]
+            with torch.cuda.stream(lanes[lane_of(i)]):          # a captured graph replays on the lane it was captured on
+                ga.replay()
+                env.dist.all_gather_into_tensor(gbuf, flat)
+                gb.replay()
+            return out
         with torch.cuda.stream(lanes[ln]):
             if graphs is not None:
                 g, out = graphs[i % len(graphs)]
@@ -461,7 +501,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 world, batches[0]["doc_rep"].shape[1], "RCCL" if env.backend == "nccl" else env.backend)
     return {"name": name, "baseline_config": c.get("baseline"), "workload": tag, "pairs_per_s": round(value, 1), "ms_per_step": round(ms_per_step, 5),
             "ms_per_step_one_batch_in_flight": round(single_ms, 5), "global_batch_pairs": per_step_pairs, "parallelism": par, "world_size": world,
-            "steps": steps, "hipgraph": graphs is not None, "batches_in_flight": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
+            "steps": steps, "hipgraph": (graphs is not None) or (stages is not None), "batches_in_flight": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
             "dtype": c.get("dtype", "f32"), "roofline": roofline, "cpu_baseline": cpu}
 

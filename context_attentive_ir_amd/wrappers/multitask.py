@@ -51,6 +51,27 @@ class Multitask(WrapperBase):
                                                       want_states=want_states)
         return s, states, attns, (encoded, src_lens)
 
+    # ---- the candidate-sharded ranking step in two capturable halves (bench.py / a serving loop replays each as a hipGraph and issues
+    # the one all-gather between them eagerly: a collective cannot sit inside the graph, and the eager step is host-bound) ----------
+    @torch.no_grad()
+    def shard_stage_a(self, ex, doc_shard, len_shard):
+        """queries + this rank's candidate shard -> (pooled queries [B,S,D], pooled shard [B,S,per,D])."""
+        self.network.eval()
+        pooled, _, _ = self.network.encode(self._dev(ex["source_words"]), self._dev(ex["source_lens"]))
+        return pooled, self.network.encode_document(doc_shard, len_shard)
+
+    @torch.no_grad()
+    def shard_stage_b(self, pooled, gathered, labels, n_candidates):
+        """gathered = all_gather_into_tensor of every rank's pooled shard, [world*B*S, per*D] -> softmaxed click scores [B,S,N]."""
+        B, S, D = pooled.shape
+        world = gathered.shape[0] // (B * S)
+        per = gathered.shape[1] // D
+        docs = gathered.view(world, B, S, per, D).permute(1, 2, 0, 3, 4).reshape(B, S, world * per, D)[:, :, :n_candidates].contiguous()
+        s = self.network._rank_session(pooled, docs, labels, want_states=False)[0].contiguous()
+        probs = torch.empty_like(s)
+        lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()), "nir_softmax_rows")
+        return probs
+
     @torch.no_grad()
     def scores(self, ex):
         """raw click scores [B,S,N] (ranking path only)."""
