@@ -242,12 +242,24 @@ class Env(object):
         return float(t.item())
 
 
+# hipGraph captures are thread-local: the ProcessGroupNCCL watchdog thread polls hipEventQuery on the warm-up collectives while the
+# main thread captures, and in the default (global) mode that query invalidates the capture and aborts the process (seen 1 run in 6).
+CAPTURE_MODE = "thread_local"
+
+
 def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2d=False):
     """Time one workload; returns the record dict (rank 0) or None."""
     L = lib.load()
     dev, world, rank = env.dev, env.world, env.rank
     is_sess = c["model"] in SESSION_MODELS
     sharded = shard and env.multi
+    # lane-count tuning aid (never set by the driver): BENCH_FORCE_DIST=1 BENCH_EMULATE_WORLD=W on ONE GPU gives this process rank 0's
+    # 1/W candidate shard and a W-shard gather buffer (the other shards stay zero), so the per-rank GPU work of an N=W run can be
+    # timed here; the scores are meaningless and the cross-GPU latency of the collective is not included.
+    wsh = world
+    if world == 1 and env.multi and os.environ.get("BENCH_EMULATE_WORLD"):
+        wsh = int(os.environ["BENCH_EMULATE_WORLD"])
+    emu = wsh != world
     model = build_model(c, args)
     # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
     batches = make_batches(c, args.nbatches, 0 if sharded or not env.multi else rank, dev)
@@ -257,7 +269,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         model.parallelize()
     if sharded and not is_sess:       # pre-slice this rank's candidate shard (resident in HBM like the full batch would be)
         for b in batches:
-            b["doc_rep"], b["doc_len"] = sharding.shard_candidates(b["doc_rep"], b["doc_len"], world, rank)
+            b["doc_rep"], b["doc_len"] = sharding.shard_candidates(b["doc_rep"], b["doc_len"], wsh, rank)
 
     def forward(i):
         ex = batches[i % len(batches)]
@@ -279,7 +291,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     staged = sharded and is_sess and env.backend == "nccl" and c["model"] == "cars" and not args.no_graph
     if staged:
         for b in batches:
-            b["_doc_shard"], b["_len_shard"] = sharding.shard_session_candidates(b["document_words"], b["document_lens"], world, rank)
+            b["_doc_shard"], b["_len_shard"] = sharding.shard_session_candidates(b["document_words"], b["document_lens"], wsh, rank)
 
     def finish(s):
         """cross-rank part of a ranker step (eager): one all-gather of the score shards, softmax over all candidates."""
@@ -289,10 +301,10 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             cur = torch.cuda.current_stream()
             ln = lanes.index(cur) if cur in lanes else 0
             if fbufs[ln] is None:
-                fbufs[ln] = (torch.empty(world * s.shape[0], s.shape[1], device=dev), torch.empty(s.shape[0], ncand, device=dev))
+                fbufs[ln] = (torch.zeros(wsh * s.shape[0], s.shape[1], device=dev), torch.empty(s.shape[0], ncand, device=dev))
             gbuf, probs = fbufs[ln]
-            env.dist.all_gather_into_tensor(gbuf, s.contiguous())
-            lib.check(L.nir_softmax_gathered(lib.ptr(gbuf), lib.ptr(probs), None, world, s.shape[0], s.shape[1], ncand, lib.stream()),
+            env.dist.all_gather_into_tensor(gbuf[:s.shape[0]] if emu else gbuf, s.contiguous())
+            lib.check(L.nir_softmax_gathered(lib.ptr(gbuf), lib.ptr(probs), None, wsh, s.shape[0], s.shape[1], ncand, lib.stream()),
                       "nir_softmax_gathered")
             return probs
         full = sharding.gather_scores(s.cpu(), ncand).to(dev)
@@ -310,6 +322,8 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     torch.cuda.synchronize()
     graphs = None
     stages = None
+    if env.multi:
+        time.sleep(0.3)      # let the RCCL watchdog (100 ms poll) retire the finished warm-up collectives before any capture starts
     if staged:
         try:
             stages = []
@@ -318,18 +332,20 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 with torch.cuda.stream(ln):                     # warm (packs, workspaces), then capture both halves
                     pq, pl = model.shard_stage_a(ex, ex["_doc_shard"], ex["_len_shard"])
                     B_, S_, per_, D_ = pl.shape
-                    gbuf = torch.empty(world * B_ * S_, per_ * D_, device=dev, dtype=pl.dtype)
-                    env.dist.all_gather_into_tensor(gbuf, pl.reshape(B_ * S_, per_ * D_))
+                    gbuf = torch.zeros(wsh * B_ * S_, per_ * D_, device=dev, dtype=pl.dtype)
+                    gdst = gbuf[:B_ * S_] if emu else gbuf
+                    env.dist.all_gather_into_tensor(gdst, pl.reshape(B_ * S_, per_ * D_))
                     model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand)
                 torch.cuda.synchronize()
+                time.sleep(0.3)
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=ln):
+                with torch.cuda.graph(ga, stream=ln, capture_error_mode=CAPTURE_MODE):
                     pq, pl = model.shard_stage_a(ex, ex["_doc_shard"], ex["_len_shard"])
                     flat = pl.reshape(B_ * S_, per_ * D_)
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, stream=ln):
+                with torch.cuda.graph(gb, stream=ln, capture_error_mode=CAPTURE_MODE):
                     out = model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand)
-                stages.append((ga, flat, gbuf, gb, out))
+                stages.append((ga, flat, gdst, gb, out))
         except Exception as e:  # pragma: no cover - falls back to the eager sharded step
             print("[bench] staged graph capture unavailable for %s (%s); eager sharded steps" % (name, e), file=sys.stderr)
             stages = None
@@ -341,7 +357,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             graphs = []
             for i in range(len(batches)):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=lanes[lane_of(i)]):
+                with torch.cuda.graph(g, stream=lanes[lane_of(i)], capture_error_mode=CAPTURE_MODE):
                     out = forward(i)
                 graphs.append((g, out))
         except Exception as e:  # pragma: no cover - graph capture is an optimisation only
@@ -353,10 +369,14 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         ln = lane_of(i) if only_lane is None else only_lane
         if stages is not None:
             ga, flat, gbuf, gb, out = stages[i % len(stages)]
-            with torch.cuda.stream(lanes[lane_of(i)]):          # a captured graph replays on the lane it was captured on
-                ga.replay()
-                env.dist.all_gather_into_tensor(gbuf, flat)
-                gb.replay()
+            with torch.cuda.stream(lanes[ln]):
+                so = os.environ.get("BENCH_STAGE_ONLY", "agb")
+                if "a" in so:
+                    ga.replay()
+                if "g" in so:
+                    env.dist.all_gather_into_tensor(gbuf, flat)
+                if "b" in so:
+                    gb.replay()
             return out
         with torch.cuda.stream(lanes[ln]):
             if graphs is not None:
@@ -554,6 +574,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     env = Env()
+    for kv in filter(None, os.environ.get("NIR_TUNE", "").split(",")):     # kernel-variant A/B runs: NIR_TUNE=name=value,...
+        k, v = kv.split("=")
+        lib.check(lib.load().nir_debug_set_tunable(k.encode(), int(v)), "nir_debug_set_tunable")
     assert env.world == args.gpus or env.world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     head = dict(CONFIGS[args.config])
     adhoc = False

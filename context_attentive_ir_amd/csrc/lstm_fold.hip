@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     const int mylen = lens_s[sq];
 
     f16x8 w1[NT][KB], w2[NT][KB];
-    float creg[NT], hreg[NT];
+    float creg[NT];
     int unit_d[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -464,16 +464,17 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
             }
         unit_d[t] = 4 * tile + kq;
         creg[t] = 0.f;
-        hreg[t] = 0.f;
     }
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
                                                                              (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
     const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;
-    auto load_g = [&](int step, f32x4 (&dst)[NT]) {
+    auto id_of = [&](int step) {
         int s_ = min(step, mylen - 1);
         s_ = s_ < 0 ? 0 : s_;
         const int t_ = dir == 0 ? s_ : mylen - 1 - s_;
-        const int id = ids_s[sq * T + (t_ < 0 ? 0 : t_)];
+        return ids_s[sq * T + (t_ < 0 ? 0 : t_)];
+    };
+    auto load_g = [&](int id, f32x4 (&dst)[NT]) {
         const float* row = ptf + (int64_t)id * GW;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -481,19 +482,32 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
             dst[t] = *reinterpret_cast<const f32x4*>(row + 4 * u);
         }
     };
+    // The rows of step t+1 are requested at the top of step t, right after the rows of step t (requested one step earlier) have been
+    // taken over as the MFMA C operand: the only s_waitcnt vmcnt in the loop sits at that hand-over and covers requests that are a
+    // whole step old.  (Waiting at the END of the step made the waitcnt pass merge "step 0's rows may be in flight" into the loop
+    // header and wait for the NEXT step's rows in front of the first MFMA: +18 % on the H = 70 kernel.)
+    // The id of step t+1 is looked up (LDS) a step early and its rows are requested after the first k-block of MFMAs has been issued:
+    // with lookup + request at the top of the step, an LDS round trip and the 64-bit address arithmetic sat in front of the h reads.
     f32x4 gcur[NT], gnext[NT];
-    load_g(0, gcur);
-
+    load_g(id_of(0), gnext);
+    int id_n = id_of(1);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)                     // NT dropped stores behind the first requests: the loop-entry and back-edge states match
+        __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
     for (int step = 0; step < tmax; ++step) {
         const _Float16* zc = z + (step & 1) * 2 * SEQ * ZLD;
         _Float16* zn = z + ((step + 1) & 1) * 2 * SEQ * ZLD;
-        load_g(step + 1, gnext);                     // lands during this step (4 waves per SIMD cover an occasional late row)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            asm volatile("" : "+v"(gnext[t]));       // pins the hand-over (and its wait) to this point
+            gcur[t] = gnext[t];
+        }
         const bool live = step < mylen;
         const int tt = dir == 0 ? step : mylen - 1 - step;
         const _Float16* zr = zc + sq * ZLD + 8 * kq;
         f32x4 acc[NT], acx[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int t = 0; t < NT; ++t) { acc[t] = gcur[t]; acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }   // the gate rows ride in as the MFMA's C operand
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {            // h terms are read per k-block (8 live VGPRs instead of 8*KB)
             const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
@@ -504,31 +518,39 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
                 acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h2, acx[t], 0, 0, 0);
                 acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], h1, acx[t], 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (NT * wave + t < ntiles) {            // wave-uniform
-                const bool dv = unit_d[t] < H;
-                const float gi = fast_sigmoid(fmaf(acx[t][0], ISC, acc[t][0]) + gcur[t][0]);
-                const float gf = fast_sigmoid(fmaf(acx[t][1], ISC, acc[t][1]) + gcur[t][1]);
-                const float gg = fast_tanh(fmaf(acx[t][2], ISC, acc[t][2]) + gcur[t][2]);
-                const float go = fast_sigmoid(fmaf(acx[t][3], ISC, acc[t][3]) + gcur[t][3]);
-                const float cn = gf * creg[t] + gi * gg;
-                const float hn = go * fast_tanh(cn);
-                const bool act = dv && live;
-                creg[t] = act ? cn : creg[t];
-                hreg[t] = act ? hn : hreg[t];
-                if (dv) {
-                    const _Float16 a = (_Float16)hreg[t];
-                    zn[sq * ZLD + unit_d[t]] = a;
-                    zn[SEQ * ZLD + sq * ZLD + unit_d[t]] = (_Float16)((hreg[t] - (float)a) * SC);
-                }
-                const uint32_t off = act ? (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn), out_rs, off, 0, 0);
+            if (kb == 0) {
+                load_g(id_n, gnext);
+                id_n = id_of(step + 2);
             }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) gcur[t] = gnext[t];
+        for (int t = 0; t < NT; ++t) {
+            uint32_t off = OOB;
+            float hv = 0.f;
+            if (NT * wave + t < ntiles) {            // wave-uniform
+                const bool dv = unit_d[t] < H;
+                const float gi = fast_sigmoid(fmaf(acx[t][0], ISC, acc[t][0]));
+                const float gf = fast_sigmoid(fmaf(acx[t][1], ISC, acc[t][1]));
+                const float gg = fast_tanh(fmaf(acx[t][2], ISC, acc[t][2]));
+                const float go = fast_sigmoid(fmaf(acx[t][3], ISC, acc[t][3]));
+                const float cn = gf * creg[t] + gi * gg;
+                const float hn = go * fast_tanh(cn);
+                // no hold for finished sequences: a sequence's column of the B operand only feeds its own gates, and nothing of a
+                // finished sequence is stored again (its padded outputs are zero-filled below), in either direction
+                creg[t] = cn;
+                if (dv) {
+                    const _Float16 a = (_Float16)hn;
+                    zn[sq * ZLD + unit_d[t]] = a;
+                    zn[SEQ * ZLD + sq * ZLD + unit_d[t]] = (_Float16)((hn - (float)a) * SC);
+                }
+                if (dv && live) off = (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u;
+                hv = hn;
+            }
+            // one store per tile on every path (out-of-range offset = dropped), at the end of its own step: the waitcnt pass can then
+            // count the NT stores behind the row requests and the hand-over at the top of the next step waits for the rows only.
+            // (Deferring the store to the next step measured 7-9 % slower: its address arithmetic then sits in front of the h reads.)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), out_rs, off, 0, 0);
+        }
         lds_barrier();
     }
 #pragma unroll

@@ -54,7 +54,7 @@ class GraphedPredictor(object):
                 self._call()
             self.stream.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may query events
                 self.out = self._call()
 
     def pack(self, ex, pin=True):
