@@ -30,7 +30,7 @@ int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const
 // cars_attn.hip
 bool attn_pool_fused_usable(int D, int T);
 int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, const float* w3, const float* b3, const int64_t* lens, int64_t M,
-                           int T, float* pooled, hipStream_t st);
+                           int T, float* pooled, int one_term, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------------
 // attention pooling: one wave per sequence; logits [M,T], h [M,T,D] (D % 4 == 0, D <= 1024)
@@ -199,7 +199,7 @@ extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, i
     NIR_PROPAGATE(launch_bilstm_folded(folded, dtype, ids, lens, w->whh, enc, err_flag, M, V, T, H, 2, st));
     // enc = o * tanh(c) lies in (-1,1); the attention weights are bounded (checked by the host when it packs them)
     if (w->attn_frag && w->bounded && attn_pool_fused_usable(D, T) && !tun(g_tun.attn_unfused) && !tun(g_tun.exact_f32))
-        return launch_attn_pool_fused(enc, w->attn_frag, w->attn0_b, w->attn3_w, w->attn3_b, lens, M, T, pooled, st);
+        return launch_attn_pool_fused(enc, w->attn_frag, w->attn0_b, w->attn3_w, w->attn3_b, lens, M, T, pooled, dtype == NIR_DTYPE_BF16, st);
     NIR_PROPAGATE(launch_linear_ex(enc, D, nullptr, nullptr, 0, 0, 0, w->attn0_w, D, w->attn0_b, nullptr, p.lpart, NP, M * T, D, D,
                                    ACT_TANH_ROWDOT16 | (w->bounded ? ACT_BOUNDED : 0), w->attn3_w, 0, st));
     {

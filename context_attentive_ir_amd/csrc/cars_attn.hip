@@ -269,14 +269,19 @@ __device__ long long ap_dbg[16];
 #endif
 constexpr size_t AP2_LDS = (size_t)2 * AP_PLANE_HALVES * 2 + (2 * 4 * 64 + 4 * 64) * 4;
 
+template <bool ONE>
 __device__ __forceinline__ void ap2_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32x4 (&acx)[AP_CT][AP_RT], const f16x8 (&af)[AP_RT][2],
                                           const f16x8 (&w)[AP_CT][2]) {
     const int i = n / (3 * AP_CT), ph = (n / AP_CT) % 3, j = n % AP_CT;      // row tile outermost
-    if (ph == 0) AP_MMA(acx[j][i], af[i][1], w[j][0]);
-    else if (ph == 1) AP_MMA(acx[j][i], af[i][0], w[j][1]);
-    else AP_MMA(acc[j][i], af[i][0], w[j][0]);
+    if (ph == 2) AP_MMA(acc[j][i], af[i][0], w[j][0]);
+    else if (ONE) return;                                                      // leading fp16 term only (bf16 encoders)
+    else if (ph == 0) AP_MMA(acx[j][i], af[i][1], w[j][0]);
+    else AP_MMA(acx[j][i], af[i][0], w[j][1]);
 }
 
+// ONE: the encoder runs in bf16 (bf16 folded table + bf16 recurrence): h and W0 enter the attention MLP as single fp16 terms (11
+// mantissa bits, still 3 more than the bf16 operands upstream) -- one MFMA per fragment pair instead of three, one term plane.
+template <bool ONE>
 __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, int64_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned short asm2_[];
     constexpr int KG = AP_KG;
@@ -292,15 +297,22 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
 
     if (mma_role) {
         // ================================================= MMA waves =================================================
-        const _Float16* wp = p.wf + ((int64_t)(AP_CT * w4) * 2 * 64 + lane) * 8;
+        // W fragments are addressed as (wave-uniform base + compile-time offset) + one 32-bit lane offset: with a per-lane 64-bit
+        // pointer the unrolled last k-steps kept one precomputed pointer per fragment live across the tile loop, 25 registers went to
+        // scratch and every reload carried an s_waitcnt vmcnt(0) into the MFMA stream (12 per tile)
+        const _Float16* wbase = p.wf + (int64_t)(AP_CT * __builtin_amdgcn_readfirstlane(w4)) * 2 * 64 * 8;
+        uint32_t wlane = (uint32_t)lane * 16u;                       // bytes; made opaque once per k-step (below) so that the addresses
+        auto ldw = [&](int off_halves) {                             // are recomputed (2 VALU) instead of hoisted out of the tile loop
+            return *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(wbase + off_halves) + (uint64_t)wlane);
+        };
         constexpr int WSTEP = 16 * 2 * 64 * 8;
         const int foff = g * KG + c16 * 8;
         f16x8 wa[AP_CT][2], wb[AP_CT][2], af[AP_RT][2];
         f32x4 acc[AP_CT][AP_RT], acx[AP_CT][AP_RT];
 #pragma unroll
         for (int j = 0; j < AP_CT; ++j) {
-            wa[j][0] = *reinterpret_cast<const f16x8*>(wp + (j * 2) * 512);
-            wa[j][1] = *reinterpret_cast<const f16x8*>(wp + (j * 2 + 1) * 512);
+            wa[j][0] = ldw((j * 2) * 512);
+            wa[j][1] = ldw((j * 2 + 1) * 512);
         }
         for (int64_t it = 0; it < nk + 2; ++it) {
             if (w4 == 0) { AP_T(0) }
@@ -325,14 +337,14 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
 #define AP2_STEP(S, WC, WN, LAST)                                                         \
                 {                                                                         \
                     const int sn_ = ((S) + 1) & (AP_S - 1);                               \
-                    const _Float16* wn_ = wp + (int64_t)sn_ * WSTEP;                      \
+                    asm volatile("" : "+v"(wlane));                                       \
                     const unsigned short* pc_ = Pp + (S) * 4 * KG + foff;                 \
                     const unsigned short* pn_ = Pp + sn_ * 4 * KG + foff;                 \
                     _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 3 * AP_RT * AP_CT; ++n_) { \
-                        ap2_mma_n(n_, acc, acx, af, WC);                                  \
+                        ap2_mma_n<ONE>(n_, acc, acx, af, WC);                             \
                         if (n_ % 6 == 2 && n_ / 6 < 2 * AP_CT) {                          \
                             asm volatile("" ::"v"(WN[(n_ / 6) >> 1][(n_ / 6) & 1]));      \
-                            WN[(n_ / 6) >> 1][(n_ / 6) & 1] = *reinterpret_cast<const f16x8*>(wn_ + (n_ / 6) * 512); \
+                            WN[(n_ / 6) >> 1][(n_ / 6) & 1] = ldw(sn_ * WSTEP + (n_ / 6) * 512);  \
                         }                                                                 \
                         if (n_ == 7 || n_ == 8) {                                         \
                             asm volatile("" ::"v"(af[3][n_ - 7]));                        \
@@ -444,14 +456,21 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                 for (int q = 0; q < 16; ++q) {
                     const int row = 4 * q + sub;
                     const uint2 u1 = *reinterpret_cast<const uint2*>(Pb + row * 8);
-                    const uint2 u2 = *reinterpret_cast<const uint2*>(Pb + AP_S * 4 * KG + row * 8);
                     const fp16x2_t a01 = __builtin_bit_cast(fp16x2_t, u1.x), a23 = __builtin_bit_cast(fp16x2_t, u1.y);
-                    const fp16x2_t b01 = __builtin_bit_cast(fp16x2_t, u2.x), b23 = __builtin_bit_cast(fp16x2_t, u2.y);
                     const float pr = pw[row];
-                    a.x = fmaf(pr, fmaf((float)b01[0], 1.0f / 2048.0f, (float)a01[0]), a.x);
-                    a.y = fmaf(pr, fmaf((float)b01[1], 1.0f / 2048.0f, (float)a01[1]), a.y);
-                    a.z = fmaf(pr, fmaf((float)b23[0], 1.0f / 2048.0f, (float)a23[0]), a.z);
-                    a.w = fmaf(pr, fmaf((float)b23[1], 1.0f / 2048.0f, (float)a23[1]), a.w);
+                    if (ONE) {
+                        a.x = fmaf(pr, (float)a01[0], a.x);
+                        a.y = fmaf(pr, (float)a01[1], a.y);
+                        a.z = fmaf(pr, (float)a23[0], a.z);
+                        a.w = fmaf(pr, (float)a23[1], a.w);
+                    } else {
+                        const uint2 u2 = *reinterpret_cast<const uint2*>(Pb + AP_S * 4 * KG + row * 8);
+                        const fp16x2_t b01 = __builtin_bit_cast(fp16x2_t, u2.x), b23 = __builtin_bit_cast(fp16x2_t, u2.y);
+                        a.x = fmaf(pr, fmaf((float)b01[0], 1.0f / 2048.0f, (float)a01[0]), a.x);
+                        a.y = fmaf(pr, fmaf((float)b01[1], 1.0f / 2048.0f, (float)a01[1]), a.y);
+                        a.z = fmaf(pr, fmaf((float)b23[0], 1.0f / 2048.0f, (float)a23[0]), a.z);
+                        a.w = fmaf(pr, fmaf((float)b23[1], 1.0f / 2048.0f, (float)a23[1]), a.w);
+                    }
                     if ((q + 1) % per == 0) {              // sequence complete: fold the four row subgroups, subgroup 0 stores
                         a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
                         a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
@@ -467,11 +486,13 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                 for (int q = 0; q < 16; ++q) {
                     const float4 v = ld[q];
                     const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-                    const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz((v.x - (float)a01[0]) * 2048.0f, (v.y - (float)a01[1]) * 2048.0f);
-                    const fp16x2_t b23 = __builtin_amdgcn_cvt_pkrtz((v.z - (float)a23[0]) * 2048.0f, (v.w - (float)a23[1]) * 2048.0f);
                     unsigned short* d = Pb + (4 * q + sub) * 8;
                     *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
-                    *reinterpret_cast<uint2*>(d + AP_S * 4 * KG) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+                    if (!ONE) {
+                        const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz((v.x - (float)a01[0]) * 2048.0f, (v.y - (float)a01[1]) * 2048.0f);
+                        const fp16x2_t b23 = __builtin_amdgcn_cvt_pkrtz((v.z - (float)a23[0]) * 2048.0f, (v.w - (float)a23[1]) * 2048.0f);
+                        *reinterpret_cast<uint2*>(d + AP_S * 4 * KG) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+                    }
                 }
                 if (w4 == 0) { AP_T(6) }
                 if (it + 1 < nk) load_rows(it + 1);
@@ -490,7 +511,7 @@ namespace nir {
 bool attn_pool_fused_usable(int D, int T) { return D == AP_D && (T == 4 || T == 8 || T == 16 || T == 32 || T == 64); }
 
 int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, const float* w3, const float* b3, const int64_t* lens, int64_t M,
-                           int T, float* pooled, hipStream_t st) {
+                           int T, float* pooled, int one_term, hipStream_t st) {
     NIR_REQUIRE(h && wfrag && b0 && w3 && b3 && pooled && attn_pool_fused_usable(AP_D, T), "attn_pool_fused: bad args (T=%d)", T);
     if (M == 0) return 0;
     AttnPoolArgs a;
@@ -502,7 +523,8 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     static int ncu = 0;
     static std::once_flag once2;
     std::call_once(once2, [] {
-        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -510,7 +532,8 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     });
     const int pipe = tun(g_tun.attn_unfused_pipe);     // 0: by size, 1: never, 2: always (tests)
     if ((tiles >= 2 * (int64_t)ncu && pipe == 0) || pipe == 2) {          // several tiles per CU: the role-specialised pipeline
-        hipLaunchKernelGGL(attn_pool_pipe_kernel, dim3((unsigned)std::min<int64_t>(tiles, ncu)), dim3(512), AP2_LDS, st, a, tiles);
+        if (one_term) hipLaunchKernelGGL(attn_pool_pipe_kernel<true>, dim3((unsigned)std::min<int64_t>(tiles, ncu)), dim3(512), AP2_LDS, st, a, tiles);
+        else hipLaunchKernelGGL(attn_pool_pipe_kernel<false>, dim3((unsigned)std::min<int64_t>(tiles, ncu)), dim3(512), AP2_LDS, st, a, tiles);
     } else {
         hipLaunchKernelGGL(attn_pool_fused_kernel, dim3((unsigned)tiles), dim3(256), AP_LDS, st, a);
     }

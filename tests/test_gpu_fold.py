@@ -217,3 +217,28 @@ def test_bilstm_folded_four_wave_variant_matches():
                                                         None, M, V, T_, H, 2, lib.stream()), "folded")
         outs.append(out)
     _close(outs[0], outs[1], 1e-6)
+
+
+def test_cars_bf16_single_term_attention_pipeline():
+    """bf16 encoders hand the attention MLP single fp16 terms in the pipelined kernel (csrc/cars_attn.hip, ONE = true; bench-size
+    launches select the pipeline by tile count, here it is forced with attn_unfused_pipe = 2).  The pooled vectors stay within fp16
+    rounding of the three-term result (|h| < 1: 2^-11 absolute on the weighted sum, plus the logit perturbation), and the scores stay
+    inside the bf16 bound against the fp32 oracle."""
+    from context_attentive_ir_amd import lib, synth
+    V, B, S, N, QL, DL = 3000, 3, 4, 9, 4, 64
+    m = build_model("CARS", vocab=V, device=DEV)
+    m.compute_dtype = "bf16"
+    ex = synth.session_batch(B, S, N, QL, DL, V, seed=11, full_length=False)
+    dex = {k: v.to(DEV) for k, v in ex.items()}
+    with lib.tunable("attn_unfused_pipe", 1, 0):
+        d3 = m.encode_document(dex["document_words"], dex["document_lens"])
+    with lib.tunable("attn_unfused_pipe", 2, 0):
+        d1 = m.encode_document(dex["document_words"], dex["document_lens"])
+        pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
+        s, _, _ = m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"])
+    assert float((d1 - d3).abs().max()) > 0.0          # the single-term variant really ran
+    _close(d1, d3, 2e-3)
+    ref = O.cars_scores(cpu_state_dict(m), ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"],
+                        ex["document_labels"])
+    assert float((s.cpu() - ref).abs().max()) <= BF16_SCORE_TOL
+    _close(torch.softmax(s.cpu(), -1), torch.softmax(ref, -1), BF16_PROB_TOL)
