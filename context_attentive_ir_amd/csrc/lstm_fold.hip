@@ -274,7 +274,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
     const int mylen = lens_s[sq];
 
     bf16x8 wreg[NT][KB];
-    float creg[NT], hreg[NT];
+    float creg[NT];
     int unit_d[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -282,25 +282,43 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
         const int unit_a = 4 * tile + (sq >> 2), gate_a = sq & 3;
         const bool av = unit_a < H;
         const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0)) * H;
+        // the lane's 8*KB weights of this tile as 2*KB independent 16-byte loads (a scalar load -> convert loop serialises 64 memory
+        // round trips: ~35 us of prologue per workgroup, a quarter of a 64-step workgroup's life at the C5 shape)
+        const bool vec_ok = (H % 8) == 0 && ((reinterpret_cast<uintptr_t>(wr) & 15) == 0);
+        if (vec_ok) {                                         // wave-uniform
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 32 * kb + 8 * kq + j;
-                wreg[t][kb][j] = (short)f2bf(wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f));
+            for (int kb = 0; kb < KB; ++kb) {
+                const int k0 = 32 * kb + 8 * kq;
+                const int kc = k0 + 8 <= H ? k0 : 0;           // branch-free: out-of-range chunks re-read chunk 0 and are zeroed below
+                const float4 a = *reinterpret_cast<const float4*>(wr + kc), b = *reinterpret_cast<const float4*>(wr + kc + 4);
+                const float m = (av && k0 + 8 <= H) ? 1.f : 0.f;
+                wreg[t][kb][0] = (short)f2bf(a.x * m); wreg[t][kb][1] = (short)f2bf(a.y * m);
+                wreg[t][kb][2] = (short)f2bf(a.z * m); wreg[t][kb][3] = (short)f2bf(a.w * m);
+                wreg[t][kb][4] = (short)f2bf(b.x * m); wreg[t][kb][5] = (short)f2bf(b.y * m);
+                wreg[t][kb][6] = (short)f2bf(b.z * m); wreg[t][kb][7] = (short)f2bf(b.w * m);
             }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * kb + 8 * kq + j;
+                    wreg[t][kb][j] = (short)f2bf(wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f));
+                }
+        }
         unit_d[t] = 4 * tile + kq;
         creg[t] = 0.f;
-        hreg[t] = 0.f;
     }
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
                                                                              (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
     const unsigned short* pth = reinterpret_cast<const unsigned short*>(p.pt) + (int64_t)dir * H4;
-    auto load_g = [&](int step, uint2 (&dst)[NT]) {
+    auto id_of = [&](int step) {
         int s_ = min(step, mylen - 1);
         s_ = s_ < 0 ? 0 : s_;
         const int t_ = dir == 0 ? s_ : mylen - 1 - s_;
-        const int id = ids_s[sq * T + (t_ < 0 ? 0 : t_)];
+        return ids_s[sq * T + (t_ < 0 ? 0 : t_)];
+    };
+    auto load_g = [&](int id, uint2 (&dst)[NT]) {
         const unsigned short* row = pth + (int64_t)id * GW;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -308,45 +326,62 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
             dst[t] = *reinterpret_cast<const uint2*>(row + 4 * u);
         }
     };
-    uint2 gcur[NT], gnext[NT], gnext2[NT];
-    load_g(0, gcur);
-    load_g(1, gnext);
+    // Same step structure as lstm16_pt_h2_kernel below: the gate rows of step t are handed over at the top of step t (the only vmcnt
+    // wait of the loop, on a request that is two steps old -- a bf16 step is shorter than an HBM round trip) and ride in as the MFMA C
+    // operand; the rows of step t+2 are requested under the MFMA phase from an id looked up one step earlier; every path issues NT stores
+    // per step (out-of-range offset = dropped) so the waitcnt pass can count them; no hold registers for finished sequences.
+    uint2 ga[NT], gb[NT];
+    load_g(id_of(0), ga);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
+    load_g(id_of(1), gb);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
+    int id_n = id_of(2);
 
     for (int step = 0; step < tmax; ++step) {
         const unsigned short* zc = z + (step & 1) * SEQ * ZLD;
         unsigned short* zn = z + ((step + 1) & 1) * SEQ * ZLD;
-        load_g(step + 2, gnext2);                    // two steps ahead: a bf16 step is shorter than an HBM round trip
-        const bool live = step < mylen;
-        const int tt = dir == 0 ? step : mylen - 1 - step;
-        bf16x8 hb[KB];
-        const unsigned short* zr = zc + sq * ZLD + 8 * kq;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) hb[kb] = *reinterpret_cast<const bf16x8*>(zr + 32 * kb);
+        f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (NT * wave + t < ntiles) {            // wave-uniform
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+v"(ga[t].x), "+v"(ga[t].y));     // pins the hand-over (and its wait) to this point
+            acc[t] = (f32x4){bf2f((unsigned short)(ga[t].x & 0xFFFFu)), bf2f((unsigned short)(ga[t].x >> 16)),
+                             bf2f((unsigned short)(ga[t].y & 0xFFFFu)), bf2f((unsigned short)(ga[t].y >> 16))};
+            ga[t] = gb[t];
+        }
+        const bool live = step < mylen;
+        const int tt = dir == 0 ? step : mylen - 1 - step;
+        const unsigned short* zr = zc + sq * ZLD + 8 * kq;
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][kb], hb[kb], acc, 0, 0, 0);
-                const bool dv = unit_d[t] < H;
-                const float xi = bf2f((unsigned short)(gcur[t].x & 0xFFFFu)), xf = bf2f((unsigned short)(gcur[t].x >> 16));
-                const float xg = bf2f((unsigned short)(gcur[t].y & 0xFFFFu)), xo = bf2f((unsigned short)(gcur[t].y >> 16));
-                const float gi = fast_sigmoid(acc[0] + xi);
-                const float gf = fast_sigmoid(acc[1] + xf);
-                const float gg = fast_tanh(acc[2] + xg);
-                const float go = fast_sigmoid(acc[3] + xo);
-                const float cn = gf * creg[t] + gi * gg;
-                const float hn = go * fast_tanh(cn);
-                const bool act = dv && live;
-                creg[t] = act ? cn : creg[t];
-                hreg[t] = act ? hn : hreg[t];
-                if (dv) zn[sq * ZLD + unit_d[t]] = f2bf(hreg[t]);
-                const uint32_t off = act ? (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn), out_rs, off, 0, 0);
+        for (int kb = 0; kb < KB; ++kb) {
+            const bf16x8 hb = *reinterpret_cast<const bf16x8*>(zr + 32 * kb);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][kb], hb, acc[t], 0, 0, 0);
+            if (kb == 0) {
+                load_g(id_n, gb);
+                id_n = id_of(step + 3);
             }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { gcur[t] = gnext[t]; gnext[t] = gnext2[t]; }
+        for (int t = 0; t < NT; ++t) {
+            uint32_t off = OOB;
+            float hv = 0.f;
+            if (NT * wave + t < ntiles) {            // wave-uniform
+                const bool dv = unit_d[t] < H;
+                const float gi = fast_sigmoid(acc[t][0]);
+                const float gf = fast_sigmoid(acc[t][1]);
+                const float gg = fast_tanh(acc[t][2]);
+                const float go = fast_sigmoid(acc[t][3]);
+                const float cn = gf * creg[t] + gi * gg;
+                const float hn = go * fast_tanh(cn);
+                creg[t] = cn;
+                if (dv) zn[sq * ZLD + unit_d[t]] = f2bf(hn);
+                if (dv && live) off = (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u;
+                hv = hn;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), out_rs, off, 0, 0);
+        }
         lds_barrier();
     }
 #pragma unroll
