@@ -240,39 +240,10 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sq = lane & 15, kq = lane >> 4;
     const int dir = blockIdx.y;
-    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
     const int H = p.H, T = p.T, H4 = 4 * H;
-    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
     const int OW = p.ND * H;
     const int64_t GW = (int64_t)p.ND * H4;
     const int ntiles = (H + 3) / 4;
-
-    if (tid < SEQ) {
-        int l = 0;
-        if (tid < nvalid) {
-            l = p.lens ? (int)p.lens[m0 + tid] : T;
-            l = l < 0 ? 0 : (l > T ? T : l);
-        }
-        lens_s[tid] = l;
-    }
-    {
-        bool bad = false;
-        for (int e = tid; e < SEQ * T; e += 1024) {
-            const int s = e / T;
-            int64_t id = 0;
-            if (s < nvalid) id = p.ids[m0 * T + e];
-            if (id < 0 || id >= p.V) { bad = true; id = 0; }
-            ids_s[e] = (int)id;
-        }
-        if (bad && p.err) atomicOr(p.err, 1);
-    }
-    for (int e = tid; e < SEQ * ZLD; e += 1024) reinterpret_cast<unsigned*>(z)[e] = 0u;   // both buffers (2*SEQ*ZLD bf16)
-    __syncthreads();
-    int tmax = 0;
-#pragma unroll
-    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
-    const int mylen = lens_s[sq];
-
     bf16x8 wreg[NT][KB];
     float creg[NT];
     int unit_d[NT];
@@ -307,88 +278,123 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
                 }
         }
         unit_d[t] = 4 * tile + kq;
-        creg[t] = 0.f;
     }
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
-                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
-    const unsigned short* pth = reinterpret_cast<const unsigned short*>(p.pt) + (int64_t)dir * H4;
-    auto id_of = [&](int step) {
-        int s_ = min(step, mylen - 1);
-        s_ = s_ < 0 ? 0 : s_;
-        const int t_ = dir == 0 ? s_ : mylen - 1 - s_;
-        return ids_s[sq * T + (t_ < 0 ? 0 : t_)];
-    };
-    auto load_g = [&](int id, uint2 (&dst)[NT]) {
-        const unsigned short* row = pth + (int64_t)id * GW;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int u = unit_d[t] < H ? unit_d[t] : H - 1;
-            dst[t] = *reinterpret_cast<const uint2*>(row + 4 * u);
-        }
-    };
-    // Same step structure as lstm16_pt_h2_kernel below: the gate rows of step t are handed over at the top of step t (the only vmcnt
-    // wait of the loop, on a request that is two steps old -- a bf16 step is shorter than an HBM round trip) and ride in as the MFMA C
-    // operand; the rows of step t+2 are requested under the MFMA phase from an id looked up one step earlier; every path issues NT stores
-    // per step (out-of-range offset = dropped) so the waitcnt pass can count them; no hold registers for finished sequences.
-    uint2 ga[NT], gb[NT];
-    load_g(id_of(0), ga);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
-    load_g(id_of(1), gb);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
-    int id_n = id_of(2);
+    // persistent over sequence tiles: W_hh is fetched and converted once per workgroup, not once per 16 sequences (the launcher sizes the
+    // grid to the CU count when the tiles outnumber it)
+    for (int64_t mt = blockIdx.x; mt * SEQ < p.M; mt += gridDim.x) {
+        __syncthreads();                                 // the previous tile's last readers of lens_s / ids_s are done
+        const int64_t m0 = mt * SEQ;
+        const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
 
-    for (int step = 0; step < tmax; ++step) {
-        const unsigned short* zc = z + (step & 1) * SEQ * ZLD;
-        unsigned short* zn = z + ((step + 1) & 1) * SEQ * ZLD;
-        f32x4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            asm volatile("" : "+v"(ga[t].x), "+v"(ga[t].y));     // pins the hand-over (and its wait) to this point
-            acc[t] = (f32x4){bf2f((unsigned short)(ga[t].x & 0xFFFFu)), bf2f((unsigned short)(ga[t].x >> 16)),
-                             bf2f((unsigned short)(ga[t].y & 0xFFFFu)), bf2f((unsigned short)(ga[t].y >> 16))};
-            ga[t] = gb[t];
-        }
-        const bool live = step < mylen;
-        const int tt = dir == 0 ? step : mylen - 1 - step;
-        const unsigned short* zr = zc + sq * ZLD + 8 * kq;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const bf16x8 hb = *reinterpret_cast<const bf16x8*>(zr + 32 * kb);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][kb], hb, acc[t], 0, 0, 0);
-            if (kb == 0) {
-                load_g(id_n, gb);
-                id_n = id_of(step + 3);
+        if (tid < SEQ) {
+            int l = 0;
+            if (tid < nvalid) {
+                l = p.lens ? (int)p.lens[m0 + tid] : T;
+                l = l < 0 ? 0 : (l > T ? T : l);
             }
+            lens_s[tid] = l;
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            uint32_t off = OOB;
-            float hv = 0.f;
-            if (NT * wave + t < ntiles) {            // wave-uniform
-                const bool dv = unit_d[t] < H;
-                const float gi = fast_sigmoid(acc[t][0]);
-                const float gf = fast_sigmoid(acc[t][1]);
-                const float gg = fast_tanh(acc[t][2]);
-                const float go = fast_sigmoid(acc[t][3]);
-                const float cn = gf * creg[t] + gi * gg;
-                const float hn = go * fast_tanh(cn);
-                creg[t] = cn;
-                if (dv) zn[sq * ZLD + unit_d[t]] = f2bf(hn);
-                if (dv && live) off = (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u;
-                hv = hn;
+        {
+            bool bad = false;
+            for (int e = tid; e < SEQ * T; e += 1024) {
+                const int s = e / T;
+                int64_t id = 0;
+                if (s < nvalid) id = p.ids[m0 * T + e];
+                if (id < 0 || id >= p.V) { bad = true; id = 0; }
+                ids_s[e] = (int)id;
             }
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), out_rs, off, 0, 0);
+            if (bad && p.err) atomicOr(p.err, 1);
         }
-        lds_barrier();
-    }
+        for (int e = tid; e < SEQ * ZLD; e += 1024) reinterpret_cast<unsigned*>(z)[e] = 0u;   // both buffers (2*SEQ*ZLD bf16)
+        __syncthreads();
+        int tmax = 0;
+    #pragma unroll
+        for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+        const int mylen = lens_s[sq];
+
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (unit_d[t] < H && sq < nvalid) {
-            const int64_t m = m0 + sq;
-            for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
+        for (int t = 0; t < NT; ++t) creg[t] = 0.f;
+        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
+                                                                                 (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+        const unsigned short* pth = reinterpret_cast<const unsigned short*>(p.pt) + (int64_t)dir * H4;
+        auto id_of = [&](int step) {
+            int s_ = min(step, mylen - 1);
+            s_ = s_ < 0 ? 0 : s_;
+            const int t_ = dir == 0 ? s_ : mylen - 1 - s_;
+            return ids_s[sq * T + (t_ < 0 ? 0 : t_)];
+        };
+        auto load_g = [&](int id, uint2 (&dst)[NT]) {
+            const unsigned short* row = pth + (int64_t)id * GW;
+    #pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int u = unit_d[t] < H ? unit_d[t] : H - 1;
+                dst[t] = *reinterpret_cast<const uint2*>(row + 4 * u);
+            }
+        };
+        // Same step structure as lstm16_pt_h2_kernel below: the gate rows of step t are handed over at the top of step t (the only vmcnt
+        // wait of the loop, on a request that is two steps old -- a bf16 step is shorter than an HBM round trip) and ride in as the MFMA C
+        // operand; the rows of step t+2 are requested under the MFMA phase from an id looked up one step earlier; every path issues NT stores
+        // per step (out-of-range offset = dropped) so the waitcnt pass can count them; no hold registers for finished sequences.
+        uint2 ga[NT], gb[NT];
+        load_g(id_of(0), ga);
+    #pragma unroll
+        for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
+        load_g(id_of(1), gb);
+    #pragma unroll
+        for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
+        int id_n = id_of(2);
+
+        for (int step = 0; step < tmax; ++step) {
+            const unsigned short* zc = z + (step & 1) * SEQ * ZLD;
+            unsigned short* zn = z + ((step + 1) & 1) * SEQ * ZLD;
+            f32x4 acc[NT];
+    #pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                asm volatile("" : "+v"(ga[t].x), "+v"(ga[t].y));     // pins the hand-over (and its wait) to this point
+                acc[t] = (f32x4){bf2f((unsigned short)(ga[t].x & 0xFFFFu)), bf2f((unsigned short)(ga[t].x >> 16)),
+                                 bf2f((unsigned short)(ga[t].y & 0xFFFFu)), bf2f((unsigned short)(ga[t].y >> 16))};
+                ga[t] = gb[t];
+            }
+            const bool live = step < mylen;
+            const int tt = dir == 0 ? step : mylen - 1 - step;
+            const unsigned short* zr = zc + sq * ZLD + 8 * kq;
+    #pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const bf16x8 hb = *reinterpret_cast<const bf16x8*>(zr + 32 * kb);
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][kb], hb, acc[t], 0, 0, 0);
+                if (kb == 0) {
+                    load_g(id_n, gb);
+                    id_n = id_of(step + 3);
+                }
+            }
+    #pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint32_t off = OOB;
+                float hv = 0.f;
+                if (NT * wave + t < ntiles) {            // wave-uniform
+                    const bool dv = unit_d[t] < H;
+                    const float gi = fast_sigmoid(acc[t][0]);
+                    const float gf = fast_sigmoid(acc[t][1]);
+                    const float gg = fast_tanh(acc[t][2]);
+                    const float go = fast_sigmoid(acc[t][3]);
+                    const float cn = gf * creg[t] + gi * gg;
+                    const float hn = go * fast_tanh(cn);
+                    creg[t] = cn;
+                    if (dv) zn[sq * ZLD + unit_d[t]] = f2bf(hn);
+                    if (dv && live) off = (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u;
+                    hv = hn;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), out_rs, off, 0, 0);
+            }
+            lds_barrier();
+        }
+    #pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (unit_d[t] < H && sq < nvalid) {
+                const int64_t m = m0 + sq;
+                for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
+            }
         }
     }
 }
@@ -616,12 +622,24 @@ static int launch_pt(const LstmPtArgs& p, hipStream_t st) {
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f32]");
     return 0;
 }
+static int cu_count() {
+    static const int ncu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }();
+    return ncu;
+}
+
 template <int KB, int NT>
 static int launch_pt_bf16(const LstmPtArgs& p, hipStream_t st) {
     static const std::string pname = "lstm16_pt_bf16_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + ">";
     const size_t lds = (size_t)(2 * 16 * (32 * KB + 8)) * 2 + 16 * 4 + (size_t)16 * p.T * 4;
     ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
-    hipLaunchKernelGGL((lstm16_pt_bf16_kernel<KB, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), lds, st, p);
+    const int64_t tiles = (p.M + 15) / 16;
+    const int64_t cap = std::max(1, (cu_count() + p.ND - 1) / p.ND);       // one 1024-thread workgroup per CU
+    hipLaunchKernelGGL((lstm16_pt_bf16_kernel<KB, NT>), dim3((unsigned)std::min(tiles, cap), (unsigned)p.ND), dim3(1024), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[bf16]");
     return 0;
 }
@@ -648,12 +666,7 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
         // outnumber the CUs twice over -- 32x50 MatchTensor with 4 batches in flight: 8.8 M -> 10.4 M pairs/s; at 32x10 the dispatcher
         // pairs workgroups on a CU while other CUs idle and the same kernel LOSES 18 % (tunable lstm_s: 1 = never, 2 = always)
         if (KB == 3 && H <= 80) {
-            static const int ncu = [] {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                           ? prop.multiProcessorCount : 256;
-            }();
+            const int ncu = cu_count();
             const int64_t wgs = ((p.M + 15) / 16) * p.ND * (int64_t)std::max(1, batches_in_flight(st));
             const int sel = tun(g_tun.lstm_s);
             if (sel == 2 || (sel != 1 && wgs >= 2 * (int64_t)ncu)) return launch_pt_h2<3, 5, 4>(p, st);
