@@ -39,7 +39,9 @@ def _synth(rng, B, N, QL, DL, V, full=False):
                                        (8200, 512, 301, 1), (4100, 1024, 70, 2), (33000, 128, 64, 0),
                                        (5000, 50, 140, 0), (4100, 64, 300, 1), (4097, 17, 20, 2), (20481, 33, 8, 0),
                                        # large enough for the split-precision (3 x bf16) kernel: ragged M/N/K tails included
-                                       (13000, 300, 900, 1), (71680, 256, 256, 0), (12289, 129, 36, 2), (40000, 1024, 300, 0)])
+                                       (13000, 300, 900, 1), (71680, 256, 256, 0), (12289, 129, 36, 2), (40000, 1024, 300, 0),
+                                       # mid-size: the 32x32-block exact-fp32 kernel (CARS maxout shapes; ragged M / N tails)
+                                       (1120, 512, 1024, 0), (1101, 250, 256, 1), (999, 300, 64, 2)])
 def test_linear_dense(M, N, K, act):
     from context_attentive_ir_amd import lib
     g = torch.Generator().manual_seed(M * 1000 + N)
