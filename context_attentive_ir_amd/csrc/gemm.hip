@@ -320,46 +320,52 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p) {
 
 // Mid-size path (hundreds to a few thousand rows: CARS' maxout layers over B*S*N candidate rows).  Same exact-fp32 arithmetic and K split
 // as gemm16_kernel, but a workgroup owns a 32x32 output block: a wave's two A and two W fragments of a k-group feed 16 MFMAs instead of
-// 4 (half the L2 bytes per flop, twice the MFMA work behind every load).  1120x512x1024: 43 -> ~20 us.
+// 4 (half the L2 bytes per flop, twice the MFMA work behind every load).  1120x512x1024: 43 -> 27 us.
+template <int RA>                                  // RA row tiles x 2 column tiles of 16x16 per workgroup (32 or 64 rows x 32 columns)
 __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
-    __shared__ float red[4][4][256];
+    __shared__ float red[4][2 * RA][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int64_t mbase = (int64_t)blockIdx.x * 32;
+    const int64_t mbase = (int64_t)blockIdx.x * (16 * RA);
     const int nbase = blockIdx.y * 32;
-    const float* ar[2];
+    const float* ar[RA];
     const float* wr[2];
-    float am[2], wm[2];
+    float am[RA], wm[2];
+#pragma unroll
+    for (int h = 0; h < RA; ++h) {
+        const int64_t m = mbase + 16 * h + i;
+        am[h] = m < p.M ? 1.f : 0.f;
+        ar[h] = p.a + (m < p.M ? m : p.M - 1) * p.lda + 4 * g;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int64_t m = mbase + 16 * h + i;
         const int n = nbase + 16 * h + i;
-        am[h] = m < p.M ? 1.f : 0.f;
         wm[h] = n < p.N ? 1.f : 0.f;
-        ar[h] = p.a + (m < p.M ? m : p.M - 1) * p.lda + 4 * g;
         wr[h] = p.w + (int64_t)(n < p.N ? n : p.N - 1) * p.ldw + 4 * g;
     }
-    f32x4 acc[2][2];
+    f32x4 acc[RA][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nq = p.K / 16;                       // K % 16 == 0 (launcher)
 #pragma unroll 2
     for (int q = wave; q < nq; q += 4) {
-        float4 a4[2], b4[2];
+        float4 a4[RA], b4[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            a4[h] = *reinterpret_cast<const float4*>(ar[h] + 16 * q);
-            b4[h] = *reinterpret_cast<const float4*>(wr[h] + 16 * q);
+        for (int h = 0; h < RA; ++h) a4[h] = *reinterpret_cast<const float4*>(ar[h] + 16 * q);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) b4[h] = *reinterpret_cast<const float4*>(wr[h] + 16 * q);
+#pragma unroll
+        for (int h = 0; h < RA; ++h) {             // rows / columns past the edge contribute zeros (clamped address, 0/1 mask)
+            a4[h].x *= am[h]; a4[h].y *= am[h]; a4[h].z *= am[h]; a4[h].w *= am[h];
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {              // rows / columns past the edge contribute zeros (clamped address, 0/1 mask)
-            a4[h].x *= am[h]; a4[h].y *= am[h]; a4[h].z *= am[h]; a4[h].w *= am[h];
+        for (int h = 0; h < 2; ++h) {
             b4[h].x *= wm[h]; b4[h].y *= wm[h]; b4[h].z *= wm[h]; b4[h].w *= wm[h];
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < RA; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[a].x, b4[b].x, acc[a][b], 0, 0, 0);
@@ -369,14 +375,16 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
             }
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][2 * a + b][r * 64 + lane] = acc[a][b][r];
     __syncthreads();
-    {   // wave w finishes 16x16 tile w = (a, b): C/D layout col = lane & 15, row = (lane >> 4) * 4 + r
-        const int a = wave >> 1, b = wave & 1;
+    // wave w finishes the 16x16 tiles t = w, w + 4, ..: t = (a, b); C/D layout col = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+    for (int t = wave; t < 2 * RA; t += 4) {
+        const int a = t >> 1, b = t & 1;
         const int nn = nbase + 16 * b + (lane & 15);
         float bsum = 0.f;
         if (nn < p.N) {
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t mm = mbase + 16 * a + (lane >> 4) * 4 + r;
-            const float v = (red[0][wave][r * 64 + lane] + red[1][wave][r * 64 + lane]) + (red[2][wave][r * 64 + lane] + red[3][wave][r * 64 + lane]);
+            const float v = (red[0][t][r * 64 + lane] + red[1][t][r * 64 + lane]) + (red[2][t][r * 64 + lane] + red[3][t][r * 64 + lane]);
             gemm_store(p, mm, nn, v, bsum);
         }
     }
@@ -1025,7 +1033,11 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     } else if (mb * nb < 160 && !tun(g_tun.no_gemm16) && !ids && vec && K % 16 == 0 && ((M + 31) / 32) * ((N + 31) / 32) >= 200) {
         // mid-size: 32x32 output blocks still give >= 200 workgroups
         ProfScope ps(prof_shape_name("gemm32_kernel", M, N, K), st);
-        hipLaunchKernelGGL(gemm32_kernel, dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, st, p);
+        if (((M + 63) / 64) * ((N + 31) / 32) >= 256)   // 64-row blocks once they still cover every CU: 3 us slower alone (27 -> 30 us at
+                                                         // 1120x512x1024), less CU time with several batches in flight (C3: 6.05 M -> 6.15 M pairs/s)
+            hipLaunchKernelGGL(gemm32_kernel<4>, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 31) / 32)), dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL(gemm32_kernel<2>, dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, st, p);
     } else if (mb * nb < 160 && !tun(g_tun.no_gemm16)) {
         // too few 64x64 tiles to fill 256 CUs: one 16x16 tile per workgroup, K split over the waves
         ProfScope ps(prof_shape_name(ids ? "gemm16_kernel[gather]" : "gemm16_kernel", M, N, K), st);
