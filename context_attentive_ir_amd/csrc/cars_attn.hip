@@ -281,7 +281,9 @@ __device__ __forceinline__ void ap2_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32
 
 // ONE: the encoder runs in bf16 (bf16 folded table + bf16 recurrence): h and W0 enter the attention MLP as single fp16 terms (11
 // mantissa bits, still 3 more than the bf16 operands upstream) -- one MFMA per fragment pair instead of three, one term plane.
-template <bool ONE>
+// IN16 (implies ONE): the encoder output arrives as fp16 rows (bf16-table recurrence with fp16 output): the IO waves copy it into the
+// term plane as it is -- half the HBM read, no conversion.
+template <bool ONE, bool IN16>
 __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, int64_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned short asm2_[];
     constexpr int KG = AP_KG;
@@ -419,14 +421,16 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
         const int sub = lane >> 4, per = T / 4;
         const int col = 64 * w4 + 4 * c16;
         const int poff = ((col >> 5) * 4 + ((col >> 3) & 3)) * KG + (col & 7);
-        float4 ld[16];
+        float4 ld[IN16 ? 1 : 16];
+        uint2 ld16[IN16 ? 16 : 1];
         auto load_rows = [&](int64_t k) {
             const int64_t row0 = (blockIdx.x + k * G) * AP_ROWS;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 int64_t r = row0 + 4 * q + sub;
                 r = r < nrows ? r : nrows - 1;             // rows past the end belong to sequences that are never written
-                ld[q] = *reinterpret_cast<const float4*>(p.h + r * AP_D + col);
+                if (IN16) ld16[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(p.h) + r * AP_D + col);
+                else ld[q] = *reinterpret_cast<const float4*>(p.h + r * AP_D + col);
             }
         };
         if (nk > 0) load_rows(0);
@@ -484,9 +488,13 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
             if (it < nk) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
+                    unsigned short* d = Pb + (4 * q + sub) * 8;
+                    if (IN16) {
+                        *reinterpret_cast<uint2*>(d) = ld16[q];
+                        continue;
+                    }
                     const float4 v = ld[q];
                     const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-                    unsigned short* d = Pb + (4 * q + sub) * 8;
                     *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
                     if (!ONE) {
                         const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz((v.x - (float)a01[0]) * 2048.0f, (v.y - (float)a01[1]) * 2048.0f);
@@ -510,8 +518,24 @@ namespace nir {
 
 bool attn_pool_fused_usable(int D, int T) { return D == AP_D && (T == 4 || T == 8 || T == 16 || T == 32 || T == 64); }
 
+static int ap_cu_count() {
+    static const int ncu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }();
+    return ncu;
+}
+// true when launch_attn_pool_fused(M, T) runs the role-specialised pipeline (several tiles per CU, or forced by the tunable)
+bool attn_pool_pipe_selected(int64_t M, int T) {
+    const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
+    const int pipe = tun(g_tun.attn_unfused_pipe);     // 0: by size, 1: never, 2: always (tests)
+    return (tiles >= 2 * (int64_t)ap_cu_count() && pipe == 0) || pipe == 2;
+}
+
 int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, const float* w3, const float* b3, const int64_t* lens, int64_t M,
-                           int T, float* pooled, int one_term, hipStream_t st) {
+                           int T, float* pooled, int one_term, hipStream_t st, int in_f16) {
     NIR_REQUIRE(h && wfrag && b0 && w3 && b3 && pooled && attn_pool_fused_usable(AP_D, T), "attn_pool_fused: bad args (T=%d)", T);
     if (M == 0) return 0;
     AttnPoolArgs a;
@@ -520,21 +544,20 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)attn_pool_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS); });
     const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
     ProfScope ps(prof_shape_name("attn_pool_fused_kernel", M * T, AP_D, AP_D), st);
-    static int ncu = 0;
     static std::once_flag once2;
     std::call_once(once2, [] {
-        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
     });
-    const int pipe = tun(g_tun.attn_unfused_pipe);     // 0: by size, 1: never, 2: always (tests)
-    if ((tiles >= 2 * (int64_t)ncu && pipe == 0) || pipe == 2) {          // several tiles per CU: the role-specialised pipeline
-        if (one_term) hipLaunchKernelGGL(attn_pool_pipe_kernel<true>, dim3((unsigned)std::min<int64_t>(tiles, ncu)), dim3(512), AP2_LDS, st, a, tiles);
-        else hipLaunchKernelGGL(attn_pool_pipe_kernel<false>, dim3((unsigned)std::min<int64_t>(tiles, ncu)), dim3(512), AP2_LDS, st, a, tiles);
+    const int ncu = ap_cu_count();
+    if (attn_pool_pipe_selected(M, T)) {                                   // several tiles per CU: the role-specialised pipeline
+        const dim3 grid((unsigned)std::min<int64_t>(tiles, ncu));
+        if (in_f16) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, true>), grid, dim3(512), AP2_LDS, st, a, tiles);
+        else if (one_term) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, false>), grid, dim3(512), AP2_LDS, st, a, tiles);
+        else hipLaunchKernelGGL((attn_pool_pipe_kernel<false, false>), grid, dim3(512), AP2_LDS, st, a, tiles);
     } else {
+        NIR_REQUIRE(!in_f16, "attn_pool_fused: fp16 input is only taken by the pipelined kernel (attn_pool_pipe_selected)");
         hipLaunchKernelGGL(attn_pool_fused_kernel, dim3((unsigned)tiles), dim3(256), AP_LDS, st, a);
     }
     NIR_CHECK_LAUNCH("attn_pool_fused_kernel");

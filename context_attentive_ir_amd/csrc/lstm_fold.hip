@@ -30,6 +30,7 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // wperm[(dir*H + unit)*4 + gate][:] = wih[dir*4H + gate*H + unit][:],  bperm likewise = bih + bhh
 __global__ void fold_permute_kernel(const float* __restrict__ wih, const float* __restrict__ bih, const float* __restrict__ bhh,
@@ -66,6 +67,7 @@ struct LstmPtArgs {
     int* err;               // device flag (may be NULL): set to 1 when an id falls outside [0,V)
     int64_t M, V;
     int T, H, ND;
+    int out_f16;            // bf16-table kernels only: `out` is [M,T,ND*H] fp16
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -228,12 +230,16 @@ __global__ __launch_bounds__(1024) void lstm16_pt_kernel(LstmPtArgs p) {
 // A operand (16 gate rows x 32 k): lane (row = lane & 15, k = 8*(lane >> 4) + j), B operand (32 k x 16 sequences): lane
 // (col = lane & 15, k = 8*(lane >> 4) + j); C/D: col = lane & 15 (sequence), row = 4*(lane >> 4) + r (unit kq, gate r).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KB, int NT>
+// O16: h_t leaves as fp16 rows [M,T,ND*H] (the attention-pooling pipeline takes single fp16 terms from a bf16 encoder anyway): the fp16
+// copy of h_t that the next step's MFMAs read from LDS IS the output, so wave w streams sequence w's row (256 contiguous bytes at
+// H = 128) with one store at the top of the next step instead of NT scattered 4-byte stores per lane.
+template <int KB, int NT, bool O16>
 __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
     constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // bf16 elements per h row (+8: 16-byte aligned, bank-staggered)
     constexpr uint32_t OOB = 0x7FFFFFF0u;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned short* z = reinterpret_cast<unsigned short*>(smem);   // [2][SEQ][ZLD] bf16
+    unsigned short* z = reinterpret_cast<unsigned short*>(smem);   // [2][SEQ][ZLD] fp16 (W_hh and h_t are fp16 MFMA operands: 11
+                                                                    // mantissa bits, three more than bf16, same matrix-pipe rate)
     int* lens_s = reinterpret_cast<int*>(z + 2 * SEQ * ZLD);
     int* ids_s = lens_s + SEQ;
 
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
     const int OW = p.ND * H;
     const int64_t GW = (int64_t)p.ND * H4;
     const int ntiles = (H + 3) / 4;
-    bf16x8 wreg[NT][KB];
+    f16x8 wreg[NT][KB];
     float creg[NT];
     int unit_d[NT];
 #pragma unroll
@@ -263,10 +269,10 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
                 const int kc = k0 + 8 <= H ? k0 : 0;           // branch-free: out-of-range chunks re-read chunk 0 and are zeroed below
                 const float4 a = *reinterpret_cast<const float4*>(wr + kc), b = *reinterpret_cast<const float4*>(wr + kc + 4);
                 const float m = (av && k0 + 8 <= H) ? 1.f : 0.f;
-                wreg[t][kb][0] = (short)f2bf(a.x * m); wreg[t][kb][1] = (short)f2bf(a.y * m);
-                wreg[t][kb][2] = (short)f2bf(a.z * m); wreg[t][kb][3] = (short)f2bf(a.w * m);
-                wreg[t][kb][4] = (short)f2bf(b.x * m); wreg[t][kb][5] = (short)f2bf(b.y * m);
-                wreg[t][kb][6] = (short)f2bf(b.z * m); wreg[t][kb][7] = (short)f2bf(b.w * m);
+                wreg[t][kb][0] = (_Float16)(a.x * m); wreg[t][kb][1] = (_Float16)(a.y * m);
+                wreg[t][kb][2] = (_Float16)(a.z * m); wreg[t][kb][3] = (_Float16)(a.w * m);
+                wreg[t][kb][4] = (_Float16)(b.x * m); wreg[t][kb][5] = (_Float16)(b.y * m);
+                wreg[t][kb][6] = (_Float16)(b.z * m); wreg[t][kb][7] = (_Float16)(b.w * m);
             }
         } else {
 #pragma unroll
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = 32 * kb + 8 * kq + j;
-                    wreg[t][kb][j] = (short)f2bf(wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f));
+                    wreg[t][kb][j] = (_Float16)(wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f));
                 }
         }
         unit_d[t] = 4 * tile + kq;
@@ -308,14 +314,24 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
         for (int e = tid; e < SEQ * ZLD; e += 1024) reinterpret_cast<unsigned*>(z)[e] = 0u;   // both buffers (2*SEQ*ZLD bf16)
         __syncthreads();
         int tmax = 0;
-    #pragma unroll
+#pragma unroll
         for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
         const int mylen = lens_s[sq];
 
 #pragma unroll
         for (int t = 0; t < NT; ++t) creg[t] = 0.f;
-        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
-                                                                                 (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t out_rs =
+            O16 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<_Float16*>(p.out) + m0 * T * OW, 0, (int)((uint32_t)nvalid * T * OW * 2u), 0x00020000)
+                : __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0, (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+        // O16: wave w copies sequence w's row of h_{t-1} (lane = two consecutive units) out of the LDS buffer the MFMAs of step t read
+        const int wlen = __builtin_amdgcn_readfirstlane(lens_s[wave & (SEQ - 1)]);
+        auto copy_out = [&](int s_, const unsigned short* zsrc) {
+            const bool on = s_ >= 0 && s_ < wlen && 2 * lane < H;
+            const int tt_ = dir == 0 ? s_ : wlen - 1 - s_;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(zsrc + wave * ZLD + 2 * lane);
+            const uint32_t off = on ? (uint32_t)((wave * T + tt_) * OW + dir * H + 2 * lane) * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(v, out_rs, off, 0, 0);
+        };
         const unsigned short* pth = reinterpret_cast<const unsigned short*>(p.pt) + (int64_t)dir * H4;
         auto id_of = [&](int step) {
             int s_ = min(step, mylen - 1);
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
         };
         auto load_g = [&](int id, uint2 (&dst)[NT]) {
             const unsigned short* row = pth + (int64_t)id * GW;
-    #pragma unroll
+#pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int u = unit_d[t] < H ? unit_d[t] : H - 1;
                 dst[t] = *reinterpret_cast<const uint2*>(row + 4 * u);
@@ -337,18 +353,18 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
         // per step (out-of-range offset = dropped) so the waitcnt pass can count them; no hold registers for finished sequences.
         uint2 ga[NT], gb[NT];
         load_g(id_of(0), ga);
-    #pragma unroll
-        for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
+#pragma unroll
+        for (int t = 0; t < (O16 ? 1 : NT); ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
         load_g(id_of(1), gb);
-    #pragma unroll
-        for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
+#pragma unroll
+        for (int t = 0; t < (O16 ? 1 : NT); ++t) __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
         int id_n = id_of(2);
 
         for (int step = 0; step < tmax; ++step) {
             const unsigned short* zc = z + (step & 1) * SEQ * ZLD;
             unsigned short* zn = z + ((step + 1) & 1) * SEQ * ZLD;
             f32x4 acc[NT];
-    #pragma unroll
+#pragma unroll
             for (int t = 0; t < NT; ++t) {
                 asm volatile("" : "+v"(ga[t].x), "+v"(ga[t].y));     // pins the hand-over (and its wait) to this point
                 acc[t] = (f32x4){bf2f((unsigned short)(ga[t].x & 0xFFFFu)), bf2f((unsigned short)(ga[t].x >> 16)),
@@ -358,17 +374,18 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
             const bool live = step < mylen;
             const int tt = dir == 0 ? step : mylen - 1 - step;
             const unsigned short* zr = zc + sq * ZLD + 8 * kq;
-    #pragma unroll
+            if (O16) copy_out(step - 1, zc);             // step 0: nothing yet (a dropped store keeps the per-step store count fixed)
+#pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                const bf16x8 hb = *reinterpret_cast<const bf16x8*>(zr + 32 * kb);
-    #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][kb], hb, acc[t], 0, 0, 0);
+                const f16x8 hb = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[t][kb], hb, acc[t], 0, 0, 0);
                 if (kb == 0) {
                     load_g(id_n, gb);
                     id_n = id_of(step + 3);
                 }
             }
-    #pragma unroll
+#pragma unroll
             for (int t = 0; t < NT; ++t) {
                 uint32_t off = OOB;
                 float hv = 0.f;
@@ -381,19 +398,23 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
                     const float cn = gf * creg[t] + gi * gg;
                     const float hn = go * fast_tanh(cn);
                     creg[t] = cn;
-                    if (dv) zn[sq * ZLD + unit_d[t]] = f2bf(hn);
+                    if (dv) reinterpret_cast<_Float16*>(zn)[sq * ZLD + unit_d[t]] = (_Float16)hn;
                     if (dv && live) off = (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u;
                     hv = hn;
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), out_rs, off, 0, 0);
+                if (!O16) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), out_rs, off, 0, 0);
             }
             lds_barrier();
         }
-    #pragma unroll
+        if (O16 && tmax > 0) copy_out(tmax - 1, z + (tmax & 1) * SEQ * ZLD);
+#pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (unit_d[t] < H && sq < nvalid) {
                 const int64_t m = m0 + sq;
-                for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
+                for (int t2 = mylen; t2 < T; ++t2) {
+                    if (O16) reinterpret_cast<_Float16*>(p.out)[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = (_Float16)0.f;
+                    else p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
+                }
             }
         }
     }
@@ -408,7 +429,6 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
 // the same fp32-class error (measured against fp64: 2.9e-6 vs 3.4e-6 for the fp32 chain at K = 128).  Gate math, cell state,
 // the folded table and the output stay fp32.  W_hh terms live in VGPRs (2 x 16 per tile), the two h terms in LDS.
 // ---------------------------------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // NW waves per workgroup, NT gate tiles per wave (NW * NT * 4 >= H units).  16 waves x 2 tiles is the latency form (H = 128); for
 // H <= 80 four waves x 5 tiles leave room for three workgroups per CU, which fill each other's per-step bubbles when several
@@ -639,13 +659,14 @@ static int launch_pt_bf16(const LstmPtArgs& p, hipStream_t st) {
     ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
     const int64_t tiles = (p.M + 15) / 16;
     const int64_t cap = std::max(1, (cu_count() + p.ND - 1) / p.ND);       // one 1024-thread workgroup per CU
-    hipLaunchKernelGGL((lstm16_pt_bf16_kernel<KB, NT>), dim3((unsigned)std::min(tiles, cap), (unsigned)p.ND), dim3(1024), lds, st, p);
+    if (p.out_f16) hipLaunchKernelGGL((lstm16_pt_bf16_kernel<KB, NT, true>), dim3((unsigned)std::min(tiles, cap), (unsigned)p.ND), dim3(1024), lds, st, p);
+    else hipLaunchKernelGGL((lstm16_pt_bf16_kernel<KB, NT, false>), dim3((unsigned)std::min(tiles, cap), (unsigned)p.ND), dim3(1024), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[bf16]");
     return 0;
 }
 
 int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
-                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st) {
+                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st, int out_f16) {
     NIR_REQUIRE(pt && ids && whh && out, "bilstm_folded: null pointer");
     NIR_REQUIRE(M >= 0 && V > 0 && T > 0 && (ND == 1 || ND == 2), "bilstm_folded: bad dims");
     NIR_REQUIRE(H >= 4 && H <= 128, "bilstm_folded: hidden size %d per direction unsupported (4..128)", H);
@@ -653,7 +674,8 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     NIR_REQUIRE((int64_t)16 * T * ND * H * 4 < 0x7FFFFFF0LL, "bilstm_folded: T*H too large for 32-bit tile offsets");
     NIR_REQUIRE(pt_dtype == NIR_DTYPE_F32 || pt_dtype == NIR_DTYPE_BF16, "bilstm_folded: unknown table dtype %d", pt_dtype);
     if (M == 0) return 0;
-    LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND};
+    NIR_REQUIRE(!out_f16 || (pt_dtype == NIR_DTYPE_BF16 && H > 64 && H % 2 == 0), "bilstm_folded: fp16 output needs the bf16 table and an even H > 64");
+    LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND, out_f16};
     if (pt_dtype == NIR_DTYPE_BF16) {
         const int KB = (H + 31) / 32;
         if (H <= 64) return KB == 1 ? launch_pt_bf16<1, 1>(p, st) : launch_pt_bf16<2, 1>(p, st);
@@ -742,5 +764,5 @@ extern "C" int nir_lstm_fold_table(const float* table, int64_t V, int E, const f
 
 extern "C" int nir_bilstm_folded_fwd(const void* folded, int dtype, const int64_t* ids, const int64_t* lengths, const float* w_hh,
                                      float* out, int* err_flag, int64_t M, int64_t V, int T, int H, int ndir, nir_stream_t stream) {
-    return nir::launch_bilstm_folded(folded, dtype, ids, lengths, w_hh, out, err_flag, M, V, T, H, ndir, (hipStream_t)stream);
+    return nir::launch_bilstm_folded(folded, dtype, ids, lengths, w_hh, out, err_flag, M, V, T, H, ndir, (hipStream_t)stream, 0);
 }
