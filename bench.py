@@ -115,15 +115,22 @@ def kernel_work(name, c):
     if base.startswith("attn_pool_fused_kernel"):
         # fused attention pooling (csrc/cars_attn.hip): M rows of D = N = K = 256: the attention MLP GEMM + row dot, softmax and the
         # weighted sum; bytes: the encoder output read once (the second read for the weighted sum is served by L2) + pooled rows
-        return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=4.0 * M * K + 4.0 * N * K, peak=PEAK_BF16_TFLOPS / 3.0)
+        # bf16 encoders (C5): single fp16 terms (1 MFMA per product block) and, once the pipelined kernel is selected (>= 2 tiles of 64
+        # rows per CU), fp16 encoder rows
+        one = c.get("dtype") == "bf16"
+        in16 = one and M >= 2 * 256 * 64
+        return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=(2.0 if in16 else 4.0) * M * K + 4.0 * N * K,
+                    peak=PEAK_BF16_TFLOPS / (1.0 if one else 3.0))
     if base.startswith("gemm3_kernel"):
         gathered = "[gather]" in base
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),
                     peak=PEAK_BF16X3_TFLOPS)
-    if base.startswith("gemm_kernel") or base.startswith("gemm16_kernel") or base.startswith("gemm_skinny_kernel"):
+    if base.startswith("gemm_kernel") or base.startswith("gemm16_kernel") or base.startswith("gemm32_kernel") or base.startswith("gemm_skinny_kernel"):
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N), peak=PEAK_FP32_TFLOPS)
-    if base.startswith("lstm16_pt_bf16_kernel"):      # M sequences, N = T steps, K = H; both directions in one launch
-        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * 4), peak=PEAK_BF16_TFLOPS)
+    if base.startswith("lstm16_pt_bf16_kernel"):      # M sequences, N = T steps, K = H; both directions in one launch; bf16 table rows,
+        # fp16 MFMA operands; the states leave as fp16 when they feed the pipelined attention kernel of the same encode call
+        out_b = 2.0 if M * N >= 2 * 256 * 64 else 4.0
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * out_b), peak=PEAK_BF16_TFLOPS)
     if base.startswith("lstm16_pt_h2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block -> peak 2500 / 3
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), peak=PEAK_BF16_TFLOPS / 3.0)
     if base.startswith("lstm16_pt_kernel"):
