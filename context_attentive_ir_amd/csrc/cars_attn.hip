@@ -314,7 +314,7 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
 #pragma unroll
         for (int j = 0; j < AP_CT; ++j) {
             wa[j][0] = ldw((j * 2) * 512);
-            wa[j][1] = ldw((j * 2 + 1) * 512);
+            wa[j][1] = ONE ? wa[j][0] : ldw((j * 2 + 1) * 512);
         }
         for (int64_t it = 0; it < nk + 2; ++it) {
             if (w4 == 0) { AP_T(0) }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                     const unsigned short* pn_ = Pp + sn_ * 4 * KG + foff;                 \
                     _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 3 * AP_RT * AP_CT; ++n_) { \
                         ap2_mma_n<ONE>(n_, acc, acx, af, WC);                             \
-                        if (n_ % 6 == 2 && n_ / 6 < 2 * AP_CT) {                          \
+                        if (n_ % 6 == 2 && n_ / 6 < 2 * AP_CT && !(ONE && ((n_ / 6) & 1))) { /* ONE: the residual-term fragments are never read */ \
                             asm volatile("" ::"v"(WN[(n_ / 6) >> 1][(n_ / 6) & 1]));      \
                             WN[(n_ / 6) >> 1][(n_ / 6) & 1] = ldw(sn_ * WSTEP + (n_ / 6) * 512);  \
                         }                                                                 \
