@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void attn_pool_fused_kernel(AttnPoolArgs p)
     // ================= masked softmax over each sequence (wave 0: lane = row of the tile) =================
     if (wave == 0) {
         const int64_t r = row0 + lane;
-        const int64_t seq = r / T;
+        const int64_t seq = r >> p.logT;                   // T is a power of two: no 64-bit division per lane
         const int t = (int)(r - seq * T);
         int len = T;
         if (p.lens && seq < p.M) len = (int)p.lens[seq];
@@ -227,15 +227,15 @@ __global__ __launch_bounds__(256, 1) void attn_pool_fused_kernel(AttnPoolArgs p)
         for (int j = 0; j < 16; ++j) {                     // row wave + 4 j belongs to sequence j / per of the tile
             const float pr = prob[wave + 4 * j];
             a.x = fmaf(pr, hv[j].x, a.x); a.y = fmaf(pr, hv[j].y, a.y); a.z = fmaf(pr, hv[j].z, a.z); a.w = fmaf(pr, hv[j].w, a.w);
-            if ((j + 1) % per == 0) {                      // last row of its sequence held by this thread
-                red[(wave * RS + j / per) * 64 + lane] = a;
+            if (((j + 1) & (per - 1)) == 0) {                      // last row of its sequence held by this thread
+                red[(wave * RS + (j >> (p.logT - 2))) * 64 + lane] = a;
                 a = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         __syncthreads();
         for (int idx = tid; idx < RS * 64; idx += 256) {
             const int q = idx >> 6, c = idx & 63;
-            const int64_t seq = row0 / T + q;
+            const int64_t seq = (row0 >> p.logT) + q;
             if (seq < p.M) {
                 const float4 a0 = red[(0 * RS + q) * 64 + c], a1 = red[(1 * RS + q) * 64 + c], a2 = red[(2 * RS + q) * 64 + c],
                              a3 = red[(3 * RS + q) * 64 + c];
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                 const float* rp = rowpart + (it & 1) * 4 * 64;
                 {
                     const int64_t r = rowS + lane;
-                    const int64_t seq = r / T;
+                    const int64_t seq = r >> p.logT;                   // T is a power of two: no 64-bit division per lane
                     const int t = (int)(r - seq * T);
                     int len = T;
                     if (p.lens && seq < p.M) len = (int)p.lens[seq];
@@ -475,10 +475,10 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                         a.z = fmaf(pr, fmaf((float)b23[0], 1.0f / 2048.0f, (float)a23[0]), a.z);
                         a.w = fmaf(pr, fmaf((float)b23[1], 1.0f / 2048.0f, (float)a23[1]), a.w);
                     }
-                    if ((q + 1) % per == 0) {              // sequence complete: fold the four row subgroups, subgroup 0 stores
+                    if (((q + 1) & (per - 1)) == 0) {              // sequence complete: fold the four row subgroups, subgroup 0 stores
                         a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
                         a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
-                        const int64_t seq = rowS / T + q / per;
+                        const int64_t seq = (rowS >> p.logT) + (q >> (p.logT - 2));
                         if (sub == 0 && seq < p.M) *reinterpret_cast<float4*>(p.pooled + seq * AP_D + col) = a;
                         a = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
@@ -539,7 +539,7 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     NIR_REQUIRE(h && wfrag && b0 && w3 && b3 && pooled && attn_pool_fused_usable(AP_D, T), "attn_pool_fused: bad args (T=%d)", T);
     if (M == 0) return 0;
     AttnPoolArgs a;
-    a.h = h; a.wf = (const _Float16*)wfrag; a.b0 = b0; a.w3 = w3; a.b3 = b3; a.lens = lens; a.pooled = pooled; a.M = M; a.T = T; a.logT = 0;
+    a.h = h; a.wf = (const _Float16*)wfrag; a.b0 = b0; a.w3 = w3; a.b3 = b3; a.lens = lens; a.pooled = pooled; a.M = M; a.T = T; a.logT = __builtin_ctz((unsigned)T);
     static std::once_flag once;
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)attn_pool_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS); });
     const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
