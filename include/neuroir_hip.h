@@ -277,12 +277,16 @@ size_t nir_lstm_fold_table_workspace_bytes(int64_t V, int E, int H, int ndir, in
 int nir_lstm_fold_table(const float* table, int64_t V, int E, const float* w_ih, const float* b_ih, const float* b_hh, int H,
                         int ndir, void* folded, int dtype, void* workspace, size_t workspace_bytes, nir_stream_t stream);
 /* BiLSTM over a folded table: ids [M,T] int64, lengths [M] (or NULL), w_hh [ndir,4H,H] fp32 -> out [M,T,ndir*H] fp32, zero at
- * t >= length.  dtype F32: v_mfma_f32_16x16x4_f32 recurrence (parity path).  dtype BF16: bf16 folded table, bf16 W_hh / h_t
- * MFMA operands (v_mfma_f32_16x16x32_bf16), fp32 accumulation, gate math and cell state.  An id outside [0,V) is read as id 0
- * and sets *err_flag (device int, may be NULL) to 1 -- the reference's nn.Embedding raises IndexError. */
+ * t >= length.  dtype F32: fp32-accurate recurrence (two-term fp16 split on v_mfma_f32_16x16x32_f16 for H >= 32, exact
+ * v_mfma_f32_16x16x4_f32 below / with the exact_f32 tunable; the parity path).  dtype BF16: bf16 folded table, W_hh and h_t as
+ * single fp16 MFMA operands (v_mfma_f32_16x16x32_f16: 11 mantissa bits), fp32 accumulation, gate math and cell state.  Both
+ * MFMA paths need |w_hh| < 65504 (fp16 range).  An id outside [0,V) is read as id 0 and sets *err_flag (device int, may be
+ * NULL) to 1 -- the reference's nn.Embedding raises IndexError. */
 int nir_bilstm_folded_fwd(const void* folded, int dtype, const int64_t* ids, const int64_t* lengths, const float* w_hh,
                           float* out, int* err_flag, int64_t M, int64_t V, int T, int H, int ndir, nir_stream_t stream);
-/* CARS.encode / encode_document (cars.py:193-260) over a folded table: same outputs as nir_cars_encode. */
+/* CARS.encode / encode_document (cars.py:193-260) over a folded table: same outputs as nir_cars_encode.  With a bf16 table,
+ * `encoded` == NULL and a launch large enough for the pipelined attention kernel, the per-token states stay inside the call as
+ * fp16 rows (the attention MLP then takes single fp16 terms); pass `encoded` to get them as fp32. */
 size_t nir_cars_encode_folded_workspace_bytes(int64_t M, int T, const nir_cars_encoder_weights* w /*host*/);
 int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, int64_t M, int T, const void* folded, int dtype, int64_t V,
                            const nir_cars_encoder_weights* w /*host*/, void* workspace, size_t workspace_bytes, float* pooled,
