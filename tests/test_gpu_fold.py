@@ -242,3 +242,39 @@ def test_cars_bf16_single_term_attention_pipeline():
                         ex["document_labels"])
     assert float((s.cpu() - ref).abs().max()) <= BF16_SCORE_TOL
     _close(torch.softmax(s.cpu(), -1), torch.softmax(ref, -1), BF16_PROB_TOL)
+
+
+def test_cars_bf16_full_c5_shape_against_fp32_path():
+    """BASELINE config 5 at its full per-GPU shape (64 sessions x 7 queries x 50 candidates, q_len 4, doc_len 64): here the document
+    encoder takes the paths only large launches select -- persistent bf16-table recurrence with fp16 states streamed from LDS, the
+    pipelined attention kernel on fp16 rows.  Checked against the fp32 path of the same model on the same batch (itself pinned to
+    the oracle at smaller sizes): scores within the bf16 bound, softmax within the probability bound, MAP within 0.02, and -- size
+    independent -- padded candidates / permutation of the candidate axis leave the other scores unchanged."""
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.eval import ltorank
+    V, B, S, N, QL, DL = 5000, 64, 7, 50, 4, 64
+    m = build_model("CARS", vocab=V, device=DEV)
+    ex = {k: v.to(DEV) for k, v in synth.session_batch(B, S, N, QL, DL, V, seed=5, full_length=False).items()}
+
+    def scores(model, e):
+        pooled, _, _ = model.encode(e["source_words"], e["source_lens"])
+        return model.rank_document(pooled, e["document_words"], e["document_lens"], e["document_labels"])[0]
+
+    ref = scores(m, ex).cpu()
+    m.compute_dtype = "bf16"
+    got = scores(m, ex).cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= BF16_SCORE_TOL, float((got - ref).abs().max())
+    _close(torch.softmax(got, -1), torch.softmax(ref, -1), BF16_PROB_TOL)
+    lab = ex["document_labels"].reshape(-1, N).cpu().numpy()
+    map_ref = ltorank.MAP(np.argsort(-ref.reshape(-1, N).numpy(), 1), lab)
+    map_got = ltorank.MAP(np.argsort(-got.reshape(-1, N).numpy(), 1), lab)
+    assert abs(map_ref - map_got) <= 0.02, (map_ref, map_got)
+    # permuting the candidates permutes the scores (the click-pooled session state is order independent up to summation order)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(DEV)
+    pex = dict(ex)
+    pex["document_words"] = ex["document_words"][:, :, perm]
+    pex["document_lens"] = ex["document_lens"][:, :, perm]
+    pex["document_labels"] = ex["document_labels"][:, :, perm]
+    gp = scores(m, pex).cpu()
+    assert float((gp - got[:, :, perm.cpu()]).abs().max()) <= 2e-3
