@@ -543,12 +543,12 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
             dst[t] = *reinterpret_cast<const f32x4*>(row + 4 * u);
         }
     };
-    // The rows of step t+1 are requested at the top of step t, right after the rows of step t (requested one step earlier) have been
-    // taken over as the MFMA C operand: the only s_waitcnt vmcnt in the loop sits at that hand-over and covers requests that are a
-    // whole step old.  (Waiting at the END of the step made the waitcnt pass merge "step 0's rows may be in flight" into the loop
-    // header and wait for the NEXT step's rows in front of the first MFMA: +18 % on the H = 70 kernel.)
-    // The id of step t+1 is looked up (LDS) a step early and its rows are requested after the first k-block of MFMAs has been issued:
-    // with lookup + request at the top of the step, an LDS round trip and the 64-bit address arithmetic sat in front of the h reads.
+    // Step t begins by taking over the gate rows of step t (requested during step t-1) as the MFMA C operand: the only s_waitcnt
+    // vmcnt of the loop sits at that hand-over and covers a request that is most of a step old.  (With the hand-over at the END of
+    // the step the waitcnt pass merged "step 0's rows may be in flight" into the loop header and waited for the NEXT step's rows in
+    // front of the first MFMA: +18 % on the H = 70 kernel.)  The rows of step t+1 are requested behind the first k-block of MFMAs,
+    // from an id looked up in LDS a step earlier: with lookup + request at the top of the step, an LDS round trip and the 64-bit
+    // address arithmetic sat in front of the h reads.
     f32x4 gcur[NT], gnext[NT];
     load_g(id_of(0), gnext);
     int id_n = id_of(1);
