@@ -291,8 +291,9 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
 
     lanes = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
     fbufs = [None] * len(lanes)
-    # Candidate-sharded CARS over RCCL: the step is two hipGraphs (queries + this rank's document shard -> pooled vectors | session
-    # part + softmax) around ONE eager all-gather of the pooled shard; replaying the whole step eagerly is host-bound (measured
+    # Candidate-sharded CARS over RCCL: the step is two hipGraphs (queries + this rank's document shard -> pooled vectors | clicks,
+    # sessions and the ranker MLP over this rank's candidate slice) around an eager all-gather of the pooled shard, followed by an
+    # eager KB-sized all-gather of the score slices and the softmax kernel; replaying the whole step eagerly is host-bound (measured
     # 0.43 ms/step of enqueue against 0.22 ms of GPU time).  torch.distributed runs the collectives of all lanes on its own stream in
     # issue order.
     staged = sharded and is_sess and env.backend == "nccl" and c["model"] == "cars" and not args.no_graph
@@ -342,7 +343,11 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     gbuf = torch.zeros(wsh * B_ * S_, per_ * D_, device=dev, dtype=pl.dtype)
                     gdst = gbuf[:B_ * S_] if emu else gbuf
                     env.dist.all_gather_into_tensor(gdst, pl.reshape(B_ * S_, per_ * D_))
-                    model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand)
+                    sl = model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand, own=pl)
+                    sbuf = torch.zeros(wsh * B_ * S_, per_, device=dev)
+                    sdst = sbuf[:B_ * S_] if emu else sbuf
+                    env.dist.all_gather_into_tensor(sdst, sl)
+                    probs = model.shard_stage_c(sbuf, torch.empty(B_ * S_, ncand, device=dev), ncand)
                 torch.cuda.synchronize()
                 time.sleep(0.3)
                 ga = torch.cuda.CUDAGraph()
@@ -351,8 +356,8 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     flat = pl.reshape(B_ * S_, per_ * D_)
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, stream=ln, capture_error_mode=CAPTURE_MODE):
-                    out = model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand)
-                stages.append((ga, flat, gdst, gb, out))
+                    sl = model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand, own=pl)
+                stages.append((ga, flat, gdst, gb, sl, sdst, sbuf, probs))
         except Exception as e:  # pragma: no cover - falls back to the eager sharded step
             print("[bench] staged graph capture unavailable for %s (%s); eager sharded steps" % (name, e), file=sys.stderr)
             stages = None
@@ -375,16 +380,14 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     def run(i, only_lane=None):
         ln = lane_of(i) if only_lane is None else only_lane
         if stages is not None:
-            ga, flat, gbuf, gb, out = stages[i % len(stages)]
+            ga, flat, gbuf, gb, sl, sdst, sbuf, probs = stages[i % len(stages)]
             with torch.cuda.stream(lanes[ln]):
-                so = os.environ.get("BENCH_STAGE_ONLY", "agb")
-                if "a" in so:
-                    ga.replay()
-                if "g" in so:
-                    env.dist.all_gather_into_tensor(gbuf, flat)
-                if "b" in so:
-                    gb.replay()
-            return out
+                ga.replay()
+                env.dist.all_gather_into_tensor(gbuf, flat)
+                gb.replay()
+                env.dist.all_gather_into_tensor(sdst, sl)
+                model.shard_stage_c(sbuf, probs, ncand)
+            return probs.view(sl.shape[0] // c["session"], c["session"], ncand)
         with torch.cuda.stream(lanes[ln]):
             if graphs is not None:
                 g, out = graphs[i % len(graphs)]

@@ -376,6 +376,14 @@ extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_
                                      const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
                                      float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
                                      nir_stream_t stream) {
+    return nir_cars_rank_session_shard(pooled_q, pooled_docs, labels, B, S, N, w, workspace, workspace_bytes, click_scores, clicks_out, extra,
+                                       nullptr, 0, stream);
+}
+
+extern "C" int nir_cars_rank_session_shard(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
+                                           const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
+                                           float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
+                                           const float* rank_docs, int NR, nir_stream_t stream) {
     using namespace nir;
     hipStream_t st = (hipStream_t)stream;
     NIR_REQUIRE(pooled_q && w, "cars_rank_session: null pointer");
@@ -386,6 +394,7 @@ extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_
     NIR_REQUIRE(nch == 0 || !rank_on || w->attn_ut, "cars_rank_session: packed attention weights missing (nir_cars_session_pack)");
     NIR_REQUIRE(B >= 0 && S > 0 && N > 0, "cars_rank_session: bad dims");
     NIR_REQUIRE(N <= 64, "cars_rank_session: %d candidates > 64 unsupported", N);
+    NIR_REQUIRE(!rank_docs || (NR > 0 && NR <= N), "cars_rank_session: the ranked candidate slice must hold 1..N candidates (got %d)", NR);
     NIR_REQUIRE(S <= 63, "cars_rank_session: session length %d > 63 unsupported", S);
     NIR_REQUIRE(w->D % 64 == 0 && w->HS % 16 == 0 && w->D % 16 == 0, "cars_rank_session: D %% 64 / HS %% 16 required");
     if (B == 0) return 0;
@@ -446,15 +455,20 @@ extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_
             xrows = p.xcat;
         }
         NIR_PROPAGATE(launch_linear(xrows, KR, nullptr, nullptr, 0, 0, 0, w->wrank, KR, w->qproj_b, nullptr, p.qp, D, BS, D, KR, NIR_ACT_NONE, st));
+        // the ranker scores a candidate against the session state only: a candidate-sharded caller hands its own slice of the pooled
+        // documents here (rank_docs [B,S,NR,D] -> click_scores [B,S,NR]) while clicks and sessions above saw all N candidates
+        const float* rdocs = rank_docs ? rank_docs : pooled_docs;
+        const int Nr = rank_docs ? NR : N;
+        const int64_t Rr = BS * Nr;
         {
             ProfScope ps("rank_feats_kernel", st);
-            hipLaunchKernelGGL(rank_feats_kernel, g1(R * D / 4), dim3(256), 0, st, p.qp, pooled_docs, N, D, R, p.feats);
+            hipLaunchKernelGGL(rank_feats_kernel, g1(Rr * D / 4), dim3(256), 0, st, p.qp, rdocs, Nr, D, Rr, p.feats);
         }
         NIR_CHECK_LAUNCH("rank_feats_kernel");
         // maxout 1024 -> 256 -> 128 -> 1 (pool 2): the pairwise max is fused into the GEMM epilogues
-        NIR_PROPAGATE(launch_linear_ex(p.feats, 4 * D, nullptr, nullptr, 0, 0, 0, w->mo0_w, 4 * D, w->mo0_b, nullptr, p.y0, 256, R, 512, 4 * D, ACT_MAXOUT2, nullptr, 0, st));
-        NIR_PROPAGATE(launch_linear_ex(p.y0, 256, nullptr, nullptr, 0, 0, 0, w->mo1_w, 256, w->mo1_b, nullptr, p.y1, 128, R, 256, 256, ACT_MAXOUT2, nullptr, 0, st));
-        NIR_PROPAGATE(launch_linear_ex(p.y1, 128, nullptr, nullptr, 0, 0, 0, w->mo2_w, 128, w->mo2_b, nullptr, click_scores, 1, R, 2, 128, ACT_MAXOUT2, nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear_ex(p.feats, 4 * D, nullptr, nullptr, 0, 0, 0, w->mo0_w, 4 * D, w->mo0_b, nullptr, p.y0, 256, Rr, 512, 4 * D, ACT_MAXOUT2, nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear_ex(p.y0, 256, nullptr, nullptr, 0, 0, 0, w->mo1_w, 256, w->mo1_b, nullptr, p.y1, 128, Rr, 256, 256, ACT_MAXOUT2, nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear_ex(p.y1, 128, nullptr, nullptr, 0, 0, 0, w->mo2_w, 128, w->mo2_b, nullptr, click_scores, 1, Rr, 2, 128, ACT_MAXOUT2, nullptr, 0, st));
     }
     if (want_states) {
         // ---- suggestion-side outputs (cars.py:382-456): inner attention pools and the decoder initial states

@@ -279,7 +279,9 @@ class CARS(nn.Module, lib.IdCheck):
         pooled, _ = self._encode_seqs("d", docs.reshape(B * S * N, DL), docs_length.reshape(-1), False)
         return pooled.view(B, S, N, -1)
 
-    def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False):
+    def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False, rank_docs=None):
+        """rank_docs [B,S,NR,D] (optional): the ranker scores only this slice of the candidates -> scores [B,S,NR]; clicks and sessions
+        still see all of pooled_docs (candidate-sharded callers: nir_cars_rank_session_shard)."""
         lib.require_device(pooled_q, pooled_docs, labels)
         L = lib.load()
         B, S, D = pooled_q.shape
@@ -291,7 +293,9 @@ class CARS(nn.Module, lib.IdCheck):
         pdv = pooled_docs.float().contiguous() if pooled_docs is not None else None
         lab = labels.float().contiguous() if labels is not None else None
         HS, HDEC = self._dims["HS"], self._dims["HDEC"]
-        scores = torch.empty(B, S, N, device=dev, dtype=torch.float32) if not self.no_ranker else None
+        rd = rank_docs.float().contiguous() if rank_docs is not None else None
+        NR = rd.shape[2] if rd is not None else N
+        scores = torch.empty(B, S, NR, device=dev, dtype=torch.float32) if not self.no_ranker else None
         clicks = torch.empty(B, S, D, device=dev, dtype=torch.float32) if want_clicks else None
         extra, outs = None, {}
         if want_states:
@@ -304,9 +308,9 @@ class CARS(nn.Module, lib.IdCheck):
             outs["dec_c"] = torch.empty(1, (S - 1) * B, HDEC, device=dev)
             for k, v in outs.items():
                 setattr(extra, k, v.data_ptr())
-        lib.check(L.nir_cars_rank_session(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
-                                          lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
-                                          lib.stream()), "nir_cars_rank_session")
+        lib.check(L.nir_cars_rank_session_shard(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
+                                                lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
+                                                lib.ptr(rd), NR if rd is not None else 0, lib.stream()), "nir_cars_rank_session")
         return scores, clicks, outs
 
     def encode_clicks(self, docs, doc_labels):
@@ -324,18 +328,25 @@ class CARS(nn.Module, lib.IdCheck):
         [B,S,HS] are the decoder inputs (cars.py:382-456); they are produced when `want_states` (default: whenever the
         recommender is on, like the reference), otherwise returned as None / (None, None).
         shard=True: candidate-sharded document encoding over the torch.distributed `group` + one all-gather of the
-        pooled document vectors (sharding.sharded_pooled_docs); the session part runs replicated."""
+        pooled document vectors (sharding.sharded_pooled_docs); clicks and sessions run replicated, the ranker MLP scores this
+        rank's candidate slice and a second, KB-sized all-gather re-assembles the scores."""
         self._check_eval()
         if want_states is None:
             want_states = not self.no_recommender
-        encoded_docs = None
+        encoded_docs, own = None, None
         if not (self.no_ranker and self.no_document_session_encoding):
             if shard:
                 from .. import sharding
-                encoded_docs = sharding.sharded_pooled_docs(self.encode_document, document_rep, document_len, group)
+                encoded_docs, own = sharding.sharded_pooled_docs(self.encode_document, document_rep, document_len, group, return_local=True)
             else:
                 encoded_docs = self.encode_document(document_rep, document_len)
-        scores, _, outs = self._rank_session(pooled_rep, encoded_docs, document_label, want_states=want_states)
+        # candidate-sharded: the ranker MLP scores this rank's slice only (clicks / sessions need every pooled candidate and stay
+        # replicated); the score slices are gathered afterwards
+        scores, _, outs = self._rank_session(pooled_rep, encoded_docs, document_label, want_states=want_states,
+                                             rank_docs=own if not self.no_ranker else None)
+        if own is not None and scores is not None:
+            from .. import sharding
+            scores = sharding.gather_session_scores(scores, document_rep.shape[2], group)
         states = (outs["dec_h"], outs["dec_c"]) if want_states else None
         attns = (outs.get("inner_q"), outs.get("inner_d")) if want_states else (None, None)
         return (scores if scores is not None else []), states, attns

@@ -127,10 +127,21 @@ def gather_pooled_docs(local, N, group=None):
     return out.view(world, B, S, per, D).permute(1, 2, 0, 3, 4).reshape(B, S, world * per, D)[:, :, :N].contiguous()
 
 
-def sharded_pooled_docs(encode_fn, document_words, document_lens, group=None):
-    """encode_fn(doc_shard [B,S,per,DL], len_shard [B,S,per]) -> pooled [B,S,per,D]; returns [B,S,N,D] everywhere."""
+def sharded_pooled_docs(encode_fn, document_words, document_lens, group=None, return_local=False):
+    """encode_fn(doc_shard [B,S,per,DL], len_shard [B,S,per]) -> pooled [B,S,per,D]; returns [B,S,N,D] everywhere
+    (return_local: also this rank's own pooled shard [B,S,per,D], None without a process group -- the ranker then scores the
+    shard only and the score slices are gathered with gather_session_scores)."""
     if not (dist.is_available() and dist.is_initialized()):
-        return encode_fn(document_words, document_lens)
+        full = encode_fn(document_words, document_lens)
+        return (full, None) if return_local else full
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     d, l = shard_session_candidates(document_words, document_lens, world, rank)
-    return gather_pooled_docs(encode_fn(d, l), document_words.shape[2], group)
+    local = encode_fn(d, l)
+    full = gather_pooled_docs(local, document_words.shape[2], group)
+    return (full, local) if return_local else full
+
+
+def gather_session_scores(local, N, group=None):
+    """all-gather click-score slices [B,S,per] from every rank -> [B,S,N] on every rank (padding removed)."""
+    B, S, per = local.shape
+    return gather_scores(local.reshape(B * S, per), N, group).view(B, S, N)

@@ -61,15 +61,30 @@ class Multitask(WrapperBase):
         return pooled, self.network.encode_document(doc_shard, len_shard)
 
     @torch.no_grad()
-    def shard_stage_b(self, pooled, gathered, labels, n_candidates):
-        """gathered = all_gather_into_tensor of every rank's pooled shard, [world*B*S, per*D] -> softmaxed click scores [B,S,N]."""
+    def shard_stage_b(self, pooled, gathered, labels, n_candidates, own=None):
+        """gathered = all_gather_into_tensor of every rank's pooled shard, [world*B*S, per*D].
+        own = None: softmaxed click scores [B,S,N] (every rank scores every candidate).
+        own = this rank's pooled shard [B,S,per,D] (the second output of shard_stage_a): raw click scores of that slice, [B*S, per] --
+        the caller all-gathers them and finishes with shard_stage_c (the ranker MLP is then sharded as well)."""
         B, S, D = pooled.shape
         world = gathered.shape[0] // (B * S)
         per = gathered.shape[1] // D
         docs = gathered.view(world, B, S, per, D).permute(1, 2, 0, 3, 4).reshape(B, S, world * per, D)[:, :, :n_candidates].contiguous()
-        s = self.network._rank_session(pooled, docs, labels, want_states=False)[0].contiguous()
+        s = self.network._rank_session(pooled, docs, labels, want_states=False, rank_docs=own)[0].contiguous()
+        if own is not None:
+            return s.view(B * S, per)
         probs = torch.empty_like(s)
         lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()), "nir_softmax_rows")
+        return probs
+
+    @torch.no_grad()
+    def shard_stage_c(self, gathered_scores, probs, n_candidates):
+        """gathered_scores = all_gather_into_tensor of every rank's [B*S, per] score slice, [world*B*S, per]; writes the softmax over
+        the n_candidates of each (session, step) into probs [B*S, N] (nir_softmax_gathered) and returns it."""
+        rows, n = probs.shape
+        world = gathered_scores.shape[0] // rows
+        lib.check(lib.load().nir_softmax_gathered(lib.ptr(gathered_scores), lib.ptr(probs), None, world, rows, gathered_scores.shape[1],
+                                                  n_candidates, lib.stream()), "nir_softmax_gathered")
         return probs
 
     @torch.no_grad()

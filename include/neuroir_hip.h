@@ -330,6 +330,13 @@ int nir_cars_rank_session(const float* pooled_q, const float* pooled_docs, const
                           const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
                           float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra /*host*/,
                           nir_stream_t stream);
+/* The same with the ranker (cars.py:505-520) restricted to a slice of the candidates: rank_docs [B,S,NR,D] (NULL = all N) ->
+ * click_scores [B,S,NR].  Clicks and sessions still see all N pooled documents.  For candidate-sharded callers (one rank scores its
+ * own slice after the all-gather of the pooled documents; the score slices are gathered afterwards). */
+int nir_cars_rank_session_shard(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
+                                const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                                float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra /*host*/,
+                                const float* rank_docs, int NR, nir_stream_t stream);
 
 /* --- CARS.decode: greedy query suggestion (cars.py:706-791; decoders/rnn_decoder.py:19-88; global_attention.py:98-196) ---- */
 typedef struct {

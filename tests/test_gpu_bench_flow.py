@@ -89,5 +89,34 @@ def test_sharded_stages_reproduce_predict():
         d, l = sharding.shard_session_candidates(ex["document_words"], ex["document_lens"], world, rank)
         pq, pl = mt.shard_stage_a(ex, d, l)
         parts.append(pl.reshape(B * S, -1))
-    got = mt.shard_stage_b(pq, torch.cat(parts, 0).contiguous(), ex["document_labels"], N)
+    gathered = torch.cat(parts, 0).contiguous()
+    got = mt.shard_stage_b(pq, gathered, ex["document_labels"], N)
     assert float((got - ref).abs().max()) < 1e-6
+    # sharded ranker MLP: every simulated rank scores its own slice (padded with a repeat of its last candidate), the slices are
+    # concatenated rank-major like the second all-gather leaves them, shard_stage_c applies the softmax over the N real candidates
+    per = parts[0].shape[1] // pq.shape[2]
+    slices = []
+    for rank in range(world):
+        own = parts[rank].view(B, S, per, -1)
+        slices.append(mt.shard_stage_b(pq, gathered, ex["document_labels"], N, own=own))
+    probs = mt.shard_stage_c(torch.cat(slices, 0).contiguous(), torch.empty(B * S, N, device="cuda"), N).view(B, S, N)
+    assert float((probs - ref).abs().max()) < 1e-6
+
+
+def test_rank_session_candidate_slice_matches_full_scores():
+    """nir_cars_rank_session_shard: scoring a slice of the pooled candidates (clicks / sessions over all of them) gives exactly the
+    columns of the full score matrix -- a candidate's score depends on the session state and its own pooled vector only."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import build_model
+    from context_attentive_ir_amd import synth
+    V, B, S, N = 1200, 4, 5, 9
+    m = build_model("CARS", vocab=V, device="cuda")
+    ex = {k: v.cuda() for k, v in synth.session_batch(B, S, N, 5, 24, V, seed=8, full_length=False).items()}
+    pooled, _, _ = m.encode(ex["source_words"], ex["source_lens"])
+    docs = m.encode_document(ex["document_words"], ex["document_lens"])
+    full = m._rank_session(pooled, docs, ex["document_labels"])[0]
+    for lo, hi in ((0, 3), (3, 9), (8, 9), (0, 9)):
+        part = m._rank_session(pooled, docs, ex["document_labels"], rank_docs=docs[:, :, lo:hi].contiguous())[0]
+        assert part.shape == (B, S, hi - lo)
+        assert torch.equal(part, full[:, :, lo:hi])
