@@ -37,11 +37,18 @@ __global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restric
     __shared__ int part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {   // every workgroup recomputes m from the (tiny) label matrix: no extra launch, no cross-workgroup dependency
+        // (N <= 64: one label per lane, the row's count is the population count of a ballot -- a DPP wave_sum per row made this
+        // prologue 112 x ~150 cycles per workgroup at the C5 shape)
         int best = 0;
-        for (int r = wave; r < rows; r += 4) {
-            float c = 0.f;
-            for (int k = lane; k < N; k += 64) c += labels[(int64_t)r * N + k] != 0.f ? 1.f : 0.f;
-            best = max(best, (int)wave_sum(c));
+        for (int r0 = wave; r0 < rows; r0 += 4 * 16) {     // 16 independent row loads in flight per wave (each is an L2 round trip)
+            float lv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {               // unconditional loads from clamped addresses (a predicated load becomes its own
+                const int r = r0 + 4 * j;                // exec-masked block with a full wait behind it), masked afterwards
+                lv[j] = labels[(int64_t)(r < rows ? r : 0) * N + (lane < N ? lane : 0)];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) best = max(best, (int)__popcll(__ballot(lv[j] != 0.f && lane < N && r0 + 4 * j < rows)));
         }
         if (lane == 0) part[wave] = best;
     }
@@ -51,8 +58,9 @@ __global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restric
     if (r >= rows) return;
     const float lab = lane < N ? labels[(int64_t)r * N + lane] : -INFINITY;
     int rank = 0;
+#pragma unroll 8
     for (int k = 0; k < N; ++k) {
-        const float lk = __shfl(lab, k, 64);
+        const float lk = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lab), k));   // k is wave-uniform: no LDS permute
         rank += (lk > lab) || (lk == lab && k < lane);
     }
     const int count = (int)wave_sum((lane < N && lab != 0.f) ? 1.f : 0.f);
@@ -73,8 +81,9 @@ __global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restric
     const int nch = D >> 2;
     for (int c = lane; c < nch; c += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < N; ++k) {
-            const float pk = __shfl(p, k, 64);
+#pragma unroll 8
+        for (int k = 0; k < N; ++k) {                     // 8 independent 1 KB row reads in flight
+            const float pk = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p), k));
             const float4 v = *reinterpret_cast<const float4*>(docs + ((int64_t)r * N + k) * D + 4 * c);
             acc.x = fmaf(pk, v.x, acc.x); acc.y = fmaf(pk, v.y, acc.y); acc.z = fmaf(pk, v.z, acc.z); acc.w = fmaf(pk, v.w, acc.w);
         }
