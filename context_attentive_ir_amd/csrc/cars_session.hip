@@ -157,17 +157,17 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
 #pragma unroll 4
         for (int q = wave; q < nq1; q += 4) {
             const int k = 16 * q + 4 * g;
-            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            // unconditional loads from a clamped k (a per-lane `if (k < I) load` becomes an exec-masked block with its own wait);
+            // the weight fragment carries the k mask, the batch rows their row mask
+            const float km = k < I ? 1.f : 0.f;
+            const int kc = k < I ? k : 0;
+            float4 a4 = *reinterpret_cast<const float4*>(wi + kc);
+            a4.x *= km; a4.y *= km; a4.z *= km; a4.w *= km;
             float4 b4[NB];
-            const bool kv = k < I;
-            if (kv) a4 = *reinterpret_cast<const float4*>(wi + k);
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
-                b4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kv) {
-                    b4[t] = *reinterpret_cast<const float4*>(xr[t] + k);
-                    b4[t].x *= bm[t]; b4[t].y *= bm[t]; b4[t].z *= bm[t]; b4[t].w *= bm[t];
-                }
+                b4[t] = *reinterpret_cast<const float4*>(xr[t] + kc);
+                b4[t].x *= bm[t]; b4[t].y *= bm[t]; b4[t].z *= bm[t]; b4[t].w *= bm[t];
             }
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
@@ -180,17 +180,15 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
 #pragma unroll 4
         for (int q = wave; q < nq2; q += 4) {
             const int k = 16 * q + 4 * g;
-            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float km = k < H ? 1.f : 0.f;
+            const int kc = k < H ? k : 0;
+            float4 a4 = *reinterpret_cast<const float4*>(wh + kc);
+            a4.x *= km; a4.y *= km; a4.z *= km; a4.w *= km;
             float4 b4[NB];
-            const bool kv = k < H;
-            if (kv) a4 = *reinterpret_cast<const float4*>(wh + k);
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
-                b4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kv) {
-                    b4[t] = *reinterpret_cast<const float4*>(hr[t] + k);
-                    b4[t].x *= bm[t]; b4[t].y *= bm[t]; b4[t].z *= bm[t]; b4[t].w *= bm[t];
-                }
+                b4[t] = *reinterpret_cast<const float4*>(hr[t] + kc);
+                b4[t].x *= bm[t]; b4[t].y *= bm[t]; b4[t].z *= bm[t]; b4[t].w *= bm[t];
             }
 #pragma unroll
             for (int t = 0; t < NB; ++t) {

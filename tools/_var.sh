@@ -4,5 +4,5 @@ for cfg in C5_cars_bf16 C3_cars; do
 for S in 1 4; do
   st=400; case $cfg in C5_cars_bf16) st=40;; esac
   out=$(timeout 300 python bench.py --config $cfg --sub none --streams $S --steps $st --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1)
-  echo "$cfg S=$S $(echo "$out" | python -c 'import sys,json; r=json.loads(sys.stdin.read()); k=r["roofline"]["kernels_us_per_step"]; print(r["value"], r["ms_per_step"], {a:b for a,b in k.items() if "click_pool" in a})' 2>&1 | tail -1)"
+  echo "$cfg S=$S $(echo "$out" | python -c 'import sys,json; r=json.loads(sys.stdin.read()); k=r["roofline"]["kernels_us_per_step"]; print(r["value"], r["ms_per_step"], {a:b for a,b in k.items() if "lstm_step" in a or "gemm16" in a})' 2>&1 | tail -1)"
 done; done
