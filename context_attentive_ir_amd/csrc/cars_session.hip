@@ -154,50 +154,40 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
         f32x4 acc[NB];
 #pragma unroll
         for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int q = wave; q < nq1; q += 4) {
-            const int k = 16 * q + 4 * g;
-            // unconditional loads from a clamped k (a per-lane `if (k < I) load` becomes an exec-masked block with its own wait);
-            // the weight fragment carries the k mask, the batch rows their row mask
-            const float km = k < I ? 1.f : 0.f;
-            const int kc = k < I ? k : 0;
-            float4 a4 = *reinterpret_cast<const float4*>(wi + kc);
-            a4.x *= km; a4.y *= km; a4.z *= km; a4.w *= km;
-            float4 b4[NB];
+        // k-groups in chunks of CH with all of a chunk's operand loads issued before its first MFMA.  (`#pragma unroll 4` on the
+        // runtime-strided loop `for (q = wave; q < nq; q += 4)` was not honoured: every k-group waited for its own L2 round trip --
+        // 12 round trips per step at I + H = 768.)  Unconditional loads from a clamped k, masked afterwards.
+        constexpr int CH = NB <= 2 ? 4 : 2;       // (8 measured slower at B = 16: the 4 x-part groups of a wave fill half a chunk)
+        auto accumulate = [&](const float* wrow, const float* const (&rows)[NB], int K, int nq) {
+            for (int q0 = wave; q0 < nq; q0 += 4 * CH) {
+                float4 a4[CH], b4[CH][NB];
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                b4[t] = *reinterpret_cast<const float4*>(xr[t] + kc);
-                b4[t].x *= bm[t]; b4[t].y *= bm[t]; b4[t].z *= bm[t]; b4[t].w *= bm[t];
-            }
+                for (int c = 0; c < CH; ++c) {
+                    const int k = 16 * (q0 + 4 * c) + 4 * g;
+                    const float km = k < K ? 1.f : 0.f;
+                    const int kc = k < K ? k : 0;
+                    a4[c] = *reinterpret_cast<const float4*>(wrow + kc);
+                    a4[c].x *= km; a4[c].y *= km; a4[c].z *= km; a4[c].w *= km;
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
-            }
-        }
-#pragma unroll 4
-        for (int q = wave; q < nq2; q += 4) {
-            const int k = 16 * q + 4 * g;
-            const float km = k < H ? 1.f : 0.f;
-            const int kc = k < H ? k : 0;
-            float4 a4 = *reinterpret_cast<const float4*>(wh + kc);
-            a4.x *= km; a4.y *= km; a4.z *= km; a4.w *= km;
-            float4 b4[NB];
+                    for (int t = 0; t < NB; ++t) {
+                        b4[c][t] = *reinterpret_cast<const float4*>(rows[t] + kc);
+                        b4[c][t].x *= bm[t]; b4[c][t].y *= bm[t]; b4[c][t].z *= bm[t]; b4[c][t].w *= bm[t];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);     // without it the scheduler sinks every load next to its first use again
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                b4[t] = *reinterpret_cast<const float4*>(hr[t] + kc);
-                b4[t].x *= bm[t]; b4[t].y *= bm[t]; b4[t].z *= bm[t]; b4[t].w *= bm[t];
-            }
+                for (int c = 0; c < CH; ++c)
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NB; ++t) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].x, b4[c][t].x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].y, b4[c][t].y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].z, b4[c][t].z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].w, b4[c][t].w, acc[t], 0, 0, 0);
+                    }
             }
-        }
+        };
+        accumulate(wi, xr, I, nq1);
+        if (nq2 > 0) accumulate(wh, hr, H, nq2);
 #pragma unroll
         for (int t = 0; t < NB; ++t)
 #pragma unroll
