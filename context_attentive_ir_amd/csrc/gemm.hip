@@ -255,6 +255,45 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p) {
     const float* wrow = p.w + (int64_t)(nval ? n : 0) * p.ldw;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int nq = (p.K + 15) / 16;
+    if (VEC && !p.ids && nq >= 32) {               // K >= 512 (shorter K: one chunk per wave, the look-ahead only over-fetches: 7 -> 10 us at K = 256)
+        // dense operands: k-groups in chunks of 4, two chunks in ping-pong -- the loads of the next chunk are issued before the MFMAs
+        // of the current one.  (The `#pragma unroll 4` below is not honoured on this runtime-strided loop: every k-group paid its own
+        // L2 round trip, 20 in a row at K = 1280.)  Unconditional loads from clamped addresses, masked afterwards.
+        constexpr int CH = 4;
+        const float* abase = p.a + (mval ? m : 0) * p.lda;
+        auto loadc = [&](int q0, float4 (&a4)[CH], float4 (&b4)[CH]) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int k = 16 * (q0 + 4 * c) + 4 * g;
+                const int kc = k < p.K ? k : 0;
+                a4[c] = *reinterpret_cast<const float4*>(abase + kc);
+                b4[c] = *reinterpret_cast<const float4*>(wrow + kc);
+            }
+        };
+        auto mmac = [&](int q0, float4 (&a4)[CH], float4 (&b4)[CH]) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int k = 16 * (q0 + 4 * c) + 4 * g;
+                const float ma = (mval && k < p.K) ? 1.f : 0.f, mb = (nval && k < p.K) ? 1.f : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].x * ma, b4[c].x * mb, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].y * ma, b4[c].y * mb, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].z * ma, b4[c].z * mb, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].w * ma, b4[c].w * mb, acc, 0, 0, 0);
+            }
+        };
+        float4 a0[CH], b0[CH], a1[CH], b1[CH];
+        loadc(wave, a0, b0);
+        for (int q0 = wave; q0 < nq; q0 += 8 * CH) {
+            loadc(q0 + 4 * CH, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mmac(q0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            loadc(q0 + 8 * CH, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mmac(q0 + 4 * CH, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
 #pragma unroll 4
     for (int q = wave; q < nq; q += 4) {
         const int k = 16 * q + 4 * g;
@@ -349,7 +388,9 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nq = p.K / 16;                       // K % 16 == 0 (launcher)
-#pragma unroll 2
+    // (one k-group per iteration: issuing the next group's loads ahead of the MFMAs -- two operand sets in ping-pong -- changed nothing
+    // here: 32 fp32 MFMAs per k-group are ~1 000 matrix-pipe cycles, longer than the L2 round trip; the kernel is bound by its 288
+    // workgroups on 256 CUs and the fp32 MFMA rate)
     for (int q = wave; q < nq; q += 4) {
         float4 a4[RA], b4[2];
 #pragma unroll
