@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(GemmArgs p) {
 // Mid-size path (hundreds to a few thousand rows: CARS' maxout layers over B*S*N candidate rows).  Same exact-fp32 arithmetic and K split
 // as gemm16_kernel, but a workgroup owns a 32x32 output block: a wave's two A and two W fragments of a k-group feed 16 MFMAs instead of
 // 4 (half the L2 bytes per flop, twice the MFMA work behind every load).  1120x512x1024: 43 -> 27 us.
-template <int RA>                                  // RA row tiles x 2 column tiles of 16x16 per workgroup (32 or 64 rows x 32 columns)
+template <int RA>                                  // RA row tiles x 2 column tiles of 16x16 per workgroup (16 RA rows x 32 columns)
 __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
     __shared__ float red[4][2 * RA][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1074,11 +1074,30 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
     } else if (mb * nb < 160 && !tun(g_tun.no_gemm16) && !ids && vec && K % 16 == 0 && ((M + 31) / 32) * ((N + 31) / 32) >= 200) {
         // mid-size: 32x32 output blocks still give >= 200 workgroups
         ProfScope ps(prof_shape_name("gemm32_kernel", M, N, K), st);
-        if (((M + 63) / 64) * ((N + 31) / 32) >= 256)   // 64-row blocks once they still cover every CU: 3 us slower alone (27 -> 30 us at
-                                                         // 1120x512x1024), less CU time with several batches in flight (C3: 6.05 M -> 6.15 M pairs/s)
-            hipLaunchKernelGGL(gemm32_kernel<4>, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 31) / 32)), dim3(256), 0, st, p);
-        else
-            hipLaunchKernelGGL(gemm32_kernel<2>, dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, st, p);
+        // rows per workgroup (16 RA) chosen for the fewest rounds of workgroups over the CUs times the work per workgroup: 1120 x 512 is
+        // 288 workgroups of 64 rows (two rounds on 256 CUs, 28 us) but 224 of 80 rows (one round)
+        static const int ncu = [] {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                       ? prop.multiProcessorCount : 256;
+        }();
+        const int64_t ncol = (N + 31) / 32;
+        int best = 2;
+        int64_t best_cost = INT64_MAX;
+        for (int ra = 2; ra <= (K >= 512 ? 6 : 2); ++ra) {     // short K: prologue / reduction dominate, the smallest block wins (1120 x 256 x 256)
+            const int64_t wgs = ((M + 16 * ra - 1) / (16 * ra)) * ncol;
+            const int64_t cost = ((wgs + ncu - 1) / ncu) * ra;
+            if (cost < best_cost) { best_cost = cost; best = ra; }
+        }
+        const dim3 grid((unsigned)((M + 16 * best - 1) / (16 * best)), (unsigned)ncol);
+        switch (best) {
+            case 2: hipLaunchKernelGGL(gemm32_kernel<2>, grid, dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL(gemm32_kernel<3>, grid, dim3(256), 0, st, p); break;
+            case 4: hipLaunchKernelGGL(gemm32_kernel<4>, grid, dim3(256), 0, st, p); break;
+            case 5: hipLaunchKernelGGL(gemm32_kernel<5>, grid, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL(gemm32_kernel<6>, grid, dim3(256), 0, st, p); break;
+        }
     } else if (mb * nb < 160 && !tun(g_tun.no_gemm16)) {
         // too few 64x64 tiles to fill 256 CUs: one 16x16 tile per workgroup, K split over the waves
         ProfScope ps(prof_shape_name(ids ? "gemm16_kernel[gather]" : "gemm16_kernel", M, N, K), st);
