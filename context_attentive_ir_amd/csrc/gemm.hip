@@ -388,18 +388,23 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nq = p.K / 16;                       // K % 16 == 0 (launcher)
-    // (one k-group per iteration: issuing the next group's loads ahead of the MFMAs -- two operand sets in ping-pong -- changed nothing
-    // here: 32 fp32 MFMAs per k-group are ~1 000 matrix-pipe cycles, longer than the L2 round trip; the kernel is bound by its 288
-    // workgroups on 256 CUs and the fp32 MFMA rate)
-    for (int q = wave; q < nq; q += 4) {
-        float4 a4[RA], b4[2];
+    // Two operand sets in ping-pong: the loads of k-group q+4 are issued before the MFMAs of k-group q (the strided k-loop is not
+    // unrolled by the compiler, and without the sched_barriers every load sinks next to its first use).  With one workgroup per CU
+    // (the launcher picks RA for a single round) nothing else hides the L2 round trip of a k-group.  A k-group past the end re-reads
+    // group 0 and is masked to zero.
+    auto loadk = [&](int q, float4 (&a4)[RA], float4 (&b4)[2], float& km) {
+        km = q < nq ? 1.f : 0.f;
+        const int qc = q < nq ? q : 0;
 #pragma unroll
-        for (int h = 0; h < RA; ++h) a4[h] = *reinterpret_cast<const float4*>(ar[h] + 16 * q);
+        for (int h = 0; h < RA; ++h) a4[h] = *reinterpret_cast<const float4*>(ar[h] + 16 * qc);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) b4[h] = *reinterpret_cast<const float4*>(wr[h] + 16 * q);
+        for (int h = 0; h < 2; ++h) b4[h] = *reinterpret_cast<const float4*>(wr[h] + 16 * qc);
+    };
+    auto mma = [&](float4 (&a4)[RA], float4 (&b4)[2], float km) {
 #pragma unroll
         for (int h = 0; h < RA; ++h) {             // rows / columns past the edge contribute zeros (clamped address, 0/1 mask)
-            a4[h].x *= am[h]; a4[h].y *= am[h]; a4[h].z *= am[h]; a4[h].w *= am[h];
+            const float m = am[h] * km;
+            a4[h].x *= m; a4[h].y *= m; a4[h].z *= m; a4[h].w *= m;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -414,6 +419,19 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs p) {
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[a].z, b4[b].z, acc[a][b], 0, 0, 0);
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[a].w, b4[b].w, acc[a][b], 0, 0, 0);
             }
+    };
+    float4 a0[RA], b0[2], a1[RA], b1[2];
+    float k0, k1;
+    loadk(wave, a0, b0, k0);
+    for (int q = wave; q < nq; q += 8) {
+        loadk(q + 4, a1, b1, k1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0, k0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadk(q + 8, a0, b0, k0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1, k1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int a = 0; a < RA; ++a)
