@@ -383,41 +383,46 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-                f16x8 an[2][2];
+                // Two A-fragment sets in ping-pong (the step count 2 kw2 is even): a step first pins the hand-over of its own set (loaded
+                // during the previous step), then issues the loads of the other set for the next step, then runs its 12 MFMAs.  With one
+                // set copied at the top of each step the compiler moved the copies to where the old values died -- two MFMAs into the
+                // step, behind an s_waitcnt for the loads issued a few instructions earlier: one exposed L2 round trip per k-step.
+                f16x8 fa[2][2], fb[2][2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) an[i][t] = *reinterpret_cast<const f16x8*>(ua + (i * 2 + t) * 512);
+                    for (int t = 0; t < 2; ++t) fa[i][t] = *reinterpret_cast<const f16x8*>(ua + (i * 2 + t) * 512);
                 const int nstep = 2 * kw2;
-                for (int st = 0; st < nstep; ++st) {
-                    f16x8 af[2][2], bf[2][2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) af[i][t] = an[i][t];
-                    const int sn = st + 1 < nstep ? st + 1 : st;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) an[i][t] = *reinterpret_cast<const f16x8*>(ua + sn * astep + (i * 2 + t) * 512);
-                    const _Float16* bp = bb + (st >> 1) * CPH + 32 * (st & 1);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) bf[j][t] = *reinterpret_cast<const f16x8*>(bp + t * DLH * CPH + j * 16 * CPH);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], acx[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], acx[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+#define MT_H2_STEP(ST, CUR, NXT)                                                                                              \
+                {                                                                                                             \
+                    f16x8 bf[2][2];                                                                                           \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+                        _Pragma("unroll") for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(CUR[i][t]));                     \
+                    const int sn = (ST) + 1 < nstep ? (ST) + 1 : (ST);                                                        \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+                        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
+                            NXT[i][t] = *reinterpret_cast<const f16x8*>(ua + sn * astep + (i * 2 + t) * 512);                 \
+                    const _Float16* bp = bb + ((ST) >> 1) * CPH + 32 * ((ST) & 1);                                            \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+                        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
+                            bf[j][t] = *reinterpret_cast<const f16x8*>(bp + t * DLH * CPH + j * 16 * CPH);                    \
+                    __builtin_amdgcn_sched_barrier(0);                                                                        \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+                            acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[i][1], bf[j][0], acx[i][j], 0, 0, 0);      \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+                            acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[i][0], bf[j][1], acx[i][j], 0, 0, 0);      \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[i][0], bf[j][0], acc[i][j], 0, 0, 0);      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                        \
                 }
+                for (int st = 0; st < nstep; st += 2) {
+                    MT_H2_STEP(st, fa, fb)
+                    MT_H2_STEP(st + 1, fb, fa)
+                }
+#undef MT_H2_STEP
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
