@@ -149,6 +149,12 @@ for N in (5, 3):
     s_full = O.cars_encode_session(sdc, pooled, full, O.cars_encode_clicks(sdc, full, ex["document_labels"]))
     s_got = O.cars_encode_session(sdc, pooled, got, O.cars_encode_clicks(sdc, got, ex["document_labels"]))
     assert torch.allclose(s_got, s_full, atol=1e-6)
+    # sharded ranker MLP: clicks / sessions from the gathered documents, scores of this rank's own pooled slice, score slices gathered
+    got2, own = sharding.sharded_pooled_docs(enc, ex["document_words"], ex["document_lens"], return_local=True)
+    assert torch.allclose(got2, full, atol=1e-6) and own.shape[2] == (N + world - 1) // world
+    s_loc = O.cars_encode_session(sdc, pooled, own, O.cars_encode_clicks(sdc, got2, ex["document_labels"]))
+    s_all = sharding.gather_session_scores(s_loc, N)
+    assert s_all.shape == s_full.shape and torch.allclose(s_all, s_full, atol=1e-6), (rank, N)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
