@@ -272,14 +272,54 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     batches = make_batches(c, args.nbatches, 0 if sharded or not env.multi else rank, dev)
     pairs_global = c["batch"] * c["cands"] * (c["session"] if is_sess else 1)
     ncand = c["cands"]
-    if sharded and is_sess:
+    plan = None
+    if sharded and c["model"] == "cars":
+        # round 3: candidate-sharded encode -> all-to-all -> session-sharded tail -> all-gather of the probabilities (sharding.SessionShardPlan);
+        # every per-rank input slice is resident in HBM like the full batch would be
+        plan = sharding.SessionShardPlan(c["batch"], c["session"], ncand, wsh, rank)
+        for b in batches:
+            b["_q_own"], b["_ql_own"] = plan.own(b["source_words"]), plan.own(b["source_lens"])
+            b["_doc_shard"], b["_len_shard"] = plan.doc_shard(b["document_words"], b["document_lens"])
+            b["_lab_own"] = plan.own(b["document_labels"])
+    elif sharded and is_sess:
         model.parallelize()
     if sharded and not is_sess:       # pre-slice this rank's candidate shard (resident in HBM like the full batch would be)
         for b in batches:
             b["doc_rep"], b["doc_len"] = sharding.shard_candidates(b["doc_rep"], b["doc_len"], wsh, rank)
 
+    coll = {}       # per (batch slot) exchange / gather buffers of the sharded CARS step
+
+    def cars_bufs(key, D=256):
+        if key not in coll:
+            G, bper, S_, per = plan.world, plan.bper, plan.S, plan.per
+            coll[key] = (torch.zeros(G, bper, S_, per, D, device=dev), torch.zeros(bper, S_, ncand, device=dev),
+                         torch.zeros(G * bper, S_, ncand, device=dev))
+        return coll[key]
+
+    def sharded_cars_step(ex, key):
+        """one candidate-/session-sharded CARS ranking step (eager or under capture): encode | all-to-all | tail | all-gather."""
+        recv, probs_own, allp = cars_bufs(key)
+        pq, pl = model.shard_encode(ex["_q_own"], ex["_ql_own"], ex["_doc_shard"], ex["_len_shard"])
+        if env.backend == "nccl":
+            # (emulated world: the 1-rank group copies the whole buffer -- the bytes a real exchange moves, meaningless scores)
+            env.dist.all_to_all_single(recv.view(pl.shape), pl)
+        else:
+            h = torch.empty(pl.shape)
+            env.dist.all_to_all_single(h, pl.cpu())
+            recv.view(pl.shape).copy_(h)
+        model.shard_tail(pq, recv, ex["_lab_own"], ex["document_labels"], ncand, probs_own)
+        if env.backend == "nccl":
+            env.dist.all_gather_into_tensor(allp[:plan.bper] if emu else allp, probs_own)
+        else:
+            h = torch.empty(allp.shape)
+            env.dist.all_gather_into_tensor(h, probs_own.cpu())
+            allp.copy_(h)
+        return allp[:c["batch"]]
+
     def forward(i):
         ex = batches[i % len(batches)]
+        if plan is not None:
+            return sharded_cars_step(ex, ("eager", i % len(batches)))
         if is_sess:
             return model.predict(ex, suggest=False)["click_scores"]
         s = model.network(ex["que_rep"], ex["que_len"], ex["doc_rep"], ex["doc_len"])
@@ -291,16 +331,13 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
 
     lanes = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
     fbufs = [None] * len(lanes)
-    # Candidate-sharded CARS over RCCL: the step is two hipGraphs (queries + this rank's document shard -> pooled vectors | clicks,
-    # sessions and the ranker MLP over this rank's candidate slice) around an eager all-gather of the pooled shard, followed by an
-    # eager KB-sized all-gather of the score slices and the softmax kernel; replaying the whole step eagerly is host-bound (measured
-    # 0.43 ms/step of enqueue against 0.22 ms of GPU time).  torch.distributed runs the collectives of all lanes on its own stream in
-    # issue order.
-    staged = sharded and is_sess and env.backend == "nccl" and c["model"] == "cars" and not args.no_graph
-    if staged:
-        for b in batches:
-            b["_doc_shard"], b["_len_shard"] = sharding.shard_session_candidates(b["document_words"], b["document_lens"], wsh, rank)
-
+    # Candidate-/session-sharded CARS over RCCL.  Preferred: FUSED graphs -- KSTEP whole steps (kernels AND both collectives) captured into one
+    # hipGraph as KSTEP parallel branches, replayed back to back on one stream: one host call per KSTEP steps, and the collectives of all ranks
+    # run in capture order on the process group's communication stream (identical on every rank; only one such graph is in flight per
+    # communicator).  Fallback: STAGED -- two hipGraphs per step around eager collectives (host-bound at ~0.07 ms/step).  Last: eager.
+    fused_ok = plan is not None and env.backend == "nccl" and not args.no_graph and not os.environ.get("BENCH_NO_COLL_CAPTURE")
+    staged = plan is not None and env.backend == "nccl" and not args.no_graph
+    KSTEP = max(1, int(os.environ.get("BENCH_KSTEP", "8")))
     def finish(s):
         """cross-rank part of a ranker step (eager): one all-gather of the score shards, softmax over all candidates."""
         if not sharded or is_sess:
@@ -332,38 +369,72 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     stages = None
     if env.multi:
         time.sleep(0.3)      # let the RCCL watchdog (100 ms poll) retire the finished warm-up collectives before any capture starts
+    fused = None
+    if fused_ok:
+        try:
+            probe_a = torch.zeros(wsh if not emu else 1, 8, device=dev); probe_b = torch.zeros_like(probe_a)
+            env.dist.all_to_all_single(probe_b, probe_a)
+            torch.cuda.synchronize()
+            time.sleep(0.3)
+            pg = torch.cuda.CUDAGraph()                       # does this build capture a collective at all?
+            with torch.cuda.graph(pg, stream=lanes[0], capture_error_mode=CAPTURE_MODE):
+                env.dist.all_to_all_single(probe_b, probe_a)
+            pg.replay()
+            torch.cuda.synchronize()
+            branches = [torch.cuda.Stream() for _ in range(KSTEP)]
+            L.nir_set_batches_in_flight(KSTEP)
+
+            def capture_group(first, n):
+                """n consecutive steps (batches first .. first+n-1) as parallel branches of ONE graph; returns (graph, outputs)."""
+                keys = [("fused", first, j) for j in range(n)]
+                for j in range(n):                               # warm: packs, workspaces, collective buffers
+                    with torch.cuda.stream(branches[j]):
+                        sharded_cars_step(batches[(first + j) % len(batches)], keys[j])
+                torch.cuda.synchronize()
+                time.sleep(0.3)
+                g, outs = torch.cuda.CUDAGraph(), []
+                with torch.cuda.graph(g, stream=lanes[0], capture_error_mode=CAPTURE_MODE):
+                    main = torch.cuda.current_stream()
+                    for j in range(n):
+                        branches[j].wait_stream(main)
+                        with torch.cuda.stream(branches[j]):
+                            outs.append(sharded_cars_step(batches[(first + j) % len(batches)], keys[j]))
+                    for j in range(n):
+                        main.wait_stream(branches[j])
+                return g, outs
+            fused = {"full": [capture_group(0, KSTEP), capture_group(KSTEP, KSTEP)], "rem": {}, "capture": capture_group}
+            staged = False
+        except Exception as e:  # pragma: no cover - falls back to staged graphs around eager collectives
+            print("[bench] collectives could not be captured for %s (%s: %s); staged graphs" % (name, type(e).__name__, e), file=sys.stderr)
+            fused = None
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            L.nir_set_batches_in_flight(len(lanes))
     if staged:
         try:
             stages = []
             for i in range(len(batches)):
                 ex, ln = batches[i], lanes[lane_of(i)]
+                recv, probs_own, allp = cars_bufs(("staged", i))
                 with torch.cuda.stream(ln):                     # warm (packs, workspaces), then capture both halves
-                    pq, pl = model.shard_stage_a(ex, ex["_doc_shard"], ex["_len_shard"])
-                    B_, S_, per_, D_ = pl.shape
-                    gbuf = torch.zeros(wsh * B_ * S_, per_ * D_, device=dev, dtype=pl.dtype)
-                    gdst = gbuf[:B_ * S_] if emu else gbuf
-                    env.dist.all_gather_into_tensor(gdst, pl.reshape(B_ * S_, per_ * D_))
-                    sl = model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand, own=pl)
-                    sbuf = torch.zeros(wsh * B_ * S_, per_, device=dev)
-                    sdst = sbuf[:B_ * S_] if emu else sbuf
-                    env.dist.all_gather_into_tensor(sdst, sl)
-                    probs = model.shard_stage_c(sbuf, torch.empty(B_ * S_, ncand, device=dev), ncand)
+                    sharded_cars_step(ex, ("staged", i))
                 torch.cuda.synchronize()
                 time.sleep(0.3)
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga, stream=ln, capture_error_mode=CAPTURE_MODE):
-                    pq, pl = model.shard_stage_a(ex, ex["_doc_shard"], ex["_len_shard"])
-                    flat = pl.reshape(B_ * S_, per_ * D_)
+                    pq, pl = model.shard_encode(ex["_q_own"], ex["_ql_own"], ex["_doc_shard"], ex["_len_shard"])
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, stream=ln, capture_error_mode=CAPTURE_MODE):
-                    sl = model.shard_stage_b(pq, gbuf, ex["document_labels"], ncand, own=pl)
-                stages.append((ga, flat, gdst, gb, sl, sdst, sbuf, probs))
+                    model.shard_tail(pq, recv, ex["_lab_own"], ex["document_labels"], ncand, probs_own)
+                stages.append((ga, pl, recv.view(pl.shape), gb, probs_own, allp[:plan.bper] if emu else allp, allp[:c["batch"]]))
         except Exception as e:  # pragma: no cover - falls back to the eager sharded step
             print("[bench] staged graph capture unavailable for %s (%s); eager sharded steps" % (name, e), file=sys.stderr)
             stages = None
             torch.cuda.synchronize()
     # the sharded CARS step contains a collective (all-gather of the pooled documents) between its kernels: staged graphs above, else eager
-    use_graph = not args.no_graph and not (sharded and is_sess) and not (env.backend != "nccl" and env.multi)
+    use_graph = not args.no_graph and not (sharded and is_sess) and not (env.backend != "nccl" and env.multi) and fused is None
     if use_graph:
         try:
             graphs = []
@@ -380,14 +451,13 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     def run(i, only_lane=None):
         ln = lane_of(i) if only_lane is None else only_lane
         if stages is not None:
-            ga, flat, gbuf, gb, sl, sdst, sbuf, probs = stages[i % len(stages)]
+            ga, pl, rdst, gb, probs_own, adst, out = stages[i % len(stages)]
             with torch.cuda.stream(lanes[ln]):
                 ga.replay()
-                env.dist.all_gather_into_tensor(gbuf, flat)
+                env.dist.all_to_all_single(rdst, pl)
                 gb.replay()
-                env.dist.all_gather_into_tensor(sdst, sl)
-                model.shard_stage_c(sbuf, probs, ncand)
-            return probs.view(sl.shape[0] // c["session"], c["session"], ncand)
+                env.dist.all_gather_into_tensor(adst, probs_own)
+            return out
         with torch.cuda.stream(lanes[ln]):
             if graphs is not None:
                 g, out = graphs[i % len(graphs)]
@@ -396,14 +466,30 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 out = forward(i)
             return finish(out)
 
-    for i in range(warmup):
-        run(i)
+    def run_steps(n):
+        """exactly n steps: fused groups of KSTEP (+ one remainder group) on one stream, else one replay / eager call per step."""
+        if fused is None:
+            for i in range(n):
+                run(i)
+            return
+        with torch.cuda.stream(lanes[0]):
+            for k in range(n // KSTEP):
+                fused["full"][k % 2][0].replay()
+            rem = n % KSTEP
+            if rem:
+                if rem not in fused["rem"]:
+                    fused["rem"][rem] = fused["capture"](2 * KSTEP, rem)
+                fused["rem"][rem][0].replay()
+
+    if fused is not None:                    # remainder groups are captured before the timed region
+        for n in {max(warmup, 1) % KSTEP, steps % KSTEP, max(6, min(steps, 60)) % KSTEP} - {0}:
+            fused["rem"][n] = fused["capture"](2 * KSTEP, n)
+    run_steps(max(warmup, 1))
     torch.cuda.synchronize()
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        run(i)
+    run_steps(steps)
     host_ms = (time.perf_counter() - t0) / steps * 1e3
     torch.cuda.synchronize()
     env.barrier()
@@ -427,8 +513,11 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         torch.cuda.synchronize()
         env.barrier()
         ts = time.perf_counter()
-        for i in range(ns):
-            run(i, only_lane=0)
+        if fused is not None:          # (fused graphs: the same KSTEP-wide groups; "one in flight" has no separate meaning there)
+            run_steps(ns)
+        else:
+            for i in range(ns):
+                run(i, only_lane=0)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - ts) / ns * 1e3
         env.barrier()
@@ -523,6 +612,12 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     if env.multi:
         if not sharded:
             par = "x%d independent per-rank batches, no collective (weak scaling)" % world
+        elif plan is not None:
+            par = "strong: candidate-sharded encode x%d -> %s all-to-all (%d B out per rank and step) -> session-sharded tail -> all-gather of probabilities; %s" % (
+                wsh, "RCCL" if env.backend == "nccl" else env.backend, plan.exchange_bytes(256),
+                ("%d steps + collectives per hipGraph" % KSTEP) if fused is not None else ("2 hipGraphs per step around eager collectives" if stages is not None else "eager"))
+            if emu:
+                par += " [EMULATED on one GPU: rank 0's 1/%d share of the work, loop-back collectives, no xGMI latency]" % wsh
         elif is_sess:
             par = "strong: candidate-sharded document encoding x%d (Multitask.parallelize) + %s all-gather of pooled documents, session part replicated" % (
                 world, "RCCL" if env.backend == "nccl" else env.backend)
@@ -531,7 +626,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 world, batches[0]["doc_rep"].shape[1], "RCCL" if env.backend == "nccl" else env.backend)
     return {"name": name, "baseline_config": c.get("baseline"), "workload": tag, "pairs_per_s": round(value, 1), "ms_per_step": round(ms_per_step, 5),
             "ms_per_step_one_batch_in_flight": round(single_ms, 5), "global_batch_pairs": per_step_pairs, "parallelism": par, "world_size": world,
-            "steps": steps, "hipgraph": (graphs is not None) or (stages is not None), "batches_in_flight": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
+            "steps": steps, "hipgraph": (graphs is not None) or (stages is not None) or (fused is not None), "batches_in_flight": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
             "dtype": c.get("dtype", "f32"), "roofline": roofline, "cpu_baseline": cpu}
 

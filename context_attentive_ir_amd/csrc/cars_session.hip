@@ -33,22 +33,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // rank by label, attend over {rank < count} U {rank >= m} (Appendix E2), logits e_k = sum of the NP epilogue partials + b3
 __global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restrict__ docs, const float* __restrict__ epart, int NP,
                                                           const float* __restrict__ b3, const float* __restrict__ labels,
+                                                          const float* __restrict__ labels_all, int rows_all,
                                                           int rows, int N, int D, float* __restrict__ clicks) {
+    // labels_all [rows_all, N]: the label matrix the batch-wide click count m is taken over -- the rows of this call, or (session-sharded
+    // callers) those of the whole global batch, of which `labels` [rows, N] is this rank's block of sessions
     __shared__ int part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {   // every workgroup recomputes m from the (tiny) label matrix: no extra launch, no cross-workgroup dependency
         // (N <= 64: one label per lane, the row's count is the population count of a ballot -- a DPP wave_sum per row made this
         // prologue 112 x ~150 cycles per workgroup at the C5 shape)
         int best = 0;
-        for (int r0 = wave; r0 < rows; r0 += 4 * 16) {     // 16 independent row loads in flight per wave (each is an L2 round trip)
+        for (int r0 = wave; r0 < rows_all; r0 += 4 * 16) { // 16 independent row loads in flight per wave (each is an L2 round trip)
             float lv[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {               // unconditional loads from clamped addresses (a predicated load becomes its own
                 const int r = r0 + 4 * j;                // exec-masked block with a full wait behind it), masked afterwards
-                lv[j] = labels[(int64_t)(r < rows ? r : 0) * N + (lane < N ? lane : 0)];
+                lv[j] = labels_all[(int64_t)(r < rows_all ? r : 0) * N + (lane < N ? lane : 0)];
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) best = max(best, (int)__popcll(__ballot(lv[j] != 0.f && lane < N && r0 + 4 * j < rows)));
+            for (int j = 0; j < 16; ++j) best = max(best, (int)__popcll(__ballot(lv[j] != 0.f && lane < N && r0 + 4 * j < rows_all)));
         }
         if (lane == 0) part[wave] = best;
     }
@@ -84,6 +87,84 @@ __global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restric
 #pragma unroll 8
         for (int k = 0; k < N; ++k) {                     // 8 independent 1 KB row reads in flight
             const float pk = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p), k));
+            const float4 v = *reinterpret_cast<const float4*>(docs + ((int64_t)r * N + k) * D + 4 * c);
+            acc.x = fmaf(pk, v.x, acc.x); acc.y = fmaf(pk, v.y, acc.y); acc.z = fmaf(pk, v.z, acc.z); acc.w = fmaf(pk, v.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(clicks + (int64_t)r * D + 4 * c) = acc;
+    }
+}
+
+// The same for N > 64 candidates (config.py:42: --num_candidates is free): a lane owns candidates lane, lane + 64, ..; the row's labels and
+// softmax weights are staged in LDS (dynamic: 4 waves x 2 x N floats).  Not a hot shape: plain loops.
+__global__ __launch_bounds__(256) void click_pool_big_kernel(const float* __restrict__ docs, const float* __restrict__ epart, int NP,
+                                                             const float* __restrict__ b3, const float* __restrict__ labels,
+                                                             const float* __restrict__ labels_all, int rows_all, int rows, int N, int D,
+                                                             float* __restrict__ clicks) {
+    extern __shared__ float csm[];
+    __shared__ int part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        int best = 0;
+        for (int r = wave; r < rows_all; r += 4) {
+            float c = 0.f;
+            for (int k = lane; k < N; k += 64) c += labels_all[(int64_t)r * N + k] != 0.f ? 1.f : 0.f;
+            best = max(best, (int)wave_sum(c));
+        }
+        if (lane == 0) part[wave] = best;
+    }
+    __syncthreads();
+    const int m = max(max(part[0], part[1]), max(part[2], part[3]));
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;                                 // (no workgroup barrier below this line)
+    float* lab = csm + (size_t)wave * 2 * N;
+    float* pw = lab + N;
+    float cnt = 0.f;
+    for (int k = lane; k < N; k += 64) {
+        const float v = labels[(int64_t)r * N + k];
+        lab[k] = v;
+        cnt += v != 0.f ? 1.f : 0.f;
+    }
+    const int count = (int)wave_sum(cnt);
+    __builtin_amdgcn_wave_barrier();                       // one wave: its DS operations execute in issue order
+    float mx = -INFINITY;
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        const int c = c0 + lane;
+        const float lc = c < N ? lab[c] : -INFINITY;
+        int rank = 0;
+        for (int k = 0; k < N; ++k) {
+            const float lk = lab[k];                       // wave-uniform address: LDS broadcast
+            rank += (lk > lc) || (lk == lc && k < c);
+        }
+        const bool keep = c < N && (rank < count || rank >= m);
+        float lg = -INFINITY;
+        if (keep) {
+            const float* lp = epart + ((int64_t)r * N + c) * NP;
+            float sacc = b3[0];
+            for (int j = 0; j < NP; j += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(lp + j);
+                sacc += (v.x + v.y) + (v.z + v.w);
+            }
+            lg = sacc;
+        }
+        if (c < N) pw[c] = lg;
+        mx = fmaxf(mx, lg);
+    }
+    mx = wave_max(mx);
+    float den = 0.f;
+    for (int c = lane; c < N; c += 64) {
+        const float lg = pw[c];
+        const float ex = lg == -INFINITY ? 0.f : expf(lg - mx);
+        pw[c] = ex;
+        den += ex;
+    }
+    den = wave_sum(den);
+    __builtin_amdgcn_wave_barrier();
+    const int nch = D >> 2;
+    for (int c = lane; c < nch; c += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int k = 0; k < N; ++k) {
+            const float pk = pw[k] / den;                  // all masked -> 0 / 0 = NaN, exactly like softmax of all -inf in the reference
             const float4 v = *reinterpret_cast<const float4*>(docs + ((int64_t)r * N + k) * D + 4 * c);
             acc.x = fmaf(pk, v.x, acc.x); acc.y = fmaf(pk, v.y, acc.y); acc.z = fmaf(pk, v.z, acc.z); acc.w = fmaf(pk, v.w, acc.w);
         }
@@ -230,7 +311,8 @@ __global__ __launch_bounds__(256) void session_attend2_kernel(const float* __res
                                                               const float* __restrict__ Ds, const float* __restrict__ q,
                                                               int B, int S, int D, int HS, int q_on, int d_on,
                                                               float* __restrict__ xcat) {
-    __shared__ float lg[2][64];
+    extern __shared__ float lgs[];                       // [2 chains][S] logits of the <= S previous states
+    float* lg[2] = {lgs, lgs + S};
     const int bt = blockIdx.x, b = bt / S, t = bt % S;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = q_on + d_on;
@@ -319,14 +401,14 @@ __global__ void rank_feats_kernel(const float* qp, const float* docs, int N, int
 __global__ __launch_bounds__(256) void session_inner_pool_kernel(const float* __restrict__ states, const float* __restrict__ lpart,
                                                                  int NP, const float* __restrict__ b3, int B, int S, int HS,
                                                                  float* __restrict__ out /*[B,S,HS]*/) {
-    __shared__ float lg[64];
+    extern __shared__ float lg[];                         // [S]
     const int bt = blockIdx.x, b = bt / S, t = bt % S;
     const int n = t + 1;                                  // states 1..t+1
-    if (threadIdx.x < n) {
-        const float* lp = lpart + ((int64_t)threadIdx.x * B + b) * NP;     // lpart row 0 = state 1
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float* lp = lpart + ((int64_t)k * B + b) * NP;               // lpart row 0 = state 1
         float s = b3[0];
         for (int j = 0; j < NP; ++j) s += lp[j];
-        lg[threadIdx.x] = s;
+        lg[k] = s;
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -413,14 +495,22 @@ extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_
                                      const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
                                      float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
                                      nir_stream_t stream) {
-    return nir_cars_rank_session_shard(pooled_q, pooled_docs, labels, B, S, N, w, workspace, workspace_bytes, click_scores, clicks_out, extra,
-                                       nullptr, 0, stream);
+    return nir_cars_rank_session_rows(pooled_q, pooled_docs, labels, B, S, N, w, workspace, workspace_bytes, click_scores, clicks_out, extra,
+                                      nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int nir_cars_rank_session_shard(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
                                            const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
                                            float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
                                            const float* rank_docs, int NR, nir_stream_t stream) {
+    return nir_cars_rank_session_rows(pooled_q, pooled_docs, labels, B, S, N, w, workspace, workspace_bytes, click_scores, clicks_out, extra,
+                                      rank_docs, NR, nullptr, 0, stream);
+}
+
+extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
+                                          const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
+                                          float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
+                                          const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, nir_stream_t stream) {
     using namespace nir;
     hipStream_t st = (hipStream_t)stream;
     NIR_REQUIRE(pooled_q && w, "cars_rank_session: null pointer");
@@ -430,9 +520,10 @@ extern "C" int nir_cars_rank_session_shard(const float* pooled_q, const float* p
     NIR_REQUIRE(!d_on || (pooled_docs && labels), "cars_rank_session: the document session needs documents and labels");
     NIR_REQUIRE(nch == 0 || !rank_on || w->attn_ut, "cars_rank_session: packed attention weights missing (nir_cars_session_pack)");
     NIR_REQUIRE(B >= 0 && S > 0 && N > 0, "cars_rank_session: bad dims");
-    NIR_REQUIRE(N <= 64, "cars_rank_session: %d candidates > 64 unsupported", N);
+    NIR_REQUIRE(N <= 2048, "cars_rank_session: %d candidates > 2048 unsupported", N);
+    NIR_REQUIRE(!labels_all || (rows_all >= (int64_t)B * S && rows_all < (1 << 30)), "cars_rank_session: labels_all must hold at least the B*S rows of this call");
     NIR_REQUIRE(!rank_docs || (NR > 0 && NR <= N), "cars_rank_session: the ranked candidate slice must hold 1..N candidates (got %d)", NR);
-    NIR_REQUIRE(S <= 63, "cars_rank_session: session length %d > 63 unsupported", S);
+    NIR_REQUIRE(S <= 4096, "cars_rank_session: session length %d > 4096 unsupported", S);
     NIR_REQUIRE(w->D % 64 == 0 && w->HS % 16 == 0 && w->D % 16 == 0, "cars_rank_session: D %% 64 / HS %% 16 required");
     if (B == 0) return 0;
     const int D = w->D, HS = w->HS, NP = D / 16;
@@ -450,8 +541,14 @@ extern "C" int nir_cars_rank_session_shard(const float* pooled_q, const float* p
                                        ACT_TANH_ROWDOT16, w->click3_w, 0, st));
         {
             ProfScope ps("click_pool2_kernel", st);
-            hipLaunchKernelGGL(click_pool2_kernel, dim3((unsigned)((BS + 3) / 4)), dim3(256), 0, st, pooled_docs, p.epart, NP, w->click3_b, labels,
-                               (int)BS, N, D, clicks);
+            const float* lall = labels_all ? labels_all : labels;
+            const int rall = labels_all ? (int)rows_all : (int)BS;
+            if (N <= 64)
+                hipLaunchKernelGGL(click_pool2_kernel, dim3((unsigned)((BS + 3) / 4)), dim3(256), 0, st, pooled_docs, p.epart, NP, w->click3_b, labels,
+                                   lall, rall, (int)BS, N, D, clicks);
+            else
+                hipLaunchKernelGGL(click_pool_big_kernel, dim3((unsigned)((BS + 3) / 4)), dim3(256), (size_t)4 * 2 * N * sizeof(float), st, pooled_docs,
+                                   p.epart, NP, w->click3_b, labels, lall, rall, (int)BS, N, D, clicks);
         }
         NIR_CHECK_LAUNCH("click_pool2_kernel");
     }
@@ -485,7 +582,7 @@ extern "C" int nir_cars_rank_session_shard(const float* pooled_q, const float* p
         if (nch) {
             {
                 ProfScope ps("session_attend2_kernel", st);
-                hipLaunchKernelGGL(session_attend2_kernel, dim3((unsigned)BS), dim3(256), 0, st, p.U, NU, p.Qs, p.Ds, pooled_q, B, S, D, HS,
+                hipLaunchKernelGGL(session_attend2_kernel, dim3((unsigned)BS), dim3(256), 2 * S * sizeof(float), st, p.U, NU, p.Qs, p.Ds, pooled_q, B, S, D, HS,
                                    (int)q_on, (int)d_on, p.xcat);
             }
             NIR_CHECK_LAUNCH("session_attend2_kernel");
@@ -519,12 +616,12 @@ extern "C" int nir_cars_rank_session_shard(const float* pooled_q, const float* p
         if (extra->inner_q && q_on) {
             NIR_PROPAGATE(launch_linear_ex(p.Qs + (int64_t)B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sq_inner0_w, HS, w->sq_inner0_b, nullptr, p.lin, HS / 16,
                                            (int64_t)S * B, HS, HS, ACT_TANH_ROWDOT16, w->sq_inner3_w, 0, st));
-            hipLaunchKernelGGL(session_inner_pool_kernel, dim3((unsigned)BS), dim3(256), 0, st, p.Qs + (int64_t)B * HS, p.lin, HS / 16, w->sq_inner3_b, B, S, HS, extra->inner_q);
+            hipLaunchKernelGGL(session_inner_pool_kernel, dim3((unsigned)BS), dim3(256), S * sizeof(float), st, p.Qs + (int64_t)B * HS, p.lin, HS / 16, w->sq_inner3_b, B, S, HS, extra->inner_q);
         }
         if (extra->inner_d && d_on) {
             NIR_PROPAGATE(launch_linear_ex(p.Ds + (int64_t)B * HS, HS, nullptr, nullptr, 0, 0, 0, w->sd_inner0_w, HS, w->sd_inner0_b, nullptr, p.lin, HS / 16,
                                            (int64_t)S * B, HS, HS, ACT_TANH_ROWDOT16, w->sd_inner3_w, 0, st));
-            hipLaunchKernelGGL(session_inner_pool_kernel, dim3((unsigned)BS), dim3(256), 0, st, p.Ds + (int64_t)B * HS, p.lin, HS / 16, w->sd_inner3_b, B, S, HS, extra->inner_d);
+            hipLaunchKernelGGL(session_inner_pool_kernel, dim3((unsigned)BS), dim3(256), S * sizeof(float), st, p.Ds + (int64_t)B * HS, p.lin, HS / 16, w->sd_inner3_b, B, S, HS, extra->inner_d);
         }
         NIR_CHECK_LAUNCH("session_inner_pool_kernel");
         if (rows > 0 && extra->dec_h && w->th_w) {

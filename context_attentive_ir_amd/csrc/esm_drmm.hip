@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void drmm_kernel(const int64_t* __restrict__ q
     }
     __syncthreads();
     // phase 2: stream the document rows once
-    int cnt[NU];
+    // NU == 0 (queries longer than 25 tokens: more than 128 histogram slots): no register slots, one LDS atomic per (row, term)
+    int cnt[NU > 0 ? NU : 1];
 #pragma unroll
     for (int u = 0; u < NU; ++u) cnt[u] = 0;
     const int64_t* dids = d_ids + pair * DL;
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(256) void drmm_kernel(const int64_t* __restrict__ q
                 const int slot = (ok[r] && bin >= 0) ? i * 5 + bin : -1;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) cnt[u] += (slot == l16 + 16 * u);
+                if (NU == 0 && slot >= 0 && l16 == 0) atomicAdd(&hist[slot], 1);
             }
         }
     }
@@ -312,17 +314,28 @@ extern "C" int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     using namespace nir;
     NIR_REQUIRE(q_ids && d_ids && table && scores && w, "drmm: null pointer");
     NIR_REQUIRE(B >= 0 && N > 0 && QL > 0 && DL > 0 && V > 0, "drmm: bad dims B=%d N=%d QL=%d DL=%d", B, N, QL, DL);
-    NIR_REQUIRE(QL <= 25, "drmm: query length %d > 25 unsupported", QL);
+
     NIR_REQUIRE(E % 4 == 0 && E > 0 && E <= 256 * MAXCH, "drmm: emsize %d unsupported", E);
     NIR_REQUIRE(((uintptr_t)table & 15) == 0 && ((uintptr_t)w->gate_w & 15) == 0, "drmm: table/gate weight must be 16-byte aligned");
     if (B == 0) return 0;
     DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b};
     size_t lds = (size_t)QL * E * 4 + QL * 4 + QL * 5 * 4;
+    NIR_REQUIRE(lds <= 160 * 1024 - 512, "drmm: query length %d x emsize %d needs %zu bytes of LDS (> 160 KiB)", QL, E, lds);
+    const bool small = QL * 5 <= 32, narrow = E <= 320, longq = QL > 25;
+    if (lds > 64 * 1024) {      // (only long queries get here: the LDS-atomic instantiations)
+        hipError_t e = hipFuncSetAttribute(narrow ? (const void*)drmm_kernel<0, 5> : (const void*)drmm_kernel<0, 8>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("drmm: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
     ProfScope ps("drmm_kernel", (hipStream_t)stream);
-    const bool small = QL * 5 <= 32, narrow = E <= 320;
 #define NIR_DRMM_LAUNCH(nu, pc) hipLaunchKernelGGL((drmm_kernel<nu, pc>), dim3((unsigned)((int64_t)B * N)), dim3(256), lds, (hipStream_t)stream, \
                                                    q_ids, d_ids, N, QL, DL, table, E, dw, scores, hist_out)
-    if (small && narrow) NIR_DRMM_LAUNCH(2, 5);
+    if (longq && narrow) NIR_DRMM_LAUNCH(0, 5);
+    else if (longq) NIR_DRMM_LAUNCH(0, 8);
+    else if (small && narrow) NIR_DRMM_LAUNCH(2, 5);
     else if (small) NIR_DRMM_LAUNCH(2, 8);
     else if (narrow) NIR_DRMM_LAUNCH(8, 5);
     else NIR_DRMM_LAUNCH(8, 8);

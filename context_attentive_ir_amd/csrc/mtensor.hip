@@ -30,7 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CP = 56;     // channels padded 50 -> 56 so an 8-wide K group never straddles a conv tap (dj)
 constexpr int NFC = 6;     // filters per conv (hyparam.py:101)
 constexpr int MFC = 20;    // match_filter_size
-constexpr int JT = 64;     // document positions per chunk (2 MFMA column tiles)
+constexpr int JTMAX = 64;  // document positions per chunk: 64 (2 MFMA column tiles) or, when LDS is short (long documents), 32
+constexpr int MTGMAX = 3;  // row tiles (32 rows) of the folded operand per pass: 96 rows = 16 whole query positions x 6 filters
 
 struct MtHeadW {
     const float* conv_w[3];
@@ -144,7 +145,10 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const float* __restrict__ 
 //            index kk = dj*CP + c only shifts the column), A streamed from L2 as one float4 per 4 MFMAs;
 //   phase 2 (VALU): one lane per (query position, doc position): + bias + exact-match taps, ReLU, 1x1 conv,
 //            running max-pool;  finally max over lanes/waves and the output Linear.
-// dynamic LDS: PdT[CP][DLP] | Y[3][MT*32][JT+1] | small weights | dids[DL]
+// Queries longer than 16 tokens are processed in passes of 16 query positions (MTGMAX row tiles) per chunk, so the conv-output tile Y
+// -- and with it the LDS footprint -- does not grow with the query length (mtensor.py:100-131 takes any max_query_len; scripts/ranker.sh
+// pads to 20 x 200).
+// dynamic LDS: PdT[CP][DLP] | Y[3][min(MT,3)*32][JT+1] | small weights | dids[DL]
 // H2 = true: phase 1 on v_mfma_f32_16x16x32_f16 with both operands in the two-term fp16 form -- 720 MFMAs of 16 cycles per pair instead
 // of 840 of 64 (fp32 32x32x2): U arrives as A-fragments from mt_fold_kernel<true>, the document projections are split into two fp16
 // planes Pdh[term][position + 3][64 channels (+8 pad)] when they are staged (position-major: a B fragment = 16 bytes of one row).
@@ -152,14 +156,18 @@ constexpr int CPH = CH + 8;     // halves per position row of a Pdh plane (144 B
 template <bool H2>
 __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict__ pd, const float* __restrict__ U,
                                                       const int64_t* __restrict__ q_ids, const int64_t* __restrict__ d_ids,
-                                                      MtHeadW w, int B, int N, int QL, int DL, int MT, float* __restrict__ scores) {
+                                                      MtHeadW w, int B, int N, int QL, int DL, int MT, int jts,
+                                                      float* __restrict__ scores) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = w.C;
-    const int nchunk = (DL + JT - 1) / JT;
+    const int JT = 1 << jts, NCT = JT >> 5;        // chunk width (64 or 32 positions) and its 32-column tiles
+    const int nchunk = (DL + JT - 1) >> jts;
     const int DLP = nchunk * JT + 9;               // halo: 3 left, >= 3 right; odd pitch -> the transposed prologue
                                                    // writes pdt[c*DLP + j] (consecutive c per lane) are conflict-free
-    const int rows = MT * 32;
-    constexpr int YLD = JT + 1;
+    const int MTG = MT < MTGMAX ? MT : MTGMAX;     // row tiles per pass
+    const int ngroup = (MT + MTG - 1) / MTG;
+    const int rows = MTG * 32;                     // rows of Y
+    const int YLD = JT + 1;
     float* pdt = smem;                             // [CP][DLP]   (H2: Pdh[2 terms][DLH][CPH] halves in the same region)
     const int DLH = nchunk * JT + 6;               // positions + 3 halo rows on each side
     _Float16* pdh = reinterpret_cast<_Float16*>(smem);
@@ -251,7 +259,8 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
             const _Float16* wfp = reinterpret_cast<const _Float16*>(w.dpf) + ((int64_t)wave * 2 * 64 + lane) * 8;
             const float* hdm = w.hd + pair * DL * (int64_t)HD2;
             const float bias = c < C ? w.dpb[c] : 0.f;
-            for (int jt = 0; jt < nchunk; ++jt) {
+            const int nblk = (DL + 63) >> 6;
+            for (int jt = 0; jt < nblk; ++jt) {
                 f32x4 pa[4], px[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { pa[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; px[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
                     float4 x0[4], x1[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        int j = jt * JT + 16 * i + c16;
+                        int j = jt * 64 + 16 * i + c16;
                         j = j < DL ? j : DL - 1;
                         const float* hp = hdm + (int64_t)j * HD2;
                         x0[i] = *reinterpret_cast<const float4*>(hp + ka);
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int j = jt * JT + 16 * i + 4 * g4 + r;
+                            const int j = jt * 64 + 16 * i + 4 * g4 + r;
                             if (j < DL) {
                                 const float v = fmaf(px[i][r], 1.0f / 2048.0f, pa[i][r]) + bias;
                                 const _Float16 a = (_Float16)__builtin_amdgcn_cvt_pkrtz(v, 0.f)[0];
@@ -352,23 +361,27 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
 
     const float* ub = U + (int64_t)b * rows * KTOT;
     const int g2 = lane >> 5, col = lane & 31;
-    for (int ch = 0; ch < nchunk; ++ch) {
+    for (int ch = 0; ch < nchunk; ++ch)
+    for (int grp = 0; grp < ngroup; ++grp) {
         const int j0 = ch * JT;
+        const int mt0 = grp * MTG, mtn = MT - mt0 < MTG ? MT - mt0 : MTG;     // this pass: row tiles [mt0, mt0 + mtn)
+        const int i0 = ngroup > 1 ? 16 * grp : 0;                            // = query positions [i0, i0 + nqi)
+        const int nqi = QL - i0 < (ngroup > 1 ? 16 : QL) ? QL - i0 : (ngroup > 1 ? 16 : QL);
         // ---- phase 1: tasks (conv k, row tile mt, column tile nt), heaviest first, each handed to the least-loaded wave
         // (weights 7:5:3 taps).  Round-robin gave waves 0/1 a 7+3 pair and waves 2/3 a single 5 at MT = 1 (measured
         // 56 K vs 30 K cycles before the barrier); this gives 7, 7, 5+3, 5+3.
-        const int ntask = 3 * MT * 2;
+        const int ntask = 3 * mtn * NCT;
         int wload[4] = {0, 0, 0, 0};
         for (int task = 0; task < ntask; ++task) {
-            const int k = 2 - task / (MT * 2);
+            const int k = 2 - task / (mtn * NCT);
             int wsel = 0;
 #pragma unroll
             for (int x = 1; x < 4; ++x) wsel = wload[x] < wload[wsel] ? x : wsel;
 #pragma unroll
             for (int x = 0; x < 4; ++x) wload[x] += x == wsel ? 3 + 2 * k : 0;
             if (wsel != wave) continue;
-            const int rem = task % (MT * 2);
-            const int mt = rem >> 1, nt = rem & 1;
+            const int rem = task % (mtn * NCT);
+            const int mtl = NCT == 2 ? rem >> 1 : rem, nt = NCT == 2 ? rem & 1 : 0, mt = mt0 + mtl;
             if (H2) {
                 // 32 rows x 32 positions of conv k: 2 x 2 tiles of 16 x 16, per tap two 32-channel k-steps, three MFMAs per product
                 // block (cross terms into acx, scaled by 2^-11 at the end); the A fragments of the next k-step are in flight (L2)
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        float* yk = Y + ((int64_t)k * rows + mt * 32 + 16 * i + 4 * g4) * YLD + nt * 32 + 16 * j + c16;
+                        float* yk = Y + ((int64_t)k * rows + mtl * 32 + 16 * i + 4 * g4) * YLD + nt * 32 + 16 * j + c16;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) yk[r * YLD] = fmaf(acx[i][j][r], 1.0f / 2048.0f, acc[i][j][r]);
                     }
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u].w, b3, acc, 0, 0, 0);
                 }
             }
-            float* yk = Y + ((int64_t)k * rows + mt * 32) * YLD + nt * 32 + col;
+            float* yk = Y + ((int64_t)k * rows + mtl * 32) * YLD + nt * 32 + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) yk[((r & 3) + 8 * (r >> 2) + 4 * g2) * YLD] = acc[r];
         }
@@ -481,13 +494,13 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
         // ---- phase 2: positions (i, j) of this chunk
         typedef const float __attribute__((address_space(4))) * const_fp;      // constant address space: uniform -> s_load
         const const_fp cw_c = (const_fp)(uintptr_t)w.cw, cb_c = (const_fp)(uintptr_t)w.cb;
-        for (int pos = tid; pos < QL * JT; pos += 256) {
-            const int i = pos / JT, jl = pos - i * JT, j = j0 + jl;
+        for (int pos = tid; pos < nqi * JT; pos += 256) {
+            const int il = pos >> jts, jl = pos & (JT - 1), i = i0 + il, j = j0 + jl;
             float v[3 * NFC];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int f = 0; f < NFC; ++f) v[k * NFC + f] = Y[((int64_t)k * rows + i * NFC + f) * YLD + jl] + bias_s[k * NFC + f];
+                for (int f = 0; f < NFC; ++f) v[k * NFC + f] = Y[((int64_t)k * rows + il * NFC + f) * YLD + jl] + bias_s[k * NFC + f];
             // exact-match channel: alpha * [q_id == d_id], PAD==PAD counts (mtensor.py:144-158).  The 7 document ids
             // around j are read once into registers (a rolled loop of 21 dependent LDS reads cost ~2 K cycles per
             // position); hits are rare, so the weight adds stay in a rolled, rarely taken branch
@@ -553,10 +566,11 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
     if (w.dbg && tid == 0) w.dbg[64 + 4 * blockIdx.x + 1] = wall_clock64();
 }
 
-static size_t mt_head_lds(int QL, int DL, int MT, bool h2) {
+static size_t mt_head_lds(int QL, int DL, int MT, bool h2, int jts) {
+    const int JT = 1 << jts, MTG = MT < MTGMAX ? MT : MTGMAX;
     const int nchunk = (DL + JT - 1) / JT, DLP = nchunk * JT + 9, DLH = nchunk * JT + 6;
     const size_t pdf = ((h2 ? (size_t)(2 * DLH * CPH + 1) / 2 : (size_t)CP * DLP) + 3) & ~(size_t)3;
-    size_t fl = pdf + (size_t)3 * MT * 32 * (JT + 1) + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + MFC + 2 + 1) & ~1);
+    size_t fl = pdf + (size_t)3 * MTG * 32 * (JT + 1) + ((MFC * 3 * NFC + MFC + 3 * NFC + 270 + MFC + 2 + 1) & ~1);
     return fl * 4 + (size_t)(DL + QL) * 8;
 }
 
@@ -623,9 +637,11 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     // every shape / LDS feasibility check comes before the first launch (nothing is enqueued for a call that cannot finish)
     // two-term fp16 interaction GEMM when the host vouches for |U|, |Pd| < 2^15 (bounds derived from the projection / conv weights)
     const bool h2 = w->bounded && w->C % 2 == 0 && w->C <= CH && !tun(g_tun.exact_f32);
-    const size_t lds = mt_head_lds(QL, DL, MT, h2);
+    // chunks of 64 document positions; of 32 when the document planes of a long document leave too little LDS for a 64-wide Y tile
+    const int jts = mt_head_lds(QL, DL, MT, h2, 6) <= 160 * 1024 - 512 ? 6 : 5;
+    const size_t lds = mt_head_lds(QL, DL, MT, h2, jts);
     const size_t flds = (size_t)(((QL * w->C + 3) & ~3) + NFC * (w->C + 1) * 3 * 7) * 4;
-    NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: QL=%d / DL=%d need %zu bytes of LDS (> 160 KiB)", QL, DL, lds);
+    NIR_REQUIRE(lds <= 160 * 1024 - 512, "match_tensor: doc length %d needs %zu bytes of LDS (> 160 KiB) at any query length", DL, lds);
     NIR_REQUIRE(flds <= 160 * 1024 - 512, "match_tensor: QL=%d needs %zu bytes of LDS for the query fold (> 160 KiB)", QL, flds);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(h2 ? (const void*)mt_head_kernel<true> : (const void*)mt_head_kernel<false>,
@@ -689,9 +705,9 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     {
         ProfScope ps("mt_head_kernel", st);
         if (h2) hipLaunchKernelGGL(mt_head_kernel<true>, dim3((unsigned)(8 * N * ((B + 7) / 8))), dim3(256), lds, st, pd, p.U, q_ids, d_ids, hw,
-                                   B, N, QL, DL, MT, scores);
+                                   B, N, QL, DL, MT, jts, scores);
         else hipLaunchKernelGGL(mt_head_kernel<false>, dim3((unsigned)(8 * N * ((B + 7) / 8))), dim3(256), lds, st, pd, p.U, q_ids, d_ids,
-                                hw, B, N, QL, DL, MT, scores);
+                                hw, B, N, QL, DL, MT, jts, scores);
     }
     NIR_CHECK_LAUNCH("mt_head_kernel");
     return 0;

@@ -137,6 +137,8 @@ SIGNATURES = {
                                    c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_st]),
     "nir_cars_rank_session_shard": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
                                          c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_st]),
+    "nir_cars_rank_session_rows": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
+                                        c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_fp, _l, c_st]),
 }
 
 DTYPE_F32, DTYPE_BF16 = 0, 1

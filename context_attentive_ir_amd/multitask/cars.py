@@ -279,9 +279,11 @@ class CARS(nn.Module, lib.IdCheck):
         pooled, _ = self._encode_seqs("d", docs.reshape(B * S * N, DL), docs_length.reshape(-1), False)
         return pooled.view(B, S, N, -1)
 
-    def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False, rank_docs=None):
+    def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False, rank_docs=None, labels_all=None):
         """rank_docs [B,S,NR,D] (optional): the ranker scores only this slice of the candidates -> scores [B,S,NR]; clicks and sessions
-        still see all of pooled_docs (candidate-sharded callers: nir_cars_rank_session_shard)."""
+        still see all of pooled_docs (candidate-sharded callers).
+        labels_all [B_all,S,N] (optional): the inputs are a block of the sessions of a larger batch (session-sharded tail,
+        sharding.CarsShardPlan); the click mask's batch-wide max click count (cars.py:285-289) is taken over labels_all."""
         lib.require_device(pooled_q, pooled_docs, labels)
         L = lib.load()
         B, S, D = pooled_q.shape
@@ -292,6 +294,7 @@ class CARS(nn.Module, lib.IdCheck):
         pq = pooled_q.float().contiguous()
         pdv = pooled_docs.float().contiguous() if pooled_docs is not None else None
         lab = labels.float().contiguous() if labels is not None else None
+        lab_all = labels_all.float().contiguous() if labels_all is not None else None
         HS, HDEC = self._dims["HS"], self._dims["HDEC"]
         rd = rank_docs.float().contiguous() if rank_docs is not None else None
         NR = rd.shape[2] if rd is not None else N
@@ -308,9 +311,10 @@ class CARS(nn.Module, lib.IdCheck):
             outs["dec_c"] = torch.empty(1, (S - 1) * B, HDEC, device=dev)
             for k, v in outs.items():
                 setattr(extra, k, v.data_ptr())
-        lib.check(L.nir_cars_rank_session_shard(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
-                                                lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
-                                                lib.ptr(rd), NR if rd is not None else 0, lib.stream()), "nir_cars_rank_session")
+        lib.check(L.nir_cars_rank_session_rows(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
+                                               lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
+                                               lib.ptr(rd), NR if rd is not None else 0, lib.ptr(lab_all),
+                                               lab_all.numel() // N if lab_all is not None else 0, lib.stream()), "nir_cars_rank_session")
         return scores, clicks, outs
 
     def encode_clicks(self, docs, doc_labels):
@@ -327,13 +331,23 @@ class CARS(nn.Module, lib.IdCheck):
         hidden_states = (transform_hid(h), transform_cell(c)) [1,(S-1)*B,nhid_decoder] and session_attns = (inner_q, inner_d)
         [B,S,HS] are the decoder inputs (cars.py:382-456); they are produced when `want_states` (default: whenever the
         recommender is on, like the reference), otherwise returned as None / (None, None).
-        shard=True: candidate-sharded document encoding over the torch.distributed `group` + one all-gather of the
-        pooled document vectors (sharding.sharded_pooled_docs); clicks and sessions run replicated, the ranker MLP scores this
-        rank's candidate slice and a second, KB-sized all-gather re-assembles the scores."""
+        shard=True: candidate-sharded document encoding over the torch.distributed `group`, all-to-all of the pooled vectors, clicks /
+        sessions / ranknet for this rank's block of sessions, all-gather of the scores (sharding.SessionShardPlan); when the decoder
+        states are wanted: all-gather of the pooled vectors and a replicated session part (the states cover every session)."""
         self._check_eval()
         if want_states is None:
             want_states = not self.no_recommender
         encoded_docs, own = None, None
+        from .. import sharding
+        if shard and sharding.dist.is_available() and sharding.dist.is_initialized() and not want_states and not self.no_ranker:
+            # session-sharded tail (sharding.SessionShardPlan): candidate slice of every session -> all-to-all -> clicks / sessions / ranknet
+            # for this rank's sessions only -> all-gather of the raw scores
+            B, S, N = document_rep.shape[:3]
+            plan = sharding.SessionShardPlan(B, S, N, sharding.dist.get_world_size(group), sharding.dist.get_rank(group))
+            d, l = plan.doc_shard(document_rep, document_len)
+            docs = plan.assemble(plan.exchange(self.encode_document(d, l), group))
+            s_own = self._rank_session(plan.own(pooled_rep), docs, plan.own(document_label), labels_all=document_label)[0]
+            return plan.gather(s_own, group).contiguous(), None, (None, None)
         if not (self.no_ranker and self.no_document_session_encoding):
             if shard:
                 from .. import sharding

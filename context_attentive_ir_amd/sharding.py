@@ -145,3 +145,91 @@ def gather_session_scores(local, N, group=None):
     """all-gather click-score slices [B,S,per] from every rank -> [B,S,N] on every rank (padding removed)."""
     B, S, per = local.shape
     return gather_scores(local.reshape(B * S, per), N, group).view(B, S, N)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# CARS, round 3: candidate-sharded encode -> ALL-TO-ALL -> SESSION-sharded tail -> all-gather of the click probabilities.
+#
+# With the all-gather above every rank still ran the query encoder, click pooling, both session LSTMs and the attention for ALL B
+# sessions: a replicated tail that capped 8-GPU strong scaling at 1.9x (C3) / 4.0x (C5) before any link latency.  Sessions are
+# independent of each other (cars.py:306-458 iterates the session axis with batch-parallel ops only; the one batch-wide quantity, the
+# click mask's max click count m of cars.py:285-289, is a function of the replicated labels), so after encoding its ceil(N/G) candidates for
+# all B sessions rank g needs the N pooled vectors of ITS ceil(B/G) sessions only:
+#   stage A   queries of my sessions -> pooled_q [bper,S,D];   my candidate slice of all sessions -> pooled [G*bper,S,per,D]
+#   exchange  all_to_all_single: chunk r of my buffer (the sessions of rank r) goes to rank r          ((G-1)/G of bper*G*S*per*D*4 B out)
+#   stage B   [G,bper,S,per,D] -> [bper,S,N,D]; clicks + session LSTMs + ranknet + softmax for my sessions -> probs [bper,S,N]
+#   gather    all_gather_into_tensor of the probabilities (KBs) -> [B,S,N] on every rank
+# Nothing heavier than the KB-sized gather is replicated.  B or N not divisible by G: sessions / candidates are padded by repeating the
+# last one and dropped after the exchange / gather.
+# ----------------------------------------------------------------------------------------------------------
+class SessionShardPlan(object):
+    def __init__(self, B, S, N, world, rank):
+        self.B, self.S, self.N, self.world, self.rank = int(B), int(S), int(N), int(world), int(rank)
+        self.per = (self.N + self.world - 1) // self.world          # candidates per rank (padded)
+        self.bper = (self.B + self.world - 1) // self.world         # sessions per rank (padded)
+        self._ids = {}
+
+    def session_ids(self, device):
+        """LongTensor [G*bper]: session b of slot i (slots past B repeat the last session); rank r owns slots [r*bper, (r+1)*bper)."""
+        k = str(device)
+        if k not in self._ids:
+            self._ids[k] = torch.clamp(torch.arange(self.world * self.bper, device=device), max=self.B - 1)
+        return self._ids[k]
+
+    def own(self, t):
+        """rows of a [B, ...] tensor that belong to this rank's sessions -> [bper, ...]."""
+        ids = self.session_ids(t.device)[self.rank * self.bper:(self.rank + 1) * self.bper]
+        return t.index_select(0, ids).contiguous()
+
+    def doc_shard(self, document_words, document_lens):
+        """[B,S,N,DL] / [B,S,N] -> this rank's candidate slice of every (padded) session: [G*bper,S,per,DL] / [G*bper,S,per]."""
+        d, l = shard_session_candidates(document_words, document_lens, self.world, self.rank)
+        ids = self.session_ids(d.device)
+        return d.index_select(0, ids).contiguous(), l.index_select(0, ids).contiguous()
+
+    def exchange(self, pooled_shard, group=None, out=None):
+        """all-to-all of the pooled candidate slices [G*bper,S,per,D]: afterwards out[r] = rank r's candidates of MY sessions,
+        out [G,bper,S,per,D].  world 1: a view, no collective."""
+        G, bper, S, per = self.world, self.bper, self.S, self.per
+        D = pooled_shard.shape[-1]
+        assert tuple(pooled_shard.shape) == (G * bper, S, per, D), tuple(pooled_shard.shape)
+        if G == 1 and not (dist.is_available() and dist.is_initialized()):
+            return pooled_shard.view(1, bper, S, per, D)
+        if out is None:
+            out = torch.empty(G, bper, S, per, D, device=pooled_shard.device, dtype=pooled_shard.dtype)
+        dist.all_to_all_single(out.view(G * bper, S, per, D), pooled_shard.contiguous(), group=group)
+        return out
+
+    def assemble(self, recv):
+        """[G,bper,S,per,D] (rank-major candidate slices) -> pooled documents of my sessions [bper,S,N,D] (padding dropped)."""
+        G, bper, S, per, D = recv.shape
+        return recv.permute(1, 2, 0, 3, 4).reshape(bper, S, G * per, D)[:, :, :self.N].contiguous()
+
+    def gather(self, local, group=None, out=None):
+        """all-gather the per-rank blocks [bper,S,N] -> [B,S,N] on every rank (padded sessions dropped)."""
+        G, bper = self.world, self.bper
+        assert local.shape[0] == bper
+        if G == 1 and not (dist.is_available() and dist.is_initialized()):
+            return local[:self.B]
+        if out is None:
+            out = torch.empty((G * bper,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out[:self.B]
+
+    def exchange_bytes(self, D, itemsize=4):
+        """bytes this rank sends over xGMI per step (the chunk it keeps is excluded)."""
+        return (self.world - 1) * self.bper * self.S * self.per * D * itemsize
+
+
+def session_sharded_click_probs(plan, encode_q, encode_docs, session_tail, ex, group=None):
+    """The whole sharded step in terms of three callables (the HIP entry points on a GPU; the CPU oracle in the gloo tests):
+         encode_q(source_words [b,S,QL], source_lens [b,S])                  -> pooled queries [b,S,D]
+         encode_docs(document_words [b,S,n,DL], document_lens [b,S,n])       -> pooled documents [b,S,n,D]
+         session_tail(pooled_q [b,S,D], docs [b,S,N,D], labels [b,S,N], labels_all [B,S,N]) -> click probabilities [b,S,N]
+       -> [B,S,N] on every rank."""
+    pq = encode_q(plan.own(ex["source_words"]), plan.own(ex["source_lens"]))
+    d, l = plan.doc_shard(ex["document_words"], ex["document_lens"])
+    docs = plan.assemble(plan.exchange(encode_docs(d, l), group))
+    labels = ex["document_labels"]
+    probs = session_tail(pq, docs, plan.own(labels), labels)
+    return plan.gather(probs, group)

@@ -87,6 +87,44 @@ class Multitask(WrapperBase):
                                                   n_candidates, lib.stream()), "nir_softmax_gathered")
         return probs
 
+    # ---- round 3: candidate-sharded encode -> all-to-all -> SESSION-sharded tail (sharding.SessionShardPlan).  Two capturable halves; the
+    # caller issues plan.exchange (all_to_all_single) between them and plan.gather (all_gather_into_tensor) after, eagerly or inside the
+    # same hipGraph capture.  Nothing but the KB-sized probability gather is replicated across ranks. -------------------------------------
+    @torch.no_grad()
+    def shard_encode(self, q_own, ql_own, doc_shard, len_shard):
+        """queries of this rank's sessions [bper,S,QL] + this rank's candidate slice of every session [G*bper,S,per,DL]
+        -> (pooled queries [bper,S,D], pooled candidate slice [G*bper,S,per,D])."""
+        self.network.eval()
+        pooled, _, _ = self.network.encode(q_own, ql_own)
+        return pooled, self.network.encode_document(doc_shard, len_shard)
+
+    @torch.no_grad()
+    def tail_probs(self, pooled_q, docs, labels_own, labels_all, probs=None):
+        """pooled queries [b,S,D] + ALL N pooled documents [b,S,N,D] of a block of sessions -> click probabilities [b,S,N] (clicks, session
+        LSTMs, ranknet, softmax); the click mask's batch-wide count comes from labels_all [B,S,N] (None: the block itself)."""
+        s = self.network._rank_session(pooled_q, docs, labels_own, labels_all=labels_all)[0].contiguous()
+        if probs is None:
+            probs = torch.empty_like(s)
+        lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()), "nir_softmax_rows")
+        return probs
+
+    @torch.no_grad()
+    def shard_tail(self, pooled_q, recv, labels_own, labels_all, n_candidates, probs=None):
+        """recv [G,bper,S,per,D] = the exchanged candidate slices of this rank's sessions (SessionShardPlan.exchange) -> click
+        probabilities [bper,S,N] of those sessions."""
+        G, bper, S, per, D = recv.shape
+        docs = recv.permute(1, 2, 0, 3, 4).reshape(bper, S, G * per, D)[:, :, :n_candidates].contiguous()
+        return self.tail_probs(pooled_q, docs, labels_own, labels_all, probs)
+
+    @torch.no_grad()
+    def predict_sharded(self, ex, plan, group=None):
+        """Eager form of the whole sharded ranking step -> click probabilities [B,S,N] on every rank."""
+        from .. import sharding
+        self.network.eval()
+        dex = {k: self._dev(v) for k, v in ex.items() if torch.is_tensor(v)}
+        return sharding.session_sharded_click_probs(plan, lambda q, l: self.network.encode(q, l)[0], self.network.encode_document,
+                                                    self.tail_probs, dex, group)
+
     @torch.no_grad()
     def scores(self, ex):
         """raw click scores [B,S,N] (ranking path only)."""

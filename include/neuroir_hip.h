@@ -337,6 +337,15 @@ int nir_cars_rank_session_shard(const float* pooled_q, const float* pooled_docs,
                                 const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
                                 float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra /*host*/,
                                 const float* rank_docs, int NR, nir_stream_t stream);
+/* The same for a BLOCK OF SESSIONS of a larger batch (session-sharded tail of the multi-GPU step): pooled_q / pooled_docs /
+ * labels / outputs address this call's B sessions only, but the click mask's batch-wide `m = max_rows count_nonzero(labels)`
+ * (cars.py:285-289) is taken over labels_all [rows_all, N] -- the label matrix of the whole global batch, which every
+ * rank holds (inputs are replicated).  labels_all == NULL: the rows of this call.  Sessions are otherwise independent (cars.py:306-458
+ * iterates the session axis with batch-parallel ops only), so the scores of a block equal the rows of the unsharded call. */
+int nir_cars_rank_session_rows(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
+                               const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                               float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra /*host*/,
+                               const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, nir_stream_t stream);
 
 /* --- CARS.decode: greedy query suggestion (cars.py:706-791; decoders/rnn_decoder.py:19-88; global_attention.py:98-196) ---- */
 typedef struct {

@@ -320,13 +320,15 @@ def cars_encode_document(sd, d, d_len):
 
 
 @torch.no_grad()
-def cars_encode_clicks(sd, docs, labels):
-    """cars.py:262-304 incl. the batch-dependent mask quirk."""
+def cars_encode_clicks(sd, docs, labels, labels_all=None):
+    """cars.py:262-304 incl. the batch-dependent mask quirk.
+    labels_all (tests of the session-sharded multi-GPU tail only): docs / labels are a block of the sessions of a larger batch whose
+    full label matrix is labels_all -- the reference takes m = max click count over the WHOLE batch (:285-289), so a block must too."""
     B, S, N, H = docs.shape
     order = labels.sort(dim=2, descending=True, stable=True)[1]
     sdocs = torch.gather(docs, 2, order.unsqueeze(3).expand(-1, -1, -1, H)).view(B * S, N, H)
     count = (labels.view(B * S, N) != 0).sum(1)
-    m = int(count.max())
+    m = int(count.max()) if labels_all is None else int((labels_all.reshape(-1, N) != 0).sum(1).max())
     keep = torch.ones(B * S, N, dtype=torch.bool)
     keep[:, :m] = torch.arange(m).unsqueeze(0) < count.unsqueeze(1)
     a = _lin(sd, "click_attn.3", torch.tanh(_lin(sd, "click_attn.0", sdocs))).squeeze(2)

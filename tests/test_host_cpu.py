@@ -171,6 +171,58 @@ def test_candidate_sharding_two_rank_gloo(tmp_path):
         assert p.returncode == 0 and ("rank %d ok" % r) in o, o
 
 
+_SESSION_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from context_attentive_ir_amd import sharding, synth
+from context_attentive_ir_amd.detinit import fill_module_
+from context_attentive_ir_amd.config import default_args
+from context_attentive_ir_amd.multitask import CARS
+from oracle import neuroir_cpu as O
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[4]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+sd = {k: v for k, v in fill_module_(CARS(default_args("CARS", src_vocab_size=300))).state_dict().items()}
+enc_q = lambda q, l: O.cars_encode(sd, q, l)[0]                      # the CPU oracle stands in for the HIP entry points
+enc_d = lambda d, l: O.cars_encode_document(sd, d, l)
+def tail(pq, docs, lab, lab_all):
+    return O.predict_softmax(O.cars_encode_session(sd, pq, docs, O.cars_encode_clicks(sd, docs, lab, labels_all=lab_all)))
+for B, S, N in ((4, 3, 5), (3, 2, 9), (1, 3, 2), (5, 2, 4)):        # B, N divisible / ragged / smaller than the world
+    ex = synth.session_batch(B, S, N, 4, 10, 300, seed=10 * B + N, full_length=False, multi_click=True)
+    if B > 1:                                                         # one session with many clicks: the batch-wide m lives on ONE rank
+        ex["document_labels"][B - 1, 0, :] = 1.0
+    full = O.predict_softmax(O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"],
+                                            ex["document_labels"]))
+    plan = sharding.SessionShardPlan(B, S, N, world, rank)
+    got = sharding.session_sharded_click_probs(plan, enc_q, enc_d, tail, ex)
+    assert got.shape == full.shape and torch.allclose(got, full, atol=1e-6), (rank, B, N, float((got - full).abs().max()))
+    # a block evaluated WITHOUT the batch-wide labels differs whenever its own max click count is smaller: the quirk is really exercised
+    cnt = lambda l: int((l.reshape(-1, N) != 0).sum(1).max())
+    if B > 1 and world > 1 and rank == 0 and cnt(plan.own(ex["document_labels"])) < min(cnt(ex["document_labels"]), N - 1):
+        loc = tail(enc_q(plan.own(ex["source_words"]), plan.own(ex["source_lens"])),
+                   O.cars_encode_document(sd, plan.own(ex["document_words"]), plan.own(ex["document_lens"])),
+                   plan.own(ex["document_labels"]), None)
+        assert not torch.allclose(loc, full[:plan.bper], atol=1e-6)
+    assert plan.exchange_bytes(256) == (world - 1) * plan.bper * S * plan.per * 256 * 4
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_session_sharded_tail_gloo(tmp_path, world):
+    """candidate-sharded encode -> all-to-all -> session-sharded tail -> all-gather (sharding.SessionShardPlan) reproduces the unsharded
+    click probabilities on every rank, including the batch-wide click-mask quirk (m comes from the replicated labels)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_SESSION_WORKER)
+    port = str(31500 + (os.getpid() * 7 + world) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in o, o
+
+
 def _async_gather_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
