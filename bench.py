@@ -40,6 +40,7 @@ import time
 if not ("--streams" in sys.argv and sys.argv[sys.argv.index("--streams") + 1:][:1] == ["1"]):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -96,57 +97,69 @@ _SHAPE = re.compile(r"^(.*)\[M=(\d+),N=(\d+),K=(\d+)\]$")
 
 
 def kernel_work(name, c):
-    """Algorithmic flops / HBM bytes of ONE launch, priced from the launch's own shape label.
-    Returns dict(flops, bytes, peak_tflops) or None."""
+    """Work of ONE launch, priced from the launch's own shape label:
+      flops  algorithmic (fp32-equivalent) FLOPs of the op the kernel implements
+      terms  MFMAs EXECUTED per algorithmic product block (fp16 two-term split 3, bf16 three-term split 6, single fp16/bf16/f32 term 1)
+      pipe   dense peak of the executed MFMA type (2500 TF f16/bf16, 157.3 TF f32-input)
+      bytes  the kernel's own minimal traffic model (its operands once) -- informational; the HBM figures of the line use SURVEY 8(d)
+    Returns None for kernels without a model."""
     m = _SHAPE.match(name)
     base, M, N, K = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))) if m else (name, 0, 0, 0)
     B, NC, QL, DL, E = c["batch"], c["cands"], c["qlen"], c["dlen"], 300
     pairs = B * NC * (c.get("session", 1) if c["model"] in SESSION_MODELS else 1)
+    F16, F32 = PEAK_BF16_TFLOPS, PEAK_FP32_TFLOPS
     if base.startswith("gemm3h_kernel") or base.startswith("gemm_h2p_kernel"):     # fp16 two-term split: 3 MFMAs per product block
         gathered = "[gather]" in base
-        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),
-                    peak=PEAK_BF16_TFLOPS / 3.0)
+        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0), terms=3, pipe=F16)
     if base.startswith("duet_doc_kernel"):
         # fused DUET document branch (csrc/duet_fused.hip): the algorithmic work of the pairs it covers -- conv_d1 (K = 3E) and conv_d2
-        # (K = NF) per pooled position -- not the padded tile work in the label (M = tiles x 64 rows, N = NF, K = 3E); bytes: the
-        # embedding rows once plus ids; arithmetic: fp16 two-term split, 3 MFMAs per product block
+        # (K = NF) per pooled position -- not the padded tile work in the label (M = tiles x 64 rows, N = NF, K = 3E)
         Tc, Tp = DL - 2, DL - 6
-        return dict(flops=pairs * 2.0 * N * (Tc * K + Tp * N), bytes=pairs * DL * (4.0 * E + 8), peak=PEAK_BF16_TFLOPS / 3.0)
+        return dict(flops=pairs * 2.0 * N * (Tc * K + Tp * N), bytes=pairs * DL * (4.0 * E + 8), terms=3, pipe=F16)
     if base.startswith("attn_pool_fused_kernel"):
-        # fused attention pooling (csrc/cars_attn.hip): M rows of D = N = K = 256: the attention MLP GEMM + row dot, softmax and the
-        # weighted sum; bytes: the encoder output read once (the second read for the weighted sum is served by L2) + pooled rows
-        # bf16 encoders (C5): single fp16 terms (1 MFMA per product block) and, once the pipelined kernel is selected (>= 2 tiles of 64
-        # rows per CU), fp16 encoder rows
+        # fused attention pooling (csrc/cars_attn.hip): M rows of D = N = K = 256; bf16 encoders (C5): single fp16 terms and, once the
+        # pipelined kernel is selected (>= 2 tiles of 64 rows per CU), fp16 encoder rows
         one = c.get("dtype") == "bf16"
         in16 = one and M >= 2 * 256 * 64
-        return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=(2.0 if in16 else 4.0) * M * K + 4.0 * N * K,
-                    peak=PEAK_BF16_TFLOPS / (1.0 if one else 3.0))
+        return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=(2.0 if in16 else 4.0) * M * K + 4.0 * N * K, terms=1 if one else 3, pipe=F16)
     if base.startswith("gemm3_kernel"):
         gathered = "[gather]" in base
-        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0),
-                    peak=PEAK_BF16X3_TFLOPS)
+        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0), terms=6, pipe=F16)
     if base.startswith("gemm_kernel") or base.startswith("gemm16_kernel") or base.startswith("gemm32_kernel") or base.startswith("gemm_skinny_kernel"):
-        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N), peak=PEAK_FP32_TFLOPS)
+        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N), terms=1, pipe=F32)
     if base.startswith("lstm16_pt_bf16_kernel"):      # M sequences, N = T steps, K = H; both directions in one launch; bf16 table rows,
         # fp16 MFMA operands; the states leave as fp16 when they feed the pipelined attention kernel of the same encode call
         out_b = 2.0 if M * N >= 2 * 256 * 64 else 4.0
-        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * out_b), peak=PEAK_BF16_TFLOPS)
-    if base.startswith("lstm16_pt_h2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block -> peak 2500 / 3
-        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), peak=PEAK_BF16_TFLOPS / 3.0)
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * out_b), terms=1, pipe=F16)
+    if base.startswith("lstm16_pt_h2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), terms=3, pipe=F16)
     if base.startswith("lstm16_pt_kernel"):
-        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), peak=PEAK_FP32_TFLOPS)
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), terms=1, pipe=F32)
     if base.startswith("lstm_mfma16_gin_kernel") or base.startswith("lstm_mfma_gin_kernel") or base.startswith("lstm_rec_kernel<"):
-        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (2 * 4 * K * 4 + 2 * K * 4.0), peak=PEAK_FP32_TFLOPS)
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (2 * 4 * K * 4 + 2 * K * 4.0), terms=1, pipe=F32)
     if base.startswith("lstm_mfma_kernel") or base.startswith("lstm_mfma16_kernel") or base.startswith("lstm_rec_kernel[fused]"):
         F = 40                                         # MatchTensor: input projection fused (I = featsize 40)
-        return dict(flops=M * N * 2 * 2.0 * 4 * K * (K + F), bytes=M * N * (2 * F + 2 * K) * 4.0, peak=PEAK_FP32_TFLOPS)
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * (K + F), bytes=M * N * (2 * F + 2 * K) * 4.0, terms=1, pipe=F32)
     if base == "mt_head_kernel":
         C = 50
-        return dict(flops=pairs * QL * DL * 2.0 * (15 * C * 6 + 45 * 6 + 18 * 20), bytes=pairs * DL * (C * 4 + 8.0) + pairs * 4,
-                    peak=PEAK_FP32_TFLOPS)
+        return dict(flops=pairs * QL * DL * 2.0 * (15 * C * 6 + 45 * 6 + 18 * 20), bytes=pairs * DL * (C * 4 + 8.0) + pairs * 4, terms=3, pipe=F16)
     if base in ("esm16_kernel", "esm_kernel", "drmm_kernel"):
         fl = flops_per_pair(c["model"], QL, DL) or (2.0 * DL * E if base != "drmm_kernel" else 2.0 * QL * DL * E)
-        return dict(flops=fl * pairs, bytes=algorithmic_bytes_per_pair(NC, QL, DL) * pairs, peak=PEAK_FP32_TFLOPS)
+        return dict(flops=fl * pairs, bytes=algorithmic_bytes_per_pair(NC, QL, DL) * pairs, terms=0, pipe=F32)   # VALU kernels: no MFMA
+    return None
+
+
+def pmc_entry(name, prof_name):
+    """profiles/pmc_summary.json (tools/derive_profiles.py: rocprofv3 --pmc passes of this same workload, separate FETCH_SIZE / WRITE_SIZE /
+    SQ passes, gfx950 x2 FETCH correction): {bytes_per_launch, mfma_busy} of the kernel behind the library's profile label, or None."""
+    for fn in ("pmc_summary.json", "traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            ent = traffic_entry(tj.get("configs", {}).get(name, {}), prof_name)
+            if ent:
+                return ent
+        except (OSError, ValueError, KeyError, AttributeError):
+            pass
     return None
 
 
@@ -170,7 +183,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS), help="headline workload (default: C3 CARS)")
+    ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS) + ["C5_stream"],
+                    help="headline workload (default: C3 CARS); C5_stream = the whole 223 876-session bf16 stream, ids from the host (prints its own record)")
     ap.add_argument("--sub", default=None, help="comma-separated sub-records to measure (default: all; 'none' to skip)")
     # ad-hoc shapes (tools/, profiling): override fields of --config
     ap.add_argument("--model", default=None, choices=["match_tensor", "esm", "drmm", "duet", "cars", "m_match_tensor", "mnsrf"])
@@ -199,10 +213,40 @@ def build_model(c, args):
     fill_module_(wrapper.network, 1013)
     if kind == "CARS":
         wrapper.network.compute_dtype = c.get("dtype", "f32")
-        wrapper.network.fold_embeddings = not args.no_fold
+        wrapper.network.fold_embeddings = not (args.no_fold or c.get("nofold"))
+    elif kind == "MATCH_TENSOR" and (args.no_fold or c.get("nofold")):
+        wrapper.network.fold_embeddings = False
     wrapper.cuda()
     wrapper.network.eval()
     return wrapper
+
+
+def precompute_info(wrapper, c):
+    """Inference-time precompute behind the folded recurrences (csrc/lstm_fold.hip): emb(id) W_ih^T + b folded into one [V, ndir*4H] gate table
+    per encoder and weight version, built OUTSIDE the timed region.  Reported so the line says what it costs: build time (cold, measured
+    here by forcing a rebuild), resident bytes, and the vocabulary it scales with.  None when the model runs without folded tables."""
+    net = wrapper.network
+    kind = c["model"]
+    if kind == "cars" and net.fold_embeddings and net._use_fold(net.embedder.word_embeddings.table, net._enc_weights("d").struct.H):
+        def build():
+            return [net._folded_table(w, net._enc_weights(w)) for w in ("q", "d")]
+        caches = (net._fq, net._fd)
+    elif kind == "match_tensor" and getattr(net, "fold_embeddings", False):
+        def build():
+            return list(net._folded_tables(net._weights()))
+        caches = (net._fold,)
+    else:
+        return None
+    build()
+    torch.cuda.synchronize()
+    for ch in caches:
+        ch.invalidate()
+    t0 = time.perf_counter()
+    tabs = build()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    return {"fold_ms": round(ms, 3), "fold_bytes": int(sum(t.numel() * t.element_size() for t in tabs)), "vocab": int(c["vocab"]),
+            "tables": len(tabs), "rebuilt": "once per weight version (PackCache); not part of a step"}
 
 
 def make_batches(c, nbatches, rank_seed, dev):
@@ -268,6 +312,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         wsh = int(os.environ["BENCH_EMULATE_WORLD"])
     emu = wsh != world
     model = build_model(c, args)
+    pre = precompute_info(model, c) if rank == 0 else None
     # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
     batches = make_batches(c, args.nbatches, 0 if sharded or not env.multi else rank, dev)
     pairs_global = c["batch"] * c["cands"] * (c["session"] if is_sess else 1)
@@ -296,11 +341,20 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                          torch.zeros(G * bper, S_, ncand, device=dev))
         return coll[key]
 
-    def sharded_cars_step(ex, key):
-        """one candidate-/session-sharded CARS ranking step (eager or under capture): encode | all-to-all | tail | all-gather."""
+    def sharded_cars_step(ex, key, via_gather=False):
+        """one candidate-/session-sharded CARS ranking step (eager or under capture): encode | exchange | tail | all-gather.
+        via_gather: the exchange as all_gather_into_tensor (every slice to every rank, own sessions' chunk kept) -- the form RCCL can
+        replay from a captured hipGraph; else all_to_all_single (1/G of the bytes, eager only)."""
         recv, probs_own, allp = cars_bufs(key)
         pq, pl = model.shard_encode(ex["_q_own"], ex["_ql_own"], ex["_doc_shard"], ex["_len_shard"])
-        if env.backend == "nccl":
+        if via_gather:
+            if (key, "g") not in coll:
+                coll[(key, "g")] = torch.zeros(plan.world, plan.world * plan.bper, plan.S, plan.per, pl.shape[-1], device=dev)
+            big = coll[(key, "g")]
+            # (emulated world: the 1-rank group fills chunk 0 only; the tail reads rank 0's session block of every chunk all the same)
+            env.dist.all_gather_into_tensor(big[:1].view(pl.shape) if emu else big.view(-1, *pl.shape[1:]), pl)
+            recv = big[:, rank * plan.bper:(rank + 1) * plan.bper]
+        elif env.backend == "nccl":
             # (emulated world: the 1-rank group copies the whole buffer -- the bytes a real exchange moves, meaningless scores)
             env.dist.all_to_all_single(recv.view(pl.shape), pl)
         else:
@@ -372,13 +426,13 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     fused = None
     if fused_ok:
         try:
-            probe_a = torch.zeros(wsh if not emu else 1, 8, device=dev); probe_b = torch.zeros_like(probe_a)
-            env.dist.all_to_all_single(probe_b, probe_a)
+            probe_a = torch.zeros(1, 8, device=dev); probe_b = torch.zeros(world, 8, device=dev)
+            env.dist.all_gather_into_tensor(probe_b, probe_a)
             torch.cuda.synchronize()
             time.sleep(0.3)
             pg = torch.cuda.CUDAGraph()                       # does this build capture a collective at all?
             with torch.cuda.graph(pg, stream=lanes[0], capture_error_mode=CAPTURE_MODE):
-                env.dist.all_to_all_single(probe_b, probe_a)
+                env.dist.all_gather_into_tensor(probe_b, probe_a)
             pg.replay()
             torch.cuda.synchronize()
             branches = [torch.cuda.Stream() for _ in range(KSTEP)]
@@ -389,7 +443,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 keys = [("fused", first, j) for j in range(n)]
                 for j in range(n):                               # warm: packs, workspaces, collective buffers
                     with torch.cuda.stream(branches[j]):
-                        sharded_cars_step(batches[(first + j) % len(batches)], keys[j])
+                        sharded_cars_step(batches[(first + j) % len(batches)], keys[j], via_gather=True)
                 torch.cuda.synchronize()
                 time.sleep(0.3)
                 g, outs = torch.cuda.CUDAGraph(), []
@@ -398,7 +452,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     for j in range(n):
                         branches[j].wait_stream(main)
                         with torch.cuda.stream(branches[j]):
-                            outs.append(sharded_cars_step(batches[(first + j) % len(batches)], keys[j]))
+                            outs.append(sharded_cars_step(batches[(first + j) % len(batches)], keys[j], via_gather=True))
                     for j in range(n):
                         main.wait_stream(branches[j])
                 return g, outs
@@ -522,23 +576,46 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         single_ms = (time.perf_counter() - ts) / ns * 1e3
         env.barrier()
 
-    h2d_value = None
+    # ---- H2D-inclusive figure: ids arrive from the HOST for every batch (collate into pinned staging -> H2D -> replay -> D2H of the
+    # probabilities), sustained over >= 5 s regardless of --steps.  CARS: graph_runner.StreamingSessionPredictor (int32 wire format,
+    # 2 staging slots per lane, producer thread); rankers: GraphedPredictor fed from packed pinned batches.
+    h2d_value, h2d_info = None, None
     if with_h2d and world == 1 and not env.multi:
         try:
-            from context_attentive_ir_amd.graph_runner import GraphedPredictor
-            gps = [GraphedPredictor(model, batches[0], queue_ahead=len(lanes) == 1) for _ in lanes]
-            host = [gps[0].pack({k: v.cpu() for k, v in b.items()}) for b in batches]
-            nh = max(10, min(steps, 200))
-            for i in range(3 * len(gps)):
-                gps[i % len(gps)].predict(host[i % len(host)], clone=False)
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            for i in range(nh):
-                gps[i % len(gps)].predict(host[i % len(host)], clone=False)
-            torch.cuda.synchronize()
-            h2d_value = pairs_global * nh / (time.perf_counter() - th)
+            secs = float(os.environ.get("BENCH_H2D_SECONDS", "5"))
+            if c["model"] == "cars":
+                from context_attentive_ir_amd.graph_runner import StreamingSessionPredictor
+                from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
+                corpus = SyntheticSessionCorpus(n_sessions=64 * c["batch"], n_cands=c["cands"], qlen=c["qlen"], dlen=c["dlen"], vocab=c["vocab"],
+                                                fixed_len=c["session"], pool=64)
+                sp = StreamingSessionPredictor(model, c["cands"], c["qlen"], c["dlen"], c["batch"], max_session_len=c["session"],
+                                               lanes=len(lanes), slots=2)
+                bl = corpus.batches(c["batch"])
+                sp.prepare([c["session"]], example=(corpus, bl[0]))
+                sp.run(corpus, bl, max_batches=8 * len(lanes))
+                h2d_info = sp.run(corpus, bl, min_seconds=secs)
+                h2d_value = h2d_info["pairs_per_s"]
+                h2d_info = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in h2d_info.items()}
+                h2d_info["wire"] = "int32 ids/lengths + float32 labels, widened on device (nir_widen_ids_i32)"
+                del sp
+            else:
+                from context_attentive_ir_amd.graph_runner import GraphedPredictor
+                gps = [GraphedPredictor(model, batches[0], queue_ahead=len(lanes) == 1) for _ in lanes]
+                host = [gps[0].pack({k: v.cpu() for k, v in b.items()}) for b in batches]
+                for i in range(3 * len(gps)):
+                    gps[i % len(gps)].predict(host[i % len(host)], clone=False)
+                torch.cuda.synchronize()
+                th, nh = time.perf_counter(), 0
+                while time.perf_counter() - th < secs:
+                    for _ in range(16):
+                        gps[nh % len(gps)].predict(host[nh % len(host)], clone=False)
+                        nh += 1
+                torch.cuda.synchronize()
+                h2d_value = pairs_global * nh / (time.perf_counter() - th)
+                h2d_info = {"batches": nh, "seconds": round(time.perf_counter() - th, 3), "wire": "int64 (the reference's LongTensor batch), one pinned buffer per batch"}
+            L.nir_set_batches_in_flight(len(lanes))
         except Exception as e:  # pragma: no cover - secondary figure only
-            print("[bench] H2D-inclusive figure unavailable: %s" % e, file=sys.stderr)
+            print("[bench] H2D-inclusive figure unavailable: %s: %s" % (type(e).__name__, e), file=sys.stderr)
 
     # ---- profiled pass: HIP events around every kernel of the library, same workload, serial -------------------
     torch.cuda.set_stream(lanes[0])
@@ -570,34 +647,37 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             if sharded and not is_sess:
                 cc["cands"] = batches[0]["doc_rep"].shape[1]
             work = kernel_work(dom, cc)
+            bpp = algorithmic_bytes_per_pair(c["cands"], c["qlen"], c["dlen"], table_bytes=2 if c.get("dtype") == "bf16" else 4)
+            step_pairs_rank = pairs_global / (wsh if sharded else 1)
+            bytes_8d = bpp * step_pairs_rank * (1.0 / max(1.0, cnt / nprof))      # SURVEY 8(d) bytes of the pairs one launch covers
+            t = avg_us * 1e-6
             if work:
-                tf = work["flops"] / (avg_us * 1e-6) / 1e12
-                gbs = work["bytes"] / (avg_us * 1e-6) / 1e9
-                if work["flops"] / work["bytes"] > work["peak"] * 1e12 / (PEAK_HBM_GBS * 1e9):
-                    roofline.update(bound="mfma", achieved=round(tf, 4), peak=round(work["peak"], 1), unit="TFLOP/s", frac=round(tf / work["peak"], 5))
+                alg_tf = work["flops"] / t / 1e12
+                exe_tf = alg_tf * work["terms"]
+                gbs8 = bytes_8d / t / 1e9
+                ridge = work["pipe"] * 1e12 / (PEAK_HBM_GBS * 1e9)
+                # `frac` of an MFMA-bound kernel = EXECUTED matrix-pipe FLOP/s (algorithmic FLOPs x split terms) / the dense peak of the
+                # executed MFMA type: what SQ_VALU_MFMA_BUSY_CYCLES measures; of an HBM-bound kernel = SURVEY 8(d) bytes/s / 8 TB/s
+                if work["terms"] and work["flops"] * work["terms"] / bytes_8d > ridge:
+                    roofline.update(bound="mfma", achieved=round(exe_tf, 3), peak=round(work["pipe"], 1), unit="TFLOP/s", frac=round(exe_tf / work["pipe"], 5))
                 else:
-                    roofline.update(bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5))
-                roofline["alg_flops_per_launch"] = work["flops"]
-                roofline["alg_bytes_per_launch"] = work["bytes"]
-                if roofline["bound"] == "hbm" and gbs > PEAK_HBM_GBS:
-                    roofline["note"] = "algorithmic bytes/s above the HBM peak: repeated (Zipf) ids are served from L2/MALL, not HBM"
-            # HBM bytes per launch from the committed PMC capture of this same workload (profiles/traffic.json: separate
-            # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction); null when no capture matches
-            roofline["traffic"] = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                ent = traffic_entry(tj.get("configs", {}).get(name, {}), dom)
-                if ent and not sharded:
-                    roofline["traffic"] = ent["bytes_per_launch"]
-            except (OSError, ValueError, KeyError, AttributeError):
-                pass
-            bpp = algorithmic_bytes_per_pair(c["cands"], c["qlen"], c["dlen"])
-            roofline["step_hbm_GBps"] = round(value * bpp / 1e9 / (1 if sharded or not env.multi else world), 2)
-            roofline["step_hbm_frac"] = round(roofline["step_hbm_GBps"] / PEAK_HBM_GBS, 5)
+                    roofline.update(bound="hbm", achieved=round(gbs8, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs8 / PEAK_HBM_GBS, 5))
+                roofline.update(alg_flops_per_launch=work["flops"], mfma_terms_per_product=work["terms"], alg_TFLOPs_fp32_equiv=round(alg_tf, 3),
+                                executed_mfma_TFLOPs=round(exe_tf, 3), mfma_frac=round(exe_tf / work["pipe"], 5) if work["terms"] else 0.0,
+                                bytes_8d_per_launch=round(bytes_8d), hbm_GBps_8d=round(gbs8, 2), hbm_frac_8d=round(gbs8 / PEAK_HBM_GBS, 5),
+                                kernel_model_bytes_per_launch=work["bytes"])
+            # HBM bytes per launch and matrix-pipe busy fraction from the committed PMC capture of this same workload
+            roofline["traffic"] = roofline["traffic_ratio"] = roofline["mfma_busy_pmc"] = None
+            ent = pmc_entry(name, dom)
+            if ent and not sharded:
+                roofline["traffic"] = ent["bytes_per_launch"]
+                roofline["traffic_ratio"] = round(ent["bytes_per_launch"] / bytes_8d, 3)
+                roofline["mfma_busy_pmc"] = ent.get("mfma_busy")
+            roofline["step_hbm_GBps_8d"] = round(value * bpp / 1e9 / (1 if sharded or not env.multi else world), 2)
+            roofline["step_hbm_frac_8d"] = round(roofline["step_hbm_GBps_8d"] / PEAK_HBM_GBS, 5)
             fpp = flops_per_pair(c["model"], c["qlen"], c["dlen"])
             if fpp:
-                roofline["step_alg_TFLOPs"] = round(value * fpp / 1e12, 2)
-                roofline["step_flop_frac_of_fp32_peak"] = round(value * fpp / 1e12 / PEAK_FP32_TFLOPS / (world if env.multi else 1), 5)
+                roofline["step_alg_TFLOPs_ref_ops"] = round(value * fpp / 1e12 / (world if env.multi and not sharded else 1), 2)
 
     cpu = None
     if want_cpu and rank == 0 and not env.multi and not args.no_cpu_baseline:
@@ -613,8 +693,9 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         if not sharded:
             par = "x%d independent per-rank batches, no collective (weak scaling)" % world
         elif plan is not None:
-            par = "strong: candidate-sharded encode x%d -> %s all-to-all (%d B out per rank and step) -> session-sharded tail -> all-gather of probabilities; %s" % (
-                wsh, "RCCL" if env.backend == "nccl" else env.backend, plan.exchange_bytes(256),
+            par = "strong: candidate-sharded encode x%d -> %s %s (%d B out per rank and step) -> session-sharded tail -> all-gather of probabilities; %s" % (
+                wsh, "RCCL" if env.backend == "nccl" else env.backend, "all-gather exchange" if fused is not None else "all-to-all",
+                plan.world * plan.bper * plan.S * plan.per * 256 * 4 if fused is not None else plan.exchange_bytes(256),
                 ("%d steps + collectives per hipGraph" % KSTEP) if fused is not None else ("2 hipGraphs per step around eager collectives" if stages is not None else "eager"))
             if emu:
                 par += " [EMULATED on one GPU: rank 0's 1/%d share of the work, loop-back collectives, no xGMI latency]" % wsh
@@ -628,7 +709,8 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             "ms_per_step_one_batch_in_flight": round(single_ms, 5), "global_batch_pairs": per_step_pairs, "parallelism": par, "world_size": world,
             "steps": steps, "hipgraph": (graphs is not None) or (stages is not None) or (fused is not None), "batches_in_flight": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
-            "dtype": c.get("dtype", "f32"), "roofline": roofline, "cpu_baseline": cpu}
+            "h2d_inclusive_over_resident": None if h2d_value is None else round(h2d_value / value, 4), "h2d_stream": h2d_info,
+            "dtype": c.get("dtype", "f32"), "precompute": pre, "roofline": roofline, "cpu_baseline": cpu}
 
 
 def cpu_baseline(c, model, batches, gpu_step, pairs, args):
@@ -668,7 +750,16 @@ def cpu_baseline(c, model, batches, gpu_step, pairs, args):
         dt = time.perf_counter() - t1
         if dt > args.cpu_seconds or n >= 5000:
             break
-    return {"value": round(n * pairs / dt, 1), "unit": "pairs/s", "cores": best_t, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n * pairs / dt, 1), "unit": "pairs/s", "cores": best_t, "kind": "port", "cpu_model": cpu_model,
+            "host_logical_cores": avail, "threads_pinned": "torch.set_num_threads(%d)" % best_t,
             "sample": "%d batches of the same %s workload in %.1f s (oracle/neuroir_cpu.py = pinned port of the reference, torch %s CPU, "
                       "best of {8,16,32,64} threads = %d; host has %d logical cores)" % (n, m, dt, torch.__version__, best_t, avail),
             "max_abs_diff_vs_gpu_softmax": maxdiff}
@@ -683,6 +774,13 @@ def main():
         k, v = kv.split("=")
         lib.check(lib.load().nir_debug_set_tunable(k.encode(), int(v)), "nir_debug_set_tunable")
     assert env.world == args.gpus or env.world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if args.config == "C5_stream":
+        r = stream_record(args, env, seconds=None)
+        line = {"metric": "ranked (query,doc) pairs/sec", "value": r.get("pairs_per_s"), "unit": "pairs/s", "n_gpus": 1, "steps": r.get("batches"), "warmup": 0,
+                "ms_per_step": r.get("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": r}
+        print(json.dumps(line), flush=True)
+        return
     head = dict(CONFIGS[args.config])
     adhoc = False
     for k in ("model", "batch", "cands", "qlen", "dlen", "session", "vocab", "uniform", "dtype"):
@@ -709,7 +807,16 @@ def main():
             sub[n] = r
         torch.cuda.empty_cache()
     if head["model"] == "cars" and not adhoc and args.sub != "none" and not env.multi:
+        try:      # the same workload WITHOUT the folded gate tables: per-batch gather-GEMM for the LSTM input projection
+            r = run_config(hname + "_nofold", dict(head, nofold=True), args, env, max(40, args.steps // 4), min(args.warmup, 8), shard=True)
+        except Exception as e:
+            r = {"name": hname + "_nofold", "error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.synchronize()
+        if r is not None:
+            sub[hname + "_nofold"] = r
         sub["C3_cars_with_decode"] = decode_record(head, args, env)
+        torch.cuda.empty_cache()
+        sub["C5_stream"] = stream_record(args, env, seconds=float(os.environ.get("BENCH_H2D_SECONDS", "5")))
     weak = None
     if env.multi:           # labelled secondary number: every rank scores its own full batch, no collective
         r = run_config(hname + "_weak", head, args, env, max(20, args.steps // 4), min(args.warmup, 8), shard=False)
@@ -723,10 +830,27 @@ def main():
         cfg["hw_queues"] = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
         cfg["weak_scaling_pairs_per_s"] = weak
         cfg["sub"] = sub
+        pre = cfg.pop("precompute", None)
+        for k, v in (pre or {}).items():                  # scalar keys: survive a one-level parser
+            roof["precompute_" + k] = v
+        # the sub-records again as a SHORT flat list + scalar keys (a parser that keeps only scalars one level down still sees every config)
+        short = []
+        for n, r in sub.items():
+            rf = r.get("roofline") or {}
+            e = {"name": n, "pairs_per_s": r.get("pairs_per_s"), "ms_per_step": r.get("ms_per_step"),
+                 "ms_per_step_one_batch_in_flight": r.get("ms_per_step_one_batch_in_flight"), "dtype": r.get("dtype"),
+                 "kernel": rf.get("kernel"), "avg_us": rf.get("avg_us"), "bound": rf.get("bound"), "frac": rf.get("frac"),
+                 "mfma_frac": rf.get("mfma_frac"), "hbm_frac_8d": rf.get("hbm_frac_8d"), "traffic_ratio": rf.get("traffic_ratio"),
+                 "mfma_busy_pmc": rf.get("mfma_busy_pmc"), "error": r.get("error")}
+            short.append(e)
+            cfg["sub.%s.pairs_per_s" % n] = e["pairs_per_s"]
+            roof["sub.%s.frac" % n] = e["frac"]
+            roof["sub.%s.bound" % n] = e["bound"]
         line = {"metric": "ranked (query,doc) pairs/sec", "value": rec["pairs_per_s"], "unit": "pairs/s", "n_gpus": env.world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
-                "scaling": "strong" if env.multi else "weak", "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
-                "config": cfg, "roofline": roof, "cpu_baseline": cpu}
+                # the global batch is FIXED as N grows (every rank scores its share of the same batch): strong scaling at every N
+                "scaling": "strong", "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
+                "config": cfg, "roofline": roof, "cpu_baseline": cpu, "sub": short}
         result_line = json.dumps(line)
     if env.dist:
         env.dist.destroy_process_group()
@@ -735,6 +859,45 @@ def main():
     ctypes.CDLL(None).fflush(None)
     if result_line is not None:
         print(result_line, flush=True)
+
+
+def stream_record(args, env, seconds=None, n_sessions=223876):
+    """BASELINE.json configs[4] on ONE GPU: CARS at MSMARCO scale as a STREAM -- 223 876 synthetic sessions with
+    S ~ clip(Poisson(4.84) + 2, 2, 16) queries, batched exactly as the reference sampler does (equal-length sessions per
+    batch, full batches, shuffled; neuroir/inputters/multitask/data.py:42-72), 64 sessions x 50 candidates per batch, bf16 folded tables.
+    Ids arrive from the host for every batch (int32 wire block collated into pinned staging by a producer thread), one captured hipGraph
+    per session length and lane; value = pairs of the batches submitted / wall seconds, H2D and D2H of the probabilities included.
+    seconds=None: the WHOLE stream once; else sustained for that long (batches cycled)."""
+    try:
+        from context_attentive_ir_amd.graph_runner import StreamingSessionPredictor
+        from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
+        c = dict(CONFIGS["C5_cars_bf16"])
+        model = build_model(c, args)
+        t0 = time.perf_counter()
+        corpus = SyntheticSessionCorpus(n_sessions=n_sessions, n_cands=c["cands"], qlen=c["qlen"], dlen=c["dlen"], vocab=c["vocab"], pool=96)
+        bl = corpus.batches(c["batch"])
+        t_corpus = time.perf_counter() - t0
+        lengths = sorted({int(corpus.lengths[b[0]]) for b in bl})
+        nl = max(2, min(args.streams, 4))
+        sp = StreamingSessionPredictor(model, c["cands"], c["qlen"], c["dlen"], c["batch"], max_session_len=max(lengths), lanes=nl, slots=2)
+        t0 = time.perf_counter()
+        sp.prepare(lengths, example=(corpus, bl[0]))
+        torch.cuda.synchronize()
+        t_capture = time.perf_counter() - t0
+        sp.run(corpus, bl, max_batches=4 * nl)                                     # warm the pipeline
+        r = sp.run(corpus, bl, min_seconds=seconds, producers=2 if (nl * 2) % 2 == 0 else 1)
+        hist = {int(k): int(v) for k, v in zip(*np.unique(corpus.lengths, return_counts=True))}
+        return {"name": "C5_stream", "baseline_config": "configs[4]: CARS at MSMARCO scale: ~224k-session stream, 50 candidates/query, bf16 (one GPU's share measured here)",
+                "workload": "cars bf16, %d sessions, S ~ clip(Poisson(4.84)+2,2,16) (mean %.2f), %d candidates, q_len %d, doc_len %d, batches of %d equal-length "
+                            "sessions (reference sampler), ids from the host per batch" % (len(corpus), float(corpus.lengths.mean()), c["cands"], c["qlen"], c["dlen"], c["batch"]),
+                "pairs_per_s": round(r["pairs_per_s"], 1), "sessions_per_s": round(r["batches"] * c["batch"] / r["seconds"], 1), "batches": r["batches"],
+                "whole_stream": seconds is None, "seconds": round(r["seconds"], 3), "h2d_GBps": round(r["h2d_GBps"], 3), "lanes": r["lanes"],
+                "slots_per_lane": r["slots_per_lane"], "producer_threads": r["producers"], "session_lengths": lengths, "length_histogram": hist,
+                "graphs": len(lengths) * nl, "graph_capture_s": round(t_capture, 2), "corpus_build_s": round(t_corpus, 2), "dtype": "bf16",
+                "wire": "int32 ids/lengths + float32 labels (nir_widen_ids_i32 on device); D2H of the click probabilities included",
+                "ms_per_step": round(r["seconds"] / max(1, r["batches"]) * 1e3, 5)}
+    except Exception as e:  # pragma: no cover
+        return {"name": "C5_stream", "error": "%s: %s" % (type(e).__name__, e)}
 
 
 def decode_record(c, args, env):

@@ -222,3 +222,27 @@ extern "C" int nir_sanitize_ids(const int64_t* a, int64_t na, const int64_t* b, 
     NIR_CHECK_LAUNCH("sanitize_ids_kernel");
     return 0;
 }
+
+
+// int32 ids on the wire: the host ships token ids / lengths as int32 -- half the PCIe bytes of the reference's
+// torch.LongTensor batches (inputters/multitask/vector.py:82-149) -- and this kernel widens them into the int64 tensors every entry
+// point reads.  16 bytes in, 32 bytes out per lane and iteration; negative values sign-extend (and are then caught by the id checks).
+__global__ __launch_bounds__(256) void widen_ids_kernel(const int32_t* __restrict__ src, int64_t* __restrict__ dst, int64_t n) {
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 4 <= n) {
+        const int4 v = *reinterpret_cast<const int4*>(src + i4);
+        *reinterpret_cast<longlong2*>(dst + i4) = make_longlong2((int64_t)v.x, (int64_t)v.y);
+        *reinterpret_cast<longlong2*>(dst + i4 + 2) = make_longlong2((int64_t)v.z, (int64_t)v.w);
+    } else {
+        for (int64_t i = i4; i < n; ++i) dst[i] = (int64_t)src[i];
+    }
+}
+extern "C" int nir_widen_ids_i32(const int32_t* src, int64_t* dst, int64_t n, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(n >= 0 && (n == 0 || (src && dst)), "widen_ids: bad args");
+    NIR_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "widen_ids: buffers must be 16-byte aligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(widen_ids_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    NIR_CHECK_LAUNCH("widen_ids_kernel");
+    return 0;
+}

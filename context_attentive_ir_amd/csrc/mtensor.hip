@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, 3) void mt_head_kernel(const float* __restrict
 #pragma unroll
     for (int g = 0; g < MFC; ++g) zmax[g] = -INFINITY;
 
-    const float* ub = U + (int64_t)b * rows * KTOT;
+    const float* ub = U + (int64_t)b * (MT * 32) * KTOT;      // per query: all MT row tiles of the folded operand
     const int g2 = lane >> 5, col = lane & 31;
     for (int ch = 0; ch < nchunk; ++ch)
     for (int grp = 0; grp < ngroup; ++grp) {

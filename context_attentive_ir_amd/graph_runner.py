@@ -153,3 +153,186 @@ class GraphedPredictor(object):
         self.clone_done = torch.cuda.Event()
         self.clone_done.record(caller)
         return out
+
+
+class StreamingSessionPredictor(object):
+    """Sustained, H2D-INCLUSIVE CARS ranking over a session stream (BASELINE.json configs[4]).
+
+    Per lane (HIP stream): `slots` pinned host staging buffers, one device wire buffer, one device int64 buffer, and one captured
+    hipGraph per session length S seen so far:  [ nir_widen_ids_i32 (int32 wire block -> int64 ids/lengths) | Multitask.predict
+    ranking path ]  reading fixed device addresses.  A batch costs the host one in-place collate (producer thread, numpy `take` into
+    the pinned slot), one H2D of the int32 block (half the bytes of the reference's LongTensor batch), one graph replay and one small
+    D2H of the click probabilities.  Batches go round-robin over the lanes; a host slot is recycled as soon as ITS H2D has executed
+    (not the whole replay), so with >= 2 slots per lane the producer fills slot k+1 while slot k is in flight.
+    Shapes: batches of exactly `batch_size` sessions of one length (the reference sampler's composition,
+    neuroir/inputters/multitask/data.py:42-72); a new length is captured on first use (outside any timed region: `prepare`)."""
+
+    def __init__(self, wrapper, n_cands, qlen, dlen, batch_size, max_session_len=16, lanes=2, slots=2):
+        from .inputters.session_stream import WireLayout
+        if not wrapper.use_cuda:
+            raise RuntimeError("StreamingSessionPredictor needs a wrapper on a ROCm device (call .cuda() first)")
+        self.wrapper, self.B, self.N, self.QL, self.DL = wrapper, int(batch_size), int(n_cands), int(qlen), int(dlen)
+        self.WireLayout = WireLayout
+        self.dev = next(wrapper.network.parameters()).device
+        big = WireLayout(self.B, max_session_len, self.N, self.QL, self.DL)
+        self.max_S = int(max_session_len)
+        self.lanes = []
+        for _ in range(max(1, lanes)):
+            ln = {"stream": torch.cuda.Stream(device=self.dev),
+                  "wire": torch.empty(big.nbytes, dtype=torch.uint8, device=self.dev),
+                  "wide": torch.empty(big.n_int, dtype=torch.int64, device=self.dev),
+                  "host": [torch.empty(big.nbytes, dtype=torch.uint8).pin_memory() for _ in range(max(1, slots))],
+                  "res": [torch.empty(self.B * max_session_len * self.N, dtype=torch.float32).pin_memory() for _ in range(max(1, slots))],
+                  "copied": [None] * max(1, slots), "done": [None] * max(1, slots), "graphs": {}, "owners": {}}
+            ln["host_np"] = [h.numpy() for h in ln["host"]]
+            self.lanes.append(ln)
+        lib.check(lib.load().nir_set_batches_in_flight(len(self.lanes)), "nir_set_batches_in_flight")
+
+    # ---- capture -----------------------------------------------------------------------------------------------------
+    def _step(self, ln, lay):
+        wide = lay.wide_views(ln["wide"])
+        lib.check(lib.load().nir_widen_ids_i32(lib.ptr(ln["wire"]), lib.ptr(ln["wide"]), lay.n_int, lib.stream()), "nir_widen_ids_i32")
+        ex = dict(wide, document_labels=lay.views(ln["wire"])["document_labels"])
+        return self.wrapper.predict(ex, suggest=False)["click_scores"]
+
+    def prepare(self, lengths, example=None):
+        """capture the graphs of these session lengths on every lane (warm-up included).  `example` = (corpus, idx): a real batch used as
+        the capture input (else zeros: PAD ids, length-0 sequences -- valid inputs)."""
+        for S in sorted({int(s) for s in lengths}):
+            if S > self.max_S:
+                raise RuntimeError("session length %d > max_session_len %d" % (S, self.max_S))
+            lay = self.WireLayout(self.B, S, self.N, self.QL, self.DL)
+            for ln in self.lanes:
+                if S in ln["graphs"]:
+                    continue
+                owner = ln["owners"].setdefault(S, type("ws", (), {})())
+                with torch.cuda.stream(ln["stream"]), lib.workspace_owner(owner):
+                    ln["wire"].zero_()
+                    if example is not None and int(example[0].lengths[example[1][0]]) == S:
+                        example[0].collate_into(example[1], ln["host_np"][0])
+                        ln["wire"][:lay.nbytes].copy_(ln["host"][0][:lay.nbytes])
+                    for _ in range(2):
+                        self._step(ln, lay)
+                    ln["stream"].synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=ln["stream"], capture_error_mode="thread_local"):
+                        out = self._step(ln, lay)
+                ln["graphs"][S] = (g, out, lay)
+
+    # ---- one batch ---------------------------------------------------------------------------------------------------
+    def slot_free(self, lane, slot):
+        ev = self.lanes[lane]["copied"][slot]
+        return ev is None or ev.query()
+
+    def submit(self, lane, slot, S):
+        """the wire block of a batch of length-S sessions sits in host slot (lane, slot): H2D, replay, D2H of the probabilities."""
+        ln = self.lanes[lane]
+        g, out, lay = ln["graphs"][S]
+        with torch.cuda.stream(ln["stream"]):
+            ln["wire"][:lay.nbytes].copy_(ln["host"][slot][:lay.nbytes], non_blocking=True)
+            if ln["copied"][slot] is None:
+                ln["copied"][slot], ln["done"][slot] = torch.cuda.Event(), torch.cuda.Event()
+            ln["copied"][slot].record(ln["stream"])
+            g.replay()
+            ln["res"][slot][:lay.pairs].copy_(out.reshape(-1), non_blocking=True)
+            ln["done"][slot].record(ln["stream"])
+        return lay
+
+    def result(self, lane, slot, lay):
+        """click probabilities [B,S,N] of the batch submitted from (lane, slot) -- host tensor (valid until the slot is re-submitted)."""
+        self.lanes[lane]["done"][slot].synchronize()
+        return self.lanes[lane]["res"][slot][:lay.pairs].view(lay.B, lay.S, lay.N)
+
+    # ---- the whole pipeline ----------------------------------------------------------------------------------------------
+    def run(self, corpus, batches, on_result=None, min_seconds=None, max_batches=None, producers=1):
+        """Stream `batches` (index lists into `corpus`; cycled when min_seconds asks for more) through the lanes.
+        on_result(batch_no, idx, probs[B,S,N] host tensor): called in submission order once a batch's results are on the host.
+        -> dict(batches, pairs, seconds, pairs_per_s, h2d_bytes)."""
+        import queue
+        import threading
+        L, R = len(self.lanes), len(self.lanes[0]["host"])
+        nslots = L * R
+        self.prepare({int(corpus.lengths[b[0]]) for b in batches})
+        total = None if min_seconds else (len(batches) if max_batches is None else min(len(batches), max_batches))
+        free_q, ready = [queue.Queue() for _ in range(producers)], queue.Queue()
+        stop = threading.Event()
+        err = []
+
+        def produce(pi):
+            k = pi                                          # producer pi fills batches pi, pi + P, ... into slots k % nslots
+            try:
+                while not stop.is_set() and (total is None or k < total):
+                    try:
+                        free_q[pi].get(timeout=0.05)            # token: slot (k % nslots) may be overwritten
+                    except queue.Empty:
+                        continue
+                    idx = batches[k % len(batches)]
+                    s = k % nslots
+                    lay = corpus.collate_into(idx, self.lanes[s % L]["host_np"][s // L])
+                    ready.put((k, s, lay.S))
+                    k += producers
+            except BaseException as e:                      # surface collation errors in the consumer
+                err.append(e)
+                ready.put(None)
+
+        # slot s is owned by producer (batch k % producers) -- with nslots % producers == 0 a slot always belongs to the same producer
+        if nslots % producers:
+            raise RuntimeError("lanes * slots must be a multiple of the producer count")
+        for s in range(nslots):
+            free_q[s % producers].put(s)
+        threads = [threading.Thread(target=produce, args=(pi,), name="nir-session-collate-%d" % pi, daemon=True) for pi in range(producers)]
+        for t in threads:
+            t.start()
+        pending, inflight, waiting_copy = {}, [], []
+        nxt = done = 0
+        pairs = nbytes = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        try:
+            while True:
+                # recycle host slots whose H2D has executed (with a result consumer: once the slot's results were handed over, below)
+                while on_result is None and waiting_copy and self.slot_free(*waiting_copy[0][:2]):
+                    ln_i, sl_i, s = waiting_copy.pop(0)
+                    free_q[s % producers].put(s)
+                # hand finished results over in submission order
+                while inflight and (on_result is None or self.lanes[inflight[0][1]]["done"][inflight[0][2]].query()):
+                    k, ln_i, sl_i, lay = inflight.pop(0)
+                    if on_result is not None:
+                        on_result(k, batches[k % len(batches)], self.result(ln_i, sl_i, lay))
+                        free_q[(sl_i * L + ln_i) % producers].put(sl_i * L + ln_i)
+                    done += 1
+                if total is not None and nxt >= total:
+                    if not inflight:
+                        break
+                    time.sleep(0)
+                    continue
+                if min_seconds and time.perf_counter() - t0 >= min_seconds:
+                    total = nxt
+                    continue
+                if nxt not in pending:
+                    try:
+                        item = ready.get(timeout=0.0005)
+                    except queue.Empty:
+                        continue
+                    if item is None:
+                        raise err[0]
+                    pending[item[0]] = item
+                    if nxt not in pending:
+                        continue
+                k, s, S = pending.pop(nxt)
+                ln_i, sl_i = s % L, s // L
+                lay = self.submit(ln_i, sl_i, S)
+                if on_result is None:
+                    waiting_copy.append((ln_i, sl_i, s))
+                inflight.append((k, ln_i, sl_i, lay))
+                pairs += lay.pairs
+                nbytes += lay.nbytes
+                nxt += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            stop.set()
+            for t in threads:
+                t.join(timeout=5.0)
+        return {"batches": nxt, "pairs": pairs, "seconds": dt, "pairs_per_s": pairs / dt, "h2d_bytes": nbytes,
+                "h2d_GBps": nbytes / dt / 1e9, "lanes": L, "slots_per_lane": R, "producers": producers}

@@ -78,6 +78,7 @@ SIGNATURES = {
     "nir_split_f16x2": (_i, [c_fp, _l, _i, _l, _i, C.c_void_p, C.c_void_p, c_st]),
     "nir_linear_planes_f32": (_i, [C.c_void_p, C.c_void_p, _l, c_ip, _l, _l, _i, _i, C.c_void_p, C.c_void_p, _l, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_sanitize_ids": (_i, [c_ip, _l, c_ip, _l, _l, c_ip, c_ip, C.c_void_p, c_st]),
+    "nir_widen_ids_i32": (_i, [C.c_void_p, C.c_void_p, _l, c_st]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_rowdot_f32": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, _i, _i, c_st]),
     "nir_bilstm_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),

@@ -4,8 +4,7 @@ Mirror of neuroir.modules.embeddings.Embeddings (/root/reference/neuroir/modules
 word-only case the hot path uses: one nn.Embedding(padding_idx=PAD) stored under
 `make_embedding.emb_luts.0.weight` so reference checkpoints load unchanged.
 On the HIP path the table is never "looked up" into a [.., L, E] tensor: kernels take `table` and gather
-rows inside their operand loads.  `forward` exists for callers outside the hot path (e.g. CARS.decode on
-stock PyTorch) and is plain torch.
+rows inside their operand loads (train mode: autograd.embed).  `forward` raises: there is no stock-torch lookup.
 """
 import torch
 import torch.nn as nn

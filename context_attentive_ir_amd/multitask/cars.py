@@ -218,8 +218,8 @@ class CARS(nn.Module, lib.IdCheck):
 
     def _check_eval(self):
         if self.training:
-            raise NotImplementedError("HIP CARS implements the eval-mode forward (dropout is RNG-dependent, "
-                                      "SURVEY.md Appendix E7)")
+            raise RuntimeError("CARS.encode / encode_document / rank_document / decode are the inference entry points: call them in "
+                               "eval mode (the train-mode path is forward(), which runs the differentiable operators with dropout)")
 
     def _folded_table(self, which, w):
         """[V, 8H] folded gate table of one encoder (fp32 or bf16), rebuilt when the table or the LSTM weights change."""

@@ -87,9 +87,8 @@ class DRMM(nn.Module, lib.IdCheck):
         lib.require_device(batch_queries, batch_docs, table)
         q, d = self._clean_ids(batch_queries, batch_docs, self.word_embeddings.table.shape[0])
         if self.training and not return_hist:
-            if table.requires_grad:
-                raise NotImplementedError("DRMM training needs fix_embeddings=True: the histogram features are not differentiable "
-                                          "(the reference detaches them through numpy, drmm.py:70)")
+            # fix_embeddings=False (config.py:94, the reference's default): the table trains through the gating network only -- the
+            # histograms are constants of the graph (the reference detaches them through numpy, drmm.py:70-75; _hist reads detached rows)
             return self._forward_train(q, d)
         B, QL = q.shape
         N, DL = d.shape[1], d.shape[2]

@@ -200,6 +200,21 @@ class SessionShardPlan(object):
         dist.all_to_all_single(out.view(G * bper, S, per, D), pooled_shard.contiguous(), group=group)
         return out
 
+    def exchange_via_gather(self, pooled_shard, group=None, out=None):
+        """The same exchange through all_gather_into_tensor: every rank receives EVERY slice and keeps the chunk of its own sessions --
+        G x the bytes of the all-to-all (C5 at 8 ranks: 25.7 MB in per rank and step instead of 3.2 MB), but a collective RCCL can replay
+        from a captured hipGraph (RCCL 2.26.6: a captured all_to_all_single hangs, all_gather_into_tensor captures and replays;
+        tools/rccl_capture_probe.py).  out (optional): [G, G*bper, S, per, D] gather buffer.  -> view [G,bper,S,per,D]."""
+        G, bper, S, per = self.world, self.bper, self.S, self.per
+        D = pooled_shard.shape[-1]
+        assert tuple(pooled_shard.shape) == (G * bper, S, per, D), tuple(pooled_shard.shape)
+        if G == 1 and not (dist.is_available() and dist.is_initialized()):
+            return pooled_shard.view(1, bper, S, per, D)
+        if out is None:
+            out = torch.empty(G, G * bper, S, per, D, device=pooled_shard.device, dtype=pooled_shard.dtype)
+        dist.all_gather_into_tensor(out.view(G * G * bper, S, per, D), pooled_shard.contiguous(), group=group)
+        return out[:, self.rank * bper:(self.rank + 1) * bper]
+
     def assemble(self, recv):
         """[G,bper,S,per,D] (rank-major candidate slices) -> pooled documents of my sessions [bper,S,N,D] (padding dropped)."""
         G, bper, S, per, D = recv.shape
@@ -221,7 +236,7 @@ class SessionShardPlan(object):
         return (self.world - 1) * self.bper * self.S * self.per * D * itemsize
 
 
-def session_sharded_click_probs(plan, encode_q, encode_docs, session_tail, ex, group=None):
+def session_sharded_click_probs(plan, encode_q, encode_docs, session_tail, ex, group=None, via_gather=False):
     """The whole sharded step in terms of three callables (the HIP entry points on a GPU; the CPU oracle in the gloo tests):
          encode_q(source_words [b,S,QL], source_lens [b,S])                  -> pooled queries [b,S,D]
          encode_docs(document_words [b,S,n,DL], document_lens [b,S,n])       -> pooled documents [b,S,n,D]
@@ -229,7 +244,7 @@ def session_sharded_click_probs(plan, encode_q, encode_docs, session_tail, ex, g
        -> [B,S,N] on every rank."""
     pq = encode_q(plan.own(ex["source_words"]), plan.own(ex["source_lens"]))
     d, l = plan.doc_shard(ex["document_words"], ex["document_lens"])
-    docs = plan.assemble(plan.exchange(encode_docs(d, l), group))
+    docs = plan.assemble((plan.exchange_via_gather if via_gather else plan.exchange)(encode_docs(d, l), group))
     labels = ex["document_labels"]
     probs = session_tail(pq, docs, plan.own(labels), labels)
     return plan.gather(probs, group)

@@ -79,6 +79,36 @@ class WrapperBase(object):
                         if isinstance(v, torch.Tensor):
                             state[k] = v.cuda()
 
+    def sync_gradients(self):
+        """Multi-rank training step (replaces what nn.DataParallel's backward did for the reference, models/ranker.py:341-346,
+        models/multitask.py:402-407: replicas see different slices of the batch and their gradients are reduced).  One process per GPU:
+        after backward, before clip_grad_norm_, the gradients of all ranks of `self.group` are AVERAGED with one flat all-reduce
+        (RCCL when the group's backend is 'nccl'), so every rank applies the same update and the replicas -- which must start from the
+        same weights -- never diverge; the candidate-sharded predict then gathers scores of ONE model.  No-op unless parallelize() was
+        called and a process group with more than one rank is initialised."""
+        if not getattr(self, "parallel", False):
+            return False
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        group = getattr(self, "group", None)
+        world = dist.get_world_size(group)
+        if world == 1:
+            return False
+        params = [p for p in self.network.parameters() if p.requires_grad]
+        for p in params:                      # a parameter unused on this rank still takes part in the reduction
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat, group=group)
+        flat.div_(world)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+        return True
+
     def _params(self, extra=None):
         state = copy.copy(self.network.state_dict())
         state.pop("fixed_embedding", None)

@@ -170,6 +170,7 @@ class Multitask(WrapperBase):
         loss["total_loss"] = total
         self.optimizer.zero_grad()
         total.backward()
+        self.sync_gradients()                 # multi-rank: average the gradients of all ranks (WrapperBase.sync_gradients)
         torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.args.grad_clipping)
         self.optimizer.step()
         self.updates += 1

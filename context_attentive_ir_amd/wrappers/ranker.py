@@ -1,7 +1,7 @@
 """Ranker -- high-level wrapper with the call shapes of neuroir.models.ranker.Ranker
 (/root/reference/neuroir/models/ranker.py:25-346) for the hot-path models: build the network from
 `args.model_type`, `.cuda()`, `predict(ex)` = softmax(network(...), -1), `loss(ex)` and save/load of
-`{state_dict, args}`.  Training (`update`) is outside this round's scope.
+`{state_dict, args}`; `update(ex)` is the training step (models/ranker.py:192-230) on the HIP autograd operators.
 
 Multi-GPU: instead of the reference's nn.DataParallel batch split (models/ranker.py:341-346) the wrapper can
 shard the CANDIDATE axis over the ranks of a torch.distributed group and all-gather the scores (sharding.py).
@@ -88,7 +88,7 @@ class Ranker(WrapperBase):
         if self.kind not in BCE_MODELS:
             raise RuntimeError("%s has no training criterion (main/ranker.py:414)" % self.kind)
         if not hasattr(self.network, "_forward_train"):
-            raise NotImplementedError("train-mode forward of %s is not built yet (MATCH_TENSOR is)" % self.kind)
+            raise NotImplementedError("%s has no train-mode forward" % self.kind)
         from .. import autograd as A
         self.network.train()
         q, ql, d, dl = self._inputs(ex)
@@ -98,6 +98,7 @@ class Ranker(WrapperBase):
         loss = A.bce_with_logits(scores, labels)
         self.optimizer.zero_grad()
         loss.backward()
+        self.sync_gradients()                 # multi-rank: average the gradients of all ranks (WrapperBase.sync_gradients)
         torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.args.grad_clipping)
         self.optimizer.step()
         self.updates += 1

@@ -86,6 +86,10 @@ int nir_linear_planes_f32(const void* a1, const void* a2, int64_t lda, const int
 int nir_sanitize_ids(const int64_t* a, int64_t na, const int64_t* b, int64_t nb, int64_t V, int64_t* out_a, int64_t* out_b,
                      int* err_flag, nir_stream_t stream);
 
+/* int32 ids on the wire (the reference's collate emits int64, inputters/multitask/vector.py:82-149): widen n int32
+ * values (ids / lengths as shipped by inputters.session_stream) into the int64 tensors the entry points read.  16-byte aligned. */
+int nir_widen_ids_i32(const int32_t* src, int64_t* dst, int64_t n, nir_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Building blocks
  * ------------------------------------------------------------------------------------------------ */

@@ -214,7 +214,7 @@ def gen_cars():
 
 
 def gen_train(model="MATCH_TENSOR", fixture="match_tensor_train", seed=23, final_keys=("output.weight", "conv.weight", "linear_projection.weight",
-                                                                                      "document_encoder.rnns.0.weight_hh_l0"), disjoint=False):
+                                                                                      "document_encoder.rnns.0.weight_hh_l0"), disjoint=False, fix_embeddings=True):
     """Training step of the real reference (models/ranker.py:192-230): dropout 0, Adam lr 1e-3, grad clipping 10,
     5 updates alternating over two batches -> loss trajectory; gradients of the first backward (before clipping)."""
     rng = np.random.default_rng(seed)
@@ -230,7 +230,7 @@ def gen_train(model="MATCH_TENSOR", fixture="match_tensor_train", seed=23, final
         lab[np.arange(B), rng.integers(0, N, size=B)] = 1
         batches.append(dict(que_rep=q, que_len=qlen, doc_rep=d, doc_len=dlen, label=lab))
     args = base_args(model, dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.001, weight_decay=0,
-                     momentum=0, grad_clipping=10.0, fix_embeddings=True, max_query_len=QL, max_doc_len=DL)
+                     momentum=0, grad_clipping=10.0, fix_embeddings=fix_embeddings, max_query_len=QL, max_doc_len=DL)
     vocab = list(range(V))
     r = Ranker(args, vocab)
     load_det(r.network)
@@ -271,6 +271,13 @@ def gen_duet_train():
 
 def gen_drmm_train():
     gen_train("DRMM", "drmm_train", 37, ("gating_network.weight.weight", "ffnn.0.weight", "ffnn.1.bias", "output.weight"), disjoint=True)
+
+
+def gen_drmm_train_free():
+    """config.py:94 default fix_embeddings=False: the embedding table trains through the gating network (the histograms are constants,
+    rankers/drmm.py:70-75)."""
+    gen_train("DRMM", "drmm_train_free", 41, ("gating_network.weight.weight", "ffnn.0.weight", "output.weight", "word_embeddings.make_embedding.emb_luts.0.weight"),
+              disjoint=True, fix_embeddings=False)
 
 
 def gen_cars_train():
@@ -501,7 +508,7 @@ if __name__ == "__main__":
     torch.manual_seed(SEED)
     torch.set_num_threads(4)
     only = set(sys.argv[1:])          # e.g. `generate.py cars_decode` regenerates one fixture family
-    gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode, train=gen_train, duet_train=gen_duet_train, drmm_train=gen_drmm_train, cars_train=gen_cars_train,
+    gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode, train=gen_train, duet_train=gen_duet_train, drmm_train=gen_drmm_train, drmm_train_free=gen_drmm_train_free, cars_train=gen_cars_train,
                 losses_metrics=gen_losses_metrics, batchify=gen_batchify, samplers=gen_samplers, m_match_tensor=gen_m_match_tensor,
                 mnsrf=gen_mnsrf)
     for name, fn in gens.items():

@@ -40,7 +40,7 @@ def test_bench_two_ranks_strong_scaling_flow():
     d = _last_json(out.stdout)
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["world_size"] == 2 and "Multitask.parallelize" in d["config"]["parallelism"]
+    assert d["config"]["world_size"] == 2 and "session-sharded tail" in d["config"]["parallelism"]
     assert d["config"]["weak_scaling_pairs_per_s"] > 0
     sub = d["config"]["sub"]["C2_match_tensor"]
     assert sub["world_size"] == 2 and "5 per rank" in sub["parallelism"] and sub["pairs_per_s"] > 0

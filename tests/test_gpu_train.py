@@ -169,6 +169,41 @@ def test_duet_drmm_update_matches_reference_loss_trajectory(model):
         _rel(have, g["final_" + k], 2e-4)
 
 
+def test_drmm_trainable_embeddings_vs_reference():
+    """config.py:94 default fix_embeddings=False: the table's gradient flows through the gating network (histograms are constants);
+    gradients of the first backward and the 5-step Ranker.update trajectory of the real reference (tests/golden/drmm_train_free.npz)."""
+    g = load_golden("drmm_train_free")
+    from context_attentive_ir_amd import autograd as A
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import Ranker
+    q, ql, d, dl, lab = (T(g["b0_" + k], DEV) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label"))
+    m = build_model("DRMM", device=DEV, dropout_emb=0.0, dropout=0.0).train()
+    assert m.word_embeddings.table.requires_grad
+    s = m(q, ql, d, dl)
+    _rel(s, g["scores0"], 2e-5)
+    loss = A.bce_with_logits(s, lab.float())
+    _rel(loss, g["loss0"], 1e-5)
+    loss.backward()
+    _check_grads(m, g, floor=1e-2)
+    assert m.word_embeddings.table.grad is not None and float(m.word_embeddings.table.grad.abs().max()) > 0
+    QL, DL = g["b0_que_rep"].shape[1], g["b0_doc_rep"].shape[2]
+    args = default_args("DRMM", src_vocab_size=int(g["meta_vocab"]), dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam",
+                        learning_rate=0.001, weight_decay=0, momentum=0, grad_clipping=10.0, fix_embeddings=False, max_query_len=QL,
+                        max_doc_len=DL)
+    r = Ranker(args)
+    fill_module_(r.network, 1013)
+    r.cuda()
+    r.init_optimizer()
+    losses = [float(r.update({k: T(g["b%d_%s" % (step % 2, k)]) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label")}))
+              for step in range(5)]
+    np.testing.assert_allclose(np.asarray(losses), g["losses"], rtol=1e-4, atol=0)
+    sd = r.network.state_dict()
+    for k in [f[6:] for f in g if f.startswith("final_")]:      # (incl. the trained embedding table, every 37th element)
+        have = sd[k] if sd[k].numel() <= 20000 else sd[k].flatten()[::37]
+        _rel(have, g["final_" + k], 2e-4)
+
+
 def test_duet_dropout_replayed_through_torch():
     """DUET in train mode with dropout 0.2 at its three sites: the product's keep masks replayed through a torch-CPU restatement of
     duet.py (F.conv1d / F.linear / autograd), scores and gradients compared."""

@@ -196,6 +196,8 @@ for B, S, N in ((4, 3, 5), (3, 2, 9), (1, 3, 2), (5, 2, 4)):        # B, N divis
     plan = sharding.SessionShardPlan(B, S, N, world, rank)
     got = sharding.session_sharded_click_probs(plan, enc_q, enc_d, tail, ex)
     assert got.shape == full.shape and torch.allclose(got, full, atol=1e-6), (rank, B, N, float((got - full).abs().max()))
+    got2 = sharding.session_sharded_click_probs(plan, enc_q, enc_d, tail, ex, via_gather=True)       # the capturable form of the exchange
+    assert torch.equal(got2, got), (rank, B, N)
     # a block evaluated WITHOUT the batch-wide labels differs whenever its own max click count is smaller: the quirk is really exercised
     cnt = lambda l: int((l.reshape(-1, N) != 0).sum(1).max())
     if B > 1 and world > 1 and rank == 0 and cnt(plan.own(ex["document_labels"])) < min(cnt(ex["document_labels"]), N - 1):
@@ -221,6 +223,48 @@ def test_session_sharded_tail_gloo(tmp_path, world):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in o, o
+
+
+def _grad_sync_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from context_attentive_ir_amd.config import default_args
+        from context_attentive_ir_amd.detinit import fill_module_
+        from context_attentive_ir_amd.wrappers import Multitask, Ranker
+        ok = True
+        for w in (Ranker(default_args("DRMM", src_vocab_size=50)), Multitask(default_args("CARS", src_vocab_size=50, tgt_vocab_size=40))):
+            fill_module_(w.network, 1013)
+            params = [p for p in w.network.parameters() if p.requires_grad]
+            for i, p in enumerate(params):
+                p.grad = None if (rank == 1 and i == 0) else torch.full_like(p, float(rank + 1) * (i + 1))     # rank 1 never used param 0
+            ok &= w.sync_gradients() is False                      # not parallelised: untouched
+            ok &= float(params[1].grad.flatten()[0]) == float(rank + 1) * 2
+            w.parallelize()
+            ok &= w.sync_gradients() is True
+            for i, p in enumerate(params):                         # mean over ranks of (rank+1)*(i+1); param 0: (1 + 0) / 2
+                want = 0.5 if i == 0 else 1.5 * (i + 1)
+                ok &= bool(torch.all(p.grad == want))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_update_gradient_sync_two_ranks():
+    """Ranker.update / Multitask.update under parallelize(): gradients are averaged over the ranks before clipping
+    (WrapperBase.sync_gradients), the role nn.DataParallel's backward plays in the reference (models/ranker.py:341-346)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + os.getpid() % 100
+    procs = [ctx.Process(target=_grad_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
 
 
 def _async_gather_worker(rank, world, port, q):
@@ -379,3 +423,30 @@ def test_prefetching_stream_order_and_shutdown():
     it.close()
     import threading
     assert not any(t.name == "nir-batch-prefetch" and t.is_alive() for t in threading.enumerate())
+
+
+def test_session_stream_corpus_and_wire_layout():
+    """SURVEY.md 8(d) stream: S ~ clip(Poisson(4.84)+2, 2, 16); batches = the reference sampler's composition (equal-length, full batches);
+    the int32 wire block round-trips every field and keeps 16-byte aligned field starts."""
+    from context_attentive_ir_amd.inputters import SyntheticSessionCorpus, WireLayout
+    c = SyntheticSessionCorpus(n_sessions=6000, n_cands=5, qlen=4, dlen=12, vocab=500, seed=2, pool=6, full_length=False)
+    assert c.lengths.min() >= 2 and c.lengths.max() <= 16 and abs(float(c.lengths.mean()) - 6.84) < 0.15
+    bs = c.batches(16, seed=4)
+    assert all(len(b) == 16 and len({int(c.lengths[i]) for i in b}) == 1 for b in bs)
+    dropped = len(c) - 16 * len(bs)
+    assert 0 <= dropped < 16 * len(np.unique(c.lengths))               # only the remainder of each length cluster is dropped
+    assert bs != c.batches(16, shuffle=False)                           # shuffled batch order, same content
+    assert sorted(map(sorted, bs)) == sorted(map(sorted, c.batches(16, shuffle=False)))
+    lay = WireLayout(16, 7, 5, 4, 12)
+    assert all(o % 4 == 0 for o in lay.offset.values()) and lay.nbytes % 16 == 0
+    buf = np.full(c.layout(16, 16).nbytes, 0xAB, np.uint8)
+    lay = c.collate_into(bs[0], buf)
+    ref = c.batch_tensors(bs[0])
+    host, dev_like = lay.views(buf), lay.views(torch.from_numpy(buf))
+    for k, v in ref.items():
+        assert host[k].shape == tuple(v.shape) and (host[k] == v.numpy()).all() and (dev_like[k].numpy() == v.numpy()).all(), k
+    assert ref["document_words"].dtype == torch.int64 and host["document_words"].dtype == np.int32      # half the bytes on the wire
+    wide = lay.wide_views(torch.from_numpy(buf[:4 * lay.n_int].view(np.int32).astype(np.int64)))
+    assert all(torch.equal(wide[k], ref[k]) for k in wide)
+    pos = np.arange(12)
+    assert ((ref["document_words"].numpy() == 0) == (pos >= ref["document_lens"].numpy()[..., None])).all()
