@@ -39,6 +39,7 @@ import time
 # pairs/s at 4 queues, 3.13 M at 8 on C2).  Must be set before the HIP runtime initialises, i.e. before `import torch`.
 if not ("--streams" in sys.argv and sys.argv[sys.argv.index("--streams") + 1:][:1] == ["1"]):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "8")     # streams the runtime spreads the parallel branches of ONE hipGraph over
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -313,8 +314,14 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     emu = wsh != world
     model = build_model(c, args)
     pre = precompute_info(model, c) if rank == 0 else None
+    # batches in flight: --streams lanes; the sharded CARS step leaves each rank 1/W of the work per step, so more steps must be in flight
+    # to keep a GPU busy (8 lanes = the 8 hardware queues)
+    nlanes = max(1, args.streams)
+    if sharded and c["model"] == "cars" and wsh > 1 and env.backend == "nccl":
+        nlanes = max(nlanes, int(os.environ.get("BENCH_SHARD_LANES", "8")))
+    nbatches = (max(args.nbatches, nlanes) + nlanes - 1) // nlanes * nlanes
     # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
-    batches = make_batches(c, args.nbatches, 0 if sharded or not env.multi else rank, dev)
+    batches = make_batches(c, nbatches, 0 if sharded or not env.multi else rank, dev)
     pairs_global = c["batch"] * c["cands"] * (c["session"] if is_sess else 1)
     ncand = c["cands"]
     plan = None
@@ -341,27 +348,35 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                          torch.zeros(G * bper, S_, ncand, device=dev))
         return coll[key]
 
-    def sharded_cars_step(ex, key, via_gather=False):
-        """one candidate-/session-sharded CARS ranking step (eager or under capture): encode | exchange | tail | all-gather.
-        via_gather: the exchange as all_gather_into_tensor (every slice to every rank, own sessions' chunk kept) -- the form RCCL can
-        replay from a captured hipGraph; else all_to_all_single (1/G of the bytes, eager only)."""
-        recv, probs_own, allp = cars_bufs(key)
-        pq, pl = model.shard_encode(ex["_q_own"], ex["_ql_own"], ex["_doc_shard"], ex["_len_shard"])
+    # one candidate-/session-sharded CARS ranking step in four pieces (eager or under capture): encode | exchange | tail | gather.
+    # via_gather: the exchange as all_gather_into_tensor (every slice to every rank, own sessions' chunk kept) -- the form RCCL can replay
+    # from a captured hipGraph; else all_to_all_single (1/G of the bytes, eager only).
+    def cars_encode(ex):
+        return model.shard_encode(ex["_q_own"], ex["_ql_own"], ex["_doc_shard"], ex["_len_shard"])
+
+    def cars_exchange(key, pl, via_gather):
+        recv = cars_bufs(key)[0]
         if via_gather:
             if (key, "g") not in coll:
                 coll[(key, "g")] = torch.zeros(plan.world, plan.world * plan.bper, plan.S, plan.per, pl.shape[-1], device=dev)
             big = coll[(key, "g")]
             # (emulated world: the 1-rank group fills chunk 0 only; the tail reads rank 0's session block of every chunk all the same)
             env.dist.all_gather_into_tensor(big[:1].view(pl.shape) if emu else big.view(-1, *pl.shape[1:]), pl)
-            recv = big[:, rank * plan.bper:(rank + 1) * plan.bper]
-        elif env.backend == "nccl":
+            return big[:, rank * plan.bper:(rank + 1) * plan.bper]
+        if env.backend == "nccl":
             # (emulated world: the 1-rank group copies the whole buffer -- the bytes a real exchange moves, meaningless scores)
             env.dist.all_to_all_single(recv.view(pl.shape), pl)
         else:
             h = torch.empty(pl.shape)
             env.dist.all_to_all_single(h, pl.cpu())
             recv.view(pl.shape).copy_(h)
-        model.shard_tail(pq, recv, ex["_lab_own"], ex["document_labels"], ncand, probs_own)
+        return recv
+
+    def cars_tail(ex, key, pq, recv):
+        return model.shard_tail(pq, recv, ex["_lab_own"], ex["document_labels"], ncand, cars_bufs(key)[1])
+
+    def cars_gather(key, probs_own):
+        allp = cars_bufs(key)[2]
         if env.backend == "nccl":
             env.dist.all_gather_into_tensor(allp[:plan.bper] if emu else allp, probs_own)
         else:
@@ -369,6 +384,10 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             env.dist.all_gather_into_tensor(h, probs_own.cpu())
             allp.copy_(h)
         return allp[:c["batch"]]
+
+    def sharded_cars_step(ex, key, via_gather=False):
+        pq, pl = cars_encode(ex)
+        return cars_gather(key, cars_tail(ex, key, pq, cars_exchange(key, pl, via_gather)))
 
     def forward(i):
         ex = batches[i % len(batches)]
@@ -383,13 +402,15 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "softmax")
         return out
 
-    lanes = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+    lanes = [torch.cuda.Stream() for _ in range(nlanes)]
     fbufs = [None] * len(lanes)
-    # Candidate-/session-sharded CARS over RCCL.  Preferred: FUSED graphs -- KSTEP whole steps (kernels AND both collectives) captured into one
-    # hipGraph as KSTEP parallel branches, replayed back to back on one stream: one host call per KSTEP steps, and the collectives of all ranks
-    # run in capture order on the process group's communication stream (identical on every rank; only one such graph is in flight per
-    # communicator).  Fallback: STAGED -- two hipGraphs per step around eager collectives (host-bound at ~0.07 ms/step).  Last: eager.
-    fused_ok = plan is not None and env.backend == "nccl" and not args.no_graph and not os.environ.get("BENCH_NO_COLL_CAPTURE")
+    # Candidate-/session-sharded CARS over RCCL.  Default: PIPELINED -- per lane and step ONE hipGraph replay ( tail of the lane's previous
+    # step ; encode of this step ) and ONE eager all_to_all_single that carries this step's pooled candidate slices out and the previous
+    # step's click probabilities to everybody (sharding.SessionShardPipeline): 2 host calls per step, collectives of all lanes in issue
+    # order on the process group's communication stream (identical on every rank).  Opt-in (BENCH_FUSED_GRAPH=1): FUSED graphs -- KSTEP
+    # whole steps, kernels and collectives, captured into one hipGraph as parallel branches (measured slower: the runtime runs the branches
+    # of one graph with far less overlap than separate streams get).  Fallback: eager.
+    fused_ok = plan is not None and env.backend == "nccl" and not args.no_graph and bool(os.environ.get("BENCH_FUSED_GRAPH"))
     staged = plan is not None and env.backend == "nccl" and not args.no_graph
     KSTEP = max(1, int(os.environ.get("BENCH_KSTEP", "8")))
     def finish(s):
@@ -447,12 +468,26 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 torch.cuda.synchronize()
                 time.sleep(0.3)
                 g, outs = torch.cuda.CUDAGraph(), []
+                exs = [batches[(first + j) % len(batches)] for j in range(n)]
                 with torch.cuda.graph(g, stream=lanes[0], capture_error_mode=CAPTURE_MODE):
                     main = torch.cuda.current_stream()
+                    # captured PHASE by phase, not step by step: the process group runs its collectives in issue order on ONE
+                    # communication stream, so "exchange_1 after gather_0" would chain the branches end to end (measured: 8 branches took
+                    # 8 x the one-in-flight latency).  Issue order on that stream here: exchange_0 .. exchange_n-1, gather_0 .. gather_n-1.
+                    enc, rcv, prb = [None] * n, [None] * n, [None] * n
                     for j in range(n):
                         branches[j].wait_stream(main)
                         with torch.cuda.stream(branches[j]):
-                            outs.append(sharded_cars_step(batches[(first + j) % len(batches)], keys[j], via_gather=True))
+                            enc[j] = cars_encode(exs[j])
+                    for j in range(n):
+                        with torch.cuda.stream(branches[j]):
+                            rcv[j] = cars_exchange(keys[j], enc[j][1], True)
+                    for j in range(n):
+                        with torch.cuda.stream(branches[j]):
+                            prb[j] = cars_tail(exs[j], keys[j], enc[j][0], rcv[j])
+                    for j in range(n):
+                        with torch.cuda.stream(branches[j]):
+                            outs.append(cars_gather(keys[j], prb[j]))
                     for j in range(n):
                         main.wait_stream(branches[j])
                 return g, outs
@@ -468,23 +503,40 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             L.nir_set_batches_in_flight(len(lanes))
     if staged:
         try:
-            stages = []
-            for i in range(len(batches)):
-                ex, ln = batches[i], lanes[lane_of(i)]
-                recv, probs_own, allp = cars_bufs(("staged", i))
-                with torch.cuda.stream(ln):                     # warm (packs, workspaces), then capture both halves
-                    sharded_cars_step(ex, ("staged", i))
-                torch.cuda.synchronize()
-                time.sleep(0.3)
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=ln, capture_error_mode=CAPTURE_MODE):
-                    pq, pl = model.shard_encode(ex["_q_own"], ex["_ql_own"], ex["_doc_shard"], ex["_len_shard"])
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, stream=ln, capture_error_mode=CAPTURE_MODE):
-                    model.shard_tail(pq, recv, ex["_lab_own"], ex["document_labels"], ncand, probs_own)
-                stages.append((ga, pl, recv.view(pl.shape), gb, probs_own, allp[:plan.bper] if emu else allp, allp[:c["batch"]]))
+            nl, nb = len(lanes), len(batches)
+            pipes = [sharding.SessionShardPipeline(plan, 256, dev) for _ in lanes]
+            pq_buf = [torch.zeros(plan.bper, plan.S, 256, device=dev) for _ in batches]      # pooled queries of a step, kept for its tail
+
+            def segment(b, do_tail, do_encode):
+                """compute segment of batch b on its lane: tail of the lane's PREVIOUS batch (its pooled documents arrived with the last
+                exchange), then encode of b."""
+                pp, pb = pipes[b % nl], (b - nl) % nb
+                if do_tail:
+                    pp.put_probs(model.shard_tail(pq_buf[pb], pp.got_pooled(), batches[pb]["_lab_own"], batches[pb]["document_labels"], ncand))
+                if do_encode:
+                    pq, pl = cars_encode(batches[b])
+                    pq_buf[b].copy_(pq)
+                    pp.put_pooled(pl)
+
+            def exchange(ln):       # (emulated world: the 1-rank group copies the whole buffer -- the bytes a real exchange moves)
+                env.dist.all_to_all_single(pipes[ln].recv, pipes[ln].send)
+
+            for b in range(nb):                                 # warm: packs, workspaces, communicator
+                with torch.cuda.stream(lanes[b % nl]):
+                    segment(b, True, True)
+                    exchange(b % nl)
+            torch.cuda.synchronize()
+            time.sleep(0.3)
+            seg_graphs = {}
+            for b in range(nb):     # "full" = steady state; "first" = encode only (pipeline start); "flush" = tail only (delivers the last step)
+                for kind, (dt, de) in (("full", (True, True)), ("first", (False, True)), ("flush", (True, False))):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=lanes[b % nl], capture_error_mode=CAPTURE_MODE):
+                        segment(b, dt, de)
+                    seg_graphs[(b, kind)] = g
+            stages = {"graphs": seg_graphs, "exchange": exchange, "pipes": pipes, "pos": 0, "nl": nl, "nb": nb}
         except Exception as e:  # pragma: no cover - falls back to the eager sharded step
-            print("[bench] staged graph capture unavailable for %s (%s); eager sharded steps" % (name, e), file=sys.stderr)
+            print("[bench] pipelined graph capture unavailable for %s (%s: %s); eager sharded steps" % (name, type(e).__name__, e), file=sys.stderr)
             stages = None
             torch.cuda.synchronize()
     # the sharded CARS step contains a collective (all-gather of the pooled documents) between its kernels: staged graphs above, else eager
@@ -504,14 +556,6 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
 
     def run(i, only_lane=None):
         ln = lane_of(i) if only_lane is None else only_lane
-        if stages is not None:
-            ga, pl, rdst, gb, probs_own, adst, out = stages[i % len(stages)]
-            with torch.cuda.stream(lanes[ln]):
-                ga.replay()
-                env.dist.all_to_all_single(rdst, pl)
-                gb.replay()
-                env.dist.all_gather_into_tensor(adst, probs_own)
-            return out
         with torch.cuda.stream(lanes[ln]):
             if graphs is not None:
                 g, out = graphs[i % len(graphs)]
@@ -521,7 +565,26 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             return finish(out)
 
     def run_steps(n):
-        """exactly n steps: fused groups of KSTEP (+ one remainder group) on one stream, else one replay / eager call per step."""
+        """exactly n steps: pipelined segments (sharded CARS), fused groups of KSTEP (+ one remainder group) on one stream, else one
+        replay / eager call per step."""
+        if stages is not None:
+            # n encodes + n tails: every lane starts with an encode-only segment, runs full segments, and ends with a tail-only segment +
+            # exchange that delivers the probabilities of its last step (the results of step k arrive with the exchange of step k + lanes)
+            nl, nb, G = stages["nl"], stages["nb"], stages["graphs"]
+            start, last = stages["pos"], {}
+            for i in range(start, start + n):
+                b = i % nb
+                ln = b % nl
+                with torch.cuda.stream(lanes[ln]):
+                    G[(b, "full" if ln in last else "first")].replay()
+                    stages["exchange"](ln)
+                last[ln] = b
+            for ln, b in last.items():
+                with torch.cuda.stream(lanes[ln]):
+                    G[((b + nl) % nb, "flush")].replay()
+                    stages["exchange"](ln)
+            stages["pos"] = start + n
+            return
         if fused is None:
             for i in range(n):
                 run(i)
@@ -567,7 +630,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         torch.cuda.synchronize()
         env.barrier()
         ts = time.perf_counter()
-        if fused is not None:          # (fused graphs: the same KSTEP-wide groups; "one in flight" has no separate meaning there)
+        if fused is not None or stages is not None:   # (fused / pipelined steps: "one in flight" has no separate meaning there)
             run_steps(ns)
         else:
             for i in range(ns):
@@ -580,7 +643,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     # probabilities), sustained over >= 5 s regardless of --steps.  CARS: graph_runner.StreamingSessionPredictor (int32 wire format,
     # 2 staging slots per lane, producer thread); rankers: GraphedPredictor fed from packed pinned batches.
     h2d_value, h2d_info = None, None
-    if with_h2d and world == 1 and not env.multi:
+    if with_h2d and world == 1 and not env.multi and not os.environ.get("BENCH_NO_H2D"):
         try:
             secs = float(os.environ.get("BENCH_H2D_SECONDS", "5"))
             if c["model"] == "cars":
@@ -696,7 +759,9 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             par = "strong: candidate-sharded encode x%d -> %s %s (%d B out per rank and step) -> session-sharded tail -> all-gather of probabilities; %s" % (
                 wsh, "RCCL" if env.backend == "nccl" else env.backend, "all-gather exchange" if fused is not None else "all-to-all",
                 plan.world * plan.bper * plan.S * plan.per * 256 * 4 if fused is not None else plan.exchange_bytes(256),
-                ("%d steps + collectives per hipGraph" % KSTEP) if fused is not None else ("2 hipGraphs per step around eager collectives" if stages is not None else "eager"))
+                ("%d steps + collectives per hipGraph" % KSTEP) if fused is not None else
+                ("software-pipelined: one hipGraph replay + ONE collective per step (probabilities of step k-1 ride with the slices of step k), %d lanes" % len(lanes)
+                 if stages is not None else "eager"))
             if emu:
                 par += " [EMULATED on one GPU: rank 0's 1/%d share of the work, loop-back collectives, no xGMI latency]" % wsh
         elif is_sess:

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void esm16_kernel(const int64_t* q_ids, const 
 
 struct DrmmW {
     const float *gate_w, *gate_b, *f0w, *f0b, *f1w, *f1b, *ow, *ob;
+    int snap_one;         // opt-in: |cos - 1| <= 4 ulp counts as exactly 1 (SURVEY.md Appendix E1 iii)
 };
 
 // One workgroup (4 waves = 16 row groups of 16 lanes) per (query, candidate) pair.
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256) void drmm_kernel(const int64_t* __restrict__ q
                     if (c < nch) d += dot4(v[r][u], *reinterpret_cast<const float4*>(qn + i * E + 4 * c));
                 }
                 d = row16_sum(d) * inv;
+                if (w.snap_one && fabsf(d - 1.0f) <= 4.8e-7f) d = 1.0f;      // 4 ulp above / 8 ulp below 1: an exact token match
                 // numpy.histogram(bins=[-1,-.5,0,.5,1,1]): [-1,-.5) [-.5,0) [0,.5) [.5,1) {1}; outside -> dropped
                 int bin = -1;
                 if (d >= -1.0f && d <= 1.0f) bin = d < -0.5f ? 0 : d < 0.0f ? 1 : d < 0.5f ? 2 : d < 1.0f ? 3 : 4;
@@ -318,7 +320,7 @@ extern "C" int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     NIR_REQUIRE(E % 4 == 0 && E > 0 && E <= 256 * MAXCH, "drmm: emsize %d unsupported", E);
     NIR_REQUIRE(((uintptr_t)table & 15) == 0 && ((uintptr_t)w->gate_w & 15) == 0, "drmm: table/gate weight must be 16-byte aligned");
     if (B == 0) return 0;
-    DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b};
+    DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b, w->snap_one};
     size_t lds = (size_t)QL * E * 4 + QL * 4 + QL * 5 * 4;
     NIR_REQUIRE(lds <= 160 * 1024 - 512, "drmm: query length %d x emsize %d needs %zu bytes of LDS (> 160 KiB)", QL, E, lds);
     const bool small = QL * 5 <= 32, narrow = E <= 320, longq = QL > 25;

@@ -64,7 +64,7 @@ struct LstmPtArgs {
     const int64_t* lens;    // [M] or NULL
     const float* whh;       // [ND,4H,H]  (state-dict layout, fp32)
     float* out;             // [M,T,ND*H] fp32
-    int* err;               // device flag (may be NULL): set to 1 when an id falls outside [0,V)
+    int* err;               // device flag (may be NULL): bit 0 = an id fell outside [0,V); bit 1 = |w_hh| outside the fp16 (split) range
     int64_t M, V;
     int T, H, ND;
     int out_f16;            // bf16-table kernels only: `out` is [M,T,ND*H] fp16
@@ -253,6 +253,7 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
     f16x8 wreg[NT][KB];
     float creg[NT];
     int unit_d[NT];
+    bool wbad = false;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tile = NT * wave + t;
@@ -273,6 +274,8 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
                 wreg[t][kb][2] = (_Float16)(a.z * m); wreg[t][kb][3] = (_Float16)(a.w * m);
                 wreg[t][kb][4] = (_Float16)(b.x * m); wreg[t][kb][5] = (_Float16)(b.y * m);
                 wreg[t][kb][6] = (_Float16)(b.z * m); wreg[t][kb][7] = (_Float16)(b.w * m);
+                wbad |= !(fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                                fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))) * m < 65504.0f);
             }
         } else {
 #pragma unroll
@@ -280,11 +283,14 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = 32 * kb + 8 * kq + j;
-                    wreg[t][kb][j] = (_Float16)(wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f));
+                    const float w = wr[k < H ? k : H - 1] * ((av && k < H) ? 1.f : 0.f);
+                    wreg[t][kb][j] = (_Float16)w;
+                    wbad |= !(fabsf(w) < 65504.0f);
                 }
         }
         unit_d[t] = 4 * tile + kq;
     }
+    if (wbad && p.err) atomicOr(p.err, 2);          // |w_hh| outside fp16's range (or NaN): flagged, never silently wrong
     // persistent over sequence tiles: W_hh is fetched and converted once per workgroup, not once per 16 sequences (the launcher sizes the
     // grid to the CU count when the tiles outnumber it)
     for (int64_t mt = blockIdx.x; mt * SEQ < p.M; mt += gridDim.x) {
@@ -483,6 +489,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     f16x8 w1[NT][KB], w2[NT][KB];
     float creg[NT];
     int unit_d[NT];
+    bool wbad = false;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tile = NT * wave + t;
@@ -522,10 +529,12 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
                 const _Float16 a = (_Float16)w;
                 w1[t][kb][j] = a;
                 w2[t][kb][j] = (_Float16)((w - (float)a) * SC);
+                wbad |= !(fabsf(w) < 32768.0f);             // outside the fp16 split's range (or NaN): flagged, never silently wrong
             }
         unit_d[t] = 4 * tile + kq;
         creg[t] = 0.f;
     }
+    if (wbad && p.err) atomicOr(p.err, 2);
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
                                                                              (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
     const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;

@@ -22,7 +22,7 @@ def _struct(name, float_fields, int_fields=()):
 
 
 DrmmWeights = _struct("nir_drmm_weights",
-                      ["gate_w", "gate_b", "ffnn0_w", "ffnn0_b", "ffnn1_w", "ffnn1_b", "out_w", "out_b"])
+                      ["gate_w", "gate_b", "ffnn0_w", "ffnn0_b", "ffnn1_w", "ffnn1_b", "out_w", "out_b"], ["snap_one"])
 MatchTensorWeights = _struct(
     "nir_matchtensor_weights",
     ["proj_w", "proj_b", "q_wih", "q_whh", "q_bih", "q_bhh", "d_wih", "d_whh", "d_bih", "d_bhh",
@@ -331,8 +331,12 @@ class IdCheck(object):
         """Synchronising: raise IndexError if any forward since the last check saw an id outside the vocabulary."""
         for name in ("_id_flag", "_err_flag"):
             flag = getattr(self, name, None)
-            if flag is not None and int(flag.item()) != 0:
+            v = int(flag.item()) if flag is not None else 0
+            if v != 0:
                 flag.zero_()
+                if v & 2:
+                    raise RuntimeError("recurrent weights outside the fp16 range of the folded MFMA recurrence (|w_hh| >= 2^15); "
+                                       "results of that forward are invalid -- the exact fp32 recurrence handles such weights")
                 raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
 
 

@@ -139,6 +139,9 @@ class CARS(nn.Module, lib.IdCheck):
                             dict(wih=wih, whh=whh, bih=bih, bhh=bhh, attn0_w=attn[0].weight, attn0_b=attn[0].bias,
                                  attn3_w=attn[3].weight, attn3_b=attn[3].bias),
                             dict(H=enc.hidden, bounded=int(bounded)))
+            # the folded recurrences run W_hh on the fp16 matrix cores (two-term split / single term): outside that range the encoder
+            # takes the per-batch fp32 path (one check per weight version)
+            pk.rec_ok = float(whh.detach().abs().max()) < 32768.0
             if bounded and 2 * enc.hidden == 256 and self.fuse_attention_pooling and attn[0].weight.is_cuda:
                 # operand of the fused attention-pooling kernel (csrc/cars_attn.hip): attn0_w as two fp16 term planes in MFMA-fragment
                 # order [K/32][16 column tiles][2 terms][64 lanes][8], built once per weight version
@@ -247,7 +250,7 @@ class CARS(nn.Module, lib.IdCheck):
         dev = ids.device
         pooled = torch.empty(M, H2, device=dev, dtype=torch.float32)
         encoded = torch.empty(M, T, H2, device=dev, dtype=torch.float32) if want_encoded else None
-        if self._use_fold(table, w.struct.H):
+        if self._use_fold(table, w.struct.H) and w.rec_ok:
             folded = self._folded_table(which, w)
             if self._err_flag is None or self._err_flag.device != dev:
                 self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -38,14 +38,22 @@ class DRMM(nn.Module, lib.IdCheck):
         self.ffnn = nn.Sequential(nn.Linear(self.nbins, 1), nn.Linear(1, 1))
         self.output = nn.Linear(1, 1)
         self._pack = lib.PackCache()
+        # Exact token matches (cos = 1 +- a few ulp): "numpy" (default) bins the rounded value literally like the reference's host
+        # numpy.histogram -- {1}, [.5,1) or dropped (> 1), depending on the reduction order (the reference itself is
+        # not reproducible there).  "snap" is an opt-in, intentional deviation: |cos - 1| <= 4 ulp counts as 1, so every exact match
+        # lands in the {1} bin on every device.
+        self.exact_match_policy = getattr(args, "drmm_exact_match_policy", "numpy")
 
     def _weights(self):
+        if self.exact_match_policy not in ("numpy", "snap"):
+            raise ValueError("exact_match_policy must be 'numpy' or 'snap'")
+
         def build():
             return lib.Packed(lib.DrmmWeights, dict(
                 gate_w=self.gating_network.weight.weight, gate_b=self.gating_network.weight.bias,
                 ffnn0_w=self.ffnn[0].weight, ffnn0_b=self.ffnn[0].bias, ffnn1_w=self.ffnn[1].weight,
-                ffnn1_b=self.ffnn[1].bias, out_w=self.output.weight, out_b=self.output.bias))
-        params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
+                ffnn1_b=self.ffnn[1].bias, out_w=self.output.weight, out_b=self.output.bias), dict(snap_one=int(self.exact_match_policy == "snap")))
+        params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")] + [self.exact_match_policy]
         return self._pack.get(params, build)
 
     def _hist(self, q, d, table):

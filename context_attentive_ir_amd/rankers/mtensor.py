@@ -112,7 +112,10 @@ class MatchTensor(nn.Module, lib.IdCheck):
                      conv1_w=self.conv1.weight, conv1_b=self.conv1.bias, conv2_w=self.conv2.weight,
                      conv2_b=self.conv2.bias, conv3_w=self.conv3.weight, conv3_b=self.conv3.bias,
                      conv_w=self.conv.weight, conv_b=self.conv.bias, out_w=self.output.weight, out_b=self.output.bias)
-            return attach_projection_fragments(lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self)))))
+            pk = attach_projection_fragments(lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self)))))
+            # W_hh of the folded recurrences goes onto the fp16 matrix cores as a two-term split: needs |w| < 2^15 (else: unfolded fp32 path)
+            pk.rec_ok = max(float(q[1].detach().abs().max()), float(d[1].detach().abs().max())) < 32768.0
+            return pk
         params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")]
         return self._pack.get(params, build)
 
@@ -159,7 +162,7 @@ class MatchTensor(nn.Module, lib.IdCheck):
         table = self.word_embeddings.table
         lib.require_device(batch_queries, batch_docs, query_len, doc_len, table)
         L = lib.load()
-        fold = self.fold_embeddings and self._dims["Hq"] >= 4 and self._dims["Hd"] >= 4
+        fold = self.fold_embeddings and self._dims["Hq"] >= 4 and self._dims["Hd"] >= 4 and self._weights().rec_ok
         if fold:      # the folded recurrences validate ids in-kernel
             q, d = lib.ids64(batch_queries), lib.ids64(batch_docs)
         else:

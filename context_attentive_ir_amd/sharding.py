@@ -248,3 +248,73 @@ def session_sharded_click_probs(plan, encode_q, encode_docs, session_tail, ex, g
     labels = ex["document_labels"]
     probs = session_tail(pq, docs, plan.own(labels), labels)
     return plan.gather(probs, group)
+
+
+class SessionShardPipeline(object):
+    """ONE collective per step for the session-sharded CARS step, software-pipelined over the steps of a lane (HIP stream).
+
+    The two exchanges of SessionShardPlan -- pooled candidate slices out (all-to-all), click probabilities back (all-gather) -- ride in
+    the SAME all_to_all_single: chunk r of the send buffer = [ my candidate slice of rank r's sessions, step k | my click probabilities,
+    step k-1 ] (the probabilities are KBs and simply replicated into every chunk), so after the exchange a rank holds the N pooled vectors
+    of its sessions for step k AND everybody's probabilities of step k-1.  Per step and lane the host then issues one compute segment
+    ( tail of step k-1 ; encode of step k  -- one hipGraph replay on a GPU ) and one collective, instead of two graphs and two collectives;
+    collectives of all lanes run on the process group's communication stream in issue order, identical on every rank.
+    Results lag one step: `flush()` after the last step delivers its probabilities."""
+
+    def __init__(self, plan, D, device, dtype=torch.float32):
+        self.plan, self.D = plan, int(D)
+        G, bper, S, per, N = plan.world, plan.bper, plan.S, plan.per, plan.N
+        self.n_pool, self.n_prob = bper * S * per * self.D, bper * S * N
+        self.send = torch.zeros(G, self.n_pool + self.n_prob, device=device, dtype=dtype)
+        self.recv = torch.zeros_like(self.send)
+
+    # -- compute-side views (written / read inside the captured segment) ----------------------------------------------------------------
+    def put_pooled(self, pooled_shard):
+        """pooled_shard [G*bper,S,per,D] (chunk r = the sessions of rank r) -> the pooled section of the send buffer."""
+        self.send[:, :self.n_pool].copy_(pooled_shard.reshape(self.plan.world, self.n_pool))
+
+    def put_probs(self, probs_own):
+        """probs_own [bper,S,N] -> replicated into the probability section of every chunk."""
+        self.send[:, self.n_pool:].copy_(probs_own.reshape(1, self.n_prob).expand(self.plan.world, self.n_prob))
+
+    def got_pooled(self):
+        """-> [G,bper,S,per,D]: rank r's candidate slice of MY sessions (strided view of the receive buffer)."""
+        p = self.plan
+        return self.recv[:, :self.n_pool].view(p.world, p.bper, p.S, p.per, self.D)
+
+    def got_probs(self):
+        """-> [B,S,N]: the click probabilities of the PREVIOUS step, every session (rank-major = session order)."""
+        p = self.plan
+        return self.recv[:, self.n_pool:].reshape(p.world * p.bper, p.S, p.N)[:p.B]
+
+    # -- the one collective ------------------------------------------------------------------------------------------------------------
+    def exchange(self, group=None):
+        if self.plan.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            self.recv.copy_(self.send)
+        else:
+            dist.all_to_all_single(self.recv, self.send, group=group)
+
+
+def pipelined_session_sharded_probs(plan, encode_q, encode_docs, session_tail, batches, group=None, D=None):
+    """Reference driver of SessionShardPipeline over a list of batches (one lane): -> list of [B,S,N] probabilities, one per batch.
+    Same callables as session_sharded_click_probs (HIP entry points on a GPU; the CPU oracle in the gloo tests)."""
+    pipe, prev, out = None, None, []
+    for ex in list(batches) + [None]:
+        cur = None
+        if ex is not None:
+            pq = encode_q(plan.own(ex["source_words"]), plan.own(ex["source_lens"]))
+            d, l = plan.doc_shard(ex["document_words"], ex["document_lens"])
+            pooled = encode_docs(d, l)
+            if pipe is None:
+                pipe = SessionShardPipeline(plan, pooled.shape[-1] if D is None else D, pooled.device, pooled.dtype)
+            cur = (pq, ex["document_labels"])
+        if prev is not None:                                 # tail of the previous step: its pooled documents arrived with the last exchange
+            docs = plan.assemble(pipe.got_pooled())
+            pipe.put_probs(session_tail(prev[0], docs, plan.own(prev[1]), prev[1]))
+        if ex is not None:
+            pipe.put_pooled(pooled)
+        pipe.exchange(group)
+        if prev is not None:
+            out.append(pipe.got_probs().clone())
+        prev = cur
+    return out

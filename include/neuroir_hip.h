@@ -163,6 +163,10 @@ typedef struct {
     const float* ffnn1_b; /* ffnn.1.bias   [1]   */
     const float* out_w;   /* output.weight [1,1] */
     const float* out_b;   /* output.bias   [1]   */
+    int snap_one;         /* 0 (default): numpy.histogram taken literally -- a cosine of 1 +- a few ulp (an exact token match) lands in {1},
+                             in [.5,1) or is dropped (> 1), depending on rounding, exactly as in the reference.
+                             1 (opt-in, an INTENTIONAL deviation): |cos - 1| <= 4 ulp counts as 1 -> every exact match lands in {1},
+                             independent of the reduction order (deterministic across devices) */
 } nir_drmm_weights;
 /* hist_out (optional, may be NULL): [B*N, QL, 5] matching-histogram counts as float. */
 int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
@@ -284,8 +288,9 @@ int nir_lstm_fold_table(const float* table, int64_t V, int E, const float* w_ih,
  * t >= length.  dtype F32: fp32-accurate recurrence (two-term fp16 split on v_mfma_f32_16x16x32_f16 for H >= 32, exact
  * v_mfma_f32_16x16x4_f32 below / with the exact_f32 tunable; the parity path).  dtype BF16: bf16 folded table, W_hh and h_t as
  * single fp16 MFMA operands (v_mfma_f32_16x16x32_f16: 11 mantissa bits), fp32 accumulation, gate math and cell state.  Both
- * MFMA paths need |w_hh| < 65504 (fp16 range).  An id outside [0,V) is read as id 0 and sets *err_flag (device int, may be
- * NULL) to 1 -- the reference's nn.Embedding raises IndexError. */
+ * MFMA paths need |w_hh| in fp16's range (two-term split: < 2^15; single term: < 65504): the kernels check while they convert W_hh and
+ * set bit 1 of *err_flag otherwise (the host mirrors check at pack time and route such weights to the exact fp32 recurrence).  An id
+ * outside [0,V) is read as id 0 and sets bit 0 of *err_flag (device int, may be NULL) -- the reference's nn.Embedding raises IndexError. */
 int nir_bilstm_folded_fwd(const void* folded, int dtype, const int64_t* ids, const int64_t* lengths, const float* w_hh,
                           float* out, int* err_flag, int64_t M, int64_t V, int T, int H, int ndir, nir_stream_t stream);
 /* CARS.encode / encode_document (cars.py:193-260) over a folded table: same outputs as nir_cars_encode.  With a bf16 table,

@@ -1,0 +1,201 @@
+"""GPU (-m gpu): parity away from the default-init operating point (VERDICT r2 "what's weak" 3-4):
+* trained-scale weights (every non-embedding parameter x8 and x1/64) for MATCH_TENSOR / DUET / CARS against the oracle;
+* the range-safe fallbacks FORCED (bounded = 0: bf16x3 GEMMs, fp32 head, unfused attention; |w_hh| beyond the fp16 split: unfolded fp32
+  recurrence) against the oracle;
+* bf16 (config 5) against the ORACLE at B = 16, with MAP equality on every row the oracle separates by more than the bf16 bound."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, cpu_state_dict
+from oracle import neuroir_cpu as O
+from test_gpu_parity import _synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel_close(got, ref, tol=1e-4):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, "max abs diff %.3g > %.3g (score scale %.3g)" % (err, tol * scale, scale)
+
+
+def _scale_(m, factor):
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "emb_luts" not in n:
+                p.mul_(factor)             # in place: bumps ._version, the PackCaches re-pack
+    return m
+
+
+@pytest.mark.parametrize("factor", [8.0, 1.0 / 64])
+@pytest.mark.parametrize("kind", ["MATCH_TENSOR", "DUET"])
+def test_rankers_trained_scale_weights(kind, factor):
+    V, B, N, QL, DL = 600, 3, 4, 5, 40
+    kw = dict(max_query_len=QL, max_doc_len=DL) if kind == "DUET" else {}
+    m = _scale_(build_model(kind, vocab=V, device=DEV, **kw), factor)
+    q, ql, d, dl = _synth(np.random.default_rng(7), B, N, QL, DL, V)
+    d[0, 0, :3] = q[0, :3]                                   # exact matches: the exact-match channel / local model see them
+    s = m(q.to(DEV), ql.to(DEV), d.to(DEV), dl.to(DEV))
+    _rel_close(s, O.MODEL_FNS[kind](cpu_state_dict(m), q, ql, d, dl))
+
+
+@pytest.mark.parametrize("factor", [8.0, 1.0 / 64])
+def test_cars_trained_scale_weights(factor):
+    from context_attentive_ir_amd import synth
+    V = 2000
+    m = _scale_(build_model("CARS", vocab=V, tgt_vocab_size=300, device=DEV), factor)
+    ex = synth.session_batch(3, 4, 6, 4, 20, V, seed=3, full_length=False, multi_click=True)
+    sd = cpu_state_dict(m)
+    ref = O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])
+    dex = {k: v.to(DEV) for k, v in ex.items()}
+    pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
+    s = m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"], want_states=False)[0]
+    _rel_close(s, ref)
+    _rel_close(torch.softmax(s, -1), torch.softmax(ref, -1))
+
+
+def test_match_tensor_unbounded_head_fallback(monkeypatch):
+    """bounded = 0 (the host cannot vouch for |U|, |Pd| < 2^15): fp32-MFMA interaction GEMM + separate channel projection."""
+    from context_attentive_ir_amd.rankers import mtensor as MT
+    V, B, N, QL, DL = 400, 2, 3, 6, 33
+    m = build_model("MATCH_TENSOR", vocab=V, device=DEV)
+    q, ql, d, dl = _synth(np.random.default_rng(11), B, N, QL, DL, V)
+    args = [t.to(DEV) for t in (q, ql, d, dl)]
+    s_fast = m(*args)
+    assert m._weights().struct.bounded == 1
+    monkeypatch.setattr(MT, "interaction_bounded", lambda mod: False)
+    m._pack.invalidate()
+    s_safe = m(*args)
+    assert m._weights().struct.bounded == 0 and not m._weights().struct.dproj_frag
+    ref = O.match_tensor_scores(cpu_state_dict(m), q, ql, d, dl)
+    _rel_close(s_safe, ref); _rel_close(s_fast, ref)
+
+
+def test_duet_unbounded_weights_take_the_range_safe_gemms():
+    """One conv weight beyond 2^15: no fp16 two-term split anywhere (bf16x3 GEMMs, layer chain instead of the fused document kernel)."""
+    V, B, N, QL, DL = 500, 2, 3, 4, 40
+    m = build_model("DUET", vocab=V, device=DEV, max_query_len=QL, max_doc_len=DL)
+    with torch.no_grad():
+        m.distributed_model.conv_q.weight[0, 0, 0] = 4.0e4
+    q, ql, d, dl = _synth(np.random.default_rng(13), B, N, QL, DL, V)
+    s = m(q.to(DEV), ql.to(DEV), d.to(DEV), dl.to(DEV))
+    w = m._weights()
+    assert w.struct.bounded == 0 and not w.struct.fw1
+    _rel_close(s, O.duet_scores(cpu_state_dict(m), q, ql, d, dl))
+
+
+def test_cars_unbounded_attention_and_recurrent_weights():
+    """(a) an attention weight beyond 2^15: GEMM (bf16x3) + pooling chain instead of the fused fp16-split kernel; (b) a recurrent weight
+    beyond the fp16 split's range: the encoder leaves the folded MFMA recurrence for the per-batch fp32 path -- both against the oracle;
+    (c) the C-ABI recurrence called directly with such weights raises the device flag instead of returning garbage silently."""
+    from context_attentive_ir_amd import lib, synth
+    V = 1500
+    ex = synth.session_batch(2, 3, 5, 4, 16, V, seed=8, full_length=False)
+    dex = {k: v.to(DEV) for k, v in ex.items()}
+
+    def run(m):
+        pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
+        return m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"], want_states=False)[0]
+
+    def ref(m):
+        return O.cars_scores(cpu_state_dict(m), ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"],
+                             ex["document_labels"])
+    m = build_model("CARS", vocab=V, tgt_vocab_size=300, device=DEV)
+    with torch.no_grad():
+        m.d_attn[0].weight[3, 5] = 4.0e4                      # tanh saturates for that unit; still a valid model
+    s = run(m)
+    assert m._enc_weights("d").struct.bounded == 0 and not m._enc_weights("d").struct.attn_frag
+    _rel_close(s, ref(m))
+    m = build_model("CARS", vocab=V, tgt_vocab_size=300, device=DEV)
+    with torch.no_grad():
+        m.document_encoder.encoder.rnns[0].weight_hh_l0[7, 9] = 5.0e4
+    s = run(m)
+    assert m._enc_weights("d").rec_ok is False and m._enc_weights("q").rec_ok is True
+    _rel_close(s, ref(m))
+    m.check_ids()                                             # nothing flagged: the folded kernel never saw those weights
+    # (c) direct C-ABI call
+    from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
+    wih, whh, bih, bhh = [t.detach().contiguous() for t in lstm_cat_weights(m.document_encoder.encoder.rnns[0])]
+    table = m.embedder.word_embeddings.table.detach()
+    folded = lib.fold_lstm_table(table, wih, bih, bhh, 128, 2, "f32")
+    ids = dex["document_words"].reshape(-1, 16).contiguous(); lens = dex["document_lens"].reshape(-1).contiguous()
+    out = torch.empty(ids.shape[0], 16, 256, device=DEV); flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib.check(lib.load().nir_bilstm_folded_fwd(lib.ptr(folded), lib.DTYPE_F32, lib.ptr(ids), lib.ptr(lens), lib.ptr(whh), lib.ptr(out),
+                                                lib.ptr(flag), ids.shape[0], V, 16, 128, 2, lib.stream()), "folded")
+    assert int(flag.item()) & 2
+
+
+def test_cars_bf16_vs_oracle_batch16_map_on_separated_rows():
+    """bf16 folded tables against the ORACLE (not the fp32 HIP path) at B = 16: |score diff| within the bf16 bound, and on every
+    (session, step) row whose oracle scores are separated by more than twice that bound the ranking -- hence AP -- is IDENTICAL; the
+    +-0.02 MAP allowance only covers the remaining (near-tie) rows."""
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.eval import ltorank
+    TOL = 6e-2
+    V, B, S, N, QL, DL = 3000, 16, 3, 10, 4, 32
+    m = build_model("CARS", vocab=V, device=DEV)
+    m.compute_dtype = "bf16"
+    ex = synth.session_batch(B, S, N, QL, DL, V, seed=21, full_length=False)
+    ref = O.cars_scores(cpu_state_dict(m), ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])
+    dex = {k: v.to(DEV) for k, v in ex.items()}
+    pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
+    s = m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"], want_states=False)[0].cpu()
+    assert float((s - ref).abs().max()) <= TOL
+    lab = ex["document_labels"].reshape(-1, N).numpy()
+    r_ref, r_got = ref.reshape(-1, N).numpy(), s.reshape(-1, N).numpy()
+    safe = np.diff(np.sort(r_ref, 1), axis=1).min(1) > 2 * TOL
+    a_ref, a_got = np.argsort(-r_ref, 1, kind="stable"), np.argsort(-r_got, 1, kind="stable")
+    assert (a_ref[safe] == a_got[safe]).all()
+    if safe.any():
+        assert ltorank.MAP(a_ref[safe], lab[safe]) == ltorank.MAP(a_got[safe], lab[safe])
+    if (~safe).any():
+        assert abs(ltorank.MAP(a_ref[~safe], lab[~safe]) - ltorank.MAP(a_got[~safe], lab[~safe])) <= 0.02
+
+
+def test_drmm_exact_match_policies_on_overlapping_zipf_ids():
+    """DRMM on inputs where its exact-match signal EXISTS (Zipf ids: queries and documents share tokens).  Reported for both policies:
+    (query term, pair) histogram rows that differ from the oracle's, and the MAP delta.  Asserted: the three lower bins never differ; a
+    differing row differs in the two top bins only, by at most 2 per exact overlap; 'snap' (opt-in deviation: |cos-1| <= 4 ulp -> {1}) puts
+    EVERY exact match into the {1} bin -- its count there equals the number of exact token overlaps, row by row -- and is reproducible
+    run to run; scores agree with the oracle wherever the histograms do."""
+    import json
+    import os
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.eval import ltorank
+    V, B, N, QL, DL = 100000, 16, 50, 4, 290
+    ex = synth.ranker_batch(B, N, QL, DL, V, seed=1013, full_length=False)
+    q, ql, d, dl, lab = (ex[k] for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label"))
+    m = build_model("DRMM", vocab=V, device=DEV)
+    sd = cpu_state_dict(m)
+    gate, cos, hist_ref = O.drmm_parts(sd, q, d)
+    s_ref = O.drmm_scores_from_hist(sd, gate, hist_ref, B, N)
+    overlaps = ((q[:, None, :, None] == d[:, :, None, :]) & (q[:, None, :, None] != 0)).sum(-1).reshape(B * N, QL).numpy()
+    assert overlaps.sum() > 50                                 # the exact-match signal is really there
+    rep = {"shape": [B, N, QL, DL], "vocab": V, "exact_overlaps": int(overlaps.sum()), "histogram_rows": int(B * N * QL)}
+    hr = hist_ref.numpy()
+    for policy in ("numpy", "snap"):
+        m.exact_match_policy = policy
+        s, h = m(q.to(DEV), ql.to(DEV), d.to(DEV), dl.to(DEV), return_hist=True)
+        s2, h2 = m(q.to(DEV), ql.to(DEV), d.to(DEV), dl.to(DEV), return_hist=True)
+        assert torch.equal(h, h2) and torch.equal(s, s2)
+        h, s = h.cpu().numpy(), s.cpu()
+        np.testing.assert_array_equal(h[..., :3], hr[..., :3])
+        top = np.abs(h[..., 3:] - hr[..., 3:]).sum(-1)
+        assert (top <= 2 * overlaps).all()
+        same = (h == hr).all(axis=(1, 2))
+        np.testing.assert_allclose(s.reshape(-1).numpy()[same], s_ref.reshape(-1).numpy()[same], rtol=0, atol=5e-4)
+        a_ref, a_got = np.argsort(-s_ref.numpy(), 1, kind="stable"), np.argsort(-s.numpy(), 1, kind="stable")
+        rep[policy] = {"rows_differing_from_oracle": int((top > 0).sum()), "pairs_differing": int((~same).sum()),
+                       "MAP_oracle": ltorank.MAP(a_ref, lab.numpy()), "MAP_hip": ltorank.MAP(a_got, lab.numpy())}
+        rep[policy]["MAP_delta"] = rep[policy]["MAP_hip"] - rep[policy]["MAP_oracle"]
+        if policy == "snap":
+            # rows without an exact match: bin {1} holds what the oracle holds; rows with matches: every one of them is in {1}
+            assert (h[..., 4] >= overlaps).all() and ((h[..., 4] == overlaps) | (overlaps == 0)).all()
+        assert abs(rep[policy]["MAP_delta"]) <= 0.03
+    print("DRMM_OVERLAP_REPORT " + json.dumps(rep))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(rep, open(os.path.join(out, "drmm_overlap_r03.json"), "w"), indent=1)

@@ -206,6 +206,16 @@ for B, S, N in ((4, 3, 5), (3, 2, 9), (1, 3, 2), (5, 2, 4)):        # B, N divis
                    plan.own(ex["document_labels"]), None)
         assert not torch.allclose(loc, full[:plan.bper], atol=1e-6)
     assert plan.exchange_bytes(256) == (world - 1) * plan.bper * S * plan.per * 256 * 4
+# the software-pipelined form: ONE all_to_all_single per step carries the pooled slices of step k and the probabilities of step k-1
+B, S, N = 4, 3, 6
+exs = [synth.session_batch(B, S, N, 4, 10, 300, seed=77 + i, full_length=False, multi_click=True) for i in range(3)]
+plan = sharding.SessionShardPlan(B, S, N, world, rank)
+outs = sharding.pipelined_session_sharded_probs(plan, enc_q, enc_d, tail, exs)
+assert len(outs) == 3
+for ex, got in zip(exs, outs):
+    full = O.predict_softmax(O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"],
+                                            ex["document_labels"]))
+    assert got.shape == full.shape and torch.allclose(got, full, atol=1e-6), (rank, float((got - full).abs().max()))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -1,14 +1,14 @@
 #!/bin/bash
 # rocprofv3 evidence for every bench.py configuration (run on the GPU box through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash tools/capture_r02.sh [config ...]'
+#   gpurun --timeout 2400 -- 'bash tools/capture_r03.sh [config ...]'
 # per config: (1) --kernel-trace --stats of the serial eager run (one batch in flight: every launch attributed, not stretched by
 # co-running batches -- the condition bench.py's own HIP-event pass measures under); (2) FETCH_SIZE pass; (3) WRITE_SIZE pass;
 # (4) SQ/MFMA pass.  Counter passes use --kernel-trace only (never combined with sys/hip/hsa trace domains).
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/r02prof
+OUT=$REPO/gpurun_out/r03prof
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp BENCH_NO_H2D=1
 CFGS=${@:-C3_cars C1_esm C2_match_tensor NS_match_tensor_50 C4_duet C4_drmm C4_esm_hbm C5_cars_bf16}
 for c in $CFGS; do
   steps=20; case $c in C4_duet|C5_cars_bf16) steps=6;; esac
@@ -20,5 +20,5 @@ for c in $CFGS; do
   echo "captured $c"
 done
 # keep the merged-back payload small: the per-dispatch traces are condensed on the box
-python $REPO/tools/derive_r02.py $OUT
+python $REPO/tools/derive_profiles.py $OUT
 find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete

@@ -1,7 +1,10 @@
-"""Condense gpurun_out/r02prof (tools/capture_r02.sh) into per-config summaries: <cfg>/kernel_stats.csv (rocprofv3 --stats),
-<cfg>/pmc.json (mean counter per launch per kernel) and traffic.json ((2*FETCH_SIZE + WRITE_SIZE) KiB per launch -- the x2 is the
-gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md section HBM).  usage: python tools/derive_r02.py <dir>; run
-`python tools/derive_r02.py --install <dir>` in the authoring container to copy the summaries into profiles/."""
+"""Condense gpurun_out/r03prof (tools/capture_r03.sh) into per-config summaries: <cfg>/kernel_stats.csv (rocprofv3 --stats),
+<cfg>/pmc.json (mean counter per launch per kernel) and pmc_summary.json: per config and kernel
+  bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB  (the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md section HBM),
+  mfma_busy        = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)   (matrix-pipe busy fraction, chip-wide, while
+                     the kernel runs; GRBM_GUI_ACTIVE is summed over the 8 XCDs).
+usage: python tools/derive_profiles.py <dir>; `python tools/derive_profiles.py --install <dir> [prefix]` in the authoring container copies the
+summaries into profiles/ (prefix default r03)."""
 import csv
 import glob
 import json
@@ -53,24 +56,35 @@ def condense(root):
             if "FETCH_SIZE" in d:
                 t[k] = {"FETCH_SIZE_KB": d["FETCH_SIZE"], "WRITE_SIZE_KB": d.get("WRITE_SIZE", 0.0),
                         "bytes_per_launch": int((2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024)}
+                if d.get("GRBM_GUI_ACTIVE"):
+                    t[k]["mfma_busy"] = round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0), 5)
+                    t[k]["gui_active_cycles_per_xcd"] = round(d["GRBM_GUI_ACTIVE"] / 8.0, 1)
+                    t[k]["SQ_INSTS_MFMA"] = d.get("SQ_INSTS_MFMA")
         traffic[cfg] = t
-    json.dump({"note": "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, mean over the launches of the serial eager bench.py run of each config; "
-                       "separate --pmc passes (tools/capture_r02.sh); kernels launched with several shapes in one step are averaged over all of them",
-               "configs": traffic}, open(os.path.join(root, "traffic.json"), "w"), indent=1, sort_keys=True)
+    json.dump({"note": "bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 * GRBM_GUI_ACTIVE / 8); mean over the "
+                       "launches of the serial eager bench.py run of each config; separate --pmc passes (tools/capture_r03.sh); a kernel launched with "
+                       "several grids in one step is reported for its largest grid",
+               "configs": traffic}, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
 
-def install(root):
+def install(root, prefix="r03"):
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     for cdir in sorted(glob.glob(os.path.join(root, "*", ""))):
         cfg = os.path.basename(os.path.dirname(cdir))
-        for f, name in (("kernel_stats.csv", "r02_%s_kernel_stats.csv"), ("pmc.json", "r02_%s_pmc.json")):
+        for f, name in (("kernel_stats.csv", "%s_%s_kernel_stats.csv"), ("pmc.json", "%s_%s_pmc.json")):
             if os.path.exists(os.path.join(cdir, f)):
-                shutil.copy(os.path.join(cdir, f), os.path.join(dst, name % cfg))
-    shutil.copy(os.path.join(root, "traffic.json"), os.path.join(dst, "traffic.json"))
+                shutil.copy(os.path.join(cdir, f), os.path.join(dst, name % (prefix, cfg)))
+    new = json.load(open(os.path.join(root, "pmc_summary.json")))
+    old_path = os.path.join(dst, "pmc_summary.json")
+    if os.path.exists(old_path):          # a partial re-capture replaces only the configs it holds
+        old = json.load(open(old_path))
+        old["configs"].update(new["configs"])
+        new["configs"] = old["configs"]
+    json.dump(new, open(old_path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "--install":
-        install(sys.argv[2])
+        install(sys.argv[2], *(sys.argv[3:4]))
     else:
         condense(sys.argv[1])
