@@ -144,6 +144,11 @@ def kernel_work(name, c):
     if base == "mt_head_kernel":
         C = 50
         return dict(flops=pairs * QL * DL * 2.0 * (15 * C * 6 + 45 * 6 + 18 * 20), bytes=pairs * DL * (C * 4 + 8.0) + pairs * 4, terms=3, pipe=F16)
+    if base.startswith("wgrad_kernel"):               # dW = dY^T X on the f32 MFMA (csrc/train.hip): M rows reduced, [N, K] output
+        return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K), terms=1, pipe=F32)
+    if base.startswith("lstm_train_fwd_kernel") or base.startswith("lstm_train_bwd_kernel"):
+        # M sequences, N = T steps, K = H units, both directions: the recurrent product h W_hh^T (forward) / W_hh^T dg (BPTT), f32 MFMA
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * 2 * (4 * K + 2 * K) * 4.0, terms=1, pipe=F32)
     if base in ("esm16_kernel", "esm_kernel", "drmm_kernel"):
         fl = flops_per_pair(c["model"], QL, DL) or (2.0 * DL * E if base != "drmm_kernel" else 2.0 * QL * DL * E)
         return dict(flops=fl * pairs, bytes=algorithmic_bytes_per_pair(NC, QL, DL) * pairs, terms=0, pipe=F32)   # VALU kernels: no MFMA
@@ -882,6 +887,9 @@ def main():
         sub["C3_cars_with_decode"] = decode_record(head, args, env)
         torch.cuda.empty_cache()
         sub["C5_stream"] = stream_record(args, env, seconds=float(os.environ.get("BENCH_H2D_SECONDS", "5")))
+        torch.cuda.empty_cache()
+        sub["train_C3_cars_update"] = train_record("CARS", dict(head), args, env)
+        sub["train_C2_match_tensor_update"] = train_record("MATCH_TENSOR", dict(CONFIGS["C2_match_tensor"]), args, env)
     weak = None
     if env.multi:           # labelled secondary number: every rank scores its own full batch, no collective
         r = run_config(hname + "_weak", head, args, env, max(20, args.steps // 4), min(args.warmup, 8), shard=False)
@@ -965,22 +973,118 @@ def stream_record(args, env, seconds=None, n_sessions=223876):
         return {"name": "C5_stream", "error": "%s: %s" % (type(e).__name__, e)}
 
 
+def train_record(kind, c, args, env, steps=12):
+    """Training step throughput: Ranker.update / Multitask.update (models/ranker.py:192-230, models/multitask.py:161-223)
+    = train-mode forward with the reference's default dropouts, loss, backward, clip_grad_norm, Adam -- on the config's batch shape, batches
+    resident in HBM, eager (torch.autograd over the HIP operators of autograd.py).  Dominant kernel from the library profiler."""
+    try:
+        L = lib.load()
+        V = c["vocab"]
+        extra = dict(optimizer="adam", learning_rate=0.001, weight_decay=0, momentum=0, grad_clipping=10.0, fix_embeddings=True)
+        if kind == "CARS":
+            w = Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=30000, **extra))
+        else:
+            w = Ranker(default_args(kind, src_vocab_size=V, **extra))
+        fill_module_(w.network, 1013)
+        w.cuda()
+        w.init_optimizer()
+        batches = make_batches(c, 4, 0, env.dev)
+        if kind == "CARS":                      # teacher-forcing targets: the next query of the session, [BOS w.. EOS] (multitask/vector.py:82-149)
+            for b in batches:
+                src = b["source_words"][:, 1:]                                                     # [B,S-1,QL]
+                B_, S1, QL = src.shape
+                tw = torch.zeros(B_, S1, QL + 2, dtype=torch.int64, device=env.dev)
+                tw[..., 0] = 2
+                tw[..., 1:QL + 1] = src
+                tw[..., QL + 1] = 3
+                b["target_words"], b["target_seq"] = tw, tw % 30000
+                b["target_lens"] = torch.full((B_, S1), QL + 2, dtype=torch.int64, device=env.dev)
+        for i in range(3):
+            w.update(batches[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            w.update(batches[i % 4])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        L.nir_profile_enable(1)
+        for i in range(4):
+            w.update(batches[i % 4])
+        torch.cuda.synchronize()
+        L.nir_profile_enable(0)
+        buf = ctypes.create_string_buffer(1 << 17)
+        L.nir_profile_report(buf, len(buf))
+        kern = {}
+        for line in buf.value.decode().strip().splitlines():
+            kname, cnt, ms = line.rsplit(",", 2)
+            kern[kname] = (int(cnt), float(ms))
+        pairs = c["batch"] * c["cands"] * (c.get("session", 1) if kind == "CARS" else 1)
+        rec = {"workload": "%s.update on the %s batch shape (train-mode forward + loss + backward + clip + Adam, default dropouts), eager" % (
+                   "Multitask" if kind == "CARS" else "Ranker", c.get("baseline", "")[:11]),
+               "ms_per_step": round(dt * 1e3, 4), "updates_per_s": round(1.0 / dt, 2), "pairs_per_s": round(pairs / dt, 1), "dtype": "f32",
+               "hip_kernel_ms_per_step": round(sum(v[1] for v in kern.values()) / 4, 4)}
+        if kern:
+            dom = max(kern, key=lambda k: kern[k][1])
+            cnt, ms = kern[dom]
+            avg_us = ms / cnt * 1e3
+            rf = {"kernel": dom, "avg_us": round(avg_us, 3), "launches_per_step": cnt / 4.0, "share_of_hip_kernel_time": round(ms / sum(v[1] for v in kern.values()), 4)}
+            work = kernel_work(dom, c)
+            if work:
+                tf = work["flops"] * max(1, work["terms"]) / (avg_us * 1e-6) / 1e12
+                rf.update(bound="mfma", achieved=round(tf, 3), peak=round(work["pipe"], 1), unit="TFLOP/s", frac=round(tf / work["pipe"], 5),
+                          mfma_frac=round(tf / work["pipe"], 5))
+            rec["roofline"] = rf
+            rec["top_kernels_ms_per_step"] = {k: round(v[1] / 4, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:6]}
+        return rec
+    except Exception as e:  # pragma: no cover
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def decode_record(c, args, env):
-    """Full Multitask.predict (ranking + greedy suggestion decode, models/multitask.py:229-317) on the headline workload."""
+    """Full Multitask.predict (ranking + greedy suggestion decode, models/multitask.py:229-317) on the headline workload: the whole predict
+    -- encoders, session part, 10 greedy decoding steps with the 256 -> 30 000 projection -- captured into one hipGraph per resident batch,
+    replayed with --streams batches in flight like the headline (eager single-stream figure reported beside it)."""
     try:
         model = build_model(c, args)
-        batches = make_batches(c, 4, 0, env.dev)
-        for i in range(3):
-            model.predict(batches[i % 4])
+        nl = max(1, args.streams)
+        batches = make_batches(c, 2 * nl, 0, env.dev)
+        lanes = [torch.cuda.Stream() for _ in range(nl)]
+        lib.load().nir_set_batches_in_flight(nl)
+        for i in range(2 * nl):
+            with torch.cuda.stream(lanes[i % nl]):
+                model.predict(batches[i])
         torch.cuda.synchronize()
-        n, t0 = 20, time.perf_counter()
+        pairs = c["batch"] * c["session"] * c["cands"]
+        n, t0 = 12, time.perf_counter()
         for i in range(n):
-            model.predict(batches[i % 4])
+            model.predict(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / n
+        graphs = []
+        for i in range(len(batches)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=lanes[i % nl], capture_error_mode=CAPTURE_MODE):
+                out = model.predict(batches[i])
+            graphs.append((g, out))
+        ref = model.predict(batches[0])
+        graphs[0][0].replay()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref["predictions"], graphs[0][1]["predictions"]))
+        for i in range(2 * len(graphs)):
+            with torch.cuda.stream(lanes[i % nl]):
+                graphs[i % len(graphs)][0].replay()
+        torch.cuda.synchronize()
+        n, t0 = 40 * nl, time.perf_counter()
+        for i in range(n):
+            with torch.cuda.stream(lanes[i % nl]):
+                graphs[i % len(graphs)][0].replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        pairs = c["batch"] * c["session"] * c["cands"]
-        return {"workload": "headline batch through the full predict: ranking + greedy decode of max_query_len tokens", "ms_per_step": round(dt * 1e3, 4),
-                "pairs_per_s": round(pairs / dt, 1), "suggested_queries_per_s": round(c["batch"] * (c["session"] - 1) / dt, 1), "eager": True}
+        lib.load().nir_set_batches_in_flight(1)
+        return {"workload": "headline batch through the full predict: ranking + greedy decode of max_query_len tokens; one hipGraph per batch, %d in flight" % nl,
+                "ms_per_step": round(dt * 1e3, 4), "pairs_per_s": round(pairs / dt, 1), "suggested_queries_per_s": round(c["batch"] * (c["session"] - 1) / dt, 1),
+                "hipgraph": True, "batches_in_flight": nl, "graph_predictions_equal_eager": same,
+                "eager_one_in_flight_ms_per_step": round(eager * 1e3, 4), "eager_one_in_flight_pairs_per_s": round(pairs / eager, 1)}
     except Exception as e:  # pragma: no cover
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -43,7 +43,7 @@ def rnn_encode(sd, prefix, x, lengths, bidirectional=True, init=None):
     key = (prefix, bidirectional)
     lstm = cache.get(key)
     if lstm is None:
-        lstm = torch.nn.LSTM(inp, hid, 1, batch_first=True, bidirectional=bidirectional)
+        lstm = torch.nn.LSTM(inp, hid, 1, batch_first=True, bidirectional=bidirectional).to(w_ih.dtype)   # (float64 state dicts: the
         names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
         if bidirectional:
             names += [n + "_reverse" for n in names]
