@@ -195,8 +195,12 @@ class _BiLSTM(Function):
         whh = torch.stack([params[4 * d + 1] for d in range(nd)], 0).float().contiguous()
         bias = torch.cat([params[4 * d + 2] + params[4 * d + 3] for d in range(nd)], 0).float().contiguous()
         H = whh.shape[2]
-        if H > 128 * 4:
-            raise NotImplementedError("train-mode recurrence supports H <= 512 per direction (got %d)" % H)
+        if H > 128:
+            raise NotImplementedError("train-mode recurrence (nir_lstm_train_fwd / _bwd) supports H <= 128 per direction (got %d); "
+                                      "wider single-direction LSTMs go through lstm_seq" % H)
+        if h0 is not None and nd != 1:
+            raise NotImplementedError("initial states are supported for one direction only (the backward's h_{t-1} of the reverse "
+                                      "direction at t = length-1 would have to be h0[1])")
         x2 = _f32c(x).reshape(M * T, I)
         gates = _linear_raw(x2, wih, bias, 0)
         dev = x.device

@@ -13,6 +13,8 @@
 //   pred = argmax logits; tgt = lut[pred]                                    argmax_map_kernel (softmax is monotone; first
 //                                                                           index wins ties like torch.max)
 // Everything is enqueued on the caller's stream; no host synchronisation.
+#include <algorithm>
+#include <mutex>
 #include "common.hpp"
 
 namespace nir {
@@ -117,6 +119,144 @@ __global__ __launch_bounds__(256) void argmax_map_kernel(const float* __restrict
     }
 }
 
+// ---- token_prob_predictor2 fused with the arg-max (cars.py:779-787): logits[b, v] = p1[b, :] . W2[v, :] never leave the chip. ----------
+// W2 [VT, 256] arrives as pre-split fp16 two-term planes in MFMA A-fragment order (built once per weight version by the host):
+//   frag[vt][ks][term][lane][8],  element (lane, j) = W2[16 vt + (lane & 15)][32 ks + 8 (lane >> 4) + j]      (vt = 16-row vocabulary tile)
+// p1 (<= 96 decode rows per pass) is split into two fp16 planes in LDS and read as the B operand; a wave owns PA_TW vocabulary tiles at a
+// time, three v_mfma_f32_16x16x32_f16 per product block (x = x1 + 2^-11 x2': fp32-class error, as everywhere else).  Each lane keeps the
+// running (max, first index) of the 4 x PA_TW vocabulary rows it sees per decode row; lanes that share a decode row combine through two
+// ds_bpermute hops, the four waves write one partial per decode row, argmax_finish_kernel reduces the partials of all workgroups and maps
+// the winner to the next input token.  Replaces a 96 x 30 000 x 256 fp32 GEMM that wrote 11.5 MB of logits per step plus an arg-max kernel
+// that read them back.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int PA_K = 256, PA_KS = PA_K / 32, PA_NBT = 6, PA_ROWS = 16 * PA_NBT, PA_LD = PA_K + 8;     // 96 decode rows per pass
+constexpr int PA_TW = 2;                                                                              // vocabulary tiles per wave and pass
+constexpr size_t PA_LDS = (size_t)2 * PA_ROWS * PA_LD * 2;
+
+__global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __restrict__ p1, const _Float16* __restrict__ wfrag, int64_t VT,
+                                                             int64_t ntiles, int64_t Bd, float* __restrict__ pval, int* __restrict__ pidx) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 pa_sm[];          // [2 terms][96 rows][PA_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int64_t per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t_lo = (int64_t)blockIdx.x * per_wg, t_hi = min(ntiles, t_lo + per_wg);
+    for (int64_t b0 = 0; b0 < Bd; b0 += PA_ROWS) {
+        __syncthreads();
+        for (int e = tid; e < PA_ROWS * (PA_K / 4); e += 256) {            // stage + split this pass's decode rows (zero rows past Bd)
+            const int r = e / (PA_K / 4), k4 = (e - r * (PA_K / 4)) * 4;
+            const int64_t b = b0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < Bd) v = *reinterpret_cast<const float4*>(p1 + b * PA_K + k4);
+            const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+            const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz((v.x - (float)a01[0]) * 2048.0f, (v.y - (float)a01[1]) * 2048.0f);
+            const fp16x2_t b23 = __builtin_amdgcn_cvt_pkrtz((v.z - (float)a23[0]) * 2048.0f, (v.w - (float)a23[1]) * 2048.0f);
+            _Float16* d = pa_sm + r * PA_LD + k4;
+            *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
+            *reinterpret_cast<uint2*>(d + PA_ROWS * PA_LD) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+        }
+        __syncthreads();
+        float best[PA_NBT];
+        int bidx[PA_NBT];
+#pragma unroll
+        for (int bt = 0; bt < PA_NBT; ++bt) { best[bt] = -INFINITY; bidx[bt] = 0x7FFFFFFF; }
+        for (int64_t t0 = t_lo + wave * PA_TW; t0 < t_hi; t0 += 4 * PA_TW) {
+            f32x4 acc[PA_TW][PA_NBT], acx[PA_TW][PA_NBT];
+#pragma unroll
+            for (int u = 0; u < PA_TW; ++u)
+#pragma unroll
+                for (int bt = 0; bt < PA_NBT; ++bt) { acc[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            f16x8 wa[PA_TW][2], wb[PA_TW][2];
+            auto load_w = [&](int ks, f16x8 (&dst)[PA_TW][2]) {
+#pragma unroll
+                for (int u = 0; u < PA_TW; ++u) {
+                    const int64_t t = t0 + u < t_hi ? t0 + u : t_hi - 1;      // clamped: a duplicate tile's results are discarded below
+                    const _Float16* wp = wfrag + ((t * PA_KS + ks) * 2 * 64 + lane) * 8;
+                    dst[u][0] = *reinterpret_cast<const f16x8*>(wp);
+                    dst[u][1] = *reinterpret_cast<const f16x8*>(wp + 512);
+                }
+            };
+            load_w(0, wa);
+#define PA_STEP(KS, CUR, NXT)                                                                                          \
+            {                                                                                                          \
+                load_w((KS) + 1 < PA_KS ? (KS) + 1 : (KS), NXT);                                                         \
+                const _Float16* bp = pa_sm + c16 * PA_LD + 32 * (KS) + 8 * g4;                                           \
+                _Pragma("unroll") for (int bt = 0; bt < PA_NBT; ++bt) {                                                  \
+                    const f16x8 b1 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD);                              \
+                    const f16x8 b2 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD + PA_ROWS * PA_LD);            \
+                    _Pragma("unroll") for (int u = 0; u < PA_TW; ++u) {                                                  \
+                        acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[u][1], b1, acx[u][bt], 0, 0, 0);        \
+                        acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[u][0], b2, acx[u][bt], 0, 0, 0);        \
+                        acc[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[u][0], b1, acc[u][bt], 0, 0, 0);        \
+                    }                                                                                                    \
+                }                                                                                                        \
+            }
+#pragma unroll
+            for (int ks = 0; ks < PA_KS; ks += 2) {
+                PA_STEP(ks, wa, wb)
+                PA_STEP(ks + 1, wb, wa)
+            }
+#undef PA_STEP
+#pragma unroll
+            for (int u = 0; u < PA_TW; ++u) {
+                if (t0 + u >= t_hi) continue;                              // wave-uniform
+#pragma unroll
+                for (int bt = 0; bt < PA_NBT; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t v = (t0 + u) * 16 + 4 * g4 + r;         // ascending in (u, r): '>' keeps the first index on ties
+                        const float x = fmaf(acx[u][bt][r], 1.0f / 2048.0f, acc[u][bt][r]);
+                        if (v < VT && x > best[bt]) { best[bt] = x; bidx[bt] = (int)v; }
+                    }
+            }
+        }
+        // lanes l, l+16, l+32, l+48 hold the same decode column: combine (first index wins ties), then one partial per wave and column
+#pragma unroll
+        for (int bt = 0; bt < PA_NBT; ++bt) {
+#pragma unroll
+            for (int sh = 16; sh <= 32; sh <<= 1) {
+                const float ov = __shfl_xor(best[bt], sh);
+                const int oi = __shfl_xor(bidx[bt], sh);
+                if (ov > best[bt] || (ov == best[bt] && oi < bidx[bt])) { best[bt] = ov; bidx[bt] = oi; }
+            }
+            const int64_t b = b0 + bt * 16 + c16;
+            if (g4 == 0 && b < Bd) {
+                const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * Bd + b;
+                pval[slot] = best[bt];
+                pidx[slot] = bidx[bt];
+            }
+        }
+    }
+}
+
+// one wave per decode row: reduce the per-(workgroup, wave) partials, first index on ties; pred[i*pstride] = winner, tgt[i] = lut[winner]
+__global__ __launch_bounds__(64) void argmax_finish_kernel(const float* __restrict__ pval, const int* __restrict__ pidx, int nparts, int64_t Bd,
+                                                           const int64_t* __restrict__ lut, int64_t* __restrict__ pred, int64_t pstride,
+                                                           int64_t* __restrict__ tgt, int64_t Vsrc) {
+    const int64_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    float best = -INFINITY;
+    int idx = 0x7FFFFFFF;
+    for (int p = lane; p < nparts; p += 64) {
+        const float v = pval[(int64_t)p * Bd + i];
+        const int vi = pidx[(int64_t)p * Bd + i];
+        if (v > best || (v == best && vi < idx)) { best = v; idx = vi; }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const float ov = __shfl_xor(best, sh);
+        const int oi = __shfl_xor(idx, sh);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) {
+        const int64_t w = idx != 0x7FFFFFFF ? idx : 0;
+        pred[i * pstride] = w;
+        const int64_t nxt = lut ? lut[w] : w;
+        tgt[i] = (nxt >= 0 && nxt < Vsrc) ? nxt : 1;
+    }
+}
+
 __global__ void fill_i64_kernel(int64_t* p, int64_t v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -129,11 +269,24 @@ __global__ void add_weights_kernel(const float* a, const float* b, float* o, int
 }
 
 struct DecPlan {
-    float *mem, *sess, *h[2], *c[2], *qv, *cat, *ah, *p1, *logits;
+    float *mem, *sess, *h[2], *c[2], *qv, *cat, *ah, *p1, *logits, *pval;
+    int* pidx;
     int64_t* tgt;
     size_t bytes;
 };
-static DecPlan dec_plan(void* ws, size_t cap, int64_t rows_src, int64_t Bd, int QL, int HD, int P, int64_t VT) {
+constexpr int PA_MAX_WGS = 256;
+static int cu_count() {
+    static int n = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    });
+    return n;
+}
+static DecPlan dec_plan(void* ws, size_t cap, int64_t rows_src, int64_t Bd, int QL, int HD, int P, int64_t VT, bool fused_argmax) {
     Workspace a(ws, cap);
     DecPlan p;
     p.mem = a.take<float>((size_t)rows_src * QL * HD);
@@ -143,7 +296,9 @@ static DecPlan dec_plan(void* ws, size_t cap, int64_t rows_src, int64_t Bd, int 
     p.cat = a.take<float>((size_t)Bd * 2 * HD);
     p.ah = a.take<float>((size_t)Bd * HD);
     p.p1 = a.take<float>((size_t)Bd * P);
-    p.logits = a.take<float>((size_t)Bd * VT);
+    p.logits = a.take<float>(fused_argmax ? 0 : (size_t)Bd * VT);
+    p.pval = a.take<float>(fused_argmax ? (size_t)PA_MAX_WGS * 4 * Bd : 0);
+    p.pidx = a.take<int>(fused_argmax ? (size_t)PA_MAX_WGS * 4 * Bd : 0);
     p.tgt = a.take<int64_t>((size_t)Bd);
     p.bytes = align_up(a.off, 256);
     return p;
@@ -162,7 +317,7 @@ extern "C" int nir_add_f32(const float* a, const float* b, float* out, int64_t n
 
 extern "C" size_t nir_cars_decode_workspace_bytes(int64_t rows_src, int64_t Bd, int QL, const nir_cars_decoder_weights* w) {
     if (!w || rows_src < 0 || Bd < 0 || QL <= 0) return 0;
-    return nir::dec_plan(nullptr, 0, rows_src, Bd, QL, w->HD, w->P, w->VT).bytes;
+    return nir::dec_plan(nullptr, 0, rows_src, Bd, QL, w->HD, w->P, w->VT, w->pred2_frag != nullptr && w->P == nir::PA_K).bytes;
 }
 
 extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, const float* encoded_source, const int64_t* source_len,
@@ -179,7 +334,14 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
     NIR_REQUIRE(bos >= 0 && bos < V, "cars_decode: BOS id outside the vocabulary");
     if (Bd == 0) return 0;
     const int HD = w->HD, P = w->P;
-    DecPlan p = dec_plan(workspace, workspace_bytes, rows_src, Bd, QL, HD, P, w->VT);
+    const bool fused_argmax = w->pred2_frag != nullptr && P == PA_K && w->VT < 0x7FFFFFF0LL;
+    DecPlan p = dec_plan(workspace, workspace_bytes, rows_src, Bd, QL, HD, P, w->VT, fused_argmax);
+    const int64_t ntiles = (w->VT + 15) / 16;
+    const int pa_wgs = (int)std::min<int64_t>(std::min<int64_t>(PA_MAX_WGS, cu_count()), (ntiles + 4 * PA_TW - 1) / (4 * PA_TW));
+    if (fused_argmax && PA_LDS > 64 * 1024) {
+        static std::once_flag once;
+        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)pred_argmax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PA_LDS); });
+    }
     if (!workspace || p.bytes > workspace_bytes) {
         set_error("cars_decode: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
         return NIR_ERR_WORKSPACE;
@@ -216,12 +378,24 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
         NIR_PROPAGATE(launch_linear(p.cat, 2 * HD, nullptr, nullptr, 0, 0, 0, w->attn_out_w, 2 * HD, nullptr, nullptr, p.ah, HD, Bd, HD, 2 * HD, NIR_ACT_TANH, st));
         NIR_PROPAGATE(launch_linear_ex(p.ah, HD, nullptr, nullptr, 0, 0, 0, w->pred1_w, HD, nullptr, nullptr, p.p1, P, Bd, P, HD, NIR_ACT_NONE,
                                        w->KS > 0 ? p.sess : nullptr, P, st));
-        NIR_PROPAGATE(launch_linear(p.p1, P, nullptr, nullptr, 0, 0, 0, w->pred2_w, P, nullptr, nullptr, p.logits, w->VT, Bd, (int)w->VT, P, NIR_ACT_NONE, st));
-        {
-            ProfScope ps("argmax_map_kernel", st);
-            hipLaunchKernelGGL(argmax_map_kernel, dim3((unsigned)Bd), dim3(256), 0, st, p.logits, w->VT, tgt2src, predictions + step, (int64_t)max_len, p.tgt, V);
+        if (fused_argmax) {
+            {
+                ProfScope ps(prof_shape_name("pred_argmax_kernel", (long long)Bd, (long long)w->VT, P), st);
+                hipLaunchKernelGGL(pred_argmax_kernel, dim3((unsigned)pa_wgs), dim3(256), PA_LDS, st, p.p1, (const _Float16*)w->pred2_frag, w->VT, ntiles, Bd,
+                                   p.pval, p.pidx);
+            }
+            NIR_CHECK_LAUNCH("pred_argmax_kernel");
+            hipLaunchKernelGGL(argmax_finish_kernel, dim3((unsigned)Bd), dim3(64), 0, st, p.pval, p.pidx, pa_wgs * 4, Bd, tgt2src, predictions + step,
+                               (int64_t)max_len, p.tgt, V);
+            NIR_CHECK_LAUNCH("argmax_finish_kernel");
+        } else {
+            NIR_PROPAGATE(launch_linear(p.p1, P, nullptr, nullptr, 0, 0, 0, w->pred2_w, P, nullptr, nullptr, p.logits, w->VT, Bd, (int)w->VT, P, NIR_ACT_NONE, st));
+            {
+                ProfScope ps("argmax_map_kernel", st);
+                hipLaunchKernelGGL(argmax_map_kernel, dim3((unsigned)Bd), dim3(256), 0, st, p.logits, w->VT, tgt2src, predictions + step, (int64_t)max_len, p.tgt, V);
+            }
+            NIR_CHECK_LAUNCH("argmax_map_kernel");
         }
-        NIR_CHECK_LAUNCH("argmax_map_kernel");
         hp = hn;
         cp = cn;
     }

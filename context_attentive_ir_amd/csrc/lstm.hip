@@ -33,7 +33,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // matrix-core variants (lstm_mfma.hip); return NIR_ERR_UNSUPPORTED when the shape has no instantiation
 int launch_bilstm_mfma16(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
-                         float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st);
+                         float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st, float* act = nullptr, float* cst = nullptr);
 int launch_bilstm_mfma(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
                        float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st);
 

@@ -250,6 +250,8 @@ struct LstmMfmaGinArgs {
     float* cn;
     int64_t M;
     int T, H, ND;
+    float* act;             // train-mode forward only (lstm_mfma16_gin_kernel<.., true>): [M,T,ND,4H] gate activations i,f,g,o and
+    float* cst;             //   [M,T,ND,H] cell states of every valid step, for the BPTT kernel (csrc/train.hip)
 };
 
 template <int NG, int KQ, int NWC>
@@ -399,7 +401,7 @@ static int launch_mfma_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
 //     step needs ONE barrier (h ping-pong in LDS); its slice of W_hh (2 x 4*ceil(H/16) floats per lane) stays in VGPRs
 //     for all T steps.  The input part of the gates (gates_in, biases included) is prefetched one step ahead.
 // ------------------------------------------------------------------------------------------------------------------
-template <int G, int NT>
+template <int G, int NT, bool TR = false>
 __global__ __launch_bounds__(1024) void lstm_mfma16_gin_kernel(LstmMfmaGinArgs p) {
     constexpr int SEQ = 16, KP = 16 * G, ZLD = KP + 4, NW = 16;
     constexpr uint32_t OOB = 0x7FFFFFF0u;
@@ -458,6 +460,11 @@ __global__ __launch_bounds__(1024) void lstm_mfma16_gin_kernel(LstmMfmaGinArgs p
                                                                              (int)((uint32_t)nvalid * T * GW * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
                                                                              (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    // train mode: the gate activations and cell states of every valid step go to memory for the backward (same OOB-offset = dropped trick)
+    const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(TR ? p.act + m0 * T * GW : p.out, 0,
+                                                                             TR ? (int)((uint32_t)nvalid * T * GW * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cst_rs = __builtin_amdgcn_make_buffer_rsrc(TR ? p.cst + m0 * T * OW : p.out, 0,
+                                                                             TR ? (int)((uint32_t)nvalid * T * OW * 4u) : 0, 0x00020000);
     auto load_gin = [&](int step, float (&dst)[NT][4]) {
         const int t_ = dir == 0 ? step : mylen - 1 - step;
 #pragma unroll
@@ -498,6 +505,14 @@ __global__ __launch_bounds__(1024) void lstm_mfma16_gin_kernel(LstmMfmaGinArgs p
             if (dv) zn[sq * ZLD + unit_d] = hreg[t];
             const uint32_t off = act ? (uint32_t)((sq * T + tt) * OW + dir * H + unit_d) * 4u : OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn), out_rs, off, 0, 0);   // OOB lanes dropped
+            if (TR) {      // act [M,T,ND,4H] (gate-major inside a direction), cst [M,T,ND,H]
+                const uint32_t ao = act ? (uint32_t)(((sq * T + tt) * p.ND + dir) * H4 + unit_d) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gi), act_rs, ao, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gf), act_rs, act ? ao + (uint32_t)H * 4u : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gg), act_rs, act ? ao + (uint32_t)H * 8u : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(go), act_rs, act ? ao + (uint32_t)H * 12u : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cn), cst_rs, act ? (uint32_t)(((sq * T + tt) * p.ND + dir) * H + unit_d) * 4u : OOB, 0, 0);
+            }
         };
         if (has1) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -553,8 +568,11 @@ __global__ __launch_bounds__(1024) void lstm_mfma16_gin_kernel(LstmMfmaGinArgs p
 template <int G, int NT>
 static int launch_mfma16_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
     static const std::string pname = "lstm_mfma16_gin_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
-    ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
-    hipLaunchKernelGGL((lstm_mfma16_gin_kernel<G, NT>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), 0, st, p);
+    static const std::string tname = "lstm_train_fwd_mfma16_kernel<" + std::to_string(G) + "," + std::to_string(NT) + ">";
+    const bool tr = p.act != nullptr;
+    ProfScope ps(prof_shape_name(tr ? tname.c_str() : pname.c_str(), (long long)p.M, p.T, p.H), st);
+    if (tr) hipLaunchKernelGGL((lstm_mfma16_gin_kernel<G, NT, true>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((lstm_mfma16_gin_kernel<G, NT, false>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(1024), 0, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_fwd[mfma16]");
     return 0;
 }
@@ -562,11 +580,12 @@ static int launch_mfma16_gin(const LstmMfmaGinArgs& p, hipStream_t st) {
 // 16-sequence layout: pays once there are enough sequences to give most CUs a workgroup (otherwise the quad/VALU
 // kernel spreads a small batch over more CUs).  NIR_LSTM_MFMA16=0/1 forces it off/on.
 int launch_bilstm_mfma16(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
-                         float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st) {
+                         float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st, float* act, float* cst) {
     const int f = tun(g_tun.lstm_mfma16);       // -1 auto, 0 off, 1 forced
-    if (f >= 0 ? f == 0 : ((M + 15) / 16) * ND < 128) return NIR_ERR_UNSUPPORTED;
+    // (train-mode forward, act != NULL: always -- the alternative there is the scalar kernel of csrc/train.hip)
+    if (!act && (f >= 0 ? f == 0 : ((M + 15) / 16) * ND < 128)) return NIR_ERR_UNSUPPORTED;
     if (H < 33 || H > 128 || (int64_t)16 * T * ND * 4 * H * 4 >= 0x7FFFFFF0LL) return NIR_ERR_UNSUPPORTED;
-    LstmMfmaGinArgs p{gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND};
+    LstmMfmaGinArgs p{gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, act, cst};
     const int G = (H + 15) / 16;
     if (H <= 64) {
         if (G == 3) return launch_mfma16_gin<3, 1>(p, st);
@@ -583,7 +602,7 @@ int launch_bilstm_mfma16(const float* gin, const int64_t* lens, const float* whh
 int launch_bilstm_mfma(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
                        float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, hipStream_t st) {
     if ((int64_t)4 * T * ND * 4 * H * 4 >= 0x7FFFFFF0LL || H < 17) return NIR_ERR_UNSUPPORTED;
-    LstmMfmaGinArgs p{gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND};
+    LstmMfmaGinArgs p{gin, lens, whh, h0, c0, out, hn, cn, M, T, H, ND, nullptr, nullptr};
     if (H <= 64) return launch_mfma_gin<4, 16, 1>(p, st);
     if (H <= 96) return launch_mfma_gin<3, 24, 2>(p, st);
     if (H <= 128) return launch_mfma_gin<4, 32, 2>(p, st);

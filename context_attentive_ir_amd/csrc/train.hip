@@ -14,6 +14,8 @@
 #include <algorithm>
 
 namespace nir {
+int launch_bilstm_mfma16(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0, float* out, float* hn,
+                         float* cn, int64_t M, int T, int H, int ND, hipStream_t st, float* act, float* cst);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -477,6 +479,13 @@ extern "C" int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths,
     NIR_REQUIRE(gates_in && w_hh && out && act && cst, "lstm_train_fwd: null pointer");
     NIR_REQUIRE(M >= 0 && T > 0 && (ndir == 1 || ndir == 2) && H >= 1 && H <= 128, "lstm_train_fwd: bad dims (H <= 128)");
     if (M == 0) return 0;
+    if (H >= 33 && !tun(g_tun.lstm_valu)) {
+        // the inference recurrence on the f32 matrix cores (csrc/lstm_mfma.hip: 16 sequences per workgroup, W_hh resident in registers, one
+        // barrier per step) with the activation / cell-state stores of train mode: 4.9 ms -> 0.4 ms at the C3 document shape against the
+        // one-thread-per-gate-row kernel below (kept for H <= 32 and as the `lstm_valu` cross-check)
+        const int rc = launch_bilstm_mfma16(gates_in, lengths, w_hh, h0, c0, out, hn, cn, M, T, H, ndir, (hipStream_t)stream, act, cst);
+        if (rc != NIR_ERR_UNSUPPORTED) return rc;
+    }
     LstmTrainArgs a{gates_in, lengths, w_hh, out, act, cst, hn, cn, h0, c0, M, T, H, ndir};
     const dim3 grid((unsigned)((M + TSQ - 1) / TSQ), (unsigned)ndir);
     const int threads = (4 * H + 63) / 64 * 64;

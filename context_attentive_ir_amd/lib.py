@@ -53,7 +53,7 @@ CarsSessionWeights = _struct(
     ["D", "HS", "HDEC", "q_on", "d_on", "rank_on"])
 class CarsDecoderWeights(C.Structure):
     _fields_ = [(f, c_fp) for f in ("rnn_wih", "rnn_whh", "rnn_bih", "rnn_bhh", "attn_in_w", "attn_out_w", "dec_attn_w", "pred1_w",
-                                    "pred2_w", "sess_w")] + [(f, C.c_int) for f in ("HD", "DQ", "P", "KS")] + [("VT", C.c_int64)]
+                                    "pred2_w", "sess_w")] + [(f, C.c_int) for f in ("HD", "DQ", "P", "KS")] + [("VT", C.c_int64), ("pred2_frag", C.c_void_p)]
 
 
 CarsSessionOutputs = _struct("nir_cars_session_outputs", ["inner_q", "inner_d", "dec_h", "dec_c"])

@@ -121,6 +121,7 @@ class CARS(nn.Module, lib.IdCheck):
         # bf16 folded table + bf16 MFMA recurrence (BASELINE config 5), "f32" is the parity path.
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
         self.fuse_attention_pooling = True   # attention MLP + masked softmax + weighted sum as one kernel (csrc/cars_attn.hip)
+        self.fuse_decoder_argmax = True      # decode: 256 -> V_tgt projection + arg-max as one kernel, no [Bd, V_tgt] logits
         self.fold_budget_bytes = 64 << 30
         self.compute_dtype = getattr(args, "compute_dtype", "f32")
         self._fq, self._fd = lib.PackCache(), lib.PackCache()
@@ -214,6 +215,16 @@ class CARS(nn.Module, lib.IdCheck):
             pk.keep["sess_w"] = torch.empty_like(a)
             lib.check(lib.load().nir_add_f32(lib.ptr(a), lib.ptr(b), lib.ptr(pk.keep["sess_w"]), a.numel(), lib.stream()), "nir_add_f32")
             pk.struct.sess_w = pk.keep["sess_w"].data_ptr()
+            # token_prob_predictor2 as pre-split fp16 A-fragments for the fused projection + arg-max kernel (csrc/cars_decode.hip)
+            w2 = pk.keep["pred2_w"]
+            VT, P = w2.shape
+            if self.fuse_decoder_argmax and P == 256 and w2.is_cuda and float(w2.abs().max()) < 32768.0:
+                vp = (VT + 15) // 16 * 16
+                pad = torch.zeros(vp, P, device=w2.device, dtype=torch.float32)
+                pad[:VT] = w2
+                planes = torch.stack(lib.split_f16x2(pad, P))                         # [2 terms, vp, P] int16
+                pk.keep["pred2_frag"] = planes.view(2, vp // 16, 16, P // 32, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+                pk.struct.pred2_frag = pk.keep["pred2_frag"].data_ptr()
             return pk
         mods = [self.decoder, self.dec_attn, self.token_prob_predictor1, self.token_prob_predictor2,
                 self.shared_session_projector, self.private_session_projector2]
@@ -436,11 +447,14 @@ class CARS(nn.Module, lib.IdCheck):
             if not self.no_ranker:
                 parts = ([attend(qs, self.session_query_attn)] if q_on else []) + ([attend(ds, self.session_doc_attn)] if d_on else [])
                 qp = self._proj(self.q_projection, qv)
-                if parts:
-                    sess = torch.cat(parts, 1)
-                    qp = qp + self._proj(self.shared_session_projector, sess) + self._proj(self.private_session_projector1, sess)
                 D = docs.shape[-1]
                 qx = qp.unsqueeze(1).expand(B, N, D).reshape(B * N, D)
+                if parts:
+                    # the reference expands the session representation to [B,N,.] BEFORE the two projectors (cars.py:484-508): their
+                    # dropout draws one mask per candidate, not one per query
+                    sess = torch.cat(parts, 1)
+                    sx = sess.unsqueeze(1).expand(B, N, sess.shape[1]).reshape(B * N, sess.shape[1])
+                    qx = qx + self._proj(self.shared_session_projector, sx) + self._proj(self.private_session_projector1, sx)
                 dx = docs[:, t].reshape(B * N, D)
                 x = torch.cat((qx, dx, (qx - dx).abs(), qx * dx), 1)
                 for layer, o, pool in zip(self.ranknet._linear_layers, self.ranknet._output_dims, self.ranknet._pool_sizes):

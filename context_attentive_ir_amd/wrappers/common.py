@@ -61,6 +61,18 @@ class WrapperBase(object):
                 p.requires_grad = False
         parameters = [p for p in self.network.parameters() if p.requires_grad]
         a = self.args
+        # dropout masks of the HIP train-mode forwards come from a counter-based stream (autograd.DROPOUT): tie it to the run's seed
+        # (args.random_seed, main/ranker.py:49; else torch's) and to the rank, so runs / ranks / resumed runs do not replay one sequence
+        from .. import autograd as A
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:  # pragma: no cover
+            pass
+        seed = getattr(a, "random_seed", None)
+        A.DROPOUT.manual_seed((int(seed) if seed is not None else int(torch.initial_seed())) * 1000003 + rank)
         if a.optimizer == "sgd":
             self.optimizer = optim.SGD(parameters, a.learning_rate, momentum=a.momentum, weight_decay=a.weight_decay)
         elif a.optimizer == "adam":
@@ -72,6 +84,9 @@ class WrapperBase(object):
         else:
             raise RuntimeError("Unsupported optimizer: %s" % a.optimizer)
         if state_dict is not None:
+            ds = state_dict.pop("_nir_dropout_state", None) if isinstance(state_dict, dict) else None
+            if ds is not None:                      # resume: continue the mask stream where the checkpoint left it
+                A.DROPOUT.seed, A.DROPOUT.counter = int(ds[0]), int(ds[1])
             self.optimizer.load_state_dict(state_dict)
             if use_gpu:
                 for state in self.optimizer.state.values():
@@ -128,7 +143,10 @@ class WrapperBase(object):
         if self.optimizer is None:
             raise RuntimeError("No optimizer set.")
         try:
-            torch.save(self._params({"epoch": epoch, "optimizer": self.optimizer.state_dict()}), filename)
+            from .. import autograd as A
+            opt = dict(self.optimizer.state_dict())
+            opt["_nir_dropout_state"] = (A.DROPOUT.seed, A.DROPOUT.counter)
+            torch.save(self._params({"epoch": epoch, "optimizer": opt}), filename)
         except BaseException:
             logger.warning("WARN: Saving failed... continuing anyway.")
 

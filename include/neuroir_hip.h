@@ -368,6 +368,10 @@ typedef struct {
                                                            (nir_add_f32) [P,KS]; NULL when KS == 0 */
     int HD, DQ, P, KS;                                  /* 512, 256, 256, nch*HS */
     int64_t VT;                                         /* tgt_vocab_size */
+    const void* pred2_frag;                             /* optional (NULL: fp32 GEMM + arg-max kernel): token_prob_predictor2.weight [VT, P = 256], rows
+                                                           zero-padded to a multiple of 16, split into two fp16 terms (x = x1 + 2^-11 x2', needs |w| < 2^15)
+                                                           in MFMA A-fragment order [VT/16][P/32][2 terms][64 lanes][8]: the projection and the arg-max
+                                                           then run as ONE kernel and the [Bd, VT] logits are never written */
 } nir_cars_decoder_weights;
 /* out = a + b (weight packing helper). */
 int nir_add_f32(const float* a, const float* b, float* out, int64_t n, nir_stream_t stream);

@@ -116,3 +116,29 @@ def test_ranker_off_returns_states_only():
     s, st, at = m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"])
     assert s == []
     _close(st[0], st_ref[0], 5e-5); _close(at[0], at_ref[0], 5e-5); _close(at[1], at_ref[1], 5e-5)
+
+
+@pytest.mark.parametrize("B,S,VT", [(20, 7, 1000), (3, 4, 37), (16, 7, 30000)])
+def test_decode_fused_projection_argmax_matches_logits_path(B, S, VT):
+    """csrc/cars_decode.hip pred_argmax_kernel (256 -> V_tgt projection + arg-max in one kernel, fp16 two-term MFMA, no [Bd, V_tgt] logits)
+    against the fp32 GEMM + arg-max kernels it replaces: more than 96 decode rows (two passes), a vocabulary that is not a multiple of
+    16, the reference's 30 000-word vocabulary.  Identical predictions except where the two top logits are within rounding of each other
+    (a flipped near-tie changes the rest of that row's sequence: rows are compared up to their first disagreement)."""
+    from context_attentive_ir_amd import synth
+    V = 3000
+    m = build_model("CARS", vocab=V, tgt_vocab_size=VT, device=DEV)
+    ex = {k: v.to(DEV) for k, v in synth.session_batch(B, S, 5, 4, 12, V, seed=B + VT, full_length=False).items()}
+    pooled, enc, _ = m.encode(ex["source_words"], ex["source_lens"])
+    _, st, at = m.rank_document(pooled, ex["document_words"], ex["document_lens"], ex["document_labels"])
+    lut = torch.randint(4, V, (VT,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    kw = dict(states=st, max_len=8, src_dict=None, tgt_dict=None, batch_size=B, session_len=S - 1, use_cuda=True, encoded_source=enc,
+              source_len=ex["source_lens"], session_attns=at, tgt2src=lut)
+    assert m._decoder_weights().struct.pred2_frag
+    fused = m.decode(**kw)["predictions"].cpu()
+    m.fuse_decoder_argmax = False
+    m._pdec.invalidate()
+    assert not m._decoder_weights().struct.pred2_frag
+    plain = m.decode(**kw)["predictions"].cpu()
+    assert fused.shape == (B, S - 1, 8) and int(fused.min()) >= 0 and int(fused.max()) < VT
+    agree = (fused == plain).all(-1).float().mean()
+    assert float(agree) >= 0.97, float(agree)
