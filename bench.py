@@ -319,11 +319,10 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     emu = wsh != world
     model = build_model(c, args)
     pre = precompute_info(model, c) if rank == 0 else None
-    # batches in flight: --streams lanes; the sharded CARS step leaves each rank 1/W of the work per step, so more steps must be in flight
-    # to keep a GPU busy (8 lanes = the 8 hardware queues)
+    # batches in flight: --streams lanes (BENCH_SHARD_LANES overrides it for the sharded CARS step)
     nlanes = max(1, args.streams)
     if sharded and c["model"] == "cars" and wsh > 1 and env.backend == "nccl":
-        nlanes = max(nlanes, int(os.environ.get("BENCH_SHARD_LANES", "8")))
+        nlanes = int(os.environ.get("BENCH_SHARD_LANES", nlanes))       # (8 lanes measured SLOWER than 4 in the 8-rank emulation: C3 0.111 vs 0.097 ms)
     nbatches = (max(args.nbatches, nlanes) + nlanes - 1) // nlanes * nlanes
     # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
     batches = make_batches(c, nbatches, 0 if sharded or not env.multi else rank, dev)

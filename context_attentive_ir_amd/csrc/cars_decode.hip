@@ -167,37 +167,35 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
             for (int u = 0; u < PA_TW; ++u)
 #pragma unroll
                 for (int bt = 0; bt < PA_NBT; ++bt) { acc[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            f16x8 wa[PA_TW][2], wb[PA_TW][2];
-            auto load_w = [&](int ks, f16x8 (&dst)[PA_TW][2]) {
+            // all of the tile pair's W fragments are requested up front (2 tiles x 8 k-steps x 2 terms x 16 B per lane = 128 VGPRs; one
+            // workgroup per CU has them to spare): ONE memory round trip per tile pair instead of one per k-step (first version: 32 us per
+            // launch = 0.96 TB/s on a 30.7 MB weight stream, latency-bound on 8 dependent round trips)
+            f16x8 wf[PA_KS][PA_TW][2];
+#pragma unroll
+            for (int ks = 0; ks < PA_KS; ++ks)
 #pragma unroll
                 for (int u = 0; u < PA_TW; ++u) {
                     const int64_t t = t0 + u < t_hi ? t0 + u : t_hi - 1;      // clamped: a duplicate tile's results are discarded below
                     const _Float16* wp = wfrag + ((t * PA_KS + ks) * 2 * 64 + lane) * 8;
-                    dst[u][0] = *reinterpret_cast<const f16x8*>(wp);
-                    dst[u][1] = *reinterpret_cast<const f16x8*>(wp + 512);
+                    wf[ks][u][0] = *reinterpret_cast<const f16x8*>(wp);
+                    wf[ks][u][1] = *reinterpret_cast<const f16x8*>(wp + 512);
                 }
-            };
-            load_w(0, wa);
-#define PA_STEP(KS, CUR, NXT)                                                                                          \
-            {                                                                                                          \
-                load_w((KS) + 1 < PA_KS ? (KS) + 1 : (KS), NXT);                                                         \
-                const _Float16* bp = pa_sm + c16 * PA_LD + 32 * (KS) + 8 * g4;                                           \
-                _Pragma("unroll") for (int bt = 0; bt < PA_NBT; ++bt) {                                                  \
-                    const f16x8 b1 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD);                              \
-                    const f16x8 b2 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD + PA_ROWS * PA_LD);            \
-                    _Pragma("unroll") for (int u = 0; u < PA_TW; ++u) {                                                  \
-                        acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[u][1], b1, acx[u][bt], 0, 0, 0);        \
-                        acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[u][0], b2, acx[u][bt], 0, 0, 0);        \
-                        acc[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[u][0], b1, acc[u][bt], 0, 0, 0);        \
-                    }                                                                                                    \
-                }                                                                                                        \
-            }
 #pragma unroll
-            for (int ks = 0; ks < PA_KS; ks += 2) {
-                PA_STEP(ks, wa, wb)
-                PA_STEP(ks + 1, wb, wa)
+            for (int ks = 0; ks < PA_KS; ++ks) {
+                const _Float16* bp = pa_sm + c16 * PA_LD + 32 * ks + 8 * g4;
+#pragma unroll
+                for (int bt = 0; bt < PA_NBT; ++bt) {
+                    const f16x8 b1 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD);
+                    const f16x8 b2 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD + PA_ROWS * PA_LD);
+#pragma unroll
+                    for (int u = 0; u < PA_TW; ++u) {
+                        acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][1], b1, acx[u][bt], 0, 0, 0);
+                        acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][0], b2, acx[u][bt], 0, 0, 0);
+                        acc[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][0], b1, acc[u][bt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads of later k-steps from being hoisted (384 more live registers: spills)
             }
-#undef PA_STEP
 #pragma unroll
             for (int u = 0; u < PA_TW; ++u) {
                 if (t0 + u >= t_hi) continue;                              // wave-uniform
