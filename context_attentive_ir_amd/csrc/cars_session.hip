@@ -196,12 +196,9 @@ struct LstmStepArgs {
 // NB = batch tiles of 16 rows that share one pass over the weights (B <= 16 NB): a weight fragment is loaded once per k-group and
 // feeds NB MFMA chains.  With the one-tile-at-a-time loop a 64-row batch (the C5 shape) walked the 6 MB of gate weights four times
 // per step and chain: 27 us per step against 8 us at B = 16.
-// NW = waves per workgroup that split K: 8 waves with every operand load of a wave issued before its first MFMA make the step ONE L2 round
-// trip deep for the session shapes (K = 256 + 512: 48 k-groups = 8 waves x 6) instead of three (4 waves, chunks of 4): 8.8 -> ~5 us per
-// session step at B = 16, and the decoder step (B = 96, K = 300 + 512) 20 -> ~9 us.
-template <int NB, int NW>
-__global__ __launch_bounds__(64 * NW) void lstm_step_kernel(LstmStepArgs p) {
-    __shared__ float red[NW][NB][256];
+template <int NB>
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
+    __shared__ float red[4][NB][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ch = blockIdx.y + p.chain0;
@@ -241,13 +238,16 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_kernel(LstmStepArgs p) {
         // k-groups in chunks of CH with all of a chunk's operand loads issued before its first MFMA.  (`#pragma unroll 4` on the
         // runtime-strided loop `for (q = wave; q < nq; q += 4)` was not honoured: every k-group waited for its own L2 round trip --
         // 12 round trips per step at I + H = 768.)  Unconditional loads from a clamped k, masked afterwards.
-        constexpr int CH = NB <= 2 ? 6 : 3;       // k-groups of a wave per round trip (CH * (1 + NB) float4 operand registers)
+        constexpr int CH = NB <= 2 ? 4 : 2;       // (8 measured slower at B = 16: the 4 x-part groups of a wave fill half a chunk; 8 WAVES per
+                                                  // workgroup with every load of a wave up front -- one round trip per step -- measured slower still,
+                                                  // round 3: 8.8 -> 12 us per session step, decoder step 20 -> 23 us: the 8-way LDS reduction and the
+                                                  // halved number of co-resident workgroups cost more than the two saved round trips)
         auto accumulate = [&](const float* wrow, const float* const (&rows)[NB], int K, int nq) {
-            for (int q0 = wave; q0 < nq; q0 += NW * CH) {
+            for (int q0 = wave; q0 < nq; q0 += 4 * CH) {
                 float4 a4[CH], b4[CH][NB];
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    const int k = 16 * (q0 + NW * c) + 4 * g;
+                    const int k = 16 * (q0 + 4 * c) + 4 * g;
                     const float km = k < K ? 1.f : 0.f;
                     const int kc = k < K ? k : 0;
                     a4[c] = *reinterpret_cast<const float4*>(wrow + kc);
@@ -277,16 +277,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_kernel(LstmStepArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][t][r * 64 + lane] = acc[t][r];
         __syncthreads();
-        for (int t = wave; t < NB; t += NW) {            // wave w finishes batch tiles w, w + NW, ..
+        for (int t = wave; t < NB; t += 4) {             // wave w finishes batch tiles w, w + 4, ..
             const int b = b0 + 16 * t + i;
             float g4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float sacc = 0.f;
-#pragma unroll
-                for (int w2 = 0; w2 < NW; ++w2) sacc += red[w2][t][r * 64 + lane];
-                g4[r] = bias[r] + sacc;
-            }
+            for (int r = 0; r < 4; ++r)
+                g4[r] = bias[r] + ((red[0][t][r * 64 + lane] + red[1][t][r * 64 + lane]) + (red[2][t][r * 64 + lane] + red[3][t][r * 64 + lane]));
             if (b < p.B && uv) {
                 const int64_t si = (int64_t)b * H + ud;
                 const float c0 = cprev ? cprev[si] : 0.f;
@@ -304,9 +300,9 @@ int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st) {
     if (a.B == 0) return 0;
     ProfScope ps("lstm_step_kernel", st);
     const dim3 grid((unsigned)((a.H + 3) / 4), (unsigned)nchains);
-    if (a.B > 32) hipLaunchKernelGGL((lstm_step_kernel<4, 8>), grid, dim3(512), 0, st, a);
-    else if (a.B > 16) hipLaunchKernelGGL((lstm_step_kernel<2, 8>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((lstm_step_kernel<1, 8>), grid, dim3(512), 0, st, a);
+    if (a.B > 32) hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, st, a);
+    else if (a.B > 16) hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, a);
     NIR_CHECK_LAUNCH("lstm_step_kernel");
     return 0;
 }
