@@ -332,7 +332,10 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     if sharded and c["model"] == "cars":
         # round 3: candidate-sharded encode -> all-to-all -> session-sharded tail -> all-gather of the probabilities (sharding.SessionShardPlan);
         # every per-rank input slice is resident in HBM like the full batch would be
-        plan = sharding.SessionShardPlan(c["batch"], c["session"], ncand, wsh, rank)
+        # BENCH_SHARD_AXIS: "auto" (default) = the flattened (session, candidate) pair axis in contiguous chunks when B % world == 0 -- each rank
+        # then encodes ALL candidates of B/world whole sessions: no padding of the candidate axis, no exchange of pooled vectors, only the
+        # all-gather of the probabilities -- else the candidate axis with the all-to-all exchange; "candidate" / "pair" force one of them
+        plan = sharding.SessionShardPlan(c["batch"], c["session"], ncand, wsh, rank, axis=os.environ.get("BENCH_SHARD_AXIS", "auto"))
         for b in batches:
             b["_q_own"], b["_ql_own"] = plan.own(b["source_words"]), plan.own(b["source_lens"])
             b["_doc_shard"], b["_len_shard"] = plan.doc_shard(b["document_words"], b["document_lens"])
@@ -359,6 +362,8 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         return model.shard_encode(ex["_q_own"], ex["_ql_own"], ex["_doc_shard"], ex["_len_shard"])
 
     def cars_exchange(key, pl, via_gather):
+        if plan.aligned:                                     # pair axis: this rank encoded all candidates of its own sessions
+            return pl.view(1, *pl.shape)
         recv = cars_bufs(key)[0]
         if via_gather:
             if (key, "g") not in coll:
@@ -505,7 +510,25 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             except Exception:
                 pass
             L.nir_set_batches_in_flight(len(lanes))
-    if staged:
+    if staged and plan.aligned:
+        try:      # pair axis: one hipGraph per batch ( encode own sessions -> tail -> probabilities ) + one eager all-gather of the probabilities
+            agraphs = []
+            for b in range(len(batches)):
+                ln, key = lanes[b % len(lanes)], ("aligned", b)
+                with torch.cuda.stream(ln):
+                    sharded_cars_step(batches[b], key)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=ln, capture_error_mode=CAPTURE_MODE):
+                    pq, pl = cars_encode(batches[b])
+                    po = cars_tail(batches[b], key, pq, cars_exchange(key, pl, False))
+                agraphs.append((g, po, key))
+            stages = {"aligned": agraphs, "nl": len(lanes), "nb": len(batches), "pos": 0}
+        except Exception as e:  # pragma: no cover
+            print("[bench] graph capture unavailable for %s (%s: %s); eager sharded steps" % (name, type(e).__name__, e), file=sys.stderr)
+            stages = None
+            torch.cuda.synchronize()
+    elif staged:
         try:
             nl, nb = len(lanes), len(batches)
             pipes = [sharding.SessionShardPipeline(plan, 256, dev) for _ in lanes]
@@ -571,6 +594,16 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     def run_steps(n):
         """exactly n steps: pipelined segments (sharded CARS), fused groups of KSTEP (+ one remainder group) on one stream, else one
         replay / eager call per step."""
+        if stages is not None and "aligned" in stages:
+            start = stages["pos"]
+            for i in range(start, start + n):
+                b = i % stages["nb"]
+                g, po, key = stages["aligned"][b]
+                with torch.cuda.stream(lanes[b % stages["nl"]]):
+                    g.replay()
+                    cars_gather(key, po)
+            stages["pos"] = start + n
+            return
         if stages is not None:
             # n encodes + n tails: every lane starts with an encode-only segment, runs full segments, and ends with a tail-only segment +
             # exchange that delivers the probabilities of its last step (the results of step k arrive with the exchange of step k + lanes)
@@ -759,6 +792,13 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     if env.multi:
         if not sharded:
             par = "x%d independent per-rank batches, no collective (weak scaling)" % world
+        elif plan is not None and plan.aligned:
+            par = ("strong: (session, candidate) pair axis in %d contiguous chunks = %d whole sessions x all %d candidates per rank (candidate documents "
+                   "sharded, no padding, no exchange of pooled vectors) -> session tail on the owning rank -> %s all-gather of probabilities; %s" % (
+                       wsh, plan.bper, ncand, "RCCL" if env.backend == "nccl" else env.backend,
+                       ("one hipGraph replay + one collective per step, %d lanes" % len(lanes)) if stages is not None else "eager"))
+            if emu:
+                par += " [EMULATED on one GPU: rank 0's 1/%d share of the work, loop-back collectives, no xGMI latency]" % wsh
         elif plan is not None:
             par = "strong: candidate-sharded encode x%d -> %s %s (%d B out per rank and step) -> session-sharded tail -> all-gather of probabilities; %s" % (
                 wsh, "RCCL" if env.backend == "nccl" else env.backend, "all-gather exchange" if fused is not None else "all-to-all",

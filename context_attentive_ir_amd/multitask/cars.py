@@ -357,7 +357,7 @@ class CARS(nn.Module, lib.IdCheck):
             # session-sharded tail (sharding.SessionShardPlan): candidate slice of every session -> all-to-all -> clicks / sessions / ranknet
             # for this rank's sessions only -> all-gather of the raw scores
             B, S, N = document_rep.shape[:3]
-            plan = sharding.SessionShardPlan(B, S, N, sharding.dist.get_world_size(group), sharding.dist.get_rank(group))
+            plan = sharding.SessionShardPlan(B, S, N, sharding.dist.get_world_size(group), sharding.dist.get_rank(group), axis="auto")
             d, l = plan.doc_shard(document_rep, document_len)
             docs = plan.assemble(plan.exchange(self.encode_document(d, l), group))
             s_own = self._rank_session(plan.own(pooled_rep), docs, plan.own(document_label), labels_all=document_label)[0]

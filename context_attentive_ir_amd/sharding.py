@@ -163,9 +163,26 @@ def gather_session_scores(local, N, group=None):
 # last one and dropped after the exchange / gather.
 # ----------------------------------------------------------------------------------------------------------
 class SessionShardPlan(object):
-    def __init__(self, B, S, N, world, rank):
+    """axis:
+      "candidate"  every rank encodes its slice of the N candidates of EVERY session (the split of SURVEY.md 8e), then the exchange above;
+      "pair"       the flattened (session, candidate) axis is cut into G contiguous chunks ("shard the flattened B*N pair
+                   axis in contiguous chunks -- equally valid").  With B % G == 0 a chunk is exactly B/G whole sessions x all N candidates:
+                   every rank encodes 1/G of the candidate documents WITHOUT padding the candidate axis (N = 50 over 8 ranks pads to 56) and
+                   already holds everything its sessions' tail needs -- the exchange disappears, only the all-gather of the scores remains.
+                   Requires B % G == 0;
+      "auto"       "pair" when B % G == 0, else "candidate"."""
+
+    def __init__(self, B, S, N, world, rank, axis="candidate"):
         self.B, self.S, self.N, self.world, self.rank = int(B), int(S), int(N), int(world), int(rank)
-        self.per = (self.N + self.world - 1) // self.world          # candidates per rank (padded)
+        if axis == "auto":
+            axis = "pair" if self.B % self.world == 0 else "candidate"
+        if axis not in ("candidate", "pair"):
+            raise ValueError("axis must be 'candidate', 'pair' or 'auto'")
+        if axis == "pair" and self.B % self.world:
+            raise ValueError("pair-axis sharding in whole sessions needs B %% world == 0 (B=%d, world=%d)" % (self.B, self.world))
+        self.axis = axis
+        self.aligned = axis == "pair"
+        self.per = self.N if self.aligned else (self.N + self.world - 1) // self.world   # candidates per rank and session (padded)
         self.bper = (self.B + self.world - 1) // self.world         # sessions per rank (padded)
         self._ids = {}
 
@@ -182,7 +199,10 @@ class SessionShardPlan(object):
         return t.index_select(0, ids).contiguous()
 
     def doc_shard(self, document_words, document_lens):
-        """[B,S,N,DL] / [B,S,N] -> this rank's candidate slice of every (padded) session: [G*bper,S,per,DL] / [G*bper,S,per]."""
+        """[B,S,N,DL] / [B,S,N] -> this rank's candidate slice of every (padded) session: [G*bper,S,per,DL] / [G*bper,S,per]
+        (pair axis: all N candidates of this rank's own sessions, [bper,S,N,DL] / [bper,S,N])."""
+        if self.aligned:
+            return self.own(document_words), self.own(document_lens)
         d, l = shard_session_candidates(document_words, document_lens, self.world, self.rank)
         ids = self.session_ids(d.device)
         return d.index_select(0, ids).contiguous(), l.index_select(0, ids).contiguous()
@@ -192,6 +212,9 @@ class SessionShardPlan(object):
         out [G,bper,S,per,D].  world 1: a view, no collective."""
         G, bper, S, per = self.world, self.bper, self.S, self.per
         D = pooled_shard.shape[-1]
+        if self.aligned:                                     # pair axis: the rank already holds all N candidates of its sessions
+            assert tuple(pooled_shard.shape) == (bper, S, per, D), tuple(pooled_shard.shape)
+            return pooled_shard.view(1, bper, S, per, D)
         assert tuple(pooled_shard.shape) == (G * bper, S, per, D), tuple(pooled_shard.shape)
         if G == 1 and not (dist.is_available() and dist.is_initialized()):
             return pooled_shard.view(1, bper, S, per, D)
@@ -207,6 +230,8 @@ class SessionShardPlan(object):
         tools/rccl_capture_probe.py).  out (optional): [G, G*bper, S, per, D] gather buffer.  -> view [G,bper,S,per,D]."""
         G, bper, S, per = self.world, self.bper, self.S, self.per
         D = pooled_shard.shape[-1]
+        if self.aligned:
+            return self.exchange(pooled_shard, group)
         assert tuple(pooled_shard.shape) == (G * bper, S, per, D), tuple(pooled_shard.shape)
         if G == 1 and not (dist.is_available() and dist.is_initialized()):
             return pooled_shard.view(1, bper, S, per, D)
@@ -232,8 +257,8 @@ class SessionShardPlan(object):
         return out[:self.B]
 
     def exchange_bytes(self, D, itemsize=4):
-        """bytes this rank sends over xGMI per step (the chunk it keeps is excluded)."""
-        return (self.world - 1) * self.bper * self.S * self.per * D * itemsize
+        """bytes this rank sends over xGMI per step for the pooled vectors (the chunk it keeps is excluded; pair axis: none)."""
+        return 0 if self.aligned else (self.world - 1) * self.bper * self.S * self.per * D * itemsize
 
 
 def session_sharded_click_probs(plan, encode_q, encode_docs, session_tail, ex, group=None, via_gather=False):
@@ -262,6 +287,8 @@ class SessionShardPipeline(object):
     Results lag one step: `flush()` after the last step delivers its probabilities."""
 
     def __init__(self, plan, D, device, dtype=torch.float32):
+        if plan.aligned:
+            raise ValueError("pair-axis plans have no exchange to pipeline: encode -> tail -> all-gather of the probabilities per step")
         self.plan, self.D = plan, int(D)
         G, bper, S, per, N = plan.world, plan.bper, plan.S, plan.per, plan.N
         self.n_pool, self.n_prob = bper * S * per * self.D, bper * S * N

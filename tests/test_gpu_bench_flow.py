@@ -31,19 +31,24 @@ def test_bench_single_gpu_line():
     assert d["config"]["sub"]["C1_esm"]["pairs_per_s"] > 0
 
 
-def test_bench_two_ranks_strong_scaling_flow():
-    env = dict(os.environ, BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--sub", "C2_match_tensor"]
+@pytest.mark.parametrize("axis,needle,port", [("auto", "pair axis in 2 contiguous chunks = 8 whole sessions", "29541"),
+                                              ("candidate", "session-sharded tail", "29543")])
+def test_bench_two_ranks_strong_scaling_flow(axis, needle, port):
+    """bench.py --gpus 2 as the driver launches it (two ranks on the one GPU, gloo): the sharded CARS headline in both shard axes, a sharded
+    ranker sub-record, the labelled weak-scaling figure."""
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SHARD_AXIS=axis)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--sub", "C2_match_tensor" if axis == "auto" else "none"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["world_size"] == 2 and "session-sharded tail" in d["config"]["parallelism"]
+    assert d["config"]["world_size"] == 2 and needle in d["config"]["parallelism"], d["config"]["parallelism"]
     assert d["config"]["weak_scaling_pairs_per_s"] > 0
-    sub = d["config"]["sub"]["C2_match_tensor"]
-    assert sub["world_size"] == 2 and "5 per rank" in sub["parallelism"] and sub["pairs_per_s"] > 0
+    if axis == "auto":
+        sub = d["config"]["sub"]["C2_match_tensor"]
+        assert sub["world_size"] == 2 and "5 per rank" in sub["parallelism"] and sub["pairs_per_s"] > 0
 
 
 def test_two_rank_sharding_reproduces_single_rank_scores():
@@ -56,16 +61,19 @@ def test_two_rank_sharding_reproduces_single_rank_scores():
     assert "SHARDED_OK" in out.stdout
 
 
-def test_bench_rccl_sharded_step_is_graph_replayed():
-    """The RCCL path of the sharded CARS step (world size 1 over a real RCCL process group, BENCH_FORCE_DIST): two hipGraphs around the
-    one eager all-gather -- an eager sharded step is host-bound (0.43 ms of enqueue per step against 0.22 ms of GPU time)."""
-    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_PORT="29553")
+@pytest.mark.parametrize("axis,emulate", [("auto", "1"), ("candidate", "4"), ("pair", "8")])
+def test_bench_rccl_sharded_step_is_graph_replayed(axis, emulate):
+    """The RCCL path of the sharded CARS step over a real (1-rank) RCCL process group (BENCH_FORCE_DIST; BENCH_EMULATE_WORLD gives this
+    process rank 0's share of a larger world): hipGraph replays around eager collectives -- pair axis: one graph + the all-gather of the
+    probabilities; candidate axis: the software-pipelined segment graphs + ONE all-to-all per step."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_PORT="29553", BENCH_SHARD_AXIS=axis, BENCH_EMULATE_WORLD=emulate, BENCH_NO_H2D="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--sub", "none", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "staged graph capture unavailable" not in out.stderr
+    assert "graph capture unavailable" not in out.stderr
     d = _last_json(out.stdout)
     assert d["scaling"] == "strong" and d["config"]["hipgraph"] is True and d["value"] > 0
+    assert ("pair axis" in d["config"]["parallelism"]) == (axis != "candidate")
     assert d["config"]["host_enqueue_ms_per_step"] < d["ms_per_step"] * 1.05
 
 

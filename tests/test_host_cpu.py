@@ -198,6 +198,10 @@ for B, S, N in ((4, 3, 5), (3, 2, 9), (1, 3, 2), (5, 2, 4)):        # B, N divis
     assert got.shape == full.shape and torch.allclose(got, full, atol=1e-6), (rank, B, N, float((got - full).abs().max()))
     got2 = sharding.session_sharded_click_probs(plan, enc_q, enc_d, tail, ex, via_gather=True)       # the capturable form of the exchange
     assert torch.equal(got2, got), (rank, B, N)
+    auto = sharding.SessionShardPlan(B, S, N, world, rank, axis="auto")
+    assert auto.aligned == (B % world == 0) and auto.exchange_bytes(256) == (0 if auto.aligned else plan.exchange_bytes(256))
+    got3 = sharding.session_sharded_click_probs(auto, enc_q, enc_d, tail, ex)       # pair axis (whole sessions per rank) when B % world == 0
+    assert got3.shape == full.shape and torch.allclose(got3, full, atol=1e-6), (rank, B, N, auto.axis)
     # a block evaluated WITHOUT the batch-wide labels differs whenever its own max click count is smaller: the quirk is really exercised
     cnt = lambda l: int((l.reshape(-1, N) != 0).sum(1).max())
     if B > 1 and world > 1 and rank == 0 and cnt(plan.own(ex["document_labels"])) < min(cnt(ex["document_labels"]), N - 1):
