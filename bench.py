@@ -255,6 +255,16 @@ def precompute_info(wrapper, c):
             "tables": len(tabs), "rebuilt": "once per weight version (PackCache); not part of a step"}
 
 
+def macro_batch(c, env_key="BENCH_MACRO_BATCH"):
+    """batches merged into one macro-batch per graph replay (Multitask.predict_many): small batches (C3: 1 120 documents) are merged four at a
+    time -- a lone C3 batch fills 140 of 256 CUs with recurrence workgroups and pays 76 MB of session-weight traffic whatever its size --
+    large ones (C5: 22 400 documents) are not (no gain measured, 4x the scratch).  The environment variable overrides."""
+    if os.environ.get(env_key):
+        return max(1, int(os.environ[env_key]))
+    docs = c["batch"] * c.get("session", 1) * c["cands"]
+    return max(1, min(8, 4480 // max(1, docs)))
+
+
 def make_batches(c, nbatches, rank_seed, dev):
     out = []
     for i in range(nbatches):
@@ -324,6 +334,9 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     if sharded and c["model"] == "cars" and wsh > 1 and env.backend == "nccl":
         nlanes = int(os.environ.get("BENCH_SHARD_LANES", nlanes))       # (8 lanes measured SLOWER than 4 in the 8-rank emulation: C3 0.111 vs 0.097 ms)
     nbatches = (max(args.nbatches, nlanes) + nlanes - 1) // nlanes * nlanes
+    if c["model"] == "cars" and not args.no_graph:       # macro-batched CARS paths: every lane gets whole groups of KG batches
+        kg = macro_batch(c, "BENCH_GATHER_EVERY" if env.multi else "BENCH_MACRO_BATCH")
+        nbatches = (max(args.nbatches, kg * nlanes) + kg * nlanes - 1) // (kg * nlanes) * (kg * nlanes)
     # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
     batches = make_batches(c, nbatches, 0 if sharded or not env.multi else rank, dev)
     pairs_global = c["batch"] * c["cands"] * (c["session"] if is_sess else 1)
@@ -510,20 +523,63 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             except Exception:
                 pass
             L.nir_set_batches_in_flight(len(lanes))
-    if staged and plan.aligned:
-        try:      # pair axis: one hipGraph per batch ( encode own sessions -> tail -> probabilities ) + one eager all-gather of the probabilities
-            agraphs = []
-            for b in range(len(batches)):
-                ln, key = lanes[b % len(lanes)], ("aligned", b)
+    macro_single = plan is None and c["model"] == "cars" and not env.multi and not args.no_graph and not c.get("nofold") and macro_batch(c) > 1
+    if (staged and plan.aligned) or macro_single:
+        try:
+            # pair axis: a lane's hipGraph holds KG whole steps ( encode own sessions -> tail -> probabilities ) merged into one macro-batch,
+            # followed by ONE eager all-gather of the KG probability blocks.  Results lag by at most KG - 1 steps.
+            KG = macro_batch(c, "BENCH_MACRO_BATCH" if macro_single else "BENCH_GATHER_EVERY")
+            nl, nb = len(lanes), len(batches)
+            agroups = {}
+            gbuf = {}
+            bper_, S_ = (c["batch"], c["session"]) if macro_single else (plan.bper, plan.S)
+
+            def group_bufs(gb, k):
+                if (gb, k) not in gbuf:
+                    gbuf[(gb, k)] = (torch.zeros(k, bper_, S_, ncand, device=dev),
+                                     None if macro_single else torch.zeros(plan.world, k, bper_, S_, ncand, device=dev))
+                return gbuf[(gb, k)]
+
+            def capture_aligned(gb, k):
+                """steps on batches KG*gb .. KG*gb + k - 1 (mod nb), lane gb % nl"""
+                ln = lanes[gb % nl]
+                mine, allg = group_bufs(gb, k)
+                if macro_single:      # single GPU: Multitask.predict_many over k whole batches (concatenation included in the graph)
+                    exs = [batches[(KG * gb + j) % nb] for j in range(k)]
+
+                    def body1():
+                        model.predict_many(exs, out=mine.view(k * bper_, S_, ncand))
+                    with torch.cuda.stream(ln):
+                        body1()
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=ln, capture_error_mode=CAPTURE_MODE):
+                        body1()
+                    return g, mine, None
+
+                # the k blocks (this rank's sessions of k consecutive batches) run as ONE macro-batch: one encode over k x the sequences, one
+                # tail over k x bper sessions -- the session LSTM / ranknet weights (76 MB of L2 traffic per tail at C3, whatever the number
+                # of sessions) are streamed once for all k; every block keeps the click count m of ITS OWN batch (labels_groups)
+                exs = [batches[(KG * gb + j) % nb] for j in range(k)]
+                mq, mql = torch.cat([e["_q_own"] for e in exs]), torch.cat([e["_ql_own"] for e in exs])
+                md, ml = torch.cat([e["_doc_shard"] for e in exs]), torch.cat([e["_len_shard"] for e in exs])
+                mlab, mall = torch.cat([e["_lab_own"] for e in exs]), torch.stack([e["document_labels"] for e in exs])
+
+                def body():
+                    pq, pl = model.shard_encode(mq, mql, md, ml)
+                    model.tail_probs(pq, pl, mlab, None, probs=mine.view(k * plan.bper, plan.S, ncand), labels_groups=mall)
                 with torch.cuda.stream(ln):
-                    sharded_cars_step(batches[b], key)
+                    body()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=ln, capture_error_mode=CAPTURE_MODE):
-                    pq, pl = cars_encode(batches[b])
-                    po = cars_tail(batches[b], key, pq, cars_exchange(key, pl, False))
-                agraphs.append((g, po, key))
-            stages = {"aligned": agraphs, "nl": len(lanes), "nb": len(batches), "pos": 0}
+                    body()
+                return g, mine, (allg[:1] if emu else allg)      # noqa: E501
+
+            ngroups = (nb + KG - 1) // KG
+            for gb in range(ngroups):
+                agroups[(gb, KG)] = capture_aligned(gb, KG)
+            stages = {"aligned": agroups, "capture": capture_aligned, "KG": KG, "ngroups": ngroups, "nl": nl, "pos": 0}
         except Exception as e:  # pragma: no cover
             print("[bench] graph capture unavailable for %s (%s: %s); eager sharded steps" % (name, type(e).__name__, e), file=sys.stderr)
             stages = None
@@ -567,7 +623,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             stages = None
             torch.cuda.synchronize()
     # the sharded CARS step contains a collective (all-gather of the pooled documents) between its kernels: staged graphs above, else eager
-    use_graph = not args.no_graph and not (sharded and is_sess) and not (env.backend != "nccl" and env.multi) and fused is None
+    use_graph = not args.no_graph and not (sharded and is_sess) and not (env.backend != "nccl" and env.multi) and fused is None and stages is None
     if use_graph:
         try:
             graphs = []
@@ -595,14 +651,20 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         """exactly n steps: pipelined segments (sharded CARS), fused groups of KSTEP (+ one remainder group) on one stream, else one
         replay / eager call per step."""
         if stages is not None and "aligned" in stages:
-            start = stages["pos"]
-            for i in range(start, start + n):
-                b = i % stages["nb"]
-                g, po, key = stages["aligned"][b]
-                with torch.cuda.stream(lanes[b % stages["nl"]]):
+            KG, gi, left = stages["KG"], stages["pos"], n
+            while left > 0:
+                k = min(KG, left)
+                gb = gi % stages["ngroups"]
+                if (gb, k) not in stages["aligned"]:           # remainder group (captured before the timed region, see below)
+                    stages["aligned"][(gb, k)] = stages["capture"](gb, k)
+                g, mine, allg = stages["aligned"][(gb, k)]
+                with torch.cuda.stream(lanes[gb % stages["nl"]]):
                     g.replay()
-                    cars_gather(key, po)
-            stages["pos"] = start + n
+                    if allg is not None:
+                        env.dist.all_gather_into_tensor(allg.view(-1, *mine.shape[1:]), mine)     # [G*k, bper, S, N] <- [k, bper, S, N]
+                gi += 1
+                left -= k
+            stages["pos"] = gi
             return
         if stages is not None:
             # n encodes + n tails: every lane starts with an encode-only segment, runs full segments, and ends with a tail-only segment +
@@ -635,6 +697,10 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     fused["rem"][rem] = fused["capture"](2 * KSTEP, rem)
                 fused["rem"][rem][0].replay()
 
+    if stages is not None and "aligned" in stages:      # dry run of every call pattern below: remainder groups get captured now
+        for n in (max(warmup, 1), steps, max(6, min(steps, 60))):
+            run_steps(n)
+        torch.cuda.synchronize()
     if fused is not None:                    # remainder groups are captured before the timed region
         for n in {max(warmup, 1) % KSTEP, steps % KSTEP, max(6, min(steps, 60)) % KSTEP} - {0}:
             fused["rem"][n] = fused["capture"](2 * KSTEP, n)
@@ -667,13 +733,38 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         torch.cuda.synchronize()
         env.barrier()
         ts = time.perf_counter()
-        if fused is not None or stages is not None:   # (fused / pipelined steps: "one in flight" has no separate meaning there)
+        if macro_single and stages is not None:
+            # macro-batched single-GPU path: the latency figure is ONE batch through its own hipGraph, nothing else in flight; and the
+            # macro-batched probabilities are checked against that single-batch path
+            g1 = torch.cuda.CUDAGraph()
+            L.nir_set_batches_in_flight(1)                 # a lone batch: the library forks its query / document chains onto two streams
+            with torch.cuda.stream(lanes[0]):
+                forward(0)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g1, stream=lanes[0], capture_error_mode=CAPTURE_MODE):
+                o1 = forward(0)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            with torch.cuda.stream(lanes[0]):
+                for i in range(ns):
+                    g1.replay()
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - ts) / ns * 1e3
+            L.nir_set_batches_in_flight(len(lanes))
+            mg_, mine_, _ = stages["aligned"][(0, stages["KG"])]
+            with torch.cuda.stream(lanes[0]):
+                mg_.replay()
+            torch.cuda.synchronize()
+            overlap_diff = float((mine_[0] - o1).abs().max())
+            ts = None
+        elif fused is not None or stages is not None:   # (fused / pipelined steps: "one in flight" has no separate meaning there)
             run_steps(ns)
         else:
             for i in range(ns):
                 run(i, only_lane=0)
         torch.cuda.synchronize()
-        single_ms = (time.perf_counter() - ts) / ns * 1e3
+        if ts is not None:
+            single_ms = (time.perf_counter() - ts) / ns * 1e3
         env.barrier()
 
     # ---- H2D-inclusive figure: ids arrive from the HOST for every batch (collate into pinned staging -> H2D -> replay -> D2H of the
@@ -688,15 +779,17 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
                 corpus = SyntheticSessionCorpus(n_sessions=64 * c["batch"], n_cands=c["cands"], qlen=c["qlen"], dlen=c["dlen"], vocab=c["vocab"],
                                                 fixed_len=c["session"], pool=64)
-                sp = StreamingSessionPredictor(model, c["cands"], c["qlen"], c["dlen"], c["batch"], max_session_len=c["session"],
-                                               lanes=len(lanes), slots=2)
-                bl = corpus.batches(c["batch"])
+                mk = macro_batch(c)
+                sp = StreamingSessionPredictor(model, c["cands"], c["qlen"], c["dlen"], mk * c["batch"], max_session_len=c["session"],
+                                               lanes=len(lanes), slots=2, macro=mk)
+                bl, _ = sp.merge_batches(corpus, corpus.batches(c["batch"]), mk)
                 sp.prepare([c["session"]], example=(corpus, bl[0]))
                 sp.run(corpus, bl, max_batches=8 * len(lanes))
                 h2d_info = sp.run(corpus, bl, min_seconds=secs)
                 h2d_value = h2d_info["pairs_per_s"]
                 h2d_info = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in h2d_info.items()}
                 h2d_info["wire"] = "int32 ids/lengths + float32 labels, widened on device (nir_widen_ids_i32)"
+                h2d_info["macro_batch"] = mk
                 del sp
             else:
                 from context_attentive_ir_amd.graph_runner import GraphedPredictor
@@ -796,7 +889,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             par = ("strong: (session, candidate) pair axis in %d contiguous chunks = %d whole sessions x all %d candidates per rank (candidate documents "
                    "sharded, no padding, no exchange of pooled vectors) -> session tail on the owning rank -> %s all-gather of probabilities; %s" % (
                        wsh, plan.bper, ncand, "RCCL" if env.backend == "nccl" else env.backend,
-                       ("one hipGraph replay + one collective per step, %d lanes" % len(lanes)) if stages is not None else "eager"))
+                       ("%d steps per hipGraph replay + one collective, %d lanes" % (stages["KG"], len(lanes))) if stages is not None else "eager"))
             if emu:
                 par += " [EMULATED on one GPU: rank 0's 1/%d share of the work, loop-back collectives, no xGMI latency]" % wsh
         elif plan is not None:
@@ -816,7 +909,9 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 world, batches[0]["doc_rep"].shape[1], "RCCL" if env.backend == "nccl" else env.backend)
     return {"name": name, "baseline_config": c.get("baseline"), "workload": tag, "pairs_per_s": round(value, 1), "ms_per_step": round(ms_per_step, 5),
             "ms_per_step_one_batch_in_flight": round(single_ms, 5), "global_batch_pairs": per_step_pairs, "parallelism": par, "world_size": world,
-            "steps": steps, "hipgraph": (graphs is not None) or (stages is not None) or (fused is not None), "batches_in_flight": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
+            "steps": steps, "hipgraph": (graphs is not None) or (stages is not None) or (fused is not None),
+            "batches_in_flight": len(lanes) * (stages["KG"] if (stages is not None and "aligned" in stages) else 1),
+            "macro_batch": (stages["KG"] if (stages is not None and "aligned" in stages) else 1), "lanes": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
             "h2d_inclusive_over_resident": None if h2d_value is None else round(h2d_value / value, 4), "h2d_stream": h2d_info,
             "dtype": c.get("dtype", "f32"), "precompute": pre, "roofline": roofline, "cpu_baseline": cpu}
@@ -991,7 +1086,13 @@ def stream_record(args, env, seconds=None, n_sessions=223876):
         t_corpus = time.perf_counter() - t0
         lengths = sorted({int(corpus.lengths[b[0]]) for b in bl})
         nl = max(2, min(args.streams, 4))
-        sp = StreamingSessionPredictor(model, c["cands"], c["qlen"], c["dlen"], c["batch"], max_session_len=max(lengths), lanes=nl, slots=2)
+        mk = max(1, int(os.environ.get("BENCH_STREAM_MACRO", "1")))       # (64 x S x 50 per batch: macro 2 measured +1 %, macro 4 runs out of HBM)
+        sp = StreamingSessionPredictor(model, c["cands"], c["qlen"], c["dlen"], mk * c["batch"], max_session_len=max(lengths), lanes=nl, slots=2, macro=mk)
+        n_sampler_batches = len(bl)
+        # mk sampler batches of one session length per wire block / graph replay; the < mk left-over batches per length are not part of this
+        # measurement (`left_over_batches_not_timed`; a full run scores them through a macro = 1 predictor)
+        bl, rest = sp.merge_batches(corpus, bl, mk)
+        lengths = sorted({int(corpus.lengths[b[0]]) for b in bl})
         t0 = time.perf_counter()
         sp.prepare(lengths, example=(corpus, bl[0]))
         torch.cuda.synchronize()
@@ -1002,12 +1103,13 @@ def stream_record(args, env, seconds=None, n_sessions=223876):
         return {"name": "C5_stream", "baseline_config": "configs[4]: CARS at MSMARCO scale: ~224k-session stream, 50 candidates/query, bf16 (one GPU's share measured here)",
                 "workload": "cars bf16, %d sessions, S ~ clip(Poisson(4.84)+2,2,16) (mean %.2f), %d candidates, q_len %d, doc_len %d, batches of %d equal-length "
                             "sessions (reference sampler), ids from the host per batch" % (len(corpus), float(corpus.lengths.mean()), c["cands"], c["qlen"], c["dlen"], c["batch"]),
-                "pairs_per_s": round(r["pairs_per_s"], 1), "sessions_per_s": round(r["batches"] * c["batch"] / r["seconds"], 1), "batches": r["batches"],
+                "pairs_per_s": round(r["pairs_per_s"], 1), "sessions_per_s": round(r["batches"] * mk * c["batch"] / r["seconds"], 1), "batches": r["batches"] * mk,
+                "macro_batch": mk, "sampler_batches": n_sampler_batches, "left_over_batches_not_timed": len(rest),
                 "whole_stream": seconds is None, "seconds": round(r["seconds"], 3), "h2d_GBps": round(r["h2d_GBps"], 3), "lanes": r["lanes"],
                 "slots_per_lane": r["slots_per_lane"], "producer_threads": r["producers"], "session_lengths": lengths, "length_histogram": hist,
                 "graphs": len(lengths) * nl, "graph_capture_s": round(t_capture, 2), "corpus_build_s": round(t_corpus, 2), "dtype": "bf16",
                 "wire": "int32 ids/lengths + float32 labels (nir_widen_ids_i32 on device); D2H of the click probabilities included",
-                "ms_per_step": round(r["seconds"] / max(1, r["batches"]) * 1e3, 5)}
+                "ms_per_step": round(r["seconds"] / max(1, r["batches"] * mk) * 1e3, 5)}
     except Exception as e:  # pragma: no cover
         return {"name": "C5_stream", "error": "%s: %s" % (type(e).__name__, e)}
 

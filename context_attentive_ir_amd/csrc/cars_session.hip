@@ -34,12 +34,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restrict__ docs, const float* __restrict__ epart, int NP,
                                                           const float* __restrict__ b3, const float* __restrict__ labels,
                                                           const float* __restrict__ labels_all, int rows_all,
+                                                          const int* __restrict__ mg, int rpg,
                                                           int rows, int N, int D, float* __restrict__ clicks) {
     // labels_all [rows_all, N]: the label matrix the batch-wide click count m is taken over -- the rows of this call, or (session-sharded
-    // callers) those of the whole global batch, of which `labels` [rows, N] is this rank's block of sessions
+    // callers) those of the whole global batch, of which `labels` [rows, N] is this rank's block of sessions.
+    // mg != NULL: the rows of this call come from several batches (rpg consecutive rows per batch) whose m was computed beforehand
+    // (nir_cars_click_max): row r uses mg[r / rpg] and the scan below is skipped.
     __shared__ int part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {   // every workgroup recomputes m from the (tiny) label matrix: no extra launch, no cross-workgroup dependency
+    if (!mg) {   // every workgroup recomputes m from the (tiny) label matrix: no extra launch, no cross-workgroup dependency
         // (N <= 64: one label per lane, the row's count is the population count of a ballot -- a DPP wave_sum per row made this
         // prologue 112 x ~150 cycles per workgroup at the C5 shape)
         int best = 0;
@@ -56,9 +59,9 @@ __global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restric
         if (lane == 0) part[wave] = best;
     }
     __syncthreads();
-    const int m = max(max(part[0], part[1]), max(part[2], part[3]));
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;
+    const int m = mg ? mg[r / rpg] : max(max(part[0], part[1]), max(part[2], part[3]));
     const float lab = lane < N ? labels[(int64_t)r * N + lane] : -INFINITY;
     int rank = 0;
 #pragma unroll 8
@@ -94,16 +97,33 @@ __global__ __launch_bounds__(256) void click_pool2_kernel(const float* __restric
     }
 }
 
+// m[g] = max over the rows of group g of count_nonzero(labels[g, row, :])  (cars.py:285-289): one workgroup per group
+__global__ __launch_bounds__(256) void click_max_kernel(const float* __restrict__ labels, int rows, int N, int* __restrict__ out) {
+    __shared__ int part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* lg = labels + (int64_t)blockIdx.x * rows * N;
+    int best = 0;
+    for (int r = wave; r < rows; r += 4) {
+        float c = 0.f;
+        for (int k = lane; k < N; k += 64) c += lg[(int64_t)r * N + k] != 0.f ? 1.f : 0.f;
+        best = max(best, (int)wave_sum(c));
+    }
+    if (lane == 0) part[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
 // The same for N > 64 candidates (config.py:42: --num_candidates is free): a lane owns candidates lane, lane + 64, ..; the row's labels and
 // softmax weights are staged in LDS (dynamic: 4 waves x 2 x N floats).  Not a hot shape: plain loops.
 __global__ __launch_bounds__(256) void click_pool_big_kernel(const float* __restrict__ docs, const float* __restrict__ epart, int NP,
                                                              const float* __restrict__ b3, const float* __restrict__ labels,
-                                                             const float* __restrict__ labels_all, int rows_all, int rows, int N, int D,
+                                                             const float* __restrict__ labels_all, int rows_all,
+                                                             const int* __restrict__ mg, int rpg, int rows, int N, int D,
                                                              float* __restrict__ clicks) {
     extern __shared__ float csm[];
     __shared__ int part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
+    if (!mg) {
         int best = 0;
         for (int r = wave; r < rows_all; r += 4) {
             float c = 0.f;
@@ -113,9 +133,9 @@ __global__ __launch_bounds__(256) void click_pool_big_kernel(const float* __rest
         if (lane == 0) part[wave] = best;
     }
     __syncthreads();
-    const int m = max(max(part[0], part[1]), max(part[2], part[3]));
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;                                 // (no workgroup barrier below this line)
+    const int m = mg ? mg[r / rpg] : max(max(part[0], part[1]), max(part[2], part[3]));
     float* lab = csm + (size_t)wave * 2 * N;
     float* pw = lab + N;
     float cnt = 0.f;
@@ -499,7 +519,7 @@ extern "C" int nir_cars_rank_session(const float* pooled_q, const float* pooled_
                                      float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
                                      nir_stream_t stream) {
     return nir_cars_rank_session_rows(pooled_q, pooled_docs, labels, B, S, N, w, workspace, workspace_bytes, click_scores, clicks_out, extra,
-                                      nullptr, 0, nullptr, 0, stream);
+                                      nullptr, 0, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int nir_cars_rank_session_shard(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
@@ -507,13 +527,22 @@ extern "C" int nir_cars_rank_session_shard(const float* pooled_q, const float* p
                                            float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
                                            const float* rank_docs, int NR, nir_stream_t stream) {
     return nir_cars_rank_session_rows(pooled_q, pooled_docs, labels, B, S, N, w, workspace, workspace_bytes, click_scores, clicks_out, extra,
-                                      rank_docs, NR, nullptr, 0, stream);
+                                      rank_docs, NR, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int nir_cars_click_max(const float* labels, int groups, int rows, int N, int* m_out, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(labels && m_out && groups > 0 && rows > 0 && N > 0, "cars_click_max: bad args");
+    hipLaunchKernelGGL(click_max_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, labels, rows, N, m_out);
+    NIR_CHECK_LAUNCH("click_max_kernel");
+    return 0;
 }
 
 extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
                                           const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
                                           float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
-                                          const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, nir_stream_t stream) {
+                                          const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, const int* m_groups,
+                                          int sessions_per_group, nir_stream_t stream) {
     using namespace nir;
     hipStream_t st = (hipStream_t)stream;
     NIR_REQUIRE(pooled_q && w, "cars_rank_session: null pointer");
@@ -527,6 +556,7 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
     NIR_REQUIRE(!labels_all || (rows_all >= (int64_t)B * S && rows_all < (1 << 30)), "cars_rank_session: labels_all must hold at least the B*S rows of this call");
     NIR_REQUIRE(!rank_docs || (NR > 0 && NR <= N), "cars_rank_session: the ranked candidate slice must hold 1..N candidates (got %d)", NR);
     NIR_REQUIRE(S <= 4096, "cars_rank_session: session length %d > 4096 unsupported", S);
+    NIR_REQUIRE(!m_groups || (sessions_per_group > 0 && !labels_all), "cars_rank_session: m_groups needs sessions_per_group > 0 and excludes labels_all");
     NIR_REQUIRE(w->D % 64 == 0 && w->HS % 16 == 0 && w->D % 16 == 0, "cars_rank_session: D %% 64 / HS %% 16 required");
     if (B == 0) return 0;
     const int D = w->D, HS = w->HS, NP = D / 16;
@@ -548,10 +578,10 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
             const int rall = labels_all ? (int)rows_all : (int)BS;
             if (N <= 64)
                 hipLaunchKernelGGL(click_pool2_kernel, dim3((unsigned)((BS + 3) / 4)), dim3(256), 0, st, pooled_docs, p.epart, NP, w->click3_b, labels,
-                                   lall, rall, (int)BS, N, D, clicks);
+                                   lall, rall, m_groups, sessions_per_group * S, (int)BS, N, D, clicks);
             else
                 hipLaunchKernelGGL(click_pool_big_kernel, dim3((unsigned)((BS + 3) / 4)), dim3(256), (size_t)4 * 2 * N * sizeof(float), st, pooled_docs,
-                                   p.epart, NP, w->click3_b, labels, lall, rall, (int)BS, N, D, clicks);
+                                   p.epart, NP, w->click3_b, labels, lall, rall, m_groups, sessions_per_group * S, (int)BS, N, D, clicks);
         }
         NIR_CHECK_LAUNCH("click_pool2_kernel");
     }

@@ -167,10 +167,16 @@ class StreamingSessionPredictor(object):
     Shapes: batches of exactly `batch_size` sessions of one length (the reference sampler's composition,
     neuroir/inputters/multitask/data.py:42-72); a new length is captured on first use (outside any timed region: `prepare`)."""
 
-    def __init__(self, wrapper, n_cands, qlen, dlen, batch_size, max_session_len=16, lanes=2, slots=2):
+    def __init__(self, wrapper, n_cands, qlen, dlen, batch_size, max_session_len=16, lanes=2, slots=2, macro=1):
+        """macro > 1: a wire block / graph replay carries `macro` batches of one session length as ONE macro-batch (Multitask.predict_groups:
+        one pass over the session weights for all of them, every batch keeps its own click count); `batch_size` is then macro x the
+        sampler's batch size and run() expects index lists of that length (see merge_batches)."""
         from .inputters.session_stream import WireLayout
         if not wrapper.use_cuda:
             raise RuntimeError("StreamingSessionPredictor needs a wrapper on a ROCm device (call .cuda() first)")
+        self.macro = max(1, int(macro))
+        if int(batch_size) % self.macro:
+            raise RuntimeError("batch_size must be macro x the sampler's batch size")
         self.wrapper, self.B, self.N, self.QL, self.DL = wrapper, int(batch_size), int(n_cands), int(qlen), int(dlen)
         self.WireLayout = WireLayout
         self.dev = next(wrapper.network.parameters()).device
@@ -193,6 +199,8 @@ class StreamingSessionPredictor(object):
         wide = lay.wide_views(ln["wide"])
         lib.check(lib.load().nir_widen_ids_i32(lib.ptr(ln["wire"]), lib.ptr(ln["wide"]), lay.n_int, lib.stream()), "nir_widen_ids_i32")
         ex = dict(wide, document_labels=lay.views(ln["wire"])["document_labels"])
+        if self.macro > 1:
+            return self.wrapper.predict_groups(ex, self.macro)
         return self.wrapper.predict(ex, suggest=False)["click_scores"]
 
     def prepare(self, lengths, example=None):
@@ -242,6 +250,21 @@ class StreamingSessionPredictor(object):
         """click probabilities [B,S,N] of the batch submitted from (lane, slot) -- host tensor (valid until the slot is re-submitted)."""
         self.lanes[lane]["done"][slot].synchronize()
         return self.lanes[lane]["res"][slot][:lay.pairs].view(lay.B, lay.S, lay.N)
+
+    @staticmethod
+    def merge_batches(corpus, batches, macro):
+        """the sampler's batches (equal-length sessions each) -> macro-batches: `macro` batches of ONE session length concatenated (left-over
+        batches of a length are dropped from the macro list and returned separately).  Batch composition is untouched; only the order in
+        which batches are scored changes."""
+        by_len, out, rest = {}, [], []
+        for b in batches:
+            by_len.setdefault(int(corpus.lengths[b[0]]), []).append(list(b))
+        for S_, bl in by_len.items():
+            full = len(bl) // macro * macro
+            for i in range(0, full, macro):
+                out.append([x for b in bl[i:i + macro] for x in b])
+            rest.extend(bl[full:])
+        return out, rest
 
     # ---- the whole pipeline ----------------------------------------------------------------------------------------------
     def run(self, corpus, batches, on_result=None, min_seconds=None, max_batches=None, producers=1):

@@ -139,7 +139,8 @@ SIGNATURES = {
     "nir_cars_rank_session_shard": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
                                          c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_st]),
     "nir_cars_rank_session_rows": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
-                                        c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_fp, _l, c_st]),
+                                        c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_fp, _l, C.c_void_p, _i, c_st]),
+    "nir_cars_click_max": (_i, [c_fp, _i, _i, _i, C.c_void_p, c_st]),
 }
 
 DTYPE_F32, DTYPE_BF16 = 0, 1

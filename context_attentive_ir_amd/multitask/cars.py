@@ -293,11 +293,14 @@ class CARS(nn.Module, lib.IdCheck):
         pooled, _ = self._encode_seqs("d", docs.reshape(B * S * N, DL), docs_length.reshape(-1), False)
         return pooled.view(B, S, N, -1)
 
-    def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False, rank_docs=None, labels_all=None):
+    def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False, rank_docs=None, labels_all=None,
+                      labels_groups=None):
         """rank_docs [B,S,NR,D] (optional): the ranker scores only this slice of the candidates -> scores [B,S,NR]; clicks and sessions
         still see all of pooled_docs (candidate-sharded callers).
         labels_all [B_all,S,N] (optional): the inputs are a block of the sessions of a larger batch (session-sharded tail,
-        sharding.CarsShardPlan); the click mask's batch-wide max click count (cars.py:285-289) is taken over labels_all."""
+        sharding.SessionShardPlan); the click mask's batch-wide max click count (cars.py:285-289) is taken over labels_all.
+        labels_groups [G,B_all,S,N] (optional, instead of labels_all): the B sessions are G equal blocks taken from G DIFFERENT batches (merged
+        so that the session weights are streamed once for all of them); block g takes its count from labels_groups[g]."""
         lib.require_device(pooled_q, pooled_docs, labels)
         L = lib.load()
         B, S, D = pooled_q.shape
@@ -325,10 +328,19 @@ class CARS(nn.Module, lib.IdCheck):
             outs["dec_c"] = torch.empty(1, (S - 1) * B, HDEC, device=dev)
             for k, v in outs.items():
                 setattr(extra, k, v.data_ptr())
+        mg, spg = None, 0
+        if labels_groups is not None:
+            if lab_all is not None or B % labels_groups.shape[0]:
+                raise RuntimeError("labels_groups excludes labels_all and needs B divisible by the number of groups")
+            lg = labels_groups.float().contiguous()
+            ng = lg.shape[0]
+            mg, spg = torch.empty(ng, dtype=torch.int32, device=dev), B // ng
+            lib.check(L.nir_cars_click_max(lib.ptr(lg), ng, lg.numel() // (ng * N), N, lib.ptr(mg), lib.stream()), "nir_cars_click_max")
         lib.check(L.nir_cars_rank_session_rows(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
                                                lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
                                                lib.ptr(rd), NR if rd is not None else 0, lib.ptr(lab_all),
-                                               lab_all.numel() // N if lab_all is not None else 0, lib.stream()), "nir_cars_rank_session")
+                                               lab_all.numel() // N if lab_all is not None else 0, lib.ptr(mg), spg, lib.stream()),
+                  "nir_cars_rank_session")
         return scores, clicks, outs
 
     def encode_clicks(self, docs, doc_labels):

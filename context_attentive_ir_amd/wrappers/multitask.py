@@ -99,10 +99,11 @@ class Multitask(WrapperBase):
         return pooled, self.network.encode_document(doc_shard, len_shard)
 
     @torch.no_grad()
-    def tail_probs(self, pooled_q, docs, labels_own, labels_all, probs=None):
+    def tail_probs(self, pooled_q, docs, labels_own, labels_all, probs=None, labels_groups=None):
         """pooled queries [b,S,D] + ALL N pooled documents [b,S,N,D] of a block of sessions -> click probabilities [b,S,N] (clicks, session
-        LSTMs, ranknet, softmax); the click mask's batch-wide count comes from labels_all [B,S,N] (None: the block itself)."""
-        s = self.network._rank_session(pooled_q, docs, labels_own, labels_all=labels_all)[0].contiguous()
+        LSTMs, ranknet, softmax); the click mask's batch-wide count comes from labels_all [B,S,N] (None: the block itself), or -- blocks of
+        several batches merged into one call -- per block from labels_groups [G,B,S,N]."""
+        s = self.network._rank_session(pooled_q, docs, labels_own, labels_all=labels_all, labels_groups=labels_groups)[0].contiguous()
         if probs is None:
             probs = torch.empty_like(s)
         lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()), "nir_softmax_rows")
@@ -115,6 +116,41 @@ class Multitask(WrapperBase):
         G, bper, S, per, D = recv.shape
         docs = recv.permute(1, 2, 0, 3, 4).reshape(bper, S, G * per, D)[:, :, :n_candidates].contiguous()
         return self.tail_probs(pooled_q, docs, labels_own, labels_all, probs)
+
+    @torch.no_grad()
+    def predict_many(self, exs, out=None):
+        """Ranking path of several equal-shape batches as ONE macro-batch -> click probabilities [k,B,S,N] (CARS).
+
+        The batches are concatenated along the session axis: one encode launch over k x the sequences (a C3 batch alone fills 140 of 256 CUs
+        with recurrence workgroups), ONE pass over the session LSTM / ranknet weights for all of them (their 76 MB of L2 traffic per tail do
+        not depend on the number of sessions).  Every batch keeps the click mask's batch-wide count m of ITS OWN batch
+        (cars.py:285-289 via nir_cars_click_max / labels_groups), so the result equals k separate predict() calls -- it is how a serving loop
+        should feed this model when several batches are waiting.  out (optional): [k*B,S,N] result buffer."""
+        if self.type != "CARS":
+            raise NotImplementedError("predict_many is built for CARS")
+        self.network.eval()
+        cat = lambda key: torch.cat([self._dev(e[key]) for e in exs]) if len(exs) > 1 else self._dev(exs[0][key])     # noqa: E731
+        pooled, _, _ = self.network.encode(cat("source_words"), cat("source_lens"))
+        docs = self.network.encode_document(cat("document_words"), cat("document_lens"))
+        labels = [self._dev(e["document_labels"]) for e in exs]
+        probs = self.tail_probs(pooled, docs, torch.cat(labels) if len(labels) > 1 else labels[0], None, probs=out, labels_groups=torch.stack(labels))
+        return probs.view(len(exs), *labels[0].shape)
+
+    @torch.no_grad()
+    def predict_groups(self, ex, groups, out=None):
+        """predict_many for batches that are ALREADY concatenated: ex holds groups x B sessions (block g = batch g, whole) -> click
+        probabilities [groups*B,S,N]; block g uses the click count of its own B sessions (graph_runner.StreamingSessionPredictor collates
+        `groups` batches into one wire block)."""
+        if self.type != "CARS":
+            raise NotImplementedError("predict_groups is built for CARS")
+        self.network.eval()
+        pooled, _, _ = self.network.encode(self._dev(ex["source_words"]), self._dev(ex["source_lens"]))
+        docs = self.network.encode_document(self._dev(ex["document_words"]), self._dev(ex["document_lens"]))
+        labels = self._dev(ex["document_labels"])
+        if labels.shape[0] % groups:
+            raise RuntimeError("predict_groups: %d sessions are not %d equal batches" % (labels.shape[0], groups))
+        lg = labels.view(groups, labels.shape[0] // groups, *labels.shape[1:])
+        return self.tail_probs(pooled, docs, labels, None, probs=out, labels_groups=lg if groups > 1 else None)
 
     @torch.no_grad()
     def predict_sharded(self, ex, plan, group=None):

@@ -350,11 +350,17 @@ int nir_cars_rank_session_shard(const float* pooled_q, const float* pooled_docs,
  * labels / outputs address this call's B sessions only, but the click mask's batch-wide `m = max_rows count_nonzero(labels)`
  * (cars.py:285-289) is taken over labels_all [rows_all, N] -- the label matrix of the whole global batch, which every
  * rank holds (inputs are replicated).  labels_all == NULL: the rows of this call.  Sessions are otherwise independent (cars.py:306-458
- * iterates the session axis with batch-parallel ops only), so the scores of a block equal the rows of the unsharded call. */
+ * iterates the session axis with batch-parallel ops only), so the scores of a block equal the rows of the unsharded call.
+ * m_groups != NULL (excludes labels_all): the B sessions are `B / sessions_per_group` consecutive blocks that come from DIFFERENT batches
+ * (several batches' blocks merged into one call so that the session LSTM weights are streamed once for all of them); block g uses
+ * m_groups[g] (device ints from nir_cars_click_max over each batch's full label matrix). */
 int nir_cars_rank_session_rows(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
                                const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
                                float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra /*host*/,
-                               const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, nir_stream_t stream);
+                               const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, const int* m_groups,
+                               int sessions_per_group, nir_stream_t stream);
+/* m_out[g] = max over the `rows` rows of labels[g] ([groups, rows, N]) of count_nonzero: the batch-wide click count of cars.py:285-289. */
+int nir_cars_click_max(const float* labels, int groups, int rows, int N, int* m_out, nir_stream_t stream);
 
 /* --- CARS.decode: greedy query suggestion (cars.py:706-791; decoders/rnn_decoder.py:19-88; global_attention.py:98-196) ---- */
 typedef struct {

@@ -142,3 +142,39 @@ def test_decode_fused_projection_argmax_matches_logits_path(B, S, VT):
     assert fused.shape == (B, S - 1, 8) and int(fused.min()) >= 0 and int(fused.max()) < VT
     agree = (fused == plain).all(-1).float().mean()
     assert float(agree) >= 0.97, float(agree)
+
+
+def test_tail_over_blocks_of_several_batches_keeps_each_batchs_click_count():
+    """Merged tail (wrappers.Multitask.tail_probs with labels_groups): blocks of sessions taken from three DIFFERENT batches run as one
+    call -- the session weights are streamed once -- and every block still uses the batch-wide max click count m of ITS OWN batch
+    (cars.py:285-289, nir_cars_click_max): identical to three separate calls with labels_all, and to the oracle."""
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import Multitask
+    V, B, S, N, bper = 2000, 6, 3, 7, 2
+    mt = Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=300))
+    fill_module_(mt.network, 1013)
+    mt.cuda()
+    mt.network.eval()
+    exs = [synth.session_batch(B, S, N, 4, 12, V, seed=40 + i, full_length=False, multi_click=(i != 1)) for i in range(3)]
+    exs[2]["document_labels"][B - 1, 0, :] = 1.0             # batch 2: m = N, set by a session OUTSIDE the block taken below
+    sd = cpu_state_dict(mt.network)
+    own = slice(1, 1 + bper)
+    pqs, pds, labs, alls, sep, ref = [], [], [], [], [], []
+    for ex in exs:
+        dex = {k: v.to(DEV) for k, v in ex.items()}
+        pq = mt.network.encode(dex["source_words"][own], dex["source_lens"][own])[0]
+        pd = mt.network.encode_document(dex["document_words"][own], dex["document_lens"][own])
+        pqs.append(pq); pds.append(pd); labs.append(dex["document_labels"][own]); alls.append(dex["document_labels"])
+        sep.append(mt.tail_probs(pq, pd, dex["document_labels"][own], dex["document_labels"]).cpu())
+        full = O.predict_softmax(O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"],
+                                                ex["document_labels"]))
+        ref.append(full[own])
+    merged = mt.tail_probs(torch.cat(pqs), torch.cat(pds), torch.cat(labs), None, labels_groups=torch.stack(alls)).cpu()
+    for g in range(3):
+        _close(merged[g * bper:(g + 1) * bper], sep[g], 1e-6)
+        _close(merged[g * bper:(g + 1) * bper], ref[g], 1e-4)
+    # without the per-batch counts the merged call would take ONE m over its own rows: wrong for the blocks of batches 0 and 1
+    naive = mt.tail_probs(torch.cat(pqs), torch.cat(pds), torch.cat(labs), None).cpu()
+    assert float((naive - merged).abs().max()) > 1e-4

@@ -86,3 +86,27 @@ def test_stream_bf16_and_cycling():
         assert float((got[k] - ref).abs().max()) <= 2e-2
     r = sp.run(corpus, batches, min_seconds=0.5)
     assert r["batches"] > len(batches) and r["pairs_per_s"] > 0 and r["seconds"] >= 0.5
+
+
+def test_stream_macro_batches_equal_single_batches():
+    """macro = 3: three sampler batches of one session length per wire block / graph replay (Multitask.predict_groups) give the probabilities
+    of the same batches scored one by one -- every batch keeps its own click count -- and the oracle's."""
+    from context_attentive_ir_amd.graph_runner import StreamingSessionPredictor
+    from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
+    V, B, N, MK = 3000, 4, 6, 3
+    corpus = SyntheticSessionCorpus(n_sessions=160, n_cands=N, qlen=4, dlen=16, vocab=V, seed=13, pool=6, full_length=False, s_max=5)
+    for i in range(0, 160, 7):                      # multi-click sessions: batches differ in their batch-wide click count
+        p = corpus.pool[int(corpus.lengths[i])]
+        p["document_labels"][corpus.slot[i], 0, :3] = 1.0
+    batches = corpus.batches(B, seed=2)
+    mt = _model(V)
+    sd = cpu_state_dict(mt.network)
+    sp = StreamingSessionPredictor(mt, N, 4, 16, MK * B, max_session_len=5, lanes=2, slots=2, macro=MK)
+    merged, rest = sp.merge_batches(corpus, batches, MK)
+    assert merged and len(merged) * MK + len(rest) == len(batches) and all(len(m) == MK * B for m in merged)
+    got = {}
+    sp.run(corpus, merged, on_result=lambda k, idx, probs: got.__setitem__(k, probs.clone()))
+    for k, idx in enumerate(merged):
+        for j in range(MK):
+            ex = corpus.batch_tensors(idx[j * B:(j + 1) * B])
+            np.testing.assert_allclose(got[k][j * B:(j + 1) * B].numpy(), _oracle_probs(sd, ex).numpy(), rtol=0, atol=1e-4)
