@@ -158,7 +158,7 @@ def kernel_work(name, c):
 def pmc_entry(name, prof_name):
     """profiles/pmc_summary.json (tools/derive_profiles.py: rocprofv3 --pmc passes of this same workload, separate FETCH_SIZE / WRITE_SIZE /
     SQ passes, gfx950 x2 FETCH correction): {bytes_per_launch, mfma_busy} of the kernel behind the library's profile label, or None."""
-    for fn in ("pmc_summary.json", "traffic.json"):
+    for fn in ("pmc_summary.json",):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
             ent = traffic_entry(tj.get("configs", {}).get(name, {}), prof_name)
@@ -334,7 +334,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     if sharded and c["model"] == "cars" and wsh > 1 and env.backend == "nccl":
         nlanes = int(os.environ.get("BENCH_SHARD_LANES", nlanes))       # (8 lanes measured SLOWER than 4 in the 8-rank emulation: C3 0.111 vs 0.097 ms)
     nbatches = (max(args.nbatches, nlanes) + nlanes - 1) // nlanes * nlanes
-    if c["model"] == "cars":       # macro-batched CARS paths: every lane gets whole groups of KG batches
+    if c["model"] == "cars" or not env.multi:       # macro-batched paths: every lane gets whole groups of KG batches
         kg = macro_batch(c, "BENCH_GATHER_EVERY" if env.multi else "BENCH_MACRO_BATCH")
         nbatches = (max(args.nbatches, kg * nlanes) + kg * nlanes - 1) // (kg * nlanes) * (kg * nlanes)
     # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
@@ -523,7 +523,8 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             except Exception:
                 pass
             L.nir_set_batches_in_flight(len(lanes))
-    macro_single = plan is None and c["model"] == "cars" and not env.multi and not c.get("nofold") and macro_batch(c) > 1
+    macro_single = (plan is None and not env.multi and not c.get("nofold") and macro_batch(c) > 1
+                    and c["model"] in ("cars", "match_tensor", "esm", "drmm", "duet"))
     if (staged and plan.aligned) or macro_single:
         try:
             # pair axis: a lane's hipGraph holds KG whole steps ( encode own sessions -> tail -> probabilities ) merged into one macro-batch,
@@ -532,7 +533,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             nl, nb = len(lanes), len(batches)
             agroups = {}
             gbuf = {}
-            bper_, S_ = (c["batch"], c["session"]) if macro_single else (plan.bper, plan.S)
+            bper_, S_ = (c["batch"], c.get("session", 1) if is_sess else 1) if macro_single else (plan.bper, plan.S)
 
             def group_bufs(gb, k):
                 if (gb, k) not in gbuf:
@@ -548,7 +549,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     exs = [batches[(KG * gb + j) % nb] for j in range(k)]
 
                     def body1():
-                        model.predict_many(exs, out=mine.view(k * bper_, S_, ncand))
+                        model.predict_many(exs, out=mine.view(k * bper_, S_, ncand) if is_sess else mine.view(k * bper_, ncand))
                     with torch.cuda.stream(ln):
                         body1()
                     torch.cuda.synchronize()
@@ -757,7 +758,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             with torch.cuda.stream(lanes[0]):
                 mg_.replay()
             torch.cuda.synchronize()
-            overlap_diff = float((mine_[0] - o1).abs().max())
+            overlap_diff = float((mine_[0].reshape(o1.shape) - o1).abs().max())
             ts = None
         elif fused is not None or stages is not None:   # (fused / pipelined steps: "one in flight" has no separate meaning there)
             run_steps(ns)

@@ -68,6 +68,20 @@ class Ranker(WrapperBase):
         return out
 
     @torch.no_grad()
+    def predict_many(self, exs, out=None):
+        """softmax scores of several equal-shape batches as ONE macro-batch -> [k,B,N] (every (query, candidate) pair of these rankers is
+        independent of the rest of its batch, so this is plain concatenation along the query axis): one launch sequence over k x the pairs
+        instead of k -- a C2 batch (320 documents) fills 40 of 256 CUs with recurrence workgroups.  out (optional): [k*B,N] result buffer."""
+        self.network.eval()
+        cols = [self._inputs(e) for e in exs]
+        q, ql, d, dl = (torch.cat([c[i] for c in cols]) if len(cols) > 1 else cols[0][i] for i in range(4))
+        s = self.network(q, ql, d, dl).contiguous()
+        if out is None:
+            out = torch.empty_like(s)
+        lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()), "nir_softmax_rows")
+        return out.view(len(exs), -1, s.shape[1])
+
+    @torch.no_grad()
     def loss(self, ex):
         """forward + criterion of the model (BCEWithLogits, models/ranker.py:55-69); ESM has none."""
         if self.kind not in BCE_MODELS:
