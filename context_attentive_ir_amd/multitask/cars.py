@@ -352,14 +352,17 @@ class CARS(nn.Module, lib.IdCheck):
         dummy_q = torch.zeros(B, S, D, device=docs.device)
         return self._rank_session(dummy_q, docs, doc_labels, want_clicks=True)[1]
 
-    def rank_document(self, pooled_rep, document_rep, document_len, document_label, group=None, shard=False, want_states=None):
+    def rank_document(self, pooled_rep, document_rep, document_len, document_label, group=None, shard=False, want_states=None,
+                      labels_groups=None):
         """cars.py:522-540 -> (click_scores [B,S,N] (or [] when the ranker is off), hidden_states, session_attns).
         hidden_states = (transform_hid(h), transform_cell(c)) [1,(S-1)*B,nhid_decoder] and session_attns = (inner_q, inner_d)
         [B,S,HS] are the decoder inputs (cars.py:382-456); they are produced when `want_states` (default: whenever the
         recommender is on, like the reference), otherwise returned as None / (None, None).
         shard=True: candidate-sharded document encoding over the torch.distributed `group`, all-to-all of the pooled vectors, clicks /
         sessions / ranknet for this rank's block of sessions, all-gather of the scores (sharding.SessionShardPlan); when the decoder
-        states are wanted: all-gather of the pooled vectors and a replicated session part (the states cover every session)."""
+        states are wanted: all-gather of the pooled vectors and a replicated session part (the states cover every session).
+        labels_groups [G,B0,S,N] (optional): the B = G*B0 sessions are G whole batches merged into one macro-batch (Multitask.predict_many);
+        batch g keeps the click count of its own labels."""
         self._check_eval()
         if want_states is None:
             want_states = not self.no_recommender
@@ -383,7 +386,7 @@ class CARS(nn.Module, lib.IdCheck):
         # candidate-sharded: the ranker MLP scores this rank's slice only (clicks / sessions need every pooled candidate and stay
         # replicated); the score slices are gathered afterwards
         scores, _, outs = self._rank_session(pooled_rep, encoded_docs, document_label, want_states=want_states,
-                                             rank_docs=own if not self.no_ranker else None)
+                                             rank_docs=own if not self.no_ranker else None, labels_groups=labels_groups)
         if own is not None and scores is not None:
             from .. import sharding
             scores = sharding.gather_session_scores(scores, document_rep.shape[2], group)

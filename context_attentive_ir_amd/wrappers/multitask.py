@@ -118,8 +118,9 @@ class Multitask(WrapperBase):
         return self.tail_probs(pooled_q, docs, labels_own, labels_all, probs)
 
     @torch.no_grad()
-    def predict_many(self, exs, out=None):
-        """Ranking path of several equal-shape batches as ONE macro-batch -> click probabilities [k,B,S,N] (CARS).
+    def predict_many(self, exs, out=None, suggest=False):
+        """Ranking path of several equal-shape batches as ONE macro-batch -> click probabilities [k,B,S,N] (CARS); suggest=True: the full
+        predict -> {'click_scores': [k,B,S,N], 'predictions': [k,B,S-1,max_query_len]} (greedy decode over the k*B*(S-1) rows at once).
 
         The batches are concatenated along the session axis: one encode launch over k x the sequences (a C3 batch alone fills 140 of 256 CUs
         with recurrence workgroups), ONE pass over the session LSTM / ranknet weights for all of them (their 76 MB of L2 traffic per tail do
@@ -130,9 +131,33 @@ class Multitask(WrapperBase):
             raise NotImplementedError("predict_many is built for CARS")
         self.network.eval()
         cat = lambda key: torch.cat([self._dev(e[key]) for e in exs]) if len(exs) > 1 else self._dev(exs[0][key])     # noqa: E731
+        labels = [self._dev(e["document_labels"]) for e in exs]
+        if suggest and not self.network.no_recommender:
+            src_lens = cat("source_lens")
+            pooled, encoded, _ = self.network.encode(cat("source_words"), src_lens)
+            lab = torch.cat(labels) if len(labels) > 1 else labels[0]
+            s, states, attns = self.network.rank_document(pooled, cat("document_words"), cat("document_lens"), lab, want_states=True,
+                                                          labels_groups=torch.stack(labels))
+            s = s.contiguous()
+            probs = out if out is not None else torch.empty_like(s)
+            lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()), "nir_softmax_rows")
+            KB, S = lab.shape[0], lab.shape[1]
+            # The reference concatenates the per-step decoder states along the batch axis in STEP-major order and the decoder then reads
+            # row j as (session j // (S-1), step j % (S-1)) (cars.py:431-445, 716-760): which state meets which query depends on the
+            # batch size.  To give every batch of the macro-batch exactly the pairing it has on its own, the rows are regrouped from
+            # (step, batch, session) to (batch, step, session) order.
+            k, B0, SD = len(exs), labels[0].shape[0], S - 1
+            dv = states[0].device
+            idx = (torch.arange(SD, device=dv).view(1, SD, 1) * KB + torch.arange(k, device=dv).view(k, 1, 1) * B0
+                   + torch.arange(B0, device=dv).view(1, 1, B0)).reshape(-1)
+            states = tuple(st.index_select(1, idx) for st in states)
+            dec = self.network.decode(states=states, max_len=self.args.max_query_len, src_dict=self.src_dict, tgt_dict=self.tgt_dict,
+                                      batch_size=KB, session_len=S - 1, use_cuda=self.use_cuda, encoded_source=encoded, source_len=src_lens,
+                                      session_attns=attns)
+            return {"click_scores": probs.view(len(exs), *labels[0].shape),
+                    "predictions": dec["predictions"].view(len(exs), labels[0].shape[0], S - 1, -1)}
         pooled, _, _ = self.network.encode(cat("source_words"), cat("source_lens"))
         docs = self.network.encode_document(cat("document_words"), cat("document_lens"))
-        labels = [self._dev(e["document_labels"]) for e in exs]
         probs = self.tail_probs(pooled, docs, torch.cat(labels) if len(labels) > 1 else labels[0], None, probs=out, labels_groups=torch.stack(labels))
         return probs.view(len(exs), *labels[0].shape)
 

@@ -178,3 +178,32 @@ def test_tail_over_blocks_of_several_batches_keeps_each_batchs_click_count():
     # without the per-batch counts the merged call would take ONE m over its own rows: wrong for the blocks of batches 0 and 1
     naive = mt.tail_probs(torch.cat(pqs), torch.cat(pds), torch.cat(labs), None).cpu()
     assert float((naive - merged).abs().max()) > 1e-4
+
+
+def test_predict_many_equals_separate_predicts():
+    """Multitask.predict_many: three batches as one macro-batch -- ranking only, and the full predict with the greedy decoder -- against
+    three separate predict() calls: probabilities to rounding, predictions identical."""
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import Multitask
+    V = 2500
+    mt = Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=400))
+    fill_module_(mt.network, 1013)
+    mt.cuda()
+    exs = [synth.session_batch(4, 3, 6, 4, 14, V, seed=60 + i, full_length=False, multi_click=(i == 1)) for i in range(3)]
+    sep = [mt.predict(e) for e in exs]
+    many = mt.predict_many(exs)
+    full = mt.predict_many(exs, suggest=True)
+    for g in range(3):
+        _close(many[g], sep[g]["click_scores"], 1e-6)
+        _close(full["click_scores"][g], sep[g]["click_scores"], 1e-6)
+        assert torch.equal(full["predictions"][g], sep[g]["predictions"])
+    from context_attentive_ir_amd.wrappers import Ranker
+    r = Ranker(default_args("MATCH_TENSOR", src_vocab_size=V))
+    fill_module_(r.network, 1013)
+    r.cuda()
+    rex = [synth.ranker_batch(3, 5, 4, 20, V, seed=70 + i, full_length=False) for i in range(3)]
+    rm = r.predict_many(rex)
+    for g in range(3):
+        _close(rm[g], r.predict(rex[g]), 1e-6)
