@@ -15,6 +15,13 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libneuroir_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# Instrumented / experimental builds for the tools (never the product library): NIR_VARIANT=name NIR_VARIANT_FLAGS="-D..." build into
+# csrc/_obj_<name> and libneuroir_hip_<name>.so; tools load that file explicitly.
+if os.environ.get("NIR_VARIANT"):
+    _v = os.environ["NIR_VARIANT"]
+    OBJ = os.path.join(HERE, "csrc", "_obj_" + _v)
+    LIB = os.path.join(HERE, "libneuroir_hip_%s.so" % _v)
+    FLAGS = FLAGS + os.environ.get("NIR_VARIANT_FLAGS", "").split()
 
 
 def _sources():

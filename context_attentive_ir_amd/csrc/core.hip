@@ -140,7 +140,7 @@ static int env_int(const char* name, int dflt) {
 }
 static int env_flag(const char* name) { return getenv(name) ? 1 : 0; }
 Tunables g_tun{{env_flag("NIR_NO_FORK")}, {env_flag("NIR_LSTM_VALU")}, {env_int("NIR_LSTM_MFMA16", -1)}, {env_int("NIR_LSTM_MFMA_S", 0)},
-               {env_int("NIR_LSTM_S", 0)}, {env_flag("NIR_NO_SKINNY")}, {env_flag("NIR_NO_GEMM16")}, {env_flag("NIR_ESM_WAVE_ROWS")},
+               {env_int("NIR_LSTM_S", 0)}, {env_int("NIR_LSTM_W16", 0)}, {env_flag("NIR_NO_SKINNY")}, {env_flag("NIR_NO_GEMM16")}, {env_flag("NIR_ESM_WAVE_ROWS")},
                {env_flag("NIR_DEBUG")}, {env_flag("NIR_EXACT_F32")}};
 }  // namespace nir
 extern "C" int nir_set_batches_in_flight(int n) {
@@ -158,7 +158,7 @@ extern "C" int nir_debug_set_tunable(const char* name, int value) {
     if (!name) return NIR_ERR_BAD_ARG;
     struct { const char* n; std::atomic<int>* a; } tab[] = {
         {"no_fork", &g_tun.no_fork}, {"lstm_valu", &g_tun.lstm_valu}, {"lstm_mfma16", &g_tun.lstm_mfma16}, {"lstm_mfma_s", &g_tun.lstm_mfma_s},
-        {"lstm_s", &g_tun.lstm_s}, {"no_skinny", &g_tun.no_skinny}, {"no_gemm16", &g_tun.no_gemm16}, {"esm_wave_rows", &g_tun.esm_wave_rows},
+        {"lstm_s", &g_tun.lstm_s}, {"lstm_w16", &g_tun.lstm_w16}, {"no_skinny", &g_tun.no_skinny}, {"no_gemm16", &g_tun.no_gemm16}, {"esm_wave_rows", &g_tun.esm_wave_rows},
         {"debug", &g_tun.debug}, {"exact_f32", &g_tun.exact_f32}, {"duet_unfused", &g_tun.duet_unfused}, {"attn_unfused", &g_tun.attn_unfused}, {"attn_unfused_pipe", &g_tun.attn_unfused_pipe}};
     for (auto& t : tab)
         if (!strcmp(t.n, name)) { t.a->store(value); return 0; }

@@ -224,6 +224,30 @@ __global__ __launch_bounds__(1024) void lstm16_pt_kernel(LstmPtArgs p) {
     }
 }
 
+// LSTM cell on the four pre-activations x = (i, f, g, o) of one unit, merged fractions: sigma(i) tanh(g) = sgn(g) (1 - d) / ((1 + a)(1 + d))
+// with a = e^-i, d = e^-2|g| (d in (0, 1]; a = inf gives 1 / inf = 0, the right limit), likewise o and tanh(c): 5 v_exp_f32 + 3 v_rcp_f32
+// instead of 5 + 5 -- the transcendentals are quarter rate, and the VALU port (gate math of all waves of a SIMD) is as loaded as the
+// matrix pipe in these recurrences.  The plain arithmetic is packed along the gate axis, (i, f) and (g, o) are adjacent accumulator
+// registers: v_pk_{fma,mul,add}_f32 without any register shuffling.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lstm_cell_v(const f32x4 x, float& c, float& h) {
+    constexpr float L2E = 1.4426950408889634f;
+    const f32x2 e_if = (f32x2){x[0], x[1]} * (f32x2){-L2E, -L2E};
+    const f32x2 e_go = (f32x2){fabsf(x[2]), x[3]} * (f32x2){-2.f * L2E, -L2E};
+    const float a = __builtin_amdgcn_exp2f(e_if.x), b = __builtin_amdgcn_exp2f(e_if.y);
+    const float d = __builtin_amdgcn_exp2f(e_go.x), q = __builtin_amdgcn_exp2f(e_go.y);
+    const f32x2 p_ab = (f32x2){a, b} + (f32x2){1.f, 1.f};
+    const f32x2 p_dq = (f32x2){d, q} + (f32x2){1.f, 1.f};
+    const float r1 = __builtin_amdgcn_rcpf(p_ab.x * p_dq.x), rf = __builtin_amdgcn_rcpf(p_ab.y);
+    c = fmaf(c, rf, copysignf((1.f - d) * r1, x[2]));
+    const float e = __builtin_amdgcn_exp2f(fabsf(c) * (-2.f * L2E));
+    h = copysignf((1.f - e) * __builtin_amdgcn_rcpf(p_dq.y * (1.f + e)), c);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // bf16 recurrence over the bf16 folded table: W_hh and h_t as bf16 MFMA operands (v_mfma_f32_16x16x32_bf16), fp32
 // accumulators, fp32 gate math and cell state.  KB = ceil(H / 32) K-blocks; wave w owns tiles NT*w .. NT*w+NT-1.
@@ -397,13 +421,8 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
                 float hv = 0.f;
                 if (NT * wave + t < ntiles) {            // wave-uniform
                     const bool dv = unit_d[t] < H;
-                    const float gi = fast_sigmoid(acc[t][0]);
-                    const float gf = fast_sigmoid(acc[t][1]);
-                    const float gg = fast_tanh(acc[t][2]);
-                    const float go = fast_sigmoid(acc[t][3]);
-                    const float cn = gf * creg[t] + gi * gg;
-                    const float hn = go * fast_tanh(cn);
-                    creg[t] = cn;
+                    float hn;
+                    lstm_cell_v(acc[t], creg[t], hn);
                     if (dv) reinterpret_cast<_Float16*>(zn)[sq * ZLD + unit_d[t]] = (_Float16)hn;
                     if (dv && live) off = (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u;
                     hv = hn;
@@ -413,15 +432,14 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
             lds_barrier();
         }
         if (O16 && tmax > 0) copy_out(tmax - 1, z + (tmax & 1) * SEQ * ZLD);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (unit_d[t] < H && sq < nvalid) {
-                const int64_t m = m0 + sq;
-                for (int t2 = mylen; t2 < T; ++t2) {
-                    if (O16) reinterpret_cast<_Float16*>(p.out)[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = (_Float16)0.f;
-                    else p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
+        // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced (ragged batches are the normal case)
+        for (int s_ = 0; s_ < nvalid; ++s_) {
+            const int64_t ob = (m0 + s_) * T * OW + (int64_t)dir * H;
+            for (int t2 = lens_s[s_] + wave; t2 < T; t2 += 16)
+                for (int col = lane; col < H; col += 64) {
+                    if (O16) reinterpret_cast<_Float16*>(p.out)[ob + (int64_t)t2 * OW + col] = (_Float16)0.f;
+                    else p.out[ob + (int64_t)t2 * OW + col] = 0.f;
                 }
-            }
         }
     }
 }
@@ -436,6 +454,10 @@ __global__ __launch_bounds__(1024) void lstm16_pt_bf16_kernel(LstmPtArgs p) {
 // the folded table and the output stay fp32.  W_hh terms live in VGPRs (2 x 16 per tile), the two h terms in LDS.
 // ---------------------------------------------------------------------------------------------------------------------
 
+#ifdef NIR_PT_TRACE   // tools/recur_micro.py --trace: per-wave phase clocks of workgroup (0, 0), summed over the steps
+__device__ unsigned long long* g_pt_trace_dev;
+#define PT_T(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#endif
 // NW waves per workgroup, NT gate tiles per wave (NW * NT * 4 >= H units).  16 waves x 2 tiles is the latency form (H = 128); for
 // H <= 80 four waves x 5 tiles leave room for three workgroups per CU, which fill each other's per-step bubbles when several
 // batches are in flight.
@@ -445,10 +467,14 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // fp16 elements per h row
     constexpr uint32_t OOB = 0x7FFFFFF0u;
     constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
+    constexpr bool PIPE = NT >= 4 && NW == 8;               // in-wave software pipeline over the tiles (see the loop); 4 waves x 5 tiles: slower with it
+    constexpr bool DEFER = NW >= 8;                         // output stores one step late, in front of the row requests (see store_prev)
+    const int TP = p.T + 3;                                 // id columns per sequence: the lookup runs two steps ahead
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* z = reinterpret_cast<_Float16*>(smem);        // [2 buffers][2 terms][SEQ][ZLD]
     int* lens_s = reinterpret_cast<int*>(z + 4 * SEQ * ZLD);
-    int* ids_s = lens_s + SEQ;
+    int* simd_s = lens_s + SEQ;                             // [16] SIMD of every wave (issue-priority ranking below)
+    int* ids_s = simd_s + 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sq = lane & 15, kq = lane >> 4;
@@ -458,8 +484,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
     const int OW = p.ND * H;
     const int64_t GW = (int64_t)p.ND * H4;
-    const int ntiles = (H + 3) / 4;
-
+    if (NW > 4 && lane == 0) simd_s[wave] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));   // HW_REG_HW_ID bits [5:4] = SIMD_ID
     if (tid < SEQ) {
         int l = 0;
         if (tid < nvalid) {
@@ -468,13 +493,27 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         }
         lens_s[tid] = l;
     }
+    __syncthreads();
     {
+        // ids_s[s][k] = the id sequence s consumes at STEP k (reverse direction: from its last valid token down; past its end the last
+        // valid id repeats -- those gate rows feed nothing that is stored): the loop's lookup is one LDS read at base + 4 * step.
         bool bad = false;
-        for (int e = tid; e < SEQ * T; e += NTH) {
-            const int s = e / T;
+        for (int e = tid; e < SEQ * TP; e += NTH) {
+            const int s_ = e / TP, k = e - s_ * TP;
             int64_t id = 0;
-            if (s < nvalid) id = p.ids[m0 * T + e];
-            if (id < 0 || id >= p.V) { bad = true; id = 0; }
+            if (s_ < nvalid) {
+                const int l = lens_s[s_];
+                int kk = k < l - 1 ? k : l - 1;
+                kk = kk < 0 ? 0 : kk;
+                int t_ = dir == 0 ? kk : l - 1 - kk;
+                t_ = t_ < 0 ? 0 : t_;
+                id = p.ids[(m0 + s_) * T + t_];
+                if (k < T) {                                   // every id of the padded row is validated, like the reference's nn.Embedding
+                    const int64_t raw = p.ids[(m0 + s_) * T + k];
+                    bad |= raw < 0 || raw >= p.V;
+                }
+            }
+            if (id < 0 || id >= p.V) id = 0;
             ids_s[e] = (int)id;
         }
         if (bad && p.err) atomicOr(p.err, 1);
@@ -485,15 +524,36 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 #pragma unroll
     for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
     const int mylen = lens_s[sq];
+    if (NW > 4) {
+        // The waves that share a SIMD get DISTINCT issue priorities.  With equal priorities the arbiter interleaves their MFMAs one by
+        // one, all of them leave the matrix phase together and then queue for the VALU with the matrix pipe idle (the gate math is
+        // ~2400 VALU cycles per SIMD and step against ~1500 of MFMA).  Ranked, wave A's MFMAs go back to back, and its gate math
+        // runs under wave B's MFMAs, and so on down the ranks.
+        const int mine = simd_s[wave];
+        int rank = 0;
+#pragma unroll
+        for (int w2_ = 0; w2_ < NW; ++w2_) rank += (w2_ < wave && simd_s[w2_] == mine) ? 1 : 0;
+        rank = __builtin_amdgcn_readfirstlane(rank);
+        if (rank == 0) __builtin_amdgcn_s_setprio(3);
+        else if (rank == 1) __builtin_amdgcn_s_setprio(2);
+        else if (rank == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
 
+    // Unit mapping: lane (sq, kq) of wave w owns the NT CONSECUTIVE units u0 .. u0 + NT - 1, u0 = NT * (4 w + kq), of sequence sq -- tile t of
+    // the wave holds unit u0 + t of each of its four unit groups (A rows 4 g + gate <-> unit NT * (4 w + g) + t).  The lane's output is then
+    // one 4 NT-byte store, its h terms one 2 NT-byte LDS write each, its gate rows one 16 NT-byte piece of the folded row.
     f16x8 w1[NT][KB], w2[NT][KB];
     float creg[NT];
-    int unit_d[NT];
+    const int u0 = NT * (4 * wave + kq);
+    // wave-uniform: a wave whose units are all past H skips the step's work (H = 70 on 16 waves x 2 tiles: 7 of 16).  Not in the pipelined form:
+    // the branch around its loop body costs the H = 128 kernel 13 % (measured), and at most one of its eight waves can be idle.
+    const bool wave_on = PIPE || NT * 4 * wave < H;
+    const bool full = u0 + NT <= H;                           // all NT units real (the vector forms); otherwise unit by unit
     bool wbad = false;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tile = NT * wave + t;
-        const int unit_a = 4 * tile + (sq >> 2), gate_a = sq & 3;
+        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
         const bool av = unit_a < H;
         const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0)) * H;
         // the lane's 8*KB weights of this tile: issued as 2*KB independent 16-byte loads up front (a scalar load -> convert loop
@@ -531,112 +591,193 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
                 w2[t][kb][j] = (_Float16)((w - (float)a) * SC);
                 wbad |= !(fabsf(w) < 32768.0f);             // outside the fp16 split's range (or NaN): flagged, never silently wrong
             }
-        unit_d[t] = 4 * tile + kq;
         creg[t] = 0.f;
     }
     if (wbad && p.err) atomicOr(p.err, 2);
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
                                                                              (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    // per-unit base of the lane's 16-byte gate groups inside a folded row (units past H re-read the last real one: never used);
+    // row = base + id * GW floats
     const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;
-    auto id_of = [&](int step) {
-        int s_ = min(step, mylen - 1);
-        s_ = s_ < 0 ? 0 : s_;
-        const int t_ = dir == 0 ? s_ : mylen - 1 - s_;
-        return ids_s[sq * T + (t_ < 0 ? 0 : t_)];
-    };
-    auto load_g = [&](int id, f32x4 (&dst)[NT]) {
-        const float* row = ptf + (int64_t)id * GW;
+    const float* pb[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int u = unit_d[t] < H ? unit_d[t] : H - 1;
-            dst[t] = *reinterpret_cast<const f32x4*>(row + 4 * u);
+    for (int t = 0; t < NT; ++t) pb[t] = ptf + 4 * (u0 + t < H ? u0 + t : H - 1);
+    const uint32_t gw = (uint32_t)GW;
+    auto load_g = [&](int id, f32x4 (&dst)[NT]) {
+        const uint64_t ro = (uint64_t)(uint32_t)id * gw;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dst[t] = *reinterpret_cast<const f32x4*>(pb[t] + ro);
+    };
+    // DEFER (8 / 16 waves): the output of step t is stored during step t+1, immediately IN FRONT of the row requests for step t+2: the vector-memory queue of a
+    // step is then [stores, requests] and the wait the compiler derives for the requests (vmcnt counts in order) never covers a store
+    // that is younger than they are.  (With [requests, stores] the derived wait flipped with unrelated edits between "requests only" and
+    // "requests and the first store" -- a store round trip, ~1000 cycles, in front of the first MFMA of every step.)
+    float hprev[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) hprev[t] = 0.f;
+    uint32_t poff = OOB;                                      // byte offset of (sequence, step, u0) in the output block, OOB = dropped
+    auto store_prev = [&]() {
+        if (NT == 4) {
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(hprev[0]), __float_as_uint(hprev[1 % NT]), __float_as_uint(hprev[2 % NT]),
+                                                           __float_as_uint(hprev[3 % NT])}, out_rs, full ? poff : OOB, 0, 0);
+        } else if (NT == 2) {
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(hprev[0]), __float_as_uint(hprev[1 % NT])}, out_rs, full ? poff : OOB, 0, 0);
+        }
+        if ((NT != 4 && NT != 2) || !full) {                  // unit by unit (NT = 4 / 2: only the lanes that straddle H)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hprev[t]), out_rs, (u0 + t < H && poff != OOB) ? poff + 4u * t : OOB, 0, 0);
         }
     };
-    // Step t begins by taking over the gate rows of step t (requested during step t-1) as the MFMA C operand: the only s_waitcnt
-    // vmcnt of the loop sits at that hand-over and covers a request that is most of a step old.  (With the hand-over at the END of
-    // the step the waitcnt pass merged "step 0's rows may be in flight" into the loop header and waited for the NEXT step's rows in
-    // front of the first MFMA: +18 % on the H = 70 kernel.)  The rows of step t+1 are requested behind the first k-block of MFMAs,
-    // from an id looked up in LDS a step earlier: with lookup + request at the top of the step, an LDS round trip and the 64-bit
-    // address arithmetic sat in front of the h reads.
-    f32x4 gcur[NT], gnext[NT];
-    load_g(id_of(0), gnext);
-    int id_n = id_of(1);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)                     // NT dropped stores behind the first requests: the loop-entry and back-edge states match
-        __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs, OOB, 0, 0);
+    const int* idp = ids_s + sq * TP;
+    f32x4 gnext[NT];
+    load_g(idp[0], gnext);
+    int id_n = idp[1];
+    uint32_t soff = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen - 1)) * OW + dir * H + u0) * 4);
+    const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
+    f32x4 acc[NT], acx[NT];
+    float hn[NT] = {};
+    auto gates = [&](int t) { lstm_cell_v(acx[t] * ISC + acc[t], creg[t], hn[t]); };
+#ifdef NIR_PT_TRACE
+    unsigned long long tr_a = 0, tr_b = 0, tr_c = 0, tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_first = 0;
+#endif
     for (int step = 0; step < tmax; ++step) {
+#ifdef NIR_PT_TRACE
+        { unsigned long long tn; PT_T(tn); if (step > 0) tr_c += tn - tr_t2; else tr_first = tn; tr_t0 = tn; }
+#endif
         const _Float16* zc = z + (step & 1) * 2 * SEQ * ZLD;
         _Float16* zn = z + ((step + 1) & 1) * 2 * SEQ * ZLD;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            asm volatile("" : "+v"(gnext[t]));       // pins the hand-over (and its wait) to this point
-            gcur[t] = gnext[t];
+            acc[t] = gnext[t];                       // the gate rows ride in as the MFMA's C operand
+            acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         const bool live = step < mylen;
-        const int tt = dir == 0 ? step : mylen - 1 - step;
         const _Float16* zr = zc + sq * ZLD + 8 * kq;
-        f32x4 acc[NT], acx[NT];
+        if (!wave_on) {                                // all of this wave's units are past H: it only keeps the barriers company
+        } else if constexpr (!PIPE) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { acc[t] = gcur[t]; acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }   // the gate rows ride in as the MFMA's C operand
+            for (int kb = 0; kb < KB; ++kb) {            // h terms are read per k-block (8 live VGPRs instead of 8*KB)
+                const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+                const f16x8 h2 = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {            // h terms are read per k-block (8 live VGPRs instead of 8*KB)
-            const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
-            const f16x8 h2 = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {           // independent accumulators back to back: no dependent-MFMA stalls
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h1, acc[t], 0, 0, 0);
-                acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h2, acx[t], 0, 0, 0);
-                acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], h1, acx[t], 0, 0, 0);
-            }
-            if (kb == 0) {
-                load_g(id_n, gnext);
-                id_n = id_of(step + 2);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            uint32_t off = OOB;
-            float hv = 0.f;
-            if (NT * wave + t < ntiles) {            // wave-uniform
-                const bool dv = unit_d[t] < H;
-                const float gi = fast_sigmoid(fmaf(acx[t][0], ISC, acc[t][0]));
-                const float gf = fast_sigmoid(fmaf(acx[t][1], ISC, acc[t][1]));
-                const float gg = fast_tanh(fmaf(acx[t][2], ISC, acc[t][2]));
-                const float go = fast_sigmoid(fmaf(acx[t][3], ISC, acc[t][3]));
-                const float cn = gf * creg[t] + gi * gg;
-                const float hn = go * fast_tanh(cn);
-                // no hold for finished sequences: a sequence's column of the B operand only feeds its own gates, and nothing of a
-                // finished sequence is stored again (its padded outputs are zero-filled below), in either direction
-                creg[t] = cn;
-                if (dv) {
-                    const _Float16 a = (_Float16)hn;
-                    zn[sq * ZLD + unit_d[t]] = a;
-                    zn[SEQ * ZLD + sq * ZLD + unit_d[t]] = (_Float16)((hn - (float)a) * SC);
+                for (int t = 0; t < NT; ++t) {           // independent accumulators back to back: no dependent-MFMA stalls
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h1, acc[t], 0, 0, 0);
+                    acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h2, acx[t], 0, 0, 0);
+                    acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], h1, acx[t], 0, 0, 0);
                 }
-                if (dv && live) off = (uint32_t)((sq * T + tt) * OW + dir * H + unit_d[t]) * 4u;
-                hv = hn;
+                if (kb == 0) {
+                    if (DEFER) store_prev();
+                    load_g(id_n, gnext);
+                    id_n = idp[step + 2];
+                }
             }
-            // one store per tile on every path (out-of-range offset = dropped), at the end of its own step: the waitcnt pass can then
-            // count the NT stores behind the row requests and the hand-over at the top of the next step waits for the rows only.
-            // (Deferring the store to the next step measured 7-9 % slower: its address arithmetic then sits in front of the h reads.)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), out_rs, off, 0, 0);
+#ifdef NIR_PT_TRACE
+#pragma unroll
+            for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]), "+v"(acx[t]));
+            PT_T(tr_t1); tr_a += tr_t1 - tr_t0;
+#endif
+            // Gate math of all NT tiles in one straight-line block (units past H compute on zero weights and are masked at the writes); no
+            // hold for finished sequences either -- a sequence's column of the B operand only feeds its own gates, and nothing of a
+            // finished sequence is stored again (its padded outputs are zero-filled below), in either direction.
+#pragma unroll
+            for (int t = 0; t < NT; ++t) gates(t);
+        } else {
+            // Software pipeline over the tiles inside the wave (two waves per SIMD): the MFMAs of tile k+1 are issued over the gate math of
+            // tile k -- an MFMA occupies the matrix pipe for 16 cycles and the issue port for 4 -- so only the last tile's gate math of
+            // the lower-priority wave is exposed.  All KB h fragments are read once (half the LDS traffic of the 16-wave form: every
+            // wave reads the whole B operand, 128 KB per step and CU there, a third of the step at 128 B/clk).
+            f16x8 hh1[KB], hh2[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                hh1[kb] = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+                hh2[kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh1[kb], acc[t], 0, 0, 0);
+                    acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh2[kb], acx[t], 0, 0, 0);
+                    acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], hh1[kb], acx[t], 0, 0, 0);
+                }
+                if (t == 0) {
+                    if (DEFER) store_prev();
+                    load_g(id_n, gnext);
+                    id_n = idp[step + 2];
+                } else {
+                    gates(t - 1);
+#pragma unroll
+                    for (int q = 0; q < 3 * KB; ++q) {       // one MFMA, then three of the previous tile's VALU instructions, ...
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    }
+                }
+            }
+#ifdef NIR_PT_TRACE
+            asm volatile("" : "+v"(acc[NT - 1]), "+v"(acx[NT - 1]));
+            PT_T(tr_t1); tr_a += tr_t1 - tr_t0;
+#endif
+            gates(NT - 1);
         }
+        // the two h terms for the next step's B operand
+        if (full && (NT == 4 || NT == 2)) {
+            _Float16 a[NT], r[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                a[t] = (_Float16)hn[t];
+                r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
+            }
+            if (NT == 4) {
+                *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = (f16x4){a[0], a[1 % NT], a[2 % NT], a[3 % NT]};
+                *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = (f16x4){r[0], r[1 % NT], r[2 % NT], r[3 % NT]};
+            } else {
+                *reinterpret_cast<f16x2*>(zn + sq * ZLD + u0) = (f16x2){a[0], a[1 % NT]};
+                *reinterpret_cast<f16x2*>(zn + SEQ * ZLD + sq * ZLD + u0) = (f16x2){r[0], r[1 % NT]};
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (u0 + t < H) {
+                    const _Float16 a = (_Float16)hn[t];
+                    zn[sq * ZLD + u0 + t] = a;
+                    zn[SEQ * ZLD + sq * ZLD + u0 + t] = (_Float16)((hn[t] - (float)a) * SC);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) hprev[t] = hn[t];
+        poff = live ? soff : OOB;
+        soff += sstep;
+        if (!DEFER) store_prev();                  // (this step's output)
+#ifdef NIR_PT_TRACE
+        PT_T(tr_t2); tr_b += tr_t2 - tr_t1;
+#endif
         lds_barrier();
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (unit_d[t] < H && sq < nvalid) {
-            const int64_t m = m0 + sq;
-            for (int t2 = mylen; t2 < T; ++t2) p.out[(m * T + t2) * OW + (int64_t)dir * H + unit_d[t]] = 0.f;
-        }
+    if (DEFER) store_prev();
+#ifdef NIR_PT_TRACE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && g_pt_trace_dev) {
+        unsigned long long tn; PT_T(tn);
+        unsigned long long* o = g_pt_trace_dev + wave * 8;
+        o[0] = tr_a; o[1] = tr_b; o[2] = tr_c; o[3] = tn - tr_first; o[4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)); o[5] = tmax;
+    }
+#endif
+    // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced (ragged batches are the normal case)
+    for (int s_ = 0; s_ < nvalid; ++s_) {
+        float* orow = p.out + (m0 + s_) * T * OW + (int64_t)dir * H;
+        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
+            for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = 0.f;
     }
 }
 
 template <int KB, int NT, int NW = 16>
 static int launch_pt_h2(const LstmPtArgs& p, hipStream_t st) {
     static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + ">";
-    const size_t lds = (size_t)(4 * 16 * (32 * KB + 8)) * 2 + 16 * 4 + (size_t)16 * p.T * 4;
+    const size_t lds = (size_t)(4 * 16 * (32 * KB + 8)) * 2 + 2 * 16 * 4 + (size_t)16 * (p.T + 3) * 4;
     ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
+#ifdef NIR_PT_TRACE
+    { unsigned long long* d = g_debug_buf; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pt_trace_dev), &d, sizeof(d), 0, hipMemcpyHostToDevice, st); }
+#endif
     hipLaunchKernelGGL((lstm16_pt_h2_kernel<KB, NT, NW>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(64 * NW), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2]");
     return 0;
@@ -702,7 +843,9 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
             const int sel = tun(g_tun.lstm_s);
             if (sel == 2 || (sel != 1 && wgs >= 2 * (int64_t)ncu)) return launch_pt_h2<3, 5, 4>(p, st);
         }
-        return KB == 3 ? launch_pt_h2<3, 2>(p, st) : launch_pt_h2<4, 2>(p, st);
+        if (KB == 3) return launch_pt_h2<3, 2>(p, st);
+        // H in (96, 128]: 8 waves x 4 tiles with the in-wave pipeline (tunable lstm_w16 = 1: the 16-wave x 2-tile form)
+        return tun(g_tun.lstm_w16) ? launch_pt_h2<4, 2>(p, st) : launch_pt_h2<4, 4, 8>(p, st);
     }
     const int G = (H + 15) / 16;
     if (H <= 64) {
