@@ -255,43 +255,42 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
         f32x4 acc[NB];
 #pragma unroll
         for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // k-groups in chunks of CH with all of a chunk's operand loads issued before its first MFMA.  (`#pragma unroll 4` on the
-        // runtime-strided loop `for (q = wave; q < nq; q += 4)` was not honoured: every k-group waited for its own L2 round trip --
-        // 12 round trips per step at I + H = 768.)  Unconditional loads from a clamped k, masked afterwards.
-        constexpr int CH = NB <= 2 ? 4 : 2;       // (8 measured slower at B = 16: the 4 x-part groups of a wave fill half a chunk; 8 WAVES per
-                                                  // workgroup with every load of a wave up front -- one round trip per step -- measured slower still,
-                                                  // round 3: 8.8 -> 12 us per session step, decoder step 20 -> 23 us: the 8-way LDS reduction and the
-                                                  // halved number of co-resident workgroups cost more than the two saved round trips)
-        auto accumulate = [&](const float* wrow, const float* const (&rows)[NB], int K, int nq) {
-            for (int q0 = wave; q0 < nq; q0 += 4 * CH) {
-                float4 a4[CH], b4[CH][NB];
+        // ONE list of k-groups over both products (x W_ih^T: groups 0 .. nq1-1, h W_hh^T: the rest), walked in chunks of CH per wave with
+        // all of a chunk's operand loads issued before its first MFMA: at I + H = 768 and B <= 16 a wave's 12 groups are a single chunk,
+        // i.e. ONE L2 / HBM round trip per step.  (Two separate walks -- 4 + 8 groups per wave in chunks of 4 -- were three dependent
+        // round trips: 9.4 us per session step against ~6 MB of weights; `#pragma unroll` on the runtime-strided loop was not honoured
+        // either.)  Unconditional loads from a clamped k, masked afterwards.
+        constexpr int CH = NB == 1 ? 12 : (NB == 2 ? 8 : 6);
+        const int nqt = nq1 + nq2;
+        for (int q0 = wave; q0 < nqt; q0 += 4 * CH) {
+            float4 a4[CH], b4[CH][NB];
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int k = 16 * (q0 + 4 * c) + 4 * g;
-                    const float km = k < K ? 1.f : 0.f;
-                    const int kc = k < K ? k : 0;
-                    a4[c] = *reinterpret_cast<const float4*>(wrow + kc);
-                    a4[c].x *= km; a4[c].y *= km; a4[c].z *= km; a4[c].w *= km;
+            for (int c = 0; c < CH; ++c) {
+                const int q = q0 + 4 * c;
+                const bool second = q >= nq1;                 // wave-uniform
+                const int K = second ? H : I;
+                const int k = 16 * (second ? q - nq1 : q) + 4 * g;
+                const float km = (q < nqt && k < K) ? 1.f : 0.f;
+                const int kc = (q < nqt && k < K) ? k : 0;
+                a4[c] = *reinterpret_cast<const float4*>((second ? wh : wi) + kc);
+                a4[c].x *= km; a4[c].y *= km; a4[c].z *= km; a4[c].w *= km;
 #pragma unroll
-                    for (int t = 0; t < NB; ++t) {
-                        b4[c][t] = *reinterpret_cast<const float4*>(rows[t] + kc);
-                        b4[c][t].x *= bm[t]; b4[c][t].y *= bm[t]; b4[c][t].z *= bm[t]; b4[c][t].w *= bm[t];
-                    }
+                for (int t = 0; t < NB; ++t) {
+                    b4[c][t] = *reinterpret_cast<const float4*>(((second && hr[t]) ? hr[t] : xr[t]) + kc);
+                    b4[c][t].x *= bm[t]; b4[c][t].y *= bm[t]; b4[c][t].z *= bm[t]; b4[c][t].w *= bm[t];
                 }
-                __builtin_amdgcn_sched_barrier(0);     // without it the scheduler sinks every load next to its first use again
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-#pragma unroll
-                    for (int t = 0; t < NB; ++t) {
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].x, b4[c][t].x, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].y, b4[c][t].y, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].z, b4[c][t].z, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].w, b4[c][t].w, acc[t], 0, 0, 0);
-                    }
             }
-        };
-        accumulate(wi, xr, I, nq1);
-        if (nq2 > 0) accumulate(wh, hr, H, nq2);
+            __builtin_amdgcn_sched_barrier(0);         // without it the scheduler sinks every load next to its first use again
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].x, b4[c][t].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].y, b4[c][t].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].z, b4[c][t].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].w, b4[c][t].w, acc[t], 0, 0, 0);
+                }
+        }
 #pragma unroll
         for (int t = 0; t < NB; ++t)
 #pragma unroll

@@ -637,9 +637,13 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
     f32x4 acc[NT], acx[NT];
     float hn[NT] = {};
+#ifdef NIR_X_NOGATES   // ablation: the step without its gate math (tools/recur_micro.py)
+    auto gates = [&](int t) { hn[t] = (acx[t][0] + acc[t][1]) * 1e-3f; };
+#else
     auto gates = [&](int t) { lstm_cell_v(acx[t] * ISC + acc[t], creg[t], hn[t]); };
+#endif
 #ifdef NIR_PT_TRACE
-    unsigned long long tr_a = 0, tr_b = 0, tr_c = 0, tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_first = 0;
+    unsigned long long tr_a = 0, tr_b = 0, tr_c = 0, tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_first = 0, tr_l = 0, tr_m = 0;
 #endif
     for (int step = 0; step < tmax; ++step) {
 #ifdef NIR_PT_TRACE
@@ -693,6 +697,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
                 hh1[kb] = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
                 hh2[kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
             }
+#ifdef NIR_PT_TRACE
+            { unsigned long long tn; PT_T(tn); tr_l += tn - tr_t0; }
+#endif
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -706,6 +713,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
                     load_g(id_n, gnext);
                     id_n = idp[step + 2];
                 } else {
+#ifdef NIR_PT_TRACE
+                    if (t == 1) { asm volatile("" : "+v"(acc[0]), "+v"(acx[0])); unsigned long long tn; PT_T(tn); tr_m += tn - tr_t0; }
+#endif
                     gates(t - 1);
 #pragma unroll
                     for (int q = 0; q < 3 * KB; ++q) {       // one MFMA, then three of the previous tile's VALU instructions, ...
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && g_pt_trace_dev) {
         unsigned long long tn; PT_T(tn);
         unsigned long long* o = g_pt_trace_dev + wave * 8;
-        o[0] = tr_a; o[1] = tr_b; o[2] = tr_c; o[3] = tn - tr_first; o[4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)); o[5] = tmax;
+        o[0] = tr_a; o[1] = tr_b; o[2] = tr_c; o[3] = tn - tr_first; o[4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)); o[5] = tmax; o[6] = tr_l; o[7] = tr_m;
     }
 #endif
     // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced (ragged batches are the normal case)

@@ -43,6 +43,29 @@ __global__ __launch_bounds__(256) void lstm_step_cell_kernel(const float* __rest
     out[(m * T + t) * ND * (int64_t)H + (int64_t)dir * H + j] = h;
 }
 
+// GRU step (torch.nn.GRU gate order r, z, n): gin = x W_ih^T + b_ih; hw = h_{t-1} W_hh^T + b_hh (null at the first step of a zero state:
+// then hw = b_hh);  r = s(gin_r + hw_r), z = s(gin_z + hw_z), n = tanh(gin_n + r hw_n), h = (1 - z) n + z h_{t-1}.
+__global__ __launch_bounds__(256) void gru_step_cell_kernel(const float* __restrict__ hw, const float* __restrict__ bhh, const float* __restrict__ gin,
+                                                            const int64_t* __restrict__ lens, float* __restrict__ hstate, float* __restrict__ out,
+                                                            int64_t M, int T, int H, int ND, int dir, int step) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * H) return;
+    const int64_t m = i / H;
+    const int j = (int)(i - m * H);
+    int len = lens ? (int)lens[m] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);
+    if (step >= len) return;
+    const int t = dir == 0 ? step : len - 1 - step;
+    const float* g = gin + ((m * T + t) * ND + dir) * 3 * (int64_t)H;
+    const float* r = hw ? hw + m * 3 * (int64_t)H : bhh;
+    const float gr = fast_sigmoid(g[j] + r[j]);
+    const float gz = fast_sigmoid(g[H + j] + r[H + j]);
+    const float gn = fast_tanh(g[2 * H + j] + gr * r[2 * H + j]);
+    const float h = (1.0f - gz) * gn + gz * hstate[i];
+    hstate[i] = h;
+    out[(m * T + t) * ND * (int64_t)H + (int64_t)dir * H + j] = h;
+}
+
 __global__ void fill_f32_kernel(float* p, float v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -58,8 +81,16 @@ size_t lstm_steps_ws_floats(int64_t M, int H) { return 2 * ((size_t)M * H * 2 + 
 // gates_in [M,T,ND*4H] (both biases included), w_hh [ND,4H,H]; out [M,T,ND*H] zero beyond each length; hn/cn [ND,M,H] or null.
 // The two directions are independent chains of T x (GEMM, cell): with one batch in flight the reverse direction runs on
 // the side stream (own state / scratch set), with several batches in flight ForkJoin is a no-op and they run back to back.
+int launch_birnn_steps(int cell, const float* gin, const int64_t* lens, const float* whh, const float* bhh, const float* h0, const float* c0,
+                       float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st);
 int launch_bilstm_steps(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0, float* out,
                         float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st) {
+    return launch_birnn_steps(0, gin, lens, whh, nullptr, h0, c0, out, hn, cn, M, T, H, ND, ws, st);
+}
+// cell 0: LSTM (gates_in carries both biases, G = 4); cell 1: GRU (gates_in carries b_ih, b_hh [ND,3H] joins the recurrent product, G = 3)
+int launch_birnn_steps(int cell, const float* gin, const int64_t* lens, const float* whh, const float* bhh, const float* h0, const float* c0,
+                       float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st) {
+    const int G = cell == 1 ? 3 : 4;
     hipLaunchKernelGGL(fill_f32_kernel, g1(M * T * ND * H), dim3(256), 0, st, out, 0.f, M * T * ND * (int64_t)H);
     ForkJoin fj(st);
     if (ND == 2) fj.fork();
@@ -68,20 +99,25 @@ int launch_bilstm_steps(const float* gin, const int64_t* lens, const float* whh,
         float* hs = ws + (size_t)dir * ((size_t)M * H * 2 + (size_t)M * 4 * H);
         float* cs = hs + M * H;
         float* hw = cs + M * H;
-        const float* w = whh + (int64_t)dir * 4 * H * H;
+        const float* w = whh + (int64_t)dir * G * H * H;
+        const float* bh = bhh ? bhh + (int64_t)dir * G * H : nullptr;
         if (h0) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, h0 + (int64_t)dir * M * H, hs, M * (int64_t)H);
         else hipLaunchKernelGGL(fill_f32_kernel, g1(M * H), dim3(256), 0, ds, hs, 0.f, M * (int64_t)H);
         if (c0) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, c0 + (int64_t)dir * M * H, cs, M * (int64_t)H);
         else hipLaunchKernelGGL(fill_f32_kernel, g1(M * H), dim3(256), 0, ds, cs, 0.f, M * (int64_t)H);
         for (int step = 0; step < T; ++step) {
             const bool skip_gemm = step == 0 && !h0;          // h_{-1} = 0
-            if (!skip_gemm) NIR_PROPAGATE(launch_linear(hs, H, nullptr, nullptr, 0, 0, 0, w, H, nullptr, nullptr, hw, 4 * H, M, 4 * H, H, NIR_ACT_NONE, ds));
-            ProfScope ps("lstm_step_cell_kernel", ds);
-            hipLaunchKernelGGL(lstm_step_cell_kernel, g1(M * H), dim3(256), 0, ds, skip_gemm ? nullptr : hw, gin, lens, hs, cs, out, M, T, H,
-                               ND, dir, step);
+            if (!skip_gemm) NIR_PROPAGATE(launch_linear(hs, H, nullptr, nullptr, 0, 0, 0, w, H, bh, nullptr, hw, G * H, M, G * H, H, NIR_ACT_NONE, ds));
+            ProfScope ps(cell == 1 ? "gru_step_cell_kernel" : "lstm_step_cell_kernel", ds);
+            if (cell == 1)
+                hipLaunchKernelGGL(gru_step_cell_kernel, g1(M * H), dim3(256), 0, ds, skip_gemm ? nullptr : hw, bh, gin, lens, hs, out, M, T, H, ND,
+                                   dir, step);
+            else
+                hipLaunchKernelGGL(lstm_step_cell_kernel, g1(M * H), dim3(256), 0, ds, skip_gemm ? nullptr : hw, gin, lens, hs, cs, out, M, T, H,
+                                   ND, dir, step);
         }
         if (hn) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, hs, hn + (int64_t)dir * M * H, M * (int64_t)H);
-        if (cn) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, cs, cn + (int64_t)dir * M * H, M * (int64_t)H);
+        if (cn && cell == 0) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, cs, cn + (int64_t)dir * M * H, M * (int64_t)H);
     }
     if (ND == 2) fj.join();
     NIR_CHECK_LAUNCH("nir_bilstm_steps_fwd");
@@ -177,6 +213,20 @@ extern "C" int nir_bilstm_steps_fwd(const float* gates_in, const int64_t* length
     NIR_REQUIRE(workspace_bytes >= nir_bilstm_steps_workspace_bytes(M, H), "bilstm_steps: workspace too small");
     if (M == 0) return 0;
     return launch_bilstm_steps(gates_in, lengths, w_hh, h0, c0, out, hn, cn, M, T, H, ndir, (float*)workspace, (hipStream_t)stream);
+}
+
+extern "C" int nir_birnn_steps_fwd(int cell, const float* gates_in, const int64_t* lengths, const float* w_hh, const float* b_hh, const float* h0,
+                                   const float* c0, float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir, void* workspace,
+                                   size_t workspace_bytes, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(cell == NIR_CELL_LSTM || cell == NIR_CELL_GRU, "birnn_steps: cell must be NIR_CELL_LSTM or NIR_CELL_GRU");
+    NIR_REQUIRE(gates_in && w_hh && out && workspace, "birnn_steps: null pointer");
+    NIR_REQUIRE(cell == NIR_CELL_LSTM || b_hh, "birnn_steps: the GRU needs b_hh (it sits inside the reset-gate product)");
+    NIR_REQUIRE(M >= 0 && T > 0 && H > 0 && (ndir == 1 || ndir == 2), "birnn_steps: bad dims");
+    NIR_REQUIRE(workspace_bytes >= nir_bilstm_steps_workspace_bytes(M, H), "birnn_steps: workspace too small");
+    if (M == 0) return 0;
+    return launch_birnn_steps(cell, gates_in, lengths, w_hh, cell == NIR_CELL_GRU ? b_hh : nullptr, h0, c0, out, hn, cn, M, T, H, ndir,
+                              (float*)workspace, (hipStream_t)stream);
 }
 
 extern "C" size_t nir_mnsrf_workspace_bytes(int64_t B, int S, int N, int QL, int DL, const nir_mnsrf_weights* w) {

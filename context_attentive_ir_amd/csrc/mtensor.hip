@@ -606,14 +606,16 @@ namespace nir {
 static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const int64_t* d_ids, const int64_t* d_len, int B, int N, int QL,
                             int DL, const float* table, int64_t V, int E, const void* fold_q, const void* fold_d, int fold_dtype,
                             const nir_matchtensor_weights* w, void* workspace, size_t workspace_bytes, float* scores, float* enc_q,
-                            float* enc_d, float* proj_q, float* proj_d, int* err_flag, hipStream_t st) {
+                            float* enc_d, float* proj_q, float* proj_d, int* err_flag, hipStream_t st, const float* given_q = nullptr,
+                            const float* given_d = nullptr) {
     const bool folded = fold_q != nullptr && fold_d != nullptr;
-    NIR_REQUIRE(q_ids && q_len && d_ids && d_len && (table || folded) && w && scores, "match_tensor: null pointer");
+    const bool given = given_q != nullptr && given_d != nullptr;      // encoder states supplied by the caller (any RNNEncoder configuration)
+    NIR_REQUIRE(q_ids && d_ids && (given || (q_len && d_len)) && (table || folded || given) && w && scores, "match_tensor: null pointer");
     NIR_REQUIRE(B >= 0 && N > 0 && QL > 0 && DL > 0 && V > 0 && E > 0, "match_tensor: bad dims");
     NIR_REQUIRE(w->NF == NFC && w->MF == MFC, "match_tensor: nfilters=%d match_filter_size=%d unsupported (6, 20)", w->NF, w->MF);
     NIR_REQUIRE(w->C >= 1 && w->C <= CP - 6, "match_tensor: nchannels=%d unsupported (<= 50)", w->C);
-    NIR_REQUIRE(nir_bilstm_supported(w->Hq) && nir_bilstm_supported(w->Hd), "match_tensor: hidden size unsupported");
-    NIR_REQUIRE(w->F >= 1 && w->F <= 64, "match_tensor: featsize %d unsupported (1..64)", w->F);
+    NIR_REQUIRE(given || (nir_bilstm_supported(w->Hq) && nir_bilstm_supported(w->Hd)), "match_tensor: hidden size unsupported");
+    NIR_REQUIRE(given || (w->F >= 1 && w->F <= 64), "match_tensor: featsize %d unsupported (1..64)", w->F);
     NIR_REQUIRE(QL <= 256, "match_tensor: query length %d > 256 unsupported", QL);
     if (B == 0) return 0;
     MtPlan p = mt_plan(workspace, workspace_bytes, B, N, QL, DL, w);
@@ -622,8 +624,8 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
         return NIR_ERR_WORKSPACE;
     }
     const int64_t Mq = (int64_t)B * QL, Md = (int64_t)B * N * DL;
-    float* hq = enc_q ? enc_q : p.hq;
-    float* hd = enc_d ? enc_d : p.hd;
+    float* hq = given ? const_cast<float*>(given_q) : (enc_q ? enc_q : p.hq);
+    float* hd = given ? const_cast<float*>(given_d) : (enc_d ? enc_d : p.hd);
     float* pq = proj_q ? proj_q : p.pq;
     float* pd = proj_d ? proj_d : p.pd;
     MtHeadW hw;
@@ -664,7 +666,8 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     fj.fork();
     {   // ---- query side: gather+projection GEMM -> BiLSTM -> channel projection -> per-query weight folding
         hipStream_t qs = fj.side;
-        if (folded) {   // embedding, Linear(E->F) and the LSTM input projection folded into one table lookup (nir_lstm_fold_table)
+        if (given) {    // states come from the caller
+        } else if (folded) {   // embedding, Linear(E->F) and the LSTM input projection folded into one table lookup (nir_lstm_fold_table)
             NIR_PROPAGATE(launch_bilstm_folded(fold_q, fold_dtype, q_ids, q_len, w->q_whh, hq, err_flag, B, V, QL, w->Hq, 2, qs));
         } else {
             NIR_PROPAGATE(launch_linear(nullptr, 0, q_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xq, w->F, Mq, w->F, E, NIR_ACT_NONE, qs));
@@ -681,7 +684,8 @@ static int matchtensor_impl(const int64_t* q_ids, const int64_t* q_len, const in
     // ---- document side (mtensor.py:80-110): gather fused into the projection GEMM; the LSTM input projection
     // (I = featsize = 40) is fused into the recurrence, so the [tokens, 8H] gate tensor is never written;
     // padded positions of the channel projection give the bias (E3)
-    if (folded) {
+    if (given) {
+    } else if (folded) {
         NIR_PROPAGATE(launch_bilstm_folded(fold_d, fold_dtype, d_ids, d_len, w->d_whh, hd, err_flag, (int64_t)B * N, V, DL, w->Hd, 2, st));
     } else {
         NIR_PROPAGATE(launch_linear(nullptr, 0, d_ids, table, E, 1, 1, w->proj_w, E, w->proj_b, nullptr, p.xd, w->F, Md, w->F, E, NIR_ACT_NONE, st));
@@ -733,3 +737,12 @@ extern "C" int nir_matchtensor_score_folded(const int64_t* q_ids, const int64_t*
                             scores, enc_q, enc_d, proj_q, proj_d, err_flag, (hipStream_t)stream);
 }
 
+
+extern "C" int nir_matchtensor_score_encoded(const int64_t* q_ids, const int64_t* d_ids, const float* enc_q, const float* enc_d, int B, int N,
+                                             int QL, int DL, const nir_matchtensor_weights* w, void* workspace, size_t workspace_bytes,
+                                             float* scores, float* proj_q, float* proj_d, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(enc_q && enc_d, "match_tensor_encoded: null encoder states");
+    return matchtensor_impl(q_ids, nullptr, d_ids, nullptr, B, N, QL, DL, nullptr, 1, 1, nullptr, nullptr, 0, w, workspace, workspace_bytes, scores,
+                            nullptr, nullptr, proj_q, proj_d, nullptr, (hipStream_t)stream, enc_q, enc_d);
+}

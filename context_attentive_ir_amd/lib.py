@@ -86,6 +86,7 @@ SIGNATURES = {
     "nir_bilstm_fused_fwd": (_i, [c_fp, _i, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
     "nir_bilstm_steps_workspace_bytes": (_z, [_l, _i]),
     "nir_bilstm_steps_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, C.c_void_p, _z, c_st]),
+    "nir_birnn_steps_fwd": (_i, [_i, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, C.c_void_p, _z, c_st]),
     "nir_mnsrf_workspace_bytes": (_z, [_l, _i, _i, _i, _i, C.POINTER(MnsrfWeights)]),
     "nir_mnsrf_encode": (_i, [c_ip, c_ip, _l, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z, c_fp, c_fp, c_st]),
     "nir_mnsrf_score": (_i, [c_ip, c_ip, c_ip, c_ip, _l, _i, _i, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z,
@@ -99,6 +100,8 @@ SIGNATURES = {
     "nir_matchtensor_workspace_bytes": (_z, [_i, _i, _i, _i, C.POINTER(MatchTensorWeights)]),
     "nir_matchtensor_score": (_i, [c_ip, c_ip, c_ip, c_ip, _i, _i, _i, _i, c_fp, _l, _i,
                                    C.POINTER(MatchTensorWeights), C.c_void_p, _z, c_fp, c_fp, c_fp, c_fp, c_fp, c_st]),
+    "nir_matchtensor_score_encoded": (_i, [c_ip, c_ip, c_fp, c_fp, _i, _i, _i, _i, C.POINTER(MatchTensorWeights), C.c_void_p, _z, c_fp, c_fp, c_fp,
+                                           c_st]),
     "nir_matchtensor_score_folded": (_i, [c_ip, c_ip, c_ip, c_ip, _i, _i, _i, _i, C.c_void_p, C.c_void_p, _i, _l,
                                           C.POINTER(MatchTensorWeights), C.c_void_p, _z, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_void_p, c_st]),
     "nir_duet_workspace_bytes": (_z, [_i, _i, _i, _i, _i, C.POINTER(DuetWeights)]),

@@ -54,8 +54,12 @@ class CARS(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1 or args.pool_type != "attn":
-            raise NotImplementedError("HIP CARS supports the reference configuration (hyparam.py:197-225): "
-                                      "LSTM, bidirectional, 1 layer, pool_type='attn'")
+            # rnn_type='GRU' and nlayers > 1 are not working configurations of the reference's session models either: the session loop hands
+            # the previous state back as init_states (cars.py:378-402), and rnn_encoder.py:77 evaluates `if init_states:` on a tensor (GRU:
+            # RuntimeError) / :79-91 splits the states by `nlayers` (2 layers: IndexError) -- verified against /root/reference.  The general
+            # RNNEncoder (GRU, stacked layers, bridge) serves MATCH_TENSOR, which has no initial states.
+            raise NotImplementedError("HIP CARS supports the reference configuration (hyparam.py:197-225): LSTM, bidirectional, 1 layer, "
+                                      "pool_type='attn' (GRU / stacked layers fail in the reference's own session loop too)")
         if getattr(args, "attn_type", "general") != "general":
             raise NotImplementedError("HIP CARS decoder supports attn_type='general' (hyparam.py:206)")
         p = args.dropout

@@ -29,7 +29,8 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1:
-            raise NotImplementedError("HIP M_MATCH_TENSOR expects the reference configuration: 1-layer bidirectional LSTM")
+            raise NotImplementedError("HIP M_MATCH_TENSOR expects the reference configuration: 1-layer bidirectional LSTM encoders (GRU / stacked layers fail in "
+                                      "the reference's own session loop: rnn_encoder.py:77-91 on the states it hands back as init_states)")
         self.embedder = Embedder(args.emsize, args.src_vocab_size, args.dropout_emb)
         self.linear_projection = nn.Linear(args.emsize, args.featsize)
         self.query_encoder = Encoder(args.rnn_type, args.featsize, args.bidirection, args.nlayers, args.nhid_query,

@@ -22,7 +22,8 @@ class MNSRF(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
         if args.rnn_type != "LSTM" or not args.bidirection or args.nlayers != 1:
-            raise NotImplementedError("HIP MNSRF expects the reference configuration: 1-layer bidirectional LSTM encoders")
+            raise NotImplementedError("HIP MNSRF expects the reference configuration: 1-layer bidirectional LSTM encoders (GRU / stacked layers fail in "
+                                      "the reference's own session loop: rnn_encoder.py:77-91 on the states it hands back as init_states)")
         self.embedder = Embedder(args.emsize, args.src_vocab_size, args.dropout_emb)
         self.query_encoder = Encoder(args.rnn_type, args.emsize, args.bidirection, args.nlayers, args.nhid_query, args.dropout_rnn)
         self.document_encoder = Encoder(args.rnn_type, args.emsize, args.bidirection, args.nlayers, args.nhid_document,

@@ -153,8 +153,49 @@ class MatchTensor(nn.Module, lib.IdCheck):
         g = g.view(M, QL * DL, -1).max(1)[0]
         return A.linear(g, self.output.weight, self.output.bias).view(B, N)
 
+    def _generic_encoders(self):
+        """encoder configurations outside the fused / folded kernels (rnn_encoder.py:28-60 admits GRU and stacked layers; hyparam pins the
+        1-layer LSTM): the encoders then run as RNNEncoder modules and the head takes their states (nir_matchtensor_score_encoded)"""
+        e = self.query_encoder
+        return e.cell != 0 or e.nlayers != 1
+
+    def _forward_generic(self, batch_queries, query_len, batch_docs, doc_len, return_parts):
+        table = self.word_embeddings.table
+        lib.require_device(batch_queries, batch_docs, query_len, doc_len, table)
+        L = lib.load()
+        q, d = self._clean_ids(batch_queries, batch_docs, table.shape[0])
+        ql, dl = lib.ids64(query_len), lib.ids64(doc_len.reshape(-1))
+        B, QL = q.shape
+        N, DL = d.shape[1], d.shape[2]
+        dev, dm = q.device, self._dims
+        w = self._weights()
+        scores = torch.empty(B, N, device=dev, dtype=torch.float32)
+        if B == 0:
+            return (scores, [None] * 4) if return_parts else scores
+        t = table.detach().float().contiguous()
+        E, F_ = t.shape[1], dm["F"]
+
+        def project(ids):                                        # embedding gather fused into the Linear(E -> F) GEMM
+            x = torch.empty(ids.numel(), F_, device=dev, dtype=torch.float32)
+            lib.check(L.nir_linear_f32(None, 0, lib.ptr(ids), lib.ptr(t), E, 1, 1, lib.ptr(w.keep["proj_w"]), E, lib.ptr(w.keep["proj_b"]), None,
+                                       lib.ptr(x), F_, ids.numel(), F_, E, 0, lib.stream()), "nir_linear_f32")
+            return x
+        hq = self.query_encoder(project(q).view(B, QL, F_), ql)[1].contiguous()
+        hd = self.document_encoder(project(d).view(B * N, DL, F_), dl)[1].contiguous()
+        ws = lib.workspace(L.nir_matchtensor_workspace_bytes(B, N, QL, DL, w.ref()), dev)
+        pq = torch.empty(B, QL, dm["C"], device=dev) if return_parts else None
+        pd = torch.empty(B * N, DL, dm["C"], device=dev) if return_parts else None
+        lib.check(L.nir_matchtensor_score_encoded(lib.ptr(q), lib.ptr(d), lib.ptr(hq), lib.ptr(hd), B, N, QL, DL, w.ref(), lib.ptr(ws), ws.numel(),
+                                                  lib.ptr(scores), lib.ptr(pq), lib.ptr(pd), lib.stream()), "nir_matchtensor_score_encoded")
+        return (scores, [hq, hd, pq, pd]) if return_parts else scores
+
     def forward(self, batch_queries, query_len, batch_docs, doc_len, return_parts=False):
         assert batch_queries.shape[0] == batch_docs.shape[0]
+        if self._generic_encoders():
+            if self.training:
+                raise NotImplementedError("HIP MatchTensor trains the hyparam configuration (1-layer LSTM encoders, autograd.py); "
+                                          "GRU / stacked encoders are eval-only")
+            return self._forward_generic(batch_queries, query_len, batch_docs, doc_len, return_parts)
         if self.training:
             lib.require_device(batch_queries, batch_docs, query_len, doc_len, self.word_embeddings.table)
             q, d = self._clean_ids(batch_queries, batch_docs, self.word_embeddings.table.shape[0])

@@ -215,6 +215,14 @@ int nir_matchtensor_score_folded(const int64_t* q_ids, const int64_t* q_len, con
                                  const nir_matchtensor_weights* w /*host*/, void* workspace, size_t workspace_bytes, float* scores,
                                  float* enc_q, float* enc_d, float* proj_q, float* proj_d, int* err_flag, nir_stream_t stream);
 
+/* The same interaction head over encoder states the caller computed (enc_q [B,QL,2*Hq], enc_d [B*N,DL,2*Hd], w->Hq / w->Hd = half their
+ * widths; zero rows at padded positions, as RNNEncoder returns them): channel projections -> exact-match channel -> three convolutions ->
+ * 1x1 convolution -> global max -> output (mtensor.py:74-131).  This is the path of every RNNEncoder configuration the fused entries do
+ * not cover (GRU, stacked layers: rnn_encoder.py:28-60); the LSTM / projection fields of w are not read. */
+int nir_matchtensor_score_encoded(const int64_t* q_ids, const int64_t* d_ids, const float* enc_q, const float* enc_d, int B, int N, int QL,
+                                  int DL, const nir_matchtensor_weights* w /*host*/, void* workspace, size_t workspace_bytes, float* scores,
+                                  float* proj_q, float* proj_d, nir_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * DUET  (neuroir/rankers/duet.py:28-59 forward, 77-121 local, 148-208 distributed)
  * ------------------------------------------------------------------------------------------------ */
@@ -403,6 +411,14 @@ size_t nir_bilstm_steps_workspace_bytes(int64_t M, int H);
 int nir_bilstm_steps_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0,
                          float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir, void* workspace,
                          size_t workspace_bytes, nir_stream_t stream);
+/* The same streaming recurrence for either cell of the reference's RNNEncoder (rnn_encoder.py:28-60: getattr(nn, rnn_type), one module per
+ * layer): NIR_CELL_LSTM = nir_bilstm_steps_fwd; NIR_CELL_GRU: torch.nn.GRU semantics, gate order (r, z, n), gates_in = x W_ih^T + b_ih
+ * [M,T,ndir*3H], w_hh [ndir,3H,H], b_hh [ndir,3H] (inside the reset-gate product), c0 / cn unused.  Workspace: nir_bilstm_steps_workspace_bytes. */
+#define NIR_CELL_LSTM 0
+#define NIR_CELL_GRU 1
+int nir_birnn_steps_fwd(int cell, const float* gates_in, const int64_t* lengths, const float* w_hh, const float* b_hh, const float* h0,
+                        const float* c0, float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir, void* workspace,
+                        size_t workspace_bytes, nir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * MNSRF, ranking side (neuroir/multitask/mnsrf.py:62-162)

@@ -67,6 +67,61 @@ def rnn_encode(sd, prefix, x, lengths, bidirectional=True, init=None):
     return fin, out
 
 
+def rnn_encoder_general(sd, prefix, x, lengths, rnn_type="LSTM", bidirectional=True, nlayers=1, use_last=True, use_bridge=False, init=None):
+    """neuroir/encoders/rnn_encoder.py:62-185 in full: one single-layer nn.LSTM / nn.GRU per layer (`rnns.{i}`), sort -> pack -> rnn ->
+    unpack per layer (:93-117), `use_last` selection or concatenation over layers (:119-132), bridge = Linear + ReLU on every state viewed
+    as [-1, total_hidden_dim] (:159-185).  `sd` keys are `prefix + rnns.{i}.*` / `prefix + bridge.{j}.*` (prefix '' or ending in '.').
+    Final states stay in length-sorted order like the reference; dropout between layers is the eval-mode identity."""
+    ndir = 2 if bidirectional else 1
+    mods = []
+    for i in range(nlayers):
+        w_ih = sd["%srnns.%d.weight_ih_l0" % (prefix, i)]
+        G = 4 if rnn_type == "LSTM" else 3
+        m = getattr(torch.nn, rnn_type)(w_ih.shape[1], w_ih.shape[0] // G, 1, batch_first=True, bidirectional=bidirectional).to(w_ih.dtype)
+        m.load_state_dict({k[len("%srnns.%d." % (prefix, i)):]: v for k, v in sd.items() if isinstance(k, str) and k.startswith("%srnns.%d." % (prefix, i))})
+        mods.append(m.eval())
+    order = inv = slen = None
+    cur = x
+    if lengths is not None:
+        slen, order = torch.sort(lengths, 0, True)
+        inv = torch.sort(order, 0)[1]
+        cur = pack_padded_sequence(x[order], slen.tolist(), batch_first=True)
+    ist = []
+    if init is not None:                                          # :76-91 (tuple states only: `if init_states:` on a tensor raises)
+        hs, cs = init
+        hs, cs = hs.split(nlayers, 0), cs.split(nlayers, 0)
+        ist = [(hs[i], cs[i]) for i in range(nlayers)]
+    bank, h_n, c_n = [], [], []
+    for i in range(nlayers):
+        if i != 0 and lengths is not None:
+            cur = pack_padded_sequence(cur, slen.tolist(), batch_first=True)
+        cur, st = mods[i](cur, ist[i]) if ist else mods[i](cur)
+        if isinstance(st, tuple):
+            h_n.append(st[0]); c_n.append(st[1])
+        else:
+            h_n.append(st)
+        if lengths is not None:
+            cur = pad_packed_sequence(cur, batch_first=True)[0]
+        if not use_last or i == nlayers - 1:
+            bank.append(cur[inv] if lengths is not None else cur)
+    if use_last:
+        mem = bank[-1]
+        fin = (h_n[-1], c_n[-1]) if c_n else h_n[-1]
+    else:
+        mem = torch.cat(bank, 2)
+        fin = (torch.cat(h_n, 0), torch.cat(c_n, 0)) if c_n else torch.cat(h_n, 0)
+    if use_bridge:
+        hid = mods[0].hidden_size
+        tot = hid * (1 if use_last else nlayers)
+
+        def bottle(j, states):
+            return F.relu(F.linear(states.reshape(-1, tot), sd["%sbridge.%d.weight" % (prefix, j)], sd["%sbridge.%d.bias" % (prefix, j)])).view(states.shape)
+        fin = tuple(bottle(j, t) for j, t in enumerate(fin)) if isinstance(fin, tuple) else bottle(0, fin)
+    if mem.size(1) < x.size(1):
+        mem = torch.cat([mem, mem.new_zeros(mem.size(0), x.size(1) - mem.size(1), mem.size(2))], 1)
+    return fin, mem
+
+
 # ------------------------------------------------------------------------------------------
 # ESM  (neuroir/rankers/esm.py:19-45)
 # ------------------------------------------------------------------------------------------
@@ -95,10 +150,26 @@ def match_tensor_parts(sd, q, q_len, d, d_len):
 
 
 @torch.no_grad()
+def match_tensor_general_scores(sd, q, q_len, d, d_len, rnn_type="LSTM", nlayers=1):
+    """neuroir/rankers/mtensor.py:62-131 with any encoder configuration of its constructor (:36-49: rnn_type, nlayers; use_last = True)."""
+    B, N, DL = d.shape
+    eq = _lin(sd, "linear_projection", embed(sd, "word_embeddings", q))
+    ed = _lin(sd, "linear_projection", embed(sd, "word_embeddings", d.reshape(B * N, DL)))
+    _, hq = rnn_encoder_general(sd, "query_encoder.", eq, q_len, rnn_type, True, nlayers)
+    _, hd = rnn_encoder_general(sd, "document_encoder.", ed, d_len.reshape(-1), rnn_type, True, nlayers)
+    return _match_tensor_head(sd, q, d, _lin(sd, "query_projection", hq), _lin(sd, "document_projection", hd)), hq, hd
+
+
+@torch.no_grad()
 def match_tensor_scores(sd, q, q_len, d, d_len):
+    hq, hd, pq, pd = match_tensor_parts(sd, q, q_len, d, d_len)
+    return _match_tensor_head(sd, q, d, pq, pd)
+
+
+def _match_tensor_head(sd, q, d, pq, pd):
+    """mtensor.py:100-131: broadcast product, exact-match channel, three convolutions, 1x1 convolution, global max, output layer."""
     B, QL = q.shape
     N, DL = d.shape[1], d.shape[2]
-    hq, hd, pq, pd = match_tensor_parts(sd, q, q_len, d, d_len)
     C = pq.shape[-1]
     # the reference materialises both broadcast operands (torch.stack) before multiplying
     pq_x = pq.unsqueeze(1).expand(B, N, QL, C).reshape(B * N, QL, 1, C).expand(-1, -1, DL, -1).contiguous()

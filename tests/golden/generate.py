@@ -155,6 +155,28 @@ def gen_match_tensor():
 
 
 @torch.no_grad()
+def gen_match_tensor_general():
+    """MATCH_TENSOR with the encoder configurations hyparam does not pin but the constructor admits (rnn_type GRU, stacked layers):
+    the reference ranker end to end."""
+    out = {}
+    for tag, kw in (("gru2", dict(rnn_type="GRU", nlayers=2)), ("lstm2", dict(rnn_type="LSTM", nlayers=2)), ("gru1", dict(rnn_type="GRU", nlayers=1))):
+        rng = np.random.default_rng(12)
+        B, N, QL, DL = 3, 4, 6, 20
+        qlen = np.array([6, 3, 1]); dlen = rng.integers(1, DL + 1, size=(B, N)); dlen[0, 0] = DL; dlen[2, 1] = 1
+        q = rand_ids(rng, (B, QL), qlen, hi=40); d = rand_ids(rng, (B, N, DL), dlen, hi=40)
+        m = load_det(MatchTensor(base_args("MATCH_TENSOR", **kw)))
+        tq, tql, td, tdl = T(q), T(qlen), T(d), T(dlen)
+        s = m(tq, tql, td, tdl)
+        eq = m.linear_projection(m.word_embeddings(tq.unsqueeze(2)))
+        ed = m.linear_projection(m.word_embeddings(td.view(B * N, DL).unsqueeze(2)))
+        _, hq = m.query_encoder(eq, tql)
+        _, hd = m.document_encoder(ed, tdl.reshape(-1))
+        out.update({tag + ".que_rep": q, tag + ".que_len": qlen, tag + ".doc_rep": d, tag + ".doc_len": dlen, tag + ".scores": s,
+                    tag + ".enc_q": hq, tag + ".enc_d": hd})
+    save("match_tensor_general", **out)
+
+
+@torch.no_grad()
 def gen_drmm():
     rng = np.random.default_rng(3)
     B, N, QL, DL = 3, 4, 5, 24
@@ -436,6 +458,46 @@ def gen_mnsrf():
          session_bank=sess, scores=scores, softmax=torch.softmax(scores, -1), tgt_vocab_size=50)
 
 
+@torch.no_grad()
+def gen_rnn_encoder():
+    """The reference RNNEncoder itself (encoders/rnn_encoder.py) outside the hyparam-pinned 1-layer LSTM: GRU, stacked layers, bridge,
+    use_last = False, initial states.  Final states are saved as the reference returns them (length-SORTED batch order) together with
+    the sort indices; lengths are distinct so that the (unstable) sort is unambiguous."""
+    from neuroir.encoders.rnn_encoder import RNNEncoder
+    from context_attentive_ir_amd.detinit import fill_module_
+    rng = np.random.default_rng(SEED + 55)
+    out = {}
+    cfgs = dict(gru2_bi_bridge=dict(rnn_type="GRU", input_size=10, bidirectional=True, num_layers=2, hidden_size=24, use_bridge=True, use_last=False),
+                lstm2_uni=dict(rnn_type="LSTM", input_size=10, bidirectional=False, num_layers=2, hidden_size=16, use_bridge=False, use_last=True),
+                lstm2_bi_cat=dict(rnn_type="LSTM", input_size=12, bidirectional=True, num_layers=2, hidden_size=20, use_bridge=True, use_last=False),
+                # (a GRU with initial states is not a working configuration of the reference: `if init_states:` on a tensor raises, :77)
+                lstm1_uni_init=dict(rnn_type="LSTM", input_size=8, bidirectional=False, num_layers=1, hidden_size=12, use_bridge=False, use_last=True))
+    for name, kw in cfgs.items():
+        enc = fill_module_(RNNEncoder(dropout=0.0, **kw).eval(), SEED + len(name))
+        M, Tn = 4, 7
+        x = T(rng.normal(size=(M, Tn, kw["input_size"])).astype(np.float32))
+        lens = T(np.array([5, 7, 1, 3], dtype=np.int64))
+        init = None
+        if name == "lstm1_uni_init":
+            init = (T(rng.normal(size=(1, M, 12)).astype(np.float32) * 0.5), T(rng.normal(size=(1, M, 12)).astype(np.float32) * 0.5))
+            lens = None                                           # (with lengths the reference would feed the unsorted states to sorted rows)
+        final, bank = enc(x, lens, init)
+        out[name + ".x"] = x
+        out[name + ".lens"] = lens if lens is not None else np.zeros(0, np.int64)
+        out[name + ".bank"] = bank
+        if init is not None:
+            out[name + ".init_h"], out[name + ".init_c"] = init
+        if isinstance(final, tuple):
+            out[name + ".h"], out[name + ".c"] = final
+        else:
+            out[name + ".h"] = final
+        if lens is not None:
+            out[name + ".sort_idx"] = torch.sort(lens, 0, True)[1]
+        for k, v in enc.state_dict().items():
+            out[name + ".sd." + k] = v
+    save("rnn_encoder", **out)
+
+
 def gen_batchify():
     """Input contract: the reference's own collate functions on ragged synthetic examples."""
     from neuroir.inputters.ranker.vector import batchify as ranker_batchify
@@ -510,7 +572,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])          # e.g. `generate.py cars_decode` regenerates one fixture family
     gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode, train=gen_train, duet_train=gen_duet_train, drmm_train=gen_drmm_train, drmm_train_free=gen_drmm_train_free, cars_train=gen_cars_train,
                 losses_metrics=gen_losses_metrics, batchify=gen_batchify, samplers=gen_samplers, m_match_tensor=gen_m_match_tensor,
-                mnsrf=gen_mnsrf)
+                mnsrf=gen_mnsrf, rnn_encoder=gen_rnn_encoder, match_tensor_general=gen_match_tensor_general)
     for name, fn in gens.items():
         if not only or name in only:
             fn()

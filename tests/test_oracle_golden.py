@@ -156,3 +156,42 @@ def test_match_tensor_train_gradients():
     for k, v in sd.items():
         if torch.is_tensor(v) and v.requires_grad:
             _close(v.grad, g["grad_" + k], 2e-6)
+
+
+RNN_CFGS = dict(gru2_bi_bridge=dict(rnn_type="GRU", bidirectional=True, nlayers=2, use_bridge=True, use_last=False),
+                lstm2_uni=dict(rnn_type="LSTM", bidirectional=False, nlayers=2, use_bridge=False, use_last=True),
+                lstm2_bi_cat=dict(rnn_type="LSTM", bidirectional=True, nlayers=2, use_bridge=True, use_last=False),
+                lstm1_uni_init=dict(rnn_type="LSTM", bidirectional=False, nlayers=1, use_bridge=False, use_last=True))
+
+
+def rnn_fixture(name):
+    g = load_golden("rnn_encoder")
+    pre = name + "."
+    sd = {k[len(pre) + 3:]: T(v) for k, v in g.items() if k.startswith(pre + "sd.")}
+    lens = T(g[pre + "lens"]) if g[pre + "lens"].size else None
+    init = (T(g[pre + "init_h"]), T(g[pre + "init_c"])) if pre + "init_h" in g else None
+    return g, sd, T(g[pre + "x"]), lens, init
+
+
+@pytest.mark.parametrize("name", sorted(RNN_CFGS))
+def test_rnn_encoder_general(name):
+    """oracle.rnn_encoder_general against the reference's RNNEncoder outside the 1-layer LSTM (GRU, stacked layers, bridge, use_last=False,
+    initial states): rnn_encoder.npz."""
+    g, sd, x, lens, init = rnn_fixture(name)
+    fin, mem = O.rnn_encoder_general(sd, "", x, lens, init=init, **RNN_CFGS[name])
+    assert float((mem - T(g[name + ".bank"])).abs().max()) < 1e-6
+    h = fin[0] if isinstance(fin, tuple) else fin
+    assert float((h - T(g[name + ".h"])).abs().max()) < 1e-6
+    if isinstance(fin, tuple):
+        assert float((fin[1] - T(g[name + ".c"])).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("tag,rnn_type,nlayers", [("gru2", "GRU", 2), ("lstm2", "LSTM", 2), ("gru1", "GRU", 1)])
+def test_match_tensor_general(tag, rnn_type, nlayers):
+    """oracle.match_tensor_general_scores against the reference MatchTensor built with GRU / stacked encoders (match_tensor_general.npz)."""
+    g = load_golden("match_tensor_general")
+    m = build_model("MATCH_TENSOR", rnn_type=rnn_type, nlayers=nlayers)
+    s, hq, hd = O.match_tensor_general_scores(cpu_state_dict(m), T(g[tag + ".que_rep"]), T(g[tag + ".que_len"]), T(g[tag + ".doc_rep"]),
+                                              T(g[tag + ".doc_len"]), rnn_type, nlayers)
+    assert float((hq - T(g[tag + ".enc_q"])).abs().max()) < 1e-6 and float((hd - T(g[tag + ".enc_d"])).abs().max()) < 1e-6
+    assert float((s - T(g[tag + ".scores"])).abs().max()) < 1e-5

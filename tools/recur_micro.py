@@ -77,11 +77,12 @@ def main():
           % (M, T, H, a.dtype, us, wgs, wgs / 256.0, us / T / max(1, -(-wgs // 256)), float(out.double().abs().sum()), int(err.item())))
     tr = trace.cpu().view(16, 8)
     if int(tr[:, 5].max()) > 0:
-        print("wave  hw_id(simd,slot)  matrix   gates  barrier   total   [cycles / step]")
+        print("wave  hw_id(simd,slot)  matrix   gates  barrier   total  lds-in  tile0   [s_memtime ticks / step]")
         for w in range(16):
             n = float(tr[w, 5]) or 1.0
             hw = int(tr[w, 4])
-            print("%4d  simd %d slot %2d   %7.0f %7.0f %7.0f %7.0f" % (w, (hw >> 4) & 3, hw & 15, tr[w, 0] / n, tr[w, 1] / n, tr[w, 2] / n, tr[w, 3] / n))
+            print("%4d  simd %d slot %2d   %7.0f %7.0f %7.0f %7.0f %7.0f %7.0f" % (w, (hw >> 4) & 3, hw & 15, tr[w, 0] / n, tr[w, 1] / n, tr[w, 2] / n, tr[w, 3] / n,
+                                                                             tr[w, 6] / n, tr[w, 7] / n))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,75 @@
+// Issue-rate probe for gfx950 VALU classes: cycles per wave64 instruction of v_mul_f32, v_pk_mul_f32, v_exp_f32, v_rcp_f32 and
+// v_mfma_f32_16x16x32_f16, one wave per SIMD (1 workgroup of 256 threads), independent chains.  hipcc --offload-arch=gfx950 -O2.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define REP 64
+template <int MODE>
+__global__ void probe(unsigned long long* out, float* sink, int iters) {
+    float a[8];
+    f32x2 p[8];
+    f32x4 acc[4];
+    f16x8 ha, hb;
+    for (int i = 0; i < 8; ++i) { a[i] = 1.0f + 0.001f * (threadIdx.x + i); p[i] = (f32x2){a[i], a[i] + 0.5f}; ha[i] = (_Float16)0.01f; hb[i] = (_Float16)0.02f; }
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (MODE == 0) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(1.0001f));
+                if (MODE == 1) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+                if (MODE == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                if (MODE == 3) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+                if (MODE == 4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(ha), "v"(hb));
+                if (MODE == 5) {   // 1 MFMA + 3 v_mul interleaved (can the VALU issue under a running MFMA?)
+                    if ((i & 3) == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[(i >> 2) & 3]) : "v"(ha), "v"(hb));
+                    else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(1.0001f));
+                }
+                if (MODE == 6) {   // 1 MFMA + 1 v_exp interleaved
+                    if ((i & 1) == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[(i >> 1) & 3]) : "v"(ha), "v"(hb));
+                    else asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                }
+                if (MODE == 7) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(1.0001f));
+                if (MODE == 8) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(a[i]));
+            }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 4; ++i) s += acc[i][0];
+    if (s == 12345.678f) sink[0] = s;
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+}
+int main() {
+    unsigned long long* d; float* sink;
+    hipMalloc(&d, 64 * 8); hipMalloc(&sink, 4);
+    const char* names[] = {"v_mul_f32", "v_pk_mul_f32", "v_exp_f32", "v_rcp_f32", "mfma16x16x32f16", "1 mfma + 3 v_mul (per 4)", "1 mfma + 1 v_exp (per 2)", "v_fma_f32", "v_cvt_f16_f32"};
+    for (int waves = 1; waves <= 4; waves *= 2)
+    for (int m = 0; m < 9; ++m) {
+        const int iters = 200;
+        auto launch = [&](int mode) {
+            dim3 g(1), b(256 * waves);
+            switch (mode) {
+                case 0: hipLaunchKernelGGL(probe<0>, g, b, 0, 0, d, sink, iters); break;
+                case 1: hipLaunchKernelGGL(probe<1>, g, b, 0, 0, d, sink, iters); break;
+                case 2: hipLaunchKernelGGL(probe<2>, g, b, 0, 0, d, sink, iters); break;
+                case 3: hipLaunchKernelGGL(probe<3>, g, b, 0, 0, d, sink, iters); break;
+                case 4: hipLaunchKernelGGL(probe<4>, g, b, 0, 0, d, sink, iters); break;
+                case 5: hipLaunchKernelGGL(probe<5>, g, b, 0, 0, d, sink, iters); break;
+                case 6: hipLaunchKernelGGL(probe<6>, g, b, 0, 0, d, sink, iters); break;
+                case 7: hipLaunchKernelGGL(probe<7>, g, b, 0, 0, d, sink, iters); break;
+                case 8: hipLaunchKernelGGL(probe<8>, g, b, 0, 0, d, sink, iters); break;
+            }
+        };
+        launch(m); launch(m);
+        hipDeviceSynchronize();
+        unsigned long long h = 0;
+        hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+        printf("%d wave(s)/SIMD  %-28s %.2f s_memtime ticks per instruction (per wave)\n", waves, names[m], (double)h / (iters * REP));
+    }
+    return 0;
+}
