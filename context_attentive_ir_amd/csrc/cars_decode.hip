@@ -399,3 +399,55 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Greedy decoding WITHOUT attention: the suggestion side of M_MATCH_TENSOR and MNSRF (multitask/mmtensor.py:281-325,
+// mnsrf.py:251-296: Decoder(attn_type='none') + generator).  Per step: embedding gather + LSTM cell in one launch (lstm_step_kernel),
+// generator GEMM [Bd, V_tgt], arg-max + target -> source id map (argmax_map_kernel).  No host synchronisation.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" size_t nir_decode_greedy_plain_workspace_bytes(int64_t Bd, int H, int64_t VT) {
+    if (Bd <= 0 || H <= 0 || VT <= 0) return 0;
+    return ((size_t)4 * Bd * H + (size_t)Bd * VT) * sizeof(float) + (size_t)Bd * sizeof(int64_t) + 1024;
+}
+
+extern "C" int nir_decode_greedy_plain(const float* dec_h, const float* dec_c, int64_t Bd, int H, const float* table, int64_t V, int E,
+                                       const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* gen_w,
+                                       const float* gen_b, int64_t VT, const int64_t* tgt2src, int64_t bos, int max_len, void* workspace,
+                                       size_t workspace_bytes, int64_t* predictions, nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(dec_h && dec_c && table && w_ih && w_hh && b_ih && b_hh && gen_w && predictions && workspace, "decode_plain: null pointer");
+    NIR_REQUIRE(Bd >= 0 && H > 0 && E > 0 && V > 0 && VT > 0 && max_len >= 0, "decode_plain: bad dims");
+    NIR_REQUIRE(E % 4 == 0 && H % 4 == 0, "decode_plain: emsize and hidden size must be multiples of 4");
+    NIR_REQUIRE(bos >= 0 && bos < V, "decode_plain: BOS id outside the vocabulary");
+    NIR_REQUIRE(workspace_bytes >= nir_decode_greedy_plain_workspace_bytes(Bd, H, VT), "decode_plain: workspace too small");
+    if (Bd == 0 || max_len == 0) return 0;
+    Workspace a(workspace, workspace_bytes);
+    float* hb[2] = {a.take<float>((size_t)Bd * H), a.take<float>((size_t)Bd * H)};
+    float* cb[2] = {a.take<float>((size_t)Bd * H), a.take<float>((size_t)Bd * H)};
+    float* logits = a.take<float>((size_t)Bd * VT);
+    int64_t* tgt = a.take<int64_t>((size_t)Bd);
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((Bd + 255) / 256)), dim3(256), 0, st, tgt, bos, Bd);
+    NIR_CHECK_LAUNCH("fill_i64_kernel");
+    LstmStepArgs s;
+    s.x[0] = table; s.xid[0] = tgt; s.xstride[0] = E;
+    s.wih[0] = w_ih; s.whh[0] = w_hh; s.bih[0] = b_ih; s.bhh[0] = b_hh;
+    s.x[1] = nullptr; s.xid[1] = nullptr; s.xstride[1] = 0; s.wih[1] = s.whh[1] = s.bih[1] = s.bhh[1] = nullptr;
+    s.hprev[1] = s.cprev[1] = nullptr; s.hnext[1] = s.cnext[1] = nullptr;
+    s.chain0 = 0; s.B = (int)Bd; s.I = E; s.H = H;
+    const float* hp = dec_h;
+    const float* cp = dec_c;
+    for (int step = 0; step < max_len; ++step) {
+        s.hprev[0] = hp; s.cprev[0] = cp; s.hnext[0] = hb[step & 1]; s.cnext[0] = cb[step & 1];
+        NIR_PROPAGATE(launch_lstm_step(s, 1, st));
+        NIR_PROPAGATE(launch_linear(hb[step & 1], H, nullptr, nullptr, 0, 0, 0, gen_w, H, gen_b, nullptr, logits, VT, Bd, (int)VT, H, NIR_ACT_NONE, st));
+        {
+            ProfScope ps("argmax_map_kernel", st);
+            hipLaunchKernelGGL(argmax_map_kernel, dim3((unsigned)Bd), dim3(256), 0, st, logits, VT, tgt2src, predictions + step, (int64_t)max_len, tgt, V);
+        }
+        NIR_CHECK_LAUNCH("argmax_map_kernel");
+        hp = hb[step & 1];
+        cp = cb[step & 1];
+    }
+    return 0;
+}

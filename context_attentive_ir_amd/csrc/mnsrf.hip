@@ -20,8 +20,8 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
 // hw [M,4H] = h_{t-1} W_hh^T (null at the first step of a zero initial state); gates = hw + gin[m][t_m][dir]
 __global__ __launch_bounds__(256) void lstm_step_cell_kernel(const float* __restrict__ hw, const float* __restrict__ gin,
                                                              const int64_t* __restrict__ lens, float* __restrict__ hstate,
-                                                             float* __restrict__ cstate, float* __restrict__ out, int64_t M, int T,
-                                                             int H, int ND, int dir, int step) {
+                                                             float* __restrict__ cstate, float* __restrict__ out, float* __restrict__ cst,
+                                                             int64_t M, int T, int H, int ND, int dir, int step) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * H) return;
     const int64_t m = i / H;
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void lstm_step_cell_kernel(const float* __rest
     cstate[i] = c;
     hstate[i] = h;
     out[(m * T + t) * ND * (int64_t)H + (int64_t)dir * H + j] = h;
+    if (cst) cst[(m * T + t) * ND * (int64_t)H + (int64_t)dir * H + j] = c;      // cell state of every step (decoder initialisation)
 }
 
 // GRU step (torch.nn.GRU gate order r, z, n): gin = x W_ih^T + b_ih; hw = h_{t-1} W_hh^T + b_hh (null at the first step of a zero state:
@@ -82,16 +83,17 @@ size_t lstm_steps_ws_floats(int64_t M, int H) { return 2 * ((size_t)M * H * 2 + 
 // The two directions are independent chains of T x (GEMM, cell): with one batch in flight the reverse direction runs on
 // the side stream (own state / scratch set), with several batches in flight ForkJoin is a no-op and they run back to back.
 int launch_birnn_steps(int cell, const float* gin, const int64_t* lens, const float* whh, const float* bhh, const float* h0, const float* c0,
-                       float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st);
+                       float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st, float* cst = nullptr);
 int launch_bilstm_steps(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0, float* out,
                         float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st) {
     return launch_birnn_steps(0, gin, lens, whh, nullptr, h0, c0, out, hn, cn, M, T, H, ND, ws, st);
 }
 // cell 0: LSTM (gates_in carries both biases, G = 4); cell 1: GRU (gates_in carries b_ih, b_hh [ND,3H] joins the recurrent product, G = 3)
 int launch_birnn_steps(int cell, const float* gin, const int64_t* lens, const float* whh, const float* bhh, const float* h0, const float* c0,
-                       float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st) {
+                       float* out, float* hn, float* cn, int64_t M, int T, int H, int ND, float* ws, hipStream_t st, float* cst) {
     const int G = cell == 1 ? 3 : 4;
     hipLaunchKernelGGL(fill_f32_kernel, g1(M * T * ND * H), dim3(256), 0, st, out, 0.f, M * T * ND * (int64_t)H);
+    if (cst) hipLaunchKernelGGL(fill_f32_kernel, g1(M * T * ND * H), dim3(256), 0, st, cst, 0.f, M * T * ND * (int64_t)H);
     ForkJoin fj(st);
     if (ND == 2) fj.fork();
     for (int dir = 0; dir < ND; ++dir) {
@@ -113,8 +115,8 @@ int launch_birnn_steps(int cell, const float* gin, const int64_t* lens, const fl
                 hipLaunchKernelGGL(gru_step_cell_kernel, g1(M * H), dim3(256), 0, ds, skip_gemm ? nullptr : hw, bh, gin, lens, hs, out, M, T, H, ND,
                                    dir, step);
             else
-                hipLaunchKernelGGL(lstm_step_cell_kernel, g1(M * H), dim3(256), 0, ds, skip_gemm ? nullptr : hw, gin, lens, hs, cs, out, M, T, H,
-                                   ND, dir, step);
+                hipLaunchKernelGGL(lstm_step_cell_kernel, g1(M * H), dim3(256), 0, ds, skip_gemm ? nullptr : hw, gin, lens, hs, cs, out, cst, M, T,
+                                   H, ND, dir, step);
         }
         if (hn) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, hs, hn + (int64_t)dir * M * H, M * (int64_t)H);
         if (cn && cell == 0) hipLaunchKernelGGL(copy_f32_kernel, g1(M * H), dim3(256), 0, ds, cs, cn + (int64_t)dir * M * H, M * (int64_t)H);
@@ -215,9 +217,18 @@ extern "C" int nir_bilstm_steps_fwd(const float* gates_in, const int64_t* length
     return launch_bilstm_steps(gates_in, lengths, w_hh, h0, c0, out, hn, cn, M, T, H, ndir, (float*)workspace, (hipStream_t)stream);
 }
 
+extern "C" int nir_maxpool_time_f32(const float* x, int64_t M, int T, int D, float* y, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(x && y && M >= 0 && T > 0 && D > 0, "maxpool_time: bad arguments");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(maxpool_time_kernel, g1(M * D), dim3(256), 0, (hipStream_t)stream, x, y, M, T, D);
+    NIR_CHECK_LAUNCH("nir_maxpool_time_f32");
+    return 0;
+}
+
 extern "C" int nir_birnn_steps_fwd(int cell, const float* gates_in, const int64_t* lengths, const float* w_hh, const float* b_hh, const float* h0,
-                                   const float* c0, float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir, void* workspace,
-                                   size_t workspace_bytes, nir_stream_t stream) {
+                                   const float* c0, float* out, float* c_steps, float* hn, float* cn, int64_t M, int T, int H, int ndir,
+                                   void* workspace, size_t workspace_bytes, nir_stream_t stream) {
     using namespace nir;
     NIR_REQUIRE(cell == NIR_CELL_LSTM || cell == NIR_CELL_GRU, "birnn_steps: cell must be NIR_CELL_LSTM or NIR_CELL_GRU");
     NIR_REQUIRE(gates_in && w_hh && out && workspace, "birnn_steps: null pointer");
@@ -226,7 +237,7 @@ extern "C" int nir_birnn_steps_fwd(int cell, const float* gates_in, const int64_
     NIR_REQUIRE(workspace_bytes >= nir_bilstm_steps_workspace_bytes(M, H), "birnn_steps: workspace too small");
     if (M == 0) return 0;
     return launch_birnn_steps(cell, gates_in, lengths, w_hh, cell == NIR_CELL_GRU ? b_hh : nullptr, h0, c0, out, hn, cn, M, T, H, ndir,
-                              (float*)workspace, (hipStream_t)stream);
+                              (float*)workspace, (hipStream_t)stream, cell == NIR_CELL_LSTM ? c_steps : nullptr);
 }
 
 extern "C" size_t nir_mnsrf_workspace_bytes(int64_t B, int S, int N, int QL, int DL, const nir_mnsrf_weights* w) {

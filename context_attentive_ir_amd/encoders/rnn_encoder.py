@@ -104,7 +104,7 @@ class RNNEncoder(nn.Module):
                                    lib.ptr(gates), ND * 3 * H, M * T, ND * 3 * H, I, 0, st), "nir_linear_f32")
         ws = lib.workspace(L.nir_bilstm_steps_workspace_bytes(M, H), x.device)
         lib.check(L.nir_birnn_steps_fwd(1, lib.ptr(gates), lib.ptr(lens), lib.ptr(whh), lib.ptr(bhh), lib.ptr(h0), None, lib.ptr(out),
-                                        lib.ptr(hn), None, M, T, H, ND, lib.ptr(ws), ws.numel(), st), "nir_birnn_steps_fwd")
+                                        None, lib.ptr(hn), None, M, T, H, ND, lib.ptr(ws), ws.numel(), st), "nir_birnn_steps_fwd")
         return hn, out
 
     def _bridge(self, hidden):

@@ -86,7 +86,11 @@ SIGNATURES = {
     "nir_bilstm_fused_fwd": (_i, [c_fp, _i, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
     "nir_bilstm_steps_workspace_bytes": (_z, [_l, _i]),
     "nir_bilstm_steps_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, C.c_void_p, _z, c_st]),
-    "nir_birnn_steps_fwd": (_i, [_i, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, C.c_void_p, _z, c_st]),
+    "nir_birnn_steps_fwd": (_i, [_i, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, C.c_void_p, _z, c_st]),
+    "nir_maxpool_time_f32": (_i, [c_fp, _l, _i, _i, c_fp, c_st]),
+    "nir_decode_greedy_plain_workspace_bytes": (_z, [_l, _i, _l]),
+    "nir_decode_greedy_plain": (_i, [c_fp, c_fp, _l, _i, c_fp, _l, _i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, c_ip, _l, _i, C.c_void_p, _z, c_ip,
+                                     c_st]),
     "nir_mnsrf_workspace_bytes": (_z, [_l, _i, _i, _i, _i, C.POINTER(MnsrfWeights)]),
     "nir_mnsrf_encode": (_i, [c_ip, c_ip, _l, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z, c_fp, c_fp, c_st]),
     "nir_mnsrf_score": (_i, [c_ip, c_ip, c_ip, c_ip, _l, _i, _i, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z,

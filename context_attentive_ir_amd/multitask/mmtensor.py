@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import lib
+from . import suggest
 from ..encoders.rnn_encoder import lstm_cat_weights
 from ..rankers.mtensor import ExactMatchChannel
 from .layers import Embedder, Encoder
@@ -82,8 +83,8 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
             raise NotImplementedError("HIP M_MATCH_TENSOR implements the eval-mode forward (SURVEY.md Appendix E7)")
 
     def encode(self, source_rep, source_len):
-        """source_rep [B,S,QL] ids, source_len [B,S] -> (projected_queries [B*S,QL,C], None, None)  (mmtensor.py:70-88;
-        session_bank / states belong to the suggestion side)."""
+        """source_rep [B,S,QL] ids, source_len [B,S] -> (projected_queries [B*S,QL,C], session_bank [B,S,nhid_session],
+        states = (h, c) [1,(S-1)*B,nhid_session])  (mmtensor.py:70-125)."""
         self._check_eval()
         table = self.embedder.word_embeddings.table
         lib.require_device(source_rep, source_len, table)
@@ -100,7 +101,12 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
         lib.check(L.nir_linear_f32(lib.ptr(enc), Hq2, None, None, 0, 0, 0, lib.ptr(self.query_projection.weight), Hq2,
                                    lib.ptr(self.query_projection.bias), None, lib.ptr(pq), C, M, C, Hq2, 0, st), "nir_linear_f32")
         self._src_len = source_len                     # rank_document's signature carries no query lengths
-        return pq, None, None
+        # suggestion side (mmtensor.py:88-124): max over the query positions -> unidirectional session LSTM -> session bank and the
+        # decoder's initial states (the state after every query but the last, step-major along the batch axis)
+        mem = torch.empty(B * S, C, device=ids.device, dtype=torch.float32)
+        lib.check(L.nir_maxpool_time_f32(lib.ptr(pq), B * S, QL, C, lib.ptr(mem), st), "nir_maxpool_time_f32")
+        session_bank, states = suggest.session_states(mem.view(B, S, C), self.session_query_encoder.encoder.rnns[0])
+        return pq, session_bank, states
 
     def rank_document(self, source_rep, projected_queries, session_bank, document_rep, document_len, source_len=None):
         """-> scores [B,S,N]  (mmtensor.py:127-189).  The query side is re-derived from the ids inside the fused call
@@ -131,5 +137,8 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
     def forward(self, *a, **k):
         raise NotImplementedError("training forward (ranking + suggestion losses) is outside the hot path (SURVEY.md 8f)")
 
-    def decode(self, **kwargs):
-        raise NotImplementedError("query suggestion decoding is outside the hot path (SURVEY.md section 8f rank 4)")
+    def decode(self, states, max_len, src_dict, tgt_dict, batch_size, session_len, use_cuda=True, tgt2src=None, **kwargs):
+        """mmtensor.py:281-325 (greedy, decoder without attention) -> {'predictions': LongTensor [batch_size, session_len, max_len]}."""
+        self._check_eval()
+        return suggest.greedy_decode(self, states, max_len, src_dict, tgt_dict, batch_size, session_len, self.embedder.word_embeddings.table,
+                                     self.decoder.decoder.rnn, self.generator, tgt2src)

@@ -13,6 +13,7 @@ import torch.nn as nn
 from collections import OrderedDict
 
 from .. import lib
+from . import suggest
 from ..encoders.rnn_encoder import lstm_cat_weights
 from .layers import Embedder, Encoder
 from .mmtensor import _PlainDecoderParams
@@ -58,8 +59,8 @@ class MNSRF(nn.Module, lib.IdCheck):
             raise NotImplementedError("HIP MNSRF implements the eval-mode forward (SURVEY.md Appendix E7)")
 
     def encode(self, source_rep, source_len):
-        """source_rep [B,S,QL], source_len [B,S] -> (memory_bank [B,S,nhid_query], session_bank [B,S,nhid_session], None)
-        (mnsrf.py:62-114; the per-step decoder states are suggestion-side and not produced)."""
+        """source_rep [B,S,QL], source_len [B,S] -> (memory_bank [B,S,nhid_query], session_bank [B,S,nhid_session],
+        states = (h, c) [1,(S-1)*B,nhid_session])  (mnsrf.py:62-114)."""
         self._check_eval()
         table = self.embedder.word_embeddings.table
         lib.require_device(source_rep, source_len, table)
@@ -75,7 +76,10 @@ class MNSRF(nn.Module, lib.IdCheck):
                                          w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(mem), lib.ptr(sess), lib.stream()),
                       "nir_mnsrf_encode")
         self._src_len = source_len
-        return mem, sess, None
+        # the decoder's initial states (mnsrf.py:96-112): the session LSTM's state after every query but the last, step-major along the
+        # batch axis -- the fused encode keeps only h, so the (tiny) session recurrence is run once more with its cell states written out
+        states = suggest.session_states(mem, self.session_query_encoder.encoder.rnns[0])[1] if B > 0 and S > 1 else None
+        return mem, sess, states
 
     def rank_document(self, source_rep, memory_bank, session_bank, document_rep, document_len, source_len=None):
         """-> scores [B,S,N]  (mnsrf.py:116-162).  The query side is re-derived from the ids inside the fused call (the
@@ -106,5 +110,8 @@ class MNSRF(nn.Module, lib.IdCheck):
     def forward(self, *a, **k):
         raise NotImplementedError("training forward (ranking + suggestion losses) is outside the hot path (SURVEY.md 8f)")
 
-    def decode(self, **kwargs):
-        raise NotImplementedError("query suggestion decoding is outside the hot path (SURVEY.md section 8f rank 4)")
+    def decode(self, states, max_len, src_dict, tgt_dict, batch_size, session_len, use_cuda=True, tgt2src=None, **kwargs):
+        """mnsrf.py:251-296 (greedy, decoder without attention) -> {'predictions': LongTensor [batch_size, session_len, max_len]}."""
+        self._check_eval()
+        return suggest.greedy_decode(self, states, max_len, src_dict, tgt_dict, batch_size, session_len, self.embedder.word_embeddings.table,
+                                     self.decoder.decoder.rnn, self.generator, tgt2src)

@@ -41,9 +41,9 @@ class Multitask(WrapperBase):
         self.network.eval()
         if self.type != "CARS":     # models/multitask.py:271-278: encode -> rank_document(source, memory, session, docs, lens)
             src = self._dev(ex["source_words"])
-            memory_bank, session_bank, _ = self.network.encode(src, self._dev(ex["source_lens"]))
+            memory_bank, session_bank, states = self.network.encode(src, self._dev(ex["source_lens"]))
             s = self.network.rank_document(src, memory_bank, session_bank, self._dev(ex["document_words"]), self._dev(ex["document_lens"]))
-            return s, None, None, None
+            return s, states, None, (None, None)
         src_lens = self._dev(ex["source_lens"])
         pooled, encoded, _ = self.network.encode(self._dev(ex["source_words"]), src_lens)
         s, states, attns = self.network.rank_document(pooled, self._dev(ex["document_words"]), self._dev(ex["document_lens"]),
@@ -194,9 +194,9 @@ class Multitask(WrapperBase):
     @torch.no_grad()
     def predict(self, ex, suggest=True):
         """models/multitask.py:229-317: {'click_scores': softmax over candidates [B,S,N], 'predictions': LongTensor
-        [B,S-1,max_query_len] (CARS with the recommender on, suggest=True; else None)}.
+        [B,S-1,max_query_len] (suggest=True; None for CARS with the recommender off)}.
         suggest=False = the ranking path only (what bench.py times as a step and GraphedPredictor captures)."""
-        do_decode = bool(suggest) and self.type == "CARS" and not self.network.no_recommender
+        do_decode = bool(suggest) and not (self.type == "CARS" and self.network.no_recommender)
         s, states, attns, enc = self._rank(ex, do_decode)
         out = {"click_scores": None, "predictions": None}
         if torch.is_tensor(s):
@@ -205,7 +205,7 @@ class Multitask(WrapperBase):
             lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()),
                       "nir_softmax_rows")
             out["click_scores"] = probs
-        if do_decode:
+        if do_decode and states is not None:
             B, S = ex["source_words"].shape[0], ex["source_words"].shape[1]
             dec = self.network.decode(states=states, max_len=self.args.max_query_len, src_dict=self.src_dict, tgt_dict=self.tgt_dict,
                                       batch_size=B, session_len=S - 1, use_cuda=self.use_cuda, encoded_source=enc[0], source_len=enc[1],

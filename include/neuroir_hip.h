@@ -417,8 +417,21 @@ int nir_bilstm_steps_fwd(const float* gates_in, const int64_t* lengths, const fl
 #define NIR_CELL_LSTM 0
 #define NIR_CELL_GRU 1
 int nir_birnn_steps_fwd(int cell, const float* gates_in, const int64_t* lengths, const float* w_hh, const float* b_hh, const float* h0,
-                        const float* c0, float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir, void* workspace,
-                        size_t workspace_bytes, nir_stream_t stream);
+                        const float* c0, float* out, float* c_steps /*[M,T,ndir*H] cell state of every step (LSTM), or NULL*/, float* hn,
+                        float* cn, int64_t M, int T, int H, int ndir, void* workspace, size_t workspace_bytes, nir_stream_t stream);
+
+/* y[m,d] = max over ALL T positions of x[m,t,d] (apply_pooling(.., 'max'), mmtensor.py:191-201 / mnsrf.py:226-240: padded positions take part). */
+int nir_maxpool_time_f32(const float* x, int64_t M, int T, int D, float* y, nir_stream_t stream);
+
+/* Greedy decoding without attention -- the suggestion side of M_MATCH_TENSOR / MNSRF (multitask/mmtensor.py:281-325, mnsrf.py:251-296:
+ * Decoder(attn_type='none'), generator Linear(H -> V_tgt), arg-max, target id -> source id through tgt2src [V_tgt] (NULL = identity), fed
+ * back through the embedding table [V,E]).  dec_h / dec_c [Bd,H]: the decoder's initial state per decoded query; w_ih [4H,E], w_hh [4H,H],
+ * b_ih / b_hh [4H] of the decoder LSTM; predictions [Bd,max_len] (target-vocabulary ids).  E % 4 == 0, H % 4 == 0. */
+size_t nir_decode_greedy_plain_workspace_bytes(int64_t Bd, int H, int64_t VT);
+int nir_decode_greedy_plain(const float* dec_h, const float* dec_c, int64_t Bd, int H, const float* table, int64_t V, int E, const float* w_ih,
+                            const float* w_hh, const float* b_ih, const float* b_hh, const float* gen_w, const float* gen_b, int64_t VT,
+                            const int64_t* tgt2src, int64_t bos, int max_len, void* workspace, size_t workspace_bytes, int64_t* predictions,
+                            nir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * MNSRF, ranking side (neuroir/multitask/mnsrf.py:62-162)

@@ -251,6 +251,41 @@ def mnsrf_scores(sd, source_rep, source_len, document_rep, document_len):
 
 
 # ------------------------------------------------------------------------------------------
+# Suggestion side of MNSRF / M_MATCH_TENSOR: session-LSTM states that initialise the decoder, greedy decode without attention
+# ------------------------------------------------------------------------------------------
+@torch.no_grad()
+def session_decoder_states(sd, prefix, pooled):
+    """mmtensor.py:94-124 / mnsrf.py:88-112: the unidirectional session LSTM is stepped one query at a time carrying (h, c); the
+    states after every query but the last are concatenated along the batch axis (step-major).  pooled [B,S,I]; sd keys
+    `prefix.rnns.0.*` -> (session_bank [B,S,HS], h [1,(S-1)*B,HS], c [1,(S-1)*B,HS])."""
+    B, S, _ = pooled.shape
+    hidden, hs, cs, bank = None, [], [], []
+    for qidx in range(S):
+        hidden, rep = rnn_encode(sd, prefix, pooled[:, qidx:qidx + 1], None, bidirectional=False, init=hidden)
+        bank.append(rep.squeeze(1)); hs.append(hidden[0]); cs.append(hidden[1])
+    return torch.stack(bank, 1), torch.cat(hs[:-1], 1), torch.cat(cs[:-1], 1)
+
+
+@torch.no_grad()
+def plain_greedy_decode(sd, table, h, c, max_len, tgt2src=None, bos=2, dec="decoder.decoder.rnn", gen="generator"):
+    """mmtensor.py:281-325 / mnsrf.py:251-296: embed(tgt) -> one decoder-LSTM step from the running state -> generator -> soft-max ->
+    arg-max (first index on ties, torch.max) -> the prediction; the next input is its source-vocabulary id.  h, c [1,Bd,H] -> [Bd,max_len]."""
+    W_ih, W_hh, b_ih, b_hh = (sd["%s.%s_l0" % (dec, n)] for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+    h, c = h[0], c[0]
+    tgt = torch.full((h.shape[0],), bos, dtype=torch.int64)
+    preds = []
+    for _ in range(max_len):
+        g = F.linear(F.embedding(tgt, table), W_ih, b_ih) + F.linear(h, W_hh, b_hh)
+        i, f, gg, o = g.chunk(4, 1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        p = torch.softmax(_lin(sd, gen, h), 1).max(1)[1]
+        preds.append(p)
+        tgt = tgt2src[p] if tgt2src is not None else p
+    return torch.stack(preds, 1)
+
+
+# ------------------------------------------------------------------------------------------
 # M_MATCH_TENSOR, ranking side  (neuroir/multitask/mmtensor.py:70-88 encode, :127-189 rank_document):
 # MatchTensor over the B*S (session, query) rows; only the module nesting of the state dict differs.
 # ------------------------------------------------------------------------------------------

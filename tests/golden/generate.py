@@ -434,10 +434,15 @@ def gen_m_match_tensor():
     dlen = rng.integers(1, DL + 1, size=(B, S, N)); dlen[0, 0, 0] = DL
     src = rand_ids(rng, (B, S, QL), slen); docs = rand_ids(rng, (B, S, N, DL), dlen)
     docs[0, 0, 1, :3] = src[0, 0, :3]                              # some exact matches
-    pq, session_bank, _ = net.encode(T(src), T(slen))
+    pq, session_bank, states = net.encode(T(src), T(slen))
     scores = net.rank_document(T(src), pq, session_bank, T(docs), T(dlen))
+    # suggestion side (mmtensor.py:94-125, 281-325): decoder-initialisation states and the greedy decode
+    tgt2src = rng.permutation(V)[:50].astype(np.int64)
+    tgt_dict, src_dict = list(range(50)), [int(x) for x in tgt2src]
+    dec = net.decode(states=states, max_len=6, src_dict=src_dict, tgt_dict=tgt_dict, batch_size=B, session_len=S - 1, use_cuda=False)
     save("m_match_tensor", source_words=src, source_lens=slen, document_words=docs, document_lens=dlen,
-         projected_queries=pq, scores=scores, softmax=torch.softmax(scores, -1), tgt_vocab_size=50)
+         projected_queries=pq, scores=scores, softmax=torch.softmax(scores, -1), tgt_vocab_size=50, session_bank=session_bank,
+         dec_h=states[0], dec_c=states[1], tgt2src=tgt2src, max_len=6, predictions=dec["predictions"])
 
 
 @torch.no_grad()
@@ -452,10 +457,14 @@ def gen_mnsrf():
     slen = rng.integers(1, QL + 1, size=(B, S)); slen[0, 0] = QL
     dlen = rng.integers(1, DL + 1, size=(B, S, N)); dlen[0, 0, 0] = DL
     src = rand_ids(rng, (B, S, QL), slen); docs = rand_ids(rng, (B, S, N, DL), dlen)
-    mem, sess, _ = net.encode(T(src), T(slen))
+    mem, sess, states = net.encode(T(src), T(slen))
     scores = net.rank_document(T(src), mem, sess, T(docs), T(dlen))
+    tgt2src = rng.permutation(V)[:50].astype(np.int64)               # suggestion side (mnsrf.py:88-112, 251-296)
+    tgt_dict, src_dict = list(range(50)), [int(x) for x in tgt2src]
+    dec = net.decode(states=states, max_len=6, src_dict=src_dict, tgt_dict=tgt_dict, batch_size=B, session_len=S - 1, use_cuda=False)
     save("mnsrf", source_words=src, source_lens=slen, document_words=docs, document_lens=dlen, memory_bank=mem,
-         session_bank=sess, scores=scores, softmax=torch.softmax(scores, -1), tgt_vocab_size=50)
+         session_bank=sess, scores=scores, softmax=torch.softmax(scores, -1), tgt_vocab_size=50, dec_h=states[0], dec_c=states[1],
+         tgt2src=tgt2src, max_len=6, predictions=dec["predictions"])
 
 
 @torch.no_grad()

@@ -601,9 +601,14 @@ def test_m_match_tensor_golden_and_oracle():
     m = build_model("M_MATCH_TENSOR", tgt_vocab_size=int(g["tgt_vocab_size"]), device=DEV)
     src, sl, d, dl = (T(g[k], DEV) for k in ("source_words", "source_lens", "document_words", "document_lens"))
     pq, bank, states = m.encode(src, sl)
-    assert bank is None and states is None
     _close(pq, g["projected_queries"])
     _close(m.rank_document(src, pq, bank, d, dl), g["scores"])
+    # suggestion side (mmtensor.py:94-125, 281-325): session bank, decoder-initialisation states, greedy decode
+    _close(bank, g["session_bank"], 1e-5); _close(states[0], g["dec_h"], 1e-5); _close(states[1], g["dec_c"], 1e-5)
+    B_, S_ = src.shape[0], src.shape[1]
+    dec = m.decode(states=states, max_len=int(g["max_len"]), src_dict=None, tgt_dict=None, batch_size=B_, session_len=S_ - 1, use_cuda=True,
+                   tgt2src=T(g["tgt2src"], DEV))
+    assert torch.equal(dec["predictions"].cpu(), T(g["predictions"]))
 
     w = Multitask(default_args("M_MATCH_TENSOR", src_vocab_size=300, tgt_vocab_size=40))
     fill_module_(w.network, 77)
@@ -617,11 +622,24 @@ def test_m_match_tensor_golden_and_oracle():
     ex = {"source_words": torch.from_numpy(srcw), "source_lens": torch.from_numpy(slen),
           "document_words": torch.from_numpy(docw), "document_lens": torch.from_numpy(dlen),
           "document_labels": torch.zeros(B, S, N)}
-    out = w.predict(ex)["click_scores"]
+    res = w.predict(ex)                                        # the reference's predict always decodes (models/multitask.py:281-292)
     ref = torch.softmax(O.m_match_tensor_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)
-    _close(out, ref)
-    with pytest.raises(NotImplementedError):
-        w.network.decode()
+    _close(res["click_scores"], ref)
+    # greedy decode vs the oracle, with generator weights scaled up so that the arg-max moves between tokens
+    sd2 = dict(sd)
+    sd2["generator.weight"] = sd["generator.weight"] * 40.0
+    w.network.load_state_dict(sd2)
+    w.cuda()
+    pq_o = O.m_match_tensor_encode(sd2, ex["source_words"], ex["source_lens"])
+    m2 = O._strip_encoder_nesting(sd2)
+    _, h_o, c_o = O.session_decoder_states(m2, "session_query_encoder", pq_o.max(1)[0].view(B, S, -1))
+    lut = torch.from_numpy(np.random.default_rng(3).permutation(300)[:40].astype(np.int64))
+    want = O.plain_greedy_decode(sd2, sd2["embedder.word_embeddings.make_embedding.emb_luts.0.weight"], h_o, c_o, 7, lut)
+    _, _, st = w.network.encode(ex["source_words"].to(DEV), ex["source_lens"].to(DEV))
+    _close(st[0], h_o, 1e-5)
+    got = w.network.decode(states=st, max_len=7, src_dict=None, tgt_dict=None, batch_size=B, session_len=S - 1, tgt2src=lut.to(DEV))
+    assert torch.equal(got["predictions"].cpu().view(-1, 7), want) and len(set(want.view(-1).tolist())) > 2
+    assert tuple(w.predict(ex)["predictions"].shape) == (B, S - 1, w.args.max_query_len)
 
 
 def test_m_match_tensor_state_dict_keys():
@@ -645,9 +663,12 @@ def test_mnsrf_golden_and_oracle():
     m = build_model("MNSRF", tgt_vocab_size=int(g["tgt_vocab_size"]), device=DEV)
     src, sl, d, dl = (T(g[k], DEV) for k in ("source_words", "source_lens", "document_words", "document_lens"))
     mem, sess, states = m.encode(src, sl)
-    assert states is None
     _close(mem, g["memory_bank"]); _close(sess, g["session_bank"])
     _close(m.rank_document(src, mem, sess, d, dl), g["scores"])
+    _close(states[0], g["dec_h"], 1e-5); _close(states[1], g["dec_c"], 1e-5)       # suggestion side (mnsrf.py:88-112, 251-296)
+    dec = m.decode(states=states, max_len=int(g["max_len"]), src_dict=None, tgt_dict=None, batch_size=src.shape[0], session_len=src.shape[1] - 1,
+                   use_cuda=True, tgt2src=T(g["tgt2src"], DEV))
+    assert torch.equal(dec["predictions"].cpu(), T(g["predictions"]))
 
     w = Multitask(default_args("MNSRF", src_vocab_size=300, tgt_vocab_size=40))
     fill_module_(w.network, 23)
@@ -661,12 +682,16 @@ def test_mnsrf_golden_and_oracle():
     ex = {"source_words": torch.from_numpy(srcw), "source_lens": torch.from_numpy(slen),
           "document_words": torch.from_numpy(docw), "document_lens": torch.from_numpy(dlen),
           "document_labels": torch.zeros(B, S, N)}
-    out = w.predict(ex)["click_scores"]
+    res = w.predict(ex)
     ref = torch.softmax(O.mnsrf_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)
-    _close(out, ref)
+    _close(res["click_scores"], ref)
     assert len(w.network.state_dict()) == 29                  # the reference's key set (probed)
-    with pytest.raises(NotImplementedError):
-        w.network.decode()
+    assert tuple(res["predictions"].shape) == (B, S - 1, w.args.max_query_len)
+    mem_o, _ = O.mnsrf_encode(sd, ex["source_words"], ex["source_lens"])
+    m2 = O._strip_encoder_nesting(sd)
+    _, h_o, c_o = O.session_decoder_states(m2, "session_query_encoder", mem_o)
+    want = O.plain_greedy_decode(sd, sd["embedder.word_embeddings.make_embedding.emb_luts.0.weight"], h_o, c_o, w.args.max_query_len, None)
+    assert torch.equal(res["predictions"].cpu().view(-1, w.args.max_query_len), want)
 
 
 @pytest.mark.parametrize("H,I,M,T_,bi", [(256, 300, 9, 7, True), (200, 40, 5, 6, True), (1024, 64, 4, 5, False), (130, 300, 33, 4, True)])

@@ -79,6 +79,11 @@ def test_m_match_tensor():
     s = O.m_match_tensor_scores(sd, src, sl, d, dl)
     _close(s, g["scores"], 2e-6)
     _close(O.predict_softmax(s), g["softmax"])
+    B, S = src.shape[:2]                                        # suggestion side: session states and the greedy decode
+    bank, h, c = O.session_decoder_states(O._strip_encoder_nesting(sd), "session_query_encoder", T(g["projected_queries"]).max(1)[0].view(B, S, -1))
+    _close(bank, g["session_bank"], 2e-6); _close(h, g["dec_h"], 2e-6); _close(c, g["dec_c"], 2e-6)
+    p = O.plain_greedy_decode(sd, sd["embedder.word_embeddings.make_embedding.emb_luts.0.weight"], h, c, int(g["max_len"]), T(g["tgt2src"]))
+    assert torch.equal(p.view(B, S - 1, -1), T(g["predictions"]))
 
 
 def test_mnsrf():
@@ -90,6 +95,11 @@ def test_mnsrf():
     s = O.mnsrf_scores(sd, src, sl, d, dl)
     _close(s, g["scores"], 5e-6)
     _close(O.predict_softmax(s), g["softmax"], 2e-6)
+    B, S = src.shape[:2]
+    bank, h, c = O.session_decoder_states(O._strip_encoder_nesting(sd), "session_query_encoder", mem)
+    _close(bank, g["session_bank"], 2e-6); _close(h, g["dec_h"], 2e-6); _close(c, g["dec_c"], 2e-6)
+    p = O.plain_greedy_decode(sd, sd["embedder.word_embeddings.make_embedding.emb_luts.0.weight"], h, c, int(g["max_len"]), T(g["tgt2src"]))
+    assert torch.equal(p.view(B, S - 1, -1), T(g["predictions"]))
 
 
 def test_losses_and_metrics():
