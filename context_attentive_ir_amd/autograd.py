@@ -295,9 +295,12 @@ class _LSTMCell(Function):
         B, H = c.shape
         dg = torch.empty_like(act)
         dcp = torch.empty_like(c)
-        lib.check(lib.load().nir_lstm_cell_bwd(lib.ptr(_f32c(dh)) if dh is not None else None, lib.ptr(_f32c(dc)) if dc is not None else None,
-                                               lib.ptr(act), lib.ptr(c), lib.ptr(cp) if ctx.has_cp else None, lib.ptr(dg), lib.ptr(dcp), B, H,
-                                               lib.stream()), "nir_lstm_cell_bwd")
+        # the contiguous copies stay referenced until the launch is enqueued: as temporaries inside the call they were freed one by one, and
+        # with BOTH gradients arriving as strided slices (torch.stack's backward) the second copy reused the first one's block
+        dhc = _f32c(dh) if dh is not None else None
+        dcc = _f32c(dc) if dc is not None else None
+        lib.check(lib.load().nir_lstm_cell_bwd(lib.ptr(dhc), lib.ptr(dcc), lib.ptr(act), lib.ptr(c), lib.ptr(cp) if ctx.has_cp else None,
+                                               lib.ptr(dg), lib.ptr(dcp), B, H, lib.stream()), "nir_lstm_cell_bwd")
         return dg, (dcp if ctx.has_cp else None)
 
 

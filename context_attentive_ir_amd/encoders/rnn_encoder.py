@@ -115,8 +115,8 @@ class RNNEncoder(nn.Module):
             x = states.contiguous().view(-1, self.total_hidden_dim)
             y = torch.empty_like(x)
             D = self.total_hidden_dim
-            lib.check(L.nir_linear_f32(lib.ptr(x), D, None, None, 0, 0, 0, lib.ptr(linear.weight.detach().float().contiguous()), D,
-                                       lib.ptr(linear.bias.detach().float().contiguous()), None, lib.ptr(y), D, x.shape[0], D, D,
+            wt, bs = linear.weight.detach().float().contiguous(), linear.bias.detach().float().contiguous()    # (referenced until enqueued)
+            lib.check(L.nir_linear_f32(lib.ptr(x), D, None, None, 0, 0, 0, lib.ptr(wt), D, lib.ptr(bs), None, lib.ptr(y), D, x.shape[0], D, D,
                                        2, lib.stream()), "nir_linear_f32")   # NIR_ACT_RELU
             return y.view(states.shape)
         if isinstance(hidden, tuple):

@@ -11,10 +11,11 @@ strict=True, `decode` raises, and `encode` returns None for session_bank / state
 import torch
 import torch.nn as nn
 
+from .. import autograd as A
 from .. import lib
 from . import suggest
 from ..encoders.rnn_encoder import lstm_cat_weights
-from ..rankers.mtensor import ExactMatchChannel
+from ..rankers.mtensor import ExactMatchChannel, train_head
 from .layers import Embedder, Encoder
 
 
@@ -56,6 +57,7 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
         self.dropout = nn.Dropout(args.dropout)
         self.generator = nn.Linear(args.nhid_session, args.tgt_vocab_size)
         self.regularize_coeff = args.regularize_coeff
+        self.dec_dropout_p = float(args.dropout_rnn)        # RNNDecoder.dropout (decoders/decoder.py:87), train mode only
         self._dims = dict(F=args.featsize, Hq=args.nhid_query // 2, Hd=args.nhid_document // 2, C=args.nchannels,
                           NF=args.nfilters, MF=args.match_filter_size)
         self._pack = lib.PackCache()
@@ -134,8 +136,29 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
                                               lib.ptr(scores), None, None, None, None, lib.stream()), "nir_matchtensor_score")
         return scores.view(B, S, N)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("training forward (ranking + suggestion losses) is outside the hot path (SURVEY.md 8f)")
+    def forward(self, source_rep, source_len, target_rep, target_len, target_seq, document_rep, document_len, document_label):
+        """mmtensor.py:191-259 (train mode) -> {'ranking_loss', 'suggestion_loss'}, differentiable through the HIP operators of autograd.py:
+        the projected queries are computed ONCE and feed both the interaction head and, max-pooled, the session LSTM whose states start
+        the teacher-forced decoder -- as in the reference, where encode()'s tensor is handed to rank_document()."""
+        table = self.embedder.word_embeddings.table
+        lib.require_device(source_rep, document_rep, table)
+        B, S, QL = source_rep.shape
+        N, DL = document_rep.shape[2], document_rep.shape[3]
+        q, d = self._clean_ids(source_rep.reshape(B * S, QL), document_rep.reshape(B * S, N, DL), table.shape[0])
+        pe, p = self.embedder.dropout.p, self.dropout.p
+        lp = self.linear_projection
+        xq = A.linear(A.dropout(A.embed(q, table), pe, True), lp.weight, lp.bias)
+        hq = A.dropout(suggest.bilstm_train(xq, lib.ids64(source_len.reshape(-1)), self.query_encoder.encoder.rnns[0]), p, True)
+        pq = A.linear(hq, self.query_projection.weight, self.query_projection.bias)               # [B*S,QL,C]
+        mem = pq.max(1)[0].view(B, S, -1)                                                         # all positions take part (:88-90)
+        h_steps, c_steps = A.lstm_seq(mem, self.session_query_encoder.encoder.rnns[0])            # session states, every step
+        # ranking (mmtensor.py:127-189; the dropout on the encoded documents is `self.dropout` as well, :153)
+        xd = A.linear(A.dropout(A.embed(d.reshape(B * S * N, DL), table), pe, True), lp.weight, lp.bias)
+        hd = A.dropout(suggest.bilstm_train(xd, lib.ids64(document_len.reshape(-1)), self.document_encoder.encoder.rnns[0]), p, True)
+        pd = A.linear(hd, self.document_projection.weight, self.document_projection.bias)
+        scores = train_head(self, q, d, pq, pd).view(B, S, N)
+        return {"ranking_loss": A.bce_with_logits(scores, document_label.float()),
+                "suggestion_loss": suggest.suggestion_loss(self, h_steps, c_steps, target_rep, target_seq)}
 
     def decode(self, states, max_len, src_dict, tgt_dict, batch_size, session_len, use_cuda=True, tgt2src=None, **kwargs):
         """mmtensor.py:281-325 (greedy, decoder without attention) -> {'predictions': LongTensor [batch_size, session_len, max_len]}."""

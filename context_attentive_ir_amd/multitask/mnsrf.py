@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 from collections import OrderedDict
 
+from .. import autograd as A
 from .. import lib
 from . import suggest
 from ..encoders.rnn_encoder import lstm_cat_weights
@@ -39,6 +40,7 @@ class MNSRF(nn.Module, lib.IdCheck):
         self.dropout = nn.Dropout(args.dropout)
         self.generator = nn.Linear(args.nhid_session, args.tgt_vocab_size)
         self.regularize_coeff = args.regularize_coeff
+        self.dec_dropout_p = float(args.dropout_rnn)        # RNNDecoder.dropout (decoders/decoder.py:87), train mode only
         self._dims = dict(Hq=args.nhid_query // 2, Hd=args.nhid_document // 2, HS=args.nhid_session)
         self._pack = lib.PackCache()
 
@@ -107,8 +109,26 @@ class MNSRF(nn.Module, lib.IdCheck):
                                         lib.stream()), "nir_mnsrf_score")
         return scores
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("training forward (ranking + suggestion losses) is outside the hot path (SURVEY.md 8f)")
+    def forward(self, source_rep, source_len, target_rep, target_len, target_seq, document_rep, document_len, document_label):
+        """mnsrf.py:164-232 (train mode) -> {'ranking_loss', 'suggestion_loss'}, differentiable through the HIP operators of autograd.py
+        (the 256-per-direction encoders run as two unidirectional lstm_seq passes, suggest.bilstm_train)."""
+        table = self.embedder.word_embeddings.table
+        lib.require_device(source_rep, document_rep, table)
+        B, S, QL = source_rep.shape
+        N, DL = document_rep.shape[2], document_rep.shape[3]
+        q, d = self._clean_ids(source_rep.reshape(B * S, QL), document_rep.reshape(B * S * N, DL), table.shape[0])
+        pe, p = self.embedder.dropout.p, self.dropout.p
+        eq = A.dropout(A.embed(q, table), pe, True)
+        mem = A.dropout(suggest.bilstm_train(eq, lib.ids64(source_len.reshape(-1)), self.query_encoder.encoder.rnns[0]), p, True)
+        mem = mem.max(1)[0].view(B, S, -1)                                                        # mnsrf.py:79-83
+        h_steps, c_steps = A.lstm_seq(mem, self.session_query_encoder.encoder.rnns[0])
+        ed = A.dropout(A.embed(d, table), pe, True)
+        docs = suggest.bilstm_train(ed, lib.ids64(document_len.reshape(-1)), self.document_encoder.encoder.rnns[0]).max(1)[0].view(B, S, N, -1)
+        sess_in = torch.cat((torch.zeros_like(h_steps[:, :1]), h_steps[:, 1:]), 1)                # zeros at the first query, s_t afterwards (:139-146)
+        comb = A.linear(torch.cat((mem, sess_in), 2), self.projection.linear.weight, self.projection.linear.bias, act="tanh")
+        scores = (comb.unsqueeze(2) * docs).sum(3)
+        return {"ranking_loss": A.bce_with_logits(scores, document_label.float()),
+                "suggestion_loss": suggest.suggestion_loss(self, h_steps, c_steps, target_rep, target_seq)}
 
     def decode(self, states, max_len, src_dict, tgt_dict, batch_size, session_len, use_cuda=True, tgt2src=None, **kwargs):
         """mnsrf.py:251-296 (greedy, decoder without attention) -> {'predictions': LongTensor [batch_size, session_len, max_len]}."""

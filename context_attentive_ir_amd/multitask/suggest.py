@@ -8,8 +8,9 @@
 """
 import torch
 
+from .. import autograd as A
 from .. import lib
-from ..constants import BOS
+from ..constants import BOS, PAD
 
 
 def session_states(x, lstm):
@@ -69,3 +70,51 @@ def greedy_decode(owner, states, max_len, src_dict, tgt_dict, batch_size, sessio
                                         lib.ptr(p[2]), lib.ptr(p[3]), lib.ptr(gw), lib.ptr(gb), VT, lib.ptr(tgt2src), BOS, int(max_len), lib.ptr(ws),
                                         ws.numel(), lib.ptr(preds), lib.stream()), "nir_decode_greedy_plain")
     return {"predictions": preds.view(int(batch_size), int(session_len), int(max_len))}
+
+
+def bilstm_train(x, lens, lstm):
+    """Train-mode BiLSTM memory bank [M,T,2H] for any hidden size: the register-resident training recurrence (autograd.bilstm) up to H = 128
+    per direction, beyond it two unidirectional passes of autograd.lstm_seq -- the reverse direction over each sequence's valid part read
+    backwards (packed-sequence semantics: zero past the length; states past a sequence's end never reach a kept output)."""
+    H = lstm.hidden_size
+    if H <= 128:
+        return A.bilstm(x, lens, lstm)
+    M, T, _ = x.shape
+    dev = x.device
+    ln = lens.to(dev).view(M, 1) if lens is not None else torch.full((M, 1), T, device=dev, dtype=torch.int64)
+    pos = torch.arange(T, device=dev).view(1, T)
+    valid = (pos < ln).unsqueeze(2).float()
+    ridx = (ln - 1 - pos).clamp(min=0)                                             # position read at reverse step t
+
+    class _Dir(object):                                                          # one direction's parameters under the names lstm_seq reads
+        def __init__(self, sfx):
+            for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                setattr(self, n, getattr(lstm, n + sfx))
+    fwd = A.lstm_seq(x, _Dir(""))[0] * valid
+    xr = torch.gather(x, 1, ridx.unsqueeze(2).expand(M, T, x.shape[2])) * valid
+    rev = A.lstm_seq(xr, _Dir("_reverse"))[0] * valid
+    rev = torch.gather(rev, 1, ridx.unsqueeze(2).expand(M, T, H)) * valid            # back to time order
+    return torch.cat((fwd, rev), 2)
+
+
+def suggestion_loss(model, h_steps, c_steps, target_rep, target_seq):
+    """Teacher-forced decoding loss shared by M_MATCH_TENSOR and MNSRF (mmtensor.py:224-254, mnsrf.py:198-228): the decoder without
+    attention starts from the session state after queries 0 .. S-2 (rows step-major: torch.cat(states[:-1], 1), paired with the
+    batch-major target rows exactly as the reference pairs them), generator, masked NLL summed over time and averaged over rows, plus the
+    entropy regulariser.  h_steps / c_steps [B,S,HS] differentiable session states."""
+    B, S, HS = h_steps.shape
+    Bd = B * (S - 1)
+    dec_h = h_steps[:, :S - 1].transpose(0, 1).reshape(Bd, HS)
+    dec_c = c_steps[:, :S - 1].transpose(0, 1).reshape(Bd, HS)
+    tgt = lib.ids64(target_rep.reshape(Bd, -1))
+    seq = lib.ids64(target_seq.reshape(Bd, -1))
+    emb = A.dropout(A.embed(tgt, model.embedder.word_embeddings.table), model.embedder.dropout.p, True)
+    h_all, _ = A.lstm_seq(emb, model.decoder.decoder.rnn, dec_h, dec_c)                  # [Bd,TL,HS]
+    h_all = A.dropout(h_all, model.dec_dropout_p, True)                                   # RNNDecoder's own dropout (dropout_rnn)
+    logll = torch.log_softmax(A.linear(h_all, model.generator.weight, model.generator.bias)[:, :-1], -1)
+    target = seq[:, 1:]
+    nll = -logll.gather(2, target.unsqueeze(2)).squeeze(2) * target.ne(PAD).float()
+    loss = nll.sum(1).mean()
+    if model.regularize_coeff > 0:
+        loss = loss + ((logll.exp() * logll).sum(2) * model.regularize_coeff).sum(1).mean()
+    return loss

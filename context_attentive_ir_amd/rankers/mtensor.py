@@ -53,6 +53,29 @@ def attach_projection_fragments(pk):
     return pk
 
 
+def train_head(mod, q, d, pq, pd):
+    """Differentiable interaction head (mtensor.py:100-131) shared by MatchTensor and M_MATCH_TENSOR: q [B,QL] / d [B,N,DL] ids, projected
+    queries pq [B,QL,C] and documents pd [B*N,DL,C] -> scores [B,N].  `mod` holds exact_match_channel, conv1..3, conv, output."""
+    B, QL = q.shape
+    N, DL = d.shape[1], d.shape[2]
+    M = B * N
+    C = pq.shape[-1]
+    pqe = pq.unsqueeze(1).expand(B, N, QL, C).reshape(M, QL, C)
+    prod = pqe.unsqueeze(2) * pd.unsqueeze(1)                                              # [M,QL,DL,C]
+    em = (q.unsqueeze(1).expand(B, N, QL).reshape(M, QL).unsqueeze(2) == d.reshape(M, DL).unsqueeze(1)).float()
+    em = em * mod.exact_match_channel.alpha
+    T = torch.cat((prod, em.unsqueeze(3)), 3).permute(0, 3, 1, 2).contiguous()            # [M,C+1,QL,DL]
+    feats = []
+    for conv in (mod.conv1, mod.conv2, mod.conv3):
+        kh, kw = conv.kernel_size
+        cols = F.unfold(T, (kh, kw), padding=conv.padding)                                 # [M,(C+1)*kh*kw,QL*DL]
+        rows = cols.transpose(1, 2).reshape(M * QL * DL, -1)
+        feats.append(A.linear(rows, conv.weight.reshape(conv.out_channels, -1), conv.bias, act="relu"))
+    g = A.linear(torch.cat(feats, 1), mod.conv.weight.reshape(mod.conv.out_channels, -1), mod.conv.bias)
+    g = g.view(M, QL * DL, -1).max(1)[0]
+    return A.linear(g, mod.output.weight, mod.output.bias).view(B, N)
+
+
 class MatchTensor(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
@@ -137,21 +160,7 @@ class MatchTensor(nn.Module, lib.IdCheck):
         hd = A.bilstm(xd, dl.reshape(-1), self.document_encoder.rnns[0])
         pq = A.linear(hq, self.query_projection.weight, self.query_projection.bias)            # [B,QL,C]
         pd = A.linear(hd, self.document_projection.weight, self.document_projection.bias)      # [M,DL,C]
-        C = pq.shape[-1]
-        pqe = pq.unsqueeze(1).expand(B, N, QL, C).reshape(M, QL, C)
-        prod = pqe.unsqueeze(2) * pd.unsqueeze(1)                                              # [M,QL,DL,C]
-        em = (q.unsqueeze(1).expand(B, N, QL).reshape(M, QL).unsqueeze(2) == d.reshape(M, DL).unsqueeze(1)).float()
-        em = em * self.exact_match_channel.alpha
-        T = torch.cat((prod, em.unsqueeze(3)), 3).permute(0, 3, 1, 2).contiguous()            # [M,C+1,QL,DL]
-        feats = []
-        for conv in (self.conv1, self.conv2, self.conv3):
-            kh, kw = conv.kernel_size
-            cols = F.unfold(T, (kh, kw), padding=conv.padding)                                 # [M,(C+1)*kh*kw,QL*DL]
-            rows = cols.transpose(1, 2).reshape(M * QL * DL, -1)
-            feats.append(A.linear(rows, conv.weight.reshape(conv.out_channels, -1), conv.bias, act="relu"))
-        g = A.linear(torch.cat(feats, 1), self.conv.weight.reshape(self.conv.out_channels, -1), self.conv.bias)
-        g = g.view(M, QL * DL, -1).max(1)[0]
-        return A.linear(g, self.output.weight, self.output.bias).view(B, N)
+        return train_head(self, q, d, pq, pd)
 
     def _generic_encoders(self):
         """encoder configurations outside the fused / folded kernels (rnn_encoder.py:28-60 admits GRU and stacked layers; hyparam pins the

@@ -215,11 +215,9 @@ class Multitask(WrapperBase):
 
     def update(self, ex):
         """models/multitask.py:161-223: train-mode forward -> (1 - alpha) ranking + alpha suggestion (+ regularisation) -> backward
-        -> clip_grad_norm(grad_clipping) -> optimizer step.  CARS only (the other multitask networks keep their eval mirrors)."""
+        -> clip_grad_norm(grad_clipping) -> optimizer step (CARS, M_MATCH_TENSOR, MNSRF)."""
         if self.optimizer is None:
             raise RuntimeError("No optimizer set.")
-        if self.type != "CARS":
-            raise NotImplementedError("train-mode forward of %s is not built (CARS and MATCH_TENSOR are)" % self.type)
         self.network.train()
         g = lambda k: self._dev(ex[k])        # noqa: E731
         loss = self.network(source_rep=g("source_words"), source_len=g("source_lens"), target_rep=g("target_words"),

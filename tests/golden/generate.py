@@ -363,6 +363,74 @@ def gen_cars_train():
     save("cars_train", **out)
 
 
+def gen_session_train(model, fixture, keep, seed):
+    """Training step of the real reference Multitask (models/multitask.py:161-223) for M_MATCH_TENSOR / MNSRF, all dropouts 0: both losses
+    and selected gradients of the first backward (all gradient norms), then the total-loss trajectory of 4 Adam updates over two batches."""
+    from neuroir.models.multitask import Multitask
+    rng = np.random.default_rng(seed)
+    B, S, N, QL, DL, TL = 2, 3, 3, 5, 8, 6
+    batches = []
+    for _ in range(2):
+        qlen = rng.integers(1, QL + 1, size=(B, S)); qlen[0, 0] = QL
+        dlen = rng.integers(1, DL + 1, size=(B, S, N)); dlen[0, 0, 0] = DL
+        tlen = rng.integers(2, TL + 1, size=(B, S - 1)); tlen[0, 0] = TL
+        q = rand_ids(rng, (B, S, QL), qlen); d = rand_ids(rng, (B, S, N, DL), dlen)
+        tw = rand_ids(rng, (B, S - 1, TL), tlen, hi=50); ts = rand_ids(rng, (B, S - 1, TL), tlen, hi=50)
+        lab = np.zeros((B, S, N), np.float32)
+        for b in range(B):
+            for s_ in range(S):
+                lab[b, s_, rng.choice(N, int(rng.integers(1, 3)), replace=False)] = 1.0
+        batches.append(dict(source_words=q, source_lens=qlen, document_words=d, document_lens=dlen, document_labels=lab,
+                            target_words=tw, target_seq=ts, target_lens=tlen))
+    args = base_args(model, tgt_vocab_size=50, dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.001,
+                     weight_decay=0, momentum=0, grad_clipping=10.0, fix_embeddings=True)
+    m = Multitask(args, list(range(V)), list(range(50)))
+    from context_attentive_ir_amd.detinit import fill_module_
+    fill_module_(m.network, SEED)
+    m.init_optimizer()
+    m.network.train()
+    b0 = {k: T(v) for k, v in batches[0].items()}
+    loss = m.network(source_rep=b0["source_words"], source_len=b0["source_lens"], target_rep=b0["target_words"], target_len=b0["target_lens"],
+                     target_seq=b0["target_seq"], document_rep=b0["document_words"], document_len=b0["document_lens"],
+                     document_label=b0["document_labels"])
+    total = (1 - args.alpha) * loss["ranking_loss"] + args.alpha * loss["suggestion_loss"]
+    m.optimizer.zero_grad()
+    total.backward()
+    out = {}
+    for bi, b in enumerate(batches):
+        for k, v in b.items():
+            out["b%d_%s" % (bi, k)] = v
+    out["ranking_loss"], out["suggestion_loss"], out["total_loss"] = loss["ranking_loss"].detach(), loss["suggestion_loss"].detach(), total.detach()
+    norms = {}
+    for name, p in m.network.named_parameters():
+        if p.grad is not None:
+            norms[name] = float(p.grad.norm())
+            if name in keep and p.numel() <= 20000:
+                out["grad_" + name] = p.grad.detach().clone()
+    out["grad_norm_names"] = np.asarray(sorted(norms))
+    out["grad_norms"] = np.asarray([norms[k] for k in sorted(norms)], np.float64)
+    m.optimizer.zero_grad()
+    losses = []
+    for step in range(4):
+        b = {k: T(v) for k, v in batches[step % 2].items()}
+        losses.append(float(m.update(b)["total_loss"]))
+    out["losses"] = np.asarray(losses, np.float64)
+    out["alpha"] = float(args.alpha)
+    save(fixture, **out)
+
+
+def gen_mmt_train():
+    gen_session_train("M_MATCH_TENSOR", "m_match_tensor_train", ("output.weight", "conv.weight", "query_projection.bias", "generator.bias",
+                                                                  "decoder.decoder.rnn.bias_hh_l0", "session_query_encoder.encoder.rnns.0.bias_ih_l0",
+                                                                  "query_encoder.encoder.rnns.0.bias_ih_l0", "exact_match_channel.alpha"), 61)
+
+
+def gen_mnsrf_train():
+    gen_session_train("MNSRF", "mnsrf_train", ("projection.linear.bias", "generator.bias", "decoder.decoder.rnn.bias_hh_l0",
+                                               "session_query_encoder.encoder.rnns.0.bias_ih_l0", "query_encoder.encoder.rnns.0.bias_ih_l0",
+                                               "document_encoder.encoder.rnns.0.bias_hh_l0_reverse"), 67)
+
+
 @torch.no_grad()
 def gen_cars_decode():
     """CARS suggestion side + session switches from the real reference: decoder-initialisation states, inner-attention
@@ -581,7 +649,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])          # e.g. `generate.py cars_decode` regenerates one fixture family
     gens = dict(esm=gen_esm, match_tensor=gen_match_tensor, drmm=gen_drmm, duet=gen_duet, cars=gen_cars, cars_decode=gen_cars_decode, train=gen_train, duet_train=gen_duet_train, drmm_train=gen_drmm_train, drmm_train_free=gen_drmm_train_free, cars_train=gen_cars_train,
                 losses_metrics=gen_losses_metrics, batchify=gen_batchify, samplers=gen_samplers, m_match_tensor=gen_m_match_tensor,
-                mnsrf=gen_mnsrf, rnn_encoder=gen_rnn_encoder, match_tensor_general=gen_match_tensor_general)
+                mnsrf=gen_mnsrf, rnn_encoder=gen_rnn_encoder, match_tensor_general=gen_match_tensor_general, mmt_train=gen_mmt_train, mnsrf_train=gen_mnsrf_train)
     for name, fn in gens.items():
         if not only or name in only:
             fn()
