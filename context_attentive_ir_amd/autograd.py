@@ -139,7 +139,11 @@ class _Dropout(Function):
         xc = _f32c(x)
         y = torch.empty_like(xc)
         keep = torch.empty(xc.numel(), dtype=torch.uint8, device=xc.device)
-        lib.check(L.nir_dropout_f32(lib.ptr(xc), lib.ptr(y), lib.ptr(keep), xc.numel(), float(p), int(seed), lib.stream()), "nir_dropout_f32")
+        if DROPOUT.device_seed is not None:       # captured training step: the seed lives on the device, `seed` is the call site's salt
+            lib.check(L.nir_dropout_dev_f32(lib.ptr(xc), lib.ptr(y), lib.ptr(keep), xc.numel(), float(p), lib.ptr(DROPOUT.device_seed), int(seed),
+                                            lib.stream()), "nir_dropout_dev_f32")
+        else:
+            lib.check(L.nir_dropout_f32(lib.ptr(xc), lib.ptr(y), lib.ptr(keep), xc.numel(), float(p), int(seed), lib.stream()), "nir_dropout_f32")
         ctx.p = float(p)
         ctx.save_for_backward(keep)
         ctx.mark_non_differentiable(keep)
@@ -161,11 +165,16 @@ class DropoutState(object):
 
     def __init__(self, seed=1013):
         self.seed, self.counter, self.masks, self.record = int(seed), 0, [], False
+        self.device_seed = None         # int64 [1] device tensor while a training step is being captured / replayed (wrappers.GraphedUpdate)
+        self.site = 0
 
     def manual_seed(self, seed):
         self.seed, self.counter = int(seed), 0
 
     def next(self):
+        if self.device_seed is not None:   # the per-step seed comes from the device; sites are numbered within the step
+            self.site += 1
+            return self.site
         self.counter += 1
         return (self.seed * 0x9E3779B97F4A7C15 + self.counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 

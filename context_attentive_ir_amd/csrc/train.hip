@@ -338,6 +338,17 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     keep[i] = k ? 1 : 0;
     y[i] = k ? x[i] / (1.0f - pdrop) : 0.f;
 }
+// the same with the seed read from device memory (a captured training step replays with a fresh seed: the graph's first node advances it)
+__global__ void dropout_dev_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ keep, int64_t n, float pdrop,
+                                   const uint64_t* __restrict__ seed_dev, uint64_t salt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t seed = splitmix(seed_dev[0] * 0x9E3779B97F4A7C15ull + salt * 0xD1B54A32D192ED03ull);
+    const float u = (float)(splitmix(seed ^ (uint64_t)i * 0xD1342543DE82EF95ull) >> 40) * (1.0f / 16777216.0f);
+    const bool k = u >= pdrop;
+    keep[i] = k ? 1 : 0;
+    y[i] = k ? x[i] / (1.0f - pdrop) : 0.f;
+}
 __global__ void mask_scale_kernel(const float* __restrict__ x, const unsigned char* __restrict__ keep, float scale, float* __restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = keep[i] ? x[i] * scale : 0.f;
@@ -521,6 +532,15 @@ extern "C" int nir_dropout_f32(const float* x, float* y, unsigned char* keep, in
     if (n == 0) return 0;
     hipLaunchKernelGGL(dropout_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, x, y, keep, n, p, seed);
     NIR_CHECK_LAUNCH("dropout_kernel");
+    return 0;
+}
+extern "C" int nir_dropout_dev_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, const uint64_t* seed_dev, uint64_t salt,
+                                   nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(x && y && keep && seed_dev && n >= 0 && p >= 0.f && p < 1.f, "dropout_dev: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_dev_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, x, y, keep, n, p, seed_dev, salt);
+    NIR_CHECK_LAUNCH("dropout_dev_kernel");
     return 0;
 }
 extern "C" int nir_mask_scale_f32(const float* x, const unsigned char* keep, float scale, float* y, int64_t n, nir_stream_t stream) {

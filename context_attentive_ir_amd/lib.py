@@ -130,6 +130,7 @@ SIGNATURES = {
     "nir_lstm_cell_fwd": (_i, [c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, c_st]),
     "nir_lstm_cell_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, c_st]),
     "nir_dropout_f32": (_i, [c_fp, c_fp, C.c_void_p, _l, C.c_float, C.c_uint64, c_st]),
+    "nir_dropout_dev_f32": (_i, [c_fp, c_fp, C.c_void_p, _l, C.c_float, C.c_void_p, C.c_uint64, c_st]),
     "nir_mask_scale_f32": (_i, [c_fp, C.c_void_p, C.c_float, c_fp, _l, c_st]),
     "nir_act_bwd_f32": (_i, [c_fp, c_fp, c_fp, _l, _i, c_st]),
     "nir_rank_loss_bce_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, _l, c_st]),

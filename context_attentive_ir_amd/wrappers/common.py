@@ -73,14 +73,16 @@ class WrapperBase(object):
             pass
         seed = getattr(a, "random_seed", None)
         A.DROPOUT.manual_seed((int(seed) if seed is not None else int(torch.initial_seed())) * 1000003 + rank)
+        # capturable: the step counters live on the device, so a whole update can be captured into a hipGraph (GraphedUpdate); same arithmetic
+        cap = dict(capturable=True) if (use_gpu and torch.cuda.is_available()) else {}
         if a.optimizer == "sgd":
             self.optimizer = optim.SGD(parameters, a.learning_rate, momentum=a.momentum, weight_decay=a.weight_decay)
         elif a.optimizer == "adam":
-            self.optimizer = optim.Adam(parameters, a.learning_rate, weight_decay=a.weight_decay)
+            self.optimizer = optim.Adam(parameters, a.learning_rate, weight_decay=a.weight_decay, **cap)
         elif a.optimizer == "adamax":
-            self.optimizer = optim.Adamax(parameters, a.learning_rate, weight_decay=a.weight_decay)
+            self.optimizer = optim.Adamax(parameters, a.learning_rate, weight_decay=a.weight_decay, **cap)
         elif a.optimizer == "adadelta":
-            self.optimizer = optim.Adadelta(parameters, a.learning_rate, weight_decay=a.weight_decay)
+            self.optimizer = optim.Adadelta(parameters, a.learning_rate, weight_decay=a.weight_decay, **cap)
         else:
             raise RuntimeError("Unsupported optimizer: %s" % a.optimizer)
         if state_dict is not None:
@@ -159,3 +161,64 @@ class WrapperBase(object):
         self.use_cuda = False
         self.network = self.network.cpu()
         return self
+
+
+class GraphedUpdate(object):
+    """The whole training step of a wrapper -- train-mode forward, losses, backward, gradient clipping, optimizer step
+    (models/ranker.py:192-230, models/multitask.py:161-223) -- as ONE hipGraph per batch shape.
+
+    The eager update() is host-bound: a CARS step enqueues ~900 launches from Python / autograd for 9.6 ms of kernels (27 ms per step).
+    Captured, the step costs one graph launch.  What capture needs and gets:
+      * static inputs: the batch is copied into per-shape device buffers;
+      * fresh dropout masks on every replay: the mask seed lives in device memory (nir_dropout_dev_f32), the graph's first node advances it;
+      * a capturable optimizer (init_optimizer builds Adam / Adamax / Adadelta with capturable=True on a GPU);
+      * no host synchronisation inside the step: id validation stays deferred (`wrapper.network.check_ids()` whenever the caller wants it).
+    The first batch of every shape is an ordinary eager update (it is that step, and it creates the optimizer state); the graph is captured
+    right after it and replayed from the second batch of the shape on.  Multi-rank gradient averaging is not captured: with a process group
+    the call falls back to update().  Returns the loss dict of device tensors (valid until the next call)."""
+
+    def __init__(self, wrapper):
+        self.w = wrapper
+        self.graphs = {}
+        self.seed = None
+
+    def _key(self, ex):
+        return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(ex.items()) if torch.is_tensor(v))
+
+    def __call__(self, ex):
+        from .. import autograd as A
+        w = self.w
+        if w.optimizer is None:
+            raise RuntimeError("No optimizer set.")
+        if getattr(w, "group", None) is not None or getattr(w, "parallel", False):
+            return w.update(ex)
+        key = self._key(ex)
+        ent = self.graphs.get(key)
+        if ent is None:
+            out = w.update(ex)                                   # this batch's step, eager
+            # only detached values survive into the capture: with the eager step's autograd graph still referenced (through its loss), ending
+            # the capture crashed inside hipStreamEndCapture (ROCm 7.0 / torch 2.10; reproduced in isolation, fine once the reference is dropped)
+            out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()} if isinstance(out, dict) else out.detach()
+            dev = next(w.network.parameters()).device
+            static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in ex.items()}
+            if self.seed is None:
+                self.seed = torch.full((1,), (A.DROPOUT.seed * 2654435761 + 12345) & 0x7FFFFFFFFFFF, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            w.optimizer.zero_grad(set_to_none=True)
+            A.DROPOUT.device_seed, A.DROPOUT.site = self.seed, 0
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.seed.add_(1)
+                    loss = w._update_body(static)
+            finally:
+                A.DROPOUT.device_seed = None
+            self.graphs[key] = (g, static, loss)
+            return out
+        g, static, loss = ent
+        for k, v in ex.items():
+            if torch.is_tensor(v):
+                static[k].copy_(v, non_blocking=True)
+        g.replay()
+        w.updates += 1
+        return loss

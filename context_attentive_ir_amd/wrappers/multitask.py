@@ -218,6 +218,14 @@ class Multitask(WrapperBase):
         -> clip_grad_norm(grad_clipping) -> optimizer step (CARS, M_MATCH_TENSOR, MNSRF)."""
         if self.optimizer is None:
             raise RuntimeError("No optimizer set.")
+        self.optimizer.zero_grad()
+        loss = self._update_body(ex)
+        self.updates += 1
+        return loss
+
+    def _update_body(self, ex):
+        """forward -> losses -> backward -> (gradient averaging) -> clipping -> optimizer step; no host synchronisation, so that
+        common.GraphedUpdate can capture it into one hipGraph (gradients must be cleared by the caller)."""
         self.network.train()
         g = lambda k: self._dev(ex[k])        # noqa: E731
         loss = self.network(source_rep=g("source_words"), source_len=g("source_lens"), target_rep=g("target_words"),
@@ -227,12 +235,10 @@ class Multitask(WrapperBase):
         if loss.get("regularization") is not None:
             total = total + loss["regularization"]
         loss["total_loss"] = total
-        self.optimizer.zero_grad()
         total.backward()
         self.sync_gradients()                 # multi-rank: average the gradients of all ranks (WrapperBase.sync_gradients)
         torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.args.grad_clipping)
         self.optimizer.step()
-        self.updates += 1
         return loss
 
     @staticmethod

@@ -103,6 +103,14 @@ class Ranker(WrapperBase):
             raise RuntimeError("%s has no training criterion (main/ranker.py:414)" % self.kind)
         if not hasattr(self.network, "_forward_train"):
             raise NotImplementedError("%s has no train-mode forward" % self.kind)
+        self.optimizer.zero_grad()
+        loss = self._update_body(ex)
+        self.updates += 1
+        return loss
+
+    def _update_body(self, ex):
+        """forward -> criterion -> backward -> (gradient averaging) -> clipping -> optimizer step; no host synchronisation, so that
+        common.GraphedUpdate can capture it into one hipGraph (gradients must be cleared by the caller)."""
         from .. import autograd as A
         self.network.train()
         q, ql, d, dl = self._inputs(ex)
@@ -110,12 +118,10 @@ class Ranker(WrapperBase):
         labels = labels.cuda(non_blocking=True) if self.use_cuda else labels
         scores = self.network(q, ql, d, dl)
         loss = A.bce_with_logits(scores, labels)
-        self.optimizer.zero_grad()
         loss.backward()
         self.sync_gradients()                 # multi-rank: average the gradients of all ranks (WrapperBase.sync_gradients)
         torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.args.grad_clipping)
         self.optimizer.step()
-        self.updates += 1
         return loss
 
     # -- persistence (save / checkpoint in WrapperBase) ---------------------------------------------

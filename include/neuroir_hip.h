@@ -486,6 +486,10 @@ int nir_lstm_cell_bwd(const float* dh, const float* dc, const float* act, const 
 /* Inverted dropout with a counter-based mask: keep[i] = uniform(splitmix64(seed ^ i*c)) >= p, y = x*keep/(1-p).  The mask is an
  * output so that a parity test can replay it through the oracle. */
 int nir_dropout_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, uint64_t seed, nir_stream_t stream);
+/* nir_dropout_f32 with the seed in device memory (*seed_dev, mixed with the call site's `salt`): a hipGraph-captured training step draws new
+ * masks on every replay -- the graph advances *seed_dev itself. */
+int nir_dropout_dev_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, const uint64_t* seed_dev, uint64_t salt,
+                        nir_stream_t stream);
 int nir_mask_scale_f32(const float* x, const unsigned char* keep, float scale, float* y, int64_t n, nir_stream_t stream);
 /* dx = dy * f'(.) expressed through y = f(x): act 1 tanh, 2 relu, 3 sigmoid. */
 int nir_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int act, nir_stream_t stream);

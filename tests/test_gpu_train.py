@@ -464,3 +464,61 @@ def test_lstm_seq_gradients_with_both_state_outputs(M, T_, I, H, init):
         res.append([xx.grad.clone()] + [p.grad.clone() for p in lstm.parameters()])
     for a, b in zip(*res):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+
+
+# ------------------------------------------------------------------ the training step as one hipGraph (wrappers.GraphedUpdate)
+@pytest.mark.parametrize("kind", ["MATCH_TENSOR", "CARS"])
+def test_graphed_update_reproduces_eager_trajectory_without_dropout(kind):
+    """With all dropouts 0 the captured step is deterministic: N graphed updates leave the same parameters as N eager ones."""
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import GraphedUpdate, Multitask, Ranker
+    extra = dict(dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.001, weight_decay=0, momentum=0, grad_clipping=10.0,
+                 fix_embeddings=True)
+    if kind == "CARS":
+        g = load_golden("cars_train")
+        V = int(g["meta_vocab"])
+        mk = lambda: Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=V, **extra))          # noqa: E731
+        batches = [_cars_train_batch(g, i, DEV) for i in range(2)]
+    else:
+        g = load_golden("match_tensor_train")
+        mk = lambda: Ranker(default_args("MATCH_TENSOR", src_vocab_size=int(g["meta_vocab"]), **extra))      # noqa: E731
+        batches = [{k: T(g["b%d_%s" % (i, k)], DEV) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label")} for i in range(2)]
+    finals = []
+    for graphed in (False, True):
+        w = mk()
+        fill_module_(w.network, 1013)
+        w.cuda()
+        w.init_optimizer()
+        step = GraphedUpdate(w) if graphed else w.update
+        losses = []
+        for i in range(6):
+            out = step(batches[i % 2])
+            losses.append(float(out["total_loss"] if isinstance(out, dict) else out))
+        finals.append((losses, {k: v.detach().clone() for k, v in w.network.state_dict().items()}, w.updates))
+    (le, pe, ue), (lg, pg, ug) = finals
+    assert ue == ug == 6
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    for k in pe:
+        if k.endswith("attn.3.bias"):       # bias of a logit that only enters a softmax: its gradient is rounding noise and Adam normalises noise to +-lr
+            continue
+        # (Adam turns run-to-run rounding differences of near-zero gradients -- atomically accumulated weight gradients -- into parameter
+        # differences of a few 1e-5 over six steps; a real divergence would be of the order of the learning rate, 1e-3 per step)
+        assert float((pe[k] - pg[k]).abs().max()) <= 1e-4 * max(1.0, float(pe[k].abs().max())), k
+
+
+def test_graphed_update_draws_fresh_dropout_masks():
+    """Default dropouts: replays of the captured step must not repeat one mask set (the seed lives on the device and advances per replay)."""
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import GraphedUpdate, Ranker
+    g = load_golden("match_tensor_train")
+    w = Ranker(default_args("MATCH_TENSOR", src_vocab_size=int(g["meta_vocab"]), optimizer="sgd", learning_rate=0.0, weight_decay=0, momentum=0,
+                            grad_clipping=10.0, fix_embeddings=True))
+    fill_module_(w.network, 1013)
+    w.cuda()
+    w.init_optimizer()
+    b = {k: T(g["b0_%s" % k], DEV) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label")}
+    step = GraphedUpdate(w)
+    losses = [float(step(b)) for _ in range(5)]          # learning rate 0: the loss changes through the masks only
+    assert len({round(x, 6) for x in losses[1:]}) >= 3, losses
