@@ -17,6 +17,7 @@
 //   lstm16_pt_kernel<G,NT>       fp32: v_mfma_f32_16x16x4_f32, W_hh slice in VGPRs, exact-fp32 (the parity path)
 //   lstm16_pt_bf16_kernel<KB,NT> bf16: v_mfma_f32_16x16x32_bf16, bf16 W_hh / h_t operands, fp32 accumulate, fp32 cell
 //                                state, bf16 folded table (BASELINE config 5)
+#include <type_traits>
 #include "common.hpp"
 #include <hip/hip_bf16.h>
 #include <string>
@@ -780,6 +781,260 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two sequence groups per workgroup (H = 128): the step of the kernel above is a serial chain -- barrier, LDS reads of h, ~1500 cycles of
+// MFMA per SIMD, the last tile's gate math, conversion, LDS write, barrier -- in which the matrix pipe idles for ~45 % of the time, and a
+// second workgroup cannot share the CU because the two-term W_hh of one direction fills half its register file.  Here one workgroup owns TWO
+// independent groups of 16 sequences that share the W registers and alternate in halves of a step:
+//     phase A:  MFMAs of group A (step t)   ||  gate math, h write, output store, next row request of group B (step t-1)     barrier
+//     phase B:  MFMAs of group B (step t)   ||  gate math, ... of group A (step t)                                            barrier
+// so every MFMA block of one group is issued over the VALU work of the other (k-block kb of the running group over tile kb of the resting
+// one).  Per wave: W 128 VGPRs, 2 x (acc + acx) 64, one k-block of h fragments at a time; the gate rows of a group's next step are requested
+// straight into its accumulators as soon as its gate math has read them (they ride in as the C operand half a step later).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void lstm16_pt_h2x2_kernel(LstmPtArgs p) {
+    constexpr int KB = 4, NT = 4, NW = 8, NTH = 64 * NW, SEQ = 16, KP = 32 * KB, ZLD = KP + 8, H = 128, H4 = 4 * H, NG = 2;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
+    const int TP = p.T + 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* z = reinterpret_cast<_Float16*>(smem);        // [2 groups][2 buffers][2 terms][SEQ][ZLD]
+    int* lens_s = reinterpret_cast<int*>(z + NG * 4 * SEQ * ZLD);      // [32]
+    int* simd_s = lens_s + NG * SEQ;                                     // [16]
+    int* ids_s = simd_s + 16;                                            // [32][TP]
+    float* rows_s = reinterpret_cast<float*>(ids_s + ((NG * SEQ * TP + 3) & ~3));   // [2 groups][8 waves][4 tiles][64 lanes][4]: gate rows, LDS-direct
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * (NG * SEQ);
+    const int T = p.T;
+    const int nvalid = (int)min((int64_t)(NG * SEQ), p.M - m0);
+    const int OW = p.ND * H;
+    const int64_t GW = (int64_t)p.ND * H4;
+
+    if (lane == 0) simd_s[wave] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
+    if (tid < NG * SEQ) {
+        int l = 0;
+        if (tid < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    __syncthreads();
+    {
+        bool bad = false;
+        for (int e = tid; e < NG * SEQ * TP; e += NTH) {
+            const int s_ = e / TP, k = e - s_ * TP;
+            int64_t id = 0;
+            if (s_ < nvalid) {
+                const int l = lens_s[s_];
+                int kk = k < l - 1 ? k : l - 1;
+                kk = kk < 0 ? 0 : kk;
+                int t_ = dir == 0 ? kk : l - 1 - kk;
+                t_ = t_ < 0 ? 0 : t_;
+                id = p.ids[(m0 + s_) * T + t_];
+                if (k < T) {
+                    const int64_t raw = p.ids[(m0 + s_) * T + k];
+                    bad |= raw < 0 || raw >= p.V;
+                }
+            }
+            if (id < 0 || id >= p.V) id = 0;
+            ids_s[e] = (int)id;
+        }
+        if (bad && p.err) atomicOr(p.err, 1);
+    }
+    for (int e = tid; e < NG * 2 * SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < NG * SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    int mylen[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) mylen[g] = lens_s[SEQ * g + sq];
+    {
+        const int mine = simd_s[wave];
+        int rank = 0;
+#pragma unroll
+        for (int w2_ = 0; w2_ < NW; ++w2_) rank += (w2_ < wave && simd_s[w2_] == mine) ? 1 : 0;
+        rank = __builtin_amdgcn_readfirstlane(rank);
+        if (rank == 0) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(1);
+    }
+
+    f16x8 w1[NT][KB], w2[NT][KB];
+    const int u0 = NT * (4 * wave + kq);
+    bool wbad = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + unit_a) * H;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int k0 = 32 * kb + 8 * kq;
+            const float4 a = *reinterpret_cast<const float4*>(wr + k0), b = *reinterpret_cast<const float4*>(wr + k0 + 4);
+            const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hi = (_Float16)wv[j];
+                w1[t][kb][j] = hi;
+                w2[t][kb][j] = (_Float16)((wv[j] - (float)hi) * SC);
+                wbad |= !(fabsf(wv[j]) < 32768.0f);
+            }
+        }
+    }
+    if (wbad && p.err) atomicOr(p.err, 2);
+
+    const float* pb = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4 + 4 * u0;      // the lane's 64 contiguous bytes of a folded row
+    const uint32_t gw = (uint32_t)GW;
+    f32x4 acc[NG][NT], acx[NG][NT];
+    float creg[NG][NT], hn[NT];
+    uint32_t soff[NG];
+    const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
+    __amdgpu_buffer_rsrc_t out_rs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int nv = max(0, min(SEQ, nvalid - SEQ * g));
+        out_rs[g] = __builtin_amdgcn_make_buffer_rsrc(p.out + (m0 + SEQ * g) * T * OW, 0, (int)((uint32_t)nv * T * OW * 4u), 0x00020000);
+        soff[g] = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen[g] - 1)) * OW + dir * H + u0) * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) creg[g][t] = 0.f;
+    }
+    // The gate rows of a group's step travel global -> LDS without touching registers (global_load_lds_dwordx4: the wave's 64 x 16 bytes land
+    // lane by lane in its own 1 KB slot) and are requested a FULL step ahead, right behind the first k-block of the group's previous MFMA
+    // phase; the group takes them over as its MFMA C operands at the top of its phase.  Vector-memory queue per phase, in order:
+    // [4 requests of the running group, 1 output store of the resting group] -- so behind a group's requests there are always
+    // store + 4 requests + store = 6 younger operations when it takes them over (s_waitcnt vmcnt(6), in-order completion).
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    auto request_rows = [&](int g, int step) {
+        const uint64_t ro = (uint64_t)(uint32_t)ids_s[(SEQ * g + sq) * TP + step] * gw;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb + ro + 4 * t), (lds_ptr_t)(rows_s + (((g * NW + wave) * NT + t) * 64) * 4), 16, 0, 0);
+    };
+    auto take_rows = [&](int g) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[g][t] = *reinterpret_cast<const f32x4*>(rows_s + ((((g * NW + wave) * NT + t) * 64) + lane) * 4);
+            acx[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // the resting group's finished step: h terms for its next B operand, its output, then its next rows
+    auto finish = [&](auto Gc, int step) {
+        constexpr int g = decltype(Gc)::value;
+        _Float16* zn = z + (g * 2 + ((step + 1) & 1)) * 2 * SEQ * ZLD;
+        _Float16 a[NT], r[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            a[t] = (_Float16)hn[t];
+            r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
+        }
+        *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = (f16x4){a[0], a[1], a[2], a[3]};
+        *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = (f16x4){r[0], r[1], r[2], r[3]};
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(hn[0]), __float_as_uint(hn[1]), __float_as_uint(hn[2]), __float_as_uint(hn[3])},
+                                               out_rs[g], step < mylen[g] ? soff[g] : OOB, 0, 0);
+        soff[g] += sstep;
+    };
+#ifdef NIR_PT_TRACE
+    unsigned long long tr[4] = {0, 0, 0, 0};
+#endif
+    // one half step: the MFMAs of group GM's step `sm` over the gate math of group GG's step `sg` (sg < 0: nothing to finish yet)
+    auto phase = [&](auto GMc, auto GGc, int sm, int sg, bool mm, bool gates_on) {
+        constexpr int GM = decltype(GMc)::value, GG = decltype(GGc)::value;
+        const _Float16* zr = z + (GM * 2 + (sm & 1)) * 2 * SEQ * ZLD + sq * ZLD + 8 * kq;
+#ifdef NIR_PT_TRACE
+        unsigned long long tq0, tq1, tq2, tq3;
+        PT_T(tq0);
+#endif
+        if (mm) take_rows(GM);
+#ifdef NIR_PT_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PT_T(tq1);
+#endif
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (mm) {
+                const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+                const f16x8 h2 = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h1, acc[GM][t], 0, 0, 0);
+                    acx[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h2, acx[GM][t], 0, 0, 0);
+                    acx[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], h1, acx[GM][t], 0, 0, 0);
+                }
+            }
+            if (mm && kb == 0) request_rows(GM, sm + 1);      // the slot's reads above are complete: the first MFMAs consumed them
+#ifdef NIR_X_NOGATES
+            if (gates_on) hn[kb] = (acx[GG][kb][0] + acc[GG][kb][1]) * 1e-3f;
+#else
+            if (gates_on) lstm_cell_v(acx[GG][kb] * ISC + acc[GG][kb], creg[GG][kb], hn[kb]);      // tile kb of the resting group
+#endif
+            if (mm && gates_on) {
+#pragma unroll
+                for (int q = 0; q < 3 * NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            }
+        }
+#ifdef NIR_PT_TRACE
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[GM][t]), "+v"(acx[GM][t]));
+        PT_T(tq2);
+#endif
+        if (gates_on) finish(GGc, sg);
+        else __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs[0], OOB, 0, 0);      // (dropped) keeps the queue pattern of every phase
+#ifdef NIR_PT_TRACE
+        PT_T(tq3);
+        tr[0] += tq1 - tq0; tr[1] += tq2 - tq1; tr[2] += tq3 - tq2;
+#endif
+        lds_barrier();
+#ifdef NIR_PT_TRACE
+        { unsigned long long tn; PT_T(tn); tr[3] += tn - tq3; }
+#endif
+    };
+    request_rows(0, 0);
+    request_rows(1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    using G0 = std::integral_constant<int, 0>;
+    using G1 = std::integral_constant<int, 1>;
+    for (int step = 0; step < tmax; ++step) {
+        phase(G0{}, G1{}, step, step - 1, true, step > 0);      // MFMA A(step)  || finish B(step-1)
+        phase(G1{}, G0{}, step, step, true, true);              // MFMA B(step)  || finish A(step)
+    }
+    if (tmax > 0) phase(G0{}, G1{}, tmax, tmax - 1, false, true);   // the last step of B
+#ifdef NIR_PT_TRACE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && g_pt_trace_dev) {
+        unsigned long long* o = g_pt_trace_dev + wave * 8;
+        o[0] = tr[1]; o[1] = tr[2]; o[2] = tr[3]; o[3] = tr[0] + tr[1] + tr[2] + tr[3]; o[4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11));
+        o[5] = 2 * tmax; o[6] = tr[0]; o[7] = 0;
+    }
+#endif
+    // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced
+    for (int s_ = 0; s_ < nvalid; ++s_) {
+        float* orow = p.out + (m0 + s_) * T * OW + (int64_t)dir * H;
+        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
+            for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = 0.f;
+    }
+}
+
+static int launch_pt_h2x2(const LstmPtArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)(2 * 4 * 16 * (32 * 4 + 8)) * 2 + (2 * 16 + 16) * 4 + (size_t)((2 * 16 * (p.T + 3) + 3) & ~3) * 4 + (size_t)2 * 8 * 4 * 64 * 16;
+    ProfScope ps(prof_shape_name("lstm16_pt_h2x2_kernel", (long long)p.M, p.T, p.H), st);
+    static bool attr = [] {
+        return hipFuncSetAttribute((const void*)lstm16_pt_h2x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
+    }();
+    (void)attr;
+#ifdef NIR_PT_TRACE
+    { unsigned long long* d = g_debug_buf; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pt_trace_dev), &d, sizeof(d), 0, hipMemcpyHostToDevice, st); }
+#endif
+    hipLaunchKernelGGL(lstm16_pt_h2x2_kernel, dim3((unsigned)((p.M + 31) / 32), (unsigned)p.ND), dim3(512), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2, two groups]");
+    return 0;
+}
+
 template <int KB, int NT, int NW = 16>
 static int launch_pt_h2(const LstmPtArgs& p, hipStream_t st) {
     static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + ">";
@@ -855,7 +1110,13 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
         }
         if (KB == 3) return launch_pt_h2<3, 2>(p, st);
         // H in (96, 128]: 8 waves x 4 tiles with the in-wave pipeline (tunable lstm_w16 = 1: the 16-wave x 2-tile form)
-        return tun(g_tun.lstm_w16) ? launch_pt_h2<4, 2>(p, st) : launch_pt_h2<4, 4, 8>(p, st);
+        if (tun(g_tun.lstm_w16) == 1) return launch_pt_h2<4, 2>(p, st);
+        // two sequence groups per workgroup: opt-in only (tunable lstm_w16 = 3).  Measured (round 3, tools/recur_micro.py): per group and step
+        // 1.75 us against 1.85 us of the single-group form at equal occupancy -- the gate math does NOT disappear under the other group's
+        // MFMAs (skeleton without gate math: 1.31 vs 1.48 us; the gate math adds 0.4 us to either) -- and with half as many workgroups the
+        // C3 macro-batch (280 of them on 256 CUs) loses a whole round: 433 us against 368 us.
+        if (H == 128 && p.T + 3 <= 1024 && tun(g_tun.lstm_w16) == 3) return launch_pt_h2x2(p, st);
+        return launch_pt_h2<4, 4, 8>(p, st);
     }
     const int G = (H + 15) / 16;
     if (H <= 64) {
