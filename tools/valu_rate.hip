@@ -71,5 +71,20 @@ int main() {
         hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
         printf("%d wave(s)/SIMD  %-28s %.2f s_memtime ticks per instruction (per wave)\n", waves, names[m], (double)h / (iters * REP));
     }
+    // whole-chip MFMA rate under sustained load (the clock the matrix pipe really runs at): 2048 workgroups x 4 waves of independent MFMAs
+    {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int iters = 4000;
+        hipLaunchKernelGGL(probe<4>, dim3(2048), dim3(256), 0, 0, d, sink, 200);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(probe<4>, dim3(2048), dim3(256), 0, 0, d, sink, iters);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h = 0; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+        const double flops = 2048.0 * 4 * iters * REP * 16384.0;
+        printf("sustained v_mfma_f32_16x16x32_f16, whole chip: %.1f TFLOP/s (%.2f ms); block 0: %.2f ticks per MFMA, %.3f ticks per ns\n",
+               flops / (ms * 1e-3) / 1e12, ms, (double)h / (iters * (double)REP), (double)h / (ms * 1e6) * (2048.0 / 2048.0));
+    }
     return 0;
 }
