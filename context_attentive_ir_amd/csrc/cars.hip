@@ -22,7 +22,7 @@ constexpr int ACT_MAXOUT2 = 16;
 constexpr int ACT_TANH_ROWDOT16 = 17;
 constexpr int ACT_BOUNDED = 0x100;      // operands bounded by 2^15: the split-precision GEMM may use its fp16 two-term form
 int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
-                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st, int out_f16 = 0);
+                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st, int out_f16 = 0, const void* whh_frag = nullptr);
 int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, float* out, int64_t M, int K, int act,
                   hipStream_t st);
 int launch_bilstm(const float* gin, const int64_t* lens, const float* whh, const float* h0, const float* c0,
@@ -201,7 +201,7 @@ extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, i
     // bf16 encoder whose per-token states stay inside this call and go to the attention pipeline: they travel as fp16 (the pipeline
     // takes single fp16 terms from a bf16 encoder anyway) -- half the bytes written by the recurrence and read by the pooling
     const bool enc16 = fused_attn && dtype == NIR_DTYPE_BF16 && !encoded && H > 64 && attn_pool_pipe_selected(M, T);
-    NIR_PROPAGATE(launch_bilstm_folded(folded, dtype, ids, lens, w->whh, enc, err_flag, M, V, T, H, 2, st, enc16));
+    NIR_PROPAGATE(launch_bilstm_folded(folded, dtype, ids, lens, w->whh, enc, err_flag, M, V, T, H, 2, st, enc16, dtype == NIR_DTYPE_F32 ? w->whh_frag : nullptr));
     // enc = o * tanh(c) lies in (-1,1); the attention weights are bounded (checked by the host when it packs them)
     if (fused_attn)
         return launch_attn_pool_fused(enc, w->attn_frag, w->attn0_b, w->attn3_w, w->attn3_b, lens, M, T, pooled, dtype == NIR_DTYPE_BF16, st, enc16);

@@ -69,6 +69,7 @@ struct LstmPtArgs {
     int64_t M, V;
     int T, H, ND;
     int out_f16;            // bf16-table kernels only: `out` is [M,T,ND*H] fp16
+    const void* whh_frag;   // optional: W_hh pre-split into the two fp16 terms, in the lane order of lstm16_pt_h2_kernel<4,4,8> (nir_lstm_pack_whh_frag)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -485,6 +486,21 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
     const int OW = p.ND * H;
     const int64_t GW = (int64_t)p.ND * H4;
+    f16x8 w1[NT][KB], w2[NT][KB];
+    const bool use_frag = KB == 4 && NT == 4 && NW == 8 && p.whh_frag != nullptr && H == 128;   // wave-uniform
+    if (use_frag) {
+        // W_hh arrives pre-split in this kernel's lane order (packed once per weight version): 32 independent 16-byte loads per lane, no
+        // conversion arithmetic (the in-kernel split below costs ~1 000 VALU instructions per wave and workgroup), requested before anything
+        // else so that their round trip runs under the id staging (the barriers of the prologue are LDS-only: no vmcnt wait)
+        const f16x8* fp = reinterpret_cast<const f16x8*>(p.whh_frag) + ((size_t)(dir * NW + wave) * NT * KB * 2) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                w1[t][kb] = fp[((t * KB + kb) * 2 + 0) * 64];
+                w2[t][kb] = fp[((t * KB + kb) * 2 + 1) * 64];
+            }
+    }
     if (NW > 4 && lane == 0) simd_s[wave] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));   // HW_REG_HW_ID bits [5:4] = SIMD_ID
     if (tid < SEQ) {
         int l = 0;
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         }
         lens_s[tid] = l;
     }
-    __syncthreads();
+    lds_barrier();
     {
         // ids_s[s][k] = the id sequence s consumes at STEP k (reverse direction: from its last valid token down; past its end the last
         // valid id repeats -- those gate rows feed nothing that is stored): the loop's lookup is one LDS read at base + 4 * step.
@@ -520,7 +536,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         if (bad && p.err) atomicOr(p.err, 1);
     }
     for (int e = tid; e < 2 * SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;   // 4*SEQ*ZLD halves
-    __syncthreads();
+    lds_barrier();
     int tmax = 0;
 #pragma unroll
     for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
@@ -544,7 +560,6 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     // Unit mapping: lane (sq, kq) of wave w owns the NT CONSECUTIVE units u0 .. u0 + NT - 1, u0 = NT * (4 w + kq), of sequence sq -- tile t of
     // the wave holds unit u0 + t of each of its four unit groups (A rows 4 g + gate <-> unit NT * (4 w + g) + t).  The lane's output is then
     // one 4 NT-byte store, its h terms one 2 NT-byte LDS write each, its gate rows one 16 NT-byte piece of the folded row.
-    f16x8 w1[NT][KB], w2[NT][KB];
     float creg[NT];
     const int u0 = NT * (4 * wave + kq);
     // wave-uniform: a wave whose units are all past H skips the step's work (H = 70 on 16 waves x 2 tiles: 7 of 16).  Not in the pipelined form:
@@ -554,6 +569,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     bool wbad = false;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        if (use_frag) { creg[t] = 0.f; continue; }
         const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
         const bool av = unit_a < H;
         const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0)) * H;
@@ -1080,8 +1096,32 @@ static int launch_pt_bf16(const LstmPtArgs& p, hipStream_t st) {
     return 0;
 }
 
+// W_hh as the two fp16 terms of the split, in the lane order of lstm16_pt_h2_kernel<4,4,8>: [ND][8 waves][4 tiles][4 k-blocks][2 terms][64 lanes][8]
+__global__ __launch_bounds__(64) void lstm_whh_frag_kernel(const float* __restrict__ whh, int H, _Float16* __restrict__ out, int* __restrict__ err) {
+    constexpr int NT = 4, KB = 4, NW = 8;
+    const int lane = threadIdx.x, wave = blockIdx.x, dir = blockIdx.y;
+    const int sq = lane & 15, kq = lane >> 4;
+    bool bad = false;
+    for (int t = 0; t < NT; ++t) {
+        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
+        const float* wr = whh + ((int64_t)dir * 4 * H + (int64_t)gate_a * H + unit_a) * H;
+        for (int kb = 0; kb < KB; ++kb) {
+            _Float16* o1 = out + ((((size_t)(dir * NW + wave) * NT + t) * KB + kb) * 2 * 64 + lane) * 8;
+            _Float16* o2 = o1 + 64 * 8;
+            for (int j = 0; j < 8; ++j) {
+                const float w = wr[32 * kb + 8 * kq + j];
+                const _Float16 hi = (_Float16)w;
+                o1[j] = hi;
+                o2[j] = (_Float16)((w - (float)hi) * 2048.0f);
+                bad |= !(fabsf(w) < 32768.0f);
+            }
+        }
+    }
+    if (bad && err) atomicOr(err, 2);
+}
+
 int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
-                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st, int out_f16) {
+                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st, int out_f16, const void* whh_frag) {
     NIR_REQUIRE(pt && ids && whh && out, "bilstm_folded: null pointer");
     NIR_REQUIRE(M >= 0 && V > 0 && T > 0 && (ND == 1 || ND == 2), "bilstm_folded: bad dims");
     NIR_REQUIRE(H >= 4 && H <= 128, "bilstm_folded: hidden size %d per direction unsupported (4..128)", H);
@@ -1090,7 +1130,7 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     NIR_REQUIRE(pt_dtype == NIR_DTYPE_F32 || pt_dtype == NIR_DTYPE_BF16, "bilstm_folded: unknown table dtype %d", pt_dtype);
     if (M == 0) return 0;
     NIR_REQUIRE(!out_f16 || (pt_dtype == NIR_DTYPE_BF16 && H > 64 && H % 2 == 0), "bilstm_folded: fp16 output needs the bf16 table and an even H > 64");
-    LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND, out_f16};
+    LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND, out_f16, whh_frag};
     if (pt_dtype == NIR_DTYPE_BF16) {
         const int KB = (H + 31) / 32;
         if (H <= 64) return KB == 1 ? launch_pt_bf16<1, 1>(p, st) : launch_pt_bf16<2, 1>(p, st);
@@ -1187,5 +1227,17 @@ extern "C" int nir_lstm_fold_table(const float* table, int64_t V, int E, const f
 
 extern "C" int nir_bilstm_folded_fwd(const void* folded, int dtype, const int64_t* ids, const int64_t* lengths, const float* w_hh,
                                      float* out, int* err_flag, int64_t M, int64_t V, int T, int H, int ndir, nir_stream_t stream) {
-    return nir::launch_bilstm_folded(folded, dtype, ids, lengths, w_hh, out, err_flag, M, V, T, H, ndir, (hipStream_t)stream, 0);
+    return nir::launch_bilstm_folded(folded, dtype, ids, lengths, w_hh, out, err_flag, M, V, T, H, ndir, (hipStream_t)stream, 0, nullptr);
+}
+
+extern "C" size_t nir_lstm_whh_frag_bytes(int H, int ndir) {
+    return (H == 128 && (ndir == 1 || ndir == 2)) ? (size_t)ndir * 8 * 4 * 4 * 2 * 64 * 8 * sizeof(_Float16) : 0;
+}
+extern "C" int nir_lstm_pack_whh_frag(const float* w_hh, int H, int ndir, void* frag, int* err_flag, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(w_hh && frag, "lstm_pack_whh_frag: null pointer");
+    NIR_REQUIRE(nir_lstm_whh_frag_bytes(H, ndir) != 0, "lstm_pack_whh_frag: only the H = 128 recurrence takes pre-split fragments (got H = %d)", H);
+    hipLaunchKernelGGL(lstm_whh_frag_kernel, dim3(8, (unsigned)ndir), dim3(64), 0, (hipStream_t)stream, w_hh, H, (_Float16*)frag, err_flag);
+    NIR_CHECK_LAUNCH("nir_lstm_pack_whh_frag");
+    return 0;
 }

@@ -23,7 +23,7 @@ int launch_bilstm_fused(const float* x, int I, const float* wih, const float* bi
                         int T, int H, int ND, hipStream_t st);
 
 int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
-                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st, int out_f16 = 0);
+                         int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st, int out_f16 = 0, const void* whh_frag = nullptr);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -42,7 +42,8 @@ DuetWeights = type("nir_duet_weights", (C.Structure,), {"_fields_": list(DuetWei
 CarsEncoderWeights = _struct(
     "nir_cars_encoder_weights",
     ["wih", "whh", "bih", "bhh", "attn0_w", "attn0_b", "attn3_w", "attn3_b"], ["H", "bounded"])
-CarsEncoderWeights = type("nir_cars_encoder_weights", (C.Structure,), {"_fields_": list(CarsEncoderWeights._fields_) + [("attn_frag", C.c_void_p)]})
+CarsEncoderWeights = type("nir_cars_encoder_weights", (C.Structure,), {"_fields_": list(CarsEncoderWeights._fields_) + [("attn_frag", C.c_void_p),
+                                                                                                   ("whh_frag", C.c_void_p)]})
 CarsSessionWeights = _struct(
     "nir_cars_session_weights",
     ["click0_w", "click0_b", "click3_w", "click3_b", "sq_attn_w", "sq_attn_b", "sd_attn_w", "sd_attn_b",
@@ -114,6 +115,8 @@ SIGNATURES = {
     "nir_cars_encode_workspace_bytes": (_z, [_l, _i, _i, C.POINTER(CarsEncoderWeights)]),
     "nir_cars_encode": (_i, [c_ip, c_ip, _l, _i, c_fp, _l, _i, C.POINTER(CarsEncoderWeights), C.c_void_p, _z,
                              c_fp, c_fp, c_st]),
+    "nir_lstm_whh_frag_bytes": (_z, [_i, _i]),
+    "nir_lstm_pack_whh_frag": (_i, [c_fp, _i, _i, C.c_void_p, C.c_void_p, c_st]),
     "nir_lstm_fold_table_bytes": (_z, [_l, _i, _i, _i]),
     "nir_lstm_fold_table_workspace_bytes": (_z, [_l, _i, _i, _i, _i]),
     "nir_lstm_fold_table": (_i, [c_fp, _l, _i, c_fp, c_fp, c_fp, _i, _i, C.c_void_p, _i, C.c_void_p, _z, c_st]),

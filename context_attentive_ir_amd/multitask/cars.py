@@ -147,6 +147,13 @@ class CARS(nn.Module, lib.IdCheck):
             # the folded recurrences run W_hh on the fp16 matrix cores (two-term split / single term): outside that range the encoder
             # takes the per-batch fp32 path (one check per weight version)
             pk.rec_ok = float(whh.detach().abs().max()) < 32768.0
+            L = lib.load()
+            nb = L.nir_lstm_whh_frag_bytes(enc.hidden, 2)
+            if nb and pk.rec_ok and whh.is_cuda:     # W_hh pre-split in the lane order of the folded fp32 recurrence (once per weight version)
+                pk.keep["whh_frag"] = torch.empty(nb, dtype=torch.uint8, device=whh.device)
+                lib.check(L.nir_lstm_pack_whh_frag(lib.ptr(pk.keep["whh"]), enc.hidden, 2, lib.ptr(pk.keep["whh_frag"]), None, lib.stream()),
+                          "nir_lstm_pack_whh_frag")
+                pk.struct.whh_frag = pk.keep["whh_frag"].data_ptr()
             if bounded and 2 * enc.hidden == 256 and self.fuse_attention_pooling and attn[0].weight.is_cuda:
                 # operand of the fused attention-pooling kernel (csrc/cars_attn.hip): attn0_w as two fp16 term planes in MFMA-fragment
                 # order [K/32][16 column tiles][2 terms][64 lanes][8], built once per weight version

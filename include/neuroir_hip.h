@@ -273,6 +273,8 @@ typedef struct {
                                             (nir_split_f16x2) in MFMA-fragment order [K/32][16 column tiles][2 terms][64 lanes][8], lane =
                                             16*(k%32/8) + column%16 -- operand of the fused attention-pooling kernel (csrc/cars_attn.hip),
                                             used when `bounded` and T is 4, 8, 16, 32 or 64 */
+    const void* whh_frag;                /* optional (NULL: split inside the kernel's prologue): whh as the two fp16 terms of the folded fp32
+                                            recurrence in its lane order (nir_lstm_pack_whh_frag; H = 128 only) */
 } nir_cars_encoder_weights;
 size_t nir_cars_encode_workspace_bytes(int64_t M, int T, int E, const nir_cars_encoder_weights* w /*host*/);
 /* CARS.encode / CARS.encode_document (cars.py:193-260): ids [M,T], lens [M] -> pooled [M,2H];
@@ -292,6 +294,12 @@ size_t nir_lstm_fold_table_bytes(int64_t V, int H, int ndir, int dtype);
 size_t nir_lstm_fold_table_workspace_bytes(int64_t V, int E, int H, int ndir, int dtype);
 int nir_lstm_fold_table(const float* table, int64_t V, int E, const float* w_ih, const float* b_ih, const float* b_hh, int H,
                         int ndir, void* folded, int dtype, void* workspace, size_t workspace_bytes, nir_stream_t stream);
+/* Optional operand of the H = 128 fp32 folded recurrence: w_hh [ndir,4H,H] pre-split into its two fp16 terms in the kernel's lane order
+ * ([ndir][8 waves][4 tiles][4 k-blocks][2 terms][64 lanes][8]); packed once per weight version, it replaces ~1 000 conversion instructions
+ * per wave in the prologue of every recurrence workgroup.  nir_lstm_whh_frag_bytes = 0: the size has no fragment form.  |w| >= 2^15 sets
+ * bit 1 of *err_flag (as the in-kernel split does). */
+size_t nir_lstm_whh_frag_bytes(int H, int ndir);
+int nir_lstm_pack_whh_frag(const float* w_hh, int H, int ndir, void* frag, int* err_flag, nir_stream_t stream);
 /* BiLSTM over a folded table: ids [M,T] int64, lengths [M] (or NULL), w_hh [ndir,4H,H] fp32 -> out [M,T,ndir*H] fp32, zero at
  * t >= length.  dtype F32: fp32-accurate recurrence (two-term fp16 split on v_mfma_f32_16x16x32_f16 for H >= 32, exact
  * v_mfma_f32_16x16x4_f32 below / with the exact_f32 tunable; the parity path).  dtype BF16: bf16 folded table, W_hh and h_t as
