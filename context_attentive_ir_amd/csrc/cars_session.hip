@@ -25,6 +25,7 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
                      int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
                      int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st);
 constexpr int ACT_MAXOUT2 = 16;
+constexpr int ACT_BOUNDED = 0x100;      // (gemm.hip) operands bounded by 2^15: the split-precision GEMM may use its fp16 two-term form
 constexpr int ACT_TANH_ROWDOT16 = 17;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -570,7 +571,7 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
     // ---- encode_clicks (cars.py:262-304)
     if (d_on) {
         NIR_PROPAGATE(launch_linear_ex(pooled_docs, D, nullptr, nullptr, 0, 0, 0, w->click0_w, D, w->click0_b, nullptr, p.epart, NP, R, D, D,
-                                       ACT_TANH_ROWDOT16, w->click3_w, 0, st));
+                                       ACT_TANH_ROWDOT16 | ((w->rank_bounded & 4) ? ACT_BOUNDED : 0), w->click3_w, 0, st));
         {
             ProfScope ps("click_pool2_kernel", st);
             const float* lall = labels_all ? labels_all : labels;
@@ -632,8 +633,10 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
         }
         NIR_CHECK_LAUNCH("rank_feats_kernel");
         // maxout 1024 -> 256 -> 128 -> 1 (pool 2): the pairwise max is fused into the GEMM epilogues
-        NIR_PROPAGATE(launch_linear_ex(p.feats, 4 * D, nullptr, nullptr, 0, 0, 0, w->mo0_w, 4 * D, w->mo0_b, nullptr, p.y0, 256, Rr, 512, 4 * D, ACT_MAXOUT2, nullptr, 0, st));
-        NIR_PROPAGATE(launch_linear_ex(p.y0, 256, nullptr, nullptr, 0, 0, 0, w->mo1_w, 256, w->mo1_b, nullptr, p.y1, 128, Rr, 256, 256, ACT_MAXOUT2, nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear_ex(p.feats, 4 * D, nullptr, nullptr, 0, 0, 0, w->mo0_w, 4 * D, w->mo0_b, nullptr, p.y0, 256, Rr, 512, 4 * D,
+                                       ACT_MAXOUT2 | ((w->rank_bounded & 1) ? ACT_BOUNDED : 0), nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear_ex(p.y0, 256, nullptr, nullptr, 0, 0, 0, w->mo1_w, 256, w->mo1_b, nullptr, p.y1, 128, Rr, 256, 256,
+                                       ACT_MAXOUT2 | ((w->rank_bounded & 2) ? ACT_BOUNDED : 0), nullptr, 0, st));
         NIR_PROPAGATE(launch_linear_ex(p.y1, 128, nullptr, nullptr, 0, 0, 0, w->mo2_w, 128, w->mo2_b, nullptr, click_scores, 1, Rr, 2, 128, ACT_MAXOUT2, nullptr, 0, st));
     }
     if (want_states) {

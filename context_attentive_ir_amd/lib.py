@@ -51,7 +51,7 @@ CarsSessionWeights = _struct(
      "shared_w", "priv1_w", "mo0_w", "mo0_b", "mo1_w", "mo1_b", "mo2_w", "mo2_b", "wrank", "attn_ut",
      "sq_inner0_w", "sq_inner0_b", "sq_inner3_w", "sq_inner3_b", "sd_inner0_w", "sd_inner0_b", "sd_inner3_w", "sd_inner3_b",
      "th_w", "th_b", "tc_w", "tc_b"],
-    ["D", "HS", "HDEC", "q_on", "d_on", "rank_on"])
+    ["D", "HS", "HDEC", "q_on", "d_on", "rank_on", "rank_bounded"])
 class CarsDecoderWeights(C.Structure):
     _fields_ = [(f, c_fp) for f in ("rnn_wih", "rnn_whh", "rnn_bih", "rnn_bhh", "attn_in_w", "attn_out_w", "dec_attn_w", "pred1_w",
                                     "pred2_w", "sess_w")] + [(f, C.c_int) for f in ("HD", "DQ", "P", "KS")] + [("VT", C.c_int64), ("pred2_frag", C.c_void_p)]

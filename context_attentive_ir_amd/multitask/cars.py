@@ -209,6 +209,17 @@ class CARS(nn.Module, lib.IdCheck):
                           "nir_cars_session_pack")
                 pk.struct.wrank = pk.keep["wrank"].data_ptr()
                 pk.struct.attn_ut = pk.keep["attn_ut"].data_ptr()
+                # rank features [q', d, |q' - d|, q' d]: d and the inputs of q' are pooled encoder / session states in (-1, 1), so
+                # |q'| <= max_row(sum |W_rank| + |b|); with that and the layer's weights below 2^15 the first maxout GEMM takes the fp16
+                # two-term split (one check per weight version)
+                D_ = self._dims["D"]
+                kr = na.value // D_ if D_ else 0
+                qb = float((pk.keep["wrank"][:D_ * kr].view(D_, kr).abs().sum(1) + pk.keep["qproj_b"].abs()).max()) if kr else 0.0
+                b0 = int(qb + 1.0 < 32768.0 and float(pk.keep["mo0_w"].abs().max()) < 32768.0)
+                y0 = (qb + 1.0) * float(pk.keep["mo0_w"].abs().sum(1).max()) + float(pk.keep["mo0_b"].abs().max())     # bound of layer 0's outputs
+                b1 = int(b0 and y0 < 32768.0 and float(pk.keep["mo1_w"].abs().max()) < 32768.0)
+                b2 = int("click0_w" in pk.keep and float(pk.keep["click0_w"].abs().max()) < 32768.0)
+                pk.struct.rank_bounded = b0 | (b1 << 1) | (b2 << 2)
             return pk
         return self._ps.get([p for m in self._session_modules() for p in m.parameters()], build)
 

@@ -335,6 +335,12 @@ typedef struct {
     const float *th_w, *th_b, *tc_w, *tc_b;                 /* transform_hid / transform_cell .linear [HDEC, nch*HS],[HDEC] */
     int D, HS, HDEC;                                        /* 256, 512, 512 */
     int q_on, d_on, rank_on;                                /* !query_session_off, !doc_session_off, !turn_ranker_off (cars.py:185-188) */
+    int rank_bounded;                                       /* bit 0, host-checked: |ranknet layer 0 weights| < 2^15 and the rank features are too -- the
+                                                               projected query is bounded by max_row(sum |[W_q | W_shared + W_priv1]| + |b|) because
+                                                               its inputs (pooled states) lie in (-1,1) -- so the first maxout GEMM may use the fp16
+                                                               two-term split (3 MFMAs per product instead of the range-safe 6); bit 1: the same for
+                                                               layer 1 (its inputs are bounded by |features| * max_row(sum |W_0|) + |b_0|); bit 2:
+                                                               |click_attn.0 weights| < 2^15 (its inputs are pooled documents in (-1,1)) */
 } nir_cars_session_weights;
 /* Optional suggestion-side outputs of the session loop (cars.py:382-456); any pointer may be NULL. */
 typedef struct {
