@@ -101,6 +101,25 @@ def linear(x, weight, bias=None, act=None):
     return _Linear.apply(x, weight, bias, ACT[act])
 
 
+_ID_FLAGS = {}
+
+
+def id_flag(device):
+    """device int32 flag the train-mode lookups set for an id outside [0, V) (the reference's nn.Embedding raises IndexError)"""
+    f = _ID_FLAGS.get(str(device))
+    if f is None:
+        f = _ID_FLAGS[str(device)] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
+
+
+def check_ids():
+    """Synchronising: raise IndexError if a train-mode lookup since the last check saw an id outside the vocabulary."""
+    for f in _ID_FLAGS.values():
+        if int(f.item()) != 0:
+            f.zero_()
+            raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
+
+
 class _Embed(Function):
     @staticmethod
     def forward(ctx, ids, table, pad_idx):
@@ -110,7 +129,8 @@ class _Embed(Function):
         V, E = table.shape
         out = torch.empty(flat.numel(), E, device=table.device, dtype=torch.float32)
         tc = _f32c(table)
-        lib.check(L.nir_embed_f32(lib.ptr(flat), lib.ptr(tc), V, E, flat.numel(), lib.ptr(out), None, lib.stream()), "nir_embed_f32")
+        lib.check(L.nir_embed_f32(lib.ptr(flat), lib.ptr(tc), V, E, flat.numel(), lib.ptr(out), lib.ptr(id_flag(table.device)), lib.stream()),
+                  "nir_embed_f32")
         ctx.save_for_backward(flat)
         ctx.dims, ctx.pad = (V, E), pad_idx
         return out.view(*ids.shape, E)

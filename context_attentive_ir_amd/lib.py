@@ -233,8 +233,12 @@ class PackCache(object):
     """
     RETAIN = 8
 
-    def __init__(self):
+    def __init__(self, retain=None):
+        """retain: superseded packs kept alive (default RETAIN); the folded [V, 8H] tables pass 1 -- alternating train and eval would
+        otherwise pin eight dead multi-hundred-MB tables; a graph captured over an older table must be re-captured after training anyway."""
         self.key, self.val, self.retired = None, None, []
+        if retain is not None:
+            self.RETAIN = int(retain)
 
     def invalidate(self):
         self.key = None
@@ -243,7 +247,7 @@ class PackCache(object):
         key = tuple((p.data_ptr(), p._version, str(p.device)) if torch.is_tensor(p) else p for p in params)
         if key != self.key:
             if self.val is not None:
-                self.retired = (self.retired + [self.val])[-self.RETAIN:]
+                self.retired = (self.retired + [self.val])[-self.RETAIN:] if self.RETAIN > 0 else []
             self.val, self.key = builder(), key
         return self.val
 

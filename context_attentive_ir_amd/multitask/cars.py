@@ -128,7 +128,7 @@ class CARS(nn.Module, lib.IdCheck):
         self.fuse_decoder_argmax = True      # decode: 256 -> V_tgt projection + arg-max as one kernel, no [Bd, V_tgt] logits
         self.fold_budget_bytes = 64 << 30
         self.compute_dtype = getattr(args, "compute_dtype", "f32")
-        self._fq, self._fd = lib.PackCache(), lib.PackCache()
+        self._fq, self._fd = lib.PackCache(retain=1), lib.PackCache(retain=1)
         self._err_flag = None
 
     # ---- weight packing -------------------------------------------------------------------------

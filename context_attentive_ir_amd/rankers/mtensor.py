@@ -102,7 +102,7 @@ class MatchTensor(nn.Module, lib.IdCheck):
         self._pack = lib.PackCache()
         # eval mode: fold embedding -> Linear(E->F) -> LSTM input projection into one table per encoder (csrc/lstm_fold.hip)
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
-        self._fold = lib.PackCache()
+        self._fold = lib.PackCache(retain=1)
         self._err_flag = None
 
     def _folded_tables(self, w):

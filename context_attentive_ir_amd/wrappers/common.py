@@ -12,6 +12,27 @@ logger = logging.getLogger(__name__)
 
 class WrapperBase(object):
     optimizer = None
+    # Token ids are validated on the device without a host round trip (invalid ids are read as PAD and a flag is set).  The reference's
+    # nn.Embedding raises IndexError at the offending call; the wrappers read the flag back after every `id_check_interval`-th
+    # predict() / update() (1 = the reference's behaviour, at the price of one synchronisation per call; 0 = never: the caller calls
+    # check_ids() itself, e.g. once per epoch).  Never inside a hipGraph capture.
+    id_check_interval = 1
+    _id_calls = 0
+
+    def check_ids(self):
+        """Synchronising: raise IndexError / RuntimeError if a forward since the last check saw an invalid id or out-of-range weights."""
+        from .. import autograd as A
+        if hasattr(self.network, "check_ids"):
+            self.network.check_ids()
+        A.check_ids()
+
+    def _maybe_check_ids(self):
+        if self.id_check_interval <= 0 or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            return
+        self._id_calls += 1
+        if self._id_calls >= self.id_check_interval:
+            self._id_calls = 0
+            self.check_ids()
 
     # the module whose `.word_vec_size / .init_word_vectors / .parameters()` the drivers use
     def _word_embeddings(self):

@@ -211,6 +211,7 @@ class Multitask(WrapperBase):
                                       batch_size=B, session_len=S - 1, use_cuda=self.use_cuda, encoded_source=enc[0], source_len=enc[1],
                                       session_attns=attns)
             out["predictions"] = dec["predictions"]
+        self._maybe_check_ids()
         return out
 
     def update(self, ex):
@@ -221,6 +222,7 @@ class Multitask(WrapperBase):
         self.optimizer.zero_grad()
         loss = self._update_body(ex)
         self.updates += 1
+        self._maybe_check_ids()
         return loss
 
     def _update_body(self, ex):

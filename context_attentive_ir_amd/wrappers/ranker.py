@@ -65,6 +65,7 @@ class Ranker(WrapperBase):
         out = torch.empty_like(s)
         lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()),
                   "nir_softmax_rows")
+        self._maybe_check_ids()
         return out
 
     @torch.no_grad()
@@ -106,6 +107,7 @@ class Ranker(WrapperBase):
         self.optimizer.zero_grad()
         loss = self._update_body(ex)
         self.updates += 1
+        self._maybe_check_ids()
         return loss
 
     def _update_body(self, ex):

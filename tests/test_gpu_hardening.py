@@ -217,3 +217,29 @@ def test_drmm_exact_match_policies_on_overlapping_zipf_ids():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         json.dump(rep, open(os.path.join(out, "drmm_overlap_r03.json"), "w"), indent=1)
+
+
+def test_wrappers_raise_indexerror_for_out_of_vocabulary_ids():
+    """The reference's nn.Embedding raises IndexError at the offending call; the wrappers read the device flag back after predict / update
+    (WrapperBase.id_check_interval = 1), in eval (folded kernels: in-kernel check) and in train mode (autograd.embed)."""
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import Ranker
+    V = 200
+    w = Ranker(default_args("MATCH_TENSOR", src_vocab_size=V, optimizer="sgd", learning_rate=0.01, weight_decay=0, momentum=0, grad_clipping=10.0,
+                            fix_embeddings=True))
+    fill_module_(w.network, 3)
+    w.cuda()
+    w.init_optimizer()
+    rng = np.random.default_rng(1)
+    q = torch.from_numpy(rng.integers(4, V, size=(2, 5))); d = torch.from_numpy(rng.integers(4, V, size=(2, 3, 12)))
+    ex = {"que_rep": q, "que_len": torch.full((2,), 5), "doc_rep": d, "doc_len": torch.full((2, 3), 12), "label": torch.zeros(2, 3)}
+    assert torch.isfinite(w.predict(ex)).all()
+    bad = dict(ex, doc_rep=d.clone())
+    bad["doc_rep"][1, 2, 7] = V + 5
+    with pytest.raises(IndexError):
+        w.predict(bad)
+    assert torch.isfinite(w.predict(ex)).all()                 # the flag was cleared
+    with pytest.raises(IndexError):
+        w.update(bad)
+    w.update(ex)
