@@ -1083,6 +1083,226 @@ static int cu_count() {
     return ncu;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 recurrence, H in (96, 128], as 8 waves x 4 tiles in 128 VGPRs: TWO workgroups per CU.  A single term of W_hh is 64 registers per
+// lane, so unlike the fp32-parity kernel two workgroups fit a CU's register file -- and this recurrence needs exactly that: its step is a
+// latency chain (barrier -> LDS reads -> 16 MFMAs per wave -> gate math -> LDS write -> barrier) with the matrix pipe 19 % busy; a second
+// workgroup's chain runs in the other one's bubbles.  Same step structure as lstm16_pt_bf16_kernel (gate rows two steps ahead as the MFMA C
+// operand, persistent over sequence tiles, fp16 output rows copied from the LDS h buffer), consecutive-unit lane mapping of
+// lstm16_pt_h2_kernel (8-byte LDS writes, 16-byte fp32 stores), step-ordered id lists, merged-fraction cell.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool O16>
+__global__ __launch_bounds__(512, 4) void lstm16_pt_bf16w8_kernel(LstmPtArgs p) {
+    constexpr int KB = 4, NT = 4, NW = 8, NTH = 64 * NW, SEQ = 16, KP = 32 * KB, ZLD = KP + 8;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* z = reinterpret_cast<unsigned short*>(smem);       // [2][SEQ][ZLD] fp16
+    f16x8* wl = reinterpret_cast<f16x8*>(z + 2 * SEQ * ZLD);            // [8 waves][4 tiles][64 lanes]: the W fragments of the LAST k-block (see below)
+    int* lens_s = reinterpret_cast<int*>(wl + NW * NT * 64);
+    int* ids_s = lens_s + SEQ;                                          // [SEQ][TP]: the id sequence s consumes at step k
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y;
+    const int H = p.H, T = p.T, H4 = 4 * H, TP = p.T + 4;
+    const int OW = p.ND * H;
+    const int64_t GW = (int64_t)p.ND * H4;
+    const int u0 = NT * (4 * wave + kq);
+    const bool full = u0 + NT <= H;
+
+    // W_hh of k-blocks 0..2 lives in registers (48 VGPRs), the fragments of k-block 3 in LDS (32 KB per workgroup, one ds_read_b128 per tile
+    // and step): with all four in registers the loop spills at 128 VGPRs, and 128 is what two workgroups per CU allow
+    f16x8 wreg[NT][KB - 1];
+    bool wbad = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
+        const bool av = unit_a < H;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + (av ? unit_a : 0)) * H;
+        const bool vec_ok = (H % 8) == 0 && ((reinterpret_cast<uintptr_t>(wr) & 15) == 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            float wv[8];
+            const int k0 = 32 * kb + 8 * kq;
+            if (vec_ok) {
+                const int kc = k0 + 8 <= H ? k0 : 0;
+                const float4 a = *reinterpret_cast<const float4*>(wr + kc), b = *reinterpret_cast<const float4*>(wr + kc + 4);
+                const float m = (av && k0 + 8 <= H) ? 1.f : 0.f;
+                wv[0] = a.x * m; wv[1] = a.y * m; wv[2] = a.z * m; wv[3] = a.w * m; wv[4] = b.x * m; wv[5] = b.y * m; wv[6] = b.z * m; wv[7] = b.w * m;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[j] = wr[k0 + j < H ? k0 + j : H - 1] * ((av && k0 + j < H) ? 1.f : 0.f);
+            }
+            f16x8 wf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wf[j] = (_Float16)wv[j];
+                wbad |= !(fabsf(wv[j]) < 65504.0f);
+            }
+            if (kb < KB - 1) wreg[t][kb < KB - 1 ? kb : 0] = wf;
+            else wl[(wave * NT + t) * 64 + lane] = wf;
+        }
+    }
+    if (wbad && p.err) atomicOr(p.err, 2);
+    const f16x8* wlp = wl + wave * NT * 64 + lane;           // (read back by the lane that wrote it: no barrier needed)
+    const unsigned short* pth = reinterpret_cast<const unsigned short*>(p.pt) + (int64_t)dir * H4;
+    // the lane's four units are 32 contiguous bytes of a folded bf16 row (H % 4 == 0: a lane is all real or all past H -- those re-read unit 0)
+    const unsigned short* pb = pth + 4 * (full ? u0 : 0);
+    const uint32_t gw = (uint32_t)GW;
+
+    for (int64_t mt = blockIdx.x; mt * SEQ < p.M; mt += gridDim.x) {
+        __syncthreads();                                 // the previous tile's last readers of lens_s / ids_s / z are done
+        const int64_t m0 = mt * SEQ;
+        const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+        if (tid < SEQ) {
+            int l = 0;
+            if (tid < nvalid) {
+                l = p.lens ? (int)p.lens[m0 + tid] : T;
+                l = l < 0 ? 0 : (l > T ? T : l);
+            }
+            lens_s[tid] = l;
+        }
+        __syncthreads();
+        {
+            bool bad = false;
+            for (int e = tid; e < SEQ * TP; e += NTH) {
+                const int s_ = e / TP, k = e - s_ * TP;
+                int64_t id = 0;
+                if (s_ < nvalid) {
+                    const int l = lens_s[s_];
+                    int kk = k < l - 1 ? k : l - 1;
+                    kk = kk < 0 ? 0 : kk;
+                    int t_ = dir == 0 ? kk : l - 1 - kk;
+                    t_ = t_ < 0 ? 0 : t_;
+                    id = p.ids[(m0 + s_) * T + t_];
+                    if (k < T) {
+                        const int64_t raw = p.ids[(m0 + s_) * T + k];
+                        bad |= raw < 0 || raw >= p.V;
+                    }
+                }
+                if (id < 0 || id >= p.V) id = 0;
+                ids_s[e] = (int)id;
+            }
+            if (bad && p.err) atomicOr(p.err, 1);
+        }
+        for (int e = tid; e < SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;      // both buffers
+        __syncthreads();
+        int tmax = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+        const int mylen = lens_s[sq];
+        float creg[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) creg[t] = 0.f;
+        const __amdgpu_buffer_rsrc_t out_rs =
+            O16 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<_Float16*>(p.out) + m0 * T * OW, 0, (int)((uint32_t)nvalid * T * OW * 2u), 0x00020000)
+                : __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0, (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+        // O16: wave w copies the rows of sequences 2w and 2w+1 of h_{t-1} (lane = two consecutive units) out of the LDS buffer the MFMAs of
+        // step t read: 256 contiguous bytes per row
+        int wlen[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) wlen[r] = __builtin_amdgcn_readfirstlane(lens_s[2 * wave + r]);
+        auto copy_out = [&](int s_, const unsigned short* zsrc) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int sr = 2 * wave + r;
+                const bool on = s_ >= 0 && s_ < wlen[r] && 2 * lane < H;
+                const int tt_ = dir == 0 ? s_ : wlen[r] - 1 - s_;
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(zsrc + sr * ZLD + 2 * lane);
+                __builtin_amdgcn_raw_buffer_store_b32(v, out_rs, on ? (uint32_t)((sr * T + tt_) * OW + dir * H + 2 * lane) * 2u : OOB, 0, 0);
+            }
+        };
+        const int* idp = ids_s + sq * TP;
+        auto load_g = [&](int id, uint4 (&dst)[2]) {
+            const uint4* row = reinterpret_cast<const uint4*>(pb + (uint64_t)(uint32_t)id * gw);
+            dst[0] = row[0];
+            dst[1] = row[1];
+        };
+        uint4 ga[2];                                     // rows of the NEXT step (one step ahead: with two workgroups per CU the other one covers a late row)
+        load_g(idp[0], ga);
+        int id_n = idp[1];
+        float hprev[NT] = {0.f, 0.f, 0.f, 0.f};
+        uint32_t poff = OOB;
+        uint32_t soff = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen - 1)) * OW + dir * H + u0) * 4);
+        const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
+        auto store_prev = [&]() {                        // fp32 output of the previous step, in front of this step's row requests
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(hprev[0]), __float_as_uint(hprev[1]), __float_as_uint(hprev[2]), __float_as_uint(hprev[3])},
+                                                   out_rs, full ? poff : OOB, 0, 0);
+            if (!full) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hprev[t]), out_rs, (u0 + t < H && poff != OOB) ? poff + 4u * t : OOB, 0, 0);
+            }
+        };
+        for (int step = 0; step < tmax; ++step) {
+            const unsigned short* zc = z + (step & 1) * SEQ * ZLD;
+            unsigned short* zn = z + ((step + 1) & 1) * SEQ * ZLD;
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint32_t lo = (t & 1) ? ga[t >> 1].z : ga[t >> 1].x, hi = (t & 1) ? ga[t >> 1].w : ga[t >> 1].y;
+                acc[t] = (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xFFFF0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
+            }
+            const bool live = step < mylen;
+            const unsigned short* zr = zc + sq * ZLD + 8 * kq;
+            if (O16) copy_out(step - 1, zc);
+            else store_prev();
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const f16x8 hb = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb < KB - 1 ? wreg[t][kb < KB - 1 ? kb : 0] : wlp[t * 64], hb, acc[t], 0, 0, 0);
+                if (kb == 0) {
+                    load_g(id_n, ga);
+                    id_n = idp[step + 2];
+                }
+                __builtin_amdgcn_sched_barrier(0);       // one k-block of h fragments live at a time (128 VGPRs; the other waves of the SIMD cover the LDS latency)
+            }
+            float hn[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                lstm_cell_v(acc[t], creg[t], hn[t]);
+                __builtin_amdgcn_sched_barrier(0);       // tile by tile: the temporaries of four interleaved cells do not fit 128 VGPRs
+            }
+            if (full) {
+                *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(zn) + sq * ZLD + u0) = (f16x4){(_Float16)hn[0], (_Float16)hn[1], (_Float16)hn[2], (_Float16)hn[3]};
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (u0 + t < H) reinterpret_cast<_Float16*>(zn)[sq * ZLD + u0 + t] = (_Float16)hn[t];
+            }
+            if (!O16) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) hprev[t] = hn[t];
+                poff = live ? soff : OOB;
+                soff += sstep;
+            }
+            lds_barrier();
+        }
+        if (O16) { if (tmax > 0) copy_out(tmax - 1, z + (tmax & 1) * SEQ * ZLD); }
+        else store_prev();
+        for (int s_ = 0; s_ < nvalid; ++s_) {
+            const int64_t ob = (m0 + s_) * T * OW + (int64_t)dir * H;
+            for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
+                for (int col = lane; col < H; col += 64) {
+                    if (O16) reinterpret_cast<_Float16*>(p.out)[ob + (int64_t)t2 * OW + col] = (_Float16)0.f;
+                    else p.out[ob + (int64_t)t2 * OW + col] = 0.f;
+                }
+        }
+    }
+}
+
+static int launch_pt_bf16w8(const LstmPtArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)(2 * 16 * (32 * 4 + 8)) * 2 + (size_t)8 * 4 * 64 * 16 + 16 * 4 + (size_t)16 * (p.T + 4) * 4;
+    ProfScope ps(prof_shape_name("lstm16_pt_bf16w8_kernel", (long long)p.M, p.T, p.H), st);
+    const int64_t tiles = (p.M + 15) / 16;
+    const int64_t cap = std::max(1, (2 * cu_count() + p.ND - 1) / p.ND);    // two 512-thread workgroups per CU
+    if (p.out_f16) hipLaunchKernelGGL((lstm16_pt_bf16w8_kernel<true>), dim3((unsigned)std::min(tiles, cap), (unsigned)p.ND), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL((lstm16_pt_bf16w8_kernel<false>), dim3((unsigned)std::min(tiles, cap), (unsigned)p.ND), dim3(512), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[bf16, 8 waves]");
+    return 0;
+}
+
 template <int KB, int NT>
 static int launch_pt_bf16(const LstmPtArgs& p, hipStream_t st) {
     static const std::string pname = "lstm16_pt_bf16_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + ">";
@@ -1134,7 +1354,9 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     if (pt_dtype == NIR_DTYPE_BF16) {
         const int KB = (H + 31) / 32;
         if (H <= 64) return KB == 1 ? launch_pt_bf16<1, 1>(p, st) : launch_pt_bf16<2, 1>(p, st);
-        return KB == 3 ? launch_pt_bf16<3, 2>(p, st) : launch_pt_bf16<4, 2>(p, st);
+        if (KB == 3) return launch_pt_bf16<3, 2>(p, st);
+        // H in (96, 128]: two 8-wave workgroups per CU (tunable lstm_w16 = 1: the 16-wave form, one workgroup per CU)
+        return tun(g_tun.lstm_w16) == 1 ? launch_pt_bf16<4, 2>(p, st) : launch_pt_bf16w8(p, st);
     }
     if (!tun(g_tun.exact_f32) && H >= 32) {      // fp32-accurate two-term fp16 split on the fp16 matrix cores
         const int KB = (H + 31) / 32;
