@@ -320,6 +320,223 @@ __global__ __launch_bounds__(512) void lstm_train_bwd_kernel(LstmBwdArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// BPTT on the matrix cores with W_hh RESIDENT (the kernel above re-reads W_hh from L2 in every step and multiplies on the VALU:
+// 1.75 ms at the C3 document shape, 6.8 % of the fp32-MFMA roof).  16 sequences x one direction per workgroup, 4 waves (one per SIMD,
+// up to 512 registers each):
+//     dh_{t-1}[unit, seq] = sum_jj W_hh[jj, unit] * dg_t[seq, jj]      as   D[16 units x 16 seqs] += A[16 units x 4] B[4 x 16 seqs]
+// on v_mfma_f32_16x16x4_f32 (exact fp32: gradients span too many binades for the fp16 split).  Wave w owns the unit tiles 2w, 2w+1
+// and keeps their columns of W_hh as A fragments in registers for all T steps (the reduction index runs over (gate, unit) = 4 x HP
+// values, HP = H rounded up to 4: NKS = HP MFMA k-steps per tile and step, fragment lane (unit = lane & 15, q = lane >> 4) holds
+// W_hh[g*H + 4c + q][unit] for k-step (g, c)).  The C/D layout hands a lane (seq = lane & 15, units 4*(lane >> 4) + r of each tile):
+// the lane that receives dh_{t-1} of a cell is the lane that computes that cell's gate gradients in the next step -- dh never leaves
+// registers.  Per step: gate gradients of the lane's 8 cells (loads prefetched one step ahead) -> dgates to HBM and, as the B operand, to
+// LDS [seq][q][k-step] (fp32, 16 B reads feed four k-steps) -> barrier -> NKS MFMAs per tile -> next step.  Two LDS buffers, one barrier
+// per step.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NKS>
+__global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs p) {
+    constexpr int SEQ = 16, NTW = 2;                       // unit tiles per wave
+    constexpr int HP = NKS;                                // padded hidden size (k-steps per gate x 4 ... = 4 * HP / 4)
+    constexpr int RS = NKS + 4;                            // LDS row stride in floats: with NKS (a multiple of 64 banks at H = 128) every lane of a
+                                                           // ds_read_b128 hit the same four banks -- 7 us of the 17 us step
+    extern __shared__ __attribute__((aligned(16))) float smb[];
+    float* dgs = smb;                                      // [2][SEQ][4][RS]
+    int* lens_s = reinterpret_cast<int*>(smb + 2 * SEQ * 4 * RS);
+    const int H = p.H, H4 = 4 * H, T = p.T, ND = p.ND;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, pq = lane >> 4;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const bool sv = m0 + sq < p.M;
+    if (tid < SEQ) {
+        int l = 0;
+        if (m0 + tid < p.M) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    for (int e = tid; e < 2 * SEQ * 4 * RS; e += 256) dgs[e] = 0.f;
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    const int len = lens_s[sq];
+    // A fragments: tile tau = NTW*wave + i, output unit = 16*tau + (lane & 15); k-step ks = g*(HP/4) + c reads W_hh[g*H + 4c + pq][unit]
+    float afr[NTW][NKS];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int uo = 16 * (NTW * wave + i) + sq;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int g = ks / (HP / 4), c = ks % (HP / 4), ui = 4 * c + pq;
+            // unconditional load from a clamped index, masked by a multiply: a select lets the compiler predicate the load, and every
+            // predicated load became its own exec-masked block with an s_waitcnt vmcnt(0) behind it (256 serialised round trips)
+            afr[i][ks] = p.whh[((int64_t)dir * H4 + (int64_t)g * H + (ui < H ? ui : H - 1)) * H + (uo < H ? uo : H - 1)] * ((uo < H && ui < H) ? 1.f : 0.f);
+        }
+    }
+    // the lane's cells: sequence sq, units ub[i] + r (r = 0..3) of its two tiles
+    int ub[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) ub[i] = 16 * (NTW * wave + i) + 4 * pq;
+    float dh[NTW][4], dc[NTW][4];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = ub[i] + r;
+            const int64_t si = ((int64_t)dir * p.M + m0 + sq) * H + u;
+            dh[i][r] = (sv && u < H && p.dhn) ? p.dhn[si] : 0.f;
+            dc[i][r] = (sv && u < H && p.dcn) ? p.dcn[si] : 0.f;
+        }
+    // the cell inputs of a step are requested a full step ahead (under the previous step's MFMAs), unconditionally from clamped addresses:
+    // per-cell conditional loads serialised eight memory round trips per step (18.8 us per step measured)
+    struct CellIn { float a[NTW][4][4]; float ct[NTW][4], cp[NTW][4], dy[NTW][4], dcs[NTW][4]; };
+    const bool vec = (H & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.act) | reinterpret_cast<uintptr_t>(p.cst) | reinterpret_cast<uintptr_t>(p.dout) |
+                                       reinterpret_cast<uintptr_t>(p.dgates) | reinterpret_cast<uintptr_t>(p.dcst) | reinterpret_cast<uintptr_t>(p.c0)) & 15) == 0;
+    auto load_cells = [&](int step, CellIn& ci) {
+        const bool on_ = step >= 0 && step < len;
+        const int st_ = on_ ? step : 0;
+        const int t_ = dir == 0 ? st_ : (len > 0 ? len - 1 - st_ : 0);
+        const int64_t row_ = (sv ? m0 + sq : m0) * T + t_;
+        const float* a = p.act + (row_ * ND + dir) * (int64_t)H4;
+        const float* cs = p.cst + (row_ * ND + dir) * (int64_t)H;
+        const int tp = dir == 0 ? st_ - 1 : len - st_;                  // position of the previous step's cell state (step > 0)
+        const float* cpv = (st_ > 0) ? p.cst + (((sv ? m0 + sq : m0) * T + (tp < 0 ? 0 : (tp >= T ? T - 1 : tp))) * ND + dir) * (int64_t)H
+                                     : (p.c0 ? p.c0 + ((int64_t)dir * p.M + (sv ? m0 + sq : m0)) * H : nullptr);
+        const float* dyp = p.dout + row_ * (int64_t)(ND * H) + dir * H;
+        const float* dcp = p.dcst ? p.dcst + (row_ * ND + dir) * (int64_t)H : nullptr;
+        if (vec) {                                       // H % 4 == 0: the lane's four units are one 16-byte piece of every row
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int u = ub[i] < H ? ub[i] : 0;
+                auto ld4 = [&](const float* q, float (&dst)[4]) {
+                    const float4 v = *reinterpret_cast<const float4*>(q + u);
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                };
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ld4(a + g * H, ci.a[i][g]);
+                ld4(cs, ci.ct[i]);
+                ld4(dyp, ci.dy[i]);
+                if (cpv) ld4(cpv, ci.cp[i]);
+                else ci.cp[i][0] = ci.cp[i][1] = ci.cp[i][2] = ci.cp[i][3] = 0.f;
+                if (dcp) ld4(dcp, ci.dcs[i]);
+                else ci.dcs[i][0] = ci.dcs[i][1] = ci.dcs[i][2] = ci.dcs[i][3] = 0.f;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = ub[i] + r < H ? ub[i] + r : H - 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ci.a[i][g][r] = a[g * H + u];
+                ci.ct[i][r] = cs[u];
+                ci.cp[i][r] = cpv ? cpv[u] : 0.f;
+                ci.dy[i][r] = dyp[u];
+                ci.dcs[i][r] = dcp ? dcp[u] : 0.f;
+            }
+    };
+    CellIn cin;
+    load_cells(tmax - 1, cin);
+    for (int step = tmax - 1; step >= 0; --step) {
+        float* dgw = dgs + (step & 1) * SEQ * 4 * RS;
+        const bool on = step < len;                                    // this sequence takes part in the step
+        const int t = dir == 0 ? step : len - 1 - step;
+        const int64_t row = (m0 + sq) * T + (on ? t : 0);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            float gv[4][4];                                  // [gate][r] of this tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = ub[i] + r;
+                const bool cv = on && sv && u < H;
+                const float i_ = cin.a[i][0][r], f_ = cin.a[i][1][r], g_ = cin.a[i][2][r], o_ = cin.a[i][3][r];
+                const float th = tanhf(cin.ct[i][r]);
+                const float dht = cin.dy[i][r] + dh[i][r];
+                const float dct = dc[i][r] + dht * o_ * (1.f - th * th) + cin.dcs[i][r];
+                const float gi = cv ? dct * g_ * i_ * (1.f - i_) : 0.f;
+                const float gf = cv ? dct * cin.cp[i][r] * f_ * (1.f - f_) : 0.f;
+                const float gg = cv ? dct * i_ * (1.f - g_ * g_) : 0.f;
+                const float go = cv ? dht * th * o_ * (1.f - o_) : 0.f;
+                gv[0][r] = gi; gv[1][r] = gf; gv[2][r] = gg; gv[3][r] = go;
+                if (cv) {
+                    dc[i][r] = dct * f_;
+#ifndef NIR_BW_NOSTORE
+                    if (!vec) {
+                        float* o = p.dgates + row * (int64_t)(ND * H4) + dir * H4;
+                        o[u] = gi; o[H + u] = gf; o[2 * H + u] = gg; o[3 * H + u] = go;
+                    }
+#endif
+                }
+                // B operand: k-step (g, c = u / 4), q = r  ->  dgw[sq][r][g * HP/4 + c]   (zero for padded units / idle sequences)
+                if (u < HP) {
+                    float* d = dgw + (sq * 4 + r) * RS + (u >> 2);
+                    d[0] = gi; d[HP / 4] = gf; d[2 * (HP / 4)] = gg; d[3 * (HP / 4)] = go;
+                }
+            }
+#ifndef NIR_BW_NOSTORE
+            if (vec && on && sv && ub[i] < H) {
+                float* o = p.dgates + row * (int64_t)(ND * H4) + dir * H4 + ub[i];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + g * H) = make_float4(gv[g][0], gv[g][1], gv[g][2], gv[g][3]);
+            }
+#endif
+        }
+#ifndef NIR_BW_NOLOAD
+        load_cells(step - 1, cin);                                     // lands under this step's MFMAs
+#endif
+        lds_barrier();                                   // LDS only: the prefetched cell inputs and the dgates stores stay in flight under the MFMAs
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* bp = dgw + (sq * 4 + pq) * RS;
+#ifndef NIR_BW_NOMFMA
+#pragma unroll
+        for (int k4 = 0; k4 < NKS / 4; ++k4) {
+            const float4 b = *reinterpret_cast<const float4*>(bp + 4 * k4);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[i][4 * k4 + 0], b.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[i][4 * k4 + 1], b.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[i][4 * k4 + 2], b.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[i][4 * k4 + 3], b.w, acc[i], 0, 0, 0);
+            }
+        }
+#else
+        acc[0][0] = bp[0] + afr[0][0] + afr[1][NKS - 1];
+#endif
+        // sequences that have not started yet (step >= len) keep the final-state gradient
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (on) dh[i][r] = acc[i][r];
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = ub[i] + r;
+            if (sv && u < H) {
+                const int64_t si = ((int64_t)dir * p.M + m0 + sq) * H + u;
+                if (p.dh0) p.dh0[si] = dh[i][r];
+                if (p.dc0) p.dc0[si] = dc[i][r];
+            }
+        }
+    // zero the gate gradients of the padded steps: one wave per (sequence, step) row, coalesced
+    __syncthreads();
+    for (int s_ = 0; s_ < SEQ && m0 + s_ < p.M; ++s_)
+        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += 4) {
+            float* o = p.dgates + ((m0 + s_) * T + t2) * (int64_t)(ND * H4) + dir * H4;
+            for (int col = lane; col < H4; col += 64) o[col] = 0.f;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // element-wise pieces
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix(uint64_t x) {
@@ -518,6 +735,22 @@ extern "C" int nir_lstm_train_bwd(const float* dout, const float* dhn, const flo
     NIR_REQUIRE(M >= 0 && T > 0 && (ndir == 1 || ndir == 2) && H >= 1 && H <= 128, "lstm_train_bwd: bad dims (H <= 128)");
     if (M == 0) return 0;
     LstmBwdArgs a{dout, dhn, dcn, dcst, act, cst, c0, lengths, w_hh, dgates, dh0, dc0, M, T, H, ndir};
+    // W_hh resident on the matrix cores for the hidden sizes that fill 4 waves x 2 unit tiles (H <= 128); tunable lstm_valu keeps the VALU form
+    const int hp = (H + 3) / 4 * 4;
+    // (H % 4 != 0 -- MatchTensor's 70 -- has no 16-byte cell IO: measured 666 against 427 us at 320 sequences, 1430 against 1790 us at 2560)
+    if (!tun(g_tun.lstm_valu) && H >= 16 && (hp == 32 || hp == 64 || hp == 72 || hp == 96 || hp == 128) && (H % 4 == 0 || M >= 1024)) {
+        const size_t ldm = (size_t)2 * 16 * 4 * (hp + 4) * 4 + 16 * 4;
+        ProfScope ps(prof_shape_name("lstm_train_bwd_mfma_kernel", M, T, H), (hipStream_t)stream);
+        const dim3 grid((unsigned)((M + 15) / 16), (unsigned)ndir);
+        hipStream_t st = (hipStream_t)stream;
+        if (hp == 32) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<32>, grid, dim3(256), ldm, st, a);
+        else if (hp == 64) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<64>, grid, dim3(256), ldm, st, a);
+        else if (hp == 72) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<72>, grid, dim3(256), ldm, st, a);
+        else if (hp == 96) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<96>, grid, dim3(256), ldm, st, a);
+        else hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<128>, grid, dim3(256), ldm, st, a);
+        NIR_CHECK_LAUNCH("lstm_train_bwd_mfma_kernel");
+        return 0;
+    }
     const int threads = (4 * H + 63) / 64 * 64;
     const size_t lds = (size_t)TSQ * (4 * H + H + 4 * H) * 4;
     ProfScope ps(prof_shape_name("lstm_train_bwd_kernel", M, T, H), (hipStream_t)stream);
