@@ -128,11 +128,11 @@ def kernel_work(name, c):
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0), terms=6, pipe=F16)
     if base.startswith("gemm_kernel") or base.startswith("gemm16_kernel") or base.startswith("gemm32_kernel") or base.startswith("gemm_skinny_kernel"):
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N), terms=1, pipe=F32)
-    if base.startswith("lstm16_pt_bf16_kernel"):      # M sequences, N = T steps, K = H; both directions in one launch; bf16 table rows,
+    if base.startswith("lstm16_pt_bf16_kernel") or base.startswith("lstm16_pt_bf16w8_kernel"):      # M sequences, N = T steps, K = H; both directions in one launch; bf16 table rows,
         # fp16 MFMA operands; the states leave as fp16 when they feed the pipelined attention kernel of the same encode call
         out_b = 2.0 if M * N >= 2 * 256 * 64 else 4.0
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * out_b), terms=1, pipe=F16)
-    if base.startswith("lstm16_pt_h2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block
+    if base.startswith("lstm16_pt_h2_kernel") or base.startswith("lstm16_pt_h2x2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), terms=3, pipe=F16)
     if base.startswith("lstm16_pt_kernel"):
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), terms=1, pipe=F32)
@@ -146,7 +146,7 @@ def kernel_work(name, c):
         return dict(flops=pairs * QL * DL * 2.0 * (15 * C * 6 + 45 * 6 + 18 * 20), bytes=pairs * DL * (C * 4 + 8.0) + pairs * 4, terms=3, pipe=F16)
     if base.startswith("wgrad_kernel"):               # dW = dY^T X on the f32 MFMA (csrc/train.hip): M rows reduced, [N, K] output
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K), terms=1, pipe=F32)
-    if base.startswith("lstm_train_fwd_kernel") or base.startswith("lstm_train_bwd_kernel"):
+    if base.startswith("lstm_train_fwd_kernel") or base.startswith("lstm_train_bwd_kernel") or base.startswith("lstm_train_bwd_mfma_kernel"):
         # M sequences, N = T steps, K = H units, both directions: the recurrent product h W_hh^T (forward) / W_hh^T dg (BPTT), f32 MFMA
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * 2 * (4 * K + 2 * K) * 4.0, terms=1, pipe=F32)
     if base in ("esm16_kernel", "esm_kernel", "drmm_kernel"):

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
                 else df_split_store_half(an_, KG, (tid >> 3) + 32 * h_, aq >> 1, 4 * (aq & 1), RAC[h_].x, RAC[h_].y); \
             }                                                                             \
             if (n_ == 8 * LPT + 2) DF_LOAD_A(RAN, s2_)                                    \
-            if (n_ == 8 * LPT + 6) __syncthreads();                                       \
+            if (n_ == 8 * LPT + 6) lds_barrier();   /* LDS-only: __syncthreads() carries s_waitcnt vmcnt(0) -- the A rows and W fragments requested a few MFMAs earlier */ \
             if (n_ >= 8 * LPT + 8 && (n_ - 8 * LPT - 8) % 3 == 0 && (n_ - 8 * LPT - 8) / 3 < 2 * RT) { \
                 const int q_ = (n_ - 8 * LPT - 8) / 3;                                    \
                 AFN[q_ % RT][q_ / RT] = *reinterpret_cast<const f16x8*>(an_ + (q_ / RT) * 4 * KG + foff + (q_ % RT) * 128); \
