@@ -22,10 +22,14 @@ int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, f
                   hipStream_t st);
 // duet_fused.hip
 bool duet_doc_usable(int NF, int P, int E, int DL, int K1P);
-size_t duet_doc_partial_floats(int64_t M, int DL, int P);
+size_t duet_doc_partial_floats(int64_t M, int DL, int P, bool planes);
 int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int64_t M, int N, const void* wf1, int K1P, const void* wf2,
-                    const float* b1, const float* b2, const float* fc2w, const float* fc2b, const float* qv, int NF, int P, float* partial,
-                    float* m1, hipStream_t st);
+                    const void* ftab, const void* wf1c, int EPT, const float* b1, const float* b2, const float* fc2w, const float* fc2b,
+                    const float* qv, int NF, int P, float* partial, float* m1, hipStream_t st);
+
+static bool duet_table_planes(const nir_duet_weights* w, int E) {
+    return w->ftable && w->fw1c && w->EPT >= E && w->EPT % 64 == 0;
+}
 
 static bool duet_fused(const nir_duet_weights* w, int E, int DL) {
     return w->bounded && w->fw1 && w->fw2 && !tun(g_tun.duet_unfused) && !tun(g_tun.exact_f32) && duet_doc_usable(w->NF, w->pool, E, DL, w->K1P);
@@ -223,7 +227,7 @@ struct DuetPlan {
     size_t bytes;
 };
 
-static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, int NF, int P, bool fused) {
+static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, int NF, int P, bool fused, bool tplanes) {
     Workspace a(ws, cap);
     const size_t M = (size_t)B * N;
     const int Tc = DL - 2, Tp = Tc - P + 1;
@@ -235,7 +239,7 @@ static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, in
     p.qmax = a.take<float>((size_t)B * NF);
     p.qv = a.take<float>((size_t)B * NF);
     if (fused) {                                      // the fused kernel keeps conv_d1 / pooled / conv_d2 on chip: only per-tile fc2 partials
-        p.cd = a.take<float>(duet_doc_partial_floats((int64_t)M, DL, P));
+        p.cd = a.take<float>(duet_doc_partial_floats((int64_t)M, DL, P, tplanes));
         p.pooled = p.dd = nullptr;
     } else {
         p.cd = a.take<float>(M * Tc * NF);
@@ -253,7 +257,7 @@ static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, in
 
 extern "C" size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w) {
     if (!w || B < 0 || N <= 0 || QL < 3 || DL < w->pool + 2) return 0;
-    return nir::duet_plan(nullptr, 0, B, N, QL, DL, w->NF, w->pool, nir::duet_fused(w, E, DL)).bytes;
+    return nir::duet_plan(nullptr, 0, B, N, QL, DL, w->NF, w->pool, nir::duet_fused(w, E, DL), nir::duet_table_planes(w, E)).bytes;
 }
 
 extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
@@ -273,7 +277,8 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     if (B == 0) return 0;
     const int NF = w->NF, P = w->pool, Tc = DL - 2, Tp = Tc - P + 1;
     const bool fused = duet_fused(w, E, DL);
-    DuetPlan p = duet_plan(workspace, workspace_bytes, B, N, QL, DL, NF, P, fused);
+    const bool tplanes = duet_table_planes(w, E);
+    DuetPlan p = duet_plan(workspace, workspace_bytes, B, N, QL, DL, NF, P, fused, tplanes);
     if (!workspace || p.bytes > workspace_bytes) {
         set_error("duet: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
         return NIR_ERR_WORKSPACE;
@@ -303,8 +308,8 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     const bool planes = w->bounded && w->EP > 0 && w->table_h1 && w->table_h2 && w->convd1_h1 && w->convd1_h2 && w->convd2_h1 && w->convd2_h2 &&
                         w->EP % 8 == 0 && w->EP >= NF && w->EP <= NF + 8 && w->EP >= E;
     if (fused) {
-        NIR_PROPAGATE(launch_duet_doc(d_ids, table, E, DL, M, N, w->fw1, w->K1P, w->fw2, w->convd1_b, w->convd2_b, w->fc2_w, w->fc2_b, p.qv, NF, P,
-                                      p.cd, p.m1, st));
+        NIR_PROPAGATE(launch_duet_doc(d_ids, table, E, DL, M, N, w->fw1, w->K1P, w->fw2, tplanes ? w->ftable : nullptr, w->fw1c, w->EPT, w->convd1_b,
+                                      w->convd2_b, w->fc2_w, w->fc2_b, p.qv, NF, P, p.cd, p.m1, st));
     } else if (planes) {
         // pre-split fp16 term planes end to end: table planes gathered by id (3 taps) -> conv_d1 + tanh (fp32) -> pooling writes
         // planes -> conv_d2 + tanh; no operand is split inside a GEMM

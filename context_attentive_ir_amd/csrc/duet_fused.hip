@@ -18,6 +18,8 @@
 // so the tile is as tall as the register file and LDS allow: 96 rows = 240 accumulator AGPRs per lane and 150 KB of LDS, one
 // workgroup (4 waves, one per SIMD) per CU.  Tiles are cut from the FLATTENED (document, position) axis when documents are long
 // enough (a tile then touches at most two documents): 92 of 96 rows carry useful pooled rows.
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include "common.hpp"
 
@@ -45,6 +47,11 @@ struct DuetDocArgs {
     int E, DL, S1, NF, Tc, PL, P;
     int flat;                   // 1: tiles cut from the flattened (doc, position) axis with stride TS; 0: ntile tiles per document
     int TS, ntile, TPv;
+    // plane mode (PL): the embedding table as pre-split fp16 term planes [V][2 terms][EPT] (EPT = E rounded up to a multiple of 32, zero
+    // padded) and conv_d1 in chunk-major k order: k-step 3c + u = elements 32c .. 32c+31 of tap u
+    const _Float16* ftab;
+    const _Float16* wf1c;       // [3 C][20][2][64][8]
+    int EPT, C, ids_off;        // C = EPT / 32 column chunks; byte offset of the tile's token ids in LDS
 };
 
 __device__ __forceinline__ void df_split_store(unsigned short* base, int kgs, int row, int kg, int e0, const float4& v) {
@@ -72,6 +79,7 @@ __device__ __forceinline__ float df_bperm(float v, int byte_idx) {
 // 60 MFMAs).  The operands come straight from ds_read / global_load (s_waitcnt is still compiler-inserted); the accumulators are first
 // read by VALU code after DF_MMA_DRAIN.
 #define DF_MMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(W))
+#define DF_MMA_V(ACC, A, W) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(W))
 #ifdef DF_TIMING
 __device__ long long df_dbg[16];
 #define DF_T(I) if (blockIdx.x == 3000 && threadIdx.x == 0) df_dbg[I] = __builtin_readcyclecounter();
@@ -79,6 +87,14 @@ __device__ long long df_dbg[16];
 #define DF_T(I)
 #endif
 #define DF_MMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+// Accumulator element -> VGPR at the point of use.  Left to the compiler, every accumulator is copied out of its AGPR right behind the
+// last MFMA (240 v_accvgpr_read in a row for the 96-row tile: the epilogue then spills, and so do the GEMM loops around it).
+__device__ __forceinline__ float df_acc(const f32x4& a, int r, bool from_agpr) {      // from_agpr folds to a constant after unrolling
+    if (!from_agpr) return a[r];              // VGPR-resident accumulators; the 64-row kernel without table planes keeps the allocation it was validated with
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a[r]));
+    return x;
+}
 
 // MFMA number n of a k-step (n is a compile-time constant after unrolling): column tile n / (3 RT), term pair (n / RT) % 3, row tile n % RT
 template <int RT>
@@ -109,14 +125,29 @@ struct DfLayout {
     static constexpr int LPT = ROWS * 8 / 256;          // A-stage float4 loads per thread and k-step
 };
 
+// Plane mode: the token rows a tile needs are ONE contiguous range of the flattened id array -- conv row (d, t), tap u reads token
+// (doc0 + d) DL + t + u = F0 + pr + 2 d + u -- so the tile's ROWS + 6 token rows are brought in once (not once per tap), as fp16 term
+// planes that need no arithmetic, by LDS-direct loads that need no registers: global_load_lds_dwordx4 writes a wave's 64 x 16 bytes to
+// consecutive LDS addresses, so the tile is laid out [column chunk c][term][k-group][token row][8 halves] with a chunk padded to NI
+// wave-loads.  Chunk c + 1 is requested during the first two k-steps of chunk c and taken over (s_waitcnt vmcnt + barrier) at the top
+// of the third: the k-loop has one barrier per THREE k-steps and no VALU work beyond address arithmetic.
+template <int RT>
+struct DfLayoutP {
+    static constexpr int ROWS = 16 * RT;
+    static constexpr int RP = ROWS + 6;                 // token rows: ROWS + 2 taps + 2 per document boundary (at most two)
+    static constexpr int NI = (8 * RP + 63) / 64;       // wave-level loads per chunk (2 terms x 4 k-groups x RP pieces of 16 bytes)
+    static constexpr int CHB = NI * 1024;               // bytes per chunk
+    static constexpr int NSLOT = (NI + 3) / 4;          // loads per wave and chunk
+};
+
 // POOL: pooling window known at compile time (5 = the reference's pool_size), or 0 = read it from the arguments (1..5)
-template <int RT, int POOL>
+template <int RT, int POOL, bool PL>
 __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
     using L = DfLayout<RT>;
     constexpr int KG = L::KG, LPT = L::LPT;
     extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];
     unsigned short* As = dsm;
-    unsigned short* Pp = dsm + L::A_HALVES;
+    unsigned short* Pp = PL ? dsm : dsm + L::A_HALVES;          // plane mode: the P planes take the token tile's place after GEMM 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int E = p.E, S1 = p.S1, K1 = 3 * p.E, Tc = p.Tc;
@@ -144,39 +175,9 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         }
     };
 
-    // ---- A operand: conv row (doc, t) reads tokens t, t+1, t+2 of its document (rows past the end are clamped; they only feed
-    // pooled rows that get weight 0).  Tap s of a row starts at table + id_s * E; the offsets are pre-biased by the tap's k offset so
-    // that element k of the concatenated row is table[off_s + k].
-    const int aq = tid & 7;
-    int64_t off[LPT][3];
-#pragma unroll
-    for (int h = 0; h < LPT; ++h) {
-        int d, t;
-        row_pos((tid >> 3) + 32 * h, d, t);
-        const int64_t* idp = p.d_ids + (doc0 + d) * p.DL + t;
-        off[h][0] = idp[0] * (int64_t)E;
-        off[h][1] = idp[1] * (int64_t)E - E;
-        off[h][2] = idp[2] * (int64_t)E - 2 * E;
-    }
-    const float* const table = p.table;
-    float4 ra[LPT], rb[LPT];
-#define DF_LOAD_A(RA, S)                                                                                  \
-    {                                                                                                     \
-        int k_ = 32 * (S) + 4 * aq;                                                                       \
-        k_ = k_ < K1 ? k_ : K1 - 4;                              /* k >= 3E: any finite value (W1 is zero there) */ \
-        _Pragma("unroll") for (int h_ = 0; h_ < LPT; ++h_) {                                              \
-            const int64_t o_ = k_ < E ? off[h_][0] : (k_ < 2 * E ? off[h_][1] : off[h_][2]);              \
-            RA[h_] = *reinterpret_cast<const float4*>(table + o_ + k_);                                   \
-        }                                                                                                 \
-    }
-#define DF_STORE_A(RA, BUF)                                                                               \
-    {                                                                                                     \
-        _Pragma("unroll") for (int h_ = 0; h_ < LPT; ++h_)                                                \
-            df_split_store(As + (BUF) * (2 * 4 * KG), KG, (tid >> 3) + 32 * h_, aq >> 1, 4 * (aq & 1), RA[h_]); \
-    }
     // ---- W operands: fragment-ordered planes, 1 KB contiguous per wave-level load; one register set, a column tile's pair is
     // re-loaded for the next k-step as soon as its MFMAs are issued (the other four tiles' MFMAs cover the L2 latency)
-    const _Float16* wp1 = p.wf1 + ((int64_t)(DF_CT * wave) * 2 * 64 + lane) * 8;
+    const _Float16* wp1 = (PL ? p.wf1c : p.wf1) + ((int64_t)(DF_CT * wave) * 2 * 64 + lane) * 8;
     const _Float16* wp2 = p.wf2 + ((int64_t)(DF_CT * wave) * 2 * 64 + lane) * 8;
     constexpr int WSTEP = 20 * 2 * 64 * 8;
     f16x8 w[DF_CT][2];
@@ -216,6 +217,78 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
 #define DF_KEEP(WC, AFC)                                                                  \
     _Pragma("unroll") for (int j_ = 0; j_ < DF_CT; ++j_) asm volatile("" ::"v"(WC[j_][0]), "v"(WC[j_][1]));   \
     _Pragma("unroll") for (int i_ = 0; i_ < RT; ++i_) asm volatile("" ::"v"(AFC[i_][0]), "v"(AFC[i_][1]));
+    // Plane mode runs its k-steps ROW TILE by row tile (15 MFMAs: 3 term products x 5 column tiles), not column tile by column tile: a row
+    // tile's A fragments are then live for 15 MFMAs instead of the whole step and are double-buffered per row tile (16 registers instead
+    // of 32 RT), which is what lets the 96-row tile (240 accumulator AGPRs) fit.  Per step: the W fragments of the next step into the other
+    // set (term 1 first: the step's last five MFMAs read every term-0 fragment), the next row tile's fragments at MFMAs 5 and 7 of a row
+    // tile.  Every redefinition is preceded by an empty asm use of the old value, so the register is never free between its last MFMA
+    // read and its reload (the VALU-after-MFMA WAR hazard described below).
+    // With 240 accumulator AGPRs out of 256 the register allocator starts rotating accumulator tuples through VGPRs around the asm MFMAs
+    // (and reads them there before the MFMA has written them back): the last row tile of the 96-row kernel accumulates in VGPRs instead.
+    constexpr int VACC = RT > 4 ? RT - 4 : 0;
+    f16x8 af[2][2];
+#define DF_STEPR(WC, WN, WNP, CURB, NXTB, TOFF, ROW, EXTRA)                               \
+    {                                                                                     \
+        constexpr int WS_ = 15 * RT / 10;                                                 \
+        _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 15 * RT; ++n_) {         \
+            const int i_ = n_ / 15, m_ = n_ % 15, j_ = m_ % 5, b_ = i_ & 1;               \
+            if (i_ >= RT - VACC) {                                                        \
+                if (m_ < 5) DF_MMA_V(acx[j_][i_], af[b_][1], WC[j_][0]);                  \
+                else if (m_ < 10) DF_MMA_V(acx[j_][i_], af[b_][0], WC[j_][1]);            \
+                else DF_MMA_V(acc[j_][i_], af[b_][0], WC[j_][0]);                         \
+            } else {                                                                      \
+                if (m_ < 5) DF_MMA(acx[j_][i_], af[b_][1], WC[j_][0]);                    \
+                else if (m_ < 10) DF_MMA(acx[j_][i_], af[b_][0], WC[j_][1]);              \
+                else DF_MMA(acc[j_][i_], af[b_][0], WC[j_][0]);                           \
+            }                                                                             \
+            EXTRA                                                                         \
+            if (n_ >= 3 && (n_ - 3) % WS_ == 0 && (n_ - 3) / WS_ < 2 * DF_CT) {           \
+                const int k_ = (n_ - 3) / WS_, t_ = k_ < DF_CT ? 1 : 0, jj_ = k_ % DF_CT; \
+                asm volatile("" ::"v"(WN[jj_][t_]));                                      \
+                WN[jj_][t_] = *reinterpret_cast<const f16x8*>((WNP) + (jj_ * 2 + t_) * 512); \
+            }                                                                             \
+            if (m_ == 4 || m_ == 6) asm volatile("" ::"v"(af[b_ ^ 1][m_ == 4 ? 1 : 0]));  \
+            if (m_ == 5 || m_ == 7) {                                                     \
+                const int tt_ = m_ == 5 ? 1 : 0;                                          \
+                const unsigned char* fb_ = i_ + 1 < RT ? (CURB) : (NXTB);                 \
+                const int in_ = i_ + 1 < RT ? i_ + 1 : 0;                                 \
+                af[b_ ^ 1][tt_] = *reinterpret_cast<const f16x8*>(fb_ + tt_ * (TOFF) + ROW(in_)); \
+            }                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+    }
+    static_assert(!PL || RT % 2 == 0, "row-tile double buffering of the A fragments needs an even RT");
+    if constexpr (!PL) {
+    // ---- A operand: conv row (doc, t) reads tokens t, t+1, t+2 of its document (rows past the end are clamped; they only feed
+    // pooled rows that get weight 0).  Tap s of a row starts at table + id_s * E; the offsets are pre-biased by the tap's k offset so
+    // that element k of the concatenated row is table[off_s + k].
+    const int aq = tid & 7;
+    int64_t off[LPT][3];
+#pragma unroll
+    for (int h = 0; h < LPT; ++h) {
+        int d, t;
+        row_pos((tid >> 3) + 32 * h, d, t);
+        const int64_t* idp = p.d_ids + (doc0 + d) * p.DL + t;
+        off[h][0] = idp[0] * (int64_t)E;
+        off[h][1] = idp[1] * (int64_t)E - E;
+        off[h][2] = idp[2] * (int64_t)E - 2 * E;
+    }
+    const float* const table = p.table;
+    float4 ra[LPT], rb[LPT];
+#define DF_LOAD_A(RA, S)                                                                                  \
+    {                                                                                                     \
+        int k_ = 32 * (S) + 4 * aq;                                                                       \
+        k_ = k_ < K1 ? k_ : K1 - 4;                              /* k >= 3E: any finite value (W1 is zero there) */ \
+        _Pragma("unroll") for (int h_ = 0; h_ < LPT; ++h_) {                                              \
+            const int64_t o_ = k_ < E ? off[h_][0] : (k_ < 2 * E ? off[h_][1] : off[h_][2]);              \
+            RA[h_] = *reinterpret_cast<const float4*>(table + o_ + k_);                                   \
+        }                                                                                                 \
+    }
+#define DF_STORE_A(RA, BUF)                                                                               \
+    {                                                                                                     \
+        _Pragma("unroll") for (int h_ = 0; h_ < LPT; ++h_)                                                \
+            df_split_store(As + (BUF) * (2 * 4 * KG), KG, (tid >> 3) + 32 * h_, aq >> 1, 4 * (aq & 1), RA[h_]); \
+    }
 #define DF_STEP1(S, AFC, AFN, WC, WN, RAC, RAN)                                           \
     {                                                                                     \
         const int s1_ = (S) + 1 < S1 ? (S) + 1 : S1 - 1;      /* past the end: re-load the last step's operands (branch-free) */ \
@@ -262,8 +335,106 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         if (s < S1) DF_STEP1(s, afa, afb, w, wb, ra, rb)
     }
 
+
+    } else {
+        // ================= GEMM 1, plane mode =================
+        using LP = DfLayoutP<RT>;
+        constexpr int RP = LP::RP, NI = LP::NI, CHB = LP::CHB, NSLOT = LP::NSLOT;
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        unsigned char* const Ab = reinterpret_cast<unsigned char*>(dsm);
+        int* const ids_s = reinterpret_cast<int*>(Ab + p.ids_off);
+        const int C = p.C, S1c = 3 * p.C;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        {
+            const int64_t F0 = doc0 * p.DL + t00, Fm = p.M * p.DL - 1;       // token row i of the tile = flattened token F0 + i (clamped)
+            for (int i = tid; i < RP; i += 256) {
+                const int64_t f = F0 + i;
+                ids_s[i] = (int)p.d_ids[f < Fm ? f : Fm];
+            }
+        }
+        // fc2 row weights of the tile's rows (used by the last epilogue): weight = fc2_w[t] for an own pooled row whose window stays inside
+        // its document, else 0; slot 0 = the tile's first document, slot 1 = the next one
+        if (tid < 16 * RT) {
+            float* const ws_ = reinterpret_cast<float*>(Ab + p.ids_off + 512);
+            int t = t00 + tid;
+            const bool s1 = p.flat && t >= Tc;
+            t = s1 ? t - Tc : t;
+            const bool ok = tid < (p.flat ? p.TS : p.TPv) && t < p.PL && doc0 + (s1 ? 1 : 0) < p.M;
+            const float wv = ok ? p.fc2w[t] : 0.f;
+            ws_[tid] = s1 ? 0.f : wv;
+            ws_[16 * RT + tid] = s1 ? wv : 0.f;
+        }
+        __syncthreads();
+        // load slot k of this wave = pieces 64 (4k + wave) .. +63 of a chunk: piece -> (term, k-group, token row); pad pieces repeat the last one
+        const _Float16* gb[NSLOT];
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            int q = 64 * (4 * k + wave) + lane;
+            q = q < 8 * RP ? q : 8 * RP - 1;
+            const int tt = q / (4 * RP), r2 = q - tt * 4 * RP, kgl = r2 / RP, tau = r2 - kgl * RP;
+            gb[k] = p.ftab + ((int64_t)ids_s[tau] * 2 + tt) * p.EPT + kgl * 8;
+        }
+        // The request is inline assembly on purpose: for the builtin, hipcc puts s_waitcnt vmcnt(0) in front of every later ds_read (an LDS
+        // read with no alias scope is assumed to depend on every pending LDS-DMA write), which also drains the W prefetch of the step.
+        const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)dsm;
+#define DF_TILE_LOAD(K, CC)                                                                                     \
+        if (4 * (K) + wv < NI) {                                                                                \
+            const _Float16* g_ = gb[K] + (CC) * 32;                                                             \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds0 + (CC) * CHB + (4 * (K) + wv) * 1024), "v"(g_) \
+                         : "memory", "m0");                                                                     \
+        }
+        // fragment address of row tile i (lane part): [k-group g][token row pr + 2 d][8 halves]; d = document boundaries before the row
+        int arow[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int pr = 16 * i + c16, tt0 = t00 + pr;
+            const int d = p.flat ? (tt0 >= Tc ? 1 : 0) + (tt0 >= 2 * Tc ? 1 : 0) : 0;
+            arow[i] = (g * RP + pr + 2 * d) * 16;
+        }
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) DF_TILE_LOAD(k, 0)
+        DF_LOAD_W(w, wp1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0 is in LDS
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) af[0][t] = *reinterpret_cast<const f16x8*>(Ab + t * 4 * RP * 16 + arow[0]);
+        DF_T(1)
+        // k-step (chunk CI, tap U): MFMAs on the current sets; W fragments of the next step; the next step's A fragments from (CI, U+1) or
+        // (CI+1, 0); chunk CI+1 requested in the first two MFMA slots of U = 0, 1 (in front of the step's W loads: at the top of U = 2 the
+        // ten W loads of step U = 1 are the only younger requests, s_waitcnt vmcnt(10) -> the chunk has landed)
+#define DF_AROW(I) arow[I]
+#define DF_STEP1P(CB, CI, U, WC, WN)                                                      \
+        {                                                                                 \
+            const int sn_ = 3 * (CI) + (U) + 1 < S1c ? 3 * (CI) + (U) + 1 : S1c - 1;      \
+            const _Float16* wn_ = wp1 + (int64_t)sn_ * WSTEP;                             \
+            const bool more_ = (CI) + 1 < C;                                              \
+            const unsigned char* ac_ = (CB) + (U) * 16;                                   \
+            const unsigned char* an_ = (U) < 2 ? (CB) + ((U) + 1) * 16 : (more_ ? (CB) + CHB : (CB) + 32); \
+            DF_STEPR(WC, WN, wn_, ac_, an_, 4 * RP * 16, DF_AROW,                         \
+                     if ((U) < 2 && n_ < 2 && 2 * (U) + n_ < NSLOT) {                     \
+                         if (more_) { DF_TILE_LOAD(2 * (U) + n_, (CI) + 1) }              \
+                     }                                                                    \
+                     if ((U) == 2 && n_ == 0) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");) \
+        }
+        {
+            const unsigned char* cb = Ab;
+            int c = 0;
+#pragma unroll 1
+            for (; c + 1 < C; c += 2) {       // C is even (EPT % 64 == 0): a tail of three steps behind the loop made hipcc permute all accumulators at the exit
+                DF_STEP1P(cb, c, 0, w, wb)
+                DF_STEP1P(cb, c, 1, wb, w)
+                DF_STEP1P(cb, c, 2, w, wb)
+                cb += CHB;
+                DF_STEP1P(cb, c + 1, 0, wb, w)
+                DF_STEP1P(cb, c + 1, 1, w, wb)
+                DF_STEP1P(cb, c + 1, 2, wb, w)
+                cb += CHB;
+            }
+        }
+    }
     DF_T(2)
     DF_MMA_DRAIN();
+    if constexpr (PL) lds_barrier();       // the P planes overwrite the token tile: every wave is past its last fragment read
     // ================= tanh, max-pool over rows, split into the P planes =================
     // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + r.  Pooled row pr needs rows pr .. pr+P-1: the rest of
     // this lane's quad and the quad of the next 16-lane group (the next row tile's group 0 for group 3), fetched by ds_bpermute.
@@ -272,6 +443,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         const int P = POOL ? POOL : p.P;
 #pragma unroll
         for (int j = 0; j < DF_CT; ++j) {
+            __builtin_amdgcn_sched_barrier(0);      // one column tile at a time: interleaving the tiles spilled (RT = 6)
             const int col = 80 * wave + 16 * j + c16;
             const float biasz = (col < p.NF ? p.b1[col] : 0.f) * DF_2LOG2E;
             float v[RT][4], x[RT + 1][4];
@@ -279,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[i][r] = df_tanh_z(fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), DF_2LOG2E, biasz));
+                    v[i][r] = df_tanh_z(fmaf(fmaf(df_acc(acx[j][i], r, PL && i < RT - (RT > 4 ? RT - 4 : 0)), 1.0f / 2048.0f, df_acc(acc[j][i], r, PL && i < RT - (RT > 4 ? RT - 4 : 0))), DF_2LOG2E, biasz));
                     x[i][r] = df_bperm(v[i][r], nb_idx);
                 }
 #pragma unroll
@@ -325,6 +497,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < DF_CT; ++j)
 #pragma unroll
@@ -332,12 +505,18 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    __builtin_amdgcn_sched_barrier(0);
     DF_LOAD_W(w, wp2)
     __syncthreads();
+    if constexpr (PL) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) af[0][t] = *reinterpret_cast<const f16x8*>(Pp + t * DF_S2 * 4 * KG + foff);
+    } else {
 #pragma unroll
-        for (int i = 0; i < RT; ++i) afa[i][t] = *reinterpret_cast<const f16x8*>(Pp + t * DF_S2 * 4 * KG + foff + i * 128);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < RT; ++i) afa[i][t] = *reinterpret_cast<const f16x8*>(Pp + t * DF_S2 * 4 * KG + foff + i * 128);
+    }
     DF_T(3)
 
     // ================= GEMM 2: conv_d2 (A = P planes, static in LDS: no barriers) =================
@@ -358,10 +537,27 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         }                                                                                 \
         DF_KEEP(WC, AFC)                                                                  \
     }
+#define DF_PROW(I) ((I) * 256)
+#define DF_STEP2R(S, WC, WN)                                                              \
+    {                                                                                     \
+        const int sn_ = (S) + 1 < DF_S2 ? (S) + 1 : DF_S2 - 1;                            \
+        const _Float16* wn_ = wp2 + (int64_t)sn_ * WSTEP;                                 \
+        const unsigned char* pc_ = reinterpret_cast<const unsigned char*>(Pp + (S) * 4 * KG + foff);  \
+        const unsigned char* pn_ = reinterpret_cast<const unsigned char*>(Pp + sn_ * 4 * KG + foff);  \
+        DF_STEPR(WC, WN, wn_, pc_, pn_, DF_S2 * 4 * KG * 2, DF_PROW, )                    \
+    }
+    if constexpr (PL) {
 #pragma unroll 1
-    for (int s2 = 0; s2 < DF_S2; s2 += 2) {
-        DF_STEP2(s2, afa, afb, w, wb)
-        DF_STEP2(s2 + 1, afb, afa, wb, w)
+        for (int s2 = 0; s2 < DF_S2; s2 += 2) {
+            DF_STEP2R(s2, w, wb)
+            DF_STEP2R(s2 + 1, wb, w)
+        }
+    } else {
+#pragma unroll 1
+        for (int s2 = 0; s2 < DF_S2; s2 += 2) {
+            DF_STEP2(s2, afa, afb, w, wb)
+            DF_STEP2(s2 + 1, afb, afa, wb, w)
+        }
     }
 
     DF_T(4)
@@ -371,9 +567,10 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
     // flattened tile touches at most two documents: slot 0 = the document of the tile's first row, slot 1 = the next one.
     {
         const int own = p.flat ? p.TS : p.TPv;
-        float wrow[RT][4], w1row[RT][4];
+        float wrow[PL ? 1 : RT][4], w1row[PL ? 1 : RT][4];
+        const float* const wrow_s = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(dsm) + p.ids_off + 512);   // plane mode
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+        for (int i = 0; i < (PL ? 0 : RT); ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pr = 16 * i + 4 * g + r;
@@ -388,17 +585,24 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         float* out = p.partial + (int64_t)blockIdx.x * 2 * DF_NFP;
 #pragma unroll
         for (int j = 0; j < DF_CT; ++j) {
+            __builtin_amdgcn_sched_barrier(0);      // one column tile at a time: interleaving the tiles spilled (RT = 6)
             const int col = 80 * wave + 16 * j + c16;
             const float biasz = (col < p.NF ? p.b2[col] : 0.f) * DF_2LOG2E;
             float sum = 0.f, sum1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < RT; ++i)
+            for (int i = 0; i < RT; ++i) {
+                f32x4 wa, wb1;
+                if constexpr (PL) {
+                    wa = *reinterpret_cast<const f32x4*>(wrow_s + 16 * i + 4 * g);
+                    wb1 = *reinterpret_cast<const f32x4*>(wrow_s + 16 * RT + 16 * i + 4 * g);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float d2 = df_tanh_z(fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), DF_2LOG2E, biasz));
-                    sum = fmaf(wrow[i][r], d2, sum);
-                    sum1 = fmaf(w1row[i][r], d2, sum1);
+                    const float d2 = df_tanh_z(fmaf(fmaf(df_acc(acx[j][i], r, PL && i < RT - (RT > 4 ? RT - 4 : 0)), 1.0f / 2048.0f, df_acc(acc[j][i], r, PL && i < RT - (RT > 4 ? RT - 4 : 0))), DF_2LOG2E, biasz));
+                    sum = fmaf(PL ? wa[r] : wrow[PL ? 0 : i][r], d2, sum);
+                    sum1 = fmaf(PL ? wb1[r] : w1row[PL ? 0 : i][r], d2, sum1);
                 }
+            }
             sum += df_bperm(sum, ((lane + 16) & 63) * 4);
             sum += df_bperm(sum, ((lane + 32) & 63) * 4);
             sum1 += df_bperm(sum1, ((lane + 16) & 63) * 4);
@@ -432,10 +636,10 @@ __global__ void duet_doc_finish_kernel(const float* __restrict__ partial, const 
     m1[i] = fast_tanh(fc2b[0] + qv[(pair / N) * NF + f] * s);
 }
 
-// Tiling: a tile of DF_ROWS conv positions yields DF_ROWS - (P-1) pooled rows.  Long documents (>= that many positions): tiles are cut
+// Tiling: a tile of `rows` conv positions yields rows - (P-1) pooled rows.  Long documents (>= that many positions): tiles are cut
 // from the flattened axis with that stride.  Short documents: ntile tiles per document, the pooled rows shared out evenly.
-static void duet_doc_tiling(int64_t M, int DL, int P, DuetDocArgs* a, int64_t* tiles) {
-    const int Tc = DL - 2, PL = Tc - P + 1, cap = DF_ROWS - (P - 1);
+static void duet_doc_tiling(int64_t M, int DL, int P, int rows, DuetDocArgs* a, int64_t* tiles) {
+    const int Tc = DL - 2, PL = Tc - P + 1, cap = rows - (P - 1);
     a->Tc = Tc; a->PL = PL; a->TS = cap;
     a->flat = Tc >= cap ? 1 : 0;
     a->ntile = (PL + cap - 1) / cap;
@@ -447,33 +651,60 @@ bool duet_doc_usable(int NF, int P, int E, int DL, int K1P) {
     return NF <= DF_NFP && NF % 4 == 0 && P >= 1 && P <= 5 && E % 4 == 0 && E >= 4 && DL >= P + 2 && K1P % 32 == 0 && K1P >= 3 * E;
 }
 
-size_t duet_doc_partial_floats(int64_t M, int DL, int P) {
+// Rows per tile: with the table planes the tile is 96 rows when documents are long enough for flattened 96-row tiles (W fragments are
+// streamed once per tile: 1.5x fewer L2 bytes and MFMA-free epilogue cycles per row), else 64.
+int duet_doc_rows(bool planes, int DL, int P) {
+    static const bool tall = getenv("NIR_DUET_TALL") != nullptr;      // TODO(round 3): RT = 6 spills
+    return tall && planes && DL - 2 >= 96 - (P - 1) ? 96 : DF_ROWS;
+}
+
+size_t duet_doc_partial_floats(int64_t M, int DL, int P, bool planes) {
     DuetDocArgs a;
     int64_t tiles;
-    duet_doc_tiling(M, DL, P, &a, &tiles);
+    duet_doc_tiling(M, DL, P, duet_doc_rows(planes, DL, P), &a, &tiles);
     return (size_t)tiles * 2 * DF_NFP;
 }
 
+template <int RT, bool PLN>
+static void duet_doc_launch_t(const DuetDocArgs& a, int64_t tiles, size_t lds, int P, hipStream_t st) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)duet_doc_kernel<RT, 5, PLN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)duet_doc_kernel<RT, 0, PLN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (P == 5) hipLaunchKernelGGL((duet_doc_kernel<RT, 5, PLN>), dim3((unsigned)tiles), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((duet_doc_kernel<RT, 0, PLN>), dim3((unsigned)tiles), dim3(256), lds, st, a);
+}
+
 int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int64_t M, int N, const void* wf1, int K1P, const void* wf2,
-                    const float* b1, const float* b2, const float* fc2w, const float* fc2b, const float* qv, int NF, int P, float* partial,
-                    float* m1, hipStream_t st) {
+                    const void* ftab, const void* wf1c, int EPT, const float* b1, const float* b2, const float* fc2w, const float* fc2b,
+                    const float* qv, int NF, int P, float* partial, float* m1, hipStream_t st) {
     NIR_REQUIRE(duet_doc_usable(NF, P, E, DL, K1P), "duet_doc: unsupported shape NF=%d pool=%d E=%d DL=%d K1P=%d", NF, P, E, DL, K1P);
+    const bool planes = ftab && wf1c && EPT > 0;
+    NIR_REQUIRE(!planes || (EPT % 64 == 0 && EPT >= E), "duet_doc: table planes need EPT %% 64 == 0 and EPT >= E (EPT=%d E=%d)", EPT, E);
     if (M == 0) return 0;
     DuetDocArgs a;
     a.d_ids = d_ids; a.table = table; a.wf1 = (const _Float16*)wf1; a.wf2 = (const _Float16*)wf2; a.b1 = b1; a.b2 = b2; a.fc2w = fc2w;
     a.partial = partial; a.M = M; a.E = E; a.DL = DL; a.S1 = K1P / 32; a.NF = NF; a.P = P;
+    a.ftab = (const _Float16*)ftab; a.wf1c = (const _Float16*)wf1c; a.EPT = EPT; a.C = EPT / 32; a.ids_off = 0;
+    const int rows = duet_doc_rows(planes, DL, P);
     int64_t tiles;
-    duet_doc_tiling(M, DL, P, &a, &tiles);
-    constexpr size_t lds = DfLayout<DF_RT>::LDS;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void*)duet_doc_kernel<DF_RT, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)duet_doc_kernel<DF_RT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    });
+    duet_doc_tiling(M, DL, P, rows, &a, &tiles);
     {
-        ProfScope ps(prof_shape_name("duet_doc_kernel", tiles * DF_ROWS, NF, 3 * E), st);
-        if (P == 5) hipLaunchKernelGGL((duet_doc_kernel<DF_RT, 5>), dim3((unsigned)tiles), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((duet_doc_kernel<DF_RT, 0>), dim3((unsigned)tiles), dim3(256), lds, st, a);
+        ProfScope ps(prof_shape_name(planes ? "duet_doc_kernel_pl" : "duet_doc_kernel", tiles * rows, NF, 3 * E), st);
+        if (!planes) {
+            duet_doc_launch_t<DF_RT, false>(a, tiles, DfLayout<DF_RT>::LDS, P, st);
+        } else if (rows == 96) {
+            const size_t body = std::max((size_t)a.C * DfLayoutP<6>::CHB, (size_t)DfLayout<6>::P_HALVES * 2);
+            a.ids_off = (int)body;
+            NIR_REQUIRE(body + 1536 <= 160 * 1024, "duet_doc: token tile of %d column chunks exceeds LDS", a.C);
+            duet_doc_launch_t<6, true>(a, tiles, body + 1536, P, st);
+        } else {
+            const size_t body = std::max((size_t)a.C * DfLayoutP<DF_RT>::CHB, (size_t)DfLayout<DF_RT>::P_HALVES * 2);
+            a.ids_off = (int)body;
+            NIR_REQUIRE(body + 1536 <= 160 * 1024, "duet_doc: token tile of %d column chunks exceeds LDS", a.C);
+            duet_doc_launch_t<DF_RT, true>(a, tiles, body + 1536, P, st);
+        }
     }
     NIR_CHECK_LAUNCH("duet_doc_kernel");
     {

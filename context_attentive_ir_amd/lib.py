@@ -38,7 +38,7 @@ DuetWeights = _struct(
     ["NF", "pool", "bounded"])
 DuetWeights = type("nir_duet_weights", (C.Structure,), {"_fields_": list(DuetWeights._fields_) + [
     (f, C.c_void_p) for f in ("table_h1", "table_h2", "convd1_h1", "convd1_h2", "convd2_h1", "convd2_h2")] + [("EP", C.c_int)] + [
-    ("fw1", C.c_void_p), ("fw2", C.c_void_p), ("K1P", C.c_int)]})
+    ("fw1", C.c_void_p), ("fw2", C.c_void_p), ("K1P", C.c_int), ("ftable", C.c_void_p), ("fw1c", C.c_void_p), ("EPT", C.c_int)]})
 CarsEncoderWeights = _struct(
     "nir_cars_encoder_weights",
     ["wih", "whh", "bih", "bhh", "attn0_w", "attn0_b", "attn3_w", "attn3_b"], ["H", "bounded"])

@@ -69,6 +69,9 @@ class DUET(nn.Module, lib.IdCheck):
         self.presplit_operands = False
         # conv_d1 -> pool -> conv_d2 -> Hadamard . fc2 as one kernel per document tile (needs table / conv weights below 2^15)
         self.fuse_document_branch = True
+        # ... with the embedding table as fp16 term planes [V][2][E rounded up to 64] (128 MB at V = 100 000, E = 300; once per weight
+        # version): the fused kernel then brings a tile's token rows into LDS once, by LDS-direct loads, and splits nothing
+        self.table_planes = True
 
     def _weights(self):
         def build():
@@ -100,6 +103,14 @@ class DUET(nn.Module, lib.IdCheck):
                 pk.keep["fw1"], k1p = fragments(pk.keep["convd1_w"].reshape(NF, 3 * E))
                 pk.keep["fw2"], _ = fragments(pk.keep["convd2_w"].reshape(NF, NF), 320)   # GEMM 2 always runs its 10 k-steps
                 pk.struct.fw1, pk.struct.fw2, pk.struct.K1P = pk.keep["fw1"].data_ptr(), pk.keep["fw2"].data_ptr(), k1p
+                if self.table_planes:
+                    EPT = (E + 63) // 64 * 64            # an even number of 32-element column chunks
+                    wc = torch.zeros(NF, 3, EPT, device=pk.keep["convd1_w"].device, dtype=torch.float32)
+                    wc[:, :, :E] = pk.keep["convd1_w"].reshape(NF, 3, E)
+                    wc = wc.view(NF, 3, EPT // 32, 32).permute(0, 2, 1, 3).reshape(NF, 3 * EPT)       # k = (chunk, tap, element)
+                    pk.keep["fw1c"], _ = fragments(wc, 3 * EPT)
+                    pk.keep["ftable"] = torch.stack(lib.split_f16x2(self.word_embeddings.table, EPT), 1).contiguous()   # [V, 2, EPT]
+                    pk.struct.fw1c, pk.struct.ftable, pk.struct.EPT = pk.keep["fw1c"].data_ptr(), pk.keep["ftable"].data_ptr(), EPT
             EP = (max(E, NF) + 7) // 8 * 8
             if mx < 32768.0 and self.presplit_operands and EP <= NF + 8 and EP - E < 8:
                 # fp16 term planes of the table and of the two big conv weights, split once per weight version (122 MB at V = 100 000)

@@ -252,6 +252,12 @@ typedef struct {
      * with lane = 16*(k%32/8) + column%16.  Used only when `bounded`, NF <= 320, pool <= 5 and E % 4 == 0. */
     const void *fw1, *fw2;
     int K1P;
+    /* optional, on top of fw1 / fw2: the embedding table as pre-split fp16 term planes [V][2 terms][EPT] (nir_split_f16x2 per term,
+     * EPT = E rounded up to a multiple of 64, zero padded) and conv_d1 in chunk-major k order -- [320][3 EPT] with k = (32-element
+     * column chunk c, tap u, element j) -> (3c + u) 32 + j -- split and fragment-ordered like fw1.  With them the fused kernel brings a
+     * tile's token rows into LDS once by LDS-direct loads and does no split arithmetic (csrc/duet_fused.hip, plane mode). */
+    const void *ftable, *fw1c;
+    int EPT;
 } nir_duet_weights;
 size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w /*host*/);
 /* local_out / dist_out: optional [B,N] debug outputs (NULL to skip). Requires QL >= 3 and DL >= 7. */

@@ -807,17 +807,19 @@ def test_duet_presplit_planes_path_matches_default():
     _close(got, ref, 5e-6)
 
 
+@pytest.mark.parametrize("planes", [True, False])
 @pytest.mark.parametrize("B,N,QL,DL,pool", [(2, 3, 4, 290, 5), (3, 5, 5, 64, 5), (1, 2, 3, 7, 5), (2, 2, 4, 131, 3), (1, 3, 4, 66, 1)])
-def test_duet_fused_document_branch_matches_layer_chain(B, N, QL, DL, pool):
+def test_duet_fused_document_branch_matches_layer_chain(B, N, QL, DL, pool, planes):
     """The fused per-document-tile kernel (csrc/duet_fused.hip: conv_d1 -> pool -> conv_d2 -> Hadamard . fc2 on chip) against the
     GEMM-per-layer chain (tunable duet_unfused) and the oracle; tile counts 5 / 1 / 1 / 3 / 2 exercise the tile split and halos."""
     from context_attentive_ir_amd import lib
     V = 500
     m = build_model("DUET", vocab=V, device=DEV, max_query_len=QL, max_doc_len=DL, pool_size=pool)
+    m.table_planes = planes          # True: token tile as fp16 term planes by LDS-direct loads; False: fp32 rows split in the kernel
     rng = np.random.default_rng(DL + pool)
     q, ql, d, dl = _synth(rng, B, N, QL, DL, V)
     qd, qld, dd, dld = (t.to(DEV) for t in (q, ql, d, dl))
-    assert m._weights().struct.fw1 and m._weights().struct.K1P == 928
+    assert m._weights().struct.fw1 and m._weights().struct.K1P == 928 and bool(m._weights().struct.ftable) == planes
     s, loc, dist = m(qd, qld, dd, dld, return_parts=True)
     with lib.tunable("duet_unfused", 1, 0):
         s0, loc0, dist0 = m(qd, qld, dd, dld, return_parts=True)
@@ -827,13 +829,15 @@ def test_duet_fused_document_branch_matches_layer_chain(B, N, QL, DL, pool):
         _close(dist, O.duet_distributed(cpu_state_dict(m), q, d))
 
 
+@pytest.mark.parametrize("planes", [True, False])
 @pytest.mark.parametrize("E,NF,DL,pool", [(52, 128, 150, 4), (100, 320, 97, 5), (300, 60, 200, 2), (64, 300, 290, 5)])
-def test_duet_fused_other_widths(E, NF, DL, pool):
+def test_duet_fused_other_widths(E, NF, DL, pool, planes):
     """Fused document branch away from the reference's 300/300/5: embedding width (k tail of conv_d1: 3E not a multiple of 32),
     filter count (masked columns, 320 = no padding), window, flattened and per-document tilings -- against the layer chain."""
     from context_attentive_ir_amd import lib
     V, B, N, QL = 400, 2, 3, 4
     m = build_model("DUET", vocab=V, device=DEV, max_query_len=QL, max_doc_len=DL, pool_size=pool, emsize=E, nfilters=NF)
+    m.table_planes = planes
     rng = np.random.default_rng(E + NF)
     q, ql, d, dl = (t.to(DEV) for t in _synth(rng, B, N, QL, DL, V))
     assert m._weights().struct.fw1 and m._weights().struct.K1P == (3 * E + 31) // 32 * 32
