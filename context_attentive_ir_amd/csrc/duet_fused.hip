@@ -19,7 +19,6 @@
 // workgroup (4 waves, one per SIMD) per CU.  Tiles are cut from the FLATTENED (document, position) axis when documents are long
 // enough (a tile then touches at most two documents): 92 of 96 rows carry useful pooled rows.
 #include <algorithm>
-#include <cstdlib>
 #include <mutex>
 #include "common.hpp"
 
@@ -219,17 +218,29 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
     _Pragma("unroll") for (int i_ = 0; i_ < RT; ++i_) asm volatile("" ::"v"(AFC[i_][0]), "v"(AFC[i_][1]));
     // Plane mode runs its k-steps ROW TILE by row tile (15 MFMAs: 3 term products x 5 column tiles), not column tile by column tile: a row
     // tile's A fragments are then live for 15 MFMAs instead of the whole step and are double-buffered per row tile (16 registers instead
-    // of 32 RT), which is what lets the 96-row tile (240 accumulator AGPRs) fit.  Per step: the W fragments of the next step into the other
-    // set (term 1 first: the step's last five MFMAs read every term-0 fragment), the next row tile's fragments at MFMAs 5 and 7 of a row
-    // tile.  Every redefinition is preceded by an empty asm use of the old value, so the register is never free between its last MFMA
+    // of 32 RT), which is what lets the 96-row tile (240 accumulators) fit.  Per step: the W fragments of the next step into the other
+    // set, in the order the next step needs them and in its first third (all ten are read by the next step's first ten MFMAs), the next
+    // row tile's fragments at MFMAs 5 and 7 of a row tile.  Every redefinition is preceded by an empty asm use of the old value, so the register is never free between its last MFMA
     // read and its reload (the VALU-after-MFMA WAR hazard described below).
     // With 240 accumulator AGPRs out of 256 the register allocator starts rotating accumulator tuples through VGPRs around the asm MFMAs
     // (and reads them there before the MFMA has written them back): the last row tile of the 96-row kernel accumulates in VGPRs instead.
     constexpr int VACC = RT > 4 ? RT - 4 : 0;
+#ifndef DF_WSTRIDE
+#define DF_WSTRIDE 2
+#endif
+#ifndef DF_AFM
+#define DF_AFM 1
+#endif
+#ifndef DF_X_NOTILE       // timing ablations (tools/duet_micro.py): results are wrong with either set
+#define DF_X_NOTILE 0
+#endif
+#ifndef DF_X_NOBAR
+#define DF_X_NOBAR 0
+#endif
     f16x8 af[2][2];
 #define DF_STEPR(WC, WN, WNP, CURB, NXTB, TOFF, ROW, EXTRA)                               \
     {                                                                                     \
-        constexpr int WS_ = 15 * RT / 10;                                                 \
+        constexpr int WS_ = DF_WSTRIDE;          /* every fragment is needed in the first ten MFMAs of the next step: request early */ \
         _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 15 * RT; ++n_) {         \
             const int i_ = n_ / 15, m_ = n_ % 15, j_ = m_ % 5, b_ = i_ & 1;               \
             if (i_ >= RT - VACC) {                                                        \
@@ -243,13 +254,13 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             }                                                                             \
             EXTRA                                                                         \
             if (n_ >= 3 && (n_ - 3) % WS_ == 0 && (n_ - 3) / WS_ < 2 * DF_CT) {           \
-                const int k_ = (n_ - 3) / WS_, t_ = k_ < DF_CT ? 1 : 0, jj_ = k_ % DF_CT; \
+                const int k_ = (n_ - 3) / WS_, t_ = k_ < DF_CT ? 0 : 1, jj_ = k_ % DF_CT; \
                 asm volatile("" ::"v"(WN[jj_][t_]));                                      \
                 WN[jj_][t_] = *reinterpret_cast<const f16x8*>((WNP) + (jj_ * 2 + t_) * 512); \
             }                                                                             \
-            if (m_ == 4 || m_ == 6) asm volatile("" ::"v"(af[b_ ^ 1][m_ == 4 ? 1 : 0]));  \
-            if (m_ == 5 || m_ == 7) {                                                     \
-                const int tt_ = m_ == 5 ? 1 : 0;                                          \
+            if (m_ == DF_AFM - 1 || m_ == DF_AFM) asm volatile("" ::"v"(af[b_ ^ 1][m_ == DF_AFM - 1 ? 1 : 0]));  \
+            if (m_ == DF_AFM || m_ == DF_AFM + 1) {                                       \
+                const int tt_ = m_ == DF_AFM ? 1 : 0;                                     \
                 const unsigned char* fb_ = i_ + 1 < RT ? (CURB) : (NXTB);                 \
                 const int in_ = i_ + 1 < RT ? i_ + 1 : 0;                                 \
                 af[b_ ^ 1][tt_] = *reinterpret_cast<const f16x8*>(fb_ + tt_ * (TOFF) + ROW(in_)); \
@@ -354,6 +365,9 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         }
         // fc2 row weights of the tile's rows (used by the last epilogue): weight = fc2_w[t] for an own pooled row whose window stays inside
         // its document, else 0; slot 0 = the tile's first document, slot 1 = the next one
+        typedef __attribute__((address_space(3))) volatile int* lds_vint_t;
+        const lds_vint_t flag_s = (lds_vint_t)(lds_ptr_t)(Ab + p.ids_off + 1280);                  // [chunk]: waves whose requests have landed
+        if (tid < 32) flag_s[tid] = 0;
         if (tid < 16 * RT) {
             float* const ws_ = reinterpret_cast<float*>(Ab + p.ids_off + 512);
             int t = t00 + tid;
@@ -393,15 +407,25 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         }
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) DF_TILE_LOAD(k, 0)
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            if (1 < C) { DF_TILE_LOAD(k, 1) }
+        }
         DF_LOAD_W(w, wp1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0 is in LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunks 0 and 1 are in LDS
+        int fl_ = 0;
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 2; ++t) af[0][t] = *reinterpret_cast<const f16x8*>(Ab + t * 4 * RP * 16 + arow[0]);
         DF_T(1)
         // k-step (chunk CI, tap U): MFMAs on the current sets; W fragments of the next step; the next step's A fragments from (CI, U+1) or
-        // (CI+1, 0); chunk CI+1 requested in the first two MFMA slots of U = 0, 1 (in front of the step's W loads: at the top of U = 2 the
-        // ten W loads of step U = 1 are the only younger requests, s_waitcnt vmcnt(10) -> the chunk has landed)
+        // (CI+1, 0).  Requests complete in order, so a W fragment waits for every token-row request issued before it: chunk CI+2 is
+        // requested in steps U = 0, 1 of chunk CI BEHIND the step's W loads (the W fragments of the next step are never stuck behind a
+        // gather that may go to HBM; those of the step after have a step and a half of slack).  Hand-over without a barrier (ten barriers
+        // per tile cost 4.5 K of 52 K cycles: the waves drift apart on their W streams and a barrier turns the mean delay into the maximum):
+        // at the top of step U = 1 of chunk CI+1 a wave waits for ITS requests of chunk CI+2 (s_waitcnt vmcnt: 20 W loads + 2 requests
+        // are younger) and counts itself in an LDS flag; a step and a half later, before the first fragment read of chunk CI+2, every wave
+        // checks that the flag says four (it does unless a wave is more than a step behind; then it polls).
 #define DF_AROW(I) arow[I]
 #define DF_STEP1P(CB, CI, U, WC, WN)                                                      \
         {                                                                                 \
@@ -411,10 +435,21 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             const unsigned char* ac_ = (CB) + (U) * 16;                                   \
             const unsigned char* an_ = (U) < 2 ? (CB) + ((U) + 1) * 16 : (more_ ? (CB) + CHB : (CB) + 32); \
             DF_STEPR(WC, WN, wn_, ac_, an_, 4 * RP * 16, DF_AROW,                         \
-                     if ((U) < 2 && n_ < 2 && 2 * (U) + n_ < NSLOT) {                     \
-                         if (more_) { DF_TILE_LOAD(2 * (U) + n_, (CI) + 1) }              \
+                     if (!DF_X_NOTILE && (U) < 2 && (n_ == 24 || n_ == 26) && 2 * (U) + (n_ - 24) / 2 < NSLOT) { \
+                         if ((CI) + 2 < C) { DF_TILE_LOAD(2 * (U) + (n_ - 24) / 2, (CI) + 2) }   \
                      }                                                                    \
-                     if ((U) == 2 && n_ == 0) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");) \
+                     if (!DF_X_NOBAR && (U) == 1 && n_ == 0 && (CI) >= 1) {               \
+                         if ((CI) + 1 < C) {          /* publish: this wave's part of chunk CI+1 has landed */ \
+                             if ((CI) + 2 < C) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");  \
+                             else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");       \
+                             if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(size_t)(flag_s + (CI) + 1)), "v"(1) : "memory"); \
+                         }                                                                \
+                     }                                                                    \
+                     if (!DF_X_NOBAR && (U) == 2 && n_ == 15 * (RT - 1) - 14 && (CI) >= 1) fl_ = flag_s[(CI) + 1 < C ? (CI) + 1 : (CI)]; \
+                     if (!DF_X_NOBAR && (U) == 2 && n_ == 15 * (RT - 1) - 4 && (CI) >= 1 && (CI) + 1 < C) { \
+                         while (__builtin_amdgcn_readfirstlane(fl_) < 4) fl_ = flag_s[(CI) + 1];  \
+                         asm volatile("" ::: "memory");                                   \
+                     }) \
         }
         {
             const unsigned char* cb = Ab;
@@ -654,8 +689,7 @@ bool duet_doc_usable(int NF, int P, int E, int DL, int K1P) {
 // Rows per tile: with the table planes the tile is 96 rows when documents are long enough for flattened 96-row tiles (W fragments are
 // streamed once per tile: 1.5x fewer L2 bytes and MFMA-free epilogue cycles per row), else 64.
 int duet_doc_rows(bool planes, int DL, int P) {
-    static const bool tall = getenv("NIR_DUET_TALL") != nullptr;      // TODO(round 3): RT = 6 spills
-    return tall && planes && DL - 2 >= 96 - (P - 1) ? 96 : DF_ROWS;
+    return planes && !tun(g_tun.duet_rows64) && DL - 2 >= 96 - (P - 1) ? 96 : DF_ROWS;
 }
 
 size_t duet_doc_partial_floats(int64_t M, int DL, int P, bool planes) {
@@ -697,12 +731,12 @@ int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int
         } else if (rows == 96) {
             const size_t body = std::max((size_t)a.C * DfLayoutP<6>::CHB, (size_t)DfLayout<6>::P_HALVES * 2);
             a.ids_off = (int)body;
-            NIR_REQUIRE(body + 1536 <= 160 * 1024, "duet_doc: token tile of %d column chunks exceeds LDS", a.C);
+            NIR_REQUIRE(body + 1536 <= 160 * 1024 && a.C <= 32, "duet_doc: token tile of %d column chunks exceeds LDS", a.C);
             duet_doc_launch_t<6, true>(a, tiles, body + 1536, P, st);
         } else {
             const size_t body = std::max((size_t)a.C * DfLayoutP<DF_RT>::CHB, (size_t)DfLayout<DF_RT>::P_HALVES * 2);
             a.ids_off = (int)body;
-            NIR_REQUIRE(body + 1536 <= 160 * 1024, "duet_doc: token tile of %d column chunks exceeds LDS", a.C);
+            NIR_REQUIRE(body + 1536 <= 160 * 1024 && a.C <= 32, "duet_doc: token tile of %d column chunks exceeds LDS", a.C);
             duet_doc_launch_t<DF_RT, true>(a, tiles, body + 1536, P, st);
         }
     }

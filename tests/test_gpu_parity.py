@@ -825,6 +825,9 @@ def test_duet_fused_document_branch_matches_layer_chain(B, N, QL, DL, pool, plan
         s0, loc0, dist0 = m(qd, qld, dd, dld, return_parts=True)
     _close(dist, dist0, 5e-6)
     _close(s, s0, 5e-6)
+    if planes:                       # 96-row tiles (documents of >= 98 - pool positions) against 64-row tiles
+        with lib.tunable("duet_rows64", 1, 0):
+            _close(m(qd, qld, dd, dld), s, 2e-6)
     if pool == 5:
         _close(dist, O.duet_distributed(cpu_state_dict(m), q, d))
 
