@@ -27,6 +27,7 @@ namespace nir {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DF_NFP = 320;                 // filter columns (4 waves x 5 tiles x 16)
 constexpr int DF_CT = 5;                    // column tiles per wave
@@ -66,6 +67,9 @@ __device__ __forceinline__ void df_split_store(unsigned short* base, int kgs, in
 // tanh(x) for z = 2 log2(e) x already formed:  1 - 2 / (1 + 2^z)   (v_exp_f32, v_rcp_f32; saturates correctly at +-inf)
 constexpr float DF_2LOG2E = 2.8853900817779268f;
 __device__ __forceinline__ float df_tanh_z(float z) {
+#ifdef DF_X_NOTANH
+    return z;
+#endif
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), 1.0f);
 }
 
@@ -79,6 +83,9 @@ __device__ __forceinline__ float df_bperm(float v, int byte_idx) {
 // read by VALU code after DF_MMA_DRAIN.
 #define DF_MMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(W))
 #define DF_MMA_V(ACC, A, W) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(W))
+// first product of an accumulator chain: C = 0 (no zero fill of 240 registers between the two GEMMs)
+#define DF_MMA0(ACC, A, W) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(W))
+#define DF_MMA0_V(ACC, A, W) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "v"(W))
 #ifdef DF_TIMING
 __device__ long long df_dbg[16];
 #define DF_T(I) if (blockIdx.x == 3000 && threadIdx.x == 0) df_dbg[I] = __builtin_readcyclecounter();
@@ -238,19 +245,19 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
 #define DF_X_NOBAR 0
 #endif
     f16x8 af[2][2];
-#define DF_STEPR(WC, WN, WNP, CURB, NXTB, TOFF, ROW, EXTRA)                               \
+#define DF_STEPR(WC, WN, WNP, CURB, NXTB, TOFF, ROW, FIRST, EXTRA)                        \
     {                                                                                     \
         constexpr int WS_ = DF_WSTRIDE;          /* every fragment is needed in the first ten MFMAs of the next step: request early */ \
         _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 15 * RT; ++n_) {         \
             const int i_ = n_ / 15, m_ = n_ % 15, j_ = m_ % 5, b_ = i_ & 1;               \
             if (i_ >= RT - VACC) {                                                        \
-                if (m_ < 5) DF_MMA_V(acx[j_][i_], af[b_][1], WC[j_][0]);                  \
+                if (m_ < 5) { if (FIRST) DF_MMA0_V(acx[j_][i_], af[b_][1], WC[j_][0]); else DF_MMA_V(acx[j_][i_], af[b_][1], WC[j_][0]); } \
                 else if (m_ < 10) DF_MMA_V(acx[j_][i_], af[b_][0], WC[j_][1]);            \
-                else DF_MMA_V(acc[j_][i_], af[b_][0], WC[j_][0]);                         \
+                else { if (FIRST) DF_MMA0_V(acc[j_][i_], af[b_][0], WC[j_][0]); else DF_MMA_V(acc[j_][i_], af[b_][0], WC[j_][0]); } \
             } else {                                                                      \
-                if (m_ < 5) DF_MMA(acx[j_][i_], af[b_][1], WC[j_][0]);                    \
+                if (m_ < 5) { if (FIRST) DF_MMA0(acx[j_][i_], af[b_][1], WC[j_][0]); else DF_MMA(acx[j_][i_], af[b_][1], WC[j_][0]); } \
                 else if (m_ < 10) DF_MMA(acx[j_][i_], af[b_][0], WC[j_][1]);              \
-                else DF_MMA(acc[j_][i_], af[b_][0], WC[j_][0]);                           \
+                else { if (FIRST) DF_MMA0(acc[j_][i_], af[b_][0], WC[j_][0]); else DF_MMA(acc[j_][i_], af[b_][0], WC[j_][0]); } \
             }                                                                             \
             EXTRA                                                                         \
             if (n_ >= 3 && (n_ - 3) % WS_ == 0 && (n_ - 3) / WS_ < 2 * DF_CT) {           \
@@ -375,8 +382,8 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             t = s1 ? t - Tc : t;
             const bool ok = tid < (p.flat ? p.TS : p.TPv) && t < p.PL && doc0 + (s1 ? 1 : 0) < p.M;
             const float wv = ok ? p.fc2w[t] : 0.f;
-            ws_[tid] = s1 ? 0.f : wv;
-            ws_[16 * RT + tid] = s1 ? wv : 0.f;
+            ws_[2 * tid] = s1 ? 0.f : wv;           // interleaved {slot 0, slot 1}: one packed FMA per value in the epilogue
+            ws_[2 * tid + 1] = s1 ? wv : 0.f;
         }
         __syncthreads();
         // load slot k of this wave = pieces 64 (4k + wave) .. +63 of a chunk: piece -> (term, k-group, token row); pad pieces repeat the last one
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             const bool more_ = (CI) + 1 < C;                                              \
             const unsigned char* ac_ = (CB) + (U) * 16;                                   \
             const unsigned char* an_ = (U) < 2 ? (CB) + ((U) + 1) * 16 : (more_ ? (CB) + CHB : (CB) + 32); \
-            DF_STEPR(WC, WN, wn_, ac_, an_, 4 * RP * 16, DF_AROW,                         \
+            DF_STEPR(WC, WN, wn_, ac_, an_, 4 * RP * 16, DF_AROW, false,                  \
                      if (!DF_X_NOTILE && (U) < 2 && (n_ == 24 || n_ == 26) && 2 * (U) + (n_ - 24) / 2 < NSLOT) { \
                          if ((CI) + 2 < C) { DF_TILE_LOAD(2 * (U) + (n_ - 24) / 2, (CI) + 2) }   \
                      }                                                                    \
@@ -482,13 +489,33 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             const int col = 80 * wave + 16 * j + c16;
             const float biasz = (col < p.NF ? p.b1[col] : 0.f) * DF_2LOG2E;
             float v[RT][4], x[RT + 1][4];
+            if constexpr (PL) {                                            // packed fp32 math: the same operations, two values per issue slot
+                const f32x2 k1 = {1.0f / 2048.0f, 1.0f / 2048.0f}, k2 = {DF_2LOG2E, DF_2LOG2E}, b2 = {biasz, biasz}, one = {1.f, 1.f}, m2 = {-2.f, -2.f};
 #pragma unroll
-            for (int i = 0; i < RT; ++i)
+                for (int i = 0; i < RT; ++i) {
+                    const bool ag = i < RT - (RT > 4 ? RT - 4 : 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[i][r] = df_tanh_z(fmaf(fmaf(df_acc(acx[j][i], r, PL && i < RT - (RT > 4 ? RT - 4 : 0)), 1.0f / 2048.0f, df_acc(acc[j][i], r, PL && i < RT - (RT > 4 ? RT - 4 : 0))), DF_2LOG2E, biasz));
-                    x[i][r] = df_bperm(v[i][r], nb_idx);
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 ax = {df_acc(acx[j][i], 2 * h, ag), df_acc(acx[j][i], 2 * h + 1, ag)};
+                        const f32x2 ac = {df_acc(acc[j][i], 2 * h, ag), df_acc(acc[j][i], 2 * h + 1, ag)};
+                        const f32x2 z = __builtin_elementwise_fma(__builtin_elementwise_fma(ax, k1, ac), k2, b2);
+                        const f32x2 den = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + one;
+                        const f32x2 t2 = __builtin_elementwise_fma(m2, f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])}, one);
+                        v[i][2 * h] = t2[0];
+                        v[i][2 * h + 1] = t2[1];
+                        x[i][2 * h] = df_bperm(t2[0], nb_idx);
+                        x[i][2 * h + 1] = df_bperm(t2[1], nb_idx);
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[i][r] = df_tanh_z(fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), DF_2LOG2E, biasz));
+                        x[i][r] = df_bperm(v[i][r], nb_idx);
+                    }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[RT][r] = x[RT - 1][r];           // rows past the tile: the last P-1 pooled rows are never used
             const int sk = col >> 5, kg = (col >> 3) & 3, e = col & 6, odd = col & 1;
@@ -524,7 +551,8 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
                     const float got = dpp_mov<0xB1>(give);
                     const float lo = odd ? got : mine, hi = odd ? mine : got;
                     const fp16x2_t h1 = __builtin_amdgcn_cvt_pkrtz(lo, hi);
-                    const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz((lo - (float)h1[0]) * 2048.0f, (hi - (float)h1[1]) * 2048.0f);
+                    const f32x2 rs = (f32x2{lo, hi} - f32x2{(float)h1[0], (float)h1[1]}) * f32x2{2048.0f, 2048.0f};      // v_pk_add / v_pk_mul
+                    const fp16x2_t h2 = __builtin_amdgcn_cvt_pkrtz(rs[0], rs[1]);
                     const int row = 16 * i + 4 * g + 2 * hh + odd;
                     *reinterpret_cast<unsigned*>(dst + row * 8) = __builtin_bit_cast(unsigned, h1);
                     *reinterpret_cast<unsigned*>(dst + DF_S2 * 4 * KG + row * 8) = __builtin_bit_cast(unsigned, h2);
@@ -533,13 +561,15 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!PL) {
 #pragma unroll
-    for (int j = 0; j < DF_CT; ++j)
+        for (int j = 0; j < DF_CT; ++j)
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int i = 0; i < RT; ++i) {
+                acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
     __builtin_amdgcn_sched_barrier(0);
     DF_LOAD_W(w, wp2)
     __syncthreads();
@@ -573,19 +603,21 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         DF_KEEP(WC, AFC)                                                                  \
     }
 #define DF_PROW(I) ((I) * 256)
-#define DF_STEP2R(S, WC, WN)                                                              \
+#define DF_STEP2R(S, WC, WN, FIRST)                                                       \
     {                                                                                     \
         const int sn_ = (S) + 1 < DF_S2 ? (S) + 1 : DF_S2 - 1;                            \
         const _Float16* wn_ = wp2 + (int64_t)sn_ * WSTEP;                                 \
         const unsigned char* pc_ = reinterpret_cast<const unsigned char*>(Pp + (S) * 4 * KG + foff);  \
         const unsigned char* pn_ = reinterpret_cast<const unsigned char*>(Pp + sn_ * 4 * KG + foff);  \
-        DF_STEPR(WC, WN, wn_, pc_, pn_, DF_S2 * 4 * KG * 2, DF_PROW, )                    \
+        DF_STEPR(WC, WN, wn_, pc_, pn_, DF_S2 * 4 * KG * 2, DF_PROW, FIRST, )             \
     }
     if constexpr (PL) {
+        DF_STEP2R(0, w, wb, true)            // starts every accumulator chain (C = 0)
+        DF_STEP2R(1, wb, w, false)
 #pragma unroll 1
-        for (int s2 = 0; s2 < DF_S2; s2 += 2) {
-            DF_STEP2R(s2, w, wb)
-            DF_STEP2R(s2 + 1, wb, w)
+        for (int s2 = 2; s2 < DF_S2; s2 += 2) {
+            DF_STEP2R(s2, w, wb, false)
+            DF_STEP2R(s2 + 1, wb, w, false)
         }
     } else {
 #pragma unroll 1
@@ -624,19 +656,39 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             const int col = 80 * wave + 16 * j + c16;
             const float biasz = (col < p.NF ? p.b2[col] : 0.f) * DF_2LOG2E;
             float sum = 0.f, sum1 = 0.f;
+            if constexpr (PL) {
+                // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot; one wave per SIMD, the epilogue is issue-bound)
+                f32x2 s2 = {0.f, 0.f};
+                const f32x2 k1 = {1.0f / 2048.0f, 1.0f / 2048.0f}, k2 = {DF_2LOG2E, DF_2LOG2E}, b2 = {biasz, biasz};
+                const f32x2 one = {1.f, 1.f}, m2 = {-2.f, -2.f};
 #pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                f32x4 wa, wb1;
-                if constexpr (PL) {
-                    wa = *reinterpret_cast<const f32x4*>(wrow_s + 16 * i + 4 * g);
-                    wb1 = *reinterpret_cast<const f32x4*>(wrow_s + 16 * RT + 16 * i + 4 * g);
-                }
+                for (int i = 0; i < RT; ++i) {
+                    const bool ag = i < RT - (RT > 4 ? RT - 4 : 0);
+                    const f32x4 wlo = *reinterpret_cast<const f32x4*>(wrow_s + 2 * (16 * i + 4 * g));        // rows 4g, 4g+1: {w, w1, w, w1}
+                    const f32x4 whi = *reinterpret_cast<const f32x4*>(wrow_s + 2 * (16 * i + 4 * g) + 4);    // rows 4g+2, 4g+3
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d2 = df_tanh_z(fmaf(fmaf(df_acc(acx[j][i], r, PL && i < RT - (RT > 4 ? RT - 4 : 0)), 1.0f / 2048.0f, df_acc(acc[j][i], r, PL && i < RT - (RT > 4 ? RT - 4 : 0))), DF_2LOG2E, biasz));
-                    sum = fmaf(PL ? wa[r] : wrow[PL ? 0 : i][r], d2, sum);
-                    sum1 = fmaf(PL ? wb1[r] : w1row[PL ? 0 : i][r], d2, sum1);
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 ax = {df_acc(acx[j][i], 2 * h, ag), df_acc(acx[j][i], 2 * h + 1, ag)};
+                        const f32x2 ac = {df_acc(acc[j][i], 2 * h, ag), df_acc(acc[j][i], 2 * h + 1, ag)};
+                        const f32x2 z = __builtin_elementwise_fma(__builtin_elementwise_fma(ax, k1, ac), k2, b2);
+                        const f32x2 den = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + one;
+                        const f32x2 d2 = __builtin_elementwise_fma(m2, f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])}, one);
+                        const f32x4 wq = h ? whi : wlo;
+                        s2 = __builtin_elementwise_fma(f32x2{wq[0], wq[1]}, f32x2{d2[0], d2[0]}, s2);
+                        s2 = __builtin_elementwise_fma(f32x2{wq[2], wq[3]}, f32x2{d2[1], d2[1]}, s2);
+                    }
                 }
+                sum = s2[0];
+                sum1 = s2[1];
+            } else {
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d2 = df_tanh_z(fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), DF_2LOG2E, biasz));
+                        sum = fmaf(wrow[i][r], d2, sum);
+                        sum1 = fmaf(w1row[i][r], d2, sum1);
+                    }
             }
             sum += df_bperm(sum, ((lane + 16) & 63) * 4);
             sum += df_bperm(sum, ((lane + 32) & 63) * 4);
