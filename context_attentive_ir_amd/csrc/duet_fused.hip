@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
 #ifndef DF_AFM
 #define DF_AFM 1
 #endif
+#ifndef DF_ROT            // 1: every workgroup starts its k walk at its own chunk (measured: no effect, see below); 0: canonical k order
+#define DF_ROT 0
+#endif
 #ifndef DF_X_NOTILE       // timing ablations (tools/duet_micro.py): results are wrong with either set
 #define DF_X_NOTILE 0
 #endif
@@ -361,29 +364,39 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         typedef __attribute__((address_space(3))) void* lds_ptr_t;
         unsigned char* const Ab = reinterpret_cast<unsigned char*>(dsm);
         int* const ids_s = reinterpret_cast<int*>(Ab + p.ids_off);
-        const int C = p.C, S1c = 3 * p.C;
+        const int C = p.C;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        {
-            const int64_t F0 = doc0 * p.DL + t00, Fm = p.M * p.DL - 1;       // token row i of the tile = flattened token F0 + i (clamped)
-            for (int i = tid; i < RP; i += 256) {
-                const int64_t f = F0 + i;
-                ids_s[i] = (int)p.d_ids[f < Fm ? f : Fm];
-            }
-        }
-        // fc2 row weights of the tile's rows (used by the last epilogue): weight = fc2_w[t] for an own pooled row whose window stays inside
-        // its document, else 0; slot 0 = the tile's first document, slot 1 = the next one
+        // The 256 workgroups stream the same W fragments (the GEMM phases run at ~1 650 cycles per 96-row k-step against 1 440 of MFMA
+        // issue: 40 KB of fragments per step and CU, ~13 TB/s of L2 reads chip-wide).  DF_ROT = 1 lets every workgroup walk the column
+        // chunks (and GEMM 2 its k-steps) from its own starting point -- logical chunk ci is column chunk ci + rot (mod C) -- in case the
+        // limit were workgroups asking the same L2 channels for the same lines at the same time: no difference (2.00 vs 2.00 ms), off.
+        const int rot1 = DF_ROT ? (int)(blockIdx.x % (unsigned)C) : 0;
+#define DF_PHYS1(CI_) ((CI_) + rot1 < C ? (CI_) + rot1 : (CI_) + rot1 - C)
+        // Everything the prologue reads from memory that does not depend on the token ids is requested first, with branch-free (clamped)
+        // addresses -- a predicated load is its own exec-masked block with s_waitcnt vmcnt(0) behind it: the tile's token ids, the fc2
+        // row weights (used by the last epilogue: weight = fc2_w[t] for an own pooled row whose window stays inside its document, else
+        // 0; slot 0 = the tile's first document, slot 1 = the next one) and the W fragments of step 0 share one round trip.
         typedef __attribute__((address_space(3))) volatile int* lds_vint_t;
         const lds_vint_t flag_s = (lds_vint_t)(lds_ptr_t)(Ab + p.ids_off + 1280);                  // [chunk]: waves whose requests have landed
-        if (tid < 32) flag_s[tid] = 0;
-        if (tid < 16 * RT) {
-            float* const ws_ = reinterpret_cast<float*>(Ab + p.ids_off + 512);
-            int t = t00 + tid;
+        {
+            static_assert(RP <= 256, "one token id per thread");
+            const int64_t F0 = doc0 * p.DL + t00, Fm = p.M * p.DL - 1;       // token row i of the tile = flattened token F0 + i (clamped)
+            const int64_t f = F0 + (tid < RP ? tid : RP - 1);
+            const int idv = (int)p.d_ids[f < Fm ? f : Fm];
+            const int tr = tid < 16 * RT ? tid : 16 * RT - 1;
+            int t = t00 + tr;
             const bool s1 = p.flat && t >= Tc;
             t = s1 ? t - Tc : t;
-            const bool ok = tid < (p.flat ? p.TS : p.TPv) && t < p.PL && doc0 + (s1 ? 1 : 0) < p.M;
-            const float wv = ok ? p.fc2w[t] : 0.f;
-            ws_[2 * tid] = s1 ? 0.f : wv;           // interleaved {slot 0, slot 1}: one packed FMA per value in the epilogue
-            ws_[2 * tid + 1] = s1 ? wv : 0.f;
+            const bool ok = tr < (p.flat ? p.TS : p.TPv) && t < p.PL && doc0 + (s1 ? 1 : 0) < p.M;
+            const float wv_ = p.fc2w[ok ? t : 0] * (ok ? 1.0f : 0.0f);
+            DF_LOAD_W(w, wp1 + (int64_t)(3 * DF_PHYS1(0)) * WSTEP)
+            if (tid < 32) flag_s[tid] = 0;
+            if (tid < RP) ids_s[tid] = idv;
+            if (tid < 16 * RT) {
+                float* const ws_ = reinterpret_cast<float*>(Ab + p.ids_off + 512);
+                ws_[2 * tid] = s1 ? 0.f : wv_;          // interleaved {slot 0, slot 1}: one packed FMA per value in the epilogue
+                ws_[2 * tid + 1] = s1 ? wv_ : 0.f;
+            }
         }
         __syncthreads();
         // load slot k of this wave = pieces 64 (4k + wave) .. +63 of a chunk: piece -> (term, k-group, token row); pad pieces repeat the last one
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)dsm;
 #define DF_TILE_LOAD(K, CC)                                                                                     \
         if (4 * (K) + wv < NI) {                                                                                \
-            const _Float16* g_ = gb[K] + (CC) * 32;                                                             \
+            const _Float16* g_ = gb[K] + DF_PHYS1(CC) * 32;                                                     \
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds0 + (CC) * CHB + (4 * (K) + wv) * 1024), "v"(g_) \
                          : "memory", "m0");                                                                     \
         }
@@ -418,7 +431,6 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         for (int k = 0; k < NSLOT; ++k) {
             if (1 < C) { DF_TILE_LOAD(k, 1) }
         }
-        DF_LOAD_W(w, wp1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunks 0 and 1 are in LDS
         int fl_ = 0;
         __syncthreads();
@@ -436,9 +448,9 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
 #define DF_AROW(I) arow[I]
 #define DF_STEP1P(CB, CI, U, WC, WN)                                                      \
         {                                                                                 \
-            const int sn_ = 3 * (CI) + (U) + 1 < S1c ? 3 * (CI) + (U) + 1 : S1c - 1;      \
-            const _Float16* wn_ = wp1 + (int64_t)sn_ * WSTEP;                             \
             const bool more_ = (CI) + 1 < C;                                              \
+            const int sn_ = (U) < 2 ? 3 * DF_PHYS1(CI) + (U) + 1 : (more_ ? 3 * DF_PHYS1((CI) + 1) : 3 * DF_PHYS1(CI) + 2); \
+            const _Float16* wn_ = wp1 + (int64_t)sn_ * WSTEP;                             \
             const unsigned char* ac_ = (CB) + (U) * 16;                                   \
             const unsigned char* an_ = (U) < 2 ? (CB) + ((U) + 1) * 16 : (more_ ? (CB) + CHB : (CB) + 32); \
             DF_STEPR(WC, WN, wn_, ac_, an_, 4 * RP * 16, DF_AROW, false,                  \
@@ -571,11 +583,12 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             }
     }
     __builtin_amdgcn_sched_barrier(0);
-    DF_LOAD_W(w, wp2)
+    const int rot2 = PL && DF_ROT ? (int)(blockIdx.x % (unsigned)DF_S2) : 0;
+    DF_LOAD_W(w, wp2 + (int64_t)rot2 * WSTEP)
     __syncthreads();
     if constexpr (PL) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) af[0][t] = *reinterpret_cast<const f16x8*>(Pp + t * DF_S2 * 4 * KG + foff);
+        for (int t = 0; t < 2; ++t) af[0][t] = *reinterpret_cast<const f16x8*>(Pp + rot2 * 4 * KG + t * DF_S2 * 4 * KG + foff);
     } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -603,11 +616,12 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         DF_KEEP(WC, AFC)                                                                  \
     }
 #define DF_PROW(I) ((I) * 256)
+#define DF_PHYS2(S_) ((S_) + rot2 < DF_S2 ? (S_) + rot2 : (S_) + rot2 - DF_S2)
 #define DF_STEP2R(S, WC, WN, FIRST)                                                       \
     {                                                                                     \
-        const int sn_ = (S) + 1 < DF_S2 ? (S) + 1 : DF_S2 - 1;                            \
+        const int sc_ = DF_PHYS2(S), sn_ = DF_PHYS2((S) + 1 < DF_S2 ? (S) + 1 : DF_S2 - 1); \
         const _Float16* wn_ = wp2 + (int64_t)sn_ * WSTEP;                                 \
-        const unsigned char* pc_ = reinterpret_cast<const unsigned char*>(Pp + (S) * 4 * KG + foff);  \
+        const unsigned char* pc_ = reinterpret_cast<const unsigned char*>(Pp + sc_ * 4 * KG + foff);  \
         const unsigned char* pn_ = reinterpret_cast<const unsigned char*>(Pp + sn_ * 4 * KG + foff);  \
         DF_STEPR(WC, WN, wn_, pc_, pn_, DF_S2 * 4 * KG * 2, DF_PROW, FIRST, )             \
     }
