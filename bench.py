@@ -242,6 +242,13 @@ def precompute_info(wrapper, c):
         def build():
             return list(net._folded_tables(net._weights()))
         caches = (net._fold,)
+    elif kind == "duet" and getattr(net, "table_planes", False) and getattr(net, "fuse_document_branch", False):
+        # fused DUET document kernel in plane mode (csrc/duet_fused.hip): the embedding table as fp16 term planes [V, 2, E -> 64k], built with the
+        # rest of the weight pack, once per weight version
+        def build():
+            pk = net._weights()
+            return [pk.keep[k] for k in ("ftable", "fw1c") if k in pk.keep]
+        caches = (net._pack,)
     else:
         return None
     build()

@@ -14,10 +14,17 @@
 // A second tiny kernel folds the tiles of a document: m1[pair][f] = tanh(fc2_b + qv[b][f] * sum partial).
 // Arithmetic: two-term fp16 split (x = h1 + 2^-11 h2', three v_mfma_f32_16x16x32_f16 per k-block, two accumulator sets) as in
 // gemm3_kernel<., true> -- needs |table|, |weights| < 2^15 (host-checked `bounded`); activations are tanh outputs.
-// The kernel is bound by the W stream out of L2 (measured with 64-row tiles: TCC busy 95 %, 13 TB/s of L2 reads, MFMA pipe 39 %),
-// so the tile is as tall as the register file and LDS allow: 96 rows = 240 accumulator AGPRs per lane and 150 KB of LDS, one
-// workgroup (4 waves, one per SIMD) per CU.  Tiles are cut from the FLATTENED (document, position) axis when documents are long
-// enough (a tile then touches at most two documents): 92 of 96 rows carry useful pooled rows.
+// The GEMM phases are bound by the W stream out of L2 (every CU streams all of W1 / W2 per tile: 40 KB per k-step; measured with 64-row
+// tiles: TCC busy 95 %, 13 TB/s of L2 reads), so the tile is as tall as registers and LDS allow, one workgroup (4 waves, one per SIMD)
+// per CU.  Two forms of GEMM 1:
+//   * plane mode (the pack carries the embedding table as fp16 term planes, nir_duet_weights.ftable): the tile's token rows are ONE
+//     contiguous range of the flattened id array; they are brought into LDS once (not once per tap), by LDS-direct loads that need no
+//     registers and no split arithmetic, two column chunks ahead of their use, and handed over through an LDS flag instead of a
+//     barrier.  k-steps run row tile by row tile (A fragments double-buffered per row tile), which leaves room for 96-row tiles
+//     (documents of >= 98 - pool positions; 64 rows otherwise): 160 accumulator AGPRs + 80 accumulator VGPRs, 133 KB of LDS.
+//   * fp32 table (no planes): 64-row tiles, the rows of a k-step are gathered per tap, split on the way into LDS, one barrier per step.
+// Tiles are cut from the FLATTENED (document, position) axis when documents are long enough (a tile then touches at most two
+// documents): 92 of 96 rows carry useful pooled rows.
 #include <algorithm>
 #include <mutex>
 #include "common.hpp"
@@ -791,7 +798,7 @@ int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int
     int64_t tiles;
     duet_doc_tiling(M, DL, P, rows, &a, &tiles);
     {
-        ProfScope ps(prof_shape_name(planes ? "duet_doc_kernel_pl" : "duet_doc_kernel", tiles * rows, NF, 3 * E), st);
+        ProfScope ps(prof_shape_name("duet_doc_kernel", tiles * rows, NF, 3 * E), st);
         if (!planes) {
             duet_doc_launch_t<DF_RT, false>(a, tiles, DfLayout<DF_RT>::LDS, P, st);
         } else if (rows == 96) {
