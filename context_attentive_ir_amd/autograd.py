@@ -104,6 +104,34 @@ def linear(x, weight, bias=None, act=None):
 _ID_FLAGS = {}
 
 
+class _Im2colRows(Function):
+    """[M,C,H,W] -> patch rows [M*H*W, C*kh*kw] of a stride-1 'same' convolution (the A operand of the filter GEMM) and back."""
+
+    @staticmethod
+    def forward(ctx, x, kh, kw, ph, pw):
+        xc = _f32c(x)
+        M, C, H, W = xc.shape
+        out = torch.empty(M * H * W, C * kh * kw, dtype=torch.float32, device=xc.device)
+        lib.check(lib.load().nir_im2col_rows_f32(lib.ptr(xc), M, C, H, W, kh, kw, ph, pw, lib.ptr(out), lib.stream()), "nir_im2col_rows_f32")
+        ctx.geom = (M, C, H, W, kh, kw, ph, pw)
+        return out
+
+    @staticmethod
+    def backward(ctx, drows):
+        M, C, H, W, kh, kw, ph, pw = ctx.geom
+        d = _f32c(drows)
+        dx = torch.empty(M, C, H, W, dtype=torch.float32, device=d.device)
+        lib.check(lib.load().nir_col2im_rows_f32(lib.ptr(d), M, C, H, W, kh, kw, ph, pw, lib.ptr(dx), lib.stream()), "nir_col2im_rows_f32")
+        return dx, None, None, None, None
+
+
+def im2col_rows(x, kernel_size, padding):
+    """Patch rows of Conv2d(kernel_size, stride 1, padding) over x [M,C,H,W]: [M*H*W, C*kh*kw] with k = (c, dy, dx) like conv.weight.reshape(out, -1)."""
+    (kh, kw), (ph, pw) = kernel_size, padding
+    lib.require_device(x)
+    return _Im2colRows.apply(x, int(kh), int(kw), int(ph), int(pw))
+
+
 def id_flag(device):
     """device int32 flag the train-mode lookups set for an id outside [0, V) (the reference's nn.Embedding raises IndexError)"""
     f = _ID_FLAGS.get(str(device))

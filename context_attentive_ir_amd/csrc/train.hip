@@ -645,6 +645,85 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* 
 
 static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
+// ---- im2col as ROWS (training forwards of the 2-D convolutions, rankers/mtensor.py:108-121): out[(m, y, x)][(c, dy, dx)] =
+// in[m, c, y + dy - ph, x + dx - pw] (0 outside), stride 1, "same" geometry (2 ph = kh - 1, 2 pw = kw - 1) -- the A operand of the
+// filter GEMM, in ONE launch.  (F.unfold runs one im2col kernel per sample -- 960 launches per MatchTensor step at C2 -- and yields
+// [M, K, L], which the GEMM needs transposed: one more copy of the largest tensor of the step.)  k is the fastest output index: coalesced
+// stores; the loads walk a [C, H, W] block that stays in L1 / L2.
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ in, int C, int H, int W, int kh, int kw, int ph, int pw,
+                                                          float* __restrict__ out) {
+    // one workgroup per (m, y): a thread owns patch columns k = tid, tid + 256, .. (its (c, dy, dx) and source row are found once per k,
+    // 32-bit arithmetic) and walks x: the W stores of a wave instruction are 64 consecutive k of one output row
+    const int64_t m = blockIdx.x / H;
+    const int y = (int)(blockIdx.x - m * H);
+    const int K = C * kh * kw;
+    float* const orow = out + ((m * H + y) * (int64_t)W) * K;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int c = k / (kh * kw), r = k - c * kh * kw, dy = r / kw, dx = r - dy * kw;
+        const int yy = y + dy - ph, x0 = dx - pw;
+        const bool rowok = yy >= 0 && yy < H;
+        const float* const src = in + ((m * C + c) * H + (rowok ? yy : 0)) * (int64_t)W;
+        for (int x = 0; x < W; ++x) {
+            const int xx = x + x0;
+            const bool ok = rowok && xx >= 0 && xx < W;
+            const float v = src[ok ? xx : 0];                                  // clamped address, no predicated load
+            orow[(int64_t)x * K + k] = ok ? v : 0.f;
+        }
+    }
+}
+
+// Its backward (col2im from rows): din[m, c, y, x] = sum over (dy, dx) of drows[(m, y - dy + ph, x - dx + pw)][(c, dy, dx)].  One workgroup
+// per (m, y), channels in groups of CG: for every tap row dy it stages the [W][CG * kw] slice of the source row y - dy + ph in LDS
+// (coalesced runs of kw floats) and every thread sums its (c, x) outputs over dx in a fixed order -- deterministic (no atomics), no
+// transposed copy of drows, one coalesced store per output.
+constexpr int C2I_MAXOUT = 8;                                 // outputs per thread and channel group: CG * W <= 2048
+__global__ __launch_bounds__(256) void col2im_rows_kernel(const float* __restrict__ drows, int C, int H, int W, int kh, int kw, int ph, int pw, int CG,
+                                                          float* __restrict__ din) {
+    extern __shared__ float c2i_slice[];                     // [W][CG * kw | 1]
+    const int64_t m = blockIdx.x / H;
+    const int y = (int)(blockIdx.x - m * H);
+    const int K = C * kh * kw;
+    for (int c0 = 0; c0 < C; c0 += CG) {
+        const int cg = C - c0 < CG ? C - c0 : CG, per = cg * kw, nout = cg * W;
+        const int perp = per | 1;                            // odd row stride: the sums below read a column of the slice (x varies across the lanes)
+        float acc[C2I_MAXOUT];
+#pragma unroll
+        for (int j = 0; j < C2I_MAXOUT; ++j) acc[j] = 0.f;
+        for (int dy = 0; dy < kh; ++dy) {
+            const int ys = y - dy + ph;                      // source row whose tap dy lands on y (uniform)
+            if (ys < 0 || ys >= H) continue;
+            const float* src = drows + ((m * H + ys) * (int64_t)W) * K + (int64_t)c0 * kh * kw + dy * kw;
+            __syncthreads();
+            for (int i = threadIdx.x; i < W * per; i += 256) {
+                const int xs = i / per, q = i - xs * per, cl = q / kw, dx = q - cl * kw;
+                c2i_slice[xs * perp + q] = src[(int64_t)xs * K + cl * kh * kw + dx];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < C2I_MAXOUT; ++j) {
+                const int o = threadIdx.x + 256 * j;
+                if (o < nout) {
+                    const int cl = o / W, x = o - cl * W;
+                    float a = acc[j];
+                    for (int dx = 0; dx < kw; ++dx) {
+                        const int xs = x - dx + pw;
+                        if (xs >= 0 && xs < W) a += c2i_slice[xs * perp + cl * kw + dx];
+                    }
+                    acc[j] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C2I_MAXOUT; ++j) {
+            const int o = threadIdx.x + 256 * j;
+            if (o < nout) {
+                const int cl = o / W, x = o - cl * W;
+                din[((m * C + c0 + cl) * H + y) * W + x] = acc[j];
+            }
+        }
+    }
+}
+
 }  // namespace nir
 
 extern "C" int nir_lstm_cell_fwd(const float* gates, const float* c_prev, float* act, float* c, float* h, int64_t B, int H, nir_stream_t stream) {
@@ -814,5 +893,31 @@ extern "C" int nir_embed_bwd_f32(const int64_t* ids, const float* dout, int64_t 
     if (M == 0) return 0;
     hipLaunchKernelGGL(embed_bwd_kernel, g1(M * E), dim3(256), 0, (hipStream_t)stream, ids, dout, V, E, M, dtable, pad_idx);
     NIR_CHECK_LAUNCH("embed_bwd_kernel");
+    return 0;
+}
+extern "C" int nir_im2col_rows_f32(const float* in, int64_t M, int C, int H, int W, int kh, int kw, int ph, int pw, float* out, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(in && out && M >= 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0, "im2col_rows: bad args");
+    NIR_REQUIRE(2 * ph == kh - 1 && 2 * pw == kw - 1, "im2col_rows: only the 'same' geometry (2 pad = kernel - 1, stride 1); got kernel %dx%d pad %dx%d", kh, kw, ph, pw);
+    if (M == 0) return 0;
+    NIR_REQUIRE(M * H < (int64_t)1 << 31, "im2col_rows: too many rows for one launch");
+    ProfScope ps("im2col_rows_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(im2col_rows_kernel, dim3((unsigned)(M * H)), dim3(256), 0, (hipStream_t)stream, in, C, H, W, kh, kw, ph, pw, out);
+    NIR_CHECK_LAUNCH("im2col_rows_kernel");
+    return 0;
+}
+extern "C" int nir_col2im_rows_f32(const float* drows, int64_t M, int C, int H, int W, int kh, int kw, int ph, int pw, float* din, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(drows && din && M >= 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0, "col2im_rows: bad args");
+    NIR_REQUIRE(2 * ph == kh - 1 && 2 * pw == kw - 1, "col2im_rows: only the 'same' geometry (2 pad = kernel - 1, stride 1)");
+    NIR_REQUIRE(W <= 2048 && kw <= 256 && (size_t)W * kw * 4 <= 64 * 1024, "col2im_rows: W = %d x kw = %d exceeds the LDS slice", W, kw);
+    if (M == 0) return 0;
+    NIR_REQUIRE(M * H < (int64_t)1 << 31, "col2im_rows: too many rows for one launch");
+    int CG = std::min(C, std::min(2048 / W, (16384 / W - 1) / kw));      // outputs per thread <= 8, slice <= 64 KB
+    CG = CG < 1 ? 1 : CG;
+    ProfScope ps("col2im_rows_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(col2im_rows_kernel, dim3((unsigned)(M * H)), dim3(256), (size_t)W * (CG * kw | 1) * 4, (hipStream_t)stream, drows, C, H, W, kh, kw, ph, pw, CG,
+                       din);
+    NIR_CHECK_LAUNCH("col2im_rows_kernel");
     return 0;
 }

@@ -136,6 +136,8 @@ SIGNATURES = {
     "nir_dropout_dev_f32": (_i, [c_fp, c_fp, C.c_void_p, _l, C.c_float, C.c_void_p, C.c_uint64, c_st]),
     "nir_mask_scale_f32": (_i, [c_fp, C.c_void_p, C.c_float, c_fp, _l, c_st]),
     "nir_act_bwd_f32": (_i, [c_fp, c_fp, c_fp, _l, _i, c_st]),
+    "nir_im2col_rows_f32": (_i, [c_fp, _l, _i, _i, _i, _i, _i, _i, _i, c_fp, c_st]),
+    "nir_col2im_rows_f32": (_i, [c_fp, _l, _i, _i, _i, _i, _i, _i, _i, c_fp, c_st]),
     "nir_rank_loss_bce_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, _l, c_st]),
     "nir_embed_f32": (_i, [c_ip, c_fp, _l, _i, _l, c_fp, C.c_void_p, c_st]),
     "nir_embed_bwd_f32": (_i, [c_ip, c_fp, _l, _i, _l, c_fp, _l, c_st]),

@@ -68,8 +68,11 @@ def train_head(mod, q, d, pq, pd):
     feats = []
     for conv in (mod.conv1, mod.conv2, mod.conv3):
         kh, kw = conv.kernel_size
-        cols = F.unfold(T, (kh, kw), padding=conv.padding)                                 # [M,(C+1)*kh*kw,QL*DL]
-        rows = cols.transpose(1, 2).reshape(M * QL * DL, -1)
+        if 2 * conv.padding[0] == kh - 1 and 2 * conv.padding[1] == kw - 1 and DL * kw * 4 <= 65536:
+            rows = A.im2col_rows(T, (kh, kw), conv.padding)                                # [M*QL*DL,(C+1)*kh*kw], one launch (HIP)
+        else:
+            cols = F.unfold(T, (kh, kw), padding=conv.padding)                             # [M,(C+1)*kh*kw,QL*DL]
+            rows = cols.transpose(1, 2).reshape(M * QL * DL, -1)
         feats.append(A.linear(rows, conv.weight.reshape(conv.out_channels, -1), conv.bias, act="relu"))
     g = A.linear(torch.cat(feats, 1), mod.conv.weight.reshape(mod.conv.out_channels, -1), mod.conv.bias)
     g = g.view(M, QL * DL, -1).max(1)[0]
@@ -145,7 +148,7 @@ class MatchTensor(nn.Module, lib.IdCheck):
     def _forward_train(self, q, ql, d, dl):
         """Train-mode forward (mtensor.py:62-131 with dropout active), differentiable: lookups, projections, both BiLSTMs, the
         three convolutions (im2col rows x filter matrix), the 1x1 convolution and the output layer run on the HIP operators of
-        autograd.py; the broadcast product, the exact-match comparison, im2col (F.unfold: data movement) and the global max are
+        autograd.py, im2col included (patch rows in one launch); the broadcast product, the exact-match comparison and the global max are
         tensor glue."""
         B, QL = q.shape
         N, DL = d.shape[1], d.shape[2]

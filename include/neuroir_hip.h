@@ -511,6 +511,11 @@ int nir_dropout_f32(const float* x, float* y, unsigned char* keep, int64_t n, fl
 int nir_dropout_dev_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, const uint64_t* seed_dev, uint64_t salt,
                         nir_stream_t stream);
 int nir_mask_scale_f32(const float* x, const unsigned char* keep, float scale, float* y, int64_t n, nir_stream_t stream);
+/* im2col as ROWS for the training forwards of the 2-D convolutions (neuroir/rankers/mtensor.py:108-121: Conv2d 3x3 / 3x5 / 3x7 over the
+ * [M, C, QL, DL] match tensor): out[(m, y, x)][(c, dy, dx)] = in[m, c, y+dy-ph, x+dx-pw] (0 outside), stride 1, 2 ph = kh-1, 2 pw = kw-1
+ * -- the A operand [M H W, C kh kw] of the filter GEMM in one launch; and its backward, din[M, C, H, W] from drows (no atomics on HBM). */
+int nir_im2col_rows_f32(const float* in, int64_t M, int C, int H, int W, int kh, int kw, int ph, int pw, float* out, nir_stream_t stream);
+int nir_col2im_rows_f32(const float* drows, int64_t M, int C, int H, int W, int kh, int kw, int ph, int pw, float* din, nir_stream_t stream);
 /* dx = dy * f'(.) expressed through y = f(x): act 1 tanh, 2 relu, 3 sigmoid. */
 int nir_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int act, nir_stream_t stream);
 /* dscores = (sigmoid(scores) - labels) * grad_out[0] / n   (backward of nir_rank_loss_bce) */

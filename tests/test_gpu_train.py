@@ -522,3 +522,27 @@ def test_graphed_update_draws_fresh_dropout_masks():
     step = GraphedUpdate(w)
     losses = [float(step(b)) for _ in range(5)]          # learning rate 0: the loss changes through the masks only
     assert len({round(x, 6) for x in losses[1:]}) >= 3, losses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C,H,W,kh,kw", [(3, 5, 4, 16, 3, 3), (2, 51, 4, 64, 3, 5), (2, 51, 4, 64, 3, 7), (2, 7, 6, 33, 3, 7), (1, 3, 1, 5, 1, 3),
+                                           (2, 20, 20, 200, 3, 7)])
+def test_im2col_rows_matches_unfold(M, C, H, W, kh, kw):
+    """Patch rows of the 'same' convolutions in one launch (nir_im2col_rows_f32) and their deterministic backward (nir_col2im_rows_f32) against
+    F.unfold / its autograd: the rows are copies (bit-equal), the gradient sums kh*kw terms in another order (1e-6)."""
+    import torch.nn.functional as F
+    from context_attentive_ir_amd import autograd as A
+    g = torch.Generator().manual_seed(M * 100 + C + kw)
+    x = torch.randn(M, C, H, W, generator=g).to(DEV).requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    rows = A.im2col_rows(x, (kh, kw), (kh // 2, kw // 2))
+    ref = F.unfold(x2, (kh, kw), padding=(kh // 2, kw // 2)).transpose(1, 2).reshape(M * H * W, -1)
+    assert torch.equal(rows, ref)
+    dy = torch.randn(rows.shape, generator=g).to(DEV)
+    rows.backward(dy)
+    ref.backward(dy)
+    torch.testing.assert_close(x.grad, x2.grad, rtol=1e-5, atol=1e-5)
+    again = torch.zeros_like(x.grad)
+    from context_attentive_ir_amd import lib
+    lib.check(lib.load().nir_col2im_rows_f32(lib.ptr(dy), M, C, H, W, kh, kw, kh // 2, kw // 2, lib.ptr(again), lib.stream()), "nir_col2im_rows_f32")
+    assert torch.equal(again, x.grad)          # deterministic: no atomics
