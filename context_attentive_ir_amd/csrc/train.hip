@@ -396,6 +396,9 @@ __global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs
     struct CellIn { float a[NTW][4][4]; float ct[NTW][4], cp[NTW][4], dy[NTW][4], dcs[NTW][4]; };
     const bool vec = (H & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.act) | reinterpret_cast<uintptr_t>(p.cst) | reinterpret_cast<uintptr_t>(p.dout) |
                                        reinterpret_cast<uintptr_t>(p.dgates) | reinterpret_cast<uintptr_t>(p.dcst) | reinterpret_cast<uintptr_t>(p.c0)) & 15) == 0;
+    // H % 4 == 2 (MatchTensor's 70): 8-byte pieces instead -- two per row and tile
+    const bool vec2 = !vec && (H & 1) == 0 && ((reinterpret_cast<uintptr_t>(p.act) | reinterpret_cast<uintptr_t>(p.cst) | reinterpret_cast<uintptr_t>(p.dout) |
+                                                 reinterpret_cast<uintptr_t>(p.dgates) | reinterpret_cast<uintptr_t>(p.dcst) | reinterpret_cast<uintptr_t>(p.c0)) & 7) == 0;
     auto load_cells = [&](int step, CellIn& ci) {
         const bool on_ = step >= 0 && step < len;
         const int st_ = on_ ? step : 0;
@@ -423,6 +426,25 @@ __global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs
                 if (cpv) ld4(cpv, ci.cp[i]);
                 else ci.cp[i][0] = ci.cp[i][1] = ci.cp[i][2] = ci.cp[i][3] = 0.f;
                 if (dcp) ld4(dcp, ci.dcs[i]);
+                else ci.dcs[i][0] = ci.dcs[i][1] = ci.dcs[i][2] = ci.dcs[i][3] = 0.f;
+            }
+            return;
+        }
+        if (vec2) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int u0 = ub[i] < H ? ub[i] : 0, u1 = ub[i] + 2 < H ? ub[i] + 2 : u0;      // units past H: any valid address (masked below)
+                auto ld22 = [&](const float* q, float (&dst)[4]) {
+                    const float2 v0 = *reinterpret_cast<const float2*>(q + u0), v1 = *reinterpret_cast<const float2*>(q + u1);
+                    dst[0] = v0.x; dst[1] = v0.y; dst[2] = v1.x; dst[3] = v1.y;
+                };
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ld22(a + g * H, ci.a[i][g]);
+                ld22(cs, ci.ct[i]);
+                ld22(dyp, ci.dy[i]);
+                if (cpv) ld22(cpv, ci.cp[i]);
+                else ci.cp[i][0] = ci.cp[i][1] = ci.cp[i][2] = ci.cp[i][3] = 0.f;
+                if (dcp) ld22(dcp, ci.dcs[i]);
                 else ci.dcs[i][0] = ci.dcs[i][1] = ci.dcs[i][2] = ci.dcs[i][3] = 0.f;
             }
             return;
@@ -466,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs
                 if (cv) {
                     dc[i][r] = dct * f_;
 #ifndef NIR_BW_NOSTORE
-                    if (!vec) {
+                    if (!vec && !vec2) {
                         float* o = p.dgates + row * (int64_t)(ND * H4) + dir * H4;
                         o[u] = gi; o[H + u] = gf; o[2 * H + u] = gg; o[3 * H + u] = go;
                     }
@@ -483,6 +505,14 @@ __global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs
                 float* o = p.dgates + row * (int64_t)(ND * H4) + dir * H4 + ub[i];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(o + g * H) = make_float4(gv[g][0], gv[g][1], gv[g][2], gv[g][3]);
+            }
+            if (vec2 && on && sv && ub[i] < H) {
+                float* o = p.dgates + row * (int64_t)(ND * H4) + dir * H4 + ub[i];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<float2*>(o + g * H) = make_float2(gv[g][0], gv[g][1]);
+                    if (ub[i] + 2 < H) *reinterpret_cast<float2*>(o + g * H + 2) = make_float2(gv[g][2], gv[g][3]);
+                }
             }
 #endif
         }
@@ -816,8 +846,9 @@ extern "C" int nir_lstm_train_bwd(const float* dout, const float* dhn, const flo
     LstmBwdArgs a{dout, dhn, dcn, dcst, act, cst, c0, lengths, w_hh, dgates, dh0, dc0, M, T, H, ndir};
     // W_hh resident on the matrix cores for the hidden sizes that fill 4 waves x 2 unit tiles (H <= 128); tunable lstm_valu keeps the VALU form
     const int hp = (H + 3) / 4 * 4;
-    // (H % 4 != 0 -- MatchTensor's 70 -- has no 16-byte cell IO: measured 666 against 427 us at 320 sequences, 1430 against 1790 us at 2560)
-    if (!tun(g_tun.lstm_valu) && H >= 16 && (hp == 32 || hp == 64 || hp == 72 || hp == 96 || hp == 128) && (H % 4 == 0 || M >= 1024)) {
+    // (H % 4 != 0 has no 16-byte cell IO: with scalar loads MatchTensor's H = 70 measured 666 against 427 us at 320 sequences, 1430 against
+    // 1790 us at 2560; even H uses 8-byte pieces, odd H keeps the scalar form and this kernel only from 1024 sequences on)
+    if (!tun(g_tun.lstm_valu) && H >= 16 && (hp == 32 || hp == 64 || hp == 72 || hp == 96 || hp == 128) && (H % 2 == 0 || M >= 1024)) {
         const size_t ldm = (size_t)2 * 16 * 4 * (hp + 4) * 4 + 16 * 4;
         ProfScope ps(prof_shape_name("lstm_train_bwd_mfma_kernel", M, T, H), (hipStream_t)stream);
         const dim3 grid((unsigned)((M + 15) / 16), (unsigned)ndir);
