@@ -28,13 +28,26 @@ def main():
     dev = torch.device("cuda:0")
     extra = dict(optimizer="adam", learning_rate=0.001, weight_decay=0, momentum=0, grad_clipping=10.0, fix_embeddings=True)
     from helpers import default_args, fill_module_
-    from context_attentive_ir_amd.wrappers import Ranker
-    w = Ranker(default_args(a.kind, src_vocab_size=c["vocab"], max_query_len=c["qlen"], max_doc_len=c["dlen"], **extra))
+    from context_attentive_ir_amd.wrappers import Multitask, Ranker
+    if a.kind == "CARS":
+        w = Multitask(default_args("CARS", src_vocab_size=c["vocab"], tgt_vocab_size=30000, **extra))
+    else:
+        w = Ranker(default_args(a.kind, src_vocab_size=c["vocab"], max_query_len=c["qlen"], max_doc_len=c["dlen"], **extra))
     fill_module_(w.network, 1013)
     w.cuda()
     w.init_optimizer()
     w.id_check_interval = 0
     batches = bench.make_batches(c, 4, 0, dev)
+    if a.kind == "CARS":                        # teacher-forcing targets as in bench.train_record
+        for b in batches:
+            src = b["source_words"][:, 1:]
+            B_, S1, QL = src.shape
+            tw = torch.zeros(B_, S1, QL + 2, dtype=torch.int64, device=dev)
+            tw[..., 0] = 2
+            tw[..., 1:QL + 1] = src
+            tw[..., QL + 1] = 3
+            b["target_words"], b["target_seq"] = tw, tw % 30000
+            b["target_lens"] = torch.full((B_, S1), QL + 2, dtype=torch.int64, device=dev)
     for i in range(3):
         w.update(batches[i % 4])
     torch.cuda.synchronize()
