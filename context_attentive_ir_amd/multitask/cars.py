@@ -50,6 +50,12 @@ class _RNNDecoderParams(nn.Module):
         self.attn.linear_out = nn.Linear(2 * nhid, nhid, bias=False)
 
 
+def _wsum(x, w):
+    """sum_t w[b,t] x[b,t,:] (the reference's torch.bmm(x^T, w), cars.py:671-691) as a broadcast product + reduction: tensor glue of the train-mode
+    forward, no library GEMM on the path."""
+    return (x * w.unsqueeze(2)).sum(1)
+
+
 class CARS(nn.Module, lib.IdCheck):
     def __init__(self, args):
         super().__init__()
@@ -429,7 +435,7 @@ class CARS(nn.Module, lib.IdCheck):
         T = enc.shape[1]
         mask = torch.arange(T, device=enc.device).unsqueeze(0) < lens.unsqueeze(1)
         w = torch.softmax(self._mlp_logits(mlp, enc, p).masked_fill(~mask, float("-inf")), 1)
-        return torch.bmm(enc.transpose(1, 2), w.unsqueeze(2)).squeeze(2)
+        return _wsum(enc, w)
 
     def _encode_train(self, which, ids, lens):
         table = self.embedder.word_embeddings.table
@@ -466,7 +472,7 @@ class CARS(nn.Module, lib.IdCheck):
                 pos = torch.arange(N, device=lab.device).unsqueeze(0)
                 keep = (pos < count.unsqueeze(1)) | (pos >= count.max())          # the batch-dependent mask quirk (Appendix E2)
                 w = torch.softmax(self._mlp_logits(self.click_attn, sd, p).masked_fill(~keep, float("-inf")), 1)
-                clicks = torch.bmm(sd.transpose(1, 2), w.unsqueeze(2)).squeeze(2).view(B, S, -1)
+                clicks = _wsum(sd, w).view(B, S, -1)
         # ---- encode_session (cars.py:306-458)
         dev = pooled_q.device
         qs = [torch.zeros(B, self.nhid_session_query, device=dev)] if q_on else []
@@ -478,8 +484,8 @@ class CARS(nn.Module, lib.IdCheck):
 
             def attend(states, lin):
                 st = torch.stack(states, 1)
-                w = torch.softmax(torch.bmm(A.linear(st, lin.weight, lin.bias), qv.unsqueeze(2)).squeeze(2), 1)
-                return torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2)
+                w = torch.softmax((A.linear(st, lin.weight, lin.bias) * qv.unsqueeze(1)).sum(2), 1)
+                return _wsum(st, w)
 
             if not self.no_ranker:
                 parts = ([attend(qs, self.session_query_attn)] if q_on else []) + ([attend(ds, self.session_doc_attn)] if d_on else [])
@@ -504,14 +510,14 @@ class CARS(nn.Module, lib.IdCheck):
                 hparts.append(qstate[0]); cparts.append(qstate[1])
                 st = torch.stack(qs[1:], 1)
                 w = torch.softmax(self._mlp_logits(self.session_query_inner_attn, st, p), 1)
-                inner_q.append(torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2))
+                inner_q.append(_wsum(st, w))
             if d_on:
                 dstate = self._cell(self.session_doc_encoder.encoder.rnns[0], clicks[:, t], dstate)
                 ds.append(A.dropout(dstate[0], p, True))
                 hparts.append(dstate[0]); cparts.append(dstate[1])
                 st = torch.stack(ds[1:], 1)
                 w = torch.softmax(self._mlp_logits(self.session_doc_inner_attn, st, p), 1)
-                inner_d.append(torch.bmm(st.transpose(1, 2), w.unsqueeze(2)).squeeze(2))
+                inner_d.append(_wsum(st, w))
             hid.append(torch.cat(hparts, 1)); cell.append(torch.cat(cparts, 1))
         out = {"ranking_loss": None, "suggestion_loss": None}
         if not self.no_ranker:
@@ -533,9 +539,9 @@ class CARS(nn.Module, lib.IdCheck):
             mlen = lib.ids64(source_len)[:, :-1].reshape(-1)
             rnn, att = self.decoder.decoder.rnn, self.decoder.decoder.attn
             h_all, _ = A.lstm_seq(temb, rnn, dec_h, dec_c)                            # [Bd,TL,HD]
-            align = torch.bmm(A.linear(h_all, att.linear_in.weight), mem.transpose(1, 2))      # [Bd,TL,QL]
+            align = (A.linear(h_all, att.linear_in.weight).unsqueeze(2) * mem.unsqueeze(1)).sum(3)      # [Bd,TL,QL] (tiny: tensor glue, no library GEMM)
             mask = (torch.arange(QL, device=dev).unsqueeze(0) < mlen.unsqueeze(1)).unsqueeze(1)
-            ctx = torch.bmm(torch.softmax(align.masked_fill(~mask, float("-inf")), -1), mem)
+            ctx = (torch.softmax(align.masked_fill(~mask, float("-inf")), -1).unsqueeze(3) * mem.unsqueeze(1)).sum(2)
             dec_out = A.linear(torch.cat((ctx, h_all), 2), att.linear_out.weight, act="tanh")
             dec_out = A.dropout(dec_out, self.dec_dropout_p, True)[:, :-1]
             po = A.linear(dec_out, self.token_prob_predictor1.weight)
