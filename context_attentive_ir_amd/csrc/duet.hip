@@ -22,13 +22,14 @@ int launch_rowdot(const float* x, int64_t ldx, const float* w, const float* b, f
                   hipStream_t st);
 // duet_fused.hip
 bool duet_doc_usable(int NF, int P, int E, int DL, int K1P);
-size_t duet_doc_partial_floats(int64_t M, int DL, int P, bool planes);
+size_t duet_doc_partial_floats(int64_t M, int DL, int P, bool planes, int EPT);
+bool duet_planes_fit(int EPT);
 int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int64_t M, int N, const void* wf1, int K1P, const void* wf2,
                     const void* ftab, const void* wf1c, int EPT, const float* b1, const float* b2, const float* fc2w, const float* fc2b,
                     const float* qv, int NF, int P, float* partial, float* m1, hipStream_t st);
 
 static bool duet_table_planes(const nir_duet_weights* w, int E) {
-    return w->ftable && w->fw1c && w->EPT >= E && w->EPT % 64 == 0;
+    return w->ftable && w->fw1c && w->EPT >= E && duet_planes_fit(w->EPT);
 }
 
 static bool duet_fused(const nir_duet_weights* w, int E, int DL) {
@@ -227,7 +228,7 @@ struct DuetPlan {
     size_t bytes;
 };
 
-static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, int NF, int P, bool fused, bool tplanes) {
+static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, int NF, int P, bool fused, bool tplanes, int EPT) {
     Workspace a(ws, cap);
     const size_t M = (size_t)B * N;
     const int Tc = DL - 2, Tp = Tc - P + 1;
@@ -239,7 +240,7 @@ static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, in
     p.qmax = a.take<float>((size_t)B * NF);
     p.qv = a.take<float>((size_t)B * NF);
     if (fused) {                                      // the fused kernel keeps conv_d1 / pooled / conv_d2 on chip: only per-tile fc2 partials
-        p.cd = a.take<float>(duet_doc_partial_floats((int64_t)M, DL, P, tplanes));
+        p.cd = a.take<float>(duet_doc_partial_floats((int64_t)M, DL, P, tplanes, EPT));
         p.pooled = p.dd = nullptr;
     } else {
         p.cd = a.take<float>(M * Tc * NF);
@@ -257,7 +258,7 @@ static DuetPlan duet_plan(void* ws, size_t cap, int B, int N, int QL, int DL, in
 
 extern "C" size_t nir_duet_workspace_bytes(int B, int N, int QL, int DL, int E, const nir_duet_weights* w) {
     if (!w || B < 0 || N <= 0 || QL < 3 || DL < w->pool + 2) return 0;
-    return nir::duet_plan(nullptr, 0, B, N, QL, DL, w->NF, w->pool, nir::duet_fused(w, E, DL), nir::duet_table_planes(w, E)).bytes;
+    return nir::duet_plan(nullptr, 0, B, N, QL, DL, w->NF, w->pool, nir::duet_fused(w, E, DL), nir::duet_table_planes(w, E), w->EPT).bytes;
 }
 
 extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,
@@ -278,7 +279,7 @@ extern "C" int nir_duet_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     const int NF = w->NF, P = w->pool, Tc = DL - 2, Tp = Tc - P + 1;
     const bool fused = duet_fused(w, E, DL);
     const bool tplanes = duet_table_planes(w, E);
-    DuetPlan p = duet_plan(workspace, workspace_bytes, B, N, QL, DL, NF, P, fused, tplanes);
+    DuetPlan p = duet_plan(workspace, workspace_bytes, B, N, QL, DL, NF, P, fused, tplanes, w->EPT);
     if (!workspace || p.bytes > workspace_bytes) {
         set_error("duet: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
         return NIR_ERR_WORKSPACE;

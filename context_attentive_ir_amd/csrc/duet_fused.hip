@@ -761,14 +761,23 @@ bool duet_doc_usable(int NF, int P, int E, int DL, int K1P) {
 
 // Rows per tile: with the table planes the tile is 96 rows when documents are long enough for flattened 96-row tiles (W fragments are
 // streamed once per tile: 1.5x fewer L2 bytes and MFMA-free epilogue cycles per row), else 64.
-int duet_doc_rows(bool planes, int DL, int P) {
-    return planes && !tun(g_tun.duet_rows64) && DL - 2 >= 96 - (P - 1) ? 96 : DF_ROWS;
+// LDS of a plane-mode tile: the token tile (C column chunks) or the P planes that later take its place, ids + fc2 weights + flags
+template <int RT>
+static size_t duet_pl_lds(int C) {
+    return std::max((size_t)C * DfLayoutP<RT>::CHB, (size_t)DfLayout<RT>::P_HALVES * 2) + 1536;
+}
+// plane mode needs the whole token tile in LDS (EPT / 32 chunks) and one flag per chunk: wide embeddings fall back to the fp32-table form
+bool duet_planes_fit(int EPT) {
+    return EPT > 0 && EPT % 64 == 0 && EPT / 32 <= 32 && duet_pl_lds<DF_RT>(EPT / 32) <= 160 * 1024;
+}
+int duet_doc_rows(bool planes, int DL, int P, int EPT) {
+    return planes && !tun(g_tun.duet_rows64) && DL - 2 >= 96 - (P - 1) && duet_pl_lds<6>(EPT / 32) <= 160 * 1024 ? 96 : DF_ROWS;
 }
 
-size_t duet_doc_partial_floats(int64_t M, int DL, int P, bool planes) {
+size_t duet_doc_partial_floats(int64_t M, int DL, int P, bool planes, int EPT) {
     DuetDocArgs a;
     int64_t tiles;
-    duet_doc_tiling(M, DL, P, duet_doc_rows(planes, DL, P), &a, &tiles);
+    duet_doc_tiling(M, DL, P, duet_doc_rows(planes, DL, P, EPT), &a, &tiles);
     return (size_t)tiles * 2 * DF_NFP;
 }
 
@@ -787,14 +796,13 @@ int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int
                     const void* ftab, const void* wf1c, int EPT, const float* b1, const float* b2, const float* fc2w, const float* fc2b,
                     const float* qv, int NF, int P, float* partial, float* m1, hipStream_t st) {
     NIR_REQUIRE(duet_doc_usable(NF, P, E, DL, K1P), "duet_doc: unsupported shape NF=%d pool=%d E=%d DL=%d K1P=%d", NF, P, E, DL, K1P);
-    const bool planes = ftab && wf1c && EPT > 0;
-    NIR_REQUIRE(!planes || (EPT % 64 == 0 && EPT >= E), "duet_doc: table planes need EPT %% 64 == 0 and EPT >= E (EPT=%d E=%d)", EPT, E);
+    const bool planes = ftab && wf1c && EPT >= E && duet_planes_fit(EPT);
     if (M == 0) return 0;
     DuetDocArgs a;
     a.d_ids = d_ids; a.table = table; a.wf1 = (const _Float16*)wf1; a.wf2 = (const _Float16*)wf2; a.b1 = b1; a.b2 = b2; a.fc2w = fc2w;
     a.partial = partial; a.M = M; a.E = E; a.DL = DL; a.S1 = K1P / 32; a.NF = NF; a.P = P;
     a.ftab = (const _Float16*)ftab; a.wf1c = (const _Float16*)wf1c; a.EPT = EPT; a.C = EPT / 32; a.ids_off = 0;
-    const int rows = duet_doc_rows(planes, DL, P);
+    const int rows = duet_doc_rows(planes, DL, P, EPT);
     int64_t tiles;
     duet_doc_tiling(M, DL, P, rows, &a, &tiles);
     {
@@ -802,15 +810,13 @@ int launch_duet_doc(const int64_t* d_ids, const float* table, int E, int DL, int
         if (!planes) {
             duet_doc_launch_t<DF_RT, false>(a, tiles, DfLayout<DF_RT>::LDS, P, st);
         } else if (rows == 96) {
-            const size_t body = std::max((size_t)a.C * DfLayoutP<6>::CHB, (size_t)DfLayout<6>::P_HALVES * 2);
-            a.ids_off = (int)body;
-            NIR_REQUIRE(body + 1536 <= 160 * 1024 && a.C <= 32, "duet_doc: token tile of %d column chunks exceeds LDS", a.C);
-            duet_doc_launch_t<6, true>(a, tiles, body + 1536, P, st);
+            const size_t lds = duet_pl_lds<6>(a.C);
+            a.ids_off = (int)(lds - 1536);
+            duet_doc_launch_t<6, true>(a, tiles, lds, P, st);
         } else {
-            const size_t body = std::max((size_t)a.C * DfLayoutP<DF_RT>::CHB, (size_t)DfLayout<DF_RT>::P_HALVES * 2);
-            a.ids_off = (int)body;
-            NIR_REQUIRE(body + 1536 <= 160 * 1024 && a.C <= 32, "duet_doc: token tile of %d column chunks exceeds LDS", a.C);
-            duet_doc_launch_t<DF_RT, true>(a, tiles, body + 1536, P, st);
+            const size_t lds = duet_pl_lds<DF_RT>(a.C);
+            a.ids_off = (int)(lds - 1536);
+            duet_doc_launch_t<DF_RT, true>(a, tiles, lds, P, st);
         }
     }
     NIR_CHECK_LAUNCH("duet_doc_kernel");

@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs
                 gv[0][r] = gi; gv[1][r] = gf; gv[2][r] = gg; gv[3][r] = go;
                 if (cv) {
                     dc[i][r] = dct * f_;
+// NIR_BW_NOSTORE / NIR_BW_NOLOAD / NIR_BW_NOMFMA: timing ablations of the step (instrumented variant builds only, results are wrong with any set)
 #ifndef NIR_BW_NOSTORE
                     if (!vec && !vec2) {
                         float* o = p.dgates + row * (int64_t)(ND * H4) + dir * H4;

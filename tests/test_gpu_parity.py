@@ -833,7 +833,8 @@ def test_duet_fused_document_branch_matches_layer_chain(B, N, QL, DL, pool, plan
 
 
 @pytest.mark.parametrize("planes", [True, False])
-@pytest.mark.parametrize("E,NF,DL,pool", [(52, 128, 150, 4), (100, 320, 97, 5), (300, 60, 200, 2), (64, 300, 290, 5)])
+@pytest.mark.parametrize("E,NF,DL,pool", [(52, 128, 150, 4), (100, 320, 97, 5), (300, 60, 200, 2), (64, 300, 290, 5),
+                                         (448, 64, 150, 5), (640, 32, 120, 3)])   # wide rows: 64-row plane tiles / no room for the token tile -> fp32-table form
 def test_duet_fused_other_widths(E, NF, DL, pool, planes):
     """Fused document branch away from the reference's 300/300/5: embedding width (k tail of conv_d1: 3E not a multiple of 32),
     filter count (masked columns, 320 = no padding), window, flattened and per-document tilings -- against the layer chain."""
