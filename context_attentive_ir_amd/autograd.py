@@ -48,18 +48,16 @@ def _transpose(w):
 def _wgrad(dy2, lddy, x2, ldx, M, N, K):
     """dW [N,K] = sum_m dy[m,:N]^T x[m,:K]; dy2 / x2 may be column windows of wider row-major buffers (lddy / ldx)."""
     L = lib.load()
-    dw = torch.zeros(N, K, device=x2.device, dtype=torch.float32)
-    if M:
-        lib.check(L.nir_linear_wgrad_f32(lib.ptr(dy2), lddy, lib.ptr(x2), ldx, None, None, 0, lib.ptr(dw), K, M, N, K, lib.stream()),
-                  "nir_linear_wgrad_f32")
+    dw = torch.empty(N, K, device=x2.device, dtype=torch.float32)          # "=" form: no zero fill (a step has ~140 of these)
+    lib.check(L.nir_linear_wgrad_set_f32(lib.ptr(dy2) if M else lib.ptr(dw), lddy, lib.ptr(x2) if M else lib.ptr(dw), ldx, None, None, 0, lib.ptr(dw), K, M, N,
+                                         K, lib.stream()), "nir_linear_wgrad_set_f32")
     return dw
 
 
 def _colsum(dy2, ld, M, N):
     L = lib.load()
-    out = torch.zeros(N, device=dy2.device, dtype=torch.float32)
-    if M:
-        lib.check(L.nir_colsum_f32(lib.ptr(dy2), ld, M, N, lib.ptr(out), lib.stream()), "nir_colsum_f32")
+    out = torch.empty(N, device=dy2.device, dtype=torch.float32)
+    lib.check(L.nir_colsum_set_f32(lib.ptr(dy2) if M else lib.ptr(out), ld, M, N, lib.ptr(out), lib.stream()), "nir_colsum_set_f32")
     return out
 
 

@@ -31,6 +31,7 @@ struct WgradArgs {
     float* dw; int64_t lddw;
     int64_t M; int N, K;
     int64_t mslice;
+    int store;                                         // 1: one slice covers M -- every element is written once, plain stores (dw needs no zero fill)
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
@@ -66,19 +67,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (nn < p.N && kv) atomicAdd(p.dw + (int64_t)nn * p.lddw + k, acc[r]);
+        if (nn < p.N && kv) {
+            if (p.store) p.dw[(int64_t)nn * p.lddw + k] = acc[r];
+            else atomicAdd(p.dw + (int64_t)nn * p.lddw + k, acc[r]);
+        }
     }
 }
 
 // out[n] += sum_m x[m*ld + n]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int N, float* __restrict__ out,
-                                                     int64_t mslice) {
+                                                     int64_t mslice, int store) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int64_t ms = (int64_t)blockIdx.y * mslice, me = min(M, ms + mslice);
     if (n >= N) return;
     float s = 0.f;
     for (int64_t m = ms; m < me; ++m) s += x[m * ld + n];
-    atomicAdd(out + n, s);
+    if (store) out[n] = s;
+    else atomicAdd(out + n, s);
 }
 
 __global__ void transpose_kernel(const float* __restrict__ in, int R, int Cc, float* __restrict__ out) {
@@ -775,32 +780,53 @@ extern "C" int nir_lstm_cell_bwd(const float* dh, const float* dc, const float* 
     return 0;
 }
 
-extern "C" int nir_linear_wgrad_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
-                                    float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream) {
+static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E, float* dw,
+                      int64_t lddw, int64_t M, int N, int K, bool set, hipStream_t st) {
     using namespace nir;
     NIR_REQUIRE(dy && dw && (ids ? (table != nullptr && E >= K) : (x != nullptr)), "linear_wgrad: null pointer");
     NIR_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_wgrad: bad dims");
-    if (M == 0) return 0;
+    if (M == 0) {
+        if (set) return (int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st);
+        return 0;
+    }
     const int64_t tiles = (int64_t)((N + 31) / 32) * ((K + 31) / 32);
     int64_t slices = std::max<int64_t>(1, std::min<int64_t>((M + 255) / 256, (4096 + tiles - 1) / tiles));
     const int64_t mslice = ((M + slices - 1) / slices + 15) / 16 * 16;
     slices = (M + mslice - 1) / mslice;
-    WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice};
-    ProfScope ps(prof_shape_name("wgrad_kernel", M, N, K), (hipStream_t)stream);
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    const int store = set && slices == 1;
+    if (set && !store) NIR_PROPAGATE((int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st));
+    WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store};
+    ProfScope ps(prof_shape_name("wgrad_kernel", M, N, K), st);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
     NIR_CHECK_LAUNCH("wgrad_kernel");
     return 0;
 }
+extern "C" int nir_linear_wgrad_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                                    float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream) {
+    return wgrad_impl(dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, false, (hipStream_t)stream);
+}
+extern "C" int nir_linear_wgrad_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                                        float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream) {
+    return wgrad_impl(dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, true, (hipStream_t)stream);
+}
 
-extern "C" int nir_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream) {
+static int colsum_impl(const float* x, int64_t ld, int64_t M, int N, float* out, bool set, hipStream_t st) {
     using namespace nir;
     NIR_REQUIRE(x && out && M >= 0 && N > 0, "colsum: bad args");
-    if (M == 0) return 0;
+    if (M == 0) return set ? (int)hipMemsetAsync(out, 0, (size_t)N * 4, st) : 0;
     const int64_t mslice = std::max<int64_t>(64, (M + 255) / 256);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((M + mslice - 1) / mslice)), dim3(256), 0, (hipStream_t)stream, x, ld,
-                       M, N, out, mslice);
+    const int64_t slices = (M + mslice - 1) / mslice;
+    const int store = set && slices == 1;
+    if (set && !store) NIR_PROPAGATE((int)hipMemsetAsync(out, 0, (size_t)N * 4, st));
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)slices), dim3(256), 0, st, x, ld, M, N, out, mslice, store);
     NIR_CHECK_LAUNCH("colsum_kernel");
     return 0;
+}
+extern "C" int nir_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream) {
+    return colsum_impl(x, ld, M, N, out, false, (hipStream_t)stream);
+}
+extern "C" int nir_colsum_set_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream) {
+    return colsum_impl(x, ld, M, N, out, true, (hipStream_t)stream);
 }
 
 extern "C" int nir_transpose_f32(const float* in, int R, int Cc, float* out, nir_stream_t stream) {

@@ -486,6 +486,11 @@ int nir_linear_wgrad_f32(const float* dy, int64_t lddy, const float* x, int64_t 
                          float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream);
 /* out[n] += sum_m x[m*ld + n]   (bias gradient) */
 int nir_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream);
+/* The same two with "=" instead of "+=": dW / out need no zero fill by the caller (one slice of M: plain stores; several: a memset node in
+ * front of the atomics) -- an autograd backward allocates its gradient buffers with torch.empty. */
+int nir_linear_wgrad_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                             float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream);
+int nir_colsum_set_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream);
 /* out [C,R] = in [R,C]^T  (data gradient: dX = dY W is nir_linear_f32(dY, W^T)) */
 int nir_transpose_f32(const float* in, int R, int C, float* out, nir_stream_t stream);
 /* Train-mode recurrence (same contract as nir_bilstm_fwd, H <= 128) that also stores act [M,T,ndir,4H] (i,f,g,o after their
