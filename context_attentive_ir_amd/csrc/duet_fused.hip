@@ -195,13 +195,13 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
     constexpr int WSTEP = 20 * 2 * 64 * 8;
     f16x8 w[DF_CT][2];
     f32x4 acc[DF_CT][RT], acx[DF_CT][RT];
-#pragma unroll
-    for (int j = 0; j < DF_CT; ++j)
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define DF_ZERO_ACC()                                                                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < DF_CT; ++j_)                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < RT; ++i_) {                               \
+            acc[j_][i_] = f32x4{0.f, 0.f, 0.f, 0.f};                                      \
+            acx[j_][i_] = f32x4{0.f, 0.f, 0.f, 0.f};                                      \
         }
+    if constexpr (!PL) { DF_ZERO_ACC() }
     const int foff = g * KG + c16 * 8;          // fragment address of the A-side operand: [term][k-group = lane >> 4][row][8]
 
     // ================= GEMM 1: conv_d1 =================
@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
 #ifndef DF_AFM
 #define DF_AFM 1
 #endif
+#ifndef DF_G1FIRST        // 1: the first k-step of GEMM 1 starts the accumulators with C = 0 (GEMM 2 does, its first step is peeled); here it would be a
+#define DF_G1FIRST 0      // uniform branch per MFMA of the step body shared by all chunks -- measured: GEMM 1 50 K -> 61 K cycles per tile (every branch
+#endif                    // ends a scheduling region).  0: 240 zero writes per tile, rematerialised by hipcc right in front of the first MFMA (~1 K cycles)
 #ifndef DF_ROT            // 1: every workgroup starts its k walk at its own chunk (measured: no effect, see below); 0: canonical k order
 #define DF_ROT 0
 #endif
@@ -389,7 +392,9 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             static_assert(RP <= 256, "one token id per thread");
             const int64_t F0 = doc0 * p.DL + t00, Fm = p.M * p.DL - 1;       // token row i of the tile = flattened token F0 + i (clamped)
             const int64_t f = F0 + (tid < RP ? tid : RP - 1);
-            const int idv = (int)p.d_ids[f < Fm ? f : Fm];
+            // the low dword of the 64-bit id: with the 8-byte load the dead upper half was re-used at once and hipcc waited for the load
+            // (a round trip) before it issued the fc2 / W requests below
+            const int idv = reinterpret_cast<const int*>(p.d_ids)[2 * (f < Fm ? f : Fm)];
             const int tr = tid < 16 * RT ? tid : 16 * RT - 1;
             int t = t00 + tr;
             const bool s1 = p.flat && t >= Tc;
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
         for (int k = 0; k < NSLOT; ++k) {
             if (1 < C) { DF_TILE_LOAD(k, 1) }
         }
+        if (!DF_G1FIRST) { DF_ZERO_ACC() }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunks 0 and 1 are in LDS
         int fl_ = 0;
         __syncthreads();
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void duet_doc_kernel(DuetDocArgs p) {
             const _Float16* wn_ = wp1 + (int64_t)sn_ * WSTEP;                             \
             const unsigned char* ac_ = (CB) + (U) * 16;                                   \
             const unsigned char* an_ = (U) < 2 ? (CB) + ((U) + 1) * 16 : (more_ ? (CB) + CHB : (CB) + 32); \
-            DF_STEPR(WC, WN, wn_, ac_, an_, 4 * RP * 16, DF_AROW, false,                  \
+            DF_STEPR(WC, WN, wn_, ac_, an_, 4 * RP * 16, DF_AROW, DF_G1FIRST && (U) == 0 && (CI) == 0,  \
                      if (!DF_X_NOTILE && (U) < 2 && (n_ == 24 || n_ == 26) && 2 * (U) + (n_ - 24) / 2 < NSLOT) { \
                          if ((CI) + 2 < C) { DF_TILE_LOAD(2 * (U) + (n_ - 24) / 2, (CI) + 2) }   \
                      }                                                                    \
