@@ -263,14 +263,16 @@ def precompute_info(wrapper, c):
             "tables": len(tabs), "rebuilt": "once per weight version (PackCache); not part of a step"}
 
 
-def macro_batch(c, env_key="BENCH_MACRO_BATCH"):
+def macro_batch(c, env_key="BENCH_MACRO_BATCH", share=1):
     """batches merged into one macro-batch per graph replay (Multitask.predict_many): small batches (C3: 1 120 documents) are merged four at a
     time -- a lone C3 batch fills 140 of 256 CUs with recurrence workgroups and pays 76 MB of session-weight traffic whatever its size --
     large ones (C5: 22 400 documents) are not (no gain measured, 4x the scratch).  The environment variable overrides."""
     if os.environ.get(env_key):
         return max(1, int(os.environ[env_key]))
-    docs = c["batch"] * c.get("session", 1) * c["cands"]
-    return max(1, min(8, 4480 // max(1, docs)))
+    # share > 1: this rank's 1/share of every batch (sharded CARS step): the macro-batch keeps the RANK's launch sequence at the same ~4 480
+    # documents -- more steps per graph replay and per gather (8-rank emulation at C3: KG 4 / 8 / 16 = 0.028 / 0.022 / 0.016 ms per step)
+    docs = c["batch"] * c.get("session", 1) * c["cands"] // max(1, share)
+    return max(1, min(8 if share == 1 else 16, 4480 // max(1, docs)))
 
 
 def make_batches(c, nbatches, rank_seed, dev):
@@ -343,7 +345,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         nlanes = int(os.environ.get("BENCH_SHARD_LANES", nlanes))       # (8 lanes measured SLOWER than 4 in the 8-rank emulation: C3 0.111 vs 0.097 ms)
     nbatches = (max(args.nbatches, nlanes) + nlanes - 1) // nlanes * nlanes
     if c["model"] == "cars" or not env.multi:       # macro-batched paths: every lane gets whole groups of KG batches
-        kg = macro_batch(c, "BENCH_GATHER_EVERY" if env.multi else "BENCH_MACRO_BATCH")
+        kg = macro_batch(c, "BENCH_GATHER_EVERY" if env.multi else "BENCH_MACRO_BATCH", wsh if (env.multi and sharded and c["model"] == "cars") else 1)
         nbatches = (max(args.nbatches, kg * nlanes) + kg * nlanes - 1) // (kg * nlanes) * (kg * nlanes)
     # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
     batches = make_batches(c, nbatches, 0 if sharded or not env.multi else rank, dev)
@@ -537,7 +539,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         try:
             # pair axis: a lane's hipGraph holds KG whole steps ( encode own sessions -> tail -> probabilities ) merged into one macro-batch,
             # followed by ONE eager all-gather of the KG probability blocks.  Results lag by at most KG - 1 steps.
-            KG = macro_batch(c, "BENCH_MACRO_BATCH" if macro_single else "BENCH_GATHER_EVERY")
+            KG = macro_batch(c, "BENCH_MACRO_BATCH" if macro_single else "BENCH_GATHER_EVERY", 1 if macro_single else wsh)
             nl, nb = len(lanes), len(batches)
             agroups = {}
             gbuf = {}
