@@ -269,10 +269,11 @@ def macro_batch(c, env_key="BENCH_MACRO_BATCH", share=1):
     large ones (C5: 22 400 documents) are not (no gain measured, 4x the scratch).  The environment variable overrides."""
     if os.environ.get(env_key):
         return max(1, int(os.environ[env_key]))
-    # share > 1: this rank's 1/share of every batch (sharded CARS step): the macro-batch keeps the RANK's launch sequence at the same ~4 480
-    # documents -- more steps per graph replay and per gather (8-rank emulation at C3: KG 4 / 8 / 16 = 0.028 / 0.022 / 0.016 ms per step)
+    # share > 1: this rank's 1/share of every batch (sharded CARS step): the macro-batch keeps the RANK's launch sequence at up to ~9 000
+    # documents -- more steps per graph replay and per gather (8-rank emulation: C3 KG 4 / 8 / 16 = 0.028 / 0.022 / 0.016 ms per step, C5 KG 1 / 2 =
+    # 0.194 / 0.167)
     docs = c["batch"] * c.get("session", 1) * c["cands"] // max(1, share)
-    return max(1, min(8 if share == 1 else 16, 4480 // max(1, docs)))
+    return max(1, min(8, 4480 // max(1, docs))) if share == 1 else max(1, min(16, 8960 // max(1, docs)))
 
 
 def make_batches(c, nbatches, rank_seed, dev):
