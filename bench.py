@@ -58,6 +58,8 @@ PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA
 PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 
 SESSION_MODELS = ("cars", "m_match_tensor", "mnsrf")
+MIN_REGION_S = 0.25          # a timed region shorter than this is repeated (median reported)
+MAX_REPS = 41
 
 # name -> workload (BASELINE.json configs; SURVEY.md section 8d shapes)
 CONFIGS = {
@@ -264,16 +266,16 @@ def precompute_info(wrapper, c):
 
 
 def macro_batch(c, env_key="BENCH_MACRO_BATCH", share=1):
-    """batches merged into one macro-batch per graph replay (Multitask.predict_many): small batches (C3: 1 120 documents) are merged four at a
-    time -- a lone C3 batch fills 140 of 256 CUs with recurrence workgroups and pays 76 MB of session-weight traffic whatever its size --
-    large ones (C5: 22 400 documents) are not (no gain measured, 4x the scratch).  The environment variable overrides."""
+    """batches merged into one macro-batch per graph replay (Multitask.predict_many): ONE policy at every N -- a rank's launch sequence is
+    filled to ~4 480 documents, at most 8 steps per replay (and per gather).  Small batches (C3: 1 120 documents) are merged four at a time at
+    N = 1 -- a lone C3 batch fills 140 of 256 CUs with recurrence workgroups and pays 76 MB of session-weight traffic whatever its size --
+    large ones (C5: 22 400 documents) are not (no gain measured, 4x the scratch).  share > 1: the rank holds 1/share of every batch (sharded CARS
+    step), so the same target merges more steps (C3 at 8 ranks: 8).  The environment variable overrides; the `*_kg_matched` sub-record of an N > 1
+    run repeats the headline with the N = 1 count."""
     if os.environ.get(env_key):
         return max(1, int(os.environ[env_key]))
-    # share > 1: this rank's 1/share of every batch (sharded CARS step): the macro-batch keeps the RANK's launch sequence at up to ~9 000
-    # documents -- more steps per graph replay and per gather (8-rank emulation: C3 KG 4 / 8 / 16 = 0.028 / 0.022 / 0.016 ms per step, C5 KG 1 / 2 =
-    # 0.194 / 0.167)
     docs = c["batch"] * c.get("session", 1) * c["cands"] // max(1, share)
-    return max(1, min(8, 4480 // max(1, docs))) if share == 1 else max(1, min(16, 8960 // max(1, docs)))
+    return max(1, min(8, 4480 // max(1, docs)))
 
 
 def make_batches(c, nbatches, rank_seed, dev):
@@ -289,8 +291,12 @@ def make_batches(c, nbatches, rank_seed, dev):
 
 
 class Env(object):
-    def __init__(self):
+    def __init__(self, gpus=None):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # --gpus N and the launched world must agree (main() re-launches itself under torch.distributed.run when WORLD_SIZE is unset):
+        # a run that says N and measures something else is refused here, before anything is timed
+        if gpus is not None and self.world != gpus and not (self.world == 1 and gpus == 1):
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- refusing to measure a world that is not the one asked for" % (gpus, self.world))
         self.rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # (N ranks on a 1-GPU box share device 0)
         torch.cuda.set_device(local)
@@ -307,6 +313,14 @@ class Env(object):
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
             self.dist = dist
+            # n_gpus of the line = the ranks the process group really has: an all-reduce of ones, not an environment variable
+            one = torch.ones(1, device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(one)
+            self.seen = int(round(float(one.item())))
+            if self.seen != self.world or dist.get_world_size() != self.world:
+                raise SystemExit("bench.py: process group has %d ranks (all-reduce of ones: %d), WORLD_SIZE=%d" % (dist.get_world_size(), self.seen, self.world))
+        else:
+            self.seen = 1
 
     def barrier(self):
         if self.dist:
@@ -325,7 +339,7 @@ class Env(object):
 CAPTURE_MODE = "thread_local"
 
 
-def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2d=False):
+def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2d=False, axis=None, kg=None):
     """Time one workload; returns the record dict (rank 0) or None."""
     L = lib.load()
     dev, world, rank = env.dev, env.world, env.rank
@@ -346,7 +360,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         nlanes = int(os.environ.get("BENCH_SHARD_LANES", nlanes))       # (8 lanes measured SLOWER than 4 in the 8-rank emulation: C3 0.111 vs 0.097 ms)
     nbatches = (max(args.nbatches, nlanes) + nlanes - 1) // nlanes * nlanes
     if c["model"] == "cars" or not env.multi:       # macro-batched paths: every lane gets whole groups of KG batches
-        kg = macro_batch(c, "BENCH_GATHER_EVERY" if env.multi else "BENCH_MACRO_BATCH", wsh if (env.multi and sharded and c["model"] == "cars") else 1)
+        kg = kg or macro_batch(c, "BENCH_GATHER_EVERY" if env.multi else "BENCH_MACRO_BATCH", wsh if (env.multi and sharded and c["model"] == "cars") else 1)
         nbatches = (max(args.nbatches, kg * nlanes) + kg * nlanes - 1) // (kg * nlanes) * (kg * nlanes)
     # strong scaling: identical global batches on every rank; weak (shard=False at N>1): independent per-rank batches
     batches = make_batches(c, nbatches, 0 if sharded or not env.multi else rank, dev)
@@ -359,7 +373,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         # BENCH_SHARD_AXIS: "auto" (default) = the flattened (session, candidate) pair axis in contiguous chunks when B % world == 0 -- each rank
         # then encodes ALL candidates of B/world whole sessions: no padding of the candidate axis, no exchange of pooled vectors, only the
         # all-gather of the probabilities -- else the candidate axis with the all-to-all exchange; "candidate" / "pair" force one of them
-        plan = sharding.SessionShardPlan(c["batch"], c["session"], ncand, wsh, rank, axis=os.environ.get("BENCH_SHARD_AXIS", "auto"))
+        plan = sharding.SessionShardPlan(c["batch"], c["session"], ncand, wsh, rank, axis=axis or os.environ.get("BENCH_SHARD_AXIS", "auto"))
         for b in batches:
             b["_q_own"], b["_ql_own"] = plan.own(b["source_words"]), plan.own(b["source_lens"])
             b["_doc_shard"], b["_len_shard"] = plan.doc_shard(b["document_words"], b["document_lens"])
@@ -540,7 +554,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         try:
             # pair axis: a lane's hipGraph holds KG whole steps ( encode own sessions -> tail -> probabilities ) merged into one macro-batch,
             # followed by ONE eager all-gather of the KG probability blocks.  Results lag by at most KG - 1 steps.
-            KG = macro_batch(c, "BENCH_MACRO_BATCH" if macro_single else "BENCH_GATHER_EVERY", 1 if macro_single else wsh)
+            KG = kg or macro_batch(c, "BENCH_MACRO_BATCH" if macro_single else "BENCH_GATHER_EVERY", 1 if macro_single else wsh)
             nl, nb = len(lanes), len(batches)
             agroups = {}
             gbuf = {}
@@ -711,27 +725,51 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     fused["rem"][rem] = fused["capture"](2 * KSTEP, rem)
                 fused["rem"][rem][0].replay()
 
+    def rewind():
+        """every call pattern starts from the same group position: the remainder groups captured in the dry run are the ones the timed
+        repetitions replay (no capture inside a timed region)"""
+        if stages is not None:
+            stages["pos"] = 0
+
     if stages is not None and "aligned" in stages:      # dry run of every call pattern below: remainder groups get captured now
         for n in (max(warmup, 1), steps, max(6, min(steps, 60))):
+            rewind()
             run_steps(n)
         torch.cuda.synchronize()
     if fused is not None:                    # remainder groups are captured before the timed region
         for n in {max(warmup, 1) % KSTEP, steps % KSTEP, max(6, min(steps, 60)) % KSTEP} - {0}:
             fused["rem"][n] = fused["capture"](2 * KSTEP, n)
+    rewind()
     run_steps(max(warmup, 1))
-    torch.cuda.synchronize()
-    env.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(steps)
-    host_ms = (time.perf_counter() - t0) / steps * 1e3
-    torch.cuda.synchronize()
-    env.barrier()
-    torch.cuda.synchronize()
-    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+
+    def timed_region():
+        """EXACTLY `steps` steps between barrier + synchronize on both sides; returns (max-over-ranks seconds, host enqueue seconds)"""
+        rewind()
+        torch.cuda.synchronize()
+        env.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        env.barrier()
+        torch.cuda.synchronize()
+        return env.max_over_ranks(time.perf_counter() - t0), host
+
+    # A short region (the driver's --steps 20 is ~3 ms of GPU time here) is one sample of launch jitter: when steps x ms_per_step < 0.25 s the
+    # SAME `steps`-step region is repeated and the MEDIAN repetition is the one reported (`reps`; `steps` stays the argument).  The count
+    # follows from the first repetition's max-over-ranks time, so every rank repeats equally often.
+    first, host_s = timed_region()
+    reps = 1
+    if first < MIN_REGION_S:
+        reps = int(min(MAX_REPS, max(3, np.ceil(MIN_REGION_S / max(first, 1e-6))))) | 1
+    samples = [first] + [timed_region()[0] for _ in range(reps - 1)]
+    elapsed = float(np.median(samples))
+    host_ms = host_s / steps * 1e3
     per_step_pairs = pairs_global if (sharded or not env.multi) else pairs_global * world
     value = per_step_pairs * steps / elapsed
     ms_per_step = elapsed / steps * 1e3
+    spread = (round(min(samples) / steps * 1e3, 5), round(max(samples) / steps * 1e3, 5))
 
     single_ms, overlap_diff = ms_per_step, None
     if len(lanes) > 1:
@@ -772,6 +810,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             overlap_diff = float((mine_[0].reshape(o1.shape) - o1).abs().max())
             ts = None
         elif fused is not None or stages is not None:   # (fused / pipelined steps: "one in flight" has no separate meaning there)
+            rewind()
             run_steps(ns)
         else:
             for i in range(ns):
@@ -929,9 +968,11 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         else:
             par = "strong: candidate-sharded x%d (%d per rank) + %s all-gather of scores" % (
                 world, batches[0]["doc_rep"].shape[1], "RCCL" if env.backend == "nccl" else env.backend)
-    return {"name": name, "baseline_config": c.get("baseline"), "workload": tag, "pairs_per_s": round(value, 1), "ms_per_step": round(ms_per_step, 5),
+    shard_axis = None if not sharded else ("pair" if plan is not None and plan.aligned else "candidate")
+    return {"name": name, "baseline_config": c.get("baseline"), "workload": tag, "shard_axis": shard_axis,
+            "kg": (stages["KG"] if (stages is not None and "aligned" in stages) else 1), "pairs_per_s": round(value, 1), "ms_per_step": round(ms_per_step, 5),
             "ms_per_step_one_batch_in_flight": round(single_ms, 5), "global_batch_pairs": per_step_pairs, "parallelism": par, "world_size": world,
-            "steps": steps, "hipgraph": (graphs is not None) or (stages is not None and stages.get("graphed", True)) or (fused is not None),
+            "steps": steps, "reps": reps, "ms_per_step_min_max": spread, "hipgraph": (graphs is not None) or (stages is not None and stages.get("graphed", True)) or (fused is not None),
             "batches_in_flight": len(lanes) * (stages["KG"] if (stages is not None and "aligned" in stages) else 1),
             "macro_batch": (stages["KG"] if (stages is not None and "aligned" in stages) else 1), "lanes": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
@@ -991,22 +1032,114 @@ def cpu_baseline(c, model, batches, gpu_step, pairs, args):
             "max_abs_diff_vs_gpu_softmax": maxdiff}
 
 
+class QuietStderr(object):
+    """The driver reads the record from the tail of stdout FOLLOWED by stderr, so whatever a successful run writes to stderr lands behind the
+    JSON line (round 3: a torch warning did, and the record could not be parsed).  File descriptor 2 is pointed at a log file for the length
+    of the run -- C-level writers (RCCL, the HIP runtime) included -- and is replayed to the real stderr only when the run fails."""
+
+    def __init__(self, path):
+        self.path, self.saved = path, None
+
+    def __enter__(self):
+        if os.environ.get("BENCH_KEEP_STDERR"):
+            return self
+        sys.stderr.flush()
+        self.saved = os.dup(2)
+        fd = os.open(self.path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.dup2(fd, 2)
+        os.close(fd)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.saved is None:
+            return False
+        sys.stderr.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved, 2)
+        os.close(self.saved)
+        if et is not None and not (et is SystemExit and not ev.code):
+            try:
+                sys.stderr.write(open(self.path, errors="replace").read()[-6000:])
+            except OSError:
+                pass
+        return False
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (torch.distributed.run, one process per GPU,
+    rendezvous on 127.0.0.1) and hand their stdout through.  The launcher's own chatter goes to the log unless the run fails."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench.py: --gpus %d asked for, %d visible -- RCCL needs one device per rank (BENCH_BACKEND=gloo runs the flow on fewer)" % (args.gpus, ndev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "8")
+    p = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
+    if p.returncode != 0:
+        sys.stderr.write(p.stderr.decode(errors="replace")[-6000:])
+    else:
+        try:
+            open(os.path.join(LOG_DIR, "bench_launcher.log"), "wb").write(p.stderr)
+        except OSError:
+            pass
+    raise SystemExit(p.returncode)
+
+
+LOG_DIR = os.environ.get("BENCH_LOG_DIR", ROOT)
+ROOF_KEYS = ("kernel", "avg_us", "launches_per_step", "bound", "achieved", "peak", "unit", "frac", "hbm_frac_8d", "traffic", "traffic_ratio",
+             "mfma_busy_pmc", "step_hbm_GBps_8d")
+
+
+def short_sub(n, r):
+    rf = r.get("roofline") or {}
+    e = {"name": n, "pairs_per_s": r.get("pairs_per_s"), "frac": rf.get("frac"), "bound": rf.get("bound")}
+    if r.get("world_size", 1) > 1 or r.get("shard_axis"):
+        e["axis"] = r.get("shard_axis")
+    if r.get("error"):
+        e["error"] = str(r["error"])[:80]
+    for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle", "kg"):
+        if k in r:
+            e[k] = r[k]
+    if n.startswith("train_") or r.get("pairs_per_s") is None:
+        e["ms_per_step"] = r.get("ms_per_step")
+    return e
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    env = Env()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    rank = int(os.environ.get("RANK", "0"))
+    with QuietStderr(os.path.join(LOG_DIR, "bench_stderr.rank%d.log" % rank)):
+        result_line = run_all(args)
+    if result_line is not None:
+        sys.stderr.flush()
+        print(result_line, flush=True)
+
+
+def run_all(args):
+    env = Env(args.gpus)
     for kv in filter(None, os.environ.get("NIR_TUNE", "").split(",")):     # kernel-variant A/B runs: NIR_TUNE=name=value,...
         k, v = kv.split("=")
         lib.check(lib.load().nir_debug_set_tunable(k.encode(), int(v)), "nir_debug_set_tunable")
-    assert env.world == args.gpus or env.world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     if args.config == "C5_stream":
         r = stream_record(args, env, seconds=None)
-        line = {"metric": "ranked (query,doc) pairs/sec", "value": r.get("pairs_per_s"), "unit": "pairs/s", "n_gpus": 1, "steps": r.get("batches"), "warmup": 0,
+        if env.rank != 0:
+            return None
+        write_detail({"C5_stream": r})
+        keep = ("name", "pairs_per_s", "sessions_per_s", "batches", "seconds", "h2d_GBps", "lanes", "macro_batch", "parallelism", "world_size", "whole_stream", "error")
+        line = {"metric": "ranked (query,doc) pairs/sec", "value": r.get("pairs_per_s"), "unit": "pairs/s", "n_gpus": env.seen, "steps": r.get("batches"), "warmup": 0,
                 "ms_per_step": r.get("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": r}
-        print(json.dumps(line), flush=True)
-        return
+                "config": {k: r.get(k) for k in keep if k in r}}
+        return json.dumps(line)
     head = dict(CONFIGS[args.config])
     adhoc = False
     for k in ("model", "batch", "cands", "qlen", "dlen", "session", "vocab", "uniform", "dtype"):
@@ -1020,88 +1153,147 @@ def main():
     rec = run_config(hname, head, args, env, args.steps, args.warmup, shard=True, want_cpu=True, with_h2d=True)
 
     sub = {}
-    names = [] if adhoc else [n for n in CONFIGS if n != args.config]
-    if args.sub is not None:
-        names = [] if args.sub == "none" else [n for n in args.sub.split(",") if n in CONFIGS]
-    for n in names:
+
+    def attempt(n, fn):
         try:
-            r = run_config(n, dict(CONFIGS[n]), args, env, SUB_STEPS.get(n, 100), min(args.warmup, 8), shard=True)
+            r = fn()
         except Exception as e:  # a sub-record must never take the headline down
+            if env.multi and env.world > 1:
+                raise      # (but a rank that leaves a collective sequence must take the JOB down, not hang the other ranks)
             r = {"name": n, "error": "%s: %s" % (type(e).__name__, e)} if env.rank == 0 else None
             torch.cuda.synchronize()
         if r is not None:
             sub[n] = r
         torch.cuda.empty_cache()
-    if head["model"] == "cars" and not adhoc and args.sub != "none" and not env.multi:
-        try:      # the same workload WITHOUT the folded gate tables: per-batch gather-GEMM for the LSTM input projection
-            r = run_config(hname + "_nofold", dict(head, nofold=True), args, env, max(40, args.steps // 4), min(args.warmup, 8), shard=True)
-        except Exception as e:
-            r = {"name": hname + "_nofold", "error": "%s: %s" % (type(e).__name__, e)}
-            torch.cuda.synchronize()
-        if r is not None:
-            sub[hname + "_nofold"] = r
+
+    # N = 1: every single-GPU BASELINE configuration.  N > 1: the configurations BASELINE shards (configs[3] DUET / DRMM candidate-sharded,
+    # configs[4] shape) next to the headline, the headline on the OTHER CARS shard axis and with the N = 1 macro-batch (KG-matched)
+    names = [] if adhoc else ([n for n in CONFIGS if n != args.config] if not env.multi else
+                              [n for n in ("C4_duet", "C4_drmm", "C5_cars_bf16") if n != args.config])
+    if args.sub is not None:
+        names = [] if args.sub == "none" else [n for n in args.sub.split(",") if n in CONFIGS]
+    for n in names:
+        attempt(n, lambda n=n: run_config(n, dict(CONFIGS[n]), args, env, SUB_STEPS.get(n, 100), min(args.warmup, 8), shard=True))
+        if n == "C4_drmm" and not env.multi and env.rank == 0 and "error" not in sub.get(n, {"error": 1}) and not args.no_cpu_baseline:
+            try:
+                gap = drmm_parity_gap(args)
+                sub[n]["parity_gap_on_overlapping_ids"] = gap
+                sub[n].update({k: gap["numpy"][k] for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle")})
+            except Exception as e:
+                sub[n]["parity_gap_on_overlapping_ids"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    full = not adhoc and args.sub is None
+    if head["model"] == "cars" and full and not env.multi:
+        # the same workload WITHOUT the folded gate tables: per-batch gather-GEMM for the LSTM input projection
+        attempt(hname + "_nofold", lambda: run_config(hname + "_nofold", dict(head, nofold=True), args, env, max(40, args.steps // 4), min(args.warmup, 8), shard=True))
         sub["C3_cars_with_decode"] = decode_record(head, args, env)
-        torch.cuda.empty_cache()
-        sub["C5_stream"] = stream_record(args, env, seconds=float(os.environ.get("BENCH_H2D_SECONDS", "5")))
         torch.cuda.empty_cache()
         sub["train_C3_cars_update"] = train_record("CARS", dict(head), args, env)
         sub["train_C2_match_tensor_update"] = train_record("MATCH_TENSOR", dict(CONFIGS["C2_match_tensor"]), args, env)
+    if head["model"] == "cars" and full and env.multi and env.world > 1:
+        ax = rec.get("shard_axis") if rec else None
+        other = "candidate" if ax == "pair" else "pair"
+        if other == "candidate" or head["batch"] % env.world == 0:
+            attempt(hname + "_axis_" + other, lambda: run_config(hname + "_axis_" + other, head, args, env, args.steps, min(args.warmup, 8), shard=True, axis=other))
+        attempt(hname + "_kg_matched", lambda: run_config(hname + "_kg_matched", head, args, env, args.steps, min(args.warmup, 8), shard=True, kg=macro_batch(head)))
+    if head["model"] == "cars" and full and not os.environ.get("BENCH_NO_STREAM"):
+        secs = float(os.environ.get("BENCH_H2D_SECONDS", "5"))
+        attempt("C5_stream", lambda: stream_record(args, env, seconds=secs, mode="batch" if env.multi else None))
+        if env.multi and CONFIGS["C5_cars_bf16"]["batch"] % int(os.environ.get("BENCH_EMULATE_WORLD", env.world)) == 0:
+            attempt("C5_stream_pair", lambda: stream_record(args, env, seconds=secs, mode="pair"))
     weak = None
-    if env.multi:           # labelled secondary number: every rank scores its own full batch, no collective
+    if env.multi and not os.environ.get("BENCH_NO_WEAK"):           # labelled secondary number: every rank scores its own full batch, no collective
         r = run_config(hname + "_weak", head, args, env, max(20, args.steps // 4), min(args.warmup, 8), shard=False)
         weak = r["pairs_per_s"] if r else None
 
     result_line = None
     if env.rank == 0:
-        roof = rec.pop("roofline")
+        roof = rec.pop("roofline") or {}
         cpu = rec.pop("cpu_baseline")
-        cfg = dict(rec)
-        cfg["hw_queues"] = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
-        cfg["weak_scaling_pairs_per_s"] = weak
-        cfg["sub"] = sub
-        pre = cfg.pop("precompute", None)
-        for k, v in (pre or {}).items():                  # scalar keys: survive a one-level parser
-            roof["precompute_" + k] = v
-        # the sub-records again as a SHORT flat list + scalar keys (a parser that keeps only scalars one level down still sees every config)
-        short = []
-        for n, r in sub.items():
-            rf = r.get("roofline") or {}
-            e = {"name": n, "pairs_per_s": r.get("pairs_per_s"), "ms_per_step": r.get("ms_per_step"),
-                 "ms_per_step_one_batch_in_flight": r.get("ms_per_step_one_batch_in_flight"), "dtype": r.get("dtype"),
-                 "kernel": rf.get("kernel"), "avg_us": rf.get("avg_us"), "bound": rf.get("bound"), "frac": rf.get("frac"),
-                 "mfma_frac": rf.get("mfma_frac"), "hbm_frac_8d": rf.get("hbm_frac_8d"), "traffic_ratio": rf.get("traffic_ratio"),
-                 "mfma_busy_pmc": rf.get("mfma_busy_pmc"), "error": r.get("error")}
-            short.append(e)
-            cfg["sub.%s.pairs_per_s" % n] = e["pairs_per_s"]
-            roof["sub.%s.frac" % n] = e["frac"]
-            roof["sub.%s.bound" % n] = e["bound"]
-        line = {"metric": "ranked (query,doc) pairs/sec", "value": rec["pairs_per_s"], "unit": "pairs/s", "n_gpus": env.world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+        pre = rec.get("precompute") or {}
+        detail = {"headline": dict(rec, roofline=roof, cpu_baseline=cpu), "sub": sub, "weak_scaling_pairs_per_s": weak,
+                  "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "argv": sys.argv[1:]}
+        where = write_detail(detail)
+        # ---- the record the driver parses: ONE compact line (every sub-record once, four scalars each); the full records are in `detail` ----
+        cfg = {"name": rec["name"], "workload": rec["workload"], "macro_batch": rec["macro_batch"], "lanes": rec["lanes"],
+               "batches_in_flight": rec["batches_in_flight"], "ms_per_step_one_batch_in_flight": rec["ms_per_step_one_batch_in_flight"],
+               "hipgraph": rec["hipgraph"], "parallelism": rec["parallelism"][:400], "shard_axis": rec.get("shard_axis"), "world_size": rec["world_size"],
+               "pairs_per_s_with_host_ids_h2d": rec["pairs_per_s_with_host_ids_h2d"], "weak_scaling_pairs_per_s": weak, "detail": where}
+        small = {k: roof.get(k) for k in ROOF_KEYS}
+        small["precompute_fold_ms"], small["precompute_fold_bytes"] = pre.get("fold_ms"), pre.get("fold_bytes")
+        if cpu:
+            cpu = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model", "host_logical_cores", "max_abs_diff_vs_gpu_softmax")}
+            cpu["sample"] = "%.0f s of the same workload through oracle/neuroir_cpu.py (torch CPU, best of 8/16/32/64 threads)" % args.cpu_seconds
+        line = {"metric": "ranked (query,doc) pairs/sec", "value": rec["pairs_per_s"], "unit": "pairs/s", "n_gpus": env.seen,
+                "steps": args.steps, "warmup": args.warmup, "reps": rec["reps"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
                 # the global batch is FIXED as N grows (every rank scores its share of the same batch): strong scaling at every N
                 "scaling": "strong", "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
-                "config": cfg, "roofline": roof, "cpu_baseline": cpu, "sub": short}
-        result_line = json.dumps(line)
+                "config": cfg, "roofline": small, "cpu_baseline": cpu, "sub": [short_sub(n, r) for n, r in sub.items()]}
+        result_line = json.dumps(line, separators=(",", ":"))
     if env.dist:
         env.dist.destroy_process_group()
     # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it out first so that the
     # JSON line is the LAST line of rank 0's stdout
     ctypes.CDLL(None).fflush(None)
-    if result_line is not None:
-        print(result_line, flush=True)
+    return result_line
 
 
-def stream_record(args, env, seconds=None, n_sessions=223876):
-    """BASELINE.json configs[4] on ONE GPU: CARS at MSMARCO scale as a STREAM -- 223 876 synthetic sessions with
+def write_detail(obj):
+    """the full records (every sub-record with its roofline block, per-kernel microseconds, precompute, H2D stream) -> bench_detail.json"""
+    path = os.environ.get("BENCH_DETAIL", os.path.join(LOG_DIR, "bench_detail.json"))
+    try:
+        with open(path, "w") as f:
+            json.dump(obj, f, indent=1, default=str)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
+def drmm_parity_gap(args):
+    """Checker leg (rank 0, N = 1; the oracle is used as the checker only): DRMM on Zipf ids, where queries and documents SHARE tokens and the
+    exact-match bins carry signal.  At an exact overlap the cosine is 1 +- 1 ulp by reduction order, so numpy.histogram's top two bins are not
+    reproducible across implementations (reference rankers/drmm.py:66-78): the integer histogram is NOT bit-exact there
+    and the record says by how much -- (pair, query term) rows and pairs whose histogram differs from the oracle's, and the MAP delta on this
+    slice (random-weight model), for the default policy and the opt-in 'snap' rule."""
+    from oracle import neuroir_cpu as O
+    from context_attentive_ir_amd.eval import ltorank
+    V, B, N, QL, DL = 100000, 16, 50, 4, 290
+    ex = synth.ranker_batch(B, N, QL, DL, V, seed=1013, full_length=False)
+    m = build_model(dict(CONFIGS["C4_drmm"], vocab=V), args).network
+    sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+    q, ql, d, dl, lab = (ex[k] for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label"))
+    gate, _, hist_ref = O.drmm_parts(sd, q, d)
+    s_ref = O.drmm_scores_from_hist(sd, gate, hist_ref, B, N)
+    overlaps = int(((q[:, None, :, None] == d[:, :, None, :]) & (q[:, None, :, None] != 0)).sum())
+    a_ref = np.argsort(-s_ref.numpy(), 1, kind="stable")
+    out = {"slice": "%dx%dx%dx%d Zipf ids, V=%d" % (B, N, QL, DL, V), "exact_overlaps": overlaps, "hist_rows": B * N * QL}
+    for policy in ("numpy", "snap"):
+        m.exact_match_policy = policy
+        s, h = m(q.cuda(), ql.cuda(), d.cuda(), dl.cuda(), return_hist=True)
+        h, hr = h.cpu().numpy(), hist_ref.numpy()
+        rows = (h != hr).any(-1)
+        a_got = np.argsort(-s.cpu().numpy(), 1, kind="stable")
+        out[policy] = {"hist_rows_differ": int(rows.sum()), "pairs_differ": int(rows.any(-1).sum()), "lower_bins_differ": int((h[..., :3] != hr[..., :3]).sum()),
+                       "map_delta_vs_oracle": round(ltorank.MAP(a_got, lab.numpy()) - ltorank.MAP(a_ref, lab.numpy()), 5)}
+    m.exact_match_policy = "numpy"
+    return out
+
+
+def stream_record(args, env, seconds=None, n_sessions=None, mode=None):
+    """BASELINE.json configs[4]: CARS at MSMARCO scale as a STREAM -- 223 876 synthetic sessions with
     S ~ clip(Poisson(4.84) + 2, 2, 16) queries, batched exactly as the reference sampler does (equal-length sessions per
     batch, full batches, shuffled; neuroir/inputters/multitask/data.py:42-72), 64 sessions x 50 candidates per batch, bf16 folded tables.
     Ids arrive from the host for every batch (int32 wire block collated into pinned staging by a producer thread), one captured hipGraph
     per session length and lane; value = pairs of the batches submitted / wall seconds, H2D and D2H of the probabilities included.
-    seconds=None: the WHOLE stream once; else sustained for that long (batches cycled)."""
+    N > 1 (sharding.StreamShardPlan): mode "batch" = rank r scores batches r, r+N, .. whole; "pair" = every batch cut into N blocks of whole
+    sessions; either way the probabilities of every batch are all-gathered to every rank on the lanes' communication streams while the
+    next batch is encoded.  Every rank runs the same number of rounds; value = pairs scored by all ranks / max-over-ranks seconds.
+    seconds=None: the WHOLE stream once; else sustained for about that long (batches cycled)."""
     try:
         from context_attentive_ir_amd.graph_runner import StreamingSessionPredictor
         from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
         c = dict(CONFIGS["C5_cars_bf16"])
         model = build_model(c, args)
+        n_sessions = n_sessions or int(os.environ.get("BENCH_STREAM_SESSIONS", "223876"))
         t0 = time.perf_counter()
         corpus = SyntheticSessionCorpus(n_sessions=n_sessions, n_cands=c["cands"], qlen=c["qlen"], dlen=c["dlen"], vocab=c["vocab"], pool=96)
         bl = corpus.batches(c["batch"])
@@ -1109,7 +1301,14 @@ def stream_record(args, env, seconds=None, n_sessions=223876):
         lengths = sorted({int(corpus.lengths[b[0]]) for b in bl})
         nl = max(2, min(args.streams, 4))
         mk = max(1, int(os.environ.get("BENCH_STREAM_MACRO", "1")))       # (64 x S x 50 per batch: macro 2 measured +1 %, macro 4 runs out of HBM)
-        sp = StreamingSessionPredictor(model, c["cands"], c["qlen"], c["dlen"], mk * c["batch"], max_session_len=max(lengths), lanes=nl, slots=2, macro=mk)
+        plan, W = None, env.world
+        if env.multi:
+            mode = mode or os.environ.get("BENCH_STREAM_MODE", "batch")
+            if env.world == 1 and os.environ.get("BENCH_EMULATE_WORLD"):
+                W = int(os.environ["BENCH_EMULATE_WORLD"])
+            plan = sharding.StreamShardPlan(W, env.rank, mode, batch_size=c["batch"])
+        sp = StreamingSessionPredictor(model, c["cands"], c["qlen"], c["dlen"], mk * c["batch"], max_session_len=max(lengths), lanes=nl, slots=2, macro=mk,
+                                       plan=plan)
         n_sampler_batches = len(bl)
         # mk sampler batches of one session length per wire block / graph replay; the < mk left-over batches per length are not part of this
         # measurement (`left_over_batches_not_timed`; a full run scores them through a macro = 1 predictor)
@@ -1119,20 +1318,57 @@ def stream_record(args, env, seconds=None, n_sessions=223876):
         sp.prepare(lengths, example=(corpus, bl[0]))
         torch.cuda.synchronize()
         t_capture = time.perf_counter() - t0
-        sp.run(corpus, bl, max_batches=4 * nl)                                     # warm the pipeline
-        r = sp.run(corpus, bl, min_seconds=seconds, producers=2 if (nl * 2) % 2 == 0 else 1)
+        prod = 2 if (nl * 2) % 2 == 0 else 1
+        sink = (lambda *a: None) if plan is not None else None        # a consumer: the gathered rounds are really handed over on every rank
+        sp.run(corpus, bl, max_batches=4 * nl, on_result=sink)                                     # warm the pipeline
+        if plan is None:
+            r = sp.run(corpus, bl, min_seconds=seconds, producers=prod)
+            elapsed, pairs_all, rounds = r["seconds"], r["pairs"], r["batches"]
+        else:
+            rounds = plan.rounds(len(bl))
+            if seconds is not None:       # a fixed round count every rank agrees on (a round is a collective): calibrated on rank-local time, MIN over ranks
+                probe = sp.run(corpus, bl, max_batches=8 * nl, cycle=True, on_result=sink, producers=prod)
+                want = torch.tensor([max(4 * nl, seconds / (probe["seconds"] / probe["batches"]))], dtype=torch.float64,
+                                    device=env.dev if env.backend == "nccl" else "cpu")
+                env.dist.all_reduce(want, op=env.dist.ReduceOp.MIN)
+                rounds = int(want.item())
+            torch.cuda.synchronize()
+            env.barrier()
+            t1 = time.perf_counter()
+            r = sp.run(corpus, bl, max_batches=rounds, cycle=True, on_result=sink, producers=prod)
+            torch.cuda.synchronize()
+            env.barrier()
+            elapsed = env.max_over_ranks(time.perf_counter() - t1)
+            tot = torch.tensor([float(r["pairs"])], dtype=torch.float64, device=env.dev if env.backend == "nccl" else "cpu")
+            env.dist.all_reduce(tot)
+            pairs_all = float(tot.item()) * (W if sp.emulated else 1)        # (emulated world: every other rank would have scored the same share)
+        if env.rank != 0:
+            return None
         hist = {int(k): int(v) for k, v in zip(*np.unique(corpus.lengths, return_counts=True))}
-        return {"name": "C5_stream", "baseline_config": "configs[4]: CARS at MSMARCO scale: ~224k-session stream, 50 candidates/query, bf16 (one GPU's share measured here)",
+        per_round_batches = mk * (1 if plan is None or plan.mode == "pair" else W)
+        par = "single GPU"
+        if plan is not None:
+            par = ("stream over %d ranks, mode '%s' (%s), all-gather of the click probabilities of every batch to every rank (%s) overlapped with the next "
+                   "batch's H2D / widen / encode; %d rounds on every rank" % (
+                       W, plan.mode, "rank r scores sampler batches r, r+%d, .. whole" % W if plan.mode == "batch" else
+                       "every batch cut into %d blocks of %d whole sessions, the batch's click count shipped with the block" % (W, plan.bper),
+                       {"device": "RCCL on the lane's communication stream", "host": "gloo through the host", "none": "none"}[sp.gather], rounds))
+            if sp.emulated:
+                par += " [EMULATED on one GPU: rank 0's share, loop-back collective, no xGMI latency; value = %d x this rank's pairs]" % W
+        return {"name": "C5_stream", "baseline_config": "configs[4]: CARS at MSMARCO scale: ~224k-session stream, 50 candidates/query, bf16",
                 "workload": "cars bf16, %d sessions, S ~ clip(Poisson(4.84)+2,2,16) (mean %.2f), %d candidates, q_len %d, doc_len %d, batches of %d equal-length "
                             "sessions (reference sampler), ids from the host per batch" % (len(corpus), float(corpus.lengths.mean()), c["cands"], c["qlen"], c["dlen"], c["batch"]),
-                "pairs_per_s": round(r["pairs_per_s"], 1), "sessions_per_s": round(r["batches"] * mk * c["batch"] / r["seconds"], 1), "batches": r["batches"] * mk,
-                "macro_batch": mk, "sampler_batches": n_sampler_batches, "left_over_batches_not_timed": len(rest),
-                "whole_stream": seconds is None, "seconds": round(r["seconds"], 3), "h2d_GBps": round(r["h2d_GBps"], 3), "lanes": r["lanes"],
+                "pairs_per_s": round(pairs_all / elapsed, 1), "sessions_per_s": round(pairs_all / c["cands"] / float(corpus.lengths.mean()) / elapsed, 1),
+                "batches": int(rounds * per_round_batches), "rounds": int(rounds), "world_size": env.world, "shard_axis": None if plan is None else plan.mode,
+                "parallelism": par, "macro_batch": mk, "sampler_batches": n_sampler_batches, "left_over_batches_not_timed": len(rest),
+                "whole_stream": seconds is None, "seconds": round(elapsed, 3), "h2d_GBps": round(r["h2d_GBps"], 3), "lanes": r["lanes"],
                 "slots_per_lane": r["slots_per_lane"], "producer_threads": r["producers"], "session_lengths": lengths, "length_histogram": hist,
                 "graphs": len(lengths) * nl, "graph_capture_s": round(t_capture, 2), "corpus_build_s": round(t_corpus, 2), "dtype": "bf16",
                 "wire": "int32 ids/lengths + float32 labels (nir_widen_ids_i32 on device); D2H of the click probabilities included",
-                "ms_per_step": round(r["seconds"] / max(1, r["batches"] * mk) * 1e3, 5)}
+                "ms_per_step": round(elapsed / max(1, rounds * per_round_batches) * 1e3, 5)}
     except Exception as e:  # pragma: no cover
+        if env.multi:
+            raise          # (a rank that drops out of a collective sequence must take the job down, not hang the others)
         return {"name": "C5_stream", "error": "%s: %s" % (type(e).__name__, e)}
 
 

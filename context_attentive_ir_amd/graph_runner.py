@@ -167,29 +167,64 @@ class StreamingSessionPredictor(object):
     Shapes: batches of exactly `batch_size` sessions of one length (the reference sampler's composition,
     neuroir/inputters/multitask/data.py:42-72); a new length is captured on first use (outside any timed region: `prepare`)."""
 
-    def __init__(self, wrapper, n_cands, qlen, dlen, batch_size, max_session_len=16, lanes=2, slots=2, macro=1):
+    def __init__(self, wrapper, n_cands, qlen, dlen, batch_size, max_session_len=16, lanes=2, slots=2, macro=1, plan=None, group=None,
+                 gather="auto"):
         """macro > 1: a wire block / graph replay carries `macro` batches of one session length as ONE macro-batch (Multitask.predict_groups:
         one pass over the session weights for all of them, every batch keeps its own click count); `batch_size` is then macro x the
-        sampler's batch size and run() expects index lists of that length (see merge_batches)."""
+        sampler's batch size and run() expects index lists of that length (see merge_batches).
+
+        plan (sharding.StreamShardPlan) + group: the stream over the ranks of a process group (BASELINE.json configs[4]).  Every rank builds
+        the same batch list; per round this rank collates / scores its share (mode "batch": one whole batch of the round; mode "pair":
+        batch_size / world whole sessions of every batch, the batch's click count riding in the wire block) and the click probabilities of
+        all ranks are all-gathered: with the RCCL backend on the lane's own COMMUNICATION stream -- [ wait for the replay | all-gather | D2H of
+        the gathered block ] -- while the lane's compute stream already runs the next batch's H2D / widen / encode; with gloo (flow tests)
+        through the host at hand-over time.  Every rank delivers every batch's probabilities (on_result).
+        gather: "device" (RCCL) / "host" (gloo) / "none" (each rank keeps its own share: weak form) / "auto" (by backend)."""
         from .inputters.session_stream import WireLayout
         if not wrapper.use_cuda:
             raise RuntimeError("StreamingSessionPredictor needs a wrapper on a ROCm device (call .cuda() first)")
         self.macro = max(1, int(macro))
         if int(batch_size) % self.macro:
             raise RuntimeError("batch_size must be macro x the sampler's batch size")
-        self.wrapper, self.B, self.N, self.QL, self.DL = wrapper, int(batch_size), int(n_cands), int(qlen), int(dlen)
+        self.wrapper, self.N, self.QL, self.DL = wrapper, int(n_cands), int(qlen), int(dlen)
+        self.plan, self.group = plan, group
+        self.B_all = int(batch_size)                       # sessions of a (macro-)batch of the stream
+        pair = plan is not None and plan.mode == "pair"
+        if pair and plan.batch_size * self.macro != self.B_all:
+            raise RuntimeError("pair-mode plan was built for batches of %d sessions, the stream has %d x %d" % (plan.batch_size, self.macro, self.B_all // self.macro))
+        self.B = self.B_all // plan.world if pair else self.B_all      # sessions THIS rank scores per replay
+        self.groups = self.macro if pair else 0            # click counts shipped in the wire block
+        self.gather = gather
+        if plan is None or plan.world == 1 and group is None:
+            self.gather = "none" if gather == "auto" else gather
+        elif gather == "auto":
+            import torch.distributed as dist
+            self.gather = "device" if dist.get_backend(group) == "nccl" else "host"
+        self.emulated = False                              # plan.world > ranks of the group: this process times ONE rank's share (tuning aid)
+        if self.gather != "none":
+            import torch.distributed as dist
+            self.emulated = dist.get_world_size(group) != plan.world
         self.WireLayout = WireLayout
         self.dev = next(wrapper.network.parameters()).device
-        big = WireLayout(self.B, max_session_len, self.N, self.QL, self.DL)
+        big = WireLayout(self.B, max_session_len, self.N, self.QL, self.DL, self.groups)
         self.max_S = int(max_session_len)
         self.lanes = []
+        G = plan.world if plan is not None else 1
+        blk = self.B * max_session_len * self.N             # one rank's (padded) probability block
+        self.block = blk
         for _ in range(max(1, lanes)):
             ln = {"stream": torch.cuda.Stream(device=self.dev),
                   "wire": torch.empty(big.nbytes, dtype=torch.uint8, device=self.dev),
                   "wide": torch.empty(big.n_int, dtype=torch.int64, device=self.dev),
                   "host": [torch.empty(big.nbytes, dtype=torch.uint8).pin_memory() for _ in range(max(1, slots))],
-                  "res": [torch.empty(self.B * max_session_len * self.N, dtype=torch.float32).pin_memory() for _ in range(max(1, slots))],
+                  "res": [torch.empty((G if self.gather != "none" else 1) * blk, dtype=torch.float32).pin_memory() for _ in range(max(1, slots))],
                   "copied": [None] * max(1, slots), "done": [None] * max(1, slots), "graphs": {}, "owners": {}}
+            if self.gather == "device":
+                # per slot: the rank's block as the replay left it + everybody's blocks; the communication stream owns them until `done`
+                ln["comm"] = torch.cuda.Stream(device=self.dev)
+                ln["gsend"] = [torch.zeros(blk, device=self.dev) for _ in range(max(1, slots))]
+                ln["grecv"] = [torch.zeros(G * blk, device=self.dev) for _ in range(max(1, slots))]
+                ln["replayed"] = [None] * max(1, slots)
             ln["host_np"] = [h.numpy() for h in ln["host"]]
             self.lanes.append(ln)
         lib.load().nir_set_batches_in_flight(len(self.lanes))      # (returns the value set, not an error code)
@@ -198,7 +233,10 @@ class StreamingSessionPredictor(object):
     def _step(self, ln, lay):
         wide = lay.wide_views(ln["wide"])
         lib.check(lib.load().nir_widen_ids_i32(lib.ptr(ln["wire"]), lib.ptr(ln["wide"]), lay.n_int, lib.stream()), "nir_widen_ids_i32")
-        ex = dict(wide, document_labels=lay.views(ln["wire"])["document_labels"])
+        wv = lay.views(ln["wire"])
+        ex = dict(wide, document_labels=wv["document_labels"])
+        if lay.groups:                                     # a slice of `groups` batches: their click counts came with the block (int32, as shipped)
+            return self.wrapper.predict_groups(ex, lay.groups, click_max=wv["click_max"])
         if self.macro > 1:
             return self.wrapper.predict_groups(ex, self.macro)
         return self.wrapper.predict(ex, suggest=False)["click_scores"]
@@ -209,7 +247,7 @@ class StreamingSessionPredictor(object):
         for S in sorted({int(s) for s in lengths}):
             if S > self.max_S:
                 raise RuntimeError("session length %d > max_session_len %d" % (S, self.max_S))
-            lay = self.WireLayout(self.B, S, self.N, self.QL, self.DL)
+            lay = self.WireLayout(self.B, S, self.N, self.QL, self.DL, self.groups)
             for ln in self.lanes:
                 if S in ln["graphs"]:
                     continue
@@ -217,7 +255,7 @@ class StreamingSessionPredictor(object):
                 with torch.cuda.stream(ln["stream"]), lib.workspace_owner(owner):
                     ln["wire"].zero_()
                     if example is not None and int(example[0].lengths[example[1][0]]) == S:
-                        example[0].collate_into(example[1], ln["host_np"][0])
+                        self._collate(example[0], example[1], ln["host_np"][0])
                         ln["wire"][:lay.nbytes].copy_(ln["host"][0][:lay.nbytes])
                     for _ in range(2):
                         self._step(ln, lay)
@@ -242,14 +280,60 @@ class StreamingSessionPredictor(object):
                 ln["copied"][slot], ln["done"][slot] = torch.cuda.Event(), torch.cuda.Event()
             ln["copied"][slot].record(ln["stream"])
             g.replay()
-            ln["res"][slot][:lay.pairs].copy_(out.reshape(-1), non_blocking=True)
-            ln["done"][slot].record(ln["stream"])
+            if self.gather != "device":
+                ln["res"][slot][:lay.pairs].copy_(out.reshape(-1), non_blocking=True)
+                ln["done"][slot].record(ln["stream"])
+            else:
+                # the slot's gather buffers are free again once the communication stream has finished the slot's previous round
+                # (`done`, recorded there); the compute stream only parks its block and moves on to the next batch
+                if ln["replayed"][slot] is None:
+                    ln["replayed"][slot] = torch.cuda.Event()
+                else:
+                    ln["stream"].wait_event(ln["done"][slot])
+                ln["gsend"][slot][:lay.pairs].copy_(out.reshape(-1), non_blocking=True)
+                ln["replayed"][slot].record(ln["stream"])
+        if self.gather == "device":
+            import torch.distributed as dist
+            G = self.plan.world
+            with torch.cuda.stream(ln["comm"]):
+                ln["comm"].wait_event(ln["replayed"][slot])
+                # issue order of the collectives = submission order of the batches, identical on every rank
+                work = dist.all_gather_into_tensor(ln["grecv"][slot][:self.block] if self.emulated else ln["grecv"][slot], ln["gsend"][slot],
+                                                   group=self.group, async_op=True)
+                work.wait()                                 # (the communication stream waits, not the host)
+                ln["res"][slot][:G * self.block].copy_(ln["grecv"][slot], non_blocking=True)
+                ln["done"][slot].record(ln["comm"])
         return lay
 
     def result(self, lane, slot, lay):
-        """click probabilities [B,S,N] of the batch submitted from (lane, slot) -- host tensor (valid until the slot is re-submitted)."""
+        """click probabilities [B,S,N] of the batch submitted from (lane, slot) -- host tensor (valid until the slot is re-submitted).
+        (With a gather: this rank's own block; run() hands the gathered rounds over through on_result.)"""
         self.lanes[lane]["done"][slot].synchronize()
-        return self.lanes[lane]["res"][slot][:lay.pairs].view(lay.B, lay.S, lay.N)
+        o = self.plan.rank * self.block if self.gather == "device" else 0
+        return self.lanes[lane]["res"][slot][o:o + lay.pairs].view(lay.B, lay.S, lay.N)
+
+    def gathered(self, lane, slot):
+        """[G, block] view of the host result slot: rank-major probability blocks of the round submitted from (lane, slot).  gloo: the
+        all-gather happens HERE, on the host, in hand-over order (identical on every rank)."""
+        ln = self.lanes[lane]
+        ln["done"][slot].synchronize()
+        G = self.plan.world
+        if self.gather == "host":
+            import torch.distributed as dist
+            if "hsend" not in ln:
+                ln["hsend"], ln["hrecv"] = torch.zeros(self.block), torch.zeros(G * self.block)
+            ln["hsend"].copy_(ln["res"][slot][:self.block])
+            dist.all_gather_into_tensor(ln["hrecv"], ln["hsend"], group=self.group)
+            return ln["hrecv"].view(G, self.block)
+        return ln["res"][slot][:G * self.block].view(G, self.block)
+
+    def _collate(self, corpus, idx, host_np):
+        """this rank's share of the (macro-)batch `idx` into a pinned slot."""
+        if self.plan is not None and self.plan.mode == "pair":
+            r, bs, bper = self.plan.rank, self.plan.batch_size, self.plan.bper
+            own = [x for g in range(len(idx) // bs) for x in idx[g * bs + r * bper:g * bs + (r + 1) * bper]]
+            return corpus.collate_into(own, host_np, whole=idx, batch_size=bs)
+        return corpus.collate_into(idx, host_np)
 
     @staticmethod
     def merge_batches(corpus, batches, macro):
@@ -267,36 +351,62 @@ class StreamingSessionPredictor(object):
         return out, rest
 
     # ---- the whole pipeline ----------------------------------------------------------------------------------------------
-    def run(self, corpus, batches, on_result=None, min_seconds=None, max_batches=None, producers=1):
-        """Stream `batches` (index lists into `corpus`; cycled when min_seconds asks for more) through the lanes.
+    def run(self, corpus, batches, on_result=None, min_seconds=None, max_batches=None, producers=1, cycle=False):
+        """Stream `batches` (index lists into `corpus`; cycled when min_seconds -- or max_batches with cycle=True -- asks for more) through the lanes.
         on_result(batch_no, idx, probs[B,S,N] host tensor): called in submission order once a batch's results are on the host.
-        -> dict(batches, pairs, seconds, pairs_per_s, h2d_bytes)."""
+        Under a process group every rank must run the SAME number of rounds (each round is a collective): pass max_batches (rounds), not
+        min_seconds.  -> dict(batches (= rounds submitted by this rank), pairs (scored by this rank), seconds, pairs_per_s, h2d_bytes)."""
+        if min_seconds and self.gather != "none":
+            raise RuntimeError("a gathered stream runs a fixed number of rounds on every rank: use max_batches (+ cycle=True), not min_seconds")
         import queue
         import threading
         L, R = len(self.lanes), len(self.lanes[0]["host"])
         nslots = L * R
-        self.prepare({int(corpus.lengths[b[0]]) for b in batches})
-        total = None if min_seconds else (len(batches) if max_batches is None else min(len(batches), max_batches))
+        plan = self.plan
+        lengths_of = lambda idx: int(corpus.lengths[idx[0]])     # noqa: E731
+        self.prepare({lengths_of(b) for b in batches})
+        # the stream in ROUNDS: without a plan round k = batch k; "pair": round k = this rank's sessions of batch k; "batch": round k = batch kG + rank
+        nrounds = len(batches) if plan is None else plan.rounds(len(batches))
+
+        def share(k):
+            """-> (index list handed to _collate, is it a real batch of this rank?)"""
+            j = k % nrounds
+            if plan is None or plan.mode == "pair":
+                return batches[j], True
+            b = j * plan.world + plan.rank
+            return (batches[b], True) if b < len(batches) else (batches[j * plan.world], False)
+
+        total = None if min_seconds else (nrounds if max_batches is None else (max_batches if cycle else min(nrounds, max_batches)))
         free_q, ready = [queue.Queue() for _ in range(producers)], queue.Queue()
         stop = threading.Event()
         err = []
 
         def produce(pi):
-            k = pi                                          # producer pi fills batches pi, pi + P, ... into slots k % nslots
+            k = pi                                          # producer pi fills rounds pi, pi + P, ... into slots k % nslots
             try:
                 while not stop.is_set() and (total is None or k < total):
                     try:
                         free_q[pi].get(timeout=0.05)            # token: slot (k % nslots) may be overwritten
                     except queue.Empty:
                         continue
-                    idx = batches[k % len(batches)]
+                    idx, real = share(k)
                     s = k % nslots
-                    lay = corpus.collate_into(idx, self.lanes[s % L]["host_np"][s // L])
-                    ready.put((k, s, lay.S))
+                    lay = self._collate(corpus, idx, self.lanes[s % L]["host_np"][s // L])
+                    ready.put((k, s, lay.S, real))
                     k += producers
             except BaseException as e:                      # surface collation errors in the consumer
                 err.append(e)
                 ready.put(None)
+
+        def hand_over(k, ln_i, sl_i, lay):
+            """results of round k to the consumer: every batch of the round (gathered) or this rank's own batch"""
+            if self.gather == "none":
+                idx, real = share(k)
+                if real:
+                    on_result(k, idx, self.result(ln_i, sl_i, lay))
+                return
+            for bno, idx, probs in plan.unpack(k % nrounds, self.gathered(ln_i, sl_i), batches, lengths_of, self.N):
+                on_result(bno, idx, probs)
 
         # slot s is owned by producer (batch k % producers) -- with nslots % producers == 0 a slot always belongs to the same producer
         if nslots % producers:
@@ -321,7 +431,7 @@ class StreamingSessionPredictor(object):
                 while inflight and (on_result is None or self.lanes[inflight[0][1]]["done"][inflight[0][2]].query()):
                     k, ln_i, sl_i, lay = inflight.pop(0)
                     if on_result is not None:
-                        on_result(k, batches[k % len(batches)], self.result(ln_i, sl_i, lay))
+                        hand_over(k, ln_i, sl_i, lay)
                         free_q[(sl_i * L + ln_i) % producers].put(sl_i * L + ln_i)
                     done += 1
                 if total is not None and nxt >= total:
@@ -342,13 +452,13 @@ class StreamingSessionPredictor(object):
                     pending[item[0]] = item
                     if nxt not in pending:
                         continue
-                k, s, S = pending.pop(nxt)
+                k, s, S, real = pending.pop(nxt)
                 ln_i, sl_i = s % L, s // L
                 lay = self.submit(ln_i, sl_i, S)
                 if on_result is None:
                     waiting_copy.append((ln_i, sl_i, s))
                 inflight.append((k, ln_i, sl_i, lay))
-                pairs += lay.pairs
+                pairs += lay.pairs if real else 0           # (a filler of a short last round is scored and dropped)
                 nbytes += lay.nbytes
                 nxt += 1
             torch.cuda.synchronize()

@@ -32,8 +32,11 @@ class WireLayout(object):
     """Byte layout of one batch on the wire (and in the device staging buffer): int32 fields back to back, then float32 labels.
     Field starts are multiples of 4 elements (16 bytes)."""
 
-    def __init__(self, B, S, N, QL, DL):
-        self.B, self.S, self.N, self.QL, self.DL = int(B), int(S), int(N), int(QL), int(DL)
+    def __init__(self, B, S, N, QL, DL, groups=0):
+        """groups > 0: the block also carries `click_max` int32 [groups] -- the click mask's batch-wide count m (cars.py:285-289) of each of
+        the `groups` sampler batches the B sessions were cut from (sharding.StreamShardPlan mode "pair": a rank holds B/G sessions of a batch and
+        cannot derive the batch's m from its own labels; the collator knows every label and ships the integer)."""
+        self.B, self.S, self.N, self.QL, self.DL, self.groups = int(B), int(S), int(N), int(QL), int(DL), int(groups)
         self.shapes = {"document_words": (B, S, N, DL), "document_lens": (B, S, N), "source_words": (B, S, QL), "source_lens": (B, S),
                        "document_labels": (B, S, N)}
         off = 0
@@ -41,6 +44,10 @@ class WireLayout(object):
         for k in INT_FIELDS:
             self.offset[k] = off
             off += (int(np.prod(self.shapes[k])) + 3) // 4 * 4
+        if self.groups:
+            self.shapes["click_max"] = (self.groups,)
+            self.offset["click_max"] = off
+            off += (self.groups + 3) // 4 * 4
         self.n_int = off                                   # int32 elements (padded), = the count handed to nir_widen_ids_i32
         self.offset["document_labels"] = off               # float32 elements from here on (same 4-byte units)
         self.n_words = off + (int(np.prod(self.shapes["document_labels"])) + 3) // 4 * 4
@@ -57,6 +64,8 @@ class WireLayout(object):
                 out[k] = w[self.offset[k]:self.offset[k] + n].reshape(self.shapes[k])
             o = self.offset["document_labels"]
             out["document_labels"] = buf_u8[:self.nbytes].view(np.float32)[o:o + self.pairs].reshape(self.shapes["document_labels"])
+            if self.groups:
+                out["click_max"] = w[self.offset["click_max"]:self.offset["click_max"] + self.groups]
             return out
         w = buf_u8[:self.nbytes].view(torch.int32)
         for k in INT_FIELDS:
@@ -64,6 +73,8 @@ class WireLayout(object):
             out[k] = w[self.offset[k]:self.offset[k] + n].view(self.shapes[k])
         o = self.offset["document_labels"]
         out["document_labels"] = buf_u8[:self.nbytes].view(torch.float32)[o:o + self.pairs].view(self.shapes["document_labels"])
+        if self.groups:
+            out["click_max"] = w[self.offset["click_max"]:self.offset["click_max"] + self.groups]
         return out
 
     def wide_views(self, buf_i64):
@@ -77,8 +88,9 @@ class WireLayout(object):
 
 class SyntheticSessionCorpus(object):
     def __init__(self, n_sessions=223876, n_cands=50, qlen=4, dlen=64, vocab=100000, seed=1013, pool=128, full_length=True,
-                 fixed_len=None, s_min=2, s_max=16):
-        """fixed_len: every session has this many queries (the fixed-shape configs); else S ~ clip(Poisson(4.84) + 2, s_min, s_max)."""
+                 fixed_len=None, s_min=2, s_max=16, multi_click=False):
+        """fixed_len: every session has this many queries (the fixed-shape configs); else S ~ clip(Poisson(4.84) + 2, s_min, s_max).
+        multi_click: 1-6 clicked candidates per query instead of one (the click mask's batch-wide count then differs between batches)."""
         rng = np.random.default_rng(seed)
         self.N, self.QL, self.DL, self.V = int(n_cands), int(qlen), int(dlen), int(vocab)
         if fixed_len is not None:
@@ -90,10 +102,12 @@ class SyntheticSessionCorpus(object):
         for S in np.unique(self.lengths):
             S = int(S)
             P = min(int(pool), int((self.lengths == S).sum()))
-            b = synth.session_batch(P, S, self.N, self.QL, self.DL, self.V, seed=seed + 7919 * S, full_length=full_length)
+            b = synth.session_batch(P, S, self.N, self.QL, self.DL, self.V, seed=seed + 7919 * S, full_length=full_length, multi_click=multi_click)
             self.pool[S] = {k: np.ascontiguousarray(v.numpy().astype(np.float32 if k == "document_labels" else np.int32)) for k, v in b.items()}
             idx = np.flatnonzero(self.lengths == S)
             self.slot[idx] = rng.integers(0, P, size=len(idx))
+            # clicked candidates of a session's most-clicked query: the per-session term of the click mask's batch-wide count m
+            self.pool[S]["_clicks"] = (self.pool[S]["document_labels"] != 0).sum(-1).max(-1).astype(np.int32)
 
     def __len__(self):
         return len(self.lengths)
@@ -104,18 +118,32 @@ class SyntheticSessionCorpus(object):
         rng = np.random.RandomState(seed)
         return samplers.session_length_batches(self.lengths, batch_size, shuffle=shuffle, rng=rng)
 
-    def layout(self, S, batch_size):
-        return WireLayout(batch_size, S, self.N, self.QL, self.DL)
+    def layout(self, S, batch_size, groups=0):
+        return WireLayout(batch_size, S, self.N, self.QL, self.DL, groups)
 
-    def collate_into(self, idx, host_u8):
-        """write the batch `idx` (sessions of one length) into the (pinned) byte buffer in wire format; returns its WireLayout."""
+    def click_max(self, idx, batch_size=None):
+        """m of cars.py:285-289 for the sampler batch(es) in `idx` (batch_size: idx holds len(idx) / batch_size batches back to back):
+        the largest number of clicked candidates of any query of the batch -> int (one batch) or int32 array [groups]."""
         S = int(self.lengths[idx[0]])
-        lay = self.layout(S, len(idx))
+        c = self.pool[S]["_clicks"][self.slot[np.asarray(idx, dtype=np.int64)]]
+        if batch_size is None or len(idx) == batch_size:
+            return int(c.max())
+        return c.reshape(-1, int(batch_size)).max(1).astype(np.int32)
+
+    def collate_into(self, idx, host_u8, whole=None, batch_size=None):
+        """write the batch `idx` (sessions of one length) into the (pinned) byte buffer in wire format; returns its WireLayout.
+        whole (optional): idx is this rank's share of the sampler batch(es) `whole` (batch_size sessions each): the block then also
+        carries their click counts (`click_max`)."""
+        S = int(self.lengths[idx[0]])
+        groups = 0 if whole is None else len(whole) // int(batch_size)
+        lay = self.layout(S, len(idx), groups)
         v = lay.views(host_u8)
         rows = self.slot[np.asarray(idx, dtype=np.int64)]
         p = self.pool[S]
         for k in INT_FIELDS + ("document_labels",):
             np.take(p[k], rows, axis=0, out=v[k], mode="clip")     # (mode='raise' would buffer `out`; rows are valid by construction)
+        if groups:
+            v["click_max"][:] = self.click_max(whole, batch_size)
         return lay
 
     def batch_tensors(self, idx):
@@ -123,4 +151,4 @@ class SyntheticSessionCorpus(object):
         S = int(self.lengths[idx[0]])
         rows = self.slot[np.asarray(idx, dtype=np.int64)]
         p = self.pool[S]
-        return {k: torch.from_numpy(p[k][rows].astype(np.float32 if k == "document_labels" else np.int64)) for k in p}
+        return {k: torch.from_numpy(p[k][rows].astype(np.float32 if k == "document_labels" else np.int64)) for k in p if not k.startswith("_")}

@@ -322,13 +322,15 @@ class CARS(nn.Module, lib.IdCheck):
         return pooled.view(B, S, N, -1)
 
     def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False, rank_docs=None, labels_all=None,
-                      labels_groups=None):
+                      labels_groups=None, click_max=None):
         """rank_docs [B,S,NR,D] (optional): the ranker scores only this slice of the candidates -> scores [B,S,NR]; clicks and sessions
         still see all of pooled_docs (candidate-sharded callers).
         labels_all [B_all,S,N] (optional): the inputs are a block of the sessions of a larger batch (session-sharded tail,
         sharding.SessionShardPlan); the click mask's batch-wide max click count (cars.py:285-289) is taken over labels_all.
         labels_groups [G,B_all,S,N] (optional, instead of labels_all): the B sessions are G equal blocks taken from G DIFFERENT batches (merged
-        so that the session weights are streamed once for all of them); block g takes its count from labels_groups[g]."""
+        so that the session weights are streamed once for all of them); block g takes its count from labels_groups[g].
+        click_max int32 [G] on the device (optional, instead of both): the counts themselves, one per block of B/G sessions -- a rank that holds
+        a slice of a batch and received the batch's count with it (sharding.StreamShardPlan, mode "pair")."""
         lib.require_device(pooled_q, pooled_docs, labels)
         L = lib.load()
         B, S, D = pooled_q.shape
@@ -364,6 +366,10 @@ class CARS(nn.Module, lib.IdCheck):
             ng = lg.shape[0]
             mg, spg = torch.empty(ng, dtype=torch.int32, device=dev), B // ng
             lib.check(L.nir_cars_click_max(lib.ptr(lg), ng, lg.numel() // (ng * N), N, lib.ptr(mg), lib.stream()), "nir_cars_click_max")
+        if click_max is not None:
+            if lab_all is not None or mg is not None or click_max.dtype != torch.int32 or not click_max.is_cuda or B % click_max.numel():
+                raise RuntimeError("click_max: int32 device tensor [G] with B % G == 0, instead of labels_all / labels_groups")
+            mg, spg = click_max, B // click_max.numel()
         lib.check(L.nir_cars_rank_session_rows(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
                                                lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
                                                lib.ptr(rd), NR if rd is not None else 0, lib.ptr(lab_all),

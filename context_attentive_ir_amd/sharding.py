@@ -345,3 +345,121 @@ def pipelined_session_sharded_probs(plan, encode_q, encode_docs, session_tail, b
             out.append(pipe.got_probs().clone())
         prev = cur
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The session STREAM over G ranks (BASELINE.json configs[4]; the reference feeds nn.DataParallel from its length-bucketing sampler,
+# neuroir/inputters/multitask/data.py:42-72 + models/multitask.py:402-407).
+#
+# The unit of the stream is a sampler batch (B sessions of ONE length S, N candidates each).  Two ways to spread it, both without any
+# exchange of encoder outputs -- the only collective is the all-gather of the click probabilities, issued asynchronously and consumed one
+# round later, so it overlaps the next batch's H2D / widen / encode:
+#   "batch"  round j = sampler batches jG .. jG+G-1, rank r scores batch jG+r WHOLE (its own click count m).  Throughput mode: per-rank
+#            work is a full batch, a round's batches may have different session lengths (gather blocks are padded to the longest).
+#   "pair"   every sampler batch is cut along the flattened (session, candidate) pair axis into G blocks of B/G whole sessions (the
+#            aligned split of SessionShardPlan); rank r scores block r of EVERY batch with the click count m of the WHOLE batch
+#            (cars.py:285-289 -- computed on the host by the collator, an integer).  Latency mode: a batch finishes in 1/G of the time.
+# A stream whose batch count is not a multiple of G ("batch" mode) ends with a short round: the idle ranks re-score the round's first
+# batch and their block is dropped.
+# ----------------------------------------------------------------------------------------------------------
+class StreamShardPlan(object):
+    def __init__(self, world, rank, mode="batch", batch_size=None):
+        self.world, self.rank, self.mode = int(world), int(rank), mode
+        if mode not in ("batch", "pair"):
+            raise ValueError("mode must be 'batch' or 'pair'")
+        if mode == "pair":
+            if batch_size is None or int(batch_size) % self.world:
+                raise ValueError("pair-mode stream sharding cuts a batch into whole sessions per rank: batch_size %% world must be 0")
+            self.bper = int(batch_size) // self.world
+        self.batch_size = None if batch_size is None else int(batch_size)
+
+    def rounds(self, nbatches):
+        return nbatches if self.mode == "pair" else (nbatches + self.world - 1) // self.world
+
+    def members(self, j, nbatches):
+        """the sampler batches of round j as [(rank, batch_no)] (real ones only)."""
+        if self.mode == "pair":
+            return [(r, j) for r in range(self.world)]
+        return [(r, j * self.world + r) for r in range(self.world) if j * self.world + r < nbatches]
+
+    def mine(self, j, batches, rank=None):
+        """-> (batch_no, this rank's session indices, the indices of the whole batch) for round j."""
+        r = self.rank if rank is None else rank
+        if self.mode == "pair":
+            idx = list(batches[j])
+            groups = len(idx) // self.batch_size               # macro-batches: `groups` sampler batches back to back
+            own = [x for g in range(groups) for x in idx[g * self.batch_size + r * self.bper:g * self.batch_size + (r + 1) * self.bper]]
+            return j, own, idx
+        k = j * self.world + r
+        if k >= len(batches):
+            k = j * self.world                                # short last round: filler, dropped after the gather
+        return k, list(batches[k]), list(batches[k])
+
+    def block_elems(self, B, S, N):
+        """elements of one rank's gather block for a round whose longest session has S queries."""
+        return (self.bper * (B // self.batch_size) if self.mode == "pair" else B) * S * N
+
+    def unpack(self, j, recv, batches, lengths_of, N):
+        """recv [G, block] (rank-major) -> [(batch_no, idx, probs [B,S,N])] of round j (padding / fillers dropped)."""
+        out = []
+        if self.mode == "pair":
+            idx = list(batches[j])
+            S = lengths_of(idx)
+            groups = len(idx) // self.batch_size
+            n = groups * self.bper * S * N
+            blocks = recv[:, :n].reshape(self.world, groups, self.bper, S, N)
+            out.append((j, idx, blocks.permute(1, 0, 2, 3, 4).reshape(len(idx), S, N)))
+            return out
+        for r, k in self.members(j, len(batches)):
+            idx = list(batches[k])
+            S = lengths_of(idx)
+            out.append((k, idx, recv[r, :len(idx) * S * N].reshape(len(idx), S, N)))
+        return out
+
+
+def sharded_stream_probs(plan, score_fn, corpus, batches, group=None, on_result=None):
+    """Reference driver of the sharded stream in terms of ONE callable (the graph-replayed HIP predict on a GPU --
+    graph_runner.StreamingSessionPredictor does the same with device buffers; the CPU oracle in the gloo tests):
+         score_fn(ex: the batch tensors of this rank's sessions, click_max: int or None) -> click probabilities [b,S,N]
+    The all-gather of round j is issued asynchronously and consumed after round j+1 has been scored (double-buffered).
+    on_result(batch_no, idx, probs [B,S,N]) is called on EVERY rank for every sampler batch, in batch order.  -> number of batches delivered."""
+    lengths_of = lambda idx: int(corpus.lengths[idx[0]])     # noqa: E731
+    N = corpus.N
+    max_S = max(lengths_of(b) for b in batches)
+    max_B = max(len(b) for b in batches)
+    block = plan.block_elems(max_B, max_S, N)
+    recv = [torch.zeros(plan.world, block), torch.zeros(plan.world, block)]
+    send = [torch.zeros(block), torch.zeros(block)]
+    have_pg = dist.is_available() and dist.is_initialized()
+    pending, delivered = None, 0
+
+    def deliver(p):
+        j, work = p
+        if work is not None:
+            work.wait()
+        n = 0
+        for k, idx, probs in plan.unpack(j, recv[j % 2], batches, lengths_of, N):
+            if on_result is not None:
+                on_result(k, idx, probs.clone())
+            n += 1
+        return n
+
+    for j in range(plan.rounds(len(batches))):
+        k, own, whole = plan.mine(j, batches)
+        ex = corpus.batch_tensors(own)
+        probs = score_fn(ex, corpus.click_max(whole, plan.batch_size) if plan.mode == "pair" else None)
+        s = send[j % 2]
+        s.zero_()
+        s[:probs.numel()] = probs.reshape(-1).float().cpu()
+        if have_pg:
+            work = dist.all_gather_into_tensor(recv[j % 2].view(-1), s, group=group, async_op=True)
+        else:
+            assert plan.world == 1
+            recv[j % 2][0].copy_(s)
+            work = None
+        if pending is not None:
+            delivered += deliver(pending)
+        pending = (j, work)
+    if pending is not None:
+        delivered += deliver(pending)
+    return delivered

@@ -202,6 +202,24 @@ class GraphedUpdate(object):
         self.w = wrapper
         self.graphs = {}
         self.seed = None
+        self.stream = None
+
+    def _hyper(self):
+        """Host-side hyper-parameters that the capture would freeze: part of the graph key, so a change re-captures instead of being ignored.
+        The learning rate of a capturable optimizer is excluded -- it lives in a device tensor (below) that the captured kernels read."""
+        a = self.w.args
+        groups = tuple((None if torch.is_tensor(g["lr"]) else float(g["lr"]), float(g.get("weight_decay", 0.0)), float(g.get("momentum", 0.0)))
+                       for g in self.w.optimizer.param_groups)
+        return groups + (float(getattr(a, "grad_clipping", 0.0)),)
+
+    def _device_lr(self, dev):
+        """The reference's training loops decay the rate in place every epoch (`optimizer.param_groups[0]['lr'] *= args.lr_decay`,
+        main/ranker.py:204, main/multitask.py:228).  A Python float would be baked into the captured kernels' arguments; a capturable
+        optimizer (Adam / Adamax / Adadelta here) takes the rate as a device tensor instead, `*=` then updates it in place and every replay
+        reads the current value.  (Assigning a new float, or SGD, which has no capturable form: the key changes and the step is re-captured.)"""
+        for g in self.w.optimizer.param_groups:
+            if g.get("capturable") and not torch.is_tensor(g["lr"]):
+                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
 
     def _key(self, ex):
         return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(ex.items()) if torch.is_tensor(v))
@@ -213,28 +231,40 @@ class GraphedUpdate(object):
             raise RuntimeError("No optimizer set.")
         if getattr(w, "group", None) is not None or getattr(w, "parallel", False):
             return w.update(ex)
-        key = self._key(ex)
+        dev = next(w.network.parameters()).device
+        self._device_lr(dev)
+        key = (self._key(ex), self._hyper())
         ent = self.graphs.get(key)
+        caller = torch.cuda.current_stream(dev)
         if ent is None:
-            out = w.update(ex)                                   # this batch's step, eager
-            # only detached values survive into the capture: with the eager step's autograd graph still referenced (through its loss), ending
-            # the capture crashed inside hipStreamEndCapture (ROCm 7.0 / torch 2.10; reproduced in isolation, fine once the reference is dropped)
-            out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()} if isinstance(out, dict) else out.detach()
-            dev = next(w.network.parameters()).device
-            static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in ex.items()}
-            if self.seed is None:
-                self.seed = torch.full((1,), (A.DROPOUT.seed * 2654435761 + 12345) & 0x7FFFFFFFFFFF, dtype=torch.int64, device=dev)
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=dev)
+            # The eager first step of a shape runs on the stream the capture will use: autograd's AccumulateGrad nodes remember the stream they
+            # were created on, and nodes of an earlier step that are still alive would meet the captured backward on a different stream
+            # (torch warns, and would synchronise the two).  Stale graphs of earlier eager steps are collected first.
+            import gc
+            self.stream.wait_stream(caller)
+            with torch.cuda.stream(self.stream):
+                out = w.update(ex)                               # this batch's step, eager
+                # only detached values survive into the capture: with the eager step's autograd graph still referenced (through its loss), ending
+                # the capture crashed inside hipStreamEndCapture (ROCm 7.0 / torch 2.10; reproduced in isolation, fine once the reference is dropped)
+                out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()} if isinstance(out, dict) else out.detach()
+                static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in ex.items()}
+                if self.seed is None:
+                    self.seed = torch.full((1,), (A.DROPOUT.seed * 2654435761 + 12345) & 0x7FFFFFFFFFFF, dtype=torch.int64, device=dev)
+            gc.collect()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             w.optimizer.zero_grad(set_to_none=True)
             A.DROPOUT.device_seed, A.DROPOUT.site = self.seed, 0
             try:
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                     self.seed.add_(1)
                     loss = w._update_body(static)
             finally:
                 A.DROPOUT.device_seed = None
             self.graphs[key] = (g, static, loss)
+            caller.wait_stream(self.stream)
             return out
         g, static, loss = ent
         for k, v in ex.items():

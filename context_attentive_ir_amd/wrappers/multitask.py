@@ -99,11 +99,11 @@ class Multitask(WrapperBase):
         return pooled, self.network.encode_document(doc_shard, len_shard)
 
     @torch.no_grad()
-    def tail_probs(self, pooled_q, docs, labels_own, labels_all, probs=None, labels_groups=None):
+    def tail_probs(self, pooled_q, docs, labels_own, labels_all, probs=None, labels_groups=None, click_max=None):
         """pooled queries [b,S,D] + ALL N pooled documents [b,S,N,D] of a block of sessions -> click probabilities [b,S,N] (clicks, session
         LSTMs, ranknet, softmax); the click mask's batch-wide count comes from labels_all [B,S,N] (None: the block itself), or -- blocks of
         several batches merged into one call -- per block from labels_groups [G,B,S,N]."""
-        s = self.network._rank_session(pooled_q, docs, labels_own, labels_all=labels_all, labels_groups=labels_groups)[0].contiguous()
+        s = self.network._rank_session(pooled_q, docs, labels_own, labels_all=labels_all, labels_groups=labels_groups, click_max=click_max)[0].contiguous()
         if probs is None:
             probs = torch.empty_like(s)
         lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()), "nir_softmax_rows")
@@ -162,10 +162,11 @@ class Multitask(WrapperBase):
         return probs.view(len(exs), *labels[0].shape)
 
     @torch.no_grad()
-    def predict_groups(self, ex, groups, out=None):
+    def predict_groups(self, ex, groups, out=None, click_max=None):
         """predict_many for batches that are ALREADY concatenated: ex holds groups x B sessions (block g = batch g, whole) -> click
         probabilities [groups*B,S,N]; block g uses the click count of its own B sessions (graph_runner.StreamingSessionPredictor collates
-        `groups` batches into one wire block)."""
+        `groups` batches into one wire block).  click_max int32 [groups] (device, optional): block g is a SLICE of its batch and takes
+        the batch's click count from here (the sharded stream, sharding.StreamShardPlan mode "pair")."""
         if self.type != "CARS":
             raise NotImplementedError("predict_groups is built for CARS")
         self.network.eval()
@@ -174,6 +175,8 @@ class Multitask(WrapperBase):
         labels = self._dev(ex["document_labels"])
         if labels.shape[0] % groups:
             raise RuntimeError("predict_groups: %d sessions are not %d equal batches" % (labels.shape[0], groups))
+        if click_max is not None:
+            return self.tail_probs(pooled, docs, labels, None, probs=out, click_max=click_max)
         lg = labels.view(groups, labels.shape[0] // groups, *labels.shape[1:])
         return self.tail_probs(pooled, docs, labels, None, probs=out, labels_groups=lg if groups > 1 else None)
 

@@ -18,17 +18,68 @@ def _last_json(out):
     return json.loads(out.strip().splitlines()[-1])
 
 
+def _detail(d):
+    return json.load(open(os.path.join(ROOT, d["config"]["detail"])))
+
+
 def test_bench_single_gpu_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--sub", "C1_esm", "--cpu-seconds", "2"],
+    """the record as the driver reads it: `python bench.py --steps 20 --warmup 5`, stdout FOLLOWED by stderr -- the last line of that is ONE
+    compact JSON object (< 4 KB) with the contract keys + roofline + cpu_baseline, stderr of a successful run is empty, a short region is
+    repeated (`reps`) with `steps` = the argument; the full sub-records are in the detail file the line names."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--sub", "C1_esm,C4_drmm", "--cpu-seconds", "2"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = _last_json(out.stdout)
-    assert KEYS <= set(d)
-    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["value"] > 0 and d["config"]["workload"].startswith("cars")
+    assert out.stderr.strip() == "", out.stderr[-2000:]
+    last = (out.stdout + out.stderr).strip().splitlines()[-1]
+    assert len(last) < 4096, len(last)
+    d = json.loads(last)
+    assert KEYS | {"sub", "reps"} <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["reps"] >= 3 and d["value"] > 0 and d["config"]["workload"].startswith("cars")
+    assert abs(d["value"] - 1120 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3         # value, ms_per_step and the C3 step (1 120 pairs) agree
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1.5 and r["kernel"] and r["avg_us"] > 0
-    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["max_abs_diff_vs_gpu_softmax"] < 1e-4
-    assert d["config"]["sub"]["C1_esm"]["pairs_per_s"] > 0
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1.5 and r["kernel"] and r["avg_us"] > 0 and r["peak"] > 0 and r["unit"]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["max_abs_diff_vs_gpu_softmax"] < 1e-4 and d["cpu_baseline"]["cores"] >= 1
+    subs = {e["name"]: e for e in d["sub"]}
+    assert subs["C1_esm"]["pairs_per_s"] > 0 and subs["C1_esm"]["bound"] == "hbm"
+    assert {"hist_rows_differ", "pairs_differ", "map_delta_vs_oracle"} <= set(subs["C4_drmm"])       # the DRMM parity gap rides with its record
+    full = _detail(d)
+    assert full["sub"]["C1_esm"]["roofline"]["kernel"] and full["headline"]["roofline"]["kernels_us_per_step"]
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """plain `python bench.py --gpus 2` (no launcher around it): bench.py starts the two ranks itself (both on the one GPU, BENCH_BACKEND=gloo)
+    and n_gpus is what the process group counted; with the RCCL backend and one visible device it refuses instead of measuring one GPU."""
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_NO_WEAK="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--sub", "none"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout + out.stderr)
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["shard_axis"] == "pair" and d["value"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("BENCH_BACKEND")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--sub", "none"],
+                             capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert out.returncode != 0 and "RCCL needs one device per rank" in out.stderr
+    # a launcher world that is not --gpus is refused as well
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "12", "--sub", "none"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0", BENCH_BACKEND="gloo"))
+    assert out.returncode != 0 and "refusing" in out.stderr
+
+
+def test_bench_two_rank_stream_record():
+    """the multi-rank C5 stream as a bench record (2 ranks on the one GPU, gloo): both modes, every rank the same number of rounds."""
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_NO_WEAK="1", BENCH_H2D_SECONDS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    for mode in ("batch", "pair"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C5_stream", "--streams", "2"],
+                             capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, BENCH_STREAM_MODE=mode, BENCH_STREAM_SESSIONS="6000"))
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = _last_json(out.stdout + out.stderr)
+        assert d["n_gpus"] == 2 and d["value"] > 0 and ("mode '%s'" % mode) in d["config"]["parallelism"], d["config"]
 
 
 @pytest.mark.parametrize("axis,needle,port", [("auto", "pair axis in 2 contiguous chunks = 8 whole sessions", "29541"),
@@ -45,10 +96,11 @@ def test_bench_two_ranks_strong_scaling_flow(axis, needle, port):
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["world_size"] == 2 and needle in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert d["config"]["shard_axis"] == ("pair" if axis == "auto" else "candidate")
     assert d["config"]["weak_scaling_pairs_per_s"] > 0
     if axis == "auto":
-        sub = d["config"]["sub"]["C2_match_tensor"]
-        assert sub["world_size"] == 2 and "5 per rank" in sub["parallelism"] and sub["pairs_per_s"] > 0
+        sub = _detail(d)["sub"]["C2_match_tensor"]
+        assert sub["world_size"] == 2 and "5 per rank" in sub["parallelism"] and sub["pairs_per_s"] > 0 and sub["shard_axis"] == "candidate"
 
 
 def test_two_rank_sharding_reproduces_single_rank_scores():
@@ -70,11 +122,11 @@ def test_bench_rccl_sharded_step_is_graph_replayed(axis, emulate):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--sub", "none", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "graph capture unavailable" not in out.stderr
+    assert "graph capture unavailable" not in open(os.path.join(ROOT, "bench_stderr.rank0.log")).read()
     d = _last_json(out.stdout)
     assert d["scaling"] == "strong" and d["config"]["hipgraph"] is True and d["value"] > 0
     assert ("pair axis" in d["config"]["parallelism"]) == (axis != "candidate")
-    assert d["config"]["host_enqueue_ms_per_step"] < d["ms_per_step"] * 1.05
+    assert _detail(d)["headline"]["host_enqueue_ms_per_step"] < d["ms_per_step"] * 1.05
 
 
 def test_sharded_stages_reproduce_predict():

@@ -110,3 +110,32 @@ def test_stream_macro_batches_equal_single_batches():
         for j in range(MK):
             ex = corpus.batch_tensors(idx[j * B:(j + 1) * B])
             np.testing.assert_allclose(got[k][j * B:(j + 1) * B].numpy(), _oracle_probs(sd, ex).numpy(), rtol=0, atol=1e-4)
+
+
+def test_pair_mode_block_with_shipped_click_count_equals_whole_batch():
+    """sharding.StreamShardPlan mode 'pair' on ONE process: the predictor of simulated rank r scores batch_size / world whole sessions of every
+    batch with the batch's click count shipped in the wire block (`click_max`, int32 on the device); the blocks of all simulated ranks put
+    together equal the whole batch scored at once (and the oracle), including batches whose count lives on another rank."""
+    from context_attentive_ir_amd import sharding
+    from context_attentive_ir_amd.graph_runner import StreamingSessionPredictor
+    from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
+    V, B, N, world = 3000, 8, 7, 4
+    corpus = SyntheticSessionCorpus(n_sessions=96, n_cands=N, qlen=4, dlen=16, vocab=V, seed=17, pool=6, full_length=False, s_max=5, multi_click=True)
+    for body in corpus.pool.values():
+        body["document_labels"][0, 0, :] = 1.0
+        body["_clicks"] = (body["document_labels"] != 0).sum(-1).max(-1).astype(np.int32)
+    bs = corpus.batches(B, seed=4)
+    mt = _model(V)
+    sd = cpu_state_dict(mt.network)
+    blocks, differs = {}, 0
+    for r in range(world):
+        plan = sharding.StreamShardPlan(world, r, "pair", batch_size=B)
+        sp = StreamingSessionPredictor(mt, N, 4, 16, B, max_session_len=5, lanes=2, slots=2, plan=plan, gather="none")
+        assert sp.B == B // world and sp.groups == 1
+        sp.run(corpus, bs, on_result=lambda k, idx, p, r=r: blocks.__setitem__((k, r), p.clone()))
+        differs += sum(int(corpus.click_max(plan.mine(j, bs)[1]) < corpus.click_max(bs[j])) for j in range(len(bs)))
+    assert differs > 0                                   # some block's own count is below its batch's: the shipped count matters
+    for k, idx in enumerate(bs):
+        got = torch.cat([blocks[(k, r)] for r in range(world)])
+        ref = _oracle_probs(sd, corpus.batch_tensors(idx))
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-4)

@@ -524,6 +524,53 @@ def test_graphed_update_draws_fresh_dropout_masks():
     assert len({round(x, 6) for x in losses[1:]}) >= 3, losses
 
 
+def test_graphed_update_follows_lr_decay_and_hyperparameter_changes():
+    """The reference decays the rate in place every epoch (`optimizer.param_groups[0]['lr'] *= lr_decay`, main/ranker.py:204): a captured step
+    must follow it.  Adam (capturable): the rate is a device tensor the captured kernels read -- graphed and eager trajectories with a decay
+    after every second step stay together, no re-capture.  A changed grad_clipping / an assigned float rate re-captures (new key) instead of
+    being ignored.  No AccumulateGrad stream-mismatch warning (eager first step and capture share one stream)."""
+    import warnings
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import GraphedUpdate, Ranker
+    g = load_golden("match_tensor_train")
+    extra = dict(dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.004, weight_decay=0, momentum=0, grad_clipping=10.0,
+                 fix_embeddings=True)
+    batches = [{k: T(g["b%d_%s" % (i, k)], DEV) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label")} for i in range(2)]
+    finals = []
+    for graphed in (False, True):
+        w = Ranker(default_args("MATCH_TENSOR", src_vocab_size=int(g["meta_vocab"]), **extra))
+        fill_module_(w.network, 1013)
+        w.cuda()
+        w.init_optimizer()
+        for _ in range(2):                                   # eager steps on the default stream BEFORE the graphed ones (their autograd nodes must not linger)
+            w.update(batches[0])
+        step = GraphedUpdate(w) if graphed else w.update
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            for i in range(8):
+                step(batches[i % 2])
+                if i % 2 == 1:
+                    w.optimizer.param_groups[0]["lr"] *= 0.5
+        if graphed:
+            assert len(step.graphs) == 1 and torch.is_tensor(w.optimizer.param_groups[0]["lr"])
+            assert abs(float(w.optimizer.param_groups[0]["lr"]) - 0.004 * 0.5 ** 4) < 1e-9
+            w.args.grad_clipping = 1e-3                      # a host-side hyper-parameter: re-captured, and it bites (tiny steps from here on)
+            before = {k: v.detach().clone() for k, v in w.network.state_dict().items()}
+            w.optimizer.param_groups[0]["lr"] = 0.0          # assigned float rate: re-captured as well; rate 0 -> parameters stand still
+            step(batches[0]); step(batches[0]); step(batches[0])
+            assert len(step.graphs) == 2
+            assert all(torch.equal(before[k], v) for k, v in w.network.state_dict().items() if v.dtype.is_floating_point)
+        else:
+            finals.append({k: v.detach().clone() for k, v in w.network.state_dict().items()})
+        if graphed:
+            for k, v in finals[0].items():
+                if v.dtype.is_floating_point and not k.endswith("attn.3.bias"):
+                    assert float((v - before[k]).abs().max()) <= 5e-4 * max(1.0, float(v.abs().max())), k
+    # without the decay the trajectories would differ by far more than the bound above: lr 0.004 x 4 more full-rate steps
+    assert finals
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,C,H,W,kh,kw", [(3, 5, 4, 16, 3, 3), (2, 51, 4, 64, 3, 5), (2, 51, 4, 64, 3, 7), (2, 7, 6, 33, 3, 7), (1, 3, 1, 5, 1, 3),
                                            (2, 20, 20, 200, 3, 7)])

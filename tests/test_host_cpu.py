@@ -464,3 +464,124 @@ def test_session_stream_corpus_and_wire_layout():
     assert all(torch.equal(wide[k], ref[k]) for k in wide)
     pos = np.arange(12)
     assert ((ref["document_words"].numpy() == 0) == (pos >= ref["document_lens"].numpy()[..., None])).all()
+
+
+def test_stream_shard_plan_covers_every_batch_once():
+    """sharding.StreamShardPlan: 'batch' mode deals whole sampler batches round-robin (short last round = fillers that are dropped),
+    'pair' mode cuts every (macro-)batch into world blocks of whole sessions; unpack() restores batch order from the rank-major gather."""
+    from context_attentive_ir_amd import sharding
+    from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
+    c = SyntheticSessionCorpus(n_sessions=500, n_cands=3, qlen=3, dlen=6, vocab=60, seed=5, pool=8, full_length=False, multi_click=True)
+    bs = c.batches(8, seed=1)
+    lengths_of = lambda idx: int(c.lengths[idx[0]])     # noqa: E731
+    for world in (1, 2, 3, 4):
+        seen = []
+        plans = [sharding.StreamShardPlan(world, r, "batch") for r in range(world)]
+        for j in range(plans[0].rounds(len(bs))):
+            real = dict(plans[0].members(j, len(bs)))
+            for r, p in enumerate(plans):
+                k, own, whole = p.mine(j, bs)
+                assert own == whole == list(bs[k])
+                if r in real:
+                    assert real[r] == k
+                    seen.append(k)
+                else:
+                    assert k == j * world                     # filler of a short last round
+        assert seen == list(range(len(bs)))
+    with pytest.raises(ValueError):
+        sharding.StreamShardPlan(3, 0, "pair", batch_size=8)
+    macro = [bs[0] + bs[0]]                                   # two batches of one length back to back
+    for world in (2, 4):
+        plans = [sharding.StreamShardPlan(world, r, "pair", batch_size=8) for r in range(world)]
+        owns = [p.mine(0, macro)[1] for p in plans]
+        assert sorted(x for o in owns for x in o) == sorted(macro[0]) and all(len(o) == 2 * 8 // world for o in owns)
+        S, N = lengths_of(macro[0]), 3
+        full = torch.arange(16 * S * N, dtype=torch.float32).view(16, S, N)
+        pos = {x: i for i, x in enumerate(macro[0][:8])}
+        blocks = []
+        for o in owns:                                       # what each rank would send: the rows of ITS sessions, group-major
+            rows = [g * 8 + pos[x] for g in range(2) for x in o[g * (8 // world):(g + 1) * (8 // world)]]
+            blk = torch.zeros(plans[0].block_elems(16, S + 2, N))
+            blk[:len(rows) * S * N] = full[rows].reshape(-1)
+            blocks.append(blk)
+        (k, idx, got), = plans[0].unpack(0, torch.stack(blocks), macro, lengths_of, N)
+        assert k == 0 and idx == macro[0] and torch.equal(got, full)
+    assert (c.click_max(macro[0], 8) == np.array([c.click_max(bs[0])] * 2)).all() and c.click_max(bs[0]) >= 1
+    lay = c.collate_into(bs[0][:4], np.zeros(c.layout(16, 8, 1).nbytes, np.uint8), whole=bs[0], batch_size=8)
+    assert lay.groups == 1 and lay.offset["click_max"] % 4 == 0 and lay.B == 4
+
+
+_STREAM_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from context_attentive_ir_amd import sharding
+from context_attentive_ir_amd.detinit import fill_module_
+from context_attentive_ir_amd.config import default_args
+from context_attentive_ir_amd.multitask import CARS
+from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
+from context_attentive_ir_amd.eval.ltorank import MAP, rank_candidates
+from oracle import neuroir_cpu as O
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[4]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.set_num_threads(2)
+sd = {k: v for k, v in fill_module_(CARS(default_args("CARS", src_vocab_size=300))).state_dict().items()}
+corpus = SyntheticSessionCorpus(n_sessions=200, n_cands=9, qlen=4, dlen=10, vocab=300, seed=11, pool=12, full_length=False, s_max=5, multi_click=True)
+for S_, body in corpus.pool.items():            # one session per length clicks EVERY candidate of its first query: the batch-wide count of a
+    body["document_labels"][0, 0, :] = 1.0      # batch that holds it lives on ONE rank in 'pair' mode
+    body["_clicks"] = (body["document_labels"] != 0).sum(-1).max(-1).astype(np.int32)
+bs = corpus.batches(8, seed=3)
+N = corpus.N
+def score(ex, m):                                   # the CPU oracle stands in for the graph-replayed HIP predict
+    pq = O.cars_encode(sd, ex["source_words"], ex["source_lens"])[0]
+    docs = O.cars_encode_document(sd, ex["document_words"], ex["document_lens"])
+    lab_all = None
+    if m is not None:                               # the batch's click count as shipped by the collator -> a label row with m clicks
+        lab_all = torch.zeros(1, 1, N); lab_all[0, 0, :int(m)] = 1.0
+    return O.predict_softmax(O.cars_encode_session(sd, pq, docs, O.cars_encode_clicks(sd, docs, ex["document_labels"], labels_all=lab_all)))
+single = {}
+for k, idx in enumerate(bs):                        # the single-rank stream: every batch whole
+    single[k] = score(corpus.batch_tensors(idx), None)
+def stream_map(res):
+    p = torch.cat([res[k].reshape(-1, N) for k in sorted(res)]); t = torch.cat([corpus.batch_tensors(bs[k])["document_labels"].reshape(-1, N) for k in sorted(res)])
+    return MAP(rank_candidates(p.numpy()), t.numpy())
+ref_map = stream_map(single)
+modes = ["batch"] + (["pair"] if 8 % world == 0 else [])
+for mode in modes:
+    plan = sharding.StreamShardPlan(world, rank, mode, batch_size=8)
+    got = {}
+    def on_result(k, idx, probs):
+        assert idx == list(bs[k]) and k not in got
+        got[k] = probs
+    n = sharding.sharded_stream_probs(plan, score, corpus, bs, on_result=on_result)
+    assert n == len(bs) and sorted(got) == list(range(len(bs))), (mode, n, len(bs))
+    for k in got:
+        assert got[k].shape == single[k].shape and torch.allclose(got[k], single[k], atol=1e-6), (mode, k, float((got[k] - single[k]).abs().max()))
+    assert stream_map(got) == ref_map, (mode, stream_map(got), ref_map)
+# the quirk is exercised: some batch has a rank block whose own max click count is below the batch's
+own_lt = 0
+if world > 1 and 8 % world == 0:
+    plan = sharding.StreamShardPlan(world, rank, "pair", batch_size=8)
+    for j in range(len(bs)):
+        _, own, whole = plan.mine(j, bs)
+        own_lt += int(corpus.click_max(own) < corpus.click_max(whole))
+t = torch.tensor([float(own_lt)]); dist.all_reduce(t)
+assert world == 1 or 8 % world or t.item() > 0
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok", len(bs), "batches, MAP", round(float(ref_map), 4))
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_session_stream_gloo(tmp_path, world):
+    """BASELINE configs[4] as a multi-rank stream (sharding.StreamShardPlan + sharded_stream_probs): both modes deliver EVERY batch's click
+    probabilities on EVERY rank, equal to the single-rank stream, with identical MAP on a 200-session slice -- including the batch-wide
+    click count in 'pair' mode, where a rank sees only a block of the batch's sessions."""
+    script = tmp_path / "worker.py"
+    script.write_text(_STREAM_WORKER)
+    port = str(33500 + (os.getpid() * 7 + world) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in o, o
