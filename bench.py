@@ -1113,12 +1113,13 @@ def short_sub(n, r):
 
 def main():
     args = parse()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)
-    rank = int(os.environ.get("RANK", "0"))
-    with QuietStderr(os.path.join(LOG_DIR, "bench_stderr.rank%d.log" % rank)):
+    launcher = args.gpus > 1 and "WORLD_SIZE" not in os.environ
+    # (the redirect starts BEFORE the HIP runtime initialises: libdrm's "amdgpu.ids: No such file" line is stderr noise of every run on this image)
+    with QuietStderr(os.path.join(LOG_DIR, "bench_stderr.%s.log" % ("launcher" if launcher else "rank%d" % int(os.environ.get("RANK", "0"))))):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+        if launcher:
+            self_launch(args)
         result_line = run_all(args)
     if result_line is not None:
         sys.stderr.flush()
