@@ -207,6 +207,8 @@ def parse():
     ap.add_argument("--no-fold", action="store_true", help="CARS: per-batch gather-GEMM instead of the folded embedding table")
     ap.add_argument("--nbatches", type=int, default=12, help="distinct resident batches cycled through")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight: step i runs on HIP stream i %% streams")
+    ap.add_argument("--in-flight-hint", type=int, default=0, help="library batches-in-flight hint (default: --streams); profiling runs pass the timed run's "
+                    "lane count with --streams 1 so that the serial capture launches the SAME kernel instantiations the timed run does")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -480,7 +482,8 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         return out
 
     # several batches in flight: the library drops its own query/document fork and packs fuller workgroups
-    L.nir_set_batches_in_flight(len(lanes))
+    hint = args.in_flight_hint or len(lanes)
+    L.nir_set_batches_in_flight(hint)
     lane_of = lambda i: (i % len(batches)) % len(lanes)   # noqa: E731
     torch.cuda.set_stream(lanes[0])
     for i in range(max(2, min(warmup, 3)) * len(lanes)):
@@ -558,6 +561,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             nl, nb = len(lanes), len(batches)
             agroups = {}
             gbuf = {}
+            macro_inputs, eager_fns = {}, {}
             bper_, S_ = (c["batch"], c.get("session", 1) if is_sess else 1) if macro_single else (plan.bper, plan.S)
 
             def group_bufs(gb, k):
@@ -570,11 +574,21 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 """steps on batches KG*gb .. KG*gb + k - 1 (mod nb), lane gb % nl"""
                 ln = lanes[gb % nl]
                 mine, allg = group_bufs(gb, k)
-                if macro_single:      # single GPU: Multitask.predict_many over k whole batches (concatenation included in the graph)
+                if macro_single:
+                    # single GPU: the k batches are resident as ONE macro-batch (concatenated once, here, outside the graph -- exactly what the
+                    # host-fed stream's collator produces): the replayed graph holds the library's kernels only, no torch.cat / copy launches
                     exs = [batches[(KG * gb + j) % nb] for j in range(k)]
+                    keys = ("source_words", "source_lens", "document_words", "document_lens", "document_labels") if is_sess else ("que_rep", "que_len", "doc_rep", "doc_len")
+                    mb = {key: (torch.cat([e[key] for e in exs]).contiguous() if k > 1 else exs[0][key]) for key in keys}
+                    macro_inputs[(gb, k)] = mb
 
                     def body1():
-                        model.predict_many(exs, out=mine.view(k * bper_, S_, ncand) if is_sess else mine.view(k * bper_, ncand))
+                        if is_sess:       # Multitask.predict_groups: every batch of the macro-batch keeps its own click count
+                            model.predict_groups(mb, k, out=mine.view(k * bper_, S_, ncand))
+                        else:             # rankers: every (query, candidate) pair is independent of the rest of its batch
+                            s_ = model.network(mb["que_rep"], mb["que_len"], mb["doc_rep"], mb["doc_len"]).contiguous()
+                            lib.check(L.nir_softmax_rows(lib.ptr(s_), lib.ptr(mine), s_.shape[0], s_.shape[1], lib.stream()), "softmax")
+                    eager_fns[(gb, k)] = body1
                     with torch.cuda.stream(ln):
                         body1()
                     torch.cuda.synchronize()
@@ -607,7 +621,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             ngroups = (nb + KG - 1) // KG
             for gb in range(ngroups):
                 agroups[(gb, KG)] = capture_aligned(gb, KG)
-            stages = {"aligned": agroups, "capture": capture_aligned, "KG": KG, "ngroups": ngroups, "nl": nl, "pos": 0, "graphed": not args.no_graph}
+            stages = {"aligned": agroups, "capture": capture_aligned, "KG": KG, "ngroups": ngroups, "nl": nl, "pos": 0, "graphed": not args.no_graph, "eager": eager_fns}
         except Exception as e:  # pragma: no cover
             print("[bench] graph capture unavailable for %s (%s: %s); eager sharded steps" % (name, type(e).__name__, e), file=sys.stderr)
             stages = None
@@ -802,7 +816,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     g1.replay()
             torch.cuda.synchronize()
             single_ms = (time.perf_counter() - ts) / ns * 1e3
-            L.nir_set_batches_in_flight(len(lanes))
+            L.nir_set_batches_in_flight(hint)
             mg_, mine_, _ = stages["aligned"][(0, stages["KG"])]
             with torch.cuda.stream(lanes[0]):
                 mg_.replay()
@@ -859,13 +873,13 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 torch.cuda.synchronize()
                 h2d_value = pairs_global * nh / (time.perf_counter() - th)
                 h2d_info = {"batches": nh, "seconds": round(time.perf_counter() - th, 3), "wire": "int64 (the reference's LongTensor batch), one pinned buffer per batch"}
-            L.nir_set_batches_in_flight(len(lanes))
+            L.nir_set_batches_in_flight(hint)
         except Exception as e:  # pragma: no cover - secondary figure only
             print("[bench] H2D-inclusive figure unavailable: %s: %s" % (type(e).__name__, e), file=sys.stderr)
 
     # ---- profiled pass: HIP events around every kernel of the library, same workload, serial -------------------
     torch.cuda.set_stream(lanes[0])
-    L.nir_set_batches_in_flight(1 if len(lanes) == 1 else len(lanes))
+    L.nir_set_batches_in_flight(hint)
     nprof = max(4, min(steps, 30))
     L.nir_debug_set_tunable(b"no_fork", 1)          # time every kernel in isolation (no query/document stream overlap)
     if rank == 0:
@@ -874,7 +888,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     if macro_single and stages is not None:        # the launches of the timed region: macro-batches of KG batches
         KGp = stages["KG"]
         for i in range(max(2, nprof // KGp)):
-            model.predict_many([batches[(KGp * i + j) % len(batches)] for j in range(KGp)])
+            stages["eager"][(i % stages["ngroups"], KGp)]()
         prof_div = max(2, nprof // KGp) * KGp
     else:
         for i in range(nprof):

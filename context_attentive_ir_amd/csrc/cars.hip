@@ -32,6 +32,7 @@ bool attn_pool_fused_usable(int D, int T);
 int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, const float* w3, const float* b3, const int64_t* lens, int64_t M,
                            int T, float* pooled, int one_term, hipStream_t st, int in_f16 = 0);
 bool attn_pool_pipe_selected(int64_t M, int T);
+bool bilstm_folded_split_out_ok(int pt_dtype, int H, int T);
 
 // ------------------------------------------------------------------------------------------------------
 // attention pooling: one wave per sequence; logits [M,T], h [M,T,D] (D % 4 == 0, D <= 1024)
@@ -200,7 +201,12 @@ extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, i
     const bool fused_attn = w->attn_frag && w->bounded && attn_pool_fused_usable(D, T) && !tun(g_tun.attn_unfused) && !tun(g_tun.exact_f32);
     // bf16 encoder whose per-token states stay inside this call and go to the attention pipeline: they travel as fp16 (the pipeline
     // takes single fp16 terms from a bf16 encoder anyway) -- half the bytes written by the recurrence and read by the pooling
-    const bool enc16 = fused_attn && dtype == NIR_DTYPE_BF16 && !encoded && H > 64 && attn_pool_pipe_selected(M, T);
+    // fp32-accurate encoder in the same situation: the recurrence already forms the two fp16 terms of every h_t for its own next step and
+    // hands exactly those to the pipeline (mode 2: same 4 bytes per element, [4 x term 1 | 4 x term 2] per group of 4 units) -- the
+    // pipeline's IO waves then copy 16 bytes per lane into their LDS planes instead of re-splitting fp32 rows (VALU-bound before)
+    const bool inside = fused_attn && !encoded && attn_pool_pipe_selected(M, T);
+    const int enc16 = !inside ? 0 : (dtype == NIR_DTYPE_BF16 ? (H > 64 ? 1 : 0) :
+                                     (bilstm_folded_split_out_ok(dtype, H, T) && !tun(g_tun.attn_fp32_rows) ? 2 : 0));
     NIR_PROPAGATE(launch_bilstm_folded(folded, dtype, ids, lens, w->whh, enc, err_flag, M, V, T, H, 2, st, enc16, dtype == NIR_DTYPE_F32 ? w->whh_frag : nullptr));
     // enc = o * tanh(c) lies in (-1,1); the attention weights are bounded (checked by the host when it packs them)
     if (fused_attn)

@@ -66,6 +66,7 @@ struct AttnPoolArgs {
     float* pooled;              // [M, 256]
     int64_t M;
     int T, logT;
+    int io_prio;                // pipelined kernel: issue priority of the IO waves (0 = like the MMA waves)
 };
 
 __global__ __launch_bounds__(256, 1) void attn_pool_fused_kernel(AttnPoolArgs p) {
@@ -267,7 +268,7 @@ __device__ long long ap_dbg[16];
 #else
 #define AP_T(I)
 #endif
-constexpr size_t AP2_LDS = (size_t)2 * AP_PLANE_HALVES * 2 + (2 * 4 * 64 + 4 * 64) * 4;
+constexpr size_t AP2_LDS = (size_t)2 * AP_PLANE_HALVES * 2 + (2 * 4 * 64 + 4 * 64 + 2 * AP_D) * 4;
 
 template <bool ONE>
 __device__ __forceinline__ void ap2_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32x4 (&acx)[AP_CT][AP_RT], const f16x8 (&af)[AP_RT][2],
@@ -281,15 +282,25 @@ __device__ __forceinline__ void ap2_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32
 
 // ONE: the encoder runs in bf16 (bf16 folded table + bf16 recurrence): h and W0 enter the attention MLP as single fp16 terms (11
 // mantissa bits, still 3 more than the bf16 operands upstream) -- one MFMA per fragment pair instead of three, one term plane.
-// IN16 (implies ONE): the encoder output arrives as fp16 rows (bf16-table recurrence with fp16 output): the IO waves copy it into the
+// IN = 1 (implies ONE): the encoder output arrives as fp16 rows (bf16-table recurrence with fp16 output): the IO waves copy it into the
 // term plane as it is -- half the HBM read, no conversion.
-template <bool ONE, bool IN16>
+// IN = 2 (two terms): the fp32-accurate recurrence hands over the two fp16 terms it formed for its own next step (lstm16_pt_h2_kernel,
+// out_f16 = 2): per row and group of 4 columns 16 bytes = [4 x leading term | 4 x residual x 2^11].  The IO waves load the same 16 bytes
+// per lane as for an fp32 row and store the halves into the two planes -- no split arithmetic (it was 16 x ~14 VALU per lane and tile and
+// made the IO waves, not the matrix pipe, the bound of this kernel).
+template <bool ONE, int IN>
 __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, int64_t ntiles) {
+    constexpr bool IN16 = IN == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned short asm2_[];
     constexpr int KG = AP_KG;
     float* rowpart = reinterpret_cast<float*>(asm2_ + 2 * AP_PLANE_HALVES);      // [2 buffers][4 waves][64 rows]
     float* probw = rowpart + 2 * 4 * 64;                                          // [4 IO waves][64 rows]
+    float* bw = probw + 4 * 64;                                                   // [256] b0 * 2 log2(e), [256] w3: read by every tile's epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w4 = wave & 3;
+    // (from global memory the eight values a lane needs were re-loaded at the start of every tile's epilogue: one exposed L2 round trip per tile)
+    if (tid < AP_D) bw[tid] = p.b0[tid] * 2.8853900817779268f;
+    else bw[tid] = p.w3[tid - AP_D];
+    __syncthreads();
     const bool mma_role = wave < 4;
     const int g = lane >> 4, c16 = lane & 15;
     const int T = p.T;
@@ -372,23 +383,29 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                 if (w4 == 0) { AP_T(1) }
                 AP_MMA_DRAIN();
                 {   // logits: tanh, times w3, summed over this wave's 64 columns
+                    // sum_c w3_c tanh(z_c) = -2 ( sum_c w3_c / (1 + 2^(C2 z_c)) - sum_c w3_c / 2 ): the lane accumulates w3_c / (1 + 2^..) starting from
+                    // -1/2 of its four w3 (one FMA per value less than forming tanh first); the factor -2 is applied once per row after the reduction
                     constexpr float C2 = 2.8853900817779268f;
-                    float rs[AP_RT][4];
-#pragma unroll
-                    for (int i = 0; i < AP_RT; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rs[i][r] = 0.f;
+                    float rs[AP_RT][4], bzv[AP_CT], w3v[AP_CT];
 #pragma unroll
                     for (int j = 0; j < AP_CT; ++j) {
                         const int col = 64 * w4 + 16 * j + c16;
-                        const float bz = p.b0[col] * C2, w3c = p.w3[col];
+                        bzv[j] = bw[col];
+                        w3v[j] = bw[AP_D + col];
+                    }
+                    const float r0 = -0.5f * ((w3v[0] + w3v[1]) + (w3v[2] + w3v[3]));
+#pragma unroll
+                    for (int i = 0; i < AP_RT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rs[i][r] = r0;
+#pragma unroll
+                    for (int j = 0; j < AP_CT; ++j) {
 #pragma unroll
                         for (int i = 0; i < AP_RT; ++i)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const float z = fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), C2, bz);
-                                const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), 1.0f);
-                                rs[i][r] = fmaf(w3c, th, rs[i][r]);
+                                const float z = fmaf(fmaf(acx[j][i][r], 1.0f / 2048.0f, acc[j][i][r]), C2, bzv[j]);
+                                rs[i][r] = fmaf(w3v[j], __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), rs[i][r]);
                             }
                     }
 #pragma unroll
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                             v += dpp_mov<0x4E>(v);
                             v += dpp_mov<0x141>(v);
                             v += dpp_mov<0x140>(v);
-                            if (c16 == 0) rp[w4 * 64 + 16 * i + 4 * g + r] = v;
+                            if (c16 == 0) rp[w4 * 64 + 16 * i + 4 * g + r] = -2.0f * v;
                         }
                 }
             }
@@ -417,14 +434,28 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
         //       tile's own term planes, still in planes[it&1] (h = h1 + 2^-11 h2' to 2^-22: no second read of the encoder output)
         //   (2) split the rows of tile it -- loaded during the previous iteration -- into planes[it&1]
         //   (3) issue the loads of tile it+1: in flight across the barrier (64 registers held): no memory latency exposed here
+        // Optional static issue priority above the MMA wave of the same SIMD (tunable attn_io_prio; measured in tools/attn_micro.py: the two
+        // waves of a SIMD share its issue bandwidth, so work moved between them does not net -- the priority only decides WHO waits)
+        if (p.io_prio) __builtin_amdgcn_s_setprio(2);
         float* pw = probw + w4 * 64;
         const int sub = lane >> 4, per = T / 4;
         const int col = 64 * w4 + 4 * c16;
         const int poff = ((col >> 5) * 4 + ((col >> 3) & 3)) * KG + (col & 7);
         float4 ld[IN16 ? 1 : 16];
         uint2 ld16[IN16 ? 16 : 1];
+        // The length of row `lane`'s sequence travels with the tile's rows: requested IN FRONT of them (vmcnt retires in order), first read where
+        // the rows are consumed anyway, then handed down a two-deep register ring to the iteration that finishes the tile.  Loaded inside the
+        // finish phase instead, its wait covered the 16 row loads in flight for tile k+1 as well: every tile paid a full memory round trip there
+        // (11.5 K of a 15 K-cycle iteration, tools/attn_micro.py).
+        const float b3v = p.b3[0];
+        int len_ld = T, len_1 = T, len_2 = T;
         auto load_rows = [&](int64_t k) {
             const int64_t row0 = (blockIdx.x + k * G) * AP_ROWS;
+            {
+                const int64_t seq = (row0 + lane) >> p.logT;
+                len_ld = T;
+                if (p.lens) len_ld = (int)p.lens[seq < p.M ? seq : p.M - 1];
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 int64_t r = row0 + 4 * q + sub;
@@ -444,43 +475,56 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                     const int64_t r = rowS + lane;
                     const int64_t seq = r >> p.logT;                   // T is a power of two: no 64-bit division per lane
                     const int t = (int)(r - seq * T);
-                    int len = T;
-                    if (p.lens && seq < p.M) len = (int)p.lens[seq];
+                    int len = len_2;
                     len = len < 0 ? 0 : (len > T ? T : len);
                     const bool ok = seq < p.M && t < len;
-                    const float lg = (rp[lane] + rp[64 + lane]) + (rp[128 + lane] + rp[192 + lane]) + p.b3[0];
+                    const float lg = (rp[lane] + rp[64 + lane]) + (rp[128 + lane] + rp[192 + lane]) + b3v;
                     const float mx = ap_group_max(ok ? lg : -INFINITY, T);
                     const float e = ok ? __expf(lg - mx) : 0.f;
                     const float den = ap_group_sum(e, T);
                     pw[lane] = e / den;                    // len == 0: 0/0 = NaN, like softmax over an all -inf row
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                if (w4 == 0) { AP_T(8) }
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                // in two halves of 8 rows: ALL LDS reads of a half are issued before its first use (40 registers).  Written row by row the
+                // compiler waited for every row's three reads before converting it -- 16 serialised LDS round trips per tile, each several
+                // hundred cycles while the MMA waves stream their fragments: 8-10 K cycles for ~300 VALU instructions (tools/attn_micro.py)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int row = 4 * q + sub;
-                    const uint2 u1 = *reinterpret_cast<const uint2*>(Pb + row * 8);
-                    const fp16x2_t a01 = __builtin_bit_cast(fp16x2_t, u1.x), a23 = __builtin_bit_cast(fp16x2_t, u1.y);
-                    const float pr = pw[row];
-                    if (ONE) {
-                        a.x = fmaf(pr, (float)a01[0], a.x);
-                        a.y = fmaf(pr, (float)a01[1], a.y);
-                        a.z = fmaf(pr, (float)a23[0], a.z);
-                        a.w = fmaf(pr, (float)a23[1], a.w);
-                    } else {
-                        const uint2 u2 = *reinterpret_cast<const uint2*>(Pb + AP_S * 4 * KG + row * 8);
-                        const fp16x2_t b01 = __builtin_bit_cast(fp16x2_t, u2.x), b23 = __builtin_bit_cast(fp16x2_t, u2.y);
-                        a.x = fmaf(pr, fmaf((float)b01[0], 1.0f / 2048.0f, (float)a01[0]), a.x);
-                        a.y = fmaf(pr, fmaf((float)b01[1], 1.0f / 2048.0f, (float)a01[1]), a.y);
-                        a.z = fmaf(pr, fmaf((float)b23[0], 1.0f / 2048.0f, (float)a23[0]), a.z);
-                        a.w = fmaf(pr, fmaf((float)b23[1], 1.0f / 2048.0f, (float)a23[1]), a.w);
+                for (int hb = 0; hb < 2; ++hb) {
+                    uint2 u1[8], u2[ONE ? 1 : 8];
+                    float prr[8];
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8) {
+                        const int row = 4 * (8 * hb + q8) + sub;
+                        u1[q8] = *reinterpret_cast<const uint2*>(Pb + row * 8);
+                        if (!ONE) u2[q8] = *reinterpret_cast<const uint2*>(Pb + AP_S * 4 * KG + row * 8);
+                        prr[q8] = pw[row];
                     }
-                    if (((q + 1) & (per - 1)) == 0) {              // sequence complete: fold the four row subgroups, subgroup 0 stores
-                        a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
-                        a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
-                        const int64_t seq = (rowS >> p.logT) + (q >> (p.logT - 2));
-                        if (sub == 0 && seq < p.M) *reinterpret_cast<float4*>(p.pooled + seq * AP_D + col) = a;
-                        a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8) {
+                        const int q = 8 * hb + q8;
+                        const fp16x2_t a01 = __builtin_bit_cast(fp16x2_t, u1[q8].x), a23 = __builtin_bit_cast(fp16x2_t, u1[q8].y);
+                        const float pr = prr[q8];
+                        if (ONE) {
+                            a.x = fmaf(pr, (float)a01[0], a.x);
+                            a.y = fmaf(pr, (float)a01[1], a.y);
+                            a.z = fmaf(pr, (float)a23[0], a.z);
+                            a.w = fmaf(pr, (float)a23[1], a.w);
+                        } else {
+                            const fp16x2_t b01 = __builtin_bit_cast(fp16x2_t, u2[q8].x), b23 = __builtin_bit_cast(fp16x2_t, u2[q8].y);
+                            a.x = fmaf(pr, fmaf((float)b01[0], 1.0f / 2048.0f, (float)a01[0]), a.x);
+                            a.y = fmaf(pr, fmaf((float)b01[1], 1.0f / 2048.0f, (float)a01[1]), a.y);
+                            a.z = fmaf(pr, fmaf((float)b23[0], 1.0f / 2048.0f, (float)a23[0]), a.z);
+                            a.w = fmaf(pr, fmaf((float)b23[1], 1.0f / 2048.0f, (float)a23[1]), a.w);
+                        }
+                        if (((q + 1) & (per - 1)) == 0) {              // sequence complete: fold the four row subgroups, subgroup 0 stores
+                            a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
+                            a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+                            const int64_t seq = (rowS >> p.logT) + (q >> (p.logT - 2));
+                            if (sub == 0 && seq < p.M) *reinterpret_cast<float4*>(p.pooled + seq * AP_D + col) = a;
+                            a = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
                 }
             }
@@ -494,6 +538,11 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                         continue;
                     }
                     const float4 v = ld[q];
+                    if (IN == 2) {                             // the two terms as the recurrence formed them
+                        *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+                        *reinterpret_cast<uint2*>(d + AP_S * 4 * KG) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+                        continue;
+                    }
                     const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
                     *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
                     if (!ONE) {
@@ -503,7 +552,11 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                     }
                 }
                 if (w4 == 0) { AP_T(6) }
+                len_2 = len_1;                               // tile it-1 is finished next
+                len_1 = len_ld;                              // tile it (its rows were consumed just above: the value has arrived)
                 if (it + 1 < nk) load_rows(it + 1);
+            } else {
+                len_2 = len_1;
             }
             if (w4 == 0) { AP_T(7) }
             __syncthreads();
@@ -540,22 +593,26 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     if (M == 0) return 0;
     AttnPoolArgs a;
     a.h = h; a.wf = (const _Float16*)wfrag; a.b0 = b0; a.w3 = w3; a.b3 = b3; a.lens = lens; a.pooled = pooled; a.M = M; a.T = T; a.logT = __builtin_ctz((unsigned)T);
+    a.io_prio = tun(g_tun.attn_io_prio);
     static std::once_flag once;
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)attn_pool_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS); });
     const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
     ProfScope ps(prof_shape_name("attn_pool_fused_kernel", M * T, AP_D, AP_D), st);
     static std::once_flag once2;
     std::call_once(once2, [] {
-        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
     });
     const int ncu = ap_cu_count();
     if (attn_pool_pipe_selected(M, T)) {                                   // several tiles per CU: the role-specialised pipeline
         const dim3 grid((unsigned)std::min<int64_t>(tiles, ncu));
-        if (in_f16) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, true>), grid, dim3(512), AP2_LDS, st, a, tiles);
-        else if (one_term) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, false>), grid, dim3(512), AP2_LDS, st, a, tiles);
-        else hipLaunchKernelGGL((attn_pool_pipe_kernel<false, false>), grid, dim3(512), AP2_LDS, st, a, tiles);
+        NIR_REQUIRE(in_f16 != 2 || !one_term, "attn_pool_fused: term-pair rows come from the fp32-accurate encoder (two terms)");
+        if (in_f16 == 1) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, 1>), grid, dim3(512), AP2_LDS, st, a, tiles);
+        else if (in_f16 == 2) hipLaunchKernelGGL((attn_pool_pipe_kernel<false, 2>), grid, dim3(512), AP2_LDS, st, a, tiles);
+        else if (one_term) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, 0>), grid, dim3(512), AP2_LDS, st, a, tiles);
+        else hipLaunchKernelGGL((attn_pool_pipe_kernel<false, 0>), grid, dim3(512), AP2_LDS, st, a, tiles);
     } else {
         NIR_REQUIRE(!in_f16, "attn_pool_fused: fp16 input is only taken by the pipelined kernel (attn_pool_pipe_selected)");
         hipLaunchKernelGGL(attn_pool_fused_kernel, dim3((unsigned)tiles), dim3(256), AP_LDS, st, a);

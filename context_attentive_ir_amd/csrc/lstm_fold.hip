@@ -68,7 +68,9 @@ struct LstmPtArgs {
     int* err;               // device flag (may be NULL): bit 0 = an id fell outside [0,V); bit 1 = |w_hh| outside the fp16 (split) range
     int64_t M, V;
     int T, H, ND;
-    int out_f16;            // bf16-table kernels only: `out` is [M,T,ND*H] fp16
+    int out_f16;            // 1 (bf16-table kernels): `out` is [M,T,ND*H] fp16.  2 (f32 table, lstm16_pt_h2_kernel<4,4,8>): `out` keeps 4 bytes per
+                            // element, but every group of 4 consecutive units holds [4 x fp16 leading term | 4 x fp16 residual x 2^11] -- the two-term
+                            // split the kernel forms anyway for its own next step, in the order attn_pool_pipe_kernel stages its LDS planes
     const void* whh_frag;   // optional: W_hh pre-split into the two fp16 terms, in the lane order of lstm16_pt_h2_kernel<4,4,8> (nir_lstm_pack_whh_frag)
 };
 
@@ -629,21 +631,22 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     // step is then [stores, requests] and the wait the compiler derives for the requests (vmcnt counts in order) never covers a store
     // that is younger than they are.  (With [requests, stores] the derived wait flipped with unrelated edits between "requests only" and
     // "requests and the first store" -- a store round trip, ~1000 cycles, in front of the first MFMA of every step.)
-    float hprev[NT];
+    uint32_t hprev[NT];                                       // fp32 bit patterns, or (split output) the packed term pairs
 #pragma unroll
-    for (int t = 0; t < NT; ++t) hprev[t] = 0.f;
+    for (int t = 0; t < NT; ++t) hprev[t] = 0u;
+    // split output (out_f16 == 2, H = 128: every lane `full`): the 16 bytes of the lane's four units carry the two fp16 terms instead of four floats
+    const bool split = NT == 4 && p.out_f16 == 2;
     uint32_t poff = OOB;                                      // byte offset of (sequence, step, u0) in the output block, OOB = dropped
     auto store_prev = [&]() {
         if (NT == 4) {
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(hprev[0]), __float_as_uint(hprev[1 % NT]), __float_as_uint(hprev[2 % NT]),
-                                                           __float_as_uint(hprev[3 % NT])}, out_rs, full ? poff : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){hprev[0], hprev[1 % NT], hprev[2 % NT], hprev[3 % NT]}, out_rs, full ? poff : OOB, 0, 0);
         } else if (NT == 2) {
-            __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(hprev[0]), __float_as_uint(hprev[1 % NT])}, out_rs, full ? poff : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){hprev[0], hprev[1 % NT]}, out_rs, full ? poff : OOB, 0, 0);
         }
         if ((NT != 4 && NT != 2) || !full) {                  // unit by unit (NT = 4 / 2: only the lanes that straddle H)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hprev[t]), out_rs, (u0 + t < H && poff != OOB) ? poff + 4u * t : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(hprev[t], out_rs, (u0 + t < H && poff != OOB) ? poff + 4u * t : OOB, 0, 0);
         }
     };
     const int* idp = ids_s + sq * TP;
@@ -756,8 +759,13 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
                 r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
             }
             if (NT == 4) {
-                *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = (f16x4){a[0], a[1 % NT], a[2 % NT], a[3 % NT]};
-                *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = (f16x4){r[0], r[1 % NT], r[2 % NT], r[3 % NT]};
+                const f16x4 av = (f16x4){a[0], a[1 % NT], a[2 % NT], a[3 % NT]}, rv = (f16x4){r[0], r[1 % NT], r[2 % NT], r[3 % NT]};
+                *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = av;
+                *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = rv;
+                if (split) {                                  // the same two vectors ARE the output (wave-uniform)
+                    const u32x2 au = __builtin_bit_cast(u32x2, av), ru = __builtin_bit_cast(u32x2, rv);
+                    hprev[0] = au[0]; hprev[1 % NT] = au[1]; hprev[2 % NT] = ru[0]; hprev[3 % NT] = ru[1];
+                }
             } else {
                 *reinterpret_cast<f16x2*>(zn + sq * ZLD + u0) = (f16x2){a[0], a[1 % NT]};
                 *reinterpret_cast<f16x2*>(zn + SEQ * ZLD + sq * ZLD + u0) = (f16x2){r[0], r[1 % NT]};
@@ -771,8 +779,10 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
                     zn[SEQ * ZLD + sq * ZLD + u0 + t] = (_Float16)((hn[t] - (float)a) * SC);
                 }
         }
+        if (!split) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) hprev[t] = hn[t];
+            for (int t = 0; t < NT; ++t) hprev[t] = __float_as_uint(hn[t]);
+        }
         poff = live ? soff : OOB;
         soff += sstep;
         if (!DEFER) store_prev();                  // (this step's output)
@@ -1340,6 +1350,12 @@ __global__ __launch_bounds__(64) void lstm_whh_frag_kernel(const float* __restri
     if (bad && err) atomicOr(err, 2);
 }
 
+// true when launch_bilstm_folded(.., out_f16 = 2) is served: the dispatch below ends in lstm16_pt_h2_kernel<4,4,8> with every lane `full`
+bool bilstm_folded_split_out_ok(int pt_dtype, int H, int T) {
+    (void)T;
+    return pt_dtype == NIR_DTYPE_F32 && H == 128 && !tun(g_tun.exact_f32) && tun(g_tun.lstm_w16) != 1 && tun(g_tun.lstm_w16) != 3;
+}
+
 int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
                          int* err, int64_t M, int64_t V, int T, int H, int ND, hipStream_t st, int out_f16, const void* whh_frag) {
     NIR_REQUIRE(pt && ids && whh && out, "bilstm_folded: null pointer");
@@ -1349,7 +1365,8 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     NIR_REQUIRE((int64_t)16 * T * ND * H * 4 < 0x7FFFFFF0LL, "bilstm_folded: T*H too large for 32-bit tile offsets");
     NIR_REQUIRE(pt_dtype == NIR_DTYPE_F32 || pt_dtype == NIR_DTYPE_BF16, "bilstm_folded: unknown table dtype %d", pt_dtype);
     if (M == 0) return 0;
-    NIR_REQUIRE(!out_f16 || (pt_dtype == NIR_DTYPE_BF16 && H > 64 && H % 2 == 0), "bilstm_folded: fp16 output needs the bf16 table and an even H > 64");
+    NIR_REQUIRE(out_f16 != 1 || (pt_dtype == NIR_DTYPE_BF16 && H > 64 && H % 2 == 0), "bilstm_folded: fp16 output needs the bf16 table and an even H > 64");
+    NIR_REQUIRE(out_f16 != 2 || bilstm_folded_split_out_ok(pt_dtype, H, T), "bilstm_folded: split-term output is produced by lstm16_pt_h2_kernel<4,4,8> only (f32 table, H = 128)");
     LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND, out_f16, whh_frag};
     if (pt_dtype == NIR_DTYPE_BF16) {
         const int KB = (H + 31) / 32;

@@ -192,8 +192,43 @@ def test_attention_pooling_pipeline_kernel(S, N, QL, DL):
         d0 = m.encode_document(ex["document_words"], ex["document_lens"])
     with lib.tunable("attn_unfused_pipe", 2, 0):
         p1, _, _ = m.encode(ex["source_words"], ex["source_lens"])
-        d1 = m.encode_document(ex["document_words"], ex["document_lens"])
-    _close(p1, p0, 5e-6); _close(d1, d0, 5e-6)
+        d1 = m.encode_document(ex["document_words"], ex["document_lens"])       # H = 128: the recurrence hands its term pairs over (mode 2)
+        with lib.tunable("attn_fp32_rows", 1, 0):
+            d2 = m.encode_document(ex["document_words"], ex["document_lens"])   # fp32 rows, split again by the IO waves (mode 0)
+    _close(p1, p0, 5e-6); _close(d1, d0, 5e-6); _close(d2, d0, 5e-6)
+    assert not torch.equal(d1, d2)                       # two different roundings of the residual term (nearest vs toward zero): both ran
+
+
+def test_recurrence_hands_term_pairs_to_attention_pipeline_vs_oracle():
+    """A document block large enough for the pipeline to be selected by tile count (608 documents x 64 steps = 608 tiles >= 2 x 256 CUs), ragged
+    lengths: lstm16_pt_h2_kernel<4,4,8> writes every h_t as [4 x leading fp16 term | 4 x residual term] per group of 4 units and
+    attn_pool_pipe_kernel<false,2> stages those 16-byte groups straight into its LDS planes.  pooled_docs against the ORACLE at 2e-5
+    (|pooled| < 1), and the raw hand-over buffer decodes to the fp32 states of the plain output (2^-22 relative to |h| < 1)."""
+    from context_attentive_ir_amd import lib
+    V, M, T_ = 3000, 608, 64
+    m = build_model("CARS", vocab=V, device=DEV)
+    g = torch.Generator().manual_seed(77)
+    ids = torch.randint(4, V, (M, T_), generator=g)
+    lens = torch.randint(1, T_ + 1, (M,), generator=g)
+    lens[:40] = T_
+    ids = torch.where(torch.arange(T_)[None, :] < lens[:, None], ids, torch.zeros_like(ids))
+    sd = cpu_state_dict(m)
+    ref = O.cars_encode_document(sd, ids.view(1, 1, M, T_), lens.view(1, 1, M)).view(M, -1)
+    got = m.encode_document(ids.view(1, 1, M, T_).to(DEV), lens.view(1, 1, M).to(DEV)).view(M, -1).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    with lib.tunable("attn_fp32_rows", 1, 0):
+        got0 = m.encode_document(ids.view(1, 1, M, T_).to(DEV), lens.view(1, 1, M).to(DEV)).view(M, -1).cpu()
+    np.testing.assert_allclose(got0.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    assert not torch.equal(got, got0)
+    # the hand-over format itself, through the C-ABI recurrence entry (plain fp32 output) against the decode of what the pipeline reads
+    from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
+    wih, whh, bih, bhh = [t.detach().contiguous() for t in lstm_cat_weights(m.document_encoder.encoder.rnns[0])]
+    folded = lib.fold_lstm_table(m.embedder.word_embeddings.table.detach(), wih, bih, bhh, 128, 2, "f32")
+    out = torch.empty(M, T_, 256, device=DEV)
+    lib.check(lib.load().nir_bilstm_folded_fwd(lib.ptr(folded), lib.DTYPE_F32, lib.ptr(ids.to(DEV)), lib.ptr(lens.to(DEV)), lib.ptr(whh), lib.ptr(out), None,
+                                                M, V, T_, 128, 2, lib.stream()), "folded")
+    _, enc = O.rnn_encode(sd, "document_encoder.encoder", O.embed(sd, "embedder.word_embeddings", ids), lens)
+    np.testing.assert_allclose(out.cpu().numpy(), enc.detach().numpy(), rtol=0, atol=2e-5)
 
 
 def test_bilstm_folded_four_wave_variant_matches():
