@@ -119,11 +119,11 @@ def kernel_work(name, c):
         # (K = NF) per pooled position -- not the padded tile work in the label (M = tiles x 64 rows, N = NF, K = 3E)
         Tc, Tp = DL - 2, DL - 6
         return dict(flops=pairs * 2.0 * N * (Tc * K + Tp * N), bytes=pairs * DL * (4.0 * E + 8), terms=3, pipe=F16)
-    if base.startswith("attn_pool_fused_kernel"):
-        # fused attention pooling (csrc/cars_attn.hip): M rows of D = N = K = 256; bf16 encoders (C5): single fp16 terms and, once the
-        # pipelined kernel is selected (>= 2 tiles of 64 rows per CU), fp16 encoder rows
-        one = c.get("dtype") == "bf16"
-        in16 = one and M >= 2 * 256 * 64
+    if base.startswith("attn_pool_fused_kernel") or base.startswith("attn_pool_pipe_kernel"):
+        # fused attention pooling (csrc/cars_attn.hip): M rows of D = N = K = 256.  Pipeline template arguments <ONE, IN>: ONE = single fp16 terms
+        # (bf16 encoders), IN = 1 fp16 rows / 2 the recurrence's term pairs (4 B per element, like fp32 rows)
+        one = "<true" in base                           # (the single-role kernel always runs the three-MFMA form)
+        in16 = "<true,1>" in base
         return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=(2.0 if in16 else 4.0) * M * K + 4.0 * N * K, terms=1 if one else 3, pipe=F16)
     if base.startswith("gemm3_kernel"):
         gathered = "[gather]" in base
@@ -1142,6 +1142,20 @@ def main():
 
 def run_all(args):
     env = Env(args.gpus)
+    try:
+        return run_records(args, env)
+    finally:
+        if env.dist:
+            try:
+                env.dist.destroy_process_group()
+            except Exception:
+                pass
+        # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it out first so that the
+        # JSON line is the LAST line of rank 0's stdout
+        ctypes.CDLL(None).fflush(None)
+
+
+def run_records(args, env):
     for kv in filter(None, os.environ.get("NIR_TUNE", "").split(",")):     # kernel-variant A/B runs: NIR_TUNE=name=value,...
         k, v = kv.split("=")
         lib.check(lib.load().nir_debug_set_tunable(k.encode(), int(v)), "nir_debug_set_tunable")
@@ -1244,11 +1258,6 @@ def run_all(args):
                 "scaling": "strong", "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
                 "config": cfg, "roofline": small, "cpu_baseline": cpu, "sub": [short_sub(n, r) for n, r in sub.items()]}
         result_line = json.dumps(line, separators=(",", ":"))
-    if env.dist:
-        env.dist.destroy_process_group()
-    # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it out first so that the
-    # JSON line is the LAST line of rank 0's stdout
-    ctypes.CDLL(None).fflush(None)
     return result_line
 
 
@@ -1334,7 +1343,9 @@ def stream_record(args, env, seconds=None, n_sessions=None, mode=None):
         torch.cuda.synchronize()
         t_capture = time.perf_counter() - t0
         prod = 2 if (nl * 2) % 2 == 0 else 1
-        sink = (lambda *a: None) if plan is not None else None        # a consumer: the gathered rounds are really handed over on every rank
+        # RCCL: the all-gather and the D2H of the gathered block are part of submit() (device side), like the single-GPU record nothing is
+        # unpacked on the host; gloo (flow tests): the gather itself happens at hand-over, so a consumer is needed
+        sink = (lambda *a: None) if (plan is not None and sp.gather == "host") else None
         sp.run(corpus, bl, max_batches=4 * nl, on_result=sink)                                     # warm the pipeline
         if plan is None:
             r = sp.run(corpus, bl, min_seconds=seconds, producers=prod)

@@ -597,7 +597,11 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     static std::once_flag once;
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)attn_pool_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS); });
     const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
-    ProfScope ps(prof_shape_name("attn_pool_fused_kernel", M * T, AP_D, AP_D), st);
+    // (profile label = the kernel that runs: the role-specialised pipeline by template arguments, else the single-role kernel)
+    const bool pipe_sel = attn_pool_pipe_selected(M, T);
+    const char* pname = !pipe_sel ? "attn_pool_fused_kernel" : in_f16 == 1 ? "attn_pool_pipe_kernel<true,1>" : in_f16 == 2 ? "attn_pool_pipe_kernel<false,2>" :
+                        one_term ? "attn_pool_pipe_kernel<true,0>" : "attn_pool_pipe_kernel<false,0>";
+    ProfScope ps(prof_shape_name(pname, M * T, AP_D, AP_D), st);
     static std::once_flag once2;
     std::call_once(once2, [] {
         (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
@@ -606,7 +610,7 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
         (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
     });
     const int ncu = ap_cu_count();
-    if (attn_pool_pipe_selected(M, T)) {                                   // several tiles per CU: the role-specialised pipeline
+    if (pipe_sel) {                                                        // several tiles per CU: the role-specialised pipeline
         const dim3 grid((unsigned)std::min<int64_t>(tiles, ncu));
         NIR_REQUIRE(in_f16 != 2 || !one_term, "attn_pool_fused: term-pair rows come from the fp32-accurate encoder (two terms)");
         if (in_f16 == 1) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, 1>), grid, dim3(512), AP2_LDS, st, a, tiles);

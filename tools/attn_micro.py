@@ -66,7 +66,7 @@ def main():
         for v in variants:
             acc[v].append(timed(*v))
     for v in variants:
-        att = sorted(r["attn_pool_fused_kernel"] for r in acc[v])
+        att = sorted(next(x for k, x in r.items() if k.startswith("attn_pool")) for r in acc[v])
         rec = sorted(next(x for k, x in r.items() if k.startswith("lstm16")) for r in acc[v])
         print("fp32_rows %d io_prio %d : attention median %.1f us (min %.1f max %.1f)   recurrence median %.1f us" % (
             v[0], v[1], att[len(att) // 2], att[0], att[-1], rec[len(rec) // 2]))

@@ -1,10 +1,10 @@
-"""Condense gpurun_out/r03prof (tools/capture_r03.sh) into per-config summaries: <cfg>/kernel_stats.csv (rocprofv3 --stats),
+"""Condense gpurun_out/<round>prof (tools/capture_profiles.sh) into per-config summaries: <cfg>/kernel_stats.csv (rocprofv3 --stats),
 <cfg>/pmc.json (mean counter per launch per kernel) and pmc_summary.json: per config and kernel
   bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB  (the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md section HBM),
   mfma_busy        = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)   (matrix-pipe busy fraction, chip-wide, while
                      the kernel runs; GRBM_GUI_ACTIVE is summed over the 8 XCDs).
 usage: python tools/derive_profiles.py <dir>; `python tools/derive_profiles.py --install <dir> [prefix]` in the authoring container copies the
-summaries into profiles/ (prefix default r03)."""
+summaries into profiles/ (prefix default r03); `--check <dir> <bench_detail.json>` verifies that every record's dominant kernel is in its capture."""
 import csv
 import glob
 import json
@@ -62,7 +62,7 @@ def condense(root):
                     t[k]["SQ_INSTS_MFMA"] = d.get("SQ_INSTS_MFMA")
         traffic[cfg] = t
     json.dump({"note": "bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 * GRBM_GUI_ACTIVE / 8); mean over the "
-                       "launches of the serial eager bench.py run of each config; separate --pmc passes (tools/capture_r03.sh); a kernel launched with "
+                       "launches of the serial eager bench.py run of each config; separate --pmc passes (tools/capture_profiles.sh); a kernel launched with "
                        "several grids in one step is reported for its largest grid",
                "configs": traffic}, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
@@ -83,8 +83,31 @@ def install(root, prefix="r03"):
     json.dump(new, open(old_path, "w"), indent=1, sort_keys=True)
 
 
+def check(root, detail_path):
+    """every record of the bench run (headline + sub-records with a roofline) must find its dominant kernel -- template arguments included -- in
+    the kernel_stats.csv captured for that config: a profile of another instantiation proves nothing about the timed one.  Exit code 1 otherwise."""
+    detail = json.load(open(detail_path))
+    recs = {detail["headline"]["name"]: detail["headline"]}
+    recs.update(detail.get("sub", {}))
+    bad = []
+    for cfg, rec in sorted(recs.items()):
+        st = os.path.join(root, cfg, "kernel_stats.csv")
+        kern = ((rec.get("roofline") or {}).get("kernel") or "").split("[")[0]
+        if not os.path.exists(st) or not kern:
+            continue
+        names = {short(r["Name"]) for r in csv.DictReader(open(st))}
+        fam = kern.replace("[gather]", "").replace("[fused]", "")
+        ok = fam in names or ("<" not in fam and any(n.split("<")[0] == fam for n in names))
+        print("%-22s %-40s %s" % (cfg, kern, "ok" if ok else "MISSING from the capture"))
+        if not ok:
+            bad.append(cfg)
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "--install":
         install(sys.argv[2], *(sys.argv[3:4]))
+    elif sys.argv[1] == "--check":
+        sys.exit(check(sys.argv[2], sys.argv[3]))
     else:
         condense(sys.argv[1])
