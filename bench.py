@@ -99,7 +99,7 @@ def flops_per_pair(model, qlen, dlen):
 _SHAPE = re.compile(r"^(.*)\[M=(\d+),N=(\d+),K=(\d+)\]$")
 
 
-def kernel_work(name, c):
+def kernel_work(name, c, pairs_per_launch=None):
     """Work of ONE launch, priced from the launch's own shape label:
       flops  algorithmic (fp32-equivalent) FLOPs of the op the kernel implements
       terms  MFMAs EXECUTED per algorithmic product block (fp16 two-term split 3, bf16 three-term split 6, single fp16/bf16/f32 term 1)
@@ -110,6 +110,8 @@ def kernel_work(name, c):
     base, M, N, K = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))) if m else (name, 0, 0, 0)
     B, NC, QL, DL, E = c["batch"], c["cands"], c["qlen"], c["dlen"], 300
     pairs = B * NC * (c.get("session", 1) if c["model"] in SESSION_MODELS else 1)
+    if pairs_per_launch:                      # a macro-batched launch covers several batches
+        pairs = pairs_per_launch
     F16, F32 = PEAK_BF16_TFLOPS, PEAK_FP32_TFLOPS
     if base.startswith("gemm3h_kernel") or base.startswith("gemm_h2p_kernel"):     # fp16 two-term split: 3 MFMAs per product block
         gathered = "[gather]" in base
@@ -269,15 +271,17 @@ def precompute_info(wrapper, c):
 
 def macro_batch(c, env_key="BENCH_MACRO_BATCH", share=1):
     """batches merged into one macro-batch per graph replay (Multitask.predict_many): ONE policy at every N -- a rank's launch sequence is
-    filled to ~4 480 documents, at most 8 steps per replay (and per gather).  Small batches (C3: 1 120 documents) are merged four at a time at
-    N = 1 -- a lone C3 batch fills 140 of 256 CUs with recurrence workgroups and pays 76 MB of session-weight traffic whatever its size --
-    large ones (C5: 22 400 documents) are not (no gain measured, 4x the scratch).  share > 1: the rank holds 1/share of every batch (sharded CARS
-    step), so the same target merges more steps (C3 at 8 ranks: 8).  The environment variable overrides; the `*_kg_matched` sub-record of an N > 1
-    run repeats the headline with the N = 1 count."""
+    filled to ~8 960 documents, at most 8 steps per replay (and per gather).  Small batches (C3: 1 120 documents) are merged eight at a time at
+    N = 1 -- a lone C3 batch fills 140 of 256 CUs with recurrence workgroups and pays 76 MB of session-weight traffic whatever its size; a
+    recurrence workgroup (16 sequences, one direction) occupies a whole CU for the 64 steps, so the launch runs in ROUNDS of 256 workgroups:
+    4 batches = 560 workgroups = 3 rounds (the last 19 % full), 8 batches = 1 120 = 5 rounds (measured, 504 steps: KG 4 / 6 / 7 / 8 / 9 = 8.15 / 8.28 /
+    8.51 / 8.64 / 8.50 M pairs/s) -- large ones (C5: 22 400 documents) are not merged (no gain measured, 4x the scratch).  share > 1: the rank holds
+    1/share of every batch (sharded CARS step), so the same target merges as many steps (cap 8).  The environment variable overrides; the
+    `*_kg_matched` sub-record of an N > 1 run repeats the headline with the N = 1 count."""
     if os.environ.get(env_key):
         return max(1, int(os.environ[env_key]))
-    docs = c["batch"] * c.get("session", 1) * c["cands"] // max(1, share)
-    return max(1, min(8, 4480 // max(1, docs)))
+    tokens = c["batch"] * c.get("session", 1) * c["cands"] * c["dlen"] // max(1, share)      # 8 960 documents of 64 tokens
+    return max(1, min(8, 8960 * 64 // max(1, tokens)))
 
 
 def make_batches(c, nbatches, rank_seed, dev):
@@ -913,9 +917,9 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             cc = dict(c)
             if sharded and not is_sess:
                 cc["cands"] = batches[0]["doc_rep"].shape[1]
-            work = kernel_work(dom, cc)
             bpp = algorithmic_bytes_per_pair(c["cands"], c["qlen"], c["dlen"], table_bytes=2 if c.get("dtype") == "bf16" else 4)
             step_pairs_rank = pairs_global / (wsh if sharded else 1)
+            work = kernel_work(dom, cc, pairs_per_launch=step_pairs_rank / (cnt / prof_div))
             # SURVEY 8(d) bytes of the pairs ONE launch of the dominant kernel covers (a macro-batched launch covers KG steps)
             bytes_8d = bpp * step_pairs_rank / (cnt / prof_div)
             t = avg_us * 1e-6

@@ -26,22 +26,7 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
                      int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
                      int64_t ldc, int64_t M, int N, int K, int act, const float* add, int64_t ldadd, hipStream_t st);
 
-struct LstmStepArgs {
-    const float* x[2];
-    const int64_t* xid[2];
-    int64_t xstride[2];
-    const float* wih[2];
-    const float* whh[2];
-    const float* bih[2];
-    const float* bhh[2];
-    const float* hprev[2];
-    const float* cprev[2];
-    float* hnext[2];
-    float* cnext[2];
-    int chain0;
-    int B, I, H;
-};
-int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st);
+
 
 // one wave per decode row i: memory block = mem[rowmap[i]] ([QL, HD]), valid length = lens[rowmap[i]]
 __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict__ qv, const float* __restrict__ h,

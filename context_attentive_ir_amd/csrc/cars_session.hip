@@ -198,21 +198,7 @@ __global__ __launch_bounds__(256) void click_pool_big_kernel(const float* __rest
 // interleaved as row = 4*unit + gate so the 16x16 MFMA's C/D layout hands ONE lane the four gates i,f,g,o of its
 // (unit, batch row): gates = x W_ih^T + h W_hh^T on v_mfma_f32_16x16x4_f32 with K split over the 4 waves, operands read
 // straight from L2 as MFMA fragments, partial tiles summed through LDS, cell update in the same kernel.
-struct LstmStepArgs {
-    const float* x[2];        // input rows: row b at x + (xid ? xid[b] : b) * xstride   (xid: embedding gather by token id)
-    const int64_t* xid[2];
-    int64_t xstride[2];
-    const float* wih[2];      // [4H, I]
-    const float* whh[2];      // [4H, H]
-    const float* bih[2];
-    const float* bhh[2];
-    const float* hprev[2];    // [B,H] or NULL (zero state: the recurrent product is skipped)
-    const float* cprev[2];    // [B,H] or NULL
-    float* hnext[2];          // [B,H]
-    float* cnext[2];
-    int chain0;               // blockIdx.y + chain0 = chain id
-    int B, I, H;
-};
+// (LstmStepArgs: common.hpp)
 
 // NB = batch tiles of 16 rows that share one pass over the weights (B <= 16 NB): a weight fragment is loaded once per k-group and
 // feeds NB MFMA chains.  With the one-tile-at-a-time loop a 64-row batch (the C5 shape) walked the 6 MB of gate weights four times
@@ -232,14 +218,24 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
     const float* wh = p.whh[ch] + (int64_t)arow * H;
     const float* hprev = p.hprev[ch];
     const float* cprev = p.cprev[ch];
-    const int nq1 = (I + 15) >> 4, nq2 = hprev ? ((H + 15) >> 4) : 0;
+    const float* gxp = p.gx[ch];
+    const int nq1 = gxp ? 0 : ((I + 15) >> 4), nq2 = hprev ? ((H + 15) >> 4) : 0;
     // result view: lane = (batch column i, unit_local g), registers r = gates i,f,g,o
     const int ud = u0 + g;
     const bool uv = ud < H;
     float bias[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[r] = uv ? p.bih[ch][r * H + ud] + p.bhh[ch][r * H + ud] : 0.f;
+    for (int r = 0; r < 4; ++r) bias[r] = (uv && !gxp) ? p.bih[ch][r * H + ud] + p.bhh[ch][r * H + ud] : 0.f;
     for (int b0 = 0; b0 < p.B; b0 += 16 * NB) {
+        // hoisted input side: the four gate pre-activations of the (row, unit) this lane finishes below (batch tile = wave), requested before the
+        // recurrent walk so that their round trip runs under it
+        float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gxp && wave < NB) {
+            const int bq = b0 + 16 * wave + i;
+            const float* gr = gxp + (int64_t)(bq < p.B ? bq : p.B - 1) * p.gxstride + (uv ? ud : 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gxv[r] = gr[r * H];
+        }
         const float* xr[NB];
         const float* hr[NB];
         float bm[NB];
@@ -302,7 +298,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
             float g4[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                g4[r] = bias[r] + ((red[0][t][r * 64 + lane] + red[1][t][r * 64 + lane]) + (red[2][t][r * 64 + lane] + red[3][t][r * 64 + lane]));
+                g4[r] = (bias[r] + gxv[r]) + ((red[0][t][r * 64 + lane] + red[1][t][r * 64 + lane]) + (red[2][t][r * 64 + lane] + red[3][t][r * 64 + lane]));
             if (b < p.B && uv) {
                 const int64_t si = (int64_t)b * H + ud;
                 const float c0 = cprev ? cprev[si] : 0.f;
@@ -315,11 +311,188 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same step with the recurrent product on the fp16 matrix cores (two-term split, fp32-class: w = w1 + 2^-11 w2', h = h1 + 2^-11 h2',
+// w.h = w1.h1 + 2^-11 (w1.h2' + w2'.h1), see lstm_fold.hip).  At the session shapes the fp32-MFMA form above is bound by its own matrix
+// work: B = 128 rows x 4 HS x HS per chain and step is 1 024 v_mfma_f32_16x16x4_f32 per workgroup (32 cycles each) in two passes over
+// the weights -- 23.6 us per step, six steps per tail.  Here a k-block of 32 is three 16-cycle MFMAs, W_hh arrives pre-split in lane
+// order (no conversion), h arrives as the term pairs the previous step wrote, and the input side comes from the hoisted GEMM (gx).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+
+// UG unit groups (4 units each) per workgroup: every workgroup reads the WHOLE previous state (B x H term pairs) as its B operand, so with 4
+// units per workgroup (H / 4 workgroups per chain) the state was fetched from L2 128 times per chain and step -- 32 MB per pass at B = 64
+// against 4 MB of weights; a k-block's state fragments now feed UG x 3 MFMAs per batch tile.
+template <int NB, int UG, int CK>
+__global__ __launch_bounds__(256) void lstm_step16_kernel(LstmStepArgs p) {
+    __shared__ float red[4][UG][NB][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int ch = blockIdx.y + p.chain0;
+    const int H = p.H, KB = H >> 5, H8 = H >> 3;
+    const int NUG = H >> 2;                                   // unit groups of the chain
+    const _Float16* hp16 = p.h16prev[ch];
+    const float* cprev = p.cprev[ch];
+    const float* gxp = p.gx[ch];
+    // result view: lane = (batch column i, unit_local g), registers r = gates i,f,g,o
+    const f16x8s* wf = reinterpret_cast<const f16x8s*>(p.whh_frag[ch]) + lane;
+    size_t wbase[UG];
+    int udv[UG];
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+        const int ug = blockIdx.x * UG + u;
+        wbase[u] = (size_t)(ug < NUG ? ug : NUG - 1) * KB * 2 * 64;       // groups past the end (H / 4 not a multiple of UG): clamped, never stored
+        udv[u] = 4 * ug + g;
+    }
+    // epilogue work items: (unit group u, batch tile t) pairs, item e = u * NB + t handled by wave e % 4
+    constexpr int NE = UG * NB, EPW = (NE + 3) / 4;
+    // batch tiles beyond the first 16 NB rows: one workgroup per slab (blockIdx.z) -- the slabs of a step are independent, and a second pass
+    // inside the workgroup was a second serialised round trip to L2
+    for (int b0 = blockIdx.z * 16 * NB; b0 < p.B; b0 += gridDim.z * 16 * NB) {
+        float gxv[EPW][4];
+#pragma unroll
+        for (int k = 0; k < EPW; ++k) {
+            const int e = wave + 4 * k, u = e / NB, t = e % NB;       // (u, t) are compile-time per k only up to the wave offset: plain integer math
+            const int bq = b0 + 16 * t + i;
+            const int ud = 4 * (blockIdx.x * UG + u) + g;
+            const float* gr = gxp + (int64_t)(bq < p.B ? bq : p.B - 1) * p.gxstride + (ud < H ? ud : H - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gxv[k][r] = (e < NE) ? gr[r * H] : 0.f;
+        }
+        f32x4 acc[UG][NB], acx[UG][NB];
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acx[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        if (hp16) {
+            const _Float16* hr[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                const int b = b0 + 16 * t + i;
+                hr[t] = hp16 + ((int64_t)(b < p.B ? b : p.B - 1) * H8 + g) * 16;      // rows past the batch: clamped (their columns are never stored)
+            }
+            for (int q0 = wave; q0 < KB; q0 += 4 * CK) {
+                f16x8s w1[CK][UG], w2[CK][UG], h1[CK][NB], h2[CK][NB];
+#pragma unroll
+                for (int c = 0; c < CK; ++c) {
+                    const int kb = q0 + 4 * c;
+                    const int kc = kb < KB ? kb : 0;             // past the end: re-read block 0, skipped below (wave-uniform)
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) {
+                        w1[c][u] = wf[wbase[u] + (size_t)(kc * 2) * 64];
+                        w2[c][u] = wf[wbase[u] + (size_t)(kc * 2 + 1) * 64];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) {
+                        h1[c][t] = *reinterpret_cast<const f16x8s*>(hr[t] + (int64_t)kc * 64);
+                        h2[c][t] = *reinterpret_cast<const f16x8s*>(hr[t] + (int64_t)kc * 64 + 8);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < CK; ++c) {
+                    if (q0 + 4 * c >= KB) continue;
+#pragma unroll
+                    for (int u = 0; u < UG; ++u)
+#pragma unroll
+                        for (int t = 0; t < NB; ++t) {
+                            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[c][u], h1[c][t], acc[u][t], 0, 0, 0);
+                            acx[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[c][u], h2[c][t], acx[u][t], 0, 0, 0);
+                            acx[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[c][u], h1[c][t], acx[u][t], 0, 0, 0);
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][u][t][r * 64 + lane] = fmaf(acx[u][t][r], 1.0f / 2048.0f, acc[u][t][r]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPW; ++k) {
+            const int e = wave + 4 * k, u = e / NB, t = e % NB;
+            if (e >= NE) break;
+            const int b = b0 + 16 * t + i;
+            const int ud = 4 * (blockIdx.x * UG + u) + g;
+            float g4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                g4[r] = gxv[k][r] + ((red[0][u][t][r * 64 + lane] + red[1][u][t][r * 64 + lane]) + (red[2][u][t][r * 64 + lane] + red[3][u][t][r * 64 + lane]));
+            if (b < p.B && ud < H) {
+                const int64_t si = (int64_t)b * H + ud;
+                const float c0 = cprev ? cprev[si] : 0.f;
+                const float cn = fast_sigmoid(g4[1]) * c0 + fast_sigmoid(g4[0]) * fast_tanh(g4[2]);
+                const float hn = fast_sigmoid(g4[3]) * fast_tanh(cn);
+                p.cnext[ch][si] = cn;
+                p.hnext[ch][si] = hn;
+                const _Float16 a = (_Float16)hn;                 // the next step's B operand: the two fp16 terms
+                _Float16* d = p.h16next[ch] + ((int64_t)b * H8 + (ud >> 3)) * 16 + (ud & 7);
+                d[0] = a;
+                d[8] = (_Float16)((hn - (float)a) * 2048.0f);
+            }
+        }
+        __syncthreads();
+    }
+    (void)udv;
+}
+
+// W_hh [4H, H] -> [H/4 unit groups][H/32 k-blocks][2 terms][64 lanes][8]: lane (i, g) of unit group ug holds k = 32 kb + 8 g .. + 7 of weight row
+// (i & 3) * H + 4 ug + (i >> 2) -- the A fragment of lstm_step16_kernel.  err |= 2 when a weight is outside the split's range (|w| >= 2^15 or NaN).
+__global__ __launch_bounds__(64) void lstm_step_whh_frag_kernel(const float* __restrict__ whh, int H, _Float16* __restrict__ out, int* __restrict__ err) {
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int ug = blockIdx.x, kb = blockIdx.y, KB = H >> 5;
+    const float* wr = whh + ((int64_t)(i & 3) * H + 4 * ug + (i >> 2)) * H + 32 * kb + 8 * g;
+    _Float16* o = out + (((int64_t)ug * KB + kb) * 2 * 64 + lane) * 8;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float w = wr[j];
+        const _Float16 a = (_Float16)w;
+        o[j] = a;
+        o[64 * 8 + j] = (_Float16)((w - (float)a) * 2048.0f);
+        bad |= !(fabsf(w) < 32768.0f);
+    }
+    if (bad && err) atomicOr(err, 2);
+}
+
 int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st) {
     NIR_REQUIRE(a.I % 4 == 0 && a.H % 4 == 0 && a.B >= 0, "lstm_step: I and H must be multiples of 4");
     if (a.B == 0) return 0;
-    ProfScope ps("lstm_step_kernel", st);
     const dim3 grid((unsigned)((a.H + 3) / 4), (unsigned)nchains);
+    bool f16 = a.H % 32 == 0 && !tun(g_tun.exact_f32);
+    for (int c = a.chain0; c < a.chain0 + nchains; ++c)
+        f16 = f16 && a.whh_frag[c] && a.gx[c] && a.h16next[c] && (a.hprev[c] == nullptr || a.h16prev[c] != nullptr);
+    if (f16) {
+        ProfScope ps("lstm_step16_kernel", st);
+        // unit groups per workgroup / batch tiles per workgroup: measured at the session shapes (HS = 512, B = 64 / 128): more, smaller workgroups win --
+        // the step is a latency chain (one L2 round trip, a few dozen MFMAs, an LDS reduction), not a bandwidth problem: UG 1 / 2 / 4 = 12.5 / 13.8 /
+        // 18.4 us per bench step at B = 128.  Tunables lstm_step_ug / lstm_step_nb override (tools, tests).
+        const int ugsel = tun(g_tun.lstm_step_ug), nbsel = tun(g_tun.lstm_step_nb);
+        const int NUG = a.H / 4;
+        int NBv = nbsel ? nbsel : (a.B > 32 ? 4 : (a.B > 16 ? 2 : 1));
+        NBv = NBv >= 4 ? 4 : (NBv >= 2 ? 2 : 1);
+        const int UGv = ugsel == 4 ? 4 : (ugsel == 2 ? 2 : 1);
+        const dim3 gridu((unsigned)((NUG + UGv - 1) / UGv), (unsigned)nchains, (unsigned)((a.B + 16 * NBv - 1) / (16 * NBv)));
+        if (NBv == 4) {
+            if (UGv == 4) hipLaunchKernelGGL((lstm_step16_kernel<4, 4, 2>), gridu, dim3(256), 0, st, a);
+            else if (UGv == 2) hipLaunchKernelGGL((lstm_step16_kernel<4, 2, 4>), gridu, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((lstm_step16_kernel<4, 1, 4>), gridu, dim3(256), 0, st, a);
+        } else if (NBv == 2) {
+            if (UGv >= 2) hipLaunchKernelGGL((lstm_step16_kernel<2, 2, 4>), gridu, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((lstm_step16_kernel<2, 1, 8>), gridu, dim3(256), 0, st, a);
+        } else {
+            if (UGv >= 2) hipLaunchKernelGGL((lstm_step16_kernel<1, 2, 4>), gridu, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((lstm_step16_kernel<1, 1, 8>), gridu, dim3(256), 0, st, a);
+        }
+        NIR_CHECK_LAUNCH("lstm_step16_kernel");
+        return 0;
+    }
+    ProfScope ps("lstm_step_kernel", st);
     if (a.B > 32) hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, st, a);
     else if (a.B > 16) hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, a);
@@ -457,7 +630,7 @@ __global__ void session_cat_states_kernel(const float* a, const float* b2, int r
 }
 
 struct SessPlan {
-    float *epart, *clicks, *Qs, *Ds, *Cq, *Cd, *U, *xcat, *qp, *feats, *y0, *y1, *lin, *cat;
+    float *epart, *clicks, *Qs, *Ds, *Cq, *Cd, *U, *xcat, *qp, *feats, *y0, *y1, *lin, *cat, *gx, *Qs16, *Ds16;
     size_t bytes;
 };
 static SessPlan sess_plan(void* ws, size_t cap, int B, int S, int N, int D, int HS, int nch, bool rank_on, bool want_states) {
@@ -478,6 +651,9 @@ static SessPlan sess_plan(void* ws, size_t cap, int B, int S, int N, int D, int 
     p.y1 = a.take<float>(rank_on ? R * 128 : 0);
     p.lin = a.take<float>(want_states ? (size_t)(S + 1) * B * (HS / 16) : 0);
     p.cat = a.take<float>(want_states ? (size_t)S * B * nch * HS : 0);
+    p.gx = a.take<float>((size_t)nch * BS * 4 * HS);            // input side of the session LSTM gates, every step at once
+    p.Qs16 = a.take<float>((size_t)(S + 1) * B * HS);          // the session states again as fp16 term pairs (4 B per element)
+    p.Ds16 = a.take<float>((size_t)(S + 1) * B * HS);
     p.bytes = align_up(a.off, 256);
     return p;
 }
@@ -485,6 +661,16 @@ static SessPlan sess_plan(void* ws, size_t cap, int B, int S, int N, int D, int 
 static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace nir
+
+extern "C" size_t nir_lstm_step_whh_frag_bytes(int H) { return (H > 0 && H % 32 == 0) ? (size_t)4 * H * H * 2 * sizeof(_Float16) : 0; }
+
+extern "C" int nir_lstm_step_pack_whh_frag(const float* w_hh, int H, void* frag, int* err_flag, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(w_hh && frag && H > 0 && H % 32 == 0, "lstm_step_pack_whh_frag: H must be a positive multiple of 32");
+    hipLaunchKernelGGL(lstm_step_whh_frag_kernel, dim3((unsigned)(H / 4), (unsigned)(H / 32)), dim3(64), 0, (hipStream_t)stream, w_hh, H, (_Float16*)frag, err_flag);
+    NIR_CHECK_LAUNCH("lstm_step_whh_frag_kernel");
+    return 0;
+}
 
 extern "C" size_t nir_cars_session_pack_floats(const nir_cars_session_weights* w, size_t* wrank_floats, size_t* ut_floats) {
     if (!w) return 0;
@@ -599,13 +785,33 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
         a.xstride[0] = a.xstride[1] = (int64_t)S * D;
         a.chain0 = q_on ? 0 : 1;
         a.B = B; a.I = D; a.H = HS;
+        // The chains' inputs -- the pooled query / the click-pooled documents of step t -- are known before the loop: their gate contribution
+        // x W_ih^T + b_ih + b_hh is ONE GEMM per chain over all B*S rows (split-precision matrix-core kernels, M = B*S rows at once) instead of a
+        // K = 256 slice of every sequential step on the fp32 MFMA; the steps then walk W_hh (K = HS) only.
+        {
+            float* gq = p.gx;
+            float* gd = p.gx + (q_on ? BS * 4 * (int64_t)HS : 0);
+            // (inputs are pooled encoder states / softmax-weighted sums of them, inside (-1, 1); bit 3 of rank_bounded: |W_ih| < 2^15 host-checked -> fp16 two-term split)
+            const int bnd = (w->rank_bounded & 8) ? ACT_BOUNDED : 0;
+            if (q_on) NIR_PROPAGATE(launch_linear_ex(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->sq_wih, D, w->sq_bih, w->sq_bhh, gq, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, st));
+            if (d_on) NIR_PROPAGATE(launch_linear_ex(clicks, D, nullptr, nullptr, 0, 0, 0, w->sd_wih, D, w->sd_bih, w->sd_bhh, gd, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, st));
+            a.gx[0] = gq; a.gx[1] = gd;
+            a.gxstride = (int64_t)S * 4 * HS;
+            a.whh_frag[0] = w->sq_whh_frag; a.whh_frag[1] = w->sd_whh_frag;
+        }
+        const float* gx0[2] = {a.gx[0], a.gx[1]};
         const int64_t slot = (int64_t)B * HS;
         for (int t = 0; t < nsteps; ++t) {      // slot 0 = the initial zero state: never read (NULL previous state), never written
+            a.gx[0] = gx0[0] + (int64_t)t * 4 * HS; a.gx[1] = gx0[1] + (int64_t)t * 4 * HS;
             a.x[0] = pooled_q + (int64_t)t * D; a.x[1] = clicks + (int64_t)t * D;
             a.hprev[0] = t ? p.Qs + t * slot : nullptr; a.cprev[0] = t ? p.Cq + t * slot : nullptr;
             a.hprev[1] = t ? p.Ds + t * slot : nullptr; a.cprev[1] = t ? p.Cd + t * slot : nullptr;
             a.hnext[0] = p.Qs + (t + 1) * slot; a.cnext[0] = p.Cq + (t + 1) * slot;
             a.hnext[1] = p.Ds + (t + 1) * slot; a.cnext[1] = p.Cd + (t + 1) * slot;
+            a.h16prev[0] = t ? reinterpret_cast<const _Float16*>(p.Qs16 + t * slot) : nullptr;
+            a.h16prev[1] = t ? reinterpret_cast<const _Float16*>(p.Ds16 + t * slot) : nullptr;
+            a.h16next[0] = reinterpret_cast<_Float16*>(p.Qs16 + (t + 1) * slot);
+            a.h16next[1] = reinterpret_cast<_Float16*>(p.Ds16 + (t + 1) * slot);
             NIR_PROPAGATE(launch_lstm_step(a, nch, st));
         }
     }

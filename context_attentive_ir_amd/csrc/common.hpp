@@ -74,7 +74,7 @@ int batches_in_flight(hipStream_t st);
 // NIR_LSTM_MFMA16, NIR_LSTM_MFMA_S, NIR_LSTM_S, NIR_NO_SKINNY, NIR_NO_GEMM16, NIR_ESM_WAVE_ROWS, NIR_DEBUG, NIR_EXACT_F32);
 // nir_debug_set_tunable changes one at run time (tests, profilers).  Hot entry points only do relaxed atomic loads.
 struct Tunables {
-    std::atomic<int> no_fork, lstm_valu, lstm_mfma16, lstm_mfma_s, lstm_s, lstm_w16, no_skinny, no_gemm16, esm_wave_rows, debug, exact_f32, duet_unfused, attn_unfused, attn_unfused_pipe, duet_rows64, attn_fp32_rows, attn_io_prio;
+    std::atomic<int> no_fork, lstm_valu, lstm_mfma16, lstm_mfma_s, lstm_s, lstm_w16, no_skinny, no_gemm16, esm_wave_rows, debug, exact_f32, duet_unfused, attn_unfused, attn_unfused_pipe, duet_rows64, attn_fp32_rows, attn_io_prio, lstm_step_ug, lstm_step_nb;
 };
 extern Tunables g_tun;
 inline int tun(const std::atomic<int>& a) { return a.load(std::memory_order_relaxed); }
@@ -165,5 +165,34 @@ struct Workspace {
     }
     bool ok() const { return off <= cap; }
 };
+
+// One LSTM time step for up to two independent chains that share (B, I, H) (csrc/cars_session.hip: lstm_step_kernel): the CARS session
+// encoders (cars.py:306-380) and the greedy decoders.  Shared by cars_session.hip and cars_decode.hip.
+struct LstmStepArgs {
+    const float* x[2];        // input rows: row b at x + (xid ? xid[b] : b) * xstride   (xid: embedding gather by token id)
+    const int64_t* xid[2];
+    int64_t xstride[2];
+    const float* wih[2];      // [4H, I]
+    const float* whh[2];      // [4H, H]
+    const float* bih[2];
+    const float* bhh[2];
+    const float* hprev[2];    // [B,H] or NULL (zero state: the recurrent product is skipped)
+    const float* cprev[2];    // [B,H] or NULL
+    float* hnext[2];          // [B,H]
+    float* cnext[2];
+    int chain0;               // blockIdx.y + chain0 = chain id
+    int B, I, H;
+    // gx != NULL: the input side of the gates -- x W_ih^T + b_ih + b_hh, [row b at gx + b * gxstride][4H] -- was computed for ALL time steps by
+    // one batched GEMM in front of the loop (the inputs of the session chains do not depend on the recurrence); the step then walks W_hh only
+    const float* gx[2] = {nullptr, nullptr};
+    int64_t gxstride = 0;
+    // whh_frag != NULL (H % 32 == 0): W_hh pre-split into two fp16 terms in MFMA-fragment order (nir_lstm_step_pack_whh_frag) and the previous
+    // state ALSO kept as fp16 term pairs (h16prev / h16next: [B][H/8][2 terms][8]) -- the recurrent product then runs as three
+    // v_mfma_f32_16x16x32_f16 per 32-wide k-block (fp32-class, like the folded recurrences) instead of eight v_mfma_f32_16x16x4_f32
+    const void* whh_frag[2] = {nullptr, nullptr};
+    const _Float16* h16prev[2] = {nullptr, nullptr};
+    _Float16* h16next[2] = {nullptr, nullptr};
+};
+int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st);
 
 }  // namespace nir

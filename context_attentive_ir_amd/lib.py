@@ -52,6 +52,8 @@ CarsSessionWeights = _struct(
      "sq_inner0_w", "sq_inner0_b", "sq_inner3_w", "sq_inner3_b", "sd_inner0_w", "sd_inner0_b", "sd_inner3_w", "sd_inner3_b",
      "th_w", "th_b", "tc_w", "tc_b"],
     ["D", "HS", "HDEC", "q_on", "d_on", "rank_on", "rank_bounded"])
+CarsSessionWeights = type("nir_cars_session_weights", (C.Structure,), {"_fields_": list(CarsSessionWeights._fields_) + [("sq_whh_frag", C.c_void_p),
+                                                                                                   ("sd_whh_frag", C.c_void_p)]})
 class CarsDecoderWeights(C.Structure):
     _fields_ = [(f, c_fp) for f in ("rnn_wih", "rnn_whh", "rnn_bih", "rnn_bhh", "attn_in_w", "attn_out_w", "dec_attn_w", "pred1_w",
                                     "pred2_w", "sess_w")] + [(f, C.c_int) for f in ("HD", "DQ", "P", "KS")] + [("VT", C.c_int64), ("pred2_frag", C.c_void_p)]
@@ -156,6 +158,8 @@ SIGNATURES = {
     "nir_cars_rank_session_rows": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
                                         c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_fp, _l, C.c_void_p, _i, c_st]),
     "nir_cars_click_max": (_i, [c_fp, _i, _i, _i, C.c_void_p, c_st]),
+    "nir_lstm_step_whh_frag_bytes": (_z, [_i]),
+    "nir_lstm_step_pack_whh_frag": (_i, [c_fp, _i, C.c_void_p, C.c_void_p, c_st]),
 }
 
 DTYPE_F32, DTYPE_BF16 = 0, 1

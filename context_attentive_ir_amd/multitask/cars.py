@@ -204,6 +204,22 @@ class CARS(nn.Module, lib.IdCheck):
                 t.update(th_w=self.transform_hid.linear.weight, th_b=self.transform_hid.linear.bias,
                          tc_w=self.transform_cell.linear.weight, tc_b=self.transform_cell.linear.bias)
             pk = lib.Packed(lib.CarsSessionWeights, t, self._dims)
+            # W_hh of the session LSTMs as fp16 term planes in the step kernel's lane order, once per weight version; a weight outside the
+            # split's range leaves the fragment pointer NULL (fp32-MFMA steps)
+            L = lib.load()
+            HS_ = self._dims["HS"]
+            nb = L.nir_lstm_step_whh_frag_bytes(HS_)
+            for key in ("sq", "sd"):
+                if nb and (key + "_whh") in pk.keep:
+                    dev = pk.keep[key + "_whh"].device
+                    frag, flag = torch.empty(nb, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+                    lib.check(L.nir_lstm_step_pack_whh_frag(lib.ptr(pk.keep[key + "_whh"]), HS_, lib.ptr(frag), lib.ptr(flag), lib.stream()),
+                              "nir_lstm_step_pack_whh_frag")
+                    if int(flag.item()) == 0:
+                        pk.keep[key + "_whh_frag"] = frag
+                        setattr(pk.struct, key + "_whh_frag", frag.data_ptr())
+            b3 = int(all(float(pk.keep[k].abs().max()) < 32768.0 for k in ("sq_wih", "sd_wih") if k in pk.keep))
+            pk.struct.rank_bounded = b3 << 3        # bit 3: the hoisted input projections of the session LSTMs may use the fp16 two-term split
             if not self.no_ranker:      # [W_q | W_shared + W_priv1] and the query-side attention projection, once per version
                 L = lib.load()
                 na, nb = lib.C.c_size_t(0), lib.C.c_size_t(0)
@@ -225,7 +241,7 @@ class CARS(nn.Module, lib.IdCheck):
                 y0 = (qb + 1.0) * float(pk.keep["mo0_w"].abs().sum(1).max()) + float(pk.keep["mo0_b"].abs().max())     # bound of layer 0's outputs
                 b1 = int(b0 and y0 < 32768.0 and float(pk.keep["mo1_w"].abs().max()) < 32768.0)
                 b2 = int("click0_w" in pk.keep and float(pk.keep["click0_w"].abs().max()) < 32768.0)
-                pk.struct.rank_bounded = b0 | (b1 << 1) | (b2 << 2)
+                pk.struct.rank_bounded = b0 | (b1 << 1) | (b2 << 2) | (b3 << 3)
             return pk
         return self._ps.get([p for m in self._session_modules() for p in m.parameters()], build)
 

@@ -346,7 +346,12 @@ typedef struct {
                                                                its inputs (pooled states) lie in (-1,1) -- so the first maxout GEMM may use the fp16
                                                                two-term split (3 MFMAs per product instead of the range-safe 6); bit 1: the same for
                                                                layer 1 (its inputs are bounded by |features| * max_row(sum |W_0|) + |b_0|); bit 2:
-                                                               |click_attn.0 weights| < 2^15 (its inputs are pooled documents in (-1,1)) */
+                                                               |click_attn.0 weights| < 2^15 (its inputs are pooled documents in (-1,1)); bit 3:
+                                                               |sq_wih|, |sd_wih| < 2^15 (inputs of the session LSTMs are pooled states in (-1,1)) */
+    const void *sq_whh_frag, *sd_whh_frag;                  /* optional (NULL: fp32-MFMA session steps): sq_whh / sd_whh pre-split into two fp16 terms in
+                                                               MFMA-fragment order by nir_lstm_step_pack_whh_frag (only when its err flag stayed clear:
+                                                               every |w| < 2^15); the session LSTM steps (cars.py:306-380) then run the recurrent product
+                                                               on the fp16 matrix cores with fp32-class accuracy */
 } nir_cars_session_weights;
 /* Optional suggestion-side outputs of the session loop (cars.py:382-456); any pointer may be NULL. */
 typedef struct {
@@ -356,6 +361,10 @@ typedef struct {
                          order torch.cat(hidden_states[:-1], dim=1) produces in the reference */
     float* dec_c;     /* [(S-1)*B, HDEC] transform_cell(...) */
 } nir_cars_session_outputs;
+/* W_hh [4H, H] of one session LSTM (replaces nothing in the reference: torch.nn.LSTM keeps fp32 weights) -> two fp16 term planes in the lane order
+ * of the session step kernel; H % 32 == 0.  err_flag |= 2 when a weight is outside the split's range (then do not pass the fragment). */
+size_t nir_lstm_step_whh_frag_bytes(int H);
+int nir_lstm_step_pack_whh_frag(const float* w_hh, int H, void* frag, int* err_flag, nir_stream_t stream);
 size_t nir_cars_session_pack_floats(const nir_cars_session_weights* w /*host*/, size_t* wrank_floats /*host*/, size_t* ut_floats /*host*/);
 int nir_cars_session_pack(const nir_cars_session_weights* w /*host*/, float* wrank, float* attn_ut, nir_stream_t stream);
 size_t nir_cars_session_workspace_bytes(int B, int S, int N, const nir_cars_session_weights* w /*host*/);
