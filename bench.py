@@ -487,7 +487,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
 
     # several batches in flight: the library drops its own query/document fork and packs fuller workgroups
     hint = args.in_flight_hint or len(lanes)
-    L.nir_set_batches_in_flight(hint)
+    lib.set_batches_in_flight(hint, lanes)             # per stream: the hint travels with the lane, nothing process-wide is mutated
     lane_of = lambda i: (i % len(batches)) % len(lanes)   # noqa: E731
     torch.cuda.set_stream(lanes[0])
     for i in range(max(2, min(warmup, 3)) * len(lanes)):
@@ -511,7 +511,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             pg.replay()
             torch.cuda.synchronize()
             branches = [torch.cuda.Stream() for _ in range(KSTEP)]
-            L.nir_set_batches_in_flight(KSTEP)
+            lib.set_batches_in_flight(KSTEP, branches + lanes)
 
             def capture_group(first, n):
                 """n consecutive steps (batches first .. first+n-1) as parallel branches of ONE graph; returns (graph, outputs)."""
@@ -554,7 +554,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 torch.cuda.synchronize()
             except Exception:
                 pass
-            L.nir_set_batches_in_flight(len(lanes))
+            lib.set_batches_in_flight(hint, lanes)
     macro_single = (plan is None and not env.multi and not c.get("nofold") and macro_batch(c) > 1
                     and c["model"] in ("cars", "match_tensor", "esm", "drmm", "duet"))
     if (staged and plan.aligned) or macro_single:
@@ -807,7 +807,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             # macro-batched single-GPU path: the latency figure is ONE batch through its own hipGraph, nothing else in flight; and the
             # macro-batched probabilities are checked against that single-batch path
             g1 = torch.cuda.CUDAGraph()
-            L.nir_set_batches_in_flight(1)                 # a lone batch: the library forks its query / document chains onto two streams
+            lib.set_batches_in_flight(1, lanes[:1])        # a lone batch: the library forks its query / document chains onto two streams
             with torch.cuda.stream(lanes[0]):
                 forward(0)
             torch.cuda.synchronize()
@@ -820,7 +820,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     g1.replay()
             torch.cuda.synchronize()
             single_ms = (time.perf_counter() - ts) / ns * 1e3
-            L.nir_set_batches_in_flight(hint)
+            lib.set_batches_in_flight(hint, lanes[:1])
             mg_, mine_, _ = stages["aligned"][(0, stages["KG"])]
             with torch.cuda.stream(lanes[0]):
                 mg_.replay()
@@ -877,13 +877,13 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 torch.cuda.synchronize()
                 h2d_value = pairs_global * nh / (time.perf_counter() - th)
                 h2d_info = {"batches": nh, "seconds": round(time.perf_counter() - th, 3), "wire": "int64 (the reference's LongTensor batch), one pinned buffer per batch"}
-            L.nir_set_batches_in_flight(hint)
+            lib.set_batches_in_flight(hint, lanes)
         except Exception as e:  # pragma: no cover - secondary figure only
             print("[bench] H2D-inclusive figure unavailable: %s: %s" % (type(e).__name__, e), file=sys.stderr)
 
     # ---- profiled pass: HIP events around every kernel of the library, same workload, serial -------------------
     torch.cuda.set_stream(lanes[0])
-    L.nir_set_batches_in_flight(hint)
+    lib.set_batches_in_flight(hint, lanes)
     nprof = max(4, min(steps, 30))
     L.nir_debug_set_tunable(b"no_fork", 1)          # time every kernel in isolation (no query/document stream overlap)
     if rank == 0:
@@ -954,7 +954,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     cpu = None
     if want_cpu and rank == 0 and not env.multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(c, model, batches, lambda: finish(forward(0)), pairs_global, args)
-    L.nir_set_batches_in_flight(1)
+    lib.set_batches_in_flight(0, lanes)
     if rank != 0:
         return None
     tag = "%s, batch=%d%s x %d candidates, q_len=%d, doc_len=%d, emb_dim=300, vocab=%d, %s, full-length %s ids" % (
@@ -1496,7 +1496,7 @@ def decode_record(c, args, env):
         nl = max(1, args.streams)
         batches = make_batches(c, 2 * nl, 0, env.dev)
         lanes = [torch.cuda.Stream() for _ in range(nl)]
-        lib.load().nir_set_batches_in_flight(nl)
+        lib.set_batches_in_flight(nl, lanes)
         for i in range(2 * nl):
             with torch.cuda.stream(lanes[i % nl]):
                 model.predict(batches[i])
@@ -1535,7 +1535,7 @@ def decode_record(c, args, env):
                 graphs[i % len(graphs)][0].replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / (n * mk)
-        lib.load().nir_set_batches_in_flight(1)
+        lib.set_batches_in_flight(0, lanes)
         return {"workload": "headline batch through the full predict: ranking + greedy decode of max_query_len tokens; macro-batches of %d batches "
                             "(Multitask.predict_many(suggest=True)), one hipGraph each, %d in flight" % (mk, nl), "macro_batch": mk,
                 "ms_per_step": round(dt * 1e3, 4), "pairs_per_s": round(pairs / dt, 1), "suggested_queries_per_s": round(c["batch"] * (c["session"] - 1) / dt, 1),

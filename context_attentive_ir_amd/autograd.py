@@ -323,9 +323,33 @@ def _lstm_params(lstm):
 
 
 def bilstm(x, lens, lstm):
-    """RNNEncoder body in train mode for an nn.LSTM(1 layer, batch_first) parameter container -> memory bank."""
+    """RNNEncoder body in train mode for an nn.LSTM(1 layer, batch_first) parameter container -> memory bank [M,T,ND*H], any hidden size:
+    the register-resident training recurrence (_BiLSTM) up to H = 128 per direction; beyond it one unidirectional pass of lstm_seq per
+    direction -- the reverse direction over each sequence's valid part read backwards (packed-sequence semantics: zero past the length;
+    states past a sequence's end never reach a kept output).  Every train-mode caller (MatchTensor, CARS, MNSRF, M_MATCH_TENSOR) goes
+    through here, so a wide encoder trains wherever it evaluates."""
     nd, params = _lstm_params(lstm)
-    return _BiLSTM.apply(x, lens, nd, None, None, *params)[0]
+    H = lstm.hidden_size
+    if H <= 128:
+        return _BiLSTM.apply(x, lens, nd, None, None, *params)[0]
+    M, T, _ = x.shape
+    dev = x.device
+    ln = lens.to(dev).view(M, 1) if lens is not None else torch.full((M, 1), T, device=dev, dtype=torch.int64)
+    pos = torch.arange(T, device=dev).view(1, T)
+    valid = (pos < ln).unsqueeze(2).float()
+
+    class _Dir(object):                                                          # one direction's parameters under the names lstm_seq reads
+        def __init__(self, sfx):
+            for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                setattr(self, n, getattr(lstm, n + sfx))
+    fwd = lstm_seq(x, _Dir(""))[0] * valid
+    if nd == 1:
+        return fwd
+    ridx = (ln - 1 - pos).clamp(min=0)                                             # position read at reverse step t
+    xr = torch.gather(x, 1, ridx.unsqueeze(2).expand(M, T, x.shape[2])) * valid
+    rev = lstm_seq(xr, _Dir("_reverse"))[0] * valid
+    rev = torch.gather(rev, 1, ridx.unsqueeze(2).expand(M, T, H)) * valid            # back to time order
+    return torch.cat((fwd, rev), 2)
 
 
 class _LSTMCell(Function):

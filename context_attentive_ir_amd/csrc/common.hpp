@@ -64,10 +64,10 @@ struct ForkJoin {
 
 // Optional device debug buffer (nir_debug_set_buffer): kernels that support it drop s_memtime stamps there.
 extern unsigned long long* g_debug_buf;
-// Scheduling hint of the caller: how many independent batches it keeps in flight (nir_set_batches_in_flight: process default;
-// nir_set_stream_batches_in_flight: per stream, overrides the default for calls enqueued on that stream).  > 1 -> favour chip
-// throughput over single-call latency.  Reads are lock-free for the default, one mutex-protected map lookup per C-ABI call
-// when per-stream hints exist.
+// Scheduling hint of the caller: how many independent batches it keeps in flight next to the calls it enqueues on THIS stream
+// (nir_set_stream_batches_in_flight; no entry = 1: optimise the latency of the single call).  > 1 -> favour chip throughput.  There is no
+// process-wide setting: callers that share the library cannot steer each other.  Lock-free while no hint exists, else one
+// mutex-protected map lookup per C-ABI call.
 int batches_in_flight(hipStream_t st);
 
 // Tuning / debug switches.  Initialised ONCE from the environment when the library is loaded (NIR_NO_FORK, NIR_LSTM_VALU,

@@ -122,7 +122,6 @@ void ForkJoin::join() {
 
 namespace nir {
 unsigned long long* g_debug_buf = nullptr;
-static std::atomic<int> g_bif_default{1};
 static std::atomic<int> g_bif_streams{0};                 // number of per-stream entries (0 -> skip the map lookup)
 static std::mutex g_bif_mu;
 static std::map<hipStream_t, int> g_bif_map;
@@ -132,7 +131,7 @@ int batches_in_flight(hipStream_t st) {
         auto it = g_bif_map.find(st);
         if (it != g_bif_map.end()) return it->second;
     }
-    return g_bif_default.load(std::memory_order_relaxed);
+    return 1;                                             // no hint for this stream: optimise the latency of the single call
 }
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -143,9 +142,6 @@ Tunables g_tun{{env_flag("NIR_NO_FORK")}, {env_flag("NIR_LSTM_VALU")}, {env_int(
                {env_int("NIR_LSTM_S", 0)}, {env_int("NIR_LSTM_W16", 0)}, {env_flag("NIR_NO_SKINNY")}, {env_flag("NIR_NO_GEMM16")}, {env_flag("NIR_ESM_WAVE_ROWS")},
                {env_flag("NIR_DEBUG")}, {env_flag("NIR_EXACT_F32")}};
 }  // namespace nir
-extern "C" int nir_set_batches_in_flight(int n) {
-    return nir::g_bif_default.exchange(n < 1 ? 1 : n);
-}
 extern "C" int nir_set_stream_batches_in_flight(nir_stream_t stream, int n) {
     std::lock_guard<std::mutex> lk(nir::g_bif_mu);
     if (n < 1) nir::g_bif_map.erase((hipStream_t)stream);

@@ -995,11 +995,14 @@ extern "C" int nir_col2im_rows_f32(const float* drows, int64_t M, int C, int H, 
     using namespace nir;
     NIR_REQUIRE(drows && din && M >= 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0, "col2im_rows: bad args");
     NIR_REQUIRE(2 * ph == kh - 1 && 2 * pw == kw - 1, "col2im_rows: only the 'same' geometry (2 pad = kernel - 1, stride 1)");
-    NIR_REQUIRE(W <= 2048 && kw <= 256 && (size_t)W * kw * 4 <= 64 * 1024, "col2im_rows: W = %d x kw = %d exceeds the LDS slice", W, kw);
+    NIR_REQUIRE(W <= 2048 && kw <= 256, "col2im_rows: W = %d x kw = %d exceeds the LDS slice", W, kw);
     if (M == 0) return 0;
     NIR_REQUIRE(M * H < (int64_t)1 << 31, "col2im_rows: too many rows for one launch");
     int CG = std::min(C, std::min(2048 / W, (16384 / W - 1) / kw));      // outputs per thread <= 8, slice <= 64 KB
     CG = CG < 1 ? 1 : CG;
+    // the slice rows are padded to an odd stride: validate the allocation that is actually requested (an even kw at the limit -- W = 2048,
+    // kw = 8 -- asks for 72 KB although W * kw * 4 is exactly 64 KB)
+    NIR_REQUIRE((size_t)W * (size_t)((CG * kw) | 1) * 4 <= 64 * 1024, "col2im_rows: W = %d x kw = %d exceeds the 64 KB LDS slice", W, kw);
     ProfScope ps("col2im_rows_kernel", (hipStream_t)stream);
     hipLaunchKernelGGL(col2im_rows_kernel, dim3((unsigned)(M * H)), dim3(256), (size_t)W * (CG * kw | 1) * 4, (hipStream_t)stream, drows, C, H, W, kh, kw, ph, pw, CG,
                        din);

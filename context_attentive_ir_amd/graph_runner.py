@@ -227,7 +227,7 @@ class StreamingSessionPredictor(object):
                 ln["replayed"] = [None] * max(1, slots)
             ln["host_np"] = [h.numpy() for h in ln["host"]]
             self.lanes.append(ln)
-        lib.load().nir_set_batches_in_flight(len(self.lanes))      # (returns the value set, not an error code)
+        lib.set_batches_in_flight(len(self.lanes), [ln["stream"] for ln in self.lanes])
 
     # ---- capture -----------------------------------------------------------------------------------------------------
     def _step(self, ln, lay):

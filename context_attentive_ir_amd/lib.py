@@ -73,7 +73,6 @@ SIGNATURES = {
     "nir_last_error_string": (C.c_char_p, []),
     "nir_debug_clock_probe": (_i, [C.c_void_p, _i, _i, C.c_void_p, c_st]),
     "nir_debug_set_buffer": (_i, [C.c_void_p]),
-    "nir_set_batches_in_flight": (_i, [_i]),
     "nir_set_stream_batches_in_flight": (_i, [c_st, _i]),
     "nir_debug_set_tunable": (_i, [C.c_char_p, _i]),
     "nir_profile_enable": (_i, [_i]),
@@ -204,6 +203,14 @@ def ptr(t):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def set_batches_in_flight(n, streams=None):
+    """the library's scheduling hint (nir_set_stream_batches_in_flight) for `streams` (torch streams; default: the current one): n independent
+    batches are kept in flight next to the calls enqueued there; n < 1 removes the entry (= 1)."""
+    L = load()
+    for s in ([torch.cuda.current_stream()] if streams is None else streams):
+        L.nir_set_stream_batches_in_flight(C.c_void_p(s.cuda_stream), int(n))
 
 
 def ids64(t):

@@ -73,28 +73,8 @@ def greedy_decode(owner, states, max_len, src_dict, tgt_dict, batch_size, sessio
 
 
 def bilstm_train(x, lens, lstm):
-    """Train-mode BiLSTM memory bank [M,T,2H] for any hidden size: the register-resident training recurrence (autograd.bilstm) up to H = 128
-    per direction, beyond it two unidirectional passes of autograd.lstm_seq -- the reverse direction over each sequence's valid part read
-    backwards (packed-sequence semantics: zero past the length; states past a sequence's end never reach a kept output)."""
-    H = lstm.hidden_size
-    if H <= 128:
-        return A.bilstm(x, lens, lstm)
-    M, T, _ = x.shape
-    dev = x.device
-    ln = lens.to(dev).view(M, 1) if lens is not None else torch.full((M, 1), T, device=dev, dtype=torch.int64)
-    pos = torch.arange(T, device=dev).view(1, T)
-    valid = (pos < ln).unsqueeze(2).float()
-    ridx = (ln - 1 - pos).clamp(min=0)                                             # position read at reverse step t
-
-    class _Dir(object):                                                          # one direction's parameters under the names lstm_seq reads
-        def __init__(self, sfx):
-            for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
-                setattr(self, n, getattr(lstm, n + sfx))
-    fwd = A.lstm_seq(x, _Dir(""))[0] * valid
-    xr = torch.gather(x, 1, ridx.unsqueeze(2).expand(M, T, x.shape[2])) * valid
-    rev = A.lstm_seq(xr, _Dir("_reverse"))[0] * valid
-    rev = torch.gather(rev, 1, ridx.unsqueeze(2).expand(M, T, H)) * valid            # back to time order
-    return torch.cat((fwd, rev), 2)
+    """Train-mode BiLSTM memory bank [M,T,2H] for any hidden size (autograd.bilstm holds the wide-H form since round 4)."""
+    return A.bilstm(x, lens, lstm)
 
 
 def suggestion_loss(model, h_steps, c_steps, target_rep, target_seq):

@@ -68,7 +68,7 @@ def train_head(mod, q, d, pq, pd):
     feats = []
     for conv in (mod.conv1, mod.conv2, mod.conv3):
         kh, kw = conv.kernel_size
-        if 2 * conv.padding[0] == kh - 1 and 2 * conv.padding[1] == kw - 1 and DL * kw * 4 <= 65536:
+        if 2 * conv.padding[0] == kh - 1 and 2 * conv.padding[1] == kw - 1 and DL * (kw | 1) * 4 <= 65536:      # (the kernel pads its LDS rows to an odd stride)
             rows = A.im2col_rows(T, (kh, kw), conv.padding)                                # [M*QL*DL,(C+1)*kh*kw], one launch (HIP)
         else:
             cols = F.unfold(T, (kh, kw), padding=conv.padding)                             # [M,(C+1)*kh*kw,QL*DL]

@@ -48,31 +48,34 @@ class WrapperBase(object):
         return "\n".join("%-*s %20s %12d" % (w, n, s, c) for n, s, c in rows)
 
     def load_embeddings(self, words, embedding_file):
-        """models/ranker.py:105-150: text embeddings (one token + emsize floats per line, optional count/dim header) for
-        the tokens of `words` present in the source dictionary; duplicates after normalisation are averaged."""
-        emb_layer = self._word_embeddings()
-        words = {w for w in words if w in self.src_dict}
-        logger.info("Loading pre-trained embeddings for %d words from %s" % (len(words), embedding_file))
-        vec_counts, embedding = {}, {}
-        with open(embedding_file) as f:
-            line = f.readline().rstrip().split(" ")
-            if len(line) != 2:
-                f.seek(0)
-            for line in f:
-                parsed = line.rstrip().split(" ")
-                assert len(parsed) == emb_layer.word_vec_size + 1
-                w = self.src_dict.normalize(parsed[0]) if hasattr(self.src_dict, "normalize") else parsed[0]
-                if w in words:
-                    vec = torch.tensor([float(i) for i in parsed[1:]])
-                    if w not in vec_counts:
-                        vec_counts[w], embedding[w] = 1, vec
-                    else:
-                        vec_counts[w] += 1
-                        embedding[w].add_(vec)
-        for w, c in vec_counts.items():
-            embedding[w].div_(c)
-        emb_layer.init_word_vectors(self.src_dict, embedding, self.args.fix_embeddings)
-        logger.info("Loaded %d embeddings (%.2f%%)" % (len(vec_counts), 100.0 * len(vec_counts) / max(len(words), 1)))
+        """Pre-trained vectors for the dictionary tokens in `words` (contract of models/ranker.py:105-150): a text file with one token and
+        emsize floats per line, optionally led by a "count dim" line; a token that occurs several times after dictionary normalisation gets
+        the mean of its vectors; tokens without a vector keep their initialisation."""
+        layer = self._word_embeddings()
+        width = layer.word_vec_size + 1
+        canon = getattr(self.src_dict, "normalize", None) or (lambda tok: tok)
+        wanted = {w for w in words if w in self.src_dict}
+        logger.info("Loading pre-trained embeddings for %d words from %s" % (len(wanted), embedding_file))
+        total, seen = {}, {}
+        with open(embedding_file) as fh:
+            for lineno, line in enumerate(fh):
+                fields = line.rstrip().split(" ")
+                if lineno == 0 and len(fields) == 2:       # header of the word2vec text format
+                    continue
+                if len(fields) != width:
+                    raise AssertionError("%s:%d: expected a token and %d values, got %d fields" % (embedding_file, lineno + 1, width - 1, len(fields)))
+                tok = canon(fields[0])
+                if tok not in wanted:
+                    continue
+                vec = torch.tensor([float(x) for x in fields[1:]])
+                if tok in total:
+                    total[tok] += vec
+                    seen[tok] += 1
+                else:
+                    total[tok], seen[tok] = vec, 1
+        vectors = {tok: v / seen[tok] for tok, v in total.items()}
+        layer.init_word_vectors(self.src_dict, vectors, self.args.fix_embeddings)
+        logger.info("Loaded %d embeddings (%.2f%%)" % (len(vectors), 100.0 * len(vectors) / max(len(wanted), 1)))
 
     def init_optimizer(self, state_dict=None, use_gpu=True):
         """models/ranker.py:152-190: freeze the embedding table when fix_embeddings, build sgd/adam/adamax/adadelta over the

@@ -39,14 +39,12 @@ typedef void* nir_stream_t; /* hipStream_t */
 int nir_version(void);
 const char* nir_last_error_string(void);
 
-/* Scheduling hint (process-wide, default 1): how many independent batches the caller keeps in flight on separate
- * streams.  One MSMARCO-sized batch cannot fill 256 CUs, so with n == 1 the library optimises the latency of a single
- * call (query chain forked onto a side stream, recurrence spread over more, smaller workgroups); with n > 1 other
- * batches fill the idle slots and it optimises chip throughput instead (no internal fork -- every extra stream
- * competes for a hardware queue -- and fuller workgroups).  Results are identical either way.  Returns the old value. */
-int nir_set_batches_in_flight(int n);
-/* The same hint for calls enqueued on ONE stream (overrides the process default for that stream; n < 1 removes the entry), so
- * that independent callers sharing the library do not steer each other. */
+/* Scheduling hint for the calls enqueued on ONE stream (default, no entry: 1): how many independent batches the caller keeps in flight on
+ * separate streams next to this one.  One MSMARCO-sized batch cannot fill 256 CUs, so with n == 1 the library optimises the latency of a
+ * single call (query chain forked onto a side stream, recurrence spread over more, smaller workgroups); with n > 1 other batches fill the
+ * idle slots and it optimises chip throughput instead (no internal fork -- every extra stream competes for a hardware queue -- and fuller
+ * workgroups).  Results are identical either way.  n < 1 removes the entry.  The hint is per stream ONLY (no process-wide default to
+ * mutate): independent callers sharing the library do not steer each other.  Returns 0. */
 int nir_set_stream_batches_in_flight(nir_stream_t stream, int n);
 /* Tuning / debug switches (kernel-family selection, fork on/off, exact f32 MFMA instead of the split-precision GEMM ...).  They
  * are read from the environment ONCE when the library is loaded (NIR_NO_FORK, NIR_LSTM_VALU, NIR_LSTM_MFMA16, NIR_LSTM_MFMA_S,

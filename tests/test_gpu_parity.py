@@ -540,7 +540,7 @@ def test_validate_official_gpu_vs_oracle():
 
 
 def test_batches_in_flight_hint_keeps_results():
-    """nir_set_batches_in_flight only changes scheduling (no internal fork, 4-sequence recurrence layout): MatchTensor and
+    """nir_set_stream_batches_in_flight only changes scheduling (no internal fork, 4-sequence recurrence layout): MatchTensor and
     CARS scores must stay within the parity tolerance of the oracle under either setting and agree with each other."""
     from context_attentive_ir_amd import lib
     L = lib.load()
@@ -551,11 +551,14 @@ def test_batches_in_flight_hint_keeps_results():
     outs = []
     try:
         for n in (1, 4):
-            L.nir_set_batches_in_flight(n)
+            lib.set_batches_in_flight(n)
             outs.append(m(q, ql, d, dl).cpu())
             _close(outs[-1], ref)
+        other = torch.cuda.Stream()                       # the hint belongs to the stream it was set on: another stream is untouched
+        with torch.cuda.stream(other):
+            outs.append(m(q, ql, d, dl).cpu())
     finally:
-        assert L.nir_set_batches_in_flight(1) == 4
+        lib.set_batches_in_flight(0)
     _close(outs[0], outs[1], 2e-6)
 
 
