@@ -37,11 +37,66 @@ def _linear_raw(x2, w, b, act):
     return y
 
 
+class StepScope(object):
+    """Per-training-step state of the operators (opened by the wrappers' _update_body around forward + backward):
+
+    * gradients of PARAMETERS that enter `linear` are accumulated IN PLACE by the weight-gradient kernels -- first use of the step: the "="
+      form (no zero fill), every later use: the "+=" form -- into one persistent buffer per parameter that becomes `p.grad` when the scope
+      closes.  Left to autograd, a weight used at every step of the session / decoder loops produced one gradient tensor per use plus an
+      `add` kernel per pair (a CARS step: ~350 adds, ~140 allocations);
+    * the transposed weight of the data-gradient GEMM (dX = dY W) is formed once per weight and step, not once per use.
+    Nothing here synchronises with the host, so a captured step (wrappers.GraphedUpdate) replays it as is."""
+
+    def __init__(self):
+        self.active = False
+        self.bufs = {}            # id(param) -> (param, persistent gradient buffer)
+        self.touched = {}         # id(param) -> param, in this step
+        self.wt = {}              # (data_ptr, version, shape) -> transposed weight, this step
+
+    def begin(self):
+        self.active, self.touched, self.wt = True, {}, {}
+
+    def grad_buffer(self, p):
+        """-> (buffer, first use in this step?)"""
+        ent = self.bufs.get(id(p))
+        if ent is None or ent[0] is not p or ent[1].shape != p.shape or ent[1].device != p.device:
+            ent = (p, torch.empty_like(p, dtype=torch.float32))
+            self.bufs[id(p)] = ent
+        first = id(p) not in self.touched
+        self.touched[id(p)] = p
+        return ent[1], first
+
+    def abort(self):
+        self.active, self.touched, self.wt = False, {}, {}
+
+    def end(self):
+        """hand the accumulated gradients over: p.grad = buffer (plus whatever autograd itself accumulated for the parameter elsewhere)"""
+        for k, p in self.touched.items():
+            buf = self.bufs[k][1]
+            if p.grad is None:
+                p.grad = buf
+            else:
+                p.grad.add_(buf)
+        self.active, self.touched, self.wt = False, {}, {}
+
+
+STEP = StepScope()
+
+
+def _is_param(t):
+    return isinstance(t, torch.nn.Parameter) and t.requires_grad and t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+
+
 def _transpose(w):
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    if STEP.active and key in STEP.wt:
+        return STEP.wt[key]
     L = lib.load()
     R, Cc = w.shape
     out = torch.empty(Cc, R, device=w.device, dtype=torch.float32)
     lib.check(L.nir_transpose_f32(lib.ptr(w), R, Cc, lib.ptr(out), lib.stream()), "nir_transpose_f32")
+    if STEP.active:
+        STEP.wt[key] = out
     return out
 
 
@@ -61,6 +116,29 @@ def _colsum(dy2, ld, M, N):
     return out
 
 
+def _wgrad_into(p, dy2, lddy, x2, ldx, M, N, K):
+    """dW of parameter p accumulated in its step buffer (STEP.grad_buffer): "=" on first use, "+=" afterwards."""
+    L = lib.load()
+    buf, first = STEP.grad_buffer(p)
+    if M == 0:
+        if first:
+            buf.zero_()
+        return
+    fn = L.nir_linear_wgrad_set_f32 if first else L.nir_linear_wgrad_f32
+    lib.check(fn(lib.ptr(dy2), lddy, lib.ptr(x2), ldx, None, None, 0, lib.ptr(buf), K, M, N, K, lib.stream()), "nir_linear_wgrad")
+
+
+def _colsum_into(p, dy2, ld, M, N):
+    L = lib.load()
+    buf, first = STEP.grad_buffer(p)
+    if M == 0:
+        if first:
+            buf.zero_()
+        return
+    fn = L.nir_colsum_set_f32 if first else L.nir_colsum_f32
+    lib.check(fn(lib.ptr(dy2), ld, M, N, lib.ptr(buf), lib.stream()), "nir_colsum")
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
@@ -70,6 +148,9 @@ class _Linear(Function):
         wc = _f32c(w)
         y = _linear_raw(x2, wc, _f32c(b) if b is not None else None, act)
         ctx.act, ctx.has_b, ctx.shp = act, b is not None, shp
+        # parameters whose gradients this step accumulates in place (StepScope)
+        ctx.wp = w if (STEP.active and _is_param(w)) else None
+        ctx.bp = b if (STEP.active and b is not None and _is_param(b)) else None
         ctx.save_for_backward(x2, wc, y if act else None)
         return y.view(*shp[:-1], wc.shape[0])
 
@@ -88,9 +169,15 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = _linear_raw(d, _transpose(w), None, 0).view(ctx.shp)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(d, N, x2, K, M, N, K)
+            if ctx.wp is not None and STEP.active:
+                _wgrad_into(ctx.wp, d, N, x2, K, M, N, K)           # (returns no tensor: the buffer becomes p.grad when the step scope closes)
+            else:
+                dw = _wgrad(d, N, x2, K, M, N, K)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = _colsum(d, N, M, N)
+            if ctx.bp is not None and STEP.active:
+                _colsum_into(ctx.bp, d, N, M, N)
+            else:
+                db = _colsum(d, N, M, N)
         return dx, dw, db, None
 
 

@@ -469,9 +469,10 @@ class CARS(nn.Module, lib.IdCheck):
     def _proj(self, seq, x):
         return A.linear(A.dropout(x, seq.dropout.p, True), seq.linear.weight, seq.linear.bias)
 
-    def _cell(self, lstm, x, state):
-        g = A.linear(x, lstm.weight_ih_l0, lstm.bias_ih_l0)
-        g = g + (A.linear(state[0], lstm.weight_hh_l0, lstm.bias_hh_l0) if state is not None else lstm.bias_hh_l0)
+    def _cell(self, lstm, gx, state):
+        """one session-LSTM step; gx = x W_ih^T + b_ih of this step (the input side of all steps is ONE linear in front of the loop: the
+        inputs -- pooled queries / click-pooled documents -- do not depend on the recurrence)"""
+        g = gx + (A.linear(state[0], lstm.weight_hh_l0, lstm.bias_hh_l0) if state is not None else lstm.bias_hh_l0)
         return A._LSTMCell.apply(g, state[1] if state is not None else None)
 
     def _forward_train(self, source_rep, source_len, target_rep, target_len, target_seq, document_rep, document_len, document_label):
@@ -501,8 +502,15 @@ class CARS(nn.Module, lib.IdCheck):
         ds = [torch.zeros(B, self.nhid_session_document, device=dev)] if d_on else []
         qstate = dstate = None
         scores, hid, cell, inner_q, inner_d = [], [], [], [], []
+        # per-step views through unbind (ONE stack in the backward instead of a zero-filled [B,S,..] tensor + copy + add per slice)
+        qv_steps = pooled_q.unbind(1)
+        doc_steps = docs.unbind(1) if docs is not None else None
+        sq_rnn = self.session_query_encoder.encoder.rnns[0] if q_on else None
+        sd_rnn = self.session_doc_encoder.encoder.rnns[0] if d_on else None
+        gq_steps = A.linear(pooled_q, sq_rnn.weight_ih_l0, sq_rnn.bias_ih_l0).unbind(1) if q_on else None
+        gd_steps = A.linear(clicks, sd_rnn.weight_ih_l0, sd_rnn.bias_ih_l0).unbind(1) if d_on else None
         for t in range(S):
-            qv = pooled_q[:, t]
+            qv = qv_steps[t]
 
             def attend(states, lin):
                 st = torch.stack(states, 1)
@@ -520,21 +528,21 @@ class CARS(nn.Module, lib.IdCheck):
                     sess = torch.cat(parts, 1)
                     sx = sess.unsqueeze(1).expand(B, N, sess.shape[1]).reshape(B * N, sess.shape[1])
                     qx = qx + self._proj(self.shared_session_projector, sx) + self._proj(self.private_session_projector1, sx)
-                dx = docs[:, t].reshape(B * N, D)
+                dx = doc_steps[t].reshape(B * N, D)
                 x = torch.cat((qx, dx, (qx - dx).abs(), qx * dx), 1)
                 for layer, o, pool in zip(self.ranknet._linear_layers, self.ranknet._output_dims, self.ranknet._pool_sizes):
                     x = A.linear(x, layer.weight, layer.bias).view(B * N, o, pool).max(-1)[0]
                 scores.append(x.view(B, N))
             hparts, cparts = [], []
             if q_on:
-                qstate = self._cell(self.session_query_encoder.encoder.rnns[0], qv, qstate)
+                qstate = self._cell(sq_rnn, gq_steps[t], qstate)
                 qs.append(A.dropout(qstate[0], p, True))
                 hparts.append(qstate[0]); cparts.append(qstate[1])
                 st = torch.stack(qs[1:], 1)
                 w = torch.softmax(self._mlp_logits(self.session_query_inner_attn, st, p), 1)
                 inner_q.append(_wsum(st, w))
             if d_on:
-                dstate = self._cell(self.session_doc_encoder.encoder.rnns[0], clicks[:, t], dstate)
+                dstate = self._cell(sd_rnn, gd_steps[t], dstate)
                 ds.append(A.dropout(dstate[0], p, True))
                 hparts.append(dstate[0]); cparts.append(dstate[1])
                 st = torch.stack(ds[1:], 1)

@@ -264,6 +264,10 @@ class GraphedUpdate(object):
                 with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                     self.seed.add_(1)
                     loss = w._update_body(static)
+                    # keep the VALUES only: a loss that still carried its grad_fn would keep the captured step's autograd graph -- and its
+                    # AccumulateGrad nodes, bound to the capture stream -- alive for as long as this object lives, and a later eager update() on
+                    # another stream would meet them (stream-mismatch warning + synchronisation)
+                    loss = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss.items()} if isinstance(loss, dict) else loss.detach()
             finally:
                 A.DROPOUT.device_seed = None
             self.graphs[key] = (g, static, loss)

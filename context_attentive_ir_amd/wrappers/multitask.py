@@ -231,16 +231,23 @@ class Multitask(WrapperBase):
     def _update_body(self, ex):
         """forward -> losses -> backward -> (gradient averaging) -> clipping -> optimizer step; no host synchronisation, so that
         common.GraphedUpdate can capture it into one hipGraph (gradients must be cleared by the caller)."""
+        from .. import autograd as A
         self.network.train()
-        g = lambda k: self._dev(ex[k])        # noqa: E731
-        loss = self.network(source_rep=g("source_words"), source_len=g("source_lens"), target_rep=g("target_words"),
-                            target_len=g("target_lens"), target_seq=g("target_seq"), document_rep=g("document_words"),
-                            document_len=g("document_lens"), document_label=g("document_labels"))
-        total = (1 - self.args.alpha) * loss["ranking_loss"] + self.args.alpha * loss["suggestion_loss"]
-        if loss.get("regularization") is not None:
-            total = total + loss["regularization"]
-        loss["total_loss"] = total
-        total.backward()
+        A.STEP.begin()                         # in-place accumulation of the parameter gradients of A.linear, transposes once per step
+        try:
+            g = lambda k: self._dev(ex[k])        # noqa: E731
+            loss = self.network(source_rep=g("source_words"), source_len=g("source_lens"), target_rep=g("target_words"),
+                                target_len=g("target_lens"), target_seq=g("target_seq"), document_rep=g("document_words"),
+                                document_len=g("document_lens"), document_label=g("document_labels"))
+            total = (1 - self.args.alpha) * loss["ranking_loss"] + self.args.alpha * loss["suggestion_loss"]
+            if loss.get("regularization") is not None:
+                total = total + loss["regularization"]
+            loss["total_loss"] = total
+            total.backward()
+        except BaseException:
+            A.STEP.abort()
+            raise
+        A.STEP.end()
         self.sync_gradients()                 # multi-rank: average the gradients of all ranks (WrapperBase.sync_gradients)
         torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.args.grad_clipping)
         self.optimizer.step()

@@ -115,12 +115,18 @@ class Ranker(WrapperBase):
         common.GraphedUpdate can capture it into one hipGraph (gradients must be cleared by the caller)."""
         from .. import autograd as A
         self.network.train()
-        q, ql, d, dl = self._inputs(ex)
-        labels = ex["label"].float()
-        labels = labels.cuda(non_blocking=True) if self.use_cuda else labels
-        scores = self.network(q, ql, d, dl)
-        loss = A.bce_with_logits(scores, labels)
-        loss.backward()
+        A.STEP.begin()                         # in-place accumulation of the parameter gradients of A.linear, transposes once per step
+        try:
+            q, ql, d, dl = self._inputs(ex)
+            labels = ex["label"].float()
+            labels = labels.cuda(non_blocking=True) if self.use_cuda else labels
+            scores = self.network(q, ql, d, dl)
+            loss = A.bce_with_logits(scores, labels)
+            loss.backward()
+        except BaseException:
+            A.STEP.abort()
+            raise
+        A.STEP.end()
         self.sync_gradients()                 # multi-rank: average the gradients of all ranks (WrapperBase.sync_gradients)
         torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.args.grad_clipping)
         self.optimizer.step()
