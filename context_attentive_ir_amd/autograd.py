@@ -40,44 +40,73 @@ def _linear_raw(x2, w, b, act):
 class StepScope(object):
     """Per-training-step state of the operators (opened by the wrappers' _update_body around forward + backward):
 
-    * gradients of PARAMETERS that enter `linear` are accumulated IN PLACE by the weight-gradient kernels -- first use of the step: the "="
-      form (no zero fill), every later use: the "+=" form -- into one persistent buffer per parameter that becomes `p.grad` when the scope
-      closes.  Left to autograd, a weight used at every step of the session / decoder loops produced one gradient tensor per use plus an
-      `add` kernel per pair (a CARS step: ~350 adds, ~140 allocations);
+    * gradients of PARAMETERS that enter `linear` are not formed use by use: every use parks its (dY, X) pair, and when the scope closes each
+      parameter gets ONE weight-gradient launch over the row-concatenation of its pairs -- dW = sum_u dY_u^T X_u = [dY_1; dY_2; ..]^T [X_1; X_2; ..]
+      -- and one column sum for its bias, written with the "=" forms (no zero fill) into a persistent buffer that becomes `p.grad`.  Left to
+      autograd, a weight used at every step of the session / decoder loops produced one small launch and one gradient tensor per use plus an
+      `add` kernel per pair (a CARS step: ~140 weight-gradient launches, ~110 column sums, ~350 adds);
     * the transposed weight of the data-gradient GEMM (dX = dY W) is formed once per weight and step, not once per use.
     Nothing here synchronises with the host, so a captured step (wrappers.GraphedUpdate) replays it as is."""
 
     def __init__(self):
         self.active = False
         self.bufs = {}            # id(param) -> (param, persistent gradient buffer)
-        self.touched = {}         # id(param) -> param, in this step
+        self.pend_w = {}          # id(weight) -> (param, [(dY [M,N], X [M,K]), ..]) of this step
+        self.pend_b = {}          # id(bias)   -> (param, [dY, ..])
         self.wt = {}              # (data_ptr, version, shape) -> transposed weight, this step
 
     def begin(self):
-        self.active, self.touched, self.wt = True, {}, {}
+        self.active, self.pend_w, self.pend_b, self.wt = True, {}, {}, {}
+
+    def abort(self):
+        self.active, self.pend_w, self.pend_b, self.wt = False, {}, {}, {}
 
     def grad_buffer(self, p):
-        """-> (buffer, first use in this step?)"""
         ent = self.bufs.get(id(p))
         if ent is None or ent[0] is not p or ent[1].shape != p.shape or ent[1].device != p.device:
             ent = (p, torch.empty_like(p, dtype=torch.float32))
             self.bufs[id(p)] = ent
-        first = id(p) not in self.touched
-        self.touched[id(p)] = p
-        return ent[1], first
+        return ent[1]
 
-    def abort(self):
-        self.active, self.touched, self.wt = False, {}, {}
+    def park_w(self, p, d, x2):
+        self.pend_w.setdefault(id(p), (p, []))[1].append((d, x2))
+
+    def park_b(self, p, d):
+        self.pend_b.setdefault(id(p), (p, []))[1].append(d)
 
     def end(self):
-        """hand the accumulated gradients over: p.grad = buffer (plus whatever autograd itself accumulated for the parameter elsewhere)"""
-        for k, p in self.touched.items():
-            buf = self.bufs[k][1]
+        """one weight-gradient launch / one column sum per parameter, then p.grad = buffer (plus whatever autograd itself accumulated for the
+        parameter elsewhere, e.g. a norm regulariser)"""
+        L = lib.load()
+        done = []
+        for p, pairs in self.pend_w.values():
+            pairs = [(d, x) for d, x in pairs if d.shape[0]]
+            buf = self.grad_buffer(p)
+            N, K = p.shape
+            if not pairs:
+                buf.zero_()
+            else:
+                d = pairs[0][0] if len(pairs) == 1 else torch.cat([a for a, _ in pairs], 0)
+                x = pairs[0][1] if len(pairs) == 1 else torch.cat([b for _, b in pairs], 0)
+                lib.check(L.nir_linear_wgrad_set_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, d.shape[0], N, K, lib.stream()),
+                          "nir_linear_wgrad_set_f32")
+            done.append((p, buf))
+        for p, ds in self.pend_b.values():
+            ds = [d for d in ds if d.shape[0]]
+            buf = self.grad_buffer(p)
+            N = p.shape[0]
+            if not ds:
+                buf.zero_()
+            else:
+                d = ds[0] if len(ds) == 1 else torch.cat(ds, 0)
+                lib.check(L.nir_colsum_set_f32(lib.ptr(d), N, d.shape[0], N, lib.ptr(buf), lib.stream()), "nir_colsum_set_f32")
+            done.append((p, buf))
+        for p, buf in done:
             if p.grad is None:
                 p.grad = buf
             else:
                 p.grad.add_(buf)
-        self.active, self.touched, self.wt = False, {}, {}
+        self.abort()
 
 
 STEP = StepScope()
@@ -116,29 +145,6 @@ def _colsum(dy2, ld, M, N):
     return out
 
 
-def _wgrad_into(p, dy2, lddy, x2, ldx, M, N, K):
-    """dW of parameter p accumulated in its step buffer (STEP.grad_buffer): "=" on first use, "+=" afterwards."""
-    L = lib.load()
-    buf, first = STEP.grad_buffer(p)
-    if M == 0:
-        if first:
-            buf.zero_()
-        return
-    fn = L.nir_linear_wgrad_set_f32 if first else L.nir_linear_wgrad_f32
-    lib.check(fn(lib.ptr(dy2), lddy, lib.ptr(x2), ldx, None, None, 0, lib.ptr(buf), K, M, N, K, lib.stream()), "nir_linear_wgrad")
-
-
-def _colsum_into(p, dy2, ld, M, N):
-    L = lib.load()
-    buf, first = STEP.grad_buffer(p)
-    if M == 0:
-        if first:
-            buf.zero_()
-        return
-    fn = L.nir_colsum_set_f32 if first else L.nir_colsum_f32
-    lib.check(fn(lib.ptr(dy2), ld, M, N, lib.ptr(buf), lib.stream()), "nir_colsum")
-
-
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
@@ -170,12 +176,12 @@ class _Linear(Function):
             dx = _linear_raw(d, _transpose(w), None, 0).view(ctx.shp)
         if ctx.needs_input_grad[1]:
             if ctx.wp is not None and STEP.active:
-                _wgrad_into(ctx.wp, d, N, x2, K, M, N, K)           # (returns no tensor: the buffer becomes p.grad when the step scope closes)
+                STEP.park_w(ctx.wp, d, x2)                         # (no tensor returned: formed with the parameter's other uses when the step scope closes)
             else:
                 dw = _wgrad(d, N, x2, K, M, N, K)
         if ctx.has_b and ctx.needs_input_grad[2]:
             if ctx.bp is not None and STEP.active:
-                _colsum_into(ctx.bp, d, N, M, N)
+                STEP.park_b(ctx.bp, d)
             else:
                 db = _colsum(d, N, M, N)
         return dx, dw, db, None
