@@ -555,7 +555,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             except Exception:
                 pass
             lib.set_batches_in_flight(hint, lanes)
-    macro_single = (plan is None and not env.multi and not c.get("nofold") and macro_batch(c) > 1
+    macro_single = (plan is None and (not env.multi or not sharded) and not c.get("nofold") and macro_batch(c) > 1
                     and c["model"] in ("cars", "match_tensor", "esm", "drmm", "duet"))
     if (staged and plan.aligned) or macro_single:
         try:
@@ -1222,12 +1222,16 @@ def run_records(args, env):
         torch.cuda.empty_cache()
         sub["train_C3_cars_update"] = train_record("CARS", dict(head), args, env)
         sub["train_C2_match_tensor_update"] = train_record("MATCH_TENSOR", dict(CONFIGS["C2_match_tensor"]), args, env)
-    if head["model"] == "cars" and full and env.multi and env.world > 1:
-        ax = rec.get("shard_axis") if rec else None
+    eff_world = int(os.environ.get("BENCH_EMULATE_WORLD", env.world)) if env.multi else 1      # (emulation: one process times rank 0's share of W)
+    if head["model"] == "cars" and full and env.multi and eff_world > 1:
+        # the SAME record on the other CARS shard axis (rank 0 holds its own axis name, every rank takes part) and -- when the per-rank macro-batch policy
+        # gives another count than N = 1 gets -- with the N = 1 count (KG-matched)
+        ax = "pair" if (os.environ.get("BENCH_SHARD_AXIS", "auto") in ("auto", "pair") and head["batch"] % eff_world == 0) else "candidate"
         other = "candidate" if ax == "pair" else "pair"
-        if other == "candidate" or head["batch"] % env.world == 0:
+        if other == "candidate" or head["batch"] % eff_world == 0:
             attempt(hname + "_axis_" + other, lambda: run_config(hname + "_axis_" + other, head, args, env, args.steps, min(args.warmup, 8), shard=True, axis=other))
-        attempt(hname + "_kg_matched", lambda: run_config(hname + "_kg_matched", head, args, env, args.steps, min(args.warmup, 8), shard=True, kg=macro_batch(head)))
+        if macro_batch(head) != macro_batch(head, "BENCH_GATHER_EVERY", eff_world):
+            attempt(hname + "_kg_matched", lambda: run_config(hname + "_kg_matched", head, args, env, args.steps, min(args.warmup, 8), shard=True, kg=macro_batch(head)))
     if head["model"] == "cars" and full and not os.environ.get("BENCH_NO_STREAM"):
         secs = float(os.environ.get("BENCH_H2D_SECONDS", "5"))
         attempt("C5_stream", lambda: stream_record(args, env, seconds=secs, mode="batch" if env.multi else None))
