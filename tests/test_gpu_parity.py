@@ -41,7 +41,10 @@ def _synth(rng, B, N, QL, DL, V, full=False):
                                        # large enough for the split-precision (3 x bf16) kernel: ragged M/N/K tails included
                                        (13000, 300, 900, 1), (71680, 256, 256, 0), (12289, 129, 36, 2), (40000, 1024, 300, 0),
                                        # mid-size: the 32x32-block exact-fp32 kernel (CARS maxout shapes; ragged M / N tails)
-                                       (1120, 512, 1024, 0), (1101, 250, 256, 1), (999, 300, 64, 2)])
+                                       (1120, 512, 1024, 0), (1101, 250, 256, 1), (999, 300, 64, 2),
+                                       # small grids of the split-precision kernel (96 .. 511 tiles of 128 x 128): KS k-tiles per pipeline stage, ragged
+                                       # M / N tails, K not a multiple of the stage (136 = 2 x 64 + 8), K = one stage + tail
+                                       (896, 2048, 256, 0), (8960, 256, 256, 1), (1500, 1100, 136, 2), (8960, 512, 1024, 0), (2000, 900, 132, 0)])
 def test_linear_dense(M, N, K, act):
     from context_attentive_ir_amd import lib
     g = torch.Generator().manual_seed(M * 1000 + N)
