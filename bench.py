@@ -951,6 +951,25 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             if fpp:
                 roofline["step_alg_TFLOPs_ref_ops"] = round(value * fpp / 1e12 / (world if env.multi and not sharded else 1), 2)
 
+    # the wrapper's DEFAULT settings next to the tuned ones: Multitask.predict / Ranker.predict eagerly on one stream with
+    # id_check_interval = 1 (two blocking flag read-backs per call: the reference's IndexError at the offending call) and with 0 (deferred)
+    eager_default = None
+    if want_cpu and rank == 0 and not env.multi:
+        eager_default = {}
+        lib.set_batches_in_flight(1, lanes[:1])
+        for iv in (1, 0):
+            model.id_check_interval = iv
+            call = (lambda: model.predict(batches[0], suggest=False)) if is_sess else (lambda: model.predict(batches[0]))
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for _ in range(20):
+                call()
+            torch.cuda.synchronize()
+            eager_default["id_check_interval_%d_ms_per_call" % iv] = round((time.perf_counter() - te) / 20 * 1e3, 4)
+        model.id_check_interval = 0
+        lib.set_batches_in_flight(hint, lanes[:1])
     cpu = None
     if want_cpu and rank == 0 and not env.multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(c, model, batches, lambda: finish(forward(0)), pairs_global, args)
@@ -995,7 +1014,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             "macro_batch": (stages["KG"] if (stages is not None and "aligned" in stages) else 1), "lanes": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
             "h2d_inclusive_over_resident": None if h2d_value is None else round(h2d_value / value, 4), "h2d_stream": h2d_info,
-            "dtype": c.get("dtype", "f32"), "precompute": pre, "roofline": roofline, "cpu_baseline": cpu}
+            "dtype": c.get("dtype", "f32"), "precompute": pre, "wrapper_predict_eager_one_stream": eager_default, "roofline": roofline, "cpu_baseline": cpu}
 
 
 def cpu_baseline(c, model, batches, gpu_step, pairs, args):

@@ -338,6 +338,37 @@ def test_ranker_predict_and_map_parity():
             O.mean_average_precision(rank_candidates(ref.numpy()), ex["label"].numpy()), abs=1e-12), kind
 
 
+def test_drmm_map_on_overlapping_zipf_ids_is_bounded():
+    """DRMM where its exact-match signal lives (Zipf ids: queries and documents share tokens).  The top two histogram bins are not reproducible
+    at an exact overlap (cos = 1 +- 1 ulp), so MAP is not asserted equal but BOUNDED: |MAP_hip - MAP_oracle| <= 0.03 for
+    both exact-match policies on a 16 x 50 x 290 slice (measured: +0.0117 default, -0.0015 'snap'; random-weight model, the worst case for
+    near-ties), and the predict softmax agrees with the oracle on every pair whose histogram does."""
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.eval import MAP, rank_candidates
+    from context_attentive_ir_amd.wrappers import Ranker
+    V, B, N, QL, DL = 100000, 16, 50, 4, 290
+    ex = synth.ranker_batch(B, N, QL, DL, V, seed=1013, full_length=False)
+    r = Ranker(default_args("DRMM", src_vocab_size=V)); fill_module_(r.network, 1013); r.cuda()
+    sd = {k: v.detach().cpu() for k, v in r.network.state_dict().items()}
+    gate, _, hist_ref = O.drmm_parts(sd, ex["que_rep"], ex["doc_rep"])
+    s_ref = O.drmm_scores_from_hist(sd, gate, hist_ref, B, N)
+    ref = O.predict_softmax(s_ref)
+    map_ref = MAP(rank_candidates(ref.numpy()), ex["label"].numpy())
+    overlaps = int(((ex["que_rep"][:, None, :, None] == ex["doc_rep"][:, :, None, :]) & (ex["que_rep"][:, None, :, None] != 0)).sum())
+    assert overlaps > 50
+    for policy in ("numpy", "snap"):
+        r.network.exact_match_policy = policy
+        got = r.predict(ex).cpu()
+        assert abs(MAP(rank_candidates(got.numpy()), ex["label"].numpy()) - map_ref) <= 0.03, policy
+        _, h = r.network(ex["que_rep"].cuda(), ex["que_len"].cuda(), ex["doc_rep"].cuda(), ex["doc_len"].cuda(), return_hist=True)
+        same = (h.cpu().numpy() == hist_ref.numpy()).all(axis=(1, 2)).reshape(B, N)
+        rows = same.all(1)                                      # queries all of whose candidates have the oracle's histogram: softmax must agree
+        if rows.any():
+            _close(got[rows], ref[rows])
+
+
 def test_multitask_predict_map_parity():
     from context_attentive_ir_amd import synth
     from context_attentive_ir_amd.config import default_args
