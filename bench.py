@@ -583,7 +583,9 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     # host-fed stream's collator produces): the replayed graph holds the library's kernels only, no torch.cat / copy launches
                     exs = [batches[(KG * gb + j) % nb] for j in range(k)]
                     keys = ("source_words", "source_lens", "document_words", "document_lens", "document_labels") if is_sess else ("que_rep", "que_len", "doc_rep", "doc_len")
-                    mb = {key: (torch.cat([e[key] for e in exs]).contiguous() if k > 1 else exs[0][key]) for key in keys}
+                    with torch.cuda.stream(ln):               # (on the lane that reads it: a remainder group is built while other lanes' graphs run)
+                        mb = {key: (torch.cat([e[key] for e in exs]).contiguous() if k > 1 else exs[0][key]) for key in keys}
+                    ln.synchronize()
                     macro_inputs[(gb, k)] = mb
 
                     def body1():
