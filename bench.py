@@ -315,7 +315,9 @@ class Env(object):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if self.backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+                import datetime      # (a rank that died takes the others down after 5 minutes, not after the default 10 + the driver's own limit)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev,
+                                        timeout=datetime.timedelta(seconds=int(os.environ.get("BENCH_PG_TIMEOUT_S", "300"))))
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
             self.dist = dist
@@ -1205,6 +1207,10 @@ def run_records(args, env):
         head.setdefault("session", 7)
     hname = args.config if not adhoc else "adhoc_" + head["model"]
     rec = run_config(hname, head, args, env, args.steps, args.warmup, shard=True, want_cpu=True, with_h2d=True)
+    if env.multi and env.world > 1 and env.rank == 0:
+        # N > 1: a rank that fails inside a sub-record must take the job down (the others would hang in its collectives) -- so the headline is
+        # printed NOW as a complete record of its own; the final line (with the sub-records) supersedes it as the last line of stdout
+        print(compose_line(args, env, rec, {}, None), flush=True)
 
     sub = {}
 
@@ -1263,31 +1269,33 @@ def run_records(args, env):
         r = run_config(hname + "_weak", head, args, env, max(20, args.steps // 4), min(args.warmup, 8), shard=False)
         weak = r["pairs_per_s"] if r else None
 
-    result_line = None
-    if env.rank == 0:
-        roof = rec.pop("roofline") or {}
-        cpu = rec.pop("cpu_baseline")
-        pre = rec.get("precompute") or {}
-        detail = {"headline": dict(rec, roofline=roof, cpu_baseline=cpu), "sub": sub, "weak_scaling_pairs_per_s": weak,
-                  "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "argv": sys.argv[1:]}
-        where = write_detail(detail)
-        # ---- the record the driver parses: ONE compact line (every sub-record once, four scalars each); the full records are in `detail` ----
-        cfg = {"name": rec["name"], "workload": rec["workload"], "macro_batch": rec["macro_batch"], "lanes": rec["lanes"],
-               "batches_in_flight": rec["batches_in_flight"], "ms_per_step_one_batch_in_flight": rec["ms_per_step_one_batch_in_flight"],
-               "hipgraph": rec["hipgraph"], "parallelism": rec["parallelism"][:400], "shard_axis": rec.get("shard_axis"), "world_size": rec["world_size"],
-               "pairs_per_s_with_host_ids_h2d": rec["pairs_per_s_with_host_ids_h2d"], "weak_scaling_pairs_per_s": weak, "detail": where}
-        small = {k: roof.get(k) for k in ROOF_KEYS}
-        small["precompute_fold_ms"], small["precompute_fold_bytes"] = pre.get("fold_ms"), pre.get("fold_bytes")
-        if cpu:
-            cpu = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model", "host_logical_cores", "max_abs_diff_vs_gpu_softmax")}
-            cpu["sample"] = "%.0f s of the same workload through oracle/neuroir_cpu.py (torch CPU, best of 8/16/32/64 threads)" % args.cpu_seconds
-        line = {"metric": "ranked (query,doc) pairs/sec", "value": rec["pairs_per_s"], "unit": "pairs/s", "n_gpus": env.seen,
-                "steps": args.steps, "warmup": args.warmup, "reps": rec["reps"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
-                # the global batch is FIXED as N grows (every rank scores its share of the same batch): strong scaling at every N
-                "scaling": "strong", "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
-                "config": cfg, "roofline": small, "cpu_baseline": cpu, "sub": [short_sub(n, r) for n, r in sub.items()]}
-        result_line = json.dumps(line, separators=(",", ":"))
-    return result_line
+    return compose_line(args, env, rec, sub, weak) if env.rank == 0 else None
+
+
+def compose_line(args, env, rec, sub, weak):
+    """detail file + the ONE compact line the driver parses (every sub-record once, four scalars each; the full records are in `detail`)"""
+    rec = dict(rec)
+    roof = rec.pop("roofline") or {}
+    cpu = rec.pop("cpu_baseline")
+    pre = rec.get("precompute") or {}
+    detail = {"headline": dict(rec, roofline=roof, cpu_baseline=cpu), "sub": sub, "weak_scaling_pairs_per_s": weak,
+              "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "argv": sys.argv[1:]}
+    where = write_detail(detail)
+    cfg = {"name": rec["name"], "workload": rec["workload"], "macro_batch": rec["macro_batch"], "lanes": rec["lanes"],
+           "batches_in_flight": rec["batches_in_flight"], "ms_per_step_one_batch_in_flight": rec["ms_per_step_one_batch_in_flight"],
+           "hipgraph": rec["hipgraph"], "parallelism": rec["parallelism"][:400], "shard_axis": rec.get("shard_axis"), "world_size": rec["world_size"],
+           "pairs_per_s_with_host_ids_h2d": rec["pairs_per_s_with_host_ids_h2d"], "weak_scaling_pairs_per_s": weak, "detail": where}
+    small = {k: roof.get(k) for k in ROOF_KEYS}
+    small["precompute_fold_ms"], small["precompute_fold_bytes"] = pre.get("fold_ms"), pre.get("fold_bytes")
+    if cpu:
+        cpu = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model", "host_logical_cores", "max_abs_diff_vs_gpu_softmax")}
+        cpu["sample"] = "%.0f s of the same workload through oracle/neuroir_cpu.py (torch CPU, best of 8/16/32/64 threads)" % args.cpu_seconds
+    line = {"metric": "ranked (query,doc) pairs/sec", "value": rec["pairs_per_s"], "unit": "pairs/s", "n_gpus": env.seen,
+            "steps": args.steps, "warmup": args.warmup, "reps": rec["reps"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+            # the global batch is FIXED as N grows (every rank scores its share of the same batch): strong scaling at every N
+            "scaling": "strong", "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
+            "config": cfg, "roofline": small, "cpu_baseline": cpu, "sub": [short_sub(n, r) for n, r in sub.items()]}
+    return json.dumps(line, separators=(",", ":"))
 
 
 def write_detail(obj):
