@@ -557,7 +557,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             except Exception:
                 pass
             lib.set_batches_in_flight(hint, lanes)
-    macro_single = (plan is None and (not env.multi or not sharded) and not c.get("nofold") and macro_batch(c) > 1
+    macro_single = (plan is None and (not env.multi or not sharded) and macro_batch(c) > 1
                     and c["model"] in ("cars", "match_tensor", "esm", "drmm", "duet"))
     if (staged and plan.aligned) or macro_single:
         try:

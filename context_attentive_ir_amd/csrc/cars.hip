@@ -33,6 +33,8 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
                            int T, float* pooled, int one_term, hipStream_t st, int in_f16 = 0);
 bool attn_pool_pipe_selected(int64_t M, int T);
 bool bilstm_folded_split_out_ok(int pt_dtype, int H, int T);
+int launch_fold_permute(const float* w_ih, const float* b_ih, const float* b_hh, int H, int ndir, int E, float* wperm, float* bperm, int64_t* iota, int64_t niota,
+                        hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------------
 // attention pooling: one wave per sequence; logits [M,T], h [M,T,D] (D % 4 == 0, D <= 1024)
@@ -114,16 +116,20 @@ __global__ __launch_bounds__(256) void attn_pool2_kernel(const float* __restrict
 }
 
 struct EncPlan {
-    float *gates, *enc, *a1, *logit;
+    float *gates, *enc, *a1, *logit, *wperm, *bperm;
+    int64_t* iota;
     size_t bytes;
 };
-static EncPlan enc_plan(void* ws, size_t cap, int64_t M, int T, int H) {
+static EncPlan enc_plan(void* ws, size_t cap, int64_t M, int T, int H, int E) {
     Workspace a(ws, cap);
     EncPlan p;
     p.gates = a.take<float>((size_t)M * T * 8 * H);
     p.enc = a.take<float>((size_t)M * T * 2 * H);
     p.a1 = a.take<float>((size_t)M * T * 2 * H);
     p.logit = a.take<float>((size_t)M * T);
+    p.wperm = a.take<float>((size_t)8 * H * E);
+    p.bperm = a.take<float>((size_t)8 * H);
+    p.iota = a.take<int64_t>((size_t)M * T);
     p.bytes = align_up(a.off, 256);
     return p;
 }
@@ -132,7 +138,7 @@ static EncPlan enc_plan(void* ws, size_t cap, int64_t M, int T, int H) {
 
 extern "C" size_t nir_cars_encode_workspace_bytes(int64_t M, int T, int E, const nir_cars_encoder_weights* w) {
     if (!w || M < 0 || T <= 0) return 0;
-    return nir::enc_plan(nullptr, 0, M, T, w->H).bytes;
+    return nir::enc_plan(nullptr, 0, M, T, w->H, E).bytes;
 }
 
 extern "C" int nir_cars_encode(const int64_t* ids, const int64_t* lens, int64_t M, int T, const float* table, int64_t V,
@@ -145,12 +151,38 @@ extern "C" int nir_cars_encode(const int64_t* ids, const int64_t* lens, int64_t 
     NIR_REQUIRE(nir_bilstm_supported(w->H) && (2 * w->H) % 4 == 0, "cars_encode: hidden size %d unsupported", w->H);
     if (M == 0) return 0;
     const int H = w->H, D = 2 * H;
-    EncPlan p = enc_plan(workspace, workspace_bytes, M, T, H);
+    EncPlan p = enc_plan(workspace, workspace_bytes, M, T, H, E);
     if (!workspace || p.bytes > workspace_bytes) {
         set_error("cars_encode: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
         return NIR_ERR_WORKSPACE;
     }
     float* enc = encoded ? encoded : p.enc;
+    // Round 4: the per-batch form shares the recurrence and the attention pooling of the folded form.  The gather-GEMM writes the gate
+    // pre-activations of THIS batch in the folded table's row layout ([dir][unit][gate]: W_ih permuted on the fly, 8H x E elements), and that
+    // [M*T, 8H] tensor is handed to the folded recurrence as a "table" of M*T rows with the row number as token id -- same kernels
+    // (fp16-split MFMA recurrence with the pre-split W_hh, term pairs to the fused attention pipeline) instead of the round-1 recurrence
+    // (347 us per 1 120 documents against 75) and the three-launch attention.  What remains of the per-batch cost is the gather-GEMM itself.
+    if (H >= 32 && (2 * H) % 64 == 0 && H <= 128 && M * T < ((int64_t)1 << 31) && !tun(g_tun.exact_f32) && !tun(g_tun.nofold_old)) {
+        NIR_PROPAGATE(launch_fold_permute(w->wih, w->bih, w->bhh, H, 2, E, p.wperm, p.bperm, p.iota, M * T, st));
+        // (bit 1 of `bounded`: |table|, |W_ih| < 2^15 host-checked -> the gather-GEMM takes the fp16 two-term split, 3 MFMAs per product instead of 6)
+        NIR_PROPAGATE(launch_linear_ex(nullptr, 0, ids, table, E, 1, 1, p.wperm, E, p.bperm, nullptr, p.gates, 8 * H, M * T, 8 * H, E,
+                                       NIR_ACT_NONE | ((w->bounded & 2) ? ACT_BOUNDED : 0), nullptr, 0, st));
+        const bool fused_attn = w->attn_frag && (w->bounded & 1) && attn_pool_fused_usable(D, T) && !tun(g_tun.attn_unfused);
+        const bool inside = fused_attn && !encoded && attn_pool_pipe_selected(M, T);
+        const int enc16 = inside && bilstm_folded_split_out_ok(NIR_DTYPE_F32, H, T) && !tun(g_tun.attn_fp32_rows) ? 2 : 0;
+        NIR_PROPAGATE(launch_bilstm_folded(p.gates, NIR_DTYPE_F32, p.iota, lens, w->whh, enc, nullptr, M, M * T, T, H, 2, st, enc16, w->whh_frag));
+        if (fused_attn)
+            return launch_attn_pool_fused(enc, w->attn_frag, w->attn0_b, w->attn3_w, w->attn3_b, lens, M, T, pooled, 0, st, enc16);
+        const int NP = D / 16;
+        NIR_PROPAGATE(launch_linear_ex(enc, D, nullptr, nullptr, 0, 0, 0, w->attn0_w, D, w->attn0_b, nullptr, p.a1, NP, M * T, D, D,
+                                       ACT_TANH_ROWDOT16 | ((w->bounded & 1) ? ACT_BOUNDED : 0), w->attn3_w, 0, st));
+        {
+            ProfScope ps("attn_pool2_kernel", st);
+            hipLaunchKernelGGL(attn_pool2_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), (size_t)4 * T * 4, st, enc, p.a1, NP, w->attn3_b, lens, M, T, D, pooled);
+        }
+        NIR_CHECK_LAUNCH("attn_pool2_kernel");
+        return 0;
+    }
     NIR_PROPAGATE(launch_linear(nullptr, 0, ids, table, E, 1, 1, w->wih, E, w->bih, w->bhh, p.gates, 8 * H, M * T, 8 * H, E, NIR_ACT_NONE, st));
     NIR_PROPAGATE(launch_bilstm(p.gates, lens, w->whh, nullptr, nullptr, enc, nullptr, nullptr, M, T, H, 2, st));
     NIR_PROPAGATE(launch_linear(enc, D, nullptr, nullptr, 0, 0, 0, w->attn0_w, D, w->attn0_b, nullptr, p.a1, D, M * T, D, D, NIR_ACT_TANH, st));
@@ -198,7 +230,7 @@ extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, i
         return NIR_ERR_WORKSPACE;
     }
     float* enc = encoded ? encoded : p.enc;
-    const bool fused_attn = w->attn_frag && w->bounded && attn_pool_fused_usable(D, T) && !tun(g_tun.attn_unfused) && !tun(g_tun.exact_f32);
+    const bool fused_attn = w->attn_frag && (w->bounded & 1) && attn_pool_fused_usable(D, T) && !tun(g_tun.attn_unfused) && !tun(g_tun.exact_f32);
     // bf16 encoder whose per-token states stay inside this call and go to the attention pipeline: they travel as fp16 (the pipeline
     // takes single fp16 terms from a bf16 encoder anyway) -- half the bytes written by the recurrence and read by the pooling
     // fp32-accurate encoder in the same situation: the recurrence already forms the two fp16 terms of every h_t for its own next step and
@@ -212,7 +244,7 @@ extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, i
     if (fused_attn)
         return launch_attn_pool_fused(enc, w->attn_frag, w->attn0_b, w->attn3_w, w->attn3_b, lens, M, T, pooled, dtype == NIR_DTYPE_BF16, st, enc16);
     NIR_PROPAGATE(launch_linear_ex(enc, D, nullptr, nullptr, 0, 0, 0, w->attn0_w, D, w->attn0_b, nullptr, p.lpart, NP, M * T, D, D,
-                                   ACT_TANH_ROWDOT16 | (w->bounded ? ACT_BOUNDED : 0), w->attn3_w, 0, st));
+                                   ACT_TANH_ROWDOT16 | ((w->bounded & 1) ? ACT_BOUNDED : 0), w->attn3_w, 0, st));
     {
         ProfScope ps("attn_pool2_kernel", st);
         hipLaunchKernelGGL(attn_pool2_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), (size_t)4 * T * 4, st, enc, p.lpart, NP,

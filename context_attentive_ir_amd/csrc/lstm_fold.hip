@@ -47,6 +47,21 @@ __global__ void fold_permute_kernel(const float* __restrict__ wih, const float* 
     if (k == 0) bperm[ro] = bih[ri] + bhh[ri];
 }
 
+__global__ void iota_i64_kernel(int64_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+// (used by the per-batch form of the CARS encoders, cars.hip) the LSTM input weights in the folded gate order + 0, 1, 2, .. as "token ids" of a per-batch gate tensor
+int launch_fold_permute(const float* w_ih, const float* b_ih, const float* b_hh, int H, int ndir, int E, float* wperm, float* bperm, int64_t* iota, int64_t niota,
+                        hipStream_t st) {
+    const int64_t n = (int64_t)ndir * 4 * H * E;
+    hipLaunchKernelGGL(fold_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_ih, b_ih, b_hh, H, ndir, E, wperm, bperm);
+    if (iota && niota > 0) hipLaunchKernelGGL(iota_i64_kernel, dim3((unsigned)((niota + 255) / 256)), dim3(256), 0, st, iota, niota);
+    NIR_CHECK_LAUNCH("fold_permute_kernel");
+    return 0;
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {

@@ -146,10 +146,14 @@ class CARS(nn.Module, lib.IdCheck):
         def build():
             wih, whh, bih, bhh = lstm_cat_weights(enc.rnns[0])
             bounded = float(attn[0].weight.detach().abs().max()) < 32768.0
+            # bit 1: embedding table and W_ih inside the fp16 split's range -> the per-batch gather-GEMM (fold_embeddings off / table over the
+            # fold budget) runs on the fp16 two-term form
+            table = self.embedder.word_embeddings.table
+            gb = float(table.detach().abs().max()) < 32768.0 and float(wih.detach().abs().max()) < 32768.0
             pk = lib.Packed(lib.CarsEncoderWeights,
                             dict(wih=wih, whh=whh, bih=bih, bhh=bhh, attn0_w=attn[0].weight, attn0_b=attn[0].bias,
                                  attn3_w=attn[3].weight, attn3_b=attn[3].bias),
-                            dict(H=enc.hidden, bounded=int(bounded)))
+                            dict(H=enc.hidden, bounded=int(bounded) | (int(gb) << 1)))
             # the folded recurrences run W_hh on the fp16 matrix cores (two-term split / single term): outside that range the encoder
             # takes the per-batch fp32 path (one check per weight version)
             pk.rec_ok = float(whh.detach().abs().max()) < 32768.0
@@ -167,7 +171,7 @@ class CARS(nn.Module, lib.IdCheck):
                 pk.keep["attn_frag"] = planes.view(2, 16, 16, 8, 4, 8).permute(3, 1, 0, 4, 2, 5).contiguous()
                 pk.struct.attn_frag = pk.keep["attn_frag"].data_ptr()
             return pk
-        return cache.get(list(enc.parameters()) + list(attn.parameters()), build)
+        return cache.get(list(enc.parameters()) + list(attn.parameters()) + [self.embedder.word_embeddings.table], build)
 
     def _session_modules(self):
         names = ["click_attn", "session_query_attn", "session_doc_attn", "session_query_encoder", "session_doc_encoder",

@@ -272,7 +272,8 @@ typedef struct {
     const float *attn3_w, *attn3_b;      /* {q,d}_attn.3 [1,2H],[1] */
     int H;                               /* 128 per direction */
     int bounded;                         /* host-checked: every attention weight is < 2^15 in magnitude (the encoder outputs are in
-                                            (-1,1) by construction) -> the attention GEMM may use the fp16 two-term split */
+                                            (-1,1) by construction) -> the attention GEMM may use the fp16 two-term split (bit 0); bit 1: the embedding table
+                                            and wih are < 2^15 as well -> the per-batch gather-GEMM of nir_cars_encode may use it too */
     const void* attn_frag;               /* optional (NULL: GEMM + pooling kernels): attn0_w [2H,2H] with 2H = 256 split into two fp16 terms
                                             (nir_split_f16x2) in MFMA-fragment order [K/32][16 column tiles][2 terms][64 lanes][8], lane =
                                             16*(k%32/8) + column%16 -- operand of the fused attention-pooling kernel (csrc/cars_attn.hip),
