@@ -625,12 +625,13 @@ __device__ __forceinline__ void g3_split_store_h2(unsigned short* base, int row,
 // The mode is a template parameter and every load is unconditional (row pointers of out-of-range rows are clamped to a valid
 // row -- their products land in accumulator rows / columns the epilogue never stores), so the k-loop has no branches: a
 // predicated load would become its own basic block with a vmcnt(0) in front of it.  Only the K tail tile masks its operands.
-template <int MODE, bool H2>
+// KS: k-tiles of 16 per pipeline stage (one barrier and one prefetch per KS tiles)
+template <int MODE, bool H2, int KS = 1>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
     constexpr int NTERM = H2 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem3[];
-    unsigned short* As = smem3;                        // [2 stages][NTERM terms][G3_PLANE]
-    unsigned short* Ws = smem3 + 2 * NTERM * G3_PLANE;
+    unsigned short* As = smem3;                        // [2 stages][KS tiles][NTERM terms][G3_PLANE]
+    unsigned short* Ws = smem3 + 2 * KS * NTERM * G3_PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nb = (p.N + G3_BN - 1) / G3_BN;
@@ -666,34 +667,41 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
         n = n < p.N ? n : p.N - 1;
         wrow[i] = p.w + (int64_t)n * p.ldw;
     }
-    float4 ra[2], rw[2];
-    auto load_tile = [&](int k0, bool tail) {
-        int k = k0 + 4 * kq;
-        const bool kv = k < p.K;
-        k = kv ? k : p.K - 4;
+    float4 ra[KS][2], rw[KS][2];
+    auto load_tile = [&](int k00, bool tail) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float* src = arow[i];
-            if (MODE == 2) src = k < p.E ? arow[i] : (k < 2 * p.E ? arow1[i] : arow2[i]);
-            ra[i] = *reinterpret_cast<const float4*>(src + k);
-            rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k);
-            if (tail && !kv) {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < KS; ++j) {
+            int k = k00 + j * G3_BK + 4 * kq;
+            const bool kv = k < p.K;
+            k = kv ? k : p.K - 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* src = arow[i];
+                if (MODE == 2) src = k < p.E ? arow[i] : (k < 2 * p.E ? arow1[i] : arow2[i]);
+                ra[j][i] = *reinterpret_cast<const float4*>(src + k);
+                rw[j][i] = *reinterpret_cast<const float4*>(wrow[i] + k);
+                if (tail && !kv) {
+                    ra[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    rw[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (H2) {
-                g3_split_store_h2(As + buf * NTERM * G3_PLANE, lr + 64 * i, kq, ra[i]);
-                g3_split_store_h2(Ws + buf * NTERM * G3_PLANE, lr + 64 * i, kq, rw[i]);
-            } else {
-                g3_split_store(As + buf * NTERM * G3_PLANE, lr + 64 * i, kq, ra[i]);
-                g3_split_store(Ws + buf * NTERM * G3_PLANE, lr + 64 * i, kq, rw[i]);
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned short* ad = As + (buf * KS + j) * NTERM * G3_PLANE;
+                unsigned short* wd = Ws + (buf * KS + j) * NTERM * G3_PLANE;
+                if (H2) {
+                    g3_split_store_h2(ad, lr + 64 * i, kq, ra[j][i]);
+                    g3_split_store_h2(wd, lr + 64 * i, kq, rw[j][i]);
+                } else {
+                    g3_split_store(ad, lr + 64 * i, kq, ra[j][i]);
+                    g3_split_store(wd, lr + 64 * i, kq, rw[j][i]);
+                }
             }
-        }
     };
 
     f32x16 acc[2][2], acx[H2 ? 2 : 1][H2 ? 2 : 1];     // acx: the 2^11-scaled cross terms of the fp16 split
@@ -707,8 +715,8 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
                 if (H2) acx[a][b][r] = 0.0f;
             }
 
-    const int nk = (p.K + G3_BK - 1) / G3_BK;
-    const bool ktail = (p.K % G3_BK) != 0;
+    const int nk = (p.K + KS * G3_BK - 1) / (KS * G3_BK);          // pipeline stages of KS k-tiles
+    const bool ktail = (p.K % (KS * G3_BK)) != 0;
     load_tile(0, nk == 1 && ktail);
     store_tile(0);
     __syncthreads();
@@ -716,8 +724,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
     const int foff_a = (lane >> 5) * G3_HALF + (wm * 64 + (lane & 31)) * 8;
     const int foff_w = (lane >> 5) * G3_HALF + (wn * 64 + (lane & 31)) * 8;
     auto mma_tile = [&](int buf) {
-        const unsigned short* ab = As + buf * NTERM * G3_PLANE + foff_a;
-        const unsigned short* wb = Ws + buf * NTERM * G3_PLANE + foff_w;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const unsigned short* ab = As + (buf * KS + j) * NTERM * G3_PLANE + foff_a;
+        const unsigned short* wb = Ws + (buf * KS + j) * NTERM * G3_PLANE + foff_w;
         if constexpr (H2) {
             f16x8 af[2][2], wf[2][2];
 #pragma unroll
@@ -754,9 +764,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
             G3_TERM(2, 0) G3_TERM(1, 1) G3_TERM(0, 2) G3_TERM(1, 0) G3_TERM(0, 1) G3_TERM(0, 0)
 #undef G3_TERM
         }
+      }
     };
     for (int kt = 0; kt + 2 < nk; ++kt) {              // steady state: the next tile is a full one
-        load_tile((kt + 1) * G3_BK, false);
+        load_tile((kt + 1) * KS * G3_BK, false);
         __builtin_amdgcn_sched_barrier(0);             // keep the loads ABOVE the MFMAs (the scheduler sinks them to their first use)
         mma_tile(kt & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -765,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
     }
     if (nk >= 2) {                                     // second-to-last tile: prefetches the (possibly partial) last tile
         const int kt = nk - 2;
-        load_tile((kt + 1) * G3_BK, ktail);
+        load_tile((kt + 1) * KS * G3_BK, ktail);
         __builtin_amdgcn_sched_barrier(0);
         mma_tile(kt & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1071,6 +1082,18 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
         // large GEMMs: fp32 accuracy from three-term bf16 splits on the bf16 matrix cores (2.65 x the f32 MFMA roof)
         ProfScope ps(prof_shape_name(bounded ? (ids ? "gemm3h_kernel[gather]" : "gemm3h_kernel") : (ids ? "gemm3_kernel[gather]" : "gemm3_kernel"), M, N, K), st);
         dim3 grid((unsigned)(8 * nb3 * ((mb3 + 7) / 8)));
+        // fp16 two-term form: two k-tiles per pipeline stage (one barrier and one prefetch per 32 of K; 66 KB of LDS: still two workgroups per CU):
+        // 8 960 x 512 x 1 024 65.5 -> 57.4 us, the gather-GEMM 573 440 x 1 024 x 300 2.135 -> 2.096 ms (tunable gemm3_ks = 1: one tile per stage)
+        if (bounded && tun(g_tun.gemm3_ks) != 1 && K >= 64) {
+            constexpr size_t lds2 = (size_t)2 * 2 * 2 * 2 * G3_PLANE * 2;
+            static std::once_flag once;
+            std::call_once(once, [] {
+                (void)hipFuncSetAttribute((const void*)gemm3_kernel<0, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                (void)hipFuncSetAttribute((const void*)gemm3_kernel<1, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            });
+            if (mode3 == 0) { hipLaunchKernelGGL((gemm3_kernel<0, true, 2>), grid, dim3(256), lds2, st, p); NIR_CHECK_LAUNCH("gemm3h ks2"); return 0; }
+            if (mode3 == 1) { hipLaunchKernelGGL((gemm3_kernel<1, true, 2>), grid, dim3(256), lds2, st, p); NIR_CHECK_LAUNCH("gemm3h ks2"); return 0; }
+        }
         if (bounded) {
             constexpr size_t lds = (size_t)2 * 2 * 2 * G3_PLANE * 2;
             if (mode3 == 0) hipLaunchKernelGGL((gemm3_kernel<0, true>), grid, dim3(256), lds, st, p);

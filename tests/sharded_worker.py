@@ -17,11 +17,15 @@ from context_attentive_ir_amd.wrappers import Multitask, Ranker  # noqa: E402
 
 def main():
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    backend = os.environ.get("SHARD_BACKEND", "gloo")          # "nccl" with ONE rank: the RCCL device-gather path of the stream (communication stream,
+    if backend == "nccl":                                       # per-slot gather buffers), which gloo never takes
+        dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]), device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     V = 1500
     # rankers: N = 7 candidates over 2 ranks (4 + 3, padded shard)
     ex = synth.ranker_batch(5, 7, 4, 33, V, seed=3, full_length=False)
-    for kind in ("MATCH_TENSOR", "ESM"):
+    for kind in (("MATCH_TENSOR", "ESM") if backend == "gloo" else ()):
         r = Ranker(default_args(kind, src_vocab_size=V))
         fill_module_(r.network, 1013)
         r.cuda()
@@ -30,14 +34,15 @@ def main():
         shard = r.predict(ex).cpu()
         assert torch.allclose(full, shard, atol=1e-6), (kind, float((full - shard).abs().max()))
     # CARS: candidate-sharded document encoding + all-gather of pooled documents, session part replicated
-    sex = synth.session_batch(3, 4, 5, 4, 21, V, seed=5, full_length=False, multi_click=True)
-    mt = Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=300))
-    fill_module_(mt.network, 1013)
-    mt.cuda()
-    full = mt.predict(sex, suggest=False)["click_scores"].cpu()
-    mt.parallelize()
-    shard = mt.predict(sex, suggest=False)["click_scores"].cpu()
-    assert torch.allclose(full, shard, atol=1e-6), float((full - shard).abs().max())
+    if backend == "gloo":
+        sex = synth.session_batch(3, 4, 5, 4, 21, V, seed=5, full_length=False, multi_click=True)
+        mt = Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=300))
+        fill_module_(mt.network, 1013)
+        mt.cuda()
+        full = mt.predict(sex, suggest=False)["click_scores"].cpu()
+        mt.parallelize()
+        shard = mt.predict(sex, suggest=False)["click_scores"].cpu()
+        assert torch.allclose(full, shard, atol=1e-6), float((full - shard).abs().max())
     # the session stream over the 2 ranks (graph_runner.StreamingSessionPredictor under a sharding.StreamShardPlan; gloo: the all-gather of
     # the probabilities goes through the host): every rank receives every batch, equal to the single-rank stream, identical MAP
     import numpy as np
@@ -62,8 +67,9 @@ def main():
     smap = MAP(rank_candidates(torch.cat([single[k].reshape(-1, N) for k in range(len(bs))]).numpy()), labs)
     for mode, macro in (("batch", 1), ("pair", 1), ("pair", 2)):
         plan = sharding.StreamShardPlan(world, rank, mode, batch_size=B)
-        sp = StreamingSessionPredictor(mt2, N, 4, 16, macro * B, max_session_len=6, lanes=2, slots=2, macro=macro, plan=plan)
-        assert sp.gather == "host" and sp.B == (macro * B // world if mode == "pair" else B)
+        sp = StreamingSessionPredictor(mt2, N, 4, 16, macro * B, max_session_len=6, lanes=2, slots=2, macro=macro, plan=plan,
+                                       gather="auto" if backend == "gloo" else "device")     # (a 1-rank world would default to no gather)
+        assert sp.gather == ("host" if backend == "gloo" else "device") and sp.B == (macro * B // world if mode == "pair" else B)
         stream, _ = sp.merge_batches(corpus, bs, macro) if macro > 1 else (bs, [])
         got = {}
         st = sp.run(corpus, stream, on_result=lambda k, idx, p: got.__setitem__(k, (list(idx), p.clone())))
@@ -76,7 +82,7 @@ def main():
         if macro == 1:
             gmap = MAP(rank_candidates(torch.cat([got[k][1].reshape(-1, N) for k in range(len(bs))]).numpy()), labs)
             assert gmap == smap, (mode, gmap, smap)
-        tot = torch.tensor([float(st["pairs"])])
+        tot = torch.tensor([float(st["pairs"])], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tot)
         assert int(tot.item()) == sum(len(b) * int(corpus.lengths[b[0]]) * N for b in stream), mode     # every pair scored exactly once
     dist.barrier()

@@ -113,6 +113,18 @@ def test_two_rank_sharding_reproduces_single_rank_scores():
     assert "SHARDED_OK" in out.stdout
 
 
+def test_stream_device_gather_over_one_rank_rccl_group():
+    """The RCCL form of the sharded stream (graph_runner.StreamingSessionPredictor, gather = "device": per lane a communication stream runs
+    [ wait for the replay | all_gather_into_tensor | D2H of the gathered block ], per-slot gather buffers, the compute stream moves on) over a
+    real 1-rank RCCL process group: both modes, macro 2 -- every batch delivered, equal to the plain single-stream results, identical MAP."""
+    env = dict(os.environ, SHARD_BACKEND="nccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29549",
+           os.path.join(ROOT, "tests", "sharded_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "SHARDED_OK" in out.stdout
+
+
 @pytest.mark.parametrize("axis,emulate", [("auto", "1"), ("candidate", "4"), ("pair", "8")])
 def test_bench_rccl_sharded_step_is_graph_replayed(axis, emulate):
     """The RCCL path of the sharded CARS step over a real (1-rank) RCCL process group (BENCH_FORCE_DIST; BENCH_EMULATE_WORLD gives this
