@@ -125,3 +125,30 @@ def test_reference_multitask_with_swapped_cars(ref, kw, monkeypatch, tmp_path):
               document_labels=torch.zeros(2, 3, 4), session_len=3, ids=["a", "b"], batch_size=2)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.predict(ex)
+
+
+def test_reference_cars_itself_fails_with_unequal_encoder_sizes(ref, monkeypatch):
+    """`multitask/cars.py` of this package refuses nhid_query != nhid_document.  That mirrors the reference: its session loop multiplies
+    session_doc_attn(states) [B, k, nhid_document] with the pooled QUERY [B, nhid_query, 1] (cars.py:357-360), so with the document-session
+    encoder and the ranker on (every hyparam configuration) its own forward raises for unequal sizes -- reproduced here against the real class."""
+    from neuroir.multitask.cars import CARS as RefCARS
+    from context_attentive_ir_amd import synth
+    orig_mf = torch.Tensor.masked_fill_                       # SURVEY Appendix D shim: the reference masks with uint8 tensors
+    monkeypatch.setattr(torch.Tensor, "masked_fill_", lambda self, mask, value: orig_mf(self, mask.bool() if mask.dtype == torch.uint8 else mask, value))
+    from context_attentive_ir_amd.multitask import CARS
+    kw = dict(src_vocab_size=60, tgt_vocab_size=60, nhid_query=16, nhid_document=24, nhid_session_query=8, nhid_session_document=8, nhid_decoder=8,
+              emsize=12, max_query_len=4)
+    a = _args(ref, "CARS", **kw)
+    net = RefCARS(a)
+    net.eval()
+    ex = synth.session_batch(2, 3, 3, 4, 6, 60, seed=1)
+    tgt = torch.ones(2, 2, 5, dtype=torch.long)                    # [B, S-1, TL]: the next query of every step but the last
+    call = lambda n: n(ex["source_words"], ex["source_lens"], tgt, torch.full((2, 2), 5), tgt, ex["document_words"], ex["document_lens"],      # noqa: E731
+                       ex["document_labels"])
+    with pytest.raises(RuntimeError, match="batch2"):                     # the bmm of cars.py:361 inside the reference's encode_session
+        call(net)
+    ok = RefCARS(_args(ref, "CARS", **dict(kw, nhid_document=16)))       # the same inputs with equal sizes go through: the failure is the size mismatch
+    ok.eval()
+    assert torch.isfinite(call(ok)["ranking_loss"])
+    with pytest.raises(NotImplementedError, match="nhid_query == nhid_document"):
+        CARS(a)
