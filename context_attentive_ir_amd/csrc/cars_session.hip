@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
     float bias[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = (uv && !gxp) ? p.bih[ch][r * H + ud] + p.bhh[ch][r * H + ud] : 0.f;
-    for (int b0 = 0; b0 < p.B; b0 += 16 * NB) {
+    // (batch slabs of 16 NB rows across workgroups -- blockIdx.z -- like lstm_step16_kernel: the greedy decoders step 768 rows at a macro-batch of 8)
+    for (int b0 = blockIdx.z * 16 * NB; b0 < p.B; b0 += gridDim.z * 16 * NB) {
         // hoisted input side: the four gate pre-activations of the (row, unit) this lane finishes below (batch tile = wave), requested before the
         // recurrent walk so that their round trip runs under it
         float gxv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -507,6 +508,15 @@ int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st) {
         return 0;
     }
     ProfScope ps("lstm_step_kernel", st);
+    {
+        const int nbv = a.B > 32 ? 4 : (a.B > 16 ? 2 : 1);
+        const dim3 gridz(grid.x, grid.y, (unsigned)((a.B + 16 * nbv - 1) / (16 * nbv)));
+        if (a.B > 32) hipLaunchKernelGGL(lstm_step_kernel<4>, gridz, dim3(256), 0, st, a);
+        else if (a.B > 16) hipLaunchKernelGGL(lstm_step_kernel<2>, gridz, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(lstm_step_kernel<1>, gridz, dim3(256), 0, st, a);
+        NIR_CHECK_LAUNCH("lstm_step_kernel");
+        return 0;
+    }
     if (a.B > 32) hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, st, a);
     else if (a.B > 16) hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, a);
