@@ -1,29 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- ranked (query,doc) pairs/sec of the encode-and-rank hot path on N MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
 
-HEADLINE (the JSON line's metric/value/roofline/cpu_baseline): BASELINE.json configs[2], the largest configuration
-BASELINE marks 1 x MI355X -- CARS multitask, 16 sessions x session_len 7 x 10 candidates, q_len 4, doc_len 64,
-emb_dim 300, fp32, synthetic MSMARCO-shaped ids (Zipf over a 100 000 x 300 table, seed 1013), full-length sequences.
-A "step" = Multitask.predict's ranking path on one batch already resident in HBM: encode + rank_document + softmax
-over the candidates (the suggestion decoder is not a ranking step; `config.sub.C3_cars_with_decode` times the full predict).
+N > 1: launched by torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) -- or plainly, in
+which case bench.py starts the N ranks itself.  A world that is not --gpus is refused; n_gpus of the line = an all-reduce of ones.
 
-The same default run also measures every other single-GPU BASELINE configuration as a SUB-RECORD under `config.sub`,
-each with its own throughput, dominant kernel and roofline (kernel, avg_us, bound, achieved, peak, frac, traffic):
-C1 ESM 8x5, C2 MatchTensor 32x10, the north-star 32x50 MatchTensor shape, C4 DUET and DRMM 64x50xdoc_len 290 (DRMM / ESM
-with uniform ids over a 1M-row table so the gather really comes from HBM) and the C5 shape (CARS 64x7x50) in bf16.
+OUTPUT.  The LAST line of stdout is ONE compact JSON object (~2.5 KB): metric / value / unit / n_gpus / steps / warmup / reps / ms_per_step /
+scaling / dtype / data, `config`, `roofline`, `cpu_baseline` and one four-scalar entry per sub-record in `sub`.  The full records (every
+sub-record's roofline block, per-kernel microseconds, precompute, H2D stream) go to bench_detail.json (`config.detail`).  stderr of a successful
+run is EMPTY: file descriptor 2 points at bench_stderr.<rank>.log for the length of the run and is replayed only on failure.  At N > 1 the
+headline is printed as a complete record before the sub-records run; the final line supersedes it.
 
-N > 1 (strong scaling): every rank holds the SAME global batch and scores its own slice of the
-candidate axis (ceil(N_cand / N) per rank, padded); rankers all-gather the score shards over RCCL, CARS goes through
-Multitask.parallelize() = candidate-sharded document encoding + one all-gather of the pooled document vectors.  value =
-global pairs / max-rank time.  `config.weak_scaling_pairs_per_s` (labelled, secondary) = every rank scoring its own
-full batch with no collective.
+HEADLINE: BASELINE.json configs[2], the largest configuration BASELINE marks 1 x MI355X -- CARS multitask, 16 sessions x session_len 7 x 10
+candidates, q_len 4, doc_len 64, emb_dim 300, fp32, synthetic MSMARCO-shaped ids (Zipf over a 100 000 x 300 table, seed 1013), full-length
+sequences.  A "step" = Multitask.predict's ranking path on one batch already resident in HBM: encode + rank_document + softmax over the
+candidates (the suggestion decoder is not a ranking step; sub-record C3_cars_with_decode times the full predict).  Steps are replayed as
+hipGraphs over resident macro-batches (8 batches per replay at C3, 4 lanes); EXACTLY --steps steps are timed between barrier + synchronize,
+max over ranks; a region shorter than 0.25 s is repeated and the median reported (`reps`).
 
-roofline: the dominant kernel (largest summed duration), timed with HIP events on its launch stream in a profiled pass
-over the same workload right after the timed region; algorithmic flops / bytes per launch are priced from the launch's
-own shape.  Peaks: HBM 8 TB/s; fp32 MFMA 157.3 TFLOP/s; split-precision GEMM (3 x bf16 terms, 6 bf16
-MFMAs per fp32-accurate product block) 2500 / 6 = 416.7 TFLOP/s; bf16 MFMA 2500 TFLOP/s.
+SUB-RECORDS (N = 1): C1 ESM 8x5, C2 MatchTensor 32x10, the north-star 32x50 MatchTensor shape, C4 DUET and DRMM 64x50xdoc_len 290 (DRMM / ESM
+with uniform ids over a 1M-row table so the gather really comes from HBM; DRMM with its histogram gap on overlapping ids), the C5 shape (CARS
+64x7x50) in bf16, C3 without folded tables, C3 with decode, the C5 session stream (ids from the host), the CARS / MatchTensor training steps.
+
+N > 1 (strong scaling): every rank holds the SAME global batch.  Rankers: its slice of the candidate axis (ceil(N_cand / N),
+padded), all-gather of the score shards over RCCL.  CARS: the (session, candidate) pair axis in whole sessions per rank when B % N == 0 (no exchange
+of pooled vectors, all-gather of the probabilities), else the candidate axis with an all-to-all.  value = global pairs / max-rank time.
+Sub-records: C4 DUET / DRMM, the C5 shape, the headline on the other CARS axis, the C5 stream in both stream modes, and
+`config.weak_scaling_pairs_per_s` (labelled, secondary: every rank scoring its own full batch with no collective).
+
+roofline: the dominant kernel (largest summed duration), timed with HIP events on its launch stream in a profiled pass over the same launches
+right after the timed region; algorithmic flops / bytes per launch are priced from the launch's own shape.  Peaks: HBM
+8 TB/s; fp32 MFMA 157.3 TFLOP/s; fp16 / bf16 MFMA 2500 TFLOP/s (a two-term fp16 split executes 3 MFMAs per product, a three-term bf16 split 6).
 cpu_baseline: the pinned CPU oracle (oracle/neuroir_cpu.py) on the host cores, bounded sample, rank 0 at N = 1 only.
 """
 import argparse
