@@ -1048,7 +1048,7 @@ def cpu_baseline(c, model, batches, gpu_step, pairs, args):
     gpu = gpu_step().cpu()
     maxdiff = float((gpu - ref.view_as(gpu)).abs().max())
     avail = os.cpu_count() or ncores
-    best_t, best_rate = ncores, 0.0
+    best_t, best_rate, by_threads = ncores, 0.0, {}
     for t in sorted({min(avail, k) for k in (8, 16, 32, 64)}):    # tiny per-op tensors oversubscribe a big host: probe thread counts
         torch.set_num_threads(t)
         fn()
@@ -1056,6 +1056,7 @@ def cpu_baseline(c, model, batches, gpu_step, pairs, args):
         while time.perf_counter() - t0 < 0.75:
             fn(); n0 += 1
         rate = n0 / (time.perf_counter() - t0)
+        by_threads[str(t)] = round(rate * pairs, 1)               # (SURVEY 8d asks for k = 8 next to the best count: kept in the detail record)
         if rate > best_rate:
             best_t, best_rate = t, rate
     torch.set_num_threads(best_t)
@@ -1075,7 +1076,7 @@ def cpu_baseline(c, model, batches, gpu_step, pairs, args):
     except OSError:
         pass
     return {"value": round(n * pairs / dt, 1), "unit": "pairs/s", "cores": best_t, "kind": "port", "cpu_model": cpu_model,
-            "host_logical_cores": avail, "threads_pinned": "torch.set_num_threads(%d)" % best_t,
+            "host_logical_cores": avail, "threads_pinned": "torch.set_num_threads(%d)" % best_t, "probe_pairs_per_s_by_threads": by_threads,
             "sample": "%d batches of the same %s workload in %.1f s (oracle/neuroir_cpu.py = pinned port of the reference, torch %s CPU, "
                       "best of {8,16,32,64} threads = %d; host has %d logical cores)" % (n, m, dt, torch.__version__, best_t, avail),
             "max_abs_diff_vs_gpu_softmax": maxdiff}
