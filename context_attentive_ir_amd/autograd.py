@@ -57,6 +57,11 @@ class StepScope(object):
 
     def begin(self):
         self.active, self.pend_w, self.pend_b, self.wt = True, {}, {}, {}
+        # a caller that cleared gradients IN PLACE (zero_grad(set_to_none=False)) left last step's buffer installed as p.grad: autograd would
+        # accumulate into it and end() would overwrite / double it -- the buffer is this scope's, so it is detached from the parameter here
+        for p, buf in self.bufs.values():
+            if p.grad is buf:
+                p.grad = None
 
     def abort(self):
         self.active, self.pend_w, self.pend_b, self.wt = False, {}, {}, {}
