@@ -619,9 +619,11 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 # tail over k x bper sessions -- the session LSTM / ranknet weights (76 MB of L2 traffic per tail at C3, whatever the number
                 # of sessions) are streamed once for all k; every block keeps the click count m of ITS OWN batch (labels_groups)
                 exs = [batches[(KG * gb + j) % nb] for j in range(k)]
-                mq, mql = torch.cat([e["_q_own"] for e in exs]), torch.cat([e["_ql_own"] for e in exs])
-                md, ml = torch.cat([e["_doc_shard"] for e in exs]), torch.cat([e["_len_shard"] for e in exs])
-                mlab, mall = torch.cat([e["_lab_own"] for e in exs]), torch.stack([e["document_labels"] for e in exs])
+                with torch.cuda.stream(ln):                   # (built on the lane that reads it, like the single-GPU macro-batches)
+                    mq, mql = torch.cat([e["_q_own"] for e in exs]), torch.cat([e["_ql_own"] for e in exs])
+                    md, ml = torch.cat([e["_doc_shard"] for e in exs]), torch.cat([e["_len_shard"] for e in exs])
+                    mlab, mall = torch.cat([e["_lab_own"] for e in exs]), torch.stack([e["document_labels"] for e in exs])
+                ln.synchronize()
 
                 def body():
                     pq, pl = model.shard_encode(mq, mql, md, ml)
