@@ -288,6 +288,18 @@ __device__ __forceinline__ void ap2_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32
 // out_f16 = 2): per row and group of 4 columns 16 bytes = [4 x leading term | 4 x residual x 2^11].  The IO waves load the same 16 bytes
 // per lane as for an fp32 row and store the halves into the two planes -- no split arithmetic (it was 16 x ~14 VALU per lane and tile and
 // made the IO waves, not the matrix pipe, the bound of this kernel).
+#ifndef AP_FMAMIX
+#define AP_FMAMIX 1
+#endif
+// a += s * (the four fp16 values of u), fp32 accumulate: the fp16 operands are read by v_fma_mix_f32 (op_sel picks the half, op_sel_hi marks
+// the source as fp16); exact in fp32 like convert-then-fma
+__device__ __forceinline__ void ap_fma_mix(float4& a, const uint2 u, const float s) {
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(a.x) : "v"(u.x), "v"(s));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a.y) : "v"(u.x), "v"(s));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(a.z) : "v"(u.y), "v"(s));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a.w) : "v"(u.y), "v"(s));
+}
+
 template <bool ONE, int IN>
 __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, int64_t ntiles) {
     constexpr bool IN16 = IN == 1;
@@ -506,6 +518,13 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                         const int q = 8 * hb + q8;
                         const fp16x2_t a01 = __builtin_bit_cast(fp16x2_t, u1[q8].x), a23 = __builtin_bit_cast(fp16x2_t, u1[q8].y);
                         const float pr = prr[q8];
+#if AP_FMAMIX
+                        // v_fma_mix_f32 reads the fp16 halves in place: 1 (one term) or 2 (two terms) instructions per element instead of a
+                        // convert per term plus the FMAs -- the IO wave shares its SIMD's issue slots with an MMA wave
+                        (void)a01; (void)a23;
+                        ap_fma_mix(a, u1[q8], pr);
+                        if (!ONE) ap_fma_mix(a, u2[q8], pr * (1.0f / 2048.0f));
+#else
                         if (ONE) {
                             a.x = fmaf(pr, (float)a01[0], a.x);
                             a.y = fmaf(pr, (float)a01[1], a.y);
@@ -518,6 +537,7 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                             a.z = fmaf(pr, fmaf((float)b23[0], 1.0f / 2048.0f, (float)a23[0]), a.z);
                             a.w = fmaf(pr, fmaf((float)b23[1], 1.0f / 2048.0f, (float)a23[1]), a.w);
                         }
+#endif
                         if (((q + 1) & (per - 1)) == 0) {              // sequence complete: fold the four row subgroups, subgroup 0 stores
                             a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
                             a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
