@@ -355,6 +355,58 @@ class Env(object):
 CAPTURE_MODE = "thread_local"
 
 
+def sample_power(keep_busy, seconds=2.5):
+    """Package power and shader clock while `keep_busy()` (one untimed call = `steps` steps of the timed workload, synchronised) loops: an
+    UNTIMED leg after the timed repetitions.  The headline kernels run at the package power cap (1.35 kW of 1.40 kW during
+    the recurrence, shader clock 1.8-2.2 GHz instead of 2.4), so `roofline.frac` is read next to these two numbers.  None when rocm-smi is
+    absent, fails or BENCH_NO_POWER is set."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if os.environ.get("BENCH_NO_POWER") or not os.path.exists(smi):
+        return None
+    dev = os.environ.get("LOCAL_RANK", "0")
+    got, stop = [], threading.Event()
+
+    def ask(*flags):
+        return subprocess.run([smi, "-d", dev] + list(flags), capture_output=True, text=True, timeout=20).stdout
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = ask("--showpower", "--showclocks")
+                w = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+                f = re.search(r"sclk clock level:[^(]*\(([0-9.]+)Mhz\)", out)
+                if w:
+                    got.append((float(w.group(1)), float(f.group(1)) if f else None))
+            except Exception:
+                return
+    try:
+        th = threading.Thread(target=poll, daemon=True)
+        t0 = time.perf_counter()
+        keep_busy()
+        th.start()
+        while time.perf_counter() - t0 < seconds or len(got) < 2:
+            keep_busy()
+            if time.perf_counter() - t0 > 4 * seconds + 10:
+                break
+        stop.set()
+        th.join(timeout=25)
+        cap = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", ask("--showmaxpower"))
+    except Exception:
+        stop.set()
+        return None
+    if not got:
+        return None
+    ws = sorted(w for w, _ in got)
+    fs = sorted(f for _, f in got if f)
+    return {"package_w": ws[len(ws) // 2], "package_w_max": ws[-1], "cap_w": float(cap.group(1)) if cap else None,
+            "sclk_mhz": fs[len(fs) // 2] if fs else None, "samples": len(got),
+            "leg": "untimed: the timed region replayed for %.1f s after the timed repetitions, rocm-smi polled beside it" % (time.perf_counter() - t0)}
+
+
 def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2d=False, axis=None, kg=None):
     """Time one workload; returns the record dict (rank 0) or None."""
     L = lib.load()
@@ -802,6 +854,13 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     value = per_step_pairs * steps / elapsed
     ms_per_step = elapsed / steps * 1e3
     spread = (round(min(samples) / steps * 1e3, 5), round(max(samples) / steps * 1e3, 5))
+    power = None
+    if want_cpu and rank == 0 and not env.multi:
+        def busy():
+            rewind()
+            run_steps(steps)
+            torch.cuda.synchronize()
+        power = sample_power(busy)
 
     single_ms, overlap_diff = ms_per_step, None
     if len(lanes) > 1:
@@ -1028,7 +1087,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             "macro_batch": (stages["KG"] if (stages is not None and "aligned" in stages) else 1), "lanes": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
             "h2d_inclusive_over_resident": None if h2d_value is None else round(h2d_value / value, 4), "h2d_stream": h2d_info,
-            "dtype": c.get("dtype", "f32"), "precompute": pre, "wrapper_predict_eager_one_stream": eager_default, "roofline": roofline, "cpu_baseline": cpu}
+            "dtype": c.get("dtype", "f32"), "precompute": pre, "wrapper_predict_eager_one_stream": eager_default, "roofline": roofline, "cpu_baseline": cpu, "power": power}
 
 
 def cpu_baseline(c, model, batches, gpu_step, pairs, args):
@@ -1296,6 +1355,8 @@ def compose_line(args, env, rec, sub, weak):
            "batches_in_flight": rec["batches_in_flight"], "ms_per_step_one_batch_in_flight": rec["ms_per_step_one_batch_in_flight"],
            "hipgraph": rec["hipgraph"], "parallelism": rec["parallelism"][:400], "shard_axis": rec.get("shard_axis"), "world_size": rec["world_size"],
            "pairs_per_s_with_host_ids_h2d": rec["pairs_per_s_with_host_ids_h2d"], "weak_scaling_pairs_per_s": weak, "detail": where}
+    pw = rec.get("power")
+    pw = {k: pw.get(k) for k in ("package_w", "cap_w", "sclk_mhz")} if pw else None
     small = {k: roof.get(k) for k in ROOF_KEYS}
     small["precompute_fold_ms"], small["precompute_fold_bytes"] = pre.get("fold_ms"), pre.get("fold_bytes")
     if cpu:
@@ -1305,7 +1366,7 @@ def compose_line(args, env, rec, sub, weak):
             "steps": args.steps, "warmup": args.warmup, "reps": rec["reps"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
             # the global batch is FIXED as N grows (every rank scores its share of the same batch): strong scaling at every N
             "scaling": "strong", "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic",
-            "config": cfg, "roofline": small, "cpu_baseline": cpu, "sub": [short_sub(n, r) for n, r in sub.items()]}
+            "config": cfg, "roofline": small, "power": pw, "cpu_baseline": cpu, "sub": [short_sub(n, r) for n, r in sub.items()]}
     return json.dumps(line, separators=(",", ":"))
 
 

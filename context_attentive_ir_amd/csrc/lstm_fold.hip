@@ -87,6 +87,7 @@ struct LstmPtArgs {
                             // element, but every group of 4 consecutive units holds [4 x fp16 leading term | 4 x fp16 residual x 2^11] -- the two-term
                             // split the kernel forms anyway for its own next step, in the order attn_pool_pipe_kernel stages its LDS planes
     const void* whh_frag;   // optional: W_hh pre-split into the two fp16 terms, in the lane order of lstm16_pt_h2_kernel<4,4,8> (nir_lstm_pack_whh_frag)
+    int skew_prio = 0;      // lstm16_pt_h2s_kernel: issue priority for the role-0 waves (measurement knob)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -265,6 +266,50 @@ __device__ __forceinline__ void lstm_cell_v(const f32x4 x, float& c, float& h) {
     c = fmaf(c, rf, copysignf((1.f - d) * r1, x[2]));
     const float e = __builtin_amdgcn_exp2f(fabsf(c) * (-2.f * L2E));
     h = copysignf((1.f - e) * __builtin_amdgcn_rcpf(p_dq.y * (1.f + e)), c);
+}
+
+// The same cell for N units at once, written statement by statement ACROSS the units: program order is then N independent dependence chains
+// interleaved (every instruction's operand was produced N instructions earlier), which is what an in-order wave needs when this block is
+// issued between the MFMAs of another sequence group -- unit by unit, each v_exp / v_rcp result was consumed by the very next instruction.
+template <int N>
+__device__ __forceinline__ void lstm_cell_vn(const f32x4 (&x)[N], float (&c)[N], float (&h)[N]) {
+    constexpr float L2E = 1.4426950408889634f;
+    f32x2 e_if[N], e_go[N], p_ab[N], p_dq[N];
+    float a[N], b[N], d[N], q[N], r1[N], rf[N], e[N], t1[N], t2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e_if[i] = (f32x2){x[i][0], x[i][1]} * (f32x2){-L2E, -L2E};
+#pragma unroll
+    for (int i = 0; i < N; ++i) e_go[i] = (f32x2){fabsf(x[i][2]), x[i][3]} * (f32x2){-2.f * L2E, -L2E};
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = __builtin_amdgcn_exp2f(e_if[i].x);
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] = __builtin_amdgcn_exp2f(e_if[i].y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = __builtin_amdgcn_exp2f(e_go[i].x);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = __builtin_amdgcn_exp2f(e_go[i].y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) p_ab[i] = (f32x2){a[i], b[i]} + (f32x2){1.f, 1.f};
+#pragma unroll
+    for (int i = 0; i < N; ++i) p_dq[i] = (f32x2){d[i], q[i]} + (f32x2){1.f, 1.f};
+#pragma unroll
+    for (int i = 0; i < N; ++i) t1[i] = p_ab[i].x * p_dq[i].x;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r1[i] = __builtin_amdgcn_rcpf(t1[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) rf[i] = __builtin_amdgcn_rcpf(p_ab[i].y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) t2[i] = (1.f - d[i]) * r1[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = fmaf(c[i], rf[i], copysignf(t2[i], x[i][2]));
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_amdgcn_exp2f(fabsf(c[i]) * (-2.f * L2E));
+#pragma unroll
+    for (int i = 0; i < N; ++i) t1[i] = p_dq[i].y * (1.f + e[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r1[i] = __builtin_amdgcn_rcpf(t1[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) h[i] = copysignf((1.f - e[i]) * r1[i], c[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -486,7 +531,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // fp16 elements per h row
     constexpr uint32_t OOB = 0x7FFFFFF0u;
     constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
+#ifdef NIR_X_NOPIPE
+    constexpr bool PIPE = false;
+#else
     constexpr bool PIPE = NT >= 4 && NW == 8;               // in-wave software pipeline over the tiles (see the loop); 4 waves x 5 tiles: slower with it
+#endif
     constexpr bool DEFER = NW >= 8;                         // output stores one step late, in front of the row requests (see store_prev)
     const int TP = p.T + 3;                                 // id columns per sequence: the lookup runs two steps ahead
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -638,10 +687,14 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     for (int t = 0; t < NT; ++t) pb[t] = ptf + 4 * (u0 + t < H ? u0 + t : H - 1);
     const uint32_t gw = (uint32_t)GW;
     auto load_g = [&](int id, f32x4 (&dst)[NT]) {
+#ifdef NIR_X_NOROWS
+        return;
+#endif
         const uint64_t ro = (uint64_t)(uint32_t)id * gw;
 #pragma unroll
         for (int t = 0; t < NT; ++t) dst[t] = *reinterpret_cast<const f32x4*>(pb[t] + ro);
     };
+    f32x4 gnext[NT];
     // DEFER (8 / 16 waves): the output of step t is stored during step t+1, immediately IN FRONT of the row requests for step t+2: the vector-memory queue of a
     // step is then [stores, requests] and the wait the compiler derives for the requests (vmcnt counts in order) never covers a store
     // that is younger than they are.  (With [requests, stores] the derived wait flipped with unrelated edits between "requests only" and
@@ -653,6 +706,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     const bool split = NT == 4 && p.out_f16 == 2;
     uint32_t poff = OOB;                                      // byte offset of (sequence, step, u0) in the output block, OOB = dropped
     auto store_prev = [&]() {
+#ifdef NIR_X_NOSTORE
+        return;
+#endif
         if (NT == 4) {
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){hprev[0], hprev[1 % NT], hprev[2 % NT], hprev[3 % NT]}, out_rs, full ? poff : OOB, 0, 0);
         } else if (NT == 2) {
@@ -665,7 +721,6 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         }
     };
     const int* idp = ids_s + sq * TP;
-    f32x4 gnext[NT];
     load_g(idp[0], gnext);
     int id_n = idp[1];
     uint32_t soff = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen - 1)) * OW + dir * H + u0) * 4);
@@ -694,6 +749,38 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         const bool live = step < mylen;
         const _Float16* zr = zc + sq * ZLD + 8 * kq;
         if (!wave_on) {                                // all of this wave's units are past H: it only keeps the barriers company
+#ifdef NIR_X_BURST
+        } else if constexpr (NT == 4 && NW == 8) {
+            // Burst form: all h fragments read once, then the step's 48 MFMAs issued back to back with no dependent pair adjacent (the same
+            // accumulator recurs every fourth MFMA), then the gate math of the four tiles as ONE straight-line block (four independent chains)
+            f16x8 hh1[KB], hh2[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                hh1[kb] = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+                hh2[kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh1[kb], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh2[kb], acx[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], hh1[kb], acx[t], 0, 0, 0);
+                if (kb == 0) {
+                    if (DEFER) store_prev();
+                    load_g(id_n, gnext);
+                    id_n = idp[step + 2];
+                }
+            }
+#ifdef NIR_PT_TRACE
+#pragma unroll
+            for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]), "+v"(acx[t]));
+            PT_T(tr_t1); tr_a += tr_t1 - tr_t0;
+#endif
+#pragma unroll
+            for (int t = 0; t < NT; ++t) gates(t);
+#endif
         } else if constexpr (!PIPE) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {            // h terms are read per k-block (8 live VGPRs instead of 8*KB)
@@ -833,6 +920,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 // one).  Per wave: W 128 VGPRs, 2 x (acc + acx) 64, one k-block of h fragments at a time; the gate rows of a group's next step are requested
 // straight into its accumulators as soon as its gate math has read them (they ride in as the C operand half a step later).
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef X2_VPM
+#define X2_VPM 3
+#endif
 __global__ __launch_bounds__(512, 1) void lstm16_pt_h2x2_kernel(LstmPtArgs p) {
     constexpr int KB = 4, NT = 4, NW = 8, NTH = 64 * NW, SEQ = 16, KP = 32 * KB, ZLD = KP + 8, H = 128, H4 = 4 * H, NG = 2;
     constexpr uint32_t OOB = 0x7FFFFFF0u;
@@ -994,30 +1084,40 @@ __global__ __launch_bounds__(512, 1) void lstm16_pt_h2x2_kernel(LstmPtArgs p) {
 #ifdef NIR_PT_TRACE
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PT_T(tq1);
 #endif
+        // The 48 MFMAs of the running group (no two adjacent ones share an accumulator: tile t recurs every fourth) with the WHOLE gate math
+        // of the resting group -- four independent chains, interleaved statement by statement (lstm_cell_vn) -- spread between them.
+        f32x4 xg[NT];
+        if (gates_on) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xg[t] = acx[GG][t] * ISC + acc[GG][t];
+        }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             if (mm) {
                 const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
                 const f16x8 h2 = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h1, acc[GM][t], 0, 0, 0);
-                    acx[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h2, acx[GM][t], 0, 0, 0);
-                    acx[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], h1, acx[GM][t], 0, 0, 0);
-                }
-            }
-            if (mm && kb == 0) request_rows(GM, sm + 1);      // the slot's reads above are complete: the first MFMAs consumed them
-#ifdef NIR_X_NOGATES
-            if (gates_on) hn[kb] = (acx[GG][kb][0] + acc[GG][kb][1]) * 1e-3f;
-#else
-            if (gates_on) lstm_cell_v(acx[GG][kb] * ISC + acc[GG][kb], creg[GG][kb], hn[kb]);      // tile kb of the resting group
-#endif
-            if (mm && gates_on) {
+                for (int t = 0; t < NT; ++t) acc[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h1, acc[GM][t], 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 3 * NT; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
+                for (int t = 0; t < NT; ++t) acx[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h2, acx[GM][t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acx[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], h1, acx[GM][t], 0, 0, 0);
+            }
+            if (mm && kb == 0) request_rows(GM, sm + 1);
+        }
+        if (gates_on) {
+#ifdef NIR_X_NOGATES
+#pragma unroll
+            for (int t = 0; t < NT; ++t) hn[t] = (xg[t][0] + xg[t][1]) * 1e-3f;
+#else
+            lstm_cell_vn<NT>(xg, creg[GG], hn);
+#endif
+        }
+        if (mm && gates_on) {
+#pragma unroll
+            for (int q = 0; q < 3 * NT * KB; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, X2_VPM, 0);
             }
         }
 #ifdef NIR_PT_TRACE
@@ -1073,6 +1173,236 @@ static int launch_pt_h2x2(const LstmPtArgs& p, hipStream_t st) {
 #endif
     hipLaunchKernelGGL(lstm16_pt_h2x2_kernel, dim3((unsigned)((p.M + 31) / 32), (unsigned)p.ND), dim3(512), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2, two groups]");
+    return 0;
+}
+
+// ---- two groups, skewed roles ----
+__global__ __launch_bounds__(512, 1) void lstm16_pt_h2s_kernel(LstmPtArgs p) {
+    constexpr int KB = 4, NT = 4, NW = 8, NTH = 64 * NW, SEQ = 16, KP = 32 * KB, ZLD = KP + 8, H = 128, H4 = 4 * H, NG = 2;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
+    const int TP = p.T + 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* z = reinterpret_cast<_Float16*>(smem);        // [2 groups][2 buffers][2 terms][SEQ][ZLD]
+    int* lens_s = reinterpret_cast<int*>(z + NG * 4 * SEQ * ZLD);      // [32]
+    int* simd_s = lens_s + NG * SEQ;                                     // [16]
+    int* ids_s = simd_s + 16;                                            // [32][TP]
+    float* rows_s = reinterpret_cast<float*>(ids_s + ((NG * SEQ * TP + 3) & ~3));   // [2 groups][8 waves][4 tiles][64 lanes][4]: gate rows, LDS-direct
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * (NG * SEQ);
+    const int T = p.T;
+    const int nvalid = (int)min((int64_t)(NG * SEQ), p.M - m0);
+    const int OW = p.ND * H;
+    const int64_t GW = (int64_t)p.ND * H4;
+
+    if (lane == 0) simd_s[wave] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
+    if (tid < NG * SEQ) {
+        int l = 0;
+        if (tid < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    __syncthreads();
+    {
+        bool bad = false;
+        for (int e = tid; e < NG * SEQ * TP; e += NTH) {
+            const int s_ = e / TP, k = e - s_ * TP;
+            int64_t id = 0;
+            if (s_ < nvalid) {
+                const int l = lens_s[s_];
+                int kk = k < l - 1 ? k : l - 1;
+                kk = kk < 0 ? 0 : kk;
+                int t_ = dir == 0 ? kk : l - 1 - kk;
+                t_ = t_ < 0 ? 0 : t_;
+                id = p.ids[(m0 + s_) * T + t_];
+                if (k < T) {
+                    const int64_t raw = p.ids[(m0 + s_) * T + k];
+                    bad |= raw < 0 || raw >= p.V;
+                }
+            }
+            if (id < 0 || id >= p.V) id = 0;
+            ids_s[e] = (int)id;
+        }
+        if (bad && p.err) atomicOr(p.err, 1);
+    }
+    for (int e = tid; e < NG * 2 * SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;
+    __syncthreads();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < NG * SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    int mylen[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) mylen[g] = lens_s[SEQ * g + sq];
+    // role: the rank of the wave among the waves of its SIMD (0 / 1 with the usual two per SIMD).  Rank-1 waves run the SAME sequence of
+    // sub-phases one barrier late, so that at any time one wave of a SIMD is in a matrix sub-phase and its partner in a gate sub-phase.
+    int role;
+    {
+        const int mine = simd_s[wave];
+        int rank = 0;
+#pragma unroll
+        for (int w2_ = 0; w2_ < NW; ++w2_) rank += (w2_ < wave && simd_s[w2_] == mine) ? 1 : 0;
+        role = __builtin_amdgcn_readfirstlane(rank) & 1;
+        if (p.skew_prio && role == 0) __builtin_amdgcn_s_setprio(1);
+    }
+
+    f16x8 w1[NT][KB], w2[NT][KB];
+    const int u0 = NT * (4 * wave + kq);
+    bool wbad = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + unit_a) * H;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int k0 = 32 * kb + 8 * kq;
+            const float4 a = *reinterpret_cast<const float4*>(wr + k0), b = *reinterpret_cast<const float4*>(wr + k0 + 4);
+            const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hi = (_Float16)wv[j];
+                w1[t][kb][j] = hi;
+                w2[t][kb][j] = (_Float16)((wv[j] - (float)hi) * SC);
+                wbad |= !(fabsf(wv[j]) < 32768.0f);
+            }
+        }
+    }
+    if (wbad && p.err) atomicOr(p.err, 2);
+
+    const float* pb = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4 + 4 * u0;      // the lane's 64 contiguous bytes of a folded row
+    const uint32_t gw = (uint32_t)GW;
+    f32x4 acc[NT], acx[NT];                                   // ONE group's accumulators are live at a time (matrix sub-phase -> its gate sub-phase)
+    float creg[NG][NT], hn[NT];
+    uint32_t soff[NG];
+    const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
+    __amdgpu_buffer_rsrc_t out_rs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int nv = max(0, min(SEQ, nvalid - SEQ * g));
+        out_rs[g] = __builtin_amdgcn_make_buffer_rsrc(p.out + (m0 + SEQ * g) * T * OW, 0, (int)((uint32_t)nv * T * OW * 4u), 0x00020000);
+        soff[g] = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen[g] - 1)) * OW + dir * H + u0) * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) creg[g][t] = 0.f;
+    }
+    // Gate rows: global -> LDS without touching registers, requested a FULL step ahead (behind the first k-block of the group's matrix
+    // sub-phase), taken over as MFMA C operands at the top of the group's next matrix sub-phase.  Vector-memory queue of a wave, in program
+    // order: [4 requests g0][store g0][4 requests g1][store g1]... -- behind a group's requests there are always store + 4 + store = 6
+    // younger operations when it takes them over (s_waitcnt vmcnt(6), in-order completion); the same for both roles.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    auto request_rows = [&](int g, int step) {
+        const uint64_t ro = (uint64_t)(uint32_t)ids_s[(SEQ * g + sq) * TP + step] * gw;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb + ro + 4 * t), (lds_ptr_t)(rows_s + (((g * NW + wave) * NT + t) * 64) * 4), 16, 0, 0);
+    };
+    // matrix sub-phase of group g, step `step`: rows -> C operands, all h fragments read once, 48 MFMAs with no two adjacent ones on the same
+    // accumulator (tile t recurs every fourth), the next step's rows requested behind the first k-block
+    auto matrix = [&](auto Gc, int step) {
+        constexpr int g = decltype(Gc)::value;
+        const _Float16* zr = z + (g * 2 + (step & 1)) * 2 * SEQ * ZLD + sq * ZLD + 8 * kq;
+        f16x8 hh1[KB], hh2[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            hh1[kb] = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+            hh2[kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
+        }
+#ifdef NIR_X_NOROWS
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[t] = acc[t]; }
+#else
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = *reinterpret_cast<const f32x4*>(rows_s + ((((g * NW + wave) * NT + t) * 64) + lane) * 4);
+            acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#endif
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh1[kb], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh2[kb], acx[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], hh1[kb], acx[t], 0, 0, 0);
+#ifndef NIR_X_NOROWS
+            if (kb == 0) request_rows(g, step + 1);            // the slot's reads above are complete: the first MFMAs consumed them
+#endif
+        }
+        // the accumulators are operands of this (empty) statement: the barrier below cannot be scheduled into the MFMA stream -- an asm
+        // "memory" clobber orders memory operations only, and with the barrier hoisted behind the LDS reads the MFMAs of this sub-phase ran
+        // inside the next one, beside the partner's MFMAs instead of beside its gate math
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]), "+v"(acx[t]));
+        lds_barrier();
+    };
+    // gate sub-phase of group g: the four cells of the lane as four interleaved chains, the two h terms for the next B operand, the output
+    auto gate = [&](auto Gc, int step) {
+        constexpr int g = decltype(Gc)::value;
+        f32x4 xg[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xg[t] = acx[t] * ISC + acc[t];
+#ifdef NIR_X_NOGATES
+#pragma unroll
+        for (int t = 0; t < NT; ++t) hn[t] = (xg[t][0] + xg[t][1]) * 1e-3f;
+#else
+        lstm_cell_vn<NT>(xg, creg[g], hn);
+#endif
+        _Float16* zn = z + (g * 2 + ((step + 1) & 1)) * 2 * SEQ * ZLD;
+        _Float16 a[NT], r[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            a[t] = (_Float16)hn[t];
+            r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
+        }
+        *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = (f16x4){a[0], a[1], a[2], a[3]};
+        *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = (f16x4){r[0], r[1], r[2], r[3]};
+#ifndef NIR_X_NOSTORE
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(hn[0]), __float_as_uint(hn[1]), __float_as_uint(hn[2]), __float_as_uint(hn[3])},
+                                               out_rs[g], step < mylen[g] ? soff[g] : OOB, 0, 0);
+#endif
+        soff[g] += sstep;
+        lds_barrier();
+    };
+    request_rows(0, 0);
+    request_rows(1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    using G0 = std::integral_constant<int, 0>;
+    using G1 = std::integral_constant<int, 1>;
+    // Sub-phase s of the workgroup = one barrier interval.  Role 0: s = 4 step + {0: matrix g0, 1: gate g0, 2: matrix g1, 3: gate g1}; role 1 the
+    // same sequence one interval later.  h_g(step) is complete after both roles' gate sub-phases (role 0 at 4 step + 2 g + 1, role 1 one
+    // later) and first read by matrix g (step + 1) at 4 step + 4 + 2 g (role 0) / one later (role 1): always at least one interval of slack,
+    // and the buffer a gate sub-phase overwrites was last read three intervals earlier.
+    if (role == 1) lds_barrier();
+    for (int step = 0; step < tmax; ++step) {
+        matrix(G0{}, step);
+        gate(G0{}, step);
+        matrix(G1{}, step);
+        gate(G1{}, step);
+    }
+    if (role == 0) lds_barrier();
+    // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced
+    for (int s_ = 0; s_ < nvalid; ++s_) {
+        float* orow = p.out + (m0 + s_) * T * OW + (int64_t)dir * H;
+        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
+            for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = 0.f;
+    }
+}
+
+static int launch_pt_h2s(const LstmPtArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)(2 * 4 * 16 * (32 * 4 + 8)) * 2 + (2 * 16 + 16) * 4 + (size_t)((2 * 16 * (p.T + 3) + 3) & ~3) * 4 + (size_t)2 * 8 * 4 * 64 * 16;
+    ProfScope ps(prof_shape_name("lstm16_pt_h2s_kernel", (long long)p.M, p.T, p.H), st);
+    static bool attr = [] {
+        return hipFuncSetAttribute((const void*)lstm16_pt_h2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL(lstm16_pt_h2s_kernel, dim3((unsigned)((p.M + 31) / 32), (unsigned)p.ND), dim3(512), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2, two groups, skewed roles]");
     return 0;
 }
 
@@ -1368,7 +1698,7 @@ __global__ __launch_bounds__(64) void lstm_whh_frag_kernel(const float* __restri
 // true when launch_bilstm_folded(.., out_f16 = 2) is served: the dispatch below ends in lstm16_pt_h2_kernel<4,4,8> with every lane `full`
 bool bilstm_folded_split_out_ok(int pt_dtype, int H, int T) {
     (void)T;
-    return pt_dtype == NIR_DTYPE_F32 && H == 128 && !tun(g_tun.exact_f32) && tun(g_tun.lstm_w16) != 1 && tun(g_tun.lstm_w16) != 3;
+    return pt_dtype == NIR_DTYPE_F32 && H == 128 && !tun(g_tun.exact_f32) && tun(g_tun.lstm_w16) != 1 && tun(g_tun.lstm_w16) < 3;
 }
 
 int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
@@ -1410,6 +1740,11 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
         // MFMAs (skeleton without gate math: 1.31 vs 1.48 us; the gate math adds 0.4 us to either) -- and with half as many workgroups the
         // C3 macro-batch (280 of them on 256 CUs) loses a whole round: 433 us against 368 us.
         if (H == 128 && p.T + 3 <= 1024 && tun(g_tun.lstm_w16) == 3) return launch_pt_h2x2(p, st);
+        if (H == 128 && p.T + 3 <= 1024 && (tun(g_tun.lstm_w16) == 4 || tun(g_tun.lstm_w16) == 5)) {
+            LstmPtArgs q = p;
+            q.skew_prio = tun(g_tun.lstm_w16) == 5;
+            return launch_pt_h2s(q, st);
+        }
         return launch_pt_h2<4, 4, 8>(p, st);
     }
     const int G = (H + 15) / 16;

@@ -254,6 +254,40 @@ def test_bilstm_folded_four_wave_variant_matches():
     _close(outs[0], outs[1], 1e-6)
 
 
+@pytest.mark.parametrize("sel", [3, 4, 5])
+def test_bilstm_folded_two_group_variants_match_default(sel):
+    """H = 128: the two-sequence-group workgroup forms (opt-in tunable lstm_w16: 3 = both groups in every wave's stream, matrix phase of one over
+    the four interleaved gate chains of the other; 4 / 5 = skewed roles, one wave of a SIMD in a matrix sub-phase while its partner is in a
+    gate sub-phase) against the default one-group kernel and the oracle: ragged lengths, a partial last workgroup, both directions."""
+    from context_attentive_ir_amd import lib
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.encoders import RNNEncoder
+    from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
+    H, M, T_, V, E = 128, 83, 37, 700, 300
+    enc = fill_module_(RNNEncoder("LSTM", E, True, 1, 2 * H), seed=9).eval()
+    g = torch.Generator().manual_seed(11)
+    table = (torch.rand(V, E, generator=g) - 0.5)
+    lens = torch.randint(1, T_ + 1, (M,), generator=g); lens[0] = T_; lens[40] = 1
+    ids = torch.randint(1, V, (M, T_), generator=g)
+    ids[torch.arange(T_)[None] >= lens[:, None]] = 0
+    sd = {"e." + k: v for k, v in enc.state_dict().items()}
+    _, ref = O.rnn_encode(sd, "e", table[ids], lens)
+    wih, whh, bih, bhh = (t.detach().float().contiguous().to(DEV) for t in lstm_cat_weights(enc.rnns[0]))
+    folded = lib.fold_lstm_table(table.to(DEV), wih, bih, bhh, H, 2, "f32")
+    idd, ld = ids.to(DEV), lens.to(DEV)
+    outs = []
+    for v in (0, sel):
+        out = torch.full((M, T_, 2 * H), float("nan"), device=DEV)
+        err = torch.zeros(1, dtype=torch.int32, device=DEV)
+        with lib.tunable("lstm_w16", v, 0):
+            lib.check(lib.load().nir_bilstm_folded_fwd(lib.ptr(folded), lib.DTYPE_F32, lib.ptr(idd), lib.ptr(ld), lib.ptr(whh), lib.ptr(out),
+                                                       lib.ptr(err), M, V, T_, H, 2, lib.stream()), "folded")
+        assert int(err.item()) == 0
+        outs.append(out)
+    _close(outs[1], ref, 2e-5)
+    _close(outs[1], outs[0], 1e-6)
+
+
 def test_cars_bf16_single_term_attention_pipeline():
     """bf16 encoders hand the attention MLP single fp16 terms in the pipelined kernel (csrc/cars_attn.hip, ONE = true; bench-size
     launches select the pipeline by tile count, here it is forced with attn_unfused_pipe = 2).  The pooled vectors stay within fp16

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--lens", default="full", help="full | ragged (uniform in [1, T])")
     ap.add_argument("--ids", default="uniform", help="uniform | zipf | hot (64 distinct rows: the row gathers hit in L2)")
+    ap.add_argument("--tune", default="", help="name=value,... through nir_debug_set_tunable (lstm_w16=3: two sequence groups per workgroup)")
     a = ap.parse_args()
     name = "libneuroir_hip%s.so" % ("_" + a.lib if a.lib else "")
     L = C.CDLL(os.path.join(ROOT, "context_attentive_ir_amd", name))
@@ -33,6 +34,9 @@ def main():
     L.nir_bilstm_folded_fwd.restype = C.c_int
     L.nir_bilstm_folded_fwd.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]
     L.nir_debug_set_buffer.argtypes = [vp]
+    for kv in filter(None, a.tune.split(",")):
+        k, v = kv.split("=")
+        L.nir_debug_set_tunable(k.encode(), int(v))
     dev = "cuda"
     g = torch.Generator(device="cpu").manual_seed(3)
     H, T, M, V = a.H, a.T, a.M, a.V
