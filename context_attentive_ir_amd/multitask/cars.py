@@ -500,70 +500,79 @@ class CARS(nn.Module, lib.IdCheck):
                 keep = (pos < count.unsqueeze(1)) | (pos >= count.max())          # the batch-dependent mask quirk (Appendix E2)
                 w = torch.softmax(self._mlp_logits(self.click_attn, sd, p).masked_fill(~keep, float("-inf")), 1)
                 clicks = _wsum(sd, w).view(B, S, -1)
-        # ---- encode_session (cars.py:306-458)
+        # ---- encode_session (cars.py:306-458), re-ordered: the two session LSTMs read pooled queries / click-pooled documents only, never a
+        # ranking output, so their S steps run first (the only loop left); everything the reference computes per step from the states collected
+        # so far -- the query-conditioned session attentions, projections, pair features, maxout ranker, inner attentions -- is then ONE batched
+        # call over all steps with a causal mask (step t sees states 0..t), instead of S copies of every node in the autograd graph.
         dev = pooled_q.device
-        qs = [torch.zeros(B, self.nhid_session_query, device=dev)] if q_on else []
-        ds = [torch.zeros(B, self.nhid_session_document, device=dev)] if d_on else []
         qstate = dstate = None
-        scores, hid, cell, inner_q, inner_d = [], [], [], [], []
-        # per-step views through unbind (ONE stack in the backward instead of a zero-filled [B,S,..] tensor + copy + add per slice)
-        qv_steps = pooled_q.unbind(1)
-        doc_steps = docs.unbind(1) if docs is not None else None
         sq_rnn = self.session_query_encoder.encoder.rnns[0] if q_on else None
         sd_rnn = self.session_doc_encoder.encoder.rnns[0] if d_on else None
         gq_steps = A.linear(pooled_q, sq_rnn.weight_ih_l0, sq_rnn.bias_ih_l0).unbind(1) if q_on else None
         gd_steps = A.linear(clicks, sd_rnn.weight_ih_l0, sd_rnn.bias_ih_l0).unbind(1) if d_on else None
+        qh, qc, dh, dc = [], [], [], []
         for t in range(S):
-            qv = qv_steps[t]
-
-            def attend(states, lin):
-                st = torch.stack(states, 1)
-                w = torch.softmax((A.linear(st, lin.weight, lin.bias) * qv.unsqueeze(1)).sum(2), 1)
-                return _wsum(st, w)
-
-            if not self.no_ranker:
-                parts = ([attend(qs, self.session_query_attn)] if q_on else []) + ([attend(ds, self.session_doc_attn)] if d_on else [])
-                qp = self._proj(self.q_projection, qv)
-                D = docs.shape[-1]
-                qx = qp.unsqueeze(1).expand(B, N, D).reshape(B * N, D)
-                if parts:
-                    # the reference expands the session representation to [B,N,.] BEFORE the two projectors (cars.py:484-508): their
-                    # dropout draws one mask per candidate, not one per query
-                    sess = torch.cat(parts, 1)
-                    sx = sess.unsqueeze(1).expand(B, N, sess.shape[1]).reshape(B * N, sess.shape[1])
-                    qx = qx + self._proj(self.shared_session_projector, sx) + self._proj(self.private_session_projector1, sx)
-                dx = doc_steps[t].reshape(B * N, D)
-                x = torch.cat((qx, dx, (qx - dx).abs(), qx * dx), 1)
-                for layer, o, pool in zip(self.ranknet._linear_layers, self.ranknet._output_dims, self.ranknet._pool_sizes):
-                    x = A.linear(x, layer.weight, layer.bias).view(B * N, o, pool).max(-1)[0]
-                scores.append(x.view(B, N))
-            hparts, cparts = [], []
             if q_on:
                 qstate = self._cell(sq_rnn, gq_steps[t], qstate)
-                qs.append(A.dropout(qstate[0], p, True))
-                hparts.append(qstate[0]); cparts.append(qstate[1])
-                st = torch.stack(qs[1:], 1)
-                w = torch.softmax(self._mlp_logits(self.session_query_inner_attn, st, p), 1)
-                inner_q.append(_wsum(st, w))
+                qh.append(qstate[0]); qc.append(qstate[1])
             if d_on:
                 dstate = self._cell(sd_rnn, gd_steps[t], dstate)
-                ds.append(A.dropout(dstate[0], p, True))
-                hparts.append(dstate[0]); cparts.append(dstate[1])
-                st = torch.stack(ds[1:], 1)
-                w = torch.softmax(self._mlp_logits(self.session_doc_inner_attn, st, p), 1)
-                inner_d.append(_wsum(st, w))
-            hid.append(torch.cat(hparts, 1)); cell.append(torch.cat(cparts, 1))
+                dh.append(dstate[0]); dc.append(dstate[1])
+        QH = torch.stack(qh, 1) if q_on else None                       # [B,S,H] raw states (decoder initial states)
+        DH = torch.stack(dh, 1) if d_on else None
+        QHd = A.dropout(QH, p, True) if q_on else None                  # the dropped copies both attentions read (one mask per state)
+        DHd = A.dropout(DH, p, True) if d_on else None
+        causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril().unsqueeze(0)          # [1, step t, state j <= t]
+
+        def attend(Hd_, lin):
+            """step t attends over [0, h_0 .. h_{t-1}] with its pooled query (cars.py:520-560)"""
+            st = torch.cat((torch.zeros(B, 1, Hd_.shape[2], device=dev), Hd_[:, :S - 1]), 1)          # [B,S,H]
+            sc = (A.linear(st, lin.weight, lin.bias).unsqueeze(1) * pooled_q.unsqueeze(2)).sum(3)     # [B, t, j]
+            w = torch.softmax(sc.masked_fill(~causal, float("-inf")), 2)
+            return (w.unsqueeze(3) * st.unsqueeze(1)).sum(2)                                          # [B,S,H]
+
+        def inner(Hd_, mlp):
+            """step t pools h_0 .. h_t with the inner attention (cars.py:562-600); its dropout draws a fresh mask at every step"""
+            a = A.linear(Hd_, mlp[0].weight, mlp[0].bias, act="tanh")                                  # [B, j, H]
+            if p > 0:
+                a = A.dropout(a.unsqueeze(1).expand(B, S, S, a.shape[2]).contiguous(), p, True)
+                lg = A.linear(a, mlp[3].weight, mlp[3].bias).squeeze(-1)                               # [B, t, j]
+            else:
+                lg = A.linear(a, mlp[3].weight, mlp[3].bias).squeeze(-1).unsqueeze(1).expand(B, S, S)
+            w = torch.softmax(lg.masked_fill(~causal, float("-inf")), 2)
+            return (w.unsqueeze(3) * Hd_.unsqueeze(1)).sum(2)                                          # [B,S,H]
+
+        scores_all = None
+        if not self.no_ranker:
+            parts = ([attend(QHd, self.session_query_attn)] if q_on else []) + ([attend(DHd, self.session_doc_attn)] if d_on else [])
+            D = docs.shape[-1]
+            qp = self._proj(self.q_projection, pooled_q.reshape(B * S, -1))
+            qx = qp.unsqueeze(1).expand(B * S, N, D).reshape(B * S * N, D)
+            if parts:
+                # the reference expands the session representation to [B,N,.] BEFORE the two projectors (cars.py:484-508): their
+                # dropout draws one mask per candidate, not one per query
+                sess = torch.cat(parts, 2)
+                sx = sess.unsqueeze(2).expand(B, S, N, sess.shape[2]).reshape(B * S * N, sess.shape[2])
+                qx = qx + self._proj(self.shared_session_projector, sx) + self._proj(self.private_session_projector1, sx)
+            dx = docs.reshape(B * S * N, D)
+            x = torch.cat((qx, dx, (qx - dx).abs(), qx * dx), 1)
+            for layer, o, pool in zip(self.ranknet._linear_layers, self.ranknet._output_dims, self.ranknet._pool_sizes):
+                x = A.linear(x, layer.weight, layer.bias).view(B * S * N, o, pool).max(-1)[0]
+            scores_all = x.view(B, S, N)
+        inner_q = inner(QHd, self.session_query_inner_attn) if q_on else None
+        inner_d = inner(DHd, self.session_doc_inner_attn) if d_on else None
         out = {"ranking_loss": None, "suggestion_loss": None}
         if not self.no_ranker:
-            click_scores = torch.stack(scores, 1)
+            click_scores = scores_all
             out["ranking_loss"] = A.bce_with_logits(click_scores, document_label.float())
             out["click_scores"] = click_scores
         if not self.no_recommender:                                    # teacher-forced decoder (cars.py:605-657)
             Bd = B * (S - 1)
-            dec_h = self._proj(self.transform_hid, torch.cat(hid[:-1], 0))        # (step, session) row order, like the reference
-            dec_c = self._proj(self.transform_cell, torch.cat(cell[:-1], 0))
-            cat = [torch.stack(a, 1) for a in (inner_q, inner_d) if a]
-            cs = torch.cat(cat, 2)[:, :-1].reshape(Bd, -1)
+            hid = torch.cat([h for h in (QH, DH) if h is not None], 2)            # [B,S,.]
+            cell = torch.cat([torch.stack(c, 1) for c in (qc, dc) if c], 2)
+            dec_h = self._proj(self.transform_hid, hid[:, :-1].transpose(0, 1).reshape(Bd, -1))     # (step, session) row order, like the reference
+            dec_c = self._proj(self.transform_cell, cell[:, :-1].transpose(0, 1).reshape(Bd, -1))
+            cs = torch.cat([a for a in (inner_q, inner_d) if a is not None], 2)[:, :-1].reshape(Bd, -1)
             tgt = lib.ids64(target_rep).reshape(Bd, -1)
             tseq = lib.ids64(target_seq).reshape(Bd, -1)
             TL = tgt.shape[1]
