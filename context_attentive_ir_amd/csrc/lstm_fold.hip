@@ -910,6 +910,302 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// lstm16_pt_h2_kernel<4,4,8> with the output stores taken off the waves that request gate rows (H = 128, split-term output).
+// Vector memory retires IN ORDER per wave, loads and stores alike, and a store's acknowledgement takes longer than a step under this kernel's
+// write load: a wave whose queue holds [store of h(s-1), 4 row requests for s+1] waits for that store whenever it waits for its rows (the
+// stores cost 14 % of the launch while their issue costs 3 %: tools/recur_micro.py, -DNIR_X_NOSTORE).  Here
+//   * ONE wave -- the last of the high-priority waves, which reach the step's barrier ~1 300 ticks early -- stores the output of ALL waves:
+//     the two fp16 terms of h(s-1) lie in the h buffer the MFMAs of step s read, which IS the hand-over format; two sequences' rows per
+//     instruction, 512 contiguous bytes each (the owning lanes stored 16 x 64 bytes).  It never waits on the vector-memory counter;
+//   * that wave issues no loads: its own gate rows are requested by another high-priority wave, global -> LDS (global_load_lds_dwordx4),
+//     two steps ahead into a ring of three 4 KB slots, and taken over as MFMA C operands with four ds_read_b128;
+//   * every other wave requests its rows into registers as before -- its queue now holds loads only.
+// (A first version moved ALL requests and stores onto the high-priority waves: 895 us against 617 us with both kinds on one wave, 640 us with
+// requesters and storer separated -- the in-order coupling itself, measured.)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void lstm16_pt_h2v_kernel(LstmPtArgs p) {
+    constexpr int KB = 4, NT = 4, NW = 8, NTH = 64 * NW, SEQ = 16, KP = 32 * KB, ZLD = KP + 8, H = 128, H4 = 4 * H, RING = 3;
+    constexpr uint32_t OOB = 0x7FFFFFF0u;
+    constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
+    const int TP = p.T + 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* z = reinterpret_cast<_Float16*>(smem);        // [2 buffers][2 terms][SEQ][ZLD]
+    int* lens_s = reinterpret_cast<int*>(z + 4 * SEQ * ZLD);
+    int* simd_s = lens_s + SEQ;
+    int* ids_s = simd_s + 16;                               // [SEQ][TP]
+    float* rows_s = reinterpret_cast<float*>(ids_s + ((SEQ * TP + 3) & ~3));      // [2 storers][RING][4 tiles][64 lanes][4]: their gate rows, LDS-direct
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sq = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
+    const int T = p.T;
+    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
+    const int OW = p.ND * H;
+    const int64_t GW = (int64_t)p.ND * H4;
+    f16x8 w1[NT][KB], w2[NT][KB];
+    const bool use_frag = p.whh_frag != nullptr;            // wave-uniform
+    if (use_frag) {
+        const f16x8* fp = reinterpret_cast<const f16x8*>(p.whh_frag) + ((size_t)(dir * NW + wave) * NT * KB * 2) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                w1[t][kb] = fp[((t * KB + kb) * 2 + 0) * 64];
+                w2[t][kb] = fp[((t * KB + kb) * 2 + 1) * 64];
+            }
+    }
+    if (lane == 0) simd_s[wave] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));   // HW_REG_HW_ID bits [5:4] = SIMD_ID
+    if (tid < SEQ) {
+        int l = 0;
+        if (tid < nvalid) {
+            l = p.lens ? (int)p.lens[m0 + tid] : T;
+            l = l < 0 ? 0 : (l > T ? T : l);
+        }
+        lens_s[tid] = l;
+    }
+    lds_barrier();
+    {
+        bool bad = false;
+        for (int e = tid; e < SEQ * TP; e += NTH) {
+            const int s_ = e / TP, k = e - s_ * TP;
+            int64_t id = 0;
+            if (s_ < nvalid) {
+                const int l = lens_s[s_];
+                int kk = k < l - 1 ? k : l - 1;
+                kk = kk < 0 ? 0 : kk;
+                int t_ = dir == 0 ? kk : l - 1 - kk;
+                t_ = t_ < 0 ? 0 : t_;
+                id = p.ids[(m0 + s_) * T + t_];
+                if (k < T) {
+                    const int64_t raw = p.ids[(m0 + s_) * T + k];
+                    bad |= raw < 0 || raw >= p.V;
+                }
+            }
+            if (id < 0 || id >= p.V) id = 0;
+            ids_s[e] = (int)id;
+        }
+        if (bad && p.err) atomicOr(p.err, 1);
+    }
+    for (int e = tid; e < 2 * SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;
+    lds_barrier();
+    int tmax = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
+    // rank among the waves of the same SIMD: rank 0 = high issue priority = the wave that reaches the barrier early = the one that does the
+    // vector memory; hidx / nh = its index among / the number of such waves (4 of 8 with the usual two waves per SIMD)
+    bool hi;
+    int hidx = 0, nh = 0, sw = 0, sw2 = 0;                  // sw / sw2: wave indices of the last / second-to-last high-priority wave (the storers)
+    {
+        const int mine = simd_s[wave];
+        int rank = 0;
+#pragma unroll
+        for (int w2_ = 0; w2_ < NW; ++w2_) {
+            int r2 = 0;
+#pragma unroll
+            for (int w3_ = 0; w3_ < NW; ++w3_) r2 += (w3_ < w2_ && simd_s[w3_] == simd_s[w2_]) ? 1 : 0;
+            if (r2 == 0) {
+                hidx += w2_ < wave ? 1 : 0;
+                nh += 1;
+                sw2 = sw;
+                sw = w2_;
+            }
+            rank += (w2_ < wave && simd_s[w2_] == mine) ? 1 : 0;
+        }
+        rank = __builtin_amdgcn_readfirstlane(rank);
+        hidx = __builtin_amdgcn_readfirstlane(hidx);
+        nh = __builtin_amdgcn_readfirstlane(nh);
+        sw = __builtin_amdgcn_readfirstlane(sw);
+        sw2 = __builtin_amdgcn_readfirstlane(sw2);
+        hi = rank == 0;
+        if (rank == 0) __builtin_amdgcn_s_setprio(3);
+        else if (rank == 1) __builtin_amdgcn_s_setprio(2);
+        else if (rank == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+    float creg[NT];
+    const int u0 = NT * (4 * wave + kq);
+    bool wbad = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        creg[t] = 0.f;
+        if (use_frag) continue;
+        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
+        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + unit_a) * H;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int k0 = 32 * kb + 8 * kq;
+            const float4 a = *reinterpret_cast<const float4*>(wr + k0), b = *reinterpret_cast<const float4*>(wr + k0 + 4);
+            const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hh = (_Float16)wv[j];
+                w1[t][kb][j] = hh;
+                w2[t][kb][j] = (_Float16)((wv[j] - (float)hh) * SC);
+                wbad |= !(fabsf(wv[j]) < 32768.0f);
+            }
+        }
+    }
+    if (wbad && p.err) atomicOr(p.err, 2);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0, (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    // roles (wave-uniform).  With fewer than two high-priority waves (never seen: the hardware places the eight waves two per SIMD) every wave
+    // stores its own output from registers, like the plain kernel
+    const bool scheme = nh >= 4;
+    // two storers (the last two high-priority waves: sequences 0-7 / 8-15), two helpers (the first two: helper j requests the rows of storer j)
+    const int sidx = hidx - (nh - 2);                        // 0 / 1 for the storers
+    const bool storer = scheme && hi && sidx >= 0, helper = scheme && hi && hidx < 2;
+    const int served = hidx == 0 ? sw2 : sw;                 // (helper) the wave it requests rows for
+    const int myslot = storer ? sidx : hidx;                 // ring half: storer j reads what helper j wrote
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;
+    const float* pb = ptf + 4 * u0;                          // the lane's 64 contiguous bytes (4 units x 4 gates) of a folded row
+    const uint32_t gw = (uint32_t)GW;
+    const int* idp = ids_s + sq * TP;
+    f32x4 gnext[NT];
+    auto load_g = [&](int id) {
+        const uint64_t ro = (uint64_t)(uint32_t)id * gw;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gnext[t] = *reinterpret_cast<const f32x4*>(pb + ro + 4 * t);
+    };
+    // the storer's rows of step `step` (helper only): lane (sq, kq) of tile t of wave sw owns unit NT (4 sw + kq) + t
+    auto request_for_storer = [&](int step) {
+        const uint64_t ro = (uint64_t)(uint32_t)idp[step] * gw;
+        const float* src = ptf + ro + 4 * (NT * (4 * served + kq));
+        float* dst = rows_s + (size_t)(myslot * RING + step % RING) * (NT * 64 * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + 4 * t), (lds_ptr_t)(dst + t * 64 * 4), 16, 0, 0);
+    };
+    // h(step) of all waves (storer only): its two term planes are in the h buffer (step + 1) & 1 -- written during step `step`, read by the
+    // MFMAs of step + 1.  Lane l of instruction i stores the 16 bytes [4 x leading | 4 x residual] of units 4 (l & 31) .. of sequence 2 i + (l >> 5)
+    auto store_h = [&](int step) {
+        const _Float16* zb = z + ((step + 1) & 1) * 2 * SEQ * ZLD;
+        uint2 t1[4], t2[4];
+        int len[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                        // all LDS reads first: one round trip for the four instructions
+            const int s_ = 8 * sidx + 2 * i + (lane >> 5), gq = lane & 31;
+            len[i] = lens_s[s_];
+            t1[i] = *reinterpret_cast<const uint2*>(zb + s_ * ZLD + 4 * gq);
+            t2[i] = *reinterpret_cast<const uint2*>(zb + SEQ * ZLD + s_ * ZLD + 4 * gq);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s_ = 8 * sidx + 2 * i + (lane >> 5), gq = lane & 31;
+            const int tt = dir == 0 ? step : len[i] - 1 - step;
+            const uint32_t off = step < len[i] ? (uint32_t)(((s_ * T + tt) * OW + dir * H + 4 * gq) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){t1[i].x, t1[i].y, t2[i].x, t2[i].y}, out_rs, off, 0, 0);
+        }
+    };
+    const int mylen = lens_s[sq];
+    uint32_t soff = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen - 1)) * OW + dir * H + u0) * 4);      // (!scheme: own stores)
+    const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
+    if (helper) {
+        request_for_storer(0);
+        request_for_storer(1);
+    }
+    if (!storer) load_g(idp[0]);
+    int id_n = idp[1];
+    if (helper) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    f32x4 acc[NT], acx[NT];
+    float hn[NT] = {};
+#ifdef NIR_X_NOGATES
+    auto gates = [&](int t) { hn[t] = (acx[t][0] + acc[t][1]) * 1e-3f; };
+#else
+    auto gates = [&](int t) { lstm_cell_v(acx[t] * ISC + acc[t], creg[t], hn[t]); };
+#endif
+    for (int step = 0; step < tmax; ++step) {
+        const _Float16* zc = z + (step & 1) * 2 * SEQ * ZLD;
+        _Float16* zn = z + ((step + 1) & 1) * 2 * SEQ * ZLD;
+        const _Float16* zr = zc + sq * ZLD + 8 * kq;
+        f16x8 hh1[KB], hh2[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            hh1[kb] = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
+            hh2[kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
+        }
+        if (storer) {
+            const float* rs = rows_s + (size_t)(myslot * RING + step % RING) * (NT * 64 * 4) + lane * 4;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(rs + t * 64 * 4);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = gnext[t];              // the gate rows ride in as the MFMA's C operand
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh1[kb], acc[t], 0, 0, 0);
+                acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh2[kb], acx[t], 0, 0, 0);
+                acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], hh1[kb], acx[t], 0, 0, 0);
+            }
+            if (t == 0) {
+                if (!storer) {
+                    load_g(id_n);                                        // rows of step + 1 (past the end: a repeated id, never used)
+                    if (helper && step + 2 < tmax) request_for_storer(step + 2);
+                }
+                id_n = idp[step + 2];
+            } else {
+                gates(t - 1);
+#pragma unroll
+                for (int q = 0; q < 3 * KB; ++q) {       // one MFMA, then three of the previous tile's VALU instructions, ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            }
+        }
+        gates(NT - 1);
+        {
+            _Float16 a[NT], r[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                a[t] = (_Float16)hn[t];
+                r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
+            }
+            const f16x4 av = (f16x4){a[0], a[1], a[2], a[3]}, rv = (f16x4){r[0], r[1], r[2], r[3]};
+            *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = av;
+            *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = rv;
+            if (!scheme) {                                               // own output, from registers
+                const u32x2 au = __builtin_bit_cast(u32x2, av), ru = __builtin_bit_cast(u32x2, rv);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){au[0], au[1], ru[0], ru[1]}, out_rs, step < mylen ? soff : OOB, 0, 0);
+                soff += sstep;
+            }
+        }
+        if (storer && step > 0) store_h(step - 1);                      // in the time this wave would wait at the barrier (h(step - 1): buffer step & 1, read-only now)
+        if (helper) {
+            // the storer's rows of step + 1 (requested during step - 1) must be in LDS when the barrier below releases the step that reads
+            // them; behind them in this wave's queue: its own 4 rows of step + 1 and the storer's 4 of step + 2, both requested in this step
+            if (step + 2 < tmax) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lds_barrier();
+    }
+    if (storer && tmax > 0) store_h(tmax - 1);
+    // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced (ragged batches are the normal case)
+    for (int s_ = 0; s_ < nvalid; ++s_) {
+        float* orow = p.out + (m0 + s_) * T * OW + (int64_t)dir * H;
+        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
+            for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = 0.f;
+    }
+}
+
+static int launch_pt_h2v(const LstmPtArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)(4 * 16 * (32 * 4 + 8)) * 2 + 2 * 16 * 4 + (size_t)((16 * (p.T + 3) + 3) & ~3) * 4 + (size_t)2 * 3 * 4 * 64 * 16;
+    ProfScope ps(prof_shape_name("lstm16_pt_h2v_kernel", (long long)p.M, p.T, p.H), st);
+    static bool attr = [] {
+        return hipFuncSetAttribute((const void*)lstm16_pt_h2v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL(lstm16_pt_h2v_kernel, dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(512), lds, st, p);
+    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2, one storing wave]");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Two sequence groups per workgroup (H = 128): the step of the kernel above is a serial chain -- barrier, LDS reads of h, ~1500 cycles of
 // MFMA per SIMD, the last tile's gate math, conversion, LDS write, barrier -- in which the matrix pipe idles for ~45 % of the time, and a
 // second workgroup cannot share the CU because the two-term W_hh of one direction fills half its register file.  Here one workgroup owns TWO
@@ -1698,7 +1994,7 @@ __global__ __launch_bounds__(64) void lstm_whh_frag_kernel(const float* __restri
 // true when launch_bilstm_folded(.., out_f16 = 2) is served: the dispatch below ends in lstm16_pt_h2_kernel<4,4,8> with every lane `full`
 bool bilstm_folded_split_out_ok(int pt_dtype, int H, int T) {
     (void)T;
-    return pt_dtype == NIR_DTYPE_F32 && H == 128 && !tun(g_tun.exact_f32) && tun(g_tun.lstm_w16) != 1 && tun(g_tun.lstm_w16) < 3;
+    return pt_dtype == NIR_DTYPE_F32 && H == 128 && !tun(g_tun.exact_f32) && tun(g_tun.lstm_w16) != 1 && (tun(g_tun.lstm_w16) < 3 || tun(g_tun.lstm_w16) == 6);
 }
 
 int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const int64_t* lens, const float* whh, float* out,
@@ -1739,6 +2035,7 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
         // 1.75 us against 1.85 us of the single-group form at equal occupancy -- the gate math does NOT disappear under the other group's
         // MFMAs (skeleton without gate math: 1.31 vs 1.48 us; the gate math adds 0.4 us to either) -- and with half as many workgroups the
         // C3 macro-batch (280 of them on 256 CUs) loses a whole round: 433 us against 368 us.
+        if (H == 128 && p.T + 3 <= 1024 && p.out_f16 == 2 && tun(g_tun.lstm_w16) == 6) return launch_pt_h2v(p, st);
         if (H == 128 && p.T + 3 <= 1024 && tun(g_tun.lstm_w16) == 3) return launch_pt_h2x2(p, st);
         if (H == 128 && p.T + 3 <= 1024 && (tun(g_tun.lstm_w16) == 4 || tun(g_tun.lstm_w16) == 5)) {
             LstmPtArgs q = p;
