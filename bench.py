@@ -21,7 +21,7 @@ max over ranks; a region shorter than 0.25 s is repeated and the median reported
 
 SUB-RECORDS (N = 1): C1 ESM 8x5, C2 MatchTensor 32x10, the north-star 32x50 MatchTensor shape, C4 DUET and DRMM 64x50xdoc_len 290 (DRMM / ESM
 with uniform ids over a 1M-row table so the gather really comes from HBM; DRMM with its histogram gap on overlapping ids), the C5 shape (CARS
-64x7x50) in bf16, C3 without folded tables, C3 with decode, the C5 session stream (ids from the host), the CARS / MatchTensor training steps.
+64x7x50) in bf16, the two other session rankers (M_MATCH_TENSOR, MNSRF) at the configs[2] shape, C3 without folded tables, C3 with decode, the C5 session stream (ids from the host), the CARS / MatchTensor training steps.
 
 N > 1 (strong scaling): every rank holds the SAME global batch.  Rankers: its slice of the candidate axis (ceil(N_cand / N),
 padded), all-gather of the score shards over RCCL.  CARS: the (session, candidate) pair axis in whole sessions per rank when B % N == 0 (no exchange
@@ -87,10 +87,15 @@ CONFIGS = {
                        baseline="ESM at the C4 shape (uniform ids, 1M-row table): the pure gather-reduce HBM roofline"),
     "C5_cars_bf16": dict(model="cars", batch=64, session=7, cands=50, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="bf16",
                          baseline="configs[4] shape on one GPU: CARS, 50 candidates/query, bf16 folded tables + bf16 MFMA recurrence"),
+    # the other two session rankers main/multitask.py can select, at the configs[2] shape (not BASELINE configurations)
+    "X3_m_match_tensor": dict(model="m_match_tensor", batch=16, session=7, cands=10, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32",
+                              baseline="SURVEY 8(f) rank 3: M_MATCH_TENSOR at the configs[2] shape"),
+    "X3_mnsrf": dict(model="mnsrf", batch=16, session=7, cands=10, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32",
+                     baseline="SURVEY 8(f) rank 3: MNSRF at the configs[2] shape (its 256-unit encoders run step by step: GEMM + cell per time step)"),
 }
 HEADLINE = "C3_cars"
 SUB_STEPS = {"C1_esm": 400, "C2_match_tensor": 400, "NS_match_tensor_50": 200, "C4_duet": 24, "C4_drmm": 60, "C4_esm_hbm": 60,
-             "C5_cars_bf16": 24}
+             "C5_cars_bf16": 24, "X3_m_match_tensor": 100, "X3_mnsrf": 30}
 
 
 def algorithmic_bytes_per_pair(N, QL, DL, E=300, table_bytes=4):
