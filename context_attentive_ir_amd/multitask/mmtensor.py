@@ -61,6 +61,28 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
         self._dims = dict(F=args.featsize, Hq=args.nhid_query // 2, Hd=args.nhid_document // 2, C=args.nchannels,
                           NF=args.nfilters, MF=args.match_filter_size)
         self._pack = lib.PackCache()
+        # eval mode: embedding -> Linear(E->F) -> LSTM input projection folded into one table per encoder, as rankers.MatchTensor does
+        self.fold_embeddings = getattr(args, "fold_embeddings", True)
+        self._fold = lib.PackCache(retain=1)
+        self._err_flag = None
+
+    def _folded_tables(self, w):
+        table = self.embedder.word_embeddings.table
+
+        def build():
+            L = lib.load()
+            V, E = table.shape
+            F_ = self._dims["F"]
+            x = torch.empty(V, F_, device=table.device, dtype=torch.float32)           # projected table x[v] = W_p table[v] + b_p
+            t = table.detach().float().contiguous()
+            lib.check(L.nir_linear_f32(lib.ptr(t), E, None, None, 0, 0, 0, lib.ptr(w.keep["proj_w"]), E, lib.ptr(w.keep["proj_b"]), None,
+                                       lib.ptr(x), F_, V, F_, E, 0, lib.stream()), "nir_linear_f32")
+            fq = lib.fold_lstm_table(x, w.keep["q_wih"], w.keep["q_bih"], w.keep["q_bhh"], self._dims["Hq"], 2, "f32")
+            fd = lib.fold_lstm_table(x, w.keep["d_wih"], w.keep["d_bih"], w.keep["d_bhh"], self._dims["Hd"], 2, "f32")
+            return fq, fd
+        params = [table, self.linear_projection.weight, self.linear_projection.bias] + list(self.query_encoder.encoder.rnns[0].parameters()) \
+            + list(self.document_encoder.encoder.rnns[0].parameters())
+        return self._fold.get(params, build)
 
     def _weights(self):
         def build():
@@ -75,7 +97,10 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
                      conv2_b=self.conv2.bias, conv3_w=self.conv3.weight, conv3_b=self.conv3.bias,
                      conv_w=self.conv.weight, conv_b=self.conv.bias, out_w=self.output.weight, out_b=self.output.bias)
             from ..rankers.mtensor import attach_projection_fragments, interaction_bounded
-            return attach_projection_fragments(lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self)))))
+            pk = attach_projection_fragments(lib.Packed(lib.MatchTensorWeights, t, dict(self._dims, bounded=int(interaction_bounded(self)))))
+            # W_hh of the folded recurrences goes onto the fp16 matrix cores as a two-term split: needs |w| < 2^15 (else: unfolded fp32 path)
+            pk.rec_ok = max(float(q[1].detach().abs().max()), float(d[1].detach().abs().max())) < 32768.0
+            return pk
         skip = ("embedder.", "session_query_encoder.", "decoder.", "generator.")
         params = [p for n, p in self.named_parameters() if not n.startswith(skip)]
         return self._pack.get(params, build)
@@ -125,12 +150,24 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
         L = lib.load()
         B, S, N, DL = document_rep.shape
         QL = source_rep.shape[2]
-        q, d = self._clean_ids(source_rep.reshape(B * S, QL), document_rep.reshape(B * S, N, DL), table.shape[0])
-        ql, dl = lib.ids64(src_len.reshape(-1)), lib.ids64(document_len.reshape(-1))
         w = self._weights()
+        fold = self.fold_embeddings and self._dims["Hq"] >= 4 and self._dims["Hd"] >= 4 and w.rec_ok
+        if fold:      # the folded recurrences validate ids in-kernel
+            q, d = lib.ids64(source_rep.reshape(B * S, QL)), lib.ids64(document_rep.reshape(B * S, N, DL))
+        else:
+            q, d = self._clean_ids(source_rep.reshape(B * S, QL), document_rep.reshape(B * S, N, DL), table.shape[0])
+        ql, dl = lib.ids64(src_len.reshape(-1)), lib.ids64(document_len.reshape(-1))
         ws = lib.workspace(L.nir_matchtensor_workspace_bytes(B * S, N, QL, DL, w.ref()), q.device)
         scores = torch.empty(B * S, N, device=q.device, dtype=torch.float32)
-        if B * S > 0:
+        if B * S > 0 and fold:
+            fq, fd = self._folded_tables(w)
+            if self._err_flag is None or self._err_flag.device != q.device:
+                self._err_flag = torch.zeros(1, dtype=torch.int32, device=q.device)
+            lib.check(L.nir_matchtensor_score_folded(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B * S, N, QL, DL, lib.ptr(fq), lib.ptr(fd),
+                                                     lib.DTYPE_F32, table.shape[0], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(scores),
+                                                     None, None, None, None, lib.ptr(self._err_flag), lib.stream()),
+                      "nir_matchtensor_score_folded")
+        elif B * S > 0:
             lib.check(L.nir_matchtensor_score(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B * S, N, QL, DL,
                                               lib.ptr(table), table.shape[0], table.shape[1], w.ref(), lib.ptr(ws), ws.numel(),
                                               lib.ptr(scores), None, None, None, None, lib.stream()), "nir_matchtensor_score")
