@@ -365,6 +365,28 @@ def test_multitask_update_matches_reference_loss_trajectory():
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(query_session_off=True), dict(doc_session_off=True)])
+def test_cars_train_forward_scores_equal_the_eval_path_under_session_flags(kw):
+    """The train-mode forward batches the session loop over its steps (causal mask); at dropout 0 its click scores are the eval path's
+    (rank_document: the HIP session kernels, pinned against the oracle for every flag combination) -- with the query-session or the
+    document-session encoder switched off as well -- and the backward runs."""
+    g = load_golden("cars_train")
+    m = build_model("CARS", vocab=int(g["meta_vocab"]), tgt_vocab_size=int(g["meta_vocab"]), device=DEV, dropout_emb=0.0, dropout=0.0,
+                    dropout_rnn=0.0, **kw)
+    m.embedder.word_embeddings.table.requires_grad_(False)
+    b = _cars_train_batch(g, 0, DEV)
+    m.eval()
+    with torch.no_grad():
+        pooled, _, _ = m.encode(b["source_words"], b["source_lens"])
+        ref = m.rank_document(pooled, b["document_words"], b["document_lens"], b["document_labels"])[0]
+    m.train()
+    out = m(source_rep=b["source_words"], source_len=b["source_lens"], target_rep=b["target_words"], target_len=b["target_lens"],
+            target_seq=b["target_seq"], document_rep=b["document_words"], document_len=b["document_lens"], document_label=b["document_labels"])
+    np.testing.assert_allclose(out["click_scores"].detach().cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
+    (out["ranking_loss"] + out["suggestion_loss"]).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def test_cars_train_with_dropout_runs_and_is_stochastic():
     from context_attentive_ir_amd import autograd as A
     g = load_golden("cars_train")
