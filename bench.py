@@ -416,6 +416,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     """Time one workload; returns the record dict (rank 0) or None."""
     L = lib.load()
     dev, world, rank = env.dev, env.world, env.rank
+    adhoc_power_off = bool(os.environ.get("BENCH_NO_POWER"))
     is_sess = c["model"] in SESSION_MODELS
     sharded = shard and env.multi
     # lane-count tuning aid (never set by the driver): BENCH_FORCE_DIST=1 BENCH_EMULATE_WORLD=W on ONE GPU gives this process rank 0's
@@ -860,12 +861,12 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     ms_per_step = elapsed / steps * 1e3
     spread = (round(min(samples) / steps * 1e3, 5), round(max(samples) / steps * 1e3, 5))
     power = None
-    if want_cpu and rank == 0 and not env.multi:
+    if rank == 0 and not env.multi and not adhoc_power_off:        # every N = 1 record: which configurations run at the package power cap
         def busy():
             rewind()
             run_steps(steps)
             torch.cuda.synchronize()
-        power = sample_power(busy)
+        power = sample_power(busy, 2.5 if want_cpu else 1.5)
 
     single_ms, overlap_diff = ms_per_step, None
     if len(lanes) > 1:
@@ -1222,6 +1223,8 @@ def short_sub(n, r):
     for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle", "kg"):
         if k in r:
             e[k] = r[k]
+    if r.get("power"):
+        e["w"] = r["power"].get("package_w")
     if n.startswith("train_") or r.get("pairs_per_s") is None:
         e["ms_per_step"] = r.get("ms_per_step")
     return e
