@@ -169,6 +169,8 @@ __global__ __launch_bounds__(256) void esm16_kernel(const int64_t* q_ids, const 
 struct DrmmW {
     const float *gate_w, *gate_b, *f0w, *f0b, *f1w, *f1b, *ow, *ob;
     int snap_one;         // opt-in: |cos - 1| <= 4 ulp counts as exactly 1 (SURVEY.md Appendix E1 iii)
+    const signed char* self_bin;   // [V] or null: numpy.histogram bin (0..4; -1 = dropped) of row v's cosine WITH ITSELF as the reference's
+                                   // host path rounds it (drmm.py:66-75) -- taken for every q_id == d_id hit instead of this kernel's own cosine
 };
 
 // One workgroup (4 waves = 16 row groups of 16 lanes) per (query, candidate) pair.
@@ -178,7 +180,11 @@ struct DrmmW {
 // rows per pass.  cos = (d . q_i/|q_i|) / max(|d|, eps); each lane of the group owns histogram slots
 // (i*5 + bin) == lane16 (mod 16) in registers.  First version (one row per wave, element-wise IEEE division, 5
 // full-wave reductions per row) was VALU-issue-bound at 2.45 TB/s algorithmic.
-// dynamic LDS: qn[QL][E] + glog[QL] + hist[QL*5]
+// Exact token matches (q_id == d_id): the reference's fp32 cosine of a row with itself is <1 / ==1 / >1 by ATen's CPU reduction
+// order (36 / 39 / 25 % of random 300-d rows) and numpy.histogram puts it in [.5,1) / {1} / nowhere.  That value is a pure function of
+// the embedding ROW (bit-equal between the reference's [B*N,QL,DL,E] materialised call and cosine_similarity(table, table, 1), invariant
+// under the thread count -- probed), so the host computes its bin once per table version (w.self_bin) and the kernel looks it up.
+// dynamic LDS: qn[QL][E] + glog[QL] + hist[QL*5] + qid[QL] (int64)
 // NU: histogram slots per lane (NU*16 >= QL*5); DR_MAXC: float4 pieces per lane of a 16-lane row group (16*4*DR_MAXC >= E):
 // 5 for the 300-d tables of the reference (a fixed 8 spent 3 of every 8 load/dot slots on always-false guards), 8 up to E = 512
 template <int NU, int DR_MAXC>
@@ -189,12 +195,14 @@ __global__ __launch_bounds__(256) void drmm_kernel(const int64_t* __restrict__ q
     float* qn = smem;                 // [QL][E] rows normalised by max(|q_i|, eps)
     float* glog = qn + QL * E;        // [QL]   gate logits
     int* hist = (int*)(glog + QL);    // [QL*5]
+    int64_t* qid = (int64_t*)(smem + ((QL * E + QL + QL * 5 + 1) & ~1));   // [QL], 8-byte aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = tid & 15, rg = tid >> 4;
     const int64_t pair = blockIdx.x;
     const int b = (int)(pair / N);
     const int nch = E >> 2;
     for (int i = tid; i < QL * 5; i += 256) hist[i] = 0;
+    for (int i = tid; i < QL; i += 256) qid[i] = q_ids[(int64_t)b * QL + i];
     // phase 1: query rows (one wave per row): normalise into LDS, gate logit
     for (int i = wave; i < QL; i += 4) {
         const float* rp = table + q_ids[(int64_t)b * QL + i] * (int64_t)E;
@@ -229,10 +237,15 @@ __global__ __launch_bounds__(256) void drmm_kernel(const int64_t* __restrict__ q
     for (int j0 = rg; j0 < DL; j0 += 32) {          // 2 rows in flight per row group
         float4 v[2][DR_MAXC];
         bool ok[2];
+        int64_t did[2];
+        int sbin[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int j = j0 + 16 * r;
             ok[r] = j < DL;
+            did[r] = ok[r] ? dids[j] : 0;
+            sbin[r] = w.self_bin ? (int)w.self_bin[did[r]] : 0;          // one byte per row, the same address in all 16 lanes
+            if (!ok[r] || !w.self_bin) did[r] = -1;                      // never equal to a query id
             const float* rp = table + (ok[r] ? dids[j] : 0) * (int64_t)E;
 #pragma unroll
             for (int u = 0; u < DR_MAXC; ++u) {
@@ -258,6 +271,7 @@ __global__ __launch_bounds__(256) void drmm_kernel(const int64_t* __restrict__ q
                 // numpy.histogram(bins=[-1,-.5,0,.5,1,1]): [-1,-.5) [-.5,0) [0,.5) [.5,1) {1}; outside -> dropped
                 int bin = -1;
                 if (d >= -1.0f && d <= 1.0f) bin = d < -0.5f ? 0 : d < 0.0f ? 1 : d < 0.5f ? 2 : d < 1.0f ? 3 : 4;
+                if (did[r] == qid[i]) bin = sbin[r];                     // exact token match: the reference's own rounding of cos(row, row)
                 const int slot = (ok[r] && bin >= 0) ? i * 5 + bin : -1;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) cnt[u] += (slot == l16 + 16 * u);
@@ -320,8 +334,8 @@ extern "C" int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B,
     NIR_REQUIRE(E % 4 == 0 && E > 0 && E <= 256 * MAXCH, "drmm: emsize %d unsupported", E);
     NIR_REQUIRE(((uintptr_t)table & 15) == 0 && ((uintptr_t)w->gate_w & 15) == 0, "drmm: table/gate weight must be 16-byte aligned");
     if (B == 0) return 0;
-    DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b, w->snap_one};
-    size_t lds = (size_t)QL * E * 4 + QL * 4 + QL * 5 * 4;
+    DrmmW dw{w->gate_w, w->gate_b, w->ffnn0_w, w->ffnn0_b, w->ffnn1_w, w->ffnn1_b, w->out_w, w->out_b, w->snap_one, w->self_bin};
+    size_t lds = (size_t)(((size_t)QL * E + QL + QL * 5 + 1) & ~(size_t)1) * 4 + (size_t)QL * 8;
     NIR_REQUIRE(lds <= 160 * 1024 - 512, "drmm: query length %d x emsize %d needs %zu bytes of LDS (> 160 KiB)", QL, E, lds);
     const bool small = QL * 5 <= 32, narrow = E <= 320, longq = QL > 25;
     if (lds > 64 * 1024) {      // (only long queries get here: the LDS-atomic instantiations)

@@ -23,6 +23,7 @@ def _struct(name, float_fields, int_fields=()):
 
 DrmmWeights = _struct("nir_drmm_weights",
                       ["gate_w", "gate_b", "ffnn0_w", "ffnn0_b", "ffnn1_w", "ffnn1_b", "out_w", "out_b"], ["snap_one"])
+DrmmWeights = type("nir_drmm_weights", (C.Structure,), {"_fields_": list(DrmmWeights._fields_) + [("self_bin", C.c_void_p)]})
 MatchTensorWeights = _struct(
     "nir_matchtensor_weights",
     ["proj_w", "proj_b", "q_wih", "q_whh", "q_bih", "q_bhh", "d_wih", "d_whh", "d_bih", "d_bhh",

@@ -5,16 +5,43 @@ The reference materialises two [B*N,QL,DL,E] tensors, takes their cosine, copies
 per-row numpy.histogram and copies the counts back.  nir_drmm_score streams each document row once,
 keeps the QL normalised query rows in LDS, bins cosines in registers and finishes gate softmax / FFN /
 output in the same kernel -- no host round trip.  Bin edges follow numpy.histogram(bins=[-1,-.5,0,.5,1,1]).
-Parity note: cosines within fp32 rounding of a bin edge (incl. exact token matches,
-cos ~ 1) may land in a neighbouring bin relative to ATen's CPU reduction order.
+Exact token matches: the reference's cosine of a row with itself is <1 / ==1 / >1 by its reduction order and lands
+in [.5,1) / {1} / nowhere; that bin is a pure function of the embedding row, computed here once per table version exactly as the
+reference's host path computes it (`self_cosine_bins`) and looked up by the kernel for every q_id == d_id hit -- the integer histograms are
+then the reference's.  Cosines of DIFFERENT rows within fp32 rounding of a bin edge (O(1e-6) of all pairs) may still land in a neighbouring bin.
 """
+import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import autograd as A
 from .. import lib
 from ..constants import PAD
 from ..modules import Embeddings
+
+
+def histogram_bin(c):
+    """numpy.histogram(x, bins=[-1,-.5,0,.5,1,1]) as a per-element bin index: [-1,-.5) [-.5,0) [0,.5) [.5,1) {1} -> 0..4, anything outside
+    [-1,1] (or NaN) -> -1 = dropped.  c: float32 numpy array or torch tensor; returns int8 of the same kind."""
+    if torch.is_tensor(c):
+        b = (c >= -0.5).to(torch.int8) + (c >= 0).to(torch.int8) + (c >= 0.5).to(torch.int8) + (c >= 1.0).to(torch.int8)
+        return torch.where((c >= -1.0) & (c <= 1.0), b, torch.full_like(b, -1))
+    c = np.asarray(c, np.float32)
+    b = (c >= -0.5).astype(np.int8) + (c >= 0).astype(np.int8) + (c >= 0.5).astype(np.int8) + (c >= 1.0).astype(np.int8)
+    return np.where((c >= -1.0) & (c <= 1.0), b, np.int8(-1)).astype(np.int8)
+
+
+def self_cosine_bins(table, host=True):
+    """[V] int8 on table.device: the histogram bin of cosine_similarity(row, row) for every embedding row (drmm.py:66-75 at a q_id == d_id hit).
+    host=True: computed by the HOST's ATen kernel on a CPU copy of the table -- the reference's CPU path bit for bit (one D2H copy of the
+    table per table version; synchronising, so not inside a graph capture).  host=False: computed on the device (what the reference gives
+    with --cuda; no synchronisation -- used while a trainable table changes every step)."""
+    t = table.detach().float()
+    if host:
+        t = t.cpu()
+        return torch.from_numpy(histogram_bin(F.cosine_similarity(t, t, 1).numpy())).to(table.device)
+    return histogram_bin(F.cosine_similarity(t, t, 1)).contiguous()
 
 
 class GatingNetwork(nn.Module):
@@ -37,26 +64,38 @@ class DRMM(nn.Module, lib.IdCheck):
         self.gating_network = GatingNetwork(args.emsize)
         self.ffnn = nn.Sequential(nn.Linear(self.nbins, 1), nn.Linear(1, 1))
         self.output = nn.Linear(1, 1)
-        self._pack = lib.PackCache()
-        # Exact token matches (cos = 1 +- a few ulp): "numpy" (default) bins the rounded value literally like the reference's host
-        # numpy.histogram -- {1}, [.5,1) or dropped (> 1), depending on the reduction order (the reference itself is
-        # not reproducible there).  "snap" is an opt-in, intentional deviation: |cos - 1| <= 4 ulp counts as 1, so every exact match
-        # lands in the {1} bin on every device.
-        self.exact_match_policy = getattr(args, "drmm_exact_match_policy", "numpy")
+        self._pack, self._pack_nobins, self._bins = lib.PackCache(), lib.PackCache(), lib.PackCache(retain=1)
+        # Exact token matches (q_id == d_id; the cosine is 1 +- a few ulp):
+        #   "reference" (default): the bin the reference's HOST path gives that row (self_cosine_bins; <1 -> [.5,1), ==1 -> {1}, >1 -> dropped) --
+        #               the integer histograms equal the reference's;
+        #   "numpy":    the kernel's own fp32 cosine binned literally (round 1-4 behaviour: right distribution, different rows);
+        #   "snap":     opt-in, intentional deviation: |cos - 1| <= 4 ulp counts as 1, every exact match lands in {1} on every device.
+        self.exact_match_policy = getattr(args, "drmm_exact_match_policy", "reference")
 
-    def _weights(self):
-        if self.exact_match_policy not in ("numpy", "snap"):
-            raise ValueError("exact_match_policy must be 'numpy' or 'snap'")
+    def _self_bins(self):
+        table = self.word_embeddings.table
+        host = not (self.training and table.requires_grad)      # a table that trains changes every step: device-side rounding, no D2H
+        return self._bins.get([table, host], lambda: self_cosine_bins(table, host))
+
+    def _weights(self, bins=True):
+        """bins=False: ids are not vocabulary ids (the dropout path addresses a per-batch row table by position) -> no self-bin lookup."""
+        if self.exact_match_policy not in ("reference", "numpy", "snap"):
+            raise ValueError("exact_match_policy must be 'reference', 'numpy' or 'snap'")
+        sb = self._self_bins() if (bins and self.exact_match_policy == "reference") else None
 
         def build():
-            return lib.Packed(lib.DrmmWeights, dict(
+            pk = lib.Packed(lib.DrmmWeights, dict(
                 gate_w=self.gating_network.weight.weight, gate_b=self.gating_network.weight.bias,
                 ffnn0_w=self.ffnn[0].weight, ffnn0_b=self.ffnn[0].bias, ffnn1_w=self.ffnn[1].weight,
                 ffnn1_b=self.ffnn[1].bias, out_w=self.output.weight, out_b=self.output.bias), dict(snap_one=int(self.exact_match_policy == "snap")))
-        params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")] + [self.exact_match_policy]
-        return self._pack.get(params, build)
+            if sb is not None:
+                pk.keep["self_bin"] = sb
+                pk.struct.self_bin = sb.data_ptr()
+            return pk
+        params = [p for n, p in self.named_parameters() if not n.startswith("word_embeddings")] + [self.exact_match_policy, sb]
+        return (self._pack if bins else self._pack_nobins).get(params, build)
 
-    def _hist(self, q, d, table):
+    def _hist(self, q, d, table, bins=True):
         """Matching histograms [B*N, QL, 5] from the scoring kernel (constants w.r.t. the parameters, as in the reference where
         they pass through numpy, drmm.py:70-75)."""
         B, QL = q.shape
@@ -64,7 +103,7 @@ class DRMM(nn.Module, lib.IdCheck):
         hist = torch.empty(B * N, QL, 5, device=q.device, dtype=torch.float32)
         scratch = torch.empty(B, N, device=q.device, dtype=torch.float32)
         lib.check(lib.load().nir_drmm_score(lib.ptr(q), lib.ptr(d), B, N, QL, DL, lib.ptr(table), table.shape[0], table.shape[1],
-                                            self._weights().ref(), lib.ptr(scratch), lib.ptr(hist), lib.stream()), "nir_drmm_score")
+                                            self._weights(bins).ref(), lib.ptr(scratch), lib.ptr(hist), lib.stream()), "nir_drmm_score")
         return hist
 
     def _forward_train(self, q, d):
@@ -82,7 +121,7 @@ class DRMM(nn.Module, lib.IdCheck):
             ed = A.dropout(A.embed(d.reshape(M, DL), table), p, True)
             rows = torch.cat((eq.detach().reshape(B * QL, -1), ed.detach().reshape(M * DL, -1)), 0).contiguous()
             pos = torch.arange(B * QL + M * DL, device=q.device, dtype=torch.int64)
-            hist = self._hist(pos[:B * QL].view(B, QL).contiguous(), pos[B * QL:].view(B, N, DL).contiguous(), rows)
+            hist = self._hist(pos[:B * QL].view(B, QL).contiguous(), pos[B * QL:].view(B, N, DL).contiguous(), rows, bins=False)
         else:
             hist = self._hist(q, d, table.detach())
         z = A.linear(A.linear(hist, self.ffnn[0].weight, self.ffnn[0].bias), self.ffnn[1].weight, self.ffnn[1].bias).squeeze(2)

@@ -165,6 +165,13 @@ typedef struct {
                              in [.5,1) or is dropped (> 1), depending on rounding, exactly as in the reference.
                              1 (opt-in, an INTENTIONAL deviation): |cos - 1| <= 4 ulp counts as 1 -> every exact match lands in {1},
                              independent of the reduction order (deterministic across devices) */
+    const signed char* self_bin; /* device [V] or NULL.  Row v: the numpy.histogram bin (0..4, -1 = outside [-1,1] = dropped) of
+                             cosine_similarity(table[v], table[v]) AS THE REFERENCE'S HOST PATH ROUNDS IT (drmm.py:66-75: <1 -> [.5,1),
+                             ==1 -> {1}, >1 -> dropped; a zero / PAD row -> 0 -> [0,.5)).  That value is a pure function of the row (bit-equal
+                             between the reference's materialised [B*N,QL,DL,E] call and cosine_similarity(table, table, 1) on the host,
+                             independent of the thread count), so the host computes it once per table version and the kernel takes the bin
+                             of every q_id == d_id hit from here: the integer histograms then equal the reference's at exact token
+                             matches.  NULL: the kernel bins its own fp32 cosine there (reduction-order dependent). */
 } nir_drmm_weights;
 /* hist_out (optional, may be NULL): [B*N, QL, 5] matching-histogram counts as float. */
 int nir_drmm_score(const int64_t* q_ids, const int64_t* d_ids, int B, int N, int QL, int DL,

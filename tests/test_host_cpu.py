@@ -585,3 +585,45 @@ def test_sharded_session_stream_gloo(tmp_path, world):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in o, o
+
+
+def test_drmm_self_cosine_bins_reproduce_the_oracle_at_exact_matches():
+    """rankers.drmm.histogram_bin == numpy.histogram(bins=[-1,-.5,0,.5,1,1]) element by element, and self_cosine_bins(table)[v] is the bin
+    the oracle's materialised [B*N,QL,DL,E] cosine (reference drmm.py:59-75) gives EVERY q_id == d_id hit -- the per-row class table the
+    HIP kernel looks up (host logic only; the GPU side is tests/test_gpu_parity.py::test_drmm_golden_overlap_exact)."""
+    from context_attentive_ir_amd.rankers.drmm import histogram_bin, self_cosine_bins
+    from helpers import cpu_state_dict
+    from oracle import neuroir_cpu as O
+    one = np.float32(1)
+    c = np.array([-1.5, -1, -0.7, -0.5, -0.2, 0, 0.3, 0.5, 0.9, np.nextafter(one, np.float32(0)), 1.0, np.nextafter(one, np.float32(2)), np.nan], np.float32)
+    want = [int(np.argmax(h)) if h.sum() else -1 for h in (np.histogram([x], bins=O.DRMM_BINS)[0] for x in c)]
+    assert histogram_bin(c).tolist() == want and histogram_bin(torch.from_numpy(c)).tolist() == want
+    V = 500
+    m = build_model("DRMM", vocab=V)
+    sd = cpu_state_dict(m)
+    bins = self_cosine_bins(m.word_embeddings.table)
+    assert bins.dtype == torch.int8 and bins.shape == (V,) and int(bins[0]) == 2            # PAD row: cos = 0 -> [0,.5)
+    assert {int(b) for b in bins[1:].unique()} == {-1, 3, 4}                                  # >1 dropped, <1, ==1: all three occur
+    rng = np.random.default_rng(7)
+    B, N, QL, DL = 3, 4, 5, 30
+    q = torch.from_numpy(rng.integers(1, 60, size=(B, QL))); d = torch.from_numpy(rng.integers(0, 60, size=(B, N, DL)))
+    _, cos, _ = O.drmm_parts(sd, q, d)
+    hit = (q.view(B, 1, QL, 1) == d.view(B, N, 1, DL)).reshape(B * N, QL, DL)
+    assert int(hit.sum()) > 20
+    got = torch.from_numpy(histogram_bin(cos.numpy()))
+    exp = bins[q].view(B, 1, QL, 1).expand(B, N, QL, DL).reshape(B * N, QL, DL)
+    assert torch.equal(got[hit], exp[hit])
+    g = load_golden("drmm_overlap")                        # and on the real reference's fixture: rebuild its histogram from the table
+    m2 = build_model("DRMM")
+    t = m2.word_embeddings.table.detach()
+    b2 = self_cosine_bins(t)
+    qg, dg = torch.from_numpy(g["que_rep"]), torch.from_numpy(g["doc_rep"])
+    Bg, Ng, DLg = dg.shape
+    QLg = qg.shape[1]
+    tn = t / t.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    cs = torch.einsum("bqe,bnde->bnqd", tn[qg], tn[dg]).reshape(Bg * Ng, QLg, DLg)      # any rounding: only used away from the edges
+    hb = torch.from_numpy(histogram_bin(cs.numpy())).long()
+    hit = (qg.view(Bg, 1, QLg, 1) == dg.view(Bg, Ng, 1, DLg)).reshape(Bg * Ng, QLg, DLg)
+    hb[hit] = b2[qg].long().view(Bg, 1, QLg, 1).expand(Bg, Ng, QLg, DLg).reshape(Bg * Ng, QLg, DLg)[hit]
+    hist = torch.stack([(hb == k).sum(-1) for k in range(5)], -1).numpy()
+    np.testing.assert_array_equal(hist, g["hist"].astype(np.int64))
