@@ -34,6 +34,8 @@ right after the timed region; algorithmic flops / bytes per launch are priced fr
 8 TB/s; fp32 MFMA 157.3 TFLOP/s; fp16 / bf16 MFMA 2500 TFLOP/s (a two-term fp16 split executes 3 MFMAs per product, a three-term bf16 split 6).
 cpu_baseline: the pinned CPU oracle (oracle/neuroir_cpu.py) on the host cores, bounded sample, rank 0 at N = 1 only.
 """
+import os
+os.environ.setdefault("NIR_DEBUG_TUNABLES", "1")      # the isolated-kernel profile pass switches the library's internal fork off (nir_debug_set_tunable)
 import argparse
 import ctypes
 import json

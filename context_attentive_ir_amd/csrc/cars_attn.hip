@@ -585,320 +585,6 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Weights-stationary form of the pipeline for the term-pair rows of the fp32-accurate recurrence (IN = 2).
-// attn_pool_pipe_kernel streams all of W0 (256 KB as two fp16 terms) from L2 for every 64-row tile -- 2.3 GB per C3 macro-batch, ~9 TB/s of L2
-// reads while it runs -- and keeps the matrix pipe of a SIMD idle while its one MMA wave does the tanh / row-dot epilogue.  Here
-//   * W0 lives in REGISTERS for the whole launch: wave w of 8 owns columns [32 w, 32 w + 32) = 32 fragments = 128 VGPRs (like W_hh in the recurrence);
-//   * the rows of a tile are staged VERBATIM -- one global_load_lds_dwordx4 per 1 KB row, no registers, no layout arithmetic: the recurrence's
-//     hand-over format (per 4 units: 4 x fp16 leading | 4 x fp16 residual) is read as MFMA A fragments by two 8-byte pieces 16 bytes apart
-//     (one ds_read2_b64), row pitch 1040 bytes = conflict-free for the 16 rows of a fragment;
-//   * both waves of a SIMD run MFMAs, half a tile period apart: while the waves of group A (0-3) are in the k-loop of tile k, those of group
-//     B (4-7) do the epilogue of tile k-1, then -- behind a mid barrier, when all eight partial row-dots of k-1 are in LDS -- its softmax and
-//     weighted sum; in the other half B runs its k-loop while A does its epilogue and stages tile k+1 into the buffer B has just released.
-// Interval schedule (every line ends in a workgroup barrier; `|` = the mid barrier):
-//     2k   :  A  K(k) first half | K(k) second half          B  E(k-1) | softmax(k-1), weighted sum(k-1) -> pooled
-//     2k+1 :  A  request rows(k+1), E(k), wait for the rows    B  K(k)
-// Two row buffers: rows(k) are read by K(k) of A (2k), K(k) of B (2k+1) and the weighted sum (2k+2); rows(k+2) arrive in 2k+3.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int WS_PITCH = 1040;                                  // bytes per staged row (256 units x 4 B + 16)
-constexpr int WS_BUF = AP_ROWS * WS_PITCH;                      // 66 560
-constexpr size_t WS_LDS = (size_t)2 * WS_BUF + (8 * 64 + 4 * 64 + 2 * AP_D) * 4;      // rows x 2, rowpart[8][64], probw[4][64], b0 C2 / w3
-
-typedef unsigned int wsu4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(512, 1) void attn_pool_ws_kernel(AttnPoolArgs p, int64_t ntiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ws_[];
-    float* rowpart = reinterpret_cast<float*>(ws_ + 2 * WS_BUF);           // [8 waves][64 rows]
-    float* probw = rowpart + 8 * 64;                                        // [4 B waves][64 rows]
-    float* bw = probw + 4 * 64;                                             // [256] b0 * C2, [256] w3
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w4 = wave & 3;
-    const bool grpB = wave >= 4;                                            // wave-uniform
-    const int g = lane >> 4, c16 = lane & 15;
-    const int T = p.T;
-    const int64_t nrows = p.M * T, G = gridDim.x;
-    const int64_t nk = (ntiles - (int64_t)blockIdx.x + G - 1) / G;          // tiles of this workgroup: blockIdx.x + k G
-    constexpr float C2 = 2.8853900817779268f, ISC = 1.0f / 2048.0f;
-
-    // ---- W0 columns [32 wave, 32 wave + 32) as MFMA B fragments, both terms, all eight k-steps: resident for the launch
-    f16x8 wf[AP_S][2][2];
-#pragma unroll
-    for (int ks = 0; ks < AP_S; ++ks)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                wf[ks][j][t] = *reinterpret_cast<const f16x8*>(p.wf + ((((int64_t)ks * 16 + (2 * wave + j)) * 2 + t) * 64 + lane) * 8);
-    for (int i = tid; i < AP_D; i += 512) {
-        bw[i] = p.b0[i] * C2;
-        bw[AP_D + i] = p.w3[i];
-    }
-    const float b3v = p.b3[0];
-    // Per-phase address arithmetic starts from an OPAQUE copy of the lane index: derived addresses cannot be hoisted out of the tile loop and
-    // parked in registers for the whole launch (W0 and the accumulators leave ~60; the hoisted invariants were spilled and re-read from
-    // scratch inside every phase)
-    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-    // rows(k) -> buffer k & 1: the four A waves request 16 rows each, one instruction per row (lane l: bytes 16 l .. 16 l + 15 of the row)
-    auto request_rows = [&](int64_t k) {
-        const int ln = fresh_lane();
-        const int w4s = __builtin_amdgcn_readfirstlane(w4);                 // scalar row index: the row base is an SGPR pair, the lane adds 16 l
-        const int64_t row0 = ((int64_t)blockIdx.x + k * G) * AP_ROWS + 16 * w4s;
-        unsigned char* dst = ws_ + (k & 1) * WS_BUF + 16 * w4s * WS_PITCH;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int64_t r = row0 + i;
-            r = r < nrows ? r : nrows - 1;                                  // rows past the end belong to sequences that are never written
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.h + r * AP_D + 4 * ln), (lds_ptr_t)(dst + i * WS_PITCH), 16, 0, 0);
-        }
-    };
-    f32x4 acc[2][AP_RT], acx[2][AP_RT];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < AP_RT; ++i) {
-                acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acx[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-    };
-    // k-steps [S0, S1) of tile k.  A fragment (16 rows x 32 k of one term) = the two 8-byte pieces 16 bytes apart of the lane's row: ONE
-    // ds_read2_b64 puts them into four consecutive registers (two ds_read_b128 + eight v_mov per fragment is what the compiler made of the
-    // equivalent C).  Work is cut into groups (k-step, row-tile pair) = 4 fragments, 12 MFMAs (no two adjacent on one accumulator); the
-    // fragments of group n+1 are requested before the MFMAs of group n are issued, and waited for with a counted lgkmcnt.
-    typedef __attribute__((address_space(3))) unsigned char* lds_u8_t;
-    auto frag = [&](auto KSc, auto TRMc, uint32_t addr) {
-        constexpr int o0 = 16 * decltype(KSc)::value + decltype(TRMc)::value, o1 = o0 + 2;      // units of 8 bytes
-        wsu4 v;
-        asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(o0), "n"(o1));
-        return v;
-    };
-    // unit n = (k-step n / 4, row tile n % 4): two fragments (8 registers), six MFMAs (an accumulator recurs every second MFMA); the fragments of
-    // unit n + 1 are requested before the MFMAs of unit n are issued, and waited for with a counted lgkmcnt
-    auto unit_load = [&](auto Nc, uint32_t a0, wsu4& t1, wsu4& t2) {
-        constexpr int n = decltype(Nc)::value, ks = n / 4, i = n % 4;
-        const uint32_t ra = a0 + (uint32_t)(16 * i * WS_PITCH);
-        t1 = frag(std::integral_constant<int, ks>{}, std::integral_constant<int, 0>{}, ra);
-        t2 = frag(std::integral_constant<int, ks>{}, std::integral_constant<int, 1>{}, ra);
-    };
-    auto unit_mma = [&](auto Nc, wsu4& t1, wsu4& t2) {
-        constexpr int n = decltype(Nc)::value, ks = n / 4, i = n % 4;
-        asm volatile("" : "+v"(t1), "+v"(t2));                                // (volatile: behind the counted wait in front of this call)
-        const f16x8 a1 = __builtin_bit_cast(f16x8, t1), a2 = __builtin_bit_cast(f16x8, t2);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wf[ks][j][0], acc[j][i], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acx[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wf[ks][j][0], acx[j][i], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acx[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wf[ks][j][1], acx[j][i], 0, 0, 0);
-    };
-    auto ksteps = [&](int64_t k, auto S0c, auto S1c) {
-        constexpr int N0 = 4 * decltype(S0c)::value, N1 = 4 * decltype(S1c)::value;
-        const int ln = fresh_lane();
-        const uint32_t a0 = (uint32_t)(uintptr_t)(lds_u8_t)(ws_) + (uint32_t)((k & 1) * WS_BUF + (ln & 15) * WS_PITCH + 32 * (ln >> 4));
-        if (p.io_prio) __builtin_amdgcn_s_setprio(2);                         // (tunable attn_io_prio: the wave in its k-loop above its partner's VALU phase)
-        wsu4 p1, p2, q1, q2;                                                  // two fragment pairs: the unit in the MFMAs, the unit in flight
-        unit_load(std::integral_constant<int, N0>{}, a0, p1, p2);
-        auto run = [&](auto self, auto Nc) {
-            constexpr int n = decltype(Nc)::value;
-            if constexpr (n < N1) {
-                if constexpr (n + 1 < N1) {
-                    unit_load(std::integral_constant<int, n + 1>{}, a0, q1, q2);
-                    asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                unit_mma(Nc, p1, p2);
-                if constexpr (n + 1 < N1) {
-                    if constexpr (n + 2 < N1) {
-                        unit_load(std::integral_constant<int, n + 2>{}, a0, p1, p2);
-                        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
-                    unit_mma(std::integral_constant<int, n + 1>{}, q1, q2);
-                    self(self, std::integral_constant<int, n + 2>{});
-                }
-            }
-        };
-        run(run, std::integral_constant<int, N0>{});
-        if (p.io_prio) __builtin_amdgcn_s_setprio(0);
-    };
-    // nothing may be scheduled across this point: a barrier written behind it cannot drift into the MFMA stream (an asm "memory" clobber orders
-    // memory operations only -- lstm_fold.hip, lstm16_pt_h2s_kernel)
-    auto pin_acc = [&]() { __builtin_amdgcn_sched_barrier(0); };
-    // tanh, times w3, summed over this wave's 32 columns: sum_c w3_c tanh(z_c) = -2 (sum_c w3_c / (1 + 2^(C2 z_c)) - sum_c w3_c / 2)
-    auto epilogue = [&]() {
-        const int ln = fresh_lane();
-        const int c16 = ln & 15, g = ln >> 4;
-        float* rpw = rowpart + wave * 64 + 4 * g;
-        float rs[AP_RT][4], bzv[2], w3v[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = 32 * wave + 16 * j + c16;
-            bzv[j] = bw[col];
-            w3v[j] = bw[AP_D + col];
-        }
-        const float r0 = -0.5f * (w3v[0] + w3v[1]);
-#pragma unroll
-        for (int i = 0; i < AP_RT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rs[i][r] = r0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < AP_RT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float z = fmaf(fmaf(acx[j][i][r], ISC, acc[j][i][r]), C2, bzv[j]);
-                    rs[i][r] = fmaf(w3v[j], __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), rs[i][r]);
-                }
-        // the 16 row sums over the 16 column lanes: step by step ACROSS the values (16 independent chains: no DPP wait states), then one
-        // 16-byte store per row tile from the lanes of column 0
-#pragma unroll
-        for (int i = 0; i < AP_RT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rs[i][r] += dpp_mov<0xB1>(rs[i][r]);
-#pragma unroll
-        for (int i = 0; i < AP_RT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rs[i][r] += dpp_mov<0x4E>(rs[i][r]);
-#pragma unroll
-        for (int i = 0; i < AP_RT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rs[i][r] += dpp_mov<0x141>(rs[i][r]);
-#pragma unroll
-        for (int i = 0; i < AP_RT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rs[i][r] += dpp_mov<0x140>(rs[i][r]);
-        if (c16 == 0) {
-#pragma unroll
-            for (int i = 0; i < AP_RT; ++i)
-                *reinterpret_cast<float4*>(rpw + 16 * i) = make_float4(-2.0f * rs[i][0], -2.0f * rs[i][1], -2.0f * rs[i][2], -2.0f * rs[i][3]);
-        }
-    };
-    // softmax over each sequence of tile k (lane = row; every B wave computes all 64 rows for itself), then the weighted sum of the wave's
-    // column block [64 w4, 64 w4 + 64) straight from the staged rows: lane = (row subgroup lane >> 4, 4 units 4 c16 ..), rows 4 q + subgroup
-    auto finish = [&](int64_t k, int len_row) {
-        const int lane = fresh_lane();
-        const int c16 = lane & 15;
-        const int64_t rowS = ((int64_t)blockIdx.x + k * G) * AP_ROWS;
-        float* pw = probw + w4 * 64;
-        {
-            const int64_t r = rowS + lane;
-            const int64_t seq = r >> p.logT;
-            const int t = (int)(r - seq * T);
-            int len = len_row;
-            len = len < 0 ? 0 : (len > T ? T : len);
-            const bool ok = seq < p.M && t < len;
-            float lg = b3v;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) lg += rowpart[w * 64 + lane];
-            const float mx = ap_group_max(ok ? lg : -INFINITY, T);
-            const float e = ok ? __expf(lg - mx) : 0.f;
-            const float den = ap_group_sum(e, T);
-            pw[lane] = e / den;                                          // len == 0: 0/0 = NaN, like softmax over an all -inf row
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        const int sub = lane >> 4, per = T / 4;
-        const int col = 64 * w4 + 4 * c16;
-        const unsigned char* src = ws_ + (k & 1) * WS_BUF + col * 4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {                                    // eight rows at a time (two LDS round trips per tile; the accumulators are dead here)
-            uint4 u[8];
-            float prr[8];
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) {
-                const int row = 4 * (8 * hb + q8) + sub;
-                u[q8] = *reinterpret_cast<const uint4*>(src + row * WS_PITCH);
-                prr[q8] = pw[row];
-            }
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) {
-                const int q = 8 * hb + q8;
-                ap_fma_mix(a, make_uint2(u[q8].x, u[q8].y), prr[q8]);
-                ap_fma_mix(a, make_uint2(u[q8].z, u[q8].w), prr[q8] * ISC);
-                if (((q + 1) & (per - 1)) == 0) {                           // sequence complete: fold the four row subgroups, subgroup 0 stores
-                    a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
-                    a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
-                    const int64_t seq = (rowS >> p.logT) + (q >> (p.logT - 2));
-                    if (sub == 0 && seq < p.M) *reinterpret_cast<float4*>(p.pooled + seq * AP_D + col) = a;
-                    a = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-    };
-    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-    if (!grpB && nk > 0) request_rows(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (W fragments and rows(0))
-    __syncthreads();
-#ifdef AP_TIMING
-#define WS_T(I) if (blockIdx.x == 7 && (tid & 255) == 0 && k == 5) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ap_dbg[(grpB ? 8 : 0) + (I)] = __builtin_readcyclecounter(); }
-#else
-#define WS_T(I)
-#endif
-    for (int64_t k = 0; k <= nk; ++k) {
-        // ---------------- interval 2k
-        WS_T(0)
-        if (!grpB) {
-            if (k < nk) {
-                zero_acc();                     // (dead until here: the registers are free during the other phases)
-                ksteps(k, std::integral_constant<int, 0>{}, std::integral_constant<int, AP_S / 2>{});
-            }
-            WS_T(1)
-            bar();
-            WS_T(2)
-            if (k < nk) ksteps(k, std::integral_constant<int, AP_S / 2>{}, std::integral_constant<int, AP_S>{});
-            pin_acc();
-            WS_T(3)
-        } else {
-            int len_row = T;
-            if (k >= 1) {
-                const int64_t seq = ((((int64_t)blockIdx.x + (k - 1) * G) * AP_ROWS) + lane) >> p.logT;
-                if (p.lens) len_row = (int)p.lens[seq < p.M ? seq : p.M - 1];   // (arrives under the epilogue)
-#ifndef WS_X_NOEPI
-                epilogue();
-#endif
-            }
-            WS_T(1)
-            bar();
-            WS_T(2)
-#ifndef WS_X_NOFINISH
-            if (k >= 1) finish(k - 1, len_row);
-#endif
-            WS_T(3)
-        }
-        bar();
-        WS_T(4)
-        // ---------------- interval 2k + 1
-        if (!grpB) {
-#ifndef WS_X_NODMA
-            if (k + 1 < nk) request_rows(k + 1);
-#endif
-            WS_T(5)
-#ifndef WS_X_NOEPI
-            if (k < nk) epilogue();
-#endif
-            WS_T(6)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-#ifndef WS_X_NOKB
-            if (k < nk) {
-                zero_acc();
-                ksteps(k, std::integral_constant<int, 0>{}, std::integral_constant<int, AP_S>{});
-            }
-#endif
-            pin_acc();
-            WS_T(5)
-            WS_T(6)
-        }
-        WS_T(7)
-        bar();
-    }
-}
-
 #ifdef AP_TIMING
 }  // namespace nir
 extern "C" int nir_debug_attn_timing(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(nir::ap_dbg), sizeof(long long) * 16); }
@@ -935,8 +621,7 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
     // (profile label = the kernel that runs: the role-specialised pipeline by template arguments, else the single-role kernel)
     const bool pipe_sel = attn_pool_pipe_selected(M, T);
-    const bool ws_sel = in_f16 == 2 && tun(g_tun.attn_ws) == 1;            // weights-stationary form of the term-pair pipeline (tunable attn_ws: 0 = streamed W0)
-    const char* pname = !pipe_sel ? "attn_pool_fused_kernel" : in_f16 == 1 ? "attn_pool_pipe_kernel<true,1>" : in_f16 == 2 ? (ws_sel ? "attn_pool_ws_kernel" : "attn_pool_pipe_kernel<false,2>") :
+    const char* pname = !pipe_sel ? "attn_pool_fused_kernel" : in_f16 == 1 ? "attn_pool_pipe_kernel<true,1>" : in_f16 == 2 ? "attn_pool_pipe_kernel<false,2>" :
                         one_term ? "attn_pool_pipe_kernel<true,0>" : "attn_pool_pipe_kernel<false,0>";
     ProfScope ps(prof_shape_name(pname, M * T, AP_D, AP_D), st);
     static std::once_flag once2;
@@ -945,14 +630,12 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
         (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
         (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
         (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_pool_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS);
     });
     const int ncu = ap_cu_count();
     if (pipe_sel) {                                                        // several tiles per CU: the role-specialised pipeline
         const dim3 grid((unsigned)std::min<int64_t>(tiles, ncu));
         NIR_REQUIRE(in_f16 != 2 || !one_term, "attn_pool_fused: term-pair rows come from the fp32-accurate encoder (two terms)");
         if (in_f16 == 1) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, 1>), grid, dim3(512), AP2_LDS, st, a, tiles);
-        else if (in_f16 == 2 && ws_sel) hipLaunchKernelGGL(attn_pool_ws_kernel, grid, dim3(512), WS_LDS, st, a, tiles);
         else if (in_f16 == 2) hipLaunchKernelGGL((attn_pool_pipe_kernel<false, 2>), grid, dim3(512), AP2_LDS, st, a, tiles);
         else if (one_term) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, 0>), grid, dim3(512), AP2_LDS, st, a, tiles);
         else hipLaunchKernelGGL((attn_pool_pipe_kernel<false, 0>), grid, dim3(512), AP2_LDS, st, a, tiles);

@@ -87,7 +87,6 @@ struct LstmPtArgs {
                             // element, but every group of 4 consecutive units holds [4 x fp16 leading term | 4 x fp16 residual x 2^11] -- the two-term
                             // split the kernel forms anyway for its own next step, in the order attn_pool_pipe_kernel stages its LDS planes
     const void* whh_frag;   // optional: W_hh pre-split into the two fp16 terms, in the lane order of lstm16_pt_h2_kernel<4,4,8> (nir_lstm_pack_whh_frag)
-    int skew_prio = 0;      // lstm16_pt_h2s_kernel: issue priority for the role-0 waves (measurement knob)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -909,799 +908,6 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// lstm16_pt_h2_kernel<4,4,8> with the output stores taken off the waves that request gate rows (H = 128, split-term output).
-// Vector memory retires IN ORDER per wave, loads and stores alike, and a store's acknowledgement takes longer than a step under this kernel's
-// write load: a wave whose queue holds [store of h(s-1), 4 row requests for s+1] waits for that store whenever it waits for its rows (the
-// stores cost 14 % of the launch while their issue costs 3 %: tools/recur_micro.py, -DNIR_X_NOSTORE).  Here
-//   * ONE wave -- the last of the high-priority waves, which reach the step's barrier ~1 300 ticks early -- stores the output of ALL waves:
-//     the two fp16 terms of h(s-1) lie in the h buffer the MFMAs of step s read, which IS the hand-over format; two sequences' rows per
-//     instruction, 512 contiguous bytes each (the owning lanes stored 16 x 64 bytes).  It never waits on the vector-memory counter;
-//   * that wave issues no loads: its own gate rows are requested by another high-priority wave, global -> LDS (global_load_lds_dwordx4),
-//     two steps ahead into a ring of three 4 KB slots, and taken over as MFMA C operands with four ds_read_b128;
-//   * every other wave requests its rows into registers as before -- its queue now holds loads only.
-// (A first version moved ALL requests and stores onto the high-priority waves: 895 us against 617 us with both kinds on one wave, 640 us with
-// requesters and storer separated -- the in-order coupling itself, measured.)
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void lstm16_pt_h2v_kernel(LstmPtArgs p) {
-    constexpr int KB = 4, NT = 4, NW = 8, NTH = 64 * NW, SEQ = 16, KP = 32 * KB, ZLD = KP + 8, H = 128, H4 = 4 * H, RING = 3;
-    constexpr uint32_t OOB = 0x7FFFFFF0u;
-    constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
-    const int TP = p.T + 3;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* z = reinterpret_cast<_Float16*>(smem);        // [2 buffers][2 terms][SEQ][ZLD]
-    int* lens_s = reinterpret_cast<int*>(z + 4 * SEQ * ZLD);
-    int* simd_s = lens_s + SEQ;
-    int* ids_s = simd_s + 16;                               // [SEQ][TP]
-    float* rows_s = reinterpret_cast<float*>(ids_s + ((SEQ * TP + 3) & ~3));      // [2 storers][RING][4 tiles][64 lanes][4]: their gate rows, LDS-direct
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sq = lane & 15, kq = lane >> 4;
-    const int dir = blockIdx.y;
-    const int64_t m0 = (int64_t)blockIdx.x * SEQ;
-    const int T = p.T;
-    const int nvalid = (int)min((int64_t)SEQ, p.M - m0);
-    const int OW = p.ND * H;
-    const int64_t GW = (int64_t)p.ND * H4;
-    f16x8 w1[NT][KB], w2[NT][KB];
-    const bool use_frag = p.whh_frag != nullptr;            // wave-uniform
-    if (use_frag) {
-        const f16x8* fp = reinterpret_cast<const f16x8*>(p.whh_frag) + ((size_t)(dir * NW + wave) * NT * KB * 2) * 64 + lane;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                w1[t][kb] = fp[((t * KB + kb) * 2 + 0) * 64];
-                w2[t][kb] = fp[((t * KB + kb) * 2 + 1) * 64];
-            }
-    }
-    if (lane == 0) simd_s[wave] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));   // HW_REG_HW_ID bits [5:4] = SIMD_ID
-    if (tid < SEQ) {
-        int l = 0;
-        if (tid < nvalid) {
-            l = p.lens ? (int)p.lens[m0 + tid] : T;
-            l = l < 0 ? 0 : (l > T ? T : l);
-        }
-        lens_s[tid] = l;
-    }
-    lds_barrier();
-    {
-        bool bad = false;
-        for (int e = tid; e < SEQ * TP; e += NTH) {
-            const int s_ = e / TP, k = e - s_ * TP;
-            int64_t id = 0;
-            if (s_ < nvalid) {
-                const int l = lens_s[s_];
-                int kk = k < l - 1 ? k : l - 1;
-                kk = kk < 0 ? 0 : kk;
-                int t_ = dir == 0 ? kk : l - 1 - kk;
-                t_ = t_ < 0 ? 0 : t_;
-                id = p.ids[(m0 + s_) * T + t_];
-                if (k < T) {
-                    const int64_t raw = p.ids[(m0 + s_) * T + k];
-                    bad |= raw < 0 || raw >= p.V;
-                }
-            }
-            if (id < 0 || id >= p.V) id = 0;
-            ids_s[e] = (int)id;
-        }
-        if (bad && p.err) atomicOr(p.err, 1);
-    }
-    for (int e = tid; e < 2 * SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;
-    lds_barrier();
-    int tmax = 0;
-#pragma unroll
-    for (int s2 = 0; s2 < SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
-    // rank among the waves of the same SIMD: rank 0 = high issue priority = the wave that reaches the barrier early = the one that does the
-    // vector memory; hidx / nh = its index among / the number of such waves (4 of 8 with the usual two waves per SIMD)
-    bool hi;
-    int hidx = 0, nh = 0, sw = 0, sw2 = 0;                  // sw / sw2: wave indices of the last / second-to-last high-priority wave (the storers)
-    {
-        const int mine = simd_s[wave];
-        int rank = 0;
-#pragma unroll
-        for (int w2_ = 0; w2_ < NW; ++w2_) {
-            int r2 = 0;
-#pragma unroll
-            for (int w3_ = 0; w3_ < NW; ++w3_) r2 += (w3_ < w2_ && simd_s[w3_] == simd_s[w2_]) ? 1 : 0;
-            if (r2 == 0) {
-                hidx += w2_ < wave ? 1 : 0;
-                nh += 1;
-                sw2 = sw;
-                sw = w2_;
-            }
-            rank += (w2_ < wave && simd_s[w2_] == mine) ? 1 : 0;
-        }
-        rank = __builtin_amdgcn_readfirstlane(rank);
-        hidx = __builtin_amdgcn_readfirstlane(hidx);
-        nh = __builtin_amdgcn_readfirstlane(nh);
-        sw = __builtin_amdgcn_readfirstlane(sw);
-        sw2 = __builtin_amdgcn_readfirstlane(sw2);
-        hi = rank == 0;
-        if (rank == 0) __builtin_amdgcn_s_setprio(3);
-        else if (rank == 1) __builtin_amdgcn_s_setprio(2);
-        else if (rank == 2) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-    }
-    float creg[NT];
-    const int u0 = NT * (4 * wave + kq);
-    bool wbad = false;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        creg[t] = 0.f;
-        if (use_frag) continue;
-        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
-        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + unit_a) * H;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int k0 = 32 * kb + 8 * kq;
-            const float4 a = *reinterpret_cast<const float4*>(wr + k0), b = *reinterpret_cast<const float4*>(wr + k0 + 4);
-            const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hh = (_Float16)wv[j];
-                w1[t][kb][j] = hh;
-                w2[t][kb][j] = (_Float16)((wv[j] - (float)hh) * SC);
-                wbad |= !(fabsf(wv[j]) < 32768.0f);
-            }
-        }
-    }
-    if (wbad && p.err) atomicOr(p.err, 2);
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0, (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
-    // roles (wave-uniform).  With fewer than two high-priority waves (never seen: the hardware places the eight waves two per SIMD) every wave
-    // stores its own output from registers, like the plain kernel
-    const bool scheme = nh >= 4;
-    // two storers (the last two high-priority waves: sequences 0-7 / 8-15), two helpers (the first two: helper j requests the rows of storer j)
-    const int sidx = hidx - (nh - 2);                        // 0 / 1 for the storers
-    const bool storer = scheme && hi && sidx >= 0, helper = scheme && hi && hidx < 2;
-    const int served = hidx == 0 ? sw2 : sw;                 // (helper) the wave it requests rows for
-    const int myslot = storer ? sidx : hidx;                 // ring half: storer j reads what helper j wrote
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-    const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;
-    const float* pb = ptf + 4 * u0;                          // the lane's 64 contiguous bytes (4 units x 4 gates) of a folded row
-    const uint32_t gw = (uint32_t)GW;
-    const int* idp = ids_s + sq * TP;
-    f32x4 gnext[NT];
-    auto load_g = [&](int id) {
-        const uint64_t ro = (uint64_t)(uint32_t)id * gw;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) gnext[t] = *reinterpret_cast<const f32x4*>(pb + ro + 4 * t);
-    };
-    // the storer's rows of step `step` (helper only): lane (sq, kq) of tile t of wave sw owns unit NT (4 sw + kq) + t
-    auto request_for_storer = [&](int step) {
-        const uint64_t ro = (uint64_t)(uint32_t)idp[step] * gw;
-        const float* src = ptf + ro + 4 * (NT * (4 * served + kq));
-        float* dst = rows_s + (size_t)(myslot * RING + step % RING) * (NT * 64 * 4);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + 4 * t), (lds_ptr_t)(dst + t * 64 * 4), 16, 0, 0);
-    };
-    // h(step) of all waves (storer only): its two term planes are in the h buffer (step + 1) & 1 -- written during step `step`, read by the
-    // MFMAs of step + 1.  Lane l of instruction i stores the 16 bytes [4 x leading | 4 x residual] of units 4 (l & 31) .. of sequence 2 i + (l >> 5)
-    auto store_h = [&](int step) {
-        const _Float16* zb = z + ((step + 1) & 1) * 2 * SEQ * ZLD;
-        uint2 t1[4], t2[4];
-        int len[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                                        // all LDS reads first: one round trip for the four instructions
-            const int s_ = 8 * sidx + 2 * i + (lane >> 5), gq = lane & 31;
-            len[i] = lens_s[s_];
-            t1[i] = *reinterpret_cast<const uint2*>(zb + s_ * ZLD + 4 * gq);
-            t2[i] = *reinterpret_cast<const uint2*>(zb + SEQ * ZLD + s_ * ZLD + 4 * gq);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int s_ = 8 * sidx + 2 * i + (lane >> 5), gq = lane & 31;
-            const int tt = dir == 0 ? step : len[i] - 1 - step;
-            const uint32_t off = step < len[i] ? (uint32_t)(((s_ * T + tt) * OW + dir * H + 4 * gq) * 4) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){t1[i].x, t1[i].y, t2[i].x, t2[i].y}, out_rs, off, 0, 0);
-        }
-    };
-    const int mylen = lens_s[sq];
-    uint32_t soff = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen - 1)) * OW + dir * H + u0) * 4);      // (!scheme: own stores)
-    const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
-    if (helper) {
-        request_for_storer(0);
-        request_for_storer(1);
-    }
-    if (!storer) load_g(idp[0]);
-    int id_n = idp[1];
-    if (helper) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    f32x4 acc[NT], acx[NT];
-    float hn[NT] = {};
-#ifdef NIR_X_NOGATES
-    auto gates = [&](int t) { hn[t] = (acx[t][0] + acc[t][1]) * 1e-3f; };
-#else
-    auto gates = [&](int t) { lstm_cell_v(acx[t] * ISC + acc[t], creg[t], hn[t]); };
-#endif
-    for (int step = 0; step < tmax; ++step) {
-        const _Float16* zc = z + (step & 1) * 2 * SEQ * ZLD;
-        _Float16* zn = z + ((step + 1) & 1) * 2 * SEQ * ZLD;
-        const _Float16* zr = zc + sq * ZLD + 8 * kq;
-        f16x8 hh1[KB], hh2[KB];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            hh1[kb] = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
-            hh2[kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
-        }
-        if (storer) {
-            const float* rs = rows_s + (size_t)(myslot * RING + step % RING) * (NT * 64 * 4) + lane * 4;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(rs + t * 64 * 4);
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = gnext[t];              // the gate rows ride in as the MFMA's C operand
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh1[kb], acc[t], 0, 0, 0);
-                acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh2[kb], acx[t], 0, 0, 0);
-                acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], hh1[kb], acx[t], 0, 0, 0);
-            }
-            if (t == 0) {
-                if (!storer) {
-                    load_g(id_n);                                        // rows of step + 1 (past the end: a repeated id, never used)
-                    if (helper && step + 2 < tmax) request_for_storer(step + 2);
-                }
-                id_n = idp[step + 2];
-            } else {
-                gates(t - 1);
-#pragma unroll
-                for (int q = 0; q < 3 * KB; ++q) {       // one MFMA, then three of the previous tile's VALU instructions, ...
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
-            }
-        }
-        gates(NT - 1);
-        {
-            _Float16 a[NT], r[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                a[t] = (_Float16)hn[t];
-                r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
-            }
-            const f16x4 av = (f16x4){a[0], a[1], a[2], a[3]}, rv = (f16x4){r[0], r[1], r[2], r[3]};
-            *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = av;
-            *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = rv;
-            if (!scheme) {                                               // own output, from registers
-                const u32x2 au = __builtin_bit_cast(u32x2, av), ru = __builtin_bit_cast(u32x2, rv);
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){au[0], au[1], ru[0], ru[1]}, out_rs, step < mylen ? soff : OOB, 0, 0);
-                soff += sstep;
-            }
-        }
-        if (storer && step > 0) store_h(step - 1);                      // in the time this wave would wait at the barrier (h(step - 1): buffer step & 1, read-only now)
-        if (helper) {
-            // the storer's rows of step + 1 (requested during step - 1) must be in LDS when the barrier below releases the step that reads
-            // them; behind them in this wave's queue: its own 4 rows of step + 1 and the storer's 4 of step + 2, both requested in this step
-            if (step + 2 < tmax) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        lds_barrier();
-    }
-    if (storer && tmax > 0) store_h(tmax - 1);
-    // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced (ragged batches are the normal case)
-    for (int s_ = 0; s_ < nvalid; ++s_) {
-        float* orow = p.out + (m0 + s_) * T * OW + (int64_t)dir * H;
-        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
-            for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = 0.f;
-    }
-}
-
-static int launch_pt_h2v(const LstmPtArgs& p, hipStream_t st) {
-    const size_t lds = (size_t)(4 * 16 * (32 * 4 + 8)) * 2 + 2 * 16 * 4 + (size_t)((16 * (p.T + 3) + 3) & ~3) * 4 + (size_t)2 * 3 * 4 * 64 * 16;
-    ProfScope ps(prof_shape_name("lstm16_pt_h2v_kernel", (long long)p.M, p.T, p.H), st);
-    static bool attr = [] {
-        return hipFuncSetAttribute((const void*)lstm16_pt_h2v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
-    }();
-    (void)attr;
-    hipLaunchKernelGGL(lstm16_pt_h2v_kernel, dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(512), lds, st, p);
-    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2, one storing wave]");
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Two sequence groups per workgroup (H = 128): the step of the kernel above is a serial chain -- barrier, LDS reads of h, ~1500 cycles of
-// MFMA per SIMD, the last tile's gate math, conversion, LDS write, barrier -- in which the matrix pipe idles for ~45 % of the time, and a
-// second workgroup cannot share the CU because the two-term W_hh of one direction fills half its register file.  Here one workgroup owns TWO
-// independent groups of 16 sequences that share the W registers and alternate in halves of a step:
-//     phase A:  MFMAs of group A (step t)   ||  gate math, h write, output store, next row request of group B (step t-1)     barrier
-//     phase B:  MFMAs of group B (step t)   ||  gate math, ... of group A (step t)                                            barrier
-// so every MFMA block of one group is issued over the VALU work of the other (k-block kb of the running group over tile kb of the resting
-// one).  Per wave: W 128 VGPRs, 2 x (acc + acx) 64, one k-block of h fragments at a time; the gate rows of a group's next step are requested
-// straight into its accumulators as soon as its gate math has read them (they ride in as the C operand half a step later).
-// ---------------------------------------------------------------------------------------------------------------------
-#ifndef X2_VPM
-#define X2_VPM 3
-#endif
-__global__ __launch_bounds__(512, 1) void lstm16_pt_h2x2_kernel(LstmPtArgs p) {
-    constexpr int KB = 4, NT = 4, NW = 8, NTH = 64 * NW, SEQ = 16, KP = 32 * KB, ZLD = KP + 8, H = 128, H4 = 4 * H, NG = 2;
-    constexpr uint32_t OOB = 0x7FFFFFF0u;
-    constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
-    const int TP = p.T + 3;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* z = reinterpret_cast<_Float16*>(smem);        // [2 groups][2 buffers][2 terms][SEQ][ZLD]
-    int* lens_s = reinterpret_cast<int*>(z + NG * 4 * SEQ * ZLD);      // [32]
-    int* simd_s = lens_s + NG * SEQ;                                     // [16]
-    int* ids_s = simd_s + 16;                                            // [32][TP]
-    float* rows_s = reinterpret_cast<float*>(ids_s + ((NG * SEQ * TP + 3) & ~3));   // [2 groups][8 waves][4 tiles][64 lanes][4]: gate rows, LDS-direct
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sq = lane & 15, kq = lane >> 4;
-    const int dir = blockIdx.y;
-    const int64_t m0 = (int64_t)blockIdx.x * (NG * SEQ);
-    const int T = p.T;
-    const int nvalid = (int)min((int64_t)(NG * SEQ), p.M - m0);
-    const int OW = p.ND * H;
-    const int64_t GW = (int64_t)p.ND * H4;
-
-    if (lane == 0) simd_s[wave] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
-    if (tid < NG * SEQ) {
-        int l = 0;
-        if (tid < nvalid) {
-            l = p.lens ? (int)p.lens[m0 + tid] : T;
-            l = l < 0 ? 0 : (l > T ? T : l);
-        }
-        lens_s[tid] = l;
-    }
-    __syncthreads();
-    {
-        bool bad = false;
-        for (int e = tid; e < NG * SEQ * TP; e += NTH) {
-            const int s_ = e / TP, k = e - s_ * TP;
-            int64_t id = 0;
-            if (s_ < nvalid) {
-                const int l = lens_s[s_];
-                int kk = k < l - 1 ? k : l - 1;
-                kk = kk < 0 ? 0 : kk;
-                int t_ = dir == 0 ? kk : l - 1 - kk;
-                t_ = t_ < 0 ? 0 : t_;
-                id = p.ids[(m0 + s_) * T + t_];
-                if (k < T) {
-                    const int64_t raw = p.ids[(m0 + s_) * T + k];
-                    bad |= raw < 0 || raw >= p.V;
-                }
-            }
-            if (id < 0 || id >= p.V) id = 0;
-            ids_s[e] = (int)id;
-        }
-        if (bad && p.err) atomicOr(p.err, 1);
-    }
-    for (int e = tid; e < NG * 2 * SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;
-    __syncthreads();
-    int tmax = 0;
-#pragma unroll
-    for (int s2 = 0; s2 < NG * SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
-    int mylen[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) mylen[g] = lens_s[SEQ * g + sq];
-    {
-        const int mine = simd_s[wave];
-        int rank = 0;
-#pragma unroll
-        for (int w2_ = 0; w2_ < NW; ++w2_) rank += (w2_ < wave && simd_s[w2_] == mine) ? 1 : 0;
-        rank = __builtin_amdgcn_readfirstlane(rank);
-        if (rank == 0) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(1);
-    }
-
-    f16x8 w1[NT][KB], w2[NT][KB];
-    const int u0 = NT * (4 * wave + kq);
-    bool wbad = false;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
-        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + unit_a) * H;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int k0 = 32 * kb + 8 * kq;
-            const float4 a = *reinterpret_cast<const float4*>(wr + k0), b = *reinterpret_cast<const float4*>(wr + k0 + 4);
-            const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hi = (_Float16)wv[j];
-                w1[t][kb][j] = hi;
-                w2[t][kb][j] = (_Float16)((wv[j] - (float)hi) * SC);
-                wbad |= !(fabsf(wv[j]) < 32768.0f);
-            }
-        }
-    }
-    if (wbad && p.err) atomicOr(p.err, 2);
-
-    const float* pb = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4 + 4 * u0;      // the lane's 64 contiguous bytes of a folded row
-    const uint32_t gw = (uint32_t)GW;
-    f32x4 acc[NG][NT], acx[NG][NT];
-    float creg[NG][NT], hn[NT];
-    uint32_t soff[NG];
-    const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
-    __amdgpu_buffer_rsrc_t out_rs[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int nv = max(0, min(SEQ, nvalid - SEQ * g));
-        out_rs[g] = __builtin_amdgcn_make_buffer_rsrc(p.out + (m0 + SEQ * g) * T * OW, 0, (int)((uint32_t)nv * T * OW * 4u), 0x00020000);
-        soff[g] = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen[g] - 1)) * OW + dir * H + u0) * 4);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) creg[g][t] = 0.f;
-    }
-    // The gate rows of a group's step travel global -> LDS without touching registers (global_load_lds_dwordx4: the wave's 64 x 16 bytes land
-    // lane by lane in its own 1 KB slot) and are requested a FULL step ahead, right behind the first k-block of the group's previous MFMA
-    // phase; the group takes them over as its MFMA C operands at the top of its phase.  Vector-memory queue per phase, in order:
-    // [4 requests of the running group, 1 output store of the resting group] -- so behind a group's requests there are always
-    // store + 4 requests + store = 6 younger operations when it takes them over (s_waitcnt vmcnt(6), in-order completion).
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-    auto request_rows = [&](int g, int step) {
-        const uint64_t ro = (uint64_t)(uint32_t)ids_s[(SEQ * g + sq) * TP + step] * gw;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb + ro + 4 * t), (lds_ptr_t)(rows_s + (((g * NW + wave) * NT + t) * 64) * 4), 16, 0, 0);
-    };
-    auto take_rows = [&](int g) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[g][t] = *reinterpret_cast<const f32x4*>(rows_s + ((((g * NW + wave) * NT + t) * 64) + lane) * 4);
-            acx[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    // the resting group's finished step: h terms for its next B operand, its output, then its next rows
-    auto finish = [&](auto Gc, int step) {
-        constexpr int g = decltype(Gc)::value;
-        _Float16* zn = z + (g * 2 + ((step + 1) & 1)) * 2 * SEQ * ZLD;
-        _Float16 a[NT], r[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            a[t] = (_Float16)hn[t];
-            r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
-        }
-        *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = (f16x4){a[0], a[1], a[2], a[3]};
-        *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = (f16x4){r[0], r[1], r[2], r[3]};
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(hn[0]), __float_as_uint(hn[1]), __float_as_uint(hn[2]), __float_as_uint(hn[3])},
-                                               out_rs[g], step < mylen[g] ? soff[g] : OOB, 0, 0);
-        soff[g] += sstep;
-    };
-#ifdef NIR_PT_TRACE
-    unsigned long long tr[4] = {0, 0, 0, 0};
-#endif
-    // one half step: the MFMAs of group GM's step `sm` over the gate math of group GG's step `sg` (sg < 0: nothing to finish yet)
-    auto phase = [&](auto GMc, auto GGc, int sm, int sg, bool mm, bool gates_on) {
-        constexpr int GM = decltype(GMc)::value, GG = decltype(GGc)::value;
-        const _Float16* zr = z + (GM * 2 + (sm & 1)) * 2 * SEQ * ZLD + sq * ZLD + 8 * kq;
-#ifdef NIR_PT_TRACE
-        unsigned long long tq0, tq1, tq2, tq3;
-        PT_T(tq0);
-#endif
-        if (mm) take_rows(GM);
-#ifdef NIR_PT_TRACE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PT_T(tq1);
-#endif
-        // The 48 MFMAs of the running group (no two adjacent ones share an accumulator: tile t recurs every fourth) with the WHOLE gate math
-        // of the resting group -- four independent chains, interleaved statement by statement (lstm_cell_vn) -- spread between them.
-        f32x4 xg[NT];
-        if (gates_on) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) xg[t] = acx[GG][t] * ISC + acc[GG][t];
-        }
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            if (mm) {
-                const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
-                const f16x8 h2 = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h1, acc[GM][t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acx[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], h2, acx[GM][t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acx[GM][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], h1, acx[GM][t], 0, 0, 0);
-            }
-            if (mm && kb == 0) request_rows(GM, sm + 1);
-        }
-        if (gates_on) {
-#ifdef NIR_X_NOGATES
-#pragma unroll
-            for (int t = 0; t < NT; ++t) hn[t] = (xg[t][0] + xg[t][1]) * 1e-3f;
-#else
-            lstm_cell_vn<NT>(xg, creg[GG], hn);
-#endif
-        }
-        if (mm && gates_on) {
-#pragma unroll
-            for (int q = 0; q < 3 * NT * KB; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, X2_VPM, 0);
-            }
-        }
-#ifdef NIR_PT_TRACE
-#pragma unroll
-        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[GM][t]), "+v"(acx[GM][t]));
-        PT_T(tq2);
-#endif
-        if (gates_on) finish(GGc, sg);
-        else __builtin_amdgcn_raw_buffer_store_b32(0u, out_rs[0], OOB, 0, 0);      // (dropped) keeps the queue pattern of every phase
-#ifdef NIR_PT_TRACE
-        PT_T(tq3);
-        tr[0] += tq1 - tq0; tr[1] += tq2 - tq1; tr[2] += tq3 - tq2;
-#endif
-        lds_barrier();
-#ifdef NIR_PT_TRACE
-        { unsigned long long tn; PT_T(tn); tr[3] += tn - tq3; }
-#endif
-    };
-    request_rows(0, 0);
-    request_rows(1, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    using G0 = std::integral_constant<int, 0>;
-    using G1 = std::integral_constant<int, 1>;
-    for (int step = 0; step < tmax; ++step) {
-        phase(G0{}, G1{}, step, step - 1, true, step > 0);      // MFMA A(step)  || finish B(step-1)
-        phase(G1{}, G0{}, step, step, true, true);              // MFMA B(step)  || finish A(step)
-    }
-    if (tmax > 0) phase(G0{}, G1{}, tmax, tmax - 1, false, true);   // the last step of B
-#ifdef NIR_PT_TRACE
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && g_pt_trace_dev) {
-        unsigned long long* o = g_pt_trace_dev + wave * 8;
-        o[0] = tr[1]; o[1] = tr[2]; o[2] = tr[3]; o[3] = tr[0] + tr[1] + tr[2] + tr[3]; o[4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11));
-        o[5] = 2 * tmax; o[6] = tr[0]; o[7] = 0;
-    }
-#endif
-    // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced
-    for (int s_ = 0; s_ < nvalid; ++s_) {
-        float* orow = p.out + (m0 + s_) * T * OW + (int64_t)dir * H;
-        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
-            for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = 0.f;
-    }
-}
-
-static int launch_pt_h2x2(const LstmPtArgs& p, hipStream_t st) {
-    const size_t lds = (size_t)(2 * 4 * 16 * (32 * 4 + 8)) * 2 + (2 * 16 + 16) * 4 + (size_t)((2 * 16 * (p.T + 3) + 3) & ~3) * 4 + (size_t)2 * 8 * 4 * 64 * 16;
-    ProfScope ps(prof_shape_name("lstm16_pt_h2x2_kernel", (long long)p.M, p.T, p.H), st);
-    static bool attr = [] {
-        return hipFuncSetAttribute((const void*)lstm16_pt_h2x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
-    }();
-    (void)attr;
-#ifdef NIR_PT_TRACE
-    { unsigned long long* d = g_debug_buf; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pt_trace_dev), &d, sizeof(d), 0, hipMemcpyHostToDevice, st); }
-#endif
-    hipLaunchKernelGGL(lstm16_pt_h2x2_kernel, dim3((unsigned)((p.M + 31) / 32), (unsigned)p.ND), dim3(512), lds, st, p);
-    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2, two groups]");
-    return 0;
-}
-
-// ---- two groups, skewed roles ----
-__global__ __launch_bounds__(512, 1) void lstm16_pt_h2s_kernel(LstmPtArgs p) {
-    constexpr int KB = 4, NT = 4, NW = 8, NTH = 64 * NW, SEQ = 16, KP = 32 * KB, ZLD = KP + 8, H = 128, H4 = 4 * H, NG = 2;
-    constexpr uint32_t OOB = 0x7FFFFFF0u;
-    constexpr float SC = 2048.0f, ISC = 1.0f / 2048.0f;
-    const int TP = p.T + 3;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* z = reinterpret_cast<_Float16*>(smem);        // [2 groups][2 buffers][2 terms][SEQ][ZLD]
-    int* lens_s = reinterpret_cast<int*>(z + NG * 4 * SEQ * ZLD);      // [32]
-    int* simd_s = lens_s + NG * SEQ;                                     // [16]
-    int* ids_s = simd_s + 16;                                            // [32][TP]
-    float* rows_s = reinterpret_cast<float*>(ids_s + ((NG * SEQ * TP + 3) & ~3));   // [2 groups][8 waves][4 tiles][64 lanes][4]: gate rows, LDS-direct
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sq = lane & 15, kq = lane >> 4;
-    const int dir = blockIdx.y;
-    const int64_t m0 = (int64_t)blockIdx.x * (NG * SEQ);
-    const int T = p.T;
-    const int nvalid = (int)min((int64_t)(NG * SEQ), p.M - m0);
-    const int OW = p.ND * H;
-    const int64_t GW = (int64_t)p.ND * H4;
-
-    if (lane == 0) simd_s[wave] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
-    if (tid < NG * SEQ) {
-        int l = 0;
-        if (tid < nvalid) {
-            l = p.lens ? (int)p.lens[m0 + tid] : T;
-            l = l < 0 ? 0 : (l > T ? T : l);
-        }
-        lens_s[tid] = l;
-    }
-    __syncthreads();
-    {
-        bool bad = false;
-        for (int e = tid; e < NG * SEQ * TP; e += NTH) {
-            const int s_ = e / TP, k = e - s_ * TP;
-            int64_t id = 0;
-            if (s_ < nvalid) {
-                const int l = lens_s[s_];
-                int kk = k < l - 1 ? k : l - 1;
-                kk = kk < 0 ? 0 : kk;
-                int t_ = dir == 0 ? kk : l - 1 - kk;
-                t_ = t_ < 0 ? 0 : t_;
-                id = p.ids[(m0 + s_) * T + t_];
-                if (k < T) {
-                    const int64_t raw = p.ids[(m0 + s_) * T + k];
-                    bad |= raw < 0 || raw >= p.V;
-                }
-            }
-            if (id < 0 || id >= p.V) id = 0;
-            ids_s[e] = (int)id;
-        }
-        if (bad && p.err) atomicOr(p.err, 1);
-    }
-    for (int e = tid; e < NG * 2 * SEQ * ZLD; e += NTH) reinterpret_cast<unsigned*>(z)[e] = 0u;
-    __syncthreads();
-    int tmax = 0;
-#pragma unroll
-    for (int s2 = 0; s2 < NG * SEQ; ++s2) tmax = max(tmax, lens_s[s2]);
-    int mylen[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) mylen[g] = lens_s[SEQ * g + sq];
-    // role: the rank of the wave among the waves of its SIMD (0 / 1 with the usual two per SIMD).  Rank-1 waves run the SAME sequence of
-    // sub-phases one barrier late, so that at any time one wave of a SIMD is in a matrix sub-phase and its partner in a gate sub-phase.
-    int role;
-    {
-        const int mine = simd_s[wave];
-        int rank = 0;
-#pragma unroll
-        for (int w2_ = 0; w2_ < NW; ++w2_) rank += (w2_ < wave && simd_s[w2_] == mine) ? 1 : 0;
-        role = __builtin_amdgcn_readfirstlane(rank) & 1;
-        if (p.skew_prio && role == 0) __builtin_amdgcn_s_setprio(1);
-    }
-
-    f16x8 w1[NT][KB], w2[NT][KB];
-    const int u0 = NT * (4 * wave + kq);
-    bool wbad = false;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int unit_a = NT * (4 * wave + (sq >> 2)) + t, gate_a = sq & 3;
-        const float* wr = p.whh + ((int64_t)dir * H4 + (int64_t)gate_a * H + unit_a) * H;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int k0 = 32 * kb + 8 * kq;
-            const float4 a = *reinterpret_cast<const float4*>(wr + k0), b = *reinterpret_cast<const float4*>(wr + k0 + 4);
-            const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hi = (_Float16)wv[j];
-                w1[t][kb][j] = hi;
-                w2[t][kb][j] = (_Float16)((wv[j] - (float)hi) * SC);
-                wbad |= !(fabsf(wv[j]) < 32768.0f);
-            }
-        }
-    }
-    if (wbad && p.err) atomicOr(p.err, 2);
-
-    const float* pb = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4 + 4 * u0;      // the lane's 64 contiguous bytes of a folded row
-    const uint32_t gw = (uint32_t)GW;
-    f32x4 acc[NT], acx[NT];                                   // ONE group's accumulators are live at a time (matrix sub-phase -> its gate sub-phase)
-    float creg[NG][NT], hn[NT];
-    uint32_t soff[NG];
-    const uint32_t sstep = (uint32_t)(dir == 0 ? OW * 4 : -(OW * 4));
-    __amdgpu_buffer_rsrc_t out_rs[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int nv = max(0, min(SEQ, nvalid - SEQ * g));
-        out_rs[g] = __builtin_amdgcn_make_buffer_rsrc(p.out + (m0 + SEQ * g) * T * OW, 0, (int)((uint32_t)nv * T * OW * 4u), 0x00020000);
-        soff[g] = (uint32_t)(((sq * T + (dir == 0 ? 0 : mylen[g] - 1)) * OW + dir * H + u0) * 4);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) creg[g][t] = 0.f;
-    }
-    // Gate rows: global -> LDS without touching registers, requested a FULL step ahead (behind the first k-block of the group's matrix
-    // sub-phase), taken over as MFMA C operands at the top of the group's next matrix sub-phase.  Vector-memory queue of a wave, in program
-    // order: [4 requests g0][store g0][4 requests g1][store g1]... -- behind a group's requests there are always store + 4 + store = 6
-    // younger operations when it takes them over (s_waitcnt vmcnt(6), in-order completion); the same for both roles.
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-    auto request_rows = [&](int g, int step) {
-        const uint64_t ro = (uint64_t)(uint32_t)ids_s[(SEQ * g + sq) * TP + step] * gw;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb + ro + 4 * t), (lds_ptr_t)(rows_s + (((g * NW + wave) * NT + t) * 64) * 4), 16, 0, 0);
-    };
-    // matrix sub-phase of group g, step `step`: rows -> C operands, all h fragments read once, 48 MFMAs with no two adjacent ones on the same
-    // accumulator (tile t recurs every fourth), the next step's rows requested behind the first k-block
-    auto matrix = [&](auto Gc, int step) {
-        constexpr int g = decltype(Gc)::value;
-        const _Float16* zr = z + (g * 2 + (step & 1)) * 2 * SEQ * ZLD + sq * ZLD + 8 * kq;
-        f16x8 hh1[KB], hh2[KB];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            hh1[kb] = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
-            hh2[kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
-        }
-#ifdef NIR_X_NOROWS
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[t] = acc[t]; }
-#else
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = *reinterpret_cast<const f32x4*>(rows_s + ((((g * NW + wave) * NT + t) * 64) + lane) * 4);
-            acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#endif
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh1[kb], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh2[kb], acx[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], hh1[kb], acx[t], 0, 0, 0);
-#ifndef NIR_X_NOROWS
-            if (kb == 0) request_rows(g, step + 1);            // the slot's reads above are complete: the first MFMAs consumed them
-#endif
-        }
-        // the accumulators are operands of this (empty) statement: the barrier below cannot be scheduled into the MFMA stream -- an asm
-        // "memory" clobber orders memory operations only, and with the barrier hoisted behind the LDS reads the MFMAs of this sub-phase ran
-        // inside the next one, beside the partner's MFMAs instead of beside its gate math
-#pragma unroll
-        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]), "+v"(acx[t]));
-        lds_barrier();
-    };
-    // gate sub-phase of group g: the four cells of the lane as four interleaved chains, the two h terms for the next B operand, the output
-    auto gate = [&](auto Gc, int step) {
-        constexpr int g = decltype(Gc)::value;
-        f32x4 xg[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) xg[t] = acx[t] * ISC + acc[t];
-#ifdef NIR_X_NOGATES
-#pragma unroll
-        for (int t = 0; t < NT; ++t) hn[t] = (xg[t][0] + xg[t][1]) * 1e-3f;
-#else
-        lstm_cell_vn<NT>(xg, creg[g], hn);
-#endif
-        _Float16* zn = z + (g * 2 + ((step + 1) & 1)) * 2 * SEQ * ZLD;
-        _Float16 a[NT], r[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            a[t] = (_Float16)hn[t];
-            r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
-        }
-        *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = (f16x4){a[0], a[1], a[2], a[3]};
-        *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = (f16x4){r[0], r[1], r[2], r[3]};
-#ifndef NIR_X_NOSTORE
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(hn[0]), __float_as_uint(hn[1]), __float_as_uint(hn[2]), __float_as_uint(hn[3])},
-                                               out_rs[g], step < mylen[g] ? soff[g] : OOB, 0, 0);
-#endif
-        soff[g] += sstep;
-        lds_barrier();
-    };
-    request_rows(0, 0);
-    request_rows(1, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    using G0 = std::integral_constant<int, 0>;
-    using G1 = std::integral_constant<int, 1>;
-    // Sub-phase s of the workgroup = one barrier interval.  Role 0: s = 4 step + {0: matrix g0, 1: gate g0, 2: matrix g1, 3: gate g1}; role 1 the
-    // same sequence one interval later.  h_g(step) is complete after both roles' gate sub-phases (role 0 at 4 step + 2 g + 1, role 1 one
-    // later) and first read by matrix g (step + 1) at 4 step + 4 + 2 g (role 0) / one later (role 1): always at least one interval of slack,
-    // and the buffer a gate sub-phase overwrites was last read three intervals earlier.
-    if (role == 1) lds_barrier();
-    for (int step = 0; step < tmax; ++step) {
-        matrix(G0{}, step);
-        gate(G0{}, step);
-        matrix(G1{}, step);
-        gate(G1{}, step);
-    }
-    if (role == 0) lds_barrier();
-    // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced
-    for (int s_ = 0; s_ < nvalid; ++s_) {
-        float* orow = p.out + (m0 + s_) * T * OW + (int64_t)dir * H;
-        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
-            for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = 0.f;
-    }
-}
-
-static int launch_pt_h2s(const LstmPtArgs& p, hipStream_t st) {
-    const size_t lds = (size_t)(2 * 4 * 16 * (32 * 4 + 8)) * 2 + (2 * 16 + 16) * 4 + (size_t)((2 * 16 * (p.T + 3) + 3) & ~3) * 4 + (size_t)2 * 8 * 4 * 64 * 16;
-    ProfScope ps(prof_shape_name("lstm16_pt_h2s_kernel", (long long)p.M, p.T, p.H), st);
-    static bool attr = [] {
-        return hipFuncSetAttribute((const void*)lstm16_pt_h2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess;
-    }();
-    (void)attr;
-    hipLaunchKernelGGL(lstm16_pt_h2s_kernel, dim3((unsigned)((p.M + 31) / 32), (unsigned)p.ND), dim3(512), lds, st, p);
-    NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2, two groups, skewed roles]");
-    return 0;
-}
-
 template <int KB, int NT, int NW = 16>
 static int launch_pt_h2(const LstmPtArgs& p, hipStream_t st) {
     static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + ">";
@@ -2031,17 +1237,8 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
         if (KB == 3) return launch_pt_h2<3, 2>(p, st);
         // H in (96, 128]: 8 waves x 4 tiles with the in-wave pipeline (tunable lstm_w16 = 1: the 16-wave x 2-tile form)
         if (tun(g_tun.lstm_w16) == 1) return launch_pt_h2<4, 2>(p, st);
-        // two sequence groups per workgroup: opt-in only (tunable lstm_w16 = 3).  Measured (round 3, tools/recur_micro.py): per group and step
-        // 1.75 us against 1.85 us of the single-group form at equal occupancy -- the gate math does NOT disappear under the other group's
-        // MFMAs (skeleton without gate math: 1.31 vs 1.48 us; the gate math adds 0.4 us to either) -- and with half as many workgroups the
-        // C3 macro-batch (280 of them on 256 CUs) loses a whole round: 433 us against 368 us.
-        if (H == 128 && p.T + 3 <= 1024 && p.out_f16 == 2 && tun(g_tun.lstm_w16) == 6) return launch_pt_h2v(p, st);
-        if (H == 128 && p.T + 3 <= 1024 && tun(g_tun.lstm_w16) == 3) return launch_pt_h2x2(p, st);
-        if (H == 128 && p.T + 3 <= 1024 && (tun(g_tun.lstm_w16) == 4 || tun(g_tun.lstm_w16) == 5)) {
-            LstmPtArgs q = p;
-            q.skew_prio = tun(g_tun.lstm_w16) == 5;
-            return launch_pt_h2s(q, st);
-        }
+        // (two sequence groups per workgroup sharing the W registers, skewed wave roles, output stores on one early wave: measured in rounds 3-4,
+        // all tied or lost -- DESIGN.md section 10; sources archived under tools/variants/, not built)
         return launch_pt_h2<4, 4, 8>(p, st);
     }
     const int G = (H + 15) / 16;

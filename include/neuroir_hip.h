@@ -49,7 +49,10 @@ int nir_set_stream_batches_in_flight(nir_stream_t stream, int n);
 /* Tuning / debug switches (kernel-family selection, fork on/off, exact f32 MFMA instead of the split-precision GEMM ...).  They
  * are read from the environment ONCE when the library is loaded (NIR_NO_FORK, NIR_LSTM_VALU, NIR_LSTM_MFMA16, NIR_LSTM_MFMA_S,
  * NIR_LSTM_S, NIR_NO_SKINNY, NIR_NO_GEMM16, NIR_ESM_WAVE_ROWS, NIR_DEBUG, NIR_EXACT_F32); this call changes one at run time by
- * its lower-case name without the prefix ("lstm_mfma16", ...).  Never changes results beyond fp32 rounding. */
+ * its lower-case name without the prefix ("lstm_mfma16", ...).  Never changes results beyond fp32 rounding.
+ * FROZEN in a product process: the call only takes effect when the library was loaded with NIR_DEBUG_TUNABLES set in the environment
+ * (tests, profilers, bench.py's isolated-kernel pass); otherwise it returns NIR_ERR_BAD_ARG and changes nothing -- no caller can change
+ * what another caller's entry points do. */
 int nir_debug_set_tunable(const char* name /*host*/, int value);
 
 /* Per-kernel timing for bench.py's roofline block: while enabled, every kernel launch of this library is

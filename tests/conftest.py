@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("NIR_DEBUG_TUNABLES", "1")      # tests force kernel families (lib.tunable); a product process keeps the switches frozen
 
 
 def pytest_configure(config):

@@ -231,52 +231,6 @@ def test_recurrence_hands_term_pairs_to_attention_pipeline_vs_oracle():
     np.testing.assert_allclose(out.cpu().numpy(), enc.detach().numpy(), rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("M,DL", [(608, 64), (37, 64), (300, 16), (41, 8)])
-def test_attention_weights_stationary_kernel_vs_oracle_and_pipeline(M, DL):
-    """attn_pool_ws_kernel (opt-in, tunable attn_ws = 1: W0 resident in registers, rows staged verbatim by LDS-direct loads, both waves of a
-    SIMD in the matrix pipe half a tile period apart) against the ORACLE and the streamed-W0 pipeline: more / fewer tiles than workgroups, a
-    partial last tile, several sequences per tile (T = 16, 8), ragged lengths."""
-    from context_attentive_ir_amd import lib
-    V = 3000
-    m = build_model("CARS", vocab=V, device=DEV)
-    g = torch.Generator().manual_seed(M + DL)
-    ids = torch.randint(4, V, (M, DL), generator=g)
-    lens = torch.randint(1, DL + 1, (M,), generator=g)
-    lens[: min(9, M)] = DL
-    ids = torch.where(torch.arange(DL)[None, :] < lens[:, None], ids, torch.zeros_like(ids))
-    sd = cpu_state_dict(m)
-    ref = O.cars_encode_document(sd, ids.view(1, 1, M, DL), lens.view(1, 1, M)).view(M, -1)
-    a = (ids.view(1, 1, M, DL).to(DEV), lens.view(1, 1, M).to(DEV))
-    with lib.tunable("attn_unfused_pipe", 2, 0):
-        pipe = m.encode_document(*a).view(M, -1).cpu()
-        with lib.tunable("attn_ws", 1, 0):
-            ws = m.encode_document(*a).view(M, -1).cpu()
-    np.testing.assert_allclose(ws.numpy(), ref.numpy(), rtol=0, atol=2e-5)
-    np.testing.assert_allclose(ws.numpy(), pipe.numpy(), rtol=0, atol=1e-6)
-
-
-def test_recurrence_storing_wave_variant_is_bit_identical():
-    """lstm16_pt_h2v_kernel (opt-in, tunable lstm_w16 = 6: the output of all waves stored by two early-finishing waves out of the LDS h buffer, their
-    own gate rows requested by two other waves global -> LDS; every other wave's vector-memory queue holds loads only) hands the attention
-    pipeline the same term pairs bit for bit: pooled documents equal to the default kernel's, ragged lengths, a partial last workgroup."""
-    from context_attentive_ir_amd import lib
-    V, M, DL = 3000, 611, 64
-    m = build_model("CARS", vocab=V, device=DEV)
-    g = torch.Generator().manual_seed(5)
-    ids = torch.randint(4, V, (M, DL), generator=g)
-    lens = torch.randint(1, DL + 1, (M,), generator=g)
-    lens[:7] = DL
-    lens[7] = 1
-    ids = torch.where(torch.arange(DL)[None, :] < lens[:, None], ids, torch.zeros_like(ids))
-    a = (ids.view(1, 1, M, DL).to(DEV), lens.view(1, 1, M).to(DEV))
-    base = m.encode_document(*a).clone()
-    with lib.tunable("lstm_w16", 6, 0):
-        got = m.encode_document(*a).clone()
-    assert torch.equal(got, base)
-    ref = O.cars_encode_document(cpu_state_dict(m), ids.view(1, 1, M, DL), lens.view(1, 1, M)).view(M, -1)
-    np.testing.assert_allclose(got.view(M, -1).cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
-
-
 def test_bilstm_folded_four_wave_variant_matches():
     """H = 70: the 4-wave x 5-tile workgroup form (selected by workgroup count; forced here with tunable lstm_s = 2) against the
     16-wave form (lstm_s = 1): the same arithmetic in another wave layout (agreement to rounding, 1e-6)."""

@@ -627,3 +627,18 @@ def test_drmm_self_cosine_bins_reproduce_the_oracle_at_exact_matches():
     hb[hit] = b2[qg].long().view(Bg, 1, QLg, 1).expand(Bg, Ng, QLg, DLg).reshape(Bg * Ng, QLg, DLg)[hit]
     hist = torch.stack([(hb == k).sum(-1) for k in range(5)], -1).numpy()
     np.testing.assert_array_equal(hist, g["hist"].astype(np.int64))
+
+
+def test_debug_tunables_are_frozen_in_a_product_process():
+    """nir_debug_set_tunable only works when the library is loaded with NIR_DEBUG_TUNABLES (tests / profilers); a product process gets
+    NIR_ERR_BAD_ARG and the switches stay what the environment said at load time (no caller can steer another's entry points)."""
+    lib_path = os.path.join(ROOT, "context_attentive_ir_amd", "libneuroir_hip.so")
+    code = ("import ctypes,sys; L=ctypes.CDLL(%r); L.nir_last_error_string.restype=ctypes.c_char_p; "
+            "rc=L.nir_debug_set_tunable(b'no_fork',1); print(rc, L.nir_last_error_string().decode()[:60])" % lib_path)
+    env = {k: v for k, v in os.environ.items() if k != "NIR_DEBUG_TUNABLES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, msg = out.stdout.strip().split(" ", 1)
+    assert int(rc) != 0 and "frozen" in msg
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, NIR_DEBUG_TUNABLES="1"), capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip().split(" ", 1)[0] == "0"

@@ -6,6 +6,8 @@ the phase stamps of workgroup 7, tile 5 of attn_pool_pipe_kernel: MMA waves (k-l
 
     python tools/attn_micro.py [--M 4480 --T 64 --iters 20 --lib aptime --fp32-rows 0|1 --dtype f32|bf16]
 """
+import os
+os.environ.setdefault("NIR_DEBUG_TUNABLES", "1")
 import argparse
 import ctypes as C
 import os
@@ -29,7 +31,6 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--io-prio", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--ws", action="store_true", help="compare the weights-stationary attention kernel (tunable attn_ws) with the pipeline")
     a = ap.parse_args()
     from context_attentive_ir_amd import lib
     if a.lib:
@@ -60,28 +61,6 @@ def main():
             out[k.split("[")[0]] = float(ms) / int(cnt) * 1e3
         return out
 
-    if a.ws:
-        # weights-stationary kernel (tunable attn_ws = 1) against the streamed-W0 pipeline: the same pooled vectors, then interleaved timing
-        lens_r = torch.randint(1, a.T + 1, (1, 1, a.M), generator=g).cuda()
-        outs = {}
-        for ws in (0, 1):
-            L.nir_debug_set_tunable(b"attn_ws", ws)
-            L.nir_debug_set_tunable(b"attn_fp32_rows", 0)
-            outs[ws] = [m.encode_document(ids, ln).float().clone() for ln in (lens, lens_r)]
-        torch.cuda.synchronize()
-        for i, name in enumerate(("full lengths", "ragged lengths")):
-            d = (outs[0][i] - outs[1][i]).abs()
-            print("%s: max |pooled(ws) - pooled(pipe)| = %.3g (max |pooled| %.3g), NaNs %d / %d" % (
-                name, float(torch.nan_to_num(d).max()), float(torch.nan_to_num(outs[0][i]).abs().max()), int(torch.isnan(outs[1][i]).sum()), int(torch.isnan(outs[0][i]).sum())))
-        res = {0: [], 1: []}
-        for rep in range(a.reps):
-            for ws in (0, 1):
-                L.nir_debug_set_tunable(b"attn_ws", ws)
-                res[ws].append(timed(0, a.io_prio))
-        for ws in (0, 1):
-            att = sorted(next(x for k, x in r.items() if k.startswith("attn_pool")) for r in res[ws])
-            print("attn_ws %d: attention median %.1f us (min %.1f max %.1f)" % (ws, att[len(att) // 2], att[0], att[-1]))
-        return
     # variants interleaved in ONE process (box-to-box and run-to-run differences are ~5 %, larger than the effects looked for)
     variants = [(0, 0), (1, 0), (0, 1), (1, 1)] if a.dtype == "f32" else [(0, 0), (0, 1)]
     acc = {v: [] for v in variants}

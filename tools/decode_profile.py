@@ -1,4 +1,6 @@
 """Per-kernel HIP-event times of one full Multitask.predict (ranking + greedy decode) at the C3 shape.  python tools/decode_profile.py"""
+import os
+os.environ.setdefault("NIR_DEBUG_TUNABLES", "1")
 import ctypes
 import os
 import sys

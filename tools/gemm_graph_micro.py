@@ -1,5 +1,7 @@
 """nir_linear_f32 at one shape, 50 launches captured into ONE hipGraph (no host launch overhead, no events between kernels): us per launch.
     python tools/gemm_graph_micro.py M N K [tunable=value ...]"""
+import os
+os.environ.setdefault("NIR_DEBUG_TUNABLES", "1")
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

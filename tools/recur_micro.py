@@ -5,6 +5,8 @@ barrier wait -- shader-clock cycles per step.
 
     python tools/recur_micro.py [--M 4480 --T 64 --H 128 --iters 50 --lib trace --dtype f32]
 """
+import os
+os.environ.setdefault("NIR_DEBUG_TUNABLES", "1")
 import argparse
 import ctypes as C
 import os
