@@ -91,6 +91,10 @@ SIGNATURES = {
     "nir_bilstm_steps_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, C.c_void_p, _z, c_st]),
     "nir_birnn_steps_fwd": (_i, [_i, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, C.c_void_p, _z, c_st]),
     "nir_maxpool_time_f32": (_i, [c_fp, _l, _i, _i, c_fp, c_st]),
+    "nir_lstm256_whh_frag_bytes": (_z, [_i]),
+    "nir_lstm256_pack_whh_frag": (_i, [c_fp, _i, C.c_void_p, C.c_void_p, c_st]),
+    "nir_lstm256_workspace_bytes": (_z, [_l, _i]),
+    "nir_lstm256_rows_fwd": (_i, [c_fp, c_ip, c_ip, C.c_void_p, c_fp, _i, C.c_void_p, _l, _l, _i, _i, C.c_void_p, _z, c_st]),
     "nir_decode_greedy_plain_workspace_bytes": (_z, [_l, _i, _l]),
     "nir_decode_greedy_plain": (_i, [c_fp, c_fp, _l, _i, c_fp, _l, _i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, c_ip, _l, _i, C.c_void_p, _z, c_ip,
                                      c_st]),

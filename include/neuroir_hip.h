@@ -449,6 +449,27 @@ size_t nir_bilstm_steps_workspace_bytes(int64_t M, int H);
 int nir_bilstm_steps_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0,
                          float* out, float* hn, float* cn, int64_t M, int T, int H, int ndir, void* workspace,
                          size_t workspace_bytes, nir_stream_t stream);
+/* ---------------------------------------------------------------------------------------------------
+ * Resident-weight recurrence for 256 units per direction (csrc/lstm_cluster.hip) -- MNSRF's encoders
+ * (neuroir/multitask/mnsrf.py:62-114: nn.LSTM over every query / candidate document, then a max over time, :79-83, 235-237).
+ * W_hh of one direction as two fp16 terms is 1 MB: a cluster of FOUR workgroups (four CUs of one XCD) holds it in registers, each member
+ * owns 64 units and the members exchange their slices of h through L2 every step (self-tagged 8-byte granules, device-scope stores /
+ * polled loads).  fp32-accurate (three fp16 MFMAs per product block, fp32 gate math and cell state): the same arithmetic as
+ * nir_bilstm_folded_fwd.  Replaces the per-step GEMM + cell launches of nir_birnn_steps_fwd for H = 256.
+ *   whh_frag: nir_lstm256_pack_whh_frag(w_hh [ndir,1024,256] fp32) -- once per weight version; err bit 1 = |w_hh| >= 2^15.
+ *   rows [R][ndir][256][4] fp32: the gate pre-activations (x W_ih^T + b_ih + b_hh) in the folded order (unit-major, the four gates i,f,g,o of
+ *       a unit adjacent: nir_lstm_fold_table(.., H = 256, ..) builds it per vocabulary row, R = V); ids [M,T] picks the row of every token
+ *       (validated: err bit 0), ids == NULL: row = m*T + t (per-batch gates).
+ *   mode 0: out [M,T,ndir*256], zeros beyond each length (RNNEncoder's memory bank);
+ *   mode 1: out [M,ndir*256] = max over ALL T positions of that bank (padded positions count as zeros) -- the bank is never written.
+ *   workspace: nir_lstm256_workspace_bytes(M, ndir) bytes of exchange buffer (zeroed by the call: one memset node in front of the kernel).
+ *   err bit 2: a cluster member waited ~1 s for a partner that never arrived (all four must be resident together; bounded, never a hang). */
+size_t nir_lstm256_whh_frag_bytes(int ndir);
+int nir_lstm256_pack_whh_frag(const float* w_hh, int ndir, void* frag, int* err_flag, nir_stream_t stream);
+size_t nir_lstm256_workspace_bytes(int64_t M, int ndir);
+int nir_lstm256_rows_fwd(const float* rows, const int64_t* ids, const int64_t* lengths, const void* whh_frag, float* out, int mode,
+                         int* err_flag, int64_t M, int64_t R, int T, int ndir, void* workspace, size_t workspace_bytes, nir_stream_t stream);
+
 /* The same streaming recurrence for either cell of the reference's RNNEncoder (rnn_encoder.py:28-60: getattr(nn, rnn_type), one module per
  * layer): NIR_CELL_LSTM = nir_bilstm_steps_fwd; NIR_CELL_GRU: torch.nn.GRU semantics, gate order (r, z, n), gates_in = x W_ih^T + b_ih
  * [M,T,ndir*3H], w_hh [ndir,3H,H], b_hh [ndir,3H] (inside the reset-gate product), c0 / cn unused.  Workspace: nir_bilstm_steps_workspace_bytes. */

@@ -1,0 +1,105 @@
+"""GPU (-m gpu): the four-workgroup resident-weight recurrence for 256 units per direction (csrc/lstm_cluster.hip) through the C-ABI, against
+torch's CPU nn.LSTM over packed sequences (what the reference's RNNEncoder runs, encoders/rnn_encoder.py:62-141) -- memory bank with zeros
+beyond each length (mode 0) and MNSRF's max over time (mode 1, mnsrf.py:79-83).  fp32 parity: 3e-5 absolute on |h| < 1."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _reference_bank(lstm, x, lens):
+    T = x.shape[1]
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False)
+    out, _ = lstm(packed)
+    out, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=T)
+    return out
+
+
+def _run(lstm, table, ids, lens, mode, use_ids=True):
+    from context_attentive_ir_amd import lib
+    from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
+    L = lib.load()
+    nd = 2 if lstm.bidirectional else 1
+    M, T = ids.shape
+    wih, whh, bih, bhh = [t.detach().to(DEV).contiguous() for t in lstm_cat_weights(lstm)]
+    ids_d = ids.to(DEV)
+    if use_ids:
+        rows = lib.fold_lstm_table(table.to(DEV), wih, bih, bhh, 256, nd, "f32")
+        idp, R = lib.ptr(ids_d), table.shape[0]
+    else:       # per-batch gates in the folded order: row = m*T + t
+        rows = lib.fold_lstm_table(table[ids.reshape(-1)].to(DEV).contiguous(), wih, bih, bhh, 256, nd, "f32")
+        idp, R = None, M * T
+    frag = torch.empty(L.nir_lstm256_whh_frag_bytes(nd), dtype=torch.uint8, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib.check(L.nir_lstm256_pack_whh_frag(lib.ptr(whh), nd, lib.ptr(frag), lib.ptr(err), lib.stream()), "pack")
+    ws = torch.empty(L.nir_lstm256_workspace_bytes(M, nd), dtype=torch.uint8, device=DEV)
+    out = torch.full((M, T, nd * 256) if mode == 0 else (M, nd * 256), 7.0, device=DEV)
+    lens_d = lens.to(DEV)
+    lib.check(L.nir_lstm256_rows_fwd(lib.ptr(rows), idp, lib.ptr(lens_d), lib.ptr(frag), lib.ptr(out), mode, lib.ptr(err), M, R, T, nd,
+                                     lib.ptr(ws), ws.numel(), lib.stream()), "nir_lstm256_rows_fwd")
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0, int(err.item())
+    del ids_d
+    return out.cpu()
+
+
+@pytest.mark.parametrize("M,T,bi,full", [(37, 7, True, False), (16, 4, True, True), (5, 3, False, False), (112, 4, True, False),
+                                         (1120, 64, True, False), (1120, 64, True, True), (49, 33, True, False), (130, 12, False, False)])
+def test_lstm256_cluster_matches_packed_lstm(M, T, bi, full):
+    g = torch.Generator().manual_seed(M * 100 + T)
+    V, E = 500, 300
+    lstm = torch.nn.LSTM(E, 256, bidirectional=bi, batch_first=True)
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.08)
+    table = torch.randn(V, E, generator=g) * 0.5
+    ids = torch.randint(1, V, (M, T), generator=g)
+    lens = torch.full((M,), T, dtype=torch.int64) if full else torch.randint(1, T + 1, (M,), generator=g)
+    lens[0] = T
+    if not full and M > 3:
+        lens[1] = 1
+    with torch.no_grad():
+        ref = _reference_bank(lstm, table[ids], lens)
+    bank = _run(lstm, table, ids, lens, 0)
+    np.testing.assert_allclose(bank.numpy(), ref.numpy(), rtol=0, atol=3e-5)
+    assert float(bank[1, int(lens[1]):].abs().max() if int(lens[1]) < T else 0.0) == 0.0       # exact zeros beyond the length
+    pooled = _run(lstm, table, ids, lens, 1)
+    np.testing.assert_allclose(pooled.numpy(), ref.max(1)[0].numpy(), rtol=0, atol=3e-5)
+    if M <= 112:                                                                                  # per-batch gate rows (ids == NULL)
+        bank2 = _run(lstm, table, ids, lens, 0, use_ids=False)
+        np.testing.assert_allclose(bank2.numpy(), bank.numpy(), rtol=0, atol=1e-5)      # (the two gate GEMMs differ in shape -> kernel -> rounding)
+
+
+def test_lstm256_cluster_concurrent_launches_on_four_streams():
+    """Four launches in flight on four streams (clusters of different launches compete for CUs): same results as alone, no timeout flag."""
+    g = torch.Generator().manual_seed(3)
+    V, E, M, T = 500, 300, 640, 32
+    lstm = torch.nn.LSTM(E, 256, bidirectional=True, batch_first=True)
+    table = torch.randn(V, E, generator=g) * 0.5
+    ids = [torch.randint(1, V, (M, T), generator=g) for _ in range(4)]
+    lens = [torch.randint(1, T + 1, (M,), generator=g) for _ in range(4)]
+    alone = [_run(lstm, table, i, l, 1) for i, l in zip(ids, lens)]
+    from context_attentive_ir_amd import lib
+    from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
+    L = lib.load()
+    wih, whh, bih, bhh = [t.detach().to(DEV).contiguous() for t in lstm_cat_weights(lstm)]
+    rows = lib.fold_lstm_table(table.to(DEV), wih, bih, bhh, 256, 2, "f32")
+    frag = torch.empty(L.nir_lstm256_whh_frag_bytes(2), dtype=torch.uint8, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib.check(L.nir_lstm256_pack_whh_frag(lib.ptr(whh), 2, lib.ptr(frag), lib.ptr(err), lib.stream()), "pack")
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    wss = [torch.empty(L.nir_lstm256_workspace_bytes(M, 2), dtype=torch.uint8, device=DEV) for _ in range(4)]
+    outs = [torch.empty(M, 512, device=DEV) for _ in range(4)]
+    di, dl = [i.to(DEV) for i in ids], [l.to(DEV) for l in lens]
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for k in range(4):
+            with torch.cuda.stream(streams[k]):
+                lib.check(L.nir_lstm256_rows_fwd(lib.ptr(rows), lib.ptr(di[k]), lib.ptr(dl[k]), lib.ptr(frag), lib.ptr(outs[k]), 1, lib.ptr(err),
+                                                 M, V, T, 2, lib.ptr(wss[k]), wss[k].numel(), lib.stream()), "fwd")
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0
+    for k in range(4):
+        assert torch.equal(outs[k].cpu(), alone[k])
