@@ -287,9 +287,11 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
     // phase k = step * NG + g; k + d -> (group, step)
     auto ph_g = [&](int g, int d) { return (g + d) % NG; };
     auto ph_s = [&](int g, int step, int d) { return step + (g + d) / NG; };
+    // (issued in the order the loop leaves its queue at a phase start -- rows(k), pieces(k), rows(k+1) -- so that the wait counts the compiler
+    // derives at the loop head are the steady-state ones)
     load_g(ids_s[(0 * SEQ + sq) * TP + 0], gnr[0]);                                       // rows of phase 0
-    load_g(ids_s[(ph_g(0, 1) * SEQ + sq) * TP + ph_s(0, 0, 1)], gnr[1]);                 // rows of phase 1
     request_pieces(0, 0);                                // (the pieces of a step-0 request are never looked at)
+    load_g(ids_s[(ph_g(0, 1) * SEQ + sq) * TP + ph_s(0, 0, 1)], gnr[1]);                 // rows of phase 1
 #ifdef NIR_CL_TRACE
     const bool tr_on = blockIdx.x == 0 && wave == NIR_CL_TRACE_WAVE;
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_last = 0;
@@ -315,6 +317,10 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
                 acc[t] = gnr[pp][t];                                          // the gate rows ride in as the MFMA's C operand
                 acx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            // (taken over NOW, in front of the poll loop: behind it the compiler has lost count of what is in flight and waits for everything,
+            // the rows requested one phase ago included; the slot is re-requested below)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
 #ifndef NIR_CL_NOX
             if (step > 0) {
                 // the three other members' slices of h(step): 1536 pieces, three per thread, both tags of each must read `step`; what the early
@@ -336,6 +342,10 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) ok &= pv[i][1] == (uint32_t)step && pv[i][3] == (uint32_t)step;
                 }
+                CL_T(6)
+#ifdef NIR_CL_TRACE
+                if (tr_on) tr[7] += (unsigned long long)tries;
+#endif
                 uint32_t* zw = reinterpret_cast<uint32_t*>(zc);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -344,8 +354,6 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
                 }
             }
 #endif
-#pragma unroll
-            for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));   // (the rows are taken over NOW: their slot is re-requested below)
             CL_T(0)
             if (timed_out) abort_s[0] = 1;
             lds_barrier();

@@ -16,6 +16,10 @@ namespace nir {
 int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* table, int E, int64_t rows_per_seq,
                   int64_t seq_stride, const float* w, int64_t ldw, const float* bias, const float* bias2, float* c,
                   int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
+// csrc/lstm_cluster.hip: the resident-weight recurrence for 256 units per direction (four-workgroup clusters)
+size_t lstm256_xbuf_bytes(int64_t M, int ND);
+int launch_lstm256_cluster(const float* rows, const int64_t* ids, const int64_t* lens, const void* wfrag, float* out, int mode, int* err,
+                           int64_t M, int64_t R, int T, int ND, void* xbuf, size_t xbuf_bytes, hipStream_t st);
 
 // hw [M,4H] = h_{t-1} W_hh^T (null at the first step of a zero initial state); gates = hw + gin[m][t_m][dir]
 __global__ __launch_bounds__(256) void lstm_step_cell_kernel(const float* __restrict__ hw, const float* __restrict__ gin,
@@ -163,40 +167,132 @@ __global__ __launch_bounds__(256) void mnsrf_dot_kernel(const float* __restrict_
     if (lane == 0) scores[pair] = s;
 }
 
-struct MnsrfPlan { float *gin, *enc, *lstm_ws, *mem, *sgin, *sess, *comb, *proj, *docs; size_t bytes; };
+// decoder-init states from batch-major banks: dst[(t * B + b), :] = src[b, t, :] for t < S - 1   (mnsrf.py:96-112, torch.cat(states[:-1], 1))
+__global__ void mnsrf_dec_states_kernel(const float* __restrict__ hbank, const float* __restrict__ cbank, float* __restrict__ dec_h,
+                                        float* __restrict__ dec_c, int64_t B, int S, int HS) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)(S - 1) * B * HS) return;
+    const int64_t r = i / HS;
+    const int c = (int)(i - r * HS);
+    const int64_t t = r / B, b = r - t * B;
+    const int64_t si = (b * S + t) * HS + c;
+    if (dec_h) dec_h[i] = hbank[si];
+    if (dec_c && cbank) dec_c[i] = cbank[si];
+}
+
+// Round 5: the resident-weight path.  With the folded gate tables and the pre-split recurrent weights in the struct (all optional; the host
+// mirror builds them once per weight version) the encoders run as ONE launch each -- lstm_cluster_kernel, max over time fused, no memory
+// bank -- and the session LSTM as one lstm_step16_kernel launch per query (W_hh as fp16 term pairs, input side hoisted into one GEMM):
+// 14 launches per batch instead of 300.
+static bool mnsrf_fast_q(const nir_mnsrf_weights* w) { return w->q_fold && w->q_whh_frag && w->Hq == 256; }
+static bool mnsrf_fast_d(const nir_mnsrf_weights* w) { return w->d_fold && w->d_whh_frag && w->Hd == 256; }
+static bool mnsrf_fast_s(const nir_mnsrf_weights* w) { return w->s_whh_frag && w->HS % 32 == 0; }
+
+struct MnsrfPlan { float *gin, *enc, *lstm_ws, *mem, *sgin, *sess, *comb, *proj, *docs, *hs, *cs, *h16; void* xbuf; size_t xbuf_bytes; size_t bytes; };
 
 static MnsrfPlan mnsrf_plan(void* ws, size_t cap, int64_t B, int S, int N, int QL, int DL, const nir_mnsrf_weights* w) {
     Workspace a(ws, cap);
     MnsrfPlan p;
     const int64_t Mq = B * S, Md = B * S * N;
     const int Hq = w->Hq, Hd = w->Hd, HS = w->HS;
-    const int64_t rows = std::max<int64_t>(Mq * QL, Md * DL);
+    const bool fq = mnsrf_fast_q(w), fd = mnsrf_fast_d(w) || Md == 0;
+    // the streaming encoders' scratch: gate pre-activations + memory bank of the encoder being run (only for the encoders that still stream)
+    const int64_t rows = std::max<int64_t>(fq ? 0 : Mq * QL, fd ? 0 : Md * DL);
     const int Hmax = std::max(Hq, Hd);
-    p.gin = a.take<float>((size_t)rows * 8 * Hmax);                     // gate pre-activations of the encoder being run
-    p.enc = a.take<float>((size_t)rows * 2 * Hmax);                     // its memory bank
-    p.lstm_ws = a.take<float>(std::max(lstm_steps_ws_floats(std::max(Mq, Md), Hmax), lstm_steps_ws_floats(B, HS)));
+    p.gin = a.take<float>((size_t)rows * 8 * Hmax);
+    p.enc = a.take<float>((size_t)rows * 2 * Hmax);
+    p.lstm_ws = a.take<float>(std::max(lstm_steps_ws_floats(std::max<int64_t>(fq ? 0 : Mq, fd ? 0 : Md), Hmax), mnsrf_fast_s(w) ? (size_t)0 : lstm_steps_ws_floats(B, HS)));
     p.mem = a.take<float>((size_t)Mq * 2 * Hq);
     p.sgin = a.take<float>((size_t)Mq * 4 * HS);
     p.sess = a.take<float>((size_t)Mq * HS);
     p.comb = a.take<float>((size_t)Mq * (2 * Hq + HS));
     p.proj = a.take<float>((size_t)Mq * 2 * Hd);
     p.docs = a.take<float>((size_t)Md * 2 * Hd);
+    // session LSTM, step-major: slot t + 1 = the state after query t (slot 0 = the zero state, never touched); fp32 h, c and h as fp16 term pairs
+    p.hs = a.take<float>((size_t)(S + 1) * B * HS);
+    p.cs = a.take<float>((size_t)(S + 1) * B * HS);
+    p.h16 = a.take<float>((size_t)(S + 1) * B * HS);
+    p.xbuf_bytes = std::max(fq ? lstm256_xbuf_bytes(Mq, 2) : (size_t)0, mnsrf_fast_d(w) && Md ? lstm256_xbuf_bytes(Md, 2) : (size_t)0);
+    p.xbuf = a.take<char>(p.xbuf_bytes);
     p.bytes = align_up(a.off, 256);
     return p;
 }
 
-// queries: ids [B*S,QL] -> memory_bank [B,S,2Hq] (BiLSTM + max over time), session_bank [B,S,HS] (session LSTM)
-static int mnsrf_encode(const int64_t* src, const int64_t* src_len, int64_t B, int S, int QL, const float* table, int E,
-                        const nir_mnsrf_weights* w, const MnsrfPlan& p, float* mem, float* sess, hipStream_t st) {
+// out[b, t, :] = steps[t + 1][b][:]   (session bank, batch-major, from the step-major states)
+__global__ void mnsrf_bank_kernel(const float* __restrict__ steps, float* __restrict__ out, int64_t B, int S, int HS) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * S * HS) return;
+    const int64_t r = i / HS;
+    const int c = (int)(i - r * HS);
+    const int64_t b = r / S;
+    const int t = (int)(r - b * S);
+    out[i] = steps[((int64_t)(t + 1) * B + b) * HS + c];
+}
+
+// queries: ids [B*S,QL] -> memory_bank [B,S,2Hq] (BiLSTM + max over time), session_bank [B,S,HS] (session LSTM); optional decoder-init
+// states dec_h / dec_c [(S-1)*B, HS] = the session LSTM's state after queries 0 .. S-2, step-major along the batch axis (mnsrf.py:96-112)
+static int mnsrf_encode(const int64_t* src, const int64_t* src_len, int64_t B, int S, int QL, const float* table, int64_t V, int E,
+                        const nir_mnsrf_weights* w, const MnsrfPlan& p, float* mem, float* sess, float* dec_h, float* dec_c, hipStream_t st) {
     const int64_t Mq = B * S;
     const int Hq = w->Hq, HS = w->HS;
-    NIR_PROPAGATE(launch_linear(nullptr, 0, src, table, E, 1, 1, w->q_wih, E, w->q_bih, w->q_bhh, p.gin, 8 * Hq, Mq * QL, 8 * Hq, E, NIR_ACT_NONE, st));
-    NIR_PROPAGATE(launch_bilstm_steps(p.gin, src_len, w->q_whh, nullptr, nullptr, p.enc, nullptr, nullptr, Mq, QL, Hq, 2, p.lstm_ws, st));
-    hipLaunchKernelGGL(maxpool_time_kernel, g1(Mq * 2 * Hq), dim3(256), 0, st, p.enc, mem, Mq, QL, 2 * Hq);
-    // session LSTM: B sequences of S steps over the pooled queries (hidden state carried from query to query)
+    if (mnsrf_fast_q(w)) {
+        NIR_PROPAGATE(launch_lstm256_cluster(w->q_fold, src, src_len, w->q_whh_frag, mem, 1, w->err, Mq, V, QL, 2, p.xbuf, p.xbuf_bytes, st));
+    } else {
+        NIR_PROPAGATE(launch_linear(nullptr, 0, src, table, E, 1, 1, w->q_wih, E, w->q_bih, w->q_bhh, p.gin, 8 * Hq, Mq * QL, 8 * Hq, E, NIR_ACT_NONE, st));
+        NIR_PROPAGATE(launch_bilstm_steps(p.gin, src_len, w->q_whh, nullptr, nullptr, p.enc, nullptr, nullptr, Mq, QL, Hq, 2, p.lstm_ws, st));
+        hipLaunchKernelGGL(maxpool_time_kernel, g1(Mq * 2 * Hq), dim3(256), 0, st, p.enc, mem, Mq, QL, 2 * Hq);
+    }
+    // session LSTM: B sequences of S steps over the pooled queries (hidden state carried from query to query); input side hoisted into one GEMM
     NIR_PROPAGATE(launch_linear(mem, 2 * Hq, nullptr, nullptr, 0, 0, 0, w->s_wih, 2 * Hq, w->s_bih, w->s_bhh, p.sgin, 4 * HS, Mq, 4 * HS, 2 * Hq, NIR_ACT_NONE, st));
-    NIR_PROPAGATE(launch_bilstm_steps(p.sgin, nullptr, w->s_whh, nullptr, nullptr, sess, nullptr, nullptr, B, S, HS, 1, p.lstm_ws, st));
+    const int64_t slot = B * (int64_t)HS;
+    if (mnsrf_fast_s(w)) {
+        LstmStepArgs a;
+        a.x[0] = a.x[1] = nullptr; a.xid[0] = a.xid[1] = nullptr; a.xstride[0] = a.xstride[1] = 0;
+        a.wih[0] = a.wih[1] = w->s_wih; a.whh[0] = a.whh[1] = w->s_whh; a.bih[0] = a.bih[1] = w->s_bih; a.bhh[0] = a.bhh[1] = w->s_bhh;
+        a.chain0 = 0; a.B = (int)B; a.I = 2 * Hq; a.H = HS;
+        a.gxstride = (int64_t)S * 4 * HS;
+        a.whh_frag[0] = w->s_whh_frag;
+        for (int t = 0; t < S; ++t) {
+            a.gx[0] = p.sgin + (int64_t)t * 4 * HS;
+            a.hprev[0] = t ? p.hs + t * slot : nullptr; a.cprev[0] = t ? p.cs + t * slot : nullptr;
+            a.hnext[0] = p.hs + (t + 1) * slot; a.cnext[0] = p.cs + (t + 1) * slot;
+            a.h16prev[0] = t ? reinterpret_cast<const _Float16*>(p.h16 + t * slot) : nullptr;
+            a.h16next[0] = reinterpret_cast<_Float16*>(p.h16 + (t + 1) * slot);
+            NIR_PROPAGATE(launch_lstm_step(a, 1, st));
+        }
+        hipLaunchKernelGGL(mnsrf_bank_kernel, g1(Mq * HS), dim3(256), 0, st, p.hs, sess, B, S, HS);
+        if (S > 1 && dec_h) hipLaunchKernelGGL(copy_f32_kernel, g1((S - 1) * slot), dim3(256), 0, st, p.hs + slot, dec_h, (S - 1) * slot);
+        if (S > 1 && dec_c) hipLaunchKernelGGL(copy_f32_kernel, g1((S - 1) * slot), dim3(256), 0, st, p.cs + slot, dec_c, (S - 1) * slot);
+    } else {
+        // streaming form; the cell states of every step are only written when the decoder states are wanted ([B,S,HS] in p.cs)
+        NIR_PROPAGATE(launch_birnn_steps(0, p.sgin, nullptr, w->s_whh, nullptr, nullptr, nullptr, sess, nullptr, nullptr, B, S, HS, 1, p.lstm_ws, st,
+                                         dec_c ? p.cs : nullptr));
+        if (S > 1 && (dec_h || dec_c))
+            hipLaunchKernelGGL(mnsrf_dec_states_kernel, g1((S - 1) * slot), dim3(256), 0, st, sess, dec_c ? p.cs : nullptr, dec_h, dec_c, B, S, HS);
+    }
     NIR_CHECK_LAUNCH("nir_mnsrf_encode");
+    return 0;
+}
+
+// scores from the query side (memory_bank [B,S,2Hq], session_bank [B,S,HS]) and the candidate documents
+static int mnsrf_rank(const float* mem, const float* sess, const int64_t* doc_ids, const int64_t* doc_lens, int64_t B, int S, int N, int DL,
+                      const float* table, int64_t V, int E, const nir_mnsrf_weights* w, const MnsrfPlan& p, float* scores, hipStream_t st) {
+    const int64_t Mq = B * S, Md = B * S * N;
+    const int Hq = w->Hq, Hd = w->Hd, HS = w->HS;
+    // documents: BiLSTM -> max over time
+    if (mnsrf_fast_d(w)) {
+        NIR_PROPAGATE(launch_lstm256_cluster(w->d_fold, doc_ids, doc_lens, w->d_whh_frag, p.docs, 1, w->err, Md, V, DL, 2, p.xbuf, p.xbuf_bytes, st));
+    } else {
+        NIR_PROPAGATE(launch_linear(nullptr, 0, doc_ids, table, E, 1, 1, w->d_wih, E, w->d_bih, w->d_bhh, p.gin, 8 * Hd, Md * DL, 8 * Hd, E, NIR_ACT_NONE, st));
+        NIR_PROPAGATE(launch_bilstm_steps(p.gin, doc_lens, w->d_whh, nullptr, nullptr, p.enc, nullptr, nullptr, Md, DL, Hd, 2, p.lstm_ws, st));
+        hipLaunchKernelGGL(maxpool_time_kernel, g1(Md * 2 * Hd), dim3(256), 0, st, p.enc, p.docs, Md, DL, 2 * Hd);
+    }
+    // tanh projection of [query ; session state] and the dot product with every candidate
+    const int KC = 2 * Hq + HS;
+    hipLaunchKernelGGL(mnsrf_concat_kernel, g1(Mq * KC), dim3(256), 0, st, mem, sess, p.comb, B, S, 2 * Hq, HS);
+    NIR_PROPAGATE(launch_linear(p.comb, KC, nullptr, nullptr, 0, 0, 0, w->proj_w, KC, w->proj_b, nullptr, p.proj, 2 * Hd, Mq, 2 * Hd, KC, NIR_ACT_TANH, st));
+    hipLaunchKernelGGL(mnsrf_dot_kernel, dim3((unsigned)((Md + 3) / 4)), dim3(256), 0, st, p.proj, p.docs, scores, Mq, N, 2 * Hd);
+    NIR_CHECK_LAUNCH("nir_mnsrf_rank");
     return 0;
 }
 
@@ -245,16 +341,35 @@ extern "C" size_t nir_mnsrf_workspace_bytes(int64_t B, int S, int N, int QL, int
     return nir::mnsrf_plan(nullptr, 0, B, S, N, QL, DL, w).bytes + 256;
 }
 
-extern "C" int nir_mnsrf_encode(const int64_t* source_ids, const int64_t* source_lens, int64_t B, int S, int QL, const float* table,
-                                int64_t V, int E, const nir_mnsrf_weights* w, void* workspace, size_t workspace_bytes,
-                                float* memory_bank, float* session_bank, nir_stream_t stream) {
+extern "C" int nir_mnsrf_encode_states(const int64_t* source_ids, const int64_t* source_lens, int64_t B, int S, int QL, const float* table,
+                                       int64_t V, int E, const nir_mnsrf_weights* w, void* workspace, size_t workspace_bytes,
+                                       float* memory_bank, float* session_bank, float* dec_h, float* dec_c, nir_stream_t stream) {
     using namespace nir;
     NIR_REQUIRE(source_ids && source_lens && table && w && workspace && memory_bank && session_bank, "mnsrf_encode: null pointer");
     NIR_REQUIRE(B >= 0 && S > 0 && QL > 0 && E > 0 && V > 0, "mnsrf_encode: bad dims");
     NIR_REQUIRE(workspace_bytes >= nir_mnsrf_workspace_bytes(B, S, 0, QL, 1, w), "mnsrf_encode: workspace too small");
     if (B == 0) return 0;
     const MnsrfPlan p = mnsrf_plan(workspace, workspace_bytes, B, S, 0, QL, 1, w);
-    return mnsrf_encode(source_ids, source_lens, B, S, QL, table, E, w, p, memory_bank, session_bank, (hipStream_t)stream);
+    return mnsrf_encode(source_ids, source_lens, B, S, QL, table, V, E, w, p, memory_bank, session_bank, dec_h, dec_c, (hipStream_t)stream);
+}
+
+extern "C" int nir_mnsrf_encode(const int64_t* source_ids, const int64_t* source_lens, int64_t B, int S, int QL, const float* table,
+                                int64_t V, int E, const nir_mnsrf_weights* w, void* workspace, size_t workspace_bytes,
+                                float* memory_bank, float* session_bank, nir_stream_t stream) {
+    return nir_mnsrf_encode_states(source_ids, source_lens, B, S, QL, table, V, E, w, workspace, workspace_bytes, memory_bank, session_bank,
+                                   nullptr, nullptr, stream);
+}
+
+extern "C" int nir_mnsrf_rank(const float* memory_bank, const float* session_bank, const int64_t* doc_ids, const int64_t* doc_lens, int64_t B,
+                              int S, int N, int DL, const float* table, int64_t V, int E, const nir_mnsrf_weights* w, void* workspace,
+                              size_t workspace_bytes, float* scores, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(memory_bank && session_bank && doc_ids && doc_lens && table && w && workspace && scores, "mnsrf_rank: null pointer");
+    NIR_REQUIRE(B >= 0 && S > 0 && N > 0 && DL > 0 && E > 0 && V > 0, "mnsrf_rank: bad dims");
+    NIR_REQUIRE(workspace_bytes >= nir_mnsrf_workspace_bytes(B, S, N, 1, DL, w), "mnsrf_rank: workspace too small");
+    if (B == 0) return 0;
+    const MnsrfPlan p = mnsrf_plan(workspace, workspace_bytes, B, S, N, 1, DL, w);
+    return mnsrf_rank(memory_bank, session_bank, doc_ids, doc_lens, B, S, N, DL, table, V, E, w, p, scores, (hipStream_t)stream);
 }
 
 extern "C" int nir_mnsrf_score(const int64_t* source_ids, const int64_t* source_lens, const int64_t* doc_ids, const int64_t* doc_lens,
@@ -268,18 +383,6 @@ extern "C" int nir_mnsrf_score(const int64_t* source_ids, const int64_t* source_
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const MnsrfPlan p = mnsrf_plan(workspace, workspace_bytes, B, S, N, QL, DL, w);
-    const int64_t Mq = B * S, Md = B * S * N;
-    const int Hq = w->Hq, Hd = w->Hd, HS = w->HS;
-    NIR_PROPAGATE(mnsrf_encode(source_ids, source_lens, B, S, QL, table, E, w, p, p.mem, p.sess, st));
-    // documents: gather-GEMM -> BiLSTM -> max over time
-    NIR_PROPAGATE(launch_linear(nullptr, 0, doc_ids, table, E, 1, 1, w->d_wih, E, w->d_bih, w->d_bhh, p.gin, 8 * Hd, Md * DL, 8 * Hd, E, NIR_ACT_NONE, st));
-    NIR_PROPAGATE(launch_bilstm_steps(p.gin, doc_lens, w->d_whh, nullptr, nullptr, p.enc, nullptr, nullptr, Md, DL, Hd, 2, p.lstm_ws, st));
-    hipLaunchKernelGGL(maxpool_time_kernel, g1(Md * 2 * Hd), dim3(256), 0, st, p.enc, p.docs, Md, DL, 2 * Hd);
-    // tanh projection of [query ; session state] and the dot product with every candidate
-    const int KC = 2 * Hq + HS;
-    hipLaunchKernelGGL(mnsrf_concat_kernel, g1(Mq * KC), dim3(256), 0, st, p.mem, p.sess, p.comb, B, S, 2 * Hq, HS);
-    NIR_PROPAGATE(launch_linear(p.comb, KC, nullptr, nullptr, 0, 0, 0, w->proj_w, KC, w->proj_b, nullptr, p.proj, 2 * Hd, Mq, 2 * Hd, KC, NIR_ACT_TANH, st));
-    hipLaunchKernelGGL(mnsrf_dot_kernel, dim3((unsigned)((Md + 3) / 4)), dim3(256), 0, st, p.proj, p.docs, scores, Mq, N, 2 * Hd);
-    NIR_CHECK_LAUNCH("nir_mnsrf_score");
-    return 0;
+    NIR_PROPAGATE(mnsrf_encode(source_ids, source_lens, B, S, QL, table, V, E, w, p, p.mem, p.sess, nullptr, nullptr, st));
+    return mnsrf_rank(p.mem, p.sess, doc_ids, doc_lens, B, S, N, DL, table, V, E, w, p, scores, st);
 }

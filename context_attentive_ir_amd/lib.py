@@ -66,6 +66,8 @@ MnsrfWeights = _struct(
     "nir_mnsrf_weights",
     ["q_wih", "q_whh", "q_bih", "q_bhh", "d_wih", "d_whh", "d_bih", "d_bhh", "s_wih", "s_whh", "s_bih", "s_bhh",
      "proj_w", "proj_b"], ["Hq", "Hd", "HS"])
+MnsrfWeights = type("nir_mnsrf_weights", (C.Structure,), {"_fields_": list(MnsrfWeights._fields_) + [
+    ("q_fold", C.c_void_p), ("d_fold", C.c_void_p), ("q_whh_frag", C.c_void_p), ("d_whh_frag", C.c_void_p), ("s_whh_frag", C.c_void_p), ("err", C.c_void_p)]})
 
 _i, _l, _z = C.c_int, C.c_int64, C.c_size_t
 # name -> (restype, argtypes); must list EVERY symbol include/neuroir_hip.h declares (tests check this)
@@ -100,6 +102,8 @@ SIGNATURES = {
                                      c_st]),
     "nir_mnsrf_workspace_bytes": (_z, [_l, _i, _i, _i, _i, C.POINTER(MnsrfWeights)]),
     "nir_mnsrf_encode": (_i, [c_ip, c_ip, _l, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z, c_fp, c_fp, c_st]),
+    "nir_mnsrf_encode_states": (_i, [c_ip, c_ip, _l, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z, c_fp, c_fp, c_fp, c_fp, c_st]),
+    "nir_mnsrf_rank": (_i, [c_fp, c_fp, c_ip, c_ip, _l, _i, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z, c_fp, c_st]),
     "nir_mnsrf_score": (_i, [c_ip, c_ip, c_ip, c_ip, _l, _i, _i, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z,
                             c_fp, c_st]),
     "nir_softmax_rows": (_i, [c_fp, c_fp, _l, _i, c_st]),
@@ -370,6 +374,9 @@ class IdCheck(object):
             v = int(flag.item()) if flag is not None else 0
             if v != 0:
                 flag.zero_()
+                if v & 4:
+                    raise RuntimeError("a recurrence cluster (csrc/lstm_cluster.hip) waited ~1 s for a partner workgroup that never became resident; "
+                                       "results of that forward are invalid")
                 if v & 2:
                     raise RuntimeError("recurrent weights outside the fp16 range of the folded MFMA recurrence (|w_hh| >= 2^15); "
                                        "results of that forward are invalid -- the exact fp32 recurrence handles such weights")

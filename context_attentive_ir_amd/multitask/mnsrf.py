@@ -4,9 +4,11 @@ neuroir.multitask.mnsrf.MNSRF, /root/reference/neuroir/multitask/mnsrf.py:10-162
 encode():        BiLSTM over every query of a session + max pooling over time -> memory_bank [B,S,nhid_query];
                  a unidirectional session LSTM over the S pooled queries   -> session_bank [B,S,nhid_session]
 rank_document(): BiLSTM + max pooling over every candidate document; score = tanh(W [q_t ; t > 0 ? s_t : 0] + b) . d
-One C-ABI call each (nir_mnsrf_encode / nir_mnsrf_score, csrc/mnsrf.hip).  The hidden sizes (256 per direction, 1024
-session units) are beyond the register-resident recurrences, so the LSTMs run in the streaming form (one MFMA GEMM +
-one cell kernel per time step).  The suggestion decoder / generator are parameter containers only (`decode` raises).
+One C-ABI call each (nir_mnsrf_encode_states / nir_mnsrf_rank, csrc/mnsrf.hip).  At the reference's sizes (256 units per direction, 1024
+session units) the encoders run on the resident-weight cluster recurrence (csrc/lstm_cluster.hip: W_hh spread over four CUs, gate rows
+gathered from a table folded once per weight version, max over time fused) and the session LSTM on the fp16-term step kernel -- built
+once per parameter version by `_weights()`; other sizes, a training model or `fold_embeddings=False` take the streaming form (one GEMM +
+one cell launch per time step).  The suggestion decoder / generator are parameter containers (greedy decode in multitask/suggest.py).
 """
 import torch
 import torch.nn as nn
@@ -43,8 +45,21 @@ class MNSRF(nn.Module, lib.IdCheck):
         self.dec_dropout_p = float(args.dropout_rnn)        # RNNDecoder.dropout (decoders/decoder.py:87), train mode only
         self._dims = dict(Hq=args.nhid_query // 2, Hd=args.nhid_document // 2, HS=args.nhid_session)
         self._pack = lib.PackCache()
+        self._pack_fold = lib.PackCache(retain=1)
+        # the folded gate tables (V x 2048 floats per encoder) + pre-split recurrent weights of the resident-weight path: on in eval mode while
+        # both tables stay under `fold_budget_bytes` (100 000 words: 1.6 GB)
+        self.fold_embeddings = getattr(args, "fold_embeddings", True)
+        self.fold_budget_bytes = 64 << 30
+
+    def _use_fold(self, table):
+        per = table.shape[0] * 8 * 256 * 4
+        return (self.fold_embeddings and not self.training and self._dims["Hq"] == 256 and self._dims["Hd"] == 256
+                and 2 * per <= self.fold_budget_bytes)
 
     def _weights(self):
+        table = self.embedder.word_embeddings.table
+        fold = self._use_fold(table)
+
         def build():
             q = lstm_cat_weights(self.query_encoder.encoder.rnns[0])
             d = lstm_cat_weights(self.document_encoder.encoder.rnns[0])
@@ -52,9 +67,31 @@ class MNSRF(nn.Module, lib.IdCheck):
             t = dict(q_wih=q[0], q_whh=q[1], q_bih=q[2], q_bhh=q[3], d_wih=d[0], d_whh=d[1], d_bih=d[2], d_bhh=d[3],
                      s_wih=s[0], s_whh=s[1], s_bih=s[2], s_bhh=s[3],
                      proj_w=self.projection.linear.weight, proj_b=self.projection.linear.bias)
-            return lib.Packed(lib.MnsrfWeights, t, self._dims)
-        skip = ("embedder.", "decoder.", "generator.")
-        return self._pack.get([p for n, p in self.named_parameters() if not n.startswith(skip)], build)
+            pk = lib.Packed(lib.MnsrfWeights, t, self._dims)
+            dev = pk.keep["q_whh"].device
+            pk.err = torch.zeros(1, dtype=torch.int32, device=dev)
+            pk.struct.err = pk.err.data_ptr()
+            self._err_flag = pk.err
+            L = lib.load()
+            HS = self._dims["HS"]
+            if HS % 32 == 0 and dev.type == "cuda":            # session LSTM: W_hh as fp16 term pairs in MFMA-fragment order
+                frag = torch.empty(max(1, L.nir_lstm_step_whh_frag_bytes(HS)), dtype=torch.uint8, device=dev)
+                lib.check(L.nir_lstm_step_pack_whh_frag(lib.ptr(pk.keep["s_whh"]), HS, lib.ptr(frag), lib.ptr(pk.err), lib.stream()), "nir_lstm_step_pack_whh_frag")
+                pk.keep["s_whh_frag"] = frag
+                pk.struct.s_whh_frag = frag.data_ptr()
+            if fold and dev.type == "cuda":
+                for k in ("q", "d"):
+                    frag = torch.empty(L.nir_lstm256_whh_frag_bytes(2), dtype=torch.uint8, device=dev)
+                    lib.check(L.nir_lstm256_pack_whh_frag(lib.ptr(pk.keep[k + "_whh"]), 2, lib.ptr(frag), lib.ptr(pk.err), lib.stream()), "nir_lstm256_pack_whh_frag")
+                    pk.keep[k + "_whh_frag"] = frag
+                    setattr(pk.struct, k + "_whh_frag", frag.data_ptr())
+                    ft = lib.fold_lstm_table(table.detach(), pk.keep[k + "_wih"], pk.keep[k + "_bih"], pk.keep[k + "_bhh"], 256, 2, "f32")
+                    pk.keep[k + "_fold"] = ft
+                    setattr(pk.struct, k + "_fold", ft.data_ptr())
+            return pk
+        skip = ("decoder.", "generator.") + (() if fold else ("embedder.",))
+        params = [p for n, p in self.named_parameters() if not n.startswith(skip)] + [fold]
+        return self._pack.get(params, build)
 
     def _check_eval(self):
         if self.training and (self.dropout.p > 0 or self.embedder.dropout.p > 0):
@@ -68,41 +105,60 @@ class MNSRF(nn.Module, lib.IdCheck):
         lib.require_device(source_rep, source_len, table)
         L = lib.load()
         B, S, QL = source_rep.shape
-        src, sl = lib.ids64(source_rep.reshape(B * S, QL)), lib.ids64(source_len.reshape(-1))
+        src, _ = self._clean_ids(source_rep.reshape(B * S, QL), None, table.shape[0])
+        sl = lib.ids64(source_len.reshape(-1))
         w = self._weights()
         ws = lib.workspace(L.nir_mnsrf_workspace_bytes(B, S, 0, QL, 1, w.ref()), src.device)
+        HS = self._dims["HS"]
         mem = torch.empty(B, S, 2 * self._dims["Hq"], device=src.device, dtype=torch.float32)
-        sess = torch.empty(B, S, self._dims["HS"], device=src.device, dtype=torch.float32)
+        sess = torch.empty(B, S, HS, device=src.device, dtype=torch.float32)
+        # the decoder's initial states (mnsrf.py:96-112): the session LSTM's (h, c) after every query but the last, step-major along the batch
+        # axis -- written by the same call (the session recurrence runs once)
+        states = None
+        if B > 0 and S > 1:
+            states = (torch.empty(1, (S - 1) * B, HS, device=src.device, dtype=torch.float32),
+                      torch.empty(1, (S - 1) * B, HS, device=src.device, dtype=torch.float32))
         if B > 0:
-            lib.check(L.nir_mnsrf_encode(lib.ptr(src), lib.ptr(sl), B, S, QL, lib.ptr(table), table.shape[0], table.shape[1],
-                                         w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(mem), lib.ptr(sess), lib.stream()),
-                      "nir_mnsrf_encode")
+            lib.check(L.nir_mnsrf_encode_states(lib.ptr(src), lib.ptr(sl), B, S, QL, lib.ptr(table), table.shape[0], table.shape[1],
+                                                w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(mem), lib.ptr(sess),
+                                                lib.ptr(states[0]) if states else None, lib.ptr(states[1]) if states else None, lib.stream()),
+                      "nir_mnsrf_encode_states")
         self._src_len = source_len
-        # the decoder's initial states (mnsrf.py:96-112): the session LSTM's state after every query but the last, step-major along the
-        # batch axis -- the fused encode keeps only h, so the (tiny) session recurrence is run once more with its cell states written out
-        states = suggest.session_states(mem, self.session_query_encoder.encoder.rnns[0])[1] if B > 0 and S > 1 else None
         return mem, sess, states
 
     def rank_document(self, source_rep, memory_bank, session_bank, document_rep, document_len, source_len=None):
-        """-> scores [B,S,N]  (mnsrf.py:116-162).  The query side is re-derived from the ids inside the fused call (the
-        same values as memory_bank / session_bank); `source_len` defaults to the lengths given to encode()."""
+        """-> scores [B,S,N]  (mnsrf.py:116-162) from the query side encode() returned.  memory_bank / session_bank None: the query side
+        is re-derived from the ids inside one fused call (`source_len` then defaults to the lengths given to encode())."""
         self._check_eval()
         table = self.embedder.word_embeddings.table
+        lib.require_device(source_rep, document_rep, document_len, table)
+        L = lib.load()
+        B, S, N, DL = document_rep.shape
+        QL = source_rep.shape[2]
+        w = self._weights()
+        scores = torch.empty(B, S, N, device=document_rep.device, dtype=torch.float32)
+        if memory_bank is not None and session_bank is not None:
+            d, _ = self._clean_ids(document_rep.reshape(B * S * N, DL), None, table.shape[0])
+            dl = lib.ids64(document_len.reshape(-1))
+            mem, sess = memory_bank.float().contiguous(), session_bank.float().contiguous()
+            if tuple(mem.shape[:2]) != (B, S) or tuple(sess.shape[:2]) != (B, S):
+                raise RuntimeError("rank_document: memory_bank %s / session_bank %s do not belong to %d x %d queries" % (
+                    tuple(mem.shape), tuple(sess.shape), B, S))
+            ws = lib.workspace(L.nir_mnsrf_workspace_bytes(B, S, N, 1, DL, w.ref()), d.device)
+            if B > 0:
+                lib.check(L.nir_mnsrf_rank(lib.ptr(mem), lib.ptr(sess), lib.ptr(d), lib.ptr(dl), B, S, N, DL, lib.ptr(table), table.shape[0],
+                                           table.shape[1], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(scores), lib.stream()), "nir_mnsrf_rank")
+            return scores
         src_len = source_len if source_len is not None else getattr(self, "_src_len", None)
         if src_len is None:
             raise RuntimeError("rank_document needs the query lengths: call encode() first or pass source_len")
         if src_len.numel() != source_rep.shape[0] * source_rep.shape[1]:
             raise RuntimeError("rank_document: %d query lengths for %d x %d queries (lengths cached by encode() belong to another "
                                "batch? pass source_len)" % (src_len.numel(), source_rep.shape[0], source_rep.shape[1]))
-        lib.require_device(source_rep, document_rep, document_len, src_len, table)
-        L = lib.load()
-        B, S, N, DL = document_rep.shape
-        QL = source_rep.shape[2]
+        lib.require_device(src_len)
         src, d = self._clean_ids(source_rep.reshape(B * S, QL), document_rep.reshape(B * S * N, DL), table.shape[0])
         sl, dl = lib.ids64(src_len.reshape(-1)), lib.ids64(document_len.reshape(-1))
-        w = self._weights()
         ws = lib.workspace(L.nir_mnsrf_workspace_bytes(B, S, N, QL, DL, w.ref()), src.device)
-        scores = torch.empty(B, S, N, device=src.device, dtype=torch.float32)
         if B > 0:
             lib.check(L.nir_mnsrf_score(lib.ptr(src), lib.ptr(sl), lib.ptr(d), lib.ptr(dl), B, S, N, QL, DL, lib.ptr(table),
                                         table.shape[0], table.shape[1], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(scores),

@@ -501,6 +501,13 @@ typedef struct {
     const float *s_wih, *s_whh, *s_bih, *s_bhh;   /* session_query_encoder.encoder.rnns.0 (unidirectional) [4HS,2Hq],[4HS,HS],[4HS],[4HS] */
     const float *proj_w, *proj_b;                 /* projection.linear [2Hd, 2Hq+HS], [2Hd] */
     int Hq, Hd, HS;                               /* per-direction hidden sizes 256, 256; session 1024 */
+    /* Optional (NULL = the streaming form: one GEMM + one cell launch per time step).  Round 5, the resident-weight path for the
+     * reference's sizes (Hq = Hd = 256, HS % 32 == 0); every field is built once per weight version: */
+    const float *q_fold, *d_fold;                 /* nir_lstm_fold_table(table, q_/d_ w_ih, b_ih, b_hh, H = 256, ndir = 2, f32): [V, 2048] gate rows */
+    const void *q_whh_frag, *d_whh_frag;          /* nir_lstm256_pack_whh_frag(q_/d_ w_hh, 2): encoders run as ONE nir_lstm256_rows_fwd launch
+                                                     each, max over time fused (mode 1) */
+    const void* s_whh_frag;                       /* nir_lstm_step_pack_whh_frag(s_whh, HS): session LSTM as one step launch per query */
+    int* err;                                     /* device flag (may be NULL): bit 0 token id outside [0,V), bit 1 |w_hh| >= 2^15, bit 2 cluster time-out */
 } nir_mnsrf_weights;
 size_t nir_mnsrf_workspace_bytes(int64_t B, int S, int N, int QL, int DL, const nir_mnsrf_weights* w /*host*/);
 /* MNSRF.encode (mnsrf.py:62-114): source ids [B,S,QL], lens [B,S] -> memory_bank [B,S,2Hq] (BiLSTM, max over time),
@@ -508,7 +515,17 @@ size_t nir_mnsrf_workspace_bytes(int64_t B, int S, int N, int QL, int DL, const 
 int nir_mnsrf_encode(const int64_t* source_ids, const int64_t* source_lens, int64_t B, int S, int QL, const float* table,
                      int64_t V, int E, const nir_mnsrf_weights* w /*host*/, void* workspace, size_t workspace_bytes,
                      float* memory_bank, float* session_bank, nir_stream_t stream);
-/* MNSRF.encode + rank_document (mnsrf.py:116-162): scores [B,S,N] = tanh(W [q_t ; t>0 ? s_t : 0] + b) . maxpool(BiLSTM(doc)). */
+/* The same, plus the suggestion decoder's initial states (mnsrf.py:96-112): dec_h / dec_c [(S-1)*B, HS] = the session LSTM's (h, c) after
+ * queries 0 .. S-2, step-major along the batch axis (torch.cat(states[:-1], 1)); either may be NULL. */
+int nir_mnsrf_encode_states(const int64_t* source_ids, const int64_t* source_lens, int64_t B, int S, int QL, const float* table,
+                            int64_t V, int E, const nir_mnsrf_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                            float* memory_bank, float* session_bank, float* dec_h, float* dec_c, nir_stream_t stream);
+/* MNSRF.rank_document (mnsrf.py:116-162) from the query side encode() returned: scores [B,S,N] = tanh(W [q_t ; t>0 ? s_t : 0] + b) .
+ * maxpool(BiLSTM(doc)).  workspace: nir_mnsrf_workspace_bytes(B, S, N, 1, DL, w). */
+int nir_mnsrf_rank(const float* memory_bank, const float* session_bank, const int64_t* doc_ids, const int64_t* doc_lens, int64_t B, int S,
+                   int N, int DL, const float* table, int64_t V, int E, const nir_mnsrf_weights* w /*host*/, void* workspace,
+                   size_t workspace_bytes, float* scores, nir_stream_t stream);
+/* MNSRF.encode + rank_document in one call (the query side re-derived from the ids). */
 int nir_mnsrf_score(const int64_t* source_ids, const int64_t* source_lens, const int64_t* doc_ids, const int64_t* doc_lens,
                     int64_t B, int S, int N, int QL, int DL, const float* table, int64_t V, int E,
                     const nir_mnsrf_weights* w /*host*/, void* workspace, size_t workspace_bytes, float* scores,

@@ -55,8 +55,8 @@ def main():
         torch.cuda.synchronize()
         v = dbg.cpu().tolist()
         n = max(1, v[8])
-        names = ["wait granules+rows, LDS fill", "barrier", "requests", "LDS reads + MFMAs", "gate math, h writes", "deferred stores"]
-        print("per phase (s_memtime ticks / 10 = shader cycles): " + "; ".join("%s %.0f" % (names[i], v[i] / n) for i in range(6)) + "; phases %d" % n)
+        names = ["LDS fill + row take-over", "barrier", "publish (+ requests of rank 1)", "LDS reads + MFMAs", "gate math, h writes", "requests of rank 0", "wait for pieces", "polls x1000"]
+        print("per phase (s_memtime ticks / 10 = shader cycles): " + "; ".join("%s %.0f" % (names[i], v[i] / n * (1000 if i == 7 else 1)) for i in range(8)) + "; phases %d" % n)
         L.nir_debug_set_buffer(None)
     t0 = time.perf_counter()
     for _ in range(a.iters):
