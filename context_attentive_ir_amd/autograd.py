@@ -53,7 +53,7 @@ class StepScope(object):
         self.bufs = {}            # id(param) -> (param, persistent gradient buffer)
         self.pend_w = {}          # id(weight) -> (param, [(dY [M,N], X [M,K]), ..]) of this step
         self.pend_b = {}          # id(bias)   -> (param, [dY, ..])
-        self.wt = {}              # (data_ptr, version, shape) -> transposed weight, this step
+        self.wt = {}              # (data_ptr, version, shape) -> (source tensor, transposed weight), this step
 
     def begin(self):
         self.active, self.pend_w, self.pend_b, self.wt = True, {}, {}, {}
@@ -124,13 +124,13 @@ def _is_param(t):
 def _transpose(w):
     key = (w.data_ptr(), w._version, tuple(w.shape))
     if STEP.active and key in STEP.wt:
-        return STEP.wt[key]
+        return STEP.wt[key][1]
     L = lib.load()
     R, Cc = w.shape
     out = torch.empty(Cc, R, device=w.device, dtype=torch.float32)
     lib.check(L.nir_transpose_f32(lib.ptr(w), R, Cc, lib.ptr(out), lib.stream()), "nir_transpose_f32")
     if STEP.active:
-        STEP.wt[key] = out
+        STEP.wt[key] = (w, out)      # the source is held for the step: its address cannot be handed to another same-shape temporary while the entry lives
     return out
 
 

@@ -162,7 +162,8 @@ extern "C" int nir_cars_encode(const int64_t* ids, const int64_t* lens, int64_t 
     // [M*T, 8H] tensor is handed to the folded recurrence as a "table" of M*T rows with the row number as token id -- same kernels
     // (fp16-split MFMA recurrence with the pre-split W_hh, term pairs to the fused attention pipeline) instead of the round-1 recurrence
     // (347 us per 1 120 documents against 75) and the three-launch attention.  What remains of the per-batch cost is the gather-GEMM itself.
-    if (H >= 32 && (2 * H) % 64 == 0 && H <= 128 && M * T < ((int64_t)1 << 31) && !tun(g_tun.exact_f32) && !tun(g_tun.nofold_old)) {
+    // (bit 2 of `bounded`: |W_hh| < 2^15, host-checked -- outside it the fp16 split overflows: the exact fp32 recurrence below takes over)
+    if (H >= 32 && (2 * H) % 64 == 0 && H <= 128 && M * T < ((int64_t)1 << 31) && (w->bounded & 4) && !tun(g_tun.exact_f32) && !tun(g_tun.nofold_old)) {
         NIR_PROPAGATE(launch_fold_permute(w->wih, w->bih, w->bhh, H, 2, E, p.wperm, p.bperm, p.iota, M * T, st));
         // (bit 1 of `bounded`: |table|, |W_ih| < 2^15 host-checked -> the gather-GEMM takes the fp16 two-term split, 3 MFMAs per product instead of 6)
         NIR_PROPAGATE(launch_linear_ex(nullptr, 0, ids, table, E, 1, 1, p.wperm, E, p.bperm, nullptr, p.gates, 8 * H, M * T, 8 * H, E,

@@ -517,11 +517,6 @@ int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st) {
         NIR_CHECK_LAUNCH("lstm_step_kernel");
         return 0;
     }
-    if (a.B > 32) hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, st, a);
-    else if (a.B > 16) hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, a);
-    NIR_CHECK_LAUNCH("lstm_step_kernel");
-    return 0;
 }
 
 // Cross attention over the session states (cars.py:348-366) for one (session b, step t) per workgroup, projection folded

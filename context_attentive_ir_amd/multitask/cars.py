@@ -150,13 +150,14 @@ class CARS(nn.Module, lib.IdCheck):
             # fold budget) runs on the fp16 two-term form
             table = self.embedder.word_embeddings.table
             gb = float(table.detach().abs().max()) < 32768.0 and float(wih.detach().abs().max()) < 32768.0
+            # the folded recurrences run W_hh on the fp16 matrix cores (two-term split / single term): outside that range the encoder
+            # takes the per-batch path with the exact fp32 recurrence (one check per weight version; bit 2 of `bounded` tells nir_cars_encode)
+            rec_ok = float(whh.detach().abs().max()) < 32768.0
             pk = lib.Packed(lib.CarsEncoderWeights,
                             dict(wih=wih, whh=whh, bih=bih, bhh=bhh, attn0_w=attn[0].weight, attn0_b=attn[0].bias,
                                  attn3_w=attn[3].weight, attn3_b=attn[3].bias),
-                            dict(H=enc.hidden, bounded=int(bounded) | (int(gb) << 1)))
-            # the folded recurrences run W_hh on the fp16 matrix cores (two-term split / single term): outside that range the encoder
-            # takes the per-batch fp32 path (one check per weight version)
-            pk.rec_ok = float(whh.detach().abs().max()) < 32768.0
+                            dict(H=enc.hidden, bounded=int(bounded) | (int(gb) << 1) | (int(rec_ok) << 2)))
+            pk.rec_ok = rec_ok
             L = lib.load()
             nb = L.nir_lstm_whh_frag_bytes(enc.hidden, 2)
             if nb and pk.rec_ok and whh.is_cuda:     # W_hh pre-split in the lane order of the folded fp32 recurrence (once per weight version)

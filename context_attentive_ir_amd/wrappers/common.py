@@ -174,6 +174,18 @@ class WrapperBase(object):
         try:
             from .. import autograd as A
             opt = dict(self.optimizer.state_dict())
+            # the reference's checkpoint holds a float learning rate and no fused / capturable flags (models/ranker.py:283-292): GraphedUpdate's
+            # device-tensor rate and this build's optimizer flavour are run-time choices, re-made by init_optimizer on the resuming side
+            groups = []
+            for g in opt.get("param_groups", []):
+                g = dict(g)
+                if torch.is_tensor(g.get("lr")):
+                    g["lr"] = float(g["lr"])
+                for k in ("fused", "capturable", "foreach"):
+                    if k in g:
+                        g[k] = None if k != "capturable" else False
+                groups.append(g)
+            opt["param_groups"] = groups
             opt["_nir_dropout_state"] = (A.DROPOUT.seed, A.DROPOUT.counter)
             torch.save(self._params({"epoch": epoch, "optimizer": opt}), filename)
         except BaseException:
@@ -241,6 +253,12 @@ class GraphedUpdate(object):
         self._device_lr(dev)
         key = (self._key(ex), self._hyper())
         ent = self.graphs.get(key)
+        if ent is None:
+            # a host-side hyper-parameter changed (SGD's per-epoch `lr *= lr_decay`, a new float rate): the graphs captured under the old
+            # values can never be replayed again -- drop them (graph, static inputs, private pool) instead of growing by one set of shapes
+            # per epoch
+            for k in [k for k in self.graphs if k[1] != key[1]]:
+                del self.graphs[k]
         caller = torch.cuda.current_stream(dev)
         if ent is None:
             if self.stream is None:

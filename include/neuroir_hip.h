@@ -283,7 +283,8 @@ typedef struct {
     int H;                               /* 128 per direction */
     int bounded;                         /* host-checked: every attention weight is < 2^15 in magnitude (the encoder outputs are in
                                             (-1,1) by construction) -> the attention GEMM may use the fp16 two-term split (bit 0); bit 1: the embedding table
-                                            and wih are < 2^15 as well -> the per-batch gather-GEMM of nir_cars_encode may use it too */
+                                            and wih are < 2^15 as well -> the per-batch gather-GEMM of nir_cars_encode may use it too;
+                                            bit 2: |whh| < 2^15 -> nir_cars_encode may run its recurrence on the fp16 two-term split (clear: the exact fp32 recurrence) */
     const void* attn_frag;               /* optional (NULL: GEMM + pooling kernels): attn0_w [2H,2H] with 2H = 256 split into two fp16 terms
                                             (nir_split_f16x2) in MFMA-fragment order [K/32][16 column tiles][2 terms][64 lanes][8], lane =
                                             16*(k%32/8) + column%16 -- operand of the fused attention-pooling kernel (csrc/cars_attn.hip),

@@ -134,6 +134,20 @@ def test_cars_unbounded_attention_and_recurrent_weights():
     assert m._enc_weights("d").rec_ok is False and m._enc_weights("q").rec_ok is True
     _rel_close(s, ref(m))
     m.check_ids()                                             # nothing flagged: the folded kernel never saw those weights
+    # (b2) ADVICE r4: a W_hh entry beyond fp16 altogether (1e5 -> inf as an fp16 term), with and without folded tables: the per-batch path must
+    # run the exact fp32 recurrence (bit 2 of `bounded` clear), not the fp16 split it shares with the folded form
+    for fold in (True, False):
+        m = build_model("CARS", vocab=V, tgt_vocab_size=300, device=DEV, fold_embeddings=fold)
+        with torch.no_grad():
+            m.document_encoder.encoder.rnns[0].weight_hh_l0[7, 9] = 1.0e5
+        s = run(m)
+        assert (m._enc_weights("d").struct.bounded & 4) == 0 and (m._enc_weights("q").struct.bounded & 4) == 4
+        assert bool(torch.isfinite(s).all())
+        _rel_close(s, ref(m))
+        m.check_ids()
+    m = build_model("CARS", vocab=V, tgt_vocab_size=300, device=DEV)
+    with torch.no_grad():
+        m.document_encoder.encoder.rnns[0].weight_hh_l0[7, 9] = 5.0e4
     # (c) direct C-ABI call
     from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
     wih, whh, bih, bhh = [t.detach().contiguous() for t in lstm_cat_weights(m.document_encoder.encoder.rnns[0])]
