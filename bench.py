@@ -939,10 +939,22 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     # ---- H2D-inclusive figure: ids arrive from the HOST for every batch (collate into pinned staging -> H2D -> replay -> D2H of the
     # probabilities), sustained over >= 5 s regardless of --steps.  CARS: graph_runner.StreamingSessionPredictor (int32 wire format,
     # 2 staging slots per lane, producer thread); rankers: GraphedPredictor fed from packed pinned batches.
-    h2d_value, h2d_info = None, None
+    h2d_value, h2d_info, sustained = None, None, None
     if with_h2d and world == 1 and not env.multi and not os.environ.get("BENCH_NO_H2D"):
         try:
             secs = float(os.environ.get("BENCH_H2D_SECONDS", "5"))
+            # the RESIDENT loop over the same protocol as the H2D-inclusive figure below (sustained for the same seconds, one synchronise at the
+            # end): the ratio of the two is then an H2D cost, not a difference between a 3 ms median region and a 5 s window
+            rewind()
+            torch.cuda.synchronize()
+            ts_, ns_ = time.perf_counter(), 0
+            while time.perf_counter() - ts_ < secs:
+                run_steps(steps)
+                ns_ += steps
+                if ns_ % (8 * steps) == 0:
+                    torch.cuda.synchronize()              # (bounded queue depth, like the streaming path's slots)
+            torch.cuda.synchronize()
+            sustained = per_step_pairs * ns_ / (time.perf_counter() - ts_)
             if c["model"] == "cars":
                 from context_attentive_ir_amd.graph_runner import StreamingSessionPredictor
                 from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
@@ -1068,6 +1080,9 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             eager_default["id_check_interval_%d_ms_per_call" % iv] = round((time.perf_counter() - te) / 20 * 1e3, 4)
         model.id_check_interval = 0
         lib.set_batches_in_flight(hint, lanes[:1])
+        # what a caller who changes NOTHING gets: wrapper.predict(), one stream, eager launches, id_check_interval = 1
+        eager_default["default_settings_pairs_per_s"] = round(pairs_global / eager_default["id_check_interval_1_ms_per_call"] * 1e3, 1)
+        eager_default["deferred_id_check_pairs_per_s"] = round(pairs_global / eager_default["id_check_interval_0_ms_per_call"] * 1e3, 1)
     cpu = None
     if want_cpu and rank == 0 and not env.multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(c, model, batches, lambda: finish(forward(0)), pairs_global, args)
@@ -1113,7 +1128,8 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             "batches_in_flight": len(lanes) * (stages["KG"] if (stages is not None and "aligned" in stages) else 1),
             "macro_batch": (stages["KG"] if (stages is not None and "aligned" in stages) else 1), "lanes": len(lanes), "host_enqueue_ms_per_step": round(host_ms, 5),
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
-            "h2d_inclusive_over_resident": None if h2d_value is None else round(h2d_value / value, 4), "h2d_stream": h2d_info,
+            "resident_sustained_pairs_per_s": None if sustained is None else round(sustained, 1),
+            "h2d_inclusive_over_resident": None if (h2d_value is None or not sustained) else round(h2d_value / sustained, 4), "h2d_stream": h2d_info,
             "dtype": c.get("dtype", "f32"), "precompute": pre, "wrapper_predict_eager_one_stream": eager_default, "roofline": roofline, "cpu_baseline": cpu, "power": power}
 
 
@@ -1136,8 +1152,14 @@ def cpu_baseline(c, model, batches, gpu_step, pairs, args):
     gpu = gpu_step().cpu()
     maxdiff = float((gpu - ref.view_as(gpu)).abs().max())
     avail = os.cpu_count() or ncores
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or avail
+    except Exception:
+        phys = avail
     best_t, best_rate, by_threads = ncores, 0.0, {}
-    for t in sorted({min(avail, k) for k in (8, 16, 32, 64)}):    # tiny per-op tensors oversubscribe a big host: probe thread counts
+    # k = 8 AND all physical cores, stated; the counts between are probed because tiny per-op tensors oversubscribe a big host
+    for t in sorted({min(avail, k) for k in (8, 16, 32, 64, phys)}):
         torch.set_num_threads(t)
         fn()
         n0, t0 = 0, time.perf_counter()
@@ -1164,7 +1186,8 @@ def cpu_baseline(c, model, batches, gpu_step, pairs, args):
     except OSError:
         pass
     return {"value": round(n * pairs / dt, 1), "unit": "pairs/s", "cores": best_t, "kind": "port", "cpu_model": cpu_model,
-            "host_logical_cores": avail, "threads_pinned": "torch.set_num_threads(%d)" % best_t, "probe_pairs_per_s_by_threads": by_threads,
+            "host_logical_cores": avail, "host_physical_cores": phys, "value_8_threads": by_threads.get(str(min(avail, 8))),
+            "value_all_physical_cores": by_threads.get(str(min(avail, phys))), "threads_pinned": "torch.set_num_threads(%d)" % best_t, "probe_pairs_per_s_by_threads": by_threads,
             "sample": "%d batches of the same %s workload in %.1f s (oracle/neuroir_cpu.py = pinned port of the reference, torch %s CPU, "
                       "best of {8,16,32,64} threads = %d; host has %d logical cores)" % (n, m, dt, torch.__version__, best_t, avail),
             "max_abs_diff_vs_gpu_softmax": maxdiff}
@@ -1246,7 +1269,7 @@ def short_sub(n, r):
         e["emulated_world"] = r.get("emulated_world")
     if r.get("overlapped_vs_serial_max_abs_diff") is not None:       # lanes in flight vs the same graphs alone (a record above OVERLAP_TOL fails)
         e["ovl"] = float("%.2g" % r["overlapped_vs_serial_max_abs_diff"])
-    for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle", "kg"):
+    for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle", "max_abs_diff_vs_oracle", "prob_max_abs_diff", "map10_equal", "kg"):
         if k in r:
             e[k] = r[k]
     if r.get("power"):
@@ -1345,6 +1368,14 @@ def run_records(args, env):
                 sub[n].update({k: gap["reference"][k] for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle")})       # the default policy
             except Exception as e:
                 sub[n]["parity_gap_on_overlapping_ids"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if n == "C5_cars_bf16" and not env.multi and env.rank == 0 and "error" not in sub.get(n, {"error": 1}) and not args.no_cpu_baseline:
+            try:
+                gap = bf16_parity_gap(args)
+                sub[n]["bf16_error_vs_oracle"] = gap
+                sub[n].update({k: gap[k] for k in ("max_abs_diff_vs_oracle", "prob_max_abs_diff", "map_delta_vs_oracle", "map10_equal")})
+            except Exception as e:
+                sub[n]["bf16_error_vs_oracle"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
     full = not adhoc and args.sub is None
     if head["model"] == "cars" and full and not env.multi:
         # the same workload WITHOUT the folded gate tables: per-batch gather-GEMM for the LSTM input projection
@@ -1366,6 +1397,14 @@ def run_records(args, env):
     if head["model"] == "cars" and full and not os.environ.get("BENCH_NO_STREAM"):
         secs = float(os.environ.get("BENCH_H2D_SECONDS", "5"))
         attempt("C5_stream", lambda: stream_record(args, env, seconds=secs, mode="batch" if env.multi else None))
+        if not env.multi and env.rank == 0 and "error" not in sub.get("C5_stream", {"error": 1}) and not args.no_cpu_baseline:
+            try:
+                gap = bf16_parity_gap(args, stream=True)
+                sub["C5_stream"]["bf16_error_vs_oracle"] = gap
+                sub["C5_stream"].update({k: gap[k] for k in ("prob_max_abs_diff", "map_delta_vs_oracle")})
+            except Exception as e:
+                sub["C5_stream"]["bf16_error_vs_oracle"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
         if env.multi and CONFIGS["C5_cars_bf16"]["batch"] % int(os.environ.get("BENCH_EMULATE_WORLD", env.world)) == 0:
             attempt("C5_stream_pair", lambda: stream_record(args, env, seconds=secs, mode="pair"))
     weak = None
@@ -1388,14 +1427,21 @@ def compose_line(args, env, rec, sub, weak):
     cfg = {"name": rec["name"], "workload": rec["workload"], "macro_batch": rec["macro_batch"], "lanes": rec["lanes"],
            "batches_in_flight": rec["batches_in_flight"], "ms_per_step_one_batch_in_flight": rec["ms_per_step_one_batch_in_flight"],
            "hipgraph": rec["hipgraph"], "parallelism": rec["parallelism"][:400], "shard_axis": rec.get("shard_axis"), "world_size": rec["world_size"],
-           "pairs_per_s_with_host_ids_h2d": rec["pairs_per_s_with_host_ids_h2d"], "weak_scaling_pairs_per_s": weak, "detail": where}
+           "pairs_per_s_with_host_ids_h2d": rec["pairs_per_s_with_host_ids_h2d"], "weak_scaling_pairs_per_s": weak, "detail": where,
+           # `value` runs hipGraph replays, several lanes, macro-batches and DEFERRED id checks (id_check_interval = 0); next to it what the wrapper's
+           # defaults give: predict() eagerly on one stream with the blocking id check of every call (id_check_interval = 1)
+           "default_settings_pairs_per_s": (rec.get("wrapper_predict_eager_one_stream") or {}).get("default_settings_pairs_per_s"),
+           "resident_sustained_pairs_per_s": rec.get("resident_sustained_pairs_per_s"),
+           "h2d_inclusive_over_resident_sustained": rec.get("h2d_inclusive_over_resident")}
     pw = rec.get("power")
     pw = {k: pw.get(k) for k in ("package_w", "cap_w", "sclk_mhz")} if pw else None
     small = {k: roof.get(k) for k in ROOF_KEYS}
     small["precompute_fold_ms"], small["precompute_fold_bytes"] = pre.get("fold_ms"), pre.get("fold_bytes")
     if cpu:
-        cpu = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model", "host_logical_cores", "max_abs_diff_vs_gpu_softmax")}
-        cpu["sample"] = "%.0f s of the same workload through oracle/neuroir_cpu.py (torch CPU, best of 8/16/32/64 threads)" % args.cpu_seconds
+        cpu = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model", "host_logical_cores", "host_physical_cores", "value_8_threads",
+                                       "value_all_physical_cores", "max_abs_diff_vs_gpu_softmax")}
+        cpu["sample"] = ("%.0f s of the same workload through oracle/neuroir_cpu.py (torch CPU); value = the best thread count (cores), next to k = 8 and "
+                         "k = all physical cores (0.75 s probes each)" % args.cpu_seconds)
     line = {"metric": "ranked (query,doc) pairs/sec", "value": rec["pairs_per_s"], "unit": "pairs/s", "n_gpus": env.seen,
             "steps": args.steps, "warmup": args.warmup, "reps": rec["reps"], "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
             # the global batch is FIXED as N grows (every rank scores its share of the same batch): strong scaling at every N
@@ -1448,6 +1494,56 @@ def drmm_parity_gap(args):
                        "map_delta_vs_oracle": round(ltorank.MAP(a_got, lab.numpy()) - ltorank.MAP(a_ref, lab.numpy()), 5)}
     m.exact_match_policy = "reference"
     return out
+
+
+def bf16_parity_gap(args, stream=False):
+    """Checker leg (rank 0, N = 1; the oracle is used as the checker only): the ACHIEVED error of the bf16 path (BASELINE configs[4]) against the
+    fp32 oracle on slices the oracle finishes in seconds -- (a) a configs[4]-shaped slice (4 sessions x 7 queries x 50 candidates, q_len 4,
+    doc_len 64, V = 100 000), (b) a 10-candidate slice for MAP@10 (BASELINE's "MAP@10 parity" = equality here); stream=True: the same model
+    through graph_runner.StreamingSessionPredictor on a 24-session stream.  Rides in the C5_cars_bf16 / C5_stream records."""
+    from oracle import neuroir_cpu as O
+    from context_attentive_ir_amd.eval import ltorank
+    c = dict(CONFIGS["C5_cars_bf16"])
+    model = build_model(c, args)
+    sd = {k: v.detach().cpu().float() for k, v in model.network.state_dict().items()}
+
+    def oracle(ex):
+        return O.cars_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])
+    out = {}
+    if not stream:
+        worst_s, worst_p = 0.0, 0.0
+        for tag, (B, S, N) in (("c5_slice", (4, 7, 50)), ("map10_slice", (8, 7, 10))):
+            ex = synth.session_batch(B, S, N, c["qlen"], c["dlen"], c["vocab"], seed=17 + N, full_length=False)
+            ref = oracle(ex)
+            got = model.scores(ex).cpu()
+            lab = ex["document_labels"].reshape(-1, N).numpy().astype(int)
+            a_ref, a_got = (np.argsort(-t.reshape(-1, N).numpy(), 1, kind="stable") for t in (ref, got))
+            ds, dp = float((got - ref).abs().max()), float((torch.softmax(got, -1) - torch.softmax(ref, -1)).abs().max())
+            worst_s, worst_p = max(worst_s, ds), max(worst_p, dp)
+            out[tag] = {"shape": [B, S, N, c["qlen"], c["dlen"]], "max_abs_diff_vs_oracle": ds, "prob_max_abs_diff": dp,
+                        "map_delta_vs_oracle": ltorank.MAP(a_got, lab) - ltorank.MAP(a_ref, lab), "rows_reordered": int((a_ref != a_got).any(1).sum())}
+        out.update({"max_abs_diff_vs_oracle": float("%.3g" % worst_s), "prob_max_abs_diff": float("%.3g" % worst_p),
+                    "map_delta_vs_oracle": out["c5_slice"]["map_delta_vs_oracle"], "map10_equal": out["map10_slice"]["map_delta_vs_oracle"] == 0.0})
+        return out
+    from context_attentive_ir_amd.graph_runner import StreamingSessionPredictor
+    from context_attentive_ir_amd.inputters import SyntheticSessionCorpus
+    B, N = 4, c["cands"]
+    corpus = SyntheticSessionCorpus(n_sessions=24, n_cands=N, qlen=c["qlen"], dlen=c["dlen"], vocab=c["vocab"], seed=9, pool=4, full_length=False, s_max=7)
+    batches = corpus.batches(B, seed=1)
+    sp = StreamingSessionPredictor(model, N, c["qlen"], c["dlen"], B, max_session_len=7, lanes=2, slots=2)
+    got = {}
+    sp.run(corpus, batches, on_result=lambda k, idx, probs: got.__setitem__(k, probs.clone()))
+    worst_p, maps = 0.0, [[], []]
+    for k, idx in enumerate(batches):
+        ex = corpus.batch_tensors(idx)
+        ref = torch.softmax(oracle(ex), -1)
+        worst_p = max(worst_p, float((got[k] - ref).abs().max()))
+        lab = ex["document_labels"].reshape(-1, N).numpy().astype(int)
+        maps[0].append(ltorank.MAP(np.argsort(-got[k].reshape(-1, N).numpy(), 1, kind="stable"), lab))
+        maps[1].append(ltorank.MAP(np.argsort(-ref.reshape(-1, N).numpy(), 1, kind="stable"), lab))
+    del sp
+    return {"stream_slice": "%d sessions in %d batches of %d, %d candidates" % (len(corpus), len(batches), B, N), "prob_max_abs_diff": float("%.3g" % worst_p),
+            "map_delta_vs_oracle": float(np.mean(maps[0]) - np.mean(maps[1]))}
 
 
 def stream_record(args, env, seconds=None, n_sessions=None, mode=None):

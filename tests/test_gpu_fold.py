@@ -1,9 +1,11 @@
 """GPU (-m gpu): folded-embedding BiLSTM (csrc/lstm_fold.hip) and the CARS encoders built on it.
 
 fp32 folded path = the parity path: same 1e-4 bar on scores as everything else (observed ~1e-6).
-bf16 path (BASELINE config 5): bf16 cannot meet 1e-4; the stated bound is |score - oracle| <= BF16_SCORE_TOL on raw
-click scores of O(1) magnitude, |softmax prob diff| <= BF16_PROB_TOL, and identical MAP on candidate sets whose oracle
-scores are separated by more than the bound."""
+bf16 path (BASELINE config 5): bf16 cannot meet 1e-4.  Its ACHIEVED error against the oracle is measured by tools/bf16_error_survey.py over the
+shapes used here (round 5, gpurun_out/bf16_error_survey_r05.json -> profiles/r05_bf16_error_survey.json): max |score - oracle| 5.4e-4, max
+|softmax prob diff| 3.3e-5, MAP delta 0 on every shape (rows reorder only where the oracle's own gap is < 1.3e-4).  The bounds below are
+<= 2x those maxima: |score - oracle| <= BF16_SCORE_TOL on raw click scores, |prob diff| <= BF16_PROB_TOL, identical order wherever the oracle
+separates neighbours by more than twice the bound, and MAP@10 EQUAL to the oracle's on 10-candidate sets."""
 import numpy as np
 import pytest
 import torch
@@ -13,8 +15,9 @@ from oracle import neuroir_cpu as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-BF16_SCORE_TOL = 6e-2
-BF16_PROB_TOL = 2e-2
+BF16_SCORE_TOL = 1.1e-3
+BF16_PROB_TOL = 7e-5
+BF16_MAP_TOL = 5e-3          # candidate sets wider than 10 (near-ties among 50 random-weight scores); 10-candidate sets: equality
 
 
 def _close(a, b, tol):
@@ -152,9 +155,12 @@ def test_cars_bf16_scores_and_map(B, S, N, QL, DL):
     safe = (np.diff(srt, axis=1).min(1) > 2 * BF16_SCORE_TOL)
     if safe.any():
         assert (np.argsort(-r_ref[safe], 1) == np.argsort(-r_got[safe], 1)).all()
-    map_ref = ltorank.MAP(np.argsort(-r_ref, 1), lab)
-    map_got = ltorank.MAP(np.argsort(-r_got, 1), lab)
-    assert abs(map_ref - map_got) <= 0.02, (map_ref, map_got)
+    map_ref = ltorank.MAP(np.argsort(-r_ref, 1, kind="stable"), lab)
+    map_got = ltorank.MAP(np.argsort(-r_got, 1, kind="stable"), lab)
+    if N == 10:
+        assert map_ref == map_got, (map_ref, map_got)              # MAP@10 parity (BASELINE metric): equality
+    else:
+        assert abs(map_ref - map_got) <= BF16_MAP_TOL, (map_ref, map_got)
 
 
 @pytest.mark.parametrize("S,N,QL,DL", [(3, 5, 4, 64), (2, 7, 8, 16), (4, 3, 16, 32), (1, 2, 4, 4)])
@@ -317,7 +323,7 @@ def test_cars_bf16_full_c5_shape_against_fp32_path():
     """BASELINE config 5 at its full per-GPU shape (64 sessions x 7 queries x 50 candidates, q_len 4, doc_len 64): here the document
     encoder takes the paths only large launches select -- persistent bf16-table recurrence with fp16 states streamed from LDS, the
     pipelined attention kernel on fp16 rows.  Checked against the fp32 path of the same model on the same batch (itself pinned to
-    the oracle at smaller sizes): scores within the bf16 bound, softmax within the probability bound, MAP within 0.02, and -- size
+    the oracle at smaller sizes): scores within the bf16 bound, softmax within the probability bound, MAP within BF16_MAP_TOL, and -- size
     independent -- padded candidates / permutation of the candidate axis leave the other scores unchanged."""
     from context_attentive_ir_amd import synth
     from context_attentive_ir_amd.eval import ltorank
@@ -338,7 +344,7 @@ def test_cars_bf16_full_c5_shape_against_fp32_path():
     lab = ex["document_labels"].reshape(-1, N).cpu().numpy()
     map_ref = ltorank.MAP(np.argsort(-ref.reshape(-1, N).numpy(), 1), lab)
     map_got = ltorank.MAP(np.argsort(-got.reshape(-1, N).numpy(), 1), lab)
-    assert abs(map_ref - map_got) <= 0.02, (map_ref, map_got)
+    assert abs(map_ref - map_got) <= BF16_MAP_TOL, (map_ref, map_got)
     # permuting the candidates permutes the scores (the click-pooled session state is order independent up to summation order)
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(DEV)
     pex = dict(ex)
@@ -354,7 +360,7 @@ def test_cars_full_c5_shape_against_the_oracle():
     ~10 s), not against another HIP path: the fp32 path -- the kernels only large launches select: 4.4 rounds of the folded recurrence, the
     attention pipeline on the recurrence's term pairs, B = 64 session steps on the fp16-split kernel -- within 1e-4 on the scores with IDENTICAL
     MAP; the bf16 path within its stated bound, identical ranking on every (session, query) row the oracle separates by more than twice that
-    bound, MAP within 0.02 on the rest."""
+    bound, MAP within BF16_MAP_TOL on the rest."""
     from context_attentive_ir_amd import synth
     from context_attentive_ir_amd.eval import ltorank
     V, B, S, N, QL, DL = 5000, 64, 7, 50, 4, 64
@@ -386,4 +392,4 @@ def test_cars_full_c5_shape_against_the_oracle():
     a16 = np.argsort(-got16.reshape(-1, N).numpy(), 1, kind="stable")
     safe = np.diff(np.sort(r_ref, 1), axis=1).min(1) > 2 * BF16_SCORE_TOL
     assert (a_ref[safe] == a16[safe]).all()
-    assert abs(ltorank.MAP(a_ref, lab) - ltorank.MAP(a16, lab)) <= 0.02
+    assert abs(ltorank.MAP(a_ref, lab) - ltorank.MAP(a16, lab)) <= BF16_MAP_TOL

@@ -162,11 +162,11 @@ def test_cars_unbounded_attention_and_recurrent_weights():
 
 def test_cars_bf16_vs_oracle_batch16_map_on_separated_rows():
     """bf16 folded tables against the ORACLE (not the fp32 HIP path) at B = 16: |score diff| within the bf16 bound, and on every
-    (session, step) row whose oracle scores are separated by more than twice that bound the ranking -- hence AP -- is IDENTICAL; the
-    +-0.02 MAP allowance only covers the remaining (near-tie) rows."""
+    (session, step) row whose oracle scores are separated by more than twice that bound the ranking -- hence AP -- is IDENTICAL; MAP@10 over
+    ALL rows equals the oracle's (round 5: the bound is 2x the measured maximum, tools/bf16_error_survey.py, not the 6e-2 of rounds 2-4)."""
     from context_attentive_ir_amd import synth
     from context_attentive_ir_amd.eval import ltorank
-    TOL = 6e-2
+    TOL = 1.1e-3
     V, B, S, N, QL, DL = 3000, 16, 3, 10, 4, 32
     m = build_model("CARS", vocab=V, device=DEV)
     m.compute_dtype = "bf16"
@@ -183,8 +183,7 @@ def test_cars_bf16_vs_oracle_batch16_map_on_separated_rows():
     assert (a_ref[safe] == a_got[safe]).all()
     if safe.any():
         assert ltorank.MAP(a_ref[safe], lab[safe]) == ltorank.MAP(a_got[safe], lab[safe])
-    if (~safe).any():
-        assert abs(ltorank.MAP(a_ref[~safe], lab[~safe]) - ltorank.MAP(a_got[~safe], lab[~safe])) <= 0.02
+    assert ltorank.MAP(a_ref, lab) == ltorank.MAP(a_got, lab)          # MAP@10 parity on the whole 10-candidate batch
 
 
 def test_drmm_exact_match_policies_on_overlapping_zipf_ids():

@@ -610,7 +610,7 @@ def test_graphed_update_follows_lr_decay_and_hyperparameter_changes():
             before = {k: v.detach().clone() for k, v in w.network.state_dict().items()}
             w.optimizer.param_groups[0]["lr"] = 0.0          # assigned float rate: re-captured as well; rate 0 -> parameters stand still
             step(batches[0]); step(batches[0]); step(batches[0])
-            assert len(step.graphs) == 2
+            assert len(step.graphs) == 1                     # re-captured under the new key; the graph of the stale hyper-parameters was dropped
             assert all(torch.equal(before[k], v) for k, v in w.network.state_dict().items() if v.dtype.is_floating_point)
         else:
             finals.append({k: v.detach().clone() for k, v in w.network.state_dict().items()})
