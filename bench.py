@@ -94,9 +94,14 @@ CONFIGS = {
                               baseline="SURVEY 8(f) rank 3: M_MATCH_TENSOR at the configs[2] shape"),
     "X3_mnsrf": dict(model="mnsrf", batch=16, session=7, cands=10, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32",
                      baseline="SURVEY 8(f) rank 3: MNSRF at the configs[2] shape (256-unit encoders on the four-CU cluster recurrence, csrc/lstm_cluster.hip)"),
+    # the opt-in 2-MFMA precision tier of the fp32-table recurrence as a LABELLED sub-record (never the headline): W_hh as two fp16
+    # terms x h as ONE fp16 term in the recurrent product and the attention GEMM (NIR_DTYPE_F32_SPLIT2), the headline's shape
+    "C3_cars_split2": dict(model="cars", batch=16, session=7, cands=10, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32_split2",
+                           baseline="the configs[2] shape on the opt-in precision tier (fp32 folded tables; fp16x2 W_hh x fp16 h recurrence, fp16 rows into the "
+                                    "attention pipeline): NOT the parity path -- its own error figure rides in the record"),
 }
 HEADLINE = "C3_cars"
-SUB_STEPS = {"C1_esm": 400, "C2_match_tensor": 400, "NS_match_tensor_50": 200, "C4_duet": 24, "C4_drmm": 60, "C4_esm_hbm": 60,
+SUB_STEPS = {"C3_cars_split2": 200, "C1_esm": 400, "C2_match_tensor": 400, "NS_match_tensor_50": 200, "C4_duet": 24, "C4_drmm": 60, "C4_esm_hbm": 60,
              "C5_cars_bf16": 24, "X3_m_match_tensor": 100, "X3_mnsrf": 100}
 
 
@@ -141,7 +146,8 @@ def kernel_work(name, c, pairs_per_launch=None):
         # (bf16 encoders), IN = 1 fp16 rows / 2 the recurrence's term pairs (4 B per element, like fp32 rows)
         one = "<true" in base                           # (the single-role kernel always runs the three-MFMA form)
         in16 = "<true,1>" in base
-        return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=(2.0 if in16 else 4.0) * M * K + 4.0 * N * K, terms=1 if one else 3, pipe=F16)
+        in16 = in16 or "<false,1>" in base                 # fp16 rows with a two-term W0 (the split2 tier): 2 MFMAs per fragment pair
+        return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=(2.0 if in16 else 4.0) * M * K + 4.0 * N * K, terms=1 if one else (2 if "<false,1>" in base else 3), pipe=F16)
     if base.startswith("gemm3_kernel"):
         gathered = "[gather]" in base
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0), terms=6, pipe=F16)
@@ -151,8 +157,9 @@ def kernel_work(name, c, pairs_per_launch=None):
         # fp16 MFMA operands; the states leave as fp16 when they feed the pipelined attention kernel of the same encode call
         out_b = 2.0 if M * N >= 2 * 256 * 64 else 4.0
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * out_b), terms=1, pipe=F16)
-    if base.startswith("lstm16_pt_h2_kernel") or base.startswith("lstm16_pt_h2x2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block
-        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * 4), terms=3, pipe=F16)
+    if base.startswith("lstm16_pt_h2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block (",h1": the one-term-h tier, 2 MFMAs, fp16 rows out)
+        h1 = ",h1>" in base
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * (2 if h1 else 4)), terms=2 if h1 else 3, pipe=F16)
     if base.startswith("lstm_cluster_kernel"):       # csrc/lstm_cluster.hip: M sequences x N steps x 2 directions, K = 256 units, W_hh resident on 4-CU clusters
         # bytes: one 4 KB folded gate row per (token, direction) + the ids (+ the bank, unless the max over time is fused: [maxpool])
         out_b = 0.0 if "[maxpool]" in base else 2 * K * 4.0
@@ -1086,6 +1093,17 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     cpu = None
     if want_cpu and rank == 0 and not env.multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(c, model, batches, lambda: finish(forward(0)), pairs_global, args)
+    tier_err = None
+    if c.get("dtype") == "f32_split2" and rank == 0 and not env.multi and not args.no_cpu_baseline:
+        # the tier's own error figure (checker leg, the oracle as the checker only): click probabilities of two resident batches against the oracle
+        from oracle import neuroir_cpu as O
+        sd_ = {k: v.detach().cpu().float() for k, v in model.network.state_dict().items()}
+        tier_err = 0.0
+        for bi in range(min(2, len(batches))):
+            ex_ = {k: v.cpu() for k, v in batches[bi].items()}
+            ref_ = O.predict_softmax(O.cars_scores(sd_, ex_["source_words"], ex_["source_lens"], ex_["document_words"], ex_["document_lens"], ex_["document_labels"]))
+            got_ = model.predict(batches[bi], suggest=False)["click_scores"].cpu()
+            tier_err = max(tier_err, float((got_ - ref_.view_as(got_)).abs().max()))
     lib.set_batches_in_flight(0, lanes)
     if rank != 0:
         return None
@@ -1130,7 +1148,8 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             "overlapped_vs_serial_max_abs_diff": overlap_diff, "pairs_per_s_with_host_ids_h2d": None if h2d_value is None else round(h2d_value, 1),
             "resident_sustained_pairs_per_s": None if sustained is None else round(sustained, 1),
             "h2d_inclusive_over_resident": None if (h2d_value is None or not sustained) else round(h2d_value / sustained, 4), "h2d_stream": h2d_info,
-            "dtype": c.get("dtype", "f32"), "precompute": pre, "wrapper_predict_eager_one_stream": eager_default, "roofline": roofline, "cpu_baseline": cpu, "power": power}
+            "dtype": c.get("dtype", "f32") if c.get("dtype") != "f32_split2" else "f32 table, fp16x2 W_hh x fp16 h recurrence and attention rows (opt-in tier)",
+            "max_abs_diff_vs_oracle_softmax": tier_err, "precompute": pre, "wrapper_predict_eager_one_stream": eager_default, "roofline": roofline, "cpu_baseline": cpu, "power": power}
 
 
 def cpu_baseline(c, model, batches, gpu_step, pairs, args):
@@ -1269,7 +1288,7 @@ def short_sub(n, r):
         e["emulated_world"] = r.get("emulated_world")
     if r.get("overlapped_vs_serial_max_abs_diff") is not None:       # lanes in flight vs the same graphs alone (a record above OVERLAP_TOL fails)
         e["ovl"] = float("%.2g" % r["overlapped_vs_serial_max_abs_diff"])
-    for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle", "max_abs_diff_vs_oracle", "prob_max_abs_diff", "map10_equal", "kg"):
+    for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle", "max_abs_diff_vs_oracle", "prob_max_abs_diff", "map10_equal", "max_abs_diff_vs_oracle_softmax", "kg"):
         if k in r:
             e[k] = r[k]
     if r.get("power"):

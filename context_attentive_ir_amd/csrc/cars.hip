@@ -224,6 +224,11 @@ extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, i
     NIR_REQUIRE(M >= 0 && T > 0 && V > 0, "cars_encode_folded: bad dims");
     NIR_REQUIRE(w->H >= 8 && w->H <= 128 && (2 * w->H) % 64 == 0, "cars_encode_folded: hidden size %d unsupported", w->H);
     if (M == 0) return 0;
+    // NIR_DTYPE_F32_SPLIT2 (round 5, opt-in precision tier): the fp32 folded table with h as ONE fp16 term in the recurrent product and the
+    // attention GEMM (2 MFMAs per block instead of 3, fp16 rows between the two kernels) -- where both kernels of the large-launch pipeline
+    // apply (H = 128, T in {4..64}, enough tiles); anywhere else the call is the plain fp32-accurate one
+    const bool split2 = dtype == NIR_DTYPE_F32_SPLIT2;
+    if (split2) dtype = NIR_DTYPE_F32;
     const int H = w->H, D = 2 * H, NP = D / 16;
     EncFoldPlan p = enc_fold_plan(workspace, workspace_bytes, M, T, H);
     if (!workspace || p.bytes > workspace_bytes) {
@@ -239,7 +244,7 @@ extern "C" int nir_cars_encode_folded(const int64_t* ids, const int64_t* lens, i
     // pipeline's IO waves then copy 16 bytes per lane into their LDS planes instead of re-splitting fp32 rows (VALU-bound before)
     const bool inside = fused_attn && !encoded && attn_pool_pipe_selected(M, T);
     const int enc16 = !inside ? 0 : (dtype == NIR_DTYPE_BF16 ? (H > 64 ? 1 : 0) :
-                                     (bilstm_folded_split_out_ok(dtype, H, T) && !tun(g_tun.attn_fp32_rows) ? 2 : 0));
+                                     (bilstm_folded_split_out_ok(dtype, H, T) && !tun(g_tun.attn_fp32_rows) ? (split2 ? 3 : 2) : 0));
     NIR_PROPAGATE(launch_bilstm_folded(folded, dtype, ids, lens, w->whh, enc, err_flag, M, V, T, H, 2, st, enc16, dtype == NIR_DTYPE_F32 ? w->whh_frag : nullptr));
     // enc = o * tanh(c) lies in (-1,1); the attention weights are bounded (checked by the host when it packs them)
     if (fused_attn)

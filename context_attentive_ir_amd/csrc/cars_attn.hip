@@ -271,13 +271,15 @@ __device__ long long ap_dbg[16];
 #endif
 constexpr size_t AP2_LDS = (size_t)2 * AP_PLANE_HALVES * 2 + (2 * 4 * 64 + 4 * 64 + 2 * AP_D) * 4;
 
-template <bool ONE>
+// ONE: W0 and the rows enter as single fp16 terms (bf16 encoders).  ROW1 (round 5, the "split2" tier: <false, 1>): the ROWS are single fp16
+// terms (the recurrence's one-term hand-over) but W0 keeps its two terms: two MFMAs per fragment pair (row . w1, row . w2').
+template <bool ONE, bool ROW1>
 __device__ __forceinline__ void ap2_mma_n(int n, f32x4 (&acc)[AP_CT][AP_RT], f32x4 (&acx)[AP_CT][AP_RT], const f16x8 (&af)[AP_RT][2],
                                           const f16x8 (&w)[AP_CT][2]) {
     const int i = n / (3 * AP_CT), ph = (n / AP_CT) % 3, j = n % AP_CT;      // row tile outermost
     if (ph == 2) AP_MMA(acc[j][i], af[i][0], w[j][0]);
     else if (ONE) return;                                                      // leading fp16 term only (bf16 encoders)
-    else if (ph == 0) AP_MMA(acx[j][i], af[i][1], w[j][0]);
+    else if (ph == 0) { if (!ROW1) AP_MMA(acx[j][i], af[i][1], w[j][0]); }
     else AP_MMA(acx[j][i], af[i][0], w[j][1]);
 }
 
@@ -304,6 +306,7 @@ __device__ __forceinline__ void ap_fma_mix(float4& a, const uint2 u, const float
 template <bool ONE, int IN>
 __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, int64_t ntiles) {
     constexpr bool IN16 = IN == 1;
+    constexpr bool ROW1 = ONE || IN16;                // the rows have no residual plane
     extern __shared__ __attribute__((aligned(16))) unsigned short asm2_[];
     constexpr int KG = AP_KG;
     float* rowpart = reinterpret_cast<float*>(asm2_ + 2 * AP_PLANE_HALVES);      // [2 buffers][4 waves][64 rows]
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                     const unsigned short* pc_ = Pp + (S) * 4 * KG + foff;                 \
                     const unsigned short* pn_ = Pp + sn_ * 4 * KG + foff;                 \
                     _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 3 * AP_RT * AP_CT; ++n_) { \
-                        ap2_mma_n<ONE>(n_, acc, acx, af, WC);                             \
+                        ap2_mma_n<ONE, ROW1>(n_, acc, acx, af, WC);                             \
                         if (n_ % 6 == 2 && n_ / 6 < 2 * AP_CT && !(ONE && ((n_ / 6) & 1))) { /* ONE: the residual-term fragments are never read */ \
                             asm volatile("" ::"v"(WN[(n_ / 6) >> 1][(n_ / 6) & 1]));      \
                             WN[(n_ / 6) >> 1][(n_ / 6) & 1] = ldw(sn_ * WSTEP + (n_ / 6) * 512);  \
@@ -505,13 +508,13 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                 // hundred cycles while the MMA waves stream their fragments: 8-10 K cycles for ~300 VALU instructions (tools/attn_micro.py)
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
-                    uint2 u1[8], u2[ONE ? 1 : 8];
+                    uint2 u1[8], u2[ROW1 ? 1 : 8];
                     float prr[8];
 #pragma unroll
                     for (int q8 = 0; q8 < 8; ++q8) {
                         const int row = 4 * (8 * hb + q8) + sub;
                         u1[q8] = *reinterpret_cast<const uint2*>(Pb + row * 8);
-                        if (!ONE) u2[q8] = *reinterpret_cast<const uint2*>(Pb + AP_S * 4 * KG + row * 8);
+                        if (!ROW1) u2[q8] = *reinterpret_cast<const uint2*>(Pb + AP_S * 4 * KG + row * 8);
                         prr[q8] = pw[row];
                     }
 #pragma unroll
@@ -524,9 +527,9 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                         // convert per term plus the FMAs -- the IO wave shares its SIMD's issue slots with an MMA wave
                         (void)a01; (void)a23;
                         ap_fma_mix(a, u1[q8], pr);
-                        if (!ONE) ap_fma_mix(a, u2[q8], pr * (1.0f / 2048.0f));
+                        if (!ROW1) ap_fma_mix(a, u2[q8], pr * (1.0f / 2048.0f));
 #else
-                        if (ONE) {
+                        if (ROW1) {
                             a.x = fmaf(pr, (float)a01[0], a.x);
                             a.y = fmaf(pr, (float)a01[1], a.y);
                             a.z = fmaf(pr, (float)a23[0], a.z);
@@ -621,7 +624,8 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
     const int64_t tiles = (M * T + AP_ROWS - 1) / AP_ROWS;
     // (profile label = the kernel that runs: the role-specialised pipeline by template arguments, else the single-role kernel)
     const bool pipe_sel = attn_pool_pipe_selected(M, T);
-    const char* pname = !pipe_sel ? "attn_pool_fused_kernel" : in_f16 == 1 ? "attn_pool_pipe_kernel<true,1>" : in_f16 == 2 ? "attn_pool_pipe_kernel<false,2>" :
+    const char* pname = !pipe_sel ? "attn_pool_fused_kernel" : in_f16 == 1 ? "attn_pool_pipe_kernel<true,1>" : in_f16 == 3 ? "attn_pool_pipe_kernel<false,1>" :
+                        in_f16 == 2 ? "attn_pool_pipe_kernel<false,2>" :
                         one_term ? "attn_pool_pipe_kernel<true,0>" : "attn_pool_pipe_kernel<false,0>";
     ProfScope ps(prof_shape_name(pname, M * T, AP_D, AP_D), st);
     static std::once_flag once2;
@@ -630,12 +634,14 @@ int launch_attn_pool_fused(const float* h, const void* wfrag, const float* b0, c
         (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
         (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
         (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_pool_pipe_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP2_LDS);
     });
     const int ncu = ap_cu_count();
     if (pipe_sel) {                                                        // several tiles per CU: the role-specialised pipeline
         const dim3 grid((unsigned)std::min<int64_t>(tiles, ncu));
         NIR_REQUIRE(in_f16 != 2 || !one_term, "attn_pool_fused: term-pair rows come from the fp32-accurate encoder (two terms)");
         if (in_f16 == 1) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, 1>), grid, dim3(512), AP2_LDS, st, a, tiles);
+        else if (in_f16 == 3) hipLaunchKernelGGL((attn_pool_pipe_kernel<false, 1>), grid, dim3(512), AP2_LDS, st, a, tiles);   // fp16 rows, two-term W0
         else if (in_f16 == 2) hipLaunchKernelGGL((attn_pool_pipe_kernel<false, 2>), grid, dim3(512), AP2_LDS, st, a, tiles);
         else if (one_term) hipLaunchKernelGGL((attn_pool_pipe_kernel<true, 0>), grid, dim3(512), AP2_LDS, st, a, tiles);
         else hipLaunchKernelGGL((attn_pool_pipe_kernel<false, 0>), grid, dim3(512), AP2_LDS, st, a, tiles);

@@ -250,16 +250,15 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
 
     // A PHASE = one step of one group; the groups take turns, every group runs all `tmax` steps of the cluster (a group that is finished -- or
     // empty -- keeps computing on rows nobody stores: the phase sequence and its vector-memory queue are then STATIC).  Everything a phase needs
-    // from memory -- the partners' pieces of h(step) and the group's gate rows of that step -- is requested during the phase BEFORE it
-    // (another group's step; the pieces were published a whole round of phases ago), in ONE burst.  The stores of a phase (its piece, its
-    // output pair) are DEFERRED into the next phase's burst, in front of the requests: the queue of a phase is [stores of the previous phase |
-    // 5 requests for the next one], so the wait at a phase start -- which the compiler can only express as vmcnt(0) once loads and stores
-    // are both in flight -- never covers a store younger than the requests it is for (vector memory retires in order; a device-scope store's
-    // acknowledgement takes longer than a phase).  The two waves of a SIMD take the halves of a phase in opposite order: rank 0 runs its
-    // MFMAs first and the burst afterwards, rank 1 the burst first -- the burst of one is issued under the MFMAs of the other instead of all
-    // eight waves queueing for the vector-memory port right behind the barrier.
+    // from memory is requested ahead: the partners' pieces of h(step) one phase before (another group's step; they were published a whole
+    // round of phases earlier), the group's gate rows two phases before (static register slots: the loop is unrolled over two rounds).
+    // Stores and loads in flight together make the compiler's wait model give up (it treats them as retiring out of order and emits
+    // s_waitcnt vmcnt(0) for every load result, which would also cover requests issued for LATER phases; the hardware retires vector memory
+    // in order).  So the one store of a phase -- its piece -- goes through inline asm, unseen by that model: the waits the compiler derives
+    // for the requests are then exact counts, and the store is older or younger than what they name, never in between.  (MODE 0's output
+    // pair stays a builtin store, deferred into the next phase in front of the requests: that mode keeps the conservative waits.)
     u32x4 pv[3];                                         // the next phase's foreign pieces
-    u32x4 gprev = (u32x4){0u, 0u, 0u, 0u};               // the previous phase's own piece (first phase: an empty piece onto an empty slot)
+    u32x4 gprev = (u32x4){0u, 0u, 0u, 0u};               // this phase's own piece
     uint32_t gsoff = xsoff(0, 0);
     u32x2 oprev = (u32x2){0u, 0u};                       // MODE 0: the previous phase's output pair and its offset (OOB = dropped)
     uint32_t ooff = OOB;
@@ -355,6 +354,14 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
             }
 #endif
             CL_T(0)
+            auto burst = [&]() {                         // round trips under MFMAs and gate math: pieces one phase ahead, gate rows two
+                request_pieces(ph_g(g, 1), ph_s(g, step, 1));
+                load_g(ids_s[(ph_g(g, 2) * SEQ + sq) * TP + ph_s(g, step, 2)], gnr[pp]);
+            };
+            // NG >= 3: the next phase's pieces were published during the PREVIOUS phase (their group's step ended two phases ago) -- asked for
+            // right here, in front of the barrier: a whole phase of lead, and the request queue drains while the waves meet.  NG == 2: they are
+            // being published in THIS phase (behind its barrier): asked for after it, the two waves of a SIMD in opposite halves of the phase.
+            if (NG >= 3) burst();
             if (timed_out) abort_s[0] = 1;
             lds_barrier();
             CL_T(1)
@@ -362,17 +369,8 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
                 if (tid == 0 && p.err) atomicOr(p.err, 4);
                 return;
             }
-            // every wave publishes the previous phase's piece right behind the barrier (the partners ask for it one phase from now); the requests
-            // for the next phase are staggered by rank
-#ifndef NIR_CL_NOX
-            if (NG > 1) publish();
-#endif
             if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b64(oprev, out_rsrc(g > 0 ? g - 1 : NG - 1), ooff, 0, 0);
-            auto burst = [&]() {                         // round trips under MFMAs and gate math: pieces one phase ahead, gate rows two
-                request_pieces(ph_g(g, 1), ph_s(g, step, 1));
-                load_g(ids_s[(ph_g(g, 2) * SEQ + sq) * TP + ph_s(g, step, 2)], gnr[pp]);
-            };
-            if (rank != 0) burst();
+            if (NG < 3 && rank != 0) burst();
             CL_T(2)
             const _Float16* zr = zc + sq * ZLD + 8 * kq;
 #pragma unroll
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
             for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]), "+v"(acx[t]));
 #endif
             CL_T(3)
-            if (rank == 0) burst();
+            if (NG < 3 && rank == 0) burst();
             CL_T(5)
             float hn[NT];
 #pragma unroll
@@ -419,8 +417,7 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
                 gprev = (u32x4){lo0, (uint32_t)(step + 1), lo1, (uint32_t)(step + 1)};
                 gsoff = xsoff(g, nxt);
 #ifndef NIR_CL_NOX
-                // one group per cluster: the partners wait for exactly this piece at their next phase start -- published at once
-                if (NG == 1) publish();
+                publish();                               // at once: the partners ask for it one phase (NG == 1: a few hundred cycles) from now
 #endif
             }
             const bool live = step < mylen[g];

@@ -524,7 +524,10 @@ __device__ unsigned long long* g_pt_trace_dev;
 // NW waves per workgroup, NT gate tiles per wave (NW * NT * 4 >= H units).  16 waves x 2 tiles is the latency form (H = 128); for
 // H <= 80 four waves x 5 tiles leave room for three workgroups per CU, which fill each other's per-step bubbles when several
 // batches are in flight.
-template <int KB, int NT, int NW>
+// H1 (round 5, the opt-in "split2" precision tier, <4,4,8,true> only): h enters the recurrent product as ONE fp16 term -- w.h = w1.h1 + 2^-11 w2'.h1:
+// two MFMAs per k-block instead of three, one LDS h plane instead of two -- and leaves as fp16 rows [M,T,ND*H] (out_f16 == 3) for
+// attn_pool_pipe_kernel<false,1>.  Measured error and where it holds: DESIGN.md section 10; never selected by default.
+template <int KB, int NT, int NW, bool H1 = false>
 __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(LstmPtArgs p) {   // (second argument: waves per SIMD)
     constexpr int NTH = 64 * NW;
     constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // fp16 elements per h row
@@ -676,8 +679,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         creg[t] = 0.f;
     }
     if (wbad && p.err) atomicOr(p.err, 2);
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0,
-                                                                             (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = H1 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<_Float16*>(p.out) + m0 * T * OW, 0,
+                                                                                  (int)((uint32_t)nvalid * T * OW * 2u), 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0, (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
     // per-unit base of the lane's 16-byte gate groups inside a folded row (units past H re-read the last real one: never used);
     // row = base + id * GW floats
     const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;
@@ -708,6 +712,10 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 #ifdef NIR_X_NOSTORE
         return;
 #endif
+        if (H1) {                                             // four fp16 values = 8 bytes at half the fp32 offset
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){hprev[0], hprev[1 % NT]}, out_rs, poff == OOB ? OOB : poff >> 1, 0, 0);
+            return;
+        }
         if (NT == 4) {
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){hprev[0], hprev[1 % NT], hprev[2 % NT], hprev[3 % NT]}, out_rs, full ? poff : OOB, 0, 0);
         } else if (NT == 2) {
@@ -812,11 +820,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
             // tile k -- an MFMA occupies the matrix pipe for 16 cycles and the issue port for 4 -- so only the last tile's gate math of
             // the lower-priority wave is exposed.  All KB h fragments are read once (half the LDS traffic of the 16-wave form: every
             // wave reads the whole B operand, 128 KB per step and CU there, a third of the step at 128 B/clk).
-            f16x8 hh1[KB], hh2[KB];
+            f16x8 hh1[KB], hh2[H1 ? 1 : KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 hh1[kb] = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
-                hh2[kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
+                if (!H1) hh2[H1 ? 0 : kb] = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
             }
 #ifdef NIR_PT_TRACE
             { unsigned long long tn; PT_T(tn); tr_l += tn - tr_t0; }
@@ -826,7 +834,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh1[kb], acc[t], 0, 0, 0);
-                    acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh2[kb], acx[t], 0, 0, 0);
+                    if (!H1) acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[t][kb], hh2[H1 ? 0 : kb], acx[t], 0, 0, 0);
                     acx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[t][kb], hh1[kb], acx[t], 0, 0, 0);
                 }
                 if (t == 0) {
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 #endif
                     gates(t - 1);
 #pragma unroll
-                    for (int q = 0; q < 3 * KB; ++q) {       // one MFMA, then three of the previous tile's VALU instructions, ...
+                    for (int q = 0; q < (H1 ? 2 : 3) * KB; ++q) {       // one MFMA, then three of the previous tile's VALU instructions, ...
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                     }
@@ -862,7 +870,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
             if (NT == 4) {
                 const f16x4 av = (f16x4){a[0], a[1 % NT], a[2 % NT], a[3 % NT]}, rv = (f16x4){r[0], r[1 % NT], r[2 % NT], r[3 % NT]};
                 *reinterpret_cast<f16x4*>(zn + sq * ZLD + u0) = av;
-                *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = rv;
+                if (!H1) *reinterpret_cast<f16x4*>(zn + SEQ * ZLD + sq * ZLD + u0) = rv;
+                if (H1) {                                     // the leading terms ARE the output: fp16 rows
+                    const u32x2 au = __builtin_bit_cast(u32x2, av);
+                    hprev[0] = au[0]; hprev[1 % NT] = au[1];
+                } else
                 if (split) {                                  // the same two vectors ARE the output (wave-uniform)
                     const u32x2 au = __builtin_bit_cast(u32x2, av), ru = __builtin_bit_cast(u32x2, rv);
                     hprev[0] = au[0]; hprev[1 % NT] = au[1]; hprev[2 % NT] = ru[0]; hprev[3 % NT] = ru[1];
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
                     zn[SEQ * ZLD + sq * ZLD + u0 + t] = (_Float16)((hn[t] - (float)a) * SC);
                 }
         }
-        if (!split) {
+        if (!split && !H1) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) hprev[t] = __float_as_uint(hn[t]);
         }
@@ -902,21 +914,27 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 #endif
     // zero the padded steps of this direction's half: one wave per (sequence, step) row, coalesced (ragged batches are the normal case)
     for (int s_ = 0; s_ < nvalid; ++s_) {
+        if (H1) {
+            _Float16* orow = reinterpret_cast<_Float16*>(p.out) + (m0 + s_) * T * OW + (int64_t)dir * H;
+            for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
+                for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = (_Float16)0.f;
+            continue;
+        }
         float* orow = p.out + (m0 + s_) * T * OW + (int64_t)dir * H;
         for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NW)
             for (int col = lane; col < H; col += 64) orow[(int64_t)t2 * OW + col] = 0.f;
     }
 }
 
-template <int KB, int NT, int NW = 16>
+template <int KB, int NT, int NW = 16, bool H1 = false>
 static int launch_pt_h2(const LstmPtArgs& p, hipStream_t st) {
-    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + ">";
+    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + (H1 ? ",h1" : "") + ">";
     const size_t lds = (size_t)(4 * 16 * (32 * KB + 8)) * 2 + 2 * 16 * 4 + (size_t)16 * (p.T + 3) * 4;
     ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
 #ifdef NIR_PT_TRACE
     { unsigned long long* d = g_debug_buf; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pt_trace_dev), &d, sizeof(d), 0, hipMemcpyHostToDevice, st); }
 #endif
-    hipLaunchKernelGGL((lstm16_pt_h2_kernel<KB, NT, NW>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((lstm16_pt_h2_kernel<KB, NT, NW, H1>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(64 * NW), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2]");
     return 0;
 }
@@ -1213,7 +1231,7 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     NIR_REQUIRE(pt_dtype == NIR_DTYPE_F32 || pt_dtype == NIR_DTYPE_BF16, "bilstm_folded: unknown table dtype %d", pt_dtype);
     if (M == 0) return 0;
     NIR_REQUIRE(out_f16 != 1 || (pt_dtype == NIR_DTYPE_BF16 && H > 64 && H % 2 == 0), "bilstm_folded: fp16 output needs the bf16 table and an even H > 64");
-    NIR_REQUIRE(out_f16 != 2 || bilstm_folded_split_out_ok(pt_dtype, H, T), "bilstm_folded: split-term output is produced by lstm16_pt_h2_kernel<4,4,8> only (f32 table, H = 128)");
+    NIR_REQUIRE((out_f16 != 2 && out_f16 != 3) || bilstm_folded_split_out_ok(pt_dtype, H, T), "bilstm_folded: split-term / one-term output is produced by lstm16_pt_h2_kernel<4,4,8> only (f32 table, H = 128)");
     LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND, out_f16, whh_frag};
     if (pt_dtype == NIR_DTYPE_BF16) {
         const int KB = (H + 31) / 32;
@@ -1239,6 +1257,7 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
         if (tun(g_tun.lstm_w16) == 1) return launch_pt_h2<4, 2>(p, st);
         // (two sequence groups per workgroup sharing the W registers, skewed wave roles, output stores on one early wave: measured in rounds 3-4,
         // all tied or lost -- DESIGN.md section 10; sources archived under tools/variants/, not built)
+        if (p.out_f16 == 3) return launch_pt_h2<4, 4, 8, true>(p, st);      // the opt-in one-term-h tier (H = 128, checked by the caller)
         return launch_pt_h2<4, 4, 8>(p, st);
     }
     const int G = (H + 15) / 16;

@@ -170,8 +170,8 @@ SIGNATURES = {
     "nir_lstm_step_pack_whh_frag": (_i, [c_fp, _i, C.c_void_p, C.c_void_p, c_st]),
 }
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
-DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "bf16": DTYPE_BF16}
+DTYPE_F32, DTYPE_BF16, DTYPE_F32_SPLIT2 = 0, 1, 2
+DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "bf16": DTYPE_BF16, "f32_split2": DTYPE_F32_SPLIT2}
 
 _lib = None
 

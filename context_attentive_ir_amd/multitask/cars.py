@@ -127,7 +127,8 @@ class CARS(nn.Module, lib.IdCheck):
                           rank_on=int(not self.no_ranker))
         self._pq, self._pd, self._ps, self._pdec = lib.PackCache(), lib.PackCache(), lib.PackCache(), lib.PackCache()
         # Inference-time folding of the embedding table into the LSTM input projection (csrc/lstm_fold.hip): on in eval
-        # mode while the two folded tables (V x 8H each) stay under `fold_budget_bytes`; `compute_dtype` "bf16" selects the
+        # mode while the two folded tables (V x 8H each) stay under `fold_budget_bytes`; `compute_dtype` "f32_split2" = the opt-in precision tier
+        # of round 5 (fp32 tables, h as ONE fp16 term in the recurrent product and the attention GEMM: NIR_DTYPE_F32_SPLIT2); "bf16" selects the
         # bf16 folded table + bf16 MFMA recurrence (BASELINE config 5), "f32" is the parity path.
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
         self.fuse_attention_pooling = True   # attention MLP + masked softmax + weighted sum as one kernel (csrc/cars_attn.hip)
@@ -289,7 +290,7 @@ class CARS(nn.Module, lib.IdCheck):
         table = self.embedder.word_embeddings.table
         enc = (self.query_encoder if which == "q" else self.document_encoder).encoder
         cache = self._fq if which == "q" else self._fd
-        dt = self.compute_dtype
+        dt = "bf16" if self.compute_dtype == "bf16" else "f32"          # ("f32_split2" reads the fp32 table)
         return cache.get([table] + list(enc.parameters()) + [dt],
                          lambda: lib.fold_lstm_table(table, w.keep["wih"], w.keep["bih"], w.keep["bhh"], w.struct.H, 2, dt))
 

@@ -35,6 +35,11 @@ typedef void* nir_stream_t; /* hipStream_t */
 /* element types of buffers whose precision is a caller choice (folded tables) */
 #define NIR_DTYPE_F32 0
 #define NIR_DTYPE_BF16 1
+#define NIR_DTYPE_F32_SPLIT2 2 /* nir_cars_encode_folded only (opt-in precision tier, never a default): the fp32 folded table, but h enters the
+                                  recurrent product and the attention GEMM as ONE fp16 term (w two terms x h one term: 2 MFMAs per block
+                                  instead of 3; fp16 rows between the two kernels).  |h - fp32 h| <= 2^-12 per step instead of 2^-23:
+                                  measured score error in DESIGN.md section 10; applies where the large-launch kernels do (H = 128,
+                                  T in {4,8,16,32,64}, >= 2 tiles per CU), otherwise the call equals NIR_DTYPE_F32 */
 
 int nir_version(void);
 const char* nir_last_error_string(void);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for every bench.py configuration (run on the GPU box through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash tools/capture_profiles.sh r04 [config ...]'
+#   gpurun --timeout 2400 -- 'bash tools/capture_profiles.sh r05 [config ...]'
 # First the default `python bench.py` (its compact line + bench_detail.json are kept beside the captures); then per config:
 # (1) --kernel-trace --stats of the serial eager run -- one lane, nothing co-running, every launch attributed -- with the library's batches-in-flight
 #     hint set to the TIMED run's lane count (--in-flight-hint 4), so that the capture launches the same kernel instantiations the timed run does
@@ -8,14 +8,14 @@
 # (2) FETCH_SIZE pass; (3) WRITE_SIZE pass; (4) SQ/MFMA pass.  Counter passes use --kernel-trace only (never combined with sys/hip/hsa trace domains).
 # tools/derive_profiles.py condenses the traces and FAILS when a record's dominant kernel is missing from its capture.
 set -u
-PREFIX=${1:-r04}; shift || true
+PREFIX=${1:-r05}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/${PREFIX}prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH_DETAIL=$OUT/bench_detail.json python $REPO/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 export BENCH_NO_H2D=1
-CFGS=${@:-C3_cars C1_esm C2_match_tensor NS_match_tensor_50 C4_duet C4_drmm C4_esm_hbm C5_cars_bf16}
+CFGS=${@:-C3_cars C1_esm C2_match_tensor NS_match_tensor_50 C4_duet C4_drmm C4_esm_hbm C5_cars_bf16 X3_mnsrf}
 for c in $CFGS; do
   steps=20; case $c in C4_duet|C5_cars_bf16) steps=6;; esac
   RUN="python $REPO/bench.py --config $c --sub none --streams 1 --in-flight-hint 4 --no-graph --steps $steps --warmup 3 --no-cpu-baseline"
