@@ -393,3 +393,41 @@ def test_cars_full_c5_shape_against_the_oracle():
     safe = np.diff(np.sort(r_ref, 1), axis=1).min(1) > 2 * BF16_SCORE_TOL
     assert (a_ref[safe] == a16[safe]).all()
     assert abs(ltorank.MAP(a_ref, lab) - ltorank.MAP(a16, lab)) <= BF16_MAP_TOL
+
+
+def test_cars_split2_precision_tier_vs_oracle():
+    """The opt-in 2-MFMA tier (compute_dtype "f32_split2" = NIR_DTYPE_F32_SPLIT2: W_hh two fp16 terms x h ONE fp16 term in the recurrent product,
+    fp16 rows into attn_pool_pipe_kernel<false,1>) at a shape where its kernels run (560 documents of 64 tokens): the tier's kernels really ran,
+    scores within 1e-4 of the ORACLE at default-scale weights (measured 1.6e-5 against 5.7e-7 of the default path: tools/split2_error_survey.py),
+    MAP@10 equal; the default path of the same model is untouched by the switch."""
+    import ctypes as C
+    from context_attentive_ir_amd import lib, synth
+    from context_attentive_ir_amd.eval import ltorank
+    V, B, S, N, QL, DL = 20000, 8, 7, 10, 4, 64
+    m = build_model("CARS", vocab=V, device=DEV)
+    ex = synth.session_batch(B, S, N, QL, DL, V, seed=3, full_length=True)
+    ref = O.cars_scores(cpu_state_dict(m), ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])
+    dex = {k: v.to(DEV) for k, v in ex.items()}
+
+    def run():
+        pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
+        return m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"], want_states=False)[0]
+    base = run().cpu()
+    m.compute_dtype = "f32_split2"
+    L = lib.load()
+    L.nir_profile_enable(1)
+    got = run().cpu()
+    torch.cuda.synchronize()
+    L.nir_profile_enable(0)
+    buf = C.create_string_buffer(1 << 16)
+    L.nir_profile_report(buf, len(buf))
+    names = {ln.rsplit(",", 2)[0].split("[")[0] for ln in buf.value.decode().strip().splitlines()}
+    assert "lstm16_pt_h2_kernel<4,4,8,h1>" in names and "attn_pool_pipe_kernel<false,1>" in names, names
+    err = float((got - ref).abs().max())
+    assert 1e-6 < err <= 1e-4, err                                   # (not the parity path: its error is visible, and inside the bar)
+    assert float((base - ref).abs().max()) <= 2e-6
+    lab = ex["document_labels"].reshape(-1, N).numpy().astype(int)
+    a_ref, a_got = (np.argsort(-t.reshape(-1, N).numpy(), 1, kind="stable") for t in (ref, got))
+    assert ltorank.MAP(a_ref, lab) == ltorank.MAP(a_got, lab)
+    m.compute_dtype = "f32"
+    assert torch.equal(run().cpu(), base)

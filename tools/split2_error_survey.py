@@ -29,7 +29,7 @@ def kernels_of(fn):
 
 def main():
     out = []
-    for factor in (1.0, 8.0, 1.0 / 64):
+    for factor in (1.0, 2.0, 4.0, 1.0 / 64):
         for (B, S, N, QL, DL, V, seed) in [(8, 7, 10, 4, 64, 20000, 3), (2, 6, 50, 4, 64, 100000, 5)]:
             m = build_model("CARS", vocab=V, device="cuda")
             with torch.no_grad():
@@ -40,10 +40,8 @@ def main():
             sd = cpu_state_dict(m)
             args = (ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"], ex["document_labels"])
             ref = O.cars_scores(sd, *args)
-            ref64 = O.cars_scores({k: (v.double() if torch.is_tensor(v) else v) for k, v in sd.items()}, *args[:4], args[4].double())
             dex = {k: v.cuda() for k, v in ex.items()}
-            rec = {"shape": [B, S, N, QL, DL], "vocab": V, "weight_factor": factor, "score_scale": float(ref.abs().max()),
-                   "oracle_f32_vs_f64": float((ref.double() - ref64).abs().max())}
+            rec = {"shape": [B, S, N, QL, DL], "vocab": V, "weight_factor": factor, "score_scale": float(ref.abs().max())}
             for dt in ("f32", "f32_split2"):
                 m.compute_dtype = dt
 
@@ -51,8 +49,7 @@ def main():
                     pooled, _, _ = m.encode(dex["source_words"], dex["source_lens"])
                     return m.rank_document(pooled, dex["document_words"], dex["document_lens"], dex["document_labels"], want_states=False)[0]
                 s = run().cpu()
-                rec[dt] = {"score_max_abs_diff_vs_oracle": float((s - ref).abs().max()), "vs_f64_oracle": float((s.double() - ref64).abs().max()),
-                           "prob_max_abs_diff": float((torch.softmax(s, -1) - torch.softmax(ref, -1)).abs().max()),
+                rec[dt] = {"score_max_abs_diff_vs_oracle": float((s - ref).abs().max()), "prob_max_abs_diff": float((torch.softmax(s, -1) - torch.softmax(ref, -1)).abs().max()),
                            "kernels": [k for k in kernels_of(run) if k.startswith("lstm16") or k.startswith("attn_pool")]}
             out.append(rec)
             print(json.dumps(rec), flush=True)
