@@ -17,16 +17,20 @@ V = 100000
 mt = Multitask(default_args("CARS", src_vocab_size=V))
 fill_module_(mt.network, 1013)
 mt.cuda()
-ex = {k: v.cuda() for k, v in synth.session_batch(16, 7, 10, 4, 64, V, seed=1).items()}
+MACRO = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # python tools/decode_profile.py 8: the bench's macro-batch of 8 (predict_many)
+exs = [{k: v.cuda() for k, v in synth.session_batch(16, 7, 10, 4, 64, V, seed=1 + i).items()} for i in range(MACRO)]
+ex = exs[0]
+mt.id_check_interval = 0
+run = (lambda: mt.predict(ex)) if MACRO == 1 else (lambda: mt.predict_many(exs, suggest=True))
 L = lib.load()
 for _ in range(3):
-    mt.predict(ex)
+    run()
 torch.cuda.synchronize()
 L.nir_debug_set_tunable(b"no_fork", 1)
 L.nir_profile_enable(1)
 N = 5
 for _ in range(N):
-    mt.predict(ex)
+    run()
 torch.cuda.synchronize()
 L.nir_profile_enable(0)
 buf = ctypes.create_string_buffer(1 << 17)
