@@ -17,7 +17,7 @@ def _reference_bank(lstm, x, lens):
     return out
 
 
-def _run(lstm, table, ids, lens, mode, use_ids=True):
+def _run(lstm, table, ids, lens, mode, use_ids=True, hint=0):
     from context_attentive_ir_amd import lib
     from context_attentive_ir_amd.encoders.rnn_encoder import lstm_cat_weights
     L = lib.load()
@@ -37,8 +37,14 @@ def _run(lstm, table, ids, lens, mode, use_ids=True):
     ws = torch.empty(L.nir_lstm256_workspace_bytes(M, nd), dtype=torch.uint8, device=DEV)
     out = torch.full((M, T, nd * 256) if mode == 0 else (M, nd * 256), 7.0, device=DEV)
     lens_d = lens.to(DEV)
-    lib.check(L.nir_lstm256_rows_fwd(lib.ptr(rows), idp, lib.ptr(lens_d), lib.ptr(frag), lib.ptr(out), mode, lib.ptr(err), M, R, T, nd,
-                                     lib.ptr(ws), ws.numel(), lib.stream()), "nir_lstm256_rows_fwd")
+    if hint:
+        lib.set_batches_in_flight(hint)              # the per-stream scheduling hint must not change the numbers
+    try:
+        lib.check(L.nir_lstm256_rows_fwd(lib.ptr(rows), idp, lib.ptr(lens_d), lib.ptr(frag), lib.ptr(out), mode, lib.ptr(err), M, R, T, nd,
+                                         lib.ptr(ws), ws.numel(), lib.stream()), "nir_lstm256_rows_fwd")
+    finally:
+        if hint:
+            lib.set_batches_in_flight(0)
     torch.cuda.synchronize()
     assert int(err.item()) == 0, int(err.item())
     del ids_d
@@ -46,7 +52,8 @@ def _run(lstm, table, ids, lens, mode, use_ids=True):
 
 
 @pytest.mark.parametrize("M,T,bi,full", [(37, 7, True, False), (16, 4, True, True), (5, 3, False, False), (112, 4, True, False),
-                                         (1120, 64, True, False), (1120, 64, True, True), (49, 33, True, False), (130, 12, False, False)])
+                                         (1120, 64, True, False), (1120, 64, True, True), (49, 33, True, False), (130, 12, False, False),
+                                         (300, 20, True, False), (257, 9, False, False)])
 def test_lstm256_cluster_matches_packed_lstm(M, T, bi, full):
     g = torch.Generator().manual_seed(M * 100 + T)
     V, E = 500, 300
@@ -67,6 +74,11 @@ def test_lstm256_cluster_matches_packed_lstm(M, T, bi, full):
     assert float(bank[1, int(lens[1]):].abs().max() if int(lens[1]) < T else 0.0) == 0.0       # exact zeros beyond the length
     pooled = _run(lstm, table, ids, lens, 1)
     np.testing.assert_allclose(pooled.numpy(), ref.max(1)[0].numpy(), rtol=0, atol=3e-5)
+    if M >= 256:                                       # with the several-batches-in-flight hint set: the same numbers
+        bank32 = _run(lstm, table, ids, lens, 0, hint=4)
+        np.testing.assert_allclose(bank32.numpy(), ref.numpy(), rtol=0, atol=3e-5)
+        pooled32 = _run(lstm, table, ids, lens, 1, hint=4)
+        np.testing.assert_allclose(pooled32.numpy(), ref.max(1)[0].numpy(), rtol=0, atol=3e-5)
     if M <= 112:                                                                                  # per-batch gate rows (ids == NULL)
         bank2 = _run(lstm, table, ids, lens, 0, use_ids=False)
         np.testing.assert_allclose(bank2.numpy(), bank.numpy(), rtol=0, atol=1e-5)      # (the two gate GEMMs differ in shape -> kernel -> rounding)

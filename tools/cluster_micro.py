@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--mode", type=int, default=1)
+    ap.add_argument("--hint", type=int, default=0, help="batches-in-flight hint on every stream (> 1: the 32-sequence-group kernel)")
     ap.add_argument("--lib", default="", help="variant library suffix (NIR_VARIANT build)")
     ap.add_argument("--trace", action="store_true", help="with a -DNIR_CL_TRACE variant: phase-segment clocks of wave 0 of workgroup 0")
     a = ap.parse_args()
@@ -41,6 +42,8 @@ def main():
     wss = [torch.empty(L.nir_lstm256_workspace_bytes(M, 2), dtype=torch.uint8, device="cuda") for _ in range(ns)]
     outs = [torch.empty((M, 512) if a.mode else (M, T, 512), device="cuda") for _ in range(ns)]
     streams = [torch.cuda.Stream() for _ in range(ns)]
+    if a.hint:
+        lib.set_batches_in_flight(a.hint, streams + [torch.cuda.current_stream()])
 
     def launch(k):
         lib.check(L.nir_lstm256_rows_fwd(lib.ptr(rows), lib.ptr(ids[k]), lib.ptr(lens[k]), lib.ptr(frag), lib.ptr(outs[k]), a.mode, lib.ptr(err),
