@@ -4,7 +4,7 @@ Mirror of neuroir.modules.embeddings.Embeddings (/root/reference/neuroir/modules
 word-only case the hot path uses: one nn.Embedding(padding_idx=PAD) stored under
 `make_embedding.emb_luts.0.weight` so reference checkpoints load unchanged.
 On the HIP path the table is never "looked up" into a [.., L, E] tensor: kernels take `table` and gather
-rows inside their operand loads (train mode: autograd.embed).  `forward` raises: there is no stock-torch lookup.
+rows inside their operand loads (train mode: autograd.embed).  `forward` is the same HIP gather for modules outside the hot path.
 """
 import torch
 import torch.nn as nn
@@ -49,7 +49,12 @@ class Embeddings(nn.Module):
                 self.word_lut.weight.requires_grad = False
 
     def forward(self, source):
-        """The reference materialises [B, L, E] here (embeddings.py:243-252).  On the HIP path nothing of that shape
-        exists: every consumer gathers the rows inside its own operand loads (nir_linear_f32 with ids, nir_esm_score,
-        ...), reading `self.table`.  There is deliberately no stock-torch lookup to fall back on."""
-        raise NotImplementedError("Embeddings.forward is fused into the consuming HIP kernels (pass ids + .table to the C-ABI)")
+        """embeddings.py:243-252: source `[.., .., 1]` (one word feature per position; the reference documents `[len x batch x nfeat]`, its
+        callers pass `[batch x len x 1]`) -> `[.., .., embedding_size]`.  The hot-path networks never call this -- their kernels gather rows
+        of `self.table` inside their operand loads -- but any other module that shares the embedder gets the lookup here, on the HIP gather
+        operator (nir_embed_f32; differentiable: autograd.embed; an id outside the table raises the device flag lib.IdCheck polls)."""
+        from .. import autograd as A
+        if source.dim() < 1 or (source.dim() >= 3 and source.shape[-1] != 1):
+            raise NotImplementedError("Embeddings.forward: only the word feature is implemented (nfeat = 1; the reference's char / feature merges are out of scope)")
+        ids = source[..., 0] if source.dim() >= 3 else source
+        return A.embed(ids, self.table, self.word_padding_idx)

@@ -16,8 +16,10 @@ class Embedder(nn.Module):
         self.dropout = nn.Dropout(dropout_emb)
 
     def forward(self, sequence):
-        """Fused into the consuming kernels like Embeddings.forward (layers.py:23-27 of the reference)."""
-        raise NotImplementedError("Embedder.forward is fused into the consuming HIP kernels (pass ids + word_embeddings.table)")
+        """layers.py:23-27: [B, P] ids -> dropout(word embeddings) [B, P, d].  Not on the hot path (its kernels gather from
+        word_embeddings.table themselves); HIP gather + HIP dropout operators."""
+        from .. import autograd as A
+        return A.dropout(self.word_embeddings(sequence.unsqueeze(2)), self.dropout.p, self.training)
 
 
 class Encoder(nn.Module):

@@ -984,3 +984,32 @@ def test_duet_fused_other_widths(E, NF, DL, pool, planes):
     with lib.tunable("duet_unfused", 1, 0):
         dist0 = m(q, ql, d, dl, return_parts=True)[2]
     _close(dist, dist0, 5e-6)
+
+
+def test_embeddings_and_embedder_forward_match_nn_embedding():
+    """modules.Embeddings.forward / multitask.layers.Embedder.forward (reference embeddings.py:243-252, layers.py:23-27): not on the hot path, but
+    callable -- the HIP gather operator against torch's nn.Embedding, forward and the table gradient (PAD row excluded)."""
+    from context_attentive_ir_amd.modules import Embeddings
+    from context_attentive_ir_amd.multitask.layers import Embedder
+    g = torch.Generator().manual_seed(2)
+    V, E = 50, 12
+    emb = Embeddings(E, V, 0).to(DEV)
+    ref = torch.nn.Embedding(V, E, padding_idx=0)
+    with torch.no_grad():
+        w = torch.randn(V, E, generator=g); w[0] = 0
+        emb.word_lut.weight.copy_(w.to(DEV)); ref.weight.copy_(w)
+    ids = torch.randint(0, V, (3, 7), generator=g)
+    out = emb(ids.unsqueeze(2).to(DEV))
+    assert tuple(out.shape) == (3, 7, E) and torch.equal(out.cpu(), ref(ids))
+    dout = torch.randn(3, 7, E, generator=g)
+    out.backward(dout.to(DEV)); ref(ids).backward(dout)
+    _close(emb.word_lut.weight.grad, ref.weight.grad, 1e-6)
+    e2 = Embedder(E, V, 0.5).to(DEV).eval()
+    with torch.no_grad():
+        e2.word_embeddings.word_lut.weight.copy_(w.to(DEV))
+    assert torch.equal(e2(ids.to(DEV)).cpu(), ref(ids).detach())          # eval: dropout off
+    e2.train()
+    y = e2(ids.to(DEV)).detach().cpu()
+    kept = y != 0
+    _close(y[kept], (ref(ids).detach() * 2.0)[kept], 1e-6)                # train: kept entries scaled by 1 / (1 - p)
+    assert 0.2 < float(kept.float().mean()) < 0.8
