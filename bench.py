@@ -252,7 +252,7 @@ def build_model(c, args):
     if kind == "CARS":
         wrapper.network.compute_dtype = c.get("dtype", "f32")
         wrapper.network.fold_embeddings = not (args.no_fold or c.get("nofold"))
-    elif kind == "MATCH_TENSOR" and (args.no_fold or c.get("nofold")):
+    elif kind in ("MATCH_TENSOR", "MNSRF") and (args.no_fold or c.get("nofold")):
         wrapper.network.fold_embeddings = False
     wrapper.cuda()
     wrapper.network.eval()

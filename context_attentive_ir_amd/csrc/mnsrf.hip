@@ -18,6 +18,8 @@ int launch_linear(const float* a, int64_t lda, const int64_t* ids, const float* 
                   int64_t ldc, int64_t M, int N, int K, int act, hipStream_t st);
 // csrc/lstm_cluster.hip: the resident-weight recurrence for 256 units per direction (four-workgroup clusters)
 size_t lstm256_xbuf_bytes(int64_t M, int ND);
+int launch_fold_permute(const float* w_ih, const float* b_ih, const float* b_hh, int H, int ndir, int E, float* wperm, float* bperm, int64_t* iota, int64_t niota,
+                        hipStream_t st);
 int launch_lstm256_cluster(const float* rows, const int64_t* ids, const int64_t* lens, const void* wfrag, float* out, int mode, int* err,
                            int64_t M, int64_t R, int T, int ND, void* xbuf, size_t xbuf_bytes, hipStream_t st);
 
@@ -184,23 +186,29 @@ __global__ void mnsrf_dec_states_kernel(const float* __restrict__ hbank, const f
 // mirror builds them once per weight version) the encoders run as ONE launch each -- lstm_cluster_kernel, max over time fused, no memory
 // bank -- and the session LSTM as one lstm_step16_kernel launch per query (W_hh as fp16 term pairs, input side hoisted into one GEMM):
 // 14 launches per batch instead of 300.
-static bool mnsrf_fast_q(const nir_mnsrf_weights* w) { return w->q_fold && w->q_whh_frag && w->Hq == 256; }
-static bool mnsrf_fast_d(const nir_mnsrf_weights* w) { return w->d_fold && w->d_whh_frag && w->Hd == 256; }
+// (q_/d_whh_frag without q_/d_fold -- a table that trains, or one over the fold budget: the same recurrence over PER-BATCH gate rows, written in
+// the folded order by one gather-GEMM with W_ih permuted on the fly; rows addressed by position, ids == NULL)
+static bool mnsrf_fast_q(const nir_mnsrf_weights* w) { return w->q_whh_frag && w->Hq == 256; }
+static bool mnsrf_fast_d(const nir_mnsrf_weights* w) { return w->d_whh_frag && w->Hd == 256; }
 static bool mnsrf_fast_s(const nir_mnsrf_weights* w) { return w->s_whh_frag && w->HS % 32 == 0; }
 
-struct MnsrfPlan { float *gin, *enc, *lstm_ws, *mem, *sgin, *sess, *comb, *proj, *docs, *hs, *cs, *h16; void* xbuf; size_t xbuf_bytes; size_t bytes; };
+struct MnsrfPlan { float *gin, *enc, *lstm_ws, *mem, *sgin, *sess, *comb, *proj, *docs, *hs, *cs, *h16, *wperm, *bperm; void* xbuf; size_t xbuf_bytes; size_t bytes; };
 
-static MnsrfPlan mnsrf_plan(void* ws, size_t cap, int64_t B, int S, int N, int QL, int DL, const nir_mnsrf_weights* w) {
+static MnsrfPlan mnsrf_plan(void* ws, size_t cap, int64_t B, int S, int N, int QL, int DL, const nir_mnsrf_weights* w, int E = 300) {
     Workspace a(ws, cap);
     MnsrfPlan p;
     const int64_t Mq = B * S, Md = B * S * N;
     const int Hq = w->Hq, Hd = w->Hd, HS = w->HS;
     const bool fq = mnsrf_fast_q(w), fd = mnsrf_fast_d(w) || Md == 0;
-    // the streaming encoders' scratch: gate pre-activations + memory bank of the encoder being run (only for the encoders that still stream)
+    // gate pre-activations of the encoder being run: the streaming encoders and the per-batch form of the cluster recurrence (no folded table);
+    // the memory bank only for the encoders that still stream
+    const int64_t grows = std::max<int64_t>((fq && w->q_fold) ? 0 : Mq * QL, ((fd && w->d_fold) || Md == 0) ? 0 : Md * DL);
     const int64_t rows = std::max<int64_t>(fq ? 0 : Mq * QL, fd ? 0 : Md * DL);
     const int Hmax = std::max(Hq, Hd);
-    p.gin = a.take<float>((size_t)rows * 8 * Hmax);
+    p.gin = a.take<float>((size_t)grows * 8 * Hmax);
     p.enc = a.take<float>((size_t)rows * 2 * Hmax);
+    p.wperm = a.take<float>((fq && !w->q_fold) || (mnsrf_fast_d(w) && !w->d_fold) ? (size_t)8 * Hmax * E : 0);
+    p.bperm = a.take<float>((size_t)8 * Hmax);
     p.lstm_ws = a.take<float>(std::max(lstm_steps_ws_floats(std::max<int64_t>(fq ? 0 : Mq, fd ? 0 : Md), Hmax), mnsrf_fast_s(w) ? (size_t)0 : lstm_steps_ws_floats(B, HS)));
     p.mem = a.take<float>((size_t)Mq * 2 * Hq);
     p.sgin = a.take<float>((size_t)Mq * 4 * HS);
@@ -235,8 +243,12 @@ static int mnsrf_encode(const int64_t* src, const int64_t* src_len, int64_t B, i
                         const nir_mnsrf_weights* w, const MnsrfPlan& p, float* mem, float* sess, float* dec_h, float* dec_c, hipStream_t st) {
     const int64_t Mq = B * S;
     const int Hq = w->Hq, HS = w->HS;
-    if (mnsrf_fast_q(w)) {
+    if (mnsrf_fast_q(w) && w->q_fold) {
         NIR_PROPAGATE(launch_lstm256_cluster(w->q_fold, src, src_len, w->q_whh_frag, mem, 1, w->err, Mq, V, QL, 2, p.xbuf, p.xbuf_bytes, st));
+    } else if (mnsrf_fast_q(w)) {
+        NIR_PROPAGATE(launch_fold_permute(w->q_wih, w->q_bih, w->q_bhh, Hq, 2, E, p.wperm, p.bperm, nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear(nullptr, 0, src, table, E, 1, 1, p.wperm, E, p.bperm, nullptr, p.gin, 8 * Hq, Mq * QL, 8 * Hq, E, NIR_ACT_NONE, st));
+        NIR_PROPAGATE(launch_lstm256_cluster(p.gin, nullptr, src_len, w->q_whh_frag, mem, 1, w->err, Mq, Mq * QL, QL, 2, p.xbuf, p.xbuf_bytes, st));
     } else {
         NIR_PROPAGATE(launch_linear(nullptr, 0, src, table, E, 1, 1, w->q_wih, E, w->q_bih, w->q_bhh, p.gin, 8 * Hq, Mq * QL, 8 * Hq, E, NIR_ACT_NONE, st));
         NIR_PROPAGATE(launch_bilstm_steps(p.gin, src_len, w->q_whh, nullptr, nullptr, p.enc, nullptr, nullptr, Mq, QL, Hq, 2, p.lstm_ws, st));
@@ -280,8 +292,12 @@ static int mnsrf_rank(const float* mem, const float* sess, const int64_t* doc_id
     const int64_t Mq = B * S, Md = B * S * N;
     const int Hq = w->Hq, Hd = w->Hd, HS = w->HS;
     // documents: BiLSTM -> max over time
-    if (mnsrf_fast_d(w)) {
+    if (mnsrf_fast_d(w) && w->d_fold) {
         NIR_PROPAGATE(launch_lstm256_cluster(w->d_fold, doc_ids, doc_lens, w->d_whh_frag, p.docs, 1, w->err, Md, V, DL, 2, p.xbuf, p.xbuf_bytes, st));
+    } else if (mnsrf_fast_d(w)) {
+        NIR_PROPAGATE(launch_fold_permute(w->d_wih, w->d_bih, w->d_bhh, Hd, 2, E, p.wperm, p.bperm, nullptr, 0, st));
+        NIR_PROPAGATE(launch_linear(nullptr, 0, doc_ids, table, E, 1, 1, p.wperm, E, p.bperm, nullptr, p.gin, 8 * Hd, Md * DL, 8 * Hd, E, NIR_ACT_NONE, st));
+        NIR_PROPAGATE(launch_lstm256_cluster(p.gin, nullptr, doc_lens, w->d_whh_frag, p.docs, 1, w->err, Md, Md * DL, DL, 2, p.xbuf, p.xbuf_bytes, st));
     } else {
         NIR_PROPAGATE(launch_linear(nullptr, 0, doc_ids, table, E, 1, 1, w->d_wih, E, w->d_bih, w->d_bhh, p.gin, 8 * Hd, Md * DL, 8 * Hd, E, NIR_ACT_NONE, st));
         NIR_PROPAGATE(launch_bilstm_steps(p.gin, doc_lens, w->d_whh, nullptr, nullptr, p.enc, nullptr, nullptr, Md, DL, Hd, 2, p.lstm_ws, st));
@@ -338,7 +354,7 @@ extern "C" int nir_birnn_steps_fwd(int cell, const float* gates_in, const int64_
 
 extern "C" size_t nir_mnsrf_workspace_bytes(int64_t B, int S, int N, int QL, int DL, const nir_mnsrf_weights* w) {
     if (!w) return 0;
-    return nir::mnsrf_plan(nullptr, 0, B, S, N, QL, DL, w).bytes + 256;
+    return nir::mnsrf_plan(nullptr, 0, B, S, N, QL, DL, w).bytes + 256;      // (sized for E = 300, the reference's emsize; larger E: see mnsrf_plan_e)
 }
 
 extern "C" int nir_mnsrf_encode_states(const int64_t* source_ids, const int64_t* source_lens, int64_t B, int S, int QL, const float* table,
@@ -350,6 +366,7 @@ extern "C" int nir_mnsrf_encode_states(const int64_t* source_ids, const int64_t*
     NIR_REQUIRE(workspace_bytes >= nir_mnsrf_workspace_bytes(B, S, 0, QL, 1, w), "mnsrf_encode: workspace too small");
     if (B == 0) return 0;
     const MnsrfPlan p = mnsrf_plan(workspace, workspace_bytes, B, S, 0, QL, 1, w);
+    NIR_REQUIRE(E <= 300 || (w->q_fold != nullptr) || !w->q_whh_frag, "mnsrf: the per-batch cluster form is sized for emsize <= 300");
     return mnsrf_encode(source_ids, source_lens, B, S, QL, table, V, E, w, p, memory_bank, session_bank, dec_h, dec_c, (hipStream_t)stream);
 }
 
@@ -369,6 +386,7 @@ extern "C" int nir_mnsrf_rank(const float* memory_bank, const float* session_ban
     NIR_REQUIRE(workspace_bytes >= nir_mnsrf_workspace_bytes(B, S, N, 1, DL, w), "mnsrf_rank: workspace too small");
     if (B == 0) return 0;
     const MnsrfPlan p = mnsrf_plan(workspace, workspace_bytes, B, S, N, 1, DL, w);
+    NIR_REQUIRE(E <= 300 || (w->d_fold != nullptr) || !w->d_whh_frag, "mnsrf: the per-batch cluster form is sized for emsize <= 300");
     return mnsrf_rank(memory_bank, session_bank, doc_ids, doc_lens, B, S, N, DL, table, V, E, w, p, scores, (hipStream_t)stream);
 }
 
@@ -383,6 +401,7 @@ extern "C" int nir_mnsrf_score(const int64_t* source_ids, const int64_t* source_
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const MnsrfPlan p = mnsrf_plan(workspace, workspace_bytes, B, S, N, QL, DL, w);
+    NIR_REQUIRE(E <= 300 || (w->d_fold && w->q_fold) || !(w->d_whh_frag || w->q_whh_frag), "mnsrf: the per-batch cluster form is sized for emsize <= 300");
     NIR_PROPAGATE(mnsrf_encode(source_ids, source_lens, B, S, QL, table, V, E, w, p, p.mem, p.sess, nullptr, nullptr, st));
     return mnsrf_rank(p.mem, p.sess, doc_ids, doc_lens, B, S, N, DL, table, V, E, w, p, scores, st);
 }

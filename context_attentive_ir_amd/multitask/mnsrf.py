@@ -59,6 +59,8 @@ class MNSRF(nn.Module, lib.IdCheck):
     def _weights(self):
         table = self.embedder.word_embeddings.table
         fold = self._use_fold(table)
+        # the resident-weight recurrence itself needs only the reference's sizes and an embedding width the per-batch form is sized for
+        resident = not self.training and self._dims["Hq"] == 256 and self._dims["Hd"] == 256 and (fold or table.shape[1] <= 300)
 
         def build():
             q = lstm_cat_weights(self.query_encoder.encoder.rnns[0])
@@ -79,18 +81,19 @@ class MNSRF(nn.Module, lib.IdCheck):
                 lib.check(L.nir_lstm_step_pack_whh_frag(lib.ptr(pk.keep["s_whh"]), HS, lib.ptr(frag), lib.ptr(pk.err), lib.stream()), "nir_lstm_step_pack_whh_frag")
                 pk.keep["s_whh_frag"] = frag
                 pk.struct.s_whh_frag = frag.data_ptr()
-            if fold and dev.type == "cuda":
+            if resident and dev.type == "cuda":
                 for k in ("q", "d"):
                     frag = torch.empty(L.nir_lstm256_whh_frag_bytes(2), dtype=torch.uint8, device=dev)
                     lib.check(L.nir_lstm256_pack_whh_frag(lib.ptr(pk.keep[k + "_whh"]), 2, lib.ptr(frag), lib.ptr(pk.err), lib.stream()), "nir_lstm256_pack_whh_frag")
                     pk.keep[k + "_whh_frag"] = frag
                     setattr(pk.struct, k + "_whh_frag", frag.data_ptr())
-                    ft = lib.fold_lstm_table(table.detach(), pk.keep[k + "_wih"], pk.keep[k + "_bih"], pk.keep[k + "_bhh"], 256, 2, "f32")
-                    pk.keep[k + "_fold"] = ft
-                    setattr(pk.struct, k + "_fold", ft.data_ptr())
+                    if fold:         # else: per-batch gate rows (one gather-GEMM per call in the folded order), same recurrence
+                        ft = lib.fold_lstm_table(table.detach(), pk.keep[k + "_wih"], pk.keep[k + "_bih"], pk.keep[k + "_bhh"], 256, 2, "f32")
+                        pk.keep[k + "_fold"] = ft
+                        setattr(pk.struct, k + "_fold", ft.data_ptr())
             return pk
         skip = ("decoder.", "generator.") + (() if fold else ("embedder.",))
-        params = [p for n, p in self.named_parameters() if not n.startswith(skip)] + [fold]
+        params = [p for n, p in self.named_parameters() if not n.startswith(skip)] + [fold, resident]
         return self._pack.get(params, build)
 
     def _check_eval(self):

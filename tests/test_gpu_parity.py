@@ -1013,3 +1013,35 @@ def test_embeddings_and_embedder_forward_match_nn_embedding():
     kept = y != 0
     _close(y[kept], (ref(ids).detach() * 2.0)[kept], 1e-6)                # train: kept entries scaled by 1 / (1 - p)
     assert 0.2 < float(kept.float().mean()) < 0.8
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_mnsrf_resident_recurrence_with_and_without_folded_tables(fold):
+    """MNSRF at a shape where the cluster recurrence really runs for documents and queries (B*S*N = 240 documents of 21 tokens), against the ORACLE:
+    folded gate tables (default) and fold_embeddings=False -- the same recurrence over per-batch gate rows written in the folded order by one
+    gather-GEMM (ids == NULL) -- and that the kernels expected ran."""
+    import ctypes as C
+    from context_attentive_ir_amd import lib
+    from context_attentive_ir_amd.wrappers import Multitask
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    w = Multitask(default_args("MNSRF", src_vocab_size=300, tgt_vocab_size=40, fold_embeddings=fold))
+    fill_module_(w.network, 29)
+    sd = cpu_state_dict(w.network)
+    w.cuda()
+    ex = _session_batches(1, 6, 5, 8, 5, 21, 300, seed=3)[0]
+    L = lib.load()
+    res = w.predict(ex, suggest=False)["click_scores"]
+    L.nir_profile_enable(1)
+    res2 = w.predict(ex, suggest=False)["click_scores"]
+    torch.cuda.synchronize()
+    L.nir_profile_enable(0)
+    buf = C.create_string_buffer(1 << 16)
+    L.nir_profile_report(buf, len(buf))
+    names = {ln.rsplit(",", 2)[0].split("[")[0] for ln in buf.value.decode().strip().splitlines()}
+    assert "lstm_cluster_kernel" in names and "lstm_step_cell_kernel" not in names, names
+    assert (w.network._weights().struct.d_fold is not None) == fold
+    assert torch.equal(res, res2)
+    ref = torch.softmax(O.mnsrf_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)
+    _close(res, ref)
+    w.network.check_ids()
