@@ -157,8 +157,8 @@ def kernel_work(name, c, pairs_per_launch=None):
         # fp16 MFMA operands; the states leave as fp16 when they feed the pipelined attention kernel of the same encode call
         out_b = 2.0 if M * N >= 2 * 256 * 64 else 4.0
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 2 + 2 * K * out_b), terms=1, pipe=F16)
-    if base.startswith("lstm16_pt_h2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block (",h1": the one-term-h tier, 2 MFMAs, fp16 rows out)
-        h1 = ",h1>" in base
+    if base.startswith("lstm16_pt_h2_kernel"):        # fp32-accurate two-term fp16 split: 3 fp16 MFMAs per k-block (",true" = H1: the one-term-h tier, 2 MFMAs, fp16 rows out)
+        h1 = ",true>" in base
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * (8.0 + 2 * 4 * K * 4 + 2 * K * (2 if h1 else 4)), terms=2 if h1 else 3, pipe=F16)
     if base.startswith("lstm_cluster_kernel"):       # csrc/lstm_cluster.hip: M sequences x N steps x 2 directions, K = 256 units, W_hh resident on 4-CU clusters
         # bytes: one 4 KB folded gate row per (token, direction) + the ids (+ the bank, unless the max over time is fused: [maxpool])
@@ -1289,7 +1289,7 @@ def short_sub(n, r):
     if r.get("overlapped_vs_serial_max_abs_diff") is not None:       # lanes in flight vs the same graphs alone (a record above OVERLAP_TOL fails)
         e["ovl"] = float("%.2g" % r["overlapped_vs_serial_max_abs_diff"])
     for k in ("hist_rows_differ", "pairs_differ", "map_delta_vs_oracle", "max_abs_diff_vs_oracle", "prob_max_abs_diff", "map10_equal", "max_abs_diff_vs_oracle_softmax", "kg"):
-        if k in r:
+        if k in r and r[k] is not None:
             e[k] = r[k]
     if r.get("power"):
         e["w"] = r["power"].get("package_w")

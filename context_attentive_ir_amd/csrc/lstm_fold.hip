@@ -928,7 +928,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 
 template <int KB, int NT, int NW = 16, bool H1 = false>
 static int launch_pt_h2(const LstmPtArgs& p, hipStream_t st) {
-    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + (H1 ? ",h1" : "") + ">";
+    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + (H1 ? ",true" : "") + ">";
     const size_t lds = (size_t)(4 * 16 * (32 * KB + 8)) * 2 + 2 * 16 * 4 + (size_t)16 * (p.T + 3) * 4;
     ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
 #ifdef NIR_PT_TRACE

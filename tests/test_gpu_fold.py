@@ -422,7 +422,7 @@ def test_cars_split2_precision_tier_vs_oracle():
     buf = C.create_string_buffer(1 << 16)
     L.nir_profile_report(buf, len(buf))
     names = {ln.rsplit(",", 2)[0].split("[")[0] for ln in buf.value.decode().strip().splitlines()}
-    assert "lstm16_pt_h2_kernel<4,4,8,h1>" in names and "attn_pool_pipe_kernel<false,1>" in names, names
+    assert "lstm16_pt_h2_kernel<4,4,8,true>" in names and "attn_pool_pipe_kernel<false,1>" in names, names
     err = float((got - ref).abs().max())
     assert 1e-6 < err <= 1e-4, err                                   # (not the parity path: its error is visible, and inside the bar)
     assert float((base - ref).abs().max()) <= 2e-6

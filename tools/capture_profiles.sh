@@ -15,7 +15,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH_DETAIL=$OUT/bench_detail.json python $REPO/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 export BENCH_NO_H2D=1
-CFGS=${@:-C3_cars C1_esm C2_match_tensor NS_match_tensor_50 C4_duet C4_drmm C4_esm_hbm C5_cars_bf16 X3_mnsrf}
+CFGS=${@:-C3_cars C1_esm C2_match_tensor NS_match_tensor_50 C4_duet C4_drmm C4_esm_hbm C5_cars_bf16 X3_mnsrf C3_cars_split2}
 for c in $CFGS; do
   steps=20; case $c in C4_duet|C5_cars_bf16) steps=6;; esac
   RUN="python $REPO/bench.py --config $c --sub none --streams 1 --in-flight-hint 4 --no-graph --steps $steps --warmup 3 --no-cpu-baseline"
