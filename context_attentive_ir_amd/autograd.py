@@ -54,9 +54,10 @@ class StepScope(object):
         self.pend_w = {}          # id(weight) -> (param, [(dY [M,N], X [M,K]), ..]) of this step
         self.pend_b = {}          # id(bias)   -> (param, [dY, ..])
         self.wt = {}              # (data_ptr, version, shape) -> (source tensor, transposed weight), this step
+        self.pair_b = {}          # id(weight) -> bias parameter parked with the same dY tensors
 
     def begin(self):
-        self.active, self.pend_w, self.pend_b, self.wt = True, {}, {}, {}
+        self.active, self.pend_w, self.pend_b, self.wt, self.pair_b = True, {}, {}, {}, {}
         # a caller that cleared gradients IN PLACE (zero_grad(set_to_none=False)) left last step's buffer installed as p.grad: autograd would
         # accumulate into it and end() would overwrite / double it -- the buffer is this scope's, so it is detached from the parameter here
         for p, buf in self.bufs.values():
@@ -64,7 +65,7 @@ class StepScope(object):
                 p.grad = None
 
     def abort(self):
-        self.active, self.pend_w, self.pend_b, self.wt = False, {}, {}, {}
+        self.active, self.pend_w, self.pend_b, self.wt, self.pair_b = False, {}, {}, {}, {}
 
     def grad_buffer(self, p):
         ent = self.bufs.get(id(p))
@@ -73,8 +74,10 @@ class StepScope(object):
             self.bufs[id(p)] = ent
         return ent[1]
 
-    def park_w(self, p, d, x2):
+    def park_w(self, p, d, x2, bias=None):
         self.pend_w.setdefault(id(p), (p, []))[1].append((d, x2))
+        if bias is not None:
+            self.pair_b[id(p)] = bias        # the bias that shares this weight's dY: its column sum rides in the weight-gradient launch
 
     def park_b(self, p, d):
         self.pend_b.setdefault(id(p), (p, []))[1].append(d)
@@ -83,7 +86,7 @@ class StepScope(object):
         """one weight-gradient launch / one column sum per parameter, then p.grad = buffer (plus whatever autograd itself accumulated for the
         parameter elsewhere, e.g. a norm regulariser)"""
         L = lib.load()
-        done = []
+        done, fused_b = [], set()
         for p, pairs in self.pend_w.values():
             pairs = [(d, x) for d, x in pairs if d.shape[0]]
             buf = self.grad_buffer(p)
@@ -93,10 +96,22 @@ class StepScope(object):
             else:
                 d = pairs[0][0] if len(pairs) == 1 else torch.cat([a for a, _ in pairs], 0)
                 x = pairs[0][1] if len(pairs) == 1 else torch.cat([b for _, b in pairs], 0)
-                lib.check(L.nir_linear_wgrad_set_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, d.shape[0], N, K, lib.stream()),
-                          "nir_linear_wgrad_set_f32")
+                # the bias of the same nn.Linear, parked with exactly these dY tensors: its column sum comes out of the same launch
+                bp = self.pair_b.get(id(p))
+                bent = self.pend_b.get(id(bp)) if bp is not None else None
+                if bent is not None and len(bent[1]) == len(self.pend_w[id(p)][1]) and all(a is b_[0] for a, b_ in zip(bent[1], self.pend_w[id(p)][1])):
+                    bbuf = self.grad_buffer(bp)
+                    lib.check(L.nir_linear_wgrad_bias_set_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, lib.ptr(bbuf), d.shape[0], N, K,
+                                                              lib.stream()), "nir_linear_wgrad_bias_set_f32")
+                    done.append((bp, bbuf))
+                    fused_b.add(id(bp))
+                else:
+                    lib.check(L.nir_linear_wgrad_set_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, d.shape[0], N, K, lib.stream()),
+                              "nir_linear_wgrad_set_f32")
             done.append((p, buf))
         for p, ds in self.pend_b.values():
+            if id(p) in fused_b:
+                continue
             ds = [d for d in ds if d.shape[0]]
             buf = self.grad_buffer(p)
             N = p.shape[0]
@@ -143,6 +158,16 @@ def _wgrad(dy2, lddy, x2, ldx, M, N, K):
     return dw
 
 
+def _wgrad_bias(dy2, lddy, x2, ldx, M, N, K):
+    """(dW, db) of one nn.Linear from ONE pass over dY (nir_linear_wgrad_bias_set_f32)."""
+    L = lib.load()
+    dw = torch.empty(N, K, device=x2.device, dtype=torch.float32)
+    db = torch.empty(N, device=x2.device, dtype=torch.float32)
+    lib.check(L.nir_linear_wgrad_bias_set_f32(lib.ptr(dy2) if M else lib.ptr(dw), lddy, lib.ptr(x2) if M else lib.ptr(dw), ldx, None, None, 0, lib.ptr(dw), K,
+                                              lib.ptr(db), M, N, K, lib.stream()), "nir_linear_wgrad_bias_set_f32")
+    return dw, db
+
+
 def _colsum(dy2, ld, M, N):
     L = lib.load()
     out = torch.empty(N, device=dy2.device, dtype=torch.float32)
@@ -179,12 +204,17 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _linear_raw(d, _transpose(w), None, 0).view(ctx.shp)
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if ctx.wp is not None and STEP.active:
-                STEP.park_w(ctx.wp, d, x2)                         # (no tensor returned: formed with the parameter's other uses when the step scope closes)
+                # (no tensor returned: formed with the parameter's other uses when the step scope closes)
+                STEP.park_w(ctx.wp, d, x2, bias=ctx.bp if want_b else None)
+            elif want_b and not (ctx.bp is not None and STEP.active):
+                dw, db = _wgrad_bias(d, N, x2, K, M, N, K)
+                want_b = False
             else:
                 dw = _wgrad(d, N, x2, K, M, N, K)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if want_b:
             if ctx.bp is not None and STEP.active:
                 STEP.park_b(ctx.bp, d)
             else:
@@ -393,8 +423,7 @@ class _BiLSTM(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _linear_raw(dg2, _transpose(wih), None, 0).view(M, T, I)
-        dwih = _wgrad(dg2, G, x2, I, M * T, G, I)
-        db = _colsum(dg2, G, M * T, G)
+        dwih, db = _wgrad_bias(dg2, G, x2, I, M * T, G, I)
         grads = []
         for dd in range(nd):
             # h of the PREVIOUS recurrence step: forward direction t-1 (h0 at t = 0), reverse direction t+1 (out is zero at

@@ -32,6 +32,7 @@ struct WgradArgs {
     int64_t M; int N, K;
     int64_t mslice;
     int store;                                         // 1: one slice covers M -- every element is written once, plain stores (dw needs no zero fill)
+    float* db;                                         // optional: bias gradient db[n] = sum_m dy[m,n] -- the waves of k-tile 0 hold dy's column values anyway (round 5)
 };
 
 // NB x KB register blocking: a wave owns a (32 NB) x (32 KB) tile of dW -- NB + KB operand values per lane and m for NB KB MFMAs (the 1 x 1
@@ -61,6 +62,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
         for (int j = 0; j < KB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool do_db = p.db != nullptr && k0 == 0;      // wave-uniform
+    float bs[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bs[i] = 0.f;
     for (int64_t m = ms; m < me; m += 16) {
         float a[NB][8], b[KB][8];
 #pragma unroll
@@ -81,6 +86,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = 0; j < KB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
+        if (do_db) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bs[i] += ((a[i][0] + a[i][1]) + (a[i][2] + a[i][3])) + ((a[i][4] + a[i][5]) + (a[i][6] + a[i][7]));
+        }
+    }
+    if (do_db) {                                        // lanes l and l + 32 hold the even / odd rows of column n
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float t = bs[i] + __shfl_xor(bs[i], 32);
+            if (half == 0 && nv[i]) {
+                if (p.store) p.db[n[i]] = t;
+                else atomicAdd(p.db + n[i], t);
+            }
+        }
     }
     // C/D layout: col = lane & 31 (k), row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) (n)
 #pragma unroll
@@ -804,11 +823,12 @@ extern "C" int nir_lstm_cell_bwd(const float* dh, const float* dc, const float* 
 }
 
 static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E, float* dw,
-                      int64_t lddw, int64_t M, int N, int K, bool set, hipStream_t st) {
+                      int64_t lddw, int64_t M, int N, int K, bool set, hipStream_t st, float* db = nullptr) {
     using namespace nir;
     NIR_REQUIRE(dy && dw && (ids ? (table != nullptr && E >= K) : (x != nullptr)), "linear_wgrad: null pointer");
     NIR_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_wgrad: bad dims");
     if (M == 0) {
+        if (set && db) NIR_PROPAGATE((int)hipMemsetAsync(db, 0, (size_t)N * 4, st));
         if (set) return (int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st);
         return 0;
     }
@@ -821,7 +841,8 @@ static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx
     slices = (M + mslice - 1) / mslice;
     const int store = set && slices == 1;
     if (set && !store) NIR_PROPAGATE((int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st));
-    WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store};
+    if (set && !store && db) NIR_PROPAGATE((int)hipMemsetAsync(db, 0, (size_t)N * 4, st));
+    WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store, db};
     ProfScope ps(prof_shape_name("wgrad_kernel", M, N, K), st);
     if (big) hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<1, 1>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
@@ -835,6 +856,12 @@ extern "C" int nir_linear_wgrad_f32(const float* dy, int64_t lddy, const float* 
 extern "C" int nir_linear_wgrad_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
                                         float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream) {
     return wgrad_impl(dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, true, (hipStream_t)stream);
+}
+
+extern "C" int nir_linear_wgrad_bias_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                                             float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream) {
+    NIR_REQUIRE(db != nullptr, "linear_wgrad_bias: null bias gradient");
+    return wgrad_impl(dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, true, (hipStream_t)stream, db);
 }
 
 static int colsum_impl(const float* x, int64_t ld, int64_t M, int N, float* out, bool set, hipStream_t st) {

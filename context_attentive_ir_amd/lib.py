@@ -138,6 +138,7 @@ SIGNATURES = {
     "nir_linear_wgrad_f32": (_i, [c_fp, _l, c_fp, _l, c_ip, c_fp, _i, c_fp, _l, _l, _i, _i, c_st]),
     "nir_colsum_f32": (_i, [c_fp, _l, _l, _i, c_fp, c_st]),
     "nir_linear_wgrad_set_f32": (_i, [c_fp, _l, c_fp, _l, c_ip, c_fp, _i, c_fp, _l, _l, _i, _i, c_st]),
+    "nir_linear_wgrad_bias_set_f32": (_i, [c_fp, _l, c_fp, _l, c_ip, c_fp, _i, c_fp, _l, c_fp, _l, _i, _i, c_st]),
     "nir_colsum_set_f32": (_i, [c_fp, _l, _l, _i, c_fp, c_st]),
     "nir_transpose_f32": (_i, [c_fp, _i, _i, c_fp, c_st]),
     "nir_lstm_train_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),

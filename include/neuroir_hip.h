@@ -552,6 +552,10 @@ int nir_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir
  * front of the atomics) -- an autograd backward allocates its gradient buffers with torch.empty. */
 int nir_linear_wgrad_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
                              float* dw, int64_t lddw, int64_t M, int N, int K, nir_stream_t stream);
+/* The same with the bias gradient db[n] = sum_m dY[m,n] from the same pass over dY (the waves of k-tile 0 hold dY's column values anyway):
+ * replaces nir_linear_wgrad_set_f32 + nir_colsum_set_f32 of one nn.Linear (models/ranker.py:216 loss.backward()). */
+int nir_linear_wgrad_bias_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                                  float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream);
 int nir_colsum_set_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream);
 /* out [C,R] = in [R,C]^T  (data gradient: dX = dY W is nir_linear_f32(dY, W^T)) */
 int nir_transpose_f32(const float* in, int R, int C, float* out, nir_stream_t stream);
