@@ -130,6 +130,7 @@ class StepScope(object):
 
 
 STEP = StepScope()
+PACKED_WGRAD = False       # _BiLSTM.backward: reduce the weight gradients over a list of the valid (t < length) positions only
 
 
 def _is_param(t):
@@ -423,6 +424,36 @@ class _BiLSTM(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _linear_raw(dg2, _transpose(wih), None, 0).view(M, T, I)
+        if not ctx.has_init:
+            # dW_hh straight from the saved states: h of the PREVIOUS recurrence step is the row before (forward direction) / after (reverse
+            # direction; `out` is zero at t >= length = the reverse direction's zero initial state) the gate row, and the first step of a
+            # sequence has none (period T, skip 0 / T-1) -- no shifted [M,T,H] copy of the states per direction.  PACKED_WGRAD: all three
+            # reductions over a device-built list of the valid positions only (pays for batches of short sequences, costs ~18 % on full ones)
+            dev = d.device
+            rows = cnt = [None, None]
+            if PACKED_WGRAD and ctx.has_lens and M * T < 2 ** 31:
+                offs = torch.empty(2, M + 1, device=dev, dtype=torch.int32)
+                rows = torch.empty(2, M * T, device=dev, dtype=torch.int32)
+                lib.check(L.nir_seq_rows(lib.ptr(lens64), M, T, 0, lib.ptr(offs[0]), lib.ptr(rows[0]), lib.stream()), "nir_seq_rows")
+                cnt = [offs[0, M:], offs[0, M:]]
+                rows = [rows[0], rows[0]]
+                dwih = torch.empty(G, I, device=dev)
+                db = torch.empty(G, device=dev)
+                lib.check(L.nir_linear_wgrad_rows_set_f32(lib.ptr(dg2), G, 0, lib.ptr(x2), I, 0, lib.ptr(rows[0]), lib.ptr(cnt[0]), M * T, 0, 0,
+                                                          lib.ptr(dwih), I, lib.ptr(db), G, I, lib.stream()), "nir_linear_wgrad_rows_set_f32")
+            else:
+                dwih, db = _wgrad_bias(dg2, G, x2, I, M * T, G, I)
+            grads = []
+            o2 = out.view(M * T, nd * H)
+            for dd in range(nd):
+                dwhh = torch.empty(4 * H, H, device=dev)
+                lib.check(L.nir_linear_wgrad_rows_set_f32(lib.C.c_void_p(dg2.data_ptr() + dd * 4 * H * 4), G, 0, lib.C.c_void_p(o2.data_ptr() + dd * H * 4),
+                                                          nd * H, -1 if dd == 0 else 1, lib.ptr(rows[dd]), lib.ptr(cnt[dd]), M * T, T,
+                                                          0 if dd == 0 else T - 1, lib.ptr(dwhh), H, None, 4 * H, H, lib.stream()),
+                          "nir_linear_wgrad_rows_set_f32")
+                sl = slice(dd * 4 * H, (dd + 1) * 4 * H)
+                grads += [dwih[sl], dwhh, db[sl], db[sl].clone()]
+            return (dx, None, None, dh0, dc0) + tuple(grads)
         dwih, db = _wgrad_bias(dg2, G, x2, I, M * T, G, I)
         grads = []
         for dd in range(nd):

@@ -11,6 +11,7 @@
 //                          test can replay exactly the same mask through the oracle
 //   nir_act_bwd_f32, nir_bce_bwd_f32, nir_softmax_nll_bwd_f32   element-wise backward pieces
 #include "common.hpp"
+#include <mutex>
 #include <algorithm>
 
 namespace nir {
@@ -33,7 +34,30 @@ struct WgradArgs {
     int64_t mslice;
     int store;                                         // 1: one slice covers M -- every element is written once, plain stores (dw needs no zero fill)
     float* db;                                         // optional: bias gradient db[n] = sum_m dy[m,n] -- the waves of k-tile 0 hold dy's column values anyway (round 5)
+    // row list (round 5): reduction row r reads dY row rows[r] + dyd and X row rows[r] + xd; the number of rows is read on the device (*mcount;
+    // M is its upper bound, `slices` the slice count the grid was sized for) -- padded (t >= length) positions of a sequence batch are not visited
+    const int32_t* rows; const int32_t* mcount; int64_t dyd, xd; int slices;
+    unsigned magic;                                    // ceil(2^32 / period): row % period through one mulhi (rows < 2^31)
+    int period, skip;                                  // period > 0: X counts as zero on reduction rows r with r % period == skip (the first / last step of
+                                                       // a [M,T] sequence batch has no previous state: the row before / after belongs to its neighbour)
 };
+__device__ __forceinline__ bool wgrad_skip(const WgradArgs& p, int64_t row) {
+    if (p.period <= 0) return false;
+    if (p.period == 1) return true;
+    const unsigned r = (unsigned)row, q = __umulhi(r, p.magic);          // q in {floor(r / period), + 1}
+    int rem = (int)(r - q * (unsigned)p.period);
+    if (rem < 0) rem += p.period;
+    return rem == p.skip;
+}
+__device__ __forceinline__ void wgrad_range(const WgradArgs& p, int64_t slice, int64_t& ms, int64_t& me) {
+    if (p.mcount) {
+        const int64_t Mt = min((int64_t)*p.mcount, p.M);
+        const int64_t msl = ((Mt + p.slices - 1) / p.slices + 15) / 16 * 16;
+        ms = slice * msl; me = min(Mt, ms + msl);
+    } else {
+        ms = slice * p.mslice; me = min(p.M, ms + p.mslice);
+    }
+}
 
 // NB x KB register blocking: a wave owns a (32 NB) x (32 KB) tile of dW -- NB + KB operand values per lane and m for NB KB MFMAs (the 1 x 1
 // form loads two values per MFMA and was load-bound: 0.26 of the fp32 pipe on the [71680] x [1024, 300] gradient of the CARS input projection)
@@ -46,8 +70,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     const int64_t slice = wid / tiles;
     const int tile = (int)(wid % tiles);
     const int n0 = (tile / kt) * 32 * NB, k0 = (tile % kt) * 32 * KB;
-    const int64_t ms = slice * p.mslice, me = min(p.M, ms + p.mslice);
-    if (ms >= p.M) return;
+    int64_t ms, me;
+    wgrad_range(p, slice, ms, me);
+    if (ms >= me) {
+        if (p.store && p.mcount && slice == 0) me = ms = 0;           // (an empty row list in "=" mode still writes its zeros; slice 0 only:
+                                                                     // the spare waves of the last workgroup have slice >= slices)
+        else return;
+    }
     const int half = lane >> 5;
     int n[NB], k[KB];
     bool nv[NB], kv[KB];
@@ -72,13 +101,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
         for (int u = 0; u < 8; ++u) {
             const int64_t mm = m + 2 * u + half;
             const bool mv = mm < me;
-            const int64_t mc = mv ? mm : ms;                                     // clamped row, masked value: no predicated loads
-            const float* dr = p.dy + mc * p.lddy;
-            const float* xr = p.ids ? p.table + p.ids[mc] * (int64_t)p.E : p.x + mc * p.ldx;
+            int64_t mc = mv ? mm : ms;                                           // clamped row, masked value: no predicated loads
+            if (p.rows) mc = mv ? (int64_t)p.rows[mc] : 0;
+            const bool xs = wgrad_skip(p, mc);
+            const float* dr = p.dy + (mc + p.dyd) * p.lddy;
+            const float* xr = p.ids ? p.table + p.ids[mc] * (int64_t)p.E : p.x + (mc + (xs ? 0 : p.xd)) * p.ldx;
 #pragma unroll
             for (int i = 0; i < NB; ++i) a[i][u] = (mv && nv[i]) ? dr[n[i]] : 0.f;
 #pragma unroll
-            for (int j = 0; j < KB; ++j) b[j][u] = (mv && kv[j]) ? xr[k[j]] : 0.f;
+            for (int j = 0; j < KB; ++j) b[j][u] = (mv && kv[j] && !xs) ? xr[k[j]] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -114,6 +145,189 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
                     else atomicAdd(p.dw + (int64_t)nn * p.lddw + k[j], acc[i][j][r]);
                 }
             }
+}
+
+// LDS-staged form for the big gradients (round 5).  The register-blocked kernel above has every wave fetch its own 16 x (64 + 64) operand
+// block from L2 for 32 MFMAs: at the fp32 MFMA rate that is 16 B / cycle / CU of L2 reads -- the [71680] x [1024, 300] gradient of the CARS
+// input projection ran at 0.37 of the pipe on it.  Here a workgroup of WN x WK waves owns a (64 WN) x (64 WK) tile of dW: each 16-row stage of
+// dY[.., 64 WN] and X[.., 64 WK] is fetched ONCE (float4, through registers, double-buffered in LDS: the loads of stage s + 1 are in flight
+// while stage s feeds the MFMAs) and every wave reads its 64-column halves from LDS -- (WN + WK) / (2 WN WK) of the L2 reads (0.35 at 2 x 5).
+// Row stride of the planes = 32 mod 64 words: lanes l and l + 32 (rows 2u, 2u + 1) fall in different banks.
+template <int WN, int WK>
+__global__ __launch_bounds__(64 * WN * WK) void wgrad_lds_kernel(WgradArgs p) {
+    constexpr int BN = 64 * WN, BK = 64 * WK, SA = BN + 32, SB = BK + 32, NT = 64 * WN * WK;
+    constexpr int ITEMS = 4 * (BN + BK), LA = (ITEMS + NT - 1) / NT;     // float4 items of one 16-row stage
+    extern __shared__ float wg_lds[];
+    float* sA = wg_lds;
+    float* sB = wg_lds + 2 * 16 * SA;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wn = wave / WK, wk = wave % WK;
+    const int nt = (p.N + BN - 1) / BN, kt = (p.K + BK - 1) / BK;
+    const int tiles = nt * kt;
+    const int64_t slice = blockIdx.x / tiles;
+    const int tile = (int)(blockIdx.x % tiles);
+    const int n0 = (tile / kt) * BN, k0 = (tile % kt) * BK;
+    int64_t ms, me;
+    wgrad_range(p, slice, ms, me);
+    if (ms >= me) {                                                // block-uniform
+        if (p.store && p.mcount && slice == 0) me = ms = 0;
+        else return;
+    }
+    const int half = lane >> 5;
+    float4 pre[LA];
+    auto gload = [&](int64_t m0) {
+#pragma unroll
+        for (int q = 0; q < LA; ++q) {
+            const int idx = (int)threadIdx.x + q * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < 4 * BN) {
+                const int row = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+                const int64_t mm = m0 + row;
+                if (mm < me && n0 + c < p.N) {
+                    const int64_t rr = p.rows ? (int64_t)p.rows[mm] : mm;
+                    v = *(const float4*)(p.dy + (rr + p.dyd) * p.lddy + n0 + c);
+                }
+            } else if (idx < ITEMS) {
+                const int j = idx - 4 * BN;
+                const int row = j / (BK / 4), c = (j % (BK / 4)) * 4;
+                const int64_t mm = m0 + row;
+                if (mm < me && k0 + c < p.K) {
+                    const int64_t rr = p.rows ? (int64_t)p.rows[mm] : mm;
+                    if (!wgrad_skip(p, rr)) {
+                        const float* xr = p.ids ? p.table + p.ids[rr] * (int64_t)p.E : p.x + (rr + p.xd) * p.ldx;
+                        v = *(const float4*)(xr + k0 + c);
+                    }
+                }
+            }
+            pre[q] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LA; ++q) {
+            const int idx = (int)threadIdx.x + q * NT;
+            if (idx < 4 * BN) {
+                const int row = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+                *(float4*)(sA + (buf * 16 + row) * SA + c) = pre[q];
+            } else if (idx < ITEMS) {
+                const int j = idx - 4 * BN;
+                const int row = j / (BK / 4), c = (j % (BK / 4)) * 4;
+                *(float4*)(sB + (buf * 16 + row) * SB + c) = pre[q];
+            }
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool do_db = p.db != nullptr && k0 == 0 && wk == 0;      // wave-uniform
+    float bs[2] = {0.f, 0.f};
+    gload(ms);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t m = ms; m < me; m += 16, buf ^= 1) {
+        const bool more = m + 16 < me;                             // block-uniform
+        if (more) gload(m + 16);
+        const float* ap = sA + (buf * 16 + half) * SA + wn * 64 + (lane & 31);
+        const float* bp = sB + (buf * 16 + half) * SB + wk * 64 + (lane & 31);
+        float a[2][8], b[2][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[0][u] = ap[2 * u * SA]; a[1][u] = ap[2 * u * SA + 32];
+            b[0][u] = bp[2 * u * SB]; b[1][u] = bp[2 * u * SB + 32];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
+        if (do_db) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bs[i] += ((a[i][0] + a[i][1]) + (a[i][2] + a[i][3])) + ((a[i][4] + a[i][5]) + (a[i][6] + a[i][7]));
+        }
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (do_db) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float t = bs[i] + __shfl_xor(bs[i], 32);
+            const int nn = n0 + wn * 64 + 32 * i + (lane & 31);
+            if (half == 0 && nn < p.N) {
+                if (p.store) p.db[nn] = t;
+                else atomicAdd(p.db + nn, t);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = k0 + wk * 64 + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + wn * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (nn < p.N && kk < p.K) {
+                    if (p.store) p.dw[(int64_t)nn * p.lddw + kk] = acc[i][j][r];
+                    else atomicAdd(p.dw + (int64_t)nn * p.lddw + kk, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+template <int WN, int WK>
+static void wgrad_lds_launch(const WgradArgs& a, int64_t blocks, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * 16 * (64 * WN + 32 + 64 * WK + 32) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static std::once_flag once;
+        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    }
+    hipLaunchKernelGGL((wgrad_lds_kernel<WN, WK>), dim3((unsigned)blocks), dim3(64 * WN * WK), lds, st, a);
+}
+
+// Row list of a padded sequence batch: rows = { m T + t : t0 <= t < len[m] } in (m, t) order, offs[m] = its start, offs[M] = the count.
+// The weight gradients of the recurrent encoders reduce over these rows only (the reference packs its sequences: layers.py:52-66).
+__global__ __launch_bounds__(1024) void seq_rows_scan_kernel(const int64_t* __restrict__ lens, int64_t M, int T, int t0, int32_t* __restrict__ offs) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < M; base += 1024) {
+        const int64_t m = base + threadIdx.x;
+        int v = 0;
+        if (m < M) {
+            const int64_t l = lens[m];
+            v = (int)max((int64_t)0, min((int64_t)T, l) - t0);
+        }
+        int x = v;                                                 // inclusive wave scan
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+        if (m < M) offs[m] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offs[M] = carry;
+}
+__global__ __launch_bounds__(256) void seq_rows_fill_kernel(const int64_t* __restrict__ lens, const int32_t* __restrict__ offs, int64_t M, int T, int t0,
+                                                           int32_t* __restrict__ rows) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * T) return;
+    const int64_t m = i / T;
+    const int t = (int)(i - m * T);
+    if (t >= t0 && t < lens[m]) rows[offs[m] + (t - t0)] = (int32_t)i;
 }
 
 // out[n] += sum_m x[m*ld + n]
@@ -822,14 +1036,44 @@ extern "C" int nir_lstm_cell_bwd(const float* dh, const float* dc, const float* 
     return 0;
 }
 
+struct WgradRows { const int32_t* rows = nullptr; const int32_t* mcount = nullptr; int64_t dyd = 0, xd = 0; int period = 0, skip = 0; };
 static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E, float* dw,
-                      int64_t lddw, int64_t M, int N, int K, bool set, hipStream_t st, float* db = nullptr) {
+                      int64_t lddw, int64_t M, int N, int K, bool set, hipStream_t st, float* db = nullptr, WgradRows rl = WgradRows()) {
     using namespace nir;
     NIR_REQUIRE(dy && dw && (ids ? (table != nullptr && E >= K) : (x != nullptr)), "linear_wgrad: null pointer");
     NIR_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_wgrad: bad dims");
     if (M == 0) {
         if (set && db) NIR_PROPAGATE((int)hipMemsetAsync(db, 0, (size_t)N * 4, st));
         if (set) return (int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st);
+        return 0;
+    }
+    // LDS-staged workgroup tiles for the big gradients (float4 rows: widths, strides and bases in units of 16 bytes)
+    const int64_t xstride = ids ? (int64_t)E : ldx;
+    const bool lds_ok = M >= 32768 && N >= 128 && K >= 128 && N % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && xstride % 4 == 0 &&
+                        ((uintptr_t)dy & 15) == 0 && ((uintptr_t)(ids ? table : x) & 15) == 0 && !tun(g_tun.wgrad_no_lds);
+    if (lds_ok) {
+        int wk = 2;                                                    // K tile of 64 wk columns: least padding, then the widest
+        int64_t best = -1;
+        for (int c = 2; c <= 5; ++c) {
+            const int64_t padded = (int64_t)((K + 64 * c - 1) / (64 * c)) * 64 * c;
+            if (best < 0 || padded < best || (padded == best && c > wk)) { best = padded; wk = c; }
+        }
+        const int64_t tiles = (int64_t)((N + 127) / 128) * ((K + 64 * wk - 1) / (64 * wk));
+        int64_t slices = std::max<int64_t>(1, std::min<int64_t>((M + 255) / 256, (512 + tiles - 1) / tiles));
+        const int64_t mslice = ((M + slices - 1) / slices + 15) / 16 * 16;
+        slices = (M + mslice - 1) / mslice;
+        const int store = set && slices == 1;
+        if (set && !store) NIR_PROPAGATE((int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st));
+        if (set && !store && db) NIR_PROPAGATE((int)hipMemsetAsync(db, 0, (size_t)N * 4, st));
+        WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store, db, rl.rows, rl.mcount, rl.dyd, rl.xd, (int)slices, rl.period > 1 ? (unsigned)((((uint64_t)1 << 32) + rl.period - 1) / rl.period) : 0u, rl.period, rl.skip};
+        ProfScope ps(prof_shape_name("wgrad_lds_kernel", M, N, K), st);
+        switch (wk) {
+            case 2: wgrad_lds_launch<2, 2>(a, tiles * slices, st); break;
+            case 3: wgrad_lds_launch<2, 3>(a, tiles * slices, st); break;
+            case 4: wgrad_lds_launch<2, 4>(a, tiles * slices, st); break;
+            default: wgrad_lds_launch<2, 5>(a, tiles * slices, st); break;
+        }
+        NIR_CHECK_LAUNCH("wgrad_lds_kernel");
         return 0;
     }
     // 2 x 2 blocking once there is enough work for it to pay (big M) and the tile is not mostly padding
@@ -842,7 +1086,7 @@ static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx
     const int store = set && slices == 1;
     if (set && !store) NIR_PROPAGATE((int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st));
     if (set && !store && db) NIR_PROPAGATE((int)hipMemsetAsync(db, 0, (size_t)N * 4, st));
-    WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store, db};
+    WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store, db, rl.rows, rl.mcount, rl.dyd, rl.xd, (int)slices, rl.period > 1 ? (unsigned)((((uint64_t)1 << 32) + rl.period - 1) / rl.period) : 0u, rl.period, rl.skip};
     ProfScope ps(prof_shape_name("wgrad_kernel", M, N, K), st);
     if (big) hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<1, 1>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
@@ -862,6 +1106,29 @@ extern "C" int nir_linear_wgrad_bias_set_f32(const float* dy, int64_t lddy, cons
                                              float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream) {
     NIR_REQUIRE(db != nullptr, "linear_wgrad_bias: null bias gradient");
     return wgrad_impl(dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, true, (hipStream_t)stream, db);
+}
+
+extern "C" int nir_seq_rows(const int64_t* lengths, int64_t M, int T, int t_begin, int32_t* offs, int32_t* rows, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(lengths && offs && rows, "seq_rows: null pointer");
+    NIR_REQUIRE(M >= 0 && T > 0 && t_begin >= 0 && M * (int64_t)T < ((int64_t)1 << 31), "seq_rows: bad dims (M T < 2^31)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(seq_rows_scan_kernel, dim3(1), dim3(1024), 0, st, lengths, M, T, t_begin, offs);
+    NIR_CHECK_LAUNCH("seq_rows_scan_kernel");
+    if (M) {
+        hipLaunchKernelGGL(seq_rows_fill_kernel, dim3((unsigned)((M * T + 255) / 256)), dim3(256), 0, st, lengths, offs, M, T, t_begin, rows);
+        NIR_CHECK_LAUNCH("seq_rows_fill_kernel");
+    }
+    return 0;
+}
+extern "C" int nir_linear_wgrad_rows_set_f32(const float* dy, int64_t lddy, int64_t dy_row_delta, const float* x, int64_t ldx, int64_t x_row_delta,
+                                             const int32_t* rows, const int32_t* count, int64_t max_rows, int period, int skip, float* dw, int64_t lddw,
+                                             float* db, int N, int K, nir_stream_t stream) {
+    NIR_REQUIRE((rows != nullptr) == (count != nullptr), "linear_wgrad_rows: rows and count go together");
+    NIR_REQUIRE(period >= 0 && (period == 0 || (skip >= 0 && skip < period && max_rows < ((int64_t)1 << 31))), "linear_wgrad_rows: bad period / skip");
+    WgradRows rl;
+    rl.rows = rows; rl.mcount = count; rl.dyd = dy_row_delta; rl.xd = x_row_delta; rl.period = period; rl.skip = skip;
+    return wgrad_impl(dy, lddy, x, ldx, nullptr, nullptr, 0, dw, lddw, max_rows, N, K, true, (hipStream_t)stream, db, rl);
 }
 
 static int colsum_impl(const float* x, int64_t ld, int64_t M, int N, float* out, bool set, hipStream_t st) {

@@ -556,6 +556,19 @@ int nir_linear_wgrad_set_f32(const float* dy, int64_t lddy, const float* x, int6
  * replaces nir_linear_wgrad_set_f32 + nir_colsum_set_f32 of one nn.Linear (models/ranker.py:216 loss.backward()). */
 int nir_linear_wgrad_bias_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
                                   float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream);
+/* Row list of a padded sequence batch: rows = { m T + t : t_begin <= t < min(lengths[m], T) } in (m, t) order (int32, room for M T entries),
+ * offs[m] = start of sequence m's rows, offs[M] = the number of rows -- all on the device, no host synchronisation.  The reference reaches the
+ * same set through pack_padded_sequence (neuroir/encoders/rnn_encoder.py, modules/layers). */
+int nir_seq_rows(const int64_t* lengths, int64_t M, int T, int t_begin, int32_t* offs /*[M+1]*/, int32_t* rows /*[M*T]*/, nir_stream_t stream);
+/* dW[n,k] = sum_r dY[row(r) + dy_row_delta, n] * X[row(r) + x_row_delta, k], db[n] (optional) the same sum of dY alone, over the reduction rows
+ * r < max_rows with row(r) = r (rows == NULL), or r < *count (device, <= max_rows) with row(r) = rows[r].  period > 0: X counts as ZERO (and is
+ * not read) where row(r) % period == skip.  The recurrent weight gradient of a [M,T] sequence batch is this with X = the states, x_row_delta
+ * -1 / +1 and skip 0 / T-1 (h_{t-1} is the row before / after the gate row; the first step of a sequence has none): no shifted copy of the
+ * states is made.  With a row list (nir_seq_rows) the reduction visits valid positions only -- it pays once well under ~70 % of the positions
+ * are valid (the list costs one dependent load per row).  "=" form: dW / db need no zero fill. */
+int nir_linear_wgrad_rows_set_f32(const float* dy, int64_t lddy, int64_t dy_row_delta, const float* x, int64_t ldx, int64_t x_row_delta,
+                                  const int32_t* rows, const int32_t* count, int64_t max_rows, int period, int skip, float* dw, int64_t lddw,
+                                  float* db, int N, int K, nir_stream_t stream);
 int nir_colsum_set_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream);
 /* out [C,R] = in [R,C]^T  (data gradient: dX = dY W is nir_linear_f32(dY, W^T)) */
 int nir_transpose_f32(const float* in, int R, int C, float* out, nir_stream_t stream);

@@ -24,7 +24,7 @@ def _rel(a, b, tol=1e-4, floor=1e-5):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(37, 40, 300, None), (130, 50, 30, "tanh"), (4100, 18, 1071, "relu"), (5, 1, 20, None),
-                                       (20480, 560, 40, None), (13000, 300, 260, "tanh")])
+                                       (20480, 560, 40, None), (13000, 300, 260, "tanh"), (40000, 256, 300, None), (33000, 132, 520, None)])
 def test_linear_backward(M, N, K, act):
     from context_attentive_ir_amd import autograd as A
     g = torch.Generator().manual_seed(M + N)
@@ -41,7 +41,7 @@ def test_linear_backward(M, N, K, act):
 
 
 @pytest.mark.parametrize("H,I,M,T_,bi", [(15, 40, 7, 6, True), (70, 40, 33, 20, True), (128, 300, 19, 12, True), (64, 256, 16, 7, False),
-                                         (128, 64, 3, 64, True), (1, 4, 2, 3, True)])
+                                         (128, 64, 3, 64, True), (1, 4, 2, 3, True), (128, 300, 640, 64, True), (96, 132, 1100, 30, False)])
 def test_bilstm_backward(H, I, M, T_, bi):
     """Train-mode recurrence + BPTT against torch autograd through the oracle's pack/sort/nn.LSTM restatement."""
     from context_attentive_ir_amd import autograd as A
@@ -57,11 +57,64 @@ def test_bilstm_backward(H, I, M, T_, bi):
     ref.backward(dout)
     lstm = lstm.to(DEV)
     xd = x.to(DEV).requires_grad_(True)
-    out = A.bilstm(xd, lens.to(DEV), lstm)
-    out.backward(dout.to(DEV))
-    _rel(out, ref, 2e-5); _rel(xd.grad, xr.grad)
-    for k, p in lstm.named_parameters():
-        _rel(p.grad, sd["e.rnns.0." + k].grad)
+    for packed in (False, True):
+        A.PACKED_WGRAD = packed
+        try:
+            lstm.zero_grad(); xd.grad = None
+            out = A.bilstm(xd, lens.to(DEV), lstm)
+            out.backward(dout.to(DEV))
+        finally:
+            A.PACKED_WGRAD = False
+        _rel(out, ref, 2e-5); _rel(xd.grad, xr.grad)
+        for k, p in lstm.named_parameters():
+            _rel(p.grad, sd["e.rnns.0." + k].grad)
+
+
+@pytest.mark.parametrize("M,T_,t0", [(7, 5, 0), (7, 5, 1), (2500, 9, 1), (1, 1, 0), (1, 1, 1)])
+def test_seq_rows_lists_the_valid_positions(M, T_, t0):
+    """nir_seq_rows against numpy: {m T + t : t0 <= t < len[m]} in (m, t) order, zero-length and over-long sequences included."""
+    from context_attentive_ir_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(M)
+    lens = torch.randint(0, T_ + 3, (M,), generator=g)
+    ld = lens.to(DEV)
+    offs = torch.full((M + 1,), -1, device=DEV, dtype=torch.int32)
+    rows = torch.full((M * T_,), -1, device=DEV, dtype=torch.int32)
+    lib.check(L.nir_seq_rows(lib.ptr(ld), M, T_, t0, lib.ptr(offs), lib.ptr(rows), lib.stream()), "nir_seq_rows")
+    want = [m * T_ + t for m in range(M) for t in range(t0, min(int(lens[m]), T_))]
+    cnt = np.array([max(0, min(int(l), T_) - t0) for l in lens])
+    assert int(offs[M]) == len(want)
+    assert np.array_equal(offs[:M].cpu().numpy(), np.concatenate(([0], np.cumsum(cnt)[:-1])))
+    assert np.array_equal(rows[:len(want)].cpu().numpy(), np.array(want, dtype=np.int32).reshape(-1))
+
+
+@pytest.mark.parametrize("R,N,K,frac", [(300, 40, 24, 0.5), (100, 8, 8, 0.0), (40000, 256, 132, 0.4), (5000, 130, 300, 0.0), (36000, 128, 128, 1.0)])
+def test_wgrad_over_a_row_list(R, N, K, frac):
+    """nir_linear_wgrad_rows_set_f32: sum over listed rows with row deltas (both kernels: register-blocked and LDS-staged), empty list -> zeros."""
+    from context_attentive_ir_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(R)
+    dy = torch.randn(R + 2, N, generator=g); x = torch.randn(R + 2, K, generator=g)
+    keep = (torch.rand(R, generator=g) < frac).nonzero().flatten() + 1          # rows 1 .. R (deltas of -1 / +1 stay inside)
+    rows = torch.zeros(R, dtype=torch.int32); rows[:keep.numel()] = keep.int()
+    cnt = torch.tensor([keep.numel()], dtype=torch.int32)
+    dyd, xd, rd, cd = dy.to(DEV), x.to(DEV), rows.to(DEV), cnt.to(DEV)
+    dw = torch.full((N, K), float("nan"), device=DEV); db = torch.full((N,), float("nan"), device=DEV)
+    lib.check(L.nir_linear_wgrad_rows_set_f32(lib.ptr(dyd), N, -1, lib.ptr(xd), K, 1, lib.ptr(rd), lib.ptr(cd), R, 0, 0, lib.ptr(dw), K, lib.ptr(db), N, K,
+                                              lib.stream()), "nir_linear_wgrad_rows_set_f32")
+    ref = dy[keep - 1].double().t() @ x[keep + 1].double()
+    _rel(dw, ref.float()); _rel(db, dy[keep - 1].double().sum(0).float())
+    # the same list with a period: X counts as zero where row % 7 == 3
+    lib.check(L.nir_linear_wgrad_rows_set_f32(lib.ptr(dyd), N, -1, lib.ptr(xd), K, 1, lib.ptr(rd), lib.ptr(cd), R, 7, 3, lib.ptr(dw), K, None, N, K,
+                                              lib.stream()), "nir_linear_wgrad_rows_set_f32")
+    k2 = keep[keep % 7 != 3]
+    _rel(dw, (dy[k2 - 1].double().t() @ x[k2 + 1].double()).float())
+    # dense rows 0 .. R-1 (no list), state shifted one row back, first row of every period skipped (never read: row -1 does not exist)
+    lib.check(L.nir_linear_wgrad_rows_set_f32(lib.ptr(dyd), N, 0, lib.ptr(xd), K, -1, None, None, R, 5, 0, lib.ptr(dw), K, lib.ptr(db), N, K,
+                                              lib.stream()), "nir_linear_wgrad_rows_set_f32")
+    r = torch.arange(R)
+    r = r[r % 5 != 0]
+    _rel(dw, (dy[r].double().t() @ x[r - 1].double()).float()); _rel(db, dy[:R].double().sum(0).float())
 
 
 def test_embed_backward_skips_pad_and_accumulates():
