@@ -130,6 +130,7 @@ class StepScope(object):
 
 
 STEP = StepScope()
+SPLIT_TRAIN_FWD = True     # _BiLSTM.forward at H = 128: the split-fp16 matrix-core recurrence (False: the fp32 MFMA one, any H <= 128)
 PACKED_WGRAD = False       # _BiLSTM.backward: reduce the weight gradients over a list of the valid (t < length) positions only
 
 
@@ -270,8 +271,12 @@ def id_flag(device):
 def check_ids():
     """Synchronising: raise IndexError if a train-mode lookup since the last check saw an id outside the vocabulary."""
     for f in _ID_FLAGS.values():
-        if int(f.item()) != 0:
+        v = int(f.item())
+        if v != 0:
             f.zero_()
+            if v & 2:
+                raise RuntimeError("recurrent weights outside the fp16 range of the split-fp16 train-mode recurrence (|w_hh| >= 2^15); results of that "
+                                   "step are invalid -- autograd.SPLIT_TRAIN_FWD = False selects the fp32 recurrence")
             raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
 
 
@@ -366,6 +371,20 @@ def dropout(x, p, training):
     return y
 
 
+_ROW_IDS = {}
+
+
+def _row_ids(n, dev):
+    """0 .. n-1 (int64) on the device: the "token ids" of a per-batch gate tensor read by the folded-table recurrence (built once per size)"""
+    key = (int(n), str(dev))
+    t = _ROW_IDS.get(key)
+    if t is None:
+        if len(_ROW_IDS) > 16:
+            _ROW_IDS.clear()
+        t = _ROW_IDS[key] = torch.arange(n, device=dev, dtype=torch.int64)
+    return t
+
+
 class _BiLSTM(Function):
     """x [M,T,I], lens [M] (or None), optional initial state h0/c0 [ND,M,H] and the nn.LSTM parameters (per direction: w_ih
     [4H,I], w_hh [4H,H], b_ih, b_hh) -> (memory bank [M,T,ND*H], zero at t >= length; cell states [M,T,ND,H])."""
@@ -377,7 +396,6 @@ class _BiLSTM(Function):
         M, T, I = x.shape
         wih = torch.cat([params[4 * d] for d in range(nd)], 0).float().contiguous()
         whh = torch.stack([params[4 * d + 1] for d in range(nd)], 0).float().contiguous()
-        bias = torch.cat([params[4 * d + 2] + params[4 * d + 3] for d in range(nd)], 0).float().contiguous()
         H = whh.shape[2]
         if H > 128:
             raise NotImplementedError("train-mode recurrence (nir_lstm_train_fwd / _bwd) supports H <= 128 per direction (got %d); "
@@ -386,7 +404,6 @@ class _BiLSTM(Function):
             raise NotImplementedError("initial states are supported for one direction only (the backward's h_{t-1} of the reverse "
                                       "direction at t = length-1 would have to be h0[1])")
         x2 = _f32c(x).reshape(M * T, I)
-        gates = _linear_raw(x2, wih, bias, 0)
         dev = x.device
         out = torch.empty(M, T, nd * H, device=dev)
         act = torch.empty(M, T, nd, 4 * H, device=dev)
@@ -396,8 +413,24 @@ class _BiLSTM(Function):
         lens64 = lib.ids64(lens) if lens is not None else None
         h0c = _f32c(h0) if h0 is not None else None
         c0c = _f32c(c0) if c0 is not None else None
-        lib.check(L.nir_lstm_train_fwd(lib.ptr(gates), lib.ptr(lens64), lib.ptr(whh), lib.ptr(h0c), lib.ptr(c0c), lib.ptr(out), lib.ptr(act),
-                                       lib.ptr(cst), None, None, M, T, H, nd, lib.stream()), "nir_lstm_train_fwd")
+        if SPLIT_TRAIN_FWD and H == 128 and h0 is None and M * T >= 16 and T <= 512:
+            # the fp32-accurate split-fp16 recurrence of the inference path with train-mode stores (3 fp16 MFMAs per k-block for 32 fp32 ones):
+            # the input GEMM writes the gates in the folded order [row][dir][unit][gate] (weights permuted once per step), rows are their own ids
+            ps = [_f32c(t) for t in params]
+            wperm = torch.empty(nd * 4 * H, I, device=dev)
+            bperm = torch.empty(nd * 4 * H, device=dev)
+            rev = ps[4:7] if nd == 2 else [None, None, None]
+            lib.check(L.nir_lstm_perm_weights(lib.ptr(ps[0]), lib.ptr(ps[2]), lib.ptr(ps[3]), lib.ptr(rev[0]), lib.ptr(rev[2]) if nd == 2 else None,
+                                              lib.ptr(ps[7]) if nd == 2 else None, H, nd, I, lib.ptr(wperm), lib.ptr(bperm), lib.stream()),
+                      "nir_lstm_perm_weights")
+            gates = _linear_raw(x2, wperm, bperm, 0)
+            lib.check(L.nir_lstm_train_fwd_split(lib.ptr(gates), lib.ptr(_row_ids(M * T, dev)), lib.ptr(lens64), lib.ptr(whh), lib.ptr(out), lib.ptr(act),
+                                                 lib.ptr(cst), lib.ptr(id_flag(dev)), M, T, H, nd, lib.stream()), "nir_lstm_train_fwd_split")
+        else:
+            bias = torch.cat([params[4 * d + 2] + params[4 * d + 3] for d in range(nd)], 0).float().contiguous()
+            gates = _linear_raw(x2, wih, bias, 0)
+            lib.check(L.nir_lstm_train_fwd(lib.ptr(gates), lib.ptr(lens64), lib.ptr(whh), lib.ptr(h0c), lib.ptr(c0c), lib.ptr(out), lib.ptr(act),
+                                           lib.ptr(cst), None, None, M, T, H, nd, lib.stream()), "nir_lstm_train_fwd")
         ctx.nd, ctx.dims = nd, (M, T, I, H)
         e = torch.empty(0)
         ctx.save_for_backward(x2, lens64 if lens64 is not None else e, wih, whh, out, act, cst, h0c if h0c is not None else e,

@@ -87,6 +87,8 @@ struct LstmPtArgs {
                             // element, but every group of 4 consecutive units holds [4 x fp16 leading term | 4 x fp16 residual x 2^11] -- the two-term
                             // split the kernel forms anyway for its own next step, in the order attn_pool_pipe_kernel stages its LDS planes
     const void* whh_frag;   // optional: W_hh pre-split into the two fp16 terms, in the lane order of lstm16_pt_h2_kernel<4,4,8> (nir_lstm_pack_whh_frag)
+    float* act;             // train-mode forward (lstm16_pt_h2_kernel<4,4,8,false,true>): [M,T,ND,4H] gate activations i,f,g,o (gate-major inside a direction)
+    float* cst;             //   and [M,T,ND,H] cell states of every valid step, for the backward pass (csrc/train.hip)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -527,8 +529,12 @@ __device__ unsigned long long* g_pt_trace_dev;
 // H1 (round 5, the opt-in "split2" precision tier, <4,4,8,true> only): h enters the recurrent product as ONE fp16 term -- w.h = w1.h1 + 2^-11 w2'.h1:
 // two MFMAs per k-block instead of three, one LDS h plane instead of two -- and leaves as fp16 rows [M,T,ND*H] (out_f16 == 3) for
 // attn_pool_pipe_kernel<false,1>.  Measured error and where it holds: DESIGN.md section 10; never selected by default.
-template <int KB, int NT, int NW, bool H1 = false>
+// TR (round 5, <4,4,8,false,true>, H = 128): the train-mode forward -- the "table" is the batch's own gate tensor (ids = 0, 1, 2, ..), and the
+// gate activations and the cell state of every valid step go to memory for the backward (the cell is then written gate by gate: the
+// backward needs i, f, g, o themselves, not the merged fractions of lstm_cell_v).
+template <int KB, int NT, int NW, bool H1 = false, bool TR = false>
 __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(LstmPtArgs p) {   // (second argument: waves per SIMD)
+    static_assert(!TR || (NT == 4 && !H1), "train-mode stores: four consecutive units per lane");
     constexpr int NTH = 64 * NW;
     constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // fp16 elements per h row
     constexpr uint32_t OOB = 0x7FFFFFF0u;
@@ -682,6 +688,10 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     const __amdgpu_buffer_rsrc_t out_rs = H1 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<_Float16*>(p.out) + m0 * T * OW, 0,
                                                                                   (int)((uint32_t)nvalid * T * OW * 2u), 0x00020000)
                                              : __builtin_amdgcn_make_buffer_rsrc(p.out + m0 * T * OW, 0, (int)((uint32_t)nvalid * T * OW * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(TR ? p.act + m0 * T * GW : p.out, 0,
+                                                                             TR ? (int)((uint32_t)nvalid * T * (uint32_t)GW * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cst_rs = __builtin_amdgcn_make_buffer_rsrc(TR ? p.cst + m0 * T * OW : p.out, 0,
+                                                                             TR ? (int)((uint32_t)nvalid * T * OW * 4u) : 0, 0x00020000);
     // per-unit base of the lane's 16-byte gate groups inside a folded row (units past H re-read the last real one: never used);
     // row = base + id * GW floats
     const float* ptf = reinterpret_cast<const float*>(p.pt) + (int64_t)dir * H4;
@@ -737,7 +747,21 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
 #ifdef NIR_X_NOGATES   // ablation: the step without its gate math (tools/recur_micro.py)
     auto gates = [&](int t) { hn[t] = (acx[t][0] + acc[t][1]) * 1e-3f; };
 #else
-    auto gates = [&](int t) { lstm_cell_v(acx[t] * ISC + acc[t], creg[t], hn[t]); };
+    float tga[TR ? NT : 1][4];                               // train mode: this step's i, f, g, o of the lane's units
+    auto gates = [&](int t) {
+        if constexpr (TR) {
+            const f32x4 x = acx[t] * ISC + acc[t];
+            const float gi = fast_sigmoid(x[0]), gf = fast_sigmoid(x[1]), gg = fast_tanh(x[2]), go = fast_sigmoid(x[3]);
+            const float cn = gf * creg[t] + gi * gg;
+            creg[t] = cn;
+            hn[t] = go * fast_tanh(cn);
+            tga[t][0] = gi; tga[t][1] = gf; tga[t][2] = gg; tga[t][3] = go;
+        } else {
+            lstm_cell_v(acx[t] * ISC + acc[t], creg[t], hn[t]);
+        }
+    };
+    uint32_t aoff = (uint32_t)(((int64_t)(sq * T + (dir == 0 ? 0 : mylen - 1)) * GW + dir * H4 + u0) * 4);
+    const uint32_t astep = (uint32_t)(dir == 0 ? GW * 4 : -(GW * 4));
 #endif
 #ifdef NIR_PT_TRACE
     unsigned long long tr_a = 0, tr_b = 0, tr_c = 0, tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_first = 0, tr_l = 0, tr_m = 0;
@@ -898,6 +922,18 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         }
         poff = live ? soff : OOB;
         soff += sstep;
+#ifndef NIR_X_NOGATES
+        if constexpr (TR) {                        // (younger than the row requests of this step: the wait at the top of the next one does not cover them)
+            const uint32_t ao = (live && full) ? aoff : OOB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(tga[0][r]), __float_as_uint(tga[1 % NT][r]), __float_as_uint(tga[2 % NT][r]),
+                                                               __float_as_uint(tga[3 % NT][r])}, act_rs, ao == OOB ? OOB : ao + (uint32_t)(r * H * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(creg[0]), __float_as_uint(creg[1 % NT]), __float_as_uint(creg[2 % NT]),
+                                                           __float_as_uint(creg[3 % NT])}, cst_rs, full ? poff : OOB, 0, 0);
+            aoff += astep;
+        }
+#endif
         if (!DEFER) store_prev();                  // (this step's output)
 #ifdef NIR_PT_TRACE
         PT_T(tr_t2); tr_b += tr_t2 - tr_t1;
@@ -926,15 +962,15 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
     }
 }
 
-template <int KB, int NT, int NW = 16, bool H1 = false>
+template <int KB, int NT, int NW = 16, bool H1 = false, bool TR = false>
 static int launch_pt_h2(const LstmPtArgs& p, hipStream_t st) {
-    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + (H1 ? ",true" : "") + ">";
+    static const std::string pname = "lstm16_pt_h2_kernel<" + std::to_string(KB) + "," + std::to_string(NT) + (NW == 16 ? "" : "," + std::to_string(NW)) + (TR ? ",false,true" : H1 ? ",true" : "") + ">";
     const size_t lds = (size_t)(4 * 16 * (32 * KB + 8)) * 2 + 2 * 16 * 4 + (size_t)16 * (p.T + 3) * 4;
     ProfScope ps(prof_shape_name(pname.c_str(), (long long)p.M, p.T, p.H), st);
 #ifdef NIR_PT_TRACE
     { unsigned long long* d = g_debug_buf; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pt_trace_dev), &d, sizeof(d), 0, hipMemcpyHostToDevice, st); }
 #endif
-    hipLaunchKernelGGL((lstm16_pt_h2_kernel<KB, NT, NW, H1>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((lstm16_pt_h2_kernel<KB, NT, NW, H1, TR>), dim3((unsigned)((p.M + 15) / 16), (unsigned)p.ND), dim3(64 * NW), lds, st, p);
     NIR_CHECK_LAUNCH("nir_bilstm_folded_fwd[f16x2]");
     return 0;
 }
@@ -1232,7 +1268,7 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     if (M == 0) return 0;
     NIR_REQUIRE(out_f16 != 1 || (pt_dtype == NIR_DTYPE_BF16 && H > 64 && H % 2 == 0), "bilstm_folded: fp16 output needs the bf16 table and an even H > 64");
     NIR_REQUIRE((out_f16 != 2 && out_f16 != 3) || bilstm_folded_split_out_ok(pt_dtype, H, T), "bilstm_folded: split-term / one-term output is produced by lstm16_pt_h2_kernel<4,4,8> only (f32 table, H = 128)");
-    LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND, out_f16, whh_frag};
+    LstmPtArgs p{pt, ids, lens, whh, out, err, M, V, T, H, ND, out_f16, whh_frag, nullptr, nullptr};
     if (pt_dtype == NIR_DTYPE_BF16) {
         const int KB = (H + 31) / 32;
         if (H <= 64) return KB == 1 ? launch_pt_bf16<1, 1>(p, st) : launch_pt_bf16<2, 1>(p, st);
@@ -1277,7 +1313,50 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     }
 }
 
+// Train-mode forward on the split-fp16 recurrence (H = 128 per direction): gates_perm [M*T][ND][H][4] = x W_ih^T + b in the folded gate order
+// (nir_lstm_perm_weights + one GEMM), row_ids = 0 .. M*T-1.  3 fp16 MFMAs per k-block instead of the 32 fp32 ones of lstm_mfma16_gin_kernel.
+int launch_lstm_train_split(const float* gates_perm, const int64_t* row_ids, const int64_t* lens, const float* whh, float* out, float* act, float* cst,
+                            int* err, int64_t M, int T, int H, int ND, hipStream_t st) {
+    NIR_REQUIRE(gates_perm && row_ids && whh && out && act && cst, "lstm_train_fwd_split: null pointer");
+    NIR_REQUIRE(M >= 0 && T > 0 && T <= 512 && (ND == 1 || ND == 2) && H == 128, "lstm_train_fwd_split: bad dims (H = 128 per direction, T <= 512)");
+    NIR_REQUIRE((int64_t)16 * T * ND * H * 16 < 0x7FFFFFF0LL, "lstm_train_fwd_split: T too large for 32-bit tile offsets");
+    if (M == 0) return 0;
+    LstmPtArgs p{gates_perm, row_ids, lens, whh, out, err, M, M * (int64_t)T, T, H, ND, 0, nullptr, act, cst};
+    return launch_pt_h2<4, 4, 8, false, true>(p, st);
+}
+
+// per-direction nn.LSTM parameters -> the folded gate order: wperm[(dir*H + unit)*4 + gate][:] = w_ih[dir][gate*H + unit][:], bperm = b_ih + b_hh
+__global__ void lstm_perm_weights_kernel(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ bi0, const float* __restrict__ bh0,
+                                         const float* __restrict__ bi1, const float* __restrict__ bh1, int H, int ND, int E, float* __restrict__ wperm,
+                                         float* __restrict__ bperm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = (int64_t)ND * 4 * H;
+    if (i >= rows * E) return;
+    const int64_t ro = i / E;
+    const int k = (int)(i % E);
+    const int gate = (int)(ro & 3), unit = (int)((ro >> 2) % H), dir = (int)((ro >> 2) / H);
+    const int64_t ri = (int64_t)gate * H + unit;
+    wperm[i] = (dir ? w1 : w0)[ri * E + k];
+    if (k == 0) bperm[ro] = (dir ? bi1 : bi0)[ri] + (dir ? bh1 : bh0)[ri];
+}
+
 }  // namespace nir
+
+extern "C" int nir_lstm_perm_weights(const float* w_ih_fwd, const float* b_ih_fwd, const float* b_hh_fwd, const float* w_ih_rev, const float* b_ih_rev,
+                                     const float* b_hh_rev, int H, int ndir, int E, float* wperm, float* bperm, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(w_ih_fwd && b_ih_fwd && b_hh_fwd && wperm && bperm && (ndir == 1 || (ndir == 2 && w_ih_rev && b_ih_rev && b_hh_rev)), "lstm_perm_weights: null pointer");
+    NIR_REQUIRE(H > 0 && E > 0, "lstm_perm_weights: bad dims");
+    const int64_t n = (int64_t)ndir * 4 * H * E;
+    hipLaunchKernelGGL(lstm_perm_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_ih_fwd, w_ih_rev, b_ih_fwd, b_hh_fwd,
+                       b_ih_rev, b_hh_rev, H, ndir, E, wperm, bperm);
+    NIR_CHECK_LAUNCH("lstm_perm_weights_kernel");
+    return 0;
+}
+extern "C" int nir_lstm_train_fwd_split(const float* gates_perm, const int64_t* row_ids, const int64_t* lengths, const float* w_hh, float* out, float* act,
+                                        float* cst, int* err_flag, int64_t M, int T, int H, int ndir, nir_stream_t stream) {
+    return nir::launch_lstm_train_split(gates_perm, row_ids, lengths, w_hh, out, act, cst, err_flag, M, T, H, ndir, (hipStream_t)stream);
+}
 
 extern "C" size_t nir_lstm_fold_table_bytes(int64_t V, int H, int ndir, int dtype) {
     if (V <= 0 || H <= 0 || ndir <= 0) return 0;

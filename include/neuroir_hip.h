@@ -576,6 +576,14 @@ int nir_transpose_f32(const float* in, int R, int C, float* out, nir_stream_t st
  * non-linearities) and cst [M,T,ndir,H] (c_t) of every valid step. */
 int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0, float* out,
                        float* act, float* cst, float* hn, float* cn, int64_t M, int T, int H, int ndir, nir_stream_t stream);
+/* The same forward on the split-fp16 matrix-core recurrence (lstm16_pt_h2_kernel<4,4,8,false,true>; H = 128 per direction only -- the fp32-accurate
+ * two-term split of csrc/lstm_fold.hip, 3 fp16 MFMAs per 32-wide k-block for the 32 fp32 ones above): gates_perm [M*T][ndir][H][4] is
+ * x W_ih^T + b_ih + b_hh in the folded gate order (nir_lstm_perm_weights, then one GEMM), row_ids = 0 .. M*T-1 (int64).  out / act / cst as
+ * above (the padded tail of out is zero-filled; act / cst past a sequence's length are not written).  err_flag bit 1: |w_hh| >= 2^15. */
+int nir_lstm_perm_weights(const float* w_ih_fwd, const float* b_ih_fwd, const float* b_hh_fwd, const float* w_ih_rev, const float* b_ih_rev,
+                          const float* b_hh_rev, int H, int ndir, int E, float* wperm /*[ndir*4H, E]*/, float* bperm /*[ndir*4H]*/, nir_stream_t stream);
+int nir_lstm_train_fwd_split(const float* gates_perm, const int64_t* row_ids, const int64_t* lengths, const float* w_hh, float* out, float* act,
+                             float* cst, int* err_flag, int64_t M, int T, int H, int ndir, nir_stream_t stream);
 /* BPTT: dout [M,T,ndir*H] (+ optional dhn/dcn [ndir,M,H] and dcst [M,T,ndir,H], gradients w.r.t. the final state and the stored
  * cell states) -> dgates [M,T,ndir*4H], the gradient w.r.t. gates_in (zero at t >= length), and optionally dh0/dc0.
  * dW_ih / dW_hh / db / dx follow from dgates through the GEMM entry points. */
