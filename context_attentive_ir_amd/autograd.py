@@ -280,6 +280,48 @@ def check_ids():
             raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
 
 
+class _SuggestLossRows(Function):
+    """logits [R,V], target [R] -> (nll [R], ent [R]) of nir_softmax_nll_ent_fwd; the backward writes dlogits in one pass."""
+
+    @staticmethod
+    def forward(ctx, logits, target, pad):
+        lib.require_device(logits)
+        L = lib.load()
+        z = _f32c(logits)
+        R, V = z.shape
+        t = lib.ids64(target).reshape(R).contiguous()
+        nll = torch.empty(R, device=z.device)
+        ent = torch.empty(R, device=z.device)
+        lse = torch.empty(R, device=z.device)
+        lib.check(L.nir_softmax_nll_ent_fwd(lib.ptr(z), V, lib.ptr(t), int(pad), R, V, lib.ptr(nll), lib.ptr(ent), lib.ptr(lse), lib.ptr(id_flag(z.device)),
+                                            lib.stream()), "nir_softmax_nll_ent_fwd")
+        ctx.save_for_backward(z, t, lse, ent)
+        ctx.pad = int(pad)
+        return nll, ent
+
+    @staticmethod
+    def backward(ctx, gnll, gent):
+        z, t, lse, ent = ctx.saved_tensors
+        R, V = z.shape
+        gn = _f32c(gnll) if gnll is not None else torch.zeros(R, device=z.device)
+        ge = _f32c(gent) if gent is not None else None
+        dz = torch.empty_like(z)
+        lib.check(lib.load().nir_softmax_nll_ent_bwd(lib.ptr(z), V, lib.ptr(t), ctx.pad, lib.ptr(lse), lib.ptr(ent), lib.ptr(gn), lib.ptr(ge), R, V, lib.ptr(dz),
+                                                     lib.stream()), "nir_softmax_nll_ent_bwd")
+        return dz, None, None
+
+
+def suggestion_loss(logits, target, pad, regularize_coeff=0.0):
+    """The multitask models' suggestion loss (multitask.py:203-216) from decoder logits [Bd, L, V] and targets [Bd, L]:
+    mean over Bd of sum_L( -log_softmax(logits)[target] * (target != pad) ) (+ regularize_coeff * sum_L sum_V p log p)."""
+    Bd, TL, V = logits.shape
+    nll, ent = _SuggestLossRows.apply(logits.reshape(Bd * TL, V), target.reshape(-1), pad)
+    loss = nll.view(Bd, TL).sum(1).mean()
+    if regularize_coeff > 0:
+        loss = loss + (ent.view(Bd, TL).sum(1) * regularize_coeff).mean()
+    return loss
+
+
 class _Embed(Function):
     @staticmethod
     def forward(ctx, ids, table, pad_idx):

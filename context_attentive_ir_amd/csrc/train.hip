@@ -875,6 +875,74 @@ __global__ void bce_bwd_kernel(const float* __restrict__ s, const float* __restr
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) ds[i] = (1.0f / (1.0f + expf(-s[i])) - y[i]) * gout[0] / (float)n;
 }
+// Suggestion loss rows (neuroir/models/multitask.py:203-216, seq2seq loss): for every decoder row r with logits z [V] and target t,
+//   nll[r] = -(log_softmax z)[t] (0 when t == pad),   ent[r] = sum_v p_v log p_v (the entropy regulariser's row term),   lse[r] = logsumexp z.
+// One workgroup per row, two passes over the row (the second one out of L2): the [rows, V] log-softmax, its exp and their product are never
+// written (the reference's five full-size temporaries: 16 elementwise / reduction launches per step at V = 30 000).
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+    return r;
+}
+__global__ __launch_bounds__(256) void softmax_nll_ent_fwd_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ target, int64_t pad,
+                                                                  int V, float* __restrict__ nll, float* __restrict__ ent, float* __restrict__ lse,
+                                                                  int* err) {
+    __shared__ float red[4];
+    const float* zr = z + (int64_t)blockIdx.x * ld;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmaxf(m, zr[v]);
+    m = block_reduce(m, red, true);
+    float s = 0.f, q = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float d = zr[v] - m, e = __expf(d);
+        s += e;
+        q = fmaf(e, d, q);
+    }
+    s = block_reduce(s, red, false);
+    q = block_reduce(q, red, false);
+    if (threadIdx.x == 0) {
+        const float ls = __logf(s);
+        const int64_t t = target[blockIdx.x];
+        const bool ok = t >= 0 && t < V;
+        if (!ok && err) atomicOr(err, 1);
+        lse[blockIdx.x] = m + ls;
+        ent[blockIdx.x] = q / s - ls;
+        nll[blockIdx.x] = (ok && t != pad) ? (m + ls) - zr[t] : 0.f;
+    }
+}
+// dz[r, v] = p_v (ga + gb (log p_v - ent[r])) - ga [v == t],   ga = gnll[r] (0 for a pad target), gb = gent[r]
+__global__ __launch_bounds__(256) void softmax_nll_ent_bwd_kernel(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ target, int64_t pad,
+                                                                  const float* __restrict__ lse, const float* __restrict__ ent,
+                                                                  const float* __restrict__ gnll, const float* __restrict__ gent, int V,
+                                                                  float* __restrict__ dz) {
+    const int64_t r = blockIdx.y;
+    const int64_t t = target[r];
+    const float ga = (t != pad && t >= 0 && t < V) ? gnll[r] : 0.f, gb = gent ? gent[r] : 0.f;
+    const float l = lse[r], e0 = ent[r];
+    const float* zr = z + r * ld;
+    float* dr = dz + r * (int64_t)V;
+    const int v = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (v + 3 < V && (ld & 3) == 0 && (V & 3) == 0) {
+        const float4 x = *reinterpret_cast<const float4*>(zr + v);
+        float4 o;
+        float lp = x.x - l; o.x = __expf(lp) * fmaf(gb, lp - e0, ga);
+        lp = x.y - l; o.y = __expf(lp) * fmaf(gb, lp - e0, ga);
+        lp = x.z - l; o.z = __expf(lp) * fmaf(gb, lp - e0, ga);
+        lp = x.w - l; o.w = __expf(lp) * fmaf(gb, lp - e0, ga);
+        if (t >= v && t < v + 4) (&o.x)[t - v] -= ga;
+        *reinterpret_cast<float4*>(dr + v) = o;
+    } else {
+        for (int j = v; j < min(V, v + 4); ++j) {
+            const float lp = zr[j] - l;
+            dr[j] = __expf(lp) * fmaf(gb, lp - e0, ga) - (j == t ? ga : 0.f);
+        }
+    }
+}
 // embedding lookup: out[m,:] = table[ids[m],:]  (optionally with an inverted-dropout keep mask that is also returned)
 __global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table, int64_t V, int E, int64_t M, float* __restrict__ out,
                              int* err) {
@@ -1256,6 +1324,25 @@ extern "C" int nir_rank_loss_bce_bwd(const float* scores, const float* labels, c
     if (n == 0) return 0;
     hipLaunchKernelGGL(bce_bwd_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, scores, labels, grad_out, dscores, n);
     NIR_CHECK_LAUNCH("bce_bwd_kernel");
+    return 0;
+}
+extern "C" int nir_softmax_nll_ent_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t pad, int64_t R, int V, float* nll, float* ent,
+                                       float* lse, int* err_flag, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(logits && target && nll && ent && lse && R >= 0 && V > 0 && ld >= V, "softmax_nll_ent_fwd: bad args");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(softmax_nll_ent_fwd_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, target, pad, V, nll, ent, lse, err_flag);
+    NIR_CHECK_LAUNCH("softmax_nll_ent_fwd_kernel");
+    return 0;
+}
+extern "C" int nir_softmax_nll_ent_bwd(const float* logits, int64_t ld, const int64_t* target, int64_t pad, const float* lse, const float* ent,
+                                       const float* grad_nll, const float* grad_ent, int64_t R, int V, float* dlogits, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(logits && target && lse && ent && grad_nll && dlogits && R >= 0 && R < 65536 && V > 0 && ld >= V, "softmax_nll_ent_bwd: bad args (rows < 65536)");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(softmax_nll_ent_bwd_kernel, dim3((unsigned)((V + 1023) / 1024), (unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, target, pad,
+                       lse, ent, grad_nll, grad_ent, V, dlogits);
+    NIR_CHECK_LAUNCH("softmax_nll_ent_bwd_kernel");
     return 0;
 }
 extern "C" int nir_embed_f32(const int64_t* ids, const float* table, int64_t V, int E, int64_t M, float* out, int* err_flag, nir_stream_t stream) {

@@ -592,13 +592,7 @@ class CARS(nn.Module, lib.IdCheck):
             po = A.linear(dec_out, self.token_prob_predictor1.weight)
             sess = self._proj(self.shared_session_projector, cs) + self._proj(self.private_session_projector2, cs)
             po = A.dropout(po + sess.unsqueeze(1), p, True)
-            logll = torch.log_softmax(A.linear(po, self.token_prob_predictor2.weight), -1)
-            target = tseq[:, 1:]
-            ml = -logll.gather(2, target.unsqueeze(2)).squeeze(2) * (target != PAD).float()
-            loss = ml.sum(1).mean()
-            if self.regularize_coeff > 0:
-                loss = loss + ((logll.exp() * logll).sum(2) * self.regularize_coeff).sum(1).mean()
-            out["suggestion_loss"] = loss
+            out["suggestion_loss"] = A.suggestion_loss(A.linear(po, self.token_prob_predictor2.weight), tseq[:, 1:], PAD, self.regularize_coeff)
             _ = TL
         if not self.no_ranker and not self.no_recommender:
             if q_on and d_on:

@@ -91,10 +91,6 @@ def suggestion_loss(model, h_steps, c_steps, target_rep, target_seq):
     emb = A.dropout(A.embed(tgt, model.embedder.word_embeddings.table), model.embedder.dropout.p, True)
     h_all, _ = A.lstm_seq(emb, model.decoder.decoder.rnn, dec_h, dec_c)                  # [Bd,TL,HS]
     h_all = A.dropout(h_all, model.dec_dropout_p, True)                                   # RNNDecoder's own dropout (dropout_rnn)
-    logll = torch.log_softmax(A.linear(h_all, model.generator.weight, model.generator.bias)[:, :-1], -1)
-    target = seq[:, 1:]
-    nll = -logll.gather(2, target.unsqueeze(2)).squeeze(2) * target.ne(PAD).float()
-    loss = nll.sum(1).mean()
-    if model.regularize_coeff > 0:
-        loss = loss + ((logll.exp() * logll).sum(2) * model.regularize_coeff).sum(1).mean()
-    return loss
+    # (the last step's logits feed nothing: sliced off in front of the generator)
+    logits = A.linear(h_all[:, :-1], model.generator.weight, model.generator.bias)
+    return A.suggestion_loss(logits, seq[:, 1:], PAD, model.regularize_coeff)

@@ -612,6 +612,14 @@ int nir_col2im_rows_f32(const float* drows, int64_t M, int C, int H, int W, int 
 int nir_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int act, nir_stream_t stream);
 /* dscores = (sigmoid(scores) - labels) * grad_out[0] / n   (backward of nir_rank_loss_bce) */
 int nir_rank_loss_bce_bwd(const float* scores, const float* labels, const float* grad_out, float* dscores, int64_t n, nir_stream_t stream);
+/* Suggestion-loss rows of the multitask models (neuroir/models/multitask.py:203-216; seq2seq NLL + entropy regulariser): per decoder row r with
+ * logits z [V] (row stride ld) and target t:  nll[r] = -(log_softmax z)[t] (0 for t == pad), ent[r] = sum_v p_v log p_v, lse[r] = logsumexp z --
+ * the [rows, V] log-softmax / exp / product tensors of the reference are never formed.  Backward: dlogits [R, V] (dense) =
+ * p (grad_nll + grad_ent (log p - ent)) - grad_nll [v == t]; grad_ent may be NULL.  err_flag bit 0: a target outside [0, V). */
+int nir_softmax_nll_ent_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t pad, int64_t R, int V, float* nll, float* ent,
+                            float* lse, int* err_flag, nir_stream_t stream);
+int nir_softmax_nll_ent_bwd(const float* logits, int64_t ld, const int64_t* target, int64_t pad, const float* lse, const float* ent,
+                            const float* grad_nll, const float* grad_ent, int64_t R, int V, float* dlogits, nir_stream_t stream);
 /* Embedding lookup out[m,:] = table[ids[m],:] (train mode materialises it: the weight-gradient GEMMs need x) and its backward
  * (scatter-add, PAD row excluded like nn.Embedding(padding_idx)). */
 int nir_embed_f32(const int64_t* ids, const float* table, int64_t V, int E, int64_t M, float* out, int* err_flag, nir_stream_t stream);

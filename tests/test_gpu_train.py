@@ -117,6 +117,25 @@ def test_wgrad_over_a_row_list(R, N, K, frac):
     _rel(dw, (dy[r].double().t() @ x[r - 1].double()).float()); _rel(db, dy[:R].double().sum(0).float())
 
 
+@pytest.mark.parametrize("Bd,TL,V,coeff", [(3, 4, 50, 0.1), (6, 5, 30000, 0.1), (2, 3, 1023, 0.0), (5, 2, 4097, 0.5)])
+def test_suggestion_loss_matches_log_softmax_formulation(Bd, TL, V, coeff):
+    """A.suggestion_loss (nir_softmax_nll_ent_fwd / _bwd) against the reference's formulation in torch ops (multitask.py:203-216)."""
+    from context_attentive_ir_amd import autograd as A
+    g = torch.Generator().manual_seed(V)
+    z = (torch.randn(Bd, TL, V, generator=g) * 3).requires_grad_(True)
+    t = torch.randint(1, V, (Bd, TL), generator=g); t[0, -1] = 0; t[-1, 0] = 0          # PAD = 0 targets
+    logll = torch.log_softmax(z.double(), -1)
+    ref = (-logll.gather(2, t.unsqueeze(2)).squeeze(2) * t.ne(0).double()).sum(1).mean()
+    if coeff > 0:
+        ref = ref + ((logll.exp() * logll).sum(2) * coeff).sum(1).mean()
+    ref.backward()
+    zd = z.detach().to(DEV).requires_grad_(True)
+    out = A.suggestion_loss(zd, t.to(DEV), 0, coeff)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    _rel(zd.grad, z.grad.float(), 2e-5)
+
+
 def test_embed_backward_skips_pad_and_accumulates():
     from context_attentive_ir_amd import autograd as A
     V, E = 30, 8
