@@ -1742,6 +1742,8 @@ def train_record(kind, c, args, env, steps=12):
                           mfma_frac=round(tf / work["pipe"], 5))
             rec["roofline"] = rf
             rec["top_kernels_ms_per_step"] = {k: round(v[1] / 4, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:6]}
+            if os.environ.get("BENCH_TRAIN_ALL_KERNELS"):          # every library launch label of the step: [launches per step, ms per step]
+                rec["hip_kernels_per_step"] = {k: [round(v[0] / 4, 2), round(v[1] / 4, 4)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}
         return rec
     except Exception as e:  # pragma: no cover
         return {"error": "%s: %s" % (type(e).__name__, e)}

@@ -52,7 +52,7 @@ __device__ __forceinline__ bool wgrad_skip(const WgradArgs& p, int64_t row) {
 __device__ __forceinline__ void wgrad_range(const WgradArgs& p, int64_t slice, int64_t& ms, int64_t& me) {
     if (p.mcount) {
         const int64_t Mt = min((int64_t)*p.mcount, p.M);
-        const int64_t msl = ((Mt + p.slices - 1) / p.slices + 15) / 16 * 16;
+        const int64_t msl = ((Mt + p.slices - 1) / p.slices + 31) / 32 * 32;
         ms = slice * msl; me = min(Mt, ms + msl);
     } else {
         ms = slice * p.mslice; me = min(p.M, ms + p.mslice);
@@ -61,7 +61,9 @@ __device__ __forceinline__ void wgrad_range(const WgradArgs& p, int64_t slice, i
 
 // NB x KB register blocking: a wave owns a (32 NB) x (32 KB) tile of dW -- NB + KB operand values per lane and m for NB KB MFMAs (the 1 x 1
 // form loads two values per MFMA and was load-bound: 0.26 of the fp32 pipe on the [71680] x [1024, 300] gradient of the CARS input projection)
-template <int NB, int KB>
+// RB row pairs per iteration (2 RB reduction rows): the small gradients of a step (M of a few hundred rows, one slice or a few) are bound by the
+// load -> MFMA round trip of each iteration, not by bandwidth -- 1 x 1 blocking takes 32 rows per trip (32 loads in flight per lane)
+template <int NB, int KB, int RB = 8>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt = (p.N + 32 * NB - 1) / (32 * NB), kt = (p.K + 32 * KB - 1) / (32 * KB);
@@ -95,10 +97,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     float bs[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) bs[i] = 0.f;
-    for (int64_t m = ms; m < me; m += 16) {
-        float a[NB][8], b[KB][8];
+    for (int64_t m = ms; m < me; m += 2 * RB) {
+        float a[NB][RB], b[KB][RB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < RB; ++u) {
             const int64_t mm = m + 2 * u + half;
             const bool mv = mm < me;
             int64_t mc = mv ? mm : ms;                                           // clamped row, masked value: no predicated loads
@@ -112,14 +114,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
             for (int j = 0; j < KB; ++j) b[j][u] = (mv && kv[j] && !xs) ? xr[k[j]] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < RB; ++u)
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = 0; j < KB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
         if (do_db) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bs[i] += ((a[i][0] + a[i][1]) + (a[i][2] + a[i][3])) + ((a[i][4] + a[i][5]) + (a[i][6] + a[i][7]));
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int u = 0; u < RB; u += 4) bs[i] += (a[i][u] + a[i][u + 1]) + (a[i][u + 2] + a[i][u + 3]);
         }
     }
     if (do_db) {                                        // lanes l and l + 32 hold the even / odd rows of column n
@@ -1117,7 +1121,7 @@ static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx
     }
     // LDS-staged workgroup tiles for the big gradients (float4 rows: widths, strides and bases in units of 16 bytes)
     const int64_t xstride = ids ? (int64_t)E : ldx;
-    const bool lds_ok = M >= 32768 && N >= 128 && K >= 128 && N % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && xstride % 4 == 0 &&
+    const bool lds_ok = (M >= 32768 || (M >= 256 && (int64_t)((N + 127) / 128) * ((K + 127) / 128) >= (tun(g_tun.wgrad_lds_tiles) > 0 ? tun(g_tun.wgrad_lds_tiles) : 192))) && N >= 128 && K >= 128 && N % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && xstride % 4 == 0 &&
                         ((uintptr_t)dy & 15) == 0 && ((uintptr_t)(ids ? table : x) & 15) == 0 && !tun(g_tun.wgrad_no_lds);
     if (lds_ok) {
         int wk = 2;                                                    // K tile of 64 wk columns: least padding, then the widest
@@ -1145,11 +1149,13 @@ static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx
         return 0;
     }
     // 2 x 2 blocking once there is enough work for it to pay (big M) and the tile is not mostly padding
-    const bool big = M >= 4096 && N >= 64 && K >= 64;
+    const bool big = M >= 4096 && N >= 64 && K >= 64;      // (small M with a big N x K: measured slower than 1 x 1 with 64-row slices)
     const int nb = big ? 2 : 1, kb = big ? 2 : 1;
     const int64_t tiles = (int64_t)((N + 32 * nb - 1) / (32 * nb)) * ((K + 32 * kb - 1) / (32 * kb));
-    int64_t slices = std::max<int64_t>(1, std::min<int64_t>((M + 255) / 256, (4096 + tiles - 1) / tiles));
-    const int64_t mslice = ((M + slices - 1) / slices + 15) / 16 * 16;
+    // slices of >= 256 rows (big M) / >= 64 rows (1 x 1: a slice is then two to eight load -> MFMA round trips), as many as fill the chip
+    const int64_t minrows = (big && M >= 4096) ? 256 : std::max(32, tun(g_tun.wgrad_min_rows) > 0 ? tun(g_tun.wgrad_min_rows) : 64);
+    int64_t slices = std::max<int64_t>(1, std::min<int64_t>((M + minrows - 1) / minrows, (4096 + tiles - 1) / tiles));
+    const int64_t mslice = ((M + slices - 1) / slices + 31) / 32 * 32;
     slices = (M + mslice - 1) / mslice;
     const int store = set && slices == 1;
     if (set && !store) NIR_PROPAGATE((int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st));
@@ -1157,7 +1163,7 @@ static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx
     WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store, db, rl.rows, rl.mcount, rl.dyd, rl.xd, (int)slices, rl.period > 1 ? (unsigned)((((uint64_t)1 << 32) + rl.period - 1) / rl.period) : 0u, rl.period, rl.skip};
     ProfScope ps(prof_shape_name("wgrad_kernel", M, N, K), st);
     if (big) hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<1, 1>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 1, 16>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
     NIR_CHECK_LAUNCH("wgrad_kernel");
     return 0;
 }

@@ -35,6 +35,8 @@ def run(L, dy, x, db, set_=True, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="71680x1024x300,71680x512x128,8960x1024x300,20000x256x512,4480x768x256")
+    ap.add_argument("--tiles", type=int, default=0, help="tunable wgrad_lds_tiles: LDS kernel for M >= 256 once the dW has this many 128 x 128 tiles")
+    ap.add_argument("--min-rows", type=int, default=0)
     a = ap.parse_args()
     L = lib.load()
     for sh in a.shapes.split(","):
@@ -45,6 +47,8 @@ def main():
         ref = (dy.double().t() @ x.double())
         refb = dy.double().sum(0)
         rec = {"shape": sh, "gflop": 2e-9 * M * N * K}
+        L.nir_debug_set_tunable(b"wgrad_lds_tiles", a.tiles)
+        L.nir_debug_set_tunable(b"wgrad_min_rows", a.min_rows)
         for name, flag in (("lds", 0), ("regs", 1)):
             L.nir_debug_set_tunable(b"wgrad_no_lds", flag)
             db = torch.empty(N, device="cuda")
