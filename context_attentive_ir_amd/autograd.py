@@ -260,6 +260,64 @@ def im2col_rows(x, kernel_size, padding):
     return _Im2colRows.apply(x, int(kh), int(kw), int(ph), int(pw))
 
 
+class _MTConv3(Function):
+    """relu(conv3x3 | conv3x5 | conv3x7)(T) as feature rows [M*H*W, 3*NF] -- the direct-convolution kernels of csrc/mt_conv_train.hip."""
+
+    @staticmethod
+    def forward(ctx, T, w1, b1, w2, b2, w3, b3):
+        lib.require_device(T, w1)
+        L = lib.load()
+        Tc = _f32c(T)
+        M, C1, H, W = Tc.shape
+        NF = w1.shape[0]
+        ws = [_f32c(t) for t in (w1, b1, w2, b2, w3, b3)]
+        out = torch.empty(M * H * W, 3 * NF, device=Tc.device, dtype=torch.float32)
+        lib.check(L.nir_mt_conv3_fwd(lib.ptr(Tc), *[lib.ptr(t) for t in ws], M, C1, H, W, NF, lib.ptr(out), lib.stream()), "nir_mt_conv3_fwd")
+        ctx.save_for_backward(Tc, ws[0], ws[2], ws[4], out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Tc, w1, w2, w3, out = ctx.saved_tensors
+        L = lib.load()
+        M, C1, H, W = Tc.shape
+        NF = w1.shape[0]
+        d = _f32c(dout)
+        dpre = torch.empty_like(d)
+        lib.check(L.nir_act_bwd_f32(lib.ptr(d), lib.ptr(out), lib.ptr(dpre), d.numel(), 2, lib.stream()), "nir_act_bwd_f32")
+        dev = d.device
+        need_w = any(ctx.needs_input_grad[1:])
+        dT = torch.empty_like(Tc) if ctx.needs_input_grad[0] else None
+        wt = torch.empty(L.nir_mt_conv3_wt_floats(C1, NF), device=dev) if dT is not None else None
+        part = torch.empty(M, NF * C1 * 45, device=dev) if need_w else None
+        lib.check(L.nir_mt_conv3_bwd(lib.ptr(dpre), lib.ptr(Tc), lib.ptr(w1), lib.ptr(w2), lib.ptr(w3), M, C1, H, W, NF, lib.ptr(dT), lib.ptr(wt), lib.ptr(part),
+                                     lib.stream()), "nir_mt_conv3_bwd")
+        grads = [None] * 6
+        if need_w:
+            dw = _colsum(part, part.shape[1], M, part.shape[1])
+            db = _colsum(dpre, 3 * NF, dpre.shape[0], 3 * NF)
+            o = 0
+            for g, w in enumerate((w1, w2, w3)):
+                n = w.numel()
+                grads[2 * g] = dw[o:o + n].view_as(w)
+                grads[2 * g + 1] = db[g * NF:(g + 1) * NF]
+                o += n
+        return (dT,) + tuple(grads)
+
+
+def mt_conv3_supported(T, conv1, conv2, conv3):
+    """the three MatchTensor convolutions in their reference shapes ((3,3)/(3,5)/(3,7), 'same' padding, NF = 6 filters over 51 channels)?"""
+    ks = [(3, 3), (3, 5), (3, 7)]
+    ok = all(tuple(c.kernel_size) == k and tuple(c.padding) == (1, k[1] // 2) and tuple(c.stride) == (1, 1) and c.bias is not None
+             for c, k in zip((conv1, conv2, conv3), ks))
+    ok = ok and conv1.out_channels == conv2.out_channels == conv3.out_channels and T.is_cuda
+    return bool(ok and lib.load().nir_mt_conv3_supported(conv1.out_channels, T.shape[1], T.shape[2], T.shape[3]))
+
+
+def mt_conv3(T, conv1, conv2, conv3):
+    return _MTConv3.apply(T, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight, conv3.bias)
+
+
 def id_flag(device):
     """device int32 flag the train-mode lookups set for an id outside [0, V) (the reference's nn.Embedding raises IndexError)"""
     f = _ID_FLAGS.get(str(device))

@@ -154,6 +154,11 @@ SIGNATURES = {
     "nir_mask_scale_f32": (_i, [c_fp, C.c_void_p, C.c_float, c_fp, _l, c_st]),
     "nir_act_bwd_f32": (_i, [c_fp, c_fp, c_fp, _l, _i, c_st]),
     "nir_im2col_rows_f32": (_i, [c_fp, _l, _i, _i, _i, _i, _i, _i, _i, c_fp, c_st]),
+    "nir_mt_conv3_supported": (_i, [_i, _i, _i, _i]),
+    "nir_mt_conv3_fwd": (_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, _i, c_fp, c_st]),
+    "nir_mt_conv3_wt_floats": (C.c_size_t, [_i, _i]),
+    "nir_mt_conv3_partial_floats": (C.c_size_t, [_l, _i, _i]),
+    "nir_mt_conv3_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, _i, c_fp, c_fp, c_fp, c_st]),
     "nir_col2im_rows_f32": (_i, [c_fp, _l, _i, _i, _i, _i, _i, _i, _i, c_fp, c_st]),
     "nir_rank_loss_bce_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, _l, c_st]),
     "nir_softmax_nll_ent_fwd": (_i, [c_fp, _l, c_ip, _l, _l, _i, c_fp, c_fp, c_fp, C.c_void_p, c_st]),

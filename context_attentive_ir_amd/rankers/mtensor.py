@@ -66,7 +66,10 @@ def train_head(mod, q, d, pq, pd):
     em = em * mod.exact_match_channel.alpha
     T = torch.cat((prod, em.unsqueeze(3)), 3).permute(0, 3, 1, 2).contiguous()            # [M,C+1,QL,DL]
     feats = []
-    for conv in (mod.conv1, mod.conv2, mod.conv3):
+    if A.mt_conv3_supported(T, mod.conv1, mod.conv2, mod.conv3):
+        # direct convolutions, forward and backward (csrc/mt_conv_train.hip): no [M QL DL, C kh kw] patch rows, ReLU and the concatenation fused
+        feats = [A.mt_conv3(T, mod.conv1, mod.conv2, mod.conv3)]
+    for conv in (() if feats else (mod.conv1, mod.conv2, mod.conv3)):
         kh, kw = conv.kernel_size
         if 2 * conv.padding[0] == kh - 1 and 2 * conv.padding[1] == kw - 1 and DL * (kw | 1) * 4 <= 65536:      # (the kernel pads its LDS rows to an odd stride)
             rows = A.im2col_rows(T, (kh, kw), conv.padding)                                # [M*QL*DL,(C+1)*kh*kw], one launch (HIP)
@@ -74,7 +77,7 @@ def train_head(mod, q, d, pq, pd):
             cols = F.unfold(T, (kh, kw), padding=conv.padding)                             # [M,(C+1)*kh*kw,QL*DL]
             rows = cols.transpose(1, 2).reshape(M * QL * DL, -1)
         feats.append(A.linear(rows, conv.weight.reshape(conv.out_channels, -1), conv.bias, act="relu"))
-    g = A.linear(torch.cat(feats, 1), mod.conv.weight.reshape(mod.conv.out_channels, -1), mod.conv.bias)
+    g = A.linear(feats[0] if len(feats) == 1 else torch.cat(feats, 1), mod.conv.weight.reshape(mod.conv.out_channels, -1), mod.conv.bias)
     g = g.view(M, QL * DL, -1).max(1)[0]
     return A.linear(g, mod.output.weight, mod.output.bias).view(B, N)
 

@@ -607,6 +607,21 @@ int nir_mask_scale_f32(const float* x, const unsigned char* keep, float scale, f
  * [M, C, QL, DL] match tensor): out[(m, y, x)][(c, dy, dx)] = in[m, c, y+dy-ph, x+dx-pw] (0 outside), stride 1, 2 ph = kh-1, 2 pw = kw-1
  * -- the A operand [M H W, C kh kw] of the filter GEMM in one launch; and its backward, din[M, C, H, W] from drows (no atomics on HBM). */
 int nir_im2col_rows_f32(const float* in, int64_t M, int C, int H, int W, int kh, int kw, int ph, int pw, float* out, nir_stream_t stream);
+/* The three parallel Conv2d(C1 -> NF, (3,3) / (3,5) / (3,7), 'same') + ReLU of the MatchTensor head (neuroir/rankers/mtensor.py:108-121) as DIRECT
+ * convolutions for the training step -- no patch matrix (csrc/mt_conv_train.hip).  T [M, C1, H, W]; w_g [NF, C1, 3, 3 + 2 g] / b_g [NF] in their
+ * nn.Conv2d layouts; out [M H W, 3 NF] = relu of the three outputs side by side (the rows the 1x1 convolution reads).
+ * nir_mt_conv3_supported: 1 when the shape is served (NF = 6, C1 = 51 -- the reference's defaults -- and one sample's tiles fit LDS); callers fall
+ * back to nir_im2col_rows_f32 + the GEMMs otherwise.
+ * nir_mt_conv3_bwd: dpre [M H W, 3 NF] = gradient of the PRE-activation (dout * (out > 0));  dT [M, C1, H, W] (optional; needs a workspace of
+ * nir_mt_conv3_wt_floats() floats);  partial [M, NF C1 45] (optional) = per-sample weight-gradient sums with the three filters' gradients back to
+ * back in their own layouts -- the column sum over M (nir_colsum_set_f32) is the gradient, without atomics. */
+int nir_mt_conv3_supported(int NF, int C1, int H, int W);
+int nir_mt_conv3_fwd(const float* T, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                     int64_t M, int C1, int H, int W, int NF, float* out, nir_stream_t stream);
+size_t nir_mt_conv3_wt_floats(int C1, int NF);
+size_t nir_mt_conv3_partial_floats(int64_t M, int C1, int NF);
+int nir_mt_conv3_bwd(const float* dpre, const float* T, const float* w1, const float* w2, const float* w3, int64_t M, int C1, int H, int W, int NF,
+                     float* dT, float* wt_workspace, float* partial, nir_stream_t stream);
 int nir_col2im_rows_f32(const float* drows, int64_t M, int C, int H, int W, int kh, int kw, int ph, int pw, float* din, nir_stream_t stream);
 /* dx = dy * f'(.) expressed through y = f(x): act 1 tanh, 2 relu, 3 sigmoid. */
 int nir_act_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, int act, nir_stream_t stream);

@@ -136,6 +136,34 @@ def test_suggestion_loss_matches_log_softmax_formulation(Bd, TL, V, coeff):
     _rel(zd.grad, z.grad.float(), 2e-5)
 
 
+@pytest.mark.parametrize("M,H,W", [(3, 4, 16), (2, 4, 64), (5, 2, 33), (1, 1, 5)])
+def test_mt_conv3_direct_convolutions_match_conv2d(M, H, W):
+    """A.mt_conv3 (nir_mt_conv3_fwd / _bwd): relu(conv3x3 | 3x5 | 3x7) feature rows, data and filter gradients against torch's Conv2d on the CPU."""
+    from context_attentive_ir_amd import autograd as A
+    g = torch.Generator().manual_seed(W)
+    C1, NF = 51, 6
+    convs = [torch.nn.Conv2d(C1, NF, (3, k), padding=(1, k // 2)) for k in (3, 5, 7)]
+    for c in convs:
+        for p_ in c.parameters():
+            p_.data = torch.randn(p_.shape, generator=g) * 0.2
+    T0 = torch.randn(M, C1, H, W, generator=g)
+    dout = torch.randn(M * H * W, 3 * NF, generator=g)
+    Tr = T0.clone().requires_grad_(True)
+    ref = torch.cat([torch.relu(c(Tr)).permute(0, 2, 3, 1).reshape(M * H * W, NF) for c in convs], 1)
+    ref.backward(dout)
+    import copy
+    dconvs = [copy.deepcopy(c).to(DEV) for c in convs]
+    for c in dconvs:
+        c.zero_grad()
+    Td = T0.to(DEV).requires_grad_(True)
+    assert A.mt_conv3_supported(Td, *dconvs)
+    out = A.mt_conv3(Td, *dconvs)
+    out.backward(dout.to(DEV))
+    _rel(out, ref, 2e-5); _rel(Td.grad, Tr.grad)
+    for c, d in zip(convs, dconvs):
+        _rel(d.weight.grad, c.weight.grad); _rel(d.bias.grad, c.bias.grad)
+
+
 def test_embed_backward_skips_pad_and_accumulates():
     from context_attentive_ir_amd import autograd as A
     V, E = 30, 8
