@@ -130,7 +130,7 @@ class StepScope(object):
 
 
 STEP = StepScope()
-SPLIT_TRAIN_FWD = True     # _BiLSTM.forward at H = 128: the split-fp16 matrix-core recurrence (False: the fp32 MFMA one, any H <= 128)
+SPLIT_TRAIN_FWD = True     # _BiLSTM.forward at 64 < H <= 128: the split-fp16 matrix-core recurrence (False: the fp32 MFMA one, any H <= 128)
 PACKED_WGRAD = False       # _BiLSTM.backward: reduce the weight gradients over a list of the valid (t < length) positions only
 
 
@@ -289,12 +289,13 @@ class _MTConv3(Function):
         need_w = any(ctx.needs_input_grad[1:])
         dT = torch.empty_like(Tc) if ctx.needs_input_grad[0] else None
         wt = torch.empty(L.nir_mt_conv3_wt_floats(C1, NF), device=dev) if dT is not None else None
-        part = torch.empty(M, NF * C1 * 45, device=dev) if need_w else None
+        NW = NF * C1 * 45
+        part = torch.empty(L.nir_mt_conv3_partial_floats(M, C1, NF) // NW, NW, device=dev) if need_w else None
         lib.check(L.nir_mt_conv3_bwd(lib.ptr(dpre), lib.ptr(Tc), lib.ptr(w1), lib.ptr(w2), lib.ptr(w3), M, C1, H, W, NF, lib.ptr(dT), lib.ptr(wt), lib.ptr(part),
                                      lib.stream()), "nir_mt_conv3_bwd")
         grads = [None] * 6
         if need_w:
-            dw = _colsum(part, part.shape[1], M, part.shape[1])
+            dw = _colsum(part, NW, part.shape[0], NW)
             db = _colsum(dpre, 3 * NF, dpre.shape[0], 3 * NF)
             o = 0
             for g, w in enumerate((w1, w2, w3)):
@@ -513,7 +514,7 @@ class _BiLSTM(Function):
         lens64 = lib.ids64(lens) if lens is not None else None
         h0c = _f32c(h0) if h0 is not None else None
         c0c = _f32c(c0) if c0 is not None else None
-        if SPLIT_TRAIN_FWD and H == 128 and h0 is None and M * T >= 16 and T <= 512:
+        if SPLIT_TRAIN_FWD and 64 < H <= 128 and h0 is None and M * T >= 16 and T <= 512:
             # the fp32-accurate split-fp16 recurrence of the inference path with train-mode stores (3 fp16 MFMAs per k-block for 32 fp32 ones):
             # the input GEMM writes the gates in the folded order [row][dir][unit][gate] (weights permuted once per step), rows are their own ids
             ps = [_f32c(t) for t in params]

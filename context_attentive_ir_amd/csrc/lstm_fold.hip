@@ -534,7 +534,7 @@ __device__ unsigned long long* g_pt_trace_dev;
 // backward needs i, f, g, o themselves, not the merged fractions of lstm_cell_v).
 template <int KB, int NT, int NW, bool H1 = false, bool TR = false>
 __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(LstmPtArgs p) {   // (second argument: waves per SIMD)
-    static_assert(!TR || (NT == 4 && !H1), "train-mode stores: four consecutive units per lane");
+    static_assert(!TR || !H1, "train-mode stores go with the fp32 output");
     constexpr int NTH = 64 * NW;
     constexpr int SEQ = 16, KP = 32 * KB, ZLD = KP + 8;     // fp16 elements per h row
     constexpr uint32_t OOB = 0x7FFFFFF0u;
@@ -924,13 +924,30 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         soff += sstep;
 #ifndef NIR_X_NOGATES
         if constexpr (TR) {                        // (younger than the row requests of this step: the wait at the top of the next one does not cover them)
-            const uint32_t ao = (live && full) ? aoff : OOB;
+            const uint32_t ao = live ? aoff : OOB;
+            if (NT == 4 && full) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(tga[0][r]), __float_as_uint(tga[1 % NT][r]), __float_as_uint(tga[2 % NT][r]),
-                                                               __float_as_uint(tga[3 % NT][r])}, act_rs, ao == OOB ? OOB : ao + (uint32_t)(r * H * 4), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(creg[0]), __float_as_uint(creg[1 % NT]), __float_as_uint(creg[2 % NT]),
-                                                           __float_as_uint(creg[3 % NT])}, cst_rs, full ? poff : OOB, 0, 0);
+                for (int r = 0; r < 4; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(tga[0][r]), __float_as_uint(tga[1 % NT][r]), __float_as_uint(tga[2 % NT][r]),
+                                                                   __float_as_uint(tga[3 % NT][r])}, act_rs, ao == OOB ? OOB : ao + (uint32_t)(r * H * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(creg[0]), __float_as_uint(creg[1 % NT]), __float_as_uint(creg[2 % NT]),
+                                                               __float_as_uint(creg[3 % NT])}, cst_rs, poff, 0, 0);
+            } else if (NT == 2 && full) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(tga[0][r]), __float_as_uint(tga[1 % NT][r])}, act_rs,
+                                                          ao == OOB ? OOB : ao + (uint32_t)(r * H * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(creg[0]), __float_as_uint(creg[1 % NT])}, cst_rs, poff, 0, 0);
+            } else {                               // unit by unit (lanes that straddle H, other tile counts)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bool uv = u0 + t < H && ao != OOB;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tga[t][r]), act_rs, uv ? ao + (uint32_t)((r * H + t) * 4) : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(creg[t]), cst_rs, uv ? poff + 4u * t : OOB, 0, 0);
+                }
+            }
             aoff += astep;
         }
 #endif
@@ -1313,15 +1330,16 @@ int launch_bilstm_folded(const void* pt, int pt_dtype, const int64_t* ids, const
     }
 }
 
-// Train-mode forward on the split-fp16 recurrence (H = 128 per direction): gates_perm [M*T][ND][H][4] = x W_ih^T + b in the folded gate order
+// Train-mode forward on the split-fp16 recurrence (64 < H <= 128 per direction): gates_perm [M*T][ND][H][4] = x W_ih^T + b in the folded gate order
 // (nir_lstm_perm_weights + one GEMM), row_ids = 0 .. M*T-1.  3 fp16 MFMAs per k-block instead of the 32 fp32 ones of lstm_mfma16_gin_kernel.
 int launch_lstm_train_split(const float* gates_perm, const int64_t* row_ids, const int64_t* lens, const float* whh, float* out, float* act, float* cst,
                             int* err, int64_t M, int T, int H, int ND, hipStream_t st) {
     NIR_REQUIRE(gates_perm && row_ids && whh && out && act && cst, "lstm_train_fwd_split: null pointer");
-    NIR_REQUIRE(M >= 0 && T > 0 && T <= 512 && (ND == 1 || ND == 2) && H == 128, "lstm_train_fwd_split: bad dims (H = 128 per direction, T <= 512)");
+    NIR_REQUIRE(M >= 0 && T > 0 && T <= 512 && (ND == 1 || ND == 2) && H > 64 && H <= 128, "lstm_train_fwd_split: bad dims (64 < H <= 128 per direction, T <= 512)");
     NIR_REQUIRE((int64_t)16 * T * ND * H * 16 < 0x7FFFFFF0LL, "lstm_train_fwd_split: T too large for 32-bit tile offsets");
     if (M == 0) return 0;
     LstmPtArgs p{gates_perm, row_ids, lens, whh, out, err, M, M * (int64_t)T, T, H, ND, 0, nullptr, act, cst};
+    if (H <= 96) return launch_pt_h2<3, 2, 16, false, true>(p, st);        // (MatchTensor's H = 70)
     return launch_pt_h2<4, 4, 8, false, true>(p, st);
 }
 

@@ -31,18 +31,22 @@ struct MtConvArgs {
 // forward: one thread per position (m, y, x), 3 NF accumulators; per input channel the 3 x 7 window is read once (the 3x3 and 3x5
 // filters see its middle columns) and meets the channel's 45 NF taps from SGPRs
 // ---------------------------------------------------------------------------------------------------------------------
+// blockIdx.y = output group j: filters o = j NF/3 .. of every size (one position per thread is 1 280 waves at the C2 shape -- barely one per
+// SIMD, every scalar / vector load wait exposed; three groups triple the waves and cut each one's chain to a third, with no reduction)
 template <int NF>
 __global__ __launch_bounds__(256) void mt_conv3_fwd_kernel(MtConvArgs p) {
+    constexpr int NG = NF / 3;
     const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int o0 = blockIdx.y * NG;
     const int HW = p.H * p.W;
     if (pos >= p.M * HW) return;
     const int64_t m = pos / HW;
     const int r = (int)(pos - m * HW), y = r / p.W, x = r - y * p.W;
-    float acc[3][NF];
+    float acc[3][NG];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int o = 0; o < NF; ++o) acc[g][o] = p.b[g][o];
+        for (int o = 0; o < NG; ++o) acc[g][o] = p.b[g][o0 + o];
     const float* tb = p.T + m * (int64_t)p.C1 * HW;
     bool ok[3][7];
     int off[3][7];
@@ -67,9 +71,9 @@ __global__ __launch_bounds__(256) void mt_conv3_fwd_kernel(MtConvArgs p) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const int kw = 2 * g + 3;
-            const float* wg = p.w[g] + (int64_t)c * 3 * kw;                  // + o C1 3 kw
+            const float* wg = p.w[g] + ((int64_t)o0 * p.C1 + c) * 3 * kw;       // + o C1 3 kw
 #pragma unroll
-            for (int o = 0; o < NF; ++o)
+            for (int o = 0; o < NG; ++o)
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void mt_conv3_fwd_kernel(MtConvArgs p) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int o = 0; o < NF; ++o) orow[g * NF + o] = fmaxf(acc[g][o], 0.f);
+        for (int o = 0; o < NG; ++o) orow[g * NF + o0 + o] = fmaxf(acc[g][o], 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -101,10 +105,13 @@ __global__ void mt_conv3_pack_wt_kernel(const float* __restrict__ w1, const floa
     wt[i] = c < C1 ? w[(((int64_t)o * C1 + c) * 3 + dy) * kw + dx] : 0.f;
 }
 
+// (blockIdx.y = channel group of CG = C1 / 3 channels: three times the waves, a third of the accumulators and FMAs each, no reduction)
 template <int NF, int C1>
 __global__ __launch_bounds__(256) void mt_conv3_bwd_data_kernel(MtConvArgs p) {
     extern __shared__ float dps[];                      // [H W][3 NF + 1]
-    constexpr int LD = 3 * NF + 1, C1P = (C1 + 3) / 4 * 4;
+    static_assert(C1 % 3 == 0, "channel groups");
+    constexpr int LD = 3 * NF + 1, C1P = (C1 + 3) / 4 * 4, CG = C1 / 3;
+    const int c0 = blockIdx.y * CG;
     const int HW = p.H * p.W;
     const int64_t m = blockIdx.x;
     const float* dp = p.dpre + m * (int64_t)HW * 3 * NF;
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(256) void mt_conv3_bwd_data_kernel(MtConvArgs p) {
     __syncthreads();
     for (int r = threadIdx.x; r < HW; r += 256) {
         const int y = r / p.W, x = r - y * p.W;
-        float acc[C1];
+        float acc[CG];
 #pragma unroll
-        for (int c = 0; c < C1; ++c) acc[c] = 0.f;
+        for (int c = 0; c < CG; ++c) acc[c] = 0.f;
         // (tap loops stay rolled: fully unrolled the body is 13 770 FMAs of straight-line code, more than the instruction cache)
 #pragma unroll 1
         for (int dy = 0; dy < 3; ++dy)
@@ -133,15 +140,15 @@ __global__ __launch_bounds__(256) void mt_conv3_bwd_data_kernel(MtConvArgs p) {
                     for (int o = 0; o < NF; ++o) {
                         const float dd = src[g * NF + o];
                         const float d = ok ? dd : 0.f;
-                        const float* wo = p.wt + ((int64_t)tap * NF + o) * C1P;      // uniform address: scalar loads
+                        const float* wo = p.wt + ((int64_t)tap * NF + o) * C1P + c0;      // uniform address: scalar loads
 #pragma unroll
-                        for (int c = 0; c < C1; ++c) acc[c] = fmaf(d, wo[c], acc[c]);
+                        for (int c = 0; c < CG; ++c) acc[c] = fmaf(d, wo[c], acc[c]);
                     }
                 }
             }
-        float* o_ = p.dT + m * (int64_t)C1 * HW + r;
+        float* o_ = p.dT + (m * (int64_t)C1 + c0) * HW + r;
 #pragma unroll
-        for (int c = 0; c < C1; ++c) o_[(int64_t)c * HW] = acc[c];
+        for (int c = 0; c < CG; ++c) o_[(int64_t)c * HW] = acc[c];
     }
 }
 
@@ -150,8 +157,10 @@ __global__ __launch_bounds__(256) void mt_conv3_bwd_data_kernel(MtConvArgs p) {
 //   part[m][w_g[o, c, dy, dx]] = sum_(y, x) dpre[(m, y, x), g NF + o] T[m, c, y + dy - 1, x + dx - pw_g]
 // One workgroup per sample, wave = filter row dy, lane = channel c (C1 <= 64).  The sample's T tile sits in LDS [c][y][x]; a lane walks its
 // channel's row y + dy - 1 and meets every (g, o, dx) whose window holds that element: the gradient value of that pairing is the same for
-// all lanes of the wave -- a scalar load.  45 NF accumulators per lane.
+// all lanes of the wave -- a scalar load.  45 NF accumulators per lane.  blockIdx.y = one of MT_XS column ranges of the output positions, each with
+// its own partial row (more waves in flight: the scalar loads of a position are otherwise exposed in front of its 90 FMAs).
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int MT_XS = 4;
 template <int NF>
 __global__ __launch_bounds__(192) void mt_conv3_bwd_weight_kernel(MtConvArgs p) {
     extern __shared__ float ts[];                       // [C1][CS], CS = H (W + 1) made odd: lanes are channels, an even stride is a bank conflict
@@ -174,11 +183,12 @@ __global__ __launch_bounds__(192) void mt_conv3_bwd_weight_kernel(MtConvArgs p) 
 #pragma unroll
             for (int dx = 0; dx < 7; ++dx) acc[g][o][dx] = 0.f;
     const float* dp = p.dpre + m * (int64_t)HW * 3 * NF;
+    const int xchunk = (p.W + MT_XS - 1) / MT_XS, xb = blockIdx.y * xchunk, xe = min(p.W, xb + xchunk);
     for (int y = 0; y < p.H; ++y) {                     // output row y reads input row y + dy - 1
         const int yy = y + dy - 1;
         if (yy < 0 || yy >= p.H) continue;              // wave-uniform
         const float* trow = ts + cc * CS + yy * WP;
-        for (int x = 0; x < p.W; ++x) {                 // output position (y, x): uniform across the wave
+        for (int x = xb; x < xe; ++x) {                 // output position (y, x): uniform across the wave
             const float* d = dp + ((int64_t)y * p.W + x) * 3 * NF;
             float dv[3 * NF];
 #pragma unroll
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(192) void mt_conv3_bwd_weight_kernel(MtConvArgs p) 
     }
     if (!cv) return;
     const int64_t NW = (int64_t)NF * p.C1 * 3 * 15;
-    float* pr = p.part + m * NW;
+    float* pr = p.part + (m * MT_XS + blockIdx.y) * NW;
     int64_t base = 0;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -235,12 +245,12 @@ extern "C" int nir_mt_conv3_fwd(const float* T, const float* w1, const float* b1
     MtConvArgs a{};
     a.T = T; a.w[0] = w1; a.w[1] = w2; a.w[2] = w3; a.b[0] = b1; a.b[1] = b2; a.b[2] = b3; a.out = out; a.M = M; a.C1 = C1; a.H = H; a.W = W;
     ProfScope ps(prof_shape_name("mt_conv3_fwd_kernel", M * H * W, 3 * NF, C1 * 45), (hipStream_t)stream);
-    hipLaunchKernelGGL(mt_conv3_fwd_kernel<6>, dim3((unsigned)((M * H * W + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mt_conv3_fwd_kernel<6>, dim3((unsigned)((M * H * W + 255) / 256), 3), dim3(256), 0, (hipStream_t)stream, a);
     NIR_CHECK_LAUNCH("mt_conv3_fwd_kernel");
     return 0;
 }
 
-extern "C" size_t nir_mt_conv3_partial_floats(int64_t M, int C1, int NF) { return (size_t)M * NF * C1 * 45; }
+extern "C" size_t nir_mt_conv3_partial_floats(int64_t M, int C1, int NF) { return (size_t)M * MT_XS * NF * C1 * 45; }
 
 extern "C" size_t nir_mt_conv3_wt_floats(int C1, int NF) { return (size_t)45 * NF * ((C1 + 3) / 4 * 4); }
 
@@ -259,7 +269,7 @@ extern "C" int nir_mt_conv3_bwd(const float* dpre, const float* T, const float* 
         NIR_CHECK_LAUNCH("mt_conv3_pack_wt_kernel");
         a.wt = wt_workspace;
         ProfScope ps(prof_shape_name("mt_conv3_bwd_data_kernel", M * H * W, C1, 3 * NF * 15), st);
-        hipLaunchKernelGGL((mt_conv3_bwd_data_kernel<6, 51>), dim3((unsigned)M), dim3(256), (size_t)H * W * (3 * NF + 1) * 4, st, a);
+        hipLaunchKernelGGL((mt_conv3_bwd_data_kernel<6, 51>), dim3((unsigned)M, 3), dim3(256), (size_t)H * W * (3 * NF + 1) * 4, st, a);
         NIR_CHECK_LAUNCH("mt_conv3_bwd_data_kernel");
     }
     if (partial) {
@@ -269,7 +279,7 @@ extern "C" int nir_mt_conv3_bwd(const float* dpre, const float* T, const float* 
             std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)mt_conv3_bwd_weight_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
         }
         ProfScope ps(prof_shape_name("mt_conv3_bwd_weight_kernel", M * H * W, 3 * NF, C1 * 45), st);
-        hipLaunchKernelGGL(mt_conv3_bwd_weight_kernel<6>, dim3((unsigned)M), dim3(192), lds, st, a);
+        hipLaunchKernelGGL(mt_conv3_bwd_weight_kernel<6>, dim3((unsigned)M, MT_XS), dim3(192), lds, st, a);
         NIR_CHECK_LAUNCH("mt_conv3_bwd_weight_kernel");
     }
     return 0;

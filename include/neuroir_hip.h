@@ -576,7 +576,7 @@ int nir_transpose_f32(const float* in, int R, int C, float* out, nir_stream_t st
  * non-linearities) and cst [M,T,ndir,H] (c_t) of every valid step. */
 int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0, float* out,
                        float* act, float* cst, float* hn, float* cn, int64_t M, int T, int H, int ndir, nir_stream_t stream);
-/* The same forward on the split-fp16 matrix-core recurrence (lstm16_pt_h2_kernel<4,4,8,false,true>; H = 128 per direction only -- the fp32-accurate
+/* The same forward on the split-fp16 matrix-core recurrence (lstm16_pt_h2_kernel<4,4,8,false,true> / <3,2,16,false,true>; 64 < H <= 128 per direction -- the fp32-accurate
  * two-term split of csrc/lstm_fold.hip, 3 fp16 MFMAs per 32-wide k-block for the 32 fp32 ones above): gates_perm [M*T][ndir][H][4] is
  * x W_ih^T + b_ih + b_hh in the folded gate order (nir_lstm_perm_weights, then one GEMM), row_ids = 0 .. M*T-1 (int64).  out / act / cst as
  * above (the padded tail of out is zero-filled; act / cst past a sequence's length are not written).  err_flag bit 1: |w_hh| >= 2^15. */
@@ -613,8 +613,9 @@ int nir_im2col_rows_f32(const float* in, int64_t M, int C, int H, int W, int kh,
  * nir_mt_conv3_supported: 1 when the shape is served (NF = 6, C1 = 51 -- the reference's defaults -- and one sample's tiles fit LDS); callers fall
  * back to nir_im2col_rows_f32 + the GEMMs otherwise.
  * nir_mt_conv3_bwd: dpre [M H W, 3 NF] = gradient of the PRE-activation (dout * (out > 0));  dT [M, C1, H, W] (optional; needs a workspace of
- * nir_mt_conv3_wt_floats() floats);  partial [M, NF C1 45] (optional) = per-sample weight-gradient sums with the three filters' gradients back to
- * back in their own layouts -- the column sum over M (nir_colsum_set_f32) is the gradient, without atomics. */
+ * nir_mt_conv3_wt_floats() floats);  partial (optional, nir_mt_conv3_partial_floats() floats = rows of NF C1 45) = per-sample, per-column-range
+ * weight-gradient sums with the three filters' gradients back to back in their own layouts -- the column sum over the rows (nir_colsum_set_f32)
+ * is the gradient, without atomics. */
 int nir_mt_conv3_supported(int NF, int C1, int H, int W);
 int nir_mt_conv3_fwd(const float* T, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                      int64_t M, int C1, int H, int W, int NF, float* out, nir_stream_t stream);
