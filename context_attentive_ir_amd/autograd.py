@@ -675,23 +675,102 @@ class _LSTMCell(Function):
         return dg, (dcp if ctx.has_cp else None)
 
 
+def _off(t, nbytes):
+    return lib.C.c_void_p(t.data_ptr() + int(nbytes))
+
+
+class _LSTMSeq(Function):
+    """gx [M,T,4H] (input projection of every step, b_ih included), W_hh [4H,H], b_hh, optional h0 / c0 [M,H] -> (h [M,T,H], c [M,T,H]).
+    Per step ONE recurrent GEMM and ONE cell kernel that reads / writes the sequence buffers in place (round 5: the op-by-op form cost a step an
+    add, a stack slice and, in the backward, add + fill + copy + add around the same two kernels); BPTT here, dW_hh / db_hh from ONE launch over
+    the saved states shifted by a row (nir_linear_wgrad_rows_set_f32)."""
+
+    @staticmethod
+    def forward(ctx, gx, whh, bhh, h0, c0):
+        lib.require_device(gx, whh)
+        L = lib.load()
+        g = _f32c(gx)
+        M, T, G = g.shape
+        H = G // 4
+        w, b = _f32c(whh), _f32c(bhh)
+        h0c = _f32c(h0) if h0 is not None else None
+        c0c = _f32c(c0) if c0 is not None else None
+        dev = g.device
+        hs = torch.empty(M, T, H, device=dev)
+        cs = torch.empty(M, T, H, device=dev)
+        act = torch.empty(M, T, G, device=dev)
+        gh = torch.empty(M, G, device=dev)
+        st = lib.stream()
+        for t in range(T):
+            hp, ldh = (h0c, H) if t == 0 else (_off(hs, (t - 1) * H * 4), T * H)
+            have_h = M > 0 and (t > 0 or h0c is not None)
+            if have_h:
+                lib.check(L.nir_linear_f32(lib.ptr(hp) if t == 0 else hp, ldh, None, None, 0, 0, 0, lib.ptr(w), H, lib.ptr(b), None, lib.ptr(gh), G, M, G, H, 0, st),
+                          "nir_linear_f32")
+            cp, ldcp = (lib.ptr(c0c), H) if t == 0 else (_off(cs, (t - 1) * H * 4), T * H)
+            lib.check(L.nir_lstm_cell_seq_fwd(_off(g, t * G * 4), T * G, lib.ptr(gh) if have_h else None, None if have_h else lib.ptr(b), cp, ldcp,
+                                              _off(act, t * G * 4), T * G, _off(cs, t * H * 4), T * H, _off(hs, t * H * 4), T * H, M, H, st),
+                      "nir_lstm_cell_seq_fwd")
+        e = torch.empty(0)
+        ctx.save_for_backward(w, hs, cs, act, h0c if h0c is not None else e, c0c if c0c is not None else e)
+        ctx.has_h0, ctx.has_c0 = h0c is not None, c0c is not None
+        return hs, cs
+
+    @staticmethod
+    def backward(ctx, dhs, dcs):
+        w, hs, cs, act, h0, c0 = ctx.saved_tensors
+        L = lib.load()
+        M, T, H = hs.shape
+        G = 4 * H
+        dev = hs.device
+        st = lib.stream()
+        d1 = _f32c(dhs) if dhs is not None else None
+        d2 = _f32c(dcs) if dcs is not None else None
+        dgx = torch.empty(M, T, G, device=dev)
+        wt = _transpose(w)                                     # [H, 4H]: dh_{t-1} = dg_t W_hh
+        need_h0 = ctx.has_h0 and ctx.needs_input_grad[3]
+        dh_rec = dc_rec = None
+        keep = []                                              # (buffers stay referenced until their launches are enqueued)
+        for t in range(T - 1, -1, -1):
+            cp, ldcp = (_off(cs, (t - 1) * H * 4), T * H) if t > 0 else ((lib.ptr(c0), H) if ctx.has_c0 else (None, 0))
+            dcn = torch.empty(M, H, device=dev)
+            lib.check(L.nir_lstm_cell_seq_bwd(_off(d1, t * H * 4) if d1 is not None else None, T * H, lib.ptr(dh_rec),
+                                              _off(d2, t * H * 4) if d2 is not None else None, T * H, lib.ptr(dc_rec), _off(act, t * G * 4), T * G,
+                                              _off(cs, t * H * 4), T * H, cp, ldcp, _off(dgx, t * G * 4), T * G, lib.ptr(dcn), M, H, st),
+                      "nir_lstm_cell_seq_bwd")
+            keep.append((dh_rec, dc_rec))
+            dc_rec = dcn
+            if (t > 0 or need_h0) and M > 0:
+                dh_rec = torch.empty(M, H, device=dev)
+                lib.check(L.nir_linear_f32(_off(dgx, t * G * 4), T * G, None, None, 0, 0, 0, lib.ptr(wt), G, None, None, lib.ptr(dh_rec), H, M, H, G, 0, st),
+                          "nir_linear_f32")
+            else:
+                dh_rec = None
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = torch.empty(G, H, device=dev)
+            db = torch.empty(G, device=dev)
+            if M * T:
+                # dW_hh = sum_(m, t >= 1) dg[m,t]^T h[m,t-1]: the states one row back, the first step of every sequence skipped; db = all rows of dg
+                lib.check(L.nir_linear_wgrad_rows_set_f32(lib.ptr(dgx), G, 0, lib.ptr(hs), H, -1, None, None, M * T, T, 0, lib.ptr(dw), H, lib.ptr(db), G, H, st),
+                          "nir_linear_wgrad_rows_set_f32")
+                if ctx.has_h0:                                 # + dg[:,0]^T h0
+                    lib.check(L.nir_linear_wgrad_f32(lib.ptr(dgx), T * G, lib.ptr(h0), H, None, None, 0, lib.ptr(dw), H, M, G, H, st), "nir_linear_wgrad_f32")
+            else:
+                dw.zero_(); db.zero_()
+        return dgx, dw, db, (dh_rec if need_h0 else None), (dc_rec if ctx.has_c0 and ctx.needs_input_grad[4] else None)
+
+
+def lstm_gx(gx, lstm, h0=None, c0=None):
+    """one direction of an nn.LSTM parameter container over precomputed input gates gx [M,T,4H] (x W_ih^T + b_ih) -> (h, c) of every step"""
+    return _LSTMSeq.apply(gx, lstm.weight_hh_l0, lstm.bias_hh_l0, h0, c0)
+
+
 def lstm_seq(x, lstm, h0=None, c0=None):
     """Unidirectional LSTM over full-length sequences x [M,T,I] with an optional initial state ([M,H] each) -> (h of every step
-    [M,T,H], c of every step [M,T,H]), any hidden size: the input projection of all steps is one GEMM, each step adds the
-    recurrent GEMM and the fused cell kernel; BPTT is autograd over these HIP operators (T is a session or a query: <= ~20)."""
-    M, T, _ = x.shape
-    gx = linear(x, lstm.weight_ih_l0, lstm.bias_ih_l0)                       # [M,T,4H]
-    h, c = h0, c0
-    hs, cs = [], []
-    for t in range(T):
-        g = gx[:, t]
-        if h is not None:
-            g = g + linear(h, lstm.weight_hh_l0, lstm.bias_hh_l0)
-        else:
-            g = g + lstm.bias_hh_l0
-        h, c = _LSTMCell.apply(g, c)
-        hs.append(h); cs.append(c)
-    return torch.stack(hs, 1), torch.stack(cs, 1)
+    [M,T,H], c of every step [M,T,H]), any hidden size: the input projection of all steps is one GEMM, each step is the recurrent GEMM and
+    the cell kernel working inside the sequence buffers (_LSTMSeq; T is a session or a query: <= ~20)."""
+    return lstm_gx(linear(x, lstm.weight_ih_l0, lstm.bias_ih_l0), lstm, h0, c0)
 
 
 class _BCE(Function):

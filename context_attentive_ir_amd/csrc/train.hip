@@ -1007,6 +1007,50 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* 
     dcprev[i] = dct * gf;
 }
 
+// The same cell inside a [B,T,.] sequence buffer (autograd._LSTMSeq): the step's gates are gx (row stride ldgx: the input projection of all steps) +
+// gh ([B,4H] contiguous: the recurrent GEMM of this step, bias included) or + bias (first step without an initial state); act / c / h are written
+// into the step's column of the sequence buffers (row strides).  No per-step add, stack or copy kernels around it.
+__global__ void lstm_cell_seq_fwd_kernel(const float* __restrict__ gx, int64_t ldgx, const float* __restrict__ gh, const float* __restrict__ bias,
+                                         const float* __restrict__ cprev, int64_t ldcp, float* __restrict__ act, int64_t ldact, float* __restrict__ c,
+                                         int64_t ldc, float* __restrict__ h, int64_t ldh, int64_t B, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int64_t b = i / H;
+    const int j = (int)(i % H);
+    const float* xr = gx + b * ldgx;
+    float p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = xr[q * H + j] + (gh ? gh[b * 4 * H + q * H + j] : (bias ? bias[q * H + j] : 0.f));
+    const float gi = 1.0f / (1.0f + expf(-p[0])), gf = 1.0f / (1.0f + expf(-p[1]));
+    const float gg = tanhf(p[2]), go = 1.0f / (1.0f + expf(-p[3]));
+    float* ar = act + b * ldact;
+    ar[j] = gi; ar[H + j] = gf; ar[2 * H + j] = gg; ar[3 * H + j] = go;
+    const float cn = gf * (cprev ? cprev[b * ldcp + j] : 0.f) + gi * gg;
+    c[b * ldc + j] = cn;
+    h[b * ldh + j] = go * tanhf(cn);
+}
+// dh = dh1 (strided, the consumers of this step's h) + dh2 (contiguous, from the next step's recurrent GEMM), dc likewise; any may be NULL
+__global__ void lstm_cell_seq_bwd_kernel(const float* __restrict__ dh1, int64_t ld1, const float* __restrict__ dh2, const float* __restrict__ dc1,
+                                         int64_t ldc1, const float* __restrict__ dc2, const float* __restrict__ act, int64_t ldact,
+                                         const float* __restrict__ c, int64_t ldc, const float* __restrict__ cprev, int64_t ldcp, float* __restrict__ dg,
+                                         int64_t lddg, float* __restrict__ dcprev, int64_t B, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int64_t b = i / H;
+    const int j = (int)(i % H);
+    const float* ar = act + b * ldact;
+    const float gi = ar[j], gf = ar[H + j], gg = ar[2 * H + j], go = ar[3 * H + j];
+    const float th = tanhf(c[b * ldc + j]);
+    const float dhh = (dh1 ? dh1[b * ld1 + j] : 0.f) + (dh2 ? dh2[i] : 0.f);
+    const float dct = (dc1 ? dc1[b * ldc1 + j] : 0.f) + (dc2 ? dc2[i] : 0.f) + dhh * go * (1.f - th * th);
+    float* dr = dg + b * lddg;
+    dr[j] = dct * gg * gi * (1.f - gi);
+    dr[H + j] = dct * (cprev ? cprev[b * ldcp + j] : 0.f) * gf * (1.f - gf);
+    dr[2 * H + j] = dct * gi * (1.f - gg * gg);
+    dr[3 * H + j] = dhh * th * go * (1.f - go);
+    dcprev[i] = dct * gf;
+}
+
 static inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 // ---- im2col as ROWS (training forwards of the 2-D convolutions, rankers/mtensor.py:108-121): out[(m, y, x)][(c, dy, dx)] =
@@ -1349,6 +1393,26 @@ extern "C" int nir_softmax_nll_ent_bwd(const float* logits, int64_t ld, const in
     hipLaunchKernelGGL(softmax_nll_ent_bwd_kernel, dim3((unsigned)((V + 1023) / 1024), (unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, target, pad,
                        lse, ent, grad_nll, grad_ent, V, dlogits);
     NIR_CHECK_LAUNCH("softmax_nll_ent_bwd_kernel");
+    return 0;
+}
+extern "C" int nir_lstm_cell_seq_fwd(const float* gx, int64_t ldgx, const float* gh, const float* bias, const float* c_prev, int64_t ldcp, float* act,
+                                     int64_t ldact, float* c, int64_t ldc, float* h, int64_t ldh, int64_t B, int H, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(gx && act && c && h && B >= 0 && H > 0, "lstm_cell_seq_fwd: bad args");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_seq_fwd_kernel, g1(B * H), dim3(256), 0, (hipStream_t)stream, gx, ldgx, gh, bias, c_prev, ldcp, act, ldact, c, ldc, h, ldh, B, H);
+    NIR_CHECK_LAUNCH("lstm_cell_seq_fwd_kernel");
+    return 0;
+}
+extern "C" int nir_lstm_cell_seq_bwd(const float* dh_step, int64_t ld_dh, const float* dh_rec, const float* dc_step, int64_t ld_dc, const float* dc_rec,
+                                     const float* act, int64_t ldact, const float* c, int64_t ldc, const float* c_prev, int64_t ldcp, float* dgates,
+                                     int64_t lddg, float* dc_prev, int64_t B, int H, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(act && c && dgates && dc_prev && B >= 0 && H > 0, "lstm_cell_seq_bwd: bad args");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_seq_bwd_kernel, g1(B * H), dim3(256), 0, (hipStream_t)stream, dh_step, ld_dh, dh_rec, dc_step, ld_dc, dc_rec, act, ldact, c,
+                       ldc, c_prev, ldcp, dgates, lddg, dc_prev, B, H);
+    NIR_CHECK_LAUNCH("lstm_cell_seq_bwd_kernel");
     return 0;
 }
 extern "C" int nir_embed_f32(const int64_t* ids, const float* table, int64_t V, int E, int64_t M, float* out, int* err_flag, nir_stream_t stream) {

@@ -475,12 +475,6 @@ class CARS(nn.Module, lib.IdCheck):
     def _proj(self, seq, x):
         return A.linear(A.dropout(x, seq.dropout.p, True), seq.linear.weight, seq.linear.bias)
 
-    def _cell(self, lstm, gx, state):
-        """one session-LSTM step; gx = x W_ih^T + b_ih of this step (the input side of all steps is ONE linear in front of the loop: the
-        inputs -- pooled queries / click-pooled documents -- do not depend on the recurrence)"""
-        g = gx + (A.linear(state[0], lstm.weight_hh_l0, lstm.bias_hh_l0) if state is not None else lstm.bias_hh_l0)
-        return A._LSTMCell.apply(g, state[1] if state is not None else None)
-
     def _forward_train(self, source_rep, source_len, target_rep, target_len, target_seq, document_rep, document_len, document_label):
         B, S, QL = source_rep.shape
         N, DL = document_rep.shape[2], document_rep.shape[3]
@@ -507,21 +501,14 @@ class CARS(nn.Module, lib.IdCheck):
         # so far -- the query-conditioned session attentions, projections, pair features, maxout ranker, inner attentions -- is then ONE batched
         # call over all steps with a causal mask (step t sees states 0..t), instead of S copies of every node in the autograd graph.
         dev = pooled_q.device
-        qstate = dstate = None
         sq_rnn = self.session_query_encoder.encoder.rnns[0] if q_on else None
         sd_rnn = self.session_doc_encoder.encoder.rnns[0] if d_on else None
-        gq_steps = A.linear(pooled_q, sq_rnn.weight_ih_l0, sq_rnn.bias_ih_l0).unbind(1) if q_on else None
-        gd_steps = A.linear(clicks, sd_rnn.weight_ih_l0, sd_rnn.bias_ih_l0).unbind(1) if d_on else None
-        qh, qc, dh, dc = [], [], [], []
-        for t in range(S):
-            if q_on:
-                qstate = self._cell(sq_rnn, gq_steps[t], qstate)
-                qh.append(qstate[0]); qc.append(qstate[1])
-            if d_on:
-                dstate = self._cell(sd_rnn, gd_steps[t], dstate)
-                dh.append(dstate[0]); dc.append(dstate[1])
-        QH = torch.stack(qh, 1) if q_on else None                       # [B,S,H] raw states (decoder initial states)
-        DH = torch.stack(dh, 1) if d_on else None
+        # the two session LSTMs: the input side of all S steps is one linear each, the S steps run inside the sequence buffers (A.lstm_gx)
+        QH = QC = DH = DC = None                                        # [B,S,H] raw states (decoder initial states) and cell states
+        if q_on:
+            QH, QC = A.lstm_gx(A.linear(pooled_q, sq_rnn.weight_ih_l0, sq_rnn.bias_ih_l0), sq_rnn)
+        if d_on:
+            DH, DC = A.lstm_gx(A.linear(clicks, sd_rnn.weight_ih_l0, sd_rnn.bias_ih_l0), sd_rnn)
         QHd = A.dropout(QH, p, True) if q_on else None                  # the dropped copies both attentions read (one mask per state)
         DHd = A.dropout(DH, p, True) if d_on else None
         causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril().unsqueeze(0)          # [1, step t, state j <= t]
@@ -571,7 +558,7 @@ class CARS(nn.Module, lib.IdCheck):
         if not self.no_recommender:                                    # teacher-forced decoder (cars.py:605-657)
             Bd = B * (S - 1)
             hid = torch.cat([h for h in (QH, DH) if h is not None], 2)            # [B,S,.]
-            cell = torch.cat([torch.stack(c, 1) for c in (qc, dc) if c], 2)
+            cell = torch.cat([c for c in (QC, DC) if c is not None], 2)
             dec_h = self._proj(self.transform_hid, hid[:, :-1].transpose(0, 1).reshape(Bd, -1))     # (step, session) row order, like the reference
             dec_c = self._proj(self.transform_cell, cell[:, :-1].transpose(0, 1).reshape(Bd, -1))
             cs = torch.cat([a for a in (inner_q, inner_d) if a is not None], 2)[:, :-1].reshape(Bd, -1)

@@ -595,6 +595,15 @@ int nir_lstm_train_bwd(const float* dout, const float* dhn, const float* dcn, co
 int nir_lstm_cell_fwd(const float* gates, const float* c_prev, float* act, float* c, float* h, int64_t B, int H, nir_stream_t stream);
 int nir_lstm_cell_bwd(const float* dh, const float* dc, const float* act, const float* c, const float* c_prev, float* dgates,
                       float* dc_prev, int64_t B, int H, nir_stream_t stream);
+/* The cell step inside [B,T,.] sequence buffers (autograd._LSTMSeq: session LSTMs, decoder, encoders wider than 128): gates = gx (row stride ldgx)
+ * + gh ([B,4H] contiguous; NULL: + bias [4H], or nothing), c_prev with row stride ldcp (NULL: zero); act / c / h go to the step's columns of the
+ * sequence buffers (row strides) -- no per-step add / stack / copy kernels.  Backward: dh = dh_step (strided, may be NULL) + dh_rec ([B,H], may be
+ * NULL), dc likewise -> dgates (row stride lddg) and dc_prev [B,H]. */
+int nir_lstm_cell_seq_fwd(const float* gx, int64_t ldgx, const float* gh, const float* bias, const float* c_prev, int64_t ldcp, float* act,
+                          int64_t ldact, float* c, int64_t ldc, float* h, int64_t ldh, int64_t B, int H, nir_stream_t stream);
+int nir_lstm_cell_seq_bwd(const float* dh_step, int64_t ld_dh, const float* dh_rec, const float* dc_step, int64_t ld_dc, const float* dc_rec,
+                          const float* act, int64_t ldact, const float* c, int64_t ldc, const float* c_prev, int64_t ldcp, float* dgates,
+                          int64_t lddg, float* dc_prev, int64_t B, int H, nir_stream_t stream);
 /* Inverted dropout with a counter-based mask: keep[i] = uniform(splitmix64(seed ^ i*c)) >= p, y = x*keep/(1-p).  The mask is an
  * output so that a parity test can replay it through the oracle. */
 int nir_dropout_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, uint64_t seed, nir_stream_t stream);
