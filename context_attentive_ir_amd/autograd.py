@@ -381,6 +381,51 @@ def suggestion_loss(logits, target, pad, regularize_coeff=0.0):
     return loss
 
 
+class _SoftmaxPool(Function):
+    """logits [R,T], mask (bool [MR,T] or None; row of r = (r // mdiv) % MR), values [R/G,T,D] -> out [R,D] = softmax(masked logits) @ values."""
+
+    @staticmethod
+    def forward(ctx, logits, mask, mdiv, values, G):
+        lib.require_device(logits, values)
+        L = lib.load()
+        z, v = _f32c(logits), _f32c(values)
+        R, T = z.shape
+        D = v.shape[2]
+        mk = mask.to(torch.uint8).contiguous() if mask is not None else None
+        w = torch.empty(R, T, device=z.device)
+        out = torch.empty(R, D, device=z.device)
+        lib.check(L.nir_softmax_pool_fwd(lib.ptr(z), lib.ptr(mk), int(mdiv), mk.shape[0] if mk is not None else 1, lib.ptr(v), R, int(G), T, D, lib.ptr(w),
+                                         lib.ptr(out), lib.stream()), "nir_softmax_pool_fwd")
+        ctx.save_for_backward(w, v)
+        ctx.G = int(G)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w, v = ctx.saved_tensors
+        R, T = w.shape
+        D = v.shape[2]
+        d = _f32c(dout)
+        dz = torch.empty_like(w)
+        dv = torch.empty_like(v) if ctx.needs_input_grad[3] else None
+        lib.check(lib.load().nir_softmax_pool_bwd(lib.ptr(w), lib.ptr(d), lib.ptr(v), R, ctx.G, T, D, lib.ptr(dz), lib.ptr(dv), lib.stream()),
+                  "nir_softmax_pool_bwd")
+        return dz, None, None, dv, None
+
+
+def softmax_pool(logits, mask, values, mask_div=1):
+    """softmax(logits.masked_fill(~mask, -inf), -1) @ values in one launch each way.  logits [..., T]; values [V0, T, D] with V0 dividing the number
+    of logit rows R (G = R / V0 consecutive rows share a value block); mask bool [MR, T] or None, row of r = (r // mask_div) % MR.
+    -> [R, D]"""
+    T = logits.shape[-1]
+    z = logits.reshape(-1, T)
+    R = z.shape[0]
+    G = R // values.shape[0]
+    if G * T * 8 > 64 * 1024 or T > 8192 or R % max(1, values.shape[0]):
+        raise NotImplementedError("softmax_pool: G T <= 8192 (got G = %d, T = %d)" % (G, T))
+    return _SoftmaxPool.apply(z, mask, mask_div, values, G)
+
+
 class _Embed(Function):
     @staticmethod
     def forward(ctx, ids, table, pad_idx):

@@ -947,6 +947,87 @@ __global__ __launch_bounds__(256) void softmax_nll_ent_bwd_kernel(const float* _
         }
     }
 }
+// Masked softmax + weighted sum of the attention sites of the training forwards (cars.py:262-304, 520-600 and the decoder's global attention):
+//   w[r, :] = softmax(logits[r, :] where mask, -inf elsewhere),   out[r, :] = sum_t w[r, t] V[r / G, t, :]
+// (G consecutive rows share one value block: the causal session attentions and the decoder steps).  mask row of r = (r / mdiv) % mmod.
+// The op-by-op form is ~6 launches forward (not, copy, masked_fill, softmax, mul, sum -- the product a [R, T, D] temporary) and ~8 backward.
+__global__ __launch_bounds__(256) void softmax_pool_fwd_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask, int64_t mdiv,
+                                                               int64_t mmod, const float* __restrict__ V, int G, int T, int D, float* __restrict__ w_out,
+                                                               float* __restrict__ out) {
+    extern __shared__ float ws[];                       // [T]
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x, g = r / G;
+    const unsigned char* mr = mask ? mask + ((r / mdiv) % mmod) * T : nullptr;
+    const float* lr = logits + r * T;
+    float m = -INFINITY;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float x = (!mr || mr[t]) ? lr[t] : -INFINITY;
+        ws[t] = x;
+        m = fmaxf(m, x);
+    }
+    m = block_reduce(m, red, true);
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float e = expf(ws[t] - m);
+        ws[t] = e;
+        s += e;
+    }
+    s = block_reduce(s, red, false);
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float w = ws[t] / s;
+        ws[t] = w;
+        w_out[r * T + t] = w;
+    }
+    __syncthreads();
+    const float* vb = V + g * (int64_t)T * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc = fmaf(ws[t], vb[(int64_t)t * D + d], acc);
+        out[r * D + d] = acc;
+    }
+}
+// one workgroup per value block g (its G rows):  dw[r,t] = dout[r,:] . V[g,t,:];  dlogits[r,t] = w[r,t] (dw[r,t] - sum_t' w[r,t'] dw[r,t']);
+// dV[g,t,:] = sum_r w[r,t] dout[r,:]
+__global__ __launch_bounds__(256) void softmax_pool_bwd_kernel(const float* __restrict__ w, const float* __restrict__ dout, const float* __restrict__ V,
+                                                               int G, int T, int D, float* __restrict__ dlogits, float* __restrict__ dV) {
+    extern __shared__ float sm[];                       // wl [G][T], dw [G][T]
+    float* wl = sm;
+    float* dw = sm + G * T;
+    const int64_t g = blockIdx.x, r0 = g * G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < G * T; e += 256) wl[e] = w[r0 * T + e];
+    const float* vb = V + g * (int64_t)T * D;
+    for (int pq = wave; pq < G * T; pq += 4) {           // (row, t) pairs: one wave each, lanes over d
+        const int rl = pq / T, t = pq - rl * T;
+        const float* dr = dout + (r0 + rl) * D;
+        const float* vr = vb + (int64_t)t * D;
+        float a = 0.f;
+        for (int d = lane; d < D; d += 64) a = fmaf(dr[d], vr[d], a);
+        a = wave_sum(a);
+        if (lane == 0) dw[pq] = a;
+    }
+    __syncthreads();
+    for (int rl = threadIdx.x; rl < G; rl += 256) {
+        float dot = 0.f;
+        for (int t = 0; t < T; ++t) dot = fmaf(wl[rl * T + t], dw[rl * T + t], dot);
+        for (int t = 0; t < T; ++t) {
+            const float wv = wl[rl * T + t];
+            // (a masked position has w = 0 exactly: its gradient is 0 whatever dw is; 0 * inf cannot occur, dw is finite)
+            dlogits[(r0 + rl) * T + t] = wv * (dw[rl * T + t] - dot);
+        }
+    }
+    if (dV) {
+        float* dvb = dV + g * (int64_t)T * D;
+        for (int d = threadIdx.x; d < D; d += 256)
+            for (int t = 0; t < T; ++t) {
+                float a = 0.f;
+                for (int rl = 0; rl < G; ++rl) a = fmaf(wl[rl * T + t], dout[(r0 + rl) * D + d], a);
+                dvb[(int64_t)t * D + d] = a;
+            }
+    }
+}
+
 // embedding lookup: out[m,:] = table[ids[m],:]  (optionally with an inverted-dropout keep mask that is also returned)
 __global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table, int64_t V, int E, int64_t M, float* __restrict__ out,
                              int* err) {
@@ -1413,6 +1494,28 @@ extern "C" int nir_lstm_cell_seq_bwd(const float* dh_step, int64_t ld_dh, const 
     hipLaunchKernelGGL(lstm_cell_seq_bwd_kernel, g1(B * H), dim3(256), 0, (hipStream_t)stream, dh_step, ld_dh, dh_rec, dc_step, ld_dc, dc_rec, act, ldact, c,
                        ldc, c_prev, ldcp, dgates, lddg, dc_prev, B, H);
     NIR_CHECK_LAUNCH("lstm_cell_seq_bwd_kernel");
+    return 0;
+}
+extern "C" int nir_softmax_pool_fwd(const float* logits, const unsigned char* mask, int64_t mask_div, int64_t mask_mod, const float* values, int64_t R,
+                                    int G, int T, int D, float* weights, float* out, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(logits && values && weights && out, "softmax_pool_fwd: null pointer");
+    NIR_REQUIRE(R >= 0 && G >= 1 && R % G == 0 && T >= 1 && T <= 8192 && D >= 1 && (!mask || (mask_div >= 1 && mask_mod >= 1)), "softmax_pool_fwd: bad dims");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(softmax_pool_fwd_kernel, dim3((unsigned)R), dim3(256), (size_t)T * 4, (hipStream_t)stream, logits, mask, mask_div, mask_mod, values, G, T, D,
+                       weights, out);
+    NIR_CHECK_LAUNCH("softmax_pool_fwd_kernel");
+    return 0;
+}
+extern "C" int nir_softmax_pool_bwd(const float* weights, const float* dout, const float* values, int64_t R, int G, int T, int D, float* dlogits,
+                                    float* dvalues, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(weights && dout && values && dlogits, "softmax_pool_bwd: null pointer");
+    NIR_REQUIRE(R >= 0 && G >= 1 && R % G == 0 && T >= 1 && D >= 1 && (int64_t)G * T * 8 <= 64 * 1024, "softmax_pool_bwd: bad dims (G T <= 8192)");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(softmax_pool_bwd_kernel, dim3((unsigned)(R / G)), dim3(256), (size_t)G * T * 8, (hipStream_t)stream, weights, dout, values, G, T, D, dlogits,
+                       dvalues);
+    NIR_CHECK_LAUNCH("softmax_pool_bwd_kernel");
     return 0;
 }
 extern "C" int nir_embed_f32(const int64_t* ids, const float* table, int64_t V, int E, int64_t M, float* out, int* err_flag, nir_stream_t stream) {

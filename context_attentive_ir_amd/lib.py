@@ -165,6 +165,8 @@ SIGNATURES = {
     "nir_rank_loss_bce_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, _l, c_st]),
     "nir_softmax_nll_ent_fwd": (_i, [c_fp, _l, c_ip, _l, _l, _i, c_fp, c_fp, c_fp, C.c_void_p, c_st]),
     "nir_softmax_nll_ent_bwd": (_i, [c_fp, _l, c_ip, _l, c_fp, c_fp, c_fp, c_fp, _l, _i, c_fp, c_st]),
+    "nir_softmax_pool_fwd": (_i, [c_fp, C.c_void_p, _l, _l, c_fp, _l, _i, _i, _i, c_fp, c_fp, c_st]),
+    "nir_softmax_pool_bwd": (_i, [c_fp, c_fp, c_fp, _l, _i, _i, _i, c_fp, c_fp, c_st]),
     "nir_embed_f32": (_i, [c_ip, c_fp, _l, _i, _l, c_fp, C.c_void_p, c_st]),
     "nir_embed_bwd_f32": (_i, [c_ip, c_fp, _l, _i, _l, c_fp, _l, c_st]),
     "nir_add_f32": (_i, [c_fp, c_fp, c_fp, _l, c_st]),

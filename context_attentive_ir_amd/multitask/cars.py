@@ -462,8 +462,7 @@ class CARS(nn.Module, lib.IdCheck):
     def _pool_train(self, mlp, enc, lens, p):
         T = enc.shape[1]
         mask = torch.arange(T, device=enc.device).unsqueeze(0) < lens.unsqueeze(1)
-        w = torch.softmax(self._mlp_logits(mlp, enc, p).masked_fill(~mask, float("-inf")), 1)
-        return _wsum(enc, w)
+        return A.softmax_pool(self._mlp_logits(mlp, enc, p), mask, enc)
 
     def _encode_train(self, which, ids, lens):
         table = self.embedder.word_embeddings.table
@@ -494,8 +493,7 @@ class CARS(nn.Module, lib.IdCheck):
                 count = (lab != 0).sum(1)
                 pos = torch.arange(N, device=lab.device).unsqueeze(0)
                 keep = (pos < count.unsqueeze(1)) | (pos >= count.max())          # the batch-dependent mask quirk (Appendix E2)
-                w = torch.softmax(self._mlp_logits(self.click_attn, sd, p).masked_fill(~keep, float("-inf")), 1)
-                clicks = _wsum(sd, w).view(B, S, -1)
+                clicks = A.softmax_pool(self._mlp_logits(self.click_attn, sd, p), keep, sd).view(B, S, -1)
         # ---- encode_session (cars.py:306-458), re-ordered: the two session LSTMs read pooled queries / click-pooled documents only, never a
         # ranking output, so their S steps run first (the only loop left); everything the reference computes per step from the states collected
         # so far -- the query-conditioned session attentions, projections, pair features, maxout ranker, inner attentions -- is then ONE batched
@@ -517,8 +515,7 @@ class CARS(nn.Module, lib.IdCheck):
             """step t attends over [0, h_0 .. h_{t-1}] with its pooled query (cars.py:520-560)"""
             st = torch.cat((torch.zeros(B, 1, Hd_.shape[2], device=dev), Hd_[:, :S - 1]), 1)          # [B,S,H]
             sc = (A.linear(st, lin.weight, lin.bias).unsqueeze(1) * pooled_q.unsqueeze(2)).sum(3)     # [B, t, j]
-            w = torch.softmax(sc.masked_fill(~causal, float("-inf")), 2)
-            return (w.unsqueeze(3) * st.unsqueeze(1)).sum(2)                                          # [B,S,H]
+            return A.softmax_pool(sc, causal[0], st).view(B, S, -1)                                   # [B,S,H]: step t's rows share st[b]
 
         def inner(Hd_, mlp):
             """step t pools h_0 .. h_t with the inner attention (cars.py:562-600); its dropout draws a fresh mask at every step"""
@@ -528,8 +525,7 @@ class CARS(nn.Module, lib.IdCheck):
                 lg = A.linear(a, mlp[3].weight, mlp[3].bias).squeeze(-1)                               # [B, t, j]
             else:
                 lg = A.linear(a, mlp[3].weight, mlp[3].bias).squeeze(-1).unsqueeze(1).expand(B, S, S)
-            w = torch.softmax(lg.masked_fill(~causal, float("-inf")), 2)
-            return (w.unsqueeze(3) * Hd_.unsqueeze(1)).sum(2)                                          # [B,S,H]
+            return A.softmax_pool(lg, causal[0], Hd_).view(B, S, -1)                                   # [B,S,H]
 
         scores_all = None
         if not self.no_ranker:
@@ -572,8 +568,8 @@ class CARS(nn.Module, lib.IdCheck):
             rnn, att = self.decoder.decoder.rnn, self.decoder.decoder.attn
             h_all, _ = A.lstm_seq(temb, rnn, dec_h, dec_c)                            # [Bd,TL,HD]
             align = (A.linear(h_all, att.linear_in.weight).unsqueeze(2) * mem.unsqueeze(1)).sum(3)      # [Bd,TL,QL] (tiny: tensor glue, no library GEMM)
-            mask = (torch.arange(QL, device=dev).unsqueeze(0) < mlen.unsqueeze(1)).unsqueeze(1)
-            ctx = (torch.softmax(align.masked_fill(~mask, float("-inf")), -1).unsqueeze(3) * mem.unsqueeze(1)).sum(2)
+            mask = torch.arange(QL, device=dev).unsqueeze(0) < mlen.unsqueeze(1)                       # [Bd,QL]: the TL rows of a session share it
+            ctx = A.softmax_pool(align, mask, mem, mask_div=align.shape[1]).view(Bd, align.shape[1], -1)
             dec_out = A.linear(torch.cat((ctx, h_all), 2), att.linear_out.weight, act="tanh")
             dec_out = A.dropout(dec_out, self.dec_dropout_p, True)[:, :-1]
             po = A.linear(dec_out, self.token_prob_predictor1.weight)

@@ -645,6 +645,14 @@ int nir_softmax_nll_ent_fwd(const float* logits, int64_t ld, const int64_t* targ
                             float* lse, int* err_flag, nir_stream_t stream);
 int nir_softmax_nll_ent_bwd(const float* logits, int64_t ld, const int64_t* target, int64_t pad, const float* lse, const float* ent,
                             const float* grad_nll, const float* grad_ent, int64_t R, int V, float* dlogits, nir_stream_t stream);
+/* Masked softmax + weighted sum of the attention sites of the training forwards (neuroir/multitask/cars.py:262-304, 520-600; the decoder's global
+ * attention): weights[r,:] = softmax(logits[r,:] where mask, -inf elsewhere), out[r,:] = sum_t weights[r,t] values[r / G, t, :] -- G consecutive rows
+ * share a value block; mask (bytes, may be NULL) row of r = (r / mask_div) % mask_mod.  Backward: dlogits [R,T] and (optional) dvalues [R/G,T,D] from
+ * the saved weights.  One launch each way for ~6 / ~8 tensor-op launches and a [R,T,D] product temporary. */
+int nir_softmax_pool_fwd(const float* logits, const unsigned char* mask, int64_t mask_div, int64_t mask_mod, const float* values, int64_t R, int G,
+                         int T, int D, float* weights, float* out, nir_stream_t stream);
+int nir_softmax_pool_bwd(const float* weights, const float* dout, const float* values, int64_t R, int G, int T, int D, float* dlogits,
+                         float* dvalues, nir_stream_t stream);
 /* Embedding lookup out[m,:] = table[ids[m],:] (train mode materialises it: the weight-gradient GEMMs need x) and its backward
  * (scatter-add, PAD row excluded like nn.Embedding(padding_idx)). */
 int nir_embed_f32(const int64_t* ids, const float* table, int64_t V, int E, int64_t M, float* out, int* err_flag, nir_stream_t stream);

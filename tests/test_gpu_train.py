@@ -164,6 +164,31 @@ def test_mt_conv3_direct_convolutions_match_conv2d(M, H, W):
         _rel(d.weight.grad, c.weight.grad); _rel(d.bias.grad, c.bias.grad)
 
 
+@pytest.mark.parametrize("V0,G,T_,D,mode", [(5, 1, 9, 40, "rows"), (3, 7, 7, 33, "causal"), (4, 5, 6, 300, "group"), (2, 1, 300, 17, "none"), (3, 2, 64, 256, "rows")])
+def test_softmax_pool_matches_masked_softmax_weighted_sum(V0, G, T_, D, mode):
+    """A.softmax_pool against softmax(masked_fill) + broadcast product + sum in torch ops, forward and both gradients."""
+    from context_attentive_ir_amd import autograd as A
+    g = torch.Generator().manual_seed(T_ + D)
+    R = V0 * G
+    z0 = torch.randn(R, T_, generator=g) * 2; v0 = torch.randn(V0, T_, D, generator=g); dout = torch.randn(R, D, generator=g)
+    if mode == "rows":
+        mask = torch.rand(R, T_, generator=g) < 0.6; mask[:, 0] = True; full, mdiv = mask, 1
+    elif mode == "causal":
+        mask = torch.ones(G, T_, dtype=torch.bool).tril(); full, mdiv = mask.repeat(V0, 1), 1
+    elif mode == "group":
+        mask = torch.rand(V0, T_, generator=g) < 0.6; mask[:, 1] = True; full, mdiv = mask.repeat_interleave(G, 0), G
+    else:
+        mask, full, mdiv = None, torch.ones(R, T_, dtype=torch.bool), 1
+    z = z0.double().requires_grad_(True); v = v0.double().requires_grad_(True)
+    w = torch.softmax(z.masked_fill(~full, float("-inf")), 1)
+    ref = (w.view(V0, G, T_).unsqueeze(3) * v.unsqueeze(1)).sum(2).view(R, D)
+    ref.backward(dout.double())
+    zd = z0.to(DEV).requires_grad_(True); vd = v0.to(DEV).requires_grad_(True)
+    out = A.softmax_pool(zd, mask.to(DEV) if mask is not None else None, vd, mask_div=mdiv)
+    out.backward(dout.to(DEV))
+    _rel(out, ref.float(), 2e-5); _rel(zd.grad, z.grad.float()); _rel(vd.grad, v.grad.float())
+
+
 def test_embed_backward_skips_pad_and_accumulates():
     from context_attentive_ir_amd import autograd as A
     V, E = 30, 8
