@@ -42,7 +42,8 @@ class StepScope(object):
 
     * gradients of PARAMETERS that enter `linear` are not formed use by use: every use parks its (dY, X) pair, and when the scope closes each
       parameter gets ONE weight-gradient launch over the row-concatenation of its pairs -- dW = sum_u dY_u^T X_u = [dY_1; dY_2; ..]^T [X_1; X_2; ..]
-      -- and one column sum for its bias, written with the "=" forms (no zero fill) into a persistent buffer that becomes `p.grad`.  Left to
+      -- with its bias's column sum from the same launch -- accumulated into a persistent buffer that becomes `p.grad` (the buffers of a step are
+      views of one arena, zero-filled by ONE launch: no memset node per sliced weight-gradient launch).  Left to
       autograd, a weight used at every step of the session / decoder loops produced one small launch and one gradient tensor per use plus an
       `add` kernel per pair (a CARS step: ~140 weight-gradient launches, ~110 column sums, ~350 adds);
     * the transposed weight of the data-gradient GEMM (dX = dY W) is formed once per weight and step, not once per use.
@@ -55,6 +56,7 @@ class StepScope(object):
         self.pend_b = {}          # id(bias)   -> (param, [dY, ..])
         self.wt = {}              # (data_ptr, version, shape) -> (source tensor, transposed weight), this step
         self.pair_b = {}          # id(weight) -> bias parameter parked with the same dY tensors
+        self.arena_key, self.arenas = None, []
 
     def begin(self):
         self.active, self.pend_w, self.pend_b, self.wt, self.pair_b = True, {}, {}, {}, {}
@@ -70,9 +72,30 @@ class StepScope(object):
     def grad_buffer(self, p):
         ent = self.bufs.get(id(p))
         if ent is None or ent[0] is not p or ent[1].shape != p.shape or ent[1].device != p.device:
-            ent = (p, torch.empty_like(p, dtype=torch.float32))
-            self.bufs[id(p)] = ent
+            raise KeyError("StepScope: no gradient buffer laid out for this parameter")
         return ent[1]
+
+    def _layout(self, params):
+        """the step's gradient buffers as views of ONE arena (zero-filled by one launch per step; the weight gradients then accumulate: no
+        memset node per sliced launch -- a CARS step had 67 of them); re-laid only when the set of parameters changes"""
+        key = tuple((id(p), p.numel(), str(p.device)) for p in params)
+        if key != self.arena_key:
+            by_dev = {}
+            for p in params:
+                by_dev.setdefault(str(p.device), []).append(p)
+            self.bufs, self.arenas = {}, []
+            for ps in by_dev.values():
+                offs, n = [], 0
+                for p in ps:
+                    offs.append(n)
+                    n += (p.numel() + 63) // 64 * 64
+                arena = torch.empty(n, device=ps[0].device, dtype=torch.float32)
+                self.arenas.append(arena)
+                for p, o in zip(ps, offs):
+                    self.bufs[id(p)] = (p, arena[o:o + p.numel()].view(p.shape))
+            self.arena_key = key
+        for a in self.arenas:
+            a.zero_()
 
     def park_w(self, p, d, x2, bias=None):
         self.pend_w.setdefault(id(p), (p, []))[1].append((d, x2))
@@ -87,13 +110,16 @@ class StepScope(object):
         parameter elsewhere, e.g. a norm regulariser)"""
         L = lib.load()
         done, fused_b = [], set()
+        seen, params = set(), []
+        for p in [e[0] for e in self.pend_w.values()] + [e[0] for e in self.pend_b.values()]:
+            if id(p) not in seen:
+                seen.add(id(p)); params.append(p)
+        self._layout(params)
         for p, pairs in self.pend_w.values():
             pairs = [(d, x) for d, x in pairs if d.shape[0]]
             buf = self.grad_buffer(p)
             N, K = p.shape
-            if not pairs:
-                buf.zero_()
-            else:
+            if pairs:
                 d = pairs[0][0] if len(pairs) == 1 else torch.cat([a for a, _ in pairs], 0)
                 x = pairs[0][1] if len(pairs) == 1 else torch.cat([b for _, b in pairs], 0)
                 # the bias of the same nn.Linear, parked with exactly these dY tensors: its column sum comes out of the same launch
@@ -101,13 +127,13 @@ class StepScope(object):
                 bent = self.pend_b.get(id(bp)) if bp is not None else None
                 if bent is not None and len(bent[1]) == len(self.pend_w[id(p)][1]) and all(a is b_[0] for a, b_ in zip(bent[1], self.pend_w[id(p)][1])):
                     bbuf = self.grad_buffer(bp)
-                    lib.check(L.nir_linear_wgrad_bias_set_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, lib.ptr(bbuf), d.shape[0], N, K,
-                                                              lib.stream()), "nir_linear_wgrad_bias_set_f32")
+                    lib.check(L.nir_linear_wgrad_bias_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, lib.ptr(bbuf), d.shape[0], N, K,
+                                                          lib.stream()), "nir_linear_wgrad_bias_f32")
                     done.append((bp, bbuf))
                     fused_b.add(id(bp))
                 else:
-                    lib.check(L.nir_linear_wgrad_set_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, d.shape[0], N, K, lib.stream()),
-                              "nir_linear_wgrad_set_f32")
+                    lib.check(L.nir_linear_wgrad_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, d.shape[0], N, K, lib.stream()),
+                              "nir_linear_wgrad_f32")
             done.append((p, buf))
         for p, ds in self.pend_b.values():
             if id(p) in fused_b:
@@ -115,11 +141,9 @@ class StepScope(object):
             ds = [d for d in ds if d.shape[0]]
             buf = self.grad_buffer(p)
             N = p.shape[0]
-            if not ds:
-                buf.zero_()
-            else:
+            if ds:
                 d = ds[0] if len(ds) == 1 else torch.cat(ds, 0)
-                lib.check(L.nir_colsum_set_f32(lib.ptr(d), N, d.shape[0], N, lib.ptr(buf), lib.stream()), "nir_colsum_set_f32")
+                lib.check(L.nir_colsum_f32(lib.ptr(d), N, d.shape[0], N, lib.ptr(buf), lib.stream()), "nir_colsum_f32")
             done.append((p, buf))
         for p, buf in done:
             if p.grad is None:

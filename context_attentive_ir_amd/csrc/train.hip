@@ -1301,6 +1301,11 @@ extern "C" int nir_linear_wgrad_set_f32(const float* dy, int64_t lddy, const flo
     return wgrad_impl(dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, true, (hipStream_t)stream);
 }
 
+extern "C" int nir_linear_wgrad_bias_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                                         float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream) {
+    NIR_REQUIRE(db != nullptr, "linear_wgrad_bias: null bias gradient");
+    return wgrad_impl(dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, false, (hipStream_t)stream, db);
+}
 extern "C" int nir_linear_wgrad_bias_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
                                              float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream) {
     NIR_REQUIRE(db != nullptr, "linear_wgrad_bias: null bias gradient");

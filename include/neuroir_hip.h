@@ -556,6 +556,9 @@ int nir_linear_wgrad_set_f32(const float* dy, int64_t lddy, const float* x, int6
  * replaces nir_linear_wgrad_set_f32 + nir_colsum_set_f32 of one nn.Linear (models/ranker.py:216 loss.backward()). */
 int nir_linear_wgrad_bias_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
                                   float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream);
+/* the accumulating form (dW += .., db += ..): a training step zero-fills ALL its parameter-gradient buffers with one memset (autograd.StepScope) */
+int nir_linear_wgrad_bias_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
+                              float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream);
 /* Row list of a padded sequence batch: rows = { m T + t : t_begin <= t < min(lengths[m], T) } in (m, t) order (int32, room for M T entries),
  * offs[m] = start of sequence m's rows, offs[M] = the number of rows -- all on the device, no host synchronisation.  The reference reaches the
  * same set through pack_padded_sequence (neuroir/encoders/rnn_encoder.py, modules/layers). */
