@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void mt_conv3_bwd_data_kernel(MtConvArgs p) {
 // all lanes of the wave -- a scalar load.  45 NF accumulators per lane.  blockIdx.y = one of MT_XS column ranges of the output positions, each with
 // its own partial row (more waves in flight: the scalar loads of a position are otherwise exposed in front of its 90 FMAs).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int MT_XS = 4;
+constexpr int MT_XS = 2;
 template <int NF>
 __global__ __launch_bounds__(192) void mt_conv3_bwd_weight_kernel(MtConvArgs p) {
     extern __shared__ float ts[];                       // [C1][CS], CS = H (W + 1) made odd: lanes are channels, an even stride is a bank conflict

@@ -63,20 +63,25 @@ __device__ __forceinline__ void wgrad_range(const WgradArgs& p, int64_t slice, i
 // form loads two values per MFMA and was load-bound: 0.26 of the fp32 pipe on the [71680] x [1024, 300] gradient of the CARS input projection)
 // RB row pairs per iteration (2 RB reduction rows): the small gradients of a step (M of a few hundred rows, one slice or a few) are bound by the
 // load -> MFMA round trip of each iteration, not by bandwidth -- 1 x 1 blocking takes 32 rows per trip (32 loads in flight per lane)
-template <int NB, int KB, int RB = 8>
+// SH (1 x 1 only): the four waves of a workgroup take four SLICES of the same tile and add their tiles up in LDS before the atomics -- a tiny dW
+// under a long reduction (the [81920] x [20, 18] gradient of MatchTensor's 1x1 convolution: 1 280 slices) otherwise queues a thousand atomics on
+// each of its 360 addresses (78 us for 12 MB of operands).
+template <int NB, int KB, int RB = 8, bool SH = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+    static_assert(!SH || (NB == 1 && KB == 1), "shared-tile mode: one 32 x 32 tile per wave");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt = (p.N + 32 * NB - 1) / (32 * NB), kt = (p.K + 32 * KB - 1) / (32 * KB);
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     const int64_t tiles = (int64_t)nt * kt;
-    const int64_t slice = wid / tiles;
-    const int tile = (int)(wid % tiles);
+    const int64_t slice = SH ? ((int64_t)blockIdx.x / tiles) * 4 + wave : wid / tiles;
+    const int tile = SH ? (int)(blockIdx.x % tiles) : (int)(wid % tiles);
     const int n0 = (tile / kt) * 32 * NB, k0 = (tile % kt) * 32 * KB;
     int64_t ms, me;
     wgrad_range(p, slice, ms, me);
     if (ms >= me) {
         if (p.store && p.mcount && slice == 0) me = ms = 0;           // (an empty row list in "=" mode still writes its zeros; slice 0 only:
                                                                      // the spare waves of the last workgroup have slice >= slices)
+        else if (SH) me = ms = 0;                                    // (stays for the workgroup's reduction with a zero tile)
         else return;
     }
     const int half = lane >> 5;
@@ -125,6 +130,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
                 for (int u = 0; u < RB; u += 4) bs[i] += (a[i][u] + a[i][u + 1]) + (a[i][u + 2] + a[i][u + 3]);
         }
+    }
+    if constexpr (SH) {
+        if (!p.store) {                                  // (store mode = one slice: its wave writes alone, below)
+            __shared__ float red[4][17][64];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[0][0][r];
+            red[wave][16][lane] = bs[0];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                // wave w adds up accumulator registers 4 w .. 4 w + 3 of the four tiles
+                const int r = 4 * wave + q;
+                const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+                const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (nn < p.N && kv[0]) atomicAdd(p.dw + (int64_t)nn * p.lddw + k[0], v);
+            }
+            if (wave == 0 && p.db != nullptr && k0 == 0) {
+                float t = (red[0][16][lane] + red[1][16][lane]) + (red[2][16][lane] + red[3][16][lane]);
+                t += __shfl_xor(t, 32);
+                if (half == 0 && nv[0]) atomicAdd(p.db + n[0], t);
+            }
+            return;
+        }
+        if (me == ms && !(p.mcount && slice == 0)) return;
     }
     if (do_db) {                                        // lanes l and l + 32 hold the even / odd rows of column n
 #pragma unroll
@@ -1288,6 +1316,8 @@ static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx
     WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store, db, rl.rows, rl.mcount, rl.dyd, rl.xd, (int)slices, rl.period > 1 ? (unsigned)((((uint64_t)1 << 32) + rl.period - 1) / rl.period) : 0u, rl.period, rl.skip};
     ProfScope ps(prof_shape_name("wgrad_kernel", M, N, K), st);
     if (big) hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
+    else if (slices >= 8 && tiles <= 64)             // small dW, long reduction: slices of one tile share a workgroup (LDS add before the atomics)
+        hipLaunchKernelGGL((wgrad_kernel<1, 1, 16, true>), dim3((unsigned)(tiles * ((slices + 3) / 4))), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<1, 1, 16>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
     NIR_CHECK_LAUNCH("wgrad_kernel");
     return 0;
