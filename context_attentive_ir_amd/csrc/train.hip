@@ -628,9 +628,12 @@ __global__ __launch_bounds__(512) void lstm_train_bwd_kernel(LstmBwdArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NKS>
-__global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs p) {
-    constexpr int SEQ = 16, NTW = 2;                       // unit tiles per wave
+// NTW = unit tiles per wave: 2 -> 4 waves (one per SIMD, W_hh fragments fill half the register file); 1 -> 8 waves, two per SIMD with 256
+// registers each (round 5: with 256 of 512 registers in fragments the prefetched cell inputs of the 4-wave form aliased the registers the
+// gate-gradient stores read from, and the compiler waited for the stores before issuing the prefetch -- 2.8 us of every 8.9 us step)
+template <int NKS, int NTW = 2>
+__global__ __launch_bounds__(512 / NTW, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs p) {
+    constexpr int SEQ = 16, NTH = 512 / NTW, NWV = 8 / NTW;
     constexpr int HP = NKS;                                // padded hidden size (k-steps per gate x 4 ... = 4 * HP / 4)
     constexpr int RS = NKS + 4;                            // LDS row stride in floats: with NKS (a multiple of 64 banks at H = 128) every lane of a
                                                            // ds_read_b128 hit the same four banks -- 7 us of the 17 us step
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs
         }
         lens_s[tid] = l;
     }
-    for (int e = tid; e < 2 * SEQ * 4 * RS; e += 256) dgs[e] = 0.f;
+    for (int e = tid; e < 2 * SEQ * 4 * RS; e += NTH) dgs[e] = 0.f;
     __syncthreads();
     int tmax = 0;
 #pragma unroll
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(256, 1) void lstm_train_bwd_mfma_kernel(LstmBwdArgs
     // zero the gate gradients of the padded steps: one wave per (sequence, step) row, coalesced
     __syncthreads();
     for (int s_ = 0; s_ < SEQ && m0 + s_ < p.M; ++s_)
-        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += 4) {
+        for (int t2 = lens_s[s_] + wave; t2 < T; t2 += NWV) {
             float* o = p.dgates + ((m0 + s_) * T + t2) * (int64_t)(ND * H4) + dir * H4;
             for (int col = lane; col < H4; col += 64) o[col] = 0.f;
         }
@@ -1435,7 +1438,13 @@ extern "C" int nir_lstm_train_bwd(const float* dout, const float* dhn, const flo
         ProfScope ps(prof_shape_name("lstm_train_bwd_mfma_kernel", M, T, H), (hipStream_t)stream);
         const dim3 grid((unsigned)((M + 15) / 16), (unsigned)ndir);
         hipStream_t st = (hipStream_t)stream;
-        if (hp == 32) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<32>, grid, dim3(256), ldm, st, a);
+        // more than four unit tiles: eight waves x one tile (tunable lstm_bwd_w8 = 2: the four-wave form; bit-identical results) -- C3 documents
+        // 566 -> 443 us, MatchTensor's H = 70 418 -> 372 us
+        const bool w8 = tun(g_tun.lstm_bwd_w8) != 2;
+        if (hp == 128 && w8) hipLaunchKernelGGL((lstm_train_bwd_mfma_kernel<128, 1>), grid, dim3(512), ldm, st, a);
+        else if (hp == 96 && w8) hipLaunchKernelGGL((lstm_train_bwd_mfma_kernel<96, 1>), grid, dim3(512), ldm, st, a);
+        else if (hp == 72 && w8) hipLaunchKernelGGL((lstm_train_bwd_mfma_kernel<72, 1>), grid, dim3(512), ldm, st, a);
+        else if (hp == 32) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<32>, grid, dim3(256), ldm, st, a);
         else if (hp == 64) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<64>, grid, dim3(256), ldm, st, a);
         else if (hp == 72) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<72>, grid, dim3(256), ldm, st, a);
         else if (hp == 96) hipLaunchKernelGGL(lstm_train_bwd_mfma_kernel<96>, grid, dim3(256), ldm, st, a);

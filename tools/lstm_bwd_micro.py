@@ -9,6 +9,7 @@ import json
 import os
 import sys
 
+os.environ.setdefault("NIR_DEBUG_TUNABLES", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,10 +24,12 @@ def main():
     ap.add_argument("--nd", type=int, default=2)
     ap.add_argument("--lib", default="")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--w8", type=int, default=0, help="tunable lstm_bwd_w8: 2 = the four-wave x two-tile form")
     a = ap.parse_args()
     if a.lib:
         lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "context_attentive_ir_amd", "libneuroir_hip_%s.so" % a.lib)
     L = lib.load()
+    L.nir_debug_set_tunable(b"lstm_bwd_w8", a.w8)
     M, T, H, nd = a.M, a.T, a.H, a.nd
     g = torch.Generator(device="cuda").manual_seed(0)
     r = lambda *s: torch.rand(*s, device="cuda", generator=g)
@@ -45,7 +48,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.iters * 1e3
-    print(json.dumps({"lib": a.lib or "product", "M": M, "T": T, "H": H, "nd": nd, "us": round(us, 1), "us_per_step": round(us / T, 2),
+    print(json.dumps({"lib": a.lib or "product", "w8": a.w8, "M": M, "T": T, "H": H, "nd": nd, "us": round(us, 1), "us_per_step": round(us / T, 2),
                       "checksum": float(dg.abs().sum())}))
 
 
