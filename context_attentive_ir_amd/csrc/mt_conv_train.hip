@@ -31,11 +31,11 @@ struct MtConvArgs {
 // forward: one thread per position (m, y, x), 3 NF accumulators; per input channel the 3 x 7 window is read once (the 3x3 and 3x5
 // filters see its middle columns) and meets the channel's 45 NF taps from SGPRs
 // ---------------------------------------------------------------------------------------------------------------------
-// blockIdx.y = output group j: filters o = j NF/3 .. of every size (one position per thread is 1 280 waves at the C2 shape -- barely one per
-// SIMD, every scalar / vector load wait exposed; three groups triple the waves and cut each one's chain to a third, with no reduction)
-template <int NF>
+// blockIdx.y = output group j: filters o = j NG .. of every size (one position per thread with all 3 NF outputs is 1 280 waves at the C2 shape --
+// barely one per SIMD, every scalar / vector load wait exposed: 240 us; three groups 130 us, six groups (NG = 1) 114 us; staging the tile in LDS
+// instead of reading the windows through L1: 182 us -- the waits are the per-channel scalar tap loads, not the window)
+template <int NF, int NG>
 __global__ __launch_bounds__(256) void mt_conv3_fwd_kernel(MtConvArgs p) {
-    constexpr int NG = NF / 3;
     const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int o0 = blockIdx.y * NG;
     const int HW = p.H * p.W;
@@ -106,11 +106,11 @@ __global__ void mt_conv3_pack_wt_kernel(const float* __restrict__ w1, const floa
 }
 
 // (blockIdx.y = channel group of CG = C1 / 3 channels: three times the waves, a third of the accumulators and FMAs each, no reduction)
-template <int NF, int C1>
+template <int NF, int C1, int CG>
 __global__ __launch_bounds__(256) void mt_conv3_bwd_data_kernel(MtConvArgs p) {
     extern __shared__ float dps[];                      // [H W][3 NF + 1]
-    static_assert(C1 % 3 == 0, "channel groups");
-    constexpr int LD = 3 * NF + 1, C1P = (C1 + 3) / 4 * 4, CG = C1 / 3;
+    static_assert(C1 % CG == 0, "channel groups");
+    constexpr int LD = 3 * NF + 1, C1P = (C1 + 3) / 4 * 4;
     const int c0 = blockIdx.y * CG;
     const int HW = p.H * p.W;
     const int64_t m = blockIdx.x;
@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256) void mt_conv3_bwd_data_kernel(MtConvArgs p) {
 // its own partial row (more waves in flight: the scalar loads of a position are otherwise exposed in front of its 90 FMAs).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MT_XS = 2;
+#ifndef MT_CG
+#define MT_CG 17          // channels per workgroup of the data gradient (3 groups; 17 groups of 3 measured: 186 against 140 us)
+#endif
 template <int NF>
 __global__ __launch_bounds__(192) void mt_conv3_bwd_weight_kernel(MtConvArgs p) {
     extern __shared__ float ts[];                       // [C1][CS], CS = H (W + 1) made odd: lanes are channels, an even stride is a bank conflict
@@ -245,7 +248,7 @@ extern "C" int nir_mt_conv3_fwd(const float* T, const float* w1, const float* b1
     MtConvArgs a{};
     a.T = T; a.w[0] = w1; a.w[1] = w2; a.w[2] = w3; a.b[0] = b1; a.b[1] = b2; a.b[2] = b3; a.out = out; a.M = M; a.C1 = C1; a.H = H; a.W = W;
     ProfScope ps(prof_shape_name("mt_conv3_fwd_kernel", M * H * W, 3 * NF, C1 * 45), (hipStream_t)stream);
-    hipLaunchKernelGGL(mt_conv3_fwd_kernel<6>, dim3((unsigned)((M * H * W + 255) / 256), 3), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((mt_conv3_fwd_kernel<6, 1>), dim3((unsigned)((M * H * W + 255) / 256), 6), dim3(256), 0, (hipStream_t)stream, a);
     NIR_CHECK_LAUNCH("mt_conv3_fwd_kernel");
     return 0;
 }
@@ -269,7 +272,7 @@ extern "C" int nir_mt_conv3_bwd(const float* dpre, const float* T, const float* 
         NIR_CHECK_LAUNCH("mt_conv3_pack_wt_kernel");
         a.wt = wt_workspace;
         ProfScope ps(prof_shape_name("mt_conv3_bwd_data_kernel", M * H * W, C1, 3 * NF * 15), st);
-        hipLaunchKernelGGL((mt_conv3_bwd_data_kernel<6, 51>), dim3((unsigned)M, 3), dim3(256), (size_t)H * W * (3 * NF + 1) * 4, st, a);
+        hipLaunchKernelGGL((mt_conv3_bwd_data_kernel<6, 51, MT_CG>), dim3((unsigned)M, 51 / MT_CG), dim3(256), (size_t)H * W * (3 * NF + 1) * 4, st, a);
         NIR_CHECK_LAUNCH("mt_conv3_bwd_data_kernel");
     }
     if (partial) {
