@@ -174,7 +174,7 @@ def kernel_work(name, c, pairs_per_launch=None):
     if base == "mt_head_kernel":
         C = 50
         return dict(flops=pairs * QL * DL * 2.0 * (15 * C * 6 + 45 * 6 + 18 * 20), bytes=pairs * DL * (C * 4 + 8.0) + pairs * 4, terms=3, pipe=F16)
-    if base.startswith("wgrad_kernel"):               # dW = dY^T X on the f32 MFMA (csrc/train.hip): M rows reduced, [N, K] output
+    if base.startswith("wgrad_kernel") or base.startswith("wgrad_lds_kernel"):     # dW = dY^T X on the f32 MFMA (csrc/train.hip): M rows reduced, [N, K] output
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * N + M * K + N * K), terms=1, pipe=F32)
     if base.startswith("lstm_train_fwd_kernel") or base.startswith("lstm_train_bwd_kernel") or base.startswith("lstm_train_bwd_mfma_kernel"):
         # M sequences, N = T steps, K = H units, both directions: the recurrent product h W_hh^T (forward) / W_hh^T dg (BPTT), f32 MFMA

@@ -444,6 +444,8 @@ def softmax_pool(logits, mask, values, mask_div=1):
     T = logits.shape[-1]
     z = logits.reshape(-1, T)
     R = z.shape[0]
+    if R == 0 or values.shape[0] == 0:                       # empty batch: nothing to launch (differentiable zeros of the right shape)
+        return z.sum(1, keepdim=True) * values.sum((0, 1)).unsqueeze(0)
     G = R // values.shape[0]
     if G * T * 8 > 64 * 1024 or T > 8192 or R % max(1, values.shape[0]):
         raise NotImplementedError("softmax_pool: G T <= 8192 (got G = %d, T = %d)" % (G, T))
@@ -770,7 +772,7 @@ class _LSTMSeq(Function):
         act = torch.empty(M, T, G, device=dev)
         gh = torch.empty(M, G, device=dev)
         st = lib.stream()
-        for t in range(T):
+        for t in range(T if M else 0):                       # (an empty batch launches nothing)
             hp, ldh = (h0c, H) if t == 0 else (_off(hs, (t - 1) * H * 4), T * H)
             have_h = M > 0 and (t > 0 or h0c is not None)
             if have_h:
@@ -800,7 +802,7 @@ class _LSTMSeq(Function):
         need_h0 = ctx.has_h0 and ctx.needs_input_grad[3]
         dh_rec = dc_rec = None
         keep = []                                              # (buffers stay referenced until their launches are enqueued)
-        for t in range(T - 1, -1, -1):
+        for t in range(T - 1 if M else -1, -1, -1):
             cp, ldcp = (_off(cs, (t - 1) * H * 4), T * H) if t > 0 else ((lib.ptr(c0), H) if ctx.has_c0 else (None, 0))
             dcn = torch.empty(M, H, device=dev)
             lib.check(L.nir_lstm_cell_seq_bwd(_off(d1, t * H * 4) if d1 is not None else None, T * H, lib.ptr(dh_rec),
@@ -827,6 +829,9 @@ class _LSTMSeq(Function):
                     lib.check(L.nir_linear_wgrad_f32(lib.ptr(dgx), T * G, lib.ptr(h0), H, None, None, 0, lib.ptr(dw), H, M, G, H, st), "nir_linear_wgrad_f32")
             else:
                 dw.zero_(); db.zero_()
+        if M == 0:
+            dh_rec = torch.zeros(0, H, device=dev) if need_h0 else None
+            dc_rec = torch.zeros(0, H, device=dev)
         return dgx, dw, db, (dh_rec if need_h0 else None), (dc_rec if ctx.has_c0 and ctx.needs_input_grad[4] else None)
 
 

@@ -189,6 +189,44 @@ def test_softmax_pool_matches_masked_softmax_weighted_sum(V0, G, T_, D, mode):
     _rel(out, ref.float(), 2e-5); _rel(zd.grad, z.grad.float()); _rel(vd.grad, v.grad.float())
 
 
+def test_round5_training_ops_on_degenerate_shapes():
+    """Empty and one-element edges of the round-5 operators: T = 1 sequences (no previous state anywhere), empty batches, all-PAD targets,
+    a single attention position -- values against torch ops, gradients finite and of the right shape."""
+    from context_attentive_ir_amd import autograd as A
+    from context_attentive_ir_amd.detinit import fill_module_
+    g = torch.Generator().manual_seed(5)
+    # _LSTMSeq with T = 1 and no initial state: dW_hh must be exactly zero, db_hh = column sum of the gate gradients
+    lstm = fill_module_(torch.nn.LSTM(6, 8, 1, batch_first=True), seed=3).to(DEV)
+    x = torch.randn(5, 1, 6, generator=g).to(DEV).requires_grad_(True)
+    h, c = A.lstm_seq(x, lstm)
+    ref_h, (_, ref_c) = lstm(x.detach())
+    _rel(h, ref_h, 2e-5); _rel(c[:, 0], ref_c[0], 2e-5)
+    (h.sum() + c.sum()).backward()
+    assert float(lstm.weight_hh_l0.grad.abs().max()) == 0.0 and torch.isfinite(x.grad).all()
+    # empty batch through the sequence function and the attention op
+    h0, c0 = A.lstm_seq(torch.zeros(0, 3, 6, device=DEV), lstm)
+    assert h0.shape == (0, 3, 8) and c0.shape == (0, 3, 8)
+    out = A.softmax_pool(torch.zeros(0, 4, device=DEV), None, torch.zeros(0, 4, 7, device=DEV))
+    assert out.shape == (0, 7)
+    # one attention position: the weight is 1, the gradient of the logit 0
+    z = torch.randn(3, 1, generator=g).to(DEV).requires_grad_(True); v = torch.randn(3, 1, 5, generator=g).to(DEV).requires_grad_(True)
+    o = A.softmax_pool(z, None, v)
+    o.sum().backward()
+    assert torch.equal(o, v.detach()[:, 0]) and float(z.grad.abs().max()) == 0.0 and torch.equal(v.grad, torch.ones_like(v))
+    # all targets PAD: zero NLL, zero gradient from it; the entropy term still flows
+    lg = torch.randn(2, 3, 11, generator=g).to(DEV).requires_grad_(True)
+    t = torch.zeros(2, 3, dtype=torch.int64, device=DEV)
+    l0 = A.suggestion_loss(lg, t, 0, 0.0)
+    l0.backward()
+    assert float(l0) == 0.0 and float(lg.grad.abs().max()) == 0.0
+    # weight gradient over zero rows: "=" form writes zeros
+    from context_attentive_ir_amd import lib
+    L = lib.load()
+    dw = torch.full((8, 8), float("nan"), device=DEV); db = torch.full((8,), float("nan"), device=DEV)
+    lib.check(L.nir_linear_wgrad_bias_set_f32(lib.ptr(dw), 8, lib.ptr(dw), 8, None, None, 0, lib.ptr(dw), 8, lib.ptr(db), 0, 8, 8, lib.stream()), "wgrad")
+    assert float(dw.abs().max()) == 0.0 and float(db.abs().max()) == 0.0
+
+
 def test_embed_backward_skips_pad_and_accumulates():
     from context_attentive_ir_amd import autograd as A
     V, E = 30, 8
