@@ -1403,6 +1403,9 @@ def run_records(args, env):
         torch.cuda.empty_cache()
         sub["train_C3_cars_update"] = train_record("CARS", dict(head), args, env)
         sub["train_C2_match_tensor_update"] = train_record("MATCH_TENSOR", dict(CONFIGS["C2_match_tensor"]), args, env)
+        # the other two session models on the same session shape (Multitask.update of M_MATCH_TENSOR / MNSRF: models/multitask.py:161-223)
+        sub["train_X3_m_match_tensor_update"] = train_record("M_MATCH_TENSOR", dict(CONFIGS["X3_m_match_tensor"]), args, env, steps=8)
+        sub["train_X3_mnsrf_update"] = train_record("MNSRF", dict(CONFIGS["X3_mnsrf"]), args, env, steps=8)
     eff_world = int(os.environ.get("BENCH_EMULATE_WORLD", env.world)) if env.multi else 1      # (emulation: one process times rank 0's share of W)
     if head["model"] == "cars" and full and env.multi and eff_world > 1:
         # the SAME record on the other CARS shard axis (rank 0 holds its own axis name, every rank takes part) and -- when the per-rank macro-batch policy
@@ -1670,8 +1673,8 @@ def train_record(kind, c, args, env, steps=12):
         L = lib.load()
         V = c["vocab"]
         extra = dict(optimizer="adam", learning_rate=0.001, weight_decay=0, momentum=0, grad_clipping=10.0, fix_embeddings=True)
-        if kind == "CARS":
-            w = Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=30000, **extra))
+        if kind in ("CARS", "MNSRF", "M_MATCH_TENSOR"):
+            w = Multitask(default_args(kind, src_vocab_size=V, tgt_vocab_size=30000, **extra))
         else:
             w = Ranker(default_args(kind, src_vocab_size=V, **extra))
         fill_module_(w.network, 1013)
@@ -1679,7 +1682,7 @@ def train_record(kind, c, args, env, steps=12):
         w.init_optimizer()
         w.id_check_interval = 0
         batches = make_batches(c, 4, 0, env.dev)
-        if kind == "CARS":                      # teacher-forcing targets: the next query of the session, [BOS w.. EOS] (multitask/vector.py:82-149)
+        if kind in ("CARS", "MNSRF", "M_MATCH_TENSOR"):     # teacher-forcing targets: the next query of the session, [BOS w.. EOS] (multitask/vector.py:82-149)
             for b in batches:
                 src = b["source_words"][:, 1:]                                                     # [B,S-1,QL]
                 B_, S1, QL = src.shape
@@ -1723,9 +1726,9 @@ def train_record(kind, c, args, env, steps=12):
         for line in buf.value.decode().strip().splitlines():
             kname, cnt, ms = line.rsplit(",", 2)
             kern[kname] = (int(cnt), float(ms))
-        pairs = c["batch"] * c["cands"] * (c.get("session", 1) if kind == "CARS" else 1)
+        pairs = c["batch"] * c["cands"] * (c.get("session", 1) if kind in ("CARS", "MNSRF", "M_MATCH_TENSOR") else 1)
         rec = {"workload": "%s.update on the %s batch shape (train-mode forward + loss + backward + clip + Adam, default dropouts), %s" % (
-                   "Multitask" if kind == "CARS" else "Ranker", c.get("baseline", "")[:11],
+                   "Multitask" if kind in ("CARS", "MNSRF", "M_MATCH_TENSOR") else "Ranker", c.get("baseline", "")[:11],
                    "one hipGraph per step (wrappers.GraphedUpdate)" if graphed else "eager"),
                "ms_per_step": round(dt * 1e3, 4), "updates_per_s": round(1.0 / dt, 2), "pairs_per_s": round(pairs / dt, 1), "dtype": "f32",
                "hipgraph": graphed, "eager_ms_per_step": round(dt_eager * 1e3, 4),

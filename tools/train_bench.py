@@ -18,9 +18,12 @@ def main():
     args = bench.parse()
     env = bench.Env(1)
     head = dict(bench.CONFIGS[bench.HEADLINE])
-    for name, kind, c in (("train_C3_cars_update", "CARS", head), ("train_C2_match_tensor_update", "MATCH_TENSOR", dict(bench.CONFIGS["C2_match_tensor"]))):
+    recs = [("train_C3_cars_update", "CARS", head), ("train_C2_match_tensor_update", "MATCH_TENSOR", dict(bench.CONFIGS["C2_match_tensor"]))]
+    if os.environ.get("TRAIN_ALL"):             # the other two session models on the C3 session shape
+        recs += [("train_X3_mnsrf_update", "MNSRF", dict(bench.CONFIGS["X3_mnsrf"])), ("train_X3_m_match_tensor_update", "M_MATCH_TENSOR", dict(bench.CONFIGS["X3_m_match_tensor"]))]
+    for name, kind, c in recs:
         r = bench.train_record(kind, dict(c), args, env)
-        print(json.dumps({"name": name, **{k: r.get(k) for k in ("ms_per_step", "eager_ms_per_step", "hip_kernel_ms_per_step", "top_kernels_ms_per_step", "error")}}), flush=True)
+        print(json.dumps({"name": name, **{k: r.get(k) for k in ("ms_per_step", "hipgraph", "eager_ms_per_step", "hip_kernel_ms_per_step", "top_kernels_ms_per_step", "error")}}), flush=True)
 
 
 if __name__ == "__main__":
