@@ -155,6 +155,7 @@ class StepScope(object):
 
 STEP = StepScope()
 SPLIT_TRAIN_FWD = True     # _BiLSTM.forward at 64 < H <= 128: the split-fp16 matrix-core recurrence (False: the fp32 MFMA one, any H <= 128)
+CLUSTER_TRAIN_FWD = True   # bilstm at 256 units per direction: forward on the cluster recurrence (False: two unidirectional lstm_seq passes)
 PACKED_WGRAD = False       # _BiLSTM.backward: reduce the weight gradients over a list of the valid (t < length) positions only
 
 
@@ -357,6 +358,9 @@ def check_ids():
         v = int(f.item())
         if v != 0:
             f.zero_()
+            if v & 4:
+                raise RuntimeError("a recurrence cluster (csrc/lstm_cluster.hip) waited ~1 s for a partner workgroup that never became resident; results "
+                                   "of that step are invalid -- autograd.CLUSTER_TRAIN_FWD = False selects the step-by-step recurrence")
             if v & 2:
                 raise RuntimeError("recurrent weights outside the fp16 range of the split-fp16 train-mode recurrence (|w_hh| >= 2^15); results of that "
                                    "step are invalid -- autograd.SPLIT_TRAIN_FWD = False selects the fp32 recurrence")
@@ -676,6 +680,96 @@ class _BiLSTM(Function):
         return (dx, None, None, dh0, dc0) + tuple(grads)
 
 
+_WS256 = {}
+
+
+class _BiLSTM256(Function):
+    """Train-mode encoder with 256 units per direction: x [M,T,I], lens [M] -> memory bank [M,T,ND*256] (zero past each length).  Forward = ONE launch
+    of the four-workgroup cluster recurrence of the predict path with activation / cell-state stores (nir_lstm256_train_fwd; gates in the folded
+    order from one GEMM); backward = BPTT step by step per direction on the sequence buffers (masked cell kernel + one GEMM per step; there is
+    no resident-W_hh BPTT kernel beyond H = 128), weight gradients from the saved states shifted by a row."""
+
+    @staticmethod
+    def forward(ctx, x, lens, nd, *params):
+        lib.require_device(x)
+        L = lib.load()
+        M, T, I = x.shape
+        H = 256
+        dev = x.device
+        ps = [_f32c(t) for t in params]
+        x2 = _f32c(x).reshape(M * T, I)
+        wperm = torch.empty(nd * 4 * H, I, device=dev)
+        bperm = torch.empty(nd * 4 * H, device=dev)
+        lib.check(L.nir_lstm_perm_weights(lib.ptr(ps[0]), lib.ptr(ps[2]), lib.ptr(ps[3]), lib.ptr(ps[4]) if nd == 2 else None,
+                                          lib.ptr(ps[6]) if nd == 2 else None, lib.ptr(ps[7]) if nd == 2 else None, H, nd, I, lib.ptr(wperm), lib.ptr(bperm),
+                                          lib.stream()), "nir_lstm_perm_weights")
+        gates = _linear_raw(x2, wperm, bperm, 0)
+        whh = torch.stack([ps[4 * d + 1] for d in range(nd)], 0).contiguous()
+        frag = torch.empty(L.nir_lstm256_whh_frag_bytes(nd), dtype=torch.uint8, device=dev)
+        flag = id_flag(dev)
+        lib.check(L.nir_lstm256_pack_whh_frag(lib.ptr(whh), nd, lib.ptr(frag), lib.ptr(flag), lib.stream()), "nir_lstm256_pack_whh_frag")
+        key = (int(M), int(nd), str(dev))
+        ws = _WS256.get(key)
+        if ws is None:
+            if len(_WS256) > 8:
+                _WS256.clear()
+            ws = _WS256[key] = torch.empty(L.nir_lstm256_workspace_bytes(M, nd), dtype=torch.uint8, device=dev)
+        lens64 = lib.ids64(lens)
+        out = torch.empty(M, T, nd * H, device=dev)
+        act = torch.empty(M, T, nd, 4 * H, device=dev)
+        cst = torch.empty(M, T, nd, H, device=dev)
+        lib.check(L.nir_lstm256_train_fwd(lib.ptr(gates), lib.ptr(lens64), lib.ptr(frag), lib.ptr(out), lib.ptr(act), lib.ptr(cst), lib.ptr(flag), M, T, nd,
+                                          lib.ptr(ws), ws.numel(), lib.stream()), "nir_lstm256_train_fwd")
+        wih = torch.cat([ps[4 * d] for d in range(nd)], 0) if ctx.needs_input_grad[0] else torch.empty(0)
+        ctx.save_for_backward(x2, lens64, wih, whh, out, act, cst)
+        ctx.nd, ctx.dims = nd, (M, T, I)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, lens64, wih, whh, out, act, cst = ctx.saved_tensors
+        L = lib.load()
+        nd = ctx.nd
+        M, T, I = ctx.dims
+        H, G = 256, nd * 1024
+        dev = x2.device
+        st = lib.stream()
+        d = _f32c(dout)
+        dgx = torch.empty(M, T, G, device=dev)
+        keep = []
+        for dd in range(nd):
+            wt = _transpose(whh[dd])                              # [H, 4H]: dh_prev = dg W_hh
+            dh_rec = dc_rec = None
+            order = range(T - 1, -1, -1) if dd == 0 else range(T)
+            for t in order:
+                tprev = t - 1 if dd == 0 else t + 1               # position of the previous recurrence step
+                cp = _off(cst, ((tprev * nd + dd) * H) * 4) if 0 <= tprev < T else None
+                dcn = torch.empty(M, H, device=dev)
+                lib.check(L.nir_lstm_cell_seq_bwd_masked(_off(d, (t * nd * H + dd * H) * 4), T * nd * H, lib.ptr(dh_rec), lib.ptr(dc_rec),
+                                                         _off(act, ((t * nd + dd) * 4 * H) * 4), T * G, _off(cst, ((t * nd + dd) * H) * 4), T * nd * H, cp,
+                                                         T * nd * H, _off(dgx, (t * G + dd * 4 * H) * 4), T * G, lib.ptr(dcn), lib.ptr(lens64), t, tprev, M, H, st),
+                          "nir_lstm_cell_seq_bwd_masked")
+                keep.append((dh_rec, dc_rec))
+                dc_rec = dcn
+                last = t == 0 if dd == 0 else t == T - 1
+                if not last:
+                    dh_rec = torch.empty(M, H, device=dev)
+                    lib.check(L.nir_linear_f32(_off(dgx, (t * G + dd * 4 * H) * 4), T * G, None, None, 0, 0, 0, lib.ptr(wt), 4 * H, None, None, lib.ptr(dh_rec),
+                                               H, M, H, 4 * H, 0, st), "nir_linear_f32")
+        dg2 = dgx.view(M * T, G)
+        dx = _linear_raw(dg2, _transpose(wih), None, 0).view(M, T, I) if ctx.needs_input_grad[0] else None
+        dwih, db = _wgrad_bias(dg2, G, x2, I, M * T, G, I)
+        o2 = out.view(M * T, nd * H)
+        grads = []
+        for dd in range(nd):
+            dwhh = torch.empty(4 * H, H, device=dev)
+            lib.check(L.nir_linear_wgrad_rows_set_f32(_off(dg2, dd * 4 * H * 4), G, 0, _off(o2, dd * H * 4), nd * H, -1 if dd == 0 else 1, None, None, M * T, T,
+                                                      0 if dd == 0 else T - 1, lib.ptr(dwhh), H, None, 4 * H, H, st), "nir_linear_wgrad_rows_set_f32")
+            sl = slice(dd * 4 * H, (dd + 1) * 4 * H)
+            grads += [dwih[sl], dwhh, db[sl], db[sl].clone()]
+        return (dx, None, None) + tuple(grads)
+
+
 def _lstm_params(lstm):
     sfx = ["", "_reverse"] if lstm.bidirectional else [""]
     params = []
@@ -696,6 +790,9 @@ def bilstm(x, lens, lstm):
     if H <= 128:
         return _BiLSTM.apply(x, lens, nd, None, None, *params)[0]
     M, T, _ = x.shape
+    if H == 256 and CLUSTER_TRAIN_FWD and T <= 1024 and M * T > 0 and M * T < 2 ** 31:
+        ln_ = lens if lens is not None else torch.full((M,), T, device=x.device, dtype=torch.int64)
+        return _BiLSTM256.apply(x, ln_, nd, *params)
     dev = x.device
     ln = lens.to(dev).view(M, 1) if lens is not None else torch.full((M, 1), T, device=dev, dtype=torch.int64)
     pos = torch.arange(T, device=dev).view(1, T)

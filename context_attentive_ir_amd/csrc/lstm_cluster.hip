@@ -42,7 +42,9 @@ struct LstmClArgs {
     const int64_t* ids;           // [M,T] row of every token, or null: row = m*T + t
     const int64_t* lens;          // [M] or null
     const _Float16* wfrag;        // nir_lstm256_pack_whh_frag
-    float* out;                   // MODE 0: [M,T,ND*256] (zeros beyond each length); MODE 1: [M,ND*256] max over all T positions
+    float* out;                   // MODE 0 / 2: [M,T,ND*256] (zeros beyond each length); MODE 1: [M,ND*256] max over all T positions
+    float* act;                   // MODE 2 (train-mode forward): [M,T,ND,4*256] gate activations i,f,g,o (gate-major inside a direction)
+    float* cst;                   //   and [M,T,ND,256] cell states of every valid step (the backward's inputs)
     unsigned long long* xbuf;     // [clusters][NG][2][4][1024] granules, zero at launch
     unsigned long long* hs;       // [clusters][4] handshake words (XCD of every member + 1), zero at launch
     int* err;
@@ -262,6 +264,25 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
     uint32_t gsoff = xsoff(0, 0);
     u32x2 oprev = (u32x2){0u, 0u};                       // MODE 0: the previous phase's output pair and its offset (OOB = dropped)
     uint32_t ooff = OOB;
+    u32x2 aprev[MODE == 2 ? 4 : 1], cprev = (u32x2){0u, 0u};    // MODE 2: the previous phase's gate activations / cell state of the lane's two units
+    uint32_t aoff = OOB;
+    auto act_rsrc = [&](int g) {
+        const int64_t m0g = ((int64_t)cd * NG + g) * SEQ;
+        const int nv = (int)max((int64_t)0, min((int64_t)SEQ, p.M - m0g));
+        return __builtin_amdgcn_make_buffer_rsrc(p.act + (nv > 0 ? m0g : 0) * T * p.ND * H4, 0, (int)((uint32_t)nv * T * p.ND * H4 * 4u), 0x00020000);
+    };
+    auto cst_rsrc = [&](int g) {
+        const int64_t m0g = ((int64_t)cd * NG + g) * SEQ;
+        const int nv = (int)max((int64_t)0, min((int64_t)SEQ, p.M - m0g));
+        return __builtin_amdgcn_make_buffer_rsrc(p.cst + (nv > 0 ? m0g : 0) * T * OW, 0, (int)((uint32_t)nv * T * OW * 4u), 0x00020000);
+    };
+    auto train_stores = [&](int g) {                      // (deferred like the output pair: issued in the next phase, in front of its requests)
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) __builtin_amdgcn_raw_buffer_store_b64(aprev[r], act_rsrc(g), aoff == OOB ? OOB : aoff + (uint32_t)(r * H * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(cprev, cst_rsrc(g), ooff, 0, 0);
+        }
+    };
     auto out_rsrc = [&](int g) {
         const int64_t m0g = ((int64_t)cd * NG + g) * SEQ;
         const int nv = (int)max((int64_t)0, min((int64_t)SEQ, p.M - m0g));
@@ -369,7 +390,8 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
                 if (tid == 0 && p.err) atomicOr(p.err, 4);
                 return;
             }
-            if (MODE == 0) __builtin_amdgcn_raw_buffer_store_b64(oprev, out_rsrc(g > 0 ? g - 1 : NG - 1), ooff, 0, 0);
+            if (MODE == 0 || MODE == 2) __builtin_amdgcn_raw_buffer_store_b64(oprev, out_rsrc(g > 0 ? g - 1 : NG - 1), ooff, 0, 0);
+            train_stores(g > 0 ? g - 1 : NG - 1);
             if (NG < 3 && rank != 0) burst();
             CL_T(2)
             const _Float16* zr = zc + sq * ZLD + 8 * kq;
@@ -396,11 +418,21 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
             if (NG < 3 && rank == 0) burst();
             CL_T(5)
             float hn[NT];
+            float tga[MODE == 2 ? NT : 1][4];
 #pragma unroll
 #ifdef NIR_CL_NOGATES
             for (int t = 0; t < NT; ++t) hn[t] = (acx[t][0] + acc[t][1]) * 1e-3f + creg[g][t];
 #else
-            for (int t = 0; t < NT; ++t) cl_cell(acx[t] * ISC + acc[t], creg[g][t], hn[t]);
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (MODE == 2) {            // the backward needs i, f, g, o themselves, not the merged fractions of cl_cell
+                    const f32x4 x = acx[t] * ISC + acc[t];
+                    tga[t][0] = fast_sigmoid(x[0]); tga[t][1] = fast_sigmoid(x[1]); tga[t][2] = fast_tanh(x[2]); tga[t][3] = fast_sigmoid(x[3]);
+                    creg[g][t] = tga[t][1] * creg[g][t] + tga[t][0] * tga[t][2];
+                    hn[t] = tga[t][3] * fast_tanh(creg[g][t]);
+                } else {
+                    cl_cell(acx[t] * ISC + acc[t], creg[g][t], hn[t]);
+                }
+            }
 #endif
             // the two fp16 terms of the new h: own slice of the next B operand + one 16-byte piece (two self-tagged granules) for the partners
             _Float16 a[NT], r_[NT];
@@ -428,12 +460,23 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
                 const int t_ = dir == 0 ? step : mylen[g] - 1 - step;
                 oprev = (u32x2){__float_as_uint(hn[0]), __float_as_uint(hn[1])};
                 ooff = live ? (uint32_t)(((sq * T + t_) * OW + dir * H + ug) * 4) : OOB;
+                if constexpr (MODE == 2) {
+#ifndef NIR_CL_NOGATES
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aprev[r] = (u32x2){__float_as_uint(tga[0][r]), __float_as_uint(tga[1][r])};
+#endif
+                    cprev = (u32x2){__float_as_uint(creg[g][0]), __float_as_uint(creg[g][1])};
+                    aoff = live ? (uint32_t)((((sq * T + t_) * p.ND + dir) * H4 + ug) * 4) : OOB;
+                }
             }
             CL_T(4)
         }
       }
     }
-    if (MODE == 0 && tmax > 0) __builtin_amdgcn_raw_buffer_store_b64(oprev, out_rsrc(NG - 1), ooff, 0, 0);      // the last phase's output
+    if ((MODE == 0 || MODE == 2) && tmax > 0) {                                                        // the last phase's output
+        __builtin_amdgcn_raw_buffer_store_b64(oprev, out_rsrc(NG - 1), ooff, 0, 0);
+        train_stores(NG - 1);
+    }
 #ifdef NIR_CL_TRACE
     if (tr_on && lane == 0 && g_cl_trace_dev) {
         for (int i = 0; i < 8; ++i) g_cl_trace_dev[i] = tr[i];
@@ -505,17 +548,18 @@ size_t lstm256_xbuf_bytes(int64_t M, int ND) {
 }
 
 // rows [R][ND][256][4] (folded order), ids [M,T] or null, out: mode 0 [M,T,ND*256], mode 1 [M,ND*256]
-int launch_lstm256_cluster(const float* rows, const int64_t* ids, const int64_t* lens, const void* wfrag, float* out, int mode, int* err,
-                           int64_t M, int64_t R, int T, int ND, void* xbuf, size_t xbuf_bytes, hipStream_t st) {
+static int launch_lstm256_cluster_ex(const float* rows, const int64_t* ids, const int64_t* lens, const void* wfrag, float* out, int mode, int* err,
+                                     int64_t M, int64_t R, int T, int ND, void* xbuf, size_t xbuf_bytes, hipStream_t st, float* act, float* cst) {
     NIR_REQUIRE(rows && wfrag && out && xbuf, "lstm256: null pointer");
-    NIR_REQUIRE(M >= 0 && R > 0 && T > 0 && (ND == 1 || ND == 2) && (mode == 0 || mode == 1), "lstm256: bad dims");
+    NIR_REQUIRE(M >= 0 && R > 0 && T > 0 && (ND == 1 || ND == 2) && (mode == 0 || mode == 1 || (mode == 2 && act && cst)), "lstm256: bad dims");
+    NIR_REQUIRE(mode != 2 || (int64_t)CL_SEQ * T * ND * 4 * CL_H * 4 < 0x7FFFFFF0LL, "lstm256: T too large for 32-bit tile offsets of the activation rows");
     NIR_REQUIRE(T <= 1024, "lstm256: sequence length %d > 1024 unsupported", T);
     NIR_REQUIRE(R * (int64_t)ND * 4 * CL_H < ((int64_t)1 << 40) && R < ((int64_t)1 << 31), "lstm256: too many gate rows");
     NIR_REQUIRE(xbuf_bytes >= lstm256_xbuf_bytes(M, ND), "lstm256: exchange buffer too small");
     if (M == 0) return 0;
     const int NG = cl_groups(M, ND, st);
     LstmClArgs a;
-    a.rows = rows; a.ids = ids; a.lens = lens; a.wfrag = (const _Float16*)wfrag; a.out = out; a.xbuf = (unsigned long long*)xbuf; a.err = err;
+    a.rows = rows; a.ids = ids; a.lens = lens; a.wfrag = (const _Float16*)wfrag; a.out = out; a.act = act; a.cst = cst; a.xbuf = (unsigned long long*)xbuf; a.err = err;
     a.M = M; a.R = R; a.T = T; a.ND = ND;
     a.tiles = (int)((M + CL_SEQ - 1) / CL_SEQ);
     a.ncld = (a.tiles + NG - 1) / NG;
@@ -535,18 +579,27 @@ int launch_lstm256_cluster(const float* rows, const int64_t* ids, const int64_t*
         (void)hipFuncSetAttribute((const void*)lstm_cluster_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         (void)hipFuncSetAttribute((const void*)lstm_cluster_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         (void)hipFuncSetAttribute((const void*)lstm_cluster_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)lstm_cluster_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)lstm_cluster_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)lstm_cluster_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     });
-    ProfScope ps(prof_shape_name(mode ? "lstm_cluster_kernel[maxpool]" : "lstm_cluster_kernel", (long long)M, T, CL_H), st);
+    ProfScope ps(prof_shape_name(mode == 2 ? "lstm_cluster_kernel[train]" : mode ? "lstm_cluster_kernel[maxpool]" : "lstm_cluster_kernel", (long long)M, T, CL_H), st);
 #ifdef NIR_CL_TRACE
     { unsigned long long* d = g_debug_buf; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cl_trace_dev), &d, sizeof(d), 0, hipMemcpyHostToDevice, st); }
 #endif
 #define NIR_CL_LAUNCH(ng, md) hipLaunchKernelGGL((lstm_cluster_kernel<ng, md>), dim3(grid), dim3(512), lds, st, a)
-    if (NG == 1) { if (mode) NIR_CL_LAUNCH(1, 1); else NIR_CL_LAUNCH(1, 0); }
-    else if (NG == 2) { if (mode) NIR_CL_LAUNCH(2, 1); else NIR_CL_LAUNCH(2, 0); }
-    else { if (mode) NIR_CL_LAUNCH(3, 1); else NIR_CL_LAUNCH(3, 0); }
+    if (NG == 1) { if (mode == 2) NIR_CL_LAUNCH(1, 2); else if (mode) NIR_CL_LAUNCH(1, 1); else NIR_CL_LAUNCH(1, 0); }
+    else if (NG == 2) { if (mode == 2) NIR_CL_LAUNCH(2, 2); else if (mode) NIR_CL_LAUNCH(2, 1); else NIR_CL_LAUNCH(2, 0); }
+    else { if (mode == 2) NIR_CL_LAUNCH(3, 2); else if (mode) NIR_CL_LAUNCH(3, 1); else NIR_CL_LAUNCH(3, 0); }
 #undef NIR_CL_LAUNCH
     NIR_CHECK_LAUNCH("lstm_cluster_kernel");
     return 0;
+}
+
+int launch_lstm256_cluster(const float* rows, const int64_t* ids, const int64_t* lens, const void* wfrag, float* out, int mode, int* err,
+                           int64_t M, int64_t R, int T, int ND, void* xbuf, size_t xbuf_bytes, hipStream_t st) {
+    NIR_REQUIRE(mode == 0 || mode == 1, "lstm256: bad mode");
+    return launch_lstm256_cluster_ex(rows, ids, lens, wfrag, out, mode, err, M, R, T, ND, xbuf, xbuf_bytes, st, nullptr, nullptr);
 }
 
 }  // namespace nir
@@ -567,4 +620,9 @@ extern "C" int nir_lstm256_rows_fwd(const float* rows, const int64_t* ids, const
                                     nir_stream_t stream) {
     return nir::launch_lstm256_cluster(rows, ids, lengths, whh_frag, out, mode, err_flag, M, R, T, ndir, workspace, workspace_bytes,
                                        (hipStream_t)stream);
+}
+extern "C" int nir_lstm256_train_fwd(const float* gates_perm, const int64_t* lengths, const void* whh_frag, float* out, float* act, float* cst,
+                                     int* err_flag, int64_t M, int T, int ndir, void* workspace, size_t workspace_bytes, nir_stream_t stream) {
+    return nir::launch_lstm256_cluster_ex(gates_perm, nullptr, lengths, whh_frag, out, 2, err_flag, M, M * (int64_t)T, T, ndir, workspace, workspace_bytes,
+                                          (hipStream_t)stream, act, cst);
 }

@@ -1142,14 +1142,26 @@ __global__ void lstm_cell_seq_fwd_kernel(const float* __restrict__ gx, int64_t l
     h[b * ldh + j] = go * tanhf(cn);
 }
 // dh = dh1 (strided, the consumers of this step's h) + dh2 (contiguous, from the next step's recurrent GEMM), dc likewise; any may be NULL
+// (lens != NULL: the step is position t of padded sequences -- a row with t >= lens[b] takes no part: zero gate gradients, zero dc_prev, its
+//  incoming gradients ignored; c_prev exists where 0 <= tprev < lens[b], tprev = the position of the previous recurrence step)
 __global__ void lstm_cell_seq_bwd_kernel(const float* __restrict__ dh1, int64_t ld1, const float* __restrict__ dh2, const float* __restrict__ dc1,
                                          int64_t ldc1, const float* __restrict__ dc2, const float* __restrict__ act, int64_t ldact,
                                          const float* __restrict__ c, int64_t ldc, const float* __restrict__ cprev, int64_t ldcp, float* __restrict__ dg,
-                                         int64_t lddg, float* __restrict__ dcprev, int64_t B, int H) {
+                                         int64_t lddg, float* __restrict__ dcprev, int64_t B, int H, const int64_t* __restrict__ lens, int t, int tprev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H) return;
     const int64_t b = i / H;
     const int j = (int)(i % H);
+    if (lens) {
+        const int64_t l = lens[b];
+        if (t >= l) {
+            float* dr = dg + b * lddg;
+            dr[j] = 0.f; dr[H + j] = 0.f; dr[2 * H + j] = 0.f; dr[3 * H + j] = 0.f;
+            dcprev[i] = 0.f;
+            return;
+        }
+        if (tprev < 0 || tprev >= l) cprev = nullptr;
+    }
     const float* ar = act + b * ldact;
     const float gi = ar[j], gf = ar[H + j], gg = ar[2 * H + j], go = ar[3 * H + j];
     const float th = tanhf(c[b * ldc + j]);
@@ -1536,7 +1548,18 @@ extern "C" int nir_lstm_cell_seq_bwd(const float* dh_step, int64_t ld_dh, const 
     NIR_REQUIRE(act && c && dgates && dc_prev && B >= 0 && H > 0, "lstm_cell_seq_bwd: bad args");
     if (B == 0) return 0;
     hipLaunchKernelGGL(lstm_cell_seq_bwd_kernel, g1(B * H), dim3(256), 0, (hipStream_t)stream, dh_step, ld_dh, dh_rec, dc_step, ld_dc, dc_rec, act, ldact, c,
-                       ldc, c_prev, ldcp, dgates, lddg, dc_prev, B, H);
+                       ldc, c_prev, ldcp, dgates, lddg, dc_prev, B, H, nullptr, 0, 0);
+    NIR_CHECK_LAUNCH("lstm_cell_seq_bwd_kernel");
+    return 0;
+}
+extern "C" int nir_lstm_cell_seq_bwd_masked(const float* dh_step, int64_t ld_dh, const float* dh_rec, const float* dc_rec, const float* act, int64_t ldact,
+                                            const float* c, int64_t ldc, const float* c_prev, int64_t ldcp, float* dgates, int64_t lddg, float* dc_prev,
+                                            const int64_t* lengths, int t, int t_prev, int64_t B, int H, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(act && c && dgates && dc_prev && lengths && B >= 0 && H > 0, "lstm_cell_seq_bwd_masked: bad args");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_seq_bwd_kernel, g1(B * H), dim3(256), 0, (hipStream_t)stream, dh_step, ld_dh, dh_rec, (const float*)nullptr, (int64_t)0, dc_rec,
+                       act, ldact, c, ldc, c_prev, ldcp, dgates, lddg, dc_prev, B, H, lengths, t, t_prev);
     NIR_CHECK_LAUNCH("lstm_cell_seq_bwd_kernel");
     return 0;
 }

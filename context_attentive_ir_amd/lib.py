@@ -97,6 +97,7 @@ SIGNATURES = {
     "nir_lstm256_pack_whh_frag": (_i, [c_fp, _i, C.c_void_p, C.c_void_p, c_st]),
     "nir_lstm256_workspace_bytes": (_z, [_l, _i]),
     "nir_lstm256_rows_fwd": (_i, [c_fp, c_ip, c_ip, C.c_void_p, c_fp, _i, C.c_void_p, _l, _l, _i, _i, C.c_void_p, _z, c_st]),
+    "nir_lstm256_train_fwd": (_i, [c_fp, c_ip, C.c_void_p, c_fp, c_fp, c_fp, C.c_void_p, _l, _i, _i, C.c_void_p, C.c_size_t, c_st]),
     "nir_decode_greedy_plain_workspace_bytes": (_z, [_l, _i, _l]),
     "nir_decode_greedy_plain": (_i, [c_fp, c_fp, _l, _i, c_fp, _l, _i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, c_ip, _l, _i, C.c_void_p, _z, c_ip,
                                      c_st]),
@@ -152,6 +153,7 @@ SIGNATURES = {
     "nir_lstm_cell_bwd": (_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, c_st]),
     "nir_lstm_cell_seq_fwd": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, c_fp, _l, c_fp, _l, c_fp, _l, _l, _i, c_st]),
     "nir_lstm_cell_seq_bwd": (_i, [c_fp, _l, c_fp, c_fp, _l, c_fp, c_fp, _l, c_fp, _l, c_fp, _l, c_fp, _l, c_fp, _l, _i, c_st]),
+    "nir_lstm_cell_seq_bwd_masked": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, c_fp, _l, c_fp, _l, c_fp, _l, c_fp, c_ip, _i, _i, _l, _i, c_st]),
     "nir_dropout_f32": (_i, [c_fp, c_fp, C.c_void_p, _l, C.c_float, C.c_uint64, c_st]),
     "nir_dropout_dev_f32": (_i, [c_fp, c_fp, C.c_void_p, _l, C.c_float, C.c_void_p, C.c_uint64, c_st]),
     "nir_mask_scale_f32": (_i, [c_fp, C.c_void_p, C.c_float, c_fp, _l, c_st]),

@@ -475,6 +475,11 @@ int nir_lstm256_pack_whh_frag(const float* w_hh, int ndir, void* frag, int* err_
 size_t nir_lstm256_workspace_bytes(int64_t M, int ndir);
 int nir_lstm256_rows_fwd(const float* rows, const int64_t* ids, const int64_t* lengths, const void* whh_frag, float* out, int mode,
                          int* err_flag, int64_t M, int64_t R, int T, int ndir, void* workspace, size_t workspace_bytes, nir_stream_t stream);
+/* Train-mode forward of a 256-per-direction encoder on the same cluster recurrence (MODE 2): gates_perm [M*T][ndir][256][4] = x W_ih^T + b in the
+ * folded gate order (nir_lstm_perm_weights + one GEMM), out [M,T,ndir*256] (zero past each length), act [M,T,ndir,1024] gate activations i,f,g,o
+ * and cst [M,T,ndir,256] cell states of every valid step -- the inputs of the backward pass (autograd._BiLSTM256).  err_flag as above. */
+int nir_lstm256_train_fwd(const float* gates_perm, const int64_t* lengths, const void* whh_frag, float* out, float* act, float* cst,
+                          int* err_flag, int64_t M, int T, int ndir, void* workspace, size_t workspace_bytes, nir_stream_t stream);
 
 /* The same streaming recurrence for either cell of the reference's RNNEncoder (rnn_encoder.py:28-60: getattr(nn, rnn_type), one module per
  * layer): NIR_CELL_LSTM = nir_bilstm_steps_fwd; NIR_CELL_GRU: torch.nn.GRU semantics, gate order (r, z, n), gates_in = x W_ih^T + b_ih
@@ -607,6 +612,11 @@ int nir_lstm_cell_seq_fwd(const float* gx, int64_t ldgx, const float* gh, const 
 int nir_lstm_cell_seq_bwd(const float* dh_step, int64_t ld_dh, const float* dh_rec, const float* dc_step, int64_t ld_dc, const float* dc_rec,
                           const float* act, int64_t ldact, const float* c, int64_t ldc, const float* c_prev, int64_t ldcp, float* dgates,
                           int64_t lddg, float* dc_prev, int64_t B, int H, nir_stream_t stream);
+/* The same step at position t of PADDED sequences (autograd._BiLSTM256): a row with t >= lengths[b] takes no part (zero gate gradients and
+ * dc_prev, incoming gradients ignored); c_prev counts where 0 <= t_prev < lengths[b] (t_prev = position of the previous recurrence step). */
+int nir_lstm_cell_seq_bwd_masked(const float* dh_step, int64_t ld_dh, const float* dh_rec, const float* dc_rec, const float* act, int64_t ldact,
+                                 const float* c, int64_t ldc, const float* c_prev, int64_t ldcp, float* dgates, int64_t lddg, float* dc_prev,
+                                 const int64_t* lengths, int t, int t_prev, int64_t B, int H, nir_stream_t stream);
 /* Inverted dropout with a counter-based mask: keep[i] = uniform(splitmix64(seed ^ i*c)) >= p, y = x*keep/(1-p).  The mask is an
  * output so that a parity test can replay it through the oracle. */
 int nir_dropout_f32(const float* x, float* y, unsigned char* keep, int64_t n, float p, uint64_t seed, nir_stream_t stream);
