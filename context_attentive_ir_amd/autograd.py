@@ -156,6 +156,7 @@ class StepScope(object):
 STEP = StepScope()
 SPLIT_TRAIN_FWD = True     # _BiLSTM.forward at 64 < H <= 128: the split-fp16 matrix-core recurrence (False: the fp32 MFMA one, any H <= 128)
 CLUSTER_TRAIN_FWD = True   # bilstm at 256 units per direction: forward on the cluster recurrence (False: two unidirectional lstm_seq passes)
+TWO_STREAM_BPTT = True     # _BiLSTM256.backward: the reverse direction's step chain on a side stream
 PACKED_WGRAD = False       # _BiLSTM.backward: reduce the weight gradients over a list of the valid (t < length) positions only
 
 
@@ -682,6 +683,16 @@ class _BiLSTM(Function):
 
 _WS256 = {}
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(str(dev))
+    if s is None:
+        s = _SIDE[str(dev)] = torch.cuda.Stream(device=dev)
+    return s
+
+
 
 class _BiLSTM256(Function):
     """Train-mode encoder with 256 units per direction: x [M,T,I], lens [M] -> memory bank [M,T,ND*256] (zero past each length).  Forward = ONE launch
@@ -737,25 +748,36 @@ class _BiLSTM256(Function):
         d = _f32c(dout)
         dgx = torch.empty(M, T, G, device=dev)
         keep = []
+        # the two directions are independent chains of 2 T small launches each (a [M,256] x [256,1024] GEMM is latency-bound): the reverse
+        # direction runs on a side stream (forked / joined through events: inside a captured step two branches of the graph).  Everything both
+        # streams touch (dgx, the saved tensors) was allocated before the fork; the side stream's temporaries live and die there.
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if (nd == 2 and TWO_STREAM_BPTT) else None
+        wts = [_transpose(whh[dd]) for dd in range(nd)]          # [H, 4H]: dh_prev = dg W_hh
+        if side is not None:
+            side.wait_stream(main)
         for dd in range(nd):
-            wt = _transpose(whh[dd])                              # [H, 4H]: dh_prev = dg W_hh
-            dh_rec = dc_rec = None
-            order = range(T - 1, -1, -1) if dd == 0 else range(T)
-            for t in order:
-                tprev = t - 1 if dd == 0 else t + 1               # position of the previous recurrence step
-                cp = _off(cst, ((tprev * nd + dd) * H) * 4) if 0 <= tprev < T else None
-                dcn = torch.empty(M, H, device=dev)
-                lib.check(L.nir_lstm_cell_seq_bwd_masked(_off(d, (t * nd * H + dd * H) * 4), T * nd * H, lib.ptr(dh_rec), lib.ptr(dc_rec),
-                                                         _off(act, ((t * nd + dd) * 4 * H) * 4), T * G, _off(cst, ((t * nd + dd) * H) * 4), T * nd * H, cp,
-                                                         T * nd * H, _off(dgx, (t * G + dd * 4 * H) * 4), T * G, lib.ptr(dcn), lib.ptr(lens64), t, tprev, M, H, st),
-                          "nir_lstm_cell_seq_bwd_masked")
-                keep.append((dh_rec, dc_rec))
-                dc_rec = dcn
-                last = t == 0 if dd == 0 else t == T - 1
-                if not last:
-                    dh_rec = torch.empty(M, H, device=dev)
-                    lib.check(L.nir_linear_f32(_off(dgx, (t * G + dd * 4 * H) * 4), T * G, None, None, 0, 0, 0, lib.ptr(wt), 4 * H, None, None, lib.ptr(dh_rec),
-                                               H, M, H, 4 * H, 0, st), "nir_linear_f32")
+            with torch.cuda.stream(side if (side is not None and dd == 1) else main):
+                st = lib.stream()
+                wt = wts[dd]
+                dh_rec = dc_rec = None
+                for t in (range(T - 1, -1, -1) if dd == 0 else range(T)):
+                    tprev = t - 1 if dd == 0 else t + 1               # position of the previous recurrence step
+                    cp = _off(cst, ((tprev * nd + dd) * H) * 4) if 0 <= tprev < T else None
+                    dcn = torch.empty(M, H, device=dev)
+                    lib.check(L.nir_lstm_cell_seq_bwd_masked(_off(d, (t * nd * H + dd * H) * 4), T * nd * H, lib.ptr(dh_rec), lib.ptr(dc_rec),
+                                                             _off(act, ((t * nd + dd) * 4 * H) * 4), T * G, _off(cst, ((t * nd + dd) * H) * 4), T * nd * H,
+                                                             cp, T * nd * H, _off(dgx, (t * G + dd * 4 * H) * 4), T * G, lib.ptr(dcn), lib.ptr(lens64), t,
+                                                             tprev, M, H, st), "nir_lstm_cell_seq_bwd_masked")
+                    keep.append((dh_rec, dc_rec))
+                    dc_rec = dcn
+                    if t != (0 if dd == 0 else T - 1):
+                        dh_rec = torch.empty(M, H, device=dev)
+                        lib.check(L.nir_linear_f32(_off(dgx, (t * G + dd * 4 * H) * 4), T * G, None, None, 0, 0, 0, lib.ptr(wt), 4 * H, None, None,
+                                                   lib.ptr(dh_rec), H, M, H, 4 * H, 0, st), "nir_linear_f32")
+        if side is not None:
+            main.wait_stream(side)
+        st = lib.stream()
         dg2 = dgx.view(M * T, G)
         dx = _linear_raw(dg2, _transpose(wih), None, 0).view(M, T, I) if ctx.needs_input_grad[0] else None
         dwih, db = _wgrad_bias(dg2, G, x2, I, M * T, G, I)
