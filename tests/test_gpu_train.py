@@ -241,9 +241,14 @@ def test_embed_backward_skips_pad_and_accumulates():
     _rel(td.grad, emb.weight.grad, 1e-6)
 
 
-def test_match_tensor_gradients_vs_reference():
+@pytest.mark.parametrize("direct", [True, False])
+def test_match_tensor_gradients_vs_reference(direct, monkeypatch):
+    """direct: the three convolutions as direct kernels (csrc/mt_conv_train.hip); not direct: the patch-row + GEMM form every other filter
+    geometry still takes (nir_im2col_rows_f32 / nir_col2im_rows_f32) -- both against the reference's own gradients."""
     g = load_golden("match_tensor_train")
     from context_attentive_ir_amd import autograd as A
+    if not direct:
+        monkeypatch.setattr(A, "mt_conv3_supported", lambda *a, **k: False)
     m = build_model("MATCH_TENSOR", device=DEV, dropout_emb=0.0).train()
     m.word_embeddings.table.requires_grad_(False)
     q, ql, d, dl, lab = (T(g["b0_" + k], DEV) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label"))
