@@ -185,9 +185,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 // dY[.., 64 WN] and X[.., 64 WK] is fetched ONCE (float4, through registers, double-buffered in LDS: the loads of stage s + 1 are in flight
 // while stage s feeds the MFMAs) and every wave reads its 64-column halves from LDS -- (WN + WK) / (2 WN WK) of the L2 reads (0.35 at 2 x 5).
 // Row stride of the planes = 32 mod 64 words: lanes l and l + 32 (rows 2u, 2u + 1) fall in different banks.
-template <int WN, int WK>
+// Wave tile = NBW x KBW blocks of 32 x 32 (2 x 2 by default).  The 128 x 320 tile of the K = 300 gradients is also built from 4 x 2 waves of
+// 1 x 5 blocks: EIGHT waves, two per SIMD -- ten waves of 2 x 2 sit 3,3,2,2 on the four SIMDs and the kernel is MFMA-bound on the loaded pair.
+template <int WN, int WK, int NBW = 2, int KBW = 2>
 __global__ __launch_bounds__(64 * WN * WK) void wgrad_lds_kernel(WgradArgs p) {
-    constexpr int BN = 64 * WN, BK = 64 * WK, SA = BN + 32, SB = BK + 32, NT = 64 * WN * WK;
+    constexpr int BN = 32 * NBW * WN, BK = 32 * KBW * WK, SA = BN + 32, SB = BK + 32, NT = 64 * WN * WK;
     constexpr int ITEMS = 4 * (BN + BK), LA = (ITEMS + NT - 1) / NT;     // float4 items of one 16-row stage
     extern __shared__ float wg_lds[];
     float* sA = wg_lds;
@@ -247,15 +249,17 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_lds_kernel(WgradArgs p) {
             }
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[NBW][KBW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NBW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < KBW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const bool do_db = p.db != nullptr && k0 == 0 && wk == 0;      // wave-uniform
-    float bs[2] = {0.f, 0.f};
+    float bs[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) bs[i] = 0.f;
     gload(ms);
     sstore(0);
     __syncthreads();
@@ -263,32 +267,34 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_lds_kernel(WgradArgs p) {
     for (int64_t m = ms; m < me; m += 16, buf ^= 1) {
         const bool more = m + 16 < me;                             // block-uniform
         if (more) gload(m + 16);
-        const float* ap = sA + (buf * 16 + half) * SA + wn * 64 + (lane & 31);
-        const float* bp = sB + (buf * 16 + half) * SB + wk * 64 + (lane & 31);
-        float a[2][8], b[2][8];
+        const float* ap = sA + (buf * 16 + half) * SA + wn * 32 * NBW + (lane & 31);
+        const float* bp = sB + (buf * 16 + half) * SB + wk * 32 * KBW + (lane & 31);
+        float a[NBW][8], b[KBW][8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            a[0][u] = ap[2 * u * SA]; a[1][u] = ap[2 * u * SA + 32];
-            b[0][u] = bp[2 * u * SB]; b[1][u] = bp[2 * u * SB + 32];
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) a[i][u] = ap[2 * u * SA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < KBW; ++j) b[j][u] = bp[2 * u * SB + 32 * j];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NBW; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < KBW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
         if (do_db) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) bs[i] += ((a[i][0] + a[i][1]) + (a[i][2] + a[i][3])) + ((a[i][4] + a[i][5]) + (a[i][6] + a[i][7]));
+            for (int i = 0; i < NBW; ++i) bs[i] += ((a[i][0] + a[i][1]) + (a[i][2] + a[i][3])) + ((a[i][4] + a[i][5]) + (a[i][6] + a[i][7]));
         }
         if (more) sstore(buf ^ 1);
         __syncthreads();
     }
     if (do_db) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NBW; ++i) {
             const float t = bs[i] + __shfl_xor(bs[i], 32);
-            const int nn = n0 + wn * 64 + 32 * i + (lane & 31);
+            const int nn = n0 + wn * 32 * NBW + 32 * i + (lane & 31);
             if (half == 0 && nn < p.N) {
                 if (p.store) p.db[nn] = t;
                 else atomicAdd(p.db + nn, t);
@@ -296,13 +302,13 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_lds_kernel(WgradArgs p) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NBW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int kk = k0 + wk * 64 + 32 * j + (lane & 31);
+        for (int j = 0; j < KBW; ++j) {
+            const int kk = k0 + wk * 32 * KBW + 32 * j + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int nn = n0 + wn * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int nn = n0 + wn * 32 * NBW + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (nn < p.N && kk < p.K) {
                     if (p.store) p.dw[(int64_t)nn * p.lddw + kk] = acc[i][j][r];
                     else atomicAdd(p.dw + (int64_t)nn * p.lddw + kk, acc[i][j][r]);
@@ -311,14 +317,14 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_lds_kernel(WgradArgs p) {
         }
 }
 
-template <int WN, int WK>
+template <int WN, int WK, int NBW = 2, int KBW = 2>
 static void wgrad_lds_launch(const WgradArgs& a, int64_t blocks, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * 16 * (64 * WN + 32 + 64 * WK + 32) * sizeof(float);
+    constexpr size_t lds = (size_t)2 * 16 * (32 * NBW * WN + 32 + 32 * KBW * WK + 32) * sizeof(float);
     if (lds > 64 * 1024) {
         static std::once_flag once;
-        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<WN, WK, NBW, KBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     }
-    hipLaunchKernelGGL((wgrad_lds_kernel<WN, WK>), dim3((unsigned)blocks), dim3(64 * WN * WK), lds, st, a);
+    hipLaunchKernelGGL((wgrad_lds_kernel<WN, WK, NBW, KBW>), dim3((unsigned)blocks), dim3(64 * WN * WK), lds, st, a);
 }
 
 // Row list of a padded sequence batch: rows = { m T + t : t0 <= t < len[m] } in (m, t) order, offs[m] = its start, offs[M] = the count.
@@ -1311,7 +1317,10 @@ static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx
             case 2: wgrad_lds_launch<2, 2>(a, tiles * slices, st); break;
             case 3: wgrad_lds_launch<2, 3>(a, tiles * slices, st); break;
             case 4: wgrad_lds_launch<2, 4>(a, tiles * slices, st); break;
-            default: wgrad_lds_launch<2, 5>(a, tiles * slices, st); break;
+            default:                                                    // 128 x 320: eight waves of 1 x 5 blocks (tunable wgrad_lds_tiles = -5: ten of 2 x 2)
+                if (tun(g_tun.wgrad_lds_tiles) == -5) wgrad_lds_launch<2, 5>(a, tiles * slices, st);
+                else wgrad_lds_launch<4, 2, 1, 5>(a, tiles * slices, st);
+                break;
         }
         NIR_CHECK_LAUNCH("wgrad_lds_kernel");
         return 0;
