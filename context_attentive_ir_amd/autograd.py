@@ -109,7 +109,7 @@ class StepScope(object):
         """one weight-gradient launch / one column sum per parameter, then p.grad = buffer (plus whatever autograd itself accumulated for the
         parameter elsewhere, e.g. a norm regulariser)"""
         L = lib.load()
-        done, fused_b = [], set()
+        done, fused_b, group = [], set(), []
         seen, params = set(), []
         for p in [e[0] for e in self.pend_w.values()] + [e[0] for e in self.pend_b.values()]:
             if id(p) not in seen:
@@ -125,16 +125,21 @@ class StepScope(object):
                 # the bias of the same nn.Linear, parked with exactly these dY tensors: its column sum comes out of the same launch
                 bp = self.pair_b.get(id(p))
                 bent = self.pend_b.get(id(bp)) if bp is not None else None
+                bbuf = None
                 if bent is not None and len(bent[1]) == len(self.pend_w[id(p)][1]) and all(a is b_[0] for a, b_ in zip(bent[1], self.pend_w[id(p)][1])):
                     bbuf = self.grad_buffer(bp)
-                    lib.check(L.nir_linear_wgrad_bias_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, lib.ptr(bbuf), d.shape[0], N, K,
-                                                          lib.stream()), "nir_linear_wgrad_bias_f32")
                     done.append((bp, bbuf))
                     fused_b.add(id(bp))
-                else:
-                    lib.check(L.nir_linear_wgrad_f32(lib.ptr(d), N, lib.ptr(x), K, None, None, 0, lib.ptr(buf), K, d.shape[0], N, K, lib.stream()),
-                              "nir_linear_wgrad_f32")
+                group.append((d, x, buf, bbuf, d.shape[0], N, K))
             done.append((p, buf))
+        if group:
+            # ALL weight gradients of the step through one call: the small ones share launches (nir_linear_wgrad_group_f32)
+            n = len(group)
+            PA, LA, IA = lib.C.c_void_p * n, lib.C.c_int64 * n, lib.C.c_int * n
+            args = (PA(*[g[0].data_ptr() for g in group]), LA(*[g[5] for g in group]), PA(*[g[1].data_ptr() for g in group]), LA(*[g[6] for g in group]),
+                    PA(*[g[2].data_ptr() for g in group]), LA(*[g[6] for g in group]), PA(*[(g[3].data_ptr() if g[3] is not None else None) for g in group]),
+                    LA(*[g[4] for g in group]), IA(*[g[5] for g in group]), IA(*[g[6] for g in group]))
+            lib.check(L.nir_linear_wgrad_group_f32(n, *args, lib.stream()), "nir_linear_wgrad_group_f32")
         for p, ds in self.pend_b.values():
             if id(p) in fused_b:
                 continue

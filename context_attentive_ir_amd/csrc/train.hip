@@ -66,15 +66,15 @@ __device__ __forceinline__ void wgrad_range(const WgradArgs& p, int64_t slice, i
 // SH (1 x 1 only): the four waves of a workgroup take four SLICES of the same tile and add their tiles up in LDS before the atomics -- a tiny dW
 // under a long reduction (the [81920] x [20, 18] gradient of MatchTensor's 1x1 convolution: 1 280 slices) otherwise queues a thousand atomics on
 // each of its 360 addresses (78 us for 12 MB of operands).
-template <int NB, int KB, int RB = 8, bool SH = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+template <int NB, int KB, int RB, bool SH>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int64_t bid) {      // bid = workgroup index inside this gradient's grid
     static_assert(!SH || (NB == 1 && KB == 1), "shared-tile mode: one 32 x 32 tile per wave");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt = (p.N + 32 * NB - 1) / (32 * NB), kt = (p.K + 32 * KB - 1) / (32 * KB);
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wid = bid * 4 + wave;
     const int64_t tiles = (int64_t)nt * kt;
-    const int64_t slice = SH ? ((int64_t)blockIdx.x / tiles) * 4 + wave : wid / tiles;
-    const int tile = SH ? (int)(blockIdx.x % tiles) : (int)(wid % tiles);
+    const int64_t slice = SH ? (bid / tiles) * 4 + wave : wid / tiles;
+    const int tile = SH ? (int)(bid % tiles) : (int)(wid % tiles);
     const int n0 = (tile / kt) * 32 * NB, k0 = (tile % kt) * 32 * KB;
     int64_t ms, me;
     wgrad_range(p, slice, ms, me);
@@ -177,6 +177,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
                     else atomicAdd(p.dw + (int64_t)nn * p.lddw + k[j], acc[i][j][r]);
                 }
             }
+}
+
+template <int NB, int KB, int RB = 8, bool SH = false>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+    wgrad_body<NB, KB, RB, SH>(p, (int64_t)blockIdx.x);
+}
+
+// GROUPED small gradients (round 5): a training step ends with ~35 weight gradients of a few hundred rows, each its own launch of a few dozen
+// workgroups walking a dependent load -> MFMA chain (15-40 us apiece at a few percent of the chip, 0.5 ms per CARS step back to back).  One
+// launch takes up to WG_GROUP of them: the descriptors travel as kernel arguments (no table in memory: captured by a hipGraph as they are),
+// a workgroup finds its gradient from the prefix of workgroup counts and runs the same 1 x 1 body -- all chains in flight together.
+constexpr int WG_GROUP = 20;
+struct WgradGroup {
+    int n;
+    int bstart[WG_GROUP + 1];                              // first workgroup of every gradient; bstart[n] = grid size
+    int sh[WG_GROUP];                                      // shared-tile mode of the gradient
+    WgradArgs a[WG_GROUP];
+};
+__global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.bstart[i + 1]) ++i;             // (uniform)
+    const int64_t bid = (int64_t)blockIdx.x - g.bstart[i];
+    if (g.sh[i]) wgrad_body<1, 1, 16, true>(g.a[i], bid);
+    else wgrad_body<1, 1, 16, false>(g.a[i], bid);
 }
 
 // LDS-staged form for the big gradients (round 5).  The register-blocked kernel above has every wave fetch its own 16 x (64 + 64) operand
@@ -1283,8 +1307,31 @@ extern "C" int nir_lstm_cell_bwd(const float* dh, const float* dc, const float* 
 }
 
 struct WgradRows { const int32_t* rows = nullptr; const int32_t* mcount = nullptr; int64_t dyd = 0, xd = 0; int period = 0, skip = 0; };
+// collects the small (1 x 1 path) gradients of nir_linear_wgrad_group_f32 and launches them WG_GROUP at a time
+struct WgradCollector {
+    nir::WgradGroup g;
+    hipStream_t st;
+    explicit WgradCollector(hipStream_t s) : st(s) { g.n = 0; g.bstart[0] = 0; }
+    int flush() {
+        using namespace nir;
+        if (g.n == 0) return 0;
+        ProfScope ps(prof_shape_name("wgrad_group_kernel", g.n, g.bstart[g.n], 0), st);
+        hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)g.bstart[g.n]), dim3(256), 0, st, g);
+        NIR_CHECK_LAUNCH("wgrad_group_kernel");
+        g.n = 0;
+        return 0;
+    }
+    int add(const nir::WgradArgs& a, int64_t blocks, bool sh) {
+        if (g.n == nir::WG_GROUP || (int64_t)g.bstart[g.n] + blocks > (1 << 30)) NIR_PROPAGATE(flush());
+        g.a[g.n] = a; g.sh[g.n] = sh ? 1 : 0;
+        g.bstart[g.n + 1] = g.bstart[g.n] + (int)blocks;
+        ++g.n;
+        return 0;
+    }
+};
 static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E, float* dw,
-                      int64_t lddw, int64_t M, int N, int K, bool set, hipStream_t st, float* db = nullptr, WgradRows rl = WgradRows()) {
+                      int64_t lddw, int64_t M, int N, int K, bool set, hipStream_t st, float* db = nullptr, WgradRows rl = WgradRows(),
+                      WgradCollector* grp = nullptr) {
     using namespace nir;
     NIR_REQUIRE(dy && dw && (ids ? (table != nullptr && E >= K) : (x != nullptr)), "linear_wgrad: null pointer");
     NIR_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_wgrad: bad dims");
@@ -1338,6 +1385,10 @@ static int wgrad_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx
     if (set && !store) NIR_PROPAGATE((int)hipMemset2DAsync(dw, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)N, st));
     if (set && !store && db) NIR_PROPAGATE((int)hipMemsetAsync(db, 0, (size_t)N * 4, st));
     WgradArgs a{dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, mslice, store, db, rl.rows, rl.mcount, rl.dyd, rl.xd, (int)slices, rl.period > 1 ? (unsigned)((((uint64_t)1 << 32) + rl.period - 1) / rl.period) : 0u, rl.period, rl.skip};
+    if (grp && !big && !set) {                       // (accumulating small gradient: joins the group launch)
+        const bool sh = slices >= 8 && tiles <= 64;
+        return grp->add(a, sh ? tiles * ((slices + 3) / 4) : (tiles * slices + 3) / 4, sh);
+    }
     ProfScope ps(prof_shape_name("wgrad_kernel", M, N, K), st);
     if (big) hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3((unsigned)((tiles * slices + 3) / 4)), dim3(256), 0, st, a);
     else if (slices >= 8 && tiles <= 64)             // small dW, long reduction: slices of one tile share a workgroup (LDS add before the atomics)
@@ -1359,6 +1410,14 @@ extern "C" int nir_linear_wgrad_bias_f32(const float* dy, int64_t lddy, const fl
                                          float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream) {
     NIR_REQUIRE(db != nullptr, "linear_wgrad_bias: null bias gradient");
     return wgrad_impl(dy, lddy, x, ldx, ids, table, E, dw, lddw, M, N, K, false, (hipStream_t)stream, db);
+}
+extern "C" int nir_linear_wgrad_group_f32(int n, const float* const* dy, const int64_t* lddy, const float* const* x, const int64_t* ldx, float* const* dw,
+                                          const int64_t* lddw, float* const* db, const int64_t* M, const int* N, const int* K, nir_stream_t stream) {
+    NIR_REQUIRE(n >= 0 && (n == 0 || (dy && lddy && x && ldx && dw && lddw && db && M && N && K)), "linear_wgrad_group: null array");
+    WgradCollector col((hipStream_t)stream);
+    for (int i = 0; i < n; ++i)
+        NIR_PROPAGATE(wgrad_impl(dy[i], lddy[i], x[i], ldx[i], nullptr, nullptr, 0, dw[i], lddw[i], M[i], N[i], K[i], false, (hipStream_t)stream, db[i], WgradRows(), &col));
+    return col.flush();
 }
 extern "C" int nir_linear_wgrad_bias_set_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
                                              float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream) {

@@ -140,6 +140,7 @@ SIGNATURES = {
     "nir_colsum_f32": (_i, [c_fp, _l, _l, _i, c_fp, c_st]),
     "nir_linear_wgrad_set_f32": (_i, [c_fp, _l, c_fp, _l, c_ip, c_fp, _i, c_fp, _l, _l, _i, _i, c_st]),
     "nir_linear_wgrad_bias_f32": (_i, [c_fp, _l, c_fp, _l, c_ip, c_fp, _i, c_fp, _l, c_fp, _l, _i, _i, c_st]),
+    "nir_linear_wgrad_group_f32": (_i, [_i] + [C.c_void_p] * 10 + [c_st]),
     "nir_linear_wgrad_bias_set_f32": (_i, [c_fp, _l, c_fp, _l, c_ip, c_fp, _i, c_fp, _l, c_fp, _l, _i, _i, c_st]),
     "nir_colsum_set_f32": (_i, [c_fp, _l, _l, _i, c_fp, c_st]),
     "nir_seq_rows": (_i, [c_ip, _l, _i, _i, C.c_void_p, C.c_void_p, c_st]),

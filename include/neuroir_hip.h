@@ -564,6 +564,11 @@ int nir_linear_wgrad_bias_set_f32(const float* dy, int64_t lddy, const float* x,
 /* the accumulating form (dW += .., db += ..): a training step zero-fills ALL its parameter-gradient buffers with one memset (autograd.StepScope) */
 int nir_linear_wgrad_bias_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const int64_t* ids, const float* table, int E,
                               float* dw, int64_t lddw, float* db, int64_t M, int N, int K, nir_stream_t stream);
+/* n accumulating weight (+ optional bias: db[i] may be NULL) gradients in as few launches as possible: the small ones (a few hundred rows, the
+ * register-blocked 1 x 1 path) run up to 20 per launch (wgrad_group_kernel: descriptors as kernel arguments, all their load -> MFMA chains in
+ * flight together), the big ones as nir_linear_wgrad_bias_f32 would launch them.  All arrays are HOST arrays of length n; dW / db accumulate. */
+int nir_linear_wgrad_group_f32(int n, const float* const* dy, const int64_t* lddy, const float* const* x, const int64_t* ldx, float* const* dw,
+                               const int64_t* lddw, float* const* db, const int64_t* M, const int* N, const int* K, nir_stream_t stream);
 /* Row list of a padded sequence batch: rows = { m T + t : t_begin <= t < min(lengths[m], T) } in (m, t) order (int32, room for M T entries),
  * offs[m] = start of sequence m's rows, offs[M] = the number of rows -- all on the device, no host synchronisation.  The reference reaches the
  * same set through pack_padded_sequence (neuroir/encoders/rnn_encoder.py, modules/layers). */
