@@ -57,9 +57,11 @@ class StepScope(object):
         self.wt = {}              # (data_ptr, version, shape) -> (source tensor, transposed weight), this step
         self.pair_b = {}          # id(weight) -> bias parameter parked with the same dY tensors
         self.arena_key, self.arenas = None, []
+        self.tprev, self.tcur = [], []      # weights whose transposes the previous / this step asked for (grouped into one launch)
 
     def begin(self):
         self.active, self.pend_w, self.pend_b, self.wt, self.pair_b = True, {}, {}, {}, {}
+        self.tcur = []
         # a caller that cleared gradients IN PLACE (zero_grad(set_to_none=False)) left last step's buffer installed as p.grad: autograd would
         # accumulate into it and end() would overwrite / double it -- the buffer is this scope's, so it is detached from the parameter here
         for p, buf in self.bufs.values():
@@ -155,6 +157,7 @@ class StepScope(object):
                 p.grad = buf
             else:
                 p.grad.add_(buf)
+        self.tprev = [q for q in self.tcur if _is_param(q) and q.dim() == 2][:256]
         self.abort()
 
 
@@ -174,6 +177,19 @@ def _transpose(w):
     if STEP.active and key in STEP.wt:
         return STEP.wt[key][1]
     L = lib.load()
+    if STEP.active and _is_param(w):
+        STEP.tcur.append(w)
+        if any(q is w for q in STEP.tprev):
+            # a weight the previous step transposed too: transpose ALL of that step's weights now, in one launch (nir_transpose_group_f32)
+            ws = [q for q in STEP.tprev if q.is_cuda and q.device == w.device and (q.data_ptr(), q._version, tuple(q.shape)) not in STEP.wt]
+            outs = [torch.empty(q.shape[1], q.shape[0], device=q.device, dtype=torch.float32) for q in ws]
+            n = len(ws)
+            PA, IA = lib.C.c_void_p * n, lib.C.c_int * n
+            lib.check(L.nir_transpose_group_f32(n, PA(*[q.data_ptr() for q in ws]), IA(*[q.shape[0] for q in ws]), IA(*[q.shape[1] for q in ws]),
+                                                PA(*[o.data_ptr() for o in outs]), lib.stream()), "nir_transpose_group_f32")
+            for q, o in zip(ws, outs):
+                STEP.wt[(q.data_ptr(), q._version, tuple(q.shape))] = (q, o)
+            return STEP.wt[key][1]
     R, Cc = w.shape
     out = torch.empty(Cc, R, device=w.device, dtype=torch.float32)
     lib.check(L.nir_transpose_f32(lib.ptr(w), R, Cc, lib.ptr(out), lib.stream()), "nir_transpose_f32")

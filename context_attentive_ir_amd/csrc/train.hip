@@ -418,6 +418,36 @@ __global__ void transpose_kernel(const float* __restrict__ in, int R, int Cc, fl
     }
 }
 
+// up to TG_GROUP transposes in one launch (descriptors as kernel arguments, like wgrad_group_kernel): the data-gradient GEMM of every
+// nn.Linear of a step needs its weight transposed, ~30 launches of a few tiles each
+constexpr int TG_GROUP = 48;
+struct TransposeGroup {
+    int n;
+    int bstart[TG_GROUP + 1];
+    const float* in[TG_GROUP];
+    float* out[TG_GROUP];
+    int R[TG_GROUP], Cc[TG_GROUP];
+};
+__global__ void transpose_group_kernel(TransposeGroup g) {
+    __shared__ float t[32][33];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.bstart[i + 1]) ++i;
+    const int b = (int)blockIdx.x - g.bstart[i];
+    const int R = g.R[i], Cc = g.Cc[i], tx = (Cc + 31) / 32;
+    const float* __restrict__ in = g.in[i];
+    float* __restrict__ out = g.out[i];
+    const int c0 = (b % tx) * 32, r0 = (b / tx) * 32;
+    for (int q = threadIdx.y; q < 32; q += 8) {
+        const int r = r0 + q, c = c0 + threadIdx.x;
+        t[q][threadIdx.x] = (r < R && c < Cc) ? in[(int64_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int q = threadIdx.y; q < 32; q += 8) {
+        const int c = c0 + q, r = r0 + threadIdx.x;
+        if (c < Cc && r < R) out[(int64_t)c * R + r] = t[threadIdx.x][q];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Train-mode LSTM recurrence.  One workgroup = SQ sequences of one direction, one thread per gate row j (4H <= 512 threads):
 // its W_hh row lives in registers (H <= 128), h_{t-1} of the SQ sequences in LDS.  Saves act[m,t,dir,4H] (i,f,g,o after
@@ -1473,6 +1503,29 @@ extern "C" int nir_transpose_f32(const float* in, int R, int Cc, float* out, nir
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((Cc + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, (hipStream_t)stream, in, R, Cc, out);
     NIR_CHECK_LAUNCH("transpose_kernel");
     return 0;
+}
+
+extern "C" int nir_transpose_group_f32(int n, const float* const* in, const int* R, const int* Cc, float* const* out, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(n >= 0 && (n == 0 || (in && R && Cc && out)), "transpose_group: null array");
+    TransposeGroup g;
+    g.n = 0; g.bstart[0] = 0;
+    auto flush = [&]() {
+        if (g.n == 0) return 0;
+        hipLaunchKernelGGL(transpose_group_kernel, dim3((unsigned)g.bstart[g.n]), dim3(32, 8), 0, (hipStream_t)stream, g);
+        NIR_CHECK_LAUNCH("transpose_group_kernel");
+        g.n = 0;
+        return 0;
+    };
+    for (int i = 0; i < n; ++i) {
+        NIR_REQUIRE(in[i] && out[i] && R[i] > 0 && Cc[i] > 0, "transpose_group: bad item %d", i);
+        const int64_t tiles = (int64_t)((Cc[i] + 31) / 32) * ((R[i] + 31) / 32);
+        if (g.n == TG_GROUP || (int64_t)g.bstart[g.n] + tiles > (1 << 30)) NIR_PROPAGATE(flush());
+        g.in[g.n] = in[i]; g.out[g.n] = out[i]; g.R[g.n] = R[i]; g.Cc[g.n] = Cc[i];
+        g.bstart[g.n + 1] = g.bstart[g.n] + (int)tiles;
+        ++g.n;
+    }
+    return flush();
 }
 
 extern "C" int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0, float* out,

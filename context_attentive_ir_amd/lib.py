@@ -146,6 +146,7 @@ SIGNATURES = {
     "nir_seq_rows": (_i, [c_ip, _l, _i, _i, C.c_void_p, C.c_void_p, c_st]),
     "nir_linear_wgrad_rows_set_f32": (_i, [c_fp, _l, _l, c_fp, _l, _l, C.c_void_p, C.c_void_p, _l, _i, _i, c_fp, _l, c_fp, _i, _i, c_st]),
     "nir_transpose_f32": (_i, [c_fp, _i, _i, c_fp, c_st]),
+    "nir_transpose_group_f32": (_i, [_i, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_st]),
     "nir_lstm_train_fwd": (_i, [c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, _i, _i, _i, c_st]),
     "nir_lstm_perm_weights": (_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _i, _i, _i, c_fp, c_fp, c_st]),
     "nir_lstm_train_fwd_split": (_i, [c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, C.c_void_p, _l, _i, _i, _i, c_st]),

@@ -585,6 +585,8 @@ int nir_linear_wgrad_rows_set_f32(const float* dy, int64_t lddy, int64_t dy_row_
 int nir_colsum_set_f32(const float* x, int64_t ld, int64_t M, int N, float* out, nir_stream_t stream);
 /* out [C,R] = in [R,C]^T  (data gradient: dX = dY W is nir_linear_f32(dY, W^T)) */
 int nir_transpose_f32(const float* in, int R, int C, float* out, nir_stream_t stream);
+/* n transposes (HOST arrays of device pointers and dims) in as few launches as possible (up to 48 per launch, descriptors as kernel arguments) */
+int nir_transpose_group_f32(int n, const float* const* in, const int* R, const int* Cc, float* const* out, nir_stream_t stream);
 /* Train-mode recurrence (same contract as nir_bilstm_fwd, H <= 128) that also stores act [M,T,ndir,4H] (i,f,g,o after their
  * non-linearities) and cst [M,T,ndir,H] (c_t) of every valid step. */
 int nir_lstm_train_fwd(const float* gates_in, const int64_t* lengths, const float* w_hh, const float* h0, const float* c0, float* out,
