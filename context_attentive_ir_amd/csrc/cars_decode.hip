@@ -120,15 +120,19 @@ constexpr int PA_K = 256, PA_KS = PA_K / 32, PA_NBT = 6, PA_ROWS = 16 * PA_NBT, 
 constexpr int PA_TW = 2;                                                                              // vocabulary tiles per wave and pass
 constexpr size_t PA_LDS = (size_t)2 * PA_ROWS * PA_LD * 2;
 
+// Grid (round 5) = row blocks of 96 decode rows x `nvr` vocabulary ranges: a workgroup stages ITS row block once and walks its vocabulary range
+// (at 768 rows: 8 x 32 workgroups of ~15 tiles per wave).  Before, every workgroup took all row blocks in turn over 1/256 of the vocabulary:
+// eight re-stagings of 96 rows and ~2 tiles per wave and pass -- 16 us of MFMA work in a 124 us launch.
 __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __restrict__ p1, const _Float16* __restrict__ wfrag, int64_t VT,
-                                                             int64_t ntiles, int64_t Bd, float* __restrict__ pval, int* __restrict__ pidx) {
+                                                             int64_t ntiles, int64_t Bd, float* __restrict__ pval, int* __restrict__ pidx, int nvr) {
     extern __shared__ __attribute__((aligned(16))) _Float16 pa_sm[];          // [2 terms][96 rows][PA_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
-    const int64_t per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int64_t t_lo = (int64_t)blockIdx.x * per_wg, t_hi = min(ntiles, t_lo + per_wg);
-    for (int64_t b0 = 0; b0 < Bd; b0 += PA_ROWS) {
-        __syncthreads();
+    const int vr = (int)(blockIdx.x % nvr);
+    const int64_t per_wg = (ntiles + nvr - 1) / nvr;
+    const int64_t t_lo = (int64_t)vr * per_wg, t_hi = min(ntiles, t_lo + per_wg);
+    {
+        const int64_t b0 = (int64_t)(blockIdx.x / nvr) * PA_ROWS;
         for (int e = tid; e < PA_ROWS * (PA_K / 4); e += 256) {            // stage + split this pass's decode rows (zero rows past Bd)
             const int r = e / (PA_K / 4), k4 = (e - r * (PA_K / 4)) * 4;
             const int64_t b = b0 + r;
@@ -146,25 +150,30 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
         int bidx[PA_NBT];
 #pragma unroll
         for (int bt = 0; bt < PA_NBT; ++bt) { best[bt] = -INFINITY; bidx[bt] = 0x7FFFFFFF; }
-        for (int64_t t0 = t_lo + wave * PA_TW; t0 < t_hi; t0 += 4 * PA_TW) {
-            f32x4 acc[PA_TW][PA_NBT], acx[PA_TW][PA_NBT];
-#pragma unroll
-            for (int u = 0; u < PA_TW; ++u)
-#pragma unroll
-                for (int bt = 0; bt < PA_NBT; ++bt) { acc[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            // all of the tile pair's W fragments are requested up front (2 tiles x 8 k-steps x 2 terms x 16 B per lane = 128 VGPRs; one
-            // workgroup per CU has them to spare): ONE memory round trip per tile pair instead of one per k-step (first version: 32 us per
-            // launch = 0.96 TB/s on a 30.7 MB weight stream, latency-bound on 8 dependent round trips)
-            f16x8 wf[PA_KS][PA_TW][2];
+        // all of a tile pair's W fragments are requested at once (2 tiles x 8 k-steps x 2 terms x 16 B per lane = 128 VGPRs; one workgroup per
+        // CU has them to spare): ONE memory round trip per tile pair instead of one per k-step (first version: 32 us per launch = 0.96 TB/s
+        // on a 30.7 MB weight stream, latency-bound on 8 dependent round trips).  Round 5: THREE fragment sets of one tile each -- a round trip
+        // (~4 000 cycles) runs under the 2 x 144 MFMAs (~2 300 each) of the two tiles in front of it instead of in front of its own tile (one wave
+        // per SIMD: nothing else hides it; two sets of two tiles: 512 registers, 40 spilled, 160 us).
+        constexpr int TW = 1;                                          // tiles per fragment set (three sets in flight)
+        auto load_w = [&](int64_t t0, f16x8 (&wf)[PA_KS][TW][2]) {
 #pragma unroll
             for (int ks = 0; ks < PA_KS; ++ks)
 #pragma unroll
-                for (int u = 0; u < PA_TW; ++u) {
-                    const int64_t t = t0 + u < t_hi ? t0 + u : t_hi - 1;      // clamped: a duplicate tile's results are discarded below
+                for (int u = 0; u < TW; ++u) {
+                    int64_t t = t0 + u < t_hi ? t0 + u : t_hi - 1;            // clamped: a duplicate tile's results are discarded below
+                    t = t < 0 ? 0 : t;
                     const _Float16* wp = wfrag + ((t * PA_KS + ks) * 2 * 64 + lane) * 8;
                     wf[ks][u][0] = *reinterpret_cast<const f16x8*>(wp);
                     wf[ks][u][1] = *reinterpret_cast<const f16x8*>(wp + 512);
                 }
+        };
+        auto compute = [&](int64_t t0, const f16x8 (&wf)[PA_KS][TW][2]) {
+            f32x4 acc[TW][PA_NBT], acx[TW][PA_NBT];
+#pragma unroll
+            for (int u = 0; u < TW; ++u)
+#pragma unroll
+                for (int bt = 0; bt < PA_NBT; ++bt) { acc[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int ks = 0; ks < PA_KS; ++ks) {
                 const _Float16* bp = pa_sm + c16 * PA_LD + 32 * ks + 8 * g4;
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
                     const f16x8 b1 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD);
                     const f16x8 b2 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD + PA_ROWS * PA_LD);
 #pragma unroll
-                    for (int u = 0; u < PA_TW; ++u) {
+                    for (int u = 0; u < TW; ++u) {
                         acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][1], b1, acx[u][bt], 0, 0, 0);
                         acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][0], b2, acx[u][bt], 0, 0, 0);
                         acc[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][0], b1, acc[u][bt], 0, 0, 0);
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
                 __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads of later k-steps from being hoisted (384 more live registers: spills)
             }
 #pragma unroll
-            for (int u = 0; u < PA_TW; ++u) {
+            for (int u = 0; u < TW; ++u) {
                 if (t0 + u >= t_hi) continue;                              // wave-uniform
 #pragma unroll
                 for (int bt = 0; bt < PA_NBT; ++bt)
@@ -192,6 +201,26 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
                         const float x = fmaf(acx[u][bt][r], 1.0f / 2048.0f, acc[u][bt][r]);
                         if (v < VT && x > best[bt]) { best[bt] = x; bidx[bt] = (int)v; }
                     }
+            }
+        };
+        {
+            constexpr int64_t ST = 4 * TW;
+            f16x8 wfA[PA_KS][TW][2], wfB[PA_KS][TW][2], wfC[PA_KS][TW][2];
+            int64_t t0 = t_lo + wave * TW;
+            if (t0 < t_hi) load_w(t0, wfA);
+            if (t0 + ST < t_hi) load_w(t0 + ST, wfB);
+            for (; t0 < t_hi; t0 += 3 * ST) {
+                if (t0 + 2 * ST < t_hi) load_w(t0 + 2 * ST, wfC);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(t0, wfA);
+                if (t0 + ST >= t_hi) break;
+                if (t0 + 3 * ST < t_hi) load_w(t0 + 3 * ST, wfA);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(t0 + ST, wfB);
+                if (t0 + 2 * ST >= t_hi) break;
+                if (t0 + 4 * ST < t_hi) load_w(t0 + 4 * ST, wfB);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(t0 + 2 * ST, wfC);
             }
         }
         // lanes l, l+16, l+32, l+48 hold the same decode column: combine (first index wins ties), then one partial per wave and column
@@ -205,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
             }
             const int64_t b = b0 + bt * 16 + c16;
             if (g4 == 0 && b < Bd) {
-                const int64_t slot = ((int64_t)blockIdx.x * 4 + wave) * Bd + b;
+                const int64_t slot = ((int64_t)vr * 4 + wave) * Bd + b;
                 pval[slot] = best[bt];
                 pidx[slot] = bidx[bt];
             }
@@ -320,7 +349,9 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
     const bool fused_argmax = w->pred2_frag != nullptr && P == PA_K && w->VT < 0x7FFFFFF0LL;
     DecPlan p = dec_plan(workspace, workspace_bytes, rows_src, Bd, QL, HD, P, w->VT, fused_argmax);
     const int64_t ntiles = (w->VT + 15) / 16;
-    const int pa_wgs = (int)std::min<int64_t>(std::min<int64_t>(PA_MAX_WGS, cu_count()), (ntiles + 4 * PA_TW - 1) / (4 * PA_TW));
+    // vocabulary ranges per row block: enough workgroups for the chip, at least ~4 tiles per wave
+    const int64_t pa_rb = (Bd + PA_ROWS - 1) / PA_ROWS;
+    const int pa_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(PA_MAX_WGS, (cu_count() + pa_rb - 1) / pa_rb), (ntiles + 4 * PA_TW - 1) / (4 * PA_TW)));
     if (fused_argmax && PA_LDS > 64 * 1024) {
         static std::once_flag once;
         std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)pred_argmax_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PA_LDS); });
@@ -364,8 +395,8 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
         if (fused_argmax) {
             {
                 ProfScope ps(prof_shape_name("pred_argmax_kernel", (long long)Bd, (long long)w->VT, P), st);
-                hipLaunchKernelGGL(pred_argmax_kernel, dim3((unsigned)pa_wgs), dim3(256), PA_LDS, st, p.p1, (const _Float16*)w->pred2_frag, w->VT, ntiles, Bd,
-                                   p.pval, p.pidx);
+                hipLaunchKernelGGL(pred_argmax_kernel, dim3((unsigned)(pa_wgs * pa_rb)), dim3(256), PA_LDS, st, p.p1, (const _Float16*)w->pred2_frag, w->VT, ntiles, Bd,
+                                   p.pval, p.pidx, pa_wgs);
             }
             NIR_CHECK_LAUNCH("pred_argmax_kernel");
             hipLaunchKernelGGL(argmax_finish_kernel, dim3((unsigned)Bd), dim3(64), 0, st, p.pval, p.pidx, pa_wgs * 4, Bd, tgt2src, predictions + step,
