@@ -217,40 +217,40 @@ __global__ __launch_bounds__(256) void click_pool_big_kernel(const float* __rest
 // NB = batch tiles of 16 rows that share one pass over the weights (B <= 16 NB): a weight fragment is loaded once per k-group and
 // feeds NB MFMA chains.  With the one-tile-at-a-time loop a 64-row batch (the C5 shape) walked the 6 MB of gate weights four times
 // per step and chain: 27 us per step against 8 us at B = 16.
-template <int NB>
+// UG = unit groups (of 4 units = one 16-row MFMA tile) per workgroup: the [rows, I + H] operand is re-read once per workgroup COLUMN -- at the
+// greedy decoders' 768 rows and H = 512, 128 columns x 2.5 MB = 320 MB of L2 reads per step (78 us, 5 TB/s); two groups per workgroup halve it.
+template <int NB, int UG = 1>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
-    __shared__ float red[4][NB][256];
+    __shared__ float red[4][UG * NB][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ch = blockIdx.y + p.chain0;
-    const int u0 = blockIdx.x * 4;
+    const int u0 = blockIdx.x * 4 * UG;
     const int I = p.I, H = p.H;
-    // A operand rows: row i = 4*unit_local + gate  ->  weight row gate*H + u0 + unit_local
-    const int ua = u0 + (i >> 2);
-    const int arow = (i & 3) * H + (ua < H ? ua : H - 1);
-    const float* wi = p.wih[ch] + (int64_t)arow * I;
-    const float* wh = p.whh[ch] + (int64_t)arow * H;
+    // A operand rows: row i = 4*unit_local + gate  ->  weight row gate*H + u0 + 4 ug + unit_local
+    const float* wi[UG];
+    const float* wh[UG];
+#pragma unroll
+    for (int ug = 0; ug < UG; ++ug) {
+        const int ua = u0 + 4 * ug + (i >> 2);
+        const int arow = (i & 3) * H + (ua < H ? ua : H - 1);
+        wi[ug] = p.wih[ch] + (int64_t)arow * I;
+        wh[ug] = p.whh[ch] + (int64_t)arow * H;
+    }
     const float* hprev = p.hprev[ch];
     const float* cprev = p.cprev[ch];
     const float* gxp = p.gx[ch];
     const int nq1 = gxp ? 0 : ((I + 15) >> 4), nq2 = hprev ? ((H + 15) >> 4) : 0;
     // result view: lane = (batch column i, unit_local g), registers r = gates i,f,g,o
-    const int ud = u0 + g;
-    const bool uv = ud < H;
-    float bias[4];
+    float bias[UG][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[r] = (uv && !gxp) ? p.bih[ch][r * H + ud] + p.bhh[ch][r * H + ud] : 0.f;
+    for (int ug = 0; ug < UG; ++ug) {
+        const int ud = u0 + 4 * ug + g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[ug][r] = (ud < H && !gxp) ? p.bih[ch][r * H + ud] + p.bhh[ch][r * H + ud] : 0.f;
+    }
     // (batch slabs of 16 NB rows across workgroups -- blockIdx.z -- like lstm_step16_kernel: the greedy decoders step 768 rows at a macro-batch of 8)
     for (int b0 = blockIdx.z * 16 * NB; b0 < p.B; b0 += gridDim.z * 16 * NB) {
-        // hoisted input side: the four gate pre-activations of the (row, unit) this lane finishes below (batch tile = wave), requested before the
-        // recurrent walk so that their round trip runs under it
-        float gxv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gxp && wave < NB) {
-            const int bq = b0 + 16 * wave + i;
-            const float* gr = gxp + (int64_t)(bq < p.B ? bq : p.B - 1) * p.gxstride + (uv ? ud : 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gxv[r] = gr[r * H];
-        }
         const float* xr[NB];
         const float* hr[NB];
         float bm[NB];
@@ -264,18 +264,20 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
             xr[t] = p.x[ch] + xr_i * p.xstride[ch];
             hr[t] = hprev ? hprev + (int64_t)bc * H : nullptr;
         }
-        f32x4 acc[NB];
+        f32x4 acc[UG][NB];
 #pragma unroll
-        for (int t = 0; t < NB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ug = 0; ug < UG; ++ug)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) acc[ug][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // ONE list of k-groups over both products (x W_ih^T: groups 0 .. nq1-1, h W_hh^T: the rest), walked in chunks of CH per wave with
         // all of a chunk's operand loads issued before its first MFMA: at I + H = 768 and B <= 16 a wave's 12 groups are a single chunk,
         // i.e. ONE L2 / HBM round trip per step.  (Two separate walks -- 4 + 8 groups per wave in chunks of 4 -- were three dependent
         // round trips: 9.4 us per session step against ~6 MB of weights; `#pragma unroll` on the runtime-strided loop was not honoured
         // either.)  Unconditional loads from a clamped k, masked afterwards.
-        constexpr int CH = NB == 1 ? 12 : (NB == 2 ? 8 : 6);
+        constexpr int CH = NB == 1 ? 12 : (NB == 2 ? 8 : (UG == 1 ? 6 : 4));
         const int nqt = nq1 + nq2;
         for (int q0 = wave; q0 < nqt; q0 += 4 * CH) {
-            float4 a4[CH], b4[CH][NB];
+            float4 a4[CH][UG], b4[CH][NB];
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int q = q0 + 4 * c;
@@ -284,8 +286,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
                 const int k = 16 * (second ? q - nq1 : q) + 4 * g;
                 const float km = (q < nqt && k < K) ? 1.f : 0.f;
                 const int kc = (q < nqt && k < K) ? k : 0;
-                a4[c] = *reinterpret_cast<const float4*>((second ? wh : wi) + kc);
-                a4[c].x *= km; a4[c].y *= km; a4[c].z *= km; a4[c].w *= km;
+#pragma unroll
+                for (int ug = 0; ug < UG; ++ug) {
+                    a4[c][ug] = *reinterpret_cast<const float4*>((second ? wh[ug] : wi[ug]) + kc);
+                    a4[c][ug].x *= km; a4[c][ug].y *= km; a4[c][ug].z *= km; a4[c][ug].w *= km;
+                }
 #pragma unroll
                 for (int t = 0; t < NB; ++t) {
                     b4[c][t] = *reinterpret_cast<const float4*>(((second && hr[t]) ? hr[t] : xr[t]) + kc);
@@ -296,24 +301,37 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
 #pragma unroll
             for (int c = 0; c < CH; ++c)
 #pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].x, b4[c][t].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].y, b4[c][t].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].z, b4[c][t].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c].w, b4[c][t].w, acc[t], 0, 0, 0);
-                }
+                for (int ug = 0; ug < UG; ++ug)
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) {
+                        acc[ug][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][ug].x, b4[c][t].x, acc[ug][t], 0, 0, 0);
+                        acc[ug][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][ug].y, b4[c][t].y, acc[ug][t], 0, 0, 0);
+                        acc[ug][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][ug].z, b4[c][t].z, acc[ug][t], 0, 0, 0);
+                        acc[ug][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][ug].w, b4[c][t].w, acc[ug][t], 0, 0, 0);
+                    }
         }
 #pragma unroll
-        for (int t = 0; t < NB; ++t)
+        for (int ug = 0; ug < UG; ++ug)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][t][r * 64 + lane] = acc[t][r];
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][ug * NB + t][r * 64 + lane] = acc[ug][t][r];
         __syncthreads();
-        for (int t = wave; t < NB; t += 4) {             // wave w finishes batch tiles w, w + 4, ..
+        for (int s_ = wave; s_ < UG * NB; s_ += 4) {         // wave w finishes (unit group, batch tile) slots w, w + 4, ..
+            const int ug = s_ / NB, t = s_ - ug * NB;
             const int b = b0 + 16 * t + i;
+            const int ud = u0 + 4 * ug + g;
+            const bool uv = ud < H;
             float g4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                g4[r] = (bias[r] + gxv[r]) + ((red[0][t][r * 64 + lane] + red[1][t][r * 64 + lane]) + (red[2][t][r * 64 + lane] + red[3][t][r * 64 + lane]));
+            for (int r = 0; r < 4; ++r) {
+                float gxv = 0.f;
+                if (gxp) gxv = gxp[(int64_t)(b < p.B ? b : p.B - 1) * p.gxstride + (uv ? ud : 0) + r * H];
+                float bsel = bias[0][r];
+#pragma unroll
+                for (int q = 1; q < UG; ++q) bsel = ug == q ? bias[q][r] : bsel;
+                g4[r] = (bsel + gxv) + ((red[0][s_][r * 64 + lane] + red[1][s_][r * 64 + lane]) + (red[2][s_][r * 64 + lane] + red[3][s_][r * 64 + lane]));
+            }
             if (b < p.B && uv) {
                 const int64_t si = (int64_t)b * H + ud;
                 const float c0 = cprev ? cprev[si] : 0.f;
@@ -511,7 +529,11 @@ int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st) {
     {
         const int nbv = a.B > 32 ? 4 : (a.B > 16 ? 2 : 1);
         const dim3 gridz(grid.x, grid.y, (unsigned)((a.B + 16 * nbv - 1) / (16 * nbv)));
-        if (a.B > 32) hipLaunchKernelGGL(lstm_step_kernel<4>, gridz, dim3(256), 0, st, a);
+        if (a.B >= 256 && a.H % 8 == 0) {               // many row slabs: two unit groups per workgroup (half the re-reads of the row operand)
+            const dim3 grid2((unsigned)((a.H + 7) / 8), grid.y, gridz.z);
+            hipLaunchKernelGGL((lstm_step_kernel<4, 2>), grid2, dim3(256), 0, st, a);
+        }
+        else if (a.B > 32) hipLaunchKernelGGL(lstm_step_kernel<4>, gridz, dim3(256), 0, st, a);
         else if (a.B > 16) hipLaunchKernelGGL(lstm_step_kernel<2>, gridz, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(lstm_step_kernel<1>, gridz, dim3(256), 0, st, a);
         NIR_CHECK_LAUNCH("lstm_step_kernel");
