@@ -280,8 +280,19 @@ __global__ void add_weights_kernel(const float* a, const float* b, float* o, int
     if (i < n) o[i] = a[i] + b[i];
 }
 
+// h [n = rows * H] fp32 -> the fp16 term pairs of lstm_step16_kernel's B operand: [row][H/8][2 terms][8]  (H % 8 == 0)
+__global__ void h16_pack_kernel(const float* __restrict__ h, int64_t n, _Float16* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float v = h[e];
+    const _Float16 a = (_Float16)v;
+    _Float16* d = out + (e >> 3) * 16 + (e & 7);
+    d[0] = a;
+    d[8] = (_Float16)((v - (float)a) * 2048.0f);
+}
+
 struct DecPlan {
-    float *mem, *sess, *h[2], *c[2], *qv, *cat, *ah, *p1, *logits, *pval;
+    float *mem, *sess, *h[2], *c[2], *h16[2], *qv, *cat, *ah, *p1, *logits, *pval;
     int* pidx;
     int64_t* tgt;
     size_t bytes;
@@ -304,6 +315,7 @@ static DecPlan dec_plan(void* ws, size_t cap, int64_t rows_src, int64_t Bd, int 
     p.mem = a.take<float>((size_t)rows_src * QL * HD);
     p.sess = a.take<float>((size_t)Bd * P);
     for (int k = 0; k < 2; ++k) { p.h[k] = a.take<float>((size_t)Bd * HD); p.c[k] = a.take<float>((size_t)Bd * HD); }
+    for (int k = 0; k < 2; ++k) p.h16[k] = a.take<float>((size_t)Bd * HD);      // the state as fp16 term pairs [Bd][HD/8][2][8] (fp16-term decoder step)
     p.qv = a.take<float>((size_t)Bd * HD);
     p.cat = a.take<float>((size_t)Bd * 2 * HD);
     p.ah = a.take<float>((size_t)Bd * HD);
@@ -375,12 +387,26 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
     a.x[1] = nullptr; a.xid[1] = nullptr; a.xstride[1] = 0; a.wih[1] = a.whh[1] = a.bih[1] = a.bhh[1] = nullptr;
     a.hprev[1] = a.cprev[1] = nullptr; a.hnext[1] = a.cnext[1] = nullptr;
     a.chain0 = 0; a.B = (int)Bd; a.I = E; a.H = HD;
+    // fp16-term decoder step: emb(token) W_ih^T + b_ih + b_hh is a per-token row of the folded gate table (gathered by the previous step's ids),
+    // the recurrent product runs on pre-split W_hh fragments and the state travels as term pairs next to its fp32 copy
+    const bool step16 = w->rnn_gate_fold && w->rnn_whh_frag && HD % 32 == 0 && !tun(g_tun.exact_f32);
+    if (step16) {
+        a.gx[0] = w->rnn_gate_fold; a.gxid[0] = p.tgt; a.gxstride = (int64_t)4 * HD; a.gx_unit_major = 1;
+        a.whh_frag[0] = w->rnn_whh_frag;
+        const int64_t n = Bd * HD;
+        hipLaunchKernelGGL(h16_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dec_h, n, reinterpret_cast<_Float16*>(p.h16[1]));
+        NIR_CHECK_LAUNCH("h16_pack_kernel");
+    }
     const float* hp = dec_h;
     const float* cp = dec_c;
     for (int step = 0; step < max_len; ++step) {
         float* hn = p.h[step & 1];
         float* cn = p.c[step & 1];
         a.hprev[0] = hp; a.cprev[0] = cp; a.hnext[0] = hn; a.cnext[0] = cn;
+        if (step16) {
+            a.h16prev[0] = reinterpret_cast<const _Float16*>(p.h16[(step + 1) & 1]);
+            a.h16next[0] = reinterpret_cast<_Float16*>(p.h16[step & 1]);
+        }
         NIR_PROPAGATE(launch_lstm_step(a, 1, st));
         NIR_PROPAGATE(launch_linear(hn, HD, nullptr, nullptr, 0, 0, 0, w->attn_in_w, HD, nullptr, nullptr, p.qv, HD, Bd, HD, HD, NIR_ACT_NONE, st));
         {

@@ -388,9 +388,17 @@ __global__ __launch_bounds__(256) void lstm_step16_kernel(LstmStepArgs p) {
             const int e = wave + 4 * k, u = e / NB, t = e % NB;       // (u, t) are compile-time per k only up to the wave offset: plain integer math
             const int bq = b0 + 16 * t + i;
             const int ud = 4 * (blockIdx.x * UG + u) + g;
-            const float* gr = gxp + (int64_t)(bq < p.B ? bq : p.B - 1) * p.gxstride + (ud < H ? ud : H - 1);
+            const int64_t brow = bq < p.B ? bq : p.B - 1;
+            const int udc = ud < H ? ud : H - 1;
+            const float* gr = gxp + (p.gxid[ch] ? p.gxid[ch][brow] : brow) * p.gxstride;
+            if (p.gx_unit_major) {
+                const float4 v = *reinterpret_cast<const float4*>(gr + 4 * udc);
+                gxv[k][0] = v.x; gxv[k][1] = v.y; gxv[k][2] = v.z; gxv[k][3] = v.w;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gxv[k][r] = (e < NE) ? gr[r * H] : 0.f;
+                for (int r = 0; r < 4; ++r) gxv[k][r] = gr[udc + r * H];
+            }
+            if (e >= NE) gxv[k][0] = gxv[k][1] = gxv[k][2] = gxv[k][3] = 0.f;
         }
         f32x4 acc[UG][NB], acx[UG][NB];
 #pragma unroll
@@ -509,7 +517,9 @@ int launch_lstm_step(const LstmStepArgs& a, int nchains, hipStream_t st) {
         const int NUG = a.H / 4;
         int NBv = nbsel ? nbsel : (a.B > 32 ? 4 : (a.B > 16 ? 2 : 1));
         NBv = NBv >= 4 ? 4 : (NBv >= 2 ? 2 : 1);
-        const int UGv = ugsel == 4 ? 4 : (ugsel == 2 ? 2 : 1);
+        // (from 256 rows on -- the greedy decoders' 768 -- the [rows, H] state operand is re-read once per workgroup column: four unit groups per workgroup)
+        const int ugd = ugsel ? ugsel : (a.B >= 256 ? 4 : 1);
+        const int UGv = ugd == 4 ? 4 : (ugd == 2 ? 2 : 1);
         const dim3 gridu((unsigned)((NUG + UGv - 1) / UGv), (unsigned)nchains, (unsigned)((a.B + 16 * NBv - 1) / (16 * NBv)));
         if (NBv == 4) {
             if (UGv == 4) hipLaunchKernelGGL((lstm_step16_kernel<4, 4, 2>), gridu, dim3(256), 0, st, a);

@@ -186,6 +186,10 @@ struct LstmStepArgs {
     // one batched GEMM in front of the loop (the inputs of the session chains do not depend on the recurrence); the step then walks W_hh only
     const float* gx[2] = {nullptr, nullptr};
     int64_t gxstride = 0;
+    // (fp16-term step only) gxid != NULL: row b of the gate rows is gx + gxid[b] * gxstride (a folded per-token gate table gathered by the
+    // previous step's token ids: the greedy decoders); gx_unit_major: a gate row is [unit][i,f,g,o] (nir_lstm_fold_table's order), not [gate][unit]
+    const int64_t* gxid[2] = {nullptr, nullptr};
+    int gx_unit_major = 0;
     // whh_frag != NULL (H % 32 == 0): W_hh pre-split into two fp16 terms in MFMA-fragment order (nir_lstm_step_pack_whh_frag) and the previous
     // state ALSO kept as fp16 term pairs (h16prev / h16next: [B][H/8][2 terms][8]) -- the recurrent product then runs as three
     // v_mfma_f32_16x16x32_f16 per 32-wide k-block (fp32-class, like the folded recurrences) instead of eight v_mfma_f32_16x16x4_f32

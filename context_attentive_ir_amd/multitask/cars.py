@@ -133,6 +133,7 @@ class CARS(nn.Module, lib.IdCheck):
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
         self.fuse_attention_pooling = True   # attention MLP + masked softmax + weighted sum as one kernel (csrc/cars_attn.hip)
         self.fuse_decoder_argmax = True      # decode: 256 -> V_tgt projection + arg-max as one kernel, no [Bd, V_tgt] logits
+        self.fold_decoder_step = True        # decode: per-token gate rows of the decoder LSTM folded into a [V, 4HD] table + fp16-term recurrent product
         self.fold_budget_bytes = 64 << 30
         self.compute_dtype = getattr(args, "compute_dtype", "f32")
         self._fq, self._fd = lib.PackCache(retain=1), lib.PackCache(retain=1)
@@ -275,10 +276,26 @@ class CARS(nn.Module, lib.IdCheck):
                 planes = torch.stack(lib.split_f16x2(pad, P))                         # [2 terms, vp, P] int16
                 pk.keep["pred2_frag"] = planes.view(2, vp // 16, 16, P // 32, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
                 pk.struct.pred2_frag = pk.keep["pred2_frag"].data_ptr()
+            # the decoder LSTM's input is the previous token's embedding alone: its gate half is a per-token row, folded once per weight version;
+            # W_hh as fp16 term fragments (a weight outside the split's range keeps the fp32-MFMA step)
+            table = self.embedder.word_embeddings.table
+            HD = int(rnn.hidden_size)
+            nb = lib.load().nir_lstm_step_whh_frag_bytes(HD)
+            if (self.fold_decoder_step and self.fold_embeddings and nb and table.is_cuda and table.shape[1] == rnn.input_size
+                    and table.shape[0] * 4 * HD * 4 <= self.fold_budget_bytes):
+                frag, flag = torch.empty(nb, dtype=torch.uint8, device=table.device), torch.zeros(1, dtype=torch.int32, device=table.device)
+                lib.check(lib.load().nir_lstm_step_pack_whh_frag(lib.ptr(pk.keep["rnn_whh"]), HD, lib.ptr(frag), lib.ptr(flag), lib.stream()),
+                          "nir_lstm_step_pack_whh_frag")
+                if int(flag.item()) == 0:
+                    pk.keep["rnn_whh_frag"] = frag
+                    pk.keep["rnn_gate_fold"] = lib.fold_lstm_table(table, pk.keep["rnn_wih"], pk.keep["rnn_bih"], pk.keep["rnn_bhh"], HD, 1, "f32")
+                    pk.struct.rnn_whh_frag = frag.data_ptr()
+                    pk.struct.rnn_gate_fold = pk.keep["rnn_gate_fold"].data_ptr()
             return pk
         mods = [self.decoder, self.dec_attn, self.token_prob_predictor1, self.token_prob_predictor2,
                 self.shared_session_projector, self.private_session_projector2]
-        return self._pdec.get([p for m in mods for p in m.parameters()], build)
+        return self._pdec.get([p for m in mods for p in m.parameters()] + [self.embedder.word_embeddings.table, self.fold_decoder_step,
+                                                                         self.fuse_decoder_argmax], build)
 
     def _check_eval(self):
         if self.training:

@@ -430,6 +430,11 @@ typedef struct {
                                                            zero-padded to a multiple of 16, split into two fp16 terms (x = x1 + 2^-11 x2', needs |w| < 2^15)
                                                            in MFMA A-fragment order [VT/16][P/32][2 terms][64 lanes][8]: the projection and the arg-max
                                                            then run as ONE kernel and the [Bd, VT] logits are never written */
+    const float* rnn_gate_fold;                         /* optional, both or neither (NULL: the step multiplies the gathered embedding row by rnn_wih on the */
+    const void* rnn_whh_frag;                           /* fp32 matrix cores): nir_lstm_fold_table(table, rnn_wih, rnn_bih, rnn_bhh, H = HD, ndir = 1, f32)
+                                                           [V, 4HD] -- the input half of the gates depends only on the previous token -- and
+                                                           nir_lstm_step_pack_whh_frag(rnn_whh, HD) (HD % 32 == 0, |w| < 2^15): the step then gathers its gate
+                                                           rows by token id and runs the recurrent product as fp16 term pairs (fp32-class, like the session steps) */
 } nir_cars_decoder_weights;
 /* out = a + b (weight packing helper). */
 int nir_add_f32(const float* a, const float* b, float* out, int64_t n, nir_stream_t stream);

@@ -144,6 +144,40 @@ def test_decode_fused_projection_argmax_matches_logits_path(B, S, VT):
     assert float(agree) >= 0.97, float(agree)
 
 
+@pytest.mark.parametrize("B,S,VT", [(20, 7, 1000), (3, 4, 37), (70, 7, 5000)])
+def test_decode_folded_gate_step_matches_fp32_step(B, S, VT):
+    """csrc/cars_decode.hip with rnn_gate_fold / rnn_whh_frag (the decoder LSTM's input half of the gates as a per-token row of a folded
+    [V, 4HD] table, the recurrent product as fp16 term pairs: lstm_step16_kernel with gxid) against the fp32-MFMA step that multiplies the
+    gathered embedding row by W_ih (decoders/decoder.py:94-95): 18 / 120 / 420 decode rows (the last takes the 256-row launch shape).
+    Identical predictions except at near-ties of the two top logits (rows compared whole)."""
+    from context_attentive_ir_amd import synth
+    V = 3000
+    m = build_model("CARS", vocab=V, tgt_vocab_size=VT, device=DEV)
+    ex = {k: v.to(DEV) for k, v in synth.session_batch(B, S, 5, 4, 12, V, seed=B + VT, full_length=False).items()}
+    pooled, enc, _ = m.encode(ex["source_words"], ex["source_lens"])
+    _, st, at = m.rank_document(pooled, ex["document_words"], ex["document_lens"], ex["document_labels"])
+    lut = torch.randint(4, V, (VT,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    kw = dict(states=st, max_len=8, src_dict=None, tgt_dict=None, batch_size=B, session_len=S - 1, use_cuda=True, encoded_source=enc,
+              source_len=ex["source_lens"], session_attns=at, tgt2src=lut)
+    w = m._decoder_weights()
+    assert w.struct.rnn_gate_fold and w.struct.rnn_whh_frag
+    folded = m.decode(**kw)["predictions"].cpu()
+    m.fold_decoder_step = False
+    w = m._decoder_weights()
+    assert not w.struct.rnn_gate_fold and not w.struct.rnn_whh_frag
+    plain = m.decode(**kw)["predictions"].cpu()
+    assert folded.shape == (B, S - 1, 8) and int(folded.min()) >= 0
+    agree = (folded == plain).all(-1).float().mean()
+    assert float(agree) >= 0.97, float(agree)
+    # a recurrent weight outside the fp16 split's range keeps the fp32 step
+    m.fold_decoder_step = True
+    with torch.no_grad():
+        m.decoder.decoder.rnn.weight_hh_l0[0, 0] = 1.0e5
+    w = m._decoder_weights()
+    assert not w.struct.rnn_gate_fold and not w.struct.rnn_whh_frag
+    assert m.decode(**kw)["predictions"].shape == (B, S - 1, 8)
+
+
 def test_tail_over_blocks_of_several_batches_keeps_each_batchs_click_count():
     """Merged tail (wrappers.Multitask.tail_probs with labels_groups): blocks of sessions taken from three DIFFERENT batches run as one
     call -- the session weights are streamed once -- and every block still uses the batch-wide max click count m of ITS OWN batch
