@@ -174,21 +174,41 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
             for (int u = 0; u < TW; ++u)
 #pragma unroll
                 for (int bt = 0; bt < PA_NBT; ++bt) { acc[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[u][bt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int ks = 0; ks < PA_KS; ++ks) {
-                const _Float16* bp = pa_sm + c16 * PA_LD + 32 * ks + 8 * g4;
+            // The decode rows' fragments of k-step ks + 1 are read from LDS while the MFMAs of k-step ks run (two register sets), and a k-step's
+            // MFMAs go in three passes over the six row tiles so that no MFMA waits for the one issued just before it.  (Before: two
+            // ds_read_b128 -> wait -> three MFMAs per row tile, the middle one dependent on the first: with ONE wave per SIMD every LDS round
+            // trip was exposed -- 48 of them per vocabulary tile, ~45 of the launch's 57 us; removing the W stream entirely changed nothing.)
+            const _Float16* bp0 = pa_sm + c16 * PA_LD + 8 * g4;
+            f16x8 bq[2][PA_NBT][2];
+            auto ldb = [&](int ks, f16x8 (&b)[PA_NBT][2]) {
 #pragma unroll
                 for (int bt = 0; bt < PA_NBT; ++bt) {
-                    const f16x8 b1 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD);
-                    const f16x8 b2 = *reinterpret_cast<const f16x8*>(bp + bt * 16 * PA_LD + PA_ROWS * PA_LD);
-#pragma unroll
-                    for (int u = 0; u < TW; ++u) {
-                        acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][1], b1, acx[u][bt], 0, 0, 0);
-                        acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][0], b2, acx[u][bt], 0, 0, 0);
-                        acc[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][0], b1, acc[u][bt], 0, 0, 0);
-                    }
+                    b[bt][0] = *reinterpret_cast<const f16x8*>(bp0 + 32 * ks + bt * 16 * PA_LD);
+                    b[bt][1] = *reinterpret_cast<const f16x8*>(bp0 + 32 * ks + bt * 16 * PA_LD + PA_ROWS * PA_LD);
                 }
-                __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads of later k-steps from being hoisted (384 more live registers: spills)
+            };
+            ldb(0, bq[0]);
+#pragma unroll
+            for (int ks = 0; ks < PA_KS; ++ks) {
+                if (ks + 1 < PA_KS) ldb(ks + 1, bq[(ks + 1) & 1]);
+                const f16x8 (&b)[PA_NBT][2] = bq[ks & 1];
+#pragma unroll
+                for (int u = 0; u < TW; ++u) {
+#pragma unroll
+                    for (int bt = 0; bt < PA_NBT; ++bt) acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][1], b[bt][0], acx[u][bt], 0, 0, 0);
+#pragma unroll
+                    for (int bt = 0; bt < PA_NBT; ++bt) acc[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][0], b[bt][0], acc[u][bt], 0, 0, 0);
+#pragma unroll
+                    for (int bt = 0; bt < PA_NBT; ++bt) acx[u][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][u][0], b[bt][1], acx[u][bt], 0, 0, 0);
+                }
+                // one LDS read between MFMAs: the 12 reads of the next k-step spread under this k-step's 18 MFMAs
+#pragma unroll
+                for (int i = 0; i < 2 * PA_NBT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * PA_NBT * TW - 2 * PA_NBT, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int u = 0; u < TW; ++u) {

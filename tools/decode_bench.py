@@ -1,5 +1,5 @@
 """Only bench.py's C3_cars_with_decode sub-record (full Multitask.predict: ranking + greedy decode, macro-batches of 8, 4 in flight).
-python tools/decode_bench.py"""
+python tools/decode_bench.py [--streams N]"""
 import json
 import os
 import sys
@@ -10,7 +10,7 @@ import bench  # noqa: E402
 
 
 def main():
-    sys.argv = ["bench.py", "--no-cpu-baseline"]
+    sys.argv = ["bench.py", "--no-cpu-baseline"] + sys.argv[1:]          # e.g. --streams 1: one macro-batch in flight (isolated kernel times under rocprofv3)
     args = bench.parse()
     env = bench.Env(1)
     r = bench.decode_record(dict(bench.CONFIGS[bench.HEADLINE]), args, env)
