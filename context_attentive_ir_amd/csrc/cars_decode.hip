@@ -30,8 +30,8 @@ int launch_linear_ex(const float* a, int64_t lda, const int64_t* ids, const floa
 
 // one wave per decode row i: memory block = mem[rowmap[i]] ([QL, HD]), valid length = lens[rowmap[i]]
 __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict__ qv, const float* __restrict__ h,
-                                                         const float* __restrict__ mem, const int64_t* __restrict__ rowmap,
-                                                         const int64_t* __restrict__ lens, int Bd, int QL, int HD,
+                                                         const float* __restrict__ mem, const float* __restrict__ memq,
+                                                         const int64_t* __restrict__ rowmap, const int64_t* __restrict__ lens, int Bd, int QL, int HD,
                                                          float* __restrict__ cat) {
     extern __shared__ float pr[];                 // [4][QL]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -42,12 +42,13 @@ __global__ __launch_bounds__(256) void dec_attend_kernel(const float* __restrict
     int len = (int)lens[r];
     len = len < 0 ? 0 : (len > QL ? QL : len);
     const float* mb = mem + r * QL * HD;
+    const float* mq = memq + r * QL * HD;       // the bank the scores are taken against (== mem, or the bank with linear_in folded in)
     const float* q = qv + (int64_t)i * HD;
     float mx = -INFINITY;
     for (int j = 0; j < len; ++j) {
         float s = 0.f;
         for (int f = 4 * lane; f < HD; f += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(mb + (int64_t)j * HD + f), b = *reinterpret_cast<const float4*>(q + f);
+            const float4 a = *reinterpret_cast<const float4*>(mq + (int64_t)j * HD + f), b = *reinterpret_cast<const float4*>(q + f);
             s += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
         }
         s = wave_sum(s);
@@ -312,7 +313,7 @@ __global__ void h16_pack_kernel(const float* __restrict__ h, int64_t n, _Float16
 }
 
 struct DecPlan {
-    float *mem, *sess, *h[2], *c[2], *h16[2], *qv, *cat, *ah, *p1, *logits, *pval;
+    float *mem, *memq, *sess, *h[2], *c[2], *h16[2], *qv, *cat, *ah, *p1, *logits, *pval;
     int* pidx;
     int64_t* tgt;
     size_t bytes;
@@ -329,10 +330,11 @@ static int cu_count() {
     });
     return n;
 }
-static DecPlan dec_plan(void* ws, size_t cap, int64_t rows_src, int64_t Bd, int QL, int HD, int P, int64_t VT, bool fused_argmax) {
+static DecPlan dec_plan(void* ws, size_t cap, int64_t rows_src, int64_t Bd, int QL, int HD, int P, int64_t VT, bool fused_argmax, bool foldq) {
     Workspace a(ws, cap);
     DecPlan p;
     p.mem = a.take<float>((size_t)rows_src * QL * HD);
+    p.memq = a.take<float>(foldq ? (size_t)rows_src * QL * HD : 0);
     p.sess = a.take<float>((size_t)Bd * P);
     for (int k = 0; k < 2; ++k) { p.h[k] = a.take<float>((size_t)Bd * HD); p.c[k] = a.take<float>((size_t)Bd * HD); }
     for (int k = 0; k < 2; ++k) p.h16[k] = a.take<float>((size_t)Bd * HD);      // the state as fp16 term pairs [Bd][HD/8][2][8] (fp16-term decoder step)
@@ -361,7 +363,7 @@ extern "C" int nir_add_f32(const float* a, const float* b, float* out, int64_t n
 
 extern "C" size_t nir_cars_decode_workspace_bytes(int64_t rows_src, int64_t Bd, int QL, const nir_cars_decoder_weights* w) {
     if (!w || rows_src < 0 || Bd < 0 || QL <= 0) return 0;
-    return nir::dec_plan(nullptr, 0, rows_src, Bd, QL, w->HD, w->P, w->VT, w->pred2_frag != nullptr && w->P == nir::PA_K).bytes;
+    return nir::dec_plan(nullptr, 0, rows_src, Bd, QL, w->HD, w->P, w->VT, w->pred2_frag != nullptr && w->P == nir::PA_K, w->attn_q_w != nullptr).bytes;
 }
 
 extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, const float* encoded_source, const int64_t* source_len,
@@ -379,7 +381,8 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
     if (Bd == 0) return 0;
     const int HD = w->HD, P = w->P;
     const bool fused_argmax = w->pred2_frag != nullptr && P == PA_K && w->VT < 0x7FFFFFF0LL;
-    DecPlan p = dec_plan(workspace, workspace_bytes, rows_src, Bd, QL, HD, P, w->VT, fused_argmax);
+    const bool foldq = w->attn_q_w != nullptr;
+    DecPlan p = dec_plan(workspace, workspace_bytes, rows_src, Bd, QL, HD, P, w->VT, fused_argmax, foldq);
     const int64_t ntiles = (w->VT + 15) / 16;
     // vocabulary ranges per row block: enough workgroups for the chip, at least ~4 tiles per wave
     const int64_t pa_rb = (Bd + PA_ROWS - 1) / PA_ROWS;
@@ -395,6 +398,11 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
     // memory bank = dec_attn(encoded queries)  (cars.py:757-767), all (session, query) rows; rowmap picks [:, :-1]
     NIR_PROPAGATE(launch_linear(encoded_source, w->DQ, nullptr, nullptr, 0, 0, 0, w->dec_attn_w, w->DQ, nullptr, nullptr, p.mem, HD,
                                 rows_src * QL, HD, w->DQ, NIR_ACT_NONE, st));
+    // attn.linear_in folded into a second bank: score_j = (W_in h) . mem_j = h . (W_in^T mem_j) -- memq = encoded (W_in^T W_dec_attn)^T, one GEMM per
+    // decode instead of one [Bd, HD] x [HD, HD] GEMM per step (global_attention.py:139-150 'general')
+    if (foldq)
+        NIR_PROPAGATE(launch_linear(encoded_source, w->DQ, nullptr, nullptr, 0, 0, 0, w->attn_q_w, w->DQ, nullptr, nullptr, p.memq, HD,
+                                    rows_src * QL, HD, w->DQ, NIR_ACT_NONE, st));
     // session_rep = (shared + private2)(cat_session_rep[:, :-1])  (cars.py:775-778): rows gathered through rowmap
     if (w->KS > 0)
         NIR_PROPAGATE(launch_linear(nullptr, 0, rowmap, session_cat, w->KS, 1, 1, w->sess_w, w->KS, nullptr, nullptr, p.sess, P, Bd, P, w->KS,
@@ -428,10 +436,11 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
             a.h16next[0] = reinterpret_cast<_Float16*>(p.h16[step & 1]);
         }
         NIR_PROPAGATE(launch_lstm_step(a, 1, st));
-        NIR_PROPAGATE(launch_linear(hn, HD, nullptr, nullptr, 0, 0, 0, w->attn_in_w, HD, nullptr, nullptr, p.qv, HD, Bd, HD, HD, NIR_ACT_NONE, st));
+        if (!foldq)
+            NIR_PROPAGATE(launch_linear(hn, HD, nullptr, nullptr, 0, 0, 0, w->attn_in_w, HD, nullptr, nullptr, p.qv, HD, Bd, HD, HD, NIR_ACT_NONE, st));
         {
             ProfScope ps("dec_attend_kernel", st);
-            hipLaunchKernelGGL(dec_attend_kernel, dim3((unsigned)((Bd + 3) / 4)), dim3(256), (size_t)4 * QL * 4, st, p.qv, hn, p.mem, rowmap,
+            hipLaunchKernelGGL(dec_attend_kernel, dim3((unsigned)((Bd + 3) / 4)), dim3(256), (size_t)4 * QL * 4, st, foldq ? hn : p.qv, hn, p.mem, foldq ? p.memq : p.mem, rowmap,
                                source_len, (int)Bd, QL, HD, p.cat);
         }
         NIR_CHECK_LAUNCH("dec_attend_kernel");

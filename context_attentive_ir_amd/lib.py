@@ -58,7 +58,7 @@ CarsSessionWeights = type("nir_cars_session_weights", (C.Structure,), {"_fields_
 class CarsDecoderWeights(C.Structure):
     _fields_ = [(f, c_fp) for f in ("rnn_wih", "rnn_whh", "rnn_bih", "rnn_bhh", "attn_in_w", "attn_out_w", "dec_attn_w", "pred1_w",
                                     "pred2_w", "sess_w")] + [(f, C.c_int) for f in ("HD", "DQ", "P", "KS")] + [("VT", C.c_int64), ("pred2_frag", C.c_void_p), ("rnn_gate_fold", C.c_void_p),
-                                                                                                           ("rnn_whh_frag", C.c_void_p)]
+                                                                                                           ("rnn_whh_frag", C.c_void_p), ("attn_q_w", C.c_void_p)]
 
 
 CarsSessionOutputs = _struct("nir_cars_session_outputs", ["inner_q", "inner_d", "dec_h", "dec_c"])

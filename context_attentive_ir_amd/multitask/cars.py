@@ -134,6 +134,7 @@ class CARS(nn.Module, lib.IdCheck):
         self.fuse_attention_pooling = True   # attention MLP + masked softmax + weighted sum as one kernel (csrc/cars_attn.hip)
         self.fuse_decoder_argmax = True      # decode: 256 -> V_tgt projection + arg-max as one kernel, no [Bd, V_tgt] logits
         self.fold_decoder_step = True        # decode: per-token gate rows of the decoder LSTM folded into a [V, 4HD] table + fp16-term recurrent product
+        self.fold_decoder_query = True       # decode: attn.linear_in folded into a second memory bank (one GEMM per decode instead of one per step)
         self.fold_budget_bytes = 64 << 30
         self.compute_dtype = getattr(args, "compute_dtype", "f32")
         self._fq, self._fd = lib.PackCache(retain=1), lib.PackCache(retain=1)
@@ -276,6 +277,15 @@ class CARS(nn.Module, lib.IdCheck):
                 planes = torch.stack(lib.split_f16x2(pad, P))                         # [2 terms, vp, P] int16
                 pk.keep["pred2_frag"] = planes.view(2, vp // 16, 16, P // 32, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
                 pk.struct.pred2_frag = pk.keep["pred2_frag"].data_ptr()
+            if self.fold_decoder_query and w2.is_cuda:
+                HDa, DQ = self.dec_attn.weight.shape
+                a_t = pk.keep["attn_in_w"].t().contiguous()                            # [HD(k), HD(o)]
+                d_t = pk.keep["dec_attn_w"].t().contiguous()                           # [DQ, HD(o)]
+                wq = torch.empty(HDa, DQ, device=w2.device, dtype=torch.float32)       # wq[k, d] = sum_o W_in[o, k] W_dec_attn[o, d]
+                lib.check(lib.load().nir_linear_f32(lib.ptr(a_t), HDa, None, None, 0, 0, 0, lib.ptr(d_t), HDa, None, None, lib.ptr(wq), DQ, HDa, DQ, HDa,
+                                                    0, lib.stream()), "nir_linear_f32")
+                pk.keep["attn_q_w"] = wq
+                pk.struct.attn_q_w = wq.data_ptr()
             # the decoder LSTM's input is the previous token's embedding alone: its gate half is a per-token row, folded once per weight version;
             # W_hh as fp16 term fragments (a weight outside the split's range keeps the fp32-MFMA step)
             table = self.embedder.word_embeddings.table
@@ -295,7 +305,7 @@ class CARS(nn.Module, lib.IdCheck):
         mods = [self.decoder, self.dec_attn, self.token_prob_predictor1, self.token_prob_predictor2,
                 self.shared_session_projector, self.private_session_projector2]
         return self._pdec.get([p for m in mods for p in m.parameters()] + [self.embedder.word_embeddings.table, self.fold_decoder_step,
-                                                                         self.fuse_decoder_argmax], build)
+                                                                         self.fuse_decoder_argmax, self.fold_decoder_query], build)
 
     def _check_eval(self):
         if self.training:

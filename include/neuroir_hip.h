@@ -435,6 +435,8 @@ typedef struct {
                                                            [V, 4HD] -- the input half of the gates depends only on the previous token -- and
                                                            nir_lstm_step_pack_whh_frag(rnn_whh, HD) (HD % 32 == 0, |w| < 2^15): the step then gathers its gate
                                                            rows by token id and runs the recurrent product as fp16 term pairs (fp32-class, like the session steps) */
+    const float* attn_q_w;                              /* optional (NULL: one linear_in GEMM per step): attn_in_w^T dec_attn_w [HD, DQ] -- the attention scores
+                                                           are taken against a second memory bank encoded_source attn_q_w^T, built once per decode */
 } nir_cars_decoder_weights;
 /* out = a + b (weight packing helper). */
 int nir_add_f32(const float* a, const float* b, float* out, int64_t n, nir_stream_t stream);

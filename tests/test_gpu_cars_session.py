@@ -160,11 +160,12 @@ def test_decode_folded_gate_step_matches_fp32_step(B, S, VT):
     kw = dict(states=st, max_len=8, src_dict=None, tgt_dict=None, batch_size=B, session_len=S - 1, use_cuda=True, encoded_source=enc,
               source_len=ex["source_lens"], session_attns=at, tgt2src=lut)
     w = m._decoder_weights()
-    assert w.struct.rnn_gate_fold and w.struct.rnn_whh_frag
+    assert w.struct.rnn_gate_fold and w.struct.rnn_whh_frag and w.struct.attn_q_w
     folded = m.decode(**kw)["predictions"].cpu()
     m.fold_decoder_step = False
+    m.fold_decoder_query = False         # (and attn.linear_in per step instead of folded into a second memory bank)
     w = m._decoder_weights()
-    assert not w.struct.rnn_gate_fold and not w.struct.rnn_whh_frag
+    assert not w.struct.rnn_gate_fold and not w.struct.rnn_whh_frag and not w.struct.attn_q_w
     plain = m.decode(**kw)["predictions"].cpu()
     assert folded.shape == (B, S - 1, 8) and int(folded.min()) >= 0
     agree = (folded == plain).all(-1).float().mean()
