@@ -134,11 +134,28 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
     const int64_t t_lo = (int64_t)vr * per_wg, t_hi = min(ntiles, t_lo + per_wg);
     {
         const int64_t b0 = (int64_t)(blockIdx.x / nvr) * PA_ROWS;
-        for (int e = tid; e < PA_ROWS * (PA_K / 4); e += 256) {            // stage + split this pass's decode rows (zero rows past Bd)
+        // stage + split this workgroup's decode rows (zero rows past Bd).  ALL 24 float4 loads of a thread are issued before the first is
+        // converted (unconditional, from a clamped row: a branch around a load puts an s_waitcnt vmcnt(0) at its join): written as one
+        // load -> convert -> ds_write loop the iterations stayed in order, 24 dependent L2 round trips per workgroup -- with a third of the
+        // MFMAs, no epilogue and no W stream the launch still took 31 of its 40 us.  (The requests of the first W fragment sets in front of
+        // the staging loads: no change.)
+        constexpr int PA_SIT = PA_ROWS * (PA_K / 4) / 256;
+        static_assert(PA_ROWS * (PA_K / 4) % 256 == 0, "staging: whole trips");
+        float4 sv[PA_SIT];
+#pragma unroll
+        for (int q = 0; q < PA_SIT; ++q) {
+            const int e = tid + 256 * q;
             const int r = e / (PA_K / 4), k4 = (e - r * (PA_K / 4)) * 4;
             const int64_t b = b0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b < Bd) v = *reinterpret_cast<const float4*>(p1 + b * PA_K + k4);
+            sv[q] = *reinterpret_cast<const float4*>(p1 + (b < Bd ? b : Bd - 1) * PA_K + k4);
+        }
+        __builtin_amdgcn_sched_barrier(0);         // (without it the scheduler pairs the loads with their conversions again, six in flight)
+#pragma unroll
+        for (int q = 0; q < PA_SIT; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e / (PA_K / 4), k4 = (e - r * (PA_K / 4)) * 4;
+            float4 v = sv[q];
+            if (b0 + r >= Bd) v = make_float4(0.f, 0.f, 0.f, 0.f);
             const fp16x2_t a01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), a23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
             const fp16x2_t b01 = __builtin_amdgcn_cvt_pkrtz((v.x - (float)a01[0]) * 2048.0f, (v.y - (float)a01[1]) * 2048.0f);
             const fp16x2_t b23 = __builtin_amdgcn_cvt_pkrtz((v.z - (float)a23[0]) * 2048.0f, (v.w - (float)a23[1]) * 2048.0f);
