@@ -425,7 +425,11 @@ __global__ __launch_bounds__(256) void lstm_step16_kernel(LstmStepArgs p) {
                     for (int u = 0; u < UG; ++u) {
                         w1[c][u] = wf[wbase[u] + (size_t)(kc * 2) * 64];
                         w2[c][u] = wf[wbase[u] + (size_t)(kc * 2 + 1) * 64];
-                    }
+                        if (kb >= KB) {                          // past the end: zero weights, the MFMAs below run unconditionally (a wave-uniform
+                            w1[c][u] = f16x8s{};                 // `continue` around them cost phi copies of every accumulator: 693 v_accvgpr moves,
+                            w2[c][u] = f16x8s{};                 // 512 registers and 32 bytes of scratch per lane in the <4, 4, 2> instantiation;
+                        }                                        // 391 registers and none now.  Slabs of 96 rows (<6, 4>: 256 workgroups at 768
+                    }                                            // rows, one round over the chip) still spill 140-190 bytes: not built)
 #pragma unroll
                     for (int t = 0; t < NB; ++t) {
                         h1[c][t] = *reinterpret_cast<const f16x8s*>(hr[t] + (int64_t)kc * 64);
@@ -435,7 +439,6 @@ __global__ __launch_bounds__(256) void lstm_step16_kernel(LstmStepArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < CK; ++c) {
-                    if (q0 + 4 * c >= KB) continue;
 #pragma unroll
                     for (int u = 0; u < UG; ++u)
 #pragma unroll
