@@ -495,13 +495,22 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" size_t nir_decode_greedy_plain_workspace_bytes(int64_t Bd, int H, int64_t VT) {
     if (Bd <= 0 || H <= 0 || VT <= 0) return 0;
-    return ((size_t)4 * Bd * H + (size_t)Bd * VT) * sizeof(float) + (size_t)Bd * sizeof(int64_t) + 1024;
+    return ((size_t)6 * Bd * H + (size_t)Bd * VT) * sizeof(float) + (size_t)Bd * sizeof(int64_t) + 2048;
 }
 
 extern "C" int nir_decode_greedy_plain(const float* dec_h, const float* dec_c, int64_t Bd, int H, const float* table, int64_t V, int E,
                                        const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* gen_w,
                                        const float* gen_b, int64_t VT, const int64_t* tgt2src, int64_t bos, int max_len, void* workspace,
                                        size_t workspace_bytes, int64_t* predictions, nir_stream_t stream) {
+    return nir_decode_greedy_plain_folded(dec_h, dec_c, Bd, H, table, V, E, w_ih, w_hh, b_ih, b_hh, gen_w, gen_b, VT, tgt2src, bos, max_len, nullptr,
+                                          nullptr, workspace, workspace_bytes, predictions, stream);
+}
+
+extern "C" int nir_decode_greedy_plain_folded(const float* dec_h, const float* dec_c, int64_t Bd, int H, const float* table, int64_t V, int E,
+                                              const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* gen_w,
+                                              const float* gen_b, int64_t VT, const int64_t* tgt2src, int64_t bos, int max_len,
+                                              const float* gate_fold, const void* whh_frag, void* workspace, size_t workspace_bytes,
+                                              int64_t* predictions, nir_stream_t stream) {
     using namespace nir;
     hipStream_t st = (hipStream_t)stream;
     NIR_REQUIRE(dec_h && dec_c && table && w_ih && w_hh && b_ih && b_hh && gen_w && predictions && workspace, "decode_plain: null pointer");
@@ -513,20 +522,35 @@ extern "C" int nir_decode_greedy_plain(const float* dec_h, const float* dec_c, i
     Workspace a(workspace, workspace_bytes);
     float* hb[2] = {a.take<float>((size_t)Bd * H), a.take<float>((size_t)Bd * H)};
     float* cb[2] = {a.take<float>((size_t)Bd * H), a.take<float>((size_t)Bd * H)};
+    float* h16b[2] = {a.take<float>((size_t)Bd * H), a.take<float>((size_t)Bd * H)};       // the state as fp16 term pairs (folded step)
     float* logits = a.take<float>((size_t)Bd * VT);
     int64_t* tgt = a.take<int64_t>((size_t)Bd);
     hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((Bd + 255) / 256)), dim3(256), 0, st, tgt, bos, Bd);
     NIR_CHECK_LAUNCH("fill_i64_kernel");
+    // the decoder's input is the previous token's embedding alone: with a folded gate table + W_hh fragments (both or neither) the step gathers
+    // its gate rows by token id and runs the recurrent product as fp16 term pairs, like nir_cars_decode_greedy
+    const bool step16 = gate_fold && whh_frag && H % 32 == 0 && !tun(g_tun.exact_f32);
     LstmStepArgs s;
     s.x[0] = table; s.xid[0] = tgt; s.xstride[0] = E;
     s.wih[0] = w_ih; s.whh[0] = w_hh; s.bih[0] = b_ih; s.bhh[0] = b_hh;
     s.x[1] = nullptr; s.xid[1] = nullptr; s.xstride[1] = 0; s.wih[1] = s.whh[1] = s.bih[1] = s.bhh[1] = nullptr;
     s.hprev[1] = s.cprev[1] = nullptr; s.hnext[1] = s.cnext[1] = nullptr;
     s.chain0 = 0; s.B = (int)Bd; s.I = E; s.H = H;
+    if (step16) {
+        s.gx[0] = gate_fold; s.gxid[0] = tgt; s.gxstride = (int64_t)4 * H; s.gx_unit_major = 1;
+        s.whh_frag[0] = whh_frag;
+        const int64_t n = Bd * H;
+        hipLaunchKernelGGL(h16_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dec_h, n, reinterpret_cast<_Float16*>(h16b[1]));
+        NIR_CHECK_LAUNCH("h16_pack_kernel");
+    }
     const float* hp = dec_h;
     const float* cp = dec_c;
     for (int step = 0; step < max_len; ++step) {
         s.hprev[0] = hp; s.cprev[0] = cp; s.hnext[0] = hb[step & 1]; s.cnext[0] = cb[step & 1];
+        if (step16) {
+            s.h16prev[0] = reinterpret_cast<const _Float16*>(h16b[(step + 1) & 1]);
+            s.h16next[0] = reinterpret_cast<_Float16*>(h16b[step & 1]);
+        }
         NIR_PROPAGATE(launch_lstm_step(s, 1, st));
         NIR_PROPAGATE(launch_linear(hb[step & 1], H, nullptr, nullptr, 0, 0, 0, gen_w, H, gen_b, nullptr, logits, VT, Bd, (int)VT, H, NIR_ACT_NONE, st));
         {

@@ -102,6 +102,8 @@ SIGNATURES = {
     "nir_decode_greedy_plain_workspace_bytes": (_z, [_l, _i, _l]),
     "nir_decode_greedy_plain": (_i, [c_fp, c_fp, _l, _i, c_fp, _l, _i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, c_ip, _l, _i, C.c_void_p, _z, c_ip,
                                      c_st]),
+    "nir_decode_greedy_plain_folded": (_i, [c_fp, c_fp, _l, _i, c_fp, _l, _i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, c_ip, _l, _i, c_fp, C.c_void_p,
+                                            C.c_void_p, _z, c_ip, c_st]),
     "nir_mnsrf_workspace_bytes": (_z, [_l, _i, _i, _i, _i, C.POINTER(MnsrfWeights)]),
     "nir_mnsrf_encode": (_i, [c_ip, c_ip, _l, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z, c_fp, c_fp, c_st]),
     "nir_mnsrf_encode_states": (_i, [c_ip, c_ip, _l, _i, _i, c_fp, _l, _i, C.POINTER(MnsrfWeights), C.c_void_p, _z, c_fp, c_fp, c_fp, c_fp, c_st]),

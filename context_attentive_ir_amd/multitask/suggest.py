@@ -64,11 +64,28 @@ def greedy_decode(owner, states, max_len, src_dict, tgt_dict, batch_size, sessio
         tgt2src = tgt2src_lut(owner, src_dict, tgt_dict, VT, dev)
     t = table.detach().float().contiguous()
     p = [getattr(dec_rnn, n).detach().float().contiguous() for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    # the decoder LSTM's input is the previous token's embedding alone: gate rows folded per token + W_hh as fp16 term fragments, once per weight
+    # version (a weight outside the split's range, H % 32 != 0 or `fold_decoder_step = False` on the model keep the fp32 step)
+    def build():
+        nb = L.nir_lstm_step_whh_frag_bytes(H)
+        if not (getattr(owner, "fold_decoder_step", True) and nb and t.is_cuda and t.shape[0] * 4 * H * 4 <= getattr(owner, "fold_budget_bytes", 64 << 30)):
+            return None
+        frag, flag = torch.empty(nb, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        lib.check(L.nir_lstm_step_pack_whh_frag(lib.ptr(p[1]), H, lib.ptr(frag), lib.ptr(flag), lib.stream()), "nir_lstm_step_pack_whh_frag")
+        if int(flag.item()) != 0:
+            return None
+        return lib.fold_lstm_table(t, p[0], p[2], p[3], H, 1, "f32"), frag
+    cache = getattr(owner, "_pdec_plain", None)
+    if cache is None:
+        cache = owner._pdec_plain = lib.PackCache(retain=1)
+    fold = cache.get([table] + [getattr(dec_rnn, n) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+                     + [getattr(owner, "fold_decoder_step", True)], build)
     ws = lib.workspace(L.nir_decode_greedy_plain_workspace_bytes(Bd, H, VT), dev)
     preds = torch.empty(Bd, int(max_len), dtype=torch.int64, device=dev)
-    lib.check(L.nir_decode_greedy_plain(lib.ptr(dec_h), lib.ptr(dec_c), Bd, H, lib.ptr(t), t.shape[0], t.shape[1], lib.ptr(p[0]), lib.ptr(p[1]),
-                                        lib.ptr(p[2]), lib.ptr(p[3]), lib.ptr(gw), lib.ptr(gb), VT, lib.ptr(tgt2src), BOS, int(max_len), lib.ptr(ws),
-                                        ws.numel(), lib.ptr(preds), lib.stream()), "nir_decode_greedy_plain")
+    lib.check(L.nir_decode_greedy_plain_folded(lib.ptr(dec_h), lib.ptr(dec_c), Bd, H, lib.ptr(t), t.shape[0], t.shape[1], lib.ptr(p[0]), lib.ptr(p[1]),
+                                               lib.ptr(p[2]), lib.ptr(p[3]), lib.ptr(gw), lib.ptr(gb), VT, lib.ptr(tgt2src), BOS, int(max_len),
+                                               lib.ptr(fold[0]) if fold else None, lib.ptr(fold[1]) if fold else None, lib.ptr(ws),
+                                               ws.numel(), lib.ptr(preds), lib.stream()), "nir_decode_greedy_plain_folded")
     return {"predictions": preds.view(int(batch_size), int(session_len), int(max_len))}
 
 

@@ -509,6 +509,13 @@ int nir_decode_greedy_plain(const float* dec_h, const float* dec_c, int64_t Bd, 
                             const float* w_hh, const float* b_ih, const float* b_hh, const float* gen_w, const float* gen_b, int64_t VT,
                             const int64_t* tgt2src, int64_t bos, int max_len, void* workspace, size_t workspace_bytes, int64_t* predictions,
                             nir_stream_t stream);
+/* The same with the decoder LSTM's input half of the gates folded into a per-token table: gate_fold = nir_lstm_fold_table(table, w_ih, b_ih, b_hh,
+ * H, ndir = 1, f32) [V, 4H], whh_frag = nir_lstm_step_pack_whh_frag(w_hh, H) (H % 32 == 0, |w_hh| < 2^15); both or neither (NULL, NULL = the call
+ * above).  The step gathers its gate rows by the previous token id and runs the recurrent product as fp16 term pairs (fp32-class). */
+int nir_decode_greedy_plain_folded(const float* dec_h, const float* dec_c, int64_t Bd, int H, const float* table, int64_t V, int E,
+                                   const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* gen_w,
+                                   const float* gen_b, int64_t VT, const int64_t* tgt2src, int64_t bos, int max_len, const float* gate_fold,
+                                   const void* whh_frag, void* workspace, size_t workspace_bytes, int64_t* predictions, nir_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * MNSRF, ranking side (neuroir/multitask/mnsrf.py:62-162)

@@ -242,3 +242,33 @@ def test_predict_many_equals_separate_predicts():
     rm = r.predict_many(rex)
     for g in range(3):
         _close(rm[g], r.predict(rex[g]), 1e-6)
+
+
+@pytest.mark.parametrize("Bd,H", [(20, 64), (300, 96)])
+def test_plain_greedy_decode_folded_step_matches_fp32_step(Bd, H):
+    """multitask/suggest.greedy_decode (the decoders of M_MATCH_TENSOR / MNSRF, mmtensor.py:281-325) with the folded gate table + fp16-term
+    recurrent product (nir_decode_greedy_plain_folded) against the fp32-MFMA step: equal predictions up to near-ties of the two top logits."""
+    from context_attentive_ir_amd.multitask import suggest
+
+    class Owner(object):
+        fold_decoder_step = True
+
+    g = torch.Generator().manual_seed(Bd + H)
+    V, E, VT = 900, 48, 700
+    table = torch.randn(V, E, generator=g).to(DEV)
+    rnn = torch.nn.LSTM(E, H, batch_first=True).to(DEV)
+    gen = torch.nn.Linear(H, VT).to(DEV)
+    with torch.no_grad():
+        gen.weight.mul_(30.0)
+    st = (torch.randn(1, Bd, H, generator=g).to(DEV) * 0.5, torch.randn(1, Bd, H, generator=g).to(DEV) * 0.5)
+    o = Owner()
+    kw = dict(states=st, max_len=9, src_dict=None, tgt_dict=None, batch_size=Bd, session_len=1, table=table, dec_rnn=rnn, generator=gen,
+              tgt2src=torch.randint(4, V, (VT,), generator=g).to(DEV))
+    folded = suggest.greedy_decode(o, **kw)["predictions"].cpu()
+    assert o._pdec_plain.val is not None
+    o.fold_decoder_step = False
+    plain = suggest.greedy_decode(o, **kw)["predictions"].cpu()
+    assert o._pdec_plain.val is None
+    assert len(set(plain.view(-1).tolist())) > 5
+    agree = (folded == plain).all(-1).float().mean()
+    assert float(agree) >= 0.97, float(agree)
