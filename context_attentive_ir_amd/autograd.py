@@ -368,25 +368,16 @@ def mt_conv3(T, conv1, conv2, conv3):
 
 def id_flag(device):
     """device int32 flag the train-mode lookups set for an id outside [0, V) (the reference's nn.Embedding raises IndexError)"""
-    f = _ID_FLAGS.get(str(device))
-    if f is None:
-        f = _ID_FLAGS[str(device)] = torch.zeros(1, dtype=torch.int32, device=device)
-    return f
+    _ID_FLAGS[(device.type, device.index)] = device
+    return lib.flags(device).dev
 
 
 def check_ids():
-    """Synchronising: raise IndexError if a train-mode lookup since the last check saw an id outside the vocabulary."""
-    for f in _ID_FLAGS.values():
-        v = int(f.item())
-        if v != 0:
-            f.zero_()
-            if v & 4:
-                raise RuntimeError("a recurrence cluster (csrc/lstm_cluster.hip) waited ~1 s for a partner workgroup that never became resident; results "
-                                   "of that step are invalid -- autograd.CLUSTER_TRAIN_FWD = False selects the step-by-step recurrence")
-            if v & 2:
-                raise RuntimeError("recurrent weights outside the fp16 range of the split-fp16 train-mode recurrence (|w_hh| >= 2^15); results of that "
-                                   "step are invalid -- autograd.SPLIT_TRAIN_FWD = False selects the fp32 recurrence")
-            raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
+    """Synchronising: raise IndexError / RuntimeError if a train-mode operator since the last check set an error bit (the one word of the
+    device, lib.Flags: an id outside the vocabulary; weights outside the fp16 range of the split recurrence -- SPLIT_TRAIN_FWD = False
+    selects the fp32 one --; a recurrence cluster that timed out -- CLUSTER_TRAIN_FWD = False selects the step-by-step recurrence)."""
+    for device in list(_ID_FLAGS.values()):
+        lib.flags(device).check()
 
 
 class _SuggestLossRows(Function):

@@ -229,6 +229,90 @@ extern "C" int nir_sanitize_ids(const int64_t* a, int64_t na, const int64_t* b, 
 }
 
 
+// Ranking metrics of one batch on the HOST (include/neuroir_hip.h): the reference's per-batch loop spends more time in five numpy metric calls
+// over a [112, 10] array (~20 us each, all call overhead) than the device spends ranking the batch.
+template <typename T>
+static double host_rank_metric(int what, const int64_t* pred, const T* tgt, int64_t rows, int n, int k) {
+    double acc = 0.0;
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t* p = pred + r * n;
+        const T* t = tgt + r * n;
+        if (what == 0) {
+            int nrel = 0;
+            double ap = 0.0;
+            for (int j = 0; j < n; ++j) {
+                const int64_t c = p[j];
+                if (c < 0 || c >= n) return -2.0;
+                if (t[c] == (T)1) {
+                    ++nrel;
+                    ap += (double)nrel / (double)(j + 1);
+                }
+            }
+            if (nrel == 0) return -1.0;
+            acc += ap / nrel;
+        } else if (what == 1) {
+            for (int j = 0; j < n; ++j) {
+                const int64_t c = p[j];
+                if (c < 0 || c >= n) return -2.0;
+                if (t[c] == (T)1) {
+                    acc += 1.0 / (double)(j + 1);
+                    break;
+                }
+            }
+        } else {
+            for (int j = 0; j < k; ++j) {
+                const int64_t c = p[j];
+                if (c < 0 || c >= n) return -2.0;
+                if (t[c] == (T)1) acc += 1.0;
+            }
+        }
+    }
+    if (what == 2) return acc / ((double)k * (double)rows);
+    return acc / (double)rows;
+}
+extern "C" double nir_host_rank_metric(int what, const int64_t* predictions, const void* target, int label_dtype, int64_t rows, int n, int k) {
+    if (!predictions || !target || rows <= 0 || n <= 0 || what < 0 || what > 2 || (what == 2 && (k <= 0 || k > n))) return -2.0;
+    if (label_dtype == 0) return host_rank_metric<float>(what, predictions, (const float*)target, rows, n, k);
+    if (label_dtype == 1) return host_rank_metric<int64_t>(what, predictions, (const int64_t*)target, rows, n, k);
+    if (label_dtype == 2) return host_rank_metric<double>(what, predictions, (const double*)target, rows, n, k);
+    return -2.0;
+}
+
+
+// Deferred error flags: copy a non-zero device flag into a word of pinned, device-mapped host memory (one lane; a plain system-scope
+// store -- PCIe atomics are not needed because the device flag itself stays sticky until the host clears it).
+__global__ void flag_publish_kernel(const int* __restrict__ dev_flag, int* host_flag) {
+    const int v = __builtin_nontemporal_load(dev_flag);
+    if (v != 0) __hip_atomic_store(host_flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int nir_flag_publish(const int* dev_flag, int* host_flag, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(dev_flag && host_flag, "flag_publish: null pointer");
+    // host pointer -> device-visible pointer (identical under unified addressing; resolved once per host word)
+    static std::mutex mu;
+    static std::map<const void*, int*> mapped;
+    int* dptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = mapped.find(host_flag);
+        if (it == mapped.end()) {
+            void* d = nullptr;
+            hipError_t e = hipHostGetDevicePointer(&d, host_flag, 0);
+            if (e != hipSuccess || !d) {
+                (void)hipGetLastError();
+                set_error("flag_publish: host_flag is not pinned, device-mapped host memory (%s)", hipGetErrorString(e));
+                return e != hipSuccess ? (int)e : (int)hipErrorInvalidValue;
+            }
+            it = mapped.emplace(host_flag, (int*)d).first;
+        }
+        dptr = it->second;
+    }
+    hipLaunchKernelGGL(flag_publish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev_flag, dptr);
+    NIR_CHECK_LAUNCH("flag_publish_kernel");
+    return 0;
+}
+
+
 // int32 ids on the wire: the host ships token ids / lengths as int32 -- half the PCIe bytes of the reference's
 // torch.LongTensor batches (inputters/multitask/vector.py:82-149) -- and this kernel widens them into the int64 tensors every entry
 // point reads.  16 bytes in, 32 bytes out per lane and iteration; negative values sign-extend (and are then caught by the id checks).

@@ -84,6 +84,8 @@ SIGNATURES = {
     "nir_split_f16x2": (_i, [c_fp, _l, _i, _l, _i, C.c_void_p, C.c_void_p, c_st]),
     "nir_linear_planes_f32": (_i, [C.c_void_p, C.c_void_p, _l, c_ip, _l, _l, _i, _i, C.c_void_p, C.c_void_p, _l, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_sanitize_ids": (_i, [c_ip, _l, c_ip, _l, _l, c_ip, c_ip, C.c_void_p, c_st]),
+    "nir_flag_publish": (_i, [C.c_void_p, C.c_void_p, c_st]),
+    "nir_host_rank_metric": (C.c_double, [_i, C.c_void_p, C.c_void_p, _i, _l, _i, _i]),
     "nir_widen_ids_i32": (_i, [C.c_void_p, C.c_void_p, _l, c_st]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_rowdot_f32": (_i, [c_fp, _l, c_fp, c_fp, c_fp, _l, _i, _i, c_st]),
@@ -356,6 +358,11 @@ def fold_lstm_table(table, wih, bih, bhh, H, ndir, dtype):
     return out
 
 
+# bumped by anything that changes which kernels an entry point launches without touching a weight (debug tunables): part of the key of
+# graph_runner.PredictGraphCache, so a graph captured before the change is not replayed after it
+GRAPH_EPOCH = [0]
+
+
 class tunable(object):
     """Context manager: `with lib.tunable("lstm_mfma16", 1): ...` (nir_debug_set_tunable; restores `restore` on exit)."""
 
@@ -364,27 +371,99 @@ class tunable(object):
 
     def __enter__(self):
         check(load().nir_debug_set_tunable(self.name, self.value), "nir_debug_set_tunable")
+        GRAPH_EPOCH[0] += 1
         return self
 
     def __exit__(self, *exc):
         load().nir_debug_set_tunable(self.name, self.restore)
+        GRAPH_EPOCH[0] += 1
         return False
+
+
+class Flags(object):
+    """The error word of one device + its pinned, device-mapped host mirror (round 6).
+
+    Every kernel that can detect an error ORs into `dev` (bit 0: token id outside the vocabulary; bit 1: recurrent weights outside the fp16
+    range of a split recurrence; bit 2: a recurrence cluster timed out) and never synchronises.  `publish()` enqueues nir_flag_publish at the
+    end of a predict() / update(): a non-zero word lands in `host` (pinned memory the device writes directly).  `poll()` reads the host word --
+    no device round trip -- and raises what it finds: called at the entry of the next wrapper call and from the `.cpu()` of the returned
+    scores, i.e. right after the caller's own synchronisation in the reference's drivers (main/ranker.py:255, main/multitask.py:284).
+    `check()` is the blocking form (reads the device word)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.host_np = self.host.numpy()
+        self.mapped = True
+
+    def publish(self):
+        """capturable; -> False when the host word cannot be written by the device (then only check() sees errors)"""
+        if self.mapped:
+            rc = load().nir_flag_publish(ptr(self.dev), C.c_void_p(self.host.data_ptr()), stream())
+            if rc != 0:
+                self.mapped = False
+        return self.mapped
+
+    def _raise(self, v):
+        if v & 4:
+            raise RuntimeError("a recurrence cluster (csrc/lstm_cluster.hip) waited ~1 s for a partner workgroup that never became resident; "
+                               "results of that call are invalid")
+        if v & 2:
+            raise RuntimeError("recurrent weights outside the fp16 range of the split-fp16 MFMA recurrence (|w_hh| >= 2^15); "
+                               "results of that call are invalid -- the exact fp32 recurrence handles such weights")
+        raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
+
+    def take(self):
+        """blocking read-and-clear of the device word -> its value"""
+        v = int(self.dev.item())
+        if v != 0:
+            self.dev.zero_()
+        self.host_np[0] = 0
+        return v
+
+    def poll(self):
+        if self.host_np[0] != 0:
+            torch.cuda.synchronize(self.device)         # error path only: later publishes of the same sticky word have landed
+            self._raise(self.take())
+
+    def check(self):
+        v = self.take()
+        if v != 0:
+            self._raise(v)
+
+
+_FLAGS = {}
+
+
+def flags(device):
+    """the Flags of `device` (a torch.device with an index, e.g. tensor.device)"""
+    key = (device.type, device.index)
+    f = _FLAGS.get(key)
+    if f is None:
+        f = _FLAGS[key] = Flags(device)
+    return f
 
 
 class IdCheck(object):
     """Mixin of the network mirrors: `q, d = self._clean_ids(q, d, V)` validates token ids on the device (nir_sanitize_ids, one
     launch, no sync) and `check_ids()` raises the IndexError the reference's nn.Embedding would have raised at the lookup.
-    `validate_ids = False` skips the launch for callers that guarantee 0 <= id < V themselves."""
+    `validate_ids = False` skips the launch for callers that guarantee 0 <= id < V themselves.  The flag every kernel of a device
+    writes is ONE word (lib.flags(device).dev): `_flag_word(device)` hands out its tensor."""
     validate_ids = True
+    _flag_dev = None
+
+    def _flag_word(self, device):
+        f = flags(device)
+        self._flag_dev = device
+        return f.dev
 
     def _clean_ids(self, a, b, V):
         a = ids64(a)
         b = ids64(b) if b is not None else None
         if not self.validate_ids:
             return a, b
-        flag = getattr(self, "_id_flag", None)
-        if flag is None or flag.device != a.device:
-            flag = self._id_flag = torch.zeros(1, dtype=torch.int32, device=a.device)
+        flag = self._flag_word(a.device)
         oa = torch.empty_like(a)
         ob = torch.empty_like(b) if b is not None else None
         check(load().nir_sanitize_ids(ptr(a), a.numel(), ptr(b), b.numel() if b is not None else 0, int(V), ptr(oa), ptr(ob), ptr(flag),
@@ -392,19 +471,9 @@ class IdCheck(object):
         return oa, ob
 
     def check_ids(self):
-        """Synchronising: raise IndexError if any forward since the last check saw an id outside the vocabulary."""
-        for name in ("_id_flag", "_err_flag"):
-            flag = getattr(self, name, None)
-            v = int(flag.item()) if flag is not None else 0
-            if v != 0:
-                flag.zero_()
-                if v & 4:
-                    raise RuntimeError("a recurrence cluster (csrc/lstm_cluster.hip) waited ~1 s for a partner workgroup that never became resident; "
-                                       "results of that forward are invalid")
-                if v & 2:
-                    raise RuntimeError("recurrent weights outside the fp16 range of the folded MFMA recurrence (|w_hh| >= 2^15); "
-                                       "results of that forward are invalid -- the exact fp32 recurrence handles such weights")
-                raise IndexError("index out of range in self (token id outside [0, src_vocab_size))")
+        """Synchronising: raise IndexError / RuntimeError if any forward on this network's device since the last check set an error bit."""
+        if self._flag_dev is not None:
+            flags(self._flag_dev).check()
 
 
 def split_f16x2(x, cols_pad=None):

@@ -138,7 +138,6 @@ class CARS(nn.Module, lib.IdCheck):
         self.fold_budget_bytes = 64 << 30
         self.compute_dtype = getattr(args, "compute_dtype", "f32")
         self._fq, self._fd = lib.PackCache(retain=1), lib.PackCache(retain=1)
-        self._err_flag = None
 
     # ---- weight packing -------------------------------------------------------------------------
     def _enc_weights(self, which):
@@ -340,12 +339,10 @@ class CARS(nn.Module, lib.IdCheck):
         encoded = torch.empty(M, T, H2, device=dev, dtype=torch.float32) if want_encoded else None
         if self._use_fold(table, w.struct.H) and w.rec_ok:
             folded = self._folded_table(which, w)
-            if self._err_flag is None or self._err_flag.device != dev:
-                self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
             ws = lib.workspace(L.nir_cars_encode_folded_workspace_bytes(M, T, w.ref()), dev)
             lib.check(L.nir_cars_encode_folded(lib.ptr(ids), lib.ptr(lens), M, T, lib.ptr(folded), lib.DTYPES[self.compute_dtype],
                                                table.shape[0], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(pooled),
-                                               lib.ptr(encoded), lib.ptr(self._err_flag), lib.stream()), "nir_cars_encode_folded")
+                                               lib.ptr(encoded), lib.ptr(self._flag_word(dev)), lib.stream()), "nir_cars_encode_folded")
             return pooled, encoded
         ids, _ = self._clean_ids(ids, None, table.shape[0])       # the per-batch gather-GEMM path has no in-kernel id check
         ws = lib.workspace(L.nir_cars_encode_workspace_bytes(M, T, table.shape[1], w.ref()), dev)

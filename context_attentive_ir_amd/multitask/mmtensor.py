@@ -64,7 +64,6 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
         # eval mode: embedding -> Linear(E->F) -> LSTM input projection folded into one table per encoder, as rankers.MatchTensor does
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
         self._fold = lib.PackCache(retain=1)
-        self._err_flag = None
 
     def _folded_tables(self, w):
         table = self.embedder.word_embeddings.table
@@ -161,11 +160,9 @@ class M_MATCH_TENSOR(nn.Module, lib.IdCheck):
         scores = torch.empty(B * S, N, device=q.device, dtype=torch.float32)
         if B * S > 0 and fold:
             fq, fd = self._folded_tables(w)
-            if self._err_flag is None or self._err_flag.device != q.device:
-                self._err_flag = torch.zeros(1, dtype=torch.int32, device=q.device)
             lib.check(L.nir_matchtensor_score_folded(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B * S, N, QL, DL, lib.ptr(fq), lib.ptr(fd),
                                                      lib.DTYPE_F32, table.shape[0], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(scores),
-                                                     None, None, None, None, lib.ptr(self._err_flag), lib.stream()),
+                                                     None, None, None, None, lib.ptr(self._flag_word(q.device)), lib.stream()),
                       "nir_matchtensor_score_folded")
         elif B * S > 0:
             lib.check(L.nir_matchtensor_score(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B * S, N, QL, DL,

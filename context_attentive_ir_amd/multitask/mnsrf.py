@@ -44,8 +44,8 @@ class MNSRF(nn.Module, lib.IdCheck):
         self.regularize_coeff = args.regularize_coeff
         self.dec_dropout_p = float(args.dropout_rnn)        # RNNDecoder.dropout (decoders/decoder.py:87), train mode only
         self._dims = dict(Hq=args.nhid_query // 2, Hd=args.nhid_document // 2, HS=args.nhid_session)
-        self._pack = lib.PackCache()
-        self._pack_fold = lib.PackCache(retain=1)
+        # retain = 1: the pack owns the two folded gate tables (1.6 GB at V = 100 000); alternating train / eval must not pin eight dead sets
+        self._pack = lib.PackCache(retain=1)
         # the folded gate tables (V x 2048 floats per encoder) + pre-split recurrent weights of the resident-weight path: on in eval mode while
         # both tables stay under `fold_budget_bytes` (100 000 words: 1.6 GB)
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
@@ -71,20 +71,36 @@ class MNSRF(nn.Module, lib.IdCheck):
                      proj_w=self.projection.linear.weight, proj_b=self.projection.linear.bias)
             pk = lib.Packed(lib.MnsrfWeights, t, self._dims)
             dev = pk.keep["q_whh"].device
-            pk.err = torch.zeros(1, dtype=torch.int32, device=dev)
-            pk.struct.err = pk.err.data_ptr()
-            self._err_flag = pk.err
             L = lib.load()
             HS = self._dims["HS"]
+            if dev.type == "cuda":
+                pk.struct.err = self._flag_word(dev).data_ptr()       # run time: the cluster recurrence's time-out bit (the device's one error word)
+
+            def packed(fn, *args):
+                """a W_hh fragment, or None when a weight lies outside the fp16 range of the split (one blocking flag read per weight version, like
+                CARS): the pointer then stays NULL and the entry points take the exact fp32 recurrence"""
+                flag = torch.zeros(1, dtype=torch.int32, device=dev)
+                frag = fn(flag)
+                return frag if int(flag.item()) == 0 else None
+
             if HS % 32 == 0 and dev.type == "cuda":            # session LSTM: W_hh as fp16 term pairs in MFMA-fragment order
-                frag = torch.empty(max(1, L.nir_lstm_step_whh_frag_bytes(HS)), dtype=torch.uint8, device=dev)
-                lib.check(L.nir_lstm_step_pack_whh_frag(lib.ptr(pk.keep["s_whh"]), HS, lib.ptr(frag), lib.ptr(pk.err), lib.stream()), "nir_lstm_step_pack_whh_frag")
-                pk.keep["s_whh_frag"] = frag
-                pk.struct.s_whh_frag = frag.data_ptr()
+                def s_frag(flag):
+                    frag = torch.empty(max(1, L.nir_lstm_step_whh_frag_bytes(HS)), dtype=torch.uint8, device=dev)
+                    lib.check(L.nir_lstm_step_pack_whh_frag(lib.ptr(pk.keep["s_whh"]), HS, lib.ptr(frag), lib.ptr(flag), lib.stream()), "nir_lstm_step_pack_whh_frag")
+                    return frag
+                frag = packed(s_frag)
+                if frag is not None:
+                    pk.keep["s_whh_frag"] = frag
+                    pk.struct.s_whh_frag = frag.data_ptr()
             if resident and dev.type == "cuda":
                 for k in ("q", "d"):
-                    frag = torch.empty(L.nir_lstm256_whh_frag_bytes(2), dtype=torch.uint8, device=dev)
-                    lib.check(L.nir_lstm256_pack_whh_frag(lib.ptr(pk.keep[k + "_whh"]), 2, lib.ptr(frag), lib.ptr(pk.err), lib.stream()), "nir_lstm256_pack_whh_frag")
+                    def c_frag(flag, k=k):
+                        frag = torch.empty(L.nir_lstm256_whh_frag_bytes(2), dtype=torch.uint8, device=dev)
+                        lib.check(L.nir_lstm256_pack_whh_frag(lib.ptr(pk.keep[k + "_whh"]), 2, lib.ptr(frag), lib.ptr(flag), lib.stream()), "nir_lstm256_pack_whh_frag")
+                        return frag
+                    frag = packed(c_frag)
+                    if frag is None:
+                        continue
                     pk.keep[k + "_whh_frag"] = frag
                     setattr(pk.struct, k + "_whh_frag", frag.data_ptr())
                     if fold:         # else: per-batch gate rows (one gather-GEMM per call in the folded order), same recurrence

@@ -109,7 +109,6 @@ class MatchTensor(nn.Module, lib.IdCheck):
         # eval mode: fold embedding -> Linear(E->F) -> LSTM input projection into one table per encoder (csrc/lstm_fold.hip)
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
         self._fold = lib.PackCache(retain=1)
-        self._err_flag = None
 
     def _folded_tables(self, w):
         table = self.word_embeddings.table
@@ -240,11 +239,9 @@ class MatchTensor(nn.Module, lib.IdCheck):
                      torch.empty(B, QL, dm["C"], device=dev), torch.empty(B * N, DL, dm["C"], device=dev)]
         if fold:
             fq, fd = self._folded_tables(w)
-            if self._err_flag is None or self._err_flag.device != dev:
-                self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
             lib.check(L.nir_matchtensor_score_folded(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B, N, QL, DL, lib.ptr(fq), lib.ptr(fd),
                                                      lib.DTYPE_F32, table.shape[0], w.ref(), lib.ptr(ws), ws.numel(), lib.ptr(scores),
-                                                     *[lib.ptr(p) for p in parts], lib.ptr(self._err_flag), lib.stream()),
+                                                     *[lib.ptr(p) for p in parts], lib.ptr(self._flag_word(dev)), lib.stream()),
                       "nir_matchtensor_score_folded")
         else:
             lib.check(L.nir_matchtensor_score(lib.ptr(q), lib.ptr(ql), lib.ptr(d), lib.ptr(dl), B, N, QL, DL,

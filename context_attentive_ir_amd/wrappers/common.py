@@ -12,27 +12,85 @@ logger = logging.getLogger(__name__)
 
 class WrapperBase(object):
     optimizer = None
-    # Token ids are validated on the device without a host round trip (invalid ids are read as PAD and a flag is set).  The reference's
-    # nn.Embedding raises IndexError at the offending call; the wrappers read the flag back after every `id_check_interval`-th
-    # predict() / update() (1 = the reference's behaviour, at the price of one synchronisation per call; 0 = never: the caller calls
-    # check_ids() itself, e.g. once per epoch).  Never inside a hipGraph capture.
+    # Token ids are validated on the device without a host round trip (invalid ids are read as PAD and a bit of the device's error word is
+    # set: lib.Flags).  The reference's nn.Embedding raises IndexError at the offending call.  Here, by default (`id_check = "deferred"`),
+    # every predict() / update() ends with nir_flag_publish -- a non-zero word is written into pinned host memory by the device -- and the
+    # host word is read WITHOUT a device round trip (a) by `.cpu()` / `.tolist()` of the returned scores and (b) at the entry of the next
+    # predict() / update(): in the reference's drivers, which synchronise on every batch's scores (main/ranker.py:255, main/multitask.py:284),
+    # the IndexError surfaces in the same iteration (Ranker) or at the next call (Multitask, whose driver reshapes the scores first) -- at most
+    # one call late, at no cost.  `id_check = "blocking"` reads the device word back after every `id_check_interval`-th call (the error at the
+    # offending call, one synchronisation per call); `id_check_interval = 0` switches the per-call work off (the caller calls check_ids(), the
+    # blocking read, whenever it wants).  With a deferred check an invalid id has been read as PAD and -- in update() -- the optimizer step of
+    # that batch applied before the error surfaces.
+    id_check = "deferred"
     id_check_interval = 1
     _id_calls = 0
+    # hipGraph replay inside predict(): graph_runner.PredictGraphCache (args.predict_graphs = False switches it off)
+    predict_graph_min_calls = 2
+    predict_graph_max = 32
+    _graphs = None
+    _board = None
+
+    def _flags(self):
+        if self._board is None:
+            from .. import lib
+            self._board = lib.flags(next(self.network.parameters()).device)
+        return self._board
 
     def check_ids(self):
-        """Synchronising: raise IndexError / RuntimeError if a forward since the last check saw an invalid id or out-of-range weights."""
+        """Synchronising: raise IndexError / RuntimeError if a forward since the last check saw an invalid id, out-of-range weights or a
+        recurrence cluster that timed out."""
         from .. import autograd as A
+        if self.use_cuda:
+            self._flags().check()
         if hasattr(self.network, "check_ids"):
             self.network.check_ids()
         A.check_ids()
 
+    def _poll_ids(self):
+        """entry of predict() / update(): the pinned host word of the previous calls (no device round trip)"""
+        if self.id_check_interval > 0 and self.id_check == "deferred" and self._board is not None:
+            self._board.poll()
+
     def _maybe_check_ids(self):
-        if self.id_check_interval <= 0 or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        if self.id_check_interval <= 0 or not self.use_cuda:
+            return
+        if self.id_check == "deferred":
+            if self._flags().publish():                     # capturable: part of a captured predict
+                return
+        if torch.cuda.is_current_stream_capturing():
             return
         self._id_calls += 1
         if self._id_calls >= self.id_check_interval:
             self._id_calls = 0
             self.check_ids()
+
+    def _checked(self, t):
+        """the returned scores: `.cpu()` also reads the pinned error word (graph_runner.CheckedTensor)"""
+        if self.id_check_interval > 0 and self.id_check == "deferred" and self._board is not None and self._board.mapped:
+            from ..graph_runner import checked
+            return checked(t, self._board)
+        return t
+
+    def _graph_entry(self, ex, fields, flavour, body):
+        """-> (cache, entry) when this predict() replays a captured hipGraph, else (None, None): eager."""
+        if not (self.use_cuda and getattr(self.args, "predict_graphs", True)) or getattr(self, "parallel", False):
+            return None, None
+        if torch.cuda.is_current_stream_capturing():        # an outer capture (graph_runner.GraphedPredictor, bench.py) records the eager body
+            return None, None
+        if self._graphs is None:
+            from ..graph_runner import PredictGraphCache
+            self._graphs = PredictGraphCache(self, self.predict_graph_max, self.predict_graph_min_calls)
+        for k in fields:
+            if not torch.is_tensor(ex.get(k)):
+                return None, None
+        if self.network.training:
+            self.network.eval()                             # (the key holds the network's plain attributes, `training` among them)
+        return self._graphs, self._graphs.get(ex, fields, flavour, body)
+
+    def clear_predict_graphs(self):
+        if self._graphs is not None:
+            self._graphs.clear()
 
     # the module whose `.word_vec_size / .init_word_vectors / .parameters()` the drivers use
     def _word_embeddings(self):
@@ -194,11 +252,15 @@ class WrapperBase(object):
     def cuda(self):
         self.use_cuda = True
         self.network = self.network.cuda()
+        self._board = None
+        self.clear_predict_graphs()
         return self
 
     def cpu(self):
         self.use_cuda = False
         self.network = self.network.cpu()
+        self._board = None
+        self.clear_predict_graphs()
         return self
 
 

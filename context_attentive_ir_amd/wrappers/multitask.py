@@ -194,12 +194,29 @@ class Multitask(WrapperBase):
         """raw click scores [B,S,N] (ranking path only)."""
         return self._rank(ex, False)[0]
 
+    _FIELDS = ("source_words", "source_lens", "document_words", "document_lens", "document_labels")
+
     @torch.no_grad()
     def predict(self, ex, suggest=True):
         """models/multitask.py:229-317: {'click_scores': softmax over candidates [B,S,N], 'predictions': LongTensor
         [B,S-1,max_query_len] (suggest=True; None for CARS with the recommender off)}.
-        suggest=False = the ranking path only (what bench.py times as a step and GraphedPredictor captures)."""
+        suggest=False = the ranking path only (what bench.py times as a step and GraphedPredictor captures).
+        From the second call of a batch shape on, the call replays a captured hipGraph (WrapperBase._graph_entry; decode included); an
+        out-of-vocabulary id raises IndexError from the scores' `.cpu()` or from the next call (WrapperBase.id_check)."""
+        self._poll_ids()
         do_decode = bool(suggest) and not (self.type == "CARS" and self.network.no_recommender)
+        fields = self._FIELDS if self.type == "CARS" else self._FIELDS[:4]
+        cache, ent = self._graph_entry(ex, fields, do_decode, lambda e: self._predict_body(e, do_decode))
+        if ent is None:
+            out = self._predict_body(ex, do_decode)
+        else:
+            out = cache.run(ent, ex)
+            if self.id_check == "blocking":
+                self._maybe_check_ids()
+        out["click_scores"] = self._checked(out["click_scores"])
+        return out
+
+    def _predict_body(self, ex, do_decode):
         s, states, attns, enc = self._rank(ex, do_decode)
         out = {"click_scores": None, "predictions": None}
         if torch.is_tensor(s):
@@ -222,6 +239,7 @@ class Multitask(WrapperBase):
         -> clip_grad_norm(grad_clipping) -> optimizer step (CARS, M_MATCH_TENSOR, MNSRF)."""
         if self.optimizer is None:
             raise RuntimeError("No optimizer set.")
+        self._poll_ids()
         self.optimizer.zero_grad()
         loss = self._update_body(ex)
         self.updates += 1

@@ -52,21 +52,35 @@ class Ranker(WrapperBase):
             return sharding.sharded_scores(lambda dd, ll: self.network(q, ql, dd, ll), d, dl, group=self.group)
         return self.network(q, ql, d, dl)
 
-    @torch.no_grad()
-    def predict(self, ex):
-        """softmax over the candidates (models/ranker.py:236-260)."""
-        if self.parallel and sharding.dist.is_available() and sharding.dist.is_initialized():
-            self.network.eval()
-            q, ql, d, dl = self._inputs(ex)
-            world, rank = sharding.dist.get_world_size(self.group), sharding.dist.get_rank(self.group)
-            dd, ll = sharding.shard_candidates(d, dl, world, rank)
-            return sharding.gathered_softmax(self.network(q, ql, dd, ll), d.shape[1], self.group)
+    _FIELDS = ("que_rep", "que_len", "doc_rep", "doc_len")
+
+    def _predict_body(self, ex):
         s = self.scores(ex).contiguous()
         out = torch.empty_like(s)
         lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()),
                   "nir_softmax_rows")
         self._maybe_check_ids()
         return out
+
+    @torch.no_grad()
+    def predict(self, ex):
+        """softmax over the candidates (models/ranker.py:236-260).  From the second call of a batch shape on, the call replays a captured
+        hipGraph (WrapperBase._graph_entry); an out-of-vocabulary id raises IndexError from the scores' `.cpu()` or from the next call
+        (WrapperBase.id_check)."""
+        self._poll_ids()
+        if self.parallel and sharding.dist.is_available() and sharding.dist.is_initialized():
+            self.network.eval()
+            q, ql, d, dl = self._inputs(ex)
+            world, rank = sharding.dist.get_world_size(self.group), sharding.dist.get_rank(self.group)
+            dd, ll = sharding.shard_candidates(d, dl, world, rank)
+            return sharding.gathered_softmax(self.network(q, ql, dd, ll), d.shape[1], self.group)
+        cache, ent = self._graph_entry(ex, self._FIELDS, None, self._predict_body)
+        if ent is None:
+            return self._checked(self._predict_body(ex))
+        out = cache.run(ent, ex)
+        if self.id_check == "blocking":
+            self._maybe_check_ids()
+        return self._checked(out)
 
     @torch.no_grad()
     def predict_many(self, exs, out=None):
@@ -104,6 +118,7 @@ class Ranker(WrapperBase):
             raise RuntimeError("%s has no training criterion (main/ranker.py:414)" % self.kind)
         if not hasattr(self.network, "_forward_train"):
             raise NotImplementedError("%s has no train-mode forward" % self.kind)
+        self._poll_ids()
         self.optimizer.zero_grad()
         loss = self._update_body(ex)
         self.updates += 1

@@ -92,6 +92,22 @@ int nir_linear_planes_f32(const void* a1, const void* a2, int64_t lda, const int
 int nir_sanitize_ids(const int64_t* a, int64_t na, const int64_t* b, int64_t nb, int64_t V, int64_t* out_a, int64_t* out_b,
                      int* err_flag, nir_stream_t stream);
 
+/* Deferred error flags (round 6).  Every error flag of this library (invalid token id = bit 0, weights outside the fp16 range of a split
+ * recurrence = bit 1, a recurrence cluster that timed out = bit 2) is a DEVICE int the kernels OR into; reading it back costs the host a
+ * blocking round trip per call.  nir_flag_publish enqueues a one-thread kernel that copies a non-zero *dev_flag into *host_flag, a word of
+ * PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory; resolved with hipHostGetDevicePointer): after the caller's own
+ * synchronisation on the call's results (the `.cpu()` of the reference's drivers, main/ranker.py:255, main/multitask.py:284) the host reads
+ * the word without touching the device -- the IndexError of nn.Embedding (neuroir/modules/embeddings.py:243-252) surfaces at most one call late
+ * and costs nothing on the way.  Capturable into a hipGraph.  Returns a HIP error code if host_flag is not mapped host memory. */
+int nir_flag_publish(const int* dev_flag, int* host_flag /*pinned, mapped*/, nir_stream_t stream);
+
+/* HOST-side ranking metrics of one batch with the reference's definitions (neuroir/eval/ltorank.py:4-47, 104-123), for the per-batch loop of
+ * the reference's drivers (main/ranker.py:258-262): predictions [rows, n] int64 = candidate indices by descending score (np.argsort(-scores)),
+ * target [rows, n] relevance labels (label_dtype 0: float32, 1: int64, 2: float64; relevant <=> == 1).  Plain C loops over host arrays -- no
+ * device work, no stream.  what: 0 = MAP (returns -1.0 if a row has no relevant candidate: the reference divides by zero there), 1 = MRR,
+ * 2 = precision@k.  Returns the metric, or -2.0 for bad arguments. */
+double nir_host_rank_metric(int what, const int64_t* predictions /*host*/, const void* target /*host*/, int label_dtype, int64_t rows, int n, int k);
+
 /* int32 ids on the wire (the reference's collate emits int64, inputters/multitask/vector.py:82-149): widen n int32
  * values (ids / lengths as shipped by inputters.session_stream) into the int64 tensors the entry points read.  16-byte aligned. */
 int nir_widen_ids_i32(const int32_t* src, int64_t* dst, int64_t n, nir_stream_t stream);

@@ -1,0 +1,203 @@
+"""GPU (-m gpu): predict() the way the reference's drivers call it (main/ranker.py:254-257, main/multitask.py:280-287) -- one call per
+batch, the caller synchronises on the scores -- on the round-6 path: a shape-keyed hipGraph cache inside predict()
+(graph_runner.PredictGraphCache) and the deferred id check through a pinned, device-written host word (lib.Flags)."""
+import numpy as np
+import pytest
+import torch
+
+from context_attentive_ir_amd import lib, synth
+from context_attentive_ir_amd.config import default_args
+from context_attentive_ir_amd.detinit import fill_module_
+from context_attentive_ir_amd.wrappers import Multitask, Ranker
+
+pytestmark = pytest.mark.gpu
+V = 600
+
+
+def _ranker(kind, **kw):
+    extra = dict(max_query_len=5, max_doc_len=24) if kind == "DUET" else {}
+    w = Ranker(default_args(kind, src_vocab_size=V, **extra, **kw))
+    fill_module_(w.network, 1013)
+    return w.cuda()
+
+
+def _multitask(kind, **kw):
+    w = Multitask(default_args(kind, src_vocab_size=V, tgt_vocab_size=300, **kw))
+    fill_module_(w.network, 1013)
+    return w.cuda()
+
+
+def _pin(ex):
+    return {k: v.pin_memory() for k, v in ex.items()}
+
+
+@pytest.mark.parametrize("kind", ["ESM", "MATCH_TENSOR", "DRMM", "DUET"])
+def test_ranker_predict_replays_a_graph_from_the_second_call_bit_equal_to_eager(kind):
+    w = _ranker(kind)
+    eager = _ranker(kind)
+    eager.args.predict_graphs = False
+    batches = [synth.ranker_batch(4, 5, 5, 24, V, seed=s, full_length=(s % 2 == 0)) for s in range(5)]
+    want = [eager.predict(ex).cpu() for ex in batches]
+    assert eager._graphs is None
+    got = [w.predict(ex).cpu() for ex in batches]                         # pageable host tensors: call 1 eager, call 2 captures, 3.. replay
+    got_pinned = [w.predict(_pin(ex)).cpu() for ex in batches]
+    got_dev = [w.predict({k: v.cuda() for k, v in ex.items()}).cpu() for ex in batches]
+    assert w._graphs.captures == 1 and w._graphs.replays == 4 + 5 + 5
+    for a, b, c, d in zip(want, got, got_pinned, got_dev):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    # the result of a call is a fresh tensor: a later call does not overwrite it
+    first = w.predict(batches[0])
+    keep = first.clone()
+    w.predict(batches[1])
+    assert torch.equal(first, keep)
+
+
+@pytest.mark.parametrize("kind", ["CARS", "M_MATCH_TENSOR", "MNSRF"])
+def test_multitask_predict_graph_with_decode_equals_eager(kind):
+    w, eager = _multitask(kind), _multitask(kind)
+    eager.args.predict_graphs = False
+    batches = [synth.session_batch(3, 4, 5, 4, 12, V, seed=s, full_length=(s % 2 == 1)) for s in range(4)]
+    for suggest in (False, True):
+        want = [eager.predict(ex, suggest=suggest) for ex in batches]
+        got = [w.predict(_pin(ex), suggest=suggest) for ex in batches]
+        for a, b in zip(want, got):
+            assert torch.equal(a["click_scores"].cpu(), b["click_scores"].cpu())
+            if suggest:
+                assert torch.equal(a["predictions"].cpu(), b["predictions"].cpu())
+            else:
+                assert b["predictions"] is None
+    assert w._graphs.captures == 2                                         # one graph per flavour (ranking only / with decode)
+    w.check_ids()
+
+
+def test_graph_cache_follows_weights_shapes_and_switches():
+    w, eager = _multitask("CARS"), _multitask("CARS")
+    eager.args.predict_graphs = False
+    ex = _pin(synth.session_batch(2, 3, 4, 4, 10, V, seed=3))
+    for _ in range(3):
+        w.predict(ex, suggest=False)
+    assert w._graphs.captures == 1
+    # an in-place weight change (optimizer step, load_state_dict): the stale graph is dropped, the new weights are scored
+    with torch.no_grad():
+        for net in (w.network, eager.network):
+            net.q_attn[0].weight.mul_(0.5)
+            net.ranknet._linear_layers[0].bias.add_(0.25)
+    want = eager.predict(ex, suggest=False)["click_scores"].cpu()
+    for i in range(3):
+        assert torch.equal(w.predict(ex, suggest=False)["click_scores"].cpu(), want), i
+    assert w._graphs.captures == 2 and len(w._graphs.entries) == 1
+    # a path switch on the network is part of the key
+    w.network.fold_embeddings = eager.network.fold_embeddings = False
+    want2 = eager.predict(ex, suggest=False)["click_scores"].cpu()
+    for i in range(3):
+        assert torch.equal(w.predict(ex, suggest=False)["click_scores"].cpu(), want2), i
+    assert w._graphs.captures == 3
+    assert float((want - want2).abs().max()) < 1e-5
+    # another shape gets its own graph; the cache is bounded (LRU)
+    w.predict_graph_max = 2
+    w._graphs.max_entries = 2
+    for s in (5, 6, 7):
+        e2 = _pin(synth.session_batch(2, 3, 4, 4, s + 4, V, seed=s))
+        for _ in range(3):
+            got = w.predict(e2, suggest=False)["click_scores"].cpu()
+        assert torch.equal(got, eager.predict(e2, suggest=False)["click_scores"].cpu())
+    assert len(w._graphs.entries) == 2
+
+
+def test_deferred_id_check_raises_from_cpu_or_at_the_next_call():
+    """nn.Embedding raises IndexError at the offending call (neuroir/modules/embeddings.py:243-252).  Default here: the device publishes its
+    error word into pinned host memory at the end of the call; `.cpu()` of the scores (the reference driver's own synchronisation) or the
+    next predict() / update() raises -- without a blocking read-back per call."""
+    w = _ranker("MATCH_TENSOR", optimizer="sgd", learning_rate=0.01, weight_decay=0, momentum=0, grad_clipping=10.0, fix_embeddings=True)
+    w.init_optimizer()
+    assert w.id_check == "deferred" and w.id_check_interval == 1
+    ex = synth.ranker_batch(2, 3, 5, 12, V, seed=1)
+    bad = dict(ex, doc_rep=ex["doc_rep"].clone())
+    bad["doc_rep"][1, 2, 7] = V + 5
+    for rounds in range(2):                                              # round 0: eager calls; round 1: the same shapes replay graphs
+        for _ in range(2):
+            assert torch.isfinite(w.predict(ex).cpu()).all()
+        s = w.predict(bad)                                               # no exception here, no synchronisation either
+        with pytest.raises(IndexError):
+            s.cpu()                                                      # (a) the caller's synchronisation
+        assert torch.isfinite(w.predict(ex).cpu()).all()                 # the word was cleared
+        w.predict(bad)
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError):
+            w.predict(ex)                                                # (b) entry of the next call
+        assert torch.isfinite(w.predict(ex).cpu()).all()
+    w.update(bad)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        w.update(ex)
+    w.update(ex)
+    w.check_ids()
+    # the blocking form: the reference's timing
+    w.id_check = "blocking"
+    with pytest.raises(IndexError):
+        w.predict(bad)
+    assert torch.isfinite(w.predict(ex)).all()
+    with pytest.raises(IndexError):
+        w.update(bad)
+    # Multitask: the driver reshapes the scores first (main/multitask.py:282), so it is the next call that raises
+    m = _multitask("CARS")
+    sx = synth.session_batch(2, 3, 4, 4, 10, V, seed=3)
+    sbad = dict(sx, document_words=sx["document_words"].clone())
+    sbad["document_words"][0, 1, 2, 3] = V
+    for _ in range(3):
+        m.predict(sx)
+    out = m.predict(sbad)
+    out["click_scores"].view(6, -1).contiguous().cpu()
+    with pytest.raises(IndexError):
+        m.predict(sx)
+    m.predict(sx)
+    m.check_ids()
+
+
+def test_reference_validation_loop_on_the_graph_path_matches_eager_metrics():
+    """the loop of main/multitask.py:262-300 (predict -> scores.cpu().numpy() -> argsort -> MAP / MRR / P@k per batch) on the default
+    settings equals the same loop on eager calls, batch for batch."""
+    from context_attentive_ir_amd.eval.ltorank import MAP, MRR, precision_at_k
+    w, eager = _multitask("CARS"), _multitask("CARS")
+    eager.args.predict_graphs = False
+    batches = [_pin(synth.session_batch(4, 3, 6, 4, 16, V, seed=100 + s, full_length=False)) for s in range(6)]
+
+    def loop(model):
+        out = []
+        with torch.no_grad():
+            for ex in batches:
+                rows = ex["source_words"].shape[0] * ex["source_words"].shape[1]
+                o = model.predict(ex)
+                scores = o["click_scores"].view(rows, -1).contiguous()
+                labels = ex["document_labels"].view(rows, -1).contiguous().numpy()
+                pred = np.argsort(-scores.cpu().numpy())
+                out.append((MAP(pred, labels), MRR(pred, labels), precision_at_k(pred, labels, 1), o["predictions"].cpu()))
+        return out
+    a, b = loop(eager), loop(w)
+    assert w._graphs.replays >= 4
+    for x, y in zip(a, b):
+        assert x[:3] == y[:3] and torch.equal(x[3], y[3])
+
+
+def test_flag_publish_needs_no_device_round_trip():
+    """lib.Flags: the device writes a non-zero error word into pinned host memory (nir_flag_publish); poll() reads host memory only."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f = lib.flags(dev)
+    f.check()
+    assert f.publish() and f.mapped
+    torch.cuda.synchronize()
+    assert int(f.host_np[0]) == 0
+    f.poll()
+    f.dev.fill_(1)
+    f.publish()
+    torch.cuda.synchronize()
+    assert int(f.host_np[0]) == 1
+    with pytest.raises(IndexError):
+        f.poll()
+    assert int(f.host_np[0]) == 0 and int(f.dev.item()) == 0
+    f.dev.fill_(4)
+    f.publish()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        f.poll()
+    f.check()

@@ -235,8 +235,9 @@ def test_drmm_exact_match_policies_on_overlapping_zipf_ids():
 
 
 def test_wrappers_raise_indexerror_for_out_of_vocabulary_ids():
-    """The reference's nn.Embedding raises IndexError at the offending call; the wrappers read the device flag back after predict / update
-    (WrapperBase.id_check_interval = 1), in eval (folded kernels: in-kernel check) and in train mode (autograd.embed)."""
+    """The reference's nn.Embedding raises IndexError at the offending call; with `id_check = "blocking"` the wrappers read the device flag
+    back after predict / update (WrapperBase.id_check_interval = 1), in eval (folded kernels: in-kernel check) and in train mode
+    (autograd.embed).  (The default, deferred form: tests/test_gpu_dropin_loop.py.)"""
     from context_attentive_ir_amd.config import default_args
     from context_attentive_ir_amd.detinit import fill_module_
     from context_attentive_ir_amd.wrappers import Ranker
@@ -246,6 +247,7 @@ def test_wrappers_raise_indexerror_for_out_of_vocabulary_ids():
     fill_module_(w.network, 3)
     w.cuda()
     w.init_optimizer()
+    w.id_check = "blocking"
     rng = np.random.default_rng(1)
     q = torch.from_numpy(rng.integers(4, V, size=(2, 5))); d = torch.from_numpy(rng.integers(4, V, size=(2, 3, 12)))
     ex = {"que_rep": q, "que_len": torch.full((2,), 5), "doc_rep": d, "doc_len": torch.full((2, 3), 12), "label": torch.zeros(2, 3)}
