@@ -229,6 +229,71 @@ extern "C" int nir_sanitize_ids(const int64_t* a, int64_t na, const int64_t* b, 
 }
 
 
+// Host pointer -> device-visible pointer (identical under unified addressing; resolved once per host address).
+namespace nir {
+int mapped_host_pointer(const void* host, void** out) {
+    static std::mutex mu;
+    static std::map<const void*, void*> mapped;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = mapped.find(host);
+    if (it == mapped.end()) {
+        void* d = nullptr;
+        hipError_t e = hipHostGetDevicePointer(&d, const_cast<void*>(host), 0);
+        if (e != hipSuccess || !d) {
+            (void)hipGetLastError();
+            set_error("host pointer %p is not pinned, device-mapped host memory (%s)", host, hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : (int)hipErrorInvalidValue;
+        }
+        if (mapped.size() > 4096) mapped.clear();
+        it = mapped.emplace(host, d).first;
+    }
+    *out = it->second;
+    return 0;
+}
+}  // namespace nir
+extern "C" int nir_host_device_pointer(const void* host, void** device_visible) {
+    using namespace nir;
+    NIR_REQUIRE(host && device_visible, "host_device_pointer: null pointer");
+    return mapped_host_pointer(host, device_visible);
+}
+
+// The input fields of a captured predict(), wherever they live, into the static input block: 16 bytes per lane and trip, system-scope
+// loads (a field may sit in pinned host memory the host rewrote since the previous replay: nothing may be served from a GPU cache).
+__global__ __launch_bounds__(256) void gather_fields_kernel(const int64_t* __restrict__ table, int n, char* __restrict__ dst) {
+    __shared__ int64_t t[3 * 16];
+    if (threadIdx.x < 3 * n) t[threadIdx.x] = __hip_atomic_load(table + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int f = 0; f < n; ++f) {
+        const char* src = (const char*)t[3 * f];
+        char* d = dst + t[3 * f + 1];
+        const int64_t nb = t[3 * f + 2];
+        const int64_t full = nb >> 4;
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < full; c += stride) {
+            uint4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src + (c << 4)) : "memory");
+            *reinterpret_cast<uint4*>(d + (c << 4)) = v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (nb & 15)) {
+            const int64_t o = (full << 4) + threadIdx.x;
+            d[o] = __hip_atomic_load(src + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+extern "C" int nir_gather_fields(const int64_t* table, int n, void* dst, int64_t total_bytes, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(table && dst && n > 0 && n <= 16 && total_bytes > 0, "gather_fields: bad args");
+    NIR_REQUIRE(((uintptr_t)dst & 15) == 0, "gather_fields: dst must be 16-byte aligned");
+    void* dt = nullptr;
+    NIR_PROPAGATE(mapped_host_pointer(table, &dt));
+    const int64_t chunks = (total_bytes + 15) / 16;
+    const unsigned blocks = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (chunks + 255) / 256));
+    hipLaunchKernelGGL(gather_fields_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)dt, n, (char*)dst);
+    NIR_CHECK_LAUNCH("gather_fields_kernel");
+    return 0;
+}
+
+
 // Ranking metrics of one batch on the HOST (include/neuroir_hip.h): the reference's per-batch loop spends more time in five numpy metric calls
 // over a [112, 10] array (~20 us each, all call overhead) than the device spends ranking the batch.
 template <typename T>
@@ -288,25 +353,9 @@ __global__ void flag_publish_kernel(const int* __restrict__ dev_flag, int* host_
 extern "C" int nir_flag_publish(const int* dev_flag, int* host_flag, nir_stream_t stream) {
     using namespace nir;
     NIR_REQUIRE(dev_flag && host_flag, "flag_publish: null pointer");
-    // host pointer -> device-visible pointer (identical under unified addressing; resolved once per host word)
-    static std::mutex mu;
-    static std::map<const void*, int*> mapped;
-    int* dptr = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = mapped.find(host_flag);
-        if (it == mapped.end()) {
-            void* d = nullptr;
-            hipError_t e = hipHostGetDevicePointer(&d, host_flag, 0);
-            if (e != hipSuccess || !d) {
-                (void)hipGetLastError();
-                set_error("flag_publish: host_flag is not pinned, device-mapped host memory (%s)", hipGetErrorString(e));
-                return e != hipSuccess ? (int)e : (int)hipErrorInvalidValue;
-            }
-            it = mapped.emplace(host_flag, (int*)d).first;
-        }
-        dptr = it->second;
-    }
+    void* d = nullptr;
+    NIR_PROPAGATE(mapped_host_pointer(host_flag, &d));
+    int* dptr = (int*)d;
     hipLaunchKernelGGL(flag_publish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev_flag, dptr);
     NIR_CHECK_LAUNCH("flag_publish_kernel");
     return 0;

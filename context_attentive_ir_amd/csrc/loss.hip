@@ -21,6 +21,26 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, floa
     for (int i = lane; i < n; i += 64) out[r * n + i] = expf(x[i] - mx) / s;
 }
 
+// softmax_rows + the deferred error word (core.hip: flag_publish_kernel) in one launch: lane 0 of block 0 copies a non-zero device flag into
+// the pinned host word.  Every kernel that can set the flag precedes this one in stream order.
+__global__ __launch_bounds__(256) void softmax_rows_publish_kernel(const float* in, float* out, int64_t rows, int n, const int* dev_flag, int* host_flag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int v = __builtin_nontemporal_load(dev_flag);
+        if (v != 0) __hip_atomic_store(host_flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* x = in + r * n;
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, x[i]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(x[i] - mx);
+    s = wave_sum(s);
+    for (int i = lane; i < n; i += 64) out[r * n + i] = expf(x[i] - mx) / s;
+}
+
 // Softmax over the candidates of a query straight from the rank-major all-gather buffer [world][B][per] (what
 // all_gather_into_tensor leaves on every rank): candidate n of query b lives at ((n / per) * B + b) * per + n % per.
 // Writes the query-major [B][N] probabilities (N <= world*per drops the padded tail); optionally also the raw scores.
@@ -89,6 +109,17 @@ extern "C" int nir_softmax_rows(const float* in, float* out, int64_t rows, int n
     if (rows == 0) return 0;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, rows, n);
     NIR_CHECK_LAUNCH("nir_softmax_rows");
+    return 0;
+}
+
+namespace nir { int mapped_host_pointer(const void* host, void** out); }
+extern "C" int nir_softmax_rows_publish(const float* in, float* out, int64_t rows, int n, const int* dev_flag, int* host_flag, nir_stream_t stream) {
+    using namespace nir;
+    NIR_REQUIRE(in && out && rows > 0 && n > 0 && dev_flag && host_flag, "softmax_rows_publish: bad args");
+    void* d = nullptr;
+    NIR_PROPAGATE(mapped_host_pointer(host_flag, &d));
+    hipLaunchKernelGGL(softmax_rows_publish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, out, rows, n, dev_flag, (int*)d);
+    NIR_CHECK_LAUNCH("nir_softmax_rows_publish");
     return 0;
 }
 

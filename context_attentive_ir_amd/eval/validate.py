@@ -70,3 +70,35 @@ def validate_official(data_loader, model, depth=4):
     result = {k: v / nb for k, v in sums.items()} if nb else {}
     result["examples"] = examples
     return result
+
+
+def reference_loop(batches, model, iters=None, suggest=True):
+    """The reference's validation loop AS WRITTEN (main/multitask.py:280-290 for a Multitask wrapper, main/ranker.py:254-262 for a Ranker): one
+    `model.predict(ex)` per batch, `scores.cpu().numpy()`, argsort, MAP / MRR / P@1,3,5 -- every batch is synchronised on before the next
+    one is issued, nothing else is in flight.  What `tools/dropin_loop.py` and bench.py's `dropin_loop_*` records time.  batches: list of
+    batch dicts (cycled for `iters` calls); -> list of per-batch MAP values."""
+    maps = []
+    n = len(batches) if iters is None else int(iters)
+    session = hasattr(model, "tgt_dict")
+    with torch.no_grad():
+        for i in range(n):
+            ex = batches[i % len(batches)]
+            if session:
+                rows = ex["source_words"].shape[0] * ex["source_words"].shape[1]
+                outputs = model.predict(ex) if suggest else model.predict(ex, suggest=False)
+                scores = outputs["click_scores"].view(rows, -1).contiguous()
+                labels = ex["document_labels"].view(rows, -1).contiguous().numpy()
+            else:
+                scores = model.predict(ex)
+                labels = ex["label"].numpy()
+            predictions = np.argsort(-scores.cpu().numpy())
+            maps.append(MAP(predictions, labels))
+            MRR(predictions, labels)
+            precision_at_k(predictions, labels, 1)
+            if predictions.shape[1] >= 3:
+                precision_at_k(predictions, labels, 3)
+            if predictions.shape[1] >= 5:
+                precision_at_k(predictions, labels, 5)
+            if session and suggest and outputs["predictions"] is not None:
+                outputs["predictions"].cpu()                 # (the reference turns the token ids into strings on the host here)
+    return maps

@@ -193,7 +193,9 @@ class PredictGraphCache(object):
     is ~45 launches for 0.3 ms of kernels).  The first `min_calls - 1` calls of a key run eagerly; the next one captures the eager body
     over static input buffers (scratch owned by the entry: lib.workspace_owner) and every later call is
         [small host fields -> one pinned staging block -> ONE H2D | large pinned fields: direct H2D | device fields: D2D] -> replay -> clone
-    on the CALLER's current stream.  Key = field shapes / dtypes + the call's flavour + a weights token (sum of parameter versions, first
+    on the CALLER's current stream (round 6b: the bracketed step is the graph's FIRST KERNEL -- nir_gather_fields reads a per-call table of
+    source addresses from pinned memory and copies pinned host tensors over PCIe itself, staged fields and device tensors alike: a replay
+    issues no hipMemcpyAsync at all).  Key = field shapes / dtypes + the call's flavour + a weights token (sum of parameter versions, first
     data pointer, the network's path switches): training, load_state_dict or a switch change re-captures; `clear()` on .cuda() / .cpu().
     At most `max_entries` graphs (LRU)."""
     BIG = 64 << 10          # host fields of at least this many bytes that are already pinned skip the staging copy
@@ -267,54 +269,72 @@ class PredictGraphCache(object):
         ent.dev_buf = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
         ent.host_buf = torch.empty(max(off, 16), dtype=torch.uint8).pin_memory()
         ent.static = {k: ent.dev_buf[o:o + n].view(dt).view(shape) for k, o, n, dt, shape in slots}
-        ent.h2d_done = None
+        ent.replayed, ent.hold = None, None
+        # the per-call source table {address, destination offset, bytes} x fields, in pinned memory the gather kernel reads
+        ent.table = torch.zeros(3 * len(slots), dtype=torch.int64).pin_memory()
+        ent.table_np = ent.table.numpy()
+        L = lib.load()
+        dp = ctypes.c_void_p()
+        lib.check(L.nir_host_device_pointer(ctypes.c_void_p(ent.host_buf.data_ptr()), ctypes.byref(dp)), "nir_host_device_pointer")
+        ent.stage_dev = int(dp.value)                                 # device-visible address of the staging block
+        ent.total = sum((n + 15) // 16 * 16 for _, _, n, _, _ in slots)
+        self._fill(ent, ex)
         cur = torch.cuda.current_stream(dev)
-        for k, _, _, _, _ in slots:
-            ent.static[k].copy_(ex[k])
+
+        def step():
+            lib.check(L.nir_gather_fields(ctypes.c_void_p(ent.table.data_ptr()), len(slots), lib.ptr(ent.dev_buf), ent.total, lib.stream()),
+                      "nir_gather_fields")
+            return body(ent.static)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side), lib.workspace_owner(ent):
-            body(ent.static)                                          # warm-up under the entry's own scratch (sizes it, builds packs)
+            step()                                                    # warm-up under the entry's own scratch (sizes it, builds packs)
             side.synchronize()
             ent.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ent.graph, stream=side, capture_error_mode="thread_local"):
-                ent.out = body(ent.static)
+                ent.out = step()
         cur.wait_stream(side)
         self.captures += 1
         return ent
 
-    def run(self, ent, ex):
-        """inputs -> static buffers, replay, -> fresh copies of the outputs (same structure as the eager body's)"""
-        staged_lo = staged_hi = None
-        base = ent.host_buf.data_ptr()
-        for k, o, n, dt, shape in ent.slots:
+    def _fill(self, ent, ex):
+        """the source table of this call: a device tensor or a large pinned host tensor is read where it lies, everything else is memmoved
+        into the entry's pinned staging block first.  The sources are kept referenced until the replay that reads them has finished."""
+        if ent.replayed is not None:
+            ent.replayed.synchronize()                                # the previous replay has read its table / staging block / sources
+        L = lib.load()
+        base, tab, hold = ent.host_buf.data_ptr(), ent.table_np, []
+        dp = ctypes.c_void_p()
+        for i, (k, o, n, dt, shape) in enumerate(ent.slots):
             src = ex[k]
-            if src.is_cuda:
-                ent.static[k].copy_(src, non_blocking=True)
-                continue
             if not src.is_contiguous():
                 src = src.contiguous()
-            if n >= self.BIG and src.is_pinned():
-                ent.static[k].copy_(src, non_blocking=True)
-                continue
-            if staged_lo is None:
-                if ent.h2d_done is not None:
-                    ent.h2d_done.synchronize()                        # the previous call's H2D has left the staging block (no-op once the caller synchronised)
-                staged_lo = o
-            elif o != staged_hi:                                      # a gap (a direct field in between): flush the run so far
-                ent.dev_buf[staged_lo:staged_hi].copy_(ent.host_buf[staged_lo:staged_hi], non_blocking=True)
-                staged_lo = o
-            ctypes.memmove(base + o, src.data_ptr(), n)
-            staged_hi = (o + n + 15) // 16 * 16
-        if staged_lo is not None:
-            staged_hi = min(staged_hi, ent.host_buf.numel())
-            ent.dev_buf[staged_lo:staged_hi].copy_(ent.host_buf[staged_lo:staged_hi], non_blocking=True)
-            if ent.h2d_done is None:
-                ent.h2d_done = torch.cuda.Event()
-            ent.h2d_done.record()
+            addr = 0
+            if src.is_cuda:
+                addr = src.data_ptr()
+            elif n >= self.BIG and src.is_pinned() and L.nir_host_device_pointer(ctypes.c_void_p(src.data_ptr()), ctypes.byref(dp)) == 0:
+                addr = int(dp.value)
+            if addr and addr % 16 == 0:
+                hold.append(src)
+            else:
+                ctypes.memmove(base + o, src.data_ptr(), n)
+                addr = ent.stage_dev + o
+            tab[3 * i], tab[3 * i + 1], tab[3 * i + 2] = addr, o, n
+        ent.hold = hold
+
+    def run(self, ent, ex, finish=None):
+        """source table of this call -> replay (gather kernel + the captured predict) -> fresh copies of the outputs (same structure as the
+        eager body's); finish(static_out) (optional) makes the fresh outputs itself -- e.g. the final softmax run eagerly from the static raw
+        scores into a new tensor: one launch instead of an in-graph softmax plus a copy."""
+        self._fill(ent, ex)
         ent.graph.replay()
+        if ent.replayed is None:
+            ent.replayed = torch.cuda.Event()
+        ent.replayed.record()
         self.replays += 1
         out = ent.out
+        if finish is not None:
+            return finish(out)
         if isinstance(out, dict):
             return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
         return out.clone()

@@ -85,6 +85,9 @@ SIGNATURES = {
     "nir_linear_planes_f32": (_i, [C.c_void_p, C.c_void_p, _l, c_ip, _l, _l, _i, _i, C.c_void_p, C.c_void_p, _l, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
     "nir_sanitize_ids": (_i, [c_ip, _l, c_ip, _l, _l, c_ip, c_ip, C.c_void_p, c_st]),
     "nir_flag_publish": (_i, [C.c_void_p, C.c_void_p, c_st]),
+    "nir_gather_fields": (_i, [C.c_void_p, _i, C.c_void_p, _l, c_st]),
+    "nir_host_device_pointer": (_i, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "nir_softmax_rows_publish": (_i, [c_fp, c_fp, _l, _i, C.c_void_p, C.c_void_p, c_st]),
     "nir_host_rank_metric": (C.c_double, [_i, C.c_void_p, C.c_void_p, _i, _l, _i, _i]),
     "nir_widen_ids_i32": (_i, [C.c_void_p, C.c_void_p, _l, c_st]),
     "nir_linear_f32": (_i, [c_fp, _l, c_ip, c_fp, _i, _l, _l, c_fp, _l, c_fp, c_fp, c_fp, _l, _l, _i, _i, _i, c_st]),
@@ -246,6 +249,18 @@ def set_batches_in_flight(n, streams=None):
     L = load()
     for s in ([torch.cuda.current_stream()] if streams is None else streams):
         L.nir_set_stream_batches_in_flight(C.c_void_p(s.cuda_stream), int(n))
+        if int(n) < 1:
+            _BIF.pop(s.cuda_stream, None)
+        else:
+            _BIF[s.cuda_stream] = int(n)
+
+
+_BIF = {}
+
+
+def batches_in_flight():
+    """the hint of the current stream (1 without one): the host-side mirror of the library's per-stream table"""
+    return _BIF.get(torch.cuda.current_stream().cuda_stream, 1) if _BIF else 1
 
 
 def ids64(t):

@@ -433,7 +433,7 @@ class CARS(nn.Module, lib.IdCheck):
         return self._rank_session(dummy_q, docs, doc_labels, want_clicks=True)[1]
 
     def rank_document(self, pooled_rep, document_rep, document_len, document_label, group=None, shard=False, want_states=None,
-                      labels_groups=None):
+                      labels_groups=None, after_documents=None):
         """cars.py:522-540 -> (click_scores [B,S,N] (or [] when the ranker is off), hidden_states, session_attns).
         hidden_states = (transform_hid(h), transform_cell(c)) [1,(S-1)*B,nhid_decoder] and session_attns = (inner_q, inner_d)
         [B,S,HS] are the decoder inputs (cars.py:382-456); they are produced when `want_states` (default: whenever the
@@ -442,11 +442,16 @@ class CARS(nn.Module, lib.IdCheck):
         sessions / ranknet for this rank's block of sessions, all-gather of the scores (sharding.SessionShardPlan); when the decoder
         states are wanted: all-gather of the pooled vectors and a replicated session part (the states cover every session).
         labels_groups [G,B0,S,N] (optional): the B = G*B0 sessions are G whole batches merged into one macro-batch (Multitask.predict_many);
-        batch g keeps the click count of its own labels."""
+        batch g keeps the click count of its own labels.
+        after_documents (optional callable): run between the document encoder and the session tail (a caller that produced `pooled_rep` on
+        a side stream joins it here)."""
         self._check_eval()
         if want_states is None:
             want_states = not self.no_recommender
         encoded_docs, own = None, None
+        if shard and after_documents is not None:
+            after_documents()
+            after_documents = None
         from .. import sharding
         if shard and sharding.dist.is_available() and sharding.dist.is_initialized() and not want_states and not self.no_ranker:
             # session-sharded tail (sharding.SessionShardPlan): candidate slice of every session -> all-to-all -> clicks / sessions / ranknet
@@ -463,6 +468,8 @@ class CARS(nn.Module, lib.IdCheck):
                 encoded_docs, own = sharding.sharded_pooled_docs(self.encode_document, document_rep, document_len, group, return_local=True)
             else:
                 encoded_docs = self.encode_document(document_rep, document_len)
+        if after_documents is not None:
+            after_documents()
         # candidate-sharded: the ranker MLP scores this rank's slice only (clicks / sessions need every pooled candidate and stay
         # replicated); the score slices are gathered afterwards
         scores, _, outs = self._rank_session(pooled_rep, encoded_docs, document_label, want_states=want_states,

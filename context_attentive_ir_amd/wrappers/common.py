@@ -52,11 +52,29 @@ class WrapperBase(object):
         if self.id_check_interval > 0 and self.id_check == "deferred" and self._board is not None:
             self._board.poll()
 
-    def _maybe_check_ids(self):
+    def _softmax_rows(self, s, out=None):
+        """softmax over the last axis of the raw scores `s` (contiguous) -> probabilities; with the deferred id check the same launch
+        publishes the device's error word (nir_softmax_rows_publish) -> (probs, published)."""
+        from .. import lib
+        if out is None:
+            out = torch.empty_like(s)
+        rows, n = s.numel() // s.shape[-1], s.shape[-1]
+        L = lib.load()
+        if rows > 0 and self.use_cuda and self.id_check_interval > 0 and self.id_check == "deferred":
+            f = self._flags()
+            if f.mapped:
+                rc = L.nir_softmax_rows_publish(lib.ptr(s), lib.ptr(out), rows, n, lib.ptr(f.dev), lib.C.c_void_p(f.host.data_ptr()), lib.stream())
+                if rc == 0:
+                    return out, True
+                f.mapped = False
+        lib.check(L.nir_softmax_rows(lib.ptr(s), lib.ptr(out), rows, n, lib.stream()), "nir_softmax_rows")
+        return out, False
+
+    def _maybe_check_ids(self, published=False):
         if self.id_check_interval <= 0 or not self.use_cuda:
             return
         if self.id_check == "deferred":
-            if self._flags().publish():                     # capturable: part of a captured predict
+            if published or self._flags().publish():        # capturable: part of a captured predict
                 return
         if torch.cuda.is_current_stream_capturing():
             return

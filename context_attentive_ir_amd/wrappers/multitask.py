@@ -45,10 +45,24 @@ class Multitask(WrapperBase):
             s = self.network.rank_document(src, memory_bank, session_bank, self._dev(ex["document_words"]), self._dev(ex["document_lens"]))
             return s, states, None, (None, None)
         src_lens = self._dev(ex["source_lens"])
-        pooled, encoded, _ = self.network.encode(self._dev(ex["source_words"]), src_lens)
+        join = None
+        if self.use_cuda and not self.parallel and torch.cuda.is_current_stream_capturing() and lib.batches_in_flight() <= 1:
+            # one batch in flight inside a capture (PredictGraphCache, GraphedPredictor): the query encoder (7 of 256 CUs for ~25 us at a C3
+            # batch) runs on a side stream next to the document encoder and joins in front of the session tail.  (Eagerly the host is the
+            # bound and the extra event calls would cost more than the overlap buys; with several batches in flight the chip is full anyway.)
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_fork_stream", None) is None or self._fork_stream.device != cur.device:
+                self._fork_stream = torch.cuda.Stream(device=cur.device)
+            side = self._fork_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                pooled, encoded, _ = self.network.encode(self._dev(ex["source_words"]), src_lens)
+            join = lambda: cur.wait_stream(side)             # noqa: E731
+        else:
+            pooled, encoded, _ = self.network.encode(self._dev(ex["source_words"]), src_lens)
         s, states, attns = self.network.rank_document(pooled, self._dev(ex["document_words"]), self._dev(ex["document_lens"]),
                                                       self._dev(ex["document_labels"]), group=self.group, shard=self.parallel,
-                                                      want_states=want_states)
+                                                      want_states=want_states, after_documents=join)
         return s, states, attns, (encoded, src_lens)
 
     # ---- the candidate-sharded ranking step in two capturable halves (bench.py / a serving loop replays each as a hipGraph and issues
@@ -206,24 +220,40 @@ class Multitask(WrapperBase):
         self._poll_ids()
         do_decode = bool(suggest) and not (self.type == "CARS" and self.network.no_recommender)
         fields = self._FIELDS if self.type == "CARS" else self._FIELDS[:4]
-        cache, ent = self._graph_entry(ex, fields, do_decode, lambda e: self._predict_body(e, do_decode))
+        if do_decode or self.type == "CARS" and self.network.no_ranker:
+            cache, ent = self._graph_entry(ex, fields, do_decode, lambda e: self._predict_body(e, do_decode))
+            finish = None
+        else:
+            # ranking only: the captured part ends at the raw scores; the softmax (+ the publication of the error word) runs eagerly into a
+            # fresh tensor -- one launch instead of an in-graph softmax and a copy of the static output
+            cache, ent = self._graph_entry(ex, fields, do_decode, lambda e: self._rank(e, False)[0].contiguous())
+            finish = self._finish_scores
         if ent is None:
             out = self._predict_body(ex, do_decode)
         else:
-            out = cache.run(ent, ex)
-            if self.id_check == "blocking":
+            out = cache.run(ent, ex, finish)
+            if finish is None and self.id_check == "blocking":
                 self._maybe_check_ids()
         out["click_scores"] = self._checked(out["click_scores"])
         return out
 
+    def _finish_scores(self, s):
+        probs, published = self._softmax_rows(s)
+        self._maybe_check_ids(published)
+        return {"click_scores": probs, "predictions": None}
+
     def _predict_body(self, ex, do_decode):
         s, states, attns, enc = self._rank(ex, do_decode)
         out = {"click_scores": None, "predictions": None}
+        published = False
         if torch.is_tensor(s):
             s = s.contiguous()
-            probs = torch.empty_like(s)
-            lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()),
-                      "nir_softmax_rows")
+            if do_decode and states is not None:             # (the decoder runs behind the softmax: the error word is published after it)
+                probs = torch.empty_like(s)
+                lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(probs), s.shape[0] * s.shape[1], s.shape[2], lib.stream()),
+                          "nir_softmax_rows")
+            else:
+                probs, published = self._softmax_rows(s)
             out["click_scores"] = probs
         if do_decode and states is not None:
             B, S = ex["source_words"].shape[0], ex["source_words"].shape[1]
@@ -231,7 +261,7 @@ class Multitask(WrapperBase):
                                       batch_size=B, session_len=S - 1, use_cuda=self.use_cuda, encoded_source=enc[0], source_len=enc[1],
                                       session_attns=attns)
             out["predictions"] = dec["predictions"]
-        self._maybe_check_ids()
+        self._maybe_check_ids(published)
         return out
 
     def update(self, ex):

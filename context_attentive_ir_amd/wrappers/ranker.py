@@ -56,10 +56,8 @@ class Ranker(WrapperBase):
 
     def _predict_body(self, ex):
         s = self.scores(ex).contiguous()
-        out = torch.empty_like(s)
-        lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0], s.shape[1], lib.stream()),
-                  "nir_softmax_rows")
-        self._maybe_check_ids()
+        out, published = self._softmax_rows(s)
+        self._maybe_check_ids(published)
         return out
 
     @torch.no_grad()
@@ -74,13 +72,16 @@ class Ranker(WrapperBase):
             world, rank = sharding.dist.get_world_size(self.group), sharding.dist.get_rank(self.group)
             dd, ll = sharding.shard_candidates(d, dl, world, rank)
             return sharding.gathered_softmax(self.network(q, ql, dd, ll), d.shape[1], self.group)
-        cache, ent = self._graph_entry(ex, self._FIELDS, None, self._predict_body)
+        # the captured part ends at the raw scores; the softmax (+ the publication of the error word) runs eagerly into a fresh tensor
+        cache, ent = self._graph_entry(ex, self._FIELDS, None, lambda e: self.scores(e).contiguous())
         if ent is None:
             return self._checked(self._predict_body(ex))
-        out = cache.run(ent, ex)
-        if self.id_check == "blocking":
-            self._maybe_check_ids()
-        return self._checked(out)
+        return self._checked(cache.run(ent, ex, self._finish_scores))
+
+    def _finish_scores(self, s):
+        out, published = self._softmax_rows(s)
+        self._maybe_check_ids(published)
+        return out
 
     @torch.no_grad()
     def predict_many(self, exs, out=None):

@@ -101,6 +101,20 @@ int nir_sanitize_ids(const int64_t* a, int64_t na, const int64_t* b, int64_t nb,
  * and costs nothing on the way.  Capturable into a hipGraph.  Returns a HIP error code if host_flag is not mapped host memory. */
 int nir_flag_publish(const int* dev_flag, int* host_flag /*pinned, mapped*/, nir_stream_t stream);
 
+/* The H2D step of a captured predict() as ONE kernel inside the hipGraph (round 6): `table` (int64[3*n] in PINNED, device-mapped host memory:
+ * {source address, destination offset, bytes} per field) names where each input field of this call lives -- a pinned host tensor of the caller
+ * (read over PCIe by the kernel itself: no hipMemcpyAsync, no SDMA hand-off), the entry's own pinned staging block (small or pageable fields,
+ * memmoved there by the host) or device memory -- and the kernel copies all of them into the static input block `dst` the captured kernels read.
+ * The table's CONTENT changes per call, its address does not: the graph needs no update.  Sources and destination offsets must be 16-byte
+ * aligned (sizes need not be).  total_bytes = the sum of the fields' sizes rounded up to 16 each (sizes the grid at capture time: the table of
+ * a replay must not exceed it).  nir_host_device_pointer: the device-visible address of a pinned host pointer (hipHostGetDevicePointer), or an
+ * error code when the memory is not mapped (pageable memory: the caller stages it). */
+int nir_gather_fields(const int64_t* table /*pinned, mapped*/, int n, void* dst /*device*/, int64_t total_bytes, nir_stream_t stream);
+int nir_host_device_pointer(const void* host, void** device_visible /*host out*/);
+
+/* nir_softmax_rows + nir_flag_publish in one launch (the last kernel of a ranking-only predict()). */
+int nir_softmax_rows_publish(const float* scores, float* probs, int64_t rows, int n, const int* dev_flag, int* host_flag, nir_stream_t stream);
+
 /* HOST-side ranking metrics of one batch with the reference's definitions (neuroir/eval/ltorank.py:4-47, 104-123), for the per-batch loop of
  * the reference's drivers (main/ranker.py:258-262): predictions [rows, n] int64 = candidate indices by descending score (np.argsort(-scores)),
  * target [rows, n] relevance labels (label_dtype 0: float32, 1: int64, 2: float64; relevant <=> == 1).  Plain C loops over host arrays -- no

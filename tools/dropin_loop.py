@@ -11,7 +11,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,44 +18,8 @@ sys.path.insert(0, ROOT)
 from context_attentive_ir_amd import synth  # noqa: E402
 from context_attentive_ir_amd.config import default_args  # noqa: E402
 from context_attentive_ir_amd.detinit import fill_module_  # noqa: E402
-from context_attentive_ir_amd.eval.ltorank import MAP, MRR, precision_at_k  # noqa: E402
+from context_attentive_ir_amd.eval.validate import reference_loop  # noqa: E402
 from context_attentive_ir_amd.wrappers import Multitask, Ranker  # noqa: E402
-
-
-def session_loop(model, batches, iters, decode):
-    maps = []
-    with torch.no_grad():
-        for i in range(iters):
-            ex = batches[i % len(batches)]
-            rows = ex["source_words"].shape[0] * ex["source_words"].shape[1]
-            outputs = model.predict(ex) if decode else model.predict(ex, suggest=False)
-            scores = outputs["click_scores"].view(rows, -1).contiguous()
-            labels = ex["document_labels"].view(rows, -1).contiguous().numpy()
-            predictions = np.argsort(-scores.cpu().numpy())
-            maps.append(MAP(predictions, labels))
-            MRR(predictions, labels)
-            precision_at_k(predictions, labels, 1)
-            precision_at_k(predictions, labels, 3)
-            precision_at_k(predictions, labels, 5)
-            if decode:
-                outputs["predictions"].cpu()
-    return maps
-
-
-def ranker_loop(model, batches, iters):
-    maps = []
-    with torch.no_grad():
-        for i in range(iters):
-            ex = batches[i % len(batches)]
-            scores = model.predict(ex)
-            predictions = np.argsort(-scores.cpu().numpy())
-            labels = ex["label"].numpy()
-            maps.append(MAP(predictions, labels))
-            MRR(predictions, labels)
-            precision_at_k(predictions, labels, 1)
-            precision_at_k(predictions, labels, 3)
-            precision_at_k(predictions, labels, 5)
-    return maps
 
 
 def set_mode(model, mode):
@@ -95,7 +58,7 @@ def main():
             ref = None
             for mode in a.modes.split(","):
                 set_mode(model, mode)
-                run = (lambda n: session_loop(model, batches, n, bool(dec))) if is_sess else (lambda n: ranker_loop(model, batches, n))
+                run = lambda n: reference_loop(batches, model, n, suggest=bool(dec))      # noqa: E731
                 run(16)
                 torch.cuda.synchronize()
                 best = None
