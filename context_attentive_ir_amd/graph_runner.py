@@ -8,6 +8,7 @@ neuroir/inputters/ranker/data.py:37-56, already group batches by shape).
 """
 import collections
 import ctypes
+import os
 import time
 
 import torch
@@ -199,6 +200,9 @@ class PredictGraphCache(object):
     data pointer, the network's path switches): training, load_state_dict or a switch change re-captures; `clear()` on .cuda() / .cpu().
     At most `max_entries` graphs (LRU)."""
     BIG = 64 << 10          # host fields of at least this many bytes that are already pinned skip the staging copy
+    # pinned host fields larger than this go through hipMemcpyAsync (SDMA) in front of the replay instead of the gather kernel's own PCIe reads
+    # (None: never) -- A/B switch for tools/dropin_loop.py
+    SDMA_FROM = int(os.environ["NIR_GATHER_SDMA_FROM"]) if os.environ.get("NIR_GATHER_SDMA_FROM") else None
 
     def __init__(self, wrapper, max_entries=32, min_calls=2):
         self.w = wrapper
@@ -310,6 +314,11 @@ class PredictGraphCache(object):
             if not src.is_contiguous():
                 src = src.contiguous()
             addr = 0
+            if self.SDMA_FROM is not None and n >= self.SDMA_FROM and not src.is_cuda and src.is_pinned():
+                ent.static[k].copy_(src, non_blocking=True)
+                hold.append(src)
+                tab[3 * i], tab[3 * i + 1], tab[3 * i + 2] = ent.stage_dev + o, o, 0
+                continue
             if src.is_cuda:
                 addr = src.data_ptr()
             elif n >= self.BIG and src.is_pinned() and L.nir_host_device_pointer(ctypes.c_void_p(src.data_ptr()), ctypes.byref(dp)) == 0:

@@ -22,6 +22,30 @@ from context_attentive_ir_amd.eval.validate import reference_loop  # noqa: E402
 from context_attentive_ir_amd.wrappers import Multitask, Ranker  # noqa: E402
 
 
+def breakdown(model, batches, iters, suggest):
+    """where a loop iteration goes on the host: time inside predict() (enqueue), inside `.cpu()` (the device finishing + D2H), the rest (numpy,
+    metrics) -- perf_counter stamps around the same statements as eval.validate.reference_loop"""
+    import numpy as np
+    from context_attentive_ir_amd.eval.ltorank import MAP, MRR, precision_at_k
+    tp = tc = tm = 0.0
+    with torch.no_grad():
+        for i in range(iters):
+            ex = batches[i % len(batches)]
+            rows = ex["source_words"].shape[0] * ex["source_words"].shape[1]
+            t0 = time.perf_counter()
+            outputs = model.predict(ex, suggest=suggest)
+            t1 = time.perf_counter()
+            scores = outputs["click_scores"].view(rows, -1).contiguous()
+            host = scores.cpu()
+            t2 = time.perf_counter()
+            labels = ex["document_labels"].view(rows, -1).contiguous().numpy()
+            predictions = np.argsort(-host.numpy())
+            MAP(predictions, labels), MRR(predictions, labels), precision_at_k(predictions, labels, 1), precision_at_k(predictions, labels, 3), precision_at_k(predictions, labels, 5)
+            t3 = time.perf_counter()
+            tp, tc, tm = tp + t1 - t0, tc + t2 - t1, tm + t3 - t2
+    return {"predict_us": round(tp / iters * 1e6, 1), "cpu_wait_us": round(tc / iters * 1e6, 1), "metrics_us": round(tm / iters * 1e6, 1)}
+
+
 def set_mode(model, mode):
     model.id_check_interval = 1
     model.id_check = "blocking" if mode == "r5" else "deferred"
@@ -38,6 +62,7 @@ def main():
     ap.add_argument("--cands", type=int, default=10)
     ap.add_argument("--modes", default="r5,deferred_eager,default")
     ap.add_argument("--vocab", type=int, default=100000)
+    ap.add_argument("--breakdown", action="store_true")
     a = ap.parse_args()
     V = a.vocab
     is_sess = a.model in ("CARS", "MNSRF", "M_MATCH_TENSOR")
@@ -69,7 +94,8 @@ def main():
                     best = dt if best is None else min(best, dt)
                 if ref is None:
                     ref = maps
-                print(json.dumps({"model": a.model, "batch": B, "cands": a.cands, "decode": dec, "mode": mode, "ms_per_call": round(best * 1e3, 4),
+                extra = breakdown(model, batches, a.iters, bool(dec)) if (a.breakdown and is_sess) else None
+                print(json.dumps({"breakdown": extra, "model": a.model, "batch": B, "cands": a.cands, "decode": dec, "mode": mode, "ms_per_call": round(best * 1e3, 4),
                                   "pairs_per_s": round(pairs / best, 1), "map_equal_first_mode": maps == ref,
                                   "graphs": None if model._graphs is None else [model._graphs.captures, model._graphs.replays]}), flush=True)
     model.check_ids()
