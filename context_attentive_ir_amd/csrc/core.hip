@@ -54,6 +54,7 @@ ProfScope::~ProfScope() {
 }  // namespace nir
 
 extern "C" int nir_profile_enable(int on) {
+    if (on < 0) return nir::g_prof_on.load();          // query: 1 while per-kernel timing is on
     nir::g_prof_on.store(on ? 1 : 0);
     return 0;
 }

@@ -96,6 +96,9 @@ class WrapperBase(object):
             return None, None
         if torch.cuda.is_current_stream_capturing():        # an outer capture (graph_runner.GraphedPredictor, bench.py) records the eager body
             return None, None
+        from .. import lib
+        if lib.load().nir_profile_enable(-1):               # per-kernel event timing is on: events cannot be recorded into a capture
+            return None, None
         if self._graphs is None:
             from ..graph_runner import PredictGraphCache
             self._graphs = PredictGraphCache(self, self.predict_graph_max, self.predict_graph_min_calls)

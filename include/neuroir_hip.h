@@ -63,7 +63,8 @@ int nir_debug_set_tunable(const char* name /*host*/, int value);
 /* Per-kernel timing for bench.py's roofline block: while enabled, every kernel launch of this library is
  * bracketed by two hipEvents recorded on its own stream.  nir_profile_report synchronises those events and
  * writes "kernel_name,launches,total_ms\n" lines (aggregated by kernel) into a HOST buffer; returns the number
- * of distinct kernels.  Must be off during graph capture. */
+ * of distinct kernels.  Must be off during graph capture (nir_profile_enable(-1) returns the current state: the wrappers' own graph cache
+ * stays out of the way while it is on). */
 /* Debug aid: out[0] = shader-clock ticks, out[1] = 100 MHz wall ticks spent by block 0 in a dependent FMA chain of
  * `iters` steps while `blocks` workgroups run it -> effective sclk = out[0]/out[1] * 100 MHz. */
 int nir_debug_clock_probe(void* out /*device u64[2]*/, int iters, int blocks, void* sink /*device float[1]*/, nir_stream_t stream);
