@@ -269,7 +269,18 @@ __device__ long long ap_dbg[16];
 #else
 #define AP_T(I)
 #endif
-constexpr size_t AP2_LDS = (size_t)2 * AP_PLANE_HALVES * 2 + (2 * 4 * 64 + 4 * 64 + 2 * AP_D) * 4;
+// Plane layout of the pipeline (round 6: LDS bank conflicts, 7.4 extra cycles per LDS instruction in round 5's PMC captures = a quarter of the
+// launch's CU-cycles): [2 terms][8 k-steps S][4 k-groups g][64 row positions][8 halves], blocks of exactly 1 KB, row r of block (S, g) at position
+//     r ^ x(S, g),   x = 4 (S & 1) + 2 (g >> 1).
+// * MMA waves (ds_read_b128: lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... , bank = (a / 4) mod 64): a group mixes rows {0-3,12-15} of
+//   k-group 2j with rows {4-11} of k-group 2j + 1; with the block stride a multiple of 256 B and ONE x for both k-groups of a pair the 16 lanes cover 16
+//   distinct 16-byte slots (the old 64-byte pad between blocks shifted k-group 2j + 1 by four slots: 2-way in every group, +4 cycles per read).
+// * IO waves (ds_write_b64 / ds_read_b64: 16 / 32 contiguous lanes = ONE row, 8 (S & 1, g) blocks x 2 halves): the same row sits at the same offset of
+//   every block, so only a per-block displacement separates the lanes: x spreads the four (S & 1, g >> 1) classes over 4 x 32 B of the 128-byte bank
+//   window -- 2-way (k-groups 2j / 2j + 1 must stay congruent for the MMA reads) instead of 4-way on every staging write (+12 cycles each).
+constexpr int AP2_KG = AP_ROWS * 8;                              // halves per (S, g) block: 1 KB, no pad
+constexpr int AP2_PLANE_HALVES = 2 * AP_S * 4 * AP2_KG;         // [2 terms][8 k-steps][4 k-groups][KG]
+constexpr size_t AP2_LDS = (size_t)2 * AP2_PLANE_HALVES * 2 + (2 * 4 * 64 + 4 * 64 + 2 * AP_D) * 4;
 
 // ONE: W0 and the rows enter as single fp16 terms (bf16 encoders).  ROW1 (round 5, the "split2" tier: <false, 1>): the ROWS are single fp16
 // terms (the recurrence's one-term hand-over) but W0 keeps its two terms: two MFMAs per fragment pair (row . w1, row . w2').
@@ -308,8 +319,8 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
     constexpr bool IN16 = IN == 1;
     constexpr bool ROW1 = ONE || IN16;                // the rows have no residual plane
     extern __shared__ __attribute__((aligned(16))) unsigned short asm2_[];
-    constexpr int KG = AP_KG;
-    float* rowpart = reinterpret_cast<float*>(asm2_ + 2 * AP_PLANE_HALVES);      // [2 buffers][4 waves][64 rows]
+    constexpr int KG = AP2_KG, PH = AP2_PLANE_HALVES;
+    float* rowpart = reinterpret_cast<float*>(asm2_ + 2 * PH);      // [2 buffers][4 waves][64 rows]
     float* probw = rowpart + 2 * 4 * 64;                                          // [4 IO waves][64 rows]
     float* bw = probw + 4 * 64;                                                   // [256] b0 * 2 log2(e), [256] w3: read by every tile's epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w4 = wave & 3;
@@ -329,13 +340,18 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
         // W fragments are addressed as (wave-uniform base + compile-time offset) + one 32-bit lane offset: with a per-lane 64-bit
         // pointer the unrolled last k-steps kept one precomputed pointer per fragment live across the tile loop, 25 registers went to
         // scratch and every reload carried an s_waitcnt vmcnt(0) into the MFMA stream (12 per tile)
+        // The MMA wave is the tile's critical chain (k-loop, then ITS epilogue): it issues ahead of the IO wave that shares its SIMD.  Measured with
+        // the conflict-free plane layout (tools/attn_micro.py, M = 8 960, same process): layout alone 1.07 x the round-5 kernel (the IO waves, no longer
+        // throttled by 4-way staging conflicts, take issue slots at the wrong time), priority alone 1.05 x, both 0.957 x.
+        __builtin_amdgcn_s_setprio(3);
         const _Float16* wbase = p.wf + (int64_t)(AP_CT * __builtin_amdgcn_readfirstlane(w4)) * 2 * 64 * 8;
         uint32_t wlane = (uint32_t)lane * 16u;                       // bytes; made opaque once per k-step (below) so that the addresses
         auto ldw = [&](int off_halves) {                             // are recomputed (2 VALU) instead of hoisted out of the tile loop
             return *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(wbase + off_halves) + (uint64_t)wlane);
         };
         constexpr int WSTEP = 16 * 2 * 64 * 8;
-        const int foff = g * KG + c16 * 8;
+        // row position of this lane's A rows inside block (S, g): c16 ^ x(S & 1, g >> 1) -- one offset for even, one for odd k-steps
+        const int foff_e = g * KG + (c16 ^ (2 * (g >> 1))) * 8, foff_o = g * KG + (c16 ^ (4 + 2 * (g >> 1))) * 8;
         f16x8 wa[AP_CT][2], wb[AP_CT][2], af[AP_RT][2];
         f32x4 acc[AP_CT][AP_RT], acx[AP_CT][AP_RT];
 #pragma unroll
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
         for (int64_t it = 0; it < nk + 2; ++it) {
             if (w4 == 0) { AP_T(0) }
             if (it >= 1 && it <= nk) {
-                const unsigned short* Pp = asm2_ + ((it - 1) & 1) * AP_PLANE_HALVES;
+                const unsigned short* Pp = asm2_ + ((it - 1) & 1) * PH;
                 float* rp = rowpart + ((it - 1) & 1) * 4 * 64;
 #pragma unroll
                 for (int j = 0; j < AP_CT; ++j)
@@ -357,18 +373,18 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                     }
 #pragma unroll
                 for (int i = 0; i < AP_RT - 1; ++i) {      // row tile 3 of a k-step is read at MFMAs 7, 8 of that step
-                    af[i][0] = *reinterpret_cast<const f16x8*>(Pp + foff + i * 128);
-                    af[i][1] = *reinterpret_cast<const f16x8*>(Pp + AP_S * 4 * KG + foff + i * 128);
+                    af[i][0] = *reinterpret_cast<const f16x8*>(Pp + foff_e + i * 128);
+                    af[i][1] = *reinterpret_cast<const f16x8*>(Pp + AP_S * 4 * KG + foff_e + i * 128);
                 }
                 // k-step S with W set WC; WN receives the fragments of step S+1 (after step 7: step 0 again, for the next tile).  A
                 // fragments of row tile i for step S+1 are re-read into af[i] at MFMA 12 i + 19 / + 20 (>= 7 slots after their last use;
                 // row tile 3: MFMAs 7 / 8 of the step itself); the last step reads none -- the next tile's planes are not complete yet.
-#define AP2_STEP(S, WC, WN, LAST)                                                         \
+#define AP2_STEP(S, WC, WN, LAST, ODD)                                                    \
                 {                                                                         \
                     const int sn_ = ((S) + 1) & (AP_S - 1);                               \
                     asm volatile("" : "+v"(wlane));                                       \
-                    const unsigned short* pc_ = Pp + (S) * 4 * KG + foff;                 \
-                    const unsigned short* pn_ = Pp + sn_ * 4 * KG + foff;                 \
+                    const unsigned short* pc_ = Pp + (S) * 4 * KG + ((ODD) ? foff_o : foff_e);  \
+                    const unsigned short* pn_ = Pp + sn_ * 4 * KG + ((ODD) ? foff_e : foff_o);  \
                     _Pragma("clang loop unroll(full)") for (int n_ = 0; n_ < 3 * AP_RT * AP_CT; ++n_) { \
                         ap2_mma_n<ONE, ROW1>(n_, acc, acx, af, WC);                             \
                         if (n_ % 6 == 2 && n_ / 6 < 2 * AP_CT && !(ONE && ((n_ / 6) & 1))) { /* ONE: the residual-term fragments are never read */ \
@@ -391,11 +407,11 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
                 }
 #pragma unroll 1
                 for (int s = 0; s < AP_S - 2; s += 2) {
-                    AP2_STEP(s, wa, wb, 0)
-                    AP2_STEP(s + 1, wb, wa, 0)
+                    AP2_STEP(s, wa, wb, 0, 0)
+                    AP2_STEP(s + 1, wb, wa, 0, 1)
                 }
-                AP2_STEP(AP_S - 2, wa, wb, 0)
-                AP2_STEP(AP_S - 1, wb, wa, 1)
+                AP2_STEP(AP_S - 2, wa, wb, 0, 0)
+                AP2_STEP(AP_S - 1, wb, wa, 1, 1)
                 if (w4 == 0) { AP_T(1) }
                 AP_MMA_DRAIN();
                 {   // logits: tanh, times w3, summed over this wave's 64 columns
@@ -457,6 +473,10 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
         const int sub = lane >> 4, per = T / 4;
         const int col = 64 * w4 + 4 * c16;
         const int poff = ((col >> 5) * 4 + ((col >> 3) & 3)) * KG + (col & 7);
+        // row r of this lane's blocks sits at position r ^ x, x = 4 (S & 1) + 2 (g >> 1) = 4 xq + 2 xs: r = 4 q + sub -> 4 (q ^ xq) + (sub ^ 2 xs):
+        // one base for even and one for odd q, the rest of q stays a compile-time offset
+        const int xq = c16 >> 3, sx = sub ^ (2 * ((c16 >> 2) & 1));
+        const int roff_e = (4 * xq + sx) * 8, roff_o = (4 * (1 ^ xq) + sx) * 8;
         float4 ld[IN16 ? 1 : 16];
         uint2 ld16[IN16 ? 16 : 1];
         // The length of row `lane`'s sequence travels with the tile's rows: requested IN FRONT of them (vmcnt retires in order), first read where
@@ -482,7 +502,9 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
         };
         if (nk > 0) load_rows(0);
         for (int64_t it = 0; it < nk + 2; ++it) {
-            unsigned short* Pb = asm2_ + (it & 1) * AP_PLANE_HALVES + poff;
+            unsigned short* Pb = asm2_ + (it & 1) * PH + poff;
+            unsigned short* Pbe = Pb + roff_e;
+            unsigned short* Pbo = Pb + roff_o;
             if (w4 == 0) { AP_T(4) }
             if (it >= 2) {
                 const int64_t rowS = (blockIdx.x + (it - 2) * G) * AP_ROWS;
@@ -513,8 +535,9 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
 #pragma unroll
                     for (int q8 = 0; q8 < 8; ++q8) {
                         const int row = 4 * (8 * hb + q8) + sub;
-                        u1[q8] = *reinterpret_cast<const uint2*>(Pb + row * 8);
-                        if (!ROW1) u2[q8] = *reinterpret_cast<const uint2*>(Pb + AP_S * 4 * KG + row * 8);
+                        const unsigned short* src = ((q8 & 1) ? Pbo : Pbe) + ((8 * hb + q8) >> 1) * 64;
+                        u1[q8] = *reinterpret_cast<const uint2*>(src);
+                        if (!ROW1) u2[q8] = *reinterpret_cast<const uint2*>(src + AP_S * 4 * KG);
                         prr[q8] = pw[row];
                     }
 #pragma unroll
@@ -556,7 +579,7 @@ __global__ __launch_bounds__(512, 1) void attn_pool_pipe_kernel(AttnPoolArgs p, 
             if (it < nk) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    unsigned short* d = Pb + (4 * q + sub) * 8;
+                    unsigned short* d = ((q & 1) ? Pbo : Pbe) + (q >> 1) * 64;
                     if (IN16) {
                         *reinterpret_cast<uint2*>(d) = ld16[q];
                         continue;
