@@ -37,6 +37,14 @@ constexpr int CL_H = 256, CL_KB = 8, CL_NT = 2, CL_NW = 8, CL_SEQ = 16, CL_ZLD =
 constexpr int CL_GRAN = CL_UW * CL_SEQ;                       // granules one member publishes per group and step (1024)
 constexpr int CL_POLL_LIMIT = 400000;                         // bounded spin (~0.3-1 s): then err bit 2 and exit
 
+// LDS layout of an h row (round 6; the same ds_read_b128 lane-group argument as lstm_fold.hip's lstm16_pt_h2_kernel): 32 pieces of 16 B per row and
+// term; piece (kb, kq) of sequence s sits in row s ^ 8 (kq & 1) at position 8 (kq & 1) + (kq >> 1) + 2 (kb & 3) + 16 (kb >> 2): the odd
+// k-quarters are shifted by eight 16-byte slots and eight rows, so the 16 lanes of a read group cover 16 distinct slots (was: 2-way in every group,
+// SQ_LDS_BANK_CONFLICT 3.4 per LDS instruction, 13 % of the launch's CU-cycles in round 5's capture).
+__device__ __forceinline__ constexpr int cl_zo(int s_, int k_) {          // element offset of (sequence s_, k index k_) inside a term plane
+    return (s_ ^ (8 * ((k_ >> 3) & 1))) * CL_ZLD + (8 * ((k_ >> 3) & 1) + ((k_ >> 4) & 1) + 2 * ((k_ >> 5) & 3) + 16 * (k_ >> 7)) * 8 + (k_ & 7);
+}
+
 struct LstmClArgs {
     const float* rows;            // [R][ND][256][4] fp32 gate rows in the folded order (folded table: R = V; per-batch gates: R = M*T)
     const int64_t* ids;           // [M,T] row of every token, or null: row = m*T + t
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
         const int idx = tid + NTH * i, fm = idx >> 9, r = idx & 511;
         const int mem = fm + (fm >= member ? 1 : 0);
         poff[i] = (uint32_t)((mem * CL_PIECES + r) * 16);
-        zoff[i] = (uint32_t)(((r & 15) * ZLD + CL_UW * mem + 2 * (r >> 4)) >> 1);      // (sequence, unit pair) of member mem, as a 32-bit word
+        zoff[i] = (uint32_t)(cl_zo(r & 15, CL_UW * mem + 2 * (r >> 4)) >> 1);      // (sequence, unit pair) of member mem, as a 32-bit word
     }
     const uint32_t myoff = (uint32_t)((member * CL_PIECES + (u0 >> 1) * SEQ + sq) * 16);
     // W_hh must have LANDED before the loop: its first use inside the loop would otherwise leave an s_waitcnt vmcnt(0) in every iteration
@@ -394,14 +402,14 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
             train_stores(g > 0 ? g - 1 : NG - 1);
             if (NG < 3 && rank != 0) burst();
             CL_T(2)
-            const _Float16* zr = zc + sq * ZLD + 8 * kq;
+            const _Float16* zr = zc + cl_zo(sq, 8 * kq);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
 #ifdef NIR_CL_NOLDS
                 const f16x8 h1 = w2[0][kb], h2 = w2[1][kb];
 #else
-                const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 32 * kb);
-                const f16x8 h2 = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 32 * kb);
+                const f16x8 h1 = *reinterpret_cast<const f16x8*>(zr + 16 * (kb & 3) + 128 * (kb >> 2));
+                const f16x8 h2 = *reinterpret_cast<const f16x8*>(zr + SEQ * ZLD + 16 * (kb & 3) + 128 * (kb >> 2));
 #endif
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -441,8 +449,8 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
                 a[t] = (_Float16)hn[t];
                 r_[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
             }
-            *reinterpret_cast<f16x2*>(zn + sq * ZLD + ug) = (f16x2){a[0], a[1]};
-            *reinterpret_cast<f16x2*>(zn + SEQ * ZLD + sq * ZLD + ug) = (f16x2){r_[0], r_[1]};
+            *reinterpret_cast<f16x2*>(zn + cl_zo(sq, ug)) = (f16x2){a[0], a[1]};
+            *reinterpret_cast<f16x2*>(zn + SEQ * ZLD + cl_zo(sq, ug)) = (f16x2){r_[0], r_[1]};
             {
                 const uint32_t lo0 = (uint32_t)__builtin_bit_cast(unsigned short, a[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, r_[0]) << 16);
                 const uint32_t lo1 = (uint32_t)__builtin_bit_cast(unsigned short, a[1]) | ((uint32_t)__builtin_bit_cast(unsigned short, r_[1]) << 16);
