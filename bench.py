@@ -81,6 +81,10 @@ CONFIGS = {
                             baseline="configs[1]: match_tensor ranker, batch=32 x 10 candidates, emb_dim=300, fp32"),
     "NS_match_tensor_50": dict(model="match_tensor", batch=32, cands=50, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32",
                                baseline="north_star shape: q_len 4, doc_len 64, 50 candidates"),
+    # north_star's OWN throughput workload -- sessions, q_len 4, doc_len 64, 50 candidates -- at the reference's fp32
+    # (neuroir/config.py:42 --num_candidates, multitask/cars.py:522-540); the record carries max_abs_diff_vs_oracle_softmax on a 4-session slice
+    "NS_cars_50": dict(model="cars", batch=16, session=7, cands=50, qlen=4, dlen=64, vocab=100000, uniform=False, dtype="f32", oracle_slice=4,
+                       baseline="north_star shape: CARS sessions (session_len 7), q_len 4, doc_len 64, 50 candidates, fp32"),
     "C4_duet": dict(model="duet", batch=64, cands=50, qlen=4, dlen=290, vocab=100000, uniform=False, dtype="f32",
                     baseline="configs[3]: DUET, batch=64 x 50 candidates, doc_len=290"),
     "C4_drmm": dict(model="drmm", batch=64, cands=50, qlen=4, dlen=290, vocab=1000000, uniform=True, dtype="f32",
@@ -101,7 +105,7 @@ CONFIGS = {
                                     "attention pipeline): NOT the parity path -- its own error figure rides in the record"),
 }
 HEADLINE = "C3_cars"
-SUB_STEPS = {"C3_cars_split2": 200, "C1_esm": 400, "C2_match_tensor": 400, "NS_match_tensor_50": 200, "C4_duet": 24, "C4_drmm": 60, "C4_esm_hbm": 60,
+SUB_STEPS = {"NS_cars_50": 60, "C3_cars_split2": 200, "C1_esm": 400, "C2_match_tensor": 400, "NS_match_tensor_50": 200, "C4_duet": 24, "C4_drmm": 60, "C4_esm_hbm": 60,
              "C5_cars_bf16": 24, "X3_m_match_tensor": 100, "X3_mnsrf": 100}
 
 
@@ -1104,13 +1108,21 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     if want_cpu and rank == 0 and not env.multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(c, model, batches, lambda: finish(forward(0)), pairs_global, args)
     tier_err = None
-    if c.get("dtype") == "f32_split2" and rank == 0 and not env.multi and not args.no_cpu_baseline:
-        # the tier's own error figure (checker leg, the oracle as the checker only): click probabilities of two resident batches against the oracle
+    if (c.get("dtype") == "f32_split2" or c.get("oracle_slice")) and rank == 0 and not env.multi and not args.no_cpu_baseline:
+        # the record's own error figure (checker leg, the oracle as the checker only): click probabilities of two resident batches against the oracle
+        # (oracle_slice = n: the first n sessions of each -- the synthetic labels hold exactly one click per query, so the batch-wide click count
+        # of cars.py:285-289 is 1 for the slice as for the batch)
         from oracle import neuroir_cpu as O
         sd_ = {k: v.detach().cpu().float() for k, v in model.network.state_dict().items()}
         tier_err = 0.0
         for bi in range(min(2, len(batches))):
-            ex_ = {k: v.cpu() for k, v in batches[bi].items()}
+            ex_ = {k: v.cpu() for k, v in batches[bi].items() if torch.is_tensor(v)}
+            if c.get("oracle_slice"):
+                ex_ = {k: v[:c["oracle_slice"]].contiguous() for k, v in ex_.items()}
+                got_ = model.predict({k: v.to(dev) for k, v in ex_.items()}, suggest=False)["click_scores"].cpu()
+                ref_ = O.predict_softmax(O.cars_scores(sd_, ex_["source_words"], ex_["source_lens"], ex_["document_words"], ex_["document_lens"], ex_["document_labels"]))
+                tier_err = max(tier_err, float((got_ - ref_.view_as(got_)).abs().max()))
+                continue
             ref_ = O.predict_softmax(O.cars_scores(sd_, ex_["source_words"], ex_["source_lens"], ex_["document_words"], ex_["document_lens"], ex_["document_labels"]))
             got_ = model.predict(batches[bi], suggest=False)["click_scores"].cpu()
             tier_err = max(tier_err, float((got_ - ref_.view_as(got_)).abs().max()))
