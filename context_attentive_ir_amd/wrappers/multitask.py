@@ -39,6 +39,13 @@ class Multitask(WrapperBase):
     @torch.no_grad()
     def _rank(self, ex, want_states):
         self.network.eval()
+        if self.type == "M_MATCH_TENSOR" and not want_states:
+            # ranking only: the interaction head re-derives the query side from the ids inside its fused call (bitwise the values encode()
+            # hands over, mmtensor.py:127-189); encode()'s other products -- the session LSTM over the max-pooled queries, the decoder's
+            # initial states -- feed the suggestion side alone, so the ranking path skips it (a query BiLSTM, two GEMMs and S session steps)
+            s = self.network.rank_document(self._dev(ex["source_words"]), None, None, self._dev(ex["document_words"]),
+                                           self._dev(ex["document_lens"]), source_len=self._dev(ex["source_lens"]))
+            return s, None, None, (None, None)
         if self.type != "CARS":     # models/multitask.py:271-278: encode -> rank_document(source, memory, session, docs, lens)
             src = self._dev(ex["source_words"])
             memory_bank, session_bank, states = self.network.encode(src, self._dev(ex["source_lens"]))
@@ -141,8 +148,15 @@ class Multitask(WrapperBase):
         not depend on the number of sessions).  Every batch keeps the click mask's batch-wide count m of ITS OWN batch
         (cars.py:285-289 via nir_cars_click_max / labels_groups), so the result equals k separate predict() calls -- it is how a serving loop
         should feed this model when several batches are waiting.  out (optional): [k*B,S,N] result buffer."""
+        if self.type == "M_MATCH_TENSOR" and not suggest:
+            # every (query, candidate) row of the interaction head is independent of the rest of its batch (mmtensor.py:127-189): plain
+            # concatenation along the session axis, one launch sequence over k x the rows
+            self.network.eval()
+            cat = lambda key: torch.cat([self._dev(e[key]) for e in exs]) if len(exs) > 1 else self._dev(exs[0][key])     # noqa: E731
+            probs = self.predict_groups({k_: cat(k_) for k_ in self._FIELDS[:4]}, len(exs), out=out)
+            return probs.view(len(exs), -1, *probs.shape[1:])
         if self.type != "CARS":
-            raise NotImplementedError("predict_many is built for CARS")
+            raise NotImplementedError("predict_many is built for CARS (and the ranking path of M_MATCH_TENSOR)")
         self.network.eval()
         cat = lambda key: torch.cat([self._dev(e[key]) for e in exs]) if len(exs) > 1 else self._dev(exs[0][key])     # noqa: E731
         labels = [self._dev(e["document_labels"]) for e in exs]
@@ -181,8 +195,15 @@ class Multitask(WrapperBase):
         probabilities [groups*B,S,N]; block g uses the click count of its own B sessions (graph_runner.StreamingSessionPredictor collates
         `groups` batches into one wire block).  click_max int32 [groups] (device, optional): block g is a SLICE of its batch and takes
         the batch's click count from here (the sharded stream, sharding.StreamShardPlan mode "pair")."""
+        if self.type == "M_MATCH_TENSOR" and click_max is None:
+            self.network.eval()
+            s = self._rank(ex, False)[0].contiguous()                  # [groups*B,S,N]: the rows do not see each other
+            if out is None:
+                out = torch.empty_like(s)
+            lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0] * s.shape[1], s.shape[2], lib.stream()), "nir_softmax_rows")
+            return out.view_as(s)
         if self.type != "CARS":
-            raise NotImplementedError("predict_groups is built for CARS")
+            raise NotImplementedError("predict_groups is built for CARS (and the ranking path of M_MATCH_TENSOR)")
         self.network.eval()
         pooled, _, _ = self.network.encode(self._dev(ex["source_words"]), self._dev(ex["source_lens"]))
         docs = self.network.encode_document(self._dev(ex["document_words"]), self._dev(ex["document_lens"]))

@@ -201,3 +201,24 @@ def test_flag_publish_needs_no_device_round_trip():
     with pytest.raises(RuntimeError):
         f.poll()
     f.check()
+
+
+def test_m_match_tensor_ranking_path_skips_encode_and_macro_batches_bit_equal():
+    """M_MATCH_TENSOR, ranking only: the interaction head re-derives the query side from the ids (mmtensor.py:127-189), so predict(suggest=False)
+    does not run encode() -- same scores as the full predict and as the oracle -- and predict_many / predict_groups (k batches as one launch
+    sequence: every row is independent) equal k separate calls bit for bit."""
+    from oracle import neuroir_cpu as O
+    w = _multitask("M_MATCH_TENSOR")
+    w.args.predict_graphs = False
+    exs = [synth.session_batch(3, 4, 5, 4, 12, V, seed=40 + s, full_length=(s % 2 == 0)) for s in range(3)]
+    singles = [w.predict(ex, suggest=False)["click_scores"] for ex in exs]
+    full = w.predict(exs[0], suggest=True)
+    assert torch.equal(full["click_scores"], singles[0]) and full["predictions"] is not None
+    many = w.predict_many(exs)
+    assert many.shape == (3, 3, 4, 5)
+    for i in range(3):
+        assert torch.equal(many[i], singles[i])
+    sd = {k: v.detach().cpu() for k, v in w.network.state_dict().items()}
+    ref = torch.softmax(O.m_match_tensor_scores(sd, exs[1]["source_words"], exs[1]["source_lens"], exs[1]["document_words"], exs[1]["document_lens"]), -1)
+    assert float((singles[1].cpu() - ref.view_as(singles[1])).abs().max()) < 1e-4
+    w.check_ids()
