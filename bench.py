@@ -152,6 +152,8 @@ def kernel_work(name, c, pairs_per_launch=None):
         in16 = "<true,1>" in base
         in16 = in16 or "<false,1>" in base                 # fp16 rows with a two-term W0 (the split2 tier): 2 MFMAs per fragment pair
         return dict(flops=2.0 * M * N * K + 4.0 * M * N, bytes=(2.0 if in16 else 4.0) * M * K + 4.0 * N * K, terms=1 if one else (2 if "<false,1>" in base else 3), pipe=F16)
+    if base.startswith("pred_argmax_kernel"):      # csrc/cars_decode.hip: [M decode rows] x [N = V_tgt, K = 256] projection + arg-max, fp16 two-term split, no logits
+        return dict(flops=2.0 * M * N * K, bytes=4.0 * N * K + 4.0 * M * K + 8.0 * M * max(1, N // 960), terms=3, pipe=F16)
     if base.startswith("gemm3_kernel"):
         gathered = "[gather]" in base
         return dict(flops=2.0 * M * N * K, bytes=4.0 * (M * K + N * K + M * N) + (8.0 * M * max(1, K // E) if gathered else 0), terms=6, pipe=F16)
@@ -1878,8 +1880,40 @@ def decode_record(c, args, env):
                 graphs[i % len(graphs)][0].replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / (n * mk)
+        # roofline block (VERDICT r5 #7c): HIP events around every kernel of one macro-batched full predict, eagerly on one stream; the dominant
+        # kernel priced by its own shape label (pred_argmax_kernel: executed MFMA FLOPs = 3 x 2 M N K)
+        roofline = None
+        try:
+            torch.cuda.set_stream(lanes[0])
+            lib.load().nir_profile_enable(1)
+            nrep = 3
+            for i in range(nrep):
+                model.predict_many(groups[i % len(groups)], suggest=True)
+            torch.cuda.synchronize()
+            lib.load().nir_profile_enable(0)
+            buf = ctypes.create_string_buffer(1 << 17)
+            lib.load().nir_profile_report(buf, len(buf))
+            kern = {}
+            for line in buf.value.decode().strip().splitlines():
+                kname, cnt, ms = line.rsplit(",", 2)
+                kern[kname] = (int(cnt), float(ms))
+            if kern:
+                dom = max(kern, key=lambda k_: kern[k_][1])
+                cnt, ms = kern[dom]
+                avg_us = ms / cnt * 1e3
+                roofline = {"kernel": dom, "avg_us": round(avg_us, 3), "launches_per_step": round(cnt / (nrep * mk), 4),
+                            "kernels_us_per_step": {k_: round(v[1] / (nrep * mk) * 1e3, 2) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:14]}}
+                work = kernel_work(dom, c)
+                if work and work["terms"]:
+                    exe_tf = work["flops"] * work["terms"] / (avg_us * 1e-6) / 1e12
+                    roofline.update(bound="mfma", achieved=round(exe_tf, 3), peak=round(work["pipe"], 1), unit="TFLOP/s", frac=round(exe_tf / work["pipe"], 5),
+                                    alg_flops_per_launch=work["flops"], mfma_terms_per_product=work["terms"], traffic=None)
+        except Exception as e:  # pragma: no cover - the record stands without it
+            roofline = {"error": "%s: %s" % (type(e).__name__, e)}
+            lib.load().nir_profile_enable(0)
+        torch.cuda.set_stream(torch.cuda.default_stream())
         lib.set_batches_in_flight(0, lanes)
-        return {"workload": "headline batch through the full predict: ranking + greedy decode of max_query_len tokens; macro-batches of %d batches "
+        return {"roofline": roofline, "workload": "headline batch through the full predict: ranking + greedy decode of max_query_len tokens; macro-batches of %d batches "
                             "(Multitask.predict_many(suggest=True)), one hipGraph each, %d in flight" % (mk, nl), "macro_batch": mk,
                 "ms_per_step": round(dt * 1e3, 4), "pairs_per_s": round(pairs / dt, 1), "suggested_queries_per_s": round(c["batch"] * (c["session"] - 1) / dt, 1),
                 "hipgraph": True, "batches_in_flight": nl, "graph_predictions_equal_eager": same,

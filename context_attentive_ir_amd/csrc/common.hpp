@@ -74,7 +74,7 @@ int batches_in_flight(hipStream_t st);
 // NIR_LSTM_MFMA16, NIR_LSTM_MFMA_S, NIR_LSTM_S, NIR_NO_SKINNY, NIR_NO_GEMM16, NIR_ESM_WAVE_ROWS, NIR_DEBUG, NIR_EXACT_F32);
 // nir_debug_set_tunable changes one at run time (tests, profilers).  Hot entry points only do relaxed atomic loads.
 struct Tunables {
-    std::atomic<int> no_fork, lstm_valu, lstm_mfma16, lstm_mfma_s, lstm_s, lstm_w16, no_skinny, no_gemm16, esm_wave_rows, debug, exact_f32, duet_unfused, attn_unfused, attn_unfused_pipe, duet_rows64, attn_fp32_rows, attn_io_prio, lstm_step_ug, lstm_step_nb, nofold_old, gemm3_ks, wgrad_no_lds, wgrad_lds_tiles, wgrad_min_rows, lstm_bwd_w8;
+    std::atomic<int> no_fork, lstm_valu, lstm_mfma16, lstm_mfma_s, lstm_s, lstm_w16, no_skinny, no_gemm16, esm_wave_rows, debug, exact_f32, duet_unfused, attn_unfused, attn_unfused_pipe, duet_rows64, attn_fp32_rows, attn_io_prio, lstm_step_ug, lstm_step_nb, nofold_old, gemm3_ks, wgrad_no_lds, wgrad_lds_tiles, wgrad_min_rows, lstm_bwd_w8, cl_poll_limit;
 };
 extern Tunables g_tun;
 inline int tun(const std::atomic<int>& a) { return a.load(std::memory_order_relaxed); }

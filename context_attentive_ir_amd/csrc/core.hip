@@ -165,7 +165,7 @@ extern "C" int nir_debug_set_tunable(const char* name, int value) {
         {"no_fork", &g_tun.no_fork}, {"lstm_valu", &g_tun.lstm_valu}, {"lstm_mfma16", &g_tun.lstm_mfma16}, {"lstm_mfma_s", &g_tun.lstm_mfma_s},
         {"lstm_s", &g_tun.lstm_s}, {"lstm_w16", &g_tun.lstm_w16}, {"no_skinny", &g_tun.no_skinny}, {"no_gemm16", &g_tun.no_gemm16}, {"esm_wave_rows", &g_tun.esm_wave_rows},
         {"debug", &g_tun.debug}, {"exact_f32", &g_tun.exact_f32}, {"duet_unfused", &g_tun.duet_unfused}, {"attn_unfused", &g_tun.attn_unfused}, {"attn_unfused_pipe", &g_tun.attn_unfused_pipe}, {"duet_rows64", &g_tun.duet_rows64},
-        {"attn_fp32_rows", &g_tun.attn_fp32_rows}, {"attn_io_prio", &g_tun.attn_io_prio}, {"lstm_step_ug", &g_tun.lstm_step_ug}, {"lstm_step_nb", &g_tun.lstm_step_nb}, {"nofold_old", &g_tun.nofold_old}, {"gemm3_ks", &g_tun.gemm3_ks}, {"wgrad_no_lds", &g_tun.wgrad_no_lds}, {"wgrad_lds_tiles", &g_tun.wgrad_lds_tiles}, {"wgrad_min_rows", &g_tun.wgrad_min_rows}, {"lstm_bwd_w8", &g_tun.lstm_bwd_w8}};     // 1: the fp32-accurate recurrence hands fp32 rows (not its term pairs) to the attention pipeline
+        {"attn_fp32_rows", &g_tun.attn_fp32_rows}, {"attn_io_prio", &g_tun.attn_io_prio}, {"lstm_step_ug", &g_tun.lstm_step_ug}, {"lstm_step_nb", &g_tun.lstm_step_nb}, {"nofold_old", &g_tun.nofold_old}, {"gemm3_ks", &g_tun.gemm3_ks}, {"wgrad_no_lds", &g_tun.wgrad_no_lds}, {"wgrad_lds_tiles", &g_tun.wgrad_lds_tiles}, {"wgrad_min_rows", &g_tun.wgrad_min_rows}, {"lstm_bwd_w8", &g_tun.lstm_bwd_w8}, {"cl_poll_limit", &g_tun.cl_poll_limit}};     // 1: the fp32-accurate recurrence hands fp32 rows (not its term pairs) to the attention pipeline
     for (auto& t : tab)
         if (!strcmp(t.n, name)) { t.a->store(value); return 0; }
     set_error("nir_debug_set_tunable: unknown tunable '%s'", name);

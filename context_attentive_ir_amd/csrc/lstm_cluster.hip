@@ -58,6 +58,7 @@ struct LstmClArgs {
     int* err;
     int64_t M, R;
     int T, ND, tiles, ncld;       // tiles = ceil(M/16), ncld = clusters per direction = ceil(tiles / NG)
+    int poll_limit;               // bounded spin of every wait on a partner (CL_POLL_LIMIT; the debug tunable cl_poll_limit lets a test force the time-out)
 };
 
 // the LSTM cell of lstm_fold.hip (lstm_cell_v): gates (i, f, g, o) of one unit in x; 5 v_exp + 3 v_rcp
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
         if (lane < NC) {
             unsigned long long v = 0;
             while ((v = __hip_atomic_load(hs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
-                if (++tries > CL_POLL_LIMIT) { same = -1; break; }
+                if (++tries > p.poll_limit) { same = -1; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             if (same > 0) same = (uint32_t)v == my_xcc + 1u ? 1 : 0;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(512, 1) void lstm_cluster_kernel(LstmClArgs p) {
 #ifdef NIR_CL_NOPOLL       // ablation (tools/cluster_micro.py): no waiting for the partners -- wrong results, the cost of everything else
                     break;
 #endif
-                    if (tries++ > CL_POLL_LIMIT) { timed_out = true; break; }
+                    if (tries++ > p.poll_limit) { timed_out = true; break; }
                     if (tries > 1) __builtin_amdgcn_s_sleep(1);
                     ok = true;
 #pragma unroll
@@ -574,6 +575,7 @@ static int launch_lstm256_cluster_ex(const float* rows, const int64_t* ids, cons
     const int ncl = a.ncld * ND;
     const size_t xwords = (size_t)ncl * NG * 2 * CL_NC * CL_GRAN;
     a.hs = a.xbuf + xwords;
+    a.poll_limit = tun(g_tun.cl_poll_limit) != 0 ? tun(g_tun.cl_poll_limit) : CL_POLL_LIMIT;     // (debug: -1 = the first unsuccessful poll gives up)
     const size_t used = (xwords + (size_t)ncl * CL_NC) * sizeof(unsigned long long);
     if (hipMemsetAsync(xbuf, 0, used, st) != hipSuccess) { set_error("lstm256: memset of the exchange buffer failed"); return NIR_ERR_BAD_ARG; }
     const size_t lds = (size_t)NG * 4 * CL_SEQ * CL_ZLD * 2 + (size_t)(NG * CL_SEQ + 16 + NG * CL_SEQ * (T + 3)) * 4;

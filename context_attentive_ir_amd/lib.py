@@ -411,6 +411,13 @@ class Flags(object):
         self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.host_np = self.host.numpy()
         self.mapped = True
+        self.cluster_handlers = []                          # weak references to callables run when bit 2 (cluster time-out) is found
+
+    def on_cluster_timeout(self, method):
+        """register a bound method (kept weakly) that makes its owner safe after a recurrence cluster timed out (MNSRF: switch to the streaming
+        recurrence) -- run BEFORE the RuntimeError of the failed call is raised, so the caller's retry already takes the safe path"""
+        import weakref
+        self.cluster_handlers.append(weakref.WeakMethod(method))
 
     def publish(self):
         """capturable; -> False when the host word cannot be written by the device (then only check() sees errors)"""
@@ -422,8 +429,15 @@ class Flags(object):
 
     def _raise(self, v):
         if v & 4:
-            raise RuntimeError("a recurrence cluster (csrc/lstm_cluster.hip) waited ~1 s for a partner workgroup that never became resident; "
-                               "results of that call are invalid")
+            live = []
+            for ref in self.cluster_handlers:
+                fn = ref()
+                if fn is not None:
+                    fn()
+                    live.append(ref)
+            self.cluster_handlers = live
+            raise RuntimeError("a recurrence cluster (csrc/lstm_cluster.hip) waited for a partner workgroup that never became resident; the results of "
+                               "that call are invalid -- the models on this device have been switched to the streaming recurrence: re-issue the batch")
         if v & 2:
             raise RuntimeError("recurrent weights outside the fp16 range of the split-fp16 MFMA recurrence (|w_hh| >= 2^15); "
                                "results of that call are invalid -- the exact fp32 recurrence handles such weights")

@@ -50,6 +50,19 @@ class MNSRF(nn.Module, lib.IdCheck):
         # both tables stay under `fold_budget_bytes` (100 000 words: 1.6 GB)
         self.fold_embeddings = getattr(args, "fold_embeddings", True)
         self.fold_budget_bytes = 64 << 30
+        # the four-CU cluster recurrence (csrc/lstm_cluster.hip) needs its four members co-resident; a cluster that cannot make progress raises bit 2
+        # of the device's error word and leaves (bounded poll).  Fail safe: the first such event switches this model to the streaming recurrence
+        # (nir_birnn_steps_fwd behind nir_mnsrf_*) for good -- lib.Flags runs _cluster_failed before it raises the failed call's RuntimeError.
+        self.resident_recurrence = True
+        self.uses_cluster = True                            # the wrappers publish / poll the error word even with id_check_interval = 0
+        self._cluster_registered = None
+
+    def _cluster_failed(self):
+        if self.resident_recurrence:
+            import logging
+            logging.getLogger(__name__).warning("MNSRF: a recurrence cluster timed out; switching to the streaming recurrence (slower, placement independent)")
+        self.resident_recurrence = False
+        A.CLUSTER_TRAIN_FWD = False
 
     def _use_fold(self, table):
         per = table.shape[0] * 8 * 256 * 4
@@ -60,7 +73,11 @@ class MNSRF(nn.Module, lib.IdCheck):
         table = self.embedder.word_embeddings.table
         fold = self._use_fold(table)
         # the resident-weight recurrence itself needs only the reference's sizes and an embedding width the per-batch form is sized for
-        resident = not self.training and self._dims["Hq"] == 256 and self._dims["Hd"] == 256 and (fold or table.shape[1] <= 300)
+        resident = (self.resident_recurrence and not self.training and self._dims["Hq"] == 256 and self._dims["Hd"] == 256
+                    and (fold or table.shape[1] <= 300))
+        if table.is_cuda and self._cluster_registered != table.device:
+            lib.flags(table.device).on_cluster_timeout(self._cluster_failed)
+            self._cluster_registered = table.device
 
         def build():
             q = lstm_cat_weights(self.query_encoder.encoder.rnns[0])

@@ -49,8 +49,13 @@ class WrapperBase(object):
 
     def _poll_ids(self):
         """entry of predict() / update(): the pinned host word of the previous calls (no device round trip)"""
-        if self.id_check_interval > 0 and self.id_check == "deferred" and self._board is not None:
-            self._board.poll()
+        b = self._board
+        if b is None:
+            return
+        if self.id_check_interval > 0 and self.id_check == "deferred":
+            b.poll()
+        elif b.host_np[0] & 4:                              # a cluster time-out is never left to the caller (id_check_interval = 0 included)
+            b.poll()
 
     def _softmax_rows(self, s, out=None):
         """softmax over the last axis of the raw scores `s` (contiguous) -> probabilities; with the deferred id check the same launch
@@ -60,7 +65,7 @@ class WrapperBase(object):
             out = torch.empty_like(s)
         rows, n = s.numel() // s.shape[-1], s.shape[-1]
         L = lib.load()
-        if rows > 0 and self.use_cuda and self.id_check_interval > 0 and self.id_check == "deferred":
+        if rows > 0 and self.use_cuda and self.id_check == "deferred" and (self.id_check_interval > 0 or getattr(self.network, "uses_cluster", False)):
             f = self._flags()
             if f.mapped:
                 rc = L.nir_softmax_rows_publish(lib.ptr(s), lib.ptr(out), rows, n, lib.ptr(f.dev), lib.C.c_void_p(f.host.data_ptr()), lib.stream())
@@ -71,7 +76,11 @@ class WrapperBase(object):
         return out, False
 
     def _maybe_check_ids(self, published=False):
-        if self.id_check_interval <= 0 or not self.use_cuda:
+        if not self.use_cuda:
+            return
+        if self.id_check_interval <= 0:
+            if getattr(self.network, "uses_cluster", False) and self.id_check == "deferred" and not published:
+                self._flags().publish()                     # (the cluster recurrence's time-out bit is published whatever the id check does)
             return
         if self.id_check == "deferred":
             if published or self._flags().publish():        # capturable: part of a captured predict

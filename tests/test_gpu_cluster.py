@@ -115,3 +115,39 @@ def test_lstm256_cluster_concurrent_launches_on_four_streams():
     assert int(err.item()) == 0
     for k in range(4):
         assert torch.equal(outs[k].cpu(), alone[k])
+
+
+def test_cluster_timeout_fails_safe_to_the_streaming_recurrence():
+    """a cluster that cannot make progress (forced here: the debug tunable cl_poll_limit = -1 makes the first unsuccessful poll
+    give up) raises bit 2 of the device's error word.  The wrappers publish / poll that word even with id_check_interval = 0: the failed call's
+    results raise RuntimeError at the caller's synchronisation, the model switches to the streaming recurrence (nir_birnn_steps_fwd behind
+    nir_mnsrf_*) BEFORE the error is raised, and the re-issued batch equals the oracle."""
+    from context_attentive_ir_amd import lib, synth
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import Multitask
+    from oracle import neuroir_cpu as O
+    V = 300
+    w = Multitask(default_args("MNSRF", src_vocab_size=V, tgt_vocab_size=40))
+    fill_module_(w.network, 29)
+    sd = {k: v.detach().cpu().float() for k, v in w.network.state_dict().items()}
+    w.cuda()
+    w.id_check_interval = 0                                     # the caller opted out of the id check: the cluster bit is still not silent
+    ex = synth.session_batch(6, 5, 8, 5, 21, V, seed=3)
+    ref = torch.softmax(O.mnsrf_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)
+    good = w.predict(ex, suggest=False)["click_scores"].cpu()
+    assert float((good - ref.view_as(good)).abs().max()) < 1e-4 and w.network.resident_recurrence
+    assert w.network._weights().struct.d_whh_frag
+    with lib.tunable("cl_poll_limit", -1, 0):
+        out = w.predict(ex, suggest=False)                      # enqueued, nothing raised yet
+        torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="streaming recurrence"):
+        w.predict(ex, suggest=False)                            # entry of the next call: the pinned word holds bit 2
+    del out
+    assert not w.network.resident_recurrence and not w.network._weights().struct.d_whh_frag
+    for _ in range(3):                                          # eager, capture, replay -- all on the streaming recurrence
+        again = w.predict(ex, suggest=False)["click_scores"].cpu()
+        assert float((again - ref.view_as(again)).abs().max()) < 1e-4
+    w.check_ids()
+    from context_attentive_ir_amd import autograd as A
+    A.CLUSTER_TRAIN_FWD = True                                  # (module-level switch: restore for the tests that follow)
