@@ -406,8 +406,12 @@ class _SuggestLossRows(Function):
         gn = _f32c(gnll) if gnll is not None else torch.zeros(R, device=z.device)
         ge = _f32c(gent) if gent is not None else None
         dz = torch.empty_like(z)
-        lib.check(lib.load().nir_softmax_nll_ent_bwd(lib.ptr(z), V, lib.ptr(t), ctx.pad, lib.ptr(lse), lib.ptr(ent), lib.ptr(gn), lib.ptr(ge), R, V, lib.ptr(dz),
-                                                     lib.stream()), "nir_softmax_nll_ent_bwd")
+        CH = 65535                      # rows per launch (grid.y of the kernel): larger batches run in row chunks instead of failing mid-backward
+        for r0 in range(0, R, CH):
+            r1 = min(R, r0 + CH)
+            lib.check(lib.load().nir_softmax_nll_ent_bwd(lib.ptr(z[r0:r1]), V, lib.ptr(t[r0:r1]), ctx.pad, lib.ptr(lse[r0:r1]), lib.ptr(ent[r0:r1]), lib.ptr(gn[r0:r1]),
+                                                         lib.ptr(ge[r0:r1]) if ge is not None else None, r1 - r0, V, lib.ptr(dz[r0:r1]), lib.stream()),
+                      "nir_softmax_nll_ent_bwd")
         return dz, None, None
 
 
@@ -464,8 +468,17 @@ def softmax_pool(logits, mask, values, mask_div=1):
     if R == 0 or values.shape[0] == 0:                       # empty batch: nothing to launch (differentiable zeros of the right shape)
         return z.sum(1, keepdim=True) * values.sum((0, 1)).unsqueeze(0)
     G = R // values.shape[0]
-    if G * T * 8 > 64 * 1024 or T > 8192 or R % max(1, values.shape[0]):
-        raise NotImplementedError("softmax_pool: G T <= 8192 (got G = %d, T = %d)" % (G, T))
+    if R % max(1, values.shape[0]):
+        raise RuntimeError("softmax_pool: %d logit rows are not a multiple of the %d value blocks" % (R, values.shape[0]))
+    if G * T * 8 > 64 * 1024 or T > 8192:
+        # outside the kernel's LDS budget (G T <= 8192: target_len x query_len of the CARS decoder attention, S x S of the causal session
+        # attention): the same expression as tensor glue, differentiable through torch -- any shape the reference accepts still runs
+        zz = z
+        if mask is not None:
+            rows = (torch.arange(R, device=z.device) // int(mask_div)) % mask.shape[0]
+            zz = z.masked_fill(~mask.bool()[rows], float("-inf"))
+        w = torch.softmax(zz, -1)
+        return torch.bmm(w.view(values.shape[0], G, T), values.float()).reshape(R, values.shape[2])
     return _SoftmaxPool.apply(z, mask, mask_div, values, G)
 
 
@@ -561,17 +574,20 @@ def dropout(x, p, training):
 
 
 _ROW_IDS = {}
+_ROW_IDS_RETIRED = []
 
 
 def _row_ids(n, dev):
-    """0 .. n-1 (int64) on the device: the "token ids" of a per-batch gate tensor read by the folded-table recurrence (built once per size)"""
-    key = (int(n), str(dev))
+    """0 .. n-1 (int64) on the device: the "token ids" of a per-batch gate tensor read by the folded-table recurrence.  ONE buffer per device
+    that only grows (a prefix of a longer 0 .. N-1 is the same list); a superseded buffer is retired, never freed -- a hipGraph captured by
+    GraphedUpdate holds its address (the old per-size cache dropped its entries above 16 sizes and replays then read recycled memory)."""
+    key = str(dev)
     t = _ROW_IDS.get(key)
-    if t is None:
-        if len(_ROW_IDS) > 16:
-            _ROW_IDS.clear()
-        t = _ROW_IDS[key] = torch.arange(n, device=dev, dtype=torch.int64)
-    return t
+    if t is None or t.numel() < n:
+        if t is not None:
+            _ROW_IDS_RETIRED.append(t)
+        t = _ROW_IDS[key] = torch.arange(max(int(n), 2 * (t.numel() if t is not None else 0), 1 << 16), device=dev, dtype=torch.int64)
+    return t[:n]
 
 
 class _BiLSTM(Function):
@@ -693,7 +709,6 @@ class _BiLSTM(Function):
         return (dx, None, None, dh0, dc0) + tuple(grads)
 
 
-_WS256 = {}
 
 _SIDE = {}
 
@@ -731,12 +746,9 @@ class _BiLSTM256(Function):
         frag = torch.empty(L.nir_lstm256_whh_frag_bytes(nd), dtype=torch.uint8, device=dev)
         flag = id_flag(dev)
         lib.check(L.nir_lstm256_pack_whh_frag(lib.ptr(whh), nd, lib.ptr(frag), lib.ptr(flag), lib.stream()), "nir_lstm256_pack_whh_frag")
-        key = (int(M), int(nd), str(dev))
-        ws = _WS256.get(key)
-        if ws is None:
-            if len(_WS256) > 8:
-                _WS256.clear()
-            ws = _WS256[key] = torch.empty(L.nir_lstm256_workspace_bytes(M, nd), dtype=torch.uint8, device=dev)
+        # exchange scratch of the cluster recurrence: the library pool (per device and stream -- or owned by the capturing GraphedUpdate /
+        # predictor --, grow-only, superseded buffers retired, never freed: a captured hipGraph holds the address)
+        ws = lib.workspace(L.nir_lstm256_workspace_bytes(M, nd), dev)
         lens64 = lib.ids64(lens)
         out = torch.empty(M, T, nd * H, device=dev)
         act = torch.empty(M, T, nd, 4 * H, device=dev)

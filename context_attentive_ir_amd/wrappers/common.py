@@ -204,12 +204,25 @@ class WrapperBase(object):
             ds = state_dict.pop("_nir_dropout_state", None) if isinstance(state_dict, dict) else None
             if ds is not None:                      # resume: continue the mask stream where the checkpoint left it
                 A.DROPOUT.seed, A.DROPOUT.counter = int(ds[0]), int(ds[1])
+            # torch's Optimizer.load_state_dict takes the SAVED groups' hyper-parameters and keeps only `params` of the live ones: a checkpoint
+            # (written without the run-time flavour flags, like the reference's, models/ranker.py:283-292) would turn the freshly built capturable /
+            # fused optimizer into a plain one -- GraphedUpdate could not capture it and eager steps would fall back to one host sync per
+            # parameter.  The run-time flags of the fresh groups are re-applied after the load.
+            runtime = [{k: g[k] for k in ("capturable", "fused", "foreach", "differentiable", "maximize") if k in g} for g in self.optimizer.param_groups]
             self.optimizer.load_state_dict(state_dict)
+            for g, flags in zip(self.optimizer.param_groups, runtime):
+                g.update(flags)
+                if torch.is_tensor(g.get("lr")):
+                    g["lr"] = float(g["lr"])
             if use_gpu:
+                dev = parameters[0].device if parameters else None
                 for state in self.optimizer.state.values():
                     for k, v in state.items():
                         if isinstance(v, torch.Tensor):
-                            state[k] = v.cuda()
+                            # a capturable optimizer keeps its step counter as a float32 tensor on the parameters' device
+                            state[k] = v.to(device=dev, dtype=torch.float32) if (k == "step" and cap) else v.to(dev)
+                        elif k == "step" and cap:
+                            state[k] = torch.tensor(float(v), dtype=torch.float32, device=dev)
 
     def sync_gradients(self):
         """Multi-rank training step (replaces what nn.DataParallel's backward did for the reference, models/ranker.py:341-346,

@@ -697,6 +697,50 @@ def test_graphed_update_reproduces_eager_trajectory_without_dropout(kind):
         assert float((pe[k] - pg[k]).abs().max()) <= 1e-4 * max(1.0, float(pe[k].abs().max())), k
 
 
+def test_checkpoint_resume_keeps_the_capturable_fused_optimizer_and_the_trajectory(tmp_path):
+    """checkpoint() writes reference-compatible optimizer groups (float rate, no flavour flags); load_checkpoint() -> init_optimizer()
+    must come back with the run-time flavour (capturable + fused Adam, float32 device step counters): GraphedUpdate then captures the resumed
+    step, and 3 steps + checkpoint + resume + 3 graphed steps end where 6 uninterrupted steps end."""
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import GraphedUpdate, Ranker
+    g = load_golden("match_tensor_train")
+    extra = dict(dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.001, weight_decay=0, momentum=0, grad_clipping=10.0,
+                 fix_embeddings=True)
+    batches = [{k: T(g["b%d_%s" % (i, k)], DEV) for k in ("que_rep", "que_len", "doc_rep", "doc_len", "label")} for i in range(2)]
+
+    def fresh():
+        w = Ranker(default_args("MATCH_TENSOR", src_vocab_size=int(g["meta_vocab"]), **extra))
+        fill_module_(w.network, 1013)
+        w.cuda()
+        w.init_optimizer()
+        return w
+    ref = fresh()
+    for i in range(6):
+        ref.update(batches[i % 2])
+    w = fresh()
+    for i in range(3):
+        w.update(batches[i % 2])
+    path = str(tmp_path / "ckpt.mdl")
+    w.checkpoint(path, 1)
+    saved = torch.load(path, map_location="cpu", weights_only=False)["optimizer"]["param_groups"][0]
+    assert isinstance(saved["lr"], float) and not saved.get("capturable") and not saved.get("fused")        # the file stays reference-compatible
+    r, epoch = Ranker.load_checkpoint(path, use_gpu=True)
+    assert epoch == 1
+    grp = r.optimizer.param_groups[0]
+    assert grp["capturable"] is True and grp["fused"] is True
+    st = next(iter(r.optimizer.state.values()))
+    assert st["step"].is_cuda and st["step"].dtype == torch.float32 and float(st["step"]) == 3.0
+    step = GraphedUpdate(r)
+    for i in range(3, 6):
+        step(batches[i % 2])
+    assert len(step.graphs) >= 1                                   # the resumed step WAS captured (a non-capturable Adam fails inside the capture)
+    torch.cuda.synchronize()
+    pe, pg = ref.network.state_dict(), r.network.state_dict()
+    for k in pe:
+        assert float((pe[k] - pg[k]).abs().max()) <= 1e-4 * max(1.0, float(pe[k].abs().max())), k
+
+
 def test_graphed_update_draws_fresh_dropout_masks():
     """Default dropouts: replays of the captured step must not repeat one mask set (the seed lives on the device and advances per replay)."""
     from context_attentive_ir_amd.config import default_args
@@ -812,3 +856,34 @@ def test_im2col_rows_matches_unfold(M, C, H, W, kh, kw):
     from context_attentive_ir_amd import lib
     lib.check(lib.load().nir_col2im_rows_f32(lib.ptr(dy), M, C, H, W, kh, kw, kh // 2, kw // 2, lib.ptr(again), lib.stream()), "nir_col2im_rows_f32")
     assert torch.equal(again, x.grad)          # deterministic: no atomics
+
+
+def test_softmax_pool_and_suggestion_loss_beyond_the_kernel_limits():
+    """shapes past the operators' launch limits still run (the torch expressions they replaced accepted any shape): softmax_pool with
+    G T > 8192 takes the tensor-glue form, the suggestion loss's backward runs in row chunks above 65 535 rows -- values and gradients against
+    plain torch."""
+    from context_attentive_ir_amd import autograd as A
+    g = torch.Generator().manual_seed(5)
+    R, Tn, D = 6, 9000, 8
+    z = torch.randn(R, Tn, generator=g).to(DEV).requires_grad_()
+    v = torch.randn(3, Tn, D, generator=g).to(DEV).requires_grad_()
+    mask = (torch.rand(3, Tn, generator=g) > 0.3).to(DEV)
+    out = A.softmax_pool(z, mask, v, mask_div=2)
+    z2, v2 = z.detach().clone().requires_grad_(), v.detach().clone().requires_grad_()
+    rows = (torch.arange(R, device=DEV) // 2) % 3
+    ref = torch.bmm(torch.softmax(z2.masked_fill(~mask[rows], float("-inf")), -1).view(3, 2, Tn), v2).reshape(R, D)
+    assert float((out - ref).abs().max()) < 1e-5
+    out.square().sum().backward(); ref.square().sum().backward()
+    assert float((z.grad - z2.grad).abs().max()) < 1e-5 and float((v.grad - v2.grad).abs().max()) < 1e-4
+    Bd, TL, V = 7000, 10, 6                                       # 70 000 rows
+    lg = torch.randn(Bd, TL, V, generator=g).to(DEV).requires_grad_()
+    tg = torch.randint(0, V, (Bd, TL), generator=g).to(DEV)
+    loss = A.suggestion_loss(lg, tg, 0, 0.1)
+    lg2 = lg.detach().clone().requires_grad_()
+    lp = torch.log_softmax(lg2, -1)
+    nll = -(lp.gather(2, tg.unsqueeze(2)).squeeze(2)) * (tg != 0)
+    ref = nll.sum(1).mean() + ((lp.exp() * lp).sum(2).sum(1) * 0.1).mean()
+    assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    loss.backward(); ref.backward()
+    assert float((lg.grad - lg2.grad).abs().max()) < 1e-6
+    A.check_ids()
