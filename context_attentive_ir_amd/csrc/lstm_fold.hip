@@ -903,9 +903,20 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void lstm16_pt_h2_kernel(
         if (full && (NT == 4 || NT == 2)) {
             _Float16 a[NT], r[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                a[t] = (_Float16)hn[t];
-                r[t] = (_Float16)((hn[t] - (float)a[t]) * SC);
+            for (int t = 0; t < NT; ++t) a[t] = (_Float16)hn[t];
+            // residual = fp16(2^11 (h - a)) from ONE FMA per value: 2^11 a is exact in fp16 (|a| <= 1: a packed fp16 multiply per pair) and
+            // h 2^11 - (2^11 a) is the same exact real number as (h - a) 2^11, rounded once -- bit-identical to convert / subtract / scale /
+            // convert, 12 VALU per four values instead of 16 (8 with hand-written v_fma_mix{lo,hi}_f16).  Measured (tools/recur_micro.py,
+            // M = 8 960, three builds in one run): 16 / 12 / 8 VALU = 658-666 / 657-665 / 665 us -- the step is not bound by VALU issue.
+            {
+                _Float16 as_[NT];
+#pragma unroll
+                for (int t = 0; t < NT; t += 2) {
+                    const f16x2 p2 = (f16x2){a[t], a[(t + 1) % NT]} * (f16x2){(_Float16)2048.0f, (_Float16)2048.0f};
+                    as_[t] = p2[0]; as_[(t + 1) % NT] = p2[1];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) r[t] = (_Float16)__builtin_fmaf(hn[t], SC, -(float)as_[t]);
             }
             if (NT == 4) {
                 const f16x4 av = (f16x4){a[0], a[1 % NT], a[2 % NT], a[3 % NT]}, rv = (f16x4){r[0], r[1 % NT], r[2 % NT], r[3 % NT]};
