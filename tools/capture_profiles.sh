@@ -15,14 +15,18 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH_DETAIL=$OUT/bench_detail.json python $REPO/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 export BENCH_NO_H2D=1
-CFGS=${@:-C3_cars C1_esm C2_match_tensor NS_match_tensor_50 C4_duet C4_drmm C4_esm_hbm C5_cars_bf16 X3_mnsrf C3_cars_split2}
+CFGS=${@:-C3_cars C1_esm C2_match_tensor NS_match_tensor_50 NS_cars_50 C4_duet C4_drmm C4_esm_hbm C5_cars_bf16 X3_mnsrf X3_m_match_tensor C3_cars_split2}
 for c in $CFGS; do
-  steps=20; case $c in C4_duet|C5_cars_bf16) steps=6;; esac
+  steps=20; case $c in C4_duet|C5_cars_bf16|NS_cars_50) steps=6;; esac
   RUN="python $REPO/bench.py --config $c --sub none --streams 1 --in-flight-hint 4 --no-graph --steps $steps --warmup 3 --no-cpu-baseline"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$c/stats -o s -- $RUN > $OUT/$c.stats.log 2>&1
   rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/$c/fetch -o p -- $RUN > /dev/null 2>&1
   rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/$c/write -o p -- $RUN > /dev/null 2>&1
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/$c/sq -o p -- $RUN > /dev/null 2>&1
+  # round 6: the issue / stall counters behind DESIGN 10's stall table (own pass: kernel-trace only)
+  case $c in C3_cars|C5_cars_bf16|X3_mnsrf)
+    rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE -d $OUT/$c/stall -o p -- $RUN > /dev/null 2>&1;;
+  esac
   echo "captured $c"
 done
 # keep the merged-back payload small: the per-dispatch traces are condensed on the box

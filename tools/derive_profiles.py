@@ -46,7 +46,7 @@ def condense(root):
         if st:
             shutil.copy(st[0], os.path.join(cdir, "kernel_stats.csv"))
         pmc = {}
-        for p in ("fetch", "write", "sq"):
+        for p in ("fetch", "write", "sq", "stall"):
             for k, d in counters(os.path.join(cdir, p)).items():
                 pmc.setdefault(k, {}).update({c: round(v, 1) for c, v in d.items()})
         if pmc:
