@@ -808,6 +808,23 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
     }
     const int64_t BS = (int64_t)B * S, R = BS * N;
     float* clicks = clicks_out ? clicks_out : p.clicks;
+    const int NU = nch * HS + nch;
+    float* gq = p.gx;
+    float* gd = p.gx + (q_on ? BS * 4 * (int64_t)HS : 0);
+    const int bnd = (w->rank_bounded & 8) ? ACT_BOUNDED : 0;
+    // One batch in flight (no hint on this stream): the two GEMMs that read the pooled QUERIES only -- the attention projection U and the
+    // query chain's hoisted input projection -- run on the side stream next to the click MLP, the click pooling and the document chain's
+    // projection (round 6: two dependent launches, ~10 us of 120 at a C3 batch, off the tail's critical path); several batches in flight:
+    // ForkJoin is a no-op and everything runs in order on `st`.
+    ForkJoin fj(st);
+    fj.fork();
+    {
+        hipStream_t sq_ = fj.side;
+        // ---- U = pooled_q [W_sq^T | W_sd^T | b_sq | b_sd]  (independent of the chains)
+        if (nch && rank_on)
+            NIR_PROPAGATE(launch_linear(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->attn_ut, D, nullptr, nullptr, p.U, NU, BS, NU, D, NIR_ACT_NONE, sq_));
+        if (nch && q_on) NIR_PROPAGATE(launch_linear_ex(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->sq_wih, D, w->sq_bih, w->sq_bhh, gq, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, sq_));
+    }
     // ---- encode_clicks (cars.py:262-304)
     if (d_on) {
         NIR_PROPAGATE(launch_linear_ex(pooled_docs, D, nullptr, nullptr, 0, 0, 0, w->click0_w, D, w->click0_b, nullptr, p.epart, NP, R, D, D,
@@ -825,10 +842,6 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
         }
         NIR_CHECK_LAUNCH("click_pool2_kernel");
     }
-    // ---- U = pooled_q [W_sq^T | W_sd^T | b_sq | b_sd]  (independent of the chains)
-    const int NU = nch * HS + nch;
-    if (nch && rank_on)
-        NIR_PROPAGATE(launch_linear(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->attn_ut, D, nullptr, nullptr, p.U, NU, BS, NU, D, NIR_ACT_NONE, st));
     // ---- session LSTM chains: state t+1 = LSTM(x_t, state t); the ranking path needs states 1..S-1, the decoder S as well
     const int nsteps = want_states ? S : S - 1;
     if (nch) {
@@ -843,12 +856,10 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
         // x W_ih^T + b_ih + b_hh is ONE GEMM per chain over all B*S rows (split-precision matrix-core kernels, M = B*S rows at once) instead of a
         // K = 256 slice of every sequential step on the fp32 MFMA; the steps then walk W_hh (K = HS) only.
         {
-            float* gq = p.gx;
-            float* gd = p.gx + (q_on ? BS * 4 * (int64_t)HS : 0);
             // (inputs are pooled encoder states / softmax-weighted sums of them, inside (-1, 1); bit 3 of rank_bounded: |W_ih| < 2^15 host-checked -> fp16 two-term split)
-            const int bnd = (w->rank_bounded & 8) ? ACT_BOUNDED : 0;
-            if (q_on) NIR_PROPAGATE(launch_linear_ex(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->sq_wih, D, w->sq_bih, w->sq_bhh, gq, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, st));
+            // (the query chain's projection was issued with U above, on the side stream)
             if (d_on) NIR_PROPAGATE(launch_linear_ex(clicks, D, nullptr, nullptr, 0, 0, 0, w->sd_wih, D, w->sd_bih, w->sd_bhh, gd, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, st));
+            fj.join();
             a.gx[0] = gq; a.gx[1] = gd;
             a.gxstride = (int64_t)S * 4 * HS;
             a.whh_frag[0] = w->sq_whh_frag; a.whh_frag[1] = w->sd_whh_frag;

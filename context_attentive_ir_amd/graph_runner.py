@@ -194,7 +194,7 @@ class PredictGraphCache(object):
     is ~45 launches for 0.3 ms of kernels).  The first `min_calls - 1` calls of a key run eagerly; the next one captures the eager body
     over static input buffers (scratch owned by the entry: lib.workspace_owner) and every later call is
         [small host fields -> one pinned staging block -> ONE H2D | large pinned fields: direct H2D | device fields: D2D] -> replay -> clone
-    on the CALLER's current stream (round 6b: the bracketed step is the graph's FIRST KERNEL -- nir_gather_fields reads a per-call table of
+    on the CALLER's current stream, OPTIMISTICALLY (see call()) (round 6b: the bracketed step is the graph's FIRST KERNEL -- nir_gather_fields reads a per-call table of
     source addresses from pinned memory and copies pinned host tensors over PCIe itself, staged fields and device tensors alike: a replay
     issues no hipMemcpyAsync at all).  Key = field shapes / dtypes + the call's flavour + a weights token (sum of parameter versions, first
     data pointer, the network's path switches): training, load_state_dict or a switch change re-captures; `clear()` on .cuda() / .cpu().
@@ -228,36 +228,55 @@ class PredictGraphCache(object):
         sw = tuple(x for x in self.w.network.__dict__.values() if x is None or isinstance(x, (bool, int, float, str)))
         return (v, ps[0].data_ptr() if ps else 0, lib.GRAPH_EPOCH[0], sw)
 
-    def key(self, ex, fields, flavour):
-        return (tuple((tuple(ex[k].shape), ex[k].dtype) for k in fields), flavour, self.token())
+    EAGER = object()          # call(): "run this call eagerly"
 
-    def get(self, ex, fields, flavour, body):
-        """-> entry to replay, or None (run eagerly this time).  body(static_ex) = the eager predict over a dict of device tensors."""
-        key = self.key(ex, fields, flavour)
-        ent = self.entries.get(key)
+    def call(self, ex, fields, flavour, body, finish=None):
+        """One predict() through the cache -> its outputs, or PredictGraphCache.EAGER when the caller must run the eager body itself (first
+        sightings of a shape, an un-capturable call).  body(static_ex) = the eager predict over a dict of device tensors; finish(static_out)
+        (optional) turns the graph's static outputs into the fresh tensors handed to the caller.
+
+        OPTIMISTIC replay: an entry is found by the SHAPES of the batch alone and replayed at once; the weights token (a walk over the
+        parameters' versions, ~15 us of host time in front of the device's chain) is computed while the device already runs the graph.  A
+        mismatch -- the weights changed since the capture: rare, once per training epoch -- discards that replay's outputs (the stale graph read
+        retired but still allocated packs) and re-captures over the current weights before anything is returned."""
+        skey = (tuple((tuple(ex[k].shape), ex[k].dtype) for k in fields), flavour)
+        ent = self.entries.get(skey)
+        if ent is False:
+            return self.EAGER
         if ent is not None:
-            self.entries.move_to_end(key)
-            return ent if ent is not False else None
-        n = self.seen.get(key, 0) + 1
+            # memory safety of the optimistic order: a superseded pack is freed only when some PackCache rebuilds (lib.PACK_EPOCH); while the
+            # epoch is the capture's, everything the graph references is alive and the replay may go first.  Otherwise: verify, then replay.
+            fresh = ent.epoch == lib.PACK_EPOCH[0]
+            if fresh:
+                self._replay(ent, ex)
+            if self.token() == ent.token:
+                if not fresh:
+                    ent.epoch = lib.PACK_EPOCH[0]                     # (another model repacked; this graph's packs are the current ones)
+                    self._replay(ent, ex)
+                self.entries.move_to_end(skey)
+                return self._outputs(ent, finish)
+            del self.entries[skey]                                    # stale: fall through to a fresh capture of this (recurring) shape
+            self.seen[skey] = self.min_calls
+        n = self.seen.get(skey, 0) + 1
         if n < self.min_calls:
             if len(self.seen) > 4096:
                 self.seen.clear()
-            self.seen[key] = n
-            return None
-        self.seen.pop(key, None)
-        stale = [k for k in self.entries if k[2] != key[2]]          # graphs over superseded weights can never be replayed again
-        for k in stale:
-            del self.entries[k]
+            self.seen[skey] = n
+            return self.EAGER
+        self.seen.pop(skey, None)
         while len(self.entries) >= self.max_entries:
             self.entries.popitem(last=False)
         try:
             ent = self._capture(ex, fields, body)
+            ent.token, ent.epoch = self.token(), lib.PACK_EPOCH[0]
         except RuntimeError as e:                                     # an un-capturable call stays eager (recorded, not retried)
             import logging
             logging.getLogger(__name__).warning("predict graph capture failed, staying eager for this shape: %s", e)
-            ent = False
-        self.entries[key] = ent
-        return ent if ent is not False else None
+            self.entries[skey] = False
+            return self.EAGER
+        self.entries[skey] = ent
+        self._replay(ent, ex)
+        return self._outputs(ent, finish)
 
     def _capture(self, ex, fields, body):
         dev = next(self.w.network.parameters()).device
@@ -331,16 +350,18 @@ class PredictGraphCache(object):
             tab[3 * i], tab[3 * i + 1], tab[3 * i + 2] = addr, o, n
         ent.hold = hold
 
-    def run(self, ent, ex, finish=None):
-        """source table of this call -> replay (gather kernel + the captured predict) -> fresh copies of the outputs (same structure as the
-        eager body's); finish(static_out) (optional) makes the fresh outputs itself -- e.g. the final softmax run eagerly from the static raw
-        scores into a new tensor: one launch instead of an in-graph softmax plus a copy."""
+    def _replay(self, ent, ex):
+        """source table of this call -> replay (gather kernel + the captured predict) on the caller's current stream"""
         self._fill(ent, ex)
         ent.graph.replay()
         if ent.replayed is None:
             ent.replayed = torch.cuda.Event()
         ent.replayed.record()
         self.replays += 1
+
+    def _outputs(self, ent, finish):
+        """fresh copies of the graph's static outputs (same structure as the eager body's); finish(static_out) (optional) makes them itself --
+        e.g. the final softmax run eagerly from the static raw scores into a new tensor: one launch instead of an in-graph softmax plus a copy"""
         out = ent.out
         if finish is not None:
             return finish(out)

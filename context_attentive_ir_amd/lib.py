@@ -288,6 +288,11 @@ class Packed(object):
         return C.byref(self.struct)
 
 
+# bumped whenever any PackCache rebuilds (= the only moment a superseded pack can be FREED): a hipGraph captured at epoch e references live packs
+# for as long as the epoch is still e, whatever happened to the parameters meanwhile (graph_runner.PredictGraphCache's optimistic replay)
+PACK_EPOCH = [0]
+
+
 class PackCache(object):
     """Re-pack weights only when a parameter was modified (tensor._version) or moved.
 
@@ -314,6 +319,7 @@ class PackCache(object):
             if self.val is not None:
                 self.retired = (self.retired + [self.val])[-self.RETAIN:] if self.RETAIN > 0 else []
             self.val, self.key = builder(), key
+            PACK_EPOCH[0] += 1
         return self.val
 
 

@@ -99,24 +99,25 @@ class WrapperBase(object):
             return checked(t, self._board)
         return t
 
-    def _graph_entry(self, ex, fields, flavour, body):
-        """-> (cache, entry) when this predict() replays a captured hipGraph, else (None, None): eager."""
+    def _graphed(self, ex, fields, flavour, body, finish=None):
+        """this predict() through the hipGraph cache -> its outputs, or None: run the eager body."""
         if not (self.use_cuda and getattr(self.args, "predict_graphs", True)) or getattr(self, "parallel", False):
-            return None, None
+            return None
         if torch.cuda.is_current_stream_capturing():        # an outer capture (graph_runner.GraphedPredictor, bench.py) records the eager body
-            return None, None
+            return None
         from .. import lib
         if lib.load().nir_profile_enable(-1):               # per-kernel event timing is on: events cannot be recorded into a capture
-            return None, None
+            return None
         if self._graphs is None:
             from ..graph_runner import PredictGraphCache
             self._graphs = PredictGraphCache(self, self.predict_graph_max, self.predict_graph_min_calls)
         for k in fields:
             if not torch.is_tensor(ex.get(k)):
-                return None, None
+                return None
         if self.network.training:
             self.network.eval()                             # (the key holds the network's plain attributes, `training` among them)
-        return self._graphs, self._graphs.get(ex, fields, flavour, body)
+        out = self._graphs.call(ex, fields, flavour, body, finish)
+        return None if out is self._graphs.EAGER else out
 
     def clear_predict_graphs(self):
         if self._graphs is not None:

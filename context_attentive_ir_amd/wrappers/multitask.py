@@ -242,19 +242,15 @@ class Multitask(WrapperBase):
         do_decode = bool(suggest) and not (self.type == "CARS" and self.network.no_recommender)
         fields = self._FIELDS if self.type == "CARS" else self._FIELDS[:4]
         if do_decode or self.type == "CARS" and self.network.no_ranker:
-            cache, ent = self._graph_entry(ex, fields, do_decode, lambda e: self._predict_body(e, do_decode))
-            finish = None
+            out = self._graphed(ex, fields, do_decode, lambda e: self._predict_body(e, do_decode))
+            if out is not None and self.id_check == "blocking":
+                self._maybe_check_ids()
         else:
             # ranking only: the captured part ends at the raw scores; the softmax (+ the publication of the error word) runs eagerly into a
             # fresh tensor -- one launch instead of an in-graph softmax and a copy of the static output
-            cache, ent = self._graph_entry(ex, fields, do_decode, lambda e: self._rank(e, False)[0].contiguous())
-            finish = self._finish_scores
-        if ent is None:
+            out = self._graphed(ex, fields, do_decode, lambda e: self._rank(e, False)[0].contiguous(), self._finish_scores)
+        if out is None:
             out = self._predict_body(ex, do_decode)
-        else:
-            out = cache.run(ent, ex, finish)
-            if finish is None and self.id_check == "blocking":
-                self._maybe_check_ids()
         out["click_scores"] = self._checked(out["click_scores"])
         return out
 

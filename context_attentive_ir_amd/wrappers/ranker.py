@@ -73,10 +73,8 @@ class Ranker(WrapperBase):
             dd, ll = sharding.shard_candidates(d, dl, world, rank)
             return sharding.gathered_softmax(self.network(q, ql, dd, ll), d.shape[1], self.group)
         # the captured part ends at the raw scores; the softmax (+ the publication of the error word) runs eagerly into a fresh tensor
-        cache, ent = self._graph_entry(ex, self._FIELDS, None, lambda e: self.scores(e).contiguous())
-        if ent is None:
-            return self._checked(self._predict_body(ex))
-        return self._checked(cache.run(ent, ex, self._finish_scores))
+        out = self._graphed(ex, self._FIELDS, None, lambda e: self.scores(e).contiguous(), self._finish_scores)
+        return self._checked(self._predict_body(ex) if out is None else out)
 
     def _finish_scores(self, s):
         out, published = self._softmax_rows(s)

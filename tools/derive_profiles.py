@@ -18,7 +18,8 @@ from collections import defaultdict
 def short(k):
     k = re.sub(r"^void ", "", k)
     k = re.sub(r"\(.*$", "", k)
-    return k.replace("nir::", "").replace(", ", ",")
+    k = k.replace("nir::", "").replace(", ", ",")
+    return re.sub(r"(,false)+>$", ">", k)       # defaulted trailing template arguments: the library's profile label omits them (<4,4,8,false,false> = <4,4,8>)
 
 
 def counters(d):
