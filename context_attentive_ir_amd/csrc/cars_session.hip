@@ -812,14 +812,11 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
     float* gq = p.gx;
     float* gd = p.gx + (q_on ? BS * 4 * (int64_t)HS : 0);
     const int bnd = (w->rank_bounded & 8) ? ACT_BOUNDED : 0;
-    // One batch in flight (no hint on this stream): the two GEMMs that read the pooled QUERIES only -- the attention projection U and the
-    // query chain's hoisted input projection -- run on the side stream next to the click MLP, the click pooling and the document chain's
-    // projection (round 6: two dependent launches, ~10 us of 120 at a C3 batch, off the tail's critical path); several batches in flight:
-    // ForkJoin is a no-op and everything runs in order on `st`.
-    ForkJoin fj(st);
-    fj.fork();
+    // (Round 6, measured and NOT kept: the two GEMMs that read the pooled QUERIES only -- the attention projection U and the query chain's hoisted
+    // input projection -- on a forked stream beside the click MLP / click pooling / the document chain's projection.  Inside a hipGraph every
+    // cross-queue edge costs ~9 us (fork 9.3 + join 8.7 us in tools/iter_timeline.py) against the ~10 us the two launches take: 120 -> 123 us.)
     {
-        hipStream_t sq_ = fj.side;
+        hipStream_t sq_ = st;
         // ---- U = pooled_q [W_sq^T | W_sd^T | b_sq | b_sd]  (independent of the chains)
         if (nch && rank_on)
             NIR_PROPAGATE(launch_linear(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->attn_ut, D, nullptr, nullptr, p.U, NU, BS, NU, D, NIR_ACT_NONE, sq_));
@@ -859,7 +856,6 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
             // (inputs are pooled encoder states / softmax-weighted sums of them, inside (-1, 1); bit 3 of rank_bounded: |W_ih| < 2^15 host-checked -> fp16 two-term split)
             // (the query chain's projection was issued with U above, on the side stream)
             if (d_on) NIR_PROPAGATE(launch_linear_ex(clicks, D, nullptr, nullptr, 0, 0, 0, w->sd_wih, D, w->sd_bih, w->sd_bhh, gd, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, st));
-            fj.join();
             a.gx[0] = gq; a.gx[1] = gd;
             a.gxstride = (int64_t)S * 4 * HS;
             a.whh_frag[0] = w->sq_whh_frag; a.whh_frag[1] = w->sd_whh_frag;
