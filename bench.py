@@ -1320,6 +1320,12 @@ def short_sub(n, r):
     if n.startswith("train_") or r.get("pairs_per_s") is None:
         e["ms_per_step"] = r.get("ms_per_step")
     # the line stays under 4 KB: no null entries, error figures to three significant digits
+    if e.get("kg") == 1:
+        del e["kg"]
+    if isinstance(e.get("pairs_per_s"), float):
+        e["pairs_per_s"] = int(round(e["pairs_per_s"]))
+    if isinstance(e.get("frac"), float):
+        e["frac"] = round(e["frac"], 4)
     return {k: (float("%.3g" % v) if isinstance(v, float) and k not in ("pairs_per_s", "ms_per_step", "frac") else v) for k, v in e.items() if v is not None}
 
 
