@@ -432,8 +432,18 @@ def sample_power(keep_busy, seconds=2.5):
             "leg": "untimed: the timed region replayed for %.1f s after the timed repetitions, rocm-smi polled beside it" % (time.perf_counter() - t0)}
 
 
+def _phase(name, what):
+    """BENCH_PHASES=<file>: append "record: phase" lines (synchronised) -- locates a device fault, which arrives asynchronously and without a Python trace"""
+    path = os.environ.get("BENCH_PHASES")
+    if path:
+        torch.cuda.synchronize()
+        with open(path, "a") as f:
+            f.write("%s: %s\n" % (name, what))
+
+
 def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2d=False, axis=None, kg=None):
     """Time one workload; returns the record dict (rank 0) or None."""
+    _phase(name, "start")
     L = lib.load()
     dev, world, rank = env.dev, env.world, env.rank
     adhoc_power_off = bool(os.environ.get("BENCH_NO_POWER"))
@@ -643,6 +653,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             except Exception:
                 pass
             lib.set_batches_in_flight(hint, lanes)
+    _phase(name, "setup done, capturing")
     macro_single = (plan is None and (not env.multi or not sharded) and macro_batch(c) > 1
                     and c["model"] in ("cars", "m_match_tensor", "match_tensor", "esm", "drmm", "duet"))
     if (staged and plan.aligned) or macro_single:
@@ -703,9 +714,14 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                     mlab, mall = torch.cat([e["_lab_own"] for e in exs]), torch.stack([e["document_labels"] for e in exs])
                 ln.synchronize()
 
+                # (the graph below reads these tensors on every replay: they must outlive this function -- until round 6 they did not, and a later
+                # group's inputs could be allocated over them; with the allocator handing the segment back, a replay faulted)
+                macro_inputs[(gb, k)] = (mq, mql, md, ml, mlab, mall)
+
                 def body():
                     pq, pl = model.shard_encode(mq, mql, md, ml)
                     model.tail_probs(pq, pl, mlab, None, probs=mine.view(k * plan.bper, plan.S, ncand), labels_groups=mall)
+                eager_fns[(gb, k)] = body
                 with torch.cuda.stream(ln):
                     body()
                 torch.cuda.synchronize()
@@ -775,6 +791,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             graphs = None
             torch.cuda.synchronize()
 
+    _phase(name, "graphs captured")
     def run(i, only_lane=None):
         ln = lane_of(i) if only_lane is None else only_lane
         with torch.cuda.stream(lanes[ln]):
@@ -852,6 +869,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     rewind()
     run_steps(max(warmup, 1))
 
+    _phase(name, "timed region")
     def timed_region():
         """EXACTLY `steps` steps between barrier + synchronize on both sides; returns (max-over-ranks seconds, host enqueue seconds)"""
         rewind()
@@ -888,6 +906,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             torch.cuda.synchronize()
         power = sample_power(busy, 2.5 if want_cpu else 1.5)
 
+    _phase(name, "single / overlap check")
     single_ms, overlap_diff = ms_per_step, None
     if len(lanes) > 1:
         if graphs is not None and not sharded:
@@ -1005,6 +1024,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
         except Exception as e:  # pragma: no cover - secondary figure only
             print("[bench] H2D-inclusive figure unavailable: %s: %s" % (type(e).__name__, e), file=sys.stderr)
 
+    _phase(name, "profile pass")
     # ---- profiled pass: HIP events around every kernel of the library, same workload, serial -------------------
     torch.cuda.set_stream(lanes[0])
     lib.set_batches_in_flight(hint, lanes)
@@ -1109,6 +1129,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
     cpu = None
     if want_cpu and rank == 0 and not env.multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(c, model, batches, lambda: finish(forward(0)), pairs_global, args)
+    _phase(name, "checker legs")
     tier_err = None
     if (c.get("dtype") == "f32_split2" or c.get("oracle_slice")) and rank == 0 and not env.multi and not args.no_cpu_baseline:
         # the record's own error figure (checker leg, the oracle as the checker only): click probabilities of two resident batches against the oracle
@@ -1128,6 +1149,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             ref_ = O.predict_softmax(O.cars_scores(sd_, ex_["source_words"], ex_["source_lens"], ex_["document_words"], ex_["document_lens"], ex_["document_labels"]))
             got_ = model.predict(batches[bi], suggest=False)["click_scores"].cpu()
             tier_err = max(tier_err, float((got_ - ref_.view_as(got_)).abs().max()))
+    _phase(name, "end")
     lib.set_batches_in_flight(0, lanes)
     if rank != 0:
         return None
