@@ -103,6 +103,22 @@ def test_bench_two_ranks_strong_scaling_flow(axis, needle, port):
         assert sub["world_size"] == 2 and "5 per rank" in sub["parallelism"] and sub["pairs_per_s"] > 0 and sub["shard_axis"] == "candidate"
 
 
+def test_bench_rccl_lane_graphs_with_remainder_groups_replay_live_inputs():
+    """The pair-axis path of an N > 1 run over RCCL (one GPU: BENCH_EMULATE_WORLD=8 over a real 1-rank RCCL group): lane graphs of KG merged steps
+    plus REMAINDER groups captured on the way (warm-up 8 = 3 + 3 + 2 steps at the C5 shape).  Until round 6 the macro-batched input tensors a
+    graph reads were locals of the capturing function: freed on return, overwritten -- or unmapped -- under later replays (intermittent
+    "Memory access fault by GPU", deterministic for this step pattern)."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", BENCH_EMULATE_WORLD="8", BENCH_NO_H2D="1", MASTER_PORT="29551")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_BACKEND"):
+        env.pop(k, None)
+    for cfg, extra in (("C5_cars_bf16", ["--steps", "24", "--warmup", "8"]), ("C3_cars", ["--steps", "12", "--warmup", "6"])):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--sub", "none", "--no-cpu-baseline"] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, (cfg, out.returncode, out.stderr[-1500:])
+        d = _last_json(out.stdout + out.stderr)
+        assert d["emulated"] is True and d["emulated_world"] == 8 and d["value"] > 0 and d["config"]["shard_axis"] == "pair"
+
+
 def test_two_rank_sharding_reproduces_single_rank_scores():
     """Ranker.parallelize() / Multitask.parallelize() with 2 ranks (gloo, both on the one GPU): the candidate-sharded predict
     equals the unsharded one on every rank."""
