@@ -192,7 +192,7 @@ class PredictGraphCache(object):
     """Shape-keyed hipGraph cache INSIDE Ranker.predict / Multitask.predict (round 6): the reference's drivers call `model.predict(ex)` once
     per batch and synchronise on the scores (main/ranker.py:254-257, main/multitask.py:280-287); an eager call is host-bound (a CARS batch
     is ~45 launches for 0.3 ms of kernels).  The first `min_calls - 1` calls of a key run eagerly; the next one captures the eager body
-    over static input buffers (scratch owned by the entry: lib.workspace_owner) and every later call is
+    over static input buffers (scratch owned by the cache: lib.workspace_owner, shared by its graphs) and every later call is
         [small host fields -> one pinned staging block -> ONE H2D | large pinned fields: direct H2D | device fields: D2D] -> replay -> clone
     on the CALLER's current stream, OPTIMISTICALLY (see call()) (round 6b: the bracketed step is the graph's FIRST KERNEL -- nir_gather_fields reads a per-call table of
     source addresses from pinned memory and copies pinned host tensors over PCIe itself, staged fields and device tensors alike: a replay
@@ -211,11 +211,18 @@ class PredictGraphCache(object):
         self.seen = {}
         self.params = None
         self.captures = self.replays = 0
+        # ONE capture stream and ONE scratch owner for all entries: the library's workspaces are keyed by (owner, device, stream), so every graph of
+        # this cache uses the same grow-only scratch (a C3 call at --test_batch_size 128 needs ~1 GB: 32 shapes must not mean 32 GB).  Safe because
+        # the graphs of one wrapper are replayed one after the other on the caller's stream; a wrapper shared by threads that call predict() on
+        # different streams at the same time is not supported (the reference's predict is not re-entrant either).
+        self.side = None
+        self.owner = type("PredictScratch", (), {})()
 
     def clear(self):
         self.entries.clear()
         self.seen.clear()
         self.params = None
+        self.owner = type("PredictScratch", (), {})()
 
     def token(self):
         if self.params is None:
@@ -308,9 +315,11 @@ class PredictGraphCache(object):
             lib.check(L.nir_gather_fields(ctypes.c_void_p(ent.table.data_ptr()), len(slots), lib.ptr(ent.dev_buf), ent.total, lib.stream()),
                       "nir_gather_fields")
             return body(ent.static)
-        side = torch.cuda.Stream(device=dev)
+        if self.side is None or self.side.device != dev:
+            self.side = torch.cuda.Stream(device=dev)
+        side = self.side
         side.wait_stream(cur)
-        with torch.cuda.stream(side), lib.workspace_owner(ent):
+        with torch.cuda.stream(side), lib.workspace_owner(self.owner):
             step()                                                    # warm-up under the entry's own scratch (sizes it, builds packs)
             side.synchronize()
             ent.graph = torch.cuda.CUDAGraph()

@@ -357,8 +357,8 @@ def workspace(nbytes, device):
     k = (str(device), torch.cuda.current_stream().cuda_stream)
     buf = pool.get(k)
     if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            _WS_RETIRED.append(buf)
+        if buf is not None:      # (an owner's superseded buffers live as long as the owner -- its graphs -- does; the shared pool's for the process)
+            (_WS_RETIRED if owner is None else owner.__dict__.setdefault("_nir_ws_retired", [])).append(buf)
         grow = 0 if buf is None else 2 * buf.numel()
         buf = torch.empty(max(int(nbytes), grow, 1 << 20), dtype=torch.uint8, device=device)
         pool[k] = buf
