@@ -1091,6 +1091,10 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
                 roofline["mfma_busy_pmc"] = ent.get("mfma_busy")
             roofline["step_hbm_GBps_8d"] = round(value * bpp / 1e9 / (1 if sharded or not env.multi else world), 2)
             roofline["step_hbm_frac_8d"] = round(roofline["step_hbm_GBps_8d"] / PEAK_HBM_GBS, 5)
+            if roofline["step_hbm_GBps_8d"] > 6300.0:
+                # above what MI355X_MICROARCH.md measures as achievable from HBM (6.3 TB/s): part of the 8(d) bytes is served by the 256 MB Infinity Cache
+                # (uniform ids over a 1.2 GB table re-hit ~20 % of their rows there) -- the figure is algorithmic bytes per second, not HBM traffic
+                roofline["step_hbm_source"] = "HBM + Infinity Cache (above the 6.3 TB/s achievable from HBM alone)"
             fpp = flops_per_pair(c["model"], c["qlen"], c["dlen"])
             if fpp:
                 roofline["step_alg_TFLOPs_ref_ops"] = round(value * fpp / 1e12 / (world if env.multi and not sharded else 1), 2)
