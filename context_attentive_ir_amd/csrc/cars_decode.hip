@@ -125,7 +125,8 @@ constexpr size_t PA_LDS = (size_t)2 * PA_ROWS * PA_LD * 2;
 // (at 768 rows: 8 x 32 workgroups of ~15 tiles per wave).  Before, every workgroup took all row blocks in turn over 1/256 of the vocabulary:
 // eight re-stagings of 96 rows and ~2 tiles per wave and pass -- 16 us of MFMA work in a 124 us launch.
 __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __restrict__ p1, const _Float16* __restrict__ wfrag, int64_t VT,
-                                                             int64_t ntiles, int64_t Bd, float* __restrict__ pval, int* __restrict__ pidx, int nvr) {
+                                                             int64_t ntiles, int64_t Bd, float* __restrict__ pval, int* __restrict__ pidx, int nvr,
+                                                             unsigned long long* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) _Float16 pa_sm[];          // [2 terms][96 rows][PA_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
@@ -271,10 +272,28 @@ __global__ __launch_bounds__(256, 1) void pred_argmax_kernel(const float* __rest
                 if (ov > best[bt] || (ov == best[bt] && oi < bidx[bt])) { best[bt] = ov; bidx[bt] = oi; }
             }
             const int64_t b = b0 + bt * 16 + c16;
-            if (g4 == 0 && b < Bd) {
+            if (g4 == 0 && b < Bd && !keys) {
                 const int64_t slot = ((int64_t)vr * 4 + wave) * Bd + b;
                 pval[slot] = best[bt];
                 pidx[slot] = bidx[bt];
+            }
+        }
+        if (keys) {
+            // (round 6) keyed form: the four waves' winners meet in LDS (the staged rows are dead by now), ONE 64-bit atomic max per workgroup and decode
+            // row, spread over ARGMAX_KEY_BUCKETS words per row (all 235 workgroups finish together: a single word per row serialised ~900 atomics)
+            unsigned long long* kl = reinterpret_cast<unsigned long long*>(pa_sm);      // [4 waves][96]
+            __syncthreads();
+            if (g4 == 0) {
+#pragma unroll
+                for (int bt = 0; bt < PA_NBT; ++bt) kl[wave * PA_ROWS + bt * 16 + c16] = argmax_key(best[bt], bidx[bt]);
+            }
+            __syncthreads();
+            if (tid < PA_ROWS) {
+                unsigned long long k = kl[tid];
+#pragma unroll
+                for (int w_ = 1; w_ < 4; ++w_) { const unsigned long long o = kl[w_ * PA_ROWS + tid]; k = o > k ? o : k; }
+                const int64_t b = b0 + tid;
+                if (b < Bd) atomicMax(keys + b * ARGMAX_KEY_BUCKETS + (vr % ARGMAX_KEY_BUCKETS), k);
             }
         }
     }
@@ -305,6 +324,17 @@ __global__ __launch_bounds__(64) void argmax_finish_kernel(const float* __restri
         const int64_t nxt = lut ? lut[w] : w;
         tgt[i] = (nxt >= 0 && nxt < Vsrc) ? nxt : 1;
     }
+}
+
+// keys [max_len][Bd] of a whole greedy decode -> pred [Bd][max_len] (target-vocabulary ids): ONE launch behind the last step
+__global__ void keys_to_pred_kernel(const unsigned long long* __restrict__ keys, int64_t Bd, int max_len, int64_t* __restrict__ pred) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Bd * max_len) return;
+    const int64_t step = e / Bd, row = e - step * Bd;
+    unsigned long long k = 0ull;
+#pragma unroll
+    for (int q = 0; q < ARGMAX_KEY_BUCKETS; ++q) { const unsigned long long o = keys[e * ARGMAX_KEY_BUCKETS + q]; k = o > k ? o : k; }
+    pred[row * max_len + step] = argmax_key_index(k);
 }
 
 __global__ void fill_i64_kernel(int64_t* p, int64_t v, int64_t n) {
@@ -442,6 +472,12 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
         hipLaunchKernelGGL(h16_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dec_h, n, reinterpret_cast<_Float16*>(p.h16[1]));
         NIR_CHECK_LAUNCH("h16_pack_kernel");
     }
+    // Round 6: with the fused projection + arg-max AND the folded step, the winner of step s travels as a 64-bit arg-max KEY (atomic max per wave and
+    // row, argmax_key) that the NEXT step's kernel decodes itself (token -> source id -> gate row): no argmax_finish launch between the steps
+    // (8 us of 50 per step at 96 decode rows), one keys_to_pred launch behind the loop.  The keys live in the partial-value scratch.
+    const bool keyed = fused_argmax && step16 && max_len * ARGMAX_KEY_BUCKETS <= 512;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(p.pval);
+    if (keyed) NIR_PROPAGATE((int)hipMemsetAsync(keys, 0, (size_t)max_len * Bd * ARGMAX_KEY_BUCKETS * sizeof(unsigned long long), st));
     const float* hp = dec_h;
     const float* cp = dec_c;
     for (int step = 0; step < max_len; ++step) {
@@ -451,6 +487,9 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
         if (step16) {
             a.h16prev[0] = reinterpret_cast<const _Float16*>(p.h16[(step + 1) & 1]);
             a.h16next[0] = reinterpret_cast<_Float16*>(p.h16[step & 1]);
+        }
+        if (keyed && step > 0) {
+            a.gxid[0] = nullptr; a.gxkey = keys + (size_t)(step - 1) * Bd * ARGMAX_KEY_BUCKETS; a.gxmap = tgt2src; a.gxV = V;
         }
         NIR_PROPAGATE(launch_lstm_step(a, 1, st));
         if (!foldq)
@@ -468,12 +507,14 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
             {
                 ProfScope ps(prof_shape_name("pred_argmax_kernel", (long long)Bd, (long long)w->VT, P), st);
                 hipLaunchKernelGGL(pred_argmax_kernel, dim3((unsigned)(pa_wgs * pa_rb)), dim3(256), PA_LDS, st, p.p1, (const _Float16*)w->pred2_frag, w->VT, ntiles, Bd,
-                                   p.pval, p.pidx, pa_wgs);
+                                   p.pval, p.pidx, pa_wgs, keyed ? keys + (size_t)step * Bd * ARGMAX_KEY_BUCKETS : nullptr);
             }
             NIR_CHECK_LAUNCH("pred_argmax_kernel");
-            hipLaunchKernelGGL(argmax_finish_kernel, dim3((unsigned)Bd), dim3(64), 0, st, p.pval, p.pidx, pa_wgs * 4, Bd, tgt2src, predictions + step,
-                               (int64_t)max_len, p.tgt, V);
-            NIR_CHECK_LAUNCH("argmax_finish_kernel");
+            if (!keyed) {
+                hipLaunchKernelGGL(argmax_finish_kernel, dim3((unsigned)Bd), dim3(64), 0, st, p.pval, p.pidx, pa_wgs * 4, Bd, tgt2src, predictions + step,
+                                   (int64_t)max_len, p.tgt, V);
+                NIR_CHECK_LAUNCH("argmax_finish_kernel");
+            }
         } else {
             NIR_PROPAGATE(launch_linear(p.p1, P, nullptr, nullptr, 0, 0, 0, w->pred2_w, P, nullptr, nullptr, p.logits, w->VT, Bd, (int)w->VT, P, NIR_ACT_NONE, st));
             {
@@ -484,6 +525,11 @@ extern "C" int nir_cars_decode_greedy(const float* dec_h, const float* dec_c, co
         }
         hp = hn;
         cp = cn;
+    }
+    if (keyed) {
+        const int64_t n = Bd * max_len;
+        hipLaunchKernelGGL(keys_to_pred_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, Bd, max_len, predictions);
+        NIR_CHECK_LAUNCH("keys_to_pred_kernel");
     }
     return 0;
 }

@@ -390,7 +390,21 @@ __global__ __launch_bounds__(256) void lstm_step16_kernel(LstmStepArgs p) {
             const int ud = 4 * (blockIdx.x * UG + u) + g;
             const int64_t brow = bq < p.B ? bq : p.B - 1;
             const int udc = ud < H ? ud : H - 1;
-            const float* gr = gxp + (p.gxid[ch] ? p.gxid[ch][brow] : brow) * p.gxstride;
+            int64_t grow = p.gxid[ch] ? p.gxid[ch][brow] : brow;
+            if (p.gxkey && ch == 0) {                                       // (wave-uniform) the previous decode step's arg-max key -> source token id
+                const ulonglong2* kb_ = reinterpret_cast<const ulonglong2*>(p.gxkey + brow * ARGMAX_KEY_BUCKETS);
+                unsigned long long km_ = 0ull;
+#pragma unroll
+                for (int q_ = 0; q_ < ARGMAX_KEY_BUCKETS / 2; ++q_) {
+                    const ulonglong2 kk_ = kb_[q_];
+                    km_ = kk_.x > km_ ? kk_.x : km_;
+                    km_ = kk_.y > km_ ? kk_.y : km_;
+                }
+                const int64_t w_ = argmax_key_index(km_);
+                const int64_t nx_ = p.gxmap ? p.gxmap[w_] : w_;
+                grow = (nx_ >= 0 && nx_ < p.gxV) ? nx_ : 1;
+            }
+            const float* gr = gxp + grow * p.gxstride;
             if (p.gx_unit_major) {
                 const float4 v = *reinterpret_cast<const float4*>(gr + 4 * udc);
                 gxv[k][0] = v.x; gxv[k][1] = v.y; gxv[k][2] = v.z; gxv[k][3] = v.w;

@@ -168,6 +168,17 @@ struct Workspace {
 
 // One LSTM time step for up to two independent chains that share (B, I, H) (csrc/cars_session.hip: lstm_step_kernel): the CARS session
 // encoders (cars.py:306-380) and the greedy decoders.  Shared by cars_session.hip and cars_decode.hip.
+// Arg-max key of the fused projection + arg-max (csrc/cars_decode.hip): larger value wins, the SMALLER index on ties; 0 = no candidate yet.
+__device__ __forceinline__ unsigned long long argmax_key(float x, int idx) {
+    uint32_t u = __float_as_uint(x);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)idx);
+}
+constexpr int ARGMAX_KEY_BUCKETS = 8;      // atomics of one decode row are spread over this many words (235 workgroups -> ~30 per word)
+__device__ __forceinline__ int64_t argmax_key_index(unsigned long long key) {
+    const uint32_t idx = 0xFFFFFFFFu - (uint32_t)key;
+    return (key == 0ull || idx == 0x7FFFFFFFu) ? 0 : (int64_t)idx;
+}
 struct LstmStepArgs {
     const float* x[2];        // input rows: row b at x + (xid ? xid[b] : b) * xstride   (xid: embedding gather by token id)
     const int64_t* xid[2];
@@ -190,6 +201,12 @@ struct LstmStepArgs {
     // previous step's token ids: the greedy decoders); gx_unit_major: a gate row is [unit][i,f,g,o] (nir_lstm_fold_table's order), not [gate][unit]
     const int64_t* gxid[2] = {nullptr, nullptr};
     int gx_unit_major = 0;
+    // (round 6, chain 0 only) gxkey != NULL instead of gxid: the row index is decoded from the arg-max KEY the fused projection kernel left for row b
+    // (argmax_key: value order in the high word, 0xFFFFFFFF - vocabulary index in the low word), mapped through gxmap (target -> source ids; NULL:
+    // identity) and clamped to [0, gxV) like argmax_finish_kernel did -- the greedy decoder then needs no finish launch between its steps
+    const unsigned long long* gxkey = nullptr;      // [B][ARGMAX_KEY_BUCKETS]: the row's key is the max over its buckets
+    const int64_t* gxmap = nullptr;
+    int64_t gxV = 0;
     // whh_frag != NULL (H % 32 == 0): W_hh pre-split into two fp16 terms in MFMA-fragment order (nir_lstm_step_pack_whh_frag) and the previous
     // state ALSO kept as fp16 term pairs (h16prev / h16next: [B][H/8][2 terms][8]) -- the recurrent product then runs as three
     // v_mfma_f32_16x16x32_f16 per 32-wide k-block (fp32-class, like the folded recurrences) instead of eight v_mfma_f32_16x16x4_f32
