@@ -642,3 +642,35 @@ def test_debug_tunables_are_frozen_in_a_product_process():
     assert int(rc) != 0 and "frozen" in msg
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, NIR_DEBUG_TUNABLES="1"), capture_output=True, text=True, timeout=120)
     assert out.stdout.strip().split(" ", 1)[0] == "0"
+
+
+def test_native_rank_metrics_equal_the_numpy_definitions():
+    """eval.ltorank MAP / MRR / precision_at_k take the library's host loop (nir_host_rank_metric: one C pass per metric, round 6) for plain
+    [rows, n] int64 / float32|int64|float64 arrays and the numpy form otherwise: both equal the reference's definitions
+    (neuroir/eval/ltorank.py:4-47, 104-123), MAP raises on a row without a relevant candidate."""
+    from context_attentive_ir_amd.eval import ltorank as L
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.int64, np.float64):
+        for rows, n in ((112, 10), (7, 50), (1, 1), (896, 10)):
+            s = rng.random((rows, n)).astype(np.float32)
+            lab = np.zeros((rows, n), dt)
+            for r in range(rows):
+                lab[r, rng.choice(n, int(rng.integers(1, min(n, 4) + 1)), replace=False)] = 1
+            p = np.argsort(-s)
+            hit = np.take_along_axis(lab, p, 1) == 1
+            ap = (((np.cumsum(hit, 1) / np.arange(1, n + 1)) * hit).sum(1) / hit.sum(1)).mean()
+            mrr = np.where(hit.any(1), 1.0 / (hit.argmax(1) + 1), 0.0).mean()
+            assert L._native(0, p, lab) is not None                                       # the C pass is the one taken
+            assert abs(L.MAP(p, lab) - ap) < 1e-12 and abs(L.MRR(p, lab) - mrr) < 1e-12
+            for k in (1, 3, 5):
+                if n >= k:
+                    assert abs(L.precision_at_k(p, lab, k) - hit[:, :k].sum(1).mean() / k) < 1e-12
+            pf = np.asfortranarray(p)                                                     # not C-contiguous: the numpy form
+            assert pf.flags.c_contiguous or L._native(0, pf, lab) is None
+            assert abs(L.MAP(pf, lab) - ap) < 1e-12 and abs(L.MRR(pf, lab) - mrr) < 1e-12
+    lab[3] = 0
+    with pytest.raises(ZeroDivisionError):
+        L.MAP(p, lab)
+    with pytest.raises(ZeroDivisionError):
+        L.MAP(np.asfortranarray(p), lab)
+    assert abs(L.MRR(p, lab) - L.MRR(np.asfortranarray(p), lab)) < 1e-12                  # a row without a relevant candidate counts 0
