@@ -405,5 +405,17 @@ class GraphedUpdate(object):
             if torch.is_tensor(v):
                 static[k].copy_(v, non_blocking=True)
         g.replay()
+        # a replay changes the parameters WITHOUT bumping their version counters (the in-place optimizer kernels were dispatched once, at capture): every
+        # version-keyed cache -- the weight packs / folded tables of the predict path (lib.PackCache), the predict() graph cache -- would keep serving
+        # the weights of the capture.  Round 6 (found with tools/_scratch: predict() after six graphed steps differed from a fresh model with the same
+        # state dict by 0.58): bump the counters explicitly, no kernel involved.
+        torch.autograd.graph.increment_version(self._trained())
         w.updates += 1
         return loss
+
+    def _trained(self):
+        ps = getattr(self, "_trained_params", None)
+        if ps is None or self._trained_opt is not self.w.optimizer:
+            ps = self._trained_params = [p for g in self.w.optimizer.param_groups for p in g["params"]]
+            self._trained_opt = self.w.optimizer
+        return ps

@@ -697,6 +697,48 @@ def test_graphed_update_reproduces_eager_trajectory_without_dropout(kind):
         assert float((pe[k] - pg[k]).abs().max()) <= 1e-4 * max(1.0, float(pe[k].abs().max())), k
 
 
+def test_predict_after_graphed_updates_scores_the_trained_weights():
+    """A replayed GraphedUpdate changes the parameters without bumping their version counters (the optimizer's in-place kernels were dispatched at
+    capture time only): the version-keyed weight packs / folded tables of the predict path -- and the predict() graph cache -- must still follow.
+    predict() after graphed steps equals a FRESH model loaded with the same state dict (until round 6 it scored the weights of the capture)."""
+    from context_attentive_ir_amd import synth
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.detinit import fill_module_
+    from context_attentive_ir_amd.wrappers import GraphedUpdate, Multitask, Ranker
+    V = 500
+    kw = dict(dropout_emb=0.0, dropout=0.0, dropout_rnn=0.0, optimizer="adam", learning_rate=0.01, weight_decay=0, momentum=0, grad_clipping=10.0,
+              fix_embeddings=True)
+    for kind in ("MATCH_TENSOR", "CARS"):
+        if kind == "CARS":
+            mk = lambda: Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=V, **kw))          # noqa: E731
+            g = load_golden("cars_train")
+            mk = lambda: Multitask(default_args("CARS", src_vocab_size=int(g["meta_vocab"]), tgt_vocab_size=int(g["meta_vocab"]), **kw))   # noqa: E731
+            ex = _cars_train_batch(g, 0, DEV)
+            pred = lambda m: m.predict(ex, suggest=False)["click_scores"].cpu()                              # noqa: E731
+        else:
+            mk = lambda: Ranker(default_args("MATCH_TENSOR", src_vocab_size=V, **kw))                        # noqa: E731
+            ex = {k: v.to(DEV) for k, v in synth.ranker_batch(4, 5, 5, 24, V, seed=1, full_length=False).items()}
+            ex["label"] = ex["label"].float()
+            pred = lambda m: m.predict(ex).cpu()                                                             # noqa: E731
+        w = mk()
+        fill_module_(w.network, 1013)
+        w.cuda()
+        w.init_optimizer()
+        for _ in range(3):
+            before = pred(w)                                       # (also arms the predict() graph cache on the untrained weights)
+        step = GraphedUpdate(w)
+        for _ in range(6):
+            step(ex)
+        after = pred(w)
+        fresh = mk()
+        fresh.network.load_state_dict({k: v.detach().clone() for k, v in w.network.state_dict().items()})
+        fresh.cuda()
+        fresh.args.predict_graphs = False
+        want = pred(fresh)
+        assert float((after - before).abs().max()) > 1e-4, kind    # the six steps moved the scores
+        assert float((after - want).abs().max()) < 1e-6, (kind, float((after - want).abs().max()))
+
+
 def test_checkpoint_resume_keeps_the_capturable_fused_optimizer_and_the_trajectory(tmp_path):
     """checkpoint() writes reference-compatible optimizer groups (float rate, no flavour flags); load_checkpoint() -> init_optimizer()
     must come back with the run-time flavour (capturable + fused Adam, float32 device step counters): GraphedUpdate then captures the resumed
