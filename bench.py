@@ -1113,7 +1113,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             model.id_check = "blocking" if mode == "blocking_eager" else "deferred"
             model.args.predict_graphs = mode == "default"
             call = (lambda: model.predict(batches[0], suggest=False)) if is_sess else (lambda: model.predict(batches[0]))
-            for _ in range(4):
+            for _ in range(12):                         # (past predict_graph_min_calls = 8: the "default" mode is timed on its replays)
                 call()
             torch.cuda.synchronize()
             te = time.perf_counter()

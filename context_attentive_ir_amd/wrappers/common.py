@@ -25,8 +25,12 @@ class WrapperBase(object):
     id_check = "deferred"
     id_check_interval = 1
     _id_calls = 0
-    # hipGraph replay inside predict(): graph_runner.PredictGraphCache (args.predict_graphs = False switches it off)
-    predict_graph_min_calls = 2
+    # hipGraph replay inside predict(): graph_runner.PredictGraphCache (args.predict_graphs = False switches it off).  A shape is captured at its
+    # `predict_graph_min_calls`-th sighting: a capture costs 3-5 ms (tools/_scratch measurement: CARS 3.1-3.3 ms, with decode 4.6-5.6 ms, MatchTensor
+    # 1.9-3.2 ms) and a replay saves 0.3-0.45 ms per call against the eager launches, so a shape pays for its graph after ~8-12 calls -- capturing at the
+    # 8th sighting is the ski-rental choice (never more than ~2x the cost of the better of "always eager" / "capture at once") for data whose batches
+    # are padded to per-batch maxima and repeat a shape only a few times; steady shapes lose seven eager calls once.
+    predict_graph_min_calls = 8
     predict_graph_max = 32
     _graphs = None
     _board = None

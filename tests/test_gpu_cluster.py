@@ -132,6 +132,7 @@ def test_cluster_timeout_fails_safe_to_the_streaming_recurrence():
     fill_module_(w.network, 29)
     sd = {k: v.detach().cpu().float() for k, v in w.network.state_dict().items()}
     w.cuda()
+    w.predict_graph_min_calls = 2
     w.id_check_interval = 0                                     # the caller opted out of the id check: the cluster bit is still not silent
     ex = synth.session_batch(6, 5, 8, 5, 21, V, seed=3)
     ref = torch.softmax(O.mnsrf_scores(sd, ex["source_words"], ex["source_lens"], ex["document_words"], ex["document_lens"]), -1)

@@ -724,6 +724,7 @@ def test_predict_after_graphed_updates_scores_the_trained_weights():
         fill_module_(w.network, 1013)
         w.cuda()
         w.init_optimizer()
+        w.predict_graph_min_calls = 2
         for _ in range(3):
             before = pred(w)                                       # (also arms the predict() graph cache on the untrained weights)
         step = GraphedUpdate(w)
