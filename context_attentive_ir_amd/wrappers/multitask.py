@@ -234,7 +234,9 @@ class Multitask(WrapperBase):
     @torch.no_grad()
     def predict(self, ex, suggest=True):
         """models/multitask.py:229-317: {'click_scores': softmax over candidates [B,S,N], 'predictions': LongTensor
-        [B,S-1,max_query_len] (suggest=True; None for CARS with the recommender off)}.
+        [B,S-1,max_query_len] (suggest=True; None for CARS with the recommender off)}.  For a batch in the reference's collate layout (`ids`,
+        `source_tokens`, `target_tokens`: what its DataLoader yields) the dict is the reference's: `predictions` = the decoded strings, plus `ex_ids`,
+        `targets`, `src_sequences` (and the ids under `prediction_ids`): `validate_official` of main/multitask.py runs unchanged.
         suggest=False = the ranking path only (what bench.py times as a step and GraphedPredictor captures).
         From the second call of a batch shape on, the call replays a captured hipGraph (WrapperBase._graph_entry; decode included); an
         out-of-vocabulary id raises IndexError from the scores' `.cpu()` or from the next call (WrapperBase.id_check)."""
@@ -252,7 +254,40 @@ class Multitask(WrapperBase):
         if out is None:
             out = self._predict_body(ex, do_decode)
         out["click_scores"] = self._checked(out["click_scores"])
+        if do_decode and out.get("predictions") is not None and "ids" in ex and ex.get("source_tokens") is not None:
+            out.update(self._suggestion_text(ex, out["predictions"]))
         return out
+
+    def _suggestion_text(self, ex, pred_ids):
+        """The host-side tail of the reference's predict (models/multitask.py:294-316) for a batch in the reference's collate layout (`ids`,
+        `source_tokens`, `target_tokens`, `session_len`, `batch_size`: inputters/multitask/vector.py:60-149): decoded suggestions as strings
+        (`tens2sen`, utils/misc.py:36-62: BOS skipped, cut at EOS, words through `tgt_dict`, an empty sentence becomes str(PAD)), step-major like the
+        reference's `extend` loop, next to `ex_ids`, `targets` and `src_sequences` -- what `validate_official` (main/multitask.py:288-300) reads.
+        The token ids stay available as `prediction_ids` [B, S-1, max_query_len].  This is the one place where the full predict synchronises
+        (the reference's `wt.item()` per token does too)."""
+        from ..constants import BOS, EOS, PAD
+        S = int(ex["session_len"]) if "session_len" in ex else int(pred_ids.shape[1]) + 1
+        B = int(ex.get("batch_size", pred_ids.shape[0]))
+        host = pred_ids.cpu().tolist()                                      # [B][S-1][max_len]
+        self._poll_ids()                                                    # (synchronised: the pinned error word of this call is final)
+        words, nw = self.tgt_dict, (len(self.tgt_dict) if self.tgt_dict is not None else 0)
+        preds, targets, srcs = [], [], []
+        for sidx in range(S - 1):
+            for bidx in range(len(host)):
+                sent = []
+                for wd in host[bidx][sidx]:
+                    if wd == BOS:
+                        continue
+                    if wd == EOS:
+                        break
+                    sent.append(words[wd] if (words is not None and wd < nw) else str(wd))
+                preds.append(" ".join(sent) if sent else str(PAD))
+            for bidx in range(B):
+                tokens = ex["target_tokens"][bidx][sidx]
+                targets.append([" ".join(tokens[1:-1])])
+                srcs.append(" ".join(" ".join(q[1:-1]) for q in ex["source_tokens"][bidx][0:sidx + 1]))
+        return {"prediction_ids": pred_ids, "predictions": preds, "targets": targets, "src_sequences": srcs,
+                "ex_ids": [_id + str(i) for i in range(S) for _id in ex["ids"]]}
 
     def _finish_scores(self, s):
         probs, published = self._softmax_rows(s)

@@ -224,3 +224,36 @@ def test_m_match_tensor_ranking_path_skips_encode_and_macro_batches_bit_equal():
     ref = torch.softmax(O.m_match_tensor_scores(sd, exs[1]["source_words"], exs[1]["source_lens"], exs[1]["document_words"], exs[1]["document_lens"]), -1)
     assert float((singles[1].cpu() - ref.view_as(singles[1])).abs().max()) < 1e-4
     w.check_ids()
+
+
+def test_predict_returns_the_references_dict_for_a_collated_batch():
+    """For a batch in the reference's collate layout (`ids`, `source_tokens`, `target_tokens`, `session_len`, `batch_size`) predict() returns what
+    models/multitask.py:294-316 returns -- decoded suggestion strings (step-major), `ex_ids`, `targets`, `src_sequences`, `click_scores` -- so that
+    main/multitask.py:validate_official runs on it unchanged; on the graph path as on the eager one."""
+    class Words(object):                                   # the Vocabulary contract predict needs: len() and id -> token
+        def __len__(self):
+            return 300
+
+        def __getitem__(self, i):
+            return "w%d" % i if isinstance(i, int) else 1
+    B, S = 3, 4
+    w = Multitask(default_args("CARS", src_vocab_size=V, tgt_vocab_size=300), tgt_dict=Words(), src_dict=None)
+    fill_module_(w.network, 1013)
+    w.predict_graph_min_calls = 2
+    w.cuda()
+    ex = dict(synth.session_batch(B, S, 5, 4, 12, V, seed=9))
+    toks = [[["<s>", "a%d%d" % (b, s), "b", "</s>"] for s in range(S)] for b in range(B)]
+    ex.update(ids=["s%d_" % b for b in range(B)], batch_size=B, session_len=S, source_tokens=toks, target_tokens=[t[1:] for t in toks])
+    outs = [w.predict(ex) for _ in range(3)]                # eager, capture, replay
+    for o in outs:
+        assert set(o) >= {"click_scores", "predictions", "prediction_ids", "ex_ids", "targets", "src_sequences"}
+        assert len(o["predictions"]) == B * (S - 1) == len(o["targets"]) == len(o["src_sequences"]) and len(o["ex_ids"]) == B * S
+        assert all(isinstance(p, str) and p for p in o["predictions"])
+        ids = o["prediction_ids"].cpu()
+        first = [t for t in ids[1, 0].tolist() if t != 2]
+        first = first[:first.index(3)] if 3 in first else first
+        assert o["predictions"][0 * B + 1] == (" ".join("w%d" % t for t in first) if first else "0")
+        assert o["src_sequences"][B + 0] == "a00 b a01 b" and o["targets"][0] == ["a01 b"]
+    assert torch.equal(outs[0]["prediction_ids"].cpu(), outs[2]["prediction_ids"].cpu()) and outs[0]["predictions"] == outs[2]["predictions"]
+    assert torch.equal(outs[0]["click_scores"].cpu(), outs[2]["click_scores"].cpu())
+    w.check_ids()

@@ -152,3 +152,34 @@ def test_reference_cars_itself_fails_with_unequal_encoder_sizes(ref, monkeypatch
     assert torch.isfinite(call(ok)["ranking_loss"])
     with pytest.raises(NotImplementedError, match="nhid_query == nhid_document"):
         CARS(a)
+
+
+def test_predict_text_outputs_equal_the_reference_tail(ref):
+    """wrappers.Multitask._suggestion_text (the host tail of predict for a batch in the reference's collate layout) against the reference's own
+    code: `tens2sen` over the decoder's ids per step, `ex_ids`, `targets`, `src_sequences` exactly as models/multitask.py:294-316 builds them --
+    what main/multitask.py:validate_official reads from `outputs`."""
+    from neuroir.utils.misc import tens2sen
+    from context_attentive_ir_amd.config import default_args
+    from context_attentive_ir_amd.wrappers import Multitask
+    tgt = _vocab(ref, 30)
+    w = Multitask(default_args("CARS", src_vocab_size=40, tgt_vocab_size=len(tgt)), tgt_dict=tgt)
+    B, S, ML = 3, 4, 6
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randint(0, len(tgt) + 3, (B, S - 1, ML), generator=g)           # incl. BOS / EOS / PAD and ids past the dictionary
+    pred[0, 0, :] = 2                                                              # only BOS: an empty sentence
+    pred[1, 1, 2] = 3                                                              # EOS in the middle
+    src_tok = [[["<s>"] + ["q%d_%d_%d" % (b, s, j) for j in range(2 + s)] + ["</s>"] for s in range(S)] for b in range(B)]
+    ex = {"ids": ["sess%d_" % b for b in range(B)], "batch_size": B, "session_len": S, "source_tokens": src_tok,
+          "target_tokens": [[src_tok[b][s] for s in range(1, S)] for b in range(B)]}
+    got = w._suggestion_text(ex, pred)
+    # the reference's tail, verbatim semantics
+    want_pred, want_tgt, want_src = [], [], []
+    for sidx in range(S - 1):
+        want_pred.extend(tens2sen(pred[:, sidx, :], tgt, None))
+        for bidx in range(B):
+            tokens = ex["target_tokens"][bidx][sidx]
+            want_tgt.append([" ".join(tokens[1:-1])])
+            want_src.append(" ".join(" ".join(q[1:-1]) for q in ex["source_tokens"][bidx][0:sidx + 1]))
+    assert got["predictions"] == want_pred and got["targets"] == want_tgt and got["src_sequences"] == want_src
+    assert got["ex_ids"] == [_id + str(i) for i in range(S) for _id in ex["ids"]]
+    assert got["prediction_ids"] is pred and len(got["predictions"]) == B * (S - 1)
