@@ -1465,6 +1465,13 @@ def run_records(args, env):
         # the other two session models on the same session shape (Multitask.update of M_MATCH_TENSOR / MNSRF: models/multitask.py:161-223)
         sub["train_X3_m_match_tensor_update"] = train_record("M_MATCH_TENSOR", dict(CONFIGS["X3_m_match_tensor"]), args, env, steps=8)
         sub["train_X3_mnsrf_update"] = train_record("MNSRF", dict(CONFIGS["X3_mnsrf"]), args, env, steps=8)
+    elif args.sub is not None and not env.multi:
+        # --sub train_<...>_update[,..]: the named training records alone (iteration on one training step without the whole line)
+        trains = {"train_C3_cars_update": ("CARS", HEADLINE, 12), "train_C2_match_tensor_update": ("MATCH_TENSOR", "C2_match_tensor", 12),
+                  "train_X3_m_match_tensor_update": ("M_MATCH_TENSOR", "X3_m_match_tensor", 8), "train_X3_mnsrf_update": ("MNSRF", "X3_mnsrf", 8)}
+        for n in args.sub.split(","):
+            if n in trains:
+                sub[n] = train_record(trains[n][0], dict(CONFIGS[trains[n][1]]), args, env, steps=trains[n][2])
     eff_world = int(os.environ.get("BENCH_EMULATE_WORLD", env.world)) if env.multi else 1      # (emulation: one process times rank 0's share of W)
     if head["model"] == "cars" and full and env.multi and eff_world > 1:
         # the SAME record on the other CARS shard axis (rank 0 holds its own axis name, every rank takes part) and -- when the per-rank macro-batch policy

@@ -164,7 +164,9 @@ class StepScope(object):
 STEP = StepScope()
 SPLIT_TRAIN_FWD = True     # _BiLSTM.forward at 64 < H <= 128: the split-fp16 matrix-core recurrence (False: the fp32 MFMA one, any H <= 128)
 CLUSTER_TRAIN_FWD = True   # bilstm at 256 units per direction: forward on the cluster recurrence (False: two unidirectional lstm_seq passes)
-TWO_STREAM_BPTT = True     # _BiLSTM256.backward: the reverse direction's step chain on a side stream
+TWO_STREAM_BPTT = True     # _BiLSTM256.backward (FUSED_BPTT256 = False): the reverse direction's step chain on a side stream
+FUSED_BPTT256 = True       # _BiLSTM256.backward: one launch per step for both directions, cell gradients + the recurrent product (nir_lstm256_bptt);
+                           # False: rounds 3-5's masked cell kernel + GEMM per step and direction
 PACKED_WGRAD = False       # _BiLSTM.backward: reduce the weight gradients over a list of the valid (t < length) positions only
 
 
@@ -724,8 +726,9 @@ def _side_stream(dev):
 class _BiLSTM256(Function):
     """Train-mode encoder with 256 units per direction: x [M,T,I], lens [M] -> memory bank [M,T,ND*256] (zero past each length).  Forward = ONE launch
     of the four-workgroup cluster recurrence of the predict path with activation / cell-state stores (nir_lstm256_train_fwd; gates in the folded
-    order from one GEMM); backward = BPTT step by step per direction on the sequence buffers (masked cell kernel + one GEMM per step; there is
-    no resident-W_hh BPTT kernel beyond H = 128), weight gradients from the saved states shifted by a row."""
+    order from one GEMM); backward = BPTT with ONE launch per step for both directions (nir_lstm256_bptt: the step's gate gradients + the recurrent
+    product as eight K-slice partials on the fp32 matrix cores; FUSED_BPTT256 = False: the masked cell kernel + one GEMM per step and direction of
+    rounds 3-5), weight gradients from the saved states shifted by a row."""
 
     @staticmethod
     def forward(ctx, x, lens, nd, *params):
@@ -771,6 +774,11 @@ class _BiLSTM256(Function):
         st = lib.stream()
         d = _f32c(dout)
         dgx = torch.empty(M, T, G, device=dev)
+        if FUSED_BPTT256:
+            ws = torch.empty(L.nir_lstm256_bptt_workspace_bytes(M, nd), dtype=torch.uint8, device=dev)
+            lib.check(L.nir_lstm256_bptt(lib.ptr(d), lib.ptr(act), lib.ptr(cst), lib.ptr(lens64), lib.ptr(whh), lib.ptr(dgx), M, T, nd, lib.ptr(ws),
+                                         ws.numel(), st), "nir_lstm256_bptt")
+            return _BiLSTM256._param_grads(ctx, dgx)
         keep = []
         # the two directions are independent chains of 2 T small launches each (a [M,256] x [256,1024] GEMM is latency-bound): the reverse
         # direction runs on a side stream (forked / joined through events: inside a captured step two branches of the graph).  Everything both
@@ -801,6 +809,16 @@ class _BiLSTM256(Function):
                                                    lib.ptr(dh_rec), H, M, H, 4 * H, 0, st), "nir_linear_f32")
         if side is not None:
             main.wait_stream(side)
+        return _BiLSTM256._param_grads(ctx, dgx)
+
+    @staticmethod
+    def _param_grads(ctx, dgx):
+        x2, lens64, wih, whh, out, act, cst = ctx.saved_tensors
+        L = lib.load()
+        nd = ctx.nd
+        M, T, I = ctx.dims
+        H, G = 256, nd * 1024
+        dev = x2.device
         st = lib.stream()
         dg2 = dgx.view(M * T, G)
         dx = _linear_raw(dg2, _transpose(wih), None, 0).view(M, T, I) if ctx.needs_input_grad[0] else None

@@ -104,6 +104,8 @@ SIGNATURES = {
     "nir_lstm256_workspace_bytes": (_z, [_l, _i]),
     "nir_lstm256_rows_fwd": (_i, [c_fp, c_ip, c_ip, C.c_void_p, c_fp, _i, C.c_void_p, _l, _l, _i, _i, C.c_void_p, _z, c_st]),
     "nir_lstm256_train_fwd": (_i, [c_fp, c_ip, C.c_void_p, c_fp, c_fp, c_fp, C.c_void_p, _l, _i, _i, C.c_void_p, C.c_size_t, c_st]),
+    "nir_lstm256_bptt_workspace_bytes": (_z, [_l, _i]),
+    "nir_lstm256_bptt": (_i, [c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, _l, _i, _i, C.c_void_p, C.c_size_t, c_st]),
     "nir_decode_greedy_plain_workspace_bytes": (_z, [_l, _i, _l]),
     "nir_decode_greedy_plain": (_i, [c_fp, c_fp, _l, _i, c_fp, _l, _i, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _l, c_ip, _l, _i, C.c_void_p, _z, c_ip,
                                      c_st]),

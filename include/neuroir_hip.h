@@ -518,6 +518,14 @@ int nir_lstm256_rows_fwd(const float* rows, const int64_t* ids, const int64_t* l
  * and cst [M,T,ndir,256] cell states of every valid step -- the inputs of the backward pass (autograd._BiLSTM256).  err_flag as above. */
 int nir_lstm256_train_fwd(const float* gates_perm, const int64_t* lengths, const void* whh_frag, float* out, float* act, float* cst,
                           int* err_flag, int64_t M, int T, int ndir, void* workspace, size_t workspace_bytes, nir_stream_t stream);
+/* BPTT of the same encoder (csrc/lstm256_bptt.hip; the backward of neuroir/multitask/mnsrf.py:62-114's nn.LSTM under models/multitask.py:161-223):
+ * dout [M,T,ndir*256] = gradient of the memory bank, act / cst as nir_lstm256_train_fwd stored them, w_hh [ndir,1024,256] fp32 ->
+ * dgates [M,T,ndir*1024] (gate order i,f,g,o per direction; zero at t >= length): the operand of dW_ih / dW_hh / db / dx.  T launches, each one
+ * step of BOTH directions: the gate gradients of the step and the partial products dg W_hh of eight unit slices (fp32 MFMA, summed in a fixed order
+ * by the next launch: deterministic).  workspace: nir_lstm256_bptt_workspace_bytes(M, ndir) (partials + cell-state gradients, ping-pong). */
+size_t nir_lstm256_bptt_workspace_bytes(int64_t M, int ndir);
+int nir_lstm256_bptt(const float* dout, const float* act, const float* cst, const int64_t* lengths, const float* w_hh, float* dgates,
+                     int64_t M, int T, int ndir, void* workspace, size_t workspace_bytes, nir_stream_t stream);
 
 /* The same streaming recurrence for either cell of the reference's RNNEncoder (rnn_encoder.py:28-60: getattr(nn, rnn_type), one module per
  * layer): NIR_CELL_LSTM = nir_bilstm_steps_fwd; NIR_CELL_GRU: torch.nn.GRU semantics, gate order (r, z, n), gates_in = x W_ih^T + b_ih

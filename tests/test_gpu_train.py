@@ -41,7 +41,8 @@ def test_linear_backward(M, N, K, act):
 
 
 @pytest.mark.parametrize("H,I,M,T_,bi", [(15, 40, 7, 6, True), (70, 40, 33, 20, True), (128, 300, 19, 12, True), (64, 256, 16, 7, False),
-                                         (128, 64, 3, 64, True), (1, 4, 2, 3, True), (128, 300, 640, 64, True), (96, 132, 1100, 30, False), (128, 40, 37, 9, False), (100, 40, 21, 11, True), (65, 24, 18, 5, True), (256, 40, 37, 9, True), (256, 24, 70, 5, False)])
+                                         (128, 64, 3, 64, True), (1, 4, 2, 3, True), (128, 300, 640, 64, True), (96, 132, 1100, 30, False), (128, 40, 37, 9, False), (100, 40, 21, 11, True), (65, 24, 18, 5, True), (256, 40, 37, 9, True), (256, 24, 70, 5, False),
+                                         (256, 16, 1120, 6, True), (256, 16, 700, 5, True), (256, 8, 530, 3, False), (256, 8, 300, 1, True)])
 def test_bilstm_backward(H, I, M, T_, bi):
     """Train-mode recurrence + BPTT against torch autograd through the oracle's pack/sort/nn.LSTM restatement."""
     from context_attentive_ir_amd import autograd as A
@@ -59,12 +60,13 @@ def test_bilstm_backward(H, I, M, T_, bi):
     xd = x.to(DEV).requires_grad_(True)
     for packed, split in ((False, True), (True, False)):       # (64 < H <= 128: split-fp16 and fp32 recurrence; other H: the flag changes nothing)
         A.PACKED_WGRAD, A.SPLIT_TRAIN_FWD = packed, split
+        A.FUSED_BPTT256 = not packed                           # (H = 256: the one-launch-per-step BPTT and the cell kernel + GEMM per step form)
         try:
             lstm.zero_grad(); xd.grad = None
             out = A.bilstm(xd, lens.to(DEV), lstm)
             out.backward(dout.to(DEV))
         finally:
-            A.PACKED_WGRAD, A.SPLIT_TRAIN_FWD = False, True
+            A.PACKED_WGRAD, A.SPLIT_TRAIN_FWD, A.FUSED_BPTT256 = False, True, True
         _rel(out, ref, 2e-5); _rel(xd.grad, xr.grad)
         for k, p in lstm.named_parameters():
             _rel(p.grad, sd["e.rnns.0." + k].grad)

@@ -42,9 +42,11 @@ def main():
                                                                       sum(v[1] for k, v in tot.items() if not k.startswith("NIR:"))))
     for k, (c, u) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
         print("%-36s %4d %9.1f" % (k, c, u))
-    if "--order" in sys.argv:
+    if "--order" in sys.argv:                     # start offset, duration, gap to the latest end so far (idle device time in front of the kernel)
+        t0, prev = step[0][1], step[0][1]
         for n, s, e in step:
-            print("  %-34s %7.1f" % (short(n), (e - s) / 1000.0))
+            print("  %9.1f  %-34s %7.1f  gap %6.1f" % ((s - t0) / 1000.0, short(n), (e - s) / 1000.0, (s - prev) / 1000.0))
+            prev = max(prev, e)
 
 
 if __name__ == "__main__":
