@@ -655,7 +655,7 @@ def run_config(name, c, args, env, steps, warmup, shard, want_cpu=False, with_h2
             lib.set_batches_in_flight(hint, lanes)
     _phase(name, "setup done, capturing")
     macro_single = (plan is None and (not env.multi or not sharded) and macro_batch(c) > 1
-                    and c["model"] in ("cars", "m_match_tensor", "match_tensor", "esm", "drmm", "duet"))
+                    and c["model"] in ("cars", "m_match_tensor", "mnsrf", "match_tensor", "esm", "drmm", "duet"))
     if (staged and plan.aligned) or macro_single:
         try:
             # pair axis: a lane's hipGraph holds KG whole steps ( encode own sessions -> tail -> probabilities ) merged into one macro-batch,

@@ -148,15 +148,16 @@ class Multitask(WrapperBase):
         not depend on the number of sessions).  Every batch keeps the click mask's batch-wide count m of ITS OWN batch
         (cars.py:285-289 via nir_cars_click_max / labels_groups), so the result equals k separate predict() calls -- it is how a serving loop
         should feed this model when several batches are waiting.  out (optional): [k*B,S,N] result buffer."""
-        if self.type == "M_MATCH_TENSOR" and not suggest:
-            # every (query, candidate) row of the interaction head is independent of the rest of its batch (mmtensor.py:127-189): plain
-            # concatenation along the session axis, one launch sequence over k x the rows
+        if self.type in ("M_MATCH_TENSOR", "MNSRF") and not suggest:
+            # every (query, candidate) row of the interaction head is independent of the rest of its batch (mmtensor.py:127-189), and so is
+            # every session of MNSRF (its session LSTM runs per session, mnsrf.py:62-162; no batch-wide quantity): plain concatenation
+            # along the session axis, one launch sequence over k x the rows
             self.network.eval()
             cat = lambda key: torch.cat([self._dev(e[key]) for e in exs]) if len(exs) > 1 else self._dev(exs[0][key])     # noqa: E731
             probs = self.predict_groups({k_: cat(k_) for k_ in self._FIELDS[:4]}, len(exs), out=out)
             return probs.view(len(exs), -1, *probs.shape[1:])
         if self.type != "CARS":
-            raise NotImplementedError("predict_many is built for CARS (and the ranking path of M_MATCH_TENSOR)")
+            raise NotImplementedError("predict_many is built for CARS (and the ranking path of M_MATCH_TENSOR / MNSRF)")
         self.network.eval()
         cat = lambda key: torch.cat([self._dev(e[key]) for e in exs]) if len(exs) > 1 else self._dev(exs[0][key])     # noqa: E731
         labels = [self._dev(e["document_labels"]) for e in exs]
@@ -195,7 +196,7 @@ class Multitask(WrapperBase):
         probabilities [groups*B,S,N]; block g uses the click count of its own B sessions (graph_runner.StreamingSessionPredictor collates
         `groups` batches into one wire block).  click_max int32 [groups] (device, optional): block g is a SLICE of its batch and takes
         the batch's click count from here (the sharded stream, sharding.StreamShardPlan mode "pair")."""
-        if self.type == "M_MATCH_TENSOR" and click_max is None:
+        if self.type in ("M_MATCH_TENSOR", "MNSRF") and click_max is None:
             self.network.eval()
             s = self._rank(ex, False)[0].contiguous()                  # [groups*B,S,N]: the rows do not see each other
             if out is None:
@@ -203,7 +204,7 @@ class Multitask(WrapperBase):
             lib.check(lib.load().nir_softmax_rows(lib.ptr(s), lib.ptr(out), s.shape[0] * s.shape[1], s.shape[2], lib.stream()), "nir_softmax_rows")
             return out.view_as(s)
         if self.type != "CARS":
-            raise NotImplementedError("predict_groups is built for CARS (and the ranking path of M_MATCH_TENSOR)")
+            raise NotImplementedError("predict_groups is built for CARS (and the ranking path of M_MATCH_TENSOR / MNSRF)")
         self.network.eval()
         pooled, _, _ = self.network.encode(self._dev(ex["source_words"]), self._dev(ex["source_lens"]))
         docs = self.network.encode_document(self._dev(ex["document_words"]), self._dev(ex["document_lens"]))

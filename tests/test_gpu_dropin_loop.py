@@ -226,6 +226,31 @@ def test_m_match_tensor_ranking_path_skips_encode_and_macro_batches_bit_equal():
     w.check_ids()
 
 
+def test_mnsrf_macro_batches_equal_separate_predicts():
+    """MNSRF: predict_many / predict_groups (k batches concatenated along the session axis: a session never sees another one, mnsrf.py:62-162) equal
+    k separate predict() calls to rounding (the row count picks other GEMM tilings: 5e-8 measured), predict_groups equals predict_many bit for bit,
+    both within 1e-4 of the oracle; at the bench's macro-batch of 8 x 16 sessions too."""
+    from oracle import neuroir_cpu as O
+    w = _multitask("MNSRF")
+    w.args.predict_graphs = False
+    exs = [synth.session_batch(3, 4, 5, 4, 12, V, seed=70 + s, full_length=(s % 2 == 0)) for s in range(3)]
+    singles = [w.predict(ex, suggest=False)["click_scores"] for ex in exs]
+    many = w.predict_many(exs)
+    assert many.shape == (3, 3, 4, 5)
+    for i in range(3):
+        assert float((many[i] - singles[i]).abs().max()) < 1e-6
+    cat = {k: torch.cat([e[k] for e in exs]) for k in w._FIELDS}
+    assert torch.equal(w.predict_groups(cat, 3), many.view(9, 4, 5))
+    sd = {k: v.detach().cpu() for k, v in w.network.state_dict().items()}
+    ref = torch.softmax(O.mnsrf_scores(sd, exs[1]["source_words"], exs[1]["source_lens"], exs[1]["document_words"], exs[1]["document_lens"]), -1)
+    assert float((singles[1].cpu() - ref.view_as(singles[1])).abs().max()) < 1e-4
+    big = [synth.session_batch(16, 7, 10, 4, 64, V, seed=90 + s) for s in range(8)]
+    mb = w.predict_many(big)
+    for i in (0, 3, 7):
+        assert float((mb[i] - w.predict(big[i], suggest=False)["click_scores"]).abs().max()) < 2e-6     # (M changes the cluster grid, not the arithmetic)
+    w.check_ids()
+
+
 def test_predict_returns_the_references_dict_for_a_collated_batch():
     """For a batch in the reference's collate layout (`ids`, `source_tokens`, `target_tokens`, `session_len`, `batch_size`) predict() returns what
     models/multitask.py:294-316 returns -- decoded suggestion strings (step-major), `ex_ids`, `targets`, `src_sequences`, `click_scores` -- so that
