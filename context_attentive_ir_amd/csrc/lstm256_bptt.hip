@@ -17,7 +17,7 @@
 //   Measured (MI355X, M = 1120, T = 64, both directions): 25 us per step launch against 2 x (8 + 25) us of the cell kernel + GEMM pair; the step moves
 //   ~66 MB (activations 9, gate gradients 9, partials 18 + 18, states / dout / dc 12) in 128-byte runs at ~2.6 TB/s: traffic-bound, the 9.3 us of
 //   fp32 MFMA work per workgroup hide under it (RT = 1..4, i.e. two smaller workgroups per CU, measured slower: 1.87 / 2.0 / 1.9 / 2.27 ms per 64 steps
-//   against 1.59).
+//   against 1.59; four K slices of 64 units x RT = 3 -- half the partials -- 1.585 ms: the template keeps the parameter, the host uses 8).
 #include "common.hpp"
 
 namespace nir {
@@ -39,11 +39,11 @@ struct Bptt256Args {
     int T, ND, s;
 };
 
-constexpr int B256_KS = 8, B256_KU = 32, B256_RS = 36;
+constexpr int B256_KS = 8;          // (host: workspace sizing = the largest split)
 
-template <int RT, bool FIRST>
-__global__ __launch_bounds__(512, RT <= 3 ? 2 : 1) void lstm256_bptt_step_kernel(Bptt256Args p) {
-    constexpr int H = 256, H4 = 1024, KS = B256_KS, KU = B256_KU, RS = B256_RS, ROWS = 16 * RT;
+template <int RT, bool FIRST, int KS>
+__global__ __launch_bounds__(512, 1) void lstm256_bptt_step_kernel(Bptt256Args p) {
+    constexpr int H = 256, H4 = 1024, KU = H / KS, RS = KU + 4, ROWS = 16 * RT, NSP = KU / 32, RPP = 512 / KU;   // sub-passes per tile, rows per sub-pass
     __shared__ __attribute__((aligned(16))) float bs[ROWS * 4 * RS];       // [row][k & 3][k >> 2], k = gate * 32 + local unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sq = lane & 15, pq = lane >> 4;
     const int km = blockIdx.y, dir = blockIdx.z;
@@ -52,12 +52,12 @@ __global__ __launch_bounds__(512, RT <= 3 ? 2 : 1) void lstm256_bptt_step_kernel
     const int t = dir == 0 ? T - 1 - p.s : p.s, tprev = dir == 0 ? t - 1 : t + 1;
     const bool prod = p.dhp_out != nullptr;
     // A fragments of the wave's two unit tiles (units 32 wave .. 32 wave + 31): lane (unit = sq, k = 4 ks + pq) -- requested first, used in phase 2
-    float afr[2][32];
+    float afr[2][KU];
     if (prod) {
         const float* w = p.whh + (int64_t)dir * H4 * H + 32 * wave + sq;
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) {
-            const int kl = 4 * ks + pq, row = (kl >> 5) * H + km * KU + (kl & 31);
+        for (int ks = 0; ks < KU; ++ks) {
+            const int kl = 4 * ks + pq, row = (kl / KU) * H + km * KU + (kl % KU);
 #pragma unroll
             for (int i = 0; i < 2; ++i) afr[i][ks] = w[(int64_t)row * H + 16 * i];
         }
@@ -65,18 +65,19 @@ __global__ __launch_bounds__(512, RT <= 3 ? 2 : 1) void lstm256_bptt_step_kernel
     // phase 1: the member's cells.  Thread -> (row tid >> 5 of a 16-row pass, local unit tid & 31): 128-byte runs of every operand row.  All operands
     // of all RT passes are requested up front, unconditionally from clamped addresses (a per-pass conditional load chain is 4 dependent memory
     // round trips per pass); the masks are selects on the loaded values
-    const int ul = tid & 31, u = km * KU + ul;
+    const int ul = tid % KU, u = km * KU + ul, rsub = tid / KU;
     const int tpc = tprev < 0 ? 0 : (tprev >= T ? T - 1 : tprev);
-    float ra[RT][4], rc[RT], rcp[RT], rdo[RT], rq[RT][KS], rdc[RT];
-    int64_t rlen[RT];
+    constexpr int NP = RT * NSP;                               // passes of RPP rows: pass = tile * NSP + sub-pass, row = 16 tile + RPP sub + rsub
+    float ra[NP][4], rc[NP], rcp[NP], rdo[NP], rq[NP][KS], rdc[NP];
+    int64_t rlen[NP];
 #pragma unroll
-    for (int pass = 0; pass < RT; ++pass) {
-        const int64_t m = m0 + pass * 16 + (tid >> 5), mc = m < M ? m : M - 1;
+    for (int pass = 0; pass < NP; ++pass) {
+        const int64_t m = m0 + (pass / NSP) * 16 + (pass % NSP) * RPP + rsub, mc = m < M ? m : M - 1;
         rlen[pass] = p.lens ? p.lens[mc] : (int64_t)T;
     }
 #pragma unroll
-    for (int pass = 0; pass < RT; ++pass) {
-        const int64_t m = m0 + pass * 16 + (tid >> 5), mc = m < M ? m : M - 1;
+    for (int pass = 0; pass < NP; ++pass) {
+        const int64_t m = m0 + (pass / NSP) * 16 + (pass % NSP) * RPP + rsub, mc = m < M ? m : M - 1;
         const int64_t pos = mc * T + t;
         const float* a = p.act + (pos * ND + dir) * (int64_t)H4 + u;
 #pragma unroll
@@ -90,48 +91,55 @@ __global__ __launch_bounds__(512, RT <= 3 ? 2 : 1) void lstm256_bptt_step_kernel
             rdc[pass] = p.dc_in[((int64_t)dir * M + mc) * H + u];
         }
     }
-    // per sequence tile: cells -> LDS -> barrier (LDS only: the later tiles' operands stay in flight) -> the tile's 64 MFMAs per wave -> partial out.
+    // per sequence tile: cells -> LDS -> barrier (LDS only: the later tiles' operands stay in flight) -> the tile's MFMAs -> partial out.
     // Tile p's matrix work runs while the operands of tiles p+1.. are still arriving (the serial form -- all cells, one barrier, all MFMAs -- spent
     // ~10 us in the memory phase and ~9 us in the MFMA phase of a 26.6 us step)
 #pragma unroll
-    for (int pass = 0; pass < RT; ++pass) {
-        const int rl = pass * 16 + (tid >> 5);
-        const int64_t m = m0 + rl;
-        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, dcn = 0.f;
-        if (m < M) {
-            const int64_t l = rlen[pass];
-            const int len = l < 0 ? 0 : (l > T ? T : (int)l);
-            if (t < len) {
-                const float i_ = ra[pass][0], f_ = ra[pass][1], g_ = ra[pass][2], o_ = ra[pass][3];
-                const float th = tanhf(rc[pass]);
-                const float cp = (tprev >= 0 && tprev < len) ? rcp[pass] : 0.f;
-                float dh = 0.f, dc = 0.f;
-                if (!FIRST) {
-                    const float* q = rq[pass];
-                    dh = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-                    dc = rdc[pass];
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int sp = 0; sp < NSP; ++sp) {
+            const int pass = rt * NSP + sp;
+            const int rl = rt * 16 + sp * RPP + rsub;
+            const int64_t m = m0 + rl;
+            float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, dcn = 0.f;
+            if (m < M) {
+                const int64_t l = rlen[pass];
+                const int len = l < 0 ? 0 : (l > T ? T : (int)l);
+                if (t < len) {
+                    const float i_ = ra[pass][0], f_ = ra[pass][1], g_ = ra[pass][2], o_ = ra[pass][3];
+                    const float th = tanhf(rc[pass]);
+                    const float cp = (tprev >= 0 && tprev < len) ? rcp[pass] : 0.f;
+                    float dh = 0.f, dc = 0.f;
+                    if (!FIRST) {
+                        const float* q = rq[pass];
+                        if (KS == 8) dh = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4 % KS] + q[5 % KS]) + (q[6 % KS] + q[7 % KS]));
+                        else dh = (q[0] + q[1]) + (q[2] + q[3]);
+                        dc = rdc[pass];
+                    }
+                    const float dhh = rdo[pass] + dh;
+                    const float dct = dc + dhh * o_ * (1.f - th * th);
+                    gi = dct * g_ * i_ * (1.f - i_);
+                    gf = dct * cp * f_ * (1.f - f_);
+                    gg = dct * i_ * (1.f - g_ * g_);
+                    go = dhh * th * o_ * (1.f - o_);
+                    dcn = dct * f_;
                 }
-                const float dhh = rdo[pass] + dh;
-                const float dct = dc + dhh * o_ * (1.f - th * th);
-                gi = dct * g_ * i_ * (1.f - i_);
-                gf = dct * cp * f_ * (1.f - f_);
-                gg = dct * i_ * (1.f - g_ * g_);
-                go = dhh * th * o_ * (1.f - o_);
-                dcn = dct * f_;
+                float* o = p.dgx + (m * T + t) * (int64_t)(ND * H4) + dir * H4;
+                o[u] = gi; o[H + u] = gf; o[2 * H + u] = gg; o[3 * H + u] = go;
+                p.dc_out[((int64_t)dir * M + m) * H + u] = dcn;
             }
-            float* o = p.dgx + (m * T + t) * (int64_t)(ND * H4) + dir * H4;
-            o[u] = gi; o[H + u] = gf; o[2 * H + u] = gg; o[3 * H + u] = go;
-            p.dc_out[((int64_t)dir * M + m) * H + u] = dcn;
+            if (prod) {
+                float* d = bs + (rl * 4 + (ul & 3)) * RS + (ul >> 2);          // k = g * KU + ul -> (k & 3, k >> 2) = (ul & 3, g KU/4 + (ul >> 2))
+                d[0] = gi; d[KU / 4] = gf; d[2 * (KU / 4)] = gg; d[3 * (KU / 4)] = go;
+            }
         }
         if (!prod) continue;
-        float* d = bs + (rl * 4 + (ul & 3)) * RS + (ul >> 2);              // k = g * 32 + ul -> (k & 3, k >> 2) = (ul & 3, 8 g + (ul >> 2))
-        d[0] = gi; d[8] = gf; d[16] = gg; d[24] = go;
         lds_barrier();
-        // partial dh_prev[unit, seq] += W_hh[k, unit] dg[seq, k] over the member's 128 gate rows, sequence tile `pass`
+        // partial dh_prev[unit, seq] += W_hh[k, unit] dg[seq, k] over the member's 4 KU gate rows, sequence tile rt
         f32x4_b acc0 = (f32x4_b){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        const float* bp = bs + ((16 * pass + sq) * 4 + pq) * RS;
+        const float* bp = bs + ((16 * rt + sq) * 4 + pq) * RS;
 #pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
+        for (int k4 = 0; k4 < KU / 4; ++k4) {
             const float4 b = *reinterpret_cast<const float4*>(bp + 4 * k4);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[0][4 * k4 + 0], b.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][4 * k4 + 0], b.x, acc1, 0, 0, 0);
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 2 : 1) void lstm256_bptt_step_kernel
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][4 * k4 + 3], b.w, acc1, 0, 0, 0);
         }
         // D lane (seq = sq, units 4 pq + r of the tile) -> dhp[km][dir][m][unit]
-        const int64_t mo = m0 + 16 * pass + sq;
+        const int64_t mo = m0 + 16 * rt + sq;
         if (mo < M) {
             float* o = p.dhp_out + (((int64_t)km * ND + dir) * M + mo) * H + 32 * wave + 4 * pq;
             *reinterpret_cast<float4*>(o) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
@@ -174,9 +182,10 @@ extern "C" int nir_lstm256_bptt(const float* dout, const float* act, const float
     float* dhp[2] = {ws, ws + nhp};
     float* dcb[2] = {ws + 2 * nhp, ws + 2 * nhp + ndc};
     const int64_t tiles = (M + 15) / 16;
-    int RT = (int)((tiles * B256_KS * ndir + 255) / 256);
+    const int KS = 8;            // (KS = 4 x RT = 3 -- half the partial traffic, 192 workgroups, 11 us of MFMA work each -- measured equal: 1.585 vs 1.590 ms)
+    int RT = (int)((tiles * KS * ndir + 255) / 256);
     RT = RT < 1 ? 1 : (RT > 5 ? 5 : RT);
-    const dim3 grid((unsigned)((tiles + RT - 1) / RT), B256_KS, (unsigned)ndir);
+    const dim3 grid((unsigned)((tiles + RT - 1) / RT), (unsigned)KS, (unsigned)ndir);
     ProfScope ps(prof_shape_name("lstm256_bptt_step_kernel", (long long)M, T, 256), st);
     for (int s = 0; s < T; ++s) {
         Bptt256Args a;
@@ -188,8 +197,11 @@ extern "C" int nir_lstm256_bptt(const float* dout, const float* act, const float
         a.M = M; a.T = T; a.ND = ndir; a.s = s;
 #define NIR_B256_LAUNCH(rt)                                                                                        \
     do {                                                                                                           \
-        if (s == 0) hipLaunchKernelGGL((lstm256_bptt_step_kernel<rt, true>), grid, dim3(512), 0, st, a);           \
-        else hipLaunchKernelGGL((lstm256_bptt_step_kernel<rt, false>), grid, dim3(512), 0, st, a);                 \
+        if (KS == 4 && rt <= 4) {                                                                                  \
+            if (s == 0) hipLaunchKernelGGL((lstm256_bptt_step_kernel<(rt > 4 ? 4 : rt), true, 4>), grid, dim3(512), 0, st, a);     \
+            else hipLaunchKernelGGL((lstm256_bptt_step_kernel<(rt > 4 ? 4 : rt), false, 4>), grid, dim3(512), 0, st, a);           \
+        } else if (s == 0) hipLaunchKernelGGL((lstm256_bptt_step_kernel<rt, true, 8>), grid, dim3(512), 0, st, a); \
+        else hipLaunchKernelGGL((lstm256_bptt_step_kernel<rt, false, 8>), grid, dim3(512), 0, st, a);              \
     } while (0)
         switch (RT) {
             case 1: NIR_B256_LAUNCH(1); break;
