@@ -667,8 +667,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
         n = n < p.N ? n : p.N - 1;
         wrow[i] = p.w + (int64_t)n * p.ldw;
     }
-    float4 ra[KS][2], rw[KS][2];
-    auto load_tile = [&](int k00, bool tail) {
+    // Two register sets: the tile loaded in iteration kt is staged into LDS at the END of iteration kt + 1 (prefetch distance two k-stages).
+    // Round 6: with one set (tile kt + 1 requested above the MFMAs of tile kt and staged right behind them) an iteration took ~4 000 cycles
+    // against 768 of MFMA issue per wave -- the HBM / L2 round trip of the operand loads, not the matrix pipe, set the pace of every gemm3 launch
+    struct TileRegs { float4 a[KS][2], w[KS][2]; };
+    TileRegs R0, R1;
+    auto load_tile = [&](TileRegs& R, int k00, bool tail) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             int k = k00 + j * G3_BK + 4 * kq;
@@ -678,16 +682,16 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
             for (int i = 0; i < 2; ++i) {
                 const float* src = arow[i];
                 if (MODE == 2) src = k < p.E ? arow[i] : (k < 2 * p.E ? arow1[i] : arow2[i]);
-                ra[j][i] = *reinterpret_cast<const float4*>(src + k);
-                rw[j][i] = *reinterpret_cast<const float4*>(wrow[i] + k);
+                R.a[j][i] = *reinterpret_cast<const float4*>(src + k);
+                R.w[j][i] = *reinterpret_cast<const float4*>(wrow[i] + k);
                 if (tail && !kv) {
-                    ra[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    rw[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    R.a[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    R.w[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const TileRegs& R, int buf) {
 #pragma unroll
         for (int j = 0; j < KS; ++j)
 #pragma unroll
@@ -695,11 +699,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
                 unsigned short* ad = As + (buf * KS + j) * NTERM * G3_PLANE;
                 unsigned short* wd = Ws + (buf * KS + j) * NTERM * G3_PLANE;
                 if (H2) {
-                    g3_split_store_h2(ad, lr + 64 * i, kq, ra[j][i]);
-                    g3_split_store_h2(wd, lr + 64 * i, kq, rw[j][i]);
+                    g3_split_store_h2(ad, lr + 64 * i, kq, R.a[j][i]);
+                    g3_split_store_h2(wd, lr + 64 * i, kq, R.w[j][i]);
                 } else {
-                    g3_split_store(ad, lr + 64 * i, kq, ra[j][i]);
-                    g3_split_store(wd, lr + 64 * i, kq, rw[j][i]);
+                    g3_split_store(ad, lr + 64 * i, kq, R.a[j][i]);
+                    g3_split_store(wd, lr + 64 * i, kq, R.w[j][i]);
                 }
             }
     };
@@ -717,8 +721,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
 
     const int nk = (p.K + KS * G3_BK - 1) / (KS * G3_BK);          // pipeline stages of KS k-tiles
     const bool ktail = (p.K % (KS * G3_BK)) != 0;
-    load_tile(0, nk == 1 && ktail);
-    store_tile(0);
+    const int KSTEP = KS * G3_BK;
+    load_tile(R0, 0, nk == 1 && ktail);
+    store_tile(R0, 0);
+    if (nk > 1) load_tile(R1, KSTEP, nk == 2 && ktail);        // tile 1 is in flight while tile 0 is multiplied
     __syncthreads();
     // fragment address inside a plane: [k-half = lane >> 5][row][8]
     const int foff_a = (lane >> 5) * G3_HALF + (wm * 64 + (lane & 31)) * 8;
@@ -766,24 +772,39 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
         }
       }
     };
-    for (int kt = 0; kt + 2 < nk; ++kt) {              // steady state: the next tile is a full one
-        load_tile((kt + 1) * KS * G3_BK, false);
+    // iteration kt: request tile kt + 2 into the set tile kt left free, multiply tile kt from LDS, stage tile kt + 1 (requested one iteration ago).
+    // Steady state (tile kt + 2 is a full one): no masking code in the loop
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 2) {
+        load_tile(R0, (kt + 2) * KSTEP, false);
         __builtin_amdgcn_sched_barrier(0);             // keep the loads ABOVE the MFMAs (the scheduler sinks them to their first use)
-        mma_tile(kt & 1);
+        mma_tile(0);
         __builtin_amdgcn_sched_barrier(0);
-        store_tile((kt & 1) ^ 1);
+        store_tile(R1, 1);
+        __syncthreads();
+        load_tile(R1, (kt + 3) * KSTEP, (kt + 3 == nk - 1) && ktail);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(R0, 0);
         __syncthreads();
     }
-    if (nk >= 2) {                                     // second-to-last tile: prefetches the (possibly partial) last tile
-        const int kt = nk - 2;
-        load_tile((kt + 1) * KS * G3_BK, ktail);
+    // the last one to three tiles (kt is even: tile kt sits in LDS buffer 0, tile kt + 1 -- if any -- in R1)
+    for (; kt < nk; ++kt) {
+        const bool odd = (kt & 1) != 0;
+        if (kt + 2 < nk) {
+            if (odd) load_tile(R1, (kt + 2) * KSTEP, (kt + 2 == nk - 1) && ktail);
+            else load_tile(R0, (kt + 2) * KSTEP, (kt + 2 == nk - 1) && ktail);
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma_tile(kt & 1);
         __builtin_amdgcn_sched_barrier(0);
-        store_tile((kt & 1) ^ 1);
-        __syncthreads();
+        if (kt + 1 < nk) {
+            if (odd) store_tile(R0, 0);
+            else store_tile(R1, 1);
+            __syncthreads();
+        }
     }
-    mma_tile((nk - 1) & 1);
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
