@@ -774,22 +774,41 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
     };
     // iteration kt: request tile kt + 2 into the set tile kt left free, multiply tile kt from LDS, stage tile kt + 1 (requested one iteration ago).
     // Steady state (tile kt + 2 is a full one): no masking code in the loop
+    // NIR_G3_NOLOAD / NIR_G3_NOMMA / NIR_G3_NOSTORE: timing ablations of the steady-state loop (instrumented variant builds only: results are wrong)
+#ifdef NIR_G3_NOLOAD
+#define G3_LOAD(...)
+#else
+#define G3_LOAD(...) load_tile(__VA_ARGS__)
+#endif
+#ifdef NIR_G3_NOMMA
+#define G3_MMA(b)
+#else
+#define G3_MMA(b) mma_tile(b)
+#endif
+#ifdef NIR_G3_NOSTORE
+#define G3_STORE(...)
+#else
+#define G3_STORE(...) store_tile(__VA_ARGS__)
+#endif
     int kt = 0;
-    for (; kt + 3 < nk; kt += 2) {
-        load_tile(R0, (kt + 2) * KSTEP, false);
+    for (; kt + 4 < nk; kt += 2) {                     // tiles kt + 2 and kt + 3 are full ones: a masked (tail) tile is waited for right behind its request
+        G3_LOAD(R0, (kt + 2) * KSTEP, false);
         __builtin_amdgcn_sched_barrier(0);             // keep the loads ABOVE the MFMAs (the scheduler sinks them to their first use)
-        mma_tile(0);
+        G3_MMA(0);
         __builtin_amdgcn_sched_barrier(0);
-        store_tile(R1, 1);
-        __syncthreads();
-        load_tile(R1, (kt + 3) * KSTEP, (kt + 3 == nk - 1) && ktail);
+        G3_STORE(R1, 1);
+        lds_barrier();                                 // LDS only: __syncthreads() also waits for the tile requested two stages ahead (vmcnt(0))
+        G3_LOAD(R1, (kt + 3) * KSTEP, false);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile(1);
+        G3_MMA(1);
         __builtin_amdgcn_sched_barrier(0);
-        store_tile(R0, 0);
-        __syncthreads();
+        G3_STORE(R0, 0);
+        lds_barrier();                                 // LDS only: __syncthreads() also waits for the tile requested two stages ahead (vmcnt(0))
     }
-    // the last one to three tiles (kt is even: tile kt sits in LDS buffer 0, tile kt + 1 -- if any -- in R1)
+#undef G3_LOAD
+#undef G3_MMA
+#undef G3_STORE
+    // the last one to four tiles (kt is even: tile kt sits in LDS buffer 0, tile kt + 1 -- if any -- in R1)
     for (; kt < nk; ++kt) {
         const bool odd = (kt & 1) != 0;
         if (kt + 2 < nk) {
@@ -802,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs p) {
         if (kt + 1 < nk) {
             if (odd) store_tile(R0, 0);
             else store_tile(R1, 1);
-            __syncthreads();
+            lds_barrier();                                 // LDS only: __syncthreads() also waits for the tile requested two stages ahead (vmcnt(0))
         }
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
