@@ -185,6 +185,10 @@ def kernel_work(name, c, pairs_per_launch=None):
     if base.startswith("lstm_train_fwd_kernel") or base.startswith("lstm_train_bwd_kernel") or base.startswith("lstm_train_bwd_mfma_kernel"):
         # M sequences, N = T steps, K = H units, both directions: the recurrent product h W_hh^T (forward) / W_hh^T dg (BPTT), f32 MFMA
         return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * 2 * (4 * K + 2 * K) * 4.0, terms=1, pipe=F32)
+    if base.startswith("lstm256_bptt_steps"):
+        # csrc/lstm256_bptt.hip: ONE label for the T step launches of a BPTT (both directions): dg W_hh on the f32 MFMA; bytes per step and direction:
+        # activations + gate gradients (2 x 4K), cell states x 2, dout, dc in / out, eight dh partials written and read (16K)
+        return dict(flops=M * N * 2 * 2.0 * 4 * K * K, bytes=M * N * 2 * (8 * K + 5 * K + 16 * K) * 4.0, terms=1, pipe=F32)
     if base in ("esm16_kernel", "esm_kernel", "drmm_kernel"):
         fl = flops_per_pair(c["model"], QL, DL) or (2.0 * DL * E if base != "drmm_kernel" else 2.0 * QL * DL * E)
         return dict(flops=fl * pairs, bytes=algorithmic_bytes_per_pair(NC, QL, DL) * pairs, terms=0, pipe=F32)   # VALU kernels: no MFMA

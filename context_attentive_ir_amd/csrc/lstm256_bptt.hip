@@ -186,7 +186,7 @@ extern "C" int nir_lstm256_bptt(const float* dout, const float* act, const float
     int RT = (int)((tiles * KS * ndir + 255) / 256);
     RT = RT < 1 ? 1 : (RT > 5 ? 5 : RT);
     const dim3 grid((unsigned)((tiles + RT - 1) / RT), (unsigned)KS, (unsigned)ndir);
-    ProfScope ps(prof_shape_name("lstm256_bptt_step_kernel", (long long)M, T, 256), st);
+    ProfScope ps(prof_shape_name("lstm256_bptt_steps", (long long)M, T, 256), st);      // ONE label for the T launches of lstm256_bptt_step_kernel
     for (int s = 0; s < T; ++s) {
         Bptt256Args a;
         a.dout = dout; a.act = act; a.cst = cst; a.lens = lengths; a.whh = w_hh; a.dgx = dgates;
