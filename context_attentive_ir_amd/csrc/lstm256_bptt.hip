@@ -59,7 +59,11 @@ __global__ __launch_bounds__(512, 1) void lstm256_bptt_step_kernel(Bptt256Args p
         for (int ks = 0; ks < KU; ++ks) {
             const int kl = 4 * ks + pq, row = (kl / KU) * H + km * KU + (kl % KU);
 #pragma unroll
+#ifdef NIR_B256_NOA
+            for (int i = 0; i < 2; ++i) afr[i][ks] = (float)(row + i);
+#else
             for (int i = 0; i < 2; ++i) afr[i][ks] = w[(int64_t)row * H + 16 * i];
+#endif
         }
     }
     // phase 1: the member's cells.  Thread -> (row tid >> 5 of a 16-row pass, local unit tid & 31): 128-byte runs of every operand row.  All operands
@@ -86,8 +90,14 @@ __global__ __launch_bounds__(512, 1) void lstm256_bptt_step_kernel(Bptt256Args p
         rcp[pass] = p.cst[((mc * T + tpc) * ND + dir) * (int64_t)H + u];
         rdo[pass] = p.dout[pos * (int64_t)(ND * H) + dir * H + u];
         if (!FIRST) {
+// NIR_B256_NOPART / NIR_B256_NOMMA / NIR_B256_NODGX / NIR_B256_NOA: timing ablations (instrumented variant builds only; results are wrong)
+#ifdef NIR_B256_NOPART
+#pragma unroll
+            for (int k = 0; k < KS; ++k) rq[pass][k] = 0.f;
+#else
 #pragma unroll
             for (int k = 0; k < KS; ++k) rq[pass][k] = p.dhp_in[(((int64_t)k * ND + dir) * M + mc) * H + u];
+#endif
             rdc[pass] = p.dc_in[((int64_t)dir * M + mc) * H + u];
         }
     }
@@ -124,8 +134,10 @@ __global__ __launch_bounds__(512, 1) void lstm256_bptt_step_kernel(Bptt256Args p
                     go = dhh * th * o_ * (1.f - o_);
                     dcn = dct * f_;
                 }
+#ifndef NIR_B256_NODGX
                 float* o = p.dgx + (m * T + t) * (int64_t)(ND * H4) + dir * H4;
                 o[u] = gi; o[H + u] = gf; o[2 * H + u] = gg; o[3 * H + u] = go;
+#endif
                 p.dc_out[((int64_t)dir * M + m) * H + u] = dcn;
             }
             if (prod) {
@@ -138,6 +150,7 @@ __global__ __launch_bounds__(512, 1) void lstm256_bptt_step_kernel(Bptt256Args p
         // partial dh_prev[unit, seq] += W_hh[k, unit] dg[seq, k] over the member's 4 KU gate rows, sequence tile rt
         f32x4_b acc0 = (f32x4_b){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         const float* bp = bs + ((16 * rt + sq) * 4 + pq) * RS;
+#ifndef NIR_B256_NOMMA
 #pragma unroll
         for (int k4 = 0; k4 < KU / 4; ++k4) {
             const float4 b = *reinterpret_cast<const float4*>(bp + 4 * k4);
@@ -150,9 +163,16 @@ __global__ __launch_bounds__(512, 1) void lstm256_bptt_step_kernel(Bptt256Args p
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[0][4 * k4 + 3], b.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][4 * k4 + 3], b.w, acc1, 0, 0, 0);
         }
+#else
+        acc0[0] = bp[0] + afr[0][0] + afr[1][KU - 1];
+#endif
         // D lane (seq = sq, units 4 pq + r of the tile) -> dhp[km][dir][m][unit]
         const int64_t mo = m0 + 16 * rt + sq;
+#ifdef NIR_B256_NOPART
+        if (mo < M && acc0[0] == 12345.678f) {
+#else
         if (mo < M) {
+#endif
             float* o = p.dhp_out + (((int64_t)km * ND + dir) * M + mo) * H + 32 * wave + 4 * pq;
             *reinterpret_cast<float4*>(o) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
             *reinterpret_cast<float4*>(o + 16) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
