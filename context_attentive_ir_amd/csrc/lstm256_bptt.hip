@@ -19,6 +19,7 @@
 //   fp32 MFMA work per workgroup hide under it (RT = 1..4, i.e. two smaller workgroups per CU, measured slower: 1.87 / 2.0 / 1.9 / 2.27 ms per 64 steps
 //   against 1.59; four K slices of 64 units x RT = 3 -- half the partials -- 1.585 ms: the template keeps the parameter, the host uses 8).
 #include "common.hpp"
+#include <algorithm>
 
 namespace nir {
 
@@ -37,6 +38,7 @@ struct Bptt256Args {
     float* dgx;              // [M,T,ND*1024]
     int64_t M;
     int T, ND, s;
+    int dir0;                // first direction of this launch (grid.z = directions of the launch)
 };
 
 constexpr int B256_KS = 8;          // (host: workspace sizing = the largest split)
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(512, 1) void lstm256_bptt_step_kernel(Bptt256Args p
     constexpr int H = 256, H4 = 1024, KU = H / KS, RS = KU + 4, ROWS = 16 * RT, NSP = KU / 32, RPP = 512 / KU;   // sub-passes per tile, rows per sub-pass
     __shared__ __attribute__((aligned(16))) float bs[ROWS * 4 * RS];       // [row][k & 3][k >> 2], k = gate * 32 + local unit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sq = lane & 15, pq = lane >> 4;
-    const int km = blockIdx.y, dir = blockIdx.z;
+    const int km = blockIdx.y, dir = blockIdx.z + p.dir0;
     const int64_t m0 = (int64_t)blockIdx.x * ROWS, M = p.M;
     const int T = p.T, ND = p.ND;
     const int t = dir == 0 ? T - 1 - p.s : p.s, tprev = dir == 0 ? t - 1 : t + 1;
@@ -205,23 +207,24 @@ extern "C" int nir_lstm256_bptt(const float* dout, const float* act, const float
     const int KS = 8;            // (KS = 4 x RT = 3 -- half the partial traffic, 192 workgroups, 11 us of MFMA work each -- measured equal: 1.585 vs 1.590 ms)
     int RT = (int)((tiles * KS * ndir + 255) / 256);
     RT = RT < 1 ? 1 : (RT > 5 ? 5 : RT);
+    // (Measured and not kept: the two directions as two chains of half-size launches on two streams -- 112 + 112 workgroups that could drift apart, one
+    // direction's operand burst under the other's MFMA phase: 1 602 / 1 630 us per BPTT (eager / graphed) against 1 590 / 1 593 for one launch per step.)
     const dim3 grid((unsigned)((tiles + RT - 1) / RT), (unsigned)KS, (unsigned)ndir);
     ProfScope ps(prof_shape_name("lstm256_bptt_steps", (long long)M, T, 256), st);      // ONE label for the T launches of lstm256_bptt_step_kernel
-    for (int s = 0; s < T; ++s) {
+    {
+      hipStream_t sl = st;
+      for (int s = 0; s < T; ++s) {
         Bptt256Args a;
         a.dout = dout; a.act = act; a.cst = cst; a.lens = lengths; a.whh = w_hh; a.dgx = dgates;
         a.dhp_in = s ? dhp[(s + 1) & 1] : nullptr;
         a.dc_in = s ? dcb[(s + 1) & 1] : nullptr;
         a.dhp_out = s + 1 < T ? dhp[s & 1] : nullptr;
         a.dc_out = dcb[s & 1];
-        a.M = M; a.T = T; a.ND = ndir; a.s = s;
+        a.M = M; a.T = T; a.ND = ndir; a.s = s; a.dir0 = 0;
 #define NIR_B256_LAUNCH(rt)                                                                                        \
     do {                                                                                                           \
-        if (KS == 4 && rt <= 4) {                                                                                  \
-            if (s == 0) hipLaunchKernelGGL((lstm256_bptt_step_kernel<(rt > 4 ? 4 : rt), true, 4>), grid, dim3(512), 0, st, a);     \
-            else hipLaunchKernelGGL((lstm256_bptt_step_kernel<(rt > 4 ? 4 : rt), false, 4>), grid, dim3(512), 0, st, a);           \
-        } else if (s == 0) hipLaunchKernelGGL((lstm256_bptt_step_kernel<rt, true, 8>), grid, dim3(512), 0, st, a); \
-        else hipLaunchKernelGGL((lstm256_bptt_step_kernel<rt, false, 8>), grid, dim3(512), 0, st, a);              \
+        if (s == 0) hipLaunchKernelGGL((lstm256_bptt_step_kernel<rt, true, 8>), grid, dim3(512), 0, sl, a);        \
+        else hipLaunchKernelGGL((lstm256_bptt_step_kernel<rt, false, 8>), grid, dim3(512), 0, sl, a);              \
     } while (0)
         switch (RT) {
             case 1: NIR_B256_LAUNCH(1); break;
@@ -231,6 +234,7 @@ extern "C" int nir_lstm256_bptt(const float* dout, const float* act, const float
             default: NIR_B256_LAUNCH(5); break;
         }
 #undef NIR_B256_LAUNCH
+      }
     }
     NIR_CHECK_LAUNCH("lstm256_bptt_step_kernel");
     return 0;
