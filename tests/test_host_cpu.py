@@ -674,3 +674,13 @@ def test_native_rank_metrics_equal_the_numpy_definitions():
     with pytest.raises(ZeroDivisionError):
         L.MAP(np.asfortranarray(p), lab)
     assert abs(L.MRR(p, lab) - L.MRR(np.asfortranarray(p), lab)) < 1e-12                  # a row without a relevant candidate counts 0
+
+
+def test_lstm256_bptt_workspace_size_is_a_host_function():
+    """nir_lstm256_bptt_workspace_bytes (csrc/lstm256_bptt.hip): eight dh partials + dc per (direction, sequence, unit), ping-pong, + alignment slack;
+    0 for a direction count the entry point rejects -- callable without a GPU."""
+    from context_attentive_ir_amd import lib
+    L = lib.load()
+    assert L.nir_lstm256_bptt_workspace_bytes(1120, 2) == 2 * 9 * 2 * 1120 * 256 * 4 + 256
+    assert L.nir_lstm256_bptt_workspace_bytes(7, 1) == 2 * 9 * 1 * 7 * 256 * 4 + 256
+    assert L.nir_lstm256_bptt_workspace_bytes(7, 3) == 0
