@@ -18,6 +18,8 @@
 //   ~66 MB (activations 9, gate gradients 9, partials 18 + 18, states / dout / dc 12) in 128-byte runs at ~2.6 TB/s: traffic-bound, the 9.3 us of
 //   fp32 MFMA work per workgroup hide under it (RT = 1..4, i.e. two smaller workgroups per CU, measured slower: 1.87 / 2.0 / 1.9 / 2.27 ms per 64 steps
 //   against 1.59; four K slices of 64 units x RT = 3 -- half the partials -- 1.585 ms: the template keeps the parameter, the host uses 8).
+//   Also measured and not kept: touching the NEXT step's activations / states / dout during this launch (so that they wait in the Infinity Cache):
+//   26.5 us per step against 24.8 -- every extra request lengthens the launch's one operand burst.
 #include "common.hpp"
 #include <algorithm>
 
