@@ -797,6 +797,38 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
                                           float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
                                           const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, const int* m_groups,
                                           int sessions_per_group, nir_stream_t stream) {
+    return nir_cars_rank_session_pre(pooled_q, pooled_docs, labels, B, S, N, w, workspace, workspace_bytes, click_scores, clicks_out, extra, rank_docs, NR,
+                                     labels_all, rows_all, m_groups, sessions_per_group, nullptr, nullptr, stream);
+}
+
+// The two GEMMs of the tail that read the pooled QUERIES only (cars.py:346-361 keys the session attention by the query; :364-378 feeds it to the query
+// chain): U = pooled_q [W_sq^T | W_sd^T | b_sq | b_sd] and the query chain's hoisted input projection gq.  A caller that encodes the queries on a side
+// stream next to the document encoder (wrappers.Multitask._rank under capture) issues them there and hands the results to
+// nir_cars_rank_session_pre: 10.7 us off the one-batch critical path, no additional cross-stream edge.
+extern "C" int nir_cars_session_query_side(const float* pooled_q, int B, int S, const nir_cars_session_weights* w, float* U, float* gq,
+                                           nir_stream_t stream) {
+    using namespace nir;
+    hipStream_t st = (hipStream_t)stream;
+    NIR_REQUIRE(pooled_q && w && B >= 0 && S > 0, "cars_session_query_side: bad arguments");
+    if (B == 0) return 0;
+    const bool q_on = w->q_on != 0, d_on = w->d_on != 0, rank_on = w->rank_on != 0;
+    const int nch = (q_on ? 1 : 0) + (d_on ? 1 : 0), D = w->D, HS = w->HS, NU = nch * HS + nch;
+    const int64_t BS = (int64_t)B * S;
+    const int bnd = (w->rank_bounded & 8) ? ACT_BOUNDED : 0;
+    NIR_REQUIRE(!(nch && rank_on) || (U && w->attn_ut), "cars_session_query_side: U / packed attention weights missing");
+    NIR_REQUIRE(!(nch && q_on) || gq, "cars_session_query_side: gq missing");
+    if (nch && rank_on)
+        NIR_PROPAGATE(launch_linear(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->attn_ut, D, nullptr, nullptr, U, NU, BS, NU, D, NIR_ACT_NONE, st));
+    if (nch && q_on)
+        NIR_PROPAGATE(launch_linear_ex(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->sq_wih, D, w->sq_bih, w->sq_bhh, gq, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, st));
+    return 0;
+}
+
+extern "C" int nir_cars_rank_session_pre(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
+                                         const nir_cars_session_weights* w, void* workspace, size_t workspace_bytes,
+                                         float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra,
+                                         const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, const int* m_groups,
+                                         int sessions_per_group, const float* pre_U, const float* pre_gq, nir_stream_t stream) {
     using namespace nir;
     hipStream_t st = (hipStream_t)stream;
     NIR_REQUIRE(pooled_q && w, "cars_rank_session: null pointer");
@@ -823,8 +855,9 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
     const int64_t BS = (int64_t)B * S, R = BS * N;
     float* clicks = clicks_out ? clicks_out : p.clicks;
     const int NU = nch * HS + nch;
-    float* gq = p.gx;
+    const float* gq = (pre_gq && q_on) ? pre_gq : p.gx;
     float* gd = p.gx + (q_on ? BS * 4 * (int64_t)HS : 0);
+    const float* Uq = (pre_U && nch && rank_on) ? pre_U : p.U;
     const int bnd = (w->rank_bounded & 8) ? ACT_BOUNDED : 0;
     // (Round 6, measured and NOT kept: the two GEMMs that read the pooled QUERIES only -- the attention projection U and the query chain's hoisted
     // input projection -- on a forked stream beside the click MLP / click pooling / the document chain's projection.  Inside a hipGraph every
@@ -832,9 +865,9 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
     {
         hipStream_t sq_ = st;
         // ---- U = pooled_q [W_sq^T | W_sd^T | b_sq | b_sd]  (independent of the chains)
-        if (nch && rank_on)
+        if (nch && rank_on && Uq == p.U)
             NIR_PROPAGATE(launch_linear(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->attn_ut, D, nullptr, nullptr, p.U, NU, BS, NU, D, NIR_ACT_NONE, sq_));
-        if (nch && q_on) NIR_PROPAGATE(launch_linear_ex(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->sq_wih, D, w->sq_bih, w->sq_bhh, gq, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, sq_));
+        if (nch && q_on && gq == p.gx) NIR_PROPAGATE(launch_linear_ex(pooled_q, D, nullptr, nullptr, 0, 0, 0, w->sq_wih, D, w->sq_bih, w->sq_bhh, p.gx, 4 * HS, BS, 4 * HS, D, NIR_ACT_NONE | bnd, nullptr, 0, sq_));
     }
     // ---- encode_clicks (cars.py:262-304)
     if (d_on) {
@@ -896,7 +929,7 @@ extern "C" int nir_cars_rank_session_rows(const float* pooled_q, const float* po
         if (nch) {
             {
                 ProfScope ps("session_attend2_kernel", st);
-                hipLaunchKernelGGL(session_attend2_kernel, dim3((unsigned)BS), dim3(256), 2 * S * sizeof(float), st, p.U, NU, p.Qs, p.Ds, pooled_q, B, S, D, HS,
+                hipLaunchKernelGGL(session_attend2_kernel, dim3((unsigned)BS), dim3(256), 2 * S * sizeof(float), st, Uq, NU, p.Qs, p.Ds, pooled_q, B, S, D, HS,
                                    (int)q_on, (int)d_on, p.xcat);
             }
             NIR_CHECK_LAUNCH("session_attend2_kernel");

@@ -196,6 +196,9 @@ SIGNATURES = {
                                          c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_st]),
     "nir_cars_rank_session_rows": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
                                         c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_fp, _l, C.c_void_p, _i, c_st]),
+    "nir_cars_session_query_side": (_i, [c_fp, _i, _i, C.POINTER(CarsSessionWeights), c_fp, c_fp, c_st]),
+    "nir_cars_rank_session_pre": (_i, [c_fp, c_fp, c_fp, _i, _i, _i, C.POINTER(CarsSessionWeights), C.c_void_p, _z,
+                                       c_fp, c_fp, C.POINTER(CarsSessionOutputs), c_fp, _i, c_fp, _l, C.c_void_p, _i, c_fp, c_fp, c_st]),
     "nir_cars_click_max": (_i, [c_fp, _i, _i, _i, C.c_void_p, c_st]),
     "nir_lstm_step_whh_frag_bytes": (_z, [_i]),
     "nir_lstm_step_pack_whh_frag": (_i, [c_fp, _i, C.c_void_p, C.c_void_p, c_st]),

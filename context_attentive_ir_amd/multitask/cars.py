@@ -367,8 +367,26 @@ class CARS(nn.Module, lib.IdCheck):
         pooled, _ = self._encode_seqs("d", docs.reshape(B * S * N, DL), docs_length.reshape(-1), False)
         return pooled.view(B, S, N, -1)
 
+    def session_query_side(self, pooled_q):
+        """The two GEMMs of the session tail that read the pooled queries only (nir_cars_session_query_side: the session attention's keys U and the
+        query chain's hoisted input projection gq), on the CURRENT stream -> (U, gq) for rank_document(.., query_side=...).  A caller that encodes
+        the queries on a side stream next to the document encoder issues them there: off the one-batch critical path (cars.py:346-378)."""
+        lib.require_device(pooled_q)
+        L = lib.load()
+        B, S, D = pooled_q.shape
+        w = self._session_weights()
+        nch = int(bool(w.struct.q_on)) + int(bool(w.struct.d_on))
+        if nch == 0 or B == 0:
+            return None
+        HS, dev = self._dims["HS"], pooled_q.device
+        pq = pooled_q.float().contiguous()
+        U = torch.empty(B * S, nch * HS + nch, device=dev, dtype=torch.float32) if w.struct.rank_on else None
+        gq = torch.empty(B * S, 4 * HS, device=dev, dtype=torch.float32) if w.struct.q_on else None
+        lib.check(L.nir_cars_session_query_side(lib.ptr(pq), B, S, w.ref(), lib.ptr(U), lib.ptr(gq), lib.stream()), "nir_cars_session_query_side")
+        return U, gq
+
     def _rank_session(self, pooled_q, pooled_docs, labels, want_clicks=False, want_states=False, rank_docs=None, labels_all=None,
-                      labels_groups=None, click_max=None):
+                      labels_groups=None, click_max=None, query_side=None):
         """rank_docs [B,S,NR,D] (optional): the ranker scores only this slice of the candidates -> scores [B,S,NR]; clicks and sessions
         still see all of pooled_docs (candidate-sharded callers).
         labels_all [B_all,S,N] (optional): the inputs are a block of the sessions of a larger batch (session-sharded tail,
@@ -416,10 +434,12 @@ class CARS(nn.Module, lib.IdCheck):
             if lab_all is not None or mg is not None or click_max.dtype != torch.int32 or not click_max.is_cuda or B % click_max.numel():
                 raise RuntimeError("click_max: int32 device tensor [G] with B % G == 0, instead of labels_all / labels_groups")
             mg, spg = click_max, B // click_max.numel()
-        lib.check(L.nir_cars_rank_session_rows(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
-                                               lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
-                                               lib.ptr(rd), NR if rd is not None else 0, lib.ptr(lab_all),
-                                               lab_all.numel() // N if lab_all is not None else 0, lib.ptr(mg), spg, lib.stream()),
+        pre_u, pre_gq = query_side if query_side is not None else (None, None)
+        lib.check(L.nir_cars_rank_session_pre(lib.ptr(pq), lib.ptr(pdv), lib.ptr(lab), B, S, N, w.ref(), lib.ptr(ws), ws.numel(),
+                                              lib.ptr(scores), lib.ptr(clicks), lib.C.byref(extra) if extra is not None else None,
+                                              lib.ptr(rd), NR if rd is not None else 0, lib.ptr(lab_all),
+                                              lab_all.numel() // N if lab_all is not None else 0, lib.ptr(mg), spg, lib.ptr(pre_u), lib.ptr(pre_gq),
+                                              lib.stream()),
                   "nir_cars_rank_session")
         return scores, clicks, outs
 
@@ -433,7 +453,7 @@ class CARS(nn.Module, lib.IdCheck):
         return self._rank_session(dummy_q, docs, doc_labels, want_clicks=True)[1]
 
     def rank_document(self, pooled_rep, document_rep, document_len, document_label, group=None, shard=False, want_states=None,
-                      labels_groups=None, after_documents=None):
+                      labels_groups=None, after_documents=None, query_side=None, encoded_docs=None):
         """cars.py:522-540 -> (click_scores [B,S,N] (or [] when the ranker is off), hidden_states, session_attns).
         hidden_states = (transform_hid(h), transform_cell(c)) [1,(S-1)*B,nhid_decoder] and session_attns = (inner_q, inner_d)
         [B,S,HS] are the decoder inputs (cars.py:382-456); they are produced when `want_states` (default: whenever the
@@ -444,11 +464,15 @@ class CARS(nn.Module, lib.IdCheck):
         labels_groups [G,B0,S,N] (optional): the B = G*B0 sessions are G whole batches merged into one macro-batch (Multitask.predict_many);
         batch g keeps the click count of its own labels.
         after_documents (optional callable): run between the document encoder and the session tail (a caller that produced `pooled_rep` on
-        a side stream joins it here)."""
+        a side stream joins it here).  query_side (optional): session_query_side(pooled_rep) computed by that caller (unsharded path only).
+        encoded_docs (optional, unsharded path): encode_document(document_rep, document_len) the caller already issued (it wanted the document
+        encoder's first launch in front of its side branch)."""
         self._check_eval()
         if want_states is None:
             want_states = not self.no_recommender
-        encoded_docs, own = None, None
+        own = None
+        if shard:
+            encoded_docs = None
         if shard and after_documents is not None:
             after_documents()
             after_documents = None
@@ -466,14 +490,14 @@ class CARS(nn.Module, lib.IdCheck):
             if shard:
                 from .. import sharding
                 encoded_docs, own = sharding.sharded_pooled_docs(self.encode_document, document_rep, document_len, group, return_local=True)
-            else:
+            elif encoded_docs is None:
                 encoded_docs = self.encode_document(document_rep, document_len)
         if after_documents is not None:
             after_documents()
         # candidate-sharded: the ranker MLP scores this rank's slice only (clicks / sessions need every pooled candidate and stay
         # replicated); the score slices are gathered afterwards
         scores, _, outs = self._rank_session(pooled_rep, encoded_docs, document_label, want_states=want_states,
-                                             rank_docs=own if not self.no_ranker else None, labels_groups=labels_groups)
+                                             rank_docs=own if not self.no_ranker else None, labels_groups=labels_groups, query_side=query_side)
         if own is not None and scores is not None:
             from .. import sharding
             scores = sharding.gather_session_scores(scores, document_rep.shape[2], group)

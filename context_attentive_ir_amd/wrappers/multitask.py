@@ -52,7 +52,7 @@ class Multitask(WrapperBase):
             s = self.network.rank_document(src, memory_bank, session_bank, self._dev(ex["document_words"]), self._dev(ex["document_lens"]))
             return s, states, None, (None, None)
         src_lens = self._dev(ex["source_lens"])
-        join = None
+        join = qside = docs = None
         if self.use_cuda and not self.parallel and torch.cuda.is_current_stream_capturing() and lib.batches_in_flight() <= 1:
             # one batch in flight inside a capture (PredictGraphCache, GraphedPredictor): the query encoder (7 of 256 CUs for ~25 us at a C3
             # batch) runs on a side stream next to the document encoder and joins in front of the session tail.  (Eagerly the host is the
@@ -62,14 +62,20 @@ class Multitask(WrapperBase):
                 self._fork_stream = torch.cuda.Stream(device=cur.device)
             side = self._fork_stream
             side.wait_stream(cur)
+            # the document encoder is issued FIRST: a replayed graph dispatches its nodes in creation order, and every node of the side branch in
+            # front of the document recurrence delayed it by ~5 us (tools/iter_timeline.py: 22 us from the gather's end to the recurrence's start
+            # with four side nodes in front, 12 with two)
+            if not (self.network.no_ranker and self.network.no_document_session_encoding):
+                docs = self.network.encode_document(self._dev(ex["document_words"]), self._dev(ex["document_lens"]))
             with torch.cuda.stream(side):
                 pooled, encoded, _ = self.network.encode(self._dev(ex["source_words"]), src_lens)
+                qside = self.network.session_query_side(pooled)      # the tail's two query-only GEMMs ride on the same branch (no extra edge)
             join = lambda: cur.wait_stream(side)             # noqa: E731
         else:
             pooled, encoded, _ = self.network.encode(self._dev(ex["source_words"]), src_lens)
         s, states, attns = self.network.rank_document(pooled, self._dev(ex["document_words"]), self._dev(ex["document_lens"]),
                                                       self._dev(ex["document_labels"]), group=self.group, shard=self.parallel,
-                                                      want_states=want_states, after_documents=join)
+                                                      want_states=want_states, after_documents=join, query_side=qside, encoded_docs=docs)
         return s, states, attns, (encoded, src_lens)
 
     # ---- the candidate-sharded ranking step in two capturable halves (bench.py / a serving loop replays each as a hipGraph and issues

@@ -442,6 +442,18 @@ int nir_cars_rank_session_rows(const float* pooled_q, const float* pooled_docs, 
                                float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra /*host*/,
                                const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, const int* m_groups,
                                int sessions_per_group, nir_stream_t stream);
+/* The query-only part of that tail, callable ahead of it (e.g. on the stream that encodes the queries next to the document encoder):
+ * U [B*S, NU] (NU = nch*HS + nch, nch = session encoders that are on) = pooled_q [W_sq^T | W_sd^T | b_sq | b_sd], the keys of the session attention
+ * (cars.py:346-361), and gq [B*S, 4*HS] = pooled_q W_ih^T + b_ih + b_hh of the query session LSTM (cars.py:364-378).  U / gq may be NULL when
+ * the weights switch their consumer off.  nir_cars_rank_session_pre = nir_cars_rank_session_rows that takes them instead of computing them
+ * (pre_U / pre_gq NULL: computed inside, exactly nir_cars_rank_session_rows). */
+int nir_cars_session_query_side(const float* pooled_q, int B, int S, const nir_cars_session_weights* w /*host*/, float* U, float* gq,
+                                nir_stream_t stream);
+int nir_cars_rank_session_pre(const float* pooled_q, const float* pooled_docs, const float* labels, int B, int S, int N,
+                              const nir_cars_session_weights* w /*host*/, void* workspace, size_t workspace_bytes,
+                              float* click_scores, float* clicks_out, const nir_cars_session_outputs* extra /*host*/,
+                              const float* rank_docs, int NR, const float* labels_all, int64_t rows_all, const int* m_groups,
+                              int sessions_per_group, const float* pre_U, const float* pre_gq, nir_stream_t stream);
 /* m_out[g] = max over the `rows` rows of labels[g] ([groups, rows, N]) of count_nonzero: the batch-wide click count of cars.py:285-289. */
 int nir_cars_click_max(const float* labels, int groups, int rows, int N, int* m_out, nir_stream_t stream);
 

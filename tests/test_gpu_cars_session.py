@@ -102,6 +102,30 @@ def test_cars_session_oracle(B, S, N, QL, DL, kw):
     assert float(agree) >= 0.9, float(agree)
 
 
+@pytest.mark.parametrize("tag", ["full", "qoff", "doff"])
+def test_query_side_computed_ahead_equals_the_tail_computing_it(tag):
+    """nir_cars_session_query_side + nir_cars_rank_session_pre: the session attention's keys and the query chain's input projection computed ahead of
+    the tail -- on another stream, as wrappers.Multitask._rank does under capture -- give bit-for-bit the scores, decoder states and inner pools of the
+    call that computes them itself (cars.py:346-378), with every combination of the session encoders."""
+    from context_attentive_ir_amd import synth
+    m = build_model("CARS", vocab=600, tgt_vocab_size=300, device=DEV, **CFG[tag])
+    ex = {k: v.to(DEV) for k, v in synth.session_batch(5, 4, 6, 4, 12, 600, seed=21).items()}
+    pooled, _, _ = m.encode(ex["source_words"], ex["source_lens"])
+    ref = m.rank_document(pooled, ex["document_words"], ex["document_lens"], ex["document_labels"])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        qs = m.session_query_side(pooled)
+    assert qs is not None and (qs[1] is None) == (tag == "qoff")
+    got = m.rank_document(pooled, ex["document_words"], ex["document_lens"], ex["document_labels"],
+                          after_documents=lambda: torch.cuda.current_stream().wait_stream(side), query_side=qs)
+    assert torch.equal(got[0], ref[0])
+    assert torch.equal(got[1][0], ref[1][0]) and torch.equal(got[1][1], ref[1][1])
+    for a, b in zip(got[2], ref[2]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    m.check_ids()
+
+
 def test_ranker_off_returns_states_only():
     from context_attentive_ir_amd import synth
     V = 500
