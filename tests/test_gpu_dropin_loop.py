@@ -72,6 +72,27 @@ def test_multitask_predict_graph_with_decode_equals_eager(kind):
     w.check_ids()
 
 
+@pytest.mark.parametrize("kw", [dict(query_session_off=True), dict(doc_session_off=True), dict(turn_ranker_off=True),
+                                dict(query_session_off=True, doc_session_off=True, turn_recommender_off=True)])
+def test_cars_switches_on_the_graph_path_equal_eager(kw):
+    """The captured predict() of CARS creates the document encoder in front of the query branch and hands the tail its query-only GEMMs from that
+    branch (round 6): with a session encoder or the ranker switched off (cars.py:60-130 -- the branch then has nothing, or less, to hand over) the
+    graph path still equals the eager one bit for bit."""
+    w, eager = _multitask("CARS", **kw), _multitask("CARS", **kw)
+    eager.args.predict_graphs = False
+    batches = [synth.session_batch(3, 4, 5, 4, 12, V, seed=10 + s, full_length=(s % 2 == 1)) for s in range(4)]
+    for suggest in (False, True):
+        want = [eager.predict(ex, suggest=suggest) for ex in batches]
+        got = [w.predict(_pin(ex), suggest=suggest) for ex in batches]
+        for a, b in zip(want, got):
+            if torch.is_tensor(a["click_scores"]):
+                assert torch.equal(a["click_scores"].cpu(), b["click_scores"].cpu())
+            if suggest and a["predictions"] is not None:
+                assert torch.equal(a["predictions"].cpu(), b["predictions"].cpu())
+    assert w._graphs.captures >= 1
+    w.check_ids()
+
+
 def test_graph_cache_follows_weights_shapes_and_switches():
     w, eager = _multitask("CARS"), _multitask("CARS")
     eager.args.predict_graphs = False
